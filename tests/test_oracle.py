@@ -1,0 +1,297 @@
+"""CPU tests of the oracle itself: the reference's known-answer test, tableau order conditions,
+structural assertions of test/runtests.jl, and finite-difference checks of every hand-derived VJP."""
+import numpy as np
+import pytest
+
+from oracle import ngpde_oracle as O
+
+RNG = np.random.default_rng(0)
+
+
+def fixture_graph(**kw):
+    # test/runtests.jl:11-13
+    return O.Graph([1, 1, 2, 3], [2, 3, 1, 1], **kw)
+
+
+def rand_mlp(sizes, acts, rng=RNG):
+    return [dict(weight=rng.normal(size=(o, i)) * 0.5, bias=rng.normal(size=(o, 1)) * 0.1, act=a)
+            for i, o, a in zip(sizes[:-1], sizes[1:], acts)]
+
+
+# ---- pins ------------------------------------------------------------------------------------
+
+def test_spectralconv_known_answer_float32():
+    # /root/reference/test/runtests.jl:153-162
+    n = 100
+    g = O.spectral_graph(n, np.float32)
+    x = np.linspace(0, 2 * np.pi, n + 1, dtype=np.float32)[1:]
+    e1 = O.spectral_conv(np.sin(x), g, n) - np.cos(x)
+    e2 = O.spectral_conv(np.cos(x), g, n) + np.sin(x)
+    assert e1.dtype == np.float32
+    assert float((e1 ** 2).sum()) < 1e-3
+    assert float((e2 ** 2).sum()) < 1e-3
+
+
+def test_spectralconv_docstring_residuals_float64():
+    # src/layers.jl:590-630: residuals ~1e-15 .. 4e-13
+    n = 100
+    g = O.spectral_graph(n)
+    x = np.linspace(0, 2 * np.pi, n + 1)[1:]
+    assert np.abs(O.spectral_conv(np.sin(x), g, n) - np.cos(x)).max() < 2e-12
+    assert np.abs(O.spectral_conv(np.cos(x), g, n) + np.sin(x)).max() < 2e-12
+
+
+def test_direction_convention_is_pinned():
+    # flipping source/target must break the known-answer test
+    n = 100
+    g = O.spectral_graph(n)
+    flipped = O.Graph(g.t, g.s, num_nodes=n, edata=g.edata["e"], index_base=0)
+    x = np.linspace(0, 2 * np.pi, n + 1)[1:]
+    assert ((O.spectral_conv(np.sin(x), flipped, n) - np.cos(x)) ** 2).sum() > 1.0
+
+
+def test_tsit5_tableau_order_conditions():
+    tb = O.TSIT5
+    for ci, row in zip(tb["c"], tb["a"]):
+        assert abs(sum(row) - ci) < 1e-14
+    assert abs(sum(tb["b"]) - 1.0) < 1e-14
+    rhs = lambda u: (u, None)
+    errs = []
+    for dt in (0.05, 0.1, 0.2):
+        u, _ = O.rk_solve(rhs, np.ones(1), tb, dt, 1)
+        errs.append(abs(u[0] - np.exp(dt)))
+    # 5th order: local error = C6 dt^6 + C7 dt^7 with small C6 (Tsitouras minimised it):
+    # measured 5.2e-13 / 2.3e-11 / 1.7e-10 ~ |4.3e-5 dt^6 - dt^7/5040|
+    for dt, e in zip((0.05, 0.1, 0.2), errs):
+        model = abs(4.3e-5 * dt ** 6 - dt ** 7 / 5040)
+        assert e < 1e-4 * dt ** 6
+        assert 0.5 * model < e < 2.0 * model
+
+
+# ---- structural assertions of test/runtests.jl ------------------------------------------------
+
+def test_shapes_like_reference_tests():
+    g = fixture_graph()
+    x = RNG.normal(size=(3, 3)).astype(np.float32)
+    y, _ = O.gcn_conv(x, RNG.normal(size=(5, 3)).astype(np.float32), np.zeros((5, 1), np.float32), g)
+    assert y.shape == (5, 3) and y.dtype == np.float32                       # :23
+    gh = fixture_graph(ndata={"x": RNG.random((3, 3))})
+    u = RNG.normal(size=(4, 3))
+    y, _ = O.explicit_edge_conv(u, rand_mlp([11, 5], ["identity"]), gh)      # :36
+    assert y.shape == (5, 3)
+    y, _ = O.vmh_conv(u, rand_mlp([11, 5], ["identity"]), rand_mlp([9, 7], ["identity"]), gh)  # :53
+    assert y.shape == (7, 3)
+    gm = fixture_graph(ndata={"u": RNG.random((2, 3)), "x": RNG.random((3, 3))}, gdata={"θ": RNG.random(4)})
+    h = RNG.normal(size=(5, 3))
+    y, _ = O.mppde_conv(h, rand_mlp([19, 5], ["identity"]), rand_mlp([14, 7], ["identity"]), gm)  # :72
+    assert y.shape == (7, 3)
+    ge = fixture_graph(edata={"u": RNG.random((2, 4)), "x": RNG.random((3, 4))}, gdata={"θ": RNG.random(4)})
+    y, _ = O.mppde_conv(h, rand_mlp([19, 5], ["identity"]), rand_mlp([14, 7], ["identity"]), ge)  # :86
+    assert y.shape == (7, 3)
+    gb = O.batch([gm, gm.copy()])                                            # :92
+    y, _ = O.mppde_conv(RNG.normal(size=(5, 6)), rand_mlp([19, 5], ["identity"]),
+                        rand_mlp([14, 7], ["identity"]), gb)
+    assert y.shape == (7, 6)
+    gn = fixture_graph(ndata={"u": RNG.random((2, 3)), "x": RNG.random((3, 3))})
+    y, _ = O.mppde_conv(h, rand_mlp([15, 5], ["identity"]), rand_mlp([10, 7], ["identity"]), gn)  # :119
+    assert y.shape == (7, 3)
+
+
+def test_batched_graph_equals_per_graph():
+    gm = fixture_graph(ndata={"u": RNG.random((2, 3)), "x": RNG.random((3, 3))}, gdata={"θ": RNG.random(4)})
+    g2 = fixture_graph(ndata={"u": RNG.random((2, 3)), "x": RNG.random((3, 3))}, gdata={"θ": RNG.random(4)})
+    phi, psi = rand_mlp([19, 8, 5], ["swish", "swish"]), rand_mlp([14, 7], ["identity"])
+    h1, h2 = RNG.normal(size=(5, 3)), RNG.normal(size=(5, 3))
+    yb, _ = O.mppde_conv(np.concatenate([h1, h2], 1), phi, psi, O.batch([gm, g2]))
+    y1, _ = O.mppde_conv(h1, phi, psi, gm)
+    y2, _ = O.mppde_conv(h2, phi, psi, g2)
+    np.testing.assert_allclose(yb, np.concatenate([y1, y2], 1), rtol=1e-13, atol=1e-13)
+
+
+def test_mean_of_empty_neighbourhood_is_zero():
+    g = O.Graph([1, 2], [2, 1], num_nodes=4)   # nodes 3,4 isolated
+    m = O.scatter("mean", np.ones((2, 2)), g.t, 4)
+    assert np.all(m[:, 2:] == 0) and np.all(np.isfinite(m))
+
+
+def test_gcn_matches_dense_formula():
+    # Y = act(W X C (A+I) C + b),  C = diag(1/sqrt(indeg+1))   
+    N, D = 7, 4
+    s = RNG.integers(1, N + 1, 15)
+    t = RNG.integers(1, N + 1, 15)
+    g = O.Graph(s, t, num_nodes=N)
+    A = np.zeros((N, N))
+    np.add.at(A, (s - 1, t - 1), 1.0)      # A[s, t]
+    A += np.eye(N)
+    c = 1 / np.sqrt(A.sum(0))
+    X = RNG.normal(size=(D, N))
+    W, b = RNG.normal(size=(5, D)), RNG.normal(size=(5, 1))
+    y, _ = O.gcn_conv(X, W, b, g, "tanh")
+    np.testing.assert_allclose(y, np.tanh(W @ (X * c) @ A * c + b), rtol=1e-12, atol=1e-12)
+    W2 = RNG.normal(size=(2, D))           # Dout < Din branch (:220)
+    y2, _ = O.gcn_conv(X, W2, None, g, "relu")
+    np.testing.assert_allclose(y2, np.maximum(W2 @ (X * c) @ A * c, 0), rtol=1e-12, atol=1e-12)
+
+
+# ---- finite-difference checks of the VJPs -----------------------------------------------------
+
+def fd_check(f, x, analytic, eps=1e-6, ntries=6, tol=2e-6):
+    """f: array -> scalar loss."""
+    rng = np.random.default_rng(1)
+    for _ in range(ntries):
+        idx = tuple(rng.integers(0, s) for s in x.shape)
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps
+        xm[idx] -= eps
+        num = (f(xp) - f(xm)) / (2 * eps)
+        assert abs(num - analytic[idx]) <= tol * max(1.0, abs(num)), (idx, num, analytic[idx])
+
+
+def rand_graph(N, E, rng=RNG, **kw):
+    return O.Graph(rng.integers(1, N + 1, E), rng.integers(1, N + 1, E), num_nodes=N, **kw)
+
+
+@pytest.mark.parametrize("dims", [(4, 6), (6, 3)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn_backward_fd(dims, weighted):
+    Din, Dout = dims
+    N, E = 9, 20
+    g = rand_graph(N, E)
+    ew = RNG.random(E) + 0.5 if weighted else None
+    X, W, b = RNG.normal(size=(Din, N)), RNG.normal(size=(Dout, Din)), RNG.normal(size=(Dout, 1))
+    R = RNG.normal(size=(Dout, N))
+    y, c = O.gcn_conv(X, W, b, g, "swish", edge_weight=ew)
+    gr = O.gcn_conv_backward(c, R)
+    fd_check(lambda x: (O.gcn_conv(x, W, b, g, "swish", edge_weight=ew)[0] * R).sum(), X, gr["x"])
+    fd_check(lambda w: (O.gcn_conv(X, w, b, g, "swish", edge_weight=ew)[0] * R).sum(), W, gr["weight"])
+    fd_check(lambda bb: (O.gcn_conv(X, W, bb, g, "swish", edge_weight=ew)[0] * R).sum(), b, gr["bias"])
+
+
+@pytest.mark.parametrize("aggr", ["mean", "+", "max"])
+def test_mppde_backward_fd(aggr):
+    N, E, G = 8, 24, 2
+    base = rand_graph(4, 12, ndata={"u": RNG.random((2, 4)), "x": RNG.random((1, 4))},
+                      edata={"w": RNG.random((1, 12))}, gdata={"θ": RNG.random(3)})
+    g = O.batch([base, base.copy(gdata={"θ": RNG.random(3)})])
+    h = 5
+    phi = rand_mlp([2 * h + 3 + 1 + 3, 7, 6], ["swish", "tanh"])
+    psi = rand_mlp([h + 6 + 3, 4], ["identity"])
+    X = RNG.normal(size=(h, N))
+    R = RNG.normal(size=(4, N))
+    y, c = O.mppde_conv(X, phi, psi, g, aggr)
+    gr = O.mppde_conv_backward(c, R)
+    fd_check(lambda x: (O.mppde_conv(x, phi, psi, g, aggr)[0] * R).sum(), X, gr["x"])
+
+    def with_w(w, which, k):
+        p2 = [dict(L) for L in (phi if which == "phi" else psi)]
+        p2[k]["weight"] = w
+        return (O.mppde_conv(X, p2 if which == "phi" else phi, psi if which == "phi" else p2, g, aggr)[0] * R).sum()
+    fd_check(lambda w: with_w(w, "phi", 0), phi[0]["weight"], gr["phi"][0]["weight"])
+    fd_check(lambda w: with_w(w, "phi", 1), phi[1]["weight"], gr["phi"][1]["weight"])
+    fd_check(lambda w: with_w(w, "psi", 0), psi[0]["weight"], gr["psi"][0]["weight"])
+
+
+def test_vmh_and_edgeconv_backward_fd():
+    N, E = 7, 18
+    g = rand_graph(N, E, ndata={"x": RNG.random((2, N))})
+    h = 3
+    phi = rand_mlp([2 * h + 2, 6, 5], ["tanh", "tanh"])
+    gamma = rand_mlp([h + 5, 4], ["tanh"])
+    X = RNG.normal(size=(h, N))
+    R = RNG.normal(size=(4, N))
+    y, c = O.vmh_conv(X, phi, gamma, g)
+    gr = O.vmh_conv_backward(c, R)
+    fd_check(lambda x: (O.vmh_conv(x, phi, gamma, g)[0] * R).sum(), X, gr["x"])
+    R2 = RNG.normal(size=(5, N))
+    y, c = O.explicit_edge_conv(X, phi, g)
+    gr = O.explicit_edge_conv_backward(c, R2)
+    fd_check(lambda x: (O.explicit_edge_conv(x, phi, g)[0] * R2).sum(), X, gr["x"])
+
+    def with_w(w):
+        p2 = [dict(L) for L in phi]
+        p2[0]["weight"] = w
+        return (O.explicit_edge_conv(X, p2, g)[0] * R2).sum()
+    fd_check(with_w, phi[0]["weight"], gr["phi"][0]["weight"])
+
+
+def test_gno_backward_fd_and_reshape_convention():
+    N, E, cin, cout = 6, 14, 3, 4
+    g = rand_graph(N, E, ndata={"a": RNG.random((1, N)), "x": RNG.random((2, N))})
+    phi = rand_mlp([6, 5, cin * cout], ["relu", "identity"])
+    W, b = RNG.normal(size=(cout, cin)), RNG.normal(size=(cout, 1))
+    X = RNG.normal(size=(cin, N))
+    R = RNG.normal(size=(cout, N))
+    y, c = O.gno_conv(X, phi, W, b, g, cin, cout, "tanh")
+    # literal check of K_e[o,i] = phi_out[o + out*i]  (src/layers.jl:527, column-major reshape)
+    kin = np.concatenate([c["g"].ndata["a"][:, g.t], c["g"].ndata["x"][:, g.t],
+                          c["g"].ndata["a"][:, g.s], c["g"].ndata["x"][:, g.s]], 0)
+    Wk, _ = O.mlp_forward(phi, kin)
+    m = np.zeros((cout, E))
+    for e in range(E):
+        K = Wk[:, e].reshape(cout, cin, order="F")
+        m[:, e] = K @ X[:, g.s[e]]
+    np.testing.assert_allclose(m, c["m"], rtol=1e-12, atol=1e-12)
+    gr = O.gno_conv_backward(c, R)
+    fd_check(lambda x: (O.gno_conv(x, phi, W, b, g, cin, cout, "tanh")[0] * R).sum(), X, gr["x"])
+
+    def with_w(w):
+        p2 = [dict(L) for L in phi]
+        p2[1]["weight"] = w
+        return (O.gno_conv(X, p2, W, b, g, cin, cout, "tanh")[0] * R).sum()
+    fd_check(with_w, phi[1]["weight"], gr["phi"][1]["weight"])
+    fd_check(lambda w: (O.gno_conv(X, phi, w, b, g, cin, cout, "tanh")[0] * R).sum(), W, gr["weight"])
+
+
+def test_gat_backward_fd():
+    N, E, H, C, Din = 7, 16, 2, 3, 5
+    g = rand_graph(N, E)
+    W = RNG.normal(size=(H * C, Din))
+    a = RNG.normal(size=(2 * C, H))
+    b = RNG.normal(size=(H * C,))
+    X = RNG.normal(size=(Din, N))
+    R = RNG.normal(size=(H * C, N))
+    y, c = O.gat_conv(X, W, a, b, g, H, C, "tanh")
+    assert y.shape == (H * C, N)
+    # softmax rows sum to one per (head, target)
+    np.testing.assert_allclose(O.scatter("+", c["alpha"], c["g"].t, N), 1.0, rtol=1e-12)
+    gr = O.gat_conv_backward(c, R)
+    f = lambda x=X, w=W, aa=a: (O.gat_conv(x, w, aa, b, g, H, C, "tanh")[0] * R).sum()
+    fd_check(lambda x: f(x=x), X, gr["x"])
+    fd_check(lambda w: f(w=w), W, gr["weight"])
+    fd_check(lambda aa: f(aa=aa), a, gr["a"])
+
+
+@pytest.mark.parametrize("tab", ["euler", "tsit5"])
+def test_node_adjoint_fd(tab):
+    N, E, D = 10, 30, 4
+    g = rand_graph(N, E)
+    params = [dict(weight=RNG.normal(size=(D, D)) * 0.5, bias=RNG.normal(size=(D, 1)) * 0.1) for _ in range(2)]
+    u0 = RNG.normal(size=(D, N))
+    tb = O.TABLEAUS[tab]
+    uT, du0, acc = O.gcn2_node_loss_and_grads(params, g, u0, tb, 0.1, 3, "tanh")
+    loss = lambda u: O.gcn2_node_loss_and_grads(params, g, u, tb, 0.1, 3, "tanh")[0].sum()
+    fd_check(loss, u0, du0)
+
+    def loss_w(w, layer):
+        p2 = [dict(p) for p in params]
+        p2[layer]["weight"] = w
+        return O.gcn2_node_loss_and_grads(p2, g, u0, tb, 0.1, 3, "tanh")[0].sum()
+    fd_check(lambda w: loss_w(w, 0), params[0]["weight"], acc[0]["weight"])
+    fd_check(lambda w: loss_w(w, 1), params[1]["weight"], acc[1]["weight"])
+
+
+def test_generators_are_deterministic():
+    a = O.splitmix64(7, 4)
+    assert a.dtype == np.uint64 and len(set(a.tolist())) == 4
+    # splitmix64 reference value for seed 0, first output
+    assert int(O.splitmix64(0, 1)[0]) == 0xE220A8397B1DCDAF
+    pts, s, t = O.closest_pairs_graph(512, 2048, 3)
+    assert s.size == 4096 and set(zip(s.tolist(), t.tolist())) == set(zip(t.tolist(), s.tolist()))
+    assert np.all(s != t)
+    pts2, s2, t2 = O.closest_pairs_graph(512, 2048, 3)
+    assert np.array_equal(s, s2) and np.array_equal(t, t2)
+    # brute-force check: these are the 2048 closest pairs
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    iu = np.triu_indices(512, 1)
+    thr = np.sort(d2[iu])[2047]
+    assert np.all(((pts[s] - pts[t]) ** 2).sum(-1) <= thr + 1e-15)
