@@ -1,0 +1,146 @@
+/*
+ * ngpde.h -- C ABI of libngpde_hip.so: the MI355X (gfx950) implementation of the message-passing
+ * hot path of NeuralGraphPDE.jl (edge gather -> per-edge function -> node scatter-reduce, plus the
+ * dense node-feature x weight contraction), i.e. what a Julia `ccall` shim replacing the bodies of
+ * /root/reference/src/layers.jl would bind.  See INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *   - Every function returns an int32 status (0 = NGPDE_OK, < 0 = error); the message of the last
+ *     error on the calling thread is returned by ngpde_last_error().  No C++ exception or abort()
+ *     crosses this boundary.  The reference raises AssertionError / DimensionMismatch at the same
+ *     places (src/layers.jl:204,207,216 and GNNGraph's check_num_nodes/edges).
+ *   - All tensor arguments are raw DEVICE pointers to float32 unless a parameter is documented as
+ *     "host".  A Julia (D x N) column-major matrix is passed as-is: it is the row-major [N][D]
+ *     array the kernels use (node n = D contiguous floats).  A weight (out x in) column-major is
+ *     the row-major [in][out] array.
+ *   - `stream` is a hipStream_t (NULL = the default stream).  Forward/backward calls only enqueue
+ *     work; they never allocate, free or synchronise (graph-capture safe).  Handle creation is
+ *     synchronous.
+ *   - The library keeps no hidden parameter state: parameters and inputs are passed on every call,
+ *     as in Lux's `y, st = layer(x, ps, st)` (src/layers.jl:200, :94, :312, :390, :509).  The only
+ *     cached object is the derived-graph handle, whose life is tied to the GNNGraph in `st.graph`.
+ */
+#ifndef NGPDE_H
+#define NGPDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGPDE_VERSION_STRING "0.1.0"
+
+typedef struct ngpde_graph ngpde_graph_t;     /* derived graph: CSR by target + CSR by source  */
+typedef struct ngpde_node ngpde_node_t;       /* fixed-step neural-ODE plan over 2 x GCNConv   */
+typedef void *ngpde_stream_t;                 /* hipStream_t                                   */
+
+typedef enum {
+  NGPDE_OK = 0,
+  NGPDE_ERR_INVALID_ARGUMENT = -1,   /* Julia: ArgumentError / AssertionError */
+  NGPDE_ERR_DIMENSION_MISMATCH = -2, /* Julia: DimensionMismatch              */
+  NGPDE_ERR_HIP = -3,                /* a HIP runtime call failed             */
+  NGPDE_ERR_UNSUPPORTED = -4,        /* shape/option outside what is built    */
+  NGPDE_ERR_WORKSPACE = -5,          /* caller workspace too small            */
+  NGPDE_ERR_STATE = -6               /* call order violated (e.g. norm not set, backward before forward) */
+} ngpde_status_t;
+
+/* NNlib activation names used by the reference's layers (src/layers.jl:180, Lux Dense). */
+typedef enum {
+  NGPDE_ACT_IDENTITY = 0, NGPDE_ACT_RELU = 1, NGPDE_ACT_TANH = 2, NGPDE_ACT_SIGMOID = 3,
+  NGPDE_ACT_SWISH = 4, NGPDE_ACT_GELU = 5, NGPDE_ACT_LEAKYRELU = 6, NGPDE_ACT_ELU = 7,
+  NGPDE_ACT_SOFTPLUS = 8
+} ngpde_act_t;
+
+/* `aggr` of propagate(...) (src/layers.jl:90,303,384,496; default mean). */
+typedef enum { NGPDE_AGGR_SUM = 0, NGPDE_AGGR_MEAN = 1, NGPDE_AGGR_MAX = 2, NGPDE_AGGR_MIN = 3 } ngpde_aggr_t;
+
+typedef enum { NGPDE_TABLEAU_EULER = 0, NGPDE_TABLEAU_TSIT5 = 1 } ngpde_tableau_t;
+
+const char *ngpde_version(void);
+const char *ngpde_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Derived-graph handle.  Replaces what the reference recomputes on EVERY layer call:
+ * add_self_loops (src/layers.jl:211), degree (:224) and, inside propagate [GraphNeuralNetworks.jl],
+ * the COO -> sparse-matrix build / gather+scatter index walk (:228-232, :111, :326, :416, :534).
+ *   s, t        host, int64, length n_edges, the COO vectors of the GNNGraph (edge e: s[e] -> t[e])
+ *   index_base  1 for the vectors a Julia GNNGraph holds, 0 for 0-based callers
+ *   n_graphs    number of graphs of a batched (block-diagonal) GNNGraph (test/runtests.jl:89-102)
+ * The handle is immutable after ngpde_graph_set_gcn_norm and may be shared across streams.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, const int64_t *t,
+                           int32_t index_base, int32_t n_graphs, ngpde_graph_t **out);
+int32_t ngpde_graph_destroy(ngpde_graph_t *g);
+int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_graphs);
+/* Device arrays of the derived graph (for callers that batch / inspect): CSR by target.
+ * rowptr: int32[n_nodes+1]; col: int32[n_edges] source node of each entry; eid: int32[n_edges]
+ * position of the entry in the caller's COO list. */
+int32_t ngpde_graph_csr_by_target(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
+                                  const int32_t **eid);
+int32_t ngpde_graph_csr_by_source(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
+                                  const int32_t **eid);
+
+/* GCN normalisation of src/layers.jl:210-226: c = 1/sqrt(in-degree (+1 with self loops)).
+ *   edge_weight       host float[n_edges] or NULL: the per-edge factor of e_mul_xj / w_mul_xj (:228,:230)
+ *   weighted_degree   non-zero: degree = sum of incoming weights (explicit `edge_weight` argument,
+ *                     :224 with edge_weight != nothing); zero: unweighted count (the
+ *                     `use_edge_weight=true` path of the reference normalises with unweighted degrees)
+ */
+int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
+                                 int32_t weighted_degree);
+
+/* ------------------------------------------------------------------------------------------------
+ * GCNConv  -- replaces (l::GCNConv)(x, ps, st[, edge_weight]), src/layers.jl:200-239.
+ *   y = act.( W * (x C (A+I) C) .+ b )     (W applied before the aggregation iff dout < din, :220)
+ *   x [N][din], weight (dout x din) column-major, bias [dout] or NULL (bias=false), y [N][dout]
+ *   save_agg  [N][din] or NULL: the aggregated input X C (A+I) C kept for backward (only written when dout >= din)
+ *   save_z    [N][dout] or NULL: pre-activation, kept for backward
+ * ---------------------------------------------------------------------------------------------- */
+size_t ngpde_gcn_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t backward);
+int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act,
+                          const float *x, const float *weight, const float *bias, float *y,
+                          float *save_agg, float *save_z, void *workspace, size_t workspace_bytes,
+                          ngpde_stream_t stream);
+/* Pullback of the above (what a ChainRulesCore.rrule for the shim returns; the reference gets it
+ * from Zygote through gather / scatter / mul).  z: pre-activation saved by forward (for relu/identity the
+ * output y may be passed instead).  saved_agg: as written by forward (ignored when dout < din).
+ * dx [N][din] or NULL; dweight (dout x din) column-major; dbias [dout] or NULL.  Results overwrite. */
+int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act,
+                           const float *x, const float *weight, const float *z, const float *saved_agg,
+                           const float *dy, float *dx, float *dweight, float *dbias, void *workspace,
+                           size_t workspace_bytes, ngpde_stream_t stream);
+
+/* Generic aggregation  out[:, i] = sum_{e: t_e = i} w_e * x[:, s_e]  (propagate(copy_xj / w_mul_xj, g, +),
+ * src/layers.jl:228-232) and its transpose (by_source != 0), any feature width d.
+ * edge_weight: device float[n_edges] in COO order or NULL. aggr: NGPDE_AGGR_SUM or NGPDE_AGGR_MEAN. */
+int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr, int32_t by_source,
+                                const float *x, const float *edge_weight, float *out, ngpde_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fixed-step neural graph ODE over  Chain(GCNConv(d => d, act), GCNConv(d => d, act))  -- the caller
+ * of the hot path in the reference's tutorial (docs/src/tutorials/graph_node.md:44-66, :78): the
+ * right-hand side dudt(u, p, t) is evaluated once per Runge-Kutta stage.  BASELINE configs fix the
+ * step count (Euler x 10, Tsit5 x 50), so the integrator is fixed-step and the backward pass is the
+ * discrete adjoint (backprop through the steps), with the whole solve replayed from one HIP graph.
+ * d in {16, 32, 64, 128}.  The plan owns its tape (saved activations) and scratch buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, int32_t tableau,
+                               int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out);
+int32_t ngpde_node_destroy(ngpde_node_t *plan);
+size_t ngpde_node_tape_bytes(const ngpde_node_t *plan);
+/* u0 [N][d]; w1,w2 (d x d) column-major; b1,b2 [d]; uT [N][d].  Enqueues the whole solve. */
+int32_t ngpde_node_gcn2_forward(ngpde_node_t *plan, const float *u0, const float *w1, const float *b1,
+                                const float *w2, const float *b2, float *uT, ngpde_stream_t stream);
+/* duT: adjoint of u(T).  Outputs: du0 [N][d], dw1,dw2 (d x d) column-major, db1,db2 [d]. */
+int32_t ngpde_node_gcn2_backward(ngpde_node_t *plan, const float *duT, float *du0, float *dw1,
+                                 float *db1, float *dw2, float *db2, ngpde_stream_t stream);
+/* Names and average device time of the plan's kernels are visible to rocprofv3 --kernel-trace;
+ * this returns the number of kernel launches one forward (+ backward) solve enqueues. */
+int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGPDE_H */

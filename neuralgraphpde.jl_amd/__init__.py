@@ -1,0 +1,19 @@
+"""neuralgraphpde.jl_amd -- MI355X-native message-passing hot path of NeuralGraphPDE.jl behind the
+reference's Lux explicit-layer API.  Import it as `ngpde_amd` (the directory name contains a dot,
+so the repo-root shim ngpde_amd.py loads it under that name).
+
+Everything that computes goes through libngpde_hip.so (include/ngpde.h); there is no CPU fallback.
+"""
+from . import _lib
+from ._lib import ArgumentError, DimensionMismatch, NgpdeError
+from .graphs import EMPTYGRAPH, GNNGraph, batch, rand_graph
+from .utils import drop, updategraph, wrapgraph
+from .layers import (AbstractExplicitLayer, AbstractGNNContainerLayer, AbstractGNNLayer, Chain, Dense,
+                     GCNConv, apply, glorot_normal, glorot_uniform, setup, to_device, zeros32)
+from .node import NeuralODE
+
+__all__ = [
+    "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",
+    "setup", "apply", "to_device", "updategraph", "wrapgraph", "drop", "GNNGraph", "EMPTYGRAPH", "rand_graph",
+    "batch", "glorot_uniform", "glorot_normal", "zeros32", "NgpdeError", "DimensionMismatch", "ArgumentError",
+]

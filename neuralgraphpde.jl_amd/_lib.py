@@ -1,0 +1,111 @@
+"""ctypes binding of libngpde_hip.so (the C ABI declared in include/ngpde.h).
+
+The product path has NO fallback: if the shared library is missing or does not export a symbol the
+import fails loudly.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libngpde_hip.so")
+
+
+class NgpdeError(RuntimeError):
+    """A non-zero status from the C ABI (message from ngpde_last_error())."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[ngpde status {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class DimensionMismatch(NgpdeError, ValueError):
+    """Mirrors Julia's DimensionMismatch (status NGPDE_ERR_DIMENSION_MISMATCH)."""
+
+
+class ArgumentError(NgpdeError, ValueError):
+    """Mirrors Julia's ArgumentError / AssertionError (status NGPDE_ERR_INVALID_ARGUMENT)."""
+
+
+OK, ERR_INVALID_ARGUMENT, ERR_DIMENSION_MISMATCH, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+
+ACT = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4, "gelu": 5, "leakyrelu": 6,
+       "elu": 7, "softplus": 8}
+AGGR = {"+": 0, "sum": 0, "add": 0, "mean": 1, "max": 2, "min": 3}
+TABLEAU = {"euler": 0, "tsit5": 1}
+
+_vp, _i32, _i64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes).  Every symbol include/ngpde.h declares must be listed here:
+# tests/test_abi.py checks the header against this table and against the built library.
+SIGNATURES = {
+    "ngpde_version": (C.c_char_p, []),
+    "ngpde_last_error": (C.c_char_p, []),
+    "ngpde_graph_create": (_i32, [_i64, _i64, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "ngpde_graph_destroy": (_i32, [_vp]),
+    "ngpde_graph_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "ngpde_graph_csr_by_target": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "ngpde_graph_csr_by_source": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "ngpde_graph_set_gcn_norm": (_i32, [_vp, _i32, _vp, _i32]),
+    "ngpde_gcn_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "ngpde_gcn_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_gcn_backward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_propagate_copy_xj": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ngpde_node_gcn2_create": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, C.POINTER(_vp)]),
+    "ngpde_node_destroy": (_i32, [_vp]),
+    "ngpde_node_tape_bytes": (_sz, [_vp]),
+    "ngpde_node_gcn2_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_node_gcn2_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_node_launch_count": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C neuralgraphpde.jl_amd/csrc`.  There is no CPU fallback for the hot path.")
+    import torch  # noqa: F401  -- makes torch's libamdhip64.so the process's HIP runtime before ours resolves it
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == OK:
+        return
+    msg = load().ngpde_last_error().decode("utf-8", "replace")
+    if status == ERR_DIMENSION_MISMATCH:
+        raise DimensionMismatch(status, msg)
+    if status == ERR_INVALID_ARGUMENT:
+        raise ArgumentError(status, msg)
+    raise NgpdeError(status, msg)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,137 @@
+// api_gcn.hip -- C-ABI entry points of the GCNConv path (declared in include/ngpde.h).
+// Replaces (l::GCNConv)(x, ps, st[, edge_weight]) of /root/reference/src/layers.jl:200-239 and the
+// pullback Zygote derives for it.
+#include <algorithm>
+
+#include "common.h"
+
+using namespace ngpde;
+
+namespace {
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int32_t check_common(const char *fn, const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "%s: graph is NULL", fn);
+  NGPDE_REQUIRE(din > 0 && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH, "%s: DimensionMismatch: din=%d dout=%d", fn, din, dout);
+  NGPDE_REQUIRE(act >= NGPDE_ACT_IDENTITY && act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT,
+                "%s: unknown activation code %d", fn, act);
+  NGPDE_REQUIRE(g->has_norm, NGPDE_ERR_STATE, "%s: GCN normalisation not set (call ngpde_graph_set_gcn_norm)", fn);
+  return NGPDE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ngpde_gcn_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t backward) {
+  if (!g) return 0;
+  const size_t n = (size_t)g->n_nodes;
+  if (fused_supported(din, dout)) {
+    if (!backward) return 256;
+    const size_t nb = (size_t)fused_num_blocks(g->n_nodes);
+    return align256(nb * (size_t)din * dout * 4) + align256(nb * (size_t)dout * 4) + align256(n * din * 4) + 256;
+  }
+  const size_t dmax = (size_t)std::max(din, dout);
+  if (!backward) return align256(n * dmax * 4) + 256;
+  return 2 * align256(n * dmax * 4) + 256;
+}
+
+int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
+                          const float *weight, const float *bias, float *y, float *save_agg, float *save_z,
+                          void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  int32_t st = check_common("ngpde_gcn_forward", g, din, dout, act);
+  if (st) return st;
+  if (g->n_nodes == 0) return NGPDE_OK;  // EMPTYGRAPH (src/layers.jl:14): zero columns in, zero columns out
+  NGPDE_REQUIRE(x && weight && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_forward: x/weight/y is NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n = g->n_nodes;
+  if (fused_supported(din, dout)) {
+    FusedFwdArgs a;
+    a.g = g; a.d = din; a.act = act; a.x = x; a.wt = weight; a.bias = bias; a.y = y;
+    a.save_agg = save_agg; a.save_z = save_z;
+    return launch_fused_fwd(a, stream);
+  }
+  const size_t need = ngpde_gcn_workspace_bytes(g, din, dout, 0);
+  NGPDE_REQUIRE(workspace && workspace_bytes >= need, NGPDE_ERR_WORKSPACE,
+                "ngpde_gcn_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  float *tmp = (float *)workspace;
+  if (dout >= din) {  // aggregate, then multiply (src/layers.jl:235-237)
+    float *agg = save_agg ? save_agg : tmp;
+    if ((st = launch_spmm_generic(g, false, true, din, NGPDE_AGGR_SUM, x, nullptr, agg, stream))) return st;
+    return launch_dense_fwd(n, din, dout, act, agg, weight, bias, y, save_z, stream);
+  }
+  // multiply first (src/layers.jl:220-223), then aggregate, then bias + activation
+  if ((st = launch_dense_fwd(n, din, dout, NGPDE_ACT_IDENTITY, x, weight, nullptr, tmp, nullptr, stream))) return st;
+  if ((st = launch_spmm_generic(g, false, true, dout, NGPDE_AGGR_SUM, tmp, nullptr, y, stream))) return st;
+  return launch_bias_act(n, dout, act, y, bias, y, save_z, stream);
+}
+
+int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
+                           const float *weight, const float *z, const float *saved_agg, const float *dy, float *dx,
+                           float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
+                           ngpde_stream_t stream_) {
+  int32_t st = check_common("ngpde_gcn_backward", g, din, dout, act);
+  if (st) return st;
+  NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: dweight is NULL");
+  if (g->n_nodes == 0) {  // empty graph: zero gradients
+    NGPDE_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)din * dout * 4, (hipStream_t)stream_));
+    if (dbias) NGPDE_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)dout * 4, (hipStream_t)stream_));
+    return NGPDE_OK;
+  }
+  NGPDE_REQUIRE(weight && z && dy, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: weight/z/dy is NULL");
+  NGPDE_REQUIRE(dout < din || saved_agg, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: saved_agg is NULL");
+  NGPDE_REQUIRE(dout >= din || x, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: x is NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n = g->n_nodes;
+  const size_t need = ngpde_gcn_workspace_bytes(g, din, dout, 1);
+  NGPDE_REQUIRE(workspace && workspace_bytes >= need, NGPDE_ERR_WORKSPACE,
+                "ngpde_gcn_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  char *ws = (char *)workspace;
+  if (fused_supported(din, dout)) {
+    const size_t nb = (size_t)fused_num_blocks(n);
+    float *slab_dw = (float *)ws;
+    float *slab_db = (float *)(ws + align256(nb * (size_t)din * dout * 4));
+    float *gbuf = (float *)((char *)slab_db + align256(nb * (size_t)dout * 4));
+    NGPDE_HIP_CHECK(hipMemsetAsync(slab_dw, 0, (size_t)((char *)gbuf - ws), stream));
+    FusedBwdArgs a;
+    a.g = g; a.d = din; a.act = act; a.aggregate = false; a.g_in = dy;
+    a.do_dense = true; a.z = z; a.saved_agg = saved_agg; a.wt = weight; a.g_out = gbuf;
+    a.slab_dw = slab_dw; a.slab_db = slab_db;
+    if ((st = launch_fused_bwd(a, stream))) return st;
+    if (dx) {
+      FusedBwdArgs b;
+      b.g = g; b.d = din; b.act = act; b.aggregate = true; b.g_in = gbuf; b.do_dense = false; b.store_t = dx;
+      if ((st = launch_fused_bwd(b, stream))) return st;
+    }
+    if ((st = launch_reduce_slabs(slab_dw, (int)nb, din * dout, dweight, stream))) return st;
+    if (dbias && (st = launch_reduce_slabs(slab_db, (int)nb, dout, dbias, stream))) return st;
+    return NGPDE_OK;
+  }
+  const size_t dmax = (size_t)std::max(din, dout);
+  float *dz = (float *)ws;
+  float *tmp = (float *)(ws + align256((size_t)n * dmax * 4));
+  if ((st = launch_act_bwd(n * dout, act, dy, z, dz, stream))) return st;
+  if (dbias && (st = launch_colsum(n, dout, dz, dbias, stream))) return st;
+  if (dout >= din) {
+    if ((st = launch_dense_bwd_weight(n, din, dout, saved_agg, dz, dweight, stream))) return st;
+    if (dx) {
+      if ((st = launch_dense_bwd_input(n, din, dout, dz, weight, tmp, stream))) return st;
+      if ((st = launch_spmm_generic(g, true, true, din, NGPDE_AGGR_SUM, tmp, nullptr, dx, stream))) return st;
+    }
+    return NGPDE_OK;
+  }
+  if ((st = launch_spmm_generic(g, true, true, dout, NGPDE_AGGR_SUM, dz, nullptr, tmp, stream))) return st;
+  if ((st = launch_dense_bwd_weight(n, din, dout, x, tmp, dweight, stream))) return st;
+  if (dx) return launch_dense_bwd_input(n, din, dout, tmp, weight, dx, stream);
+  return NGPDE_OK;
+}
+
+int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr, int32_t by_source, const float *x,
+                                const float *edge_weight, float *out, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_propagate_copy_xj: graph is NULL");
+  NGPDE_REQUIRE(d > 0 && x && out, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_propagate_copy_xj: bad arguments");
+  return launch_spmm_generic(g, by_source != 0, false, d, aggr, x, edge_weight, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

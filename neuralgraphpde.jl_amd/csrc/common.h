@@ -1,0 +1,132 @@
+// common.h -- internals shared by the translation units of libngpde_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/ngpde.h"
+
+namespace ngpde {
+
+// thread-local message behind ngpde_last_error()
+std::string &last_error();
+int32_t fail(int32_t code, const char *fmt, ...);
+
+#define NGPDE_HIP_CHECK(expr)                                                                     \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return ::ngpde::fail(NGPDE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                           __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define NGPDE_REQUIRE(cond, code, ...)                                                            \
+  do {                                                                                            \
+    if (!(cond)) return ::ngpde::fail(code, __VA_ARGS__);                                         \
+  } while (0)
+
+// One direction of the derived graph.  Row r lists the edges whose target (by_target) or source
+// (by_source) is r, in the caller's COO order (stable counting sort), so segmented sums visit
+// contributions in the same order as NNlib's serial scatter over the COO list.
+struct Csr {
+  int32_t *rowptr = nullptr;  // [n_nodes + 1]
+  int32_t *col = nullptr;     // [n_edges] the node at the other end of each entry
+  int32_t *eid = nullptr;     // [n_edges] position of the entry in the COO list
+  int2 *ent = nullptr;        // [n_edges] {col, bits of GCN coefficient w_e * c[col]}; set by set_gcn_norm
+  std::vector<int32_t> h_rowptr, h_col, h_eid;
+};
+
+}  // namespace ngpde
+
+struct ngpde_graph {
+  int64_t n_nodes = 0, n_edges = 0;
+  int32_t n_graphs = 1;
+  ngpde::Csr by_t, by_s;
+  // GCN normalisation (src/layers.jl:210-226)
+  bool has_norm = false;
+  int32_t self_loops = 0;
+  float *c = nullptr;  // [n_nodes] 1/sqrt(degree)
+  int32_t max_in_degree = 0, max_out_degree = 0;
+};
+
+namespace ngpde {
+
+// ---- launchers implemented in gcn_kernels.hip ---------------------------------------------------
+
+// Weighted combination of node-local rows that a fused kernel evaluates in its epilogue/prologue:
+//   v[row] = coef_self * (value held in registers) + sum_k coef[k] * ptr[k][row]
+struct Comb {
+  int n = 0;
+  const float *ptr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float coef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float coef_self = 0.f;
+};
+
+struct FusedFwdArgs {
+  const ngpde_graph *g = nullptr;
+  int d = 0, act = 0;
+  const float *x = nullptr;      // [N][d] gathered operand
+  const float *wt = nullptr;     // [d][d] row-major [in][out]  (= Julia (out x in) column-major)
+  const float *bias = nullptr;   // [d] or null
+  float *y = nullptr;            // [N][d] act(z)
+  float *save_agg = nullptr;     // [N][d] or null
+  float *save_z = nullptr;       // [N][d] or null
+  // optional Runge-Kutta stage combination evaluated on the freshly computed rows of y
+  bool has_comb = false;
+  Comb comb;
+  float *comb_out = nullptr;
+};
+bool fused_supported(int din, int dout);
+int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream);
+
+struct FusedBwdArgs {
+  const ngpde_graph *g = nullptr;
+  int d = 0, act = 0;
+  bool aggregate = false;        // true: T = A^T-aggregate(g_in) rows; false: T = rows of g_in
+  const float *g_in = nullptr;   // [N][d]
+  // combination stage (adjoint of the RK stage sums)
+  bool has_comb = false;
+  Comb comb;                     // V = comb.coef_self * T + sum_k ...
+  float *store_t = nullptr;      // [N][d] or null: T rows (the stage adjoint U-bar_i)
+  float *store_v = nullptr;      // [N][d] or null: V rows (lambda update)
+  float v_scale = 1.f;           // K-bar = v_scale * V
+  // dense part (skipped when do_dense == false)
+  bool do_dense = true;
+  const float *z = nullptr;      // [N][d] saved pre-activation (or y for relu/identity)
+  const float *saved_agg = nullptr;  // [N][d]
+  const float *wt = nullptr;     // [d][d]
+  float *g_out = nullptr;        // [N][d]  dZ * W
+  float *slab_dw = nullptr;      // [n_blocks][d*d] accumulated (+=)
+  float *slab_db = nullptr;      // [n_blocks][d]   accumulated (+=)
+};
+int fused_tile_rows();
+int fused_num_blocks(int64_t n_nodes);
+int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
+int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, float *out, hipStream_t stream);
+
+// generic (any feature width) building blocks
+int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr,
+                            const float *x, const float *edge_weight, float *out, hipStream_t stream);
+// y[n][o] = act(sum_i x[n][i] * wt[i][o] + bias[o]); optionally also stores z
+int32_t launch_dense_fwd(int64_t n, int din, int dout, int act, const float *x, const float *wt,
+                         const float *bias, float *y, float *save_z, hipStream_t stream);
+// dz = dy * act'(z)
+int32_t launch_act_bwd(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
+// dx[n][i] = sum_o dz[n][o] * wt[i][o]
+int32_t launch_dense_bwd_input(int64_t n, int din, int dout, const float *dz, const float *wt, float *dx,
+                               hipStream_t stream);
+// dwt[i][o] = sum_n x[n][i] * dz[n][o]
+int32_t launch_dense_bwd_weight(int64_t n, int din, int dout, const float *x, const float *dz, float *dwt,
+                                hipStream_t stream);
+// out[o] = sum_n a[n][o]
+int32_t launch_colsum(int64_t n, int d, const float *a, float *out, hipStream_t stream);
+// y = act(a + bias)
+int32_t launch_bias_act(int64_t n, int d, int act, const float *a, const float *bias, float *y, float *save_z,
+                        hipStream_t stream);
+
+}  // namespace ngpde

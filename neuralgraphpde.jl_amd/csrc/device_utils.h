@@ -1,0 +1,143 @@
+// device_utils.h -- gfx950 device helpers: activations, CSR row aggregation, fp32 MFMA tiles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace ngpde {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- activations (codes: ngpde_act_t) -------------------------------------------------------------
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float act_apply(int act, float z) {
+  switch (act) {
+    case NGPDE_ACT_RELU: return fmaxf(z, 0.0f);
+    case NGPDE_ACT_TANH: return tanhf(z);
+    case NGPDE_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    case NGPDE_ACT_SWISH: return z / (1.0f + expf(-z));
+    case NGPDE_ACT_GELU: {
+      float u = 0.7978845608028654f * (z + 0.044715f * z * z * z);
+      return 0.5f * z * (1.0f + tanhf(u));
+    }
+    case NGPDE_ACT_LEAKYRELU: return z > 0.f ? z : 0.01f * z;
+    case NGPDE_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case NGPDE_ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+    default: return z;
+  }
+}
+
+// derivative w.r.t. the pre-activation z (for relu / identity / leakyrelu the output y may be passed)
+__device__ __forceinline__ float act_deriv(int act, float z) {
+  switch (act) {
+    case NGPDE_ACT_RELU: return z > 0.f ? 1.0f : 0.0f;
+    case NGPDE_ACT_TANH: { float t = tanhf(z); return 1.0f - t * t; }
+    case NGPDE_ACT_SIGMOID: { float s = 1.0f / (1.0f + expf(-z)); return s * (1.0f - s); }
+    case NGPDE_ACT_SWISH: { float s = 1.0f / (1.0f + expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+    case NGPDE_ACT_GELU: {
+      float u = 0.7978845608028654f * (z + 0.044715f * z * z * z);
+      float t = tanhf(u);
+      return 0.5f * (1.0f + t) + 0.5f * z * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * z * z);
+    }
+    case NGPDE_ACT_LEAKYRELU: return z > 0.f ? 1.0f : 0.01f;
+    case NGPDE_ACT_ELU: return z > 0.f ? 1.0f : expf(z);
+    case NGPDE_ACT_SOFTPLUS: return 1.0f / (1.0f + expf(-z));
+    default: return 1.0f;
+  }
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_fma(float a, float4 v, float4 c) {
+  return make_float4(fmaf(a, v.x, c.x), fmaf(a, v.y, c.y), fmaf(a, v.z, c.z), fmaf(a, v.w, c.w));
+}
+__device__ __forceinline__ float4 f4_scale(float a, float4 v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4_act(int act, float4 z) {
+  return make_float4(act_apply(act, z.x), act_apply(act, z.y), act_apply(act, z.z), act_apply(act, z.w));
+}
+__device__ __forceinline__ float4 f4_dact(int act, float4 z) {
+  return make_float4(act_deriv(act, z.x), act_deriv(act, z.y), act_deriv(act, z.z), act_deriv(act, z.w));
+}
+
+// ---- CSR segmented aggregation of whole feature rows --------------------------------------------
+// A "group" of LPR = D/4 adjacent lanes owns R rows; lane q of the group holds features 4q..4q+3 of
+// each row as one float4 (a D=64 row = 256 B = 16 lanes x dwordx4: fully coalesced row gathers).
+// The group's lanes first load up to LPR {col, coef} entries of a row with ONE coalesced 8-byte load
+// each, then broadcast them with in-register lane shuffles while issuing R*U independent 16-byte row
+// loads, so a wave keeps 4*R*U neighbour rows in flight.  No atomics: each destination row is summed
+// by one group in CSR (= COO) order, so results are bitwise reproducible run to run.
+//   acc[r] = c[row] * ( sum_e coef_e * X[col_e] + (self ? c[row] * X[row] : 0) )
+template <int LPR, int R, int U>
+__device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, const int *__restrict__ rowptr,
+                                               const int2 *__restrict__ ent, const float *__restrict__ cnorm,
+                                               int self_loops, int n_nodes, const int (&rows)[R], int q,
+                                               float4 (&acc)[R]) {
+  static_assert(LPR % U == 0, "unroll must divide the lanes per row");
+  int rs[R], deg[R];
+  int maxdeg = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool ok = rows[r] < n_nodes;
+    rs[r] = ok ? rowptr[rows[r]] : 0;
+    deg[r] = ok ? rowptr[rows[r] + 1] - rs[r] : 0;
+    maxdeg = max(maxdeg, deg[r]);
+    acc[r] = f4_zero();
+  }
+  for (int base = 0; base < maxdeg; base += LPR) {
+    int ecol[R], ecf[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = base + q < deg[r];
+      int2 v = make_int2(0, 0);
+      if (ok) v = ent[rs[r] + base + q];
+      ecol[r] = v.x;
+      ecf[r] = v.y;
+    }
+    const int nin = min(LPR, maxdeg - base);
+    for (int e = 0; e < nin; e += U) {
+      float4 v[R][U];
+      float cf[R][U];
+      bool vld[R][U];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int src = e + u;
+          int col = __shfl(ecol[r], src, LPR);
+          cf[r][u] = __int_as_float(__shfl(ecf[r], src, LPR));
+          vld[r][u] = (base + src) < deg[r];
+          col = vld[r][u] ? col : 0;
+          v[r][u] = X4[(size_t)col * LPR + q];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (vld[r][u]) acc[r] = f4_fma(cf[r][u], v[r][u], acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (rows[r] < n_nodes) {
+      const float ci = cnorm[rows[r]];
+      if (self_loops) acc[r] = f4_fma(ci, X4[(size_t)rows[r] * LPR + q], acc[r]);
+      acc[r] = f4_scale(ci, acc[r]);
+    }
+  }
+}
+
+// ---- fp32 MFMA -------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[l&15][l>>4], B[l>>4][l&15];
+// result register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (bitwise an fmaf chain), 256 FLOP/clk/CU.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace ngpde

@@ -1,0 +1,203 @@
+// graph.hip -- derived-graph handle: COO (as held by a Julia GNNGraph) -> CSR by target + CSR by
+// source, built once per graph instead of on every layer call (the reference re-runs add_self_loops,
+// degree and the COO walk per call: /root/reference/src/layers.jl:211,224,228-232).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+namespace ngpde {
+
+std::string &last_error() {
+  thread_local std::string msg;
+  return msg;
+}
+
+int32_t fail(int32_t code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+namespace {
+
+// stable counting sort of the edge list by `key`; `other` becomes the column of each entry
+void build_csr(int64_t n, int64_t m, const std::vector<int32_t> &key, const std::vector<int32_t> &other,
+               Csr &out) {
+  out.h_rowptr.assign(n + 1, 0);
+  for (int64_t e = 0; e < m; ++e) out.h_rowptr[key[e] + 1]++;
+  for (int64_t i = 0; i < n; ++i) out.h_rowptr[i + 1] += out.h_rowptr[i];
+  out.h_col.resize(m);
+  out.h_eid.resize(m);
+  std::vector<int32_t> cursor(out.h_rowptr.begin(), out.h_rowptr.end() - 1);
+  for (int64_t e = 0; e < m; ++e) {
+    int32_t p = cursor[key[e]]++;
+    out.h_col[p] = other[e];
+    out.h_eid[p] = (int32_t)e;
+  }
+}
+
+template <class T>
+int32_t upload(T **dst, const T *src, size_t count) {
+  *dst = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  NGPDE_HIP_CHECK(hipMalloc((void **)dst, bytes));
+  if (count) NGPDE_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return NGPDE_OK;
+}
+
+int32_t upload_csr(Csr &c, int64_t n, int64_t m) {
+  int32_t st;
+  if ((st = upload(&c.rowptr, c.h_rowptr.data(), (size_t)n + 1))) return st;
+  if ((st = upload(&c.col, c.h_col.data(), (size_t)m))) return st;
+  if ((st = upload(&c.eid, c.h_eid.data(), (size_t)m))) return st;
+  return NGPDE_OK;
+}
+
+void free_csr(Csr &c) {
+  if (c.rowptr) (void)hipFree(c.rowptr);
+  if (c.col) (void)hipFree(c.col);
+  if (c.eid) (void)hipFree(c.eid);
+  if (c.ent) (void)hipFree(c.ent);
+  c = Csr();
+}
+
+}  // namespace
+}  // namespace ngpde
+
+using namespace ngpde;
+
+extern "C" {
+
+const char *ngpde_version(void) { return NGPDE_VERSION_STRING; }
+const char *ngpde_last_error(void) { return last_error().c_str(); }
+
+int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, const int64_t *t,
+                           int32_t index_base, int32_t n_graphs, ngpde_graph_t **out) {
+  NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create: out is NULL");
+  *out = nullptr;
+  NGPDE_REQUIRE(n_nodes >= 0 && n_edges >= 0, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_create: negative size (n_nodes=%lld, n_edges=%lld)", (long long)n_nodes,
+                (long long)n_edges);
+  NGPDE_REQUIRE(n_nodes < (1ll << 31) - 1 && n_edges + n_nodes < (1ll << 31) - 1, NGPDE_ERR_UNSUPPORTED,
+                "ngpde_graph_create: graph too large for int32 device indices");
+  NGPDE_REQUIRE(n_edges == 0 || (s && t), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create: s/t is NULL");
+  NGPDE_REQUIRE(index_base == 0 || index_base == 1, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_create: index_base must be 0 or 1");
+  NGPDE_REQUIRE(n_graphs >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create: n_graphs < 0");
+  std::vector<int32_t> s32((size_t)n_edges), t32((size_t)n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    int64_t a = s[e] - index_base, b = t[e] - index_base;
+    if (a < 0 || a >= n_nodes || b < 0 || b >= n_nodes)
+      return fail(NGPDE_ERR_DIMENSION_MISMATCH,
+                  "DimensionMismatch: edge %lld (%lld -> %lld) references a node outside 1:%lld",
+                  (long long)e + index_base, (long long)s[e], (long long)t[e], (long long)n_nodes);
+    s32[e] = (int32_t)a;
+    t32[e] = (int32_t)b;
+  }
+  ngpde_graph *g = new (std::nothrow) ngpde_graph();
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "out of host memory");
+  g->n_nodes = n_nodes;
+  g->n_edges = n_edges;
+  g->n_graphs = n_graphs;
+  build_csr(n_nodes, n_edges, t32, s32, g->by_t);
+  build_csr(n_nodes, n_edges, s32, t32, g->by_s);
+  for (int64_t i = 0; i < n_nodes; ++i) {
+    g->max_in_degree = std::max(g->max_in_degree, g->by_t.h_rowptr[i + 1] - g->by_t.h_rowptr[i]);
+    g->max_out_degree = std::max(g->max_out_degree, g->by_s.h_rowptr[i + 1] - g->by_s.h_rowptr[i]);
+  }
+  int32_t st;
+  if ((st = upload_csr(g->by_t, n_nodes, n_edges)) || (st = upload_csr(g->by_s, n_nodes, n_edges))) {
+    ngpde_graph_destroy(g);
+    return st;
+  }
+  *out = g;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
+  if (!g) return NGPDE_OK;
+  free_csr(g->by_t);
+  free_csr(g->by_s);
+  if (g->c) (void)hipFree(g->c);
+  delete g;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_graphs) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_info: graph is NULL");
+  if (n_nodes) *n_nodes = g->n_nodes;
+  if (n_edges) *n_edges = g->n_edges;
+  if (n_graphs) *n_graphs = g->n_graphs;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_csr_by_target(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
+                                  const int32_t **eid) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_csr_by_target: graph is NULL");
+  if (rowptr) *rowptr = g->by_t.rowptr;
+  if (col) *col = g->by_t.col;
+  if (eid) *eid = g->by_t.eid;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_csr_by_source(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
+                                  const int32_t **eid) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_csr_by_source: graph is NULL");
+  if (rowptr) *rowptr = g->by_s.rowptr;
+  if (col) *col = g->by_s.col;
+  if (eid) *eid = g->by_s.eid;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
+                                 int32_t weighted_degree) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_set_gcn_norm: graph is NULL");
+  NGPDE_REQUIRE(!(weighted_degree && !edge_weight), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_set_gcn_norm: weighted_degree requires edge_weight");
+  const int64_t n = g->n_nodes, m = g->n_edges;
+  // d = degree(g; dir=:in[, edge_weight]) after add_self_loops (weights padded with ones), :210-224
+  std::vector<float> deg((size_t)n, add_self_loops ? 1.0f : 0.0f);
+  for (int64_t i = 0; i < n; ++i) {
+    // accumulate in COO order within the row, in float, as scatter(+) does
+    float acc = 0.f;
+    for (int32_t p = g->by_t.h_rowptr[i]; p < g->by_t.h_rowptr[i + 1]; ++p)
+      acc += weighted_degree ? edge_weight[g->by_t.h_eid[p]] : 1.0f;
+    deg[i] = acc + (add_self_loops ? 1.0f : 0.0f);
+  }
+  std::vector<float> c((size_t)n);
+  for (int64_t i = 0; i < n; ++i) c[i] = 1.0f / std::sqrt(deg[i]);  // :225 (Inf for isolated nodes, as the reference)
+  auto fill = [&](Csr &csr, std::vector<int2> &ent) {
+    ent.resize((size_t)m);
+    for (int64_t p = 0; p < m; ++p) {
+      float w = edge_weight ? edge_weight[csr.h_eid[p]] : 1.0f;
+      float coef = w * c[csr.h_col[p]];
+      int2 v;
+      v.x = csr.h_col[p];
+      std::memcpy(&v.y, &coef, 4);
+      ent[p] = v;
+    }
+  };
+  std::vector<int2> et, es;
+  fill(g->by_t, et);
+  fill(g->by_s, es);
+  if (g->by_t.ent) { (void)hipFree(g->by_t.ent); g->by_t.ent = nullptr; }
+  if (g->by_s.ent) { (void)hipFree(g->by_s.ent); g->by_s.ent = nullptr; }
+  if (g->c) { (void)hipFree(g->c); g->c = nullptr; }
+  g->has_norm = false;
+  int32_t st;
+  if ((st = upload(&g->by_t.ent, et.data(), (size_t)m))) return st;
+  if ((st = upload(&g->by_s.ent, es.data(), (size_t)m))) return st;
+  if ((st = upload(&g->c, c.data(), (size_t)n))) return st;
+  g->self_loops = add_self_loops ? 1 : 0;
+  g->has_norm = true;
+  return NGPDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// node.hip -- device-resident fixed-step neural graph ODE over Chain(GCNConv(d=>d), GCNConv(d=>d)),
+// forward solve + discrete adjoint, each replayed from one HIP graph.
+//
+// Caller of the hot path in the reference: the tutorial's NeuralODE wrapper evaluates
+//   dudt(u, p, t) = Chain(GCNConv(nhidden => nhidden, relu), GCNConv(nhidden => nhidden, relu))(u, p, st)
+// once per Runge-Kutta stage (/root/reference/docs/src/tutorials/graph_node.md:59-66, :78) and its
+// pullback once per stage of the reverse pass (:54, :127).  Here every stage is two fused launches:
+//   forward  : [aggregate + MFMA + act] for layer 1, [aggregate + MFMA + act + next-stage input
+//              u_n + dt*sum_j a_ij k_j (or the step update with b_j)] for layer 2;
+//   backward : [A^T-aggregate + mask + MFMA(dZ W, X^T dZ)] for layer 1, and one launch that finishes
+//              stage i (A^T-aggregate -> U-bar_i), forms the next stage's K-bar = dt*b*lambda +
+//              dt*sum_j a_ji U-bar_j (or the lambda update at the step boundary) and runs layer 2's
+//              dense backward for that next stage.
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+using namespace ngpde;
+
+namespace {
+
+struct Tableau {
+  int S;
+  std::vector<std::vector<double>> a;  // a[i][j], j < i
+  std::vector<double> b;
+};
+
+Tableau make_tableau(int which) {
+  Tableau t;
+  if (which == NGPDE_TABLEAU_EULER) {
+    t.S = 1;
+    t.a = {{}};
+    t.b = {1.0};
+    return t;
+  }
+  // Tsitouras 5(4) as used by OrdinaryDiffEq.Tsit5 (graph_node.md:48); fixed step: only the 5th-order
+  // weights are needed, and they equal the 7th stage row (FSAL), so this is a 6-stage explicit scheme.
+  t.S = 6;
+  t.a = {{},
+         {0.161},
+         {-0.008480655492356989, 0.335480655492357},
+         {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+         {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+         {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383}};
+  t.b = {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774};
+  return t;
+}
+
+bool act_needs_z(int act) {
+  return !(act == NGPDE_ACT_IDENTITY || act == NGPDE_ACT_RELU || act == NGPDE_ACT_LEAKYRELU);
+}
+
+}  // namespace
+
+struct ngpde_node {
+  const ngpde_graph *g = nullptr;
+  int d = 0, act = 0, n_steps = 0;
+  float dt = 0.f;
+  bool with_bwd = false, needs_z = false, eager = false;
+  Tableau tb;
+  int64_t n = 0;
+  size_t row_elems = 0;  // n * d
+  int nb = 0;            // workgroups of the fused kernels (= slabs)
+  int slots = 0;         // tape slots per stage evaluation
+
+  float *u = nullptr, *ustage = nullptr;
+  float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+  float *tape = nullptr;
+  size_t tape_bytes = 0;
+  float *lam = nullptr, *g1 = nullptr, *g2 = nullptr;
+  std::vector<float *> ubar;
+  float *slabs = nullptr;
+  size_t slab_bytes = 0;
+  float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
+  float *dw1 = nullptr, *db1 = nullptr, *dw2 = nullptr, *db2 = nullptr;
+
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t fwd_graph = nullptr, bwd_graph = nullptr;
+  hipGraphExec_t fwd_exec = nullptr, bwd_exec = nullptr;
+  bool forward_done = false;
+  int fwd_launches = 0, bwd_launches = 0;
+
+  // tape slot k of (step, stage): 0 = A1 (aggregated input of layer 1), 1 = Y1, 2 = A2, 3 = Y2 = k_i,
+  // 4 = Z1, 5 = Z2 (only for activations whose derivative needs the pre-activation)
+  float *slot(int step, int stage, int k) const {
+    const int s = with_bwd ? step : 0;
+    return tape + ((size_t)(s * tb.S + stage) * slots + k) * row_elems;
+  }
+};
+
+namespace {
+
+int32_t dev_alloc(float **p, size_t elems) {
+  *p = nullptr;
+  NGPDE_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(elems, 1) * sizeof(float)));
+  return NGPDE_OK;
+}
+
+int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches) {
+  const Tableau &tb = p->tb;
+  int32_t st;
+  int count = 0;
+  for (int n = 0; n < p->n_steps; ++n) {
+    for (int i = 0; i < tb.S; ++i) {
+      FusedFwdArgs f1;
+      f1.g = p->g; f1.d = p->d; f1.act = p->act;
+      f1.x = (i == 0) ? p->u : p->ustage;
+      f1.wt = p->w1; f1.bias = p->b1;
+      f1.y = p->slot(n, i, 1);
+      f1.save_agg = p->with_bwd ? p->slot(n, i, 0) : nullptr;
+      f1.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 4) : nullptr;
+      if ((st = launch_fused_fwd(f1, stream))) return st;
+      FusedFwdArgs f2;
+      f2.g = p->g; f2.d = p->d; f2.act = p->act;
+      f2.x = p->slot(n, i, 1);
+      f2.wt = p->w2; f2.bias = p->b2;
+      f2.y = p->slot(n, i, 3);
+      f2.save_agg = p->with_bwd ? p->slot(n, i, 2) : nullptr;
+      f2.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 5) : nullptr;
+      // epilogue: next stage input, or the step update after the last stage
+      const bool last = (i == tb.S - 1);
+      const std::vector<double> &row = last ? tb.b : tb.a[i + 1];
+      f2.has_comb = true;
+      f2.comb_out = last ? p->u : p->ustage;
+      f2.comb.n = 0;
+      f2.comb.ptr[f2.comb.n] = p->u;
+      f2.comb.coef[f2.comb.n++] = 1.0f;
+      for (int j = 0; j < i; ++j) {
+        if (row[j] == 0.0) continue;
+        f2.comb.ptr[f2.comb.n] = p->slot(n, j, 3);
+        f2.comb.coef[f2.comb.n++] = (float)(p->dt * row[j]);
+      }
+      f2.comb.coef_self = (float)(p->dt * row[i]);
+      if ((st = launch_fused_fwd(f2, stream))) return st;
+      count += 2;
+    }
+  }
+  if (launches) *launches = count;
+  return NGPDE_OK;
+}
+
+void fill_dense(const ngpde_node *p, FusedBwdArgs &a, int layer, int step, int stage) {
+  a.do_dense = true;
+  if (layer == 2) {
+    a.z = p->needs_z ? p->slot(step, stage, 5) : p->slot(step, stage, 3);
+    a.saved_agg = p->slot(step, stage, 2);
+    a.wt = p->w2; a.g_out = p->g2; a.slab_dw = p->slab_dw2; a.slab_db = p->slab_db2;
+  } else {
+    a.z = p->needs_z ? p->slot(step, stage, 4) : p->slot(step, stage, 1);
+    a.saved_agg = p->slot(step, stage, 0);
+    a.wt = p->w1; a.g_out = p->g1; a.slab_dw = p->slab_dw1; a.slab_db = p->slab_db1;
+  }
+}
+
+int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches) {
+  const Tableau &tb = p->tb;
+  const int S = tb.S;
+  int32_t st;
+  int count = 0;
+  NGPDE_HIP_CHECK(hipMemsetAsync(p->slabs, 0, p->slab_bytes, stream));
+  {  // K-bar of the last stage of the last step, then layer 2's dense backward
+    FusedBwdArgs a;
+    a.g = p->g; a.d = p->d; a.act = p->act;
+    a.aggregate = false; a.g_in = p->lam;
+    a.has_comb = true; a.comb.n = 0; a.comb.coef_self = (float)(p->dt * tb.b[S - 1]);
+    fill_dense(p, a, 2, p->n_steps - 1, S - 1);
+    if ((st = launch_fused_bwd(a, stream))) return st;
+    ++count;
+  }
+  for (int n = p->n_steps - 1; n >= 0; --n) {
+    for (int i = S - 1; i >= 0; --i) {
+      FusedBwdArgs m;  // layer 1 of stage i: dY1 = A^T g2
+      m.g = p->g; m.d = p->d; m.act = p->act;
+      m.aggregate = true; m.g_in = p->g2;
+      fill_dense(p, m, 1, n, i);
+      if ((st = launch_fused_bwd(m, stream))) return st;
+      FusedBwdArgs e;  // U-bar_i = A^T g1, then the next stage's K-bar and layer-2 dense backward
+      e.g = p->g; e.d = p->d; e.act = p->act;
+      e.aggregate = true; e.g_in = p->g1;
+      e.has_comb = true; e.comb.n = 0;
+      if (i >= 1) {
+        e.store_t = p->ubar[i];
+        e.comb.ptr[e.comb.n] = p->lam;
+        e.comb.coef[e.comb.n++] = (float)(p->dt * tb.b[i - 1]);
+        for (int j = i + 1; j < S; ++j) {
+          if (tb.a[j][i - 1] == 0.0) continue;
+          e.comb.ptr[e.comb.n] = p->ubar[j];
+          e.comb.coef[e.comb.n++] = (float)(p->dt * tb.a[j][i - 1]);
+        }
+        e.comb.coef_self = (float)(p->dt * tb.a[i][i - 1]);
+        fill_dense(p, e, 2, n, i - 1);
+      } else {
+        // lambda_n = lambda_{n+1} + sum_j U-bar_j
+        e.comb.ptr[e.comb.n] = p->lam;
+        e.comb.coef[e.comb.n++] = 1.0f;
+        for (int j = 1; j < S; ++j) {
+          e.comb.ptr[e.comb.n] = p->ubar[j];
+          e.comb.coef[e.comb.n++] = 1.0f;
+        }
+        e.comb.coef_self = 1.0f;
+        e.store_v = p->lam;
+        if (n > 0) {
+          e.v_scale = (float)(p->dt * tb.b[S - 1]);
+          fill_dense(p, e, 2, n - 1, S - 1);
+        } else {
+          e.do_dense = false;
+        }
+      }
+      if ((st = launch_fused_bwd(e, stream))) return st;
+      count += 2;
+    }
+  }
+  const int dd = p->d * p->d;
+  if ((st = launch_reduce_slabs(p->slab_dw1, p->nb, dd, p->dw1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db1, p->nb, p->d, p->db1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_dw2, p->nb, dd, p->dw2, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db2, p->nb, p->d, p->db2, stream))) return st;
+  count += 4;
+  if (launches) *launches = count;
+  return NGPDE_OK;
+}
+
+int32_t capture(ngpde_node *p, bool backward) {
+  hipGraph_t graph = nullptr;
+  NGPDE_HIP_CHECK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
+  int count = 0;
+  int32_t st = backward ? enqueue_backward(p, p->cap_stream, &count) : enqueue_forward(p, p->cap_stream, &count);
+  hipError_t e = hipStreamEndCapture(p->cap_stream, &graph);
+  if (st) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return st;
+  }
+  if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  NGPDE_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  if (backward) {
+    p->bwd_graph = graph; p->bwd_exec = exec; p->bwd_launches = count;
+  } else {
+    p->fwd_graph = graph; p->fwd_exec = exec; p->fwd_launches = count;
+  }
+  return NGPDE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ngpde_node_destroy(ngpde_node_t *p) {
+  if (!p) return NGPDE_OK;
+  if (p->fwd_exec) (void)hipGraphExecDestroy(p->fwd_exec);
+  if (p->bwd_exec) (void)hipGraphExecDestroy(p->bwd_exec);
+  if (p->fwd_graph) (void)hipGraphDestroy(p->fwd_graph);
+  if (p->bwd_graph) (void)hipGraphDestroy(p->bwd_graph);
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  float *bufs[] = {p->u, p->ustage, p->w1, p->b1, p->w2, p->b2, p->tape, p->lam, p->g1, p->g2, p->slabs,
+                   p->dw1, p->db1, p->dw2, p->db2};
+  for (float *b : bufs)
+    if (b) (void)hipFree(b);
+  for (float *b : p->ubar)
+    if (b) (void)hipFree(b);
+  delete p;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, int32_t tableau, int32_t n_steps,
+                               float dt, int32_t with_backward, ngpde_node_t **out) {
+  NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: out is NULL");
+  *out = nullptr;
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: graph is NULL");
+  NGPDE_REQUIRE(g->has_norm, NGPDE_ERR_STATE, "ngpde_node_gcn2_create: GCN normalisation not set");
+  NGPDE_REQUIRE(fused_supported(d, d), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_node_gcn2_create: d must be one of 16, 32, 64, 128 (got %d)", d);
+  NGPDE_REQUIRE(act >= NGPDE_ACT_IDENTITY && act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_node_gcn2_create: unknown activation code %d", act);
+  NGPDE_REQUIRE(tableau == NGPDE_TABLEAU_EULER || tableau == NGPDE_TABLEAU_TSIT5, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_node_gcn2_create: unknown tableau %d", tableau);
+  NGPDE_REQUIRE(n_steps >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: n_steps must be >= 1");
+  NGPDE_REQUIRE(g->n_nodes >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: empty graph");
+  ngpde_node *p = new (std::nothrow) ngpde_node();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "out of host memory");
+  p->g = g; p->d = d; p->act = act; p->n_steps = n_steps; p->dt = dt;
+  p->with_bwd = with_backward != 0;
+  p->needs_z = p->with_bwd && act_needs_z(act);
+  p->tb = make_tableau(tableau);
+  p->n = g->n_nodes;
+  p->row_elems = (size_t)p->n * d;
+  p->nb = fused_num_blocks(p->n);
+  p->slots = p->with_bwd ? (p->needs_z ? 6 : 4) : 4;
+  const char *eager = std::getenv("NGPDE_NODE_EAGER");
+  p->eager = eager && eager[0] == '1';
+  const int S = p->tb.S;
+  int32_t st = NGPDE_OK;
+  auto A = [&](float **ptr, size_t elems) {
+    if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
+  };
+  A(&p->u, p->row_elems);
+  A(&p->ustage, p->row_elems);
+  A(&p->w1, (size_t)d * d); A(&p->b1, d); A(&p->w2, (size_t)d * d); A(&p->b2, d);
+  const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->row_elems;
+  p->tape_bytes = tape_elems * sizeof(float);
+  A(&p->tape, tape_elems);
+  if (p->with_bwd) {
+    A(&p->lam, p->row_elems); A(&p->g1, p->row_elems); A(&p->g2, p->row_elems);
+    p->ubar.assign(S, nullptr);
+    for (int j = 1; j < S; ++j) A(&p->ubar[j], p->row_elems);
+    const size_t dd = (size_t)d * d;
+    const size_t per = (size_t)p->nb * (dd + d);
+    p->slab_bytes = 2 * per * sizeof(float);
+    A(&p->slabs, 2 * per);
+    if (st == NGPDE_OK) {
+      p->slab_dw1 = p->slabs;
+      p->slab_db1 = p->slab_dw1 + (size_t)p->nb * dd;
+      p->slab_dw2 = p->slab_db1 + (size_t)p->nb * d;
+      p->slab_db2 = p->slab_dw2 + (size_t)p->nb * dd;
+    }
+    A(&p->dw1, dd); A(&p->db1, d); A(&p->dw2, dd); A(&p->db2, d);
+  }
+  if (st == NGPDE_OK && !p->eager) {
+    hipError_t e = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    if (st == NGPDE_OK) st = capture(p, false);
+    if (st == NGPDE_OK && p->with_bwd) st = capture(p, true);
+  } else if (st == NGPDE_OK) {
+    p->fwd_launches = 2 * S * n_steps;
+    p->bwd_launches = p->with_bwd ? 1 + 2 * S * n_steps + 4 : 0;
+  }
+  if (st != NGPDE_OK) {
+    std::string keep = last_error();
+    ngpde_node_destroy(p);
+    last_error() = keep;
+    return st;
+  }
+  *out = p;
+  return NGPDE_OK;
+}
+
+size_t ngpde_node_tape_bytes(const ngpde_node_t *p) { return p ? p->tape_bytes : 0; }
+
+int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t *backward) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_launch_count: plan is NULL");
+  if (forward) *forward = p->fwd_launches;
+  if (backward) *backward = p->bwd_launches;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w1, const float *b1, const float *w2,
+                                const float *b2, float *uT, ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: plan is NULL");
+  NGPDE_REQUIRE(u0 && w1 && w2 && uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
+  if (b1) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b1, b1, db, hipMemcpyDeviceToDevice, stream));
+  else NGPDE_HIP_CHECK(hipMemsetAsync(p->b1, 0, db, stream));
+  if (b2) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b2, b2, db, hipMemcpyDeviceToDevice, stream));
+  else NGPDE_HIP_CHECK(hipMemsetAsync(p->b2, 0, db, stream));
+  if (p->eager) {
+    int32_t st = enqueue_forward(p, stream, nullptr);
+    if (st) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipGraphLaunch(p->fwd_exec, stream));
+  }
+  NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  p->forward_done = true;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, float *dw1, float *db1, float *dw2,
+                                 float *db2, ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_backward: plan is NULL");
+  NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: plan was created without backward");
+  NGPDE_REQUIRE(p->forward_done, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: forward has not been run");
+  NGPDE_REQUIRE(duT != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_backward: duT is NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (p->eager) {
+    int32_t st = enqueue_backward(p, stream, nullptr);
+    if (st) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipGraphLaunch(p->bwd_exec, stream));
+  }
+  if (du0) NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
+  if (db1) NGPDE_HIP_CHECK(hipMemcpyAsync(db1, p->db1, db, hipMemcpyDeviceToDevice, stream));
+  if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));
+  if (db2) NGPDE_HIP_CHECK(hipMemcpyAsync(db2, p->db2, db, hipMemcpyDeviceToDevice, stream));
+  return NGPDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+"""GNNGraph -- host-side mirror of the parts of GraphNeuralNetworks.jl's GNNGraph that
+NeuralGraphPDE.jl's layers touch (re-exported at /root/reference/src/NeuralGraphPDE.jl:4), plus
+the cache of native derived-graph handles (CSR by target / by source) the HIP kernels use.
+
+Indices follow the reference: `GNNGraph(s, t)` takes the 1-based COO vectors a Julia graph holds
+(`index_base=0` for 0-based callers).  Features are (D x N) arrays, node n = column n.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _last_dim(a):
+    return a.shape[-1] if hasattr(a, "shape") and len(a.shape) else 1
+
+
+def _normalize(data, default, n, what):
+    """GNN.jl normalize_graphdata: bare array -> {default: array}; last dim must equal n."""
+    if data is None:
+        return {}
+    if not isinstance(data, dict):
+        data = {default: data}
+    out = {}
+    for k, v in data.items():
+        shape = tuple(v.shape)
+        if len(shape) == 1 and default == "u" and n == 1:
+            pass  # a vector is one graph's feature column
+        elif len(shape) == 0 or shape[-1] != n:
+            raise _lib.DimensionMismatch(
+                _lib.ERR_DIMENSION_MISMATCH,
+                f"DimensionMismatch: {what} feature '{k}' has size {shape}, last dimension must be {n}")
+        out[k] = v
+    return out
+
+
+def _as_matrix_t(v, n, gdata=False):
+    """user feature (D x n) [or vector] -> contiguous float32 torch tensor [n][D] on v's device."""
+    t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+    if t.dim() == 1:
+        t = t.reshape(-1, 1) if (gdata and n == 1) else t.reshape(1, -1)
+    return t.to(torch.float32).T.contiguous()
+
+
+class _Handle:
+    """Owner of one ngpde_graph_t (destroyed with the last GNNGraph copy that shares it)."""
+
+    def __init__(self, g, norm):
+        lib = _lib.load()
+        out = C.c_void_p()
+        s = np.ascontiguousarray(g._s0, dtype=np.int64)
+        t = np.ascontiguousarray(g._t0, dtype=np.int64)
+        _lib.check(lib.ngpde_graph_create(g.num_nodes, g.num_edges, s.ctypes.data, t.ctypes.data, 0,
+                                          g.num_graphs, C.byref(out)))
+        self.ptr = out
+        self.lib = lib
+        if norm is not None:
+            add_self_loops, w, weighted = norm
+            wp = None
+            if w is not None:
+                w = np.ascontiguousarray(w, dtype=np.float32)
+                wp = w.ctypes.data
+            _lib.check(lib.ngpde_graph_set_gcn_norm(self.ptr, int(add_self_loops), wp, int(weighted)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.ngpde_graph_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class GNNGraph:
+    """COO graph with node / edge / graph features.
+
+    GNNGraph(s, t; num_nodes, ndata, edata, gdata)        -- as test/runtests.jl:11-13
+    GNNGraph(g; ndata=..., edata=..., gdata=...)          -- copy with data replaced (:28, :58, :145)
+    """
+
+    def __init__(self, s=None, t=None, *, num_nodes=None, ndata=None, edata=None, gdata=None,
+                 num_graphs=None, edge_weight=None, index_base=1):
+        if isinstance(s, GNNGraph):
+            g = s
+            self._s0, self._t0 = g._s0, g._t0
+            self.num_nodes, self.num_edges = g.num_nodes, g.num_edges
+            self.num_graphs = g.num_graphs if num_graphs is None else num_graphs
+            self.edge_weight = g.edge_weight if edge_weight is None else edge_weight
+            self._handles = g._handles          # same structure -> share the native handles
+            self.ndata = g.ndata if ndata is None else _normalize(ndata, "x", self.num_nodes, "node")
+            self.edata = g.edata if edata is None else _normalize(edata, "e", self.num_edges, "edge")
+            self.gdata = g.gdata if gdata is None else _normalize(gdata, "u", self.num_graphs, "graph")
+            self._packs = {}
+            return
+        s0 = np.asarray(s, dtype=np.int64).reshape(-1) - index_base
+        t0 = np.asarray(t, dtype=np.int64).reshape(-1) - index_base
+        if s0.shape != t0.shape:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "DimensionMismatch: s and t differ in length")
+        if num_nodes is None:
+            num_nodes = int(max(s0.max(initial=-1), t0.max(initial=-1)) + 1)
+        if s0.size and (min(s0.min(), t0.min()) < 0 or max(s0.max(), t0.max()) >= num_nodes):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: edge index outside 1:{num_nodes}")
+        self._s0, self._t0 = s0, t0
+        self.num_nodes, self.num_edges = int(num_nodes), int(s0.size)
+        self.num_graphs = 1 if num_graphs is None else int(num_graphs)
+        self.edge_weight = edge_weight
+        self.ndata = _normalize(ndata, "x", self.num_nodes, "node")
+        self.edata = _normalize(edata, "e", self.num_edges, "edge")
+        self.gdata = _normalize(gdata, "u", self.num_graphs, "graph")
+        self._handles = {}
+        self._packs = {}
+
+    # ---- reference-visible accessors ---------------------------------------------------------
+    def edge_index(self, index_base=1):
+        return self._s0 + index_base, self._t0 + index_base
+
+    def copy(self, **kw):  # src/utils.jl:8  Base.copy(g; kwargs...) = GNNGraph(g; kwargs...)
+        return GNNGraph(self, **kw)
+
+    def __repr__(self):
+        return f"GNNGraph({self.num_nodes}, {self.num_edges})"
+
+    def __eq__(self, other):
+        if not isinstance(other, GNNGraph):
+            return NotImplemented
+        if self is other:
+            return True
+        if (self.num_nodes, self.num_edges, self.num_graphs) != (other.num_nodes, other.num_edges, other.num_graphs):
+            return False
+        if not (np.array_equal(self._s0, other._s0) and np.array_equal(self._t0, other._t0)):
+            return False
+        for a, b in ((self.ndata, other.ndata), (self.edata, other.edata), (self.gdata, other.gdata)):
+            if list(a) != list(b):
+                return False
+            for k in a:
+                if a[k] is b[k]:
+                    continue
+                if not np.array_equal(_to_numpy(a[k]), _to_numpy(b[k])):
+                    return False
+        return True
+
+    __hash__ = object.__hash__
+
+    # ---- native side -------------------------------------------------------------------------
+    def handle(self, norm=None):
+        """ngpde_graph_t for this structure; `norm` = (add_self_loops, edge_weight or None,
+        weighted_degree) selects a handle carrying that GCN normalisation."""
+        key = None
+        if norm is not None:
+            w = norm[1]
+            key = (bool(norm[0]), None if w is None else id(w), bool(norm[2]))
+        h = self._handles.get(key)
+        if h is None:
+            h = _Handle(self, norm)
+            self._handles[key] = (h, norm)   # keep `norm` alive so id(w) stays unique
+            return h
+        return h[0]
+
+    def packed(self, which, device):
+        """Concatenation of all features of one kind in NamedTuple order as a contiguous float32
+        [n][sum D] tensor on `device` (vcat(values(g.ndata)...), src/layers.jl:403-407, :517-521).
+        Float64 graph features (test/runtests.jl:58) are converted: the HIP path is fp32."""
+        key = (which, str(device))
+        p = self._packs.get(key)
+        if p is None:
+            data = {"ndata": self.ndata, "edata": self.edata, "gdata": self.gdata}[which]
+            n = {"ndata": self.num_nodes, "edata": self.num_edges, "gdata": self.num_graphs}[which]
+            cols = [_as_matrix_t(v, n, gdata=(which == "gdata")).to(device) for v in data.values()]
+            p = torch.cat(cols, dim=1).contiguous() if cols else torch.zeros((n, 0), dtype=torch.float32, device=device)
+            self._packs[key] = p
+        return p
+
+    def feature_dims(self, which):
+        data = {"ndata": self.ndata, "edata": self.edata, "gdata": self.gdata}[which]
+        n = {"ndata": self.num_nodes, "edata": self.num_edges, "gdata": self.num_graphs}[which]
+        out = {}
+        for k, v in data.items():
+            shape = tuple(v.shape)
+            out[k] = 1 if len(shape) == 1 and not (which == "gdata" and n == 1) else int(shape[0])
+            if len(shape) == 1 and which == "gdata" and n == 1:
+                out[k] = int(shape[0])
+        return out
+
+
+def _to_numpy(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+EMPTYGRAPH = GNNGraph([], [], num_nodes=0)   # src/layers.jl:14  rand_graph(0, 0)
+
+
+def rand_graph(n, m, *, bidirected=True, seed=None):
+    """[UPSTREAM GNNGraphs.rand_graph] random graph with n nodes and m directed edges (m/2 symmetric
+    pairs when bidirected).  No self loops, no multi-edges."""
+    rng = np.random.default_rng(seed)
+    if bidirected:
+        assert m % 2 == 0, "bidirected rand_graph needs an even number of edges"
+    npairs = m // 2 if bidirected else m
+    max_pairs = n * (n - 1) // 2 if bidirected else n * (n - 1)
+    assert npairs <= max_pairs, "too many edges requested"
+    chosen = set()
+    while len(chosen) < npairs:
+        i, j = int(rng.integers(0, n)), int(rng.integers(0, n))
+        if i == j:
+            continue
+        if bidirected and i > j:
+            i, j = j, i
+        chosen.add((i, j))
+    pairs = np.array(sorted(chosen), dtype=np.int64).reshape(-1, 2)
+    if bidirected:
+        s = np.concatenate([pairs[:, 0], pairs[:, 1]])
+        t = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    else:
+        s, t = pairs[:, 0], pairs[:, 1]
+    return GNNGraph(s, t, num_nodes=n, index_base=0)
+
+
+def batch(graphs):
+    """MLUtils.batch(::Vector{GNNGraph}) [UPSTREAM]: block-diagonal union; features concatenated
+    along the last dimension (test/runtests.jl:92)."""
+    graphs = list(graphs)
+    off, ss, tt = 0, [], []
+    for g in graphs:
+        ss.append(g._s0 + off)
+        tt.append(g._t0 + off)
+        off += g.num_nodes
+
+    def cat(dicts, n_of, gdata=False):
+        out = {}
+        for k in dicts[0]:
+            parts = []
+            for d, g in zip(dicts, graphs):
+                v = d[k]
+                v = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+                if v.dim() == 1:
+                    v = v.reshape(-1, 1) if (gdata and n_of(g) == 1) else v.reshape(1, -1)
+                parts.append(v)
+            out[k] = torch.cat(parts, dim=-1)
+        return out
+
+    out = GNNGraph(np.concatenate(ss) if ss else [], np.concatenate(tt) if tt else [], num_nodes=off,
+                   index_base=0, num_graphs=sum(g.num_graphs for g in graphs))
+    out.ndata = cat([g.ndata for g in graphs], lambda g: g.num_nodes)
+    out.edata = cat([g.edata for g in graphs], lambda g: g.num_edges)
+    out.gdata = cat([g.gdata for g in graphs], lambda g: g.num_graphs, gdata=True)
+    if graphs and graphs[0].edge_weight is not None:
+        out.edge_weight = np.concatenate([np.asarray(g.edge_weight) for g in graphs])
+    return out

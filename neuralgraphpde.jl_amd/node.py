@@ -1,0 +1,166 @@
+"""NeuralODE -- the caller of the hot path in the reference's tutorial
+(/root/reference/docs/src/tutorials/graph_node.md:44-66): `dudt(u, p, t) = model(u, p, st)` integrated
+by an explicit Runge-Kutta scheme.  BASELINE configs fix the step count (Euler x 10, Tsit5 x 50), so
+this integrator is fixed-step and its pullback is the discrete adjoint.
+
+When the right-hand side is Chain(GCNConv(d => d, act), GCNConv(d => d, act)) on one graph (the
+tutorial's `node_chain`, graph_node.md:78) the whole solve and its adjoint run device-resident from
+HIP graphs (ngpde_node_gcn2_*).  Any other right-hand side is stepped stage by stage through the
+layers' own kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .layers import AbstractExplicitLayer, Chain, GCNConv, rows_of
+
+_TSIT5_A = [
+    [],
+    [0.161],
+    [-0.008480655492356989, 0.335480655492357],
+    [2.8971530571054935, -6.359448489975075, 4.3622954328695815],
+    [5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525],
+    [5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383],
+]
+_TSIT5_B = [0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+            2.324710524099774]
+TABLEAUS = {"euler": ([[]], [1.0]), "tsit5": (_TSIT5_A, _TSIT5_B)}
+
+
+class _Plan:
+    def __init__(self, handle, d, act, tableau, n_steps, dt, with_backward):
+        self.lib = _lib.load()
+        self.handle = handle            # keeps the graph handle alive
+        out = C.c_void_p()
+        _lib.check(self.lib.ngpde_node_gcn2_create(handle.ptr, d, act, _lib.TABLEAU[tableau], n_steps, dt,
+                                                   int(with_backward), C.byref(out)))
+        self.ptr = out
+
+    def tape_bytes(self):
+        return int(self.lib.ngpde_node_tape_bytes(self.ptr))
+
+    def launch_count(self):
+        f, b = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.ngpde_node_launch_count(self.ptr, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.ngpde_node_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _NodeGCN2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, w1t, b1, w2t, b2, plan):
+        lib = _lib.load()
+        u, w1t, w2t = u.contiguous(), w1t.contiguous(), w2t.contiguous()
+        uT = torch.empty_like(u)
+        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, _lib.ptr(u), _lib.ptr(w1t), _lib.ptr(b1), _lib.ptr(w2t),
+                                               _lib.ptr(b2), _lib.ptr(uT), _lib.current_stream()))
+        ctx.plan = plan
+        ctx.shapes = (u.shape, w1t.shape, None if b1 is None else b1.shape, None if b2 is None else b2.shape)
+        ctx.dev = u.device
+        return uT
+
+    @staticmethod
+    def backward(ctx, duT):
+        lib = _lib.load()
+        us, ws, b1s, b2s = ctx.shapes
+        mk = lambda s: None if s is None else torch.empty(s, dtype=torch.float32, device=ctx.dev)
+        du0, dw1, dw2, db1, db2 = mk(us), mk(ws), mk(ws), mk(b1s), mk(b2s)
+        duT = duT.contiguous()
+        _lib.check(lib.ngpde_node_gcn2_backward(ctx.plan.ptr, _lib.ptr(duT), _lib.ptr(du0), _lib.ptr(dw1), _lib.ptr(db1),
+                                                _lib.ptr(dw2), _lib.ptr(db2), _lib.current_stream()))
+        return du0, dw1, db1, dw2, db2, None
+
+
+class NeuralODE(AbstractExplicitLayer):
+    """NeuralODE(model; solver="tsit5", tspan=(0, 1), n_steps=..., dt=None)
+
+    A Lux container with the single field `model`, so `ps` and `st` are the model's own
+    (graph_node.md:44-52, :59-66).  `solver` is "euler" or "tsit5"; the step is fixed:
+    dt = (tspan[1] - tspan[0]) / n_steps unless given.
+    """
+
+    def __init__(self, model, *, solver="tsit5", tspan=(0.0, 1.0), n_steps=10, dt=None):
+        solver = solver.lower()
+        if solver not in TABLEAUS:
+            raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, f"unknown solver {solver!r}; one of {list(TABLEAUS)}")
+        self.model, self.solver, self.tspan, self.n_steps = model, solver, tuple(tspan), int(n_steps)
+        self.dt = float(dt) if dt is not None else (self.tspan[1] - self.tspan[0]) / self.n_steps
+        self._plans = {}
+
+    def initialparameters(self, rng):
+        return self.model.initialparameters(rng)
+
+    def initialstates(self, rng):
+        return self.model.initialstates(rng)
+
+    def statelength(self):
+        return self.model.statelength()
+
+    # -- is the right-hand side the tutorial's two-GCNConv chain on one graph? ---------------------
+    def _gcn2(self, ps, st):
+        m = self.model
+        if not (isinstance(m, Chain) and len(m.chain) == 2 and all(isinstance(l, GCNConv) for l in m.chain)):
+            return None
+        l1, l2 = m.chain
+        d = l1.in_chs
+        same = (l1.out_chs == d and l2.in_chs == d and l2.out_chs == d and l1.act == l2.act
+                and l1.add_self_loops == l2.add_self_loops and not l1.use_edge_weight and not l2.use_edge_weight
+                and l1.bias == l2.bias)
+        if not same or d not in (16, 32, 64, 128):
+            return None
+        g1, g2 = st["layer_1"]["graph"], st["layer_2"]["graph"]
+        if g1 is not g2 and g1 != g2:
+            return None
+        return l1, g1, d
+
+    def plan_for(self, ps, st, with_backward):
+        info = self._gcn2(ps, st)
+        if info is None:
+            return None
+        l1, g, d = info
+        handle = g.handle((l1.add_self_loops, None, False))
+        key = (id(handle), d, l1.act, bool(with_backward))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward)
+            self._plans[key] = plan
+        return plan
+
+    def __call__(self, x, ps, st):
+        u = rows_of(x)
+        needs_grad = torch.is_grad_enabled() and (u.requires_grad or any(
+            v.requires_grad for lp in ps.values() if isinstance(lp, dict) for v in lp.values()))
+        plan = self.plan_for(ps, st, needs_grad)
+        if plan is not None:
+            if not u.is_cuda:
+                raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, "NeuralODE: inputs must live on the GPU (no CPU fallback)")
+            p1, p2 = ps["layer_1"], ps["layer_2"]
+            b1 = p1["bias"].reshape(-1) if "bias" in p1 else None
+            b2 = p2["bias"].reshape(-1) if "bias" in p2 else None
+            uT = _NodeGCN2Fn.apply(u, rows_of(p1["weight"]), b1, rows_of(p2["weight"]), b2, plan)
+            return uT.T, st
+        # generic right-hand side: explicit RK stepping through the layers' kernels
+        a, b = TABLEAUS[self.solver]
+        ucur = x
+        for _ in range(self.n_steps):
+            ks = []
+            for i in range(len(b)):
+                U = ucur
+                for j in range(i):
+                    if a[i][j] != 0.0:
+                        U = U + (self.dt * a[i][j]) * ks[j]
+                k, st = self.model(U, ps, st)
+                ks.append(k)
+            for i in range(len(b)):
+                ucur = ucur + (self.dt * b[i]) * ks[i]
+        return ucur, st

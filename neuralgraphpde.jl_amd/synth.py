@@ -1,0 +1,79 @@
+"""synth.py -- portable synthetic inputs for tests and bench (numpy only, no GPU needed).
+
+Counter-based splitmix64 streams, so this container and the GPU box regenerate identical large
+inputs from a seed instead of shipping them: the BASELINE config-2 graph
+(16384 uniform points, the 65536 closest pairs as 131072 symmetric directed edges), N(0,1)
+features and glorot-uniform weights.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(seed, n):
+    """n uint64 values of the splitmix64 stream started at `seed` (vectorised)."""
+    idx = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed & _M64)
+    z = idx
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n):
+    return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def normal(seed, n):
+    u1 = uniform01(seed, n)
+    u2 = uniform01(seed ^ 0x5DEECE66D, n)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def closest_pairs_graph(n_nodes, n_pairs, seed):
+    """C2 graph: n_nodes uniform points in [0,1]^2, the n_pairs closest pairs as symmetric
+    directed edges (E = 2 n_pairs).  Deterministic given seed (cell-grid candidate search +
+    stable sort on (distance, i, j))."""
+    pts = np.stack([uniform01(seed, n_nodes), uniform01(seed + 1, n_nodes)], axis=1)
+    # candidate radius: expected pairs within r is n^2/2 * pi r^2 -> take 1.6x the target
+    r = np.sqrt(1.6 * n_pairs * 2.0 / (np.pi * n_nodes * n_nodes))
+    while True:
+        ncell = max(1, int(1.0 / r))
+        cx = np.minimum((pts[:, 0] * ncell).astype(np.int64), ncell - 1)
+        cy = np.minimum((pts[:, 1] * ncell).astype(np.int64), ncell - 1)
+        cell = cx * ncell + cy
+        order = np.argsort(cell, kind="stable")
+        start = np.searchsorted(cell[order], np.arange(ncell * ncell + 1))
+        I, J = [], []
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                nx, ny = cx + dx, cy + dy
+                ok = (nx >= 0) & (nx < ncell) & (ny >= 0) & (ny < ncell)
+                nc = np.where(ok, nx * ncell + ny, 0)
+                lo, hi = start[nc], np.where(ok, start[nc + 1], start[nc])
+                cnt = hi - lo
+                src = np.repeat(np.arange(n_nodes), cnt)
+                offs = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+                dst = order[np.repeat(lo, cnt) + offs]
+                keep = src < dst
+                I.append(src[keep])
+                J.append(dst[keep])
+        I, J = np.concatenate(I), np.concatenate(J)
+        d2 = ((pts[I] - pts[J]) ** 2).sum(axis=1)
+        within = d2 <= r * r
+        I, J, d2 = I[within], J[within], d2[within]
+        if I.size >= n_pairs:
+            break
+        r *= 1.3
+    o = np.lexsort((J, I, d2))[:n_pairs]
+    I, J = I[o], J[o]
+    s = np.concatenate([I, J])
+    t = np.concatenate([J, I])
+    return pts, s.astype(np.int64), t.astype(np.int64)
+
+
+def glorot_uniform(seed, out_dims, in_dims):
+    lim = np.sqrt(6.0 / (in_dims + out_dims))
+    return ((uniform01(seed, out_dims * in_dims) * 2.0 - 1.0) * lim).reshape(out_dims, in_dims)

@@ -1,0 +1,283 @@
+"""GPU parity tests of the GCNConv path and the fixed-step neural graph ODE: HIP kernels (through
+the C ABI) against the float64 numpy oracle on the same seeded inputs.
+
+Tolerances: forward  max|y - y_oracle| <= 1e-4 * max|y_oracle| + 1e-5,
+gradients 2e-4 relative (segmented sums of <= ~150 fp32 terms; fp32 MFMA is an exact fmaf chain).
+"""
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+from oracle import ngpde_oracle as O
+from ngpde_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def close(a, ref, rtol=1e-4, atol=1e-5, what=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    err = np.abs(a - ref).max() if ref.size else 0.0
+    bound = rtol * (np.abs(ref).max() if ref.size else 0.0) + atol
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e}"
+
+
+def make_graph(N, E, seed, symmetric=False):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, N, E)
+    t = rng.integers(0, N, E)
+    if symmetric:
+        s, t = np.concatenate([s, t]), np.concatenate([t, s])
+    return s, t
+
+
+def run_layer(N, E, din, dout, act, seed, add_self_loops=True, bias=True, weights=None, use_edge_weight=False,
+              grads=True):
+    rng = np.random.default_rng(seed)
+    s, t = make_graph(N, E, seed)
+    ew = None
+    if weights == "arg" or use_edge_weight:
+        ew = (rng.random(s.size) + 0.5).astype(np.float32)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew if use_edge_weight else None)
+    og = O.Graph(s, t, num_nodes=N, index_base=0, edge_weight=ew if use_edge_weight else None)
+    l = ng.GCNConv((din, dout), act, initialgraph=g, bias=bias, add_self_loops=add_self_loops,
+                   use_edge_weight=use_edge_weight)
+    ps, st = ng.setup(seed, l)
+    ps = ng.to_device(ps, DEV)
+    if bias:
+        ps["bias"] = torch.as_tensor(rng.normal(size=(dout, 1)).astype(np.float32), device=DEV)
+    x = torch.as_tensor(rng.normal(size=(din, N)).astype(np.float32), device=DEV)
+    for p in ps.values():
+        p.requires_grad_(grads)
+    x.requires_grad_(grads)
+    ew_arg = torch.as_tensor(ew) if weights == "arg" else None
+    y, st2 = l(x, ps, st, ew_arg) if ew_arg is not None else l(x, ps, st)
+    assert y.shape == (dout, N) and st2["graph"] is st["graph"]
+    W = ps["weight"].detach().cpu().double().numpy()
+    b = ps["bias"].detach().cpu().double().numpy() if bias else None
+    X = x.detach().cpu().double().numpy()
+    yo, cache = O.gcn_conv(X, W, b, og, act, add_self_loops, use_edge_weight,
+                           edge_weight=ew.astype(np.float64) if weights == "arg" else None)
+    close(y, yo, what=f"gcn fwd {din}->{dout} {act}")
+    if grads:
+        R = rng.normal(size=(dout, N))
+        (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+        go = O.gcn_conv_backward(cache, R)
+        close(x.grad, go["x"], rtol=2e-4, what="dx")
+        close(ps["weight"].grad, go["weight"], rtol=2e-4, atol=1e-4, what="dW")
+        if bias:
+            close(ps["bias"].grad, go["bias"], rtol=2e-4, atol=1e-4, what="db")
+
+
+def test_reference_fixture_gcn_3_to_5():
+    # /root/reference/test/runtests.jl:9-25
+    g = ng.GNNGraph([1, 1, 2, 3], [2, 3, 1, 1])
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    assert st == {"graph": g}
+    x = torch.randn(3, g.num_nodes, device=DEV)
+    y, st = l(x, ng.to_device(ps, DEV), st)
+    assert tuple(y.shape) == (5, g.num_nodes)
+    assert st == {"graph": g}
+    og = O.Graph([1, 1, 2, 3], [2, 3, 1, 1])
+    yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), ps["bias"].double().numpy(), og)
+    close(y, yo)
+
+
+@pytest.mark.parametrize("din,dout", [(3, 5), (6, 3), (20, 33), (48, 16), (16, 64)])
+def test_gcn_generic_dims(din, dout):
+    run_layer(61, 300, din, dout, "tanh", seed=din * 100 + dout)
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+@pytest.mark.parametrize("act", ["relu", "swish"])
+def test_gcn_fused_dims(d, act):
+    run_layer(1000 + d, 9000, d, d, act, seed=d)   # N not a multiple of the 32-row tile
+
+
+def test_gcn_no_self_loops_no_bias_identity():
+    # every node needs an incoming edge (an isolated node gives NaN in the reference too: 0 * Inf)
+    N = 200
+    s = np.concatenate([np.arange(N), np.random.default_rng(0).integers(0, N, 600)])
+    t = np.concatenate([(np.arange(N) + 1) % N, np.random.default_rng(1).integers(0, N, 600)])
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    for d in (64, 7):
+        l = ng.GCNConv((d, d), initialgraph=g, bias=False, add_self_loops=False)
+        ps, st = ng.setup(1, l)
+        assert list(ps) == ["weight"]
+        x = torch.randn(d, N, device=DEV)
+        y, _ = l(x, ng.to_device(ps, DEV), st)
+        yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), None, og, "identity", False)
+        close(y, yo)
+
+
+def test_gcn_isolated_node_without_self_loops_is_nan_like_reference():
+    g = ng.GNNGraph([1, 2], [2, 1], num_nodes=3)
+    og = O.Graph([1, 2], [2, 1], num_nodes=3)
+    l = ng.GCNConv((16, 16), initialgraph=g, add_self_loops=False)
+    ps, st = ng.setup(1, l)
+    x = torch.randn(16, 3, device=DEV)
+    y, _ = l(x, ng.to_device(ps, DEV), st)
+    with np.errstate(invalid="ignore"):
+        yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), ps["bias"].double().numpy(), og,
+                           "identity", False)
+    assert np.isnan(yo[:, 2]).all() and torch.isnan(y[:, 2]).all()
+    close(y[:, :2], yo[:, :2])
+
+
+@pytest.mark.parametrize("d", [64, 10])
+def test_gcn_edge_weight_argument(d):
+    run_layer(300, 2500, d, d, "relu", seed=5, weights="arg")
+
+
+@pytest.mark.parametrize("d", [32, 9])
+def test_gcn_use_edge_weight_unweighted_degree_quirk(d):
+    run_layer(300, 2500, d, d, "relu", seed=6, use_edge_weight=True)
+
+
+def test_gcn_wrong_number_of_edge_weights():
+    g = ng.GNNGraph([1, 1, 2, 3], [2, 3, 1, 1])
+    l = ng.GCNConv((16, 16), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    with pytest.raises(ng.ArgumentError, match="Wrong number of edge weights \\(expected 4 but given 3\\)"):
+        l(torch.randn(16, 3, device=DEV), ng.to_device(ps, DEV), st, torch.ones(3))
+
+
+def test_gcn_empty_and_edgeless_graphs():
+    g = ng.GNNGraph([], [], num_nodes=5)
+    l = ng.GCNConv((16, 16), "relu", initialgraph=g)
+    ps, st = ng.setup(0, l)
+    x = torch.randn(16, 5, device=DEV)
+    y, _ = l(x, ng.to_device(ps, DEV), st)
+    yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), ps["bias"].double().numpy(),
+                       O.Graph([], [], num_nodes=5), "relu")
+    close(y, yo)
+    # default EMPTYGRAPH state (src/layers.jl:14,21): zero nodes in, zero nodes out
+    l0 = ng.GCNConv((16, 16))
+    ps0, st0 = ng.setup(0, l0)
+    y0, _ = l0(torch.zeros(16, 0, device=DEV), ng.to_device(ps0, DEV), st0)
+    assert tuple(y0.shape) == (16, 0)
+
+
+def test_gcn_high_degree_rows():
+    # a hub with 700 incoming edges (> one chunk of 16 entries many times over) and Cora-like skew
+    N = 800
+    s = np.concatenate([np.arange(1, 701), np.random.default_rng(0).integers(0, N, 3000)])
+    t = np.concatenate([np.zeros(700, np.int64), np.random.default_rng(1).integers(0, N, 3000)])
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    for d in (64, 32, 128):
+        l = ng.GCNConv((d, d), "relu", initialgraph=g)
+        ps, st = ng.setup(d, l)
+        x = torch.randn(d, N, device=DEV)
+        y, _ = l(x, ng.to_device(ps, DEV), st)
+        yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), ps["bias"].double().numpy(), og, "relu")
+        close(y, yo)
+
+
+def test_gcn_c2_full_size_parity_and_determinism():
+    # BASELINE config 2 graph: 16384 nodes, 65536 closest pairs -> 131072 directed edges, 64-d
+    pts, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
+    g = ng.GNNGraph(s, t, num_nodes=16384, index_base=0)
+    og = O.Graph(s, t, num_nodes=16384, index_base=0)
+    l = ng.GCNConv((64, 64), "relu", initialgraph=g)
+    ps, st = ng.setup(2, l)
+    ps = ng.to_device(ps, DEV)
+    x = torch.as_tensor(S.normal(22, 64 * 16384).reshape(64, 16384).astype(np.float32), device=DEV)
+    y, _ = l(x, ps, st)
+    yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].cpu().double().numpy(),
+                       ps["bias"].cpu().double().numpy(), og, "relu")
+    close(y, yo)
+    y2, _ = l(x, ps, st)
+    assert torch.equal(y, y2), "segmented reduction must be bitwise reproducible"
+
+
+def test_chain_of_gcn_and_updategraph_on_gpu():
+    # test/runtests.jl:181-185: one updategraph call re-targets every layer of a Chain
+    g = ng.rand_graph(50, 200, seed=0)
+    g2 = ng.rand_graph(50, 300, seed=1)
+    model = ng.Chain(ng.GCNConv((16, 16), "relu", initialgraph=g), ng.GCNConv((16, 16), initialgraph=g))
+    ps, st = ng.setup(0, model)
+    st = ng.updategraph(st, g2)
+    assert st["layer_1"]["graph"] is g2 and st["layer_2"]["graph"] is g2
+    ps = ng.to_device(ps, DEV)
+    x = torch.randn(16, 50, device=DEV)
+    y, _ = model(x, ps, st)
+    s, t = g2.edge_index(0)
+    og = O.Graph(s, t, num_nodes=50, index_base=0)
+    p = lambda k, n: ps[k][n].cpu().double().numpy()
+    h, _ = O.gcn_conv(x.cpu().double().numpy(), p("layer_1", "weight"), p("layer_1", "bias"), og, "relu")
+    yo, _ = O.gcn_conv(h, p("layer_2", "weight"), p("layer_2", "bias"), og)
+    close(y, yo)
+
+
+# ---- fixed-step neural graph ODE -----------------------------------------------------------------
+
+def node_case(N, E, d, tab, nsteps, dt, act, seed):
+    rng = np.random.default_rng(seed)
+    s, t = make_graph(N, E, seed, symmetric=False)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    params = [dict(weight=S.glorot_uniform(seed + 10 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    u0 = rng.normal(size=(d, N))
+    return g, og, params, u0
+
+
+@pytest.mark.parametrize("tab,d,act", [("euler", 32, "relu"), ("tsit5", 64, "relu"), ("tsit5", 16, "tanh"),
+                                        ("tsit5", 128, "swish")])
+def test_node_forward_backward_parity(tab, d, act):
+    N, E, nsteps, dt = 333, 2400, 3, 0.1
+    g, og, params, u0 = node_case(N, E, d, tab, nsteps, dt, act, seed=d)
+    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+    node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, og, u0, O.TABLEAUS[tab], dt, nsteps, act)
+    close(uT, uTo, rtol=2e-4, what="u(T)")
+    uT.sum().backward()
+    close(u.grad, du0o, rtol=5e-4, atol=1e-4, what="du0")
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, acc[k]["weight"], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+
+
+def test_node_matches_layerwise_euler_step():
+    # one Euler step through the plan == u + dt * Chain(GCNConv, GCNConv)(u) through the layer API
+    N, d = 200, 32
+    g = ng.rand_graph(N, 1200, seed=3)
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver="euler", n_steps=1, dt=0.25)
+    ps, st = ng.setup(4, node)
+    ps = ng.to_device(ps, DEV)
+    u = torch.randn(d, N, device=DEV)
+    uT, _ = node(u, ps, st)
+    k, _ = rhs(u, ps, st)
+    assert torch.allclose(uT, u + 0.25 * k, rtol=1e-5, atol=1e-6)
+
+
+def test_node_replay_is_deterministic_and_reusable():
+    N, d = 500, 64
+    g = ng.rand_graph(N, 4000, seed=5)
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver="tsit5", n_steps=4, dt=0.05)
+    ps, st = ng.setup(4, node)
+    ps = ng.to_device(ps, DEV)
+    u = torch.randn(d, N, device=DEV)
+    a, _ = node(u, ps, st)
+    b, _ = node(u, ps, st)
+    assert torch.equal(a, b)
+    c, _ = node(2 * u, ps, st)
+    assert not torch.equal(a, c)
