@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE config 2 (C2):
+
+    ODE-steps/sec, forward + backward, of the neural graph ODE  du/dt = Chain(GCNConv(64=>64, relu),
+    GCNConv(64=>64, relu))(u)  on a 16384-node / 131072-edge radius-style graph with 64-d features,
+    Tsit5 with a fixed step dt = 1/50 for 50 steps (6 right-hand-side evaluations per step), gradient of
+    sum(u(T)) w.r.t. u0 and all parameters by the discrete adjoint.
+
+A bench "step" (what --steps counts) is ONE full solve, forward then backward (+ the RCCL all-reduce
+of the parameter gradients when N > 1), over one batch of synthetic input already resident in HBM.
+`value` = ODE steps integrated per second by the whole job = n_gpus * 50 * K / T.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU is data parallel over independent trajectories (different u0 per rank, same graph and
+parameters): per-GPU work is fixed ("weak"), one all-reduce(sum) of the 8320-float gradient per step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import ngpde_amd as ng  # noqa: E402
+from ngpde_amd import _lib, synth as S  # noqa: E402
+from ngpde_amd.node import _Plan  # noqa: E402
+
+N_NODES, N_PAIRS, D = 16384, 65536, 64
+ODE_STEPS, DT = 50, 1.0 / 50.0
+GRAPH_SEED = 2
+# SURVEY.md §8(d) algorithmic (compulsory) HBM bytes of ONE fused layer launch at C2
+BYTES_FWD_LAYER = 9.06e6
+BYTES_BWD_LAYER = 17.47e6
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_inputs(rank):
+    _, s, t = S.closest_pairs_graph(N_NODES, N_PAIRS, seed=GRAPH_SEED)
+    u0 = S.normal(1000 + rank, D * N_NODES).reshape(N_NODES, D).astype(np.float32)      # [N][D] = (D x N) col-major
+    w1 = np.ascontiguousarray(S.glorot_uniform(11, D, D).T, np.float32)                 # [in][out]
+    w2 = np.ascontiguousarray(S.glorot_uniform(12, D, D).T, np.float32)
+    b1 = np.zeros(D, np.float32)
+    b2 = np.zeros(D, np.float32)
+    return s, t, u0, w1, b1, w2, b2
+
+
+def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
+    """The C restatement of the reference algorithm (oracle/, kind "port") timed on this box's host
+    cores on a bounded sample of the same workload: n Tsit5 steps forward + backward on the C2 graph."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    path = os.path.join(odir, "libngpde_oracle_omp.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", odir])
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.ngo_node_gcn2.argtypes = [C.c_int64, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  C.c_int] + [vp] * 11
+    lib.ngo_node_gcn2.restype = C.c_int
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    s64, t64 = np.ascontiguousarray(s, np.int64), np.ascontiguousarray(t, np.int64)
+    outs = [np.zeros_like(u0), np.zeros_like(u0), np.zeros_like(w1), np.zeros_like(b1), np.zeros_like(w2),
+            np.zeros_like(b2)]
+    P = lambda a: a.ctypes.data
+
+    def run(nsteps):
+        t0 = time.perf_counter()
+        rc = lib.ngo_node_gcn2(N_NODES, s64.size, P(s64), P(t64), D, 1, 1, nsteps, DT, 1, P(u0), P(w1), P(b1), P(w2),
+                               P(b2), *[P(o) for o in outs])
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    n = int(max(1, min(ODE_STEPS, budget_s / max(t1, 1e-6))))
+    tn = run(n) if n > 1 else t1
+    return {"value": n / tn, "unit": "ODE-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} Tsit5 step(s) fwd+bwd of the same C2 workload (C restatement of the reference "
+                      f"algorithm, OpenMP over {cores} host threads; not the Julia package)"}, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
+    g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
+    handle = g.handle((True, None, False))
+    plan = _Plan(handle, D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
+    lib = _lib.load()
+    dv = lambda a: torch.as_tensor(a, device=dev)
+    u0, w1, b1, w2, b2 = dv(u0_h), dv(w1_h), dv(b1_h), dv(w2_h), dv(b2_h)
+    uT, du0 = torch.empty_like(u0), torch.empty_like(u0)
+    seed_grad = torch.ones_like(u0)                       # d sum(u(T)) / d u(T)
+    flat = torch.empty(2 * (D * D + D), dtype=torch.float32, device=dev)   # [dw1 | db1 | dw2 | db2]
+    dw1, db1 = flat[:D * D], flat[D * D:D * D + D]
+    dw2, db2 = flat[D * D + D:2 * D * D + D], flat[2 * D * D + D:]
+    stream = torch.cuda.current_stream().cuda_stream
+    p = _lib.ptr
+
+    def step():
+        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+        _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+        if dist is not None:
+            dist.all_reduce(flat)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # forward / backward split of one solve, by HIP events on the launch stream (outside the timed region)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+    ev[1].record()
+    _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+    ev[2].record()
+    torch.cuda.synchronize()
+    ms_fwd, ms_bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+
+    out = None
+    if rank == 0:
+        # per-launch DEVICE time of the four kernel roles, from start/stop events attached to the dispatches
+        us = (C.c_float * 4)()
+        cnt = (C.c_int32 * 4)()
+        _lib.check(lib.ngpde_node_profile(plan.ptr, 1, us, cnt, stream))
+        roles = ["fwd_layer1", "fwd_layer2_stage", "bwd_layer1", "bwd_stage_layer2"]
+        algo = [BYTES_FWD_LAYER, BYTES_FWD_LAYER, BYTES_BWD_LAYER, BYTES_BWD_LAYER]
+        kernels = {r: {"avg_us": round(float(us[i]), 3), "launches_per_solve": int(cnt[i]),
+                       "algorithmic_MB": algo[i] / 1e6,
+                       "achieved_GBs": round(algo[i] / (float(us[i]) * 1e-6) / 1e9, 1) if us[i] > 0 else None}
+                   for i, r in enumerate(roles)}
+        tot = [float(us[i]) * int(cnt[i]) for i in range(4)]
+        dom = int(np.argmax(tot))
+        achieved = algo[dom] / (float(us[dom]) * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(roles[dom])
+            except Exception:
+                traffic = None
+        fl, bl = plan.launch_count()
+        value = world * ODE_STEPS * args.steps / elapsed
+        out = {
+            "metric": "ODE-steps/sec (fwd+bwd) on 16k-node graph, 64-d feats",
+            "value": round(value, 2), "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: 16384-node / 131072-edge closest-pairs radius graph, 64-d feats, "
+                                   "RHS = 2 x GCNConv(64=>64, relu, self-loops), Tsit5 fixed dt=1/50 x 50 steps, "
+                                   "forward + discrete adjoint of sum(u(T))",
+                       "bench_step": "one full solve forward + backward",
+                       "ode_steps_per_solve": ODE_STEPS, "rhs_evals_per_ode_step": 6,
+                       "launches_per_solve": {"forward": fl, "backward": bl},
+                       "ms_forward_solve": round(ms_fwd, 3), "ms_backward_solve": round(ms_bwd, 3),
+                       "tape_GB": round(plan.tape_bytes() / 1e9, 3),
+                       "parallelism": f"dp{world} (independent trajectories, all-reduce of 8320-float grads)"},
+            "roofline": {"bound": "hbm", "kernel": roles[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "avg_launch_us": round(float(us[dom]), 3)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, outs = cpu_baseline(s, t, u0_h, w1_h, b1_h, w2_h, b2_h)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

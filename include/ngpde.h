@@ -139,6 +139,15 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *plan, const float *duT, float *du
 /* Names and average device time of the plan's kernels are visible to rocprofv3 --kernel-trace;
  * this returns the number of kernel launches one forward (+ backward) solve enqueues. */
 int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);
+/* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
+ * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
+ * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity
+ * rocprofv3 --kernel-trace reports -- for the four kernel roles:
+ *   out_us[0] forward layer 1, out_us[1] forward layer 2 + stage combination,
+ *   out_us[2] backward layer 1, out_us[3] backward stage combination + layer 2.
+ * out_count[4] (nullable) receives the number of sampled launches per role.  Synchronises `stream`. */
+int32_t ngpde_node_profile(ngpde_node_t *plan, int32_t stride, float *out_us, int32_t *out_count,
+                           ngpde_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,8 +38,11 @@ struct Csr {
   int32_t *col = nullptr;     // [n_edges] the node at the other end of each entry
   int32_t *eid = nullptr;     // [n_edges] position of the entry in the COO list
   int2 *ent = nullptr;        // [n_edges] {col, bits of GCN coefficient w_e * c[col]}; set by set_gcn_norm
+  int4 *sched = nullptr;      // [n_sched] tile schedule entries {node, row start, degree, bits of c[node]}; node < 0 = padding
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
+
+constexpr int kTileRows = 32;  // node rows per workgroup of the fused kernels
 
 }  // namespace ngpde
 
@@ -52,6 +55,12 @@ struct ngpde_graph {
   int32_t self_loops = 0;
   float *c = nullptr;  // [n_nodes] 1/sqrt(degree)
   int32_t max_in_degree = 0, max_out_degree = 0;
+  // Locality schedule: a permutation of the nodes in which consecutive runs of kTileRows nodes are
+  // graph-compact clusters (BFS-grown) and consecutive clusters are adjacent.  The fused kernels give
+  // each workgroup one run, and each XCD a contiguous range of runs, so the rows a workgroup gathers
+  // are mostly the rows its own XCD wrote/read last: L2-resident instead of cross-XCD traffic.
+  std::vector<int32_t> h_order;
+  int32_t n_sched = 0;  // n_tiles * kTileRows
 };
 
 namespace ngpde {
@@ -80,6 +89,8 @@ struct FusedFwdArgs {
   bool has_comb = false;
   Comb comb;
   float *comb_out = nullptr;
+  // optional start/stop events attached to the dispatch itself (profiling pass only)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool fused_supported(int din, int dout);
 int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream);
@@ -103,11 +114,13 @@ struct FusedBwdArgs {
   float *g_out = nullptr;        // [N][d]  dZ * W
   float *slab_dw = nullptr;      // [n_blocks][d*d] accumulated (+=)
   float *slab_db = nullptr;      // [n_blocks][d]   accumulated (+=)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 int fused_tile_rows();
 int fused_num_blocks(int64_t n_nodes);
 int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
-int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, float *out, hipStream_t stream);
+// ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum
+int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream);
 
 // generic (any feature width) building blocks
 int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr,

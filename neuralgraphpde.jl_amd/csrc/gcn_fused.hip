@@ -1,0 +1,588 @@
+// gcn_fused.hip -- fused gfx950 kernels of the GCNConv hot path (/root/reference/src/layers.jl:200-239),
+// d_in = d_out = D in {16, 32, 64, 128}:
+//   forward  : CSR segmented aggregation -> LDS tile -> fp32 MFMA (x W) -> bias/activation
+//              [-> Runge-Kutta stage combination], one launch per layer evaluation;
+//   backward : [A^T aggregation of the incoming gradient ->] [adjoint stage combination ->] act' mask ->
+//              fp32 MFMA (dZ x W^T and X3^T x dZ) -> per-workgroup dW/db slabs.
+// No atomics anywhere: every output row / slab has exactly one writer, so results are bitwise
+// reproducible run to run (the reference's GPU path scatters with fp32 atomics).
+//
+// Work decomposition: a workgroup (4 waves) owns one run of kTileRows = 32 schedule entries (a
+// graph-compact node cluster, see ngpde_graph::h_order); blockIdx -> run is XCD-aware so each of the 8
+// XCDs works on a contiguous range of runs.  N = 16384 gives 512 workgroups = 2 per CU.
+#include <hip/hip_ext.h>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace ngpde {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTM = kTileRows;
+constexpr int kXcds = 8;
+
+template <int D>
+struct Geo {
+  static constexpr int LPR = D / 4;                          // lanes per feature row (float4 each)
+  static constexpr int GROUPS = kThreads / LPR;              // row groups per workgroup
+  static constexpr int R = (kTM + GROUPS - 1) / GROUPS;      // rows per group
+  static constexpr int U = (R >= 4) ? 2 : 4;                 // edge unroll (rows in flight per lane = R*U)
+  static constexpr int TS = D + 4;                           // LDS row stride (floats): 16-B aligned, b128 reads of 16 rows hit 64 banks once
+  static constexpr int W4 = (D * D / 4 + kThreads - 1) / kThreads;  // float4 of W per thread
+  static constexpr int KGP = kThreads / D;                   // k-groups (4 consecutive k) staged per pass by the transposing loader
+  static constexpr int NPASS = (D / 4 + KGP - 1) / KGP;
+  static constexpr int RT = kTM / 16;                        // 16-row MFMA tiles per workgroup
+  static constexpr int CT = D / 16;                          // 16-col MFMA tiles
+  static constexpr int WAVES = kThreads / 64;
+  static constexpr int CGRP = WAVES / RT;                    // waves sharing one row tile
+  static constexpr int CPW = (CT + CGRP - 1) / CGRP;         // column tiles per wave
+  static constexpr int DWT = (CT * CT + WAVES - 1) / WAVES;  // dW tiles per wave
+};
+
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/): per-workgroup phase timestamps; never compiled into the product library
+__device__ unsigned long long *g_stamps = nullptr;
+#define NGPDE_STAMP(k)                                                              \
+  do {                                                                              \
+    if (threadIdx.x == 0 && g_stamps) {                                             \
+      g_stamps[(size_t)blockIdx.x * 16 + 2 * (k)] = clock64();                      \
+      g_stamps[(size_t)blockIdx.x * 16 + 2 * (k) + 1] = wall_clock64();             \
+    }                                                                               \
+  } while (0)
+#else
+#define NGPDE_STAMP(k)
+#endif
+
+// blockIdx -> tile, bijective for any grid size: blocks b, b+8, b+16, ... (dispatched to one XCD in
+// practice) get consecutive tiles.  Placement only changes speed, never results.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+  const int x = b % kXcds, k = b / kXcds;
+  const int q = nb / kXcds, r = nb % kXcds;
+  return x * q + min(x, r) + k;
+}
+
+struct CombDev {
+  int n;
+  const float *ptr[8];
+  float coef[8];
+  float coef_self;
+};
+
+template <int K>
+__device__ __forceinline__ float4 comb_eval_n(const CombDev &c, float4 self, size_t idx4) {
+  float4 t[K > 0 ? K : 1];
+#pragma unroll
+  for (int k = 0; k < K; ++k) t[k] = reinterpret_cast<const float4 *>(c.ptr[k])[idx4];
+  float4 v = f4_scale(c.coef_self, self);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v = f4_fma(c.coef[k], t[k], v);
+  return v;
+}
+
+// v = coef_self * self + sum_k coef[k] * ptr[k][row]; all term loads are issued before the first use
+__device__ __forceinline__ float4 comb_eval(const CombDev &c, float4 self, size_t idx4) {
+  switch (c.n) {
+    case 0: return comb_eval_n<0>(c, self, idx4);
+    case 1: return comb_eval_n<1>(c, self, idx4);
+    case 2: return comb_eval_n<2>(c, self, idx4);
+    case 3: return comb_eval_n<3>(c, self, idx4);
+    case 4: return comb_eval_n<4>(c, self, idx4);
+    case 5: return comb_eval_n<5>(c, self, idx4);
+    case 6: return comb_eval_n<6>(c, self, idx4);
+    case 7: return comb_eval_n<7>(c, self, idx4);
+    default: return comb_eval_n<8>(c, self, idx4);
+  }
+}
+
+// ---- CSR segmented aggregation of whole feature rows ------------------------------------------------
+// A "group" of LPR = D/4 adjacent lanes owns R rows; lane q holds features 4q..4q+3 of each row as one
+// float4 (a D=64 row = 256 B = 16 lanes x dwordx4: fully coalesced row gathers).  Per row the group
+// loads up to LPR {col, coef} entries with ONE coalesced 8-byte load per lane, broadcasts them with
+// in-register lane shuffles and issues R*U independent 16-byte row loads per round, so a wave keeps
+// 4*R*U neighbour rows in flight.  Branch-free: out-of-range slots load row 0 and are zeroed by selects.
+//   acc[r] = c * ( sum_e coef_e * X[col_e] + (self ? c * X[node] : 0) ),  c = bits in sched.w
+template <int LPR, int R, int U>
+__device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, const int2 *__restrict__ ent,
+                                               int self_loops, const int4 (&sc)[R], int q, float4 (&acc)[R]) {
+  static_assert(LPR % U == 0, "unroll must divide the lanes per row");
+  int maxdeg = 0;
+  float4 selfv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    maxdeg = max(maxdeg, sc[r].z);
+    acc[r] = f4_zero();
+    selfv[r] = X4[(size_t)max(sc[r].x, 0) * LPR + q];   // requested up front; consumed last
+  }
+  for (int base = 0; base < maxdeg; base += LPR) {
+    int ecol[R], ecf[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = base + q < sc[r].z;
+      const int2 v = ent[ok ? sc[r].y + base + q : 0];
+      ecol[r] = ok ? v.x : 0;
+      ecf[r] = ok ? v.y : 0;
+    }
+    const int nin = min(LPR, maxdeg - base);
+    for (int e = 0; e < nin; e += U) {
+      float4 v[R][U];
+      float cf[R][U];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int col = __shfl(ecol[r], e + u, LPR);         // 0 for slots past the row's degree
+          cf[r][u] = __int_as_float(__shfl(ecf[r], e + u, LPR));
+          v[r][u] = X4[(size_t)col * LPR + q];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool vld = (base + e + u) < sc[r].z;
+          float4 t = v[r][u];
+          t.x = vld ? t.x : 0.f; t.y = vld ? t.y : 0.f; t.z = vld ? t.z : 0.f; t.w = vld ? t.w : 0.f;
+          acc[r] = f4_fma(cf[r][u], t, acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float ci = __int_as_float(sc[r].w);
+    if (self_loops) acc[r] = f4_fma(ci, selfv[r], acc[r]);
+    acc[r] = f4_scale(ci, acc[r]);
+  }
+}
+
+// ---- fp32 MFMA tile products from LDS ------------------------------------------------------------------
+// Out[kTM][D] = A[kTM][D] x B, with A row-major (stride TS) and B stored TRANSPOSED, Bt[col][k] (stride
+// TS), so lane (i = l&15, kq = l>>4) feeds four consecutive k-steps of v_mfma_f32_16x16x4_f32 from ONE
+// ds_read_b128 per operand: k-step (kb, r) contracts k = 16 kb + 4 kq + r on both operands.  Operand
+// registers are double-buffered across kb so LDS latency hides under the MFMAs.
+template <int D>
+__device__ __forceinline__ void mfma_rows_times_bt(const float *ldsA, const float *ldsBt, float *ldsOut, int wave_u,
+                                                   int lane) {
+  using G = Geo<D>;
+  const int rt = wave_u % G::RT;
+  const int cg = wave_u / G::RT;
+  if (cg >= G::CT) return;   // D = 16: only one column tile; wave-uniform
+  const int i = lane & 15, kq = lane >> 4;
+  const float *pa = ldsA + (rt * 16 + i) * G::TS + 4 * kq;
+  const float *pb[G::CPW];
+  f32x4 acc[G::CPW];
+#pragma unroll
+  for (int m = 0; m < G::CPW; ++m) {
+    pb[m] = ldsBt + ((cg + G::CGRP * m) * 16 + i) * G::TS + 4 * kq;
+    acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float4 a_cur = *reinterpret_cast<const float4 *>(pa);
+  float4 b_cur[G::CPW];
+#pragma unroll
+  for (int m = 0; m < G::CPW; ++m) b_cur[m] = *reinterpret_cast<const float4 *>(pb[m]);
+#pragma unroll
+  for (int kb = 0; kb < D / 16; ++kb) {
+    float4 a_nxt = a_cur, b_nxt[G::CPW];
+#pragma unroll
+    for (int m = 0; m < G::CPW; ++m) b_nxt[m] = b_cur[m];
+    if (kb + 1 < D / 16) {
+      a_nxt = *reinterpret_cast<const float4 *>(pa + (kb + 1) * 16);
+#pragma unroll
+      for (int m = 0; m < G::CPW; ++m) b_nxt[m] = *reinterpret_cast<const float4 *>(pb[m] + (kb + 1) * 16);
+    }
+    const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int m = 0; m < G::CPW; ++m) {
+        const float bv[4] = {b_cur[m].x, b_cur[m].y, b_cur[m].z, b_cur[m].w};
+        acc[m] = mfma16(av[r], bv[r], acc[m]);
+      }
+    }
+    a_cur = a_nxt;
+#pragma unroll
+    for (int m = 0; m < G::CPW; ++m) b_cur[m] = b_nxt[m];
+  }
+#pragma unroll
+  for (int m = 0; m < G::CPW; ++m) {
+    const int ct = cg + G::CGRP * m;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ldsOut[(rt * 16 + 4 * kq + reg) * G::TS + ct * 16 + i] = acc[m][reg];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused forward:  y = act( (C (A+I) C x) Wt + b ),  optional RK stage combination on the fresh rows
+// ---------------------------------------------------------------------------------------------------
+struct FwdK {
+  const float *x;
+  const int4 *sched;
+  const int2 *ent;
+  int self_loops, n_tiles, act;
+  const float *wt, *bias;
+  float *y, *save_agg, *save_z;
+  int has_comb;
+  CombDev comb;
+  float *comb_out;
+};
+
+template <int D, int ACT>
+__global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 2 + D * G::TS];
+  float *ldsT = lds, *ldsZ = lds + kTM * G::TS, *ldsBt = lds + 2 * kTM * G::TS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = tid / G::LPR, q = tid % G::LPR;
+  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  const int act = ACT >= 0 ? ACT : p.act;
+  NGPDE_STAMP(0);
+
+  // schedule entries of this thread's rows (node, row start, degree, c) -- one 16-byte load each
+  int4 sc[G::R];
+  const bool active = grp * G::R < kTM;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r)
+    sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+
+  // W is requested before the gather so it lands meanwhile.  B[k = in][j = out] = wt[in][out]; stored
+  // transposed in LDS: 4 dword loads down a column (coalesced across lanes) -> one ds_write_b128.
+  float4 wreg[G::NPASS];
+  {
+    const int j = tid % D, kg0 = tid / D;
+#pragma unroll
+    for (int ps = 0; ps < G::NPASS; ++ps) {
+      const int kg = kg0 + ps * G::KGP;
+      wreg[ps] = f4_zero();
+      if (kg < D / 4) {
+        const float *w = p.wt + (size_t)(4 * kg) * D + j;
+        wreg[ps] = make_float4(w[0], w[D], w[2 * D], w[3 * D]);
+      }
+    }
+  }
+
+  float4 acc[G::R];
+  aggregate_rows<G::LPR, G::R, G::U>(reinterpret_cast<const float4 *>(p.x), p.ent, p.self_loops, sc, q, acc);
+  NGPDE_STAMP(1);
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      if (sc[r].x < 0) acc[r] = f4_zero();
+      *reinterpret_cast<float4 *>(&ldsT[(grp * G::R + r) * G::TS + 4 * q]) = acc[r];
+      if (p.save_agg && sc[r].x >= 0) reinterpret_cast<float4 *>(p.save_agg)[(size_t)sc[r].x * G::LPR + q] = acc[r];
+    }
+  }
+  {
+    const int j = tid % D, kg0 = tid / D;
+#pragma unroll
+    for (int ps = 0; ps < G::NPASS; ++ps) {
+      const int kg = kg0 + ps * G::KGP;
+      if (kg < D / 4) *reinterpret_cast<float4 *>(&ldsBt[j * G::TS + 4 * kg]) = wreg[ps];
+    }
+  }
+  __syncthreads();
+  NGPDE_STAMP(2);
+  mfma_rows_times_bt<D>(ldsT, ldsBt, ldsZ, wave_u, lane);
+  __syncthreads();
+  NGPDE_STAMP(3);
+  if (active) {
+    const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      if (sc[r].x < 0) continue;
+      const size_t idx4 = (size_t)sc[r].x * G::LPR + q;
+      const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[(grp * G::R + r) * G::TS + 4 * q]), b4);
+      if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
+      const float4 yv = f4_act(act, z);
+      reinterpret_cast<float4 *>(p.y)[idx4] = yv;
+      if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_eval(p.comb, yv, idx4);
+    }
+  }
+  NGPDE_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused backward of one layer evaluation
+// ---------------------------------------------------------------------------------------------------
+struct BwdK {
+  const float *g_in;
+  const int4 *sched;
+  const int2 *ent;
+  int self_loops, n_tiles, act;
+  int has_comb;
+  CombDev comb;
+  float *store_t, *store_v;
+  float v_scale;
+  int do_dense;
+  const float *z, *saved_agg, *wt;
+  float *g_out, *slab_dw, *slab_db;
+};
+
+// Slab layout (per workgroup): dW as [tile tt = mt * CT + nt][lane][4] (each lane's four MFMA result
+// registers contiguous -> one 16-byte read-modify-write per tile), db as [D].
+template <int D, bool AGG, int ACT>
+__global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 3 + D * G::TS];
+  float *ldsDZ = lds, *ldsX = lds + kTM * G::TS, *ldsG = lds + 2 * kTM * G::TS, *ldsBt = lds + 3 * kTM * G::TS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = tid / G::LPR, q = tid % G::LPR;
+  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  const int act = ACT >= 0 ? ACT : p.act;
+
+  int4 sc[G::R];
+  const bool active = grp * G::R < kTM;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r)
+    sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+
+  // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
+  float4 wreg[G::W4];
+  if (p.do_dense) {
+#pragma unroll
+    for (int k = 0; k < G::W4; ++k) {
+      const int idx = tid + k * kThreads;
+      wreg[k] = (idx < D * D / 4) ? reinterpret_cast<const float4 *>(p.wt)[idx] : f4_zero();
+    }
+  }
+
+  float4 t[G::R];
+  if (AGG) {
+    aggregate_rows<G::LPR, G::R, G::U>(reinterpret_cast<const float4 *>(p.g_in), p.ent, p.self_loops, sc, q, t);
+  } else {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r)
+      t[r] = reinterpret_cast<const float4 *>(p.g_in)[(size_t)max(sc[r].x, 0) * G::LPR + q];
+  }
+  if (active) {
+    // node-local operands of the dense part are requested together, ahead of the combination
+    float4 zrow[G::R], xrow[G::R];
+    if (p.do_dense) {
+#pragma unroll
+      for (int r = 0; r < G::R; ++r) {
+        const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
+        zrow[r] = reinterpret_cast<const float4 *>(p.z)[idx4];
+        xrow[r] = reinterpret_cast<const float4 *>(p.saved_agg)[idx4];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      const bool ok = sc[r].x >= 0;
+      const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
+      float4 kbar = t[r];
+      if (ok) {
+        if (p.store_t) reinterpret_cast<float4 *>(p.store_t)[idx4] = t[r];
+        if (p.has_comb) {
+          const float4 v = comb_eval(p.comb, t[r], idx4);
+          if (p.store_v) reinterpret_cast<float4 *>(p.store_v)[idx4] = v;
+          kbar = f4_scale(p.v_scale, v);
+        }
+      }
+      if (p.do_dense) {
+        float4 dz = f4_zero(), xa = f4_zero();
+        if (ok) {
+          dz = f4_mul(kbar, f4_dact(act, zrow[r]));
+          xa = xrow[r];
+        }
+        *reinterpret_cast<float4 *>(&ldsDZ[(grp * G::R + r) * G::TS + 4 * q]) = dz;
+        *reinterpret_cast<float4 *>(&ldsX[(grp * G::R + r) * G::TS + 4 * q]) = xa;
+      }
+    }
+  }
+  if (!p.do_dense) return;  // uniform for the whole grid
+#pragma unroll
+  for (int k = 0; k < G::W4; ++k) {
+    const int idx = tid + k * kThreads;
+    if (idx < D * D / 4) {
+      const int wi = (idx * 4) / D, wo = (idx * 4) % D;
+      *reinterpret_cast<float4 *>(&ldsBt[wi * G::TS + wo]) = wreg[k];
+    }
+  }
+  __syncthreads();
+  // slab fragments of this wave's dW tiles: requested now, consumed after the MFMAs
+  const int i = lane & 15, kq = lane >> 4;
+  constexpr int NT = G::CT * G::CT;
+  float4 *slab4 = reinterpret_cast<float4 *>(p.slab_dw + (size_t)blockIdx.x * D * D);
+  float4 sl[G::DWT];
+#pragma unroll
+  for (int m = 0; m < G::DWT; ++m) {
+    const int tt = wave_u + G::WAVES * m;
+    sl[m] = (tt < NT) ? slab4[tt * 64 + lane] : f4_zero();
+  }
+  // G = dZ x Wt^T  (gradient w.r.t. the aggregated input)
+  mfma_rows_times_bt<D>(ldsDZ, ldsBt, ldsG, wave_u, lane);
+  // dWt[i][o] += sum_n X3[n][i] dZ[n][o]   (K = kTM rows of this tile)
+#pragma unroll
+  for (int m = 0; m < G::DWT; ++m) {
+    const int tt = wave_u + G::WAVES * m;
+    if (tt < NT) {   // wave-uniform
+      const int mt = tt / G::CT, nt = tt % G::CT;
+      float a[kTM / 4], b[kTM / 4];
+#pragma unroll
+      for (int ks = 0; ks < kTM / 4; ++ks) {
+        a[ks] = ldsX[(4 * ks + kq) * G::TS + mt * 16 + i];
+        b[ks] = ldsDZ[(4 * ks + kq) * G::TS + nt * 16 + i];
+      }
+      f32x4 acc = (f32x4){sl[m].x, sl[m].y, sl[m].z, sl[m].w};
+#pragma unroll
+      for (int ks = 0; ks < kTM / 4; ++ks) acc = mfma16(a[ks], b[ks], acc);
+      slab4[tt * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+  if (tid < D) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < kTM; ++n) s += ldsDZ[n * G::TS + tid];
+    p.slab_db[(size_t)blockIdx.x * D + tid] += s;
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      if (sc[r].x < 0) continue;
+      reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q] =
+          *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
+    }
+  }
+}
+
+// out (row-major dWt[i][o], or db[o] when ct == 0) = sum over slabs; 4 partial sums per element
+__global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len, int ct,
+                                    float *__restrict__ out) {
+  __shared__ float part[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part_id = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < len)
+    for (int b = part_id; b < n_slabs; b += 4) s += slab[(size_t)b * len + e];
+  part[part_id][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part_id == 0 && e < len) {
+    const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    int dst = e;
+    if (ct > 0) {  // e = (tt * 64 + lane) * 4 + reg  ->  dWt[(mt*16 + 4*kq + reg) * D + nt*16 + i]
+      const int reg = e & 3, ln = (e >> 2) & 63, tt = e >> 8;
+      const int mt = tt / ct, nt = tt % ct;
+      dst = (mt * 16 + 4 * (ln >> 4) + reg) * (ct * 16) + nt * 16 + (ln & 15);
+    }
+    out[dst] = v;
+  }
+}
+
+CombDev to_dev(const Comb &c) {
+  CombDev d;
+  d.n = c.n;
+  for (int k = 0; k < 8; ++k) {
+    d.ptr[k] = c.ptr[k];
+    d.coef[k] = c.coef[k];
+  }
+  d.coef_self = c.coef_self;
+  return d;
+}
+
+#define NGPDE_LAUNCH_CHECK(name)                                                         \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+// activations with a compiled-in fast path; everything else takes the runtime switch (ACT = -1)
+inline int act_template(int act) { return (act == NGPDE_ACT_RELU || act == NGPDE_ACT_IDENTITY) ? act : -1; }
+
+}  // namespace
+
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf) {
+  NGPDE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_buf, sizeof(dev_buf)));
+  return NGPDE_OK;
+}
+#endif
+
+bool fused_supported(int din, int dout) { return din == dout && (din == 16 || din == 32 || din == 64 || din == 128); }
+int fused_tile_rows() { return kTM; }
+int fused_num_blocks(int64_t n_nodes) { return (int)((n_nodes + kTM - 1) / kTM); }
+
+int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
+  NGPDE_REQUIRE(fused_supported(a.d, a.d), NGPDE_ERR_UNSUPPORTED, "fused GCN path needs d in {16,32,64,128}, got %d", a.d);
+  if (g->n_nodes == 0) return NGPDE_OK;
+  FwdK k;
+  k.x = a.x; k.sched = g->by_t.sched; k.ent = g->by_t.ent;
+  k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
+  k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
+  k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
+  const dim3 grid(k.n_tiles), block(kThreads);
+#define NGPDE_FWD_LAUNCH(DD, AA)                                                                                   \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA>), grid, block, 0, stream, k);
+#define NGPDE_FWD_CASE(DD)                                                            \
+  case DD:                                                                            \
+    switch (act_template(a.act)) {                                                    \
+      case NGPDE_ACT_RELU: NGPDE_FWD_LAUNCH(DD, NGPDE_ACT_RELU) break;                \
+      case NGPDE_ACT_IDENTITY: NGPDE_FWD_LAUNCH(DD, NGPDE_ACT_IDENTITY) break;        \
+      default: NGPDE_FWD_LAUNCH(DD, -1) break;                                        \
+    }                                                                                 \
+    break;
+  switch (a.d) {
+    NGPDE_FWD_CASE(16)
+    NGPDE_FWD_CASE(32)
+    NGPDE_FWD_CASE(64)
+    NGPDE_FWD_CASE(128)
+  }
+#undef NGPDE_FWD_CASE
+#undef NGPDE_FWD_LAUNCH
+  NGPDE_LAUNCH_CHECK("gcn_fused_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
+  NGPDE_REQUIRE(fused_supported(a.d, a.d), NGPDE_ERR_UNSUPPORTED, "fused GCN path needs d in {16,32,64,128}, got %d", a.d);
+  if (g->n_nodes == 0) return NGPDE_OK;
+  BwdK k;
+  k.g_in = a.g_in; k.sched = g->by_s.sched; k.ent = g->by_s.ent;
+  k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
+  k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb);
+  k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;
+  k.do_dense = a.do_dense ? 1 : 0; k.z = a.z; k.saved_agg = a.saved_agg; k.wt = a.wt;
+  k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
+  const dim3 grid(k.n_tiles), block(kThreads);
+#define NGPDE_BWD_LAUNCH(DD, AG, AA)                                                                              \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA>), grid, block, 0, stream, k);
+#define NGPDE_BWD_ACT(DD, AG)                                                         \
+  switch (act_template(a.act)) {                                                      \
+    case NGPDE_ACT_RELU: NGPDE_BWD_LAUNCH(DD, AG, NGPDE_ACT_RELU) break;              \
+    case NGPDE_ACT_IDENTITY: NGPDE_BWD_LAUNCH(DD, AG, NGPDE_ACT_IDENTITY) break;      \
+    default: NGPDE_BWD_LAUNCH(DD, AG, -1) break;                                      \
+  }
+#define NGPDE_BWD_CASE(DD)                                                            \
+  case DD:                                                                            \
+    if (a.aggregate) { NGPDE_BWD_ACT(DD, true) } else { NGPDE_BWD_ACT(DD, false) }    \
+    break;
+  switch (a.d) {
+    NGPDE_BWD_CASE(16)
+    NGPDE_BWD_CASE(32)
+    NGPDE_BWD_CASE(64)
+    NGPDE_BWD_CASE(128)
+  }
+#undef NGPDE_BWD_CASE
+#undef NGPDE_BWD_ACT
+#undef NGPDE_BWD_LAUNCH
+  NGPDE_LAUNCH_CHECK("gcn_fused_bwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream) {
+  if (len == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + 63) / 64), dim3(256), 0, stream, slab, n_slabs, len, ct, out);
+  NGPDE_LAUNCH_CHECK("reduce_slabs_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde

@@ -3,6 +3,7 @@
 // degree and the COO walk per call: /root/reference/src/layers.jl:211,224,228-232).
 #include <algorithm>
 #include <cmath>
+#include <deque>
 #include <cstring>
 #include <new>
 
@@ -43,6 +44,50 @@ void build_csr(int64_t n, int64_t m, const std::vector<int32_t> &key, const std:
   }
 }
 
+// BFS-grown clusters of `tile` nodes, emitted in a breadth-first sweep (see ngpde_graph::h_order)
+std::vector<int32_t> locality_order(int64_t n, const Csr &in, const Csr &out, int tile) {
+  std::vector<int32_t> order;
+  order.reserve((size_t)n);
+  std::vector<char> taken((size_t)n, 0);
+  std::deque<int32_t> frontier;
+  int64_t next_free = 0;
+  std::vector<int32_t> local;
+  auto neighbours = [&](int32_t v, auto &&f) {
+    for (int32_t p = in.h_rowptr[v]; p < in.h_rowptr[v + 1]; ++p) f(in.h_col[p]);
+    for (int32_t p = out.h_rowptr[v]; p < out.h_rowptr[v + 1]; ++p) f(out.h_col[p]);
+  };
+  while ((int64_t)order.size() < n) {
+    local.clear();
+    size_t head = 0;
+    while ((int)local.size() < tile && (int64_t)(order.size() + local.size()) < n) {
+      if (head == local.size()) {  // need a (new) seed: oldest frontier node, else the next untouched index
+        int32_t seed = -1;
+        while (!frontier.empty()) {
+          int32_t v = frontier.front();
+          frontier.pop_front();
+          if (!taken[v]) { seed = v; break; }
+        }
+        if (seed < 0) {
+          while (taken[next_free]) ++next_free;
+          seed = (int32_t)next_free;
+        }
+        taken[seed] = 1;
+        local.push_back(seed);
+      }
+      const int32_t v = local[head++];
+      neighbours(v, [&](int32_t w) {
+        if (taken[w]) return;
+        if ((int)local.size() < tile) { taken[w] = 1; local.push_back(w); }
+        else frontier.push_back(w);
+      });
+    }
+    for (size_t k = head; k < local.size(); ++k)
+      neighbours(local[k], [&](int32_t w) { if (!taken[w]) frontier.push_back(w); });
+    order.insert(order.end(), local.begin(), local.end());
+  }
+  return order;
+}
+
 template <class T>
 int32_t upload(T **dst, const T *src, size_t count) {
   *dst = nullptr;
@@ -65,6 +110,7 @@ void free_csr(Csr &c) {
   if (c.col) (void)hipFree(c.col);
   if (c.eid) (void)hipFree(c.eid);
   if (c.ent) (void)hipFree(c.ent);
+  if (c.sched) (void)hipFree(c.sched);
   c = Csr();
 }
 
@@ -112,6 +158,8 @@ int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, c
     g->max_in_degree = std::max(g->max_in_degree, g->by_t.h_rowptr[i + 1] - g->by_t.h_rowptr[i]);
     g->max_out_degree = std::max(g->max_out_degree, g->by_s.h_rowptr[i + 1] - g->by_s.h_rowptr[i]);
   }
+  g->h_order = locality_order(n_nodes, g->by_t, g->by_s, kTileRows);
+  g->n_sched = (int32_t)(((n_nodes + kTileRows - 1) / kTileRows) * kTileRows);
   int32_t st;
   if ((st = upload_csr(g->by_t, n_nodes, n_edges)) || (st = upload_csr(g->by_s, n_nodes, n_edges))) {
     ngpde_graph_destroy(g);
@@ -187,13 +235,32 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   std::vector<int2> et, es;
   fill(g->by_t, et);
   fill(g->by_s, es);
+  auto fill_sched = [&](const Csr &csr, std::vector<int4> &sc) {
+    sc.assign((size_t)g->n_sched, make_int4(-1, 0, 0, 0));
+    for (int64_t k = 0; k < n; ++k) {
+      const int32_t v = g->h_order[k];
+      int4 e;
+      e.x = v;
+      e.y = csr.h_rowptr[v];
+      e.z = csr.h_rowptr[v + 1] - csr.h_rowptr[v];
+      std::memcpy(&e.w, &c[v], 4);
+      sc[k] = e;
+    }
+  };
+  std::vector<int4> st_, ss_;
+  fill_sched(g->by_t, st_);
+  fill_sched(g->by_s, ss_);
   if (g->by_t.ent) { (void)hipFree(g->by_t.ent); g->by_t.ent = nullptr; }
   if (g->by_s.ent) { (void)hipFree(g->by_s.ent); g->by_s.ent = nullptr; }
+  if (g->by_t.sched) { (void)hipFree(g->by_t.sched); g->by_t.sched = nullptr; }
+  if (g->by_s.sched) { (void)hipFree(g->by_s.sched); g->by_s.sched = nullptr; }
   if (g->c) { (void)hipFree(g->c); g->c = nullptr; }
   g->has_norm = false;
   int32_t st;
   if ((st = upload(&g->by_t.ent, et.data(), (size_t)m))) return st;
   if ((st = upload(&g->by_s.ent, es.data(), (size_t)m))) return st;
+  if ((st = upload(&g->by_t.sched, st_.data(), st_.size()))) return st;
+  if ((st = upload(&g->by_s.sched, ss_.data(), ss_.size()))) return st;
   if ((st = upload(&g->c, c.data(), (size_t)n))) return st;
   g->self_loops = add_self_loops ? 1 : 0;
   g->has_norm = true;

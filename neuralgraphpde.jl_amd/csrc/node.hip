@@ -66,7 +66,7 @@ struct ngpde_node {
   int nb = 0;            // workgroups of the fused kernels (= slabs)
   int slots = 0;         // tape slots per stage evaluation
 
-  float *u = nullptr, *ustage = nullptr;
+  float *u = nullptr, *ustage = nullptr, *u0keep = nullptr;
   float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
   float *tape = nullptr;
   size_t tape_bytes = 0;
@@ -93,13 +93,32 @@ struct ngpde_node {
 
 namespace {
 
+// profiling pass: start/stop events on every stride-th launch, tagged by kernel role
+struct Prof {
+  int stride = 1, counter = 0;
+  std::vector<hipEvent_t> ev0, ev1;
+  std::vector<int> role;
+  bool want(int r, hipEvent_t *a, hipEvent_t *b) {
+    if ((counter++ % stride) != 0) return false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
+    ev0.push_back(e0); ev1.push_back(e1); role.push_back(r);
+    *a = e0; *b = e1;
+    return true;
+  }
+  ~Prof() {
+    for (hipEvent_t e : ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev1) (void)hipEventDestroy(e);
+  }
+};
+
 int32_t dev_alloc(float **p, size_t elems) {
   *p = nullptr;
   NGPDE_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(elems, 1) * sizeof(float)));
   return NGPDE_OK;
 }
 
-int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches) {
+int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *prof = nullptr) {
   const Tableau &tb = p->tb;
   int32_t st;
   int count = 0;
@@ -112,6 +131,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches) {
       f1.y = p->slot(n, i, 1);
       f1.save_agg = p->with_bwd ? p->slot(n, i, 0) : nullptr;
       f1.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 4) : nullptr;
+      if (prof) prof->want(0, &f1.ev_start, &f1.ev_stop);
       if ((st = launch_fused_fwd(f1, stream))) return st;
       FusedFwdArgs f2;
       f2.g = p->g; f2.d = p->d; f2.act = p->act;
@@ -134,6 +154,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches) {
         f2.comb.coef[f2.comb.n++] = (float)(p->dt * row[j]);
       }
       f2.comb.coef_self = (float)(p->dt * row[i]);
+      if (prof) prof->want(1, &f2.ev_start, &f2.ev_stop);
       if ((st = launch_fused_fwd(f2, stream))) return st;
       count += 2;
     }
@@ -155,7 +176,7 @@ void fill_dense(const ngpde_node *p, FusedBwdArgs &a, int layer, int step, int s
   }
 }
 
-int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches) {
+int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof *prof = nullptr) {
   const Tableau &tb = p->tb;
   const int S = tb.S;
   int32_t st;
@@ -176,6 +197,7 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches) {
       m.g = p->g; m.d = p->d; m.act = p->act;
       m.aggregate = true; m.g_in = p->g2;
       fill_dense(p, m, 1, n, i);
+      if (prof) prof->want(2, &m.ev_start, &m.ev_stop);
       if ((st = launch_fused_bwd(m, stream))) return st;
       FusedBwdArgs e;  // U-bar_i = A^T g1, then the next stage's K-bar and layer-2 dense backward
       e.g = p->g; e.d = p->d; e.act = p->act;
@@ -209,15 +231,16 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches) {
           e.do_dense = false;
         }
       }
+      if (prof && e.do_dense) prof->want(3, &e.ev_start, &e.ev_stop);
       if ((st = launch_fused_bwd(e, stream))) return st;
       count += 2;
     }
   }
   const int dd = p->d * p->d;
-  if ((st = launch_reduce_slabs(p->slab_dw1, p->nb, dd, p->dw1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db1, p->nb, p->d, p->db1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_dw2, p->nb, dd, p->dw2, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db2, p->nb, p->d, p->db2, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_dw1, p->nb, dd, p->d / 16, p->dw1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db1, p->nb, p->d, 0, p->db1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_dw2, p->nb, dd, p->d / 16, p->dw2, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db2, p->nb, p->d, 0, p->db2, stream))) return st;
   count += 4;
   if (launches) *launches = count;
   return NGPDE_OK;
@@ -255,7 +278,7 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
   if (p->fwd_graph) (void)hipGraphDestroy(p->fwd_graph);
   if (p->bwd_graph) (void)hipGraphDestroy(p->bwd_graph);
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
-  float *bufs[] = {p->u, p->ustage, p->w1, p->b1, p->w2, p->b2, p->tape, p->lam, p->g1, p->g2, p->slabs,
+  float *bufs[] = {p->u0keep, p->u, p->ustage, p->w1, p->b1, p->w2, p->b2, p->tape, p->lam, p->g1, p->g2, p->slabs,
                    p->dw1, p->db1, p->dw2, p->db2};
   for (float *b : bufs)
     if (b) (void)hipFree(b);
@@ -298,6 +321,7 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   };
   A(&p->u, p->row_elems);
   A(&p->ustage, p->row_elems);
+  A(&p->u0keep, p->row_elems);
   A(&p->w1, (size_t)d * d); A(&p->b1, d); A(&p->w2, (size_t)d * d); A(&p->b2, d);
   const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->row_elems;
   p->tape_bytes = tape_elems * sizeof(float);
@@ -353,6 +377,7 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
   if (b1) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b1, b1, db, hipMemcpyDeviceToDevice, stream));
@@ -390,6 +415,40 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   if (db1) NGPDE_HIP_CHECK(hipMemcpyAsync(db1, p->db1, db, hipMemcpyDeviceToDevice, stream));
   if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));
   if (db2) NGPDE_HIP_CHECK(hipMemcpyAsync(db2, p->db2, db, hipMemcpyDeviceToDevice, stream));
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32_t *out_count,
+                           ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(p != nullptr && out_us != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_profile: NULL argument");
+  NGPDE_REQUIRE(p->forward_done, NGPDE_ERR_STATE, "ngpde_node_profile: run a forward solve first");
+  NGPDE_REQUIRE(stride >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_profile: stride must be >= 1");
+  hipStream_t stream = (hipStream_t)stream_;
+  Prof prof;
+  prof.stride = stride;
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  int32_t st = enqueue_forward(p, stream, nullptr, &prof);
+  if (st) return st;
+  if (p->with_bwd) {
+    // adjoint seed of loss = sum(u(T)): ones
+    std::vector<float> ones(p->row_elems, 1.0f);
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, ones.data(), p->row_elems * sizeof(float), hipMemcpyHostToDevice, stream));
+    NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
+    if ((st = enqueue_backward(p, stream, nullptr, &prof))) return st;
+  }
+  NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
+  double sum[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
+  for (size_t k = 0; k < prof.role.size(); ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, prof.ev0[k], prof.ev1[k]) != hipSuccess) continue;
+    sum[prof.role[k]] += ms * 1000.0;
+    cnt[prof.role[k]]++;
+  }
+  for (int r = 0; r < 4; ++r) {
+    out_us[r] = cnt[r] ? (float)(sum[r] / cnt[r]) : 0.f;
+    if (out_count) out_count[r] = cnt[r];
+  }
   return NGPDE_OK;
 }
 
