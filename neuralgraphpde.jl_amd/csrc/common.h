@@ -39,10 +39,13 @@ struct Csr {
   int32_t *eid = nullptr;     // [n_edges] position of the entry in the COO list
   int2 *ent = nullptr;        // [n_edges] {col, bits of GCN coefficient w_e * c[col]}; set by set_gcn_norm
   int4 *sched = nullptr;      // [n_sched] tile schedule entries {node, row start, degree, bits of c[node]}; node < 0 = padding
+  int2 *ell = nullptr;        // [n_sched][kEllWidth] the first kEllWidth {col, coef} entries of each schedule row
+                              // (zero padded), addressed by schedule POSITION: loadable without first reading `sched`
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
 
 constexpr int kTileRows = 32;  // node rows per workgroup of the fused kernels
+constexpr int kEllWidth = 16;  // entries per row held in the fixed-width block (rows with more spill to the CSR list)
 
 }  // namespace ngpde
 

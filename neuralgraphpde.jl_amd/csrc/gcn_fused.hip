@@ -7,9 +7,14 @@
 // No atomics anywhere: every output row / slab has exactly one writer, so results are bitwise
 // reproducible run to run (the reference's GPU path scatters with fp32 atomics).
 //
-// Work decomposition: a workgroup (4 waves) owns one run of kTileRows = 32 schedule entries (a
+// Work decomposition: a workgroup (8 waves) owns one run of kTileRows = 32 schedule entries (a
 // graph-compact node cluster, see ngpde_graph::h_order); blockIdx -> run is XCD-aware so each of the 8
-// XCDs works on a contiguous range of runs.  N = 16384 gives 512 workgroups = 2 per CU.
+// XCDs works on a contiguous range of runs.  N = 16384 gives 512 workgroups = 2 per CU, 4 waves per SIMD.
+// The kernels are dependency-latency bound (measured ~1.5k cycles per dependent global round under
+// load), so the gather is shaped as TWO rounds: {schedule entry, fixed-width edge entries, own row,
+// weights, slab fragments} in the first -- all addressed by schedule position or node-local, none
+// depending on another load -- and every neighbour row of a row (up to 16 x 16-byte loads per lane) in
+// the second.
 #include <hip/hip_ext.h>
 
 #include "common.h"
@@ -19,7 +24,7 @@ namespace ngpde {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kTM = kTileRows;
 constexpr int kXcds = 8;
 
@@ -28,10 +33,11 @@ struct Geo {
   static constexpr int LPR = D / 4;                          // lanes per feature row (float4 each)
   static constexpr int GROUPS = kThreads / LPR;              // row groups per workgroup
   static constexpr int R = (kTM + GROUPS - 1) / GROUPS;      // rows per group
-  static constexpr int U = (R >= 4) ? 2 : 4;                 // edge unroll (rows in flight per lane = R*U)
-  static constexpr int TS = D + 4;                           // LDS row stride (floats): 16-B aligned, b128 reads of 16 rows hit 64 banks once
-  static constexpr int W4 = (D * D / 4 + kThreads - 1) / kThreads;  // float4 of W per thread
-  static constexpr int KGP = kThreads / D;                   // k-groups (4 consecutive k) staged per pass by the transposing loader
+  static constexpr int U = (16 / R < LPR) ? 16 / R : LPR;    // neighbour rows in flight per row
+  static constexpr bool ELL = (LPR <= kEllWidth);            // first entry chunk from the position-indexed block
+  static constexpr int TS = D + 4;                           // LDS row stride (floats): 16-B aligned rows, b128 reads of 16 rows cover 64 banks
+  static constexpr int W4 = (D * D / 4 + kThreads - 1) / kThreads;  // float4 of W per thread (straight copy)
+  static constexpr int KGP = kThreads / D;                   // k-groups (4 consecutive k) per pass of the transposing loader
   static constexpr int NPASS = (D / 4 + KGP - 1) / KGP;
   static constexpr int RT = kTM / 16;                        // 16-row MFMA tiles per workgroup
   static constexpr int CT = D / 16;                          // 16-col MFMA tiles
@@ -39,20 +45,29 @@ struct Geo {
   static constexpr int CGRP = WAVES / RT;                    // waves sharing one row tile
   static constexpr int CPW = (CT + CGRP - 1) / CGRP;         // column tiles per wave
   static constexpr int DWT = (CT * CT + WAVES - 1) / WAVES;  // dW tiles per wave
+  static constexpr int DBP = kThreads / D;                   // row-partials per column in the db reduction
 };
 
 #ifdef NGPDE_STAMPS
-// diagnostic build only (tools/): per-workgroup phase timestamps; never compiled into the product library
-__device__ unsigned long long *g_stamps = nullptr;
+// diagnostic build only (tools/): per-workgroup phase timestamps, one slot of [n_blocks][16] words per
+// launch; never compiled into the product library
+unsigned long long *g_stamps_base = nullptr;
+int g_stamps_max = 0, g_stamps_next = 0;
+#define NGPDE_STAMP_FIELD unsigned long long *stamps;
 #define NGPDE_STAMP(k)                                                              \
   do {                                                                              \
-    if (threadIdx.x == 0 && g_stamps) {                                             \
-      g_stamps[(size_t)blockIdx.x * 16 + 2 * (k)] = clock64();                      \
-      g_stamps[(size_t)blockIdx.x * 16 + 2 * (k) + 1] = wall_clock64();             \
+    if (threadIdx.x == 0 && p.stamps) {                                             \
+      p.stamps[(size_t)blockIdx.x * 16 + 2 * (k)] = clock64();                      \
+      p.stamps[(size_t)blockIdx.x * 16 + 2 * (k) + 1] = wall_clock64();             \
     }                                                                               \
   } while (0)
+#define NGPDE_STAMP_SET(kk, nb)                                                     \
+  kk.stamps = nullptr;                                                              \
+  if (g_stamps_base && g_stamps_next < g_stamps_max) kk.stamps = g_stamps_base + (size_t)(g_stamps_next++) * (nb) * 16;
 #else
+#define NGPDE_STAMP_FIELD
 #define NGPDE_STAMP(k)
+#define NGPDE_STAMP_SET(kk, nb)
 #endif
 
 // blockIdx -> tile, bijective for any grid size: blocks b, b+8, b+16, ... (dispatched to one XCD in
@@ -70,60 +85,61 @@ struct CombDev {
   float coef_self;
 };
 
-template <int K>
-__device__ __forceinline__ float4 comb_eval_n(const CombDev &c, float4 self, size_t idx4) {
-  float4 t[K > 0 ? K : 1];
+// v = coef_self * self + sum_k coef[k] * ptr[k][row], split so the (node-local) term loads can be
+// requested long before they are combined
+__device__ __forceinline__ void comb_prefetch(const CombDev &c, size_t idx4, float4 (&t)[8]) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) t[k] = reinterpret_cast<const float4 *>(c.ptr[k])[idx4];
+  for (int k = 0; k < 8; ++k)
+    if (k < c.n) t[k] = reinterpret_cast<const float4 *>(c.ptr[k])[idx4];
+}
+__device__ __forceinline__ float4 comb_finish(const CombDev &c, float4 self, const float4 (&t)[8]) {
   float4 v = f4_scale(c.coef_self, self);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v = f4_fma(c.coef[k], t[k], v);
+  for (int k = 0; k < 8; ++k)
+    if (k < c.n) v = f4_fma(c.coef[k], t[k], v);
   return v;
-}
-
-// v = coef_self * self + sum_k coef[k] * ptr[k][row]; all term loads are issued before the first use
-__device__ __forceinline__ float4 comb_eval(const CombDev &c, float4 self, size_t idx4) {
-  switch (c.n) {
-    case 0: return comb_eval_n<0>(c, self, idx4);
-    case 1: return comb_eval_n<1>(c, self, idx4);
-    case 2: return comb_eval_n<2>(c, self, idx4);
-    case 3: return comb_eval_n<3>(c, self, idx4);
-    case 4: return comb_eval_n<4>(c, self, idx4);
-    case 5: return comb_eval_n<5>(c, self, idx4);
-    case 6: return comb_eval_n<6>(c, self, idx4);
-    case 7: return comb_eval_n<7>(c, self, idx4);
-    default: return comb_eval_n<8>(c, self, idx4);
-  }
 }
 
 // ---- CSR segmented aggregation of whole feature rows ------------------------------------------------
 // A "group" of LPR = D/4 adjacent lanes owns R rows; lane q holds features 4q..4q+3 of each row as one
-// float4 (a D=64 row = 256 B = 16 lanes x dwordx4: fully coalesced row gathers).  Per row the group
-// loads up to LPR {col, coef} entries with ONE coalesced 8-byte load per lane, broadcasts them with
-// in-register lane shuffles and issues R*U independent 16-byte row loads per round, so a wave keeps
-// 4*R*U neighbour rows in flight.  Branch-free: out-of-range slots load row 0 and are zeroed by selects.
+// float4 (a D=64 row = 256 B = 16 lanes x dwordx4: fully coalesced row gathers).  Lane q of the group
+// holds entry (base + q) of the row -- {col, coef}, one coalesced 8-byte load -- and the entries are
+// broadcast with in-register lane shuffles while R*U independent 16-byte row loads are issued at once.
+// Branch-free: slots past the row's degree load row 0 and are zeroed by selects.
 //   acc[r] = c * ( sum_e coef_e * X[col_e] + (self ? c * X[node] : 0) ),  c = bits in sched.w
+template <int LPR, int R>
+__device__ __forceinline__ void load_entries(const int2 *__restrict__ ent, const int4 (&sc)[R], int base, int q,
+                                             int (&ecol)[R], int (&ecf)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool ok = base + q < sc[r].z;
+    const int2 v = ent[ok ? sc[r].y + base + q : 0];
+    ecol[r] = ok ? v.x : 0;
+    ecf[r] = ok ? v.y : 0;
+  }
+}
+
+// Row fetch with a scalar base and a 32-bit byte offset (saddr + voffset addressing: one VGPR per
+// in-flight load instead of a 64-bit pointer pair).  Callers guarantee n_nodes * D * 4 < 2^32.
+template <int LPR>
+__device__ __forceinline__ float4 load_row4(const float4 *__restrict__ X4, int row, int q) {
+  const unsigned off = (unsigned)row * (unsigned)(LPR * 16) + (unsigned)(q * 16);
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X4) + off);
+}
+
 template <int LPR, int R, int U>
 __device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, const int2 *__restrict__ ent,
-                                               int self_loops, const int4 (&sc)[R], int q, float4 (&acc)[R]) {
+                                               int self_loops, const int4 (&sc)[R], int q, int (&ecol)[R],
+                                               int (&ecf)[R], const float4 (&selfv)[R], float4 (&acc)[R]) {
   static_assert(LPR % U == 0, "unroll must divide the lanes per row");
   int maxdeg = 0;
-  float4 selfv[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     maxdeg = max(maxdeg, sc[r].z);
     acc[r] = f4_zero();
-    selfv[r] = X4[(size_t)max(sc[r].x, 0) * LPR + q];   // requested up front; consumed last
   }
   for (int base = 0; base < maxdeg; base += LPR) {
-    int ecol[R], ecf[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool ok = base + q < sc[r].z;
-      const int2 v = ent[ok ? sc[r].y + base + q : 0];
-      ecol[r] = ok ? v.x : 0;
-      ecf[r] = ok ? v.y : 0;
-    }
+    if (base > 0) load_entries<LPR, R>(ent, sc, base, q, ecol, ecf);   // chunk 0 arrives preloaded
     const int nin = min(LPR, maxdeg - base);
     for (int e = 0; e < nin; e += U) {
       float4 v[R][U];
@@ -134,7 +150,7 @@ __device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, co
         for (int u = 0; u < U; ++u) {
           const int col = __shfl(ecol[r], e + u, LPR);         // 0 for slots past the row's degree
           cf[r][u] = __int_as_float(__shfl(ecf[r], e + u, LPR));
-          v[r][u] = X4[(size_t)col * LPR + q];
+          v[r][u] = load_row4<LPR>(X4, col, q);
         }
       }
 #pragma unroll
@@ -157,6 +173,29 @@ __device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, co
   }
 }
 
+// First round of a tile's gather for one thread: schedule entries, first entry chunk, own rows.
+template <int D>
+__device__ __forceinline__ void tile_prologue(const int4 *__restrict__ sched, const int2 *__restrict__ ell,
+                                              const int2 *__restrict__ ent, const float4 *__restrict__ X4, int tile,
+                                              int grp, int q, bool active, int4 (&sc)[Geo<D>::R],
+                                              int (&ecol)[Geo<D>::R], int (&ecf)[Geo<D>::R],
+                                              float4 (&selfv)[Geo<D>::R]) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const size_t pos = (size_t)tile * kTM + grp * G::R + r;
+    sc[r] = active ? sched[pos] : make_int4(-1, 0, 0, 0);
+    if (G::ELL) {   // position-indexed: does not wait for sc
+      const int2 v = active ? ell[pos * kEllWidth + q] : make_int2(0, 0);
+      ecol[r] = v.x;
+      ecf[r] = v.y;
+    }
+  }
+  if (!G::ELL) load_entries<G::LPR, G::R>(ent, sc, 0, q, ecol, ecf);
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) selfv[r] = load_row4<G::LPR>(X4, max(sc[r].x, 0), q);
+}
+
 // ---- fp32 MFMA tile products from LDS ------------------------------------------------------------------
 // Out[kTM][D] = A[kTM][D] x B, with A row-major (stride TS) and B stored TRANSPOSED, Bt[col][k] (stride
 // TS), so lane (i = l&15, kq = l>>4) feeds four consecutive k-steps of v_mfma_f32_16x16x4_f32 from ONE
@@ -168,7 +207,7 @@ __device__ __forceinline__ void mfma_rows_times_bt(const float *ldsA, const floa
   using G = Geo<D>;
   const int rt = wave_u % G::RT;
   const int cg = wave_u / G::RT;
-  if (cg >= G::CT) return;   // D = 16: only one column tile; wave-uniform
+  if (cg >= G::CT) return;   // fewer column tiles than wave groups (D <= 32); wave-uniform
   const int i = lane & 15, kq = lane >> 4;
   const float *pa = ldsA + (rt * 16 + i) * G::TS + 4 * kq;
   const float *pb[G::CPW];
@@ -219,17 +258,18 @@ __device__ __forceinline__ void mfma_rows_times_bt(const float *ldsA, const floa
 struct FwdK {
   const float *x;
   const int4 *sched;
-  const int2 *ent;
+  const int2 *ent, *ell;
   int self_loops, n_tiles, act;
   const float *wt, *bias;
   float *y, *save_agg, *save_z;
   int has_comb;
   CombDev comb;
   float *comb_out;
+  NGPDE_STAMP_FIELD
 };
 
 template <int D, int ACT>
-__global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
+__global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_kernel(const FwdK p) {
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 2 + D * G::TS];
   float *ldsT = lds, *ldsZ = lds + kTM * G::TS, *ldsBt = lds + 2 * kTM * G::TS;
@@ -238,17 +278,17 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
   const int grp = tid / G::LPR, q = tid % G::LPR;
   const int tile = xcd_tile(blockIdx.x, p.n_tiles);
   const int act = ACT >= 0 ? ACT : p.act;
+  const bool active = grp * G::R < kTM;
+  const float4 *X4 = reinterpret_cast<const float4 *>(p.x);
   NGPDE_STAMP(0);
 
-  // schedule entries of this thread's rows (node, row start, degree, c) -- one 16-byte load each
+  // round 1: everything that does not depend on another load
   int4 sc[G::R];
-  const bool active = grp * G::R < kTM;
-#pragma unroll
-  for (int r = 0; r < G::R; ++r)
-    sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
-
-  // W is requested before the gather so it lands meanwhile.  B[k = in][j = out] = wt[in][out]; stored
-  // transposed in LDS: 4 dword loads down a column (coalesced across lanes) -> one ds_write_b128.
+  int ecol[G::R], ecf[G::R];
+  float4 selfv[G::R];
+  tile_prologue<D>(p.sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
+  // W: B[k = in][j = out] = wt[in][out], stored transposed in LDS: 4 dword loads down a column
+  // (coalesced across lanes) -> one ds_write_b128
   float4 wreg[G::NPASS];
   {
     const int j = tid % D, kg0 = tid / D;
@@ -262,10 +302,18 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
       }
     }
   }
+  const float4 b4 = (active && p.bias) ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
 
+  // round 2: all neighbour rows
   float4 acc[G::R];
-  aggregate_rows<G::LPR, G::R, G::U>(reinterpret_cast<const float4 *>(p.x), p.ent, p.self_loops, sc, q, acc);
+  aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
   NGPDE_STAMP(1);
+  // node-local epilogue operands: requested now so they land under the MFMA phase
+  float4 cterm[G::R][8];
+  if (active && p.has_comb) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
+  }
   if (active) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
@@ -288,7 +336,6 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
   __syncthreads();
   NGPDE_STAMP(3);
   if (active) {
-    const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       if (sc[r].x < 0) continue;
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
       if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
       const float4 yv = f4_act(act, z);
       reinterpret_cast<float4 *>(p.y)[idx4] = yv;
-      if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_eval(p.comb, yv, idx4);
+      if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_finish(p.comb, yv, cterm[r]);
     }
   }
   NGPDE_STAMP(4);
@@ -309,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_fwd_kernel(const FwdK p) {
 struct BwdK {
   const float *g_in;
   const int4 *sched;
-  const int2 *ent;
+  const int2 *ent, *ell;
   int self_loops, n_tiles, act;
   int has_comb;
   CombDev comb;
@@ -318,12 +365,13 @@ struct BwdK {
   int do_dense;
   const float *z, *saved_agg, *wt;
   float *g_out, *slab_dw, *slab_db;
+  NGPDE_STAMP_FIELD
 };
 
 // Slab layout (per workgroup): dW as [tile tt = mt * CT + nt][lane][4] (each lane's four MFMA result
 // registers contiguous -> one 16-byte read-modify-write per tile), db as [D].
 template <int D, bool AGG, int ACT>
-__global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
+__global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(const BwdK p) {
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 3 + D * G::TS];
   float *ldsDZ = lds, *ldsX = lds + kTM * G::TS, *ldsG = lds + 2 * kTM * G::TS, *ldsBt = lds + 3 * kTM * G::TS;
@@ -332,42 +380,67 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
   const int grp = tid / G::LPR, q = tid % G::LPR;
   const int tile = xcd_tile(blockIdx.x, p.n_tiles);
   const int act = ACT >= 0 ? ACT : p.act;
-
-  int4 sc[G::R];
   const bool active = grp * G::R < kTM;
-#pragma unroll
-  for (int r = 0; r < G::R; ++r)
-    sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+  const float4 *G4 = reinterpret_cast<const float4 *>(p.g_in);
+  NGPDE_STAMP(0);
 
+  // round 1
+  int4 sc[G::R];
+  int ecol[G::R], ecf[G::R];
+  float4 selfv[G::R];
+  if (AGG) {
+    tile_prologue<D>(p.sched, p.ell, p.ent, G4, tile, grp, q, active, sc, ecol, ecf, selfv);
+  } else {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r)
+      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+  }
   // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
   float4 wreg[G::W4];
+  // slab fragments of this wave's dW tiles and this thread's db column: consumed after the MFMAs
+  constexpr int NT = G::CT * G::CT;
+  float4 *slab4 = reinterpret_cast<float4 *>(p.slab_dw + (size_t)blockIdx.x * D * D);
+  float4 sl[G::DWT];
+  const int dbc = tid / G::DBP, dbpart = tid % G::DBP;
+  float dbv = 0.f;
   if (p.do_dense) {
 #pragma unroll
     for (int k = 0; k < G::W4; ++k) {
       const int idx = tid + k * kThreads;
       wreg[k] = (idx < D * D / 4) ? reinterpret_cast<const float4 *>(p.wt)[idx] : f4_zero();
     }
+#pragma unroll
+    for (int m = 0; m < G::DWT; ++m) {
+      const int tt = wave_u + G::WAVES * m;
+      sl[m] = (tt < NT) ? slab4[tt * 64 + lane] : f4_zero();
+    }
+    if (dbpart == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
+  }
+  // saved activations of this thread's rows (node-local, HBM-resident tape): also round 1
+  float4 zrow[G::R], xrow[G::R];
+  if (active && p.do_dense) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
+      zrow[r] = reinterpret_cast<const float4 *>(p.z)[idx4];
+      xrow[r] = reinterpret_cast<const float4 *>(p.saved_agg)[idx4];
+    }
   }
 
   float4 t[G::R];
   if (AGG) {
-    aggregate_rows<G::LPR, G::R, G::U>(reinterpret_cast<const float4 *>(p.g_in), p.ent, p.self_loops, sc, q, t);
+    aggregate_rows<G::LPR, G::R, G::U>(G4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, t);
   } else {
 #pragma unroll
-    for (int r = 0; r < G::R; ++r)
-      t[r] = reinterpret_cast<const float4 *>(p.g_in)[(size_t)max(sc[r].x, 0) * G::LPR + q];
+    for (int r = 0; r < G::R; ++r) t[r] = G4[(size_t)max(sc[r].x, 0) * G::LPR + q];
   }
+  NGPDE_STAMP(1);
   if (active) {
-    // node-local operands of the dense part are requested together, ahead of the combination
-    float4 zrow[G::R], xrow[G::R];
-    if (p.do_dense) {
+    // adjoint stage terms: one batch of independent node-local loads
+    float4 cterm[G::R][8];
 #pragma unroll
-      for (int r = 0; r < G::R; ++r) {
-        const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
-        zrow[r] = reinterpret_cast<const float4 *>(p.z)[idx4];
-        xrow[r] = reinterpret_cast<const float4 *>(p.saved_agg)[idx4];
-      }
-    }
+    for (int r = 0; r < G::R; ++r)
+      if (p.has_comb) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       const bool ok = sc[r].x >= 0;
@@ -376,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
       if (ok) {
         if (p.store_t) reinterpret_cast<float4 *>(p.store_t)[idx4] = t[r];
         if (p.has_comb) {
-          const float4 v = comb_eval(p.comb, t[r], idx4);
+          const float4 v = comb_finish(p.comb, t[r], cterm[r]);
           if (p.store_v) reinterpret_cast<float4 *>(p.store_v)[idx4] = v;
           kbar = f4_scale(p.v_scale, v);
         }
@@ -402,19 +475,12 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
     }
   }
   __syncthreads();
-  // slab fragments of this wave's dW tiles: requested now, consumed after the MFMAs
-  const int i = lane & 15, kq = lane >> 4;
-  constexpr int NT = G::CT * G::CT;
-  float4 *slab4 = reinterpret_cast<float4 *>(p.slab_dw + (size_t)blockIdx.x * D * D);
-  float4 sl[G::DWT];
-#pragma unroll
-  for (int m = 0; m < G::DWT; ++m) {
-    const int tt = wave_u + G::WAVES * m;
-    sl[m] = (tt < NT) ? slab4[tt * 64 + lane] : f4_zero();
-  }
+  NGPDE_STAMP(2);
   // G = dZ x Wt^T  (gradient w.r.t. the aggregated input)
   mfma_rows_times_bt<D>(ldsDZ, ldsBt, ldsG, wave_u, lane);
+  NGPDE_STAMP(3);
   // dWt[i][o] += sum_n X3[n][i] dZ[n][o]   (K = kTM rows of this tile)
+  const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int m = 0; m < G::DWT; ++m) {
     const int tt = wave_u + G::WAVES * m;
@@ -432,13 +498,18 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
       slab4[tt * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
   }
-  if (tid < D) {
+  // db += column sums of the dZ tile: DBP adjacent lanes hold row-partials of one column
+  {
     float s = 0.f;
-#pragma unroll 8
-    for (int n = 0; n < kTM; ++n) s += ldsDZ[n * G::TS + tid];
-    p.slab_db[(size_t)blockIdx.x * D + tid] += s;
+#pragma unroll
+    for (int n = dbpart; n < kTM; n += G::DBP) s += ldsDZ[n * G::TS + dbc];
+#pragma unroll
+    for (int o = 1; o < G::DBP; o <<= 1) s += __shfl_xor(s, o);
+    if (dbpart == 0) p.slab_db[(size_t)blockIdx.x * D + dbc] = dbv + s;
   }
+  NGPDE_STAMP(4);
   __syncthreads();
+  NGPDE_STAMP(5);
   if (active) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
@@ -447,6 +518,7 @@ __global__ __launch_bounds__(kThreads) void gcn_fused_bwd_kernel(const BwdK p) {
           *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
     }
   }
+  NGPDE_STAMP(6);
 }
 
 // out (row-major dWt[i][o], or db[o] when ct == 0) = sum over slabs; 4 partial sums per element
@@ -495,8 +567,10 @@ inline int act_template(int act) { return (act == NGPDE_ACT_RELU || act == NGPDE
 }  // namespace
 
 #ifdef NGPDE_STAMPS
-extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf) {
-  NGPDE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_buf, sizeof(dev_buf)));
+extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf, int32_t max_launches) {
+  g_stamps_base = dev_buf;
+  g_stamps_max = max_launches;
+  g_stamps_next = 0;
   return NGPDE_OK;
 }
 #endif
@@ -510,11 +584,14 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
   NGPDE_REQUIRE(fused_supported(a.d, a.d), NGPDE_ERR_UNSUPPORTED, "fused GCN path needs d in {16,32,64,128}, got %d", a.d);
   if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE((uint64_t)g->n_nodes * a.d * 4 < (1ull << 32), NGPDE_ERR_UNSUPPORTED,
+                "fused GCN path addresses feature arrays with 32-bit byte offsets: n_nodes * d * 4 must be < 4 GiB");
   FwdK k;
-  k.x = a.x; k.sched = g->by_t.sched; k.ent = g->by_t.ent;
+  k.x = a.x; k.sched = g->by_t.sched; k.ent = g->by_t.ent; k.ell = g->by_t.ell;
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
+  NGPDE_STAMP_SET(k, k.n_tiles)
   const dim3 grid(k.n_tiles), block(kThreads);
 #define NGPDE_FWD_LAUNCH(DD, AA)                                                                                   \
   if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
@@ -544,13 +621,16 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
   NGPDE_REQUIRE(fused_supported(a.d, a.d), NGPDE_ERR_UNSUPPORTED, "fused GCN path needs d in {16,32,64,128}, got %d", a.d);
   if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE((uint64_t)g->n_nodes * a.d * 4 < (1ull << 32), NGPDE_ERR_UNSUPPORTED,
+                "fused GCN path addresses feature arrays with 32-bit byte offsets: n_nodes * d * 4 must be < 4 GiB");
   BwdK k;
-  k.g_in = a.g_in; k.sched = g->by_s.sched; k.ent = g->by_s.ent;
+  k.g_in = a.g_in; k.sched = g->by_s.sched; k.ent = g->by_s.ent; k.ell = g->by_s.ell;
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb);
   k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;
   k.do_dense = a.do_dense ? 1 : 0; k.z = a.z; k.saved_agg = a.saved_agg; k.wt = a.wt;
   k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
+  NGPDE_STAMP_SET(k, k.n_tiles)
   const dim3 grid(k.n_tiles), block(kThreads);
 #define NGPDE_BWD_LAUNCH(DD, AG, AA)                                                                              \
   if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \

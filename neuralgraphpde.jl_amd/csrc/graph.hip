@@ -111,6 +111,7 @@ void free_csr(Csr &c) {
   if (c.eid) (void)hipFree(c.eid);
   if (c.ent) (void)hipFree(c.ent);
   if (c.sched) (void)hipFree(c.sched);
+  if (c.ell) (void)hipFree(c.ell);
   c = Csr();
 }
 
@@ -250,6 +251,19 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   std::vector<int4> st_, ss_;
   fill_sched(g->by_t, st_);
   fill_sched(g->by_s, ss_);
+  auto fill_ell = [&](const Csr &csr, const std::vector<int2> &ent, std::vector<int2> &ell) {
+    ell.assign((size_t)g->n_sched * kEllWidth, make_int2(0, 0));
+    for (int64_t k = 0; k < n; ++k) {
+      const int32_t v = g->h_order[k];
+      const int32_t rs = csr.h_rowptr[v], deg = csr.h_rowptr[v + 1] - rs;
+      for (int j = 0; j < std::min(deg, kEllWidth); ++j) ell[(size_t)k * kEllWidth + j] = ent[rs + j];
+    }
+  };
+  std::vector<int2> lt_, ls_;
+  fill_ell(g->by_t, et, lt_);
+  fill_ell(g->by_s, es, ls_);
+  if (g->by_t.ell) { (void)hipFree(g->by_t.ell); g->by_t.ell = nullptr; }
+  if (g->by_s.ell) { (void)hipFree(g->by_s.ell); g->by_s.ell = nullptr; }
   if (g->by_t.ent) { (void)hipFree(g->by_t.ent); g->by_t.ent = nullptr; }
   if (g->by_s.ent) { (void)hipFree(g->by_s.ent); g->by_s.ent = nullptr; }
   if (g->by_t.sched) { (void)hipFree(g->by_t.sched); g->by_t.sched = nullptr; }
@@ -261,6 +275,8 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   if ((st = upload(&g->by_s.ent, es.data(), (size_t)m))) return st;
   if ((st = upload(&g->by_t.sched, st_.data(), st_.size()))) return st;
   if ((st = upload(&g->by_s.sched, ss_.data(), ss_.size()))) return st;
+  if ((st = upload(&g->by_t.ell, lt_.data(), lt_.size()))) return st;
+  if ((st = upload(&g->by_s.ell, ls_.data(), ls_.size()))) return st;
   if ((st = upload(&g->c, c.data(), (size_t)n))) return st;
   g->self_loops = add_self_loops ? 1 : 0;
   g->has_norm = true;
