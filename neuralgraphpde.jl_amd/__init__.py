@@ -11,6 +11,7 @@ from .utils import drop, updategraph, wrapgraph
 from .layers import (AbstractExplicitLayer, AbstractGNNContainerLayer, AbstractGNNLayer, Chain, Dense,
                      GCNConv, apply, glorot_normal, glorot_uniform, setup, to_device, zeros32)
 from .node import NeuralODE
+from . import dist, synth
 
 __all__ = [
     "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",

@@ -1,0 +1,45 @@
+"""Multi-process path on CPU: gloo, world size 2 -- the gradient all-reduce used by bench.py --gpus N."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ngpde_amd as ng
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)
+    grads = {"layer_1": {"weight": torch.full((4, 4), float(rank + 1)), "bias": torch.full((4, 1), 10.0 * (rank + 1))},
+             "layer_2": {"weight": torch.arange(16.0).reshape(4, 4) * (rank + 1)}}
+    ng.dist.allreduce_gradients(grads)
+    ok = (torch.all(grads["layer_1"]["weight"] == 3.0) and torch.all(grads["layer_1"]["bias"] == 30.0)
+          and torch.equal(grads["layer_2"]["weight"], torch.arange(16.0).reshape(4, 4) * 3))
+    lo, hi = ng.dist.shard_range(7, rank, world)
+    out[rank] = (bool(ok), lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0][0] and out[1][0]
+    assert (out[0][1], out[0][2], out[1][1], out[1][2]) == (0, 4, 4, 7)   # 7 trajectories -> 4 + 3
+
+
+def test_single_process_is_a_no_op():
+    g = {"w": torch.ones(3)}
+    assert ng.dist.allreduce_gradients(g)["w"].tolist() == [1, 1, 1]
+    assert ng.dist.shard_range(512, 3, 8) == (192, 256)                   # C4: 512 trajectories, 64 per GPU

@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's Lux API: state structure, parameter structure, updategraph
+identity and error behaviour, as asserted by /root/reference/test/runtests.jl (CPU; no kernels run)."""
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+
+
+def fixture_graph(**kw):
+    return ng.GNNGraph([1, 1, 2, 3], [2, 3, 1, 1], **kw)      # test/runtests.jl:11-13
+
+
+def test_gcn_setup_state_and_parameters():
+    g = fixture_graph()
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    assert st == {"graph": g}                                  # :21
+    assert list(ps) == ["weight", "bias"]
+    assert tuple(ps["weight"].shape) == (5, 3) and tuple(ps["bias"].shape) == (5, 1)   # src/layers.jl:166-167
+    assert ps["weight"].stride() == (1, 5)                     # Julia column-major memory order
+    assert l.parameterlength() == 20 and l.statelength() == 1  # src/layers.jl:173-175, :24
+    assert ng.GCNConv((3, 5), bias=False).parameterlength() == 15
+    assert repr(l) == "GCNConv(3 => 5)" and repr(ng.GCNConv((3, 5), "relu")) == "GCNConv(3 => 5, relu)"
+    # positional ctor defaults to glorot_normal, pair ctor to glorot_uniform (src/layers.jl:178 vs :193)
+    assert ng.GCNConv(3, 5).init_weight is ng.glorot_normal and l.init_weight is ng.glorot_uniform
+    lim = np.sqrt(6 / 8)
+    assert float(ps["weight"].abs().max()) <= lim + 1e-6
+
+
+def test_default_initialgraph_is_emptygraph():
+    l = ng.GCNConv((3, 5))
+    _, st = ng.setup(0, l)
+    assert st["graph"].num_nodes == 0 and st["graph"].num_edges == 0   # src/layers.jl:14,21
+
+
+def test_initialgraph_accepts_graph_or_thunk():
+    g = fixture_graph()
+    assert ng.setup(0, ng.GCNConv((3, 5), initialgraph=g))[1]["graph"] == g
+    assert ng.setup(0, ng.GCNConv((3, 5), initialgraph=lambda: g))[1]["graph"] is g    # src/utils.jl:16-17
+    with pytest.raises(TypeError):
+        ng.GCNConv((3, 5), initialgraph=3)
+
+
+def test_chain_states_and_updategraph_identity():
+    # test/runtests.jl:167-185
+    g = ng.rand_graph(5, 4, bidirected=False, seed=0)
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    new_g = ng.rand_graph(5, 7, bidirected=False, seed=1)
+    new_st = ng.updategraph(st, new_g)
+    assert new_st["graph"] is new_g
+    model = ng.Chain(ng.GCNConv((3, 5), initialgraph=g), ng.GCNConv((5, 5), initialgraph=g))
+    ps, st = ng.setup(0, model)
+    assert list(ps) == ["layer_1", "layer_2"] and list(st) == ["layer_1", "layer_2"]
+    new_st = ng.updategraph(st, new_g)
+    assert new_st["layer_1"]["graph"] is new_st["layer_2"]["graph"] is new_g
+    assert ng.updategraph({}, new_g) == {}                     # src/utils.jl:25
+
+
+def test_updategraph_with_graph_data():
+    # test/runtests.jl:188-205
+    g = ng.rand_graph(5, 4, bidirected=False, seed=0)
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    _, st = ng.setup(0, l)
+    ndata = np.random.rand(3, g.num_nodes)
+    new_st = ng.updategraph(st, ndata=ndata)
+    assert new_st["graph"].ndata["x"] is ndata
+    model = ng.Chain(ng.GCNConv((3, 5), initialgraph=g), ng.GCNConv((5, 5), initialgraph=g))
+    _, st = ng.setup(0, model)
+    new_st = ng.updategraph(st, ndata=ndata)
+    assert new_st["layer_1"]["graph"].ndata["x"] is new_st["layer_2"]["graph"].ndata["x"] is ndata
+
+
+def test_graph_data_validation_and_batch():
+    g = fixture_graph()
+    with pytest.raises(ng.DimensionMismatch):
+        ng.GNNGraph(g, ndata=np.zeros((2, 5)))                 # wrong number of node columns
+    with pytest.raises(ng.DimensionMismatch):
+        ng.GNNGraph([1, 2], [2, 9], num_nodes=3)               # edge outside 1:3
+    gh = ng.GNNGraph(g, ndata={"u": np.random.rand(2, 3), "x": np.random.rand(3, 3)}, gdata={"θ": np.random.rand(4)})
+    gb = ng.batch([gh, gh.copy()])                             # test/runtests.jl:92
+    assert gb.num_nodes == 6 and gb.num_edges == 8 and gb.num_graphs == 2
+    assert tuple(gb.ndata["u"].shape) == (2, 6) and tuple(gb.gdata["θ"].shape) == (4, 2)
+    s, t = gb.edge_index()
+    assert s.tolist() == [1, 1, 2, 3, 4, 4, 5, 6] and t.tolist() == [2, 3, 1, 1, 5, 6, 4, 4]
+    assert gh.copy() == gh and gh.copy() is not gh
+
+
+def test_dimension_errors_raise_before_any_kernel():
+    g = fixture_graph()
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    with pytest.raises(ng.DimensionMismatch):
+        l(torch.zeros(4, 3), ps, st)                           # wrong feature count
+    with pytest.raises(ng.DimensionMismatch):
+        l(torch.zeros(3, 7), ps, st)                           # wrong node count
+    with pytest.raises(ng.ArgumentError, match="expected 4 but given 2"):
+        l(torch.zeros(3, 3), ps, st, torch.ones(2))            # src/layers.jl:207
+    with pytest.raises(ng.ArgumentError):
+        ng.GCNConv((3, 5), "not_an_activation")
+
+
+def test_neuralode_container_flattens_params_and_states():
+    # graph_node.md:44-52: a single-field Lux container shares its model's ps and st
+    g = fixture_graph()
+    chain = ng.Chain(ng.GCNConv((16, 16), "relu", initialgraph=g), ng.GCNConv((16, 16), "relu", initialgraph=g))
+    node = ng.NeuralODE(chain, solver="tsit5", tspan=(0.0, 1.0), n_steps=50)
+    ps, st = ng.setup(0, node)
+    assert list(ps) == ["layer_1", "layer_2"] and st["layer_1"]["graph"] == g
+    assert abs(node.dt - 0.02) < 1e-12
+    with pytest.raises(ng.ArgumentError):
+        ng.NeuralODE(chain, solver="rk45")
+
+
+def test_no_cpu_fallback_for_the_hot_path():
+    g = fixture_graph()
+    l = ng.GCNConv((3, 5), initialgraph=g)
+    ps, st = ng.setup(0, l)
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by the gpu tests")
+    with pytest.raises((ng.NgpdeError, RuntimeError)):
+        l(torch.zeros(3, 3), ps, st)                           # CPU tensors are rejected, never silently computed
