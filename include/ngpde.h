@@ -119,6 +119,76 @@ int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr,
                                 const float *x, const float *edge_weight, float *out, ngpde_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Message-passing primitives -- the pieces `propagate(message, g, aggr; xi, xj, e)` [GraphNeuralNetworks.jl]
+ * is made of, as used by ExplicitEdgeConv (src/layers.jl:94-112), VMHConv (:308-332), MPPDEConv (:390-422),
+ * GNOConv (:509-547), SpectralConv (:652-657) and the GAT-style aggregation (softmax_edge_neighbors,
+ * src/NeuralGraphPDE.jl:7).  Per-edge arrays are in "p order": CSR by target (ngpde_graph_csr_by_target),
+ * the incoming edges of one node contiguous; ngpde_edge_permute converts from / to the COO order of
+ * g.edata.  Each *_backward is the pullback Zygote would derive for the corresponding forward.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Lux Dense on a virtual vcat of up to 4 blocks:  y = act.(W * vcat(X1, X2, ...) .+ b)  (src/layers.jl:106,
+ * :316, :328, :409, :418, :523 build the vcat explicitly).  Block i is [n / row_div[i]][width[i]] row-major;
+ * row_div > 1 = a per-graph feature repeated over that graph's rows (repeat(theta; inner=...), :410,:418).
+ * weight: (dout x sum width) column-major; save_z nullable. */
+int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                            const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight,
+                            const float *bias, float *y, float *save_z, ngpde_stream_t stream);
+size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout);
+/* dseg_ptr[i] nullable: gradient block for X_i (never written for row_div > 1 blocks: graph-level features
+ * are @ignore_derivatives in the reference, :397,:418).  dweight (dout x sum width) column-major, dbias nullable. */
+int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                             const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight, const float *z,
+                             const float *dy, float *const *dseg_ptr, float *dweight, float *dbias, void *workspace,
+                             size_t workspace_bytes, ngpde_stream_t stream);
+
+/* dst[p] = src[eid[p]] (COO order -> p order; inverse != 0: the opposite scatter), rows of d floats */
+int32_t ngpde_edge_permute(const ngpde_graph_t *g, int32_t d, int32_t inverse, const float *src, float *dst,
+                           ngpde_stream_t stream);
+
+/* apply_edges for a first layer that is linear in its blocks:  z_p = P[t_p] + Q[s_p] + E_p,  a_p = act(z_p).
+ * P, Q: [N][h] node-level terms (gathered at the target / source: xi = gather(., t), xj = gather(., s));
+ * e_term: [E][h] in p order or NULL; outputs a_out, z_out (nullable) [E][h] in p order. */
+int32_t ngpde_edge_combine_forward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *p_target,
+                                   const float *q_source, const float *e_term, float *a_out, float *z_out,
+                                   ngpde_stream_t stream);
+/* dz_p = da_p * act'(z_p) (also the gradient of e_term); dP[i] = sum over incoming edges; dQ[j] = sum over
+ * outgoing edges (pullback of gather = scatter(+)).  z NULL = identity activation.  dp/dq nullable. */
+int32_t ngpde_edge_combine_backward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *da, const float *z,
+                                    float *dz, float *dp_target, float *dq_source, ngpde_stream_t stream);
+
+/* aggregate_neighbors(g, aggr, m): out[:, i] = aggr over the incoming edges of i of m[:, e]; mean of an empty
+ * neighbourhood is 0; max/min pullback routes to every extremal entry (NNlib). */
+int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, float *out,
+                                     ngpde_stream_t stream);
+int32_t ngpde_segment_reduce_backward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, const float *out,
+                                      const float *dout, float *dm, ngpde_stream_t stream);
+
+/* GNOConv message (src/layers.jl:527-530): K_e = reshape(phi_out[:, e], cout, cin) column-major,
+ * m_e = K_e * h[:, s_e].  k: [E][cin*cout] p order (element o + cout*i), h: [N][cin], m: [E][cout]. */
+int32_t ngpde_gno_contract_forward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
+                                   float *m, ngpde_stream_t stream);
+/* dk [E][cin*cout] nullable, dh [N][cin] nullable (needs workspace of n_edges*cin*4 bytes) */
+int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
+                                    const float *dm, float *dk, float *dh, void *workspace, size_t workspace_bytes,
+                                    ngpde_stream_t stream);
+
+/* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
+ * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);
+ * alpha = softmax over the incoming edges of each node; out[N][heads*c] = sum_e alpha_e Wx[s_e].
+ * Saved for backward: alpha [E][heads] (p order), al, ar [N][heads]. */
+int32_t ngpde_gat_forward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
+                          const float *a, float *out, float *alpha, float *al, float *ar, ngpde_stream_t stream);
+size_t ngpde_gat_workspace_bytes(const ngpde_graph_t *g, int32_t heads);
+int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
+                           const float *a, const float *al, const float *ar, const float *alpha, const float *dout,
+                           float *dwx, float *da, void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
+
+/* SpectralConv message weights (src/layers.jl:654): w_e = cos(e n / 2) cot(e / 2) / 2; the layer is then
+ * propagate(e_mul_xj, g, +) = ngpde_propagate_copy_xj with these weights. */
+int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float *w, ngpde_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fixed-step neural graph ODE over  Chain(GCNConv(d => d, act), GCNConv(d => d, act))  -- the caller
  * of the hot path in the reference's tutorial (docs/src/tutorials/graph_node.md:44-66, :78): the
  * right-hand side dudt(u, p, t) is evaluated once per Runge-Kutta stage.  BASELINE configs fix the

@@ -11,10 +11,12 @@ from .utils import drop, updategraph, wrapgraph
 from .layers import (AbstractExplicitLayer, AbstractGNNContainerLayer, AbstractGNNLayer, Chain, Dense,
                      GCNConv, apply, glorot_normal, glorot_uniform, setup, to_device, zeros32)
 from .node import NeuralODE
+from .layers_mp import ExplicitEdgeConv, GATConv, GNOConv, MPPDEConv, SpectralConv, VMHConv
 from . import dist, synth
 
 __all__ = [
     "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",
+    "ExplicitEdgeConv", "VMHConv", "MPPDEConv", "GNOConv", "SpectralConv", "GATConv",
     "setup", "apply", "to_device", "updategraph", "wrapgraph", "drop", "GNNGraph", "EMPTYGRAPH", "rand_graph",
     "batch", "glorot_uniform", "glorot_normal", "zeros32", "NgpdeError", "DimensionMismatch", "ArgumentError",
 ]

@@ -53,6 +53,20 @@ SIGNATURES = {
     "ngpde_gcn_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_gcn_backward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_propagate_copy_xj": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "ngpde_dense_backward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_edge_permute": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "ngpde_edge_combine_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_edge_combine_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_segment_reduce_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "ngpde_segment_reduce_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gno_contract_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ngpde_gno_contract_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_gat_forward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gat_workspace_bytes": (_sz, [_vp, _i32]),
+    "ngpde_gat_backward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_spectral_weights": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "ngpde_node_gcn2_create": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, C.POINTER(_vp)]),
     "ngpde_node_destroy": (_i32, [_vp]),
     "ngpde_node_tape_bytes": (_sz, [_vp]),

@@ -1,0 +1,222 @@
+// api_mp.hip -- C-ABI entry points of the message-passing primitives (declared in include/ngpde.h).
+// Together they replace the bodies of the reference's edge-function layers:
+//   propagate(message, g, aggr; xi, xj, e)   /root/reference/src/layers.jl:111, :326, :416, :534, :656
+#include <algorithm>
+
+#include "common.h"
+
+using namespace ngpde;
+
+namespace {
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int32_t make_segs(const char *fn, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                  const int32_t *seg_row_div, SegTable &t, int *din) {
+  NGPDE_REQUIRE(n_seg >= 1 && n_seg <= 4, NGPDE_ERR_INVALID_ARGUMENT, "%s: 1..4 input blocks supported, got %d", fn, n_seg);
+  NGPDE_REQUIRE(seg_ptr && seg_width, NGPDE_ERR_INVALID_ARGUMENT, "%s: NULL block table", fn);
+  t.n = n_seg;
+  int off = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    NGPDE_REQUIRE(seg_width[i] >= 0, NGPDE_ERR_DIMENSION_MISMATCH, "%s: negative block width", fn);
+    NGPDE_REQUIRE(seg_width[i] == 0 || seg_ptr[i], NGPDE_ERR_INVALID_ARGUMENT, "%s: block %d is NULL", fn, i);
+    t.ptr[i] = seg_ptr[i];
+    t.width[i] = seg_width[i];
+    t.row_div[i] = (seg_row_div && seg_row_div[i] > 0) ? seg_row_div[i] : 1;
+    t.offset[i] = off;
+    off += seg_width[i];
+  }
+  for (int i = n_seg; i <= 4; ++i) t.offset[i] = off;
+  *din = off;
+  return NGPDE_OK;
+}
+
+int32_t check_act(const char *fn, int32_t act) {
+  NGPDE_REQUIRE(act >= NGPDE_ACT_IDENTITY && act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT,
+                "%s: unknown activation code %d", fn, act);
+  return NGPDE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                            const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight,
+                            const float *bias, float *y, float *save_z, ngpde_stream_t stream) {
+  SegTable t;
+  int din = 0;
+  int32_t st = make_segs("ngpde_dense_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
+  if (st || (st = check_act("ngpde_dense_forward", act))) return st;
+  NGPDE_REQUIRE(n >= 0 && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH, "ngpde_dense_forward: DimensionMismatch");
+  if (n == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(weight && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_forward: weight/y is NULL");
+  return launch_dense_seg_fwd(n, t, din, dout, act, weight, bias, y, save_z, (hipStream_t)stream);
+}
+
+size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout) {
+  return align256((size_t)std::max<int64_t>(n, 1) * dout * 4) +
+         align256((size_t)dense_weight_chunks(n) * (din_total + 1) * dout * 4) + 256;
+}
+
+int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                             const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight, const float *z,
+                             const float *dy, float *const *dseg_ptr, float *dweight, float *dbias, void *workspace,
+                             size_t workspace_bytes, ngpde_stream_t stream_) {
+  SegTable t;
+  int din = 0;
+  int32_t st = make_segs("ngpde_dense_backward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
+  if (st || (st = check_act("ngpde_dense_backward", act))) return st;
+  hipStream_t stream = (hipStream_t)stream_;
+  NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_backward: dweight is NULL");
+  if (n == 0) {
+    NGPDE_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)din * dout * 4, stream));
+    if (dbias) NGPDE_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)dout * 4, stream));
+    return NGPDE_OK;
+  }
+  NGPDE_REQUIRE(weight && dy && (z || act == NGPDE_ACT_IDENTITY), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_dense_backward: weight/z/dy is NULL");
+  const size_t need = ngpde_dense_workspace_bytes(n, din, dout);
+  NGPDE_REQUIRE(workspace && workspace_bytes >= need, NGPDE_ERR_WORKSPACE,
+                "ngpde_dense_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  float *dz = (float *)workspace;
+  float *partial = (float *)((char *)workspace + align256((size_t)n * dout * 4));
+  if (act == NGPDE_ACT_IDENTITY) {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(dz, dy, (size_t)n * dout * 4, hipMemcpyDeviceToDevice, stream));
+  } else if ((st = launch_dense_dz(n * dout, act, dy, z, dz, stream))) {
+    return st;
+  }
+  if ((st = launch_dense_seg_bwd_weight(n, t, din, dout, dz, dweight, dbias, partial, stream))) return st;
+  if (dseg_ptr) {
+    SegGrad gsg;
+    gsg.n = t.n;
+    bool any = false;
+    for (int i = 0; i < t.n; ++i) {
+      gsg.ptr[i] = (t.row_div[i] == 1) ? dseg_ptr[i] : nullptr;   // per-graph blocks carry no gradient (@ignore_derivatives, :397,:418)
+      gsg.width[i] = t.width[i];
+      any = any || gsg.ptr[i];
+    }
+    for (int i = 0; i <= 4; ++i) gsg.offset[i] = t.offset[i];
+    if (any && (st = launch_dense_seg_bwd_input(n, gsg, din, dout, dz, weight, stream))) return st;
+  }
+  return NGPDE_OK;
+}
+
+int32_t ngpde_edge_permute(const ngpde_graph_t *g, int32_t d, int32_t inverse, const float *src, float *dst,
+                           ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_permute: graph is NULL");
+  if (g->n_edges == 0 || d == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(src && dst && d > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_permute: bad arguments");
+  return launch_edge_permute(g, d, inverse != 0, src, dst, (hipStream_t)stream);
+}
+
+int32_t ngpde_edge_combine_forward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *p_target,
+                                   const float *q_source, const float *e_term, float *a_out, float *z_out,
+                                   ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_forward: graph is NULL");
+  int32_t st = check_act("ngpde_edge_combine_forward", act);
+  if (st) return st;
+  if (g->n_edges == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(h > 0 && a_out, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_forward: bad arguments");
+  return launch_edge_combine_fwd(g, h, act, p_target, q_source, e_term, a_out, z_out, (hipStream_t)stream);
+}
+
+int32_t ngpde_edge_combine_backward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *da, const float *z,
+                                    float *dz, float *dp_target, float *dq_source, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_backward: graph is NULL");
+  int32_t st = check_act("ngpde_edge_combine_backward", act);
+  if (st) return st;
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(h > 0 && (g->n_edges == 0 || (da && dz)), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_backward: bad arguments");
+  return launch_edge_combine_bwd(g, h, act, da, z, dz, dp_target, dq_source, (hipStream_t)stream);
+}
+
+int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, float *out,
+                                     ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_forward: graph is NULL");
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_segment_reduce_forward: unknown aggregation %d", aggr);
+  if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(out && (m || g->n_edges == 0), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_forward: NULL argument");
+  return launch_segment_reduce_fwd(g, d, aggr, m, out, (hipStream_t)stream);
+}
+
+int32_t ngpde_segment_reduce_backward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, const float *out,
+                                      const float *dout, float *dm, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_backward: graph is NULL");
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_segment_reduce_backward: unknown aggregation %d", aggr);
+  if (g->n_edges == 0 || d == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(dout && dm, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_backward: NULL argument");
+  return launch_segment_reduce_bwd(g, d, aggr, m, out, dout, dm, (hipStream_t)stream);
+}
+
+int32_t ngpde_gno_contract_forward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
+                                   float *m, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_forward: graph is NULL");
+  if (g->n_edges == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(cin > 0 && cout > 0 && k && h && m, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_forward: bad arguments");
+  return launch_gno_contract_fwd(g, cin, cout, k, h, m, (hipStream_t)stream);
+}
+
+int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
+                                    const float *dm, float *dk, float *dh, void *workspace, size_t workspace_bytes,
+                                    ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_backward: graph is NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (g->n_edges == 0) {
+    if (dh && g->n_nodes) NGPDE_HIP_CHECK(hipMemsetAsync(dh, 0, (size_t)g->n_nodes * cin * 4, stream));
+    return NGPDE_OK;
+  }
+  NGPDE_REQUIRE(cin > 0 && cout > 0 && k && h && dm, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_backward: bad arguments");
+  const size_t need = (size_t)g->n_edges * cin * 4;
+  NGPDE_REQUIRE(!dh || (workspace && workspace_bytes >= need), NGPDE_ERR_WORKSPACE,
+                "ngpde_gno_contract_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  int32_t st = launch_gno_contract_bwd(g, cin, cout, k, h, dm, dk, dh ? (float *)workspace : nullptr, stream);
+  if (st) return st;
+  if (dh) return launch_edge_sum_by_source(g, cin, (const float *)workspace, dh, stream);
+  return NGPDE_OK;
+}
+
+int32_t ngpde_gat_forward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
+                          const float *a, float *out, float *alpha, float *al, float *ar, ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_forward: graph is NULL");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(heads > 0 && c > 0 && wx && a && out && al && ar && (alpha || g->n_edges == 0), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_gat_forward: bad arguments");
+  hipStream_t stream = (hipStream_t)stream_;
+  int32_t st = launch_gat_scores(g->n_nodes, heads, c, wx, a, al, ar, stream);
+  if (st) return st;
+  return launch_gat_fwd(g, heads, c, negative_slope, wx, al, ar, out, alpha, stream);
+}
+
+size_t ngpde_gat_workspace_bytes(const ngpde_graph_t *g, int32_t heads) {
+  if (!g) return 0;
+  return align256((size_t)std::max<int64_t>(g->n_edges, 1) * heads * 4) + 2 * align256((size_t)std::max<int64_t>(g->n_nodes, 1) * heads * 4) + 256;
+}
+
+int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
+                           const float *a, const float *al, const float *ar, const float *alpha, const float *dout,
+                           float *dwx, float *da, void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_backward: graph is NULL");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(heads > 0 && c > 0 && wx && a && al && ar && dout && dwx && da, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_gat_backward: bad arguments");
+  const size_t need = ngpde_gat_workspace_bytes(g, heads);
+  NGPDE_REQUIRE(workspace && workspace_bytes >= need, NGPDE_ERR_WORKSPACE,
+                "ngpde_gat_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  char *ws = (char *)workspace;
+  float *dscore = (float *)ws;
+  float *dal = (float *)(ws + align256((size_t)std::max<int64_t>(g->n_edges, 1) * heads * 4));
+  float *dar = (float *)((char *)dal + align256((size_t)g->n_nodes * heads * 4));
+  return launch_gat_bwd(g, heads, c, negative_slope, wx, a, al, ar, alpha, dout, dscore, dal, dar, dwx, da,
+                        (hipStream_t)stream_);
+}
+
+int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float *w, ngpde_stream_t stream) {
+  if (n_edges == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(e && w && n > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_spectral_weights: bad arguments");
+  return launch_spectral_weights(n_edges, (float)n, e, w, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -39,6 +39,7 @@ struct Csr {
   int32_t *eid = nullptr;     // [n_edges] position of the entry in the COO list
   int2 *ent = nullptr;        // [n_edges] {col, bits of GCN coefficient w_e * c[col]}; set by set_gcn_norm
   int4 *sched = nullptr;      // [n_sched] tile schedule entries {node, row start, degree, bits of c[node]}; node < 0 = padding
+  int32_t *xpos = nullptr;    // [n_edges] position of each entry in the OTHER direction's list (same COO edge)
   int2 *ell = nullptr;        // [n_sched][kEllWidth] the first kEllWidth {col, coef} entries of each schedule row
                               // (zero padded), addressed by schedule POSITION: loadable without first reading `sched`
   std::vector<int32_t> h_rowptr, h_col, h_eid;
@@ -144,5 +145,49 @@ int32_t launch_colsum(int64_t n, int d, const float *a, float *out, hipStream_t 
 // y = act(a + bias)
 int32_t launch_bias_act(int64_t n, int d, int act, const float *a, const float *bias, float *y, float *save_z,
                         hipStream_t stream);
+
+// ---- message-passing primitives (mp_kernels.hip) -------------------------------------------------------
+struct SegTable {   // virtual concatenation [X1 | X2 | ...] of up to 4 row-major blocks
+  int n = 0;
+  const float *ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  int width[4] = {0, 0, 0, 0};
+  int row_div[4] = {1, 1, 1, 1};   // block row = row / row_div (per-graph features repeated over a graph's rows)
+  int offset[5] = {0, 0, 0, 0, 0};
+};
+struct SegGrad {
+  int n = 0;
+  float *ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  int width[4] = {0, 0, 0, 0};
+  int offset[5] = {0, 0, 0, 0, 0};
+};
+int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
+                             const float *bias, float *y, float *save_z, hipStream_t stream);
+int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
+int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
+                                   hipStream_t stream);
+int dense_weight_chunks(int64_t n);
+int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
+                                    float *db, float *partial, hipStream_t stream);
+int32_t launch_edge_permute(const ngpde_graph *g, int d, bool inverse, const float *src, float *dst, hipStream_t stream);
+int32_t launch_edge_combine_fwd(const ngpde_graph *g, int h, int act, const float *P, const float *Q, const float *Eterm,
+                                float *a_out, float *z_out, hipStream_t stream);
+int32_t launch_edge_combine_bwd(const ngpde_graph *g, int h, int act, const float *da, const float *z, float *dz, float *dP,
+                                float *dQ, hipStream_t stream);
+int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_edge, float *out, hipStream_t stream);
+int32_t launch_segment_reduce_fwd(const ngpde_graph *g, int d, int aggr, const float *M, float *out, hipStream_t stream);
+int32_t launch_segment_reduce_bwd(const ngpde_graph *g, int d, int aggr, const float *M, const float *out, const float *dout,
+                                  float *dM, hipStream_t stream);
+int32_t launch_gno_contract_fwd(const ngpde_graph *g, int cin, int cout, const float *K, const float *h, float *m,
+                                hipStream_t stream);
+int32_t launch_gno_contract_bwd(const ngpde_graph *g, int cin, int cout, const float *K, const float *h, const float *dm,
+                                float *dK, float *dhe, hipStream_t stream);
+int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const float *a, float *al, float *ar,
+                          hipStream_t stream);
+int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
+                       float *out, float *alpha, hipStream_t stream);
+int32_t launch_gat_bwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *a, const float *al,
+                       const float *ar, const float *alpha, const float *dout, float *dscore, float *dal, float *dar,
+                       float *dwx, float *da, hipStream_t stream);
+int32_t launch_spectral_weights(int64_t n_edges, float nn, const float *e, float *w, hipStream_t stream);
 
 }  // namespace ngpde

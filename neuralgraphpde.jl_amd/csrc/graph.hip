@@ -112,6 +112,7 @@ void free_csr(Csr &c) {
   if (c.ent) (void)hipFree(c.ent);
   if (c.sched) (void)hipFree(c.sched);
   if (c.ell) (void)hipFree(c.ell);
+  if (c.xpos) (void)hipFree(c.xpos);
   c = Csr();
 }
 
@@ -158,6 +159,18 @@ int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, c
   for (int64_t i = 0; i < n_nodes; ++i) {
     g->max_in_degree = std::max(g->max_in_degree, g->by_t.h_rowptr[i + 1] - g->by_t.h_rowptr[i]);
     g->max_out_degree = std::max(g->max_out_degree, g->by_s.h_rowptr[i + 1] - g->by_s.h_rowptr[i]);
+  }
+  {  // cross positions: entry q of one list and entry p of the other that are the same COO edge
+    std::vector<int32_t> pos_t((size_t)n_edges), pos_s((size_t)n_edges), xt((size_t)n_edges), xs((size_t)n_edges);
+    for (int64_t p = 0; p < n_edges; ++p) pos_t[g->by_t.h_eid[p]] = (int32_t)p;
+    for (int64_t q = 0; q < n_edges; ++q) pos_s[g->by_s.h_eid[q]] = (int32_t)q;
+    for (int64_t q = 0; q < n_edges; ++q) xs[q] = pos_t[g->by_s.h_eid[q]];
+    for (int64_t p = 0; p < n_edges; ++p) xt[p] = pos_s[g->by_t.h_eid[p]];
+    int32_t stx;
+    if ((stx = upload(&g->by_s.xpos, xs.data(), xs.size())) || (stx = upload(&g->by_t.xpos, xt.data(), xt.size()))) {
+      ngpde_graph_destroy(g);
+      return stx;
+    }
   }
   g->h_order = locality_order(n_nodes, g->by_t, g->by_s, kTileRows);
   g->n_sched = (int32_t)(((n_nodes + kTileRows - 1) / kTileRows) * kTileRows);

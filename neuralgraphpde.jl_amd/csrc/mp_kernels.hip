@@ -1,0 +1,617 @@
+// mp_kernels.hip -- message-passing primitives behind the edge-MLP layers of /root/reference/src/layers.jl
+// (ExplicitEdgeConv :94-112, VMHConv :308-332, MPPDEConv :390-422, GNOConv :509-547) and the GAT-style
+// softmax aggregation (primitive re-exported at src/NeuralGraphPDE.jl:7).
+//
+// `propagate(message, g, aggr; xi, xj, e)` [GraphNeuralNetworks.jl] = gather at t / gather at s -> message on
+// the whole edge set -> scatter(aggr) at t.  Here per-edge arrays live in CSR-by-target order ("p order":
+// the edges of one target are contiguous, in COO order), so
+//   * the gathers + the first Dense layer of the message MLP collapse into  z_p = P[t_p] + Q[s_p] + E_p
+//     with node-level P, Q (the first layer is linear in the concatenated blocks:
+//     W [hi; hj; di - dj; e; theta] = (Wa hi + Wc di + We theta + b) + (Wb hj - Wc dj) + Wd e),
+//   * scatter(aggr) is an atomic-free segmented reduction over contiguous rows,
+//   * pullbacks towards source nodes walk the CSR-by-source list through `xpos` (the p position of each entry).
+// First correct versions: one wave per row, lanes stride the feature axis; no atomics, fixed summation
+// order (bitwise reproducible).
+#include <algorithm>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace ngpde {
+
+namespace {
+
+#define NGPDE_LAUNCH_CHECK(name)                                                         \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- concat-free dense:  y = act([X1 | X2 | ...] Wt + b) ------------------------------------------------
+// The reference builds vcat(...) temporaries ((sum D) x E, 1.66 GB per GPU shard at C4); here the blocks are
+// read in place.  A block with row_div > 1 is a per-graph feature: row r reads row r / row_div
+// (repeat(theta; inner=(1, E / G)), src/layers.jl:410,:418).
+
+__device__ __forceinline__ float seg_load(const SegTable &s, int64_t row, int k) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < s.n && k < s.offset[i + 1]) return s.ptr[i][(row / s.row_div[i]) * s.width[i] + (k - s.offset[i])];
+  return 0.f;
+}
+
+__global__ __launch_bounds__(256) void dense_seg_fwd_kernel(int64_t n, SegTable segs, int din, int dout, int act,
+                                                            const float *__restrict__ wt, const float *__restrict__ bias,
+                                                            float *__restrict__ y, float *__restrict__ save_z) {
+  __shared__ float xs[16][17], ws[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
+  const int o = blockIdx.y * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < din; k0 += 16) {
+    xs[ty][tx] = (row < n && k0 + tx < din) ? seg_load(segs, row, k0 + tx) : 0.f;
+    ws[ty][tx] = (k0 + ty < din && o < dout) ? wt[(size_t)(k0 + ty) * dout + o] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(xs[ty][k], ws[k][tx], acc);
+    __syncthreads();
+  }
+  if (row < n && o < dout) {
+    const float z = acc + (bias ? bias[o] : 0.f);
+    if (save_z) save_z[row * dout + o] = z;
+    y[row * dout + o] = act_apply(act, z);
+  }
+}
+
+// dz = dy * act'(z)
+__global__ void dense_dz_kernel(int64_t count, int act, const float *__restrict__ dy, const float *__restrict__ z,
+                                float *__restrict__ dz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    dz[i] = dy[i] * act_deriv(act, z[i]);
+}
+
+// dX[row][k] = sum_o dz[row][o] wt[k][o] written into the blocks that ask for a gradient
+__global__ __launch_bounds__(256) void dense_seg_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
+                                                                  const float *__restrict__ dz,
+                                                                  const float *__restrict__ wt) {
+  __shared__ float zs[16][17], ws[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
+  const int k = blockIdx.y * 16 + tx;
+  float acc = 0.f;
+  for (int o0 = 0; o0 < dout; o0 += 16) {
+    zs[ty][tx] = (row < n && o0 + tx < dout) ? dz[row * dout + o0 + tx] : 0.f;
+    const int wk = blockIdx.y * 16 + ty;
+    ws[tx][ty] = (wk < din && o0 + tx < dout) ? wt[(size_t)wk * dout + o0 + tx] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc = fmaf(zs[ty][o], ws[o][tx], acc);
+    __syncthreads();
+  }
+  if (row < n && k < din) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < segs.n && k >= segs.offset[i] && k < segs.offset[i + 1] && segs.ptr[i])
+        segs.ptr[i][row * segs.width[i] + (k - segs.offset[i])] = acc;
+  }
+}
+
+// partial[chunk][k][o] = sum_{rows of chunk} X[row][k] dz[row][o]; k == din is the bias row (X = 1)
+__global__ __launch_bounds__(256) void dense_seg_bwd_weight_kernel(int64_t n, SegTable segs, int din, int dout,
+                                                                   const float *__restrict__ dz, int64_t rows_per_chunk,
+                                                                   float *__restrict__ partial) {
+  __shared__ float xs[16][17], zs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + ty;   // row of dwt (din + 1 rows: the last is db)
+  const int o = blockIdx.y * 16 + tx;
+  const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  float acc = 0.f;
+  for (int64_t n0 = r0; n0 < r1; n0 += 16) {
+    const int kk = blockIdx.x * 16 + tx;
+    const int64_t rr = n0 + ty;
+    xs[ty][tx] = (rr < r1 && kk <= din) ? (kk == din ? 1.0f : seg_load(segs, rr, kk)) : 0.f;
+    zs[ty][tx] = (rr < r1 && o < dout) ? dz[rr * dout + o] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = fmaf(xs[j][ty], zs[j][tx], acc);
+    __syncthreads();
+  }
+  if (k <= din && o < dout) partial[((size_t)blockIdx.z * (din + 1) + k) * dout + o] = acc;
+}
+
+__global__ void dense_weight_reduce_kernel(int nchunk, int din, int dout, const float *__restrict__ partial,
+                                           float *__restrict__ dwt, float *__restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (din + 1) * dout;
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + idx];
+  if (idx < din * dout) dwt[idx] = s;
+  else if (db) db[idx - din * dout] = s;
+}
+
+// ---- edge-order helpers ------------------------------------------------------------------------------------
+
+// dst[p] = src[eid[p]]  (COO order -> p order), or the inverse scatter when `inverse`
+__global__ void edge_permute_kernel(int64_t n_edges, int d, const int *__restrict__ eid, int inverse,
+                                    const float *__restrict__ src, float *__restrict__ dst) {
+  const int64_t total = n_edges * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / d;
+    const int f = (int)(i % d);
+    const int64_t e = eid[p];
+    if (inverse) dst[e * d + f] = src[p * d + f];
+    else dst[p * d + f] = src[e * d + f];
+  }
+}
+
+// z_p = P[t] + Q[s_p] (+ E_p);  a_p = act(z_p).  One wave per target row.
+__global__ __launch_bounds__(256) void edge_combine_fwd_kernel(int n_nodes, int h, int act, const int *__restrict__ rowptr,
+                                                               const int *__restrict__ col, const float *__restrict__ P,
+                                                               const float *__restrict__ Q, const float *__restrict__ Eterm,
+                                                               float *__restrict__ a_out, float *__restrict__ z_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  for (int f = lane; f < h; f += 64) {
+    const float pv = P ? P[(size_t)row * h + f] : 0.f;
+    for (int p = rs; p < re; ++p) {
+      float z = pv + (Q ? Q[(size_t)col[p] * h + f] : 0.f);
+      if (Eterm) z += Eterm[(size_t)p * h + f];
+      if (z_out) z_out[(size_t)p * h + f] = z;
+      a_out[(size_t)p * h + f] = act_apply(act, z);
+    }
+  }
+}
+
+// dz_p = da_p * act'(z_p) (in place into dz);  dP[t] = sum over the row
+__global__ __launch_bounds__(256) void edge_combine_bwd_target_kernel(int n_nodes, int h, int act, const int *__restrict__ rowptr,
+                                                                      const float *__restrict__ da, const float *__restrict__ z,
+                                                                      float *__restrict__ dz, float *__restrict__ dP) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  for (int f = lane; f < h; f += 64) {
+    float s = 0.f;
+    for (int p = rs; p < re; ++p) {
+      const float g = da[(size_t)p * h + f] * (z ? act_deriv(act, z[(size_t)p * h + f]) : 1.0f);
+      dz[(size_t)p * h + f] = g;
+      s += g;
+    }
+    if (dP) dP[(size_t)row * h + f] = s;
+  }
+}
+
+// dQ[s] = sum over the edges leaving s of dz_p  (CSR by source, xpos = p position of each entry)
+__global__ __launch_bounds__(256) void edge_sum_by_source_kernel(int n_nodes, int h, const int *__restrict__ rowptr_s,
+                                                                 const int *__restrict__ xpos, const float *__restrict__ dz,
+                                                                 float *__restrict__ dQ) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr_s[row], re = rowptr_s[row + 1];
+  for (int f = lane; f < h; f += 64) {
+    float s = 0.f;
+    for (int q = rs; q < re; ++q) s += dz[(size_t)xpos[q] * h + f];
+    dQ[(size_t)row * h + f] = s;
+  }
+}
+
+// ---- aggregate_neighbors: out[i] = aggr_{p in row i} M[p]   (scatter(aggr, m, t) of NNlib) --------------
+__global__ __launch_bounds__(256) void segment_reduce_fwd_kernel(int n_nodes, int d, int aggr, const int *__restrict__ rowptr,
+                                                                 const float *__restrict__ M, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  for (int f = lane; f < d; f += 64) {
+    float acc;
+    if (aggr == NGPDE_AGGR_MAX) acc = -INFINITY;
+    else if (aggr == NGPDE_AGGR_MIN) acc = INFINITY;
+    else acc = 0.f;
+    for (int p = rs; p < re; ++p) {
+      const float v = M[(size_t)p * d + f];
+      if (aggr == NGPDE_AGGR_MAX) acc = fmaxf(acc, v);
+      else if (aggr == NGPDE_AGGR_MIN) acc = fminf(acc, v);
+      else acc += v;
+    }
+    if (aggr == NGPDE_AGGR_MEAN) acc = (re > rs) ? acc / (float)(re - rs) : 0.f;   // mean of an empty neighbourhood is 0
+    out[(size_t)row * d + f] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void segment_reduce_bwd_kernel(int n_nodes, int d, int aggr, const int *__restrict__ rowptr,
+                                                                 const float *__restrict__ M, const float *__restrict__ out,
+                                                                 const float *__restrict__ dout, float *__restrict__ dM) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  for (int f = lane; f < d; f += 64) {
+    const float g = dout[(size_t)row * d + f];
+    const float scale = (aggr == NGPDE_AGGR_MEAN && re > rs) ? 1.0f / (float)(re - rs) : 1.0f;
+    const float ext = (aggr == NGPDE_AGGR_MAX || aggr == NGPDE_AGGR_MIN) ? out[(size_t)row * d + f] : 0.f;
+    for (int p = rs; p < re; ++p) {
+      float v = g * scale;
+      if (aggr == NGPDE_AGGR_MAX || aggr == NGPDE_AGGR_MIN) v = (M[(size_t)p * d + f] == ext) ? g : 0.f;  // NNlib: every extremal entry
+      dM[(size_t)p * d + f] = v;
+    }
+  }
+}
+
+// ---- GNOConv contraction: m_p[o] = sum_i K_p[o + out*i] h[s_p][i]   (batched_mul, src/layers.jl:527-530) -----
+__global__ __launch_bounds__(256) void gno_contract_fwd_kernel(int64_t n_edges, int cin, int cout, const int *__restrict__ col,
+                                                               const float *__restrict__ K, const float *__restrict__ hfeat,
+                                                               float *__restrict__ m) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_edges) return;
+  const float *Kp = K + (size_t)p * cin * cout;
+  const float *hp = hfeat + (size_t)col[p] * cin;
+  for (int o = lane; o < cout; o += 64) {
+    float acc = 0.f;
+    for (int i = 0; i < cin; ++i) acc = fmaf(Kp[o + (size_t)cout * i], hp[i], acc);   // coalesced over o
+    m[(size_t)p * cout + o] = acc;
+  }
+}
+
+// dK_p[o + out*i] = dm_p[o] h[s_p][i];  dhe_p[i] = sum_o K_p[o + out*i] dm_p[o]  (per-edge; summed by source afterwards)
+__global__ __launch_bounds__(256) void gno_contract_bwd_kernel(int64_t n_edges, int cin, int cout, const int *__restrict__ col,
+                                                               const float *__restrict__ K, const float *__restrict__ hfeat,
+                                                               const float *__restrict__ dm, float *__restrict__ dK,
+                                                               float *__restrict__ dhe) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_edges) return;
+  const float *Kp = K + (size_t)p * cin * cout;
+  const float *hp = hfeat + (size_t)col[p] * cin;
+  const float *dmp = dm + (size_t)p * cout;
+  for (int i = 0; i < cin; ++i) {
+    const float hv = hp[i];
+    float part = 0.f;
+    for (int o = lane; o < cout; o += 64) {
+      const float g = dmp[o];
+      if (dK) dK[(size_t)p * cin * cout + o + (size_t)cout * i] = g * hv;
+      part = fmaf(Kp[o + (size_t)cout * i], g, part);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0 && dhe) dhe[(size_t)p * cin + i] = part;
+  }
+}
+
+// ---- GAT-style attention over incoming edges [GraphNeuralNetworks.jl GATConv] --------------------------------
+// per (target i, head k): logit_p = leakyrelu(al[i][k] + ar[s_p][k]); alpha = softmax over the row (max-subtracted);
+// out[i][k*C + c] = sum_p alpha_p Wx[s_p][k*C + c].  One wave per target row, loops over heads.
+__global__ __launch_bounds__(256) void gat_fwd_kernel(int n_nodes, int heads, int c, float slope, const int *__restrict__ rowptr,
+                                                      const int *__restrict__ col, const float *__restrict__ wx,
+                                                      const float *__restrict__ al, const float *__restrict__ ar,
+                                                      float *__restrict__ out, float *__restrict__ alpha) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int hc = heads * c;
+  for (int k = 0; k < heads; ++k) {
+    const float ali = al[(size_t)row * heads + k];
+    float mx = -INFINITY;
+    for (int p = rs + lane; p < re; p += 64) {
+      float v = ali + ar[(size_t)col[p] * heads + k];
+      v = v > 0.f ? v : slope * v;
+      mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int p = rs + lane; p < re; p += 64) {
+      float v = ali + ar[(size_t)col[p] * heads + k];
+      v = v > 0.f ? v : slope * v;
+      const float e = expf(v - mx);
+      alpha[(size_t)p * heads + k] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+    for (int p = rs + lane; p < re; p += 64) alpha[(size_t)p * heads + k] *= inv;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int f = lane; f < hc; f += 64) {
+    const int k = f / c;
+    float acc = 0.f;
+    for (int p = rs; p < re; ++p) acc = fmaf(alpha[(size_t)p * heads + k], wx[(size_t)col[p] * hc + f], acc);
+    out[(size_t)row * hc + f] = acc;
+  }
+}
+
+// backward, target side: dalpha_p = <dout[i], Wx[s_p]>_head; dlogit = alpha (dalpha - sum alpha dalpha);
+// dscore_p = dlogit * leakyrelu'(score); dal[i] = sum_p dscore_p.  Stores dscore (for the source side).
+__global__ __launch_bounds__(256) void gat_bwd_target_kernel(int n_nodes, int heads, int c, float slope,
+                                                             const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                             const float *__restrict__ wx, const float *__restrict__ al,
+                                                             const float *__restrict__ ar, const float *__restrict__ alpha,
+                                                             const float *__restrict__ dout, float *__restrict__ dscore,
+                                                             float *__restrict__ dal) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int hc = heads * c;
+  for (int k = 0; k < heads; ++k) {
+    // dalpha for every edge of the row (lanes over edges), then the softmax pullback
+    float dot_sum = 0.f;
+    for (int p = rs + lane; p < re; p += 64) {
+      float da = 0.f;
+      for (int cc = 0; cc < c; ++cc) da = fmaf(dout[(size_t)row * hc + k * c + cc], wx[(size_t)col[p] * hc + k * c + cc], da);
+      dscore[(size_t)p * heads + k] = da;
+      dot_sum = fmaf(alpha[(size_t)p * heads + k], da, dot_sum);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot_sum += __shfl_xor(dot_sum, off);
+    const float ali = al[(size_t)row * heads + k];
+    float s = 0.f;
+    for (int p = rs + lane; p < re; p += 64) {
+      const float a = alpha[(size_t)p * heads + k];
+      const float dl = a * (dscore[(size_t)p * heads + k] - dot_sum);
+      const float sc = ali + ar[(size_t)col[p] * heads + k];
+      const float g = dl * (sc > 0.f ? 1.0f : slope);
+      dscore[(size_t)p * heads + k] = g;
+      s += g;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) dal[(size_t)row * heads + k] = s;
+  }
+}
+
+// backward, source side: dWx[j] = sum_{p leaving j} alpha_p dout[t_p];  dar[j] = sum_p dscore_p
+__global__ __launch_bounds__(256) void gat_bwd_source_kernel(int n_nodes, int heads, int c, const int *__restrict__ rowptr_s,
+                                                             const int *__restrict__ col_s, const int *__restrict__ xpos,
+                                                             const float *__restrict__ alpha, const float *__restrict__ dout,
+                                                             const float *__restrict__ dscore, float *__restrict__ dwx,
+                                                             float *__restrict__ dar) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr_s[row], re = rowptr_s[row + 1];
+  const int hc = heads * c;
+  for (int f = lane; f < hc; f += 64) {
+    const int k = f / c;
+    float acc = 0.f;
+    for (int q = rs; q < re; ++q) acc = fmaf(alpha[(size_t)xpos[q] * heads + k], dout[(size_t)col_s[q] * hc + f], acc);
+    dwx[(size_t)row * hc + f] = acc;
+  }
+  for (int k = lane; k < heads; k += 64) {
+    float s = 0.f;
+    for (int q = rs; q < re; ++q) s += dscore[(size_t)xpos[q] * heads + k];
+    dar[(size_t)row * heads + k] = s;
+  }
+}
+
+// score halves: al[n][k] = sum_c a[c][k] Wx[n][k*C + c];  ar with a[C + c][k]   (a is (2C x H) column-major)
+__global__ void gat_scores_kernel(int64_t n_nodes, int heads, int c, const float *__restrict__ wx, const float *__restrict__ a,
+                                  float *__restrict__ al, float *__restrict__ ar) {
+  const int64_t total = n_nodes * heads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / heads;
+    const int k = (int)(i % heads);
+    float sl = 0.f, sr = 0.f;
+    for (int cc = 0; cc < c; ++cc) {
+      const float w = wx[n * heads * c + k * c + cc];
+      sl = fmaf(a[(size_t)k * 2 * c + cc], w, sl);
+      sr = fmaf(a[(size_t)k * 2 * c + c + cc], w, sr);
+    }
+    al[i] = sl;
+    ar[i] = sr;
+  }
+}
+
+// pullback of gat_scores, part 1: dWx[n][k*C+c] += a_l[c][k] dal[n][k] + a_r[c][k] dar[n][k]
+__global__ void gat_scores_bwd_dwx_kernel(int64_t n_nodes, int heads, int c, const float *__restrict__ a,
+                                          const float *__restrict__ dal, const float *__restrict__ dar,
+                                          float *__restrict__ dwx) {
+  const int hc = heads * c;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * hc; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / hc;
+    const int f = (int)(i % hc), k = f / c, cc = f % c;
+    dwx[i] += a[(size_t)k * 2 * c + cc] * dal[n * heads + k] + a[(size_t)k * 2 * c + c + cc] * dar[n * heads + k];
+  }
+}
+
+// part 2: da[(which*C + c) + 2C*k] = sum_n Wx[n][k*C + c] * (which ? dar : dal)[n][k]; one block per element,
+// fixed-order tree reduction (deterministic)
+__global__ __launch_bounds__(256) void gat_scores_bwd_da_kernel(int64_t n_nodes, int heads, int c, const float *__restrict__ wx,
+                                                                const float *__restrict__ dal, const float *__restrict__ dar,
+                                                                float *__restrict__ da) {
+  __shared__ float red[256];
+  const int e = blockIdx.x;                 // 0 .. 2*c*heads - 1, laid out as a (2C x H) column-major matrix
+  const int k = e / (2 * c), r = e % (2 * c), which = r / c, cc = r % c;
+  const float *gsrc = which ? dar : dal;
+  float s = 0.f;
+  for (int64_t n = threadIdx.x; n < n_nodes; n += 256) s = fmaf(wx[n * heads * c + k * c + cc], gsrc[n * heads + k], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) da[e] = red[0];
+}
+
+// SpectralConv edge weights: w_e = 1/2 cos(n e / 2) cot(e / 2)   (src/layers.jl:654)
+__global__ void spectral_weight_kernel(int64_t n_edges, float nn, const float *__restrict__ e, float *__restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = e[i];
+    w[i] = cosf(v * nn * 0.5f) * (cosf(v * 0.5f) / sinf(v * 0.5f)) * 0.5f;
+  }
+}
+
+inline int blocks_for(int64_t count) { return (int)std::min<int64_t>((count + 255) / 256, 4096); }
+inline unsigned rows4(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+
+}  // namespace
+
+int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
+                             const float *bias, float *y, float *save_z, hipStream_t stream) {
+  if (n == 0 || dout == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(dense_seg_fwd_kernel, dim3((unsigned)((n + 15) / 16), (dout + 15) / 16), dim3(256), 0, stream, n, segs,
+                     din, dout, act, wt, bias, y, save_z);
+  NGPDE_LAUNCH_CHECK("dense_seg_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream) {
+  if (count == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(dense_dz_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, count, act, dy, z, dz);
+  NGPDE_LAUNCH_CHECK("dense_dz_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
+                                   hipStream_t stream) {
+  if (n == 0 || din == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(dense_seg_bwd_input_kernel, dim3((unsigned)((n + 15) / 16), (din + 15) / 16), dim3(256), 0, stream, n,
+                     segs, din, dout, dz, wt);
+  NGPDE_LAUNCH_CHECK("dense_seg_bwd_input_kernel");
+  return NGPDE_OK;
+}
+
+int dense_weight_chunks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 4095) / 4096)); }
+
+int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
+                                    float *db, float *partial, hipStream_t stream) {
+  if (dout == 0) return NGPDE_OK;
+  const int nchunk = dense_weight_chunks(n);
+  const int64_t rpc = (((n + nchunk - 1) / nchunk) + 15) / 16 * 16;
+  hipLaunchKernelGGL(dense_seg_bwd_weight_kernel, dim3((din + 1 + 15) / 16, (dout + 15) / 16, nchunk), dim3(256), 0, stream,
+                     n, segs, din, dout, dz, std::max<int64_t>(rpc, 16), partial);
+  NGPDE_LAUNCH_CHECK("dense_seg_bwd_weight_kernel");
+  const int total = (din + 1) * dout;
+  hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, nchunk, din, dout, partial,
+                     dwt, db);
+  NGPDE_LAUNCH_CHECK("dense_weight_reduce_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_edge_permute(const ngpde_graph *g, int d, bool inverse, const float *src, float *dst, hipStream_t stream) {
+  if (g->n_edges == 0 || d == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(edge_permute_kernel, dim3(blocks_for(g->n_edges * d)), dim3(256), 0, stream, g->n_edges, d, g->by_t.eid,
+                     inverse ? 1 : 0, src, dst);
+  NGPDE_LAUNCH_CHECK("edge_permute_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_edge_combine_fwd(const ngpde_graph *g, int h, int act, const float *P, const float *Q, const float *Eterm,
+                                float *a_out, float *z_out, hipStream_t stream) {
+  if (g->n_nodes == 0 || h == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(edge_combine_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h, act,
+                     g->by_t.rowptr, g->by_t.col, P, Q, Eterm, a_out, z_out);
+  NGPDE_LAUNCH_CHECK("edge_combine_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_edge_combine_bwd(const ngpde_graph *g, int h, int act, const float *da, const float *z, float *dz, float *dP,
+                                float *dQ, hipStream_t stream) {
+  if (g->n_nodes == 0 || h == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(edge_combine_bwd_target_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h, act,
+                     g->by_t.rowptr, da, z, dz, dP);
+  NGPDE_LAUNCH_CHECK("edge_combine_bwd_target_kernel");
+  if (dQ) {
+    hipLaunchKernelGGL(edge_sum_by_source_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h,
+                       g->by_s.rowptr, g->by_s.xpos, dz, dQ);
+    NGPDE_LAUNCH_CHECK("edge_sum_by_source_kernel");
+  }
+  return NGPDE_OK;
+}
+
+int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_edge, float *out, hipStream_t stream) {
+  if (g->n_nodes == 0 || h == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(edge_sum_by_source_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h,
+                     g->by_s.rowptr, g->by_s.xpos, per_edge, out);
+  NGPDE_LAUNCH_CHECK("edge_sum_by_source_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_segment_reduce_fwd(const ngpde_graph *g, int d, int aggr, const float *M, float *out, hipStream_t stream) {
+  if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(segment_reduce_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, d, aggr,
+                     g->by_t.rowptr, M, out);
+  NGPDE_LAUNCH_CHECK("segment_reduce_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_segment_reduce_bwd(const ngpde_graph *g, int d, int aggr, const float *M, const float *out, const float *dout,
+                                  float *dM, hipStream_t stream) {
+  if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(segment_reduce_bwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, d, aggr,
+                     g->by_t.rowptr, M, out, dout, dM);
+  NGPDE_LAUNCH_CHECK("segment_reduce_bwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gno_contract_fwd(const ngpde_graph *g, int cin, int cout, const float *K, const float *h, float *m,
+                                hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gno_contract_fwd_kernel, dim3(rows4(g->n_edges)), dim3(256), 0, stream, g->n_edges, cin, cout,
+                     g->by_t.col, K, h, m);
+  NGPDE_LAUNCH_CHECK("gno_contract_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gno_contract_bwd(const ngpde_graph *g, int cin, int cout, const float *K, const float *h, const float *dm,
+                                float *dK, float *dhe, hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gno_contract_bwd_kernel, dim3(rows4(g->n_edges)), dim3(256), 0, stream, g->n_edges, cin, cout,
+                     g->by_t.col, K, h, dm, dK, dhe);
+  NGPDE_LAUNCH_CHECK("gno_contract_bwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const float *a, float *al, float *ar,
+                          hipStream_t stream) {
+  if (n == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gat_scores_kernel, dim3(blocks_for(n * heads)), dim3(256), 0, stream, n, heads, c, wx, a, al, ar);
+  NGPDE_LAUNCH_CHECK("gat_scores_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
+                       float *out, float *alpha, hipStream_t stream) {
+  if (g->n_nodes == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gat_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, heads, c, slope,
+                     g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha);
+  NGPDE_LAUNCH_CHECK("gat_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gat_bwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *a, const float *al,
+                       const float *ar, const float *alpha, const float *dout, float *dscore, float *dal, float *dar,
+                       float *dwx, float *da, hipStream_t stream) {
+  if (g->n_nodes == 0) return NGPDE_OK;
+  const int n = (int)g->n_nodes;
+  hipLaunchKernelGGL(gat_bwd_target_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, slope, g->by_t.rowptr,
+                     g->by_t.col, wx, al, ar, alpha, dout, dscore, dal);
+  NGPDE_LAUNCH_CHECK("gat_bwd_target_kernel");
+  hipLaunchKernelGGL(gat_bwd_source_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, g->by_s.rowptr, g->by_s.col,
+                     g->by_s.xpos, alpha, dout, dscore, dwx, dar);
+  NGPDE_LAUNCH_CHECK("gat_bwd_source_kernel");
+  hipLaunchKernelGGL(gat_scores_bwd_dwx_kernel, dim3(blocks_for((int64_t)n * heads * c)), dim3(256), 0, stream, (int64_t)n,
+                     heads, c, a, dal, dar, dwx);
+  NGPDE_LAUNCH_CHECK("gat_scores_bwd_dwx_kernel");
+  hipLaunchKernelGGL(gat_scores_bwd_da_kernel, dim3(2 * c * heads), dim3(256), 0, stream, (int64_t)n, heads, c, wx, dal, dar,
+                     da);
+  NGPDE_LAUNCH_CHECK("gat_scores_bwd_da_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_spectral_weights(int64_t n_edges, float nn, const float *e, float *w, hipStream_t stream) {
+  if (n_edges == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(spectral_weight_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, n_edges, nn, e, w);
+  NGPDE_LAUNCH_CHECK("spectral_weight_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde

@@ -78,3 +78,263 @@ def propagate_copy_xj(x, handle, aggr="+", edge_weight=None, by_source=False):
     _lib.check(lib.ngpde_propagate_copy_xj(handle.ptr, x.shape[1], _lib.AGGR[aggr], int(by_source), _lib.ptr(x),
                                            _lib.ptr(edge_weight), _lib.ptr(out), _lib.current_stream()))
     return out
+
+
+# ---- message-passing primitives (include/ngpde.h, "Message-passing primitives") ---------------------------
+
+
+def _ptr_array(tensors):
+    import ctypes as C
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _int_array(vals):
+    import ctypes as C
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+class _DenseFn(torch.autograd.Function):
+    """y = act([X1 | X2 | ...] Wt + b): Lux Dense on a virtual vcat (no concatenation temporary)."""
+
+    @staticmethod
+    def forward(ctx, wt, bias, act, row_divs, n, *blocks):
+        lib = _lib.load()
+        _need_cuda(wt, bias, *blocks)
+        blocks = [b.contiguous() for b in blocks]
+        wt = wt.contiguous()
+        widths = [b.shape[1] for b in blocks]
+        din, dout = sum(widths), wt.shape[1]
+        if wt.shape[0] != din:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: Dense expects {wt.shape[0]} input features, got {din}")
+        for b, rd in zip(blocks, row_divs):
+            if b.shape[0] * rd != n and not (rd > 1 and b.shape[0] * rd >= n):
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                             f"DimensionMismatch: block with {b.shape[0]} rows (x{rd}) does not cover {n} rows")
+        dev = wt.device
+        y = torch.empty((n, dout), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        z = torch.empty_like(y) if (need and act != 0) else None
+        _lib.check(lib.ngpde_dense_forward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs),
+                                           dout, act, _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
+                                           _lib.current_stream()))
+        ctx.meta = (act, tuple(row_divs), n, widths, dout, bias is not None)
+        ctx.save_for_backward(wt, z, *blocks)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        act, row_divs, n, widths, dout, has_bias = ctx.meta
+        wt, z, *blocks = ctx.saved_tensors
+        dy = dy.contiguous()
+        dev = wt.device
+        dwt = torch.empty_like(wt)
+        db = torch.empty((dout,), dtype=torch.float32, device=dev) if has_bias else None
+        dblocks = [torch.empty_like(b) if (ctx.needs_input_grad[5 + i] and row_divs[i] == 1) else None
+                   for i, b in enumerate(blocks)]
+        ws = _ws(lib.ngpde_dense_workspace_bytes(n, sum(widths), dout), dev)
+        _lib.check(lib.ngpde_dense_backward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs),
+                                            dout, act, _lib.ptr(wt), _lib.ptr(z), _lib.ptr(dy), _ptr_array(dblocks),
+                                            _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return (dwt, db, None, None, None, *dblocks)
+
+
+def dense(blocks, wt, bias, act, row_divs=None, n=None):
+    """blocks: list of [n_i][w_i] tensors; wt [sum w][dout]; returns [n][dout]."""
+    row_divs = list(row_divs) if row_divs is not None else [1] * len(blocks)
+    if n is None:
+        n = next(b.shape[0] for b, rd in zip(blocks, row_divs) if rd == 1)
+    return _DenseFn.apply(wt, bias, act, tuple(row_divs), int(n), *blocks)
+
+
+class _EdgePermuteFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, handle, inverse):
+        lib = _lib.load()
+        _need_cuda(x)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.check(lib.ngpde_edge_permute(handle.ptr, x.shape[1], int(inverse), _lib.ptr(x), _lib.ptr(out),
+                                          _lib.current_stream()))
+        ctx.handle, ctx.inverse = handle, inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _EdgePermuteFn.apply(g.contiguous(), ctx.handle, not ctx.inverse), None, None
+
+
+def edge_permute(x, handle, inverse=False):
+    """[E][d] COO order -> p order (CSR by target); inverse=True for the way back."""
+    return _EdgePermuteFn.apply(x, handle, inverse)
+
+
+class _EdgeCombineFn(torch.autograd.Function):
+    """a_p = act(P[t_p] + Q[s_p] + E_p): gather at t + gather at s + first Dense layer of the message MLP."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, handle, act, n_edges):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm)
+        ref = next(t for t in (P, Q, Eterm) if t is not None)
+        h = ref.shape[1]
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        a = torch.empty((n_edges, h), dtype=torch.float32, device=ref.device)
+        z = torch.empty_like(a) if act != 0 else None
+        _lib.check(lib.ngpde_edge_combine_forward(handle.ptr, h, act, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(a),
+                                                  _lib.ptr(z), _lib.current_stream()))
+        ctx.handle, ctx.act, ctx.h = handle, act, h
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None)
+        ctx.save_for_backward(z)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        da = da.contiguous()
+        ps, qs, has_e = ctx.shapes
+        dev = da.device
+        dz = torch.empty_like(da)
+        dP = torch.empty(ps, dtype=torch.float32, device=dev) if (ps is not None and ctx.needs_input_grad[0]) else None
+        dQ = torch.empty(qs, dtype=torch.float32, device=dev) if (qs is not None and ctx.needs_input_grad[1]) else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, ctx.h, ctx.act, _lib.ptr(da), _lib.ptr(z), _lib.ptr(dz),
+                                                   _lib.ptr(dP), _lib.ptr(dQ), _lib.current_stream()))
+        return dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), None, None, None
+
+
+def edge_combine(P, Q, Eterm, handle, act, n_edges):
+    return _EdgeCombineFn.apply(P, Q, Eterm, handle, act, n_edges)
+
+
+class _SegmentReduceFn(torch.autograd.Function):
+    """aggregate_neighbors(g, aggr, m): segmented reduction over each node's incoming edges."""
+
+    @staticmethod
+    def forward(ctx, M, handle, aggr, n_nodes):
+        lib = _lib.load()
+        _need_cuda(M)
+        M = M.contiguous()
+        d = M.shape[1]
+        out = torch.empty((n_nodes, d), dtype=torch.float32, device=M.device)
+        _lib.check(lib.ngpde_segment_reduce_forward(handle.ptr, d, aggr, _lib.ptr(M), _lib.ptr(out), _lib.current_stream()))
+        ctx.handle, ctx.aggr, ctx.d = handle, aggr, d
+        ctx.save_for_backward(M, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        M, out = ctx.saved_tensors
+        dout = dout.contiguous()
+        dM = torch.empty_like(M)
+        _lib.check(lib.ngpde_segment_reduce_backward(ctx.handle.ptr, ctx.d, ctx.aggr, _lib.ptr(M), _lib.ptr(out),
+                                                     _lib.ptr(dout), _lib.ptr(dM), _lib.current_stream()))
+        return dM, None, None, None
+
+
+def segment_reduce(M, handle, aggr, n_nodes):
+    return _SegmentReduceFn.apply(M, handle, _lib.AGGR[aggr] if isinstance(aggr, str) else aggr, n_nodes)
+
+
+class _GnoContractFn(torch.autograd.Function):
+    """m_e = reshape(K_e, out, in) * h[:, s_e]   (NNlib.batched_mul, src/layers.jl:527-530)."""
+
+    @staticmethod
+    def forward(ctx, K, h, handle, cin, cout):
+        lib = _lib.load()
+        _need_cuda(K, h)
+        K, h = K.contiguous(), h.contiguous()
+        m = torch.empty((K.shape[0], cout), dtype=torch.float32, device=K.device)
+        _lib.check(lib.ngpde_gno_contract_forward(handle.ptr, cin, cout, _lib.ptr(K), _lib.ptr(h), _lib.ptr(m),
+                                                  _lib.current_stream()))
+        ctx.handle, ctx.dims = handle, (cin, cout)
+        ctx.save_for_backward(K, h)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        K, h = ctx.saved_tensors
+        cin, cout = ctx.dims
+        dm = dm.contiguous()
+        dK = torch.empty_like(K) if ctx.needs_input_grad[0] else None
+        dh = torch.empty_like(h) if ctx.needs_input_grad[1] else None
+        ws = _ws(K.shape[0] * cin * 4, K.device)
+        _lib.check(lib.ngpde_gno_contract_backward(ctx.handle.ptr, cin, cout, _lib.ptr(K), _lib.ptr(h), _lib.ptr(dm),
+                                                   _lib.ptr(dK), _lib.ptr(dh), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return dK, dh, None, None, None
+
+
+def gno_contract(K, h, handle, cin, cout):
+    return _GnoContractFn.apply(K, h, handle, cin, cout)
+
+
+class _GatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wx, a, handle, heads, c, slope, n_edges):
+        lib = _lib.load()
+        _need_cuda(wx, a)
+        wx, a = wx.contiguous(), a.contiguous()
+        n = wx.shape[0]
+        dev = wx.device
+        out = torch.empty_like(wx)
+        alpha = torch.empty((max(n_edges, 1), heads), dtype=torch.float32, device=dev)
+        al = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        ar = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gat_forward(handle.ptr, heads, c, slope, _lib.ptr(wx), _lib.ptr(a), _lib.ptr(out), _lib.ptr(alpha),
+                                         _lib.ptr(al), _lib.ptr(ar), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (heads, c, slope)
+        ctx.save_for_backward(wx, a, al, ar, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        wx, a, al, ar, alpha = ctx.saved_tensors
+        heads, c, slope = ctx.meta
+        dout = dout.contiguous()
+        dwx, da = torch.empty_like(wx), torch.empty_like(a)
+        ws = _ws(lib.ngpde_gat_workspace_bytes(ctx.handle.ptr, heads), wx.device)
+        _lib.check(lib.ngpde_gat_backward(ctx.handle.ptr, heads, c, slope, _lib.ptr(wx), _lib.ptr(a), _lib.ptr(al), _lib.ptr(ar),
+                                          _lib.ptr(alpha), _lib.ptr(dout), _lib.ptr(dwx), _lib.ptr(da), _lib.ptr(ws),
+                                          ws.numel(), _lib.current_stream()))
+        return dwx, da, None, None, None, None, None
+
+
+def gat_aggregate(wx, a, handle, heads, c, slope, n_edges):
+    return _GatFn.apply(wx, a, handle, heads, c, float(slope), n_edges)
+
+
+class _PropagateFn(torch.autograd.Function):
+    """propagate(e_mul_xj / copy_xj, g, +) with its pullback (the transposed aggregation)."""
+
+    @staticmethod
+    def forward(ctx, x, handle, edge_weight):
+        ctx.handle = handle
+        ctx.save_for_backward(edge_weight)
+        return propagate_copy_xj(x, handle, "+", edge_weight, by_source=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        return propagate_copy_xj(dy.contiguous(), ctx.handle, "+", w, by_source=True), None, None
+
+
+def propagate_sum(x, handle, edge_weight=None):
+    return _PropagateFn.apply(x, handle, edge_weight)
+
+
+def spectral_weights(e, n):
+    lib = _lib.load()
+    _need_cuda(e)
+    e = e.contiguous().reshape(-1)
+    w = torch.empty_like(e)
+    _lib.check(lib.ngpde_spectral_weights(e.numel(), int(n), _lib.ptr(e), _lib.ptr(w), _lib.current_stream()))
+    return w

@@ -133,20 +133,26 @@ class AbstractGNNContainerLayer(AbstractGNNLayer):
 
     layers = ()
 
+    def sublayer(self, name):
+        # Python NFKC-normalises identifiers (the reference's field name U+03D5 becomes U+03C6 as an
+        # attribute); parameter / state KEYS keep the reference's spelling.
+        import unicodedata
+        return getattr(self, unicodedata.normalize("NFKC", name))
+
     def initialstates(self, rng):                      # src/layers.jl:26-30: sub-layer states, then graph
-        st = {name: getattr(self, name).initialstates(rng) for name in self.layers}
+        st = {name: self.sublayer(name).initialstates(rng) for name in self.layers}
         st["graph"] = self.initialgraph()
         return st
 
     def statelength(self):                             # src/layers.jl:32-34
-        return sum(getattr(self, name).statelength() for name in self.layers) + 1
+        return sum(self.sublayer(name).statelength() for name in self.layers) + 1
 
     def initialparameters(self, rng):
         # Lux 0.4: a container with ONE sub-layer field gets that layer's parameters un-nested
         # (docs/src/devdoc.md:74-88); otherwise NamedTuple{layers}
         if len(self.layers) == 1:
-            return getattr(self, self.layers[0]).initialparameters(rng)
-        return {name: getattr(self, name).initialparameters(rng) for name in self.layers}
+            return self.sublayer(self.layers[0]).initialparameters(rng)
+        return {name: self.sublayer(name).initialparameters(rng) for name in self.layers}
 
 
 class Dense(AbstractExplicitLayer):
@@ -168,6 +174,14 @@ class Dense(AbstractExplicitLayer):
 
     def parameterlength(self):
         return self.out_dims * (self.in_dims + (1 if self.bias else 0))
+
+    def __call__(self, x, ps, st):
+        xr = rows_of(x)
+        if xr.shape[1] != self.in_dims:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: Dense({self.in_dims} => {self.out_dims}) got {xr.shape[1]} rows")
+        b = ps["bias"].reshape(-1) if "bias" in ps else None
+        return F.dense([xr], rows_of(ps["weight"]), b, self.act).T, st
 
     def __repr__(self):
         return f"Dense({self.in_dims} => {self.out_dims}" + ("" if self.activation == "identity" else f", {self.activation}") + ")"

@@ -1,0 +1,410 @@
+"""GPU parity tests of the edge-function layers (ExplicitEdgeConv, VMHConv, MPPDEConv, GNOConv, SpectralConv,
+GATConv) and of Dense/Chain: HIP primitives through the C ABI against the float64 numpy oracle, on the
+reference's own test cases (/root/reference/test/runtests.jl:27-162) and on larger random graphs.
+
+Tolerances: forward 1e-4 * max|ref| + 1e-5, gradients 5e-4 relative (chains of 2-4 fp32 dense layers).
+"""
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+from oracle import ngpde_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(a, ref, rtol=1e-4, atol=1e-5, what=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    err = np.abs(a - ref).max() if ref.size else 0.0
+    bound = rtol * (np.abs(ref).max() if ref.size else 0.0) + atol
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e}"
+
+
+def omlp(layer, ps):
+    """oracle form of a Dense / Chain-of-Dense with the layer's current parameters"""
+    if isinstance(layer, ng.Dense):
+        pairs = [(layer, ps)]
+    else:
+        pairs = [(l, ps[n]) for n, l in zip(layer.names(), layer.chain)]
+    return [dict(weight=p["weight"].detach().cpu().double().numpy(),
+                 bias=p["bias"].detach().cpu().double().numpy() if "bias" in p else None, act=l.activation)
+            for l, p in pairs]
+
+
+def leaves(ps, prefix=""):
+    for k, v in ps.items():
+        if isinstance(v, dict):
+            yield from leaves(v, prefix + k + ".")
+        else:
+            yield prefix + k, v
+
+
+def prep(ps, seed):
+    """device copy with random biases and requires_grad"""
+    rng = np.random.default_rng(seed)
+    ps = ng.to_device(ps, DEV)
+
+    def walk(d):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v)
+            else:
+                if k == "bias":
+                    d[k] = torch.as_tensor(rng.normal(size=tuple(v.shape)).astype(np.float32) * 0.3, device=DEV)
+                d[k].requires_grad_(True)
+    walk(ps)
+    return ps
+
+
+def rgraph(N, E, seed, **kw):
+    rng = np.random.default_rng(seed)
+    s, t = rng.integers(0, N, E), rng.integers(0, N, E)
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0, **kw), O.Graph(s, t, num_nodes=N, index_base=0, **kw)
+
+
+def check_grads(ps, ogr_list, x, dx):
+    close(x.grad, dx, rtol=5e-4, atol=1e-4, what="dx")
+    for (name, p), og in zip(ogr_list[0], ogr_list[1]):
+        close(p.grad, og, rtol=5e-4, atol=2e-4, what=f"d{name}")
+
+
+def mlp_grad_pairs(ps_sub, ograds, layer):
+    """[(name, tensor)], [oracle grads] for a Dense / Chain sub-tree"""
+    names, og = [], []
+    if isinstance(layer, ng.Dense):
+        pairs = [("", ps_sub)]
+    else:
+        pairs = [(n + ".", ps_sub[n]) for n in layer.names()]
+    for (pref, p), g in zip(pairs, ograds):
+        names.append((pref + "weight", p["weight"])); og.append(g["weight"])
+        if "bias" in p:
+            names.append((pref + "bias", p["bias"])); og.append(g["bias"])
+    return names, og
+
+
+# ---- SpectralConv: the reference's own known-answer test, on the GPU ------------------------------------------
+
+def test_spectralconv_reference_known_answer():
+    # /root/reference/test/runtests.jl:153-162
+    s = ng.SpectralConv(100)
+    ps, st = ng.setup(0, s)
+    assert ps == {} and st["graph"].num_edges == 100 * 99
+    x = torch.linspace(0, 2 * np.pi, 101, dtype=torch.float32, device=DEV)[1:]
+    e1 = s(torch.sin(x), ps, st)[0] - torch.cos(x)
+    e2 = s(torch.cos(x), ps, st)[0] + torch.sin(x)
+    assert float((e1 ** 2).sum()) < 1e-3 and float((e2 ** 2).sum()) < 1e-3
+    # matrix input and gradient (the operator is antisymmetric: pullback = - forward)
+    X = torch.randn(3, 100, device=DEV, requires_grad=True)
+    Y, _ = s(X, ps, st)
+    og = O.spectral_graph(100)
+    close(Y, O.spectral_conv(X.detach().cpu().double().numpy(), og, 100), rtol=2e-4, atol=1e-4)
+    R = torch.randn_like(Y)
+    (Y * R).sum().backward()
+    close(X.grad, -O.spectral_conv(R.cpu().double().numpy(), og, 100), rtol=2e-4, atol=1e-3)
+
+
+# ---- Dense / Chain ----------------------------------------------------------------------------------------------------
+
+def test_dense_chain_parity():
+    model = ng.Chain(ng.Dense(7, 20, "tanh"), ng.Dense(20, 33, "swish"), ng.Dense(33, 5, bias=False))
+    ps, st = ng.setup(1, model)
+    assert list(ps["layer_3"]) == ["weight"]
+    ps = prep(ps, 1)
+    x = torch.randn(7, 1000, device=DEV, requires_grad=True)
+    y, _ = model(x, ps, st)
+    yo, cache = O.mlp_forward(omlp(model, ps), x.detach().cpu().double().numpy())
+    close(y, yo)
+    R = np.random.default_rng(0).normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    dx, gr = O.mlp_backward(omlp(model, ps), cache, R)
+    names, og = mlp_grad_pairs(ps, gr, model)
+    check_grads(ps, (names, og), x, dx)
+
+
+# ---- ExplicitEdgeConv ---------------------------------------------------------------------------------------------------
+
+def test_edgeconv_reference_fixture():
+    # test/runtests.jl:27-37
+    g = ng.GNNGraph([1, 1, 2, 3], [2, 3, 1, 1])
+    pos = np.random.default_rng(0).random((3, 3)).astype(np.float32)
+    gh = ng.GNNGraph(g, ndata={"x": pos})
+    l = ng.ExplicitEdgeConv(ng.Dense(4 + 4 + 3, 5), initialgraph=gh)
+    ps, st = ng.setup(0, l)
+    assert st == {"ϕ": {}, "graph": gh} and list(ps) == ["weight", "bias"]     # single sub-layer: params un-nested
+    u = torch.randn(4, 3, device=DEV)
+    y, _ = l(u, ng.to_device(ps, DEV), st)
+    assert tuple(y.shape) == (5, 3)
+    og = O.Graph([1, 1, 2, 3], [2, 3, 1, 1], ndata={"x": pos.astype(np.float64)})
+    yo, _ = O.explicit_edge_conv(u.cpu().double().numpy(), omlp(l.ϕ, ps), og)
+    close(y, yo)
+
+
+@pytest.mark.parametrize("aggr", ["mean", "+", "max"])
+def test_edgeconv_parity_and_grads(aggr):
+    N, E, h = 300, 2500, 6
+    rng = np.random.default_rng(3)
+    nd = {"x": rng.random((2, N))}
+    g, og = rgraph(N, E, 3, ndata=nd)
+    phi = ng.Chain(ng.Dense(2 * h + 2, 16, "tanh"), ng.Dense(16, 9, "tanh"))
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr=aggr)
+    ps, st = ng.setup(3, l)
+    ps = prep(ps, 3)
+    x = torch.randn(h, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, aggr)
+    if aggr == "max":
+        yo = np.where(np.isfinite(yo), yo, 0.0)
+        yv = torch.where(torch.isfinite(y), y, torch.zeros_like(y))
+        close(yv, yo)
+        return
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    check_grads(ps, (names, ogr), x, gr["x"])
+
+
+# ---- VMHConv ---------------------------------------------------------------------------------------------------------------
+
+def test_vmh_reference_fixture_and_parity():
+    # test/runtests.jl:39-54
+    g = ng.GNNGraph([1, 1, 2, 3], [2, 3, 1, 1])
+    pos = np.random.default_rng(0).random((3, 3)).astype(np.float32)
+    gh = ng.GNNGraph(g, ndata={"x": pos})
+    l = ng.VMHConv(ng.Dense(4 + 4 + 3, 5), ng.Dense(5 + 4, 7), initialgraph=gh)
+    ps, st = ng.setup(0, l)
+    assert st == {"ϕ": {}, "γ": {}, "graph": gh} and list(ps) == ["ϕ", "γ"]
+    u = torch.randn(4, 3, device=DEV)
+    y, _ = l(u, ng.to_device(ps, DEV), st)
+    assert tuple(y.shape) == (7, 3)
+    og = O.Graph([1, 1, 2, 3], [2, 3, 1, 1], ndata={"x": pos.astype(np.float64)})
+    yo, _ = O.vmh_conv(u.cpu().double().numpy(), omlp(l.ϕ, ps["ϕ"]), omlp(l.γ, ps["γ"]), og)
+    close(y, yo)
+
+
+def test_vmh_tutorial_shape_parity_and_grads():
+    # docs/src/tutorials/VMH.md:75-83: h = 1, pos = 2, 4-layer tanh MLPs 60 wide, message width 40
+    N, E = 400, 3000
+    rng = np.random.default_rng(5)
+    g, og = rgraph(N, E, 5, ndata={"x": rng.random((2, N))})
+    phi = ng.Chain(ng.Dense(4, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 40))
+    gam = ng.Chain(ng.Dense(41, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 1))
+    l = ng.VMHConv(phi, gam, initialgraph=g)
+    ps, st = ng.setup(5, l)
+    ps = prep(ps, 5)
+    x = torch.randn(1, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.vmh_conv(x.detach().cpu().double().numpy(), omlp(phi, ps["ϕ"]), omlp(gam, ps["γ"]), og)
+    close(y, yo, rtol=2e-4)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.vmh_conv_backward(c, R)
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+    n2, o2 = mlp_grad_pairs(ps["γ"], gr["gamma"], gam)
+    check_grads(ps, (n1 + n2, o1 + o2), x, gr["x"])
+
+
+# ---- MPPDEConv: the four variants of the reference's tests ----------------------------------------------------------------
+
+def mppde_case(gh, ogh, dphi_in, dpsi_in, N, seed=0, h=5):
+    l = ng.MPPDEConv(ng.Dense(dphi_in, 5), ng.Dense(dpsi_in, 7), initialgraph=gh)
+    ps, st = ng.setup(seed, l)
+    assert st["graph"] == gh
+    hh = torch.randn(h, N, device=DEV)
+    y, st2 = l(hh, ng.to_device(ps, DEV), st)
+    assert tuple(y.shape) == (7, N) and st2["graph"] == gh
+    yo, _ = O.mppde_conv(hh.cpu().double().numpy(), omlp(l.ϕ, ps["ϕ"]), omlp(l.ψ, ps["ψ"]), ogh)
+    close(y, yo)
+
+
+def test_mppde_reference_variants():
+    rng = np.random.default_rng(0)
+    s, t = [1, 1, 2, 3], [2, 3, 1, 1]
+    u, x, th = rng.random((2, 3)), rng.random((3, 3)), rng.random(4)       # Float64 graph data, as in the reference tests
+    # with theta (:57-73)
+    mppde_case(ng.GNNGraph(s, t, ndata={"u": u, "x": x}, gdata={"θ": th}),
+               O.Graph(s, t, ndata={"u": u, "x": x}, gdata={"θ": th}), 5 + 5 + 2 + 3 + 4, 5 + 5 + 4, 3)
+    # features in edata (:75-87)
+    eu, ex = rng.random((2, 4)), rng.random((3, 4))
+    mppde_case(ng.GNNGraph(s, t, edata={"u": eu, "x": ex}, gdata={"θ": th}),
+               O.Graph(s, t, edata={"u": eu, "x": ex}, gdata={"θ": th}), 5 + 5 + 2 + 3 + 4, 5 + 5 + 4, 3)
+    # batched graph (:89-102)
+    g1 = ng.GNNGraph(s, t, ndata={"u": u, "x": x}, gdata={"θ": th})
+    o1 = O.Graph(s, t, ndata={"u": u, "x": x}, gdata={"θ": th})
+    mppde_case(ng.batch([g1, g1.copy()]), O.batch([o1, o1.copy()]), 19, 14, 6)
+    # without theta (:104-120)
+    mppde_case(ng.GNNGraph(s, t, ndata={"u": u, "x": x}), O.Graph(s, t, ndata={"u": u, "x": x}), 15, 10, 3)
+
+
+@pytest.mark.parametrize("aggr", ["mean", "+"])
+def test_mppde_batched_parity_and_grads(aggr):
+    # C4-like structure at test size: periodic 1-D mesh, 3 neighbours each side, several trajectories, h = 16
+    n, G, h = 64, 5, 16
+    idx = np.arange(n)
+    s = np.concatenate([idx for k in (-3, -2, -1, 1, 2, 3)])
+    t = np.concatenate([(idx + k) % n for k in (-3, -2, -1, 1, 2, 3)])
+    rng = np.random.default_rng(7)
+    gs, ogs = [], []
+    for _ in range(G):
+        nd = {"u": rng.random((1, n)), "x": (idx / n).reshape(1, n)}
+        gd = {"θ": rng.random(2)}
+        gs.append(ng.GNNGraph(s, t, num_nodes=n, index_base=0, ndata=nd, gdata=gd))
+        ogs.append(O.Graph(s, t, num_nodes=n, index_base=0, ndata=nd, gdata=gd))
+    g, og = ng.batch(gs), O.batch(ogs)
+    phi = ng.Chain(ng.Dense(2 * h + 2 + 2, 32, "swish"), ng.Dense(32, 24, "swish"))
+    psi = ng.Chain(ng.Dense(h + 24 + 2, 32, "swish"), ng.Dense(32, h))
+    l = ng.MPPDEConv(phi, psi, initialgraph=g, aggr=aggr)
+    ps, st = ng.setup(7, l)
+    ps = prep(ps, 7)
+    N = n * G
+    x = torch.randn(h, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.mppde_conv(x.detach().cpu().double().numpy(), omlp(phi, ps["ϕ"]), omlp(psi, ps["ψ"]), og, aggr)
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.mppde_conv_backward(c, R)
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+    n2, o2 = mlp_grad_pairs(ps["ψ"], gr["psi"], psi)
+    check_grads(ps, (n1 + n2, o1 + o2), x, gr["x"])
+    # block-diagonal batching == per-graph evaluation
+    l1 = ng.MPPDEConv(phi, psi, initialgraph=gs[2], aggr=aggr)
+    y1, _ = l1(x.detach()[:, 2 * n:3 * n], ps, ng.setup(0, l1)[1])
+    assert torch.allclose(y1, y.detach()[:, 2 * n:3 * n], rtol=1e-5, atol=1e-6)
+
+
+def test_mppde_structure_mismatch_is_rejected():
+    g1 = ng.GNNGraph([1, 2], [2, 1], num_nodes=2, gdata={"θ": np.ones(1)})
+    g2 = ng.GNNGraph([1, 2, 3], [2, 3, 1], num_nodes=4, gdata={"θ": np.ones(1)})
+    gb = ng.batch([g1, g2])        # 6 nodes, 5 edges, 2 graphs: edges do not split evenly
+    l = ng.MPPDEConv(ng.Dense(4 + 4 + 1, 3), ng.Dense(4 + 3 + 1, 2), initialgraph=gb)
+    ps, st = ng.setup(0, l)
+    with pytest.raises(ng.DimensionMismatch):
+        l(torch.randn(4, 6, device=DEV), ng.to_device(ps, DEV), st)
+
+
+# ---- GNOConv --------------------------------------------------------------------------------------------------------------------
+
+def test_gno_reference_case_and_updategraph():
+    # test/runtests.jl:123-151
+    gh = ng.rand_graph(10, 6, seed=0)
+    rng = np.random.default_rng(0)
+    a, xx = rng.random((2, 10)), rng.random((3, 10))
+    gh = ng.GNNGraph(gh, ndata={"a": a, "x": xx})
+    s, t = gh.edge_index(0)
+    cin, cout = 5, 7
+    phi = ng.Dense(2 + 2 + 3 + 3, cin * cout)
+    l = ng.GNOConv((cin, cout), phi, initialgraph=gh)
+    ps, st = ng.setup(0, l)
+    assert list(ps) == ["linear", "ϕ"] and list(st) == ["linear", "ϕ", "graph"]
+    h = torch.randn(cin, 10, device=DEV)
+    psd = ng.to_device(ps, DEV)
+    y, st = l(h, psd, st)
+    assert tuple(y.shape) == (cout, 10)
+    og = O.Graph(s, t, num_nodes=10, index_base=0, ndata={"a": a, "x": xx})
+    W, b = ps["linear"]["weight"].double().numpy(), ps["linear"]["bias"].double().numpy()
+    yo, _ = O.gno_conv(h.cpu().double().numpy(), omlp(phi, ps["ϕ"]), W, b, og, cin, cout)
+    close(y, yo)
+    # positional constructor form GNOConv(in, out, ϕ)  (:494)
+    assert ng.GNOConv(cin, cout, phi).out_chs == cout
+    # swap in a graph that carries the kernel inputs as edge features (:145-150)
+    e = rng.random((10, 6))
+    ge = ng.GNNGraph(gh, ndata={}, edata=e)
+    st = ng.updategraph(st, ge)
+    y2, _ = l(h, psd, st)
+    assert tuple(y2.shape) == (cout, 10)
+    oge = O.Graph(s, t, num_nodes=10, index_base=0, edata=e)
+    yo2, _ = O.gno_conv(h.cpu().double().numpy(), omlp(phi, ps["ϕ"]), W, b, oge, cin, cout)
+    close(y2, yo2)
+
+
+def test_gno_parity_and_grads():
+    N, E, cin, cout = 120, 900, 6, 5
+    rng = np.random.default_rng(11)
+    nd = {"a": rng.random((1, N)), "x": rng.random((2, N))}
+    g, og = rgraph(N, E, 11, ndata=nd)
+    phi = ng.Chain(ng.Dense(6, 16, "relu"), ng.Dense(16, cin * cout))
+    l = ng.GNOConv((cin, cout), phi, "tanh", initialgraph=g)
+    ps, st = ng.setup(11, l)
+    ps = prep(ps, 11)
+    x = torch.randn(cin, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    W, b = ps["linear"]["weight"].detach().cpu().double().numpy(), ps["linear"]["bias"].detach().cpu().double().numpy()
+    yo, c = O.gno_conv(x.detach().cpu().double().numpy(), omlp(phi, ps["ϕ"]), W, b, og, cin, cout, "tanh")
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.gno_conv_backward(c, R)
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+    names = n1 + [("linear.weight", ps["linear"]["weight"]), ("linear.bias", ps["linear"]["bias"])]
+    check_grads(ps, (names, o1 + [gr["weight"], gr["bias"]]), x, gr["x"])
+
+
+# ---- GAT-style layer -----------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_gat_parity_and_grads(concat):
+    N, E, H, C, Din = 500, 4000, 4, 16, 64          # config 3 shape at test size: 64 => 4 heads x 16
+    rng = np.random.default_rng(13)
+    g, og = rgraph(N, E, 13)
+    l = ng.GATConv((Din, C), "relu", heads=H, concat=concat, initialgraph=g)
+    ps, st = ng.setup(13, l)
+    assert tuple(ps["weight"].shape) == (C * H, Din) and tuple(ps["a"].shape) == (2 * C, H)
+    ps = prep(ps, 13)
+    x = torch.randn(Din, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    assert tuple(y.shape) == ((C * H) if concat else C, N)
+    p = lambda k: ps[k].detach().cpu().double().numpy()
+    yo, c = O.gat_conv(x.detach().cpu().double().numpy(), p("weight"), p("a"), p("bias"), og, H, C, "relu", concat=concat)
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.gat_conv_backward(c, R)
+    close(x.grad, gr["x"], rtol=5e-4, atol=1e-4, what="dx")
+    close(ps["weight"].grad, gr["weight"], rtol=5e-4, atol=5e-4, what="dW")
+    close(ps["a"].grad, gr["a"], rtol=5e-4, atol=5e-4, what="da")
+    close(ps["bias"].grad, gr["bias"].reshape(-1, 1), rtol=5e-4, atol=5e-4, what="db")
+
+
+def test_gat_c3_full_size_forward():
+    # BASELINE config 3: 4-head x 16 on the C2 graph (16384 nodes, 131072 edges + self loops)
+    from ngpde_amd import synth as S
+    _, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
+    g = ng.GNNGraph(s, t, num_nodes=16384, index_base=0)
+    og = O.Graph(s, t, num_nodes=16384, index_base=0)
+    l = ng.GATConv((64, 16), "identity", heads=4, initialgraph=g)
+    ps, st = ng.setup(3, l)
+    psd = ng.to_device(ps, DEV)
+    x = torch.as_tensor(S.normal(33, 64 * 16384).reshape(64, 16384).astype(np.float32), device=DEV)
+    y, _ = l(x, psd, st)
+    yo, c = O.gat_conv(x.cpu().double().numpy(), ps["weight"].double().numpy(), ps["a"].double().numpy(),
+                       ps["bias"].double().numpy(), og, 4, 16)
+    close(y, yo)
+    # attention rows sum to one over each node's incoming edges (incl. the self loop): size-independent property
+    assert np.allclose(O.scatter("+", c["alpha"], c["g"].t, 16384), 1.0)
+
+
+# ---- aggregation edge cases ----------------------------------------------------------------------------------------------------
+
+def test_segment_reduce_edge_cases():
+    from ngpde_amd import functional as F
+    g = ng.GNNGraph([1, 2, 2], [2, 1, 1], num_nodes=4)            # nodes 3, 4 isolated; node 1 has two incoming edges
+    h = g.handle()
+    M = torch.tensor([[1.0, -2.0], [3.0, 5.0], [7.0, 5.0]], device=DEV)   # COO order
+    Mp = F.edge_permute(M, h)
+    mean = F.segment_reduce(Mp, h, "mean", 4)
+    assert torch.equal(mean[2:], torch.zeros(2, 2, device=DEV))   # mean of an empty neighbourhood is 0
+    assert torch.allclose(mean[0], torch.tensor([5.0, 5.0], device=DEV)) and torch.allclose(mean[1], M[0])
+    mx = F.segment_reduce(Mp, h, "max", 4)
+    assert torch.allclose(mx[0], torch.tensor([7.0, 5.0], device=DEV)) and torch.isinf(mx[2]).all()
+    # max pullback: every extremal entry receives the gradient (NNlib)
+    Mp2 = Mp.clone().requires_grad_(True)
+    F.segment_reduce(Mp2, h, "max", 4)[:2].sum().backward()
+    back = F.edge_permute(Mp2.grad, h, inverse=True)
+    assert back.tolist() == [[1.0, 1.0], [0.0, 1.0], [1.0, 1.0]]
+    assert torch.equal(F.edge_permute(Mp, h, inverse=True), M)
