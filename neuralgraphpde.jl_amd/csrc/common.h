@@ -42,10 +42,19 @@ struct Csr {
   int32_t *xpos = nullptr;    // [n_edges] position of each entry in the OTHER direction's list (same COO edge)
   int2 *ell = nullptr;        // [n_sched][kEllWidth] the first kEllWidth {col, coef} entries of each schedule row
                               // (zero padded), addressed by schedule POSITION: loadable without first reading `sched`
+  // LDS-staged aggregation: per tile the UNIQUE rows its entries reference (own rows first: slot k = k-th row
+  // of the tile), pre-scaled by c when staged; per schedule row 16 slot bytes (kHaloCap = the all-zero row).
+  int2 *halo = nullptr;       // [n_tiles][kHaloCap] {node, bits of c[node]}
+  int2 *tile_info = nullptr;  // [n_tiles] {halo count (0: tile uses the global gather), unused}
+  uint8_t *slots = nullptr;   // [n_sched][kSlotWidth]
+  float *slot_w = nullptr;    // [n_sched][kSlotWidth] per-edge weights w_e, or NULL for unweighted graphs
+  bool halo_ok = false;       // every tile fits (<= kHaloCap distinct rows, degrees <= kSlotWidth)
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
 
 constexpr int kTileRows = 32;  // node rows per workgroup of the fused kernels
+constexpr int kHaloCap = 96;   // unique rows a tile may stage in LDS (24 KB at D = 64), plus one zero row
+constexpr int kSlotWidth = 32;  // slot bytes per row of the LDS-staged aggregation (rows with more: global gather)
 constexpr int kEllWidth = 16;  // entries per row held in the fixed-width block (rows with more spill to the CSR list)
 
 }  // namespace ngpde

@@ -17,6 +17,8 @@
 // the second.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 
@@ -46,6 +48,9 @@ struct Geo {
   static constexpr int CPW = (CT + CGRP - 1) / CGRP;         // column tiles per wave
   static constexpr int DWT = (CT * CT + WAVES - 1) / WAVES;  // dW tiles per wave
   static constexpr int DBP = kThreads / D;                   // row-partials per column in the db reduction
+  static constexpr bool HALO = (D <= 64);                    // LDS-staged aggregation (a 128-wide halo would not fit beside the tiles)
+  static constexpr int HI = (kHaloCap + GROUPS - 1) / GROUPS; // halo rows staged per group
+  static constexpr int XH = HALO ? (kHaloCap + 1) * D : 0;   // floats of the halo region (+1: the all-zero row)
 };
 
 #ifdef NGPDE_STAMPS
@@ -64,10 +69,19 @@ int g_stamps_max = 0, g_stamps_next = 0;
 #define NGPDE_STAMP_SET(kk, nb)                                                     \
   kk.stamps = nullptr;                                                              \
   if (g_stamps_base && g_stamps_next < g_stamps_max) kk.stamps = g_stamps_base + (size_t)(g_stamps_next++) * (nb) * 16;
+#define NGPDE_SUBSTAMP(ptr, k)                                                      \
+  do {                                                                              \
+    if (threadIdx.x == 0 && (ptr)) (ptr)[(size_t)blockIdx.x * 16 + 10 + (k)] = clock64(); \
+  } while (0)
+#define NGPDE_USE(v) asm volatile("" ::"v"(v))
+#define NGPDE_STAMP_PTR(p) (p).stamps
 #else
 #define NGPDE_STAMP_FIELD
 #define NGPDE_STAMP(k)
 #define NGPDE_STAMP_SET(kk, nb)
+#define NGPDE_SUBSTAMP(ptr, k)
+#define NGPDE_USE(v)
+#define NGPDE_STAMP_PTR(p) nullptr
 #endif
 
 // blockIdx -> tile, bijective for any grid size: blocks b, b+8, b+16, ... (dispatched to one XCD in
@@ -117,6 +131,21 @@ __device__ __forceinline__ void load_entries(const int2 *__restrict__ ent, const
     ecol[r] = ok ? v.x : 0;
     ecf[r] = ok ? v.y : 0;
   }
+}
+
+// Streaming (touch-once) accesses of the tape -- the aggregated input saved by forward, the saved
+// activations read back by backward -- are marked non-temporal so they do not evict what the next launch
+// re-reads from the XCD's L2 (gathered rows, schedule/entry arrays, dW slabs).
+__device__ __forceinline__ void store_stream4(float4 *p, float4 v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z);
+  __builtin_nontemporal_store(v.w, &p->w);
+}
+__device__ __forceinline__ float4 load_stream4(const float4 *p) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // Row fetch with a scalar base and a 32-bit byte offset (saddr + voffset addressing: one VGPR per
@@ -196,6 +225,109 @@ __device__ __forceinline__ void tile_prologue(const int4 *__restrict__ sched, co
   for (int r = 0; r < G::R; ++r) selfv[r] = load_row4<G::LPR>(X4, max(sc[r].x, 0), q);
 }
 
+// ---- LDS-staged aggregation ---------------------------------------------------------------------------------
+// The gather above moves ~280 KB per CU per launch through the L1/TA port (16 row slots x 64 rows x 256 B),
+// although a 32-row cluster tile references only ~57 distinct rows.  Here the workgroup stages those rows
+// once (3 x 16-byte loads per lane instead of 16), pre-scaled by c[node], and every row then sums its
+// neighbours out of LDS.  The chain stays flat: halo list, slot bytes and schedule entries are all
+// position-indexed (round 1), the halo rows are round 2.  Each lane reads its row's 16 slot bytes itself (a
+// 16-byte broadcast load), so no lane shuffles; unused slots name the all-zero row, so no masking.
+template <int D>
+struct HaloRegs {
+  int2 he[Geo<D>::HI];
+  uint4 sl[Geo<D>::R][2];
+  float4 sw[Geo<D>::R][8];
+  float4 hv[Geo<D>::HI];
+};
+
+// round 1: position-indexed halo entries and slot bytes (padded lists: no count, nothing to wait for first)
+template <int D>
+__device__ __forceinline__ void halo_round1(const int2 *__restrict__ halo, const uint4 *__restrict__ slots16,
+                                            const float4 *__restrict__ slot_w4, int tile, int grp, bool active,
+                                            HaloRegs<D> &h) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) {
+    const int hh = grp + k * G::GROUPS;
+    h.he[k] = (hh < kHaloCap) ? halo[(size_t)tile * kHaloCap + hh] : make_int2(0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const size_t pos = (size_t)tile * kTM + grp * G::R + r;
+    h.sl[r][0] = active ? slots16[pos * 2] : make_uint4(0, 0, 0, 0);
+    h.sl[r][1] = active ? slots16[pos * 2 + 1] : make_uint4(0, 0, 0, 0);
+    if (slot_w4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h.sw[r][j] = active ? slot_w4[pos * 8 + j] : f4_zero();
+    }
+  }
+}
+
+// round 2: the tile's distinct rows.  Issue this BEFORE any other load of the kernel that is consumed later:
+// vmcnt retires in order, so an older, slower load (HBM tape) would otherwise sit in front of these.
+template <int D>
+__device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q, HaloRegs<D> &h) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) h.hv[k] = load_row4<G::LPR>(X4, h.he[k].x, q);
+}
+
+// stage the rows (pre-scaled by c[node]; padding entries have c = 0) and sum every row's neighbours from LDS
+template <int D>
+__device__ __forceinline__ void halo_finish(const HaloRegs<D> &h, bool weighted, int self_loops, int grp, int q,
+                                            float *ldsXh, const int4 (&sc)[Geo<D>::R], float4 (&acc)[Geo<D>::R],
+                                            unsigned long long *dbg = nullptr) {
+  using G = Geo<D>;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  NGPDE_USE(h.hv[0].x); NGPDE_USE(h.hv[G::HI - 1].x);
+  NGPDE_SUBSTAMP(dbg, 1);   // halo rows arrived
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) {
+    const int hh = grp + k * G::GROUPS;
+    if (hh < kHaloCap) Xh4[hh * G::LPR + q] = f4_scale(__int_as_float(h.he[k].y), h.hv[k]);
+  }
+  if (grp == 0) Xh4[kHaloCap * G::LPR + q] = f4_zero();
+  int wmax = 0;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) wmax = max(wmax, sc[r].z);
+  // longest row of this wave (uniform): whole 4-slot words beyond it are skipped
+  wmax = max(wmax, __shfl_xor(wmax, 16));
+  wmax = max(wmax, __shfl_xor(wmax, 32));
+  if (G::LPR < 16) {
+    wmax = max(wmax, __shfl_xor(wmax, 8));
+    wmax = max(wmax, __shfl_xor(wmax, 4));
+  }
+  wmax = __builtin_amdgcn_readfirstlane(wmax);
+  NGPDE_SUBSTAMP(dbg, 2);   // LDS written
+  __syncthreads();
+  NGPDE_SUBSTAMP(dbg, 3);   // barrier passed
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const unsigned w[8] = {h.sl[r][0].x, h.sl[r][0].y, h.sl[r][0].z, h.sl[r][0].w,
+                           h.sl[r][1].x, h.sl[r][1].y, h.sl[r][1].z, h.sl[r][1].w};
+    float4 a = f4_zero();
+#pragma unroll
+    for (int jw = 0; jw < 8; ++jw) {
+      if (jw * 4 < wmax) {   // wave-uniform
+        float4 v[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((w[jw] >> (8 * jb)) & 0xff) * G::LPR + q];
+        if (weighted) {
+          const float4 wv = h.sw[r][jw];
+          a = f4_fma(wv.x, v[0], a); a = f4_fma(wv.y, v[1], a); a = f4_fma(wv.z, v[2], a); a = f4_fma(wv.w, v[3], a);
+        } else {
+          a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+        }
+      }
+    }
+    const float ci = __int_as_float(sc[r].w);
+    if (self_loops) a = f4_add(a, Xh4[min(grp * G::R + r, kTM - 1) * G::LPR + q]);   // own row = slot (position in tile)
+    acc[r] = f4_scale(ci, a);
+  }
+  NGPDE_USE(acc[0].x);
+  NGPDE_SUBSTAMP(dbg, 4);   // LDS aggregation done
+}
+
 // ---- fp32 MFMA tile products from LDS ------------------------------------------------------------------
 // Out[kTM][D] = A[kTM][D] x B, with A row-major (stride TS) and B stored TRANSPOSED, Bt[col][k] (stride
 // TS), so lane (i = l&15, kq = l>>4) feeds four consecutive k-steps of v_mfma_f32_16x16x4_f32 from ONE
@@ -258,7 +390,9 @@ __device__ __forceinline__ void mfma_rows_times_bt(const float *ldsA, const floa
 struct FwdK {
   const float *x;
   const int4 *sched;
-  const int2 *ent, *ell;
+  const int2 *ent, *ell, *halo, *tile_info;
+  const uint8_t *slots;
+  const float *slot_w;
   int self_loops, n_tiles, act;
   const float *wt, *bias;
   float *y, *save_agg, *save_z;
@@ -268,11 +402,13 @@ struct FwdK {
   NGPDE_STAMP_FIELD
 };
 
-template <int D, int ACT>
+template <int D, int ACT, bool HALO>
 __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_kernel(const FwdK p) {
   using G = Geo<D>;
-  __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 2 + D * G::TS];
-  float *ldsT = lds, *ldsZ = lds + kTM * G::TS, *ldsBt = lds + 2 * kTM * G::TS;
+  // the halo region is dead once the aggregation is done and is re-used for the MFMA output tile
+  constexpr int kXZ = (HALO && G::XH > kTM * G::TS) ? G::XH : kTM * G::TS;
+  __shared__ __attribute__((aligned(16))) float lds[kXZ + kTM * G::TS + D * G::TS];
+  float *ldsXh = lds, *ldsZ = lds, *ldsT = lds + kXZ, *ldsBt = lds + kXZ + kTM * G::TS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / G::LPR, q = tid % G::LPR;
@@ -282,11 +418,23 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   const float4 *X4 = reinterpret_cast<const float4 *>(p.x);
   NGPDE_STAMP(0);
 
-  // round 1: everything that does not depend on another load
+  // round 1: everything that does not depend on another load; the gather chain is issued first
   int4 sc[G::R];
   int ecol[G::R], ecf[G::R];
   float4 selfv[G::R];
-  tile_prologue<D>(p.sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
+  HaloRegs<D> hr;
+  if (HALO) {
+    halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
+                   active, hr);
+#pragma unroll
+    for (int r = 0; r < G::R; ++r)
+      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+    NGPDE_USE(hr.he[0].x); NGPDE_USE(hr.sl[0][0].x);
+    NGPDE_SUBSTAMP(NGPDE_STAMP_PTR(p), 0);   // round-1 data arrived
+    halo_round2<D>(X4, q, hr);
+  } else {
+    tile_prologue<D>(p.sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
+  }
   // W: B[k = in][j = out] = wt[in][out], stored transposed in LDS: 4 dword loads down a column
   // (coalesced across lanes) -> one ds_write_b128
   float4 wreg[G::NPASS];
@@ -304,9 +452,13 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   }
   const float4 b4 = (active && p.bias) ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
 
-  // round 2: all neighbour rows
+  // round 2: the neighbour rows -- staged once per tile through LDS, or gathered per row
   float4 acc[G::R];
-  aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
+  if (HALO) {
+    halo_finish<D>(hr, p.slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, acc, NGPDE_STAMP_PTR(p));
+  } else {
+    aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
+  }
   NGPDE_STAMP(1);
   // node-local epilogue operands: requested now so they land under the MFMA phase
   float4 cterm[G::R][8];
@@ -319,7 +471,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
     for (int r = 0; r < G::R; ++r) {
       if (sc[r].x < 0) acc[r] = f4_zero();
       *reinterpret_cast<float4 *>(&ldsT[(grp * G::R + r) * G::TS + 4 * q]) = acc[r];
-      if (p.save_agg && sc[r].x >= 0) reinterpret_cast<float4 *>(p.save_agg)[(size_t)sc[r].x * G::LPR + q] = acc[r];
+      if (p.save_agg && sc[r].x >= 0) store_stream4(&reinterpret_cast<float4 *>(p.save_agg)[(size_t)sc[r].x * G::LPR + q], acc[r]);
     }
   }
   {
@@ -356,7 +508,9 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
 struct BwdK {
   const float *g_in;
   const int4 *sched;
-  const int2 *ent, *ell;
+  const int2 *ent, *ell, *halo, *tile_info;
+  const uint8_t *slots;
+  const float *slot_w;
   int self_loops, n_tiles, act;
   int has_comb;
   CombDev comb;
@@ -370,11 +524,13 @@ struct BwdK {
 
 // Slab layout (per workgroup): dW as [tile tt = mt * CT + nt][lane][4] (each lane's four MFMA result
 // registers contiguous -> one 16-byte read-modify-write per tile), db as [D].
-template <int D, bool AGG, int ACT>
+template <int D, bool AGG, int ACT, bool HALO>
 __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(const BwdK p) {
   using G = Geo<D>;
-  __shared__ __attribute__((aligned(16))) float lds[kTM * G::TS * 3 + D * G::TS];
-  float *ldsDZ = lds, *ldsX = lds + kTM * G::TS, *ldsG = lds + 2 * kTM * G::TS, *ldsBt = lds + 3 * kTM * G::TS;
+  constexpr int kXZ = (AGG && HALO && G::XH > kTM * G::TS) ? G::XH : kTM * G::TS;
+  __shared__ __attribute__((aligned(16))) float lds[kXZ + kTM * G::TS * 2 + D * G::TS];
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXZ, *ldsX = lds + kXZ + kTM * G::TS,
+        *ldsBt = lds + kXZ + 2 * kTM * G::TS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / G::LPR, q = tid % G::LPR;
@@ -384,11 +540,19 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
   const float4 *G4 = reinterpret_cast<const float4 *>(p.g_in);
   NGPDE_STAMP(0);
 
-  // round 1
+  // round 1: the gather chain first (vmcnt retires in order: slower loads must not sit in front of it)
   int4 sc[G::R];
   int ecol[G::R], ecf[G::R];
   float4 selfv[G::R];
-  if (AGG) {
+  HaloRegs<D> hr;
+  if (AGG && HALO) {
+    halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
+                   active, hr);
+#pragma unroll
+    for (int r = 0; r < G::R; ++r)
+      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+    halo_round2<D>(G4, q, hr);
+  } else if (AGG) {
     tile_prologue<D>(p.sched, p.ell, p.ent, G4, tile, grp, q, active, sc, ecol, ecf, selfv);
   } else {
 #pragma unroll
@@ -416,19 +580,21 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
     }
     if (dbpart == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
   }
-  // saved activations of this thread's rows (node-local, HBM-resident tape): also round 1
+  // saved activations of this thread's rows (node-local, HBM-resident tape)
   float4 zrow[G::R], xrow[G::R];
   if (active && p.do_dense) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
-      zrow[r] = reinterpret_cast<const float4 *>(p.z)[idx4];
-      xrow[r] = reinterpret_cast<const float4 *>(p.saved_agg)[idx4];
+      zrow[r] = load_stream4(&reinterpret_cast<const float4 *>(p.z)[idx4]);
+      xrow[r] = load_stream4(&reinterpret_cast<const float4 *>(p.saved_agg)[idx4]);
     }
   }
 
   float4 t[G::R];
-  if (AGG) {
+  if (AGG && HALO) {
+    halo_finish<D>(hr, p.slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t);
+  } else if (AGG) {
     aggregate_rows<G::LPR, G::R, G::U>(G4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, t);
   } else {
 #pragma unroll
@@ -561,6 +727,12 @@ CombDev to_dev(const Comb &c) {
     if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
   } while (0)
 
+// NGPDE_NO_HALO=1 forces the per-row global gather (A/B measurements and tests of the fallback path)
+inline bool no_halo_env() {
+  static const bool v = [] { const char *e = std::getenv("NGPDE_NO_HALO"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // activations with a compiled-in fast path; everything else takes the runtime switch (ACT = -1)
 inline int act_template(int act) { return (act == NGPDE_ACT_RELU || act == NGPDE_ACT_IDENTITY) ? act : -1; }
 
@@ -588,14 +760,18 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
                 "fused GCN path addresses feature arrays with 32-bit byte offsets: n_nodes * d * 4 must be < 4 GiB");
   FwdK k;
   k.x = a.x; k.sched = g->by_t.sched; k.ent = g->by_t.ent; k.ell = g->by_t.ell;
+  k.halo = g->by_t.halo; k.tile_info = g->by_t.tile_info; k.slots = g->by_t.slots; k.slot_w = g->by_t.slot_w;
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
   NGPDE_STAMP_SET(k, k.n_tiles)
+  const bool use_halo = g->by_t.halo_ok && !no_halo_env();
   const dim3 grid(k.n_tiles), block(kThreads);
+#define NGPDE_FWD_LAUNCH2(DD, AA, HH)                                                                              \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH>), grid, block, 0, stream, k);
 #define NGPDE_FWD_LAUNCH(DD, AA)                                                                                   \
-  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-  else hipLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA>), grid, block, 0, stream, k);
+  if (Geo<DD>::HALO && use_halo) { NGPDE_FWD_LAUNCH2(DD, AA, (Geo<DD>::HALO)) } else { NGPDE_FWD_LAUNCH2(DD, AA, false) }
 #define NGPDE_FWD_CASE(DD)                                                            \
   case DD:                                                                            \
     switch (act_template(a.act)) {                                                    \
@@ -612,6 +788,7 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   }
 #undef NGPDE_FWD_CASE
 #undef NGPDE_FWD_LAUNCH
+#undef NGPDE_FWD_LAUNCH2
   NGPDE_LAUNCH_CHECK("gcn_fused_fwd_kernel");
   return NGPDE_OK;
 }
@@ -625,16 +802,20 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
                 "fused GCN path addresses feature arrays with 32-bit byte offsets: n_nodes * d * 4 must be < 4 GiB");
   BwdK k;
   k.g_in = a.g_in; k.sched = g->by_s.sched; k.ent = g->by_s.ent; k.ell = g->by_s.ell;
+  k.halo = g->by_s.halo; k.tile_info = g->by_s.tile_info; k.slots = g->by_s.slots; k.slot_w = g->by_s.slot_w;
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb);
   k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;
   k.do_dense = a.do_dense ? 1 : 0; k.z = a.z; k.saved_agg = a.saved_agg; k.wt = a.wt;
   k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
   NGPDE_STAMP_SET(k, k.n_tiles)
+  const bool use_halo = g->by_s.halo_ok && !no_halo_env();
   const dim3 grid(k.n_tiles), block(kThreads);
+#define NGPDE_BWD_LAUNCH2(DD, AG, AA, HH)                                                                         \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH>), grid, block, 0, stream, k);
 #define NGPDE_BWD_LAUNCH(DD, AG, AA)                                                                              \
-  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA>), grid, block, 0, stream, k);
+  if (AG && Geo<DD>::HALO && use_halo) { NGPDE_BWD_LAUNCH2(DD, AG, AA, (AG && Geo<DD>::HALO)) } else { NGPDE_BWD_LAUNCH2(DD, AG, AA, false) }
 #define NGPDE_BWD_ACT(DD, AG)                                                         \
   switch (act_template(a.act)) {                                                      \
     case NGPDE_ACT_RELU: NGPDE_BWD_LAUNCH(DD, AG, NGPDE_ACT_RELU) break;              \
@@ -654,6 +835,7 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
 #undef NGPDE_BWD_CASE
 #undef NGPDE_BWD_ACT
 #undef NGPDE_BWD_LAUNCH
+#undef NGPDE_BWD_LAUNCH2
   NGPDE_LAUNCH_CHECK("gcn_fused_bwd_kernel");
   return NGPDE_OK;
 }

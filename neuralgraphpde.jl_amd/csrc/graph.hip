@@ -113,6 +113,10 @@ void free_csr(Csr &c) {
   if (c.sched) (void)hipFree(c.sched);
   if (c.ell) (void)hipFree(c.ell);
   if (c.xpos) (void)hipFree(c.xpos);
+  if (c.halo) (void)hipFree(c.halo);
+  if (c.tile_info) (void)hipFree(c.tile_info);
+  if (c.slots) (void)hipFree(c.slots);
+  if (c.slot_w) (void)hipFree(c.slot_w);
   c = Csr();
 }
 
@@ -275,6 +279,69 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   std::vector<int2> lt_, ls_;
   fill_ell(g->by_t, et, lt_);
   fill_ell(g->by_s, es, ls_);
+  // halo lists + slot bytes for the LDS-staged aggregation
+  const int64_t n_tiles = g->n_sched / kTileRows;
+  struct HaloOut { std::vector<int2> halo, info; std::vector<uint8_t> slots; std::vector<float> w; };
+  auto fill_halo = [&](const Csr &csr, HaloOut &o) {
+    o.halo.assign((size_t)n_tiles * kHaloCap, make_int2(0, 0));
+    o.info.assign((size_t)n_tiles, make_int2(0, 0));
+    o.slots.assign((size_t)g->n_sched * kSlotWidth, (uint8_t)kHaloCap);
+    if (edge_weight) o.w.assign((size_t)g->n_sched * kSlotWidth, 0.f);
+    std::vector<int32_t> slot_of((size_t)n, -1), stamp((size_t)n, -1);
+    for (int64_t tl = 0; tl < n_tiles; ++tl) {
+      int count = 0;
+      bool fits = true;
+      auto slot = [&](int32_t v) {
+        if (stamp[v] != (int32_t)tl) {
+          stamp[v] = (int32_t)tl;
+          slot_of[v] = count;
+          if (count < kHaloCap) {
+            int2 e;
+            e.x = v;
+            std::memcpy(&e.y, &c[v], 4);
+            o.halo[(size_t)tl * kHaloCap + count] = e;
+          }
+          ++count;
+        }
+        return slot_of[v];
+      };
+      for (int k = 0; k < kTileRows; ++k) {          // own rows first: slot k = k-th row (padding rows keep {0, 0})
+        const int64_t pos = tl * kTileRows + k;
+        if (pos < n) slot(g->h_order[pos]);
+        else ++count;
+      }
+      for (int k = 0; k < kTileRows && fits; ++k) {
+        const int64_t pos = tl * kTileRows + k;
+        if (pos >= n) break;
+        const int32_t v = g->h_order[pos];
+        const int32_t rs = csr.h_rowptr[v], deg = csr.h_rowptr[v + 1] - rs;
+        if (deg > kSlotWidth) { fits = false; break; }
+        for (int j = 0; j < deg; ++j) {
+          const int sl = slot(csr.h_col[rs + j]);
+          if (count > kHaloCap) { fits = false; break; }
+          o.slots[(size_t)pos * kSlotWidth + j] = (uint8_t)sl;
+          if (edge_weight) o.w[(size_t)pos * kSlotWidth + j] = edge_weight[csr.h_eid[rs + j]];
+        }
+      }
+      o.info[tl] = make_int2(fits ? count : 0, 0);
+    }
+  };
+  HaloOut ht_, hs_;
+  fill_halo(g->by_t, ht_);
+  fill_halo(g->by_s, hs_);
+  auto all_fit = [&](const HaloOut &o) {
+    for (const int2 &i : o.info)
+      if (i.x == 0) return false;
+    return n_tiles > 0;
+  };
+  g->by_t.halo_ok = all_fit(ht_);
+  g->by_s.halo_ok = all_fit(hs_);
+  for (Csr *c2 : {&g->by_t, &g->by_s}) {
+    if (c2->halo) { (void)hipFree(c2->halo); c2->halo = nullptr; }
+    if (c2->tile_info) { (void)hipFree(c2->tile_info); c2->tile_info = nullptr; }
+    if (c2->slots) { (void)hipFree(c2->slots); c2->slots = nullptr; }
+    if (c2->slot_w) { (void)hipFree(c2->slot_w); c2->slot_w = nullptr; }
+  }
   if (g->by_t.ell) { (void)hipFree(g->by_t.ell); g->by_t.ell = nullptr; }
   if (g->by_s.ell) { (void)hipFree(g->by_s.ell); g->by_s.ell = nullptr; }
   if (g->by_t.ent) { (void)hipFree(g->by_t.ent); g->by_t.ent = nullptr; }
@@ -290,6 +357,16 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   if ((st = upload(&g->by_s.sched, ss_.data(), ss_.size()))) return st;
   if ((st = upload(&g->by_t.ell, lt_.data(), lt_.size()))) return st;
   if ((st = upload(&g->by_s.ell, ls_.data(), ls_.size()))) return st;
+  if ((st = upload(&g->by_t.halo, ht_.halo.data(), ht_.halo.size()))) return st;
+  if ((st = upload(&g->by_s.halo, hs_.halo.data(), hs_.halo.size()))) return st;
+  if ((st = upload(&g->by_t.tile_info, ht_.info.data(), ht_.info.size()))) return st;
+  if ((st = upload(&g->by_s.tile_info, hs_.info.data(), hs_.info.size()))) return st;
+  if ((st = upload(&g->by_t.slots, ht_.slots.data(), ht_.slots.size()))) return st;
+  if ((st = upload(&g->by_s.slots, hs_.slots.data(), hs_.slots.size()))) return st;
+  if (edge_weight) {
+    if ((st = upload(&g->by_t.slot_w, ht_.w.data(), ht_.w.size()))) return st;
+    if ((st = upload(&g->by_s.slot_w, hs_.w.data(), hs_.w.size()))) return st;
+  }
   if ((st = upload(&g->c, c.data(), (size_t)n))) return st;
   g->self_loops = add_self_loops ? 1 : 0;
   g->has_norm = true;

@@ -44,11 +44,14 @@ def report(name, idx, nph, labels):
     print(f"{name}: kernel span (first WG start -> last WG end) median {np.median(dur)/1000:.2f} us over {len(idx)} launches")
     for l, m in zip(labels, med): print(f"    {l:26s} {m:8.0f} cycles")
     print(f"    {'WG total':26s} {np.median(clk[:, :, nph] - clk[:, :, 0]):8.0f} cycles;  start skew {np.median((wall[:, :, 0].max(axis=1) - wall[:, :, 0].min(axis=1)) * 10):.0f} ns")
-sub = a[list(range(0, nf, 2))][:, :, 4:8, :].reshape(-1, nb, 8).astype(np.float64)   # words 8..15 of each WG slot
-t0 = a[list(range(0, nf, 2))][:, :, 0, 0].astype(np.float64)
-names = ["halo idx issued", "halo idx arrived", "halo rows arrived", "LDS written + entries arrived", "barrier 1", "LDS aggregate done", "barrier 2"]
-print("fwd layer1 aggregate sub-phases (cycles since WG start, median):")
-for k, nme in enumerate(names): print(f"    {nme:32s} {np.median(sub[:, :, k] - t0):8.0f}")
+raw = stamps.cpu().numpy().reshape(nl, nb, 16)
+sub = raw[list(range(0, nf, 2))][:, :, 10:15].astype(np.float64)
+t0 = raw[list(range(0, nf, 2))][:, :, 0].astype(np.float64)
+names = ["round-1 data arrived", "halo rows arrived", "LDS written", "barrier passed", "LDS aggregation done"]
+print("fwd layer1 halo aggregation sub-phases (cycles since WG start, median / p90 over WGs):")
+for k, nme in enumerate(names):
+    dlt = sub[:, :, k] - t0
+    print(f"    {nme:26s} {np.median(dlt):8.0f} {np.percentile(dlt, 90):8.0f}")
 fl = ["sched+W issue+aggregate", "LDS stage+sync", "MFMA+sync", "epilogue"]
 report("fwd layer1", list(range(0, nf, 2)), 4, fl)
 report("fwd layer2+stage", list(range(1, nf, 2)), 4, fl)
