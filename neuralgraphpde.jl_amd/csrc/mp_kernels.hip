@@ -32,101 +32,11 @@ namespace {
 // read in place.  A block with row_div > 1 is a per-graph feature: row r reads row r / row_div
 // (repeat(theta; inner=(1, E / G)), src/layers.jl:410,:418).
 
-__device__ __forceinline__ float seg_load(const SegTable &s, int64_t row, int k) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i < s.n && k < s.offset[i + 1]) return s.ptr[i][(row / s.row_div[i]) * s.width[i] + (k - s.offset[i])];
-  return 0.f;
-}
-
-__global__ __launch_bounds__(256) void dense_seg_fwd_kernel(int64_t n, SegTable segs, int din, int dout, int act,
-                                                            const float *__restrict__ wt, const float *__restrict__ bias,
-                                                            float *__restrict__ y, float *__restrict__ save_z) {
-  __shared__ float xs[16][17], ws[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
-  const int o = blockIdx.y * 16 + tx;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < din; k0 += 16) {
-    xs[ty][tx] = (row < n && k0 + tx < din) ? seg_load(segs, row, k0 + tx) : 0.f;
-    ws[ty][tx] = (k0 + ty < din && o < dout) ? wt[(size_t)(k0 + ty) * dout + o] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(xs[ty][k], ws[k][tx], acc);
-    __syncthreads();
-  }
-  if (row < n && o < dout) {
-    const float z = acc + (bias ? bias[o] : 0.f);
-    if (save_z) save_z[row * dout + o] = z;
-    y[row * dout + o] = act_apply(act, z);
-  }
-}
-
 // dz = dy * act'(z)
 __global__ void dense_dz_kernel(int64_t count, int act, const float *__restrict__ dy, const float *__restrict__ z,
                                 float *__restrict__ dz) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     dz[i] = dy[i] * act_deriv(act, z[i]);
-}
-
-// dX[row][k] = sum_o dz[row][o] wt[k][o] written into the blocks that ask for a gradient
-__global__ __launch_bounds__(256) void dense_seg_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
-                                                                  const float *__restrict__ dz,
-                                                                  const float *__restrict__ wt) {
-  __shared__ float zs[16][17], ws[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
-  const int k = blockIdx.y * 16 + tx;
-  float acc = 0.f;
-  for (int o0 = 0; o0 < dout; o0 += 16) {
-    zs[ty][tx] = (row < n && o0 + tx < dout) ? dz[row * dout + o0 + tx] : 0.f;
-    const int wk = blockIdx.y * 16 + ty;
-    ws[tx][ty] = (wk < din && o0 + tx < dout) ? wt[(size_t)wk * dout + o0 + tx] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int o = 0; o < 16; ++o) acc = fmaf(zs[ty][o], ws[o][tx], acc);
-    __syncthreads();
-  }
-  if (row < n && k < din) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < segs.n && k >= segs.offset[i] && k < segs.offset[i + 1] && segs.ptr[i])
-        segs.ptr[i][row * segs.width[i] + (k - segs.offset[i])] = acc;
-  }
-}
-
-// partial[chunk][k][o] = sum_{rows of chunk} X[row][k] dz[row][o]; k == din is the bias row (X = 1)
-__global__ __launch_bounds__(256) void dense_seg_bwd_weight_kernel(int64_t n, SegTable segs, int din, int dout,
-                                                                   const float *__restrict__ dz, int64_t rows_per_chunk,
-                                                                   float *__restrict__ partial) {
-  __shared__ float xs[16][17], zs[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int k = blockIdx.x * 16 + ty;   // row of dwt (din + 1 rows: the last is db)
-  const int o = blockIdx.y * 16 + tx;
-  const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-  float acc = 0.f;
-  for (int64_t n0 = r0; n0 < r1; n0 += 16) {
-    const int kk = blockIdx.x * 16 + tx;
-    const int64_t rr = n0 + ty;
-    xs[ty][tx] = (rr < r1 && kk <= din) ? (kk == din ? 1.0f : seg_load(segs, rr, kk)) : 0.f;
-    zs[ty][tx] = (rr < r1 && o < dout) ? dz[rr * dout + o] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc = fmaf(xs[j][ty], zs[j][tx], acc);
-    __syncthreads();
-  }
-  if (k <= din && o < dout) partial[((size_t)blockIdx.z * (din + 1) + k) * dout + o] = acc;
-}
-
-__global__ void dense_weight_reduce_kernel(int nchunk, int din, int dout, const float *__restrict__ partial,
-                                           float *__restrict__ dwt, float *__restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = (din + 1) * dout;
-  if (idx >= total) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + idx];
-  if (idx < din * dout) dwt[idx] = s;
-  else if (db) db[idx - din * dout] = s;
 }
 
 // ---- edge-order helpers ------------------------------------------------------------------------------------
@@ -454,45 +364,10 @@ inline unsigned rows4(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 
 }  // namespace
 
-int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
-                             const float *bias, float *y, float *save_z, hipStream_t stream) {
-  if (n == 0 || dout == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(dense_seg_fwd_kernel, dim3((unsigned)((n + 15) / 16), (dout + 15) / 16), dim3(256), 0, stream, n, segs,
-                     din, dout, act, wt, bias, y, save_z);
-  NGPDE_LAUNCH_CHECK("dense_seg_fwd_kernel");
-  return NGPDE_OK;
-}
-
 int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream) {
   if (count == 0) return NGPDE_OK;
   hipLaunchKernelGGL(dense_dz_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, count, act, dy, z, dz);
   NGPDE_LAUNCH_CHECK("dense_dz_kernel");
-  return NGPDE_OK;
-}
-
-int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
-                                   hipStream_t stream) {
-  if (n == 0 || din == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(dense_seg_bwd_input_kernel, dim3((unsigned)((n + 15) / 16), (din + 15) / 16), dim3(256), 0, stream, n,
-                     segs, din, dout, dz, wt);
-  NGPDE_LAUNCH_CHECK("dense_seg_bwd_input_kernel");
-  return NGPDE_OK;
-}
-
-int dense_weight_chunks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 4095) / 4096)); }
-
-int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
-                                    float *db, float *partial, hipStream_t stream) {
-  if (dout == 0) return NGPDE_OK;
-  const int nchunk = dense_weight_chunks(n);
-  const int64_t rpc = (((n + nchunk - 1) / nchunk) + 15) / 16 * 16;
-  hipLaunchKernelGGL(dense_seg_bwd_weight_kernel, dim3((din + 1 + 15) / 16, (dout + 15) / 16, nchunk), dim3(256), 0, stream,
-                     n, segs, din, dout, dz, std::max<int64_t>(rpc, 16), partial);
-  NGPDE_LAUNCH_CHECK("dense_seg_bwd_weight_kernel");
-  const int total = (din + 1) * dout;
-  hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, nchunk, din, dout, partial,
-                     dwt, db);
-  NGPDE_LAUNCH_CHECK("dense_weight_reduce_kernel");
   return NGPDE_OK;
 }
 
