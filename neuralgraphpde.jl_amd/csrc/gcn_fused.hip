@@ -246,20 +246,37 @@ __device__ __forceinline__ void halo_round1(const int2 *__restrict__ halo, const
                                             const float4 *__restrict__ slot_w4, int tile, int grp, bool active,
                                             HaloRegs<D> &h) {
   using G = Geo<D>;
+  // unconditional loads from clamped positions (a `cond ? load : 0` becomes an exec-masked branch with its
+  // own full wait); inactive groups / padding slots are neutralised later
 #pragma unroll
   for (int k = 0; k < G::HI; ++k) {
-    const int hh = grp + k * G::GROUPS;
-    h.he[k] = (hh < kHaloCap) ? halo[(size_t)tile * kHaloCap + hh] : make_int2(0, 0);
+    const int hh = min(grp + k * G::GROUPS, kHaloCap - 1);
+    h.he[k] = halo[(size_t)tile * kHaloCap + hh];
   }
 #pragma unroll
   for (int r = 0; r < G::R; ++r) {
-    const size_t pos = (size_t)tile * kTM + grp * G::R + r;
-    h.sl[r][0] = active ? slots16[pos * 2] : make_uint4(0, 0, 0, 0);
-    h.sl[r][1] = active ? slots16[pos * 2 + 1] : make_uint4(0, 0, 0, 0);
-    if (slot_w4) {
+    const size_t pos = (size_t)tile * kTM + min(grp * G::R + r, kTM - 1);
+    h.sl[r][0] = slots16[pos * 2];
+    h.sl[r][1] = slots16[pos * 2 + 1];
+    if (slot_w4) {   // uniform
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h.sw[r][j] = active ? slot_w4[pos * 8 + j] : f4_zero();
+      for (int j = 0; j < 8; ++j) h.sw[r][j] = slot_w4[pos * 8 + j];
     }
+  }
+}
+
+// schedule entries of this thread's rows, same rule: load always, neutralise afterwards
+template <int D>
+__device__ __forceinline__ void load_sched(const int4 *__restrict__ sched, int tile, int grp, bool active,
+                                           int4 (&sc)[Geo<D>::R]) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const int4 v = sched[(size_t)tile * kTM + min(grp * G::R + r, kTM - 1)];
+    sc[r].x = active ? v.x : -1;
+    sc[r].y = active ? v.y : 0;
+    sc[r].z = active ? v.z : 0;
+    sc[r].w = active ? v.w : 0;
   }
 }
 
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   const float4 *X4 = reinterpret_cast<const float4 *>(p.x);
   NGPDE_STAMP(0);
 
-  // round 1: everything that does not depend on another load; the gather chain is issued first
+  // ---- round 1: every load whose address depends on nothing loaded; the gather chain first, pinned in this order
   int4 sc[G::R];
   int ecol[G::R], ecf[G::R];
   float4 selfv[G::R];
@@ -426,15 +443,11 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   if (HALO) {
     halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
                    active, hr);
-#pragma unroll
-    for (int r = 0; r < G::R; ++r)
-      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
-    NGPDE_USE(hr.he[0].x); NGPDE_USE(hr.sl[0][0].x);
-    NGPDE_SUBSTAMP(NGPDE_STAMP_PTR(p), 0);   // round-1 data arrived
-    halo_round2<D>(X4, q, hr);
+    load_sched<D>(p.sched, tile, grp, active, sc);
   } else {
     tile_prologue<D>(p.sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
   }
+  __builtin_amdgcn_sched_barrier(0);
   // W: B[k = in][j = out] = wt[in][out], stored transposed in LDS: 4 dword loads down a column
   // (coalesced across lanes) -> one ds_write_b128
   float4 wreg[G::NPASS];
@@ -450,9 +463,20 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
       }
     }
   }
-  const float4 b4 = (active && p.bias) ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
-
-  // round 2: the neighbour rows -- staged once per tile through LDS, or gathered per row
+  const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();   // uniform condition
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- round 2: addresses from round 1 -- the tile's distinct rows, then the node-local stage terms
+  if (HALO) {
+    NGPDE_USE(hr.he[0].x);
+    NGPDE_SUBSTAMP(NGPDE_STAMP_PTR(p), 0);   // round-1 data arrived
+    halo_round2<D>(X4, q, hr);
+  }
+  float4 cterm[G::R][8];
+  if (HALO && active && p.has_comb) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float4 acc[G::R];
   if (HALO) {
     halo_finish<D>(hr, p.slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, acc, NGPDE_STAMP_PTR(p));
@@ -460,9 +484,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
     aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
   }
   NGPDE_STAMP(1);
-  // node-local epilogue operands: requested now so they land under the MFMA phase
-  float4 cterm[G::R][8];
-  if (active && p.has_comb) {
+  if (!HALO && active && p.has_comb) {   // the per-row gather keeps 16 rows in flight: stage terms only afterwards
 #pragma unroll
     for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
   }
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
   const float4 *G4 = reinterpret_cast<const float4 *>(p.g_in);
   NGPDE_STAMP(0);
 
-  // round 1: the gather chain first (vmcnt retires in order: slower loads must not sit in front of it)
+  // ---- round 1 / round 2 of the gather chain first (vmcnt retires in order: slower loads must not sit in front)
   int4 sc[G::R];
   int ecol[G::R], ecf[G::R];
   float4 selfv[G::R];
@@ -548,16 +570,12 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
   if (AGG && HALO) {
     halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
                    active, hr);
-#pragma unroll
-    for (int r = 0; r < G::R; ++r)
-      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+    load_sched<D>(p.sched, tile, grp, active, sc);
     halo_round2<D>(G4, q, hr);
   } else if (AGG) {
     tile_prologue<D>(p.sched, p.ell, p.ent, G4, tile, grp, q, active, sc, ecol, ecf, selfv);
   } else {
-#pragma unroll
-    for (int r = 0; r < G::R; ++r)
-      sc[r] = active ? p.sched[(size_t)tile * kTM + grp * G::R + r] : make_int4(-1, 0, 0, 0);
+    load_sched<D>(p.sched, tile, grp, active, sc);
   }
   // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
   float4 wreg[G::W4];
@@ -581,7 +599,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
     if (dbpart == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
   }
   // saved activations of this thread's rows (node-local, HBM-resident tape)
-  float4 zrow[G::R], xrow[G::R];
+  float4 zrow[G::R], xrow[G::R], cterm[G::R][8];
   if (active && p.do_dense) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
@@ -601,12 +619,11 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
     for (int r = 0; r < G::R; ++r) t[r] = G4[(size_t)max(sc[r].x, 0) * G::LPR + q];
   }
   NGPDE_STAMP(1);
-  if (active) {
-    // adjoint stage terms: one batch of independent node-local loads
-    float4 cterm[G::R][8];
+  if (active && p.has_comb) {   // adjoint stage terms: one batch of independent node-local loads
 #pragma unroll
-    for (int r = 0; r < G::R; ++r)
-      if (p.has_comb) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
+    for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
+  }
+  if (active) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       const bool ok = sc[r].x >= 0;
