@@ -184,6 +184,23 @@ int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, flo
                            const float *a, const float *al, const float *ar, const float *alpha, const float *dout,
                            float *dwx, float *da, void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
 
+/* Fused message path  m_i = aggr_{e: t_e = i} phi(...)  for a message MLP whose first layer has been split into
+ * node-level terms (ngpde_edge_combine_forward) and whose remaining layers are Dense, all widths <= 64 and
+ * multiples of 4, at most 3 layers after the first (e.g. MPPDEConv 132 => 64 => 64, src/layers.jl:402-416; the VMH
+ * tutorial's 4 => 60 => 60 => 60 => 40, docs/src/tutorials/VMH.md:75-79): gather through LDS, MFMA layers with
+ * LDS-resident weights, in-tile segmented reduction; no per-edge array is written unless save_z[l] is non-NULL
+ * (save_z[0]: z1 [E][h1]; save_z[l]: pre-activation of layer l [E][tail_dout[l-1]], p order) for the pullback.
+ * Needs ngpde_graph_set_gcn_norm to have been called (it builds the tile schedule) and a graph whose tiles fit
+ * the LDS halo; ngpde_edge_mlp_supported returns 1 when this entry can be used, otherwise compose the
+ * primitives above.  out: [N][last width]. */
+int32_t ngpde_edge_mlp_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout);
+int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target,
+                               const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,
+                               const int32_t *tail_act, const float *const *tail_weight, const float *const *tail_bias,
+                               int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream);
+/* a = act.(z) (re-materialises an activation from a saved pre-activation in the pullback of the fused path) */
+int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, float *a, ngpde_stream_t stream);
+
 /* SpectralConv message weights (src/layers.jl:654): w_e = cos(e n / 2) cot(e / 2) / 2; the layer is then
  * propagate(e_mul_xj, g, +) = ngpde_propagate_copy_xj with these weights. */
 int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float *w, ngpde_stream_t stream);

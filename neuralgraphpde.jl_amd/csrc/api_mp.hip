@@ -213,6 +213,53 @@ int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, flo
                         (hipStream_t)stream_);
 }
 
+int32_t ngpde_edge_mlp_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout) {
+  EdgeMlpArgs a;
+  a.h1 = h1; a.n_tail = n_tail;
+  if (n_tail < 0 || n_tail > 3 || (n_tail > 0 && !tail_dout)) return 0;
+  int prev = h1;
+  for (int l = 0; l < n_tail; ++l) { a.din[l] = prev; a.dout[l] = tail_dout[l]; prev = tail_dout[l]; }
+  return edge_mlp_fused_supported(g, a) ? 1 : 0;
+}
+
+int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target,
+                               const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,
+                               const int32_t *tail_act, const float *const *tail_weight, const float *const *tail_bias,
+                               int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_forward: graph is NULL");
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_edge_mlp_forward: unknown aggregation %d", aggr);
+  int32_t st = check_act("ngpde_edge_mlp_forward", act1);
+  if (st) return st;
+  NGPDE_REQUIRE(n_tail >= 0 && n_tail <= 3, NGPDE_ERR_UNSUPPORTED, "ngpde_edge_mlp_forward: 0..3 layers after the first");
+  NGPDE_REQUIRE(n_tail == 0 || (tail_dout && tail_act && tail_weight), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_edge_mlp_forward: NULL layer table");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_forward: out is NULL");
+  EdgeMlpArgs a;
+  a.h1 = h1; a.act1 = act1; a.aggr = aggr; a.n_tail = n_tail;
+  a.P = p_target; a.Q = q_source; a.Eterm = e_term; a.out = out;
+  int prev = h1;
+  for (int l = 0; l < n_tail; ++l) {
+    if ((st = check_act("ngpde_edge_mlp_forward", tail_act[l]))) return st;
+    NGPDE_REQUIRE(tail_weight[l] != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_forward: layer %d weight is NULL", l);
+    a.din[l] = prev; a.dout[l] = tail_dout[l]; a.act[l] = tail_act[l];
+    a.wt[l] = tail_weight[l]; a.bias[l] = tail_bias ? tail_bias[l] : nullptr;
+    prev = tail_dout[l];
+  }
+  if (save_z)
+    for (int l = 0; l <= n_tail; ++l) a.save_z[l] = save_z[l];
+  return launch_edge_mlp_fused_fwd(g, a, (hipStream_t)stream);
+}
+
+int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, float *a, ngpde_stream_t stream) {
+  int32_t st = check_act("ngpde_activation_forward", act);
+  if (st) return st;
+  if (count == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(z && a, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_activation_forward: NULL argument");
+  return launch_activation_fwd(count, act, z, a, (hipStream_t)stream);
+}
+
 int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float *w, ngpde_stream_t stream) {
   if (n_edges == 0) return NGPDE_OK;
   NGPDE_REQUIRE(e && w && n > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_spectral_weights: bad arguments");

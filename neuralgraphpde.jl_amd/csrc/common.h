@@ -199,4 +199,17 @@ int32_t launch_gat_bwd(const ngpde_graph *g, int heads, int c, float slope, cons
                        float *dwx, float *da, hipStream_t stream);
 int32_t launch_spectral_weights(int64_t n_edges, float nn, const float *e, float *w, hipStream_t stream);
 
+// ---- fused edge-MLP forward (edge_mlp_fused.hip) ----------------------------------------------------------
+struct EdgeMlpArgs {
+  int h1 = 0, act1 = 0, aggr = 0, n_tail = 0;
+  const float *P = nullptr, *Q = nullptr, *Eterm = nullptr;
+  int din[3] = {0, 0, 0}, dout[3] = {0, 0, 0}, act[3] = {0, 0, 0};
+  const float *wt[3] = {nullptr, nullptr, nullptr}, *bias[3] = {nullptr, nullptr, nullptr};
+  float *out = nullptr;
+  float *save_z[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+bool edge_mlp_fused_supported(const ngpde_graph *g, const EdgeMlpArgs &a);
+int32_t launch_edge_mlp_fused_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
+int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, hipStream_t stream);
+
 }  // namespace ngpde

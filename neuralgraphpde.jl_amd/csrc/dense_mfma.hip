@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_input_kernel(int64_t n, Se
   }
 }
 
-// ---- weight pullback: partial[chunk][k][o] = sum_{rows of chunk} X[row][k] dz[row][o]; row k == din is the bias (X = 1)
+// ---- weight pullback: partial[chunk][k][o] = sum_{rows of chunk} X[row][k] dz[row][o]; row k == din of `partial`
+// holds the bias gradient sum_rows dz[row][o], accumulated by the blockIdx.x == 0 tiles from the staged dz chunk
 __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, SegTable segs, int din, int dout,
                                                                     const float *__restrict__ dz, int64_t rows_per_chunk,
                                                                     float *__restrict__ partial) {
@@ -173,13 +174,14 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
     for (int p = 0; p < 4; ++p) {
       const int64_t r = rr0 + sn + 4 * p;
       const int k = k0 + scol;
-      areg[p] = (r < r1 && k <= din) ? (k == din ? 1.0f : seg_load(segs, r, k)) : 0.f;
+      areg[p] = (r < r1 && k < din) ? seg_load(segs, r, k) : 0.f;
       breg[p] = (r < r1 && col0 + scol < dout) ? dz[r * dout + col0 + scol] : 0.f;
     }
   };
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
   if (r0 < r1) fetch(r0);
   for (int64_t rr = r0; rr < r1; rr += BK) {
     __syncthreads();
@@ -190,6 +192,13 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
     }
     __syncthreads();
     if (rr + BK < r1) fetch(rr + BK);
+    if (blockIdx.x == 0 && tid < BN) {   // bias row: column sums of the staged dz chunk (one wave, 16 LDS reads)
+#pragma unroll
+      for (int nn = 0; nn < BK; nn += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&ldsBt[tid * LS + nn]);
+        bsum += (v.x + v.y) + (v.z + v.w);
+      }
+    }
     mfma_chunk(ldsA, ldsBt, wave, lane, acc);
   }
   const int i = lane & 15, kq = lane >> 4;
@@ -199,9 +208,11 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int k = k0 + wave * 16 + 4 * kq + reg;
-      if (k <= din && o < dout) partial[((size_t)blockIdx.z * (din + 1) + k) * dout + o] = acc[ct][reg];
+      if (k < din && o < dout) partial[((size_t)blockIdx.z * (din + 1) + k) * dout + o] = acc[ct][reg];
     }
   }
+  if (blockIdx.x == 0 && tid < BN && col0 + tid < dout)
+    partial[((size_t)blockIdx.z * (din + 1) + din) * dout + col0 + tid] = bsum;
 }
 
 __global__ void dense_weight_reduce_kernel(int nchunk, int din, int dout, const float *__restrict__ partial,
@@ -242,7 +253,7 @@ int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, in
   if (dout == 0) return NGPDE_OK;
   const int nchunk = dense_weight_chunks(n);
   const int64_t rpc = std::max<int64_t>(BK, (((n + nchunk - 1) / nchunk) + BK - 1) / BK * BK);
-  hipLaunchKernelGGL(dense_mfma_bwd_weight_kernel, dim3((din + 1 + BM - 1) / BM, (dout + BN - 1) / BN, nchunk), dim3(256), 0,
+  hipLaunchKernelGGL(dense_mfma_bwd_weight_kernel, dim3(std::max(1, (din + BM - 1) / BM), (dout + BN - 1) / BN, nchunk), dim3(256), 0,
                      stream, n, segs, din, dout, dz, rpc, partial);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_weight_kernel");
   const int total = (din + 1) * dout;

@@ -338,3 +338,85 @@ def spectral_weights(e, n):
     w = torch.empty_like(e)
     _lib.check(lib.ngpde_spectral_weights(e.numel(), int(n), _lib.ptr(e), _lib.ptr(w), _lib.current_stream()))
     return w
+
+
+class _EdgeMlpFusedFn(torch.autograd.Function):
+    """m_i = aggr_e phi(...) in one launch (ngpde_edge_mlp_forward): gather through LDS, MFMA layers, in-tile
+    segmented reduction.  Training keeps the per-edge pre-activations and the pullback runs on the primitives."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, acts, *wb):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, *[t for t in wb if t is not None])
+        ref = next(t for t in (P, Q, Eterm) if t is not None)
+        dev, h1 = ref.device, ref.shape[1]
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        wts = [w.contiguous() for w in wb[0::2]]
+        bs = list(wb[1::2])
+        n_tail = len(wts)
+        douts = [w.shape[1] for w in wts]
+        need = any(ctx.needs_input_grad)
+        widths = [h1] + douts
+        saves = [torch.empty((n_edges, w), dtype=torch.float32, device=dev) if need else None for w in widths]
+        out = torch.empty((n_nodes, widths[-1]), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_edge_mlp_forward(handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,
+                                              _int_array(douts) if n_tail else None, _int_array(acts) if n_tail else None,
+                                              _ptr_array(wts) if n_tail else None, _ptr_array(bs) if n_tail else None,
+                                              aggr, _lib.ptr(out), _ptr_array(saves), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (act1, aggr, n_nodes, n_edges, tuple(acts), h1, tuple(douts))
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None,
+                      [b is not None for b in bs])
+        ctx.save_for_backward(*wts, *[s for s in saves if s is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        act1, aggr, n_nodes, n_edges, acts, h1, douts = ctx.meta
+        n_tail = len(douts)
+        saved = ctx.saved_tensors
+        wts, zs = saved[:n_tail], saved[n_tail:]
+        pshape, qshape, has_e, has_b = ctx.shapes
+        dev = dout.device
+        stream = _lib.current_stream()
+        widths = [h1] + list(douts)
+        dM = torch.empty((n_edges, widths[-1]), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_segment_reduce_backward(ctx.handle.ptr, widths[-1], aggr, None, None, _lib.ptr(dout.contiguous()),
+                                                     _lib.ptr(dM), stream))
+        grads_wb = [None] * (2 * n_tail)
+        for l in range(n_tail, 0, -1):
+            z_prev, z_l, wt = zs[l - 1], zs[l], wts[l - 1]
+            a_prev = torch.empty_like(z_prev)
+            _lib.check(lib.ngpde_activation_forward(z_prev.numel(), act1 if l == 1 else acts[l - 2], _lib.ptr(z_prev),
+                                                    _lib.ptr(a_prev), stream))
+            dwt = torch.empty_like(wt)
+            db = torch.empty((douts[l - 1],), dtype=torch.float32, device=dev) if has_b[l - 1] else None
+            da = torch.empty_like(a_prev)
+            ws = _ws(lib.ngpde_dense_workspace_bytes(n_edges, widths[l - 1], douts[l - 1]), dev)
+            _lib.check(lib.ngpde_dense_backward(n_edges, 1, _ptr_array([a_prev]), _int_array([widths[l - 1]]), _int_array([1]),
+                                                douts[l - 1], acts[l - 1], _lib.ptr(wt), _lib.ptr(z_l), _lib.ptr(dM),
+                                                _ptr_array([da]), _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(ws), ws.numel(), stream))
+            grads_wb[2 * (l - 1)], grads_wb[2 * (l - 1) + 1] = dwt, db
+            dM = da
+        dz = torch.empty_like(dM)
+        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if pshape is not None else None
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if qshape is not None else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, h1, act1, _lib.ptr(dM), _lib.ptr(zs[0]), _lib.ptr(dz),
+                                                   _lib.ptr(dP), _lib.ptr(dQ), stream))
+        return (dP, dQ, dz if has_e else None, None, None, None, None, None, None, *grads_wb)
+
+
+def edge_mlp_supported(handle, h1, tail_douts):
+    lib = _lib.load()
+    return bool(lib.ngpde_edge_mlp_supported(handle.ptr, int(h1), len(tail_douts), _int_array(tail_douts) if tail_douts else None))
+
+
+def edge_mlp_fused(P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, tail):
+    """tail: list of (wt [in][out], bias or None, act code) for the layers after the first."""
+    wb = []
+    for wt, b, _ in tail:
+        wb += [wt, b]
+    return _EdgeMlpFusedFn.apply(P, Q, Eterm, handle, act1, _lib.AGGR[aggr] if isinstance(aggr, str) else aggr, n_nodes,
+                                 n_edges, tuple(a for _, _, a in tail), *wb)

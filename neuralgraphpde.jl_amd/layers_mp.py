@@ -44,6 +44,26 @@ def _tail(stack, a):
     return a
 
 
+def _message_path(g, P, Q, Et, stack, aggr):
+    """aggr_e phi(...) given the node-level first-layer terms: ONE fused launch when the message MLP fits the fused
+    kernel (widths <= 64, multiples of 4, <= 3 further Dense layers, tiles fit the LDS halo; max/min only without
+    gradients), the primitives otherwise."""
+    l1 = stack[0][0]
+    ref = next(t for t in (P, Q, Et) if t is not None)
+    tail = [(_wt_b(ps)[0], _wt_b(ps)[1], layer.act) for layer, ps in stack[1:]]
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
+    aggr_code = _lib.AGGR[aggr]
+    import os
+    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or not needs_grad):
+        fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
+        if F.edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
+            return F.edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)
+    handle = g.handle()
+    a = F.edge_combine(P, Q, Et, handle, l1.act, g.num_edges)
+    return F.segment_reduce(_tail(stack, a), handle, aggr, g.num_nodes)
+
+
 def _split_rows(wt, sizes):
     out, o = [], 0
     for n in sizes:
@@ -122,9 +142,7 @@ class ExplicitEdgeConv(AbstractGNNContainerLayer):
         wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; hj...; xj - xi]
         P = F.dense(hblocks + [pos], _cat_rows([wa, -wc]), b, 0)
         Q = F.dense(hblocks + [pos], _cat_rows([wb, wc]), None, 0)
-        a = F.edge_combine(P, Q, None, handle, l1.act, g.num_edges)
-        m = _tail(stack, a)
-        y = F.segment_reduce(m, handle, self.aggr, g.num_nodes)                   # :111
+        y = _message_path(g, P, Q, None, stack, self.aggr)                          # propagate(message, g, aggr)  (:111)
         return y.T, st
 
 
@@ -158,8 +176,7 @@ class VMHConv(AbstractGNNContainerLayer):
         wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; (hj - hi)...; xj - xi]  (:316)
         P = F.dense(hblocks + [pos], _cat_rows([wa - wb, -wc]), b, 0)
         Q = F.dense(hblocks + [pos], _cat_rows([wb, wc]), None, 0)
-        a = F.edge_combine(P, Q, None, handle, l1.act, g.num_edges)
-        m = F.segment_reduce(_tail(stack, a), handle, self.aggr, g.num_nodes)     # :326
+        m = _message_path(g, P, Q, None, stack, self.aggr)                          # :326
         gstack = _dense_stack(self.γ, ps["γ"], "γ")
         g1, gp1 = gstack[0]
         gwt, gb = _wt_b(gp1)
@@ -208,8 +225,7 @@ class MPPDEConv(AbstractGNNContainerLayer):
         P = F.dense(tb, _cat_rows(tw), b, 0, row_divs=trd, n=N)
         Q = F.dense([h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0)
         Et = F.dense([e_p], wd, None, 0) if de else None
-        a = F.edge_combine(P, Q, Et, handle, l1.act, E)
-        m = F.segment_reduce(_tail(stack, a), handle, self.aggr, N)                # :416
+        m = _message_path(g, P, Q, Et, stack, self.aggr)                            # :416
         pstack = _dense_stack(self.ψ, ps["ψ"], "ψ")
         q1, qp1 = pstack[0]
         qwt, qb = _wt_b(qp1)

@@ -408,3 +408,61 @@ def test_segment_reduce_edge_cases():
     back = F.edge_permute(Mp2.grad, h, inverse=True)
     assert back.tolist() == [[1.0, 1.0], [0.0, 1.0], [1.0, 1.0]]
     assert torch.equal(F.edge_permute(Mp, h, inverse=True), M)
+
+
+# ---- fused message path (one launch) against the primitives and the oracle -------------------------------------------------
+
+@pytest.mark.parametrize("aggr", ["mean", "+", "max", "min"])
+def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
+    # MPPDE shape of BASELINE config 4 at test size: h = 64, phi 132 => 64 => 64 swish, periodic mesh, 3 trajectories
+    n, G, h = 256, 3, 64
+    idx = np.arange(n)
+    s = np.concatenate([idx for k in (-3, -2, -1, 1, 2, 3)])
+    t = np.concatenate([(idx + k) % n for k in (-3, -2, -1, 1, 2, 3)])
+    rng = np.random.default_rng(21)
+    gs, ogs = [], []
+    for _ in range(G):
+        nd = {"u": rng.random((1, n)), "x": (idx / n).reshape(1, n)}
+        gd = {"θ": rng.random(2)}
+        gs.append(ng.GNNGraph(s, t, num_nodes=n, index_base=0, ndata=nd, gdata=gd))
+        ogs.append(O.Graph(s, t, num_nodes=n, index_base=0, ndata=nd, gdata=gd))
+    g, og = ng.batch(gs), O.batch(ogs)
+    phi = ng.Chain(ng.Dense(2 * h + 2 + 2, 64, "swish"), ng.Dense(64, 64, "swish"))
+    psi = ng.Chain(ng.Dense(h + 64 + 2, 64, "swish"), ng.Dense(64, h))
+    l = ng.MPPDEConv(phi, psi, initialgraph=g, aggr=aggr)
+    ps, st = ng.setup(21, l)
+    ps = prep(ps, 21)
+    x = torch.randn(h, n * G, device=DEV)
+    from ngpde_amd import functional as F
+    fh = g.handle((False, None, False))
+    assert F.edge_mlp_supported(fh, 64, [64])
+    with torch.no_grad():
+        y_fused, _ = l(x, ps, st)
+        monkeypatch.setenv("NGPDE_NO_FUSED_EDGE", "1")
+        y_prim, _ = l(x, ps, st)
+        monkeypatch.delenv("NGPDE_NO_FUSED_EDGE")
+    yo, c = O.mppde_conv(x.cpu().double().numpy(), omlp(phi, ps["ϕ"]), omlp(psi, ps["ψ"]), og, aggr)
+    close(y_fused, yo)
+    close(y_prim, yo)
+    close(y_fused, y_prim.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    y2, _ = l(x, ps, st)
+    assert torch.equal(y2.detach(), y_fused) or aggr in ("max", "min")       # fused path is bitwise reproducible
+    if aggr in ("mean", "+"):                                                  # training: fused forward, primitive pullback
+        xg = x.clone().requires_grad_(True)
+        yg, _ = l(xg, ps, st)
+        R = rng.normal(size=yo.shape)
+        (yg * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+        gr = O.mppde_conv_backward(c, R)
+        n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+        n2, o2 = mlp_grad_pairs(ps["ψ"], gr["psi"], psi)
+        check_grads(ps, (n1 + n2, o1 + o2), xg, gr["x"])
+
+
+def test_fused_message_path_falls_back_when_unsupported():
+    from ngpde_amd import functional as F
+    g = ng.rand_graph(50, 200, seed=1)
+    fh = g.handle((False, None, False))
+    assert not F.edge_mlp_supported(fh, 66, [64])       # wider than 64
+    assert not F.edge_mlp_supported(fh, 64, [9])        # not a multiple of 4
+    assert not F.edge_mlp_supported(fh, 64, [64, 64, 64, 64])   # more than 3 further layers
+    assert F.edge_mlp_supported(fh, 60, [60, 60, 40])   # the VMH tutorial's message MLP
