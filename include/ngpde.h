@@ -173,6 +173,17 @@ int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t
                                     const float *dm, float *dk, float *dh, void *workspace, size_t workspace_bytes,
                                     ngpde_stream_t stream);
 
+/* GNOConv message in reassociated form: when the last layer of phi is Dense(k => in*out) with identity activation,
+ *   m_e = reshape(W2 z_e + b2, out, in) h_j = T_j z_e + Bh_j,   T_j[o][kk] = sum_i W2[o + out*i][kk] h_j[i]  (node level),
+ * so the in*out x E kernel tensor of src/layers.jl:527 is never formed.  t: [N][cout*kdim] (element o*kdim + kk),
+ * bh: [N][cout] or NULL, z: [E][kdim] last hidden activation of phi (p order), m: [E][cout] (p order).
+ * Backward: dt [N][cout*kdim], dbh [N][cout], dz [E][kdim], each nullable. */
+int32_t ngpde_gno_apply_supported(int32_t cout, int32_t kdim);
+int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *bh,
+                                const float *z, float *m, ngpde_stream_t stream);
+int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *z,
+                                 const float *dm, float *dt, float *dbh, float *dz, ngpde_stream_t stream);
+
 /* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
  * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);
  * alpha = softmax over the incoming edges of each node; out[N][heads*c] = sum_e alpha_e Wx[s_e].

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ngpde_segment_reduce_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gno_contract_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ngpde_gno_contract_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_gno_apply_supported": (_i32, [_i32, _i32]),
+    "ngpde_gno_apply_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gno_apply_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gat_forward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gat_workspace_bytes": (_sz, [_vp, _i32]),
     "ngpde_gat_backward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

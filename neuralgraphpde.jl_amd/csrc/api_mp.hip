@@ -56,7 +56,7 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
 
 size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout) {
   return align256((size_t)std::max<int64_t>(n, 1) * dout * 4) +
-         align256((size_t)dense_weight_chunks(n) * (din_total + 1) * dout * 4) + 256;
+         align256((size_t)dense_weight_chunks(n, din_total, dout) * (din_total + 1) * dout * 4) + 256;
 }
 
 int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
@@ -176,6 +176,27 @@ int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t
   if (st) return st;
   if (dh) return launch_edge_sum_by_source(g, cin, (const float *)workspace, dh, stream);
   return NGPDE_OK;
+}
+
+int32_t ngpde_gno_apply_supported(int32_t cout, int32_t kdim) { return gno_apply_supported(cout, kdim) ? 1 : 0; }
+
+int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *bh,
+                                const float *z, float *m, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_forward: graph is NULL");
+  NGPDE_REQUIRE(gno_apply_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_gno_apply_forward: out = %d, k = %d outside the reassociated path (out * k <= 8192, T_j must fit LDS)", cout, kdim);
+  if (g->n_edges == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(t && z && m, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_forward: NULL argument");
+  return launch_gno_apply_fwd(g, cout, kdim, t, bh, z, m, (hipStream_t)stream);
+}
+
+int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *z,
+                                 const float *dm, float *dt, float *dbh, float *dz, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_backward: graph is NULL");
+  NGPDE_REQUIRE(gno_apply_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED, "ngpde_gno_apply_backward: unsupported out = %d, k = %d", cout, kdim);
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(t && (g->n_edges == 0 || (z && dm)), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_backward: NULL argument");
+  return launch_gno_apply_bwd(g, cout, kdim, t, z, dm, dt, dbh, dz, (hipStream_t)stream);
 }
 
 int32_t ngpde_gat_forward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,

@@ -174,7 +174,7 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
 int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
                                    hipStream_t stream);
-int dense_weight_chunks(int64_t n);
+int dense_weight_chunks(int64_t n, int din, int dout);
 int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
                                     float *db, float *partial, hipStream_t stream);
 int32_t launch_edge_permute(const ngpde_graph *g, int d, bool inverse, const float *src, float *dst, hipStream_t stream);
@@ -190,6 +190,11 @@ int32_t launch_gno_contract_fwd(const ngpde_graph *g, int cin, int cout, const f
                                 hipStream_t stream);
 int32_t launch_gno_contract_bwd(const ngpde_graph *g, int cin, int cout, const float *K, const float *h, const float *dm,
                                 float *dK, float *dhe, hipStream_t stream);
+bool gno_apply_supported(int cout, int kdim);
+int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z,
+                             float *m, hipStream_t stream);
+int32_t launch_gno_apply_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm,
+                             float *dT, float *dBh, float *dz, hipStream_t stream);
 int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const float *a, float *al, float *ar,
                           hipStream_t stream);
 int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,

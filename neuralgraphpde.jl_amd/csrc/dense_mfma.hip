@@ -246,12 +246,18 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
   return NGPDE_OK;
 }
 
-int dense_weight_chunks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (n + 2047) / 2048)); }
+// row chunks of the weight pullback: enough (tile x chunk) workgroups to cover the chip several times over (the chunk
+// loop is a dependent global-load chain, ~16 rows per trip), at least 64 rows per chunk, at most 512 partial slabs
+int dense_weight_chunks(int64_t n, int din, int dout) {
+  const int64_t tiles = (int64_t)std::max(1, (din + BM - 1) / BM) * std::max(1, (dout + BN - 1) / BN);
+  const int64_t want = (2048 + tiles - 1) / tiles;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(512, want), (n + 63) / 64));
+}
 
 int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
                                     float *db, float *partial, hipStream_t stream) {
   if (dout == 0) return NGPDE_OK;
-  const int nchunk = dense_weight_chunks(n);
+  const int nchunk = dense_weight_chunks(n, din, dout);
   const int64_t rpc = std::max<int64_t>(BK, (((n + nchunk - 1) / nchunk) + BK - 1) / BK * BK);
   hipLaunchKernelGGL(dense_mfma_bwd_weight_kernel, dim3(std::max(1, (din + BM - 1) / BM), (dout + BN - 1) / BN, nchunk), dim3(256), 0,
                      stream, n, segs, din, dout, dz, rpc, partial);

@@ -191,6 +191,123 @@ __global__ __launch_bounds__(256) void gno_contract_bwd_kernel(int64_t n_edges, 
   }
 }
 
+// ---- GNOConv, reassociated: with z_e the last hidden activation of phi (width k) and W2, b2 its
+// last Dense layer, K_e = reshape(W2 z_e + b2, out, in) and  m_e = K_e h_j = T_j z_e + (B2 h_j),
+// T_j[o][kk] = sum_i W2[o + out*i][kk] h_j[i]  a NODE-level product.  The in*out x E kernel tensor (64 KB per edge at
+// 128-d) is never formed.  One workgroup per SOURCE node stages T_j in LDS (row stride out + 1: conflict-free for
+// both access directions) and serves all edges leaving j; outputs land at the edges' p positions.
+constexpr int kGnoBatch = 16;   // edges of one source staged per LDS pass
+
+__global__ __launch_bounds__(256) void gno_apply_fwd_kernel(int n_nodes, int cout, int kdim, const int *__restrict__ rowptr_s,
+                                                            const int *__restrict__ xpos, const float *__restrict__ T,
+                                                            const float *__restrict__ Bh, const float *__restrict__ z,
+                                                            float *__restrict__ m) {
+  extern __shared__ float sh[];
+  float *Tl = sh;                                   // [kdim][cout + 1]
+  float *zl = sh + (size_t)kdim * (cout + 1);       // [kGnoBatch][kdim]
+  __shared__ int pl[kGnoBatch];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int rs = rowptr_s[j], re = rowptr_s[j + 1];
+  if (rs == re) return;
+  const int ts = cout + 1;
+  for (int idx = tid; idx < cout * kdim; idx += 256) {
+    const int o = idx / kdim, kk = idx - o * kdim;  // T row-major [o][kk] in memory: coalesced reads
+    Tl[kk * ts + o] = T[(size_t)j * cout * kdim + idx];
+  }
+  const int EB = 256 / cout;                        // edges served concurrently (cout <= 256)
+  const int el = tid / cout, o = tid - el * cout;
+  const float bias = (Bh && el < EB) ? Bh[(size_t)j * cout + o] : 0.f;
+  for (int q0 = rs; q0 < re; q0 += kGnoBatch) {
+    const int nb = min(kGnoBatch, re - q0);
+    __syncthreads();
+    if (tid < nb) pl[tid] = xpos[q0 + tid];
+    for (int idx = tid; idx < nb * kdim; idx += 256) {
+      const int e2 = idx / kdim, kk = idx - e2 * kdim;
+      zl[idx] = z[(size_t)xpos[q0 + e2] * kdim + kk];
+    }
+    __syncthreads();
+    if (el < EB) {
+      for (int e2 = el; e2 < nb; e2 += EB) {
+        float acc = bias;
+        const float *zr = zl + e2 * kdim;
+        for (int kk = 0; kk < kdim; ++kk) acc = fmaf(Tl[kk * ts + o], zr[kk], acc);
+        m[(size_t)pl[e2] * cout + o] = acc;
+      }
+    }
+  }
+}
+
+// pullback: dz_e = T_j^T dm_e;  dT_j = sum_{e leaving j} dm_e (x) z_e;  dBh_j = sum_e dm_e.
+// Thread (kk = tid mod KP, og = tid / KP), KP = kdim rounded up to a power of two, keeps dT_j[og + a*OG][kk] in registers.
+__global__ __launch_bounds__(256) void gno_apply_bwd_kernel(int n_nodes, int cout, int kdim, int kp_log2,
+                                                            const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
+                                                            const float *__restrict__ T, const float *__restrict__ z,
+                                                            const float *__restrict__ dm, float *__restrict__ dT,
+                                                            float *__restrict__ dBh, float *__restrict__ dz) {
+  extern __shared__ float sh[];
+  float *Tl = sh;                                   // [kdim][cout + 1]
+  float *zl = sh + (size_t)kdim * (cout + 1);       // [kGnoBatch][kdim]
+  float *dml = zl + kGnoBatch * kdim;               // [kGnoBatch][cout]
+  __shared__ int pl[kGnoBatch];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int rs = rowptr_s[j], re = rowptr_s[j + 1];
+  const int ts = cout + 1, total = cout * kdim;
+  const int kk = tid & ((1 << kp_log2) - 1), og = tid >> kp_log2, OG = 256 >> kp_log2;
+  constexpr int MAXA = 32;                          // cout <= MAXA * OG  (host-checked)
+  float acc[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) acc[a] = 0.f;
+  float accb = 0.f;
+  if (dz && rs < re)
+    for (int idx = tid; idx < total; idx += 256) {
+      const int o = idx / kdim;
+      Tl[(idx - o * kdim) * ts + o] = T[(size_t)j * total + idx];
+    }
+  for (int q0 = rs; q0 < re; q0 += kGnoBatch) {
+    const int nb = min(kGnoBatch, re - q0);
+    __syncthreads();
+    if (tid < nb) pl[tid] = xpos[q0 + tid];
+    for (int idx = tid; idx < nb * kdim; idx += 256) {
+      const int e2 = idx / kdim;
+      zl[idx] = z[(size_t)xpos[q0 + e2] * kdim + (idx - e2 * kdim)];
+    }
+    for (int idx = tid; idx < nb * cout; idx += 256) {
+      const int e2 = idx / cout;
+      dml[idx] = dm[(size_t)xpos[q0 + e2] * cout + (idx - e2 * cout)];
+    }
+    __syncthreads();
+    if (dz && kk < kdim) {
+      for (int e2 = og; e2 < nb; e2 += OG) {
+        const float *dr = dml + e2 * cout;
+        float s = 0.f;
+        for (int o = 0; o < cout; ++o) s = fmaf(Tl[kk * ts + o], dr[o], s);
+        dz[(size_t)pl[e2] * kdim + kk] = s;
+      }
+    }
+    if (kk < kdim) {
+      for (int e2 = 0; e2 < nb; ++e2) {
+        const float zk = zl[e2 * kdim + kk];
+        const float *dr = dml + e2 * cout;
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+          const int o = og + a * OG;
+          if (o < cout) acc[a] = fmaf(dr[o], zk, acc[a]);
+        }
+      }
+    }
+    if (tid < cout)
+      for (int e2 = 0; e2 < nb; ++e2) accb += dml[e2 * cout + tid];
+  }
+  if (dT && kk < kdim) {
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+      const int o = og + a * OG;
+      if (o < cout) dT[(size_t)j * total + (size_t)o * kdim + kk] = acc[a];
+    }
+  }
+  if (dBh && tid < cout) dBh[(size_t)j * cout + tid] = accb;
+}
+
 // ---- GAT-style attention over incoming edges [GraphNeuralNetworks.jl GATConv] --------------------------------
 // per (target i, head k): logit_p = leakyrelu(al[i][k] + ar[s_p][k]); alpha = softmax over the row (max-subtracted);
 // out[i][k*C + c] = sum_p alpha_p Wx[s_p][k*C + c].  One wave per target row, loops over heads.
@@ -442,6 +559,39 @@ int32_t launch_gno_contract_bwd(const ngpde_graph *g, int cin, int cout, const f
   hipLaunchKernelGGL(gno_contract_bwd_kernel, dim3(rows4(g->n_edges)), dim3(256), 0, stream, g->n_edges, cin, cout,
                      g->by_t.col, K, h, dm, dK, dhe);
   NGPDE_LAUNCH_CHECK("gno_contract_bwd_kernel");
+  return NGPDE_OK;
+}
+
+static int gno_kp_log2(int kdim) {
+  int l = 0;
+  while ((1 << l) < kdim) ++l;
+  return l;
+}
+
+bool gno_apply_supported(int cout, int kdim) {
+  if (cout <= 0 || kdim <= 0 || cout > 256 || kdim > 256) return false;
+  const int og = 256 >> gno_kp_log2(kdim);
+  return cout <= 32 * og &&
+         ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * (kdim + cout)) * sizeof(float) <= 60 * 1024;
+}
+
+int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z,
+                             float *m, hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  const size_t sh = ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * kdim) * sizeof(float);
+  hipLaunchKernelGGL(gno_apply_fwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), sh, stream, (int)g->n_nodes, cout, kdim,
+                     g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m);
+  NGPDE_LAUNCH_CHECK("gno_apply_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gno_apply_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm,
+                             float *dT, float *dBh, float *dz, hipStream_t stream) {
+  if (g->n_nodes == 0) return NGPDE_OK;
+  const size_t sh = ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * (kdim + cout)) * sizeof(float);
+  hipLaunchKernelGGL(gno_apply_bwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), sh, stream, (int)g->n_nodes, cout, kdim,
+                     gno_kp_log2(kdim), g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, dBh, dz);
+  NGPDE_LAUNCH_CHECK("gno_apply_bwd_kernel");
   return NGPDE_OK;
 }
 

@@ -276,6 +276,45 @@ def gno_contract(K, h, handle, cin, cout):
     return _GnoContractFn.apply(K, h, handle, cin, cout)
 
 
+class _GnoApplyFn(torch.autograd.Function):
+    """Reassociated GNOConv message  m_e = T_{s_e} z_e + Bh_{s_e}  (include/ngpde.h: ngpde_gno_apply_forward)."""
+
+    @staticmethod
+    def forward(ctx, T, Bh, z, handle, cout, kdim):
+        lib = _lib.load()
+        _need_cuda(T, z)
+        T, z = T.contiguous(), z.contiguous()
+        Bh = Bh.contiguous() if Bh is not None else None
+        m = torch.empty((z.shape[0], cout), dtype=torch.float32, device=z.device)
+        _lib.check(lib.ngpde_gno_apply_forward(handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(Bh), _lib.ptr(z), _lib.ptr(m),
+                                               _lib.current_stream()))
+        ctx.handle, ctx.dims, ctx.has_bh = handle, (cout, kdim), Bh is not None
+        ctx.save_for_backward(T, z)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        T, z = ctx.saved_tensors
+        cout, kdim = ctx.dims
+        dm = dm.contiguous()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[0] else None
+        dBh = (torch.empty((T.shape[0], cout), dtype=torch.float32, device=T.device)
+               if ctx.has_bh and ctx.needs_input_grad[1] else None)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[2] else None
+        _lib.check(lib.ngpde_gno_apply_backward(ctx.handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(z), _lib.ptr(dm),
+                                                _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(dz), _lib.current_stream()))
+        return dT, dBh, dz, None, None, None
+
+
+def gno_apply_supported(cout, kdim):
+    return bool(_lib.load().ngpde_gno_apply_supported(int(cout), int(kdim)))
+
+
+def gno_apply(T, Bh, z, handle, cout, kdim):
+    return _GnoApplyFn.apply(T, Bh, z, handle, cout, kdim)
+
+
 class _GatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, wx, a, handle, heads, c, slope, n_edges):

@@ -323,12 +323,22 @@ def test_gno_reference_case_and_updategraph():
     close(y2, yo2)
 
 
-def test_gno_parity_and_grads():
+@pytest.mark.parametrize("variant", ["reassociated", "materialized", "three-layer", "no-bias"])
+def test_gno_parity_and_grads(variant, monkeypatch):
+    # "reassociated": K_e h_j = T_j z_e + B2 h_j (ngpde_gno_apply_*), the default whenever the last layer of phi is an
+    # identity Dense; "materialized": the literal reshape/batched_mul of src/layers.jl:527-530 (ngpde_gno_contract_*)
     N, E, cin, cout = 120, 900, 6, 5
     rng = np.random.default_rng(11)
     nd = {"a": rng.random((1, N)), "x": rng.random((2, N))}
     g, og = rgraph(N, E, 11, ndata=nd)
-    phi = ng.Chain(ng.Dense(6, 16, "relu"), ng.Dense(16, cin * cout))
+    if variant == "materialized":
+        monkeypatch.setenv("NGPDE_GNO_MATERIALIZE", "1")
+    if variant == "three-layer":
+        phi = ng.Chain(ng.Dense(6, 16, "relu"), ng.Dense(16, 12, "tanh"), ng.Dense(12, cin * cout))
+    elif variant == "no-bias":
+        phi = ng.Chain(ng.Dense(6, 16, "relu"), ng.Dense(16, cin * cout, bias=False))
+    else:
+        phi = ng.Chain(ng.Dense(6, 16, "relu"), ng.Dense(16, cin * cout))
     l = ng.GNOConv((cin, cout), phi, "tanh", initialgraph=g)
     ps, st = ng.setup(11, l)
     ps = prep(ps, 11)
