@@ -184,7 +184,7 @@ int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kd
                                 const float *z, float *m, ngpde_stream_t stream) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_forward: graph is NULL");
   NGPDE_REQUIRE(gno_apply_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED,
-                "ngpde_gno_apply_forward: out = %d, k = %d outside the reassociated path (out * k <= 8192, T_j must fit LDS)", cout, kdim);
+                "ngpde_gno_apply_forward: out = %d, k = %d outside the reassociated path (out, k <= 256; T_j [k][out] must fit 60 KB of LDS)", cout, kdim);
   if (g->n_edges == 0) return NGPDE_OK;
   NGPDE_REQUIRE(t && z && m, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_forward: NULL argument");
   return launch_gno_apply_fwd(g, cout, kdim, t, bh, z, m, (hipStream_t)stream);

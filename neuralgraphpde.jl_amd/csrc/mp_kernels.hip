@@ -198,22 +198,39 @@ __global__ __launch_bounds__(256) void gno_contract_bwd_kernel(int64_t n_edges, 
 // both access directions) and serves all edges leaving j; outputs land at the edges' p positions.
 constexpr int kGnoBatch = 16;   // edges of one source staged per LDS pass
 
+__device__ __forceinline__ int pad4(int v) { return (v + 3) & ~3; }
+
+// stage T_j ([cout][kdim] row-major in memory) as Tl[kk][o] with zero padding to multiples of 4 in both extents
+__device__ __forceinline__ void gno_stage_t(float *Tl, const float *__restrict__ Tj, int cout, int kdim, int cP, int kdP, int tid) {
+  const int ts = cP + 1;
+  for (int idx = tid; idx < cP * kdP; idx += 256) {
+    const int o = idx / kdP, kk = idx - o * kdP;
+    Tl[kk * ts + o] = (o < cout && kk < kdim) ? Tj[(size_t)o * kdim + kk] : 0.f;
+  }
+}
+
+// stage up to kGnoBatch edge rows (width w, padded to wP with zeros) addressed through xpos
+__device__ __forceinline__ void gno_stage_rows(float *dst, const float *__restrict__ src, const int *__restrict__ xpos, int q0, int nb,
+                                               int w, int wP, int tid) {
+  for (int idx = tid; idx < nb * wP; idx += 256) {
+    const int e2 = idx / wP, c = idx - e2 * wP;
+    dst[idx] = c < w ? src[(size_t)xpos[q0 + e2] * w + c] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void gno_apply_fwd_kernel(int n_nodes, int cout, int kdim, const int *__restrict__ rowptr_s,
                                                             const int *__restrict__ xpos, const float *__restrict__ T,
                                                             const float *__restrict__ Bh, const float *__restrict__ z,
                                                             float *__restrict__ m) {
-  extern __shared__ float sh[];
-  float *Tl = sh;                                   // [kdim][cout + 1]
-  float *zl = sh + (size_t)kdim * (cout + 1);       // [kGnoBatch][kdim]
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int cP = pad4(cout), kdP = pad4(kdim), ts = cP + 1;
+  float *zl = sh;                                   // [kGnoBatch][kdP]   (16-byte aligned rows)
+  float *Tl = sh + kGnoBatch * kdP;                 // [kdP][cP + 1]
   __shared__ int pl[kGnoBatch];
   const int j = blockIdx.x, tid = threadIdx.x;
   const int rs = rowptr_s[j], re = rowptr_s[j + 1];
   if (rs == re) return;
-  const int ts = cout + 1;
-  for (int idx = tid; idx < cout * kdim; idx += 256) {
-    const int o = idx / kdim, kk = idx - o * kdim;  // T row-major [o][kk] in memory: coalesced reads
-    Tl[kk * ts + o] = T[(size_t)j * cout * kdim + idx];
-  }
+  gno_stage_t(Tl, T + (size_t)j * cout * kdim, cout, kdim, cP, kdP, tid);
   const int EB = 256 / cout;                        // edges served concurrently (cout <= 256)
   const int el = tid / cout, o = tid - el * cout;
   const float bias = (Bh && el < EB) ? Bh[(size_t)j * cout + o] : 0.f;
@@ -221,88 +238,105 @@ __global__ __launch_bounds__(256) void gno_apply_fwd_kernel(int n_nodes, int cou
     const int nb = min(kGnoBatch, re - q0);
     __syncthreads();
     if (tid < nb) pl[tid] = xpos[q0 + tid];
-    for (int idx = tid; idx < nb * kdim; idx += 256) {
-      const int e2 = idx / kdim, kk = idx - e2 * kdim;
-      zl[idx] = z[(size_t)xpos[q0 + e2] * kdim + kk];
-    }
+    gno_stage_rows(zl, z, xpos, q0, nb, kdim, kdP, tid);
     __syncthreads();
     if (el < EB) {
-      for (int e2 = el; e2 < nb; e2 += EB) {
-        float acc = bias;
-        const float *zr = zl + e2 * kdim;
-        for (int kk = 0; kk < kdim; ++kk) acc = fmaf(Tl[kk * ts + o], zr[kk], acc);
-        m[(size_t)pl[e2] * cout + o] = acc;
+      for (int e0 = el; e0 < nb; e0 += 4 * EB) {    // register tile: 4 edges share every T read
+        int er[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) er[i] = min(e0 + i * EB, nb - 1);
+        float acc[4] = {bias, bias, bias, bias};
+        for (int kk = 0; kk < kdP; kk += 4) {
+          const float t0 = Tl[kk * ts + o], t1 = Tl[(kk + 1) * ts + o], t2 = Tl[(kk + 2) * ts + o], t3 = Tl[(kk + 3) * ts + o];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 z4 = *reinterpret_cast<const float4 *>(&zl[er[i] * kdP + kk]);
+            acc[i] = fmaf(t0, z4.x, fmaf(t1, z4.y, fmaf(t2, z4.z, fmaf(t3, z4.w, acc[i]))));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (e0 + i * EB < nb) m[(size_t)pl[e0 + i * EB] * cout + o] = acc[i];
       }
     }
   }
 }
 
 // pullback: dz_e = T_j^T dm_e;  dT_j = sum_{e leaving j} dm_e (x) z_e;  dBh_j = sum_e dm_e.
-// Thread (kk = tid mod KP, og = tid / KP), KP = kdim rounded up to a power of two, keeps dT_j[og + a*OG][kk] in registers.
-__global__ __launch_bounds__(256) void gno_apply_bwd_kernel(int n_nodes, int cout, int kdim, int kp_log2,
+// Thread (kk = tid mod KP, og = tid / KP), KP = kdim rounded up to a power of two, keeps the A consecutive rows
+// dT_j[og*A .. og*A + A)[kk] in registers (A <= 32, a multiple of 4).
+__global__ __launch_bounds__(256) void gno_apply_bwd_kernel(int n_nodes, int cout, int kdim, int kp_log2, int A,
                                                             const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
                                                             const float *__restrict__ T, const float *__restrict__ z,
                                                             const float *__restrict__ dm, float *__restrict__ dT,
                                                             float *__restrict__ dBh, float *__restrict__ dz) {
-  extern __shared__ float sh[];
-  float *Tl = sh;                                   // [kdim][cout + 1]
-  float *zl = sh + (size_t)kdim * (cout + 1);       // [kGnoBatch][kdim]
-  float *dml = zl + kGnoBatch * kdim;               // [kGnoBatch][cout]
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int cP = pad4(cout), kdP = pad4(kdim), ts = cP + 1;
+  float *zl = sh;                                   // [kGnoBatch][kdP]
+  float *dml = zl + kGnoBatch * kdP;                // [kGnoBatch][cP]
+  float *Tl = dml + kGnoBatch * cP;                 // [kdP][cP + 1]
   __shared__ int pl[kGnoBatch];
   const int j = blockIdx.x, tid = threadIdx.x;
   const int rs = rowptr_s[j], re = rowptr_s[j + 1];
-  const int ts = cout + 1, total = cout * kdim;
+  const int total = cout * kdim;
   const int kk = tid & ((1 << kp_log2) - 1), og = tid >> kp_log2, OG = 256 >> kp_log2;
-  constexpr int MAXA = 32;                          // cout <= MAXA * OG  (host-checked)
+  constexpr int MAXA = 32;
   float acc[MAXA];
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) acc[a] = 0.f;
   float accb = 0.f;
-  if (dz && rs < re)
-    for (int idx = tid; idx < total; idx += 256) {
-      const int o = idx / kdim;
-      Tl[(idx - o * kdim) * ts + o] = T[(size_t)j * total + idx];
-    }
+  if (dz && rs < re) gno_stage_t(Tl, T + (size_t)j * total, cout, kdim, cP, kdP, tid);
+  const int ob = og * A;                            // first output row of this thread's block
   for (int q0 = rs; q0 < re; q0 += kGnoBatch) {
     const int nb = min(kGnoBatch, re - q0);
     __syncthreads();
     if (tid < nb) pl[tid] = xpos[q0 + tid];
-    for (int idx = tid; idx < nb * kdim; idx += 256) {
-      const int e2 = idx / kdim;
-      zl[idx] = z[(size_t)xpos[q0 + e2] * kdim + (idx - e2 * kdim)];
-    }
-    for (int idx = tid; idx < nb * cout; idx += 256) {
-      const int e2 = idx / cout;
-      dml[idx] = dm[(size_t)xpos[q0 + e2] * cout + (idx - e2 * cout)];
-    }
+    gno_stage_rows(zl, z, xpos, q0, nb, kdim, kdP, tid);
+    gno_stage_rows(dml, dm, xpos, q0, nb, cout, cP, tid);
     __syncthreads();
     if (dz && kk < kdim) {
-      for (int e2 = og; e2 < nb; e2 += OG) {
-        const float *dr = dml + e2 * cout;
-        float s = 0.f;
-        for (int o = 0; o < cout; ++o) s = fmaf(Tl[kk * ts + o], dr[o], s);
-        dz[(size_t)pl[e2] * kdim + kk] = s;
+      for (int e0 = og; e0 < nb; e0 += 4 * OG) {    // register tile: 4 edges share every T read
+        int er[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) er[i] = min(e0 + i * OG, nb - 1);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < cP; o += 4) {
+          const float t0 = Tl[kk * ts + o], t1 = Tl[kk * ts + o + 1], t2 = Tl[kk * ts + o + 2], t3 = Tl[kk * ts + o + 3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(&dml[er[i] * cP + o]);
+            s[i] = fmaf(t0, d4.x, fmaf(t1, d4.y, fmaf(t2, d4.z, fmaf(t3, d4.w, s[i]))));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (e0 + i * OG < nb) dz[(size_t)pl[e0 + i * OG] * kdim + kk] = s[i];
       }
     }
-    if (kk < kdim) {
+    if (kk < kdim && ob < cP) {
       for (int e2 = 0; e2 < nb; ++e2) {
-        const float zk = zl[e2 * kdim + kk];
-        const float *dr = dml + e2 * cout;
+        const float zk = zl[e2 * kdP + kk];
+        const float *dr = dml + e2 * cP + ob;
 #pragma unroll
-        for (int a = 0; a < MAXA; ++a) {
-          const int o = og + a * OG;
-          if (o < cout) acc[a] = fmaf(dr[o], zk, acc[a]);
+        for (int a = 0; a < MAXA; a += 4) {
+          if (a < A && ob + a < cP) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(dr + a);
+            acc[a] = fmaf(d4.x, zk, acc[a]);
+            acc[a + 1] = fmaf(d4.y, zk, acc[a + 1]);
+            acc[a + 2] = fmaf(d4.z, zk, acc[a + 2]);
+            acc[a + 3] = fmaf(d4.w, zk, acc[a + 3]);
+          }
         }
       }
     }
     if (tid < cout)
-      for (int e2 = 0; e2 < nb; ++e2) accb += dml[e2 * cout + tid];
+      for (int e2 = 0; e2 < nb; ++e2) accb += dml[e2 * cP + tid];
   }
   if (dT && kk < kdim) {
 #pragma unroll
     for (int a = 0; a < MAXA; ++a) {
-      const int o = og + a * OG;
-      if (o < cout) dT[(size_t)j * total + (size_t)o * kdim + kk] = acc[a];
+      const int o = ob + a;
+      if (a < A && o < cout) dT[(size_t)j * total + (size_t)o * kdim + kk] = acc[a];
     }
   }
   if (dBh && tid < cout) dBh[(size_t)j * cout + tid] = accb;
@@ -568,19 +602,29 @@ static int gno_kp_log2(int kdim) {
   return l;
 }
 
+static int gno_pad4(int v) { return (v + 3) & ~3; }
+
+// rows of dT_j per thread in the pullback: ceil(pad4(cout) / OG) rounded up to a multiple of 4
+static int gno_rows_per_thread(int cout, int kdim) {
+  const int og = 256 >> gno_kp_log2(kdim);
+  return gno_pad4((gno_pad4(cout) + og - 1) / og);
+}
+
+static size_t gno_lds_bytes(int cout, int kdim, bool bwd) {
+  const int cP = gno_pad4(cout), kdP = gno_pad4(kdim);
+  return ((size_t)kdP * (cP + 1) + (size_t)kGnoBatch * kdP + (bwd ? (size_t)kGnoBatch * cP : 0)) * sizeof(float);
+}
+
 bool gno_apply_supported(int cout, int kdim) {
   if (cout <= 0 || kdim <= 0 || cout > 256 || kdim > 256) return false;
-  const int og = 256 >> gno_kp_log2(kdim);
-  return cout <= 32 * og &&
-         ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * (kdim + cout)) * sizeof(float) <= 60 * 1024;
+  return gno_rows_per_thread(cout, kdim) <= 32 && gno_lds_bytes(cout, kdim, true) <= 60 * 1024;
 }
 
 int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z,
                              float *m, hipStream_t stream) {
   if (g->n_edges == 0) return NGPDE_OK;
-  const size_t sh = ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * kdim) * sizeof(float);
-  hipLaunchKernelGGL(gno_apply_fwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), sh, stream, (int)g->n_nodes, cout, kdim,
-                     g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m);
+  hipLaunchKernelGGL(gno_apply_fwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), gno_lds_bytes(cout, kdim, false), stream,
+                     (int)g->n_nodes, cout, kdim, g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m);
   NGPDE_LAUNCH_CHECK("gno_apply_fwd_kernel");
   return NGPDE_OK;
 }
@@ -588,9 +632,9 @@ int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const flo
 int32_t launch_gno_apply_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm,
                              float *dT, float *dBh, float *dz, hipStream_t stream) {
   if (g->n_nodes == 0) return NGPDE_OK;
-  const size_t sh = ((size_t)kdim * (cout + 1) + (size_t)kGnoBatch * (kdim + cout)) * sizeof(float);
-  hipLaunchKernelGGL(gno_apply_bwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), sh, stream, (int)g->n_nodes, cout, kdim,
-                     gno_kp_log2(kdim), g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, dBh, dz);
+  hipLaunchKernelGGL(gno_apply_bwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), gno_lds_bytes(cout, kdim, true), stream,
+                     (int)g->n_nodes, cout, kdim, gno_kp_log2(kdim), gno_rows_per_thread(cout, kdim), g->by_s.rowptr,
+                     g->by_s.xpos, T, z, dm, dT, dBh, dz);
   NGPDE_LAUNCH_CHECK("gno_apply_bwd_kernel");
   return NGPDE_OK;
 }
