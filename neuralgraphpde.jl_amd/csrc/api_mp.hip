@@ -48,7 +48,8 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
   int din = 0;
   int32_t st = make_segs("ngpde_dense_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
   if (st || (st = check_act("ngpde_dense_forward", act))) return st;
-  NGPDE_REQUIRE(n >= 0 && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH, "ngpde_dense_forward: DimensionMismatch");
+  NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH,
+                "ngpde_dense_forward: DimensionMismatch (rows must be in [0, 2^31), dout > 0)");
   if (n == 0) return NGPDE_OK;
   NGPDE_REQUIRE(weight && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_forward: weight/y is NULL");
   return launch_dense_seg_fwd(n, t, din, dout, act, weight, bias, y, save_z, (hipStream_t)stream);
@@ -69,6 +70,7 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
   if (st || (st = check_act("ngpde_dense_backward", act))) return st;
   hipStream_t stream = (hipStream_t)stream_;
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_backward: dweight is NULL");
+  NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), NGPDE_ERR_DIMENSION_MISMATCH, "ngpde_dense_backward: rows must be in [0, 2^31)");
   if (n == 0) {
     NGPDE_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)din * dout * 4, stream));
     if (dbias) NGPDE_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)dout * 4, stream));

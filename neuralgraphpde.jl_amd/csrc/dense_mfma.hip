@@ -21,10 +21,15 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LS = BK + 4;   // LDS row stride 20 floats: 16-byte aligned b128 rows
 
+// rows are < 2^31 (host-checked), so the per-graph row division is a 32-bit one and only taken when a block asks for it
+__device__ __forceinline__ int64_t seg_row(int64_t row, int row_div) {
+  return row_div == 1 ? row : (int64_t)((uint32_t)row / (uint32_t)row_div);
+}
+
 __device__ __forceinline__ float seg_load(const SegTable &s, int64_t row, int k) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (i < s.n && k < s.offset[i + 1]) return s.ptr[i][(row / s.row_div[i]) * s.width[i] + (k - s.offset[i])];
+    if (i < s.n && k < s.offset[i + 1]) return s.ptr[i][seg_row(row, s.row_div[i]) * s.width[i] + (k - s.offset[i])];
   return 0.f;
 }
 
@@ -166,33 +171,43 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
   const int k0 = blockIdx.x * BM;            // rows of dWt (input features, + bias row)
   const int col0 = blockIdx.y * BN;          // cols of dWt (outputs)
   const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-  // staging: element (nn = tid / 64 + 4 p, c = tid % 64) of X chunk [16 rows][64 k] and of dz chunk [16 rows][64 o]
+  // staging: thread (sn = tid / 64, c = tid % 64) carries rows 4 sn .. 4 sn + 3 of the 16-row step for column c of the
+  // X block and of the dz block -> ONE b128 LDS store per operand into the transposed tiles
   const int sn = tid >> 6, scol = tid & 63;
-  float areg[4], breg[4];
-  auto fetch = [&](int64_t rr0) {
+  // the X column of this thread never changes: resolve its block of the segmented input once
+  const float *abase = nullptr;
+  int awidth = 0, adiv = 1;
+  {
+    const int k = k0 + scol;
+#pragma unroll
+    for (int i = 3; i >= 0; --i)
+      if (i < segs.n && k < segs.offset[i + 1] && k >= segs.offset[i] && k < din) {
+        abase = segs.ptr[i] + (k - segs.offset[i]);
+        awidth = segs.width[i];
+        adiv = segs.row_div[i];
+      }
+  }
+  const float *bbase = (col0 + scol < dout) ? dz + col0 + scol : nullptr;
+  float areg[2][4], breg[2][4];
+  auto fetch = [&](int64_t rr0, float (&ar)[4], float (&br)[4]) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int64_t r = rr0 + sn + 4 * p;
-      const int k = k0 + scol;
-      areg[p] = (r < r1 && k < din) ? seg_load(segs, r, k) : 0.f;
-      breg[p] = (r < r1 && col0 + scol < dout) ? dz[r * dout + col0 + scol] : 0.f;
+      const int64_t r = rr0 + 4 * sn + p;
+      ar[p] = (r < r1 && abase) ? abase[seg_row(r, adiv) * awidth] : 0.f;
+      br[p] = (r < r1 && bbase) ? bbase[r * dout] : 0.f;
     }
   };
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  if (r0 < r1) fetch(r0);
-  for (int64_t rr = r0; rr < r1; rr += BK) {
+  auto step = [&](float (&ar)[4], float (&br)[4], int64_t next) {
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      ldsA[scol * LS + sn + 4 * p] = areg[p];
-      ldsBt[scol * LS + sn + 4 * p] = breg[p];
-    }
+    *reinterpret_cast<float4 *>(&ldsA[scol * LS + 4 * sn]) = make_float4(ar[0], ar[1], ar[2], ar[3]);
+    *reinterpret_cast<float4 *>(&ldsBt[scol * LS + 4 * sn]) = make_float4(br[0], br[1], br[2], br[3]);
     __syncthreads();
-    if (rr + BK < r1) fetch(rr + BK);
-    if (blockIdx.x == 0 && tid < BN) {   // bias row: column sums of the staged dz chunk (one wave, 16 LDS reads)
+    fetch(next, ar, br);                 // two steps ahead: in flight across this step's and the next step's MFMAs
+    if (blockIdx.x == 0 && tid < BN) {   // bias row: column sums of the staged dz chunk (one wave, 4 b128 LDS reads)
 #pragma unroll
       for (int nn = 0; nn < BK; nn += 4) {
         const float4 v = *reinterpret_cast<const float4 *>(&ldsBt[tid * LS + nn]);
@@ -200,6 +215,12 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
       }
     }
     mfma_chunk(ldsA, ldsBt, wave, lane, acc);
+  };
+  fetch(r0, areg[0], breg[0]);
+  fetch(r0 + BK, areg[1], breg[1]);
+  for (int64_t rr = r0; rr < r1; rr += 2 * BK) {   // rows past r1 stage zeros: harmless
+    step(areg[0], breg[0], rr + 2 * BK);
+    if (rr + BK < r1) step(areg[1], breg[1], rr + 3 * BK);
   }
   const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -215,15 +236,31 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, S
     partial[((size_t)blockIdx.z * (din + 1) + din) * dout + col0 + tid] = bsum;
 }
 
-__global__ void dense_weight_reduce_kernel(int nchunk, int din, int dout, const float *__restrict__ partial,
-                                           float *__restrict__ dwt, float *__restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dwt / db = sum over the chunk slabs, in a fixed order: 64 elements x 4 chunk lanes per workgroup
+__global__ __launch_bounds__(256) void dense_weight_reduce_kernel(int nchunk, int din, int dout, const float *__restrict__ partial,
+                                                                  float *__restrict__ dwt, float *__restrict__ db) {
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
   const int total = (din + 1) * dout;
-  if (idx >= total) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + idx];
-  if (idx < din * dout) dwt[idx] = s;
-  else if (db) db[idx - din * dout] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < total) {
+    int c = cl;
+    for (; c + 12 < nchunk; c += 16) {
+      s0 += partial[(size_t)c * total + idx];
+      s1 += partial[(size_t)(c + 4) * total + idx];
+      s2 += partial[(size_t)(c + 8) * total + idx];
+      s3 += partial[(size_t)(c + 12) * total + idx];
+    }
+    for (; c < nchunk; c += 4) s0 += partial[(size_t)c * total + idx];
+  }
+  part[cl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (cl == 0 && idx < total) {
+    const float s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (idx < din * dout) dwt[idx] = s;
+    else if (db) db[idx - din * dout] = s;
+  }
 }
 
 }  // namespace
@@ -247,11 +284,11 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
 }
 
 // row chunks of the weight pullback: enough (tile x chunk) workgroups to cover the chip several times over (the chunk
-// loop is a dependent global-load chain, ~16 rows per trip), at least 64 rows per chunk, at most 512 partial slabs
+// loop is a dependent global-load chain, ~16 rows per trip), at least 64 rows per chunk, at most 1024 partial slabs
 int dense_weight_chunks(int64_t n, int din, int dout) {
   const int64_t tiles = (int64_t)std::max(1, (din + BM - 1) / BM) * std::max(1, (dout + BN - 1) / BN);
-  const int64_t want = (2048 + tiles - 1) / tiles;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(512, want), (n + 63) / 64));
+  const int64_t want = (4096 + tiles - 1) / tiles;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024, want), (n + 63) / 64));
 }
 
 int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
@@ -263,7 +300,7 @@ int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, in
                      stream, n, segs, din, dout, dz, rpc, partial);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_weight_kernel");
   const int total = (din + 1) * dout;
-  hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, nchunk, din, dout, partial,
+  hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nchunk, din, dout, partial,
                      dwt, db);
   NGPDE_LAUNCH_CHECK("dense_weight_reduce_kernel");
   return NGPDE_OK;
