@@ -24,6 +24,7 @@ int32_t make_segs(const char *fn, int32_t n_seg, const float *const *seg_ptr, co
     t.width[i] = seg_width[i];
     t.row_div[i] = (seg_row_div && seg_row_div[i] > 0) ? seg_row_div[i] : 1;
     t.offset[i] = off;
+    t.vec[i] = (off % 4 == 0 && seg_width[i] % 4 == 0 && (reinterpret_cast<uintptr_t>(seg_ptr[i]) & 15) == 0) ? 1 : 0;
     off += seg_width[i];
   }
   for (int i = n_seg; i <= 4; ++i) t.offset[i] = off;
@@ -84,7 +85,7 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
   float *dz = (float *)workspace;
   float *partial = (float *)((char *)workspace + align256((size_t)n * dout * 4));
   if (act == NGPDE_ACT_IDENTITY) {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(dz, dy, (size_t)n * dout * 4, hipMemcpyDeviceToDevice, stream));
+    dz = const_cast<float *>(dy);   // read-only below
   } else if ((st = launch_dense_dz(n * dout, act, dy, z, dz, stream))) {
     return st;
   }

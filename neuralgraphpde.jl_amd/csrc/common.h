@@ -162,6 +162,7 @@ struct SegTable {   // virtual concatenation [X1 | X2 | ...] of up to 4 row-majo
   int width[4] = {0, 0, 0, 0};
   int row_div[4] = {1, 1, 1, 1};   // block row = row / row_div (per-graph features repeated over a graph's rows)
   int offset[5] = {0, 0, 0, 0, 0};
+  int vec[4] = {0, 0, 0, 0};       // block may be read with 16-byte loads (offset, width multiples of 4, base aligned)
 };
 struct SegGrad {
   int n = 0;

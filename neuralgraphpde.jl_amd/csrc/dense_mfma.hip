@@ -5,6 +5,7 @@
 // the B operand stored transposed, so every operand fetch is one ds_read_b128 feeding four
 // v_mfma_f32_16x16x4_f32 k-steps (exact fp32); the next chunk's global loads are in flight during the MFMAs.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "device_utils.h"
@@ -160,6 +161,229 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_input_kernel(int64_t n, Se
   }
 }
 
+// ---- wide-tile variants (128 rows x 64 columns per workgroup, 32-deep K steps, b128 global loads where a block of the
+// segmented input allows it, outputs transposed through LDS into full 256-byte row stores).  Used whenever the problem
+// has enough 128-row tiles to fill the chip; the 64-row kernels above serve the small cases.
+constexpr int BM2 = 128, BK2 = 32, LS2 = BK2 + 4, OS2 = BN + 4;
+constexpr int kWideLds = (BM2 * OS2 > (BM2 + BN) * LS2) ? BM2 * OS2 : (BM2 + BN) * LS2;   // floats
+
+// 4 consecutive features k..k+3 of row `row` of the segmented input (k % 4 == 0)
+__device__ __forceinline__ float4 seg_load4(const SegTable &s, int64_t row, int k, int din) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < s.n && k < s.offset[i + 1]) {
+      if (s.vec[i] && k + 4 <= s.offset[i + 1])
+        return *reinterpret_cast<const float4 *>(s.ptr[i] + seg_row(row, s.row_div[i]) * s.width[i] + (k - s.offset[i]));
+      break;
+    }
+  float t[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = (k + r < din) ? seg_load(s, row, k + r) : 0.f;
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+// acc[rt][ct] += A[32 rows of this wave][BK2] x B[BK2][64]  from LDS (A row-major [BM2][LS2], Bt [BN][LS2])
+__device__ __forceinline__ void mfma_step_wide(const float *ldsA, const float *ldsBt, int wave, int lane, f32x4 (&acc)[2][4]) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int kh = 0; kh < BK2 / 16; ++kh) {
+    float4 a4[2], b4[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) a4[rt] = *reinterpret_cast<const float4 *>(&ldsA[(wave * 32 + rt * 16 + i) * LS2 + 16 * kh + 4 * kq]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const float4 *>(&ldsBt[(ct * 16 + i) * LS2 + 16 * kh + 4 * kq]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float av[4] = {a4[rt].x, a4[rt].y, a4[rt].z, a4[rt].w};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const float bv[4] = {b4[ct].x, b4[ct].y, b4[ct].z, b4[ct].w};
+          acc[rt][ct] = mfma16(av[r], bv[r], acc[rt][ct]);
+        }
+      }
+    }
+  }
+}
+
+// accumulators -> LDS tile out[128][OS2] (every wave owns its 32 rows)
+__device__ __forceinline__ void acc_to_lds(float *out, int wave, int lane, const f32x4 (&acc)[2][4]) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) out[(wave * 32 + rt * 16 + 4 * kq + reg) * OS2 + ct * 16 + i] = acc[rt][ct][reg];
+}
+
+__global__ __launch_bounds__(256) void dense_wide_fwd_kernel(int64_t n, SegTable segs, int din, int dout, int act,
+                                                             const float *__restrict__ wt, const float *__restrict__ bias,
+                                                             float *__restrict__ y, float *__restrict__ save_z) {
+  __shared__ __attribute__((aligned(16))) float lds[kWideLds];
+  float *ldsA = lds, *ldsBt = lds + BM2 * LS2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * BM2;
+  const int col0 = blockIdx.y * BN;
+  // staging roles: A float4 (row = tid / 8 + 32 p, k = 4 (tid % 8)); B: column tid % 64, k = 8 (tid / 64) .. + 7
+  const int ar = tid >> 3, ak = 4 * (tid & 7), bc = tid & 63, bk = 8 * (tid >> 6);
+  float4 areg[4];
+  float breg[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t r = row0 + ar + 32 * p;
+      areg[p] = (r < n && k0 + ak < din) ? seg_load4(segs, r, k0 + ak, din) : f4_zero();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + bk + j;
+      breg[j] = (k < din && col0 + bc < dout) ? wt[(size_t)k * dout + col0 + bc] : 0.f;
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  for (int k0 = 0; k0 < din; k0 += BK2) {
+    __syncthreads();   // previous step fully consumed
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4 *>(&ldsA[(ar + 32 * p) * LS2 + ak]) = areg[p];
+    *reinterpret_cast<float4 *>(&ldsBt[bc * LS2 + bk]) = make_float4(breg[0], breg[1], breg[2], breg[3]);
+    *reinterpret_cast<float4 *>(&ldsBt[bc * LS2 + bk + 4]) = make_float4(breg[4], breg[5], breg[6], breg[7]);
+    __syncthreads();
+    if (k0 + BK2 < din) fetch(k0 + BK2);   // in flight during the MFMAs
+    mfma_step_wide(ldsA, ldsBt, wave, lane, acc);
+  }
+  __syncthreads();
+  acc_to_lds(lds, wave, lane, acc);
+  __syncthreads();
+  // epilogue: thread (row = tid / 16 + 16 p, columns 4 (tid % 16) .. + 3): bias, activation, 16-byte stores
+  const int oc = 4 * (tid & 15);
+  const bool vec = (dout % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(save_z)) & 15) == 0;
+  float b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = (bias && col0 + oc + j < dout) ? bias[col0 + oc + j] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int rl = (tid >> 4) + 16 * p;
+    const int64_t r = row0 + rl;
+    if (r >= n || col0 + oc >= dout) continue;
+    const float4 v = *reinterpret_cast<const float4 *>(&lds[rl * OS2 + oc]);
+    const float z[4] = {v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]};
+    if (vec) {   // dout % 4 == 0: the four columns exist and the address is 16-byte aligned
+      if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + col0 + oc) = make_float4(z[0], z[1], z[2], z[3]);
+      *reinterpret_cast<float4 *>(y + r * dout + col0 + oc) =
+          make_float4(act_apply(act, z[0]), act_apply(act, z[1]), act_apply(act, z[2]), act_apply(act, z[3]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (col0 + oc + j < dout) {
+          if (save_z) save_z[r * dout + col0 + oc + j] = z[j];
+          y[r * dout + col0 + oc + j] = act_apply(act, z[j]);
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
+                                                                   const float *__restrict__ dz,
+                                                                   const float *__restrict__ wt) {
+  __shared__ __attribute__((aligned(16))) float lds[kWideLds];
+  float *ldsA = lds, *ldsBt = lds + BM2 * LS2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * BM2;
+  const int col0 = blockIdx.y * BN;          // columns of dX = input features k
+  const int ar = tid >> 3, ak = 4 * (tid & 7);       // A = dz: float4 (row, o)
+  const int bcol = tid >> 2, bo = 8 * (tid & 3);     // Bt[col = k][o]: 8 consecutive o of one weight row
+  const bool avec = (dout % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(wt)) & 15) == 0;
+  float4 areg[4], breg[2];
+  auto fetch = [&](int o0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t r = row0 + ar + 32 * p;
+      const int o = o0 + ak;
+      if (r < n && avec && o + 4 <= dout) {
+        areg[p] = *reinterpret_cast<const float4 *>(dz + r * dout + o);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (r < n && o + j < dout) ? dz[r * dout + o + j] : 0.f;
+        areg[p] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+    const int k = col0 + bcol;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int o = o0 + bo + 4 * h;
+      if (k < din && avec && o + 4 <= dout) {
+        breg[h] = *reinterpret_cast<const float4 *>(wt + (size_t)k * dout + o);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (k < din && o + j < dout) ? wt[(size_t)k * dout + o + j] : 0.f;
+        breg[h] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  for (int o0 = 0; o0 < dout; o0 += BK2) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4 *>(&ldsA[(ar + 32 * p) * LS2 + ak]) = areg[p];
+    *reinterpret_cast<float4 *>(&ldsBt[bcol * LS2 + bo]) = breg[0];
+    *reinterpret_cast<float4 *>(&ldsBt[bcol * LS2 + bo + 4]) = breg[1];
+    __syncthreads();
+    if (o0 + BK2 < dout) fetch(o0 + BK2);
+    mfma_step_wide(ldsA, ldsBt, wave, lane, acc);
+  }
+  __syncthreads();
+  acc_to_lds(lds, wave, lane, acc);
+  __syncthreads();
+  // epilogue: thread (row = tid / 16 + 16 p, features col0 + 4 (tid % 16) .. + 3) -> the block that owns each feature
+  const int oc = 4 * (tid & 15);
+  const int k = col0 + oc;
+  if (k >= din) return;
+  int sg = -1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (q < segs.n && k >= segs.offset[q] && k < segs.offset[q + 1]) sg = q;
+  const bool whole = sg >= 0 && k + 4 <= segs.offset[sg + 1] && (segs.offset[sg] % 4 == 0) && (segs.width[sg] % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(segs.ptr[sg]) & 15) == 0);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int rl = (tid >> 4) + 16 * p;
+    const int64_t r = row0 + rl;
+    if (r >= n) continue;
+    const float4 v = *reinterpret_cast<const float4 *>(&lds[rl * OS2 + oc]);
+    if (whole) {
+      if (segs.ptr[sg]) *reinterpret_cast<float4 *>(segs.ptr[sg] + r * segs.width[sg] + (k - segs.offset[sg])) = v;
+    } else {
+      const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kj = k + j;
+        if (kj >= din) continue;
+        int s2 = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < segs.n && kj >= segs.offset[q] && kj < segs.offset[q + 1]) s2 = q;
+        if (s2 >= 0 && segs.ptr[s2]) segs.ptr[s2][r * segs.width[s2] + (kj - segs.offset[s2])] = t[j];
+      }
+    }
+  }
+}
+
 // ---- weight pullback: partial[chunk][k][o] = sum_{rows of chunk} X[row][k] dz[row][o]; row k == din of `partial`
 // holds the bias gradient sum_rows dz[row][o], accumulated by the blockIdx.x == 0 tiles from the staged dz chunk
 __global__ __launch_bounds__(256) void dense_mfma_bwd_weight_kernel(int64_t n, SegTable segs, int din, int dout,
@@ -265,9 +489,21 @@ __global__ __launch_bounds__(256) void dense_weight_reduce_kernel(int nchunk, in
 
 }  // namespace
 
+// 128-row tiles once they alone give every CU two workgroups
+static bool use_wide_tiles(int64_t n, int cols) {
+  static const bool off = getenv("NGPDE_DENSE_NARROW") != nullptr;
+  return !off && ((n + BM2 - 1) / BM2) * ((cols + BN - 1) / BN) >= 512;
+}
+
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream) {
   if (n == 0 || dout == 0) return NGPDE_OK;
+  if (use_wide_tiles(n, dout)) {
+    hipLaunchKernelGGL(dense_wide_fwd_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (dout + BN - 1) / BN), dim3(256), 0, stream,
+                       n, segs, din, dout, act, wt, bias, y, save_z);
+    NGPDE_LAUNCH_CHECK("dense_wide_fwd_kernel");
+    return NGPDE_OK;
+  }
   hipLaunchKernelGGL(dense_mfma_fwd_kernel, dim3((unsigned)((n + BM - 1) / BM), (dout + BN - 1) / BN), dim3(256), 0, stream,
                      n, segs, din, dout, act, wt, bias, y, save_z);
   NGPDE_LAUNCH_CHECK("dense_mfma_fwd_kernel");
@@ -277,6 +513,12 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
                                    hipStream_t stream) {
   if (n == 0 || din == 0) return NGPDE_OK;
+  if (use_wide_tiles(n, din)) {
+    hipLaunchKernelGGL(dense_wide_bwd_input_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (din + BN - 1) / BN), dim3(256), 0,
+                       stream, n, segs, din, dout, dz, wt);
+    NGPDE_LAUNCH_CHECK("dense_wide_bwd_input_kernel");
+    return NGPDE_OK;
+  }
   hipLaunchKernelGGL(dense_mfma_bwd_input_kernel, dim3((unsigned)((n + BM - 1) / BM), (din + BN - 1) / BN), dim3(256), 0,
                      stream, n, segs, din, dout, dz, wt);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_input_kernel");

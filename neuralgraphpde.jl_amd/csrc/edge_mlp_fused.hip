@@ -49,12 +49,13 @@ __device__ __forceinline__ float4 load4_guard(const float *base, size_t row, int
   return (4 * q < width) ? *reinterpret_cast<const float4 *>(base + row * width + 4 * q) : f4_zero();
 }
 
-// Out[64][kTS] = A[64][kTS] x B  (B transposed in LDS: Bt[col][k]); wave: row tile w & 3, column tiles (w >> 2) + {0, 2}
-__device__ __forceinline__ void mfma_chunk64(const float *ldsA, const float *ldsBt, float *ldsOut, int wave, int lane,
-                                             int kblocks, int col_tiles) {
+// acc = A[64][kTS] x B for this wave's row tile (w & 3) and column tiles (w >> 2) + {0, 2}   (B transposed in LDS: Bt[col][k])
+__device__ __forceinline__ void mfma_chunk64(const float *ldsA, const float *ldsBt, int wave, int lane, int kblocks, int col_tiles,
+                                             f32x4 (&acc)[2]) {
   const int rt = wave & 3, cg = wave >> 2;
   const int i = lane & 15, kq = lane >> 4;
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float *pa = ldsA + (rt * 16 + i) * kTS + 4 * kq;
   const float *pb0 = ldsBt + (cg * 16 + i) * kTS + 4 * kq;
   const float *pb1 = ldsBt + ((cg + 2) * 16 + i) * kTS + 4 * kq;
@@ -73,23 +74,18 @@ __device__ __forceinline__ void mfma_chunk64(const float *ldsA, const float *lds
       acc[1] = mfma16(av[2], b4.z, acc[1]); acc[1] = mfma16(av[3], b4.w, acc[1]);
     }
   }
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int ct = cg + 2 * m;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) ldsOut[(rt * 16 + 4 * kq + reg) * kTS + ct * 16 + i] = (ct < col_tiles) ? acc[m][reg] : 0.f;
-  }
 }
 
 template <int NTAIL>
 __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p) {
   __shared__ __attribute__((aligned(16))) float ldsQ[(kHaloCap + 1) * kW];
   __shared__ __attribute__((aligned(16))) float ldsP[kGroups * kW];
-  __shared__ __attribute__((aligned(16))) float ldsA[kChunk * kTS], ldsB[kChunk * kTS];
+  __shared__ __attribute__((aligned(16))) float ldsA[kChunk * kTS];
   __shared__ __attribute__((aligned(16))) float ldsWt[(NTAIL > 0 ? NTAIL : 1) * kW * kTS];
   __shared__ int ldsOff[kGroups + 1], ldsRs[kGroups];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kGroups * 8];   // 32 slot bytes per row
-  __shared__ int ldsErow[kChunk];
+  __shared__ uint8_t ldsRowOf[kGroups * kSlotWidth];                        // tile edge k -> row of the tile
+  __shared__ int ldsPe[kChunk];                                             // chunk edge -> p position, -1 past the end
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +103,7 @@ __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p
   const int node = max(sc.x, 0);
   const float4 prow = p.P ? load4_guard(p.P, node, h1, q) : f4_zero();
   float4 wreg[NTAIL > 0 ? NTAIL : 1][2];
+  float breg[NTAIL > 0 ? NTAIL : 1][2];             // bias of this lane's two output columns (MFMA D layout)
 #pragma unroll
   for (int l = 0; l < NTAIL; ++l) {
     const int j = tid % kW, kg0 = tid / kW;   // output column j, k-groups kg0 and kg0 + 8
@@ -118,6 +115,8 @@ __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p
       for (int r = 0; r < 4; ++r)
         t[r] = (k + r < p.din[l] && j < p.dout[l]) ? p.wt[l][(size_t)(k + r) * p.dout[l] + j] : 0.f;
       wreg[l][ps] = make_float4(t[0], t[1], t[2], t[3]);
+      const int col = ((wave >> 2) + 2 * ps) * 16 + (lane & 15);
+      breg[l][ps] = (p.bias[l] && col < p.dout[l]) ? p.bias[l][col] : 0.f;
     }
   }
   // ---- round 2: the tile's distinct source rows of Q
@@ -166,11 +165,13 @@ __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p
   const int total = ldsOff[kGroups];
   const int my_lo = ldsOff[grp], my_hi = ldsOff[grp + 1];
   const int last_w = (NTAIL > 0) ? p.dout[NTAIL - 1] : h1;
+  for (int k = my_lo + q; k < my_hi; k += 16) ldsRowOf[k] = (uint8_t)grp;   // deg <= kSlotWidth: total <= 1024
 
   float4 racc;
   if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
   else racc = f4_zero();
+  __syncthreads();
 
   for (int c0 = 0; c0 < total; c0 += kChunk) {
     // ---- a1 = act1(P[t] + Q[s] + E) for the chunk's edges: 2 edges per lane group
@@ -179,48 +180,46 @@ __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p
       const int el = 2 * grp + u;
       const int k = c0 + el;
       float4 a = f4_zero();
-      int r = -1;
+      int pe_i = -1;
       if (k < total) {
-        int lo = 0, hi = kGroups;                      // largest r with off[r] <= k
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (ldsOff[mid] <= k) lo = mid; else hi = mid;
-        }
-        r = lo;
+        const int r = ldsRowOf[k];
         const int j = k - ldsOff[r];
         const int slot = (ldsSlots[r * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff;
-        const size_t pe = (size_t)ldsRs[r] + j;          // position of the edge in p order
+        pe_i = ldsRs[r] + j;                              // position of the edge in p order
+        const size_t pe = (size_t)pe_i;
         float4 z = f4_add(reinterpret_cast<const float4 *>(ldsP)[r * 16 + q], Q4[slot * 16 + q]);
         if (p.Eterm) z = f4_add(z, load4_guard(p.Eterm, pe, h1, q));
         if (p.save_z[0] && 4 * q < h1) *reinterpret_cast<float4 *>(p.save_z[0] + pe * h1 + 4 * q) = z;
         a = (4 * q < h1) ? f4_act(p.act1, z) : f4_zero();
       }
       *reinterpret_cast<float4 *>(&ldsA[el * kTS + 4 * q]) = a;
-      if (q == 0) ldsErow[el] = r;
+      if (q == 0) ldsPe[el] = pe_i;
     }
     __syncthreads();
-    // ---- remaining Dense layers on MFMA, weights resident in LDS
+    // ---- remaining Dense layers on MFMA, weights resident in LDS; bias + activation applied on the accumulators
+    // and written back over the chunk's activations (no second staging tile)
 #pragma unroll
     for (int l = 0; l < NTAIL; ++l) {
-      mfma_chunk64(ldsA, ldsWt + l * kW * kTS, ldsB, wave, lane, (p.din[l] + 15) / 16, (p.dout[l] + 15) / 16);
-      __syncthreads();
-      const int dw = p.dout[l];
-      const float4 b4 = (p.bias[l] && 4 * q < dw) ? *reinterpret_cast<const float4 *>(p.bias[l] + 4 * q) : f4_zero();
+      f32x4 acc[2];
+      const int dw = p.dout[l], col_tiles = (dw + 15) / 16;
+      mfma_chunk64(ldsA, ldsWt + l * kW * kTS, wave, lane, (p.din[l] + 15) / 16, col_tiles, acc);
+      __syncthreads();                                   // every wave is done reading the layer's input
+      const int rt = wave & 3, cg = wave >> 2, i = lane & 15, kq = lane >> 4;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int el = 2 * grp + u;
-        const int r = ldsErow[el];
-        float4 a = f4_zero();
-        if (r >= 0 && 4 * q < dw) {
-          const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsB[el * kTS + 4 * q]), b4);
-          if (p.save_z[l + 1]) {
-            const int k = c0 + el;
-            const size_t pe = (size_t)ldsRs[r] + (k - ldsOff[r]);
-            *reinterpret_cast<float4 *>(p.save_z[l + 1] + pe * dw + 4 * q) = z;
+      for (int m = 0; m < 2; ++m) {
+        const int col = (cg + 2 * m) * 16 + i;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = rt * 16 + 4 * kq + reg;
+          const int pe_i = ldsPe[row];
+          float v = 0.f;
+          if (pe_i >= 0 && col < dw) {
+            const float z = acc[m][reg] + breg[l][m];
+            if (p.save_z[l + 1]) p.save_z[l + 1][(size_t)pe_i * dw + col] = z;
+            v = act_apply(p.act[l], z);
           }
-          a = f4_act(p.act[l], z);
+          ldsA[row * kTS + col] = v;
         }
-        *reinterpret_cast<float4 *>(&ldsA[el * kTS + 4 * q]) = a;
       }
       __syncthreads();
     }

@@ -125,6 +125,40 @@ def test_dense_chain_parity():
     check_grads(ps, (names, og), x, dx)
 
 
+@pytest.mark.parametrize("widths,dout,act", [((64, 1, 3, 2), 64, "swish"), ((64, 64), 40, "identity"), ((30, 7), 37, "tanh"),
+                                            ((128,), 200, "relu")])
+def test_dense_wide_tiles_segmented(widths, dout, act):
+    # enough rows that the 128-row tile kernels serve forward and input pullback (>= 512 tiles), ragged last tile,
+    # blocks that do / do not allow 16-byte loads, a per-graph block (row_div) as MPPDEConv's theta  (src/layers.jl:397)
+    from ngpde_amd import functional as F
+    n, per_graph = 70001, 10000
+    rng = np.random.default_rng(21)
+    blocks, divs = [], []
+    for i, w in enumerate(widths):
+        rd = per_graph if (len(widths) == 4 and i == 3) else 1
+        rows = (n + rd - 1) // rd
+        blocks.append(torch.as_tensor(rng.normal(size=(rows, w)), dtype=torch.float32, device=DEV).requires_grad_(rd == 1))
+        divs.append(rd)
+    din = sum(widths)
+    wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+    b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True)
+    y = F.dense(blocks, wt, b, ng.layers._act_code(act)[1], row_divs=divs, n=n)
+    X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+    layer = [dict(weight=wt.detach().cpu().double().numpy().T, bias=b.detach().cpu().double().numpy(), act=act)]
+    yo, cache = O.mlp_forward(layer, X.T)
+    close(y, yo.T)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R.T, dtype=torch.float32, device=DEV)).sum().backward()
+    dx, gr = O.mlp_backward(layer, cache, R)
+    close(wt.grad, gr[0]["weight"].T, rtol=3e-4)
+    close(b.grad, gr[0]["bias"].reshape(-1), rtol=3e-4)
+    o = 0
+    for bl, rd, w in zip(blocks, divs, widths):
+        if rd == 1:
+            close(bl.grad, dx[o:o + w].T)
+        o += w
+
+
 # ---- ExplicitEdgeConv ---------------------------------------------------------------------------------------------------
 
 def test_edgeconv_reference_fixture():
