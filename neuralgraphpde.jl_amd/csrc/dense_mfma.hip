@@ -27,11 +27,24 @@ __device__ __forceinline__ int64_t seg_row(int64_t row, int row_div) {
   return row_div == 1 ? row : (int64_t)((uint32_t)row / (uint32_t)row_div);
 }
 
+// the block of the segmented input that holds feature k, as a select chain over the (static) table entries: the table
+// stays in SGPRs / kernel arguments (a loop with early exit made the compiler spill it to scratch)
+struct SegRef {
+  const float *ptr;
+  int width, row_div, offset, end, vec;
+};
+__device__ __forceinline__ SegRef seg_find(const SegTable &s, int k) {
+  SegRef r{s.ptr[0], s.width[0], s.row_div[0], s.offset[0], s.offset[1], s.vec[0]};
+  if (s.n > 1 && k >= s.offset[1]) r = SegRef{s.ptr[1], s.width[1], s.row_div[1], s.offset[1], s.offset[2], s.vec[1]};
+  if (s.n > 2 && k >= s.offset[2]) r = SegRef{s.ptr[2], s.width[2], s.row_div[2], s.offset[2], s.offset[3], s.vec[2]};
+  if (s.n > 3 && k >= s.offset[3]) r = SegRef{s.ptr[3], s.width[3], s.row_div[3], s.offset[3], s.offset[4], s.vec[3]};
+  return r;
+}
+
+// caller guarantees k < din (= s.offset[4])
 __device__ __forceinline__ float seg_load(const SegTable &s, int64_t row, int k) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i < s.n && k < s.offset[i + 1]) return s.ptr[i][seg_row(row, s.row_div[i]) * s.width[i] + (k - s.offset[i])];
-  return 0.f;
+  const SegRef r = seg_find(s, k);
+  return r.ptr[seg_row(row, r.row_div) * r.width + (k - r.offset)];
 }
 
 // acc[ct] += A[16 rows of this wave][BK] x B[BK][16 ct]   from LDS (A row-major [BM][LS], Bt [BN][LS])
@@ -169,16 +182,12 @@ constexpr int kWideLds = (BM2 * OS2 > (BM2 + BN) * LS2) ? BM2 * OS2 : (BM2 + BN)
 
 // 4 consecutive features k..k+3 of row `row` of the segmented input (k % 4 == 0)
 __device__ __forceinline__ float4 seg_load4(const SegTable &s, int64_t row, int k, int din) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i < s.n && k < s.offset[i + 1]) {
-      if (s.vec[i] && k + 4 <= s.offset[i + 1])
-        return *reinterpret_cast<const float4 *>(s.ptr[i] + seg_row(row, s.row_div[i]) * s.width[i] + (k - s.offset[i]));
-      break;
-    }
+  const SegRef r = seg_find(s, k);
+  if (r.vec && k + 4 <= r.end)
+    return *reinterpret_cast<const float4 *>(r.ptr + seg_row(row, r.row_div) * r.width + (k - r.offset));
   float t[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) t[r] = (k + r < din) ? seg_load(s, row, k + r) : 0.f;
+  for (int j = 0; j < 4; ++j) t[j] = (k + j < din) ? seg_load(s, row, k + j) : 0.f;
   return make_float4(t[0], t[1], t[2], t[3]);
 }
 
