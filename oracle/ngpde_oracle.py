@@ -20,7 +20,9 @@ PARITY PINNING STATUS
     Julia packages (GraphNeuralNetworks.jl 0.4-0.6 `propagate`, NNlib 0.8 `gather`/`scatter`/
     `batched_mul`, Lux 0.4 `Dense`), and no Julia toolchain exists in this image.  For those the
     oracle restates the published algorithm at the reference's call sites, and is cross-checked by
-    (i) finite differences in float64 and (ii) an independent C restatement (ngpde_oracle.c).
+    (i) finite differences in float64, (ii) an independent C restatement (ngpde_oracle.c) and (iii) an independent
+    torch float64 transcription of the same call sites whose gradients come from torch.autograd
+    (tests/test_golden.py, on the committed vectors tests/golden/*.npz, generator tests/golden/make_golden.py).
 
 Conventions (same as the reference): features are (D x N) arrays, node n = column n; edges are a
 COO list (s_e -> t_e); `xi` = features gathered at the target t, `xj` = gathered at the source s,
