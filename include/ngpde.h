@@ -72,6 +72,28 @@ const char *ngpde_last_error(void);
  * ---------------------------------------------------------------------------------------------- */
 int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, const int64_t *t,
                            int32_t index_base, int32_t n_graphs, ngpde_graph_t **out);
+/* The same handle built ON THE DEVICE from a COO list already in HBM (the reference moves the graph with `g |> gpu`
+ * and swaps it every minibatch, docs/src/tutorials/VMH.md:132-134 + src/utils.jl:24-31): s, t are DEVICE arrays of
+ * int32 or int64 (index_bits) with the given index_base.  `order` (device, n_nodes int32, nullable) is a node
+ * permutation to use as the locality schedule -- e.g. the concatenated cached orders of a batch's member graphs,
+ * see ngpde_graph_node_order; when NULL the lists are downloaded once and the order is computed on the host.
+ * Every derived array is bit-identical to ngpde_graph_create's for the same edge list and order. Synchronises `stream`. */
+int32_t ngpde_graph_create_device(int64_t n_nodes, int64_t n_edges, const void *s, const void *t, int32_t index_bits,
+                                  int32_t index_base, int32_t n_graphs, const int32_t *order, ngpde_stream_t stream,
+                                  ngpde_graph_t **out);
+/* the handle's locality order (host buffer of n_nodes int32): cache it per graph, offset + concatenate it for batches */
+int32_t ngpde_graph_node_order(const ngpde_graph_t *g, int32_t *order_out);
+/* ngpde_graph_set_gcn_norm with DEVICE edge weights, built on the device (any handle) */
+int32_t ngpde_graph_set_gcn_norm_device(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
+                                        int32_t weighted_degree, ngpde_stream_t stream);
+/* Introspection of the derived arrays (device pointers; tests compare the host and device builders with it).
+ * direction 0 = lists by target, 1 = by source. For NGPDE_GRAPH_HALO_OK *bytes is 1/0 and *ptr NULL. */
+enum {
+  NGPDE_GRAPH_ROWPTR = 0, NGPDE_GRAPH_COL = 1, NGPDE_GRAPH_EID = 2, NGPDE_GRAPH_XPOS = 3, NGPDE_GRAPH_ENT = 4,
+  NGPDE_GRAPH_SCHED = 5, NGPDE_GRAPH_ELL = 6, NGPDE_GRAPH_HALO = 7, NGPDE_GRAPH_TILE_INFO = 8, NGPDE_GRAPH_SLOTS = 9,
+  NGPDE_GRAPH_SLOT_W = 10, NGPDE_GRAPH_C = 11, NGPDE_GRAPH_ORDER = 12, NGPDE_GRAPH_HALO_OK = 13
+};
+int32_t ngpde_graph_array(const ngpde_graph_t *g, int32_t direction, int32_t which, const void **ptr, size_t *bytes);
 int32_t ngpde_graph_destroy(ngpde_graph_t *g);
 int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_graphs);
 /* Device arrays of the derived graph (for callers that batch / inspect): CSR by target.

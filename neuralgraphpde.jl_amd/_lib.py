@@ -44,6 +44,10 @@ SIGNATURES = {
     "ngpde_version": (C.c_char_p, []),
     "ngpde_last_error": (C.c_char_p, []),
     "ngpde_graph_create": (_i32, [_i64, _i64, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "ngpde_graph_create_device": (_i32, [_i64, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_vp)]),
+    "ngpde_graph_node_order": (_i32, [_vp, _vp]),
+    "ngpde_graph_set_gcn_norm_device": (_i32, [_vp, _i32, _vp, _i32, _vp]),
+    "ngpde_graph_array": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "ngpde_graph_destroy": (_i32, [_vp]),
     "ngpde_graph_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "ngpde_graph_csr_by_target": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),

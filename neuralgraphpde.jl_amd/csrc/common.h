@@ -73,10 +73,18 @@ struct ngpde_graph {
   // each workgroup one run, and each XCD a contiguous range of runs, so the rows a workgroup gathers
   // are mostly the rows its own XCD wrote/read last: L2-resident instead of cross-XCD traffic.
   std::vector<int32_t> h_order;
+  int32_t *order = nullptr;   // the same permutation on the device
+  bool device_built = false;  // built by ngpde_graph_create_device: no host copies of the CSR lists
   int32_t n_sched = 0;  // n_tiles * kTileRows
 };
 
 namespace ngpde {
+
+// ---- device-side handle construction (graph_device.hip)
+template <class I>
+int32_t graph_create_device(int64_t n_nodes, int64_t n_edges, const I *s, const I *t, int index_base, int32_t n_graphs,
+                            const int32_t *order_dev, hipStream_t stream, ngpde_graph **out);
+int32_t set_gcn_norm_device(ngpde_graph *g, int add_self_loops, const float *w_dev, int weighted_degree, hipStream_t stream);
 
 // ---- launchers implemented in gcn_kernels.hip ---------------------------------------------------
 

@@ -44,8 +44,11 @@ void build_csr(int64_t n, int64_t m, const std::vector<int32_t> &key, const std:
   }
 }
 
+}  // namespace
+
 // BFS-grown clusters of `tile` nodes, emitted in a breadth-first sweep (see ngpde_graph::h_order)
-std::vector<int32_t> locality_order(int64_t n, const Csr &in, const Csr &out, int tile) {
+std::vector<int32_t> locality_order_host(int64_t n, const std::vector<int32_t> &rp_in, const std::vector<int32_t> &col_in,
+                                         const std::vector<int32_t> &rp_out, const std::vector<int32_t> &col_out, int tile) {
   std::vector<int32_t> order;
   order.reserve((size_t)n);
   std::vector<char> taken((size_t)n, 0);
@@ -53,8 +56,8 @@ std::vector<int32_t> locality_order(int64_t n, const Csr &in, const Csr &out, in
   int64_t next_free = 0;
   std::vector<int32_t> local;
   auto neighbours = [&](int32_t v, auto &&f) {
-    for (int32_t p = in.h_rowptr[v]; p < in.h_rowptr[v + 1]; ++p) f(in.h_col[p]);
-    for (int32_t p = out.h_rowptr[v]; p < out.h_rowptr[v + 1]; ++p) f(out.h_col[p]);
+    for (int32_t p = rp_in[v]; p < rp_in[v + 1]; ++p) f(col_in[p]);
+    for (int32_t p = rp_out[v]; p < rp_out[v + 1]; ++p) f(col_out[p]);
   };
   while ((int64_t)order.size() < n) {
     local.clear();
@@ -87,6 +90,8 @@ std::vector<int32_t> locality_order(int64_t n, const Csr &in, const Csr &out, in
   }
   return order;
 }
+
+namespace {
 
 template <class T>
 int32_t upload(T **dst, const T *src, size_t count) {
@@ -176,10 +181,11 @@ int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, c
       return stx;
     }
   }
-  g->h_order = locality_order(n_nodes, g->by_t, g->by_s, kTileRows);
+  g->h_order = locality_order_host(n_nodes, g->by_t.h_rowptr, g->by_t.h_col, g->by_s.h_rowptr, g->by_s.h_col, kTileRows);
   g->n_sched = (int32_t)(((n_nodes + kTileRows - 1) / kTileRows) * kTileRows);
   int32_t st;
-  if ((st = upload_csr(g->by_t, n_nodes, n_edges)) || (st = upload_csr(g->by_s, n_nodes, n_edges))) {
+  if ((st = upload_csr(g->by_t, n_nodes, n_edges)) || (st = upload_csr(g->by_s, n_nodes, n_edges)) ||
+      (st = upload(&g->order, g->h_order.data(), g->h_order.size()))) {
     ngpde_graph_destroy(g);
     return st;
   }
@@ -192,7 +198,75 @@ int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
   free_csr(g->by_t);
   free_csr(g->by_s);
   if (g->c) (void)hipFree(g->c);
+  if (g->order) (void)hipFree(g->order);
   delete g;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_create_device(int64_t n_nodes, int64_t n_edges, const void *s, const void *t, int32_t index_bits,
+                                  int32_t index_base, int32_t n_graphs, const int32_t *order, ngpde_stream_t stream,
+                                  ngpde_graph_t **out) {
+  NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create_device: out is NULL");
+  *out = nullptr;
+  NGPDE_REQUIRE(n_nodes >= 0 && n_edges >= 0, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_create_device: negative size (n_nodes=%lld, n_edges=%lld)", (long long)n_nodes, (long long)n_edges);
+  NGPDE_REQUIRE(n_nodes < (1ll << 31) - 1 && n_edges + n_nodes < (1ll << 31) - 1, NGPDE_ERR_UNSUPPORTED,
+                "ngpde_graph_create_device: graph too large for int32 device indices");
+  NGPDE_REQUIRE(n_edges == 0 || (s && t), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create_device: s/t is NULL");
+  NGPDE_REQUIRE(index_bits == 32 || index_bits == 64, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_create_device: index_bits must be 32 or 64");
+  NGPDE_REQUIRE(index_base == 0 || index_base == 1, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_create_device: index_base must be 0 or 1");
+  NGPDE_REQUIRE(n_graphs >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create_device: n_graphs < 0");
+  if (index_bits == 32)
+    return ngpde::graph_create_device<int32_t>(n_nodes, n_edges, (const int32_t *)s, (const int32_t *)t, index_base, n_graphs,
+                                               order, (hipStream_t)stream, out);
+  return ngpde::graph_create_device<int64_t>(n_nodes, n_edges, (const int64_t *)s, (const int64_t *)t, index_base, n_graphs, order,
+                                             (hipStream_t)stream, out);
+}
+
+int32_t ngpde_graph_node_order(const ngpde_graph_t *g, int32_t *order_out) {
+  NGPDE_REQUIRE(g != nullptr && (order_out != nullptr || g->n_nodes == 0), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_node_order: NULL argument");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  if (!g->h_order.empty()) {
+    std::memcpy(order_out, g->h_order.data(), (size_t)g->n_nodes * sizeof(int32_t));
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpy(order_out, g->order, (size_t)g->n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return NGPDE_OK;
+}
+
+int32_t ngpde_graph_set_gcn_norm_device(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
+                                        int32_t weighted_degree, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_set_gcn_norm_device: graph is NULL");
+  NGPDE_REQUIRE(!(weighted_degree && !edge_weight && g->n_edges > 0), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_graph_set_gcn_norm_device: weighted_degree requires edge_weight");
+  return ngpde::set_gcn_norm_device(g, add_self_loops, edge_weight, weighted_degree, (hipStream_t)stream);
+}
+
+int32_t ngpde_graph_array(const ngpde_graph_t *g, int32_t direction, int32_t which, const void **ptr, size_t *bytes) {
+  NGPDE_REQUIRE(g && ptr && bytes, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_array: NULL argument");
+  NGPDE_REQUIRE(direction == 0 || direction == 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_array: direction must be 0 (by target) or 1 (by source)");
+  const ngpde::Csr &c = direction == 0 ? g->by_t : g->by_s;
+  const size_t n = (size_t)g->n_nodes, m = (size_t)g->n_edges, ns = (size_t)g->n_sched, nt = ns / ngpde::kTileRows;
+  switch (which) {
+    case NGPDE_GRAPH_ROWPTR: *ptr = c.rowptr; *bytes = (n + 1) * 4; break;
+    case NGPDE_GRAPH_COL: *ptr = c.col; *bytes = m * 4; break;
+    case NGPDE_GRAPH_EID: *ptr = c.eid; *bytes = m * 4; break;
+    case NGPDE_GRAPH_XPOS: *ptr = c.xpos; *bytes = m * 4; break;
+    case NGPDE_GRAPH_ENT: *ptr = c.ent; *bytes = c.ent ? m * 8 : 0; break;
+    case NGPDE_GRAPH_SCHED: *ptr = c.sched; *bytes = c.sched ? ns * 16 : 0; break;
+    case NGPDE_GRAPH_ELL: *ptr = c.ell; *bytes = c.ell ? ns * ngpde::kEllWidth * 8 : 0; break;
+    case NGPDE_GRAPH_HALO: *ptr = c.halo; *bytes = c.halo ? nt * ngpde::kHaloCap * 8 : 0; break;
+    case NGPDE_GRAPH_TILE_INFO: *ptr = c.tile_info; *bytes = c.tile_info ? nt * 8 : 0; break;
+    case NGPDE_GRAPH_SLOTS: *ptr = c.slots; *bytes = c.slots ? ns * ngpde::kSlotWidth : 0; break;
+    case NGPDE_GRAPH_SLOT_W: *ptr = c.slot_w; *bytes = c.slot_w ? ns * ngpde::kSlotWidth * 4 : 0; break;
+    case NGPDE_GRAPH_C: *ptr = g->c; *bytes = g->c ? n * 4 : 0; break;
+    case NGPDE_GRAPH_ORDER: *ptr = g->order; *bytes = g->order ? n * 4 : 0; break;
+    case NGPDE_GRAPH_HALO_OK: *ptr = nullptr; *bytes = c.halo_ok ? 1 : 0; break;
+    default: return ngpde::fail(NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_array: unknown array code %d", which);
+  }
   return NGPDE_OK;
 }
 
@@ -225,8 +299,21 @@ int32_t ngpde_graph_csr_by_source(const ngpde_graph_t *g, const int32_t **rowptr
 int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
                                  int32_t weighted_degree) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_set_gcn_norm: graph is NULL");
-  NGPDE_REQUIRE(!(weighted_degree && !edge_weight), NGPDE_ERR_INVALID_ARGUMENT,
+  NGPDE_REQUIRE(!(weighted_degree && !edge_weight && g->n_edges > 0), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_graph_set_gcn_norm: weighted_degree requires edge_weight");
+  if (g->device_built) {   // no host copies of the lists: stage the weights and build on the device
+    float *w_dev = nullptr;
+    if (edge_weight) {
+      NGPDE_HIP_CHECK(hipMalloc((void **)&w_dev, std::max<size_t>((size_t)g->n_edges, 1) * sizeof(float)));
+      if (hipMemcpy(w_dev, edge_weight, (size_t)g->n_edges * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(w_dev);
+        return ngpde::fail(NGPDE_ERR_HIP, "ngpde_graph_set_gcn_norm: upload of the edge weights failed");
+      }
+    }
+    const int32_t st_dev = ngpde::set_gcn_norm_device(g, add_self_loops, w_dev, weighted_degree, nullptr);
+    if (w_dev) (void)hipFree(w_dev);
+    return st_dev;
+  }
   const int64_t n = g->n_nodes, m = g->n_edges;
   // d = degree(g; dir=:in[, edge_weight]) after add_self_loops (weights padded with ones), :210-224
   std::vector<float> deg((size_t)n, add_self_loops ? 1.0f : 0.0f);

@@ -8,6 +8,7 @@ Indices follow the reference: `GNNGraph(s, t)` takes the 1-based COO vectors a J
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -47,24 +48,54 @@ def _as_matrix_t(v, n, gdata=False):
 
 
 class _Handle:
-    """Owner of one ngpde_graph_t (destroyed with the last GNNGraph copy that shares it)."""
+    """Owner of one ngpde_graph_t (destroyed with the last GNNGraph copy that shares it).
+
+    Built on the device (ngpde_graph_create_device: the COO list is uploaded once per structure as int32, the locality
+    order is computed once per structure and cached -- batches reuse their members' orders); NGPDE_HOST_GRAPH_BUILD=1
+    selects the host builder (ngpde_graph_create), which produces bit-identical arrays."""
 
     def __init__(self, g, norm):
         lib = _lib.load()
         out = C.c_void_p()
-        s = np.ascontiguousarray(g._s0, dtype=np.int64)
-        t = np.ascontiguousarray(g._t0, dtype=np.int64)
-        _lib.check(lib.ngpde_graph_create(g.num_nodes, g.num_edges, s.ctypes.data, t.ctypes.data, 0,
-                                          g.num_graphs, C.byref(out)))
-        self.ptr = out
         self.lib = lib
+        self.ptr = None
+        if os.environ.get("NGPDE_HOST_GRAPH_BUILD") == "1":
+            s = np.ascontiguousarray(g._s0, dtype=np.int64)
+            t = np.ascontiguousarray(g._t0, dtype=np.int64)
+            _lib.check(lib.ngpde_graph_create(g.num_nodes, g.num_edges, s.ctypes.data, t.ctypes.data, 0,
+                                              g.num_graphs, C.byref(out)))
+            self.ptr = out
+            if norm is not None:
+                add_self_loops, w, weighted = norm
+                wp = None
+                if w is not None:
+                    w = np.ascontiguousarray(_to_numpy(w), dtype=np.float32)
+                    wp = w.ctypes.data
+                _lib.check(lib.ngpde_graph_set_gcn_norm(self.ptr, int(add_self_loops), wp, int(weighted)))
+            return
+        if not torch.cuda.is_available():
+            raise _lib.NgpdeError(_lib.ERR_HIP, "no HIP device: the derived-graph handle lives in HBM (there is no CPU fallback)")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        coo = g._shared.get(("coo", str(dev)))
+        if coo is None:
+            coo = (torch.as_tensor(g._s0.astype(np.int32), device=dev), torch.as_tensor(g._t0.astype(np.int32), device=dev))
+            g._shared[("coo", str(dev))] = coo
+        order = g._shared.get("order")
+        order_t = torch.as_tensor(order, device=dev) if order is not None else None
+        _lib.check(lib.ngpde_graph_create_device(g.num_nodes, g.num_edges, _lib.ptr(coo[0]), _lib.ptr(coo[1]), 32, 0,
+                                                 g.num_graphs, _lib.ptr(order_t), _lib.current_stream(), C.byref(out)))
+        self.ptr = out
+        if order is None:
+            order = np.empty(g.num_nodes, dtype=np.int32)
+            _lib.check(lib.ngpde_graph_node_order(self.ptr, order.ctypes.data))
+            g._shared["order"] = order
         if norm is not None:
             add_self_loops, w, weighted = norm
-            wp = None
+            wt = None
             if w is not None:
-                w = np.ascontiguousarray(w, dtype=np.float32)
-                wp = w.ctypes.data
-            _lib.check(lib.ngpde_graph_set_gcn_norm(self.ptr, int(add_self_loops), wp, int(weighted)))
+                wt = (w.detach() if isinstance(w, torch.Tensor) else torch.as_tensor(np.asarray(w))).to(dev, torch.float32).contiguous()
+            _lib.check(lib.ngpde_graph_set_gcn_norm_device(self.ptr, int(add_self_loops), _lib.ptr(wt), int(weighted),
+                                                           _lib.current_stream()))
 
     def __del__(self):
         try:
@@ -91,6 +122,7 @@ class GNNGraph:
             self.num_graphs = g.num_graphs if num_graphs is None else num_graphs
             self.edge_weight = g.edge_weight if edge_weight is None else edge_weight
             self._handles = g._handles          # same structure -> share the native handles
+            self._shared = g._shared            # ... the device copy of the COO list and the locality order
             self.ndata = g.ndata if ndata is None else _normalize(ndata, "x", self.num_nodes, "node")
             self.edata = g.edata if edata is None else _normalize(edata, "e", self.num_edges, "edge")
             self.gdata = g.gdata if gdata is None else _normalize(gdata, "u", self.num_graphs, "graph")
@@ -113,6 +145,7 @@ class GNNGraph:
         self.edata = _normalize(edata, "e", self.num_edges, "edge")
         self.gdata = _normalize(gdata, "u", self.num_graphs, "graph")
         self._handles = {}
+        self._shared = {}
         self._packs = {}
 
     # ---- reference-visible accessors ---------------------------------------------------------
@@ -160,6 +193,12 @@ class GNNGraph:
             self._handles[key] = (h, norm)   # keep `norm` alive so id(w) stays unique
             return h
         return h[0]
+
+    def node_order(self):
+        """the locality order of this structure (int32 permutation), computed with the first handle and cached"""
+        if self._shared.get("order") is None:
+            self.handle()
+        return self._shared["order"]
 
     def packed(self, which, device):
         """Concatenation of all features of one kind in NamedTuple order as a contiguous float32
@@ -252,4 +291,12 @@ def batch(graphs):
     out.gdata = cat([g.gdata for g in graphs], lambda g: g.num_graphs, gdata=True)
     if graphs and graphs[0].edge_weight is not None:
         out.edge_weight = np.concatenate([np.asarray(g.edge_weight) for g in graphs])
+    # the batch's locality order = its members' cached orders, offset: no graph traversal per minibatch
+    if graphs and off > 0 and torch.cuda.is_available() and os.environ.get("NGPDE_HOST_GRAPH_BUILD") != "1":
+        parts, o = [], 0
+        for g in graphs:
+            if g.num_nodes:
+                parts.append(g.node_order() + np.int32(o))
+            o += g.num_nodes
+        out._shared["order"] = np.concatenate(parts).astype(np.int32)
     return out

@@ -689,3 +689,145 @@ def gcn2_node_loss_and_grads(params, g, u0, tableau, dt, nsteps, activation="rel
                 A["bias"] += G["bias"].reshape(A["bias"].shape)
     du0 = rk_adjoint(vjp, tape, np.ones_like(uT), tableau, dt, accumulate)
     return uT, du0, acc
+
+
+# --------------------------------------------------------------------------------------------
+# Derived-graph handle (integer / byte work; the HIP library's ngpde_graph_t, include/ngpde.h).
+# Restates what the kernels are specified to read: CSR lists by target / by source in COO order
+# inside a row (NNlib's scatter order), the cross positions, the GCN coefficients of
+# src/layers.jl:210-226 in float32, the 32-row tile schedule and the per-tile halo lists.
+# Pure-Python loops: small cases only.  Parity bar: bit-exact.
+# --------------------------------------------------------------------------------------------
+
+TILE_ROWS, HALO_CAP, SLOT_WIDTH, ELL_WIDTH = 32, 96, 32, 16
+
+
+def csr_stable(key, other, n):
+    """rowptr [n+1], col [m], eid [m]: entries of row r are the COO positions e with key[e] == r, in increasing e"""
+    key = np.asarray(key, dtype=np.int64)
+    eid = np.argsort(key, kind="stable").astype(np.int32)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rowptr, key + 1, 1)
+    return np.cumsum(rowptr, dtype=np.int32), np.asarray(other, dtype=np.int32)[eid], eid
+
+
+def locality_order(n, rp_in, col_in, rp_out, col_out, tile=TILE_ROWS):
+    """clusters of `tile` nodes grown breadth-first (in- then out-neighbours, list order), emitted in a breadth-first
+    sweep over clusters: seed = oldest untaken frontier node, else the lowest untaken index"""
+    from collections import deque
+    order, taken, frontier, next_free = [], np.zeros(n, dtype=bool), deque(), 0
+
+    def neighbours(v):
+        yield from col_in[rp_in[v]:rp_in[v + 1]]
+        yield from col_out[rp_out[v]:rp_out[v + 1]]
+
+    while len(order) < n:
+        local, head = [], 0
+        while len(local) < tile and len(order) + len(local) < n:
+            if head == len(local):
+                seed = -1
+                while frontier:
+                    v = frontier.popleft()
+                    if not taken[v]:
+                        seed = v
+                        break
+                if seed < 0:
+                    while taken[next_free]:
+                        next_free += 1
+                    seed = next_free
+                taken[seed] = True
+                local.append(int(seed))
+            v = local[head]
+            head += 1
+            for w in neighbours(v):
+                if taken[w]:
+                    continue
+                if len(local) < tile:
+                    taken[w] = True
+                    local.append(int(w))
+                else:
+                    frontier.append(int(w))
+        for v in local[head:]:
+            for w in neighbours(v):
+                if not taken[w]:
+                    frontier.append(int(w))
+        order.extend(local)
+    return np.asarray(order, dtype=np.int32)
+
+
+def derived_graph(s, t, n, order=None, add_self_loops_=True, edge_weight=None, weighted_degree=False):
+    """dict of every array of the handle, per direction 't' (lists by target) / 's' (by source)"""
+    s, t = np.asarray(s, dtype=np.int64), np.asarray(t, dtype=np.int64)
+    m = s.size
+    out = {}
+    rp_t, col_t, eid_t = csr_stable(t, s, n)
+    rp_s, col_s, eid_s = csr_stable(s, t, n)
+    pos_t, pos_s = np.empty(m, np.int32), np.empty(m, np.int32)
+    pos_t[eid_t] = np.arange(m, dtype=np.int32)
+    pos_s[eid_s] = np.arange(m, dtype=np.int32)
+    if order is None:
+        order = locality_order(n, rp_t, col_t, rp_s, col_s)
+    order = np.asarray(order, dtype=np.int32)
+    out["order"] = order
+    w = None if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)
+    deg = np.zeros(n, dtype=np.float32)
+    for i in range(n):                                  # float32 running sum in COO order, then the self loop's 1
+        acc = np.float32(0.0)
+        for p in range(rp_t[i], rp_t[i + 1]):
+            acc = np.float32(acc + (w[eid_t[p]] if weighted_degree else np.float32(1.0)))
+        deg[i] = np.float32(acc + np.float32(1.0 if add_self_loops_ else 0.0))
+    with np.errstate(divide="ignore"):
+        c = (np.float32(1.0) / np.sqrt(deg, dtype=np.float32)).astype(np.float32)
+    out["c"] = c
+    n_tiles = (n + TILE_ROWS - 1) // TILE_ROWS
+    n_sched = n_tiles * TILE_ROWS
+    for tag, rp, col, eid, xp in (("t", rp_t, col_t, eid_t, pos_s[eid_t]), ("s", rp_s, col_s, eid_s, pos_t[eid_s])):
+        coef = ((w[eid] if w is not None else np.float32(1.0)) * c[col]).astype(np.float32)
+        ent = np.stack([col.astype(np.int32), coef.view(np.int32)], axis=1) if m else np.zeros((0, 2), np.int32)
+        sched = np.zeros((n_sched, 4), dtype=np.int32)
+        sched[:, 0] = -1
+        ell = np.zeros((n_sched, ELL_WIDTH, 2), dtype=np.int32)
+        for k in range(n):
+            v = order[k]
+            d = rp[v + 1] - rp[v]
+            sched[k] = (v, rp[v], d, c[v:v + 1].view(np.int32)[0])
+            ell[k, :min(d, ELL_WIDTH)] = ent[rp[v]:rp[v] + min(d, ELL_WIDTH)]
+        halo = np.zeros((n_tiles, HALO_CAP, 2), dtype=np.int32)
+        info = np.zeros((n_tiles, 2), dtype=np.int32)
+        slots = np.full((n_sched, SLOT_WIDTH), HALO_CAP, dtype=np.uint8)
+        slot_w = np.zeros((n_sched, SLOT_WIDTH), dtype=np.float32) if w is not None else None
+        for tl in range(n_tiles):
+            slot_of, count, fits = {}, TILE_ROWS, True
+            for k in range(TILE_ROWS):                   # own rows: slot k = k-th row of the tile
+                pos = tl * TILE_ROWS + k
+                if pos < n:
+                    v = int(order[pos])
+                    slot_of[v] = k
+                    halo[tl, k] = (v, c[v:v + 1].view(np.int32)[0])
+            rows = [int(order[tl * TILE_ROWS + k]) for k in range(TILE_ROWS) if tl * TILE_ROWS + k < n]
+            if any(rp[v + 1] - rp[v] > SLOT_WIDTH for v in rows):
+                fits = False
+            else:
+                tile_slots = []
+                for v in rows:                           # other columns: order of first appearance
+                    for p in range(rp[v], rp[v + 1]):
+                        u = int(col[p])
+                        if u not in slot_of:
+                            slot_of[u] = count
+                            if count < HALO_CAP:
+                                halo[tl, count] = (u, c[u:u + 1].view(np.int32)[0])
+                            count += 1
+                        tile_slots.append(slot_of[u])
+                fits = count <= HALO_CAP
+                if fits:
+                    i = 0
+                    for k, v in enumerate(rows):
+                        for j in range(rp[v + 1] - rp[v]):
+                            slots[tl * TILE_ROWS + k, j] = tile_slots[i]
+                            if slot_w is not None:
+                                slot_w[tl * TILE_ROWS + k, j] = w[eid[rp[v] + j]]
+                            i += 1
+            info[tl, 0] = count if fits else 0
+        out[tag] = dict(rowptr=rp, col=col, eid=eid, xpos=xp.astype(np.int32), ent=ent, sched=sched, ell=ell, halo=halo,
+                        tile_info=info, slots=slots, slot_w=slot_w, halo_ok=bool(n_tiles > 0 and (info[:, 0] > 0).all()))
+    return out

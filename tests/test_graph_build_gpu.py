@@ -1,0 +1,215 @@
+"""Derived-graph handle: the device builder (ngpde_graph_create_device / _set_gcn_norm_device) against the numpy
+restatement (oracle.derived_graph) and against the host builder (ngpde_graph_create / _set_gcn_norm), array by array
+through ngpde_graph_array.  Integer / byte work: the bar is bit-exact (float coefficients compared as their int32 bits).
+Reference boundary: the COO vectors of a GNNGraph moved with `g |> gpu` and swapped by `updategraph`
+(/root/reference/src/utils.jl:24-31, docs/src/tutorials/VMH.md:132-134)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+from ngpde_amd import _lib
+from ngpde_amd import synth as S
+from oracle import ngpde_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CODES = dict(rowptr=0, col=1, eid=2, xpos=3, ent=4, sched=5, ell=6, halo=7, tile_info=8, slots=9, slot_w=10, c=11, order=12,
+             halo_ok=13)
+DTYPES = dict(rowptr=np.int32, col=np.int32, eid=np.int32, xpos=np.int32, ent=np.int32, sched=np.int32, ell=np.int32,
+              halo=np.int32, tile_info=np.int32, slots=np.uint8, slot_w=np.int32, c=np.int32, order=np.int32)
+
+
+def fetch(handle, direction, name):
+    lib = _lib.load()
+    ptr, nbytes = C.c_void_p(), C.c_size_t()
+    _lib.check(lib.ngpde_graph_array(handle, direction, CODES[name], C.byref(ptr), C.byref(nbytes)))
+    if name == "halo_ok":
+        return bool(nbytes.value)
+    if nbytes.value == 0:
+        return None
+    return torch.as_tensor(_Raw(ptr.value, nbytes.value), device=DEV).cpu().numpy().view(DTYPES[name])
+
+
+class _Raw:
+    """a device buffer of the library seen through __cuda_array_interface__ (only ever copied to the host)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def create_host(s, t, n, norm, n_graphs=1):
+    lib = _lib.load()
+    out = C.c_void_p()
+    s64, t64 = np.ascontiguousarray(s, dtype=np.int64), np.ascontiguousarray(t, dtype=np.int64)
+    _lib.check(lib.ngpde_graph_create(n, s64.size, s64.ctypes.data, t64.ctypes.data, 0, n_graphs, C.byref(out)))
+    if norm is not None:
+        w = None if norm[1] is None else np.ascontiguousarray(norm[1], dtype=np.float32)
+        _lib.check(lib.ngpde_graph_set_gcn_norm(out, int(norm[0]), None if w is None else w.ctypes.data, int(norm[2])))
+    return out
+
+
+def create_device(s, t, n, norm, order=None, bits=32, base=0, n_graphs=1):
+    lib = _lib.load()
+    out = C.c_void_p()
+    dt = torch.int32 if bits == 32 else torch.int64
+    sd = torch.as_tensor(np.asarray(s) + base, dtype=dt, device=DEV)
+    td = torch.as_tensor(np.asarray(t) + base, dtype=dt, device=DEV)
+    od = None if order is None else torch.as_tensor(np.asarray(order), dtype=torch.int32, device=DEV)
+    _lib.check(lib.ngpde_graph_create_device(n, sd.numel(), _lib.ptr(sd), _lib.ptr(td), bits, base, n_graphs, _lib.ptr(od), None,
+                                             C.byref(out)))
+    if norm is not None:
+        wd = None if norm[1] is None else torch.as_tensor(np.asarray(norm[1]), dtype=torch.float32, device=DEV)
+        _lib.check(lib.ngpde_graph_set_gcn_norm_device(out, int(norm[0]), _lib.ptr(wd), int(norm[2]), None))
+    return out
+
+
+def destroy(h):
+    _lib.load().ngpde_graph_destroy(h)
+
+
+PER_DIR = ["rowptr", "col", "eid", "xpos", "ent", "sched", "ell", "tile_info"]
+
+
+def compare_handles(a, b, n, what):
+    """every array of two handles; halo lists / slot bytes on the tiles both report as fitting"""
+    for name in ("c", "order"):
+        x, y = fetch(a, 0, name), fetch(b, 0, name)
+        assert (x is None) == (y is None), (what, name)
+        if x is not None:
+            assert np.array_equal(x, y), (what, name)
+    for d in (0, 1):
+        for name in PER_DIR:
+            x, y = fetch(a, d, name), fetch(b, d, name)
+            assert (x is None) == (y is None), (what, d, name)
+            if x is not None:
+                assert np.array_equal(x, y), (what, d, name)
+        assert fetch(a, d, "halo_ok") == fetch(b, d, "halo_ok"), (what, d)
+        info = fetch(a, d, "tile_info")
+        if info is None:
+            continue
+        fit = info.reshape(-1, 2)[:, 0] > 0
+        for name, per_tile in (("halo", O.HALO_CAP * 2), ("slots", O.TILE_ROWS * O.SLOT_WIDTH), ("slot_w", O.TILE_ROWS * O.SLOT_WIDTH)):
+            x, y = fetch(a, d, name), fetch(b, d, name)
+            if name == "slot_w" and fetch(a, d, "col") is None:
+                continue                                        # no edges: an empty weight vector has no device address
+            assert (x is None) == (y is None), (what, d, name)
+            if x is not None:
+                assert np.array_equal(x.reshape(fit.size, per_tile)[fit], y.reshape(fit.size, per_tile)[fit]), (what, d, name)
+
+
+def compare_with_oracle(h, od, what):
+    assert np.array_equal(fetch(h, 0, "order"), od["order"]), what
+    assert np.array_equal(fetch(h, 0, "c"), od["c"].view(np.int32)), what
+    for d, tag in ((0, "t"), (1, "s")):
+        o = od[tag]
+        for name in PER_DIR:
+            got = fetch(h, d, name)
+            ref = np.asarray(o[name]).reshape(-1)
+            if ref.size == 0:
+                continue
+            assert np.array_equal(got, ref.view(np.int32) if ref.dtype != np.int32 else ref), (what, tag, name)
+        assert fetch(h, d, "halo_ok") == o["halo_ok"], (what, tag)
+        fit = o["tile_info"][:, 0] > 0
+        if fit.size:
+            assert np.array_equal(fetch(h, d, "halo").reshape(fit.size, -1)[fit], o["halo"].reshape(fit.size, -1)[fit]), (what, tag)
+            assert np.array_equal(fetch(h, d, "slots").reshape(fit.size, -1)[fit], o["slots"].reshape(fit.size, -1)[fit]), (what, tag)
+            if o["slot_w"] is not None and o["col"].size:      # (an empty weight vector has no device address)
+                assert np.array_equal(fetch(h, d, "slot_w").reshape(fit.size, -1)[fit],
+                                      o["slot_w"].view(np.int32).reshape(fit.size, -1)[fit]), (what, tag)
+
+
+def small_cases():
+    rng = np.random.default_rng(5)
+    yield "random-70", rng.integers(0, 70, 300), rng.integers(0, 70, 300), 70
+    yield "ragged-33", rng.integers(0, 33, 90), rng.integers(0, 33, 90), 33          # one node past a tile boundary
+    s = rng.integers(0, 40, 200)
+    yield "duplicates+loops", np.concatenate([s, s[:50], np.arange(10)]), np.concatenate([s[::-1], s[::-1][:50], np.arange(10)]), 40
+    yield "isolated", np.array([0, 1, 2]), np.array([1, 2, 0]), 50
+    yield "hub", np.concatenate([np.zeros(60, int), np.arange(1, 61)]), np.concatenate([np.arange(1, 61), np.zeros(60, int)]), 64   # degree 60 > 32
+    yield "wide-halo", rng.integers(0, 400, 3000), rng.integers(0, 400, 3000), 400   # > 96 distinct rows per tile
+    yield "fixture", np.array([0, 0, 1, 2]), np.array([1, 2, 0, 0]), 3                # test/runtests.jl:11-13
+    yield "no-edges", np.zeros(0, int), np.zeros(0, int), 5
+
+
+@pytest.mark.parametrize("name,s,t,n", list(small_cases()), ids=[c[0] for c in small_cases()])
+@pytest.mark.parametrize("norm", ["gcn", "plain", "weighted"])
+def test_device_and_host_builders_match_oracle(name, s, t, n, norm):
+    w = (0.5 + np.random.default_rng(1).random(s.size)).astype(np.float32)
+    nm = {"gcn": (True, None, False), "plain": (False, None, False), "weighted": (True, w, True)}[norm]
+    od = O.derived_graph(s, t, n, None, nm[0], nm[1], nm[2])
+    hd, hh = create_device(s, t, n, nm), create_host(s, t, n, nm)
+    try:
+        compare_with_oracle(hd, od, f"device {name} {norm}")
+        compare_with_oracle(hh, od, f"host {name} {norm}")
+        compare_handles(hd, hh, n, f"{name} {norm}")
+    finally:
+        destroy(hd); destroy(hh)
+
+
+def test_int64_one_based_device_input_and_given_order():
+    rng = np.random.default_rng(9)
+    n, m = 200, 1500
+    s, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    order = rng.permutation(n).astype(np.int32)
+    od = O.derived_graph(s, t, n, order, True, None, False)
+    h = create_device(s, t, n, (True, None, False), order=order, bits=64, base=1)
+    try:
+        compare_with_oracle(h, od, "int64 1-based, caller's order")
+    finally:
+        destroy(h)
+
+
+def test_out_of_range_index_is_a_dimension_mismatch():
+    with pytest.raises(ng.DimensionMismatch):
+        create_device(np.array([0, 5]), np.array([1, 2]), 4, None)
+    with pytest.raises(ng.DimensionMismatch):
+        create_device(np.array([-1, 0]), np.array([1, 2]), 4, None, base=1)      # raw index 0 is not a valid 1-based index
+
+
+@pytest.mark.parametrize("which", ["C2", "C4x8"])
+def test_full_size_host_and_device_builders_agree(which):
+    if which == "C2":
+        _, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
+        n, ng_ = 16384, 1
+    else:
+        m, traj = 8192, 8
+        idx = np.arange(m)
+        s1 = np.concatenate([idx for k in (-3, -2, -1, 1, 2, 3)])
+        t1 = np.concatenate([(idx + k) % m for k in (-3, -2, -1, 1, 2, 3)])
+        s, t = np.concatenate([s1 + i * m for i in range(traj)]), np.concatenate([t1 + i * m for i in range(traj)])
+        n, ng_ = m * traj, traj
+    hd, hh = create_device(s, t, n, (True, None, False), n_graphs=ng_), create_host(s, t, n, (True, None, False), n_graphs=ng_)
+    try:
+        compare_handles(hd, hh, n, which)
+        assert fetch(hd, 0, "halo_ok") and fetch(hd, 1, "halo_ok")
+        # size-independent properties: rowptr ends at E, eid and order are permutations, xpos is the cross inverse
+        for d in (0, 1):
+            assert fetch(hd, d, "rowptr")[-1] == s.size
+            assert np.array_equal(np.sort(fetch(hd, d, "eid")), np.arange(s.size))
+        assert np.array_equal(fetch(hd, 1, "xpos")[fetch(hd, 0, "xpos")], np.arange(s.size))
+        assert np.array_equal(np.sort(fetch(hd, 0, "order")), np.arange(n))
+    finally:
+        destroy(hd); destroy(hh)
+
+
+def test_batch_reuses_member_orders_and_layers_agree(monkeypatch):
+    g1 = ng.rand_graph(150, 900, seed=1)
+    g2 = ng.rand_graph(90, 500, seed=2)
+    gb = ng.batch([g1, g2, g1])
+    o1, o2 = g1.node_order(), g2.node_order()
+    assert np.array_equal(gb.node_order(), np.concatenate([o1, o2 + 150, o1 + 240]))
+    # the same batch through the host builder (its own traversal of the whole batch): identical layer output
+    l = ng.GCNConv((8, 6), "relu", initialgraph=gb)
+    ps, st = ng.setup(0, l)
+    ps = ng.to_device(ps, DEV)
+    x = torch.randn(8, gb.num_nodes, device=DEV)
+    y_dev, _ = l(x, ps, st)
+    monkeypatch.setenv("NGPDE_HOST_GRAPH_BUILD", "1")
+    s, t = gb.edge_index(0)
+    gh = ng.GNNGraph(s, t, num_nodes=gb.num_nodes, index_base=0, num_graphs=3)
+    y_host, _ = l(x, ps, ng.updategraph(st, gh))
+    assert torch.equal(y_dev, y_host)       # per-row summation order does not depend on the schedule

@@ -296,3 +296,56 @@ def test_generators_are_deterministic():
     iu = np.triu_indices(512, 1)
     thr = np.sort(d2[iu])[2047]
     assert np.all(((pts[s] - pts[t]) ** 2).sum(-1) <= thr + 1e-15)
+
+
+# ---- derived-graph handle restatement (integer work): structural properties on random and edge-case graphs ------------------
+
+@pytest.mark.parametrize("n,m,seed", [(70, 300, 0), (33, 90, 1), (5, 0, 2), (64, 1200, 3), (3, 4, 4)])
+def test_derived_graph_properties(n, m, seed):
+    rng = np.random.default_rng(seed)
+    s, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    w = (0.5 + rng.random(m)).astype(np.float32)
+    d = O.derived_graph(s, t, n, None, True, w, True)
+    assert sorted(d["order"].tolist()) == list(range(n))                       # a permutation of the nodes
+    for tag, key, other in (("t", t, s), ("s", s, t)):
+        c = d[tag]
+        assert c["rowptr"][0] == 0 and c["rowptr"][-1] == m and (np.diff(c["rowptr"]) >= 0).all()
+        assert sorted(c["eid"].tolist()) == list(range(m))
+        for r in range(n):
+            e = c["eid"][c["rowptr"][r]:c["rowptr"][r + 1]]
+            assert (key[e] == r).all() and (np.diff(e) > 0).all()              # COO order inside a row (NNlib's scatter order)
+            assert np.array_equal(c["col"][c["rowptr"][r]:c["rowptr"][r + 1]], other[e])
+        assert np.array_equal(c["ent"][:, 0], c["col"])
+        coef = c["ent"][:, 1].copy().view(np.float32)
+        assert np.array_equal(coef, (w[c["eid"]] * d["c"][c["col"]]).astype(np.float32))
+    assert np.array_equal(d["s"]["xpos"][d["t"]["xpos"]], np.arange(m))         # the two lists index each other
+    deg = np.zeros(n); np.add.at(deg, t, w.astype(np.float64))
+    np.testing.assert_allclose(d["c"], 1 / np.sqrt(deg + 1), rtol=1e-6)          # src/layers.jl:224-225 with padded weights
+    # every slot byte of a fitting tile points at the halo entry of that entry's column
+    for tag in ("t", "s"):
+        c = d[tag]
+        for tl in range(c["tile_info"].shape[0]):
+            if c["tile_info"][tl, 0] == 0:
+                continue
+            for k in range(O.TILE_ROWS):
+                pos = tl * O.TILE_ROWS + k
+                if pos >= n:
+                    continue
+                v = d["order"][pos]
+                assert c["halo"][tl, k, 0] == v
+                for j in range(c["rowptr"][v + 1] - c["rowptr"][v]):
+                    assert c["halo"][tl, c["slots"][pos, j], 0] == c["col"][c["rowptr"][v] + j]
+                    assert c["slot_w"][pos, j] == w[c["eid"][c["rowptr"][v] + j]]
+
+
+def test_locality_order_keeps_clusters_compact():
+    # a 2-D grid graph: BFS-grown 32-node clusters touch far fewer distinct rows than index order would
+    k = 24
+    idx = np.arange(k * k).reshape(k, k)
+    pairs = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]), np.stack([idx[:-1].ravel(), idx[1:].ravel()])], axis=1)
+    s, t = np.concatenate([pairs[0], pairs[1]]), np.concatenate([pairs[1], pairs[0]])
+    perm = np.random.default_rng(0).permutation(k * k)                           # hide the geometry in the labels
+    d = O.derived_graph(perm[s], perm[t], k * k, None, True, None, False)
+    ident = O.derived_graph(perm[s], perm[t], k * k, np.arange(k * k, dtype=np.int32), True, None, False)
+    assert d["t"]["halo_ok"]
+    assert d["t"]["tile_info"][:, 0].mean() < 0.75 * np.where(ident["t"]["tile_info"][:, 0] > 0, ident["t"]["tile_info"][:, 0], 96).mean()
