@@ -269,6 +269,15 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int3
 int32_t ngpde_node_profile(ngpde_node_t *plan, int32_t stride, float *out_us, int32_t *out_count,
                            ngpde_stream_t stream);
 
+/* Optimiser step on the flat parameter vector, one launch behind the gradient all-reduce on the same stream
+ * [UPSTREAM Optimisers.jl Adam / Rprop; reference call sites docs/src/tutorials/graph_node.md:90,122-129, VMH.md:97].
+ * grad_scale multiplies the (reduced) gradient first: 1/world_size for a mean over data-parallel ranks.
+ * Adam: step counts from 1.  Rprop: grad_prev starts at 0, step_size at eta. */
+int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float *v, float eta, float beta1, float beta2,
+                        float eps, int64_t step, float grad_scale, ngpde_stream_t stream);
+int32_t ngpde_rprop_step(int64_t n, float *x, const float *grad, float *grad_prev, float *step_size, float shrink, float grow,
+                         float step_min, float step_max, float grad_scale, ngpde_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

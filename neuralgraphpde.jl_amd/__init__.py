@@ -12,7 +12,7 @@ from .layers import (AbstractExplicitLayer, AbstractGNNContainerLayer, AbstractG
                      GCNConv, apply, glorot_normal, glorot_uniform, setup, to_device, zeros32)
 from .node import NeuralODE
 from .layers_mp import ExplicitEdgeConv, GATConv, GNOConv, MPPDEConv, SpectralConv, VMHConv
-from . import dist, synth
+from . import dist, optim, synth
 
 __all__ = [
     "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",

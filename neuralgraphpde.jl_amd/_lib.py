@@ -48,6 +48,8 @@ SIGNATURES = {
     "ngpde_graph_node_order": (_i32, [_vp, _vp]),
     "ngpde_graph_set_gcn_norm_device": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "ngpde_graph_array": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "ngpde_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "ngpde_rprop_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ngpde_graph_destroy": (_i32, [_vp]),
     "ngpde_graph_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "ngpde_graph_csr_by_target": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),

@@ -831,3 +831,40 @@ def derived_graph(s, t, n, order=None, add_self_loops_=True, edge_weight=None, w
         out[tag] = dict(rowptr=rp, col=col, eid=eid, xpos=xp.astype(np.int32), ent=ent, sched=sched, ell=ell, halo=halo,
                         tile_info=info, slots=slots, slot_w=slot_w, halo_ok=bool(n_tiles > 0 and (info[:, 0] > 0).all()))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Optimiser rules on the flat parameter vector [UPSTREAM Optimisers.jl Adam / Rprop, published update rules;
+# reference call sites docs/src/tutorials/graph_node.md:122-129, VMH.md:97].  float32 arithmetic, as the
+# reference's Float32 ComponentArray.  parity unpinned (no Julia here); checked against closed forms in tests.
+# --------------------------------------------------------------------------------------------
+
+
+def adam_init(x):
+    return dict(m=np.zeros_like(x, dtype=np.float32), v=np.zeros_like(x, dtype=np.float32), t=0)
+
+
+def adam_step(x, g, state, eta=0.001, beta=(0.9, 0.999), eps=1e-8):
+    f = np.float32
+    g = g.astype(np.float32)
+    state["t"] += 1
+    state["m"] = f(beta[0]) * state["m"] + (f(1) - f(beta[0])) * g
+    state["v"] = f(beta[1]) * state["v"] + (f(1) - f(beta[1])) * g * g
+    c1 = f(1) - f(np.power(f(beta[0]), f(state["t"])))
+    c2 = f(1) - f(np.power(f(beta[1]), f(state["t"])))
+    return (x - state["m"] / c1 / (np.sqrt(state["v"] / c2) + f(eps)) * f(eta)).astype(np.float32), state
+
+
+def rprop_init(x, eta=1e-3):
+    return dict(g=np.zeros_like(x, dtype=np.float32), step=np.full_like(x, eta, dtype=np.float32))
+
+
+def rprop_step(x, g, state, ell=(0.5, 1.2), gamma=(1e-6, 50.0)):
+    f = np.float32
+    g = g.astype(np.float32)
+    p = state["g"] * g
+    s = state["step"]
+    s = np.where(p > 0, np.minimum(s * f(ell[1]), f(gamma[1])), np.where(p < 0, np.maximum(s * f(ell[0]), f(gamma[0])), s)).astype(np.float32)
+    keep = np.where(p < 0, f(0), g).astype(np.float32)
+    state["step"], state["g"] = s, keep
+    return (x - s * np.sign(keep)).astype(np.float32), state

@@ -43,3 +43,47 @@ def test_single_process_is_a_no_op():
     g = {"w": torch.ones(3)}
     assert ng.dist.allreduce_gradients(g)["w"].tolist() == [1, 1, 1]
     assert ng.dist.shard_range(512, 3, 8) == (192, 256)                   # C4: 512 trajectories, 64 per GPU
+
+
+class _SgdRule:
+    """host stand-in for the fused kernel so the collective of optim.update can run under gloo on CPU"""
+
+    def init(self, flat):
+        return {}
+
+    def apply(self, state, flat, grad_scale):
+        flat.data -= 0.5 * grad_scale * flat.grad
+        return state
+
+
+def _optim_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = {"layer_1": {"weight": torch.ones(2, 3), "bias": torch.zeros(2, 1)}}
+    flat, psv = ng.optim.flatten_parameters(ps)
+    (psv["layer_1"]["weight"] * float(rank + 1)).sum().backward()        # rank-dependent gradient: 1 resp. 2 per weight entry
+    (psv["layer_1"]["bias"] * 4.0).sum().backward()
+    st = {"rule": _SgdRule(), "state": {}}
+    ng.optim.update(st, flat)                                             # all-reduce(sum) of the flat gradient, then mean
+    out[rank] = flat.data.tolist()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optim_update_allreduces_flat_gradient_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_optim_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    expect = [1 - 0.5 * 1.5] * 6 + [0 - 0.5 * 4.0] * 2                    # mean gradient 1.5 on the weights, 4 on the bias
+    assert out[0] == expect and out[1] == expect
+
+
+def test_flatten_parameters_views_alias_the_flat_vector():
+    ps = {"a": {"weight": torch.arange(6.0).reshape(2, 3)}, "b": torch.tensor([7.0, 8.0])}
+    flat, psv = ng.optim.flatten_parameters(ps)
+    assert flat.data.tolist() == [0, 1, 2, 3, 4, 5, 7, 8] and [t[0] for t in flat.table] == ["a.weight", "b"]
+    (psv["a"]["weight"].sum() * 2 + (psv["b"] * torch.tensor([1.0, 3.0])).sum()).backward()
+    assert flat.grad.tolist() == [2] * 6 + [1, 3]
+    flat.data[0] = 42.0
+    assert float(psv["a"]["weight"].detach()[0, 0]) == 42.0

@@ -349,3 +349,19 @@ def test_locality_order_keeps_clusters_compact():
     ident = O.derived_graph(perm[s], perm[t], k * k, np.arange(k * k, dtype=np.int32), True, None, False)
     assert d["t"]["halo_ok"]
     assert d["t"]["tile_info"][:, 0].mean() < 0.75 * np.where(ident["t"]["tile_info"][:, 0] > 0, ident["t"]["tile_info"][:, 0], 96).mean()
+
+
+def test_optimiser_rules_closed_forms():
+    # Adam, t = 1: bias-corrected moments are g and g^2  =>  x1 = x0 - eta g / (|g| + eps)   [UPSTREAM Optimisers.jl]
+    g = np.array([3.0, -0.5, 1e-3, 0.0], np.float32)
+    x, st = O.adam_step(np.zeros(4, np.float32), g, O.adam_init(g), 0.1)
+    np.testing.assert_allclose(x, -0.1 * g / (np.abs(g) + 1e-8), rtol=1e-5, atol=1e-9)
+    # constant gradient: every later step has the same size eta (m/c1 = g, v/c2 = g^2 for all t)
+    x2, st = O.adam_step(x, g, st, 0.1)
+    np.testing.assert_allclose(x2 - x, x, rtol=1e-4, atol=1e-9)
+    # Rprop: first step has no remembered gradient -> step size unchanged; same sign grows by 1.2, a flip halves and skips
+    xr, rs = O.rprop_step(np.zeros(3, np.float32), np.array([1.0, -2.0, 0.0], np.float32), O.rprop_init(np.zeros(3, np.float32), 0.1))
+    np.testing.assert_allclose(xr, [-0.1, 0.1, 0.0], rtol=1e-6)
+    xr2, rs = O.rprop_step(xr, np.array([5.0, 3.0, 1.0], np.float32), rs)
+    np.testing.assert_allclose(rs["step"], [0.12, 0.05, 0.1], rtol=1e-6)
+    np.testing.assert_allclose(xr2 - xr, [-0.12, 0.0, -0.1], rtol=1e-6, atol=1e-9)

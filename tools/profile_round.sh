@@ -1,0 +1,30 @@
+#!/bin/bash
+# One measurement pass on the GPU box: bench line, rocprofv3 kernel stats, PMC passes (each counter group in its own run, no
+# trace domains combined with --pmc), layer benches, graph-build timings.  Everything lands in gpurun_out/<tag>/.
+# usage (through gpurun):  bash tools/profile_round.sh r01_d
+TAG=${1:-round}
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+python3 bench.py > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+done
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_l2.log 2>&1
+cd $R
+python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_l2 $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
+python3 tools/bench_layers.py --only c3 > $O/layers.jsonl 2>/dev/null
+python3 tools/bench_layers.py --only c4 --traj 64 >> $O/layers.jsonl 2>/dev/null
+python3 tools/bench_layers.py --only c5 --width 128 >> $O/layers.jsonl 2>/dev/null
+python3 tools/bench_layers.py --only c5 --width 128 --radius 0.1 >> $O/layers.jsonl 2>/dev/null
+python3 tools/bench_graph_build.py > $O/graph_build.jsonl 2>/dev/null
+NGPDE_HOST_GRAPH_BUILD=1 python3 tools/bench_graph_build.py | sed 's/"graph"/"builder": "host", "graph"/' >> $O/graph_build.jsonl 2>/dev/null
+python3 tools/bench_dense.py > $O/dense.jsonl 2>/dev/null
+# keep only what is small
+find $O -name "*_kernel_trace.csv" -size +8M -delete
+find $O -name "*counter_collection.csv" -size +8M -delete
+cat $O/layers.jsonl $O/graph_build.jsonl
+ls -la $O | head -30
