@@ -7,7 +7,8 @@
     sum(u(T)) w.r.t. u0 and all parameters by the discrete adjoint.
 
 A bench "step" (what --steps counts) is ONE full solve, forward then backward (+ the RCCL all-reduce
-of the parameter gradients when N > 1), over one batch of synthetic input already resident in HBM.
+of the parameter gradients when N > 1) and the fused Adam update of the flat parameter vector, over one
+batch of synthetic input already resident in HBM.
 `value` = ODE steps integrated per second by the whole job = n_gpus * 50 * K / T.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
@@ -116,7 +117,12 @@ def main():
     plan = _Plan(handle, D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
     lib = _lib.load()
     dv = lambda a: torch.as_tensor(a, device=dev)
-    u0, w1, b1, w2, b2 = dv(u0_h), dv(w1_h), dv(b1_h), dv(w2_h), dv(b2_h)
+    u0 = dv(u0_h)
+    # parameters as ONE flat vector [w1 | b1 | w2 | b2] (the reference's ComponentArray), gradients likewise
+    pflat = torch.cat([dv(w1_h).reshape(-1), dv(b1_h), dv(w2_h).reshape(-1), dv(b2_h)]).contiguous()
+    w1, b1 = pflat[:D * D], pflat[D * D:D * D + D]
+    w2, b2 = pflat[D * D + D:2 * D * D + D], pflat[2 * D * D + D:]
+    adam_m, adam_v = torch.zeros_like(pflat), torch.zeros_like(pflat)
     uT, du0 = torch.empty_like(u0), torch.empty_like(u0)
     seed_grad = torch.ones_like(u0)                       # d sum(u(T)) / d u(T)
     flat = torch.empty(2 * (D * D + D), dtype=torch.float32, device=dev)   # [dw1 | db1 | dw2 | db2]
@@ -125,11 +131,17 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     p = _lib.ptr
 
+    it = [0]
+
     def step():
+        # one training step: solve, discrete adjoint, gradient all-reduce, fused Adam on the flat vector (1/world folded in)
         _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
         _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
         if dist is not None:
             dist.all_reduce(flat)
+        it[0] += 1
+        _lib.check(lib.ngpde_adam_step(flat.numel(), p(pflat), p(flat), p(adam_m), p(adam_v), 1e-5, 0.9, 0.999, 1e-8, it[0],
+                                       1.0 / world, stream))
 
     def fence():
         if dist is not None:
@@ -192,7 +204,7 @@ def main():
             "config": {"workload": "C2: 16384-node / 131072-edge closest-pairs radius graph, 64-d feats, "
                                    "RHS = 2 x GCNConv(64=>64, relu, self-loops), Tsit5 fixed dt=1/50 x 50 steps, "
                                    "forward + discrete adjoint of sum(u(T))",
-                       "bench_step": "one full solve forward + backward",
+                       "bench_step": "one full solve forward + backward (+ gradient all-reduce when N > 1) + fused Adam step",
                        "ode_steps_per_solve": ODE_STEPS, "rhs_evals_per_ode_step": 6,
                        "launches_per_solve": {"forward": fl, "backward": bl},
                        "ms_forward_solve": round(ms_fwd, 3), "ms_backward_solve": round(ms_bwd, 3),
