@@ -69,7 +69,10 @@ def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
                                   C.c_int] + [vp] * 11
     lib.ngo_node_gcn2.restype = C.c_int
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
     s64, t64 = np.ascontiguousarray(s, np.int64), np.ascontiguousarray(t, np.int64)
     outs = [np.zeros_like(u0), np.zeros_like(u0), np.zeros_like(w1), np.zeros_like(b1), np.zeros_like(w2),
             np.zeros_like(b2)]
@@ -82,12 +85,25 @@ def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
         assert rc == 0
         return time.perf_counter() - t0
 
-    t1 = run(1)
-    n = int(max(1, min(ODE_STEPS, budget_s / max(t1, 1e-6))))
-    tn = run(n) if n > 1 else t1
-    return {"value": n / tn, "unit": "ODE-steps/s", "cores": cores, "kind": "port",
+    # the port's loops are short: more threads than the sparse products can feed only add fork/join and NUMA cost, so
+    # probe a few team sizes with one step each and keep the fastest (the first call also pays the page faults)
+    run(1)
+    best_t, best_n = None, cores
+    if gomp is not None:
+        for nt in sorted({min(cores, k) for k in (8, 16, 32, 64, cores)}):
+            gomp.omp_set_num_threads(nt)
+            t1 = run(1)
+            if best_t is None or t1 < best_t:
+                best_t, best_n = t1, nt
+        gomp.omp_set_num_threads(best_n)
+    else:
+        best_t = run(1)
+    n = int(max(1, min(ODE_STEPS, budget_s / max(best_t, 1e-6))))
+    tn = run(n) if n > 1 else best_t
+    return {"value": n / tn, "unit": "ODE-steps/s", "cores": best_n, "kind": "port",
             "sample": f"{n} Tsit5 step(s) fwd+bwd of the same C2 workload (C restatement of the reference "
-                      f"algorithm, OpenMP over {cores} host threads; not the Julia package)"}, outs
+                      f"algorithm, OpenMP, fastest of the probed team sizes = {best_n} of {cores} host threads; "
+                      f"not the Julia package)"}, outs
 
 
 def main():
