@@ -49,6 +49,7 @@ struct Csr {
   uint8_t *slots = nullptr;   // [n_sched][kSlotWidth]
   float *slot_w = nullptr;    // [n_sched][kSlotWidth] per-edge weights w_e, or NULL for unweighted graphs
   bool halo_ok = false;       // every tile fits (<= kHaloCap distinct rows, degrees <= kSlotWidth)
+  int32_t max_halo = 0;       // largest halo count over the tiles (sizes the LDS halo region of the fused edge kernel)
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
 

@@ -24,19 +24,36 @@ namespace {
     if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
   } while (0)
 
-constexpr int kT = 512, kW = 64, kTS = kW + 4, kChunk = 64, kGroups = 32;
+constexpr int kT = 512, kW = 64, kTS = kW + 4, kChunk = 128, kGroups = 32;   // kChunk = 8 waves x 16 edges
+
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/stamps_edge.py): phase timestamps of each workgroup's FIRST tile, [n_blocks][16] words
+unsigned long long *g_edge_stamps = nullptr;
+#define EDGE_STAMP(k)                                                                                     \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && p.stamps && first_tile) {                                                     \
+      p.stamps[(size_t)blockIdx.x * 16 + (k)] = clock64();                                                \
+      if ((k) == 0 || (k) == 7) p.stamps[(size_t)blockIdx.x * 16 + 8 + ((k) ? 1 : 0)] = wall_clock64();  \
+    }                                                                                                     \
+  } while (0)
+#else
+#define EDGE_STAMP(k)
+#endif
 
 struct EdgeMlpK {
   const int4 *sched;
   const int2 *halo;
   const uint8_t *slots;
-  int n_tiles, h1, act1, aggr;
+  int n_tiles, h1, act1, aggr, halo_rows;
   const float *P, *Q, *Eterm;
   int n_tail;
   int din[3], dout[3], act[3];
   const float *wt[3], *bias[3];
   float *out;
   float *save_z[4];   // [0]: z1 [E][h1]; [k]: pre-activation of tail layer k [E][dout_k]; nullable
+#ifdef NGPDE_STAMPS
+  unsigned long long *stamps;
+#endif
 };
 
 __device__ __forceinline__ int xcd_tile(int b, int nb) {
@@ -49,64 +66,64 @@ __device__ __forceinline__ float4 load4_guard(const float *base, size_t row, int
   return (4 * q < width) ? *reinterpret_cast<const float4 *>(base + row * width + 4 * q) : f4_zero();
 }
 
-// acc = A[64][kTS] x B for this wave's row tile (w & 3) and column tiles (w >> 2) + {0, 2}   (B transposed in LDS: Bt[col][k])
-__device__ __forceinline__ void mfma_chunk64(const float *ldsA, const float *ldsBt, int wave, int lane, int kblocks, int col_tiles,
-                                             f32x4 (&acc)[2]) {
-  const int rt = wave & 3, cg = wave >> 2;
-  const int i = lane & 15, kq = lane >> 4;
-  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float *pa = ldsA + (rt * 16 + i) * kTS + 4 * kq;
-  const float *pb0 = ldsBt + (cg * 16 + i) * kTS + 4 * kq;
-  const float *pb1 = ldsBt + ((cg + 2) * 16 + i) * kTS + 4 * kq;
-  const bool t0 = cg < col_tiles, t1 = cg + 2 < col_tiles;   // wave-uniform
-  for (int kb = 0; kb < kblocks; ++kb) {
-    const float4 a4 = *reinterpret_cast<const float4 *>(pa + kb * 16);
-    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-    if (t0) {
-      const float4 b4 = *reinterpret_cast<const float4 *>(pb0 + kb * 16);
-      acc[0] = mfma16(av[0], b4.x, acc[0]); acc[0] = mfma16(av[1], b4.y, acc[0]);
-      acc[0] = mfma16(av[2], b4.z, acc[0]); acc[0] = mfma16(av[3], b4.w, acc[0]);
-    }
-    if (t1) {
-      const float4 b4 = *reinterpret_cast<const float4 *>(pb1 + kb * 16);
-      acc[1] = mfma16(av[0], b4.x, acc[1]); acc[1] = mfma16(av[1], b4.y, acc[1]);
-      acc[1] = mfma16(av[2], b4.z, acc[1]); acc[1] = mfma16(av[3], b4.w, acc[1]);
-    }
-  }
-}
+// tile metadata / rows of one tile held in registers between the moment they are fetched (under the previous tile's
+// arithmetic) and the moment they are staged into LDS
+struct TileMeta {
+  int4 sc;
+  uint4 s0, s1;
+  int2 he[3];
+};
+struct TileRows {
+  float4 prow, hv[3];
+};
 
+// Register-chained message MLP.  A wave owns 16 edges of the chunk; lane (i = lane & 15, kq = lane >> 4) holds, for edge i,
+// the features {16 ct + 4 kq + r : ct = 0..3, r = 0..3} of the current activation as four float4.  A Dense layer is
+// evaluated TRANSPOSED, z^T = W^T a^T, with v_mfma_f32_16x16x4_f32(A = W^T tile from LDS, B = a^T from registers): the D
+// layout of that product (row = output feature 4 kq + r, column = edge i) is again exactly this register layout, so the
+// layers chain in registers -- no LDS round trip and no barrier between assemble, Dense layers, bias and activation.
+// MFMA step (ct, r) contracts, in lane kq, feature 16 ct + 4 kq + r of both operands (the order of a sum's terms is free).
 template <int NTAIL>
-__global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p) {
-  __shared__ __attribute__((aligned(16))) float ldsQ[(kHaloCap + 1) * kW];
-  __shared__ __attribute__((aligned(16))) float ldsP[kGroups * kW];
-  __shared__ __attribute__((aligned(16))) float ldsA[kChunk * kTS];
-  __shared__ __attribute__((aligned(16))) float ldsWt[(NTAIL > 0 ? NTAIL : 1) * kW * kTS];
+__global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]  rows of Q the tile references
+  float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]             P rows of the tile's targets
+  float *ldsWt = ldsP + kGroups * kTS;                            // [NTAIL][64 out][kTS]  tail weights, W^T
+  float *ldsMsg = ldsWt + (size_t)NTAIL * kW * kTS;               // [kChunk][kTS]         messages of the chunk
   __shared__ int ldsOff[kGroups + 1], ldsRs[kGroups];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kGroups * 8];   // 32 slot bytes per row
   __shared__ uint8_t ldsRowOf[kGroups * kSlotWidth];                        // tile edge k -> row of the tile
-  __shared__ int ldsPe[kChunk];                                             // chunk edge -> p position, -1 past the end
+  __shared__ __attribute__((aligned(16))) float ldsBias[(NTAIL > 0 ? NTAIL : 1) * kW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = tid >> 4, q = tid & 15;           // group g <-> row g of the tile; lane q <-> features 4q..4q+3
-  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
-  const int h1 = p.h1;
+  const int grp = tid >> 4, q = tid & 15;           // staging / reduction role: group g <-> row g, lane q <-> features 4q..4q+3
+  const int ei = lane & 15, kq = lane >> 4;         // MFMA role: edge ei of the wave's 16, k-quarter kq
+  const int h1 = p.h1, zero_slot = p.halo_rows;
 
-  // ---- round 1: schedule entry, slot bytes, halo entries, P row, tail weights (transposed into LDS)
-  const int4 sc = p.sched[(size_t)tile * kTileRows + grp];
-  const uint4 s0 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2];
-  const uint4 s1 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2 + 1];
-  int2 he[3];
+  // persistent workgroup: XCD x = blockIdx % 8 owns a contiguous range of tiles; its workgroups stride through it
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const int range_len = p.n_tiles / 8 + (xcd < p.n_tiles % 8 ? 1 : 0);
+  const int range_lo = xcd * (p.n_tiles / 8) + min(xcd, p.n_tiles % 8);
+
+  auto fetch_meta = [&](int tile, TileMeta &m) {
+    m.sc = p.sched[(size_t)tile * kTileRows + grp];
+    m.s0 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2];
+    m.s1 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2 + 1];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) he[k] = p.halo[(size_t)tile * kHaloCap + min(grp + k * kGroups, kHaloCap - 1)];
-  const int node = max(sc.x, 0);
-  const float4 prow = p.P ? load4_guard(p.P, node, h1, q) : f4_zero();
-  float4 wreg[NTAIL > 0 ? NTAIL : 1][2];
-  float breg[NTAIL > 0 ? NTAIL : 1][2];             // bias of this lane's two output columns (MFMA D layout)
+    for (int k = 0; k < 3; ++k) m.he[k] = p.halo[(size_t)tile * kHaloCap + min(grp + k * kGroups, kHaloCap - 1)];
+  };
+  auto fetch_rows = [&](const TileMeta &m, TileRows &r) {
+    r.prow = p.P ? load4_guard(p.P, max(m.sc.x, 0), h1, q) : f4_zero();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      r.hv[k] = (p.Q && grp + k * kGroups < p.halo_rows) ? load4_guard(p.Q, m.he[k].x, h1, q) : f4_zero();
+  };
+
+  // ---- once per workgroup: tail weights as W^T rows (output j, contiguous inputs) and biases in LDS
 #pragma unroll
   for (int l = 0; l < NTAIL; ++l) {
-    const int j = tid % kW, kg0 = tid / kW;   // output column j, k-groups kg0 and kg0 + 8
+    const int j = tid % kW, kg0 = tid / kW;   // output column j, input quads kg0 and kg0 + 8
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int k = 4 * (kg0 + 8 * ps);
@@ -114,131 +131,164 @@ __global__ __launch_bounds__(kT) void edge_mlp_fused_fwd_kernel(const EdgeMlpK p
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         t[r] = (k + r < p.din[l] && j < p.dout[l]) ? p.wt[l][(size_t)(k + r) * p.dout[l] + j] : 0.f;
-      wreg[l][ps] = make_float4(t[0], t[1], t[2], t[3]);
-      const int col = ((wave >> 2) + 2 * ps) * 16 + (lane & 15);
-      breg[l][ps] = (p.bias[l] && col < p.dout[l]) ? p.bias[l][col] : 0.f;
+      *reinterpret_cast<float4 *>(&ldsWt[l * kW * kTS + j * kTS + k]) = make_float4(t[0], t[1], t[2], t[3]);
     }
+    if (tid < kW) ldsBias[l * kW + tid] = (p.bias[l] && tid < p.dout[l]) ? p.bias[l][tid] : 0.f;
   }
-  // ---- round 2: the tile's distinct source rows of Q
-  float4 hv[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) hv[k] = p.Q ? load4_guard(p.Q, he[k].x, h1, q) : f4_zero();
+  if (grp == 0) *reinterpret_cast<float4 *>(&ldsQ[zero_slot * kTS + 4 * q]) = f4_zero();   // the all-zero row
 
-  // stage
-  float4 *Q4 = reinterpret_cast<float4 *>(ldsQ);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int hh = grp + k * kGroups;
-    if (hh < kHaloCap) Q4[hh * 16 + q] = hv[k];
+  TileMeta meta;
+  TileRows rows;
+  int jt = wg_in_xcd;
+  if (jt < range_len) {
+    fetch_meta(range_lo + jt, meta);
+    fetch_rows(meta, rows);
   }
-  if (grp == 0) Q4[kHaloCap * 16 + q] = f4_zero();
-  reinterpret_cast<float4 *>(ldsP)[grp * 16 + q] = prow;
-  if (q == 0) {
-    ldsOff[grp + 1] = sc.x >= 0 ? sc.z : 0;   // degrees; turned into offsets below
-    ldsRs[grp] = sc.y;
-    if (grp == 0) ldsOff[0] = 0;
-  }
-  if (q < 8) {
-    const unsigned w[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    unsigned v = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v = (q == j) ? w[j] : v;
-    ldsSlots[grp * 8 + q] = v;
-  }
-#pragma unroll
-  for (int l = 0; l < NTAIL; ++l) {
-    const int j = tid % kW, kg0 = tid / kW;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
-      *reinterpret_cast<float4 *>(&ldsWt[l * kW * kTS + j * kTS + 4 * (kg0 + 8 * ps)]) = wreg[l][ps];
-  }
-  __syncthreads();
-  if (tid == 0) {   // 32-entry prefix sum of the degrees
-    int run = 0;
-    for (int r = 0; r < kGroups; ++r) {
-      const int d = ldsOff[r + 1];
-      ldsOff[r + 1] = run + d;
-      run += d;
-    }
-  }
-  __syncthreads();
-  const int total = ldsOff[kGroups];
-  const int my_lo = ldsOff[grp], my_hi = ldsOff[grp + 1];
   const int last_w = (NTAIL > 0) ? p.dout[NTAIL - 1] : h1;
-  for (int k = my_lo + q; k < my_hi; k += 16) ldsRowOf[k] = (uint8_t)grp;   // deg <= kSlotWidth: total <= 1024
 
-  float4 racc;
-  if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-  else racc = f4_zero();
-  __syncthreads();
-
-  for (int c0 = 0; c0 < total; c0 += kChunk) {
-    // ---- a1 = act1(P[t] + Q[s] + E) for the chunk's edges: 2 edges per lane group
+  for (; jt < range_len; jt += wgs_per_xcd) {
+#ifdef NGPDE_STAMPS
+    const bool first_tile = (jt == wg_in_xcd + 4 * wgs_per_xcd);   // a tile in steady state (the fifth of the workgroup)
+#endif
+    EDGE_STAMP(0);
+    // ---- stage this tile (fetched under the previous tile's arithmetic)
+    const int4 sc = meta.sc;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int el = 2 * grp + u;
-      const int k = c0 + el;
-      float4 a = f4_zero();
-      int pe_i = -1;
-      if (k < total) {
-        const int r = ldsRowOf[k];
-        const int j = k - ldsOff[r];
-        const int slot = (ldsSlots[r * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff;
-        pe_i = ldsRs[r] + j;                              // position of the edge in p order
-        const size_t pe = (size_t)pe_i;
-        float4 z = f4_add(reinterpret_cast<const float4 *>(ldsP)[r * 16 + q], Q4[slot * 16 + q]);
-        if (p.Eterm) z = f4_add(z, load4_guard(p.Eterm, pe, h1, q));
-        if (p.save_z[0] && 4 * q < h1) *reinterpret_cast<float4 *>(p.save_z[0] + pe * h1 + 4 * q) = z;
-        a = (4 * q < h1) ? f4_act(p.act1, z) : f4_zero();
+    for (int k = 0; k < 3; ++k) {
+      const int hh = grp + k * kGroups;
+      if (hh < p.halo_rows) *reinterpret_cast<float4 *>(&ldsQ[hh * kTS + 4 * q]) = rows.hv[k];
+    }
+    *reinterpret_cast<float4 *>(&ldsP[grp * kTS + 4 * q]) = rows.prow;
+    if (q == 0) {
+      ldsOff[grp + 1] = sc.x >= 0 ? sc.z : 0;   // degrees; turned into offsets below
+      ldsRs[grp] = sc.y;
+      if (grp == 0) ldsOff[0] = 0;
+    }
+    if (q < 8) {
+      const unsigned w[8] = {meta.s0.x, meta.s0.y, meta.s0.z, meta.s0.w, meta.s1.x, meta.s1.y, meta.s1.z, meta.s1.w};
+      unsigned v = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v = (q == j) ? w[j] : v;
+      ldsSlots[grp * 8 + q] = v;
+    }
+    // ---- next tile: metadata now (one L2 round trip, lands during the prefix sums), rows after the first chunk
+    const int jn = jt + wgs_per_xcd;
+    const bool has_next = jn < range_len;       // workgroup-uniform
+    if (has_next) fetch_meta(range_lo + jn, meta);
+    __syncthreads();
+    if (tid < kGroups) {   // inclusive scan of the 32 degrees inside wave 0 (DPP shuffles, no LDS round trips)
+      int v = ldsOff[tid + 1];
+#pragma unroll
+      for (int o = 1; o < kGroups; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (tid >= o) v += u;
       }
-      *reinterpret_cast<float4 *>(&ldsA[el * kTS + 4 * q]) = a;
-      if (q == 0) ldsPe[el] = pe_i;
+      ldsOff[tid + 1] = v;
     }
     __syncthreads();
-    // ---- remaining Dense layers on MFMA, weights resident in LDS; bias + activation applied on the accumulators
-    // and written back over the chunk's activations (no second staging tile)
+    const int total = ldsOff[kGroups];
+    const int my_lo = ldsOff[grp], my_hi = ldsOff[grp + 1];
+    for (int k = my_lo + q; k < my_hi; k += 16) ldsRowOf[k] = (uint8_t)grp;   // deg <= kSlotWidth: total <= 1024
+
+    float4 racc;
+    if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    else racc = f4_zero();
+    __syncthreads();
+    EDGE_STAMP(1);
+
+    bool rows_fetched = false;
+    for (int c0 = 0; c0 < total; c0 += kChunk) {
+      // ---- this lane's edge: row, halo slot, position in p order (a wave past the tile's last edge only joins the barriers)
+      const bool wave_on = c0 + wave * 16 < total;   // wave-uniform
+      const int k = c0 + wave * 16 + ei;
+      const bool valid = k < total;
+      int r = 0, slot = zero_slot;
+      size_t pe = 0;
+      if (valid) {
+        r = ldsRowOf[k];
+        const int j = k - ldsOff[r];
+        slot = (ldsSlots[r * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff;
+        pe = (size_t)(ldsRs[r] + j);
+      }
+      // ---- a1 = act1(P[t] + Q[s] + E), features 16 ct + 4 kq .. + 3
+      float4 a[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+      if (wave_on) {
 #pragma unroll
-    for (int l = 0; l < NTAIL; ++l) {
-      f32x4 acc[2];
-      const int dw = p.dout[l], col_tiles = (dw + 15) / 16;
-      mfma_chunk64(ldsA, ldsWt + l * kW * kTS, wave, lane, (p.din[l] + 15) / 16, col_tiles, acc);
-      __syncthreads();                                   // every wave is done reading the layer's input
-      const int rt = wave & 3, cg = wave >> 2, i = lane & 15, kq = lane >> 4;
+      for (int ct = 0; ct < 4; ++ct) {
+        const int f = 16 * ct + 4 * kq;
+        float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
+        if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
+        if (p.save_z[0] && valid && f < h1) *reinterpret_cast<float4 *>(p.save_z[0] + pe * h1 + f) = z;
+        a[ct] = (valid && f < h1) ? f4_act(p.act1, z) : f4_zero();
+      }
+      }
+      if (c0 == 0) EDGE_STAMP(2);
+      if (has_next && !rows_fetched) {   // the next tile's rows: in flight across this tile's MFMAs
+        fetch_rows(meta, rows);
+        rows_fetched = true;
+      }
+      // ---- remaining Dense layers, transposed product on MFMA, chained in registers
+      if (wave_on) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int col = (cg + 2 * m) * 16 + i;
+      for (int l = 0; l < NTAIL; ++l) {
+        const int dw = p.dout[l];
+        const int n_ct = (p.din[l] + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
+        const float *wl = ldsWt + l * kW * kTS + ei * kTS + 4 * kq;
+        f32x4 acc[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = rt * 16 + 4 * kq + reg;
-          const int pe_i = ldsPe[row];
-          float v = 0.f;
-          if (pe_i >= 0 && col < dw) {
-            const float z = acc[m][reg] + breg[l][m];
-            if (p.save_z[l + 1]) p.save_z[l + 1][(size_t)pe_i * dw + col] = z;
-            v = act_apply(p.act[l], z);
+        for (int mt = 0; mt < 4; ++mt) {
+          acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (mt < n_mt) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              if (ct < n_ct) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wl + mt * 16 * kTS + 16 * ct);
+                acc[mt] = mfma16(w4.x, a[ct].x, acc[mt]);
+                acc[mt] = mfma16(w4.y, a[ct].y, acc[mt]);
+                acc[mt] = mfma16(w4.z, a[ct].z, acc[mt]);
+                acc[mt] = mfma16(w4.w, a[ct].w, acc[mt]);
+              }
+            }
           }
-          ldsA[row * kTS + col] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int f = 16 * mt + 4 * kq;
+          const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[l * kW + f]);
+          const float4 z = make_float4(acc[mt][0] + b4.x, acc[mt][1] + b4.y, acc[mt][2] + b4.z, acc[mt][3] + b4.w);
+          if (p.save_z[l + 1] && valid && f < dw) *reinterpret_cast<float4 *>(p.save_z[l + 1] + pe * dw + f) = z;
+          a[mt] = (valid && f < dw) ? f4_act(p.act[l], z) : f4_zero();
+        }
+      }
+      }
+      if (c0 == 0) EDGE_STAMP(3);
+      // ---- messages of the chunk -> LDS, then lane group g sums the messages of row g in edge order
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        *reinterpret_cast<float4 *>(&ldsMsg[(wave * 16 + ei) * kTS + 16 * mt + 4 * kq]) = a[mt];
+      __syncthreads();
+      if (c0 == 0) EDGE_STAMP(4);
+      {
+        const int lo = max(my_lo, c0), hi = min(my_hi, c0 + kChunk);
+        for (int kk = lo; kk < hi; ++kk) {
+          const float4 m = *reinterpret_cast<const float4 *>(&ldsMsg[(kk - c0) * kTS + 4 * q]);
+          if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(fmaxf(racc.x, m.x), fmaxf(racc.y, m.y), fmaxf(racc.z, m.z), fmaxf(racc.w, m.w));
+          else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(fminf(racc.x, m.x), fminf(racc.y, m.y), fminf(racc.z, m.z), fminf(racc.w, m.w));
+          else racc = f4_add(racc, m);
         }
       }
       __syncthreads();
+      if (c0 == 0) EDGE_STAMP(5);
     }
-    // ---- segmented reduction: lane group g sums the messages of row g that fall into this chunk, in edge order
-    {
-      const int lo = max(my_lo, c0), hi = min(my_hi, c0 + kChunk);
-      for (int k = lo; k < hi; ++k) {
-        const float4 m = *reinterpret_cast<const float4 *>(&ldsA[(k - c0) * kTS + 4 * q]);
-        if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(fmaxf(racc.x, m.x), fmaxf(racc.y, m.y), fmaxf(racc.z, m.z), fmaxf(racc.w, m.w));
-        else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(fminf(racc.x, m.x), fminf(racc.y, m.y), fminf(racc.z, m.z), fminf(racc.w, m.w));
-        else racc = f4_add(racc, m);
-      }
+    EDGE_STAMP(6);
+    if (has_next && !rows_fetched) fetch_rows(meta, rows);   // a tile without edges
+    if (sc.x >= 0 && 4 * q < last_w) {
+      const int deg = my_hi - my_lo;
+      if (p.aggr == NGPDE_AGGR_MEAN) racc = deg > 0 ? f4_scale(1.0f / (float)deg, racc) : f4_zero();
+      *reinterpret_cast<float4 *>(p.out + (size_t)sc.x * last_w + 4 * q) = racc;
     }
-    __syncthreads();
-  }
-  if (sc.x >= 0 && 4 * q < last_w) {
-    const int deg = my_hi - my_lo;
-    if (p.aggr == NGPDE_AGGR_MEAN) racc = deg > 0 ? f4_scale(1.0f / (float)deg, racc) : f4_zero();
-    *reinterpret_cast<float4 *>(p.out + (size_t)sc.x * last_w + 4 * q) = racc;
+    EDGE_STAMP(7);
   }
 }
 
@@ -275,16 +325,42 @@ int32_t launch_edge_mlp_fused_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hi
   }
   k.out = a.out;
   for (int l = 0; l < 4; ++l) k.save_z[l] = a.save_z[l];
-  const dim3 grid(k.n_tiles), block(kT);
+#ifdef NGPDE_STAMPS
+  k.stamps = g_edge_stamps;
+#endif
+  // LDS: the halo region is sized by the largest halo of this graph's tiles; persistent workgroups, a multiple of the 8 XCDs
+  k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kGroups * kTS + (size_t)a.n_tail * kW * kTS + (size_t)kChunk * kTS) * sizeof(float);
+  const int wgs_per_cu = (lds + 2048 <= 80 * 1024) ? 2 : 1;
+  const int per_xcd = std::max(1, std::min(32 * wgs_per_cu, (k.n_tiles + 7) / 8));
+  const dim3 grid(8 * per_xcd), block(kT);
+  auto launch = [&](auto kernel) -> hipError_t {
+    // more than 64 KB of dynamic LDS has to be requested explicitly
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, k);
+    return hipSuccess;
+  };
+  hipError_t le;
   switch (a.n_tail) {
-    case 0: hipLaunchKernelGGL(edge_mlp_fused_fwd_kernel<0>, grid, block, 0, stream, k); break;
-    case 1: hipLaunchKernelGGL(edge_mlp_fused_fwd_kernel<1>, grid, block, 0, stream, k); break;
-    case 2: hipLaunchKernelGGL(edge_mlp_fused_fwd_kernel<2>, grid, block, 0, stream, k); break;
-    default: hipLaunchKernelGGL(edge_mlp_fused_fwd_kernel<3>, grid, block, 0, stream, k); break;
+    case 0: le = launch(edge_mlp_fused_fwd_kernel<0>); break;
+    case 1: le = launch(edge_mlp_fused_fwd_kernel<1>); break;
+    case 2: le = launch(edge_mlp_fused_fwd_kernel<2>); break;
+    default: le = launch(edge_mlp_fused_fwd_kernel<3>); break;
   }
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp_fused_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
   NGPDE_LAUNCH_CHECK("edge_mlp_fused_fwd_kernel");
   return NGPDE_OK;
 }
+
+#ifdef NGPDE_STAMPS
+}  // namespace ngpde
+extern "C" int32_t ngpde_debug_set_edge_stamps(unsigned long long *buf) {
+  ngpde::g_edge_stamps = buf;
+  return 0;
+}
+namespace ngpde {
+#endif
 
 int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, hipStream_t stream) {
   if (count == 0) return NGPDE_OK;

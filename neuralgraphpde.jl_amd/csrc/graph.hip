@@ -423,6 +423,12 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   };
   g->by_t.halo_ok = all_fit(ht_);
   g->by_s.halo_ok = all_fit(hs_);
+  auto max_halo = [&](const HaloOut &o) {
+    int32_t mx = 0;
+    for (const int2 &i : o.info) mx = std::max(mx, i.x);
+    return mx;
+  };
+  const int32_t mh_t = max_halo(ht_), mh_s = max_halo(hs_);
   for (Csr *c2 : {&g->by_t, &g->by_s}) {
     if (c2->halo) { (void)hipFree(c2->halo); c2->halo = nullptr; }
     if (c2->tile_info) { (void)hipFree(c2->tile_info); c2->tile_info = nullptr; }
@@ -455,6 +461,8 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
     if ((st = upload(&g->by_s.slot_w, hs_.w.data(), hs_.w.size()))) return st;
   }
   if ((st = upload(&g->c, c.data(), (size_t)n))) return st;
+  g->by_t.max_halo = mh_t;
+  g->by_s.max_halo = mh_s;
   g->self_loops = add_self_loops ? 1 : 0;
   g->has_norm = true;
   return NGPDE_OK;

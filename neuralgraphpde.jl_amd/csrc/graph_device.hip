@@ -226,9 +226,12 @@ __global__ __launch_bounds__(256) void halo_kernel(int64_t n, const int32_t *__r
   if (tid == 0) info[tl] = make_int2(fits ? count : 0, 0);
 }
 
+// bad[0] |= a tile does not fit; bad[2] = max halo count
 __global__ void all_fit_kernel(int64_t n_tiles, const int2 *__restrict__ info, int32_t *__restrict__ bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_tiles && info[i].x == 0) atomicOr(bad, 1);
+  if (i >= n_tiles) return;
+  if (info[i].x == 0) atomicOr(bad, 1);
+  else atomicMax(bad + 2, info[i].x);
 }
 
 template <class T>
@@ -322,8 +325,8 @@ int32_t set_gcn_norm_device(ngpde_graph *g, int add_self_loops, const float *w_d
   const int64_t n_tiles = g->n_sched / kTileRows;
   int32_t *bad = nullptr;
   Scratch sc;
-  if ((st = sc.get(&bad, 2))) return st;
-  NGPDE_HIP_CHECK(hipMemsetAsync(bad, 0, 2 * sizeof(int32_t), stream));
+  if ((st = sc.get(&bad, 8))) return st;   // per direction: {not-fitting flag, -, max halo, -}
+  NGPDE_HIP_CHECK(hipMemsetAsync(bad, 0, 8 * sizeof(int32_t), stream));
   int dir = 0;
   for (Csr *c2 : {&g->by_t, &g->by_s}) {
     if ((st = dalloc(&c2->ent, (size_t)m)) || (st = dalloc(&c2->sched, (size_t)g->n_sched)) ||
@@ -342,16 +345,18 @@ int32_t set_gcn_norm_device(ngpde_graph *g, int add_self_loops, const float *w_d
       hipLaunchKernelGGL(halo_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, n, g->order, c2->rowptr, c2->col, c2->eid,
                          g->c, w_dev, c2->halo, c2->tile_info, c2->slots, c2->slot_w);
       NGPDE_LAUNCH_CHECK("halo_kernel");
-      hipLaunchKernelGGL(all_fit_kernel, dim3(blocks_for(n_tiles)), dim3(kB), 0, stream, n_tiles, c2->tile_info, bad + dir);
+      hipLaunchKernelGGL(all_fit_kernel, dim3(blocks_for(n_tiles)), dim3(kB), 0, stream, n_tiles, c2->tile_info, bad + 4 * dir);
       NGPDE_LAUNCH_CHECK("all_fit_kernel");
     }
     ++dir;
   }
-  int32_t h_bad[2] = {1, 1};
+  int32_t h_bad[8] = {1, 0, 0, 0, 1, 0, 0, 0};
   NGPDE_HIP_CHECK(hipMemcpyAsync(h_bad, bad, sizeof(h_bad), hipMemcpyDeviceToHost, stream));
   NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
   g->by_t.halo_ok = n_tiles > 0 && h_bad[0] == 0;
-  g->by_s.halo_ok = n_tiles > 0 && h_bad[1] == 0;
+  g->by_s.halo_ok = n_tiles > 0 && h_bad[4] == 0;
+  g->by_t.max_halo = h_bad[2];
+  g->by_s.max_halo = h_bad[6];
   g->self_loops = add_self_loops ? 1 : 0;
   g->has_norm = true;
   return NGPDE_OK;

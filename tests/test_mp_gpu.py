@@ -502,6 +502,41 @@ def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
         check_grads(ps, (n1 + n2, o1 + o2), xg, gr["x"])
 
 
+@pytest.mark.parametrize("widths,acts", [((32,), ("tanh",)), ((16, 24, 8), ("swish", "relu", "identity")),
+                                         ((60, 60, 60, 40), ("tanh", "tanh", "tanh", "identity"))])
+def test_fused_message_path_layer_counts_and_ragged_rows(widths, acts):
+    # 0, 2 and 3 Dense layers after the first (the last shape is the VMH tutorial's message MLP, VMH.md:75-83), rows of
+    # varying degree (0..9), a ragged last tile, per-edge features in the first layer -- fused kernel vs oracle, fwd + grads
+    from ngpde_amd import functional as F
+    n, h = 203, 6
+    rng = np.random.default_rng(31)
+    ss, tt = [], []
+    for i in range(n):
+        for off in rng.choice(np.arange(-5, 6), size=rng.integers(0, 10), replace=False):
+            if off != 0:
+                ss.append((i + off) % n); tt.append(i)
+    s, t = np.array(ss), np.array(tt)
+    nd = {"x": rng.random((2, n))}
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0, ndata=nd)
+    og = O.Graph(s, t, num_nodes=n, index_base=0, ndata=nd)
+    dims = [2 * h + 2] + list(widths)
+    phi = ng.Chain(*[ng.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(widths))]) if len(widths) > 1 \
+        else ng.Dense(dims[0], dims[1], acts[0])
+    assert F.edge_mlp_supported(g.handle((False, None, False)), widths[0], list(widths[1:]))
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr="mean")
+    ps, st = ng.setup(31, l)
+    ps = prep(ps, 31)
+    x = torch.randn(h, n, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, "mean")
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    check_grads(ps, (names, ogr), x, gr["x"])
+
+
 def test_fused_message_path_falls_back_when_unsupported():
     from ngpde_amd import functional as F
     g = ng.rand_graph(50, 200, seed=1)
