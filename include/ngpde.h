@@ -231,6 +231,18 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
                                const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,
                                const int32_t *tail_act, const float *const *tail_weight, const float *const *tail_bias,
                                int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream);
+/* Fused pullback of the same message path for 0 or 1 Dense layer after the first and + / mean aggregation: recomputes the
+ * per-edge activations inside the tile (nothing per-edge has to be saved by the forward), accumulates the tail layer's
+ * weight / bias gradient on MFMA in per-workgroup slabs, writes dz1 once ([E][h1], p order: de_term, required -- it is the
+ * gradient of the per-edge first-layer term and the input of the by-source sum that gives dq_source) and sums it per target
+ * into dp_target.  dout: [N][last width] gradient of the aggregated messages. */
+int32_t ngpde_edge_mlp_backward_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout, int32_t aggr);
+size_t ngpde_edge_mlp_backward_workspace_bytes(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout);
+int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target, const float *q_source,
+                                const float *e_term, int32_t n_tail, const int32_t *tail_dout, const int32_t *tail_act,
+                                const float *const *tail_weight, const float *const *tail_bias, int32_t aggr, const float *dout,
+                                float *dp_target, float *dq_source, float *de_term, float *const *dtail_weight,
+                                float *const *dtail_bias, void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
 /* a = act.(z) (re-materialises an activation from a saved pre-activation in the pullback of the fused path) */
 int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, float *a, ngpde_stream_t stream);
 

@@ -77,6 +77,10 @@ SIGNATURES = {
     "ngpde_gat_backward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_edge_mlp_supported": (_i32, [_vp, _i32, _i32, _vp]),
     "ngpde_edge_mlp_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ngpde_edge_mlp_backward_supported": (_i32, [_vp, _i32, _i32, _vp, _i32]),
+    "ngpde_edge_mlp_backward_workspace_bytes": (_sz, [_vp, _i32, _i32, _vp]),
+    "ngpde_edge_mlp_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _sz, _vp]),
     "ngpde_activation_forward": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "ngpde_spectral_weights": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "ngpde_node_gcn2_create": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, C.POINTER(_vp)]),

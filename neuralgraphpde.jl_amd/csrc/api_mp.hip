@@ -276,6 +276,39 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
   return launch_edge_mlp_fused_fwd(g, a, (hipStream_t)stream);
 }
 
+int32_t ngpde_edge_mlp_backward_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout, int32_t aggr) {
+  return edge_mlp_fused_bwd_supported(g, h1, n_tail, (n_tail == 1 && tail_dout) ? tail_dout[0] : 0, aggr) ? 1 : 0;
+}
+
+size_t ngpde_edge_mlp_backward_workspace_bytes(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout) {
+  if (!g) return 0;
+  return edge_mlp_fused_bwd_workspace(g, h1, n_tail, (n_tail == 1 && tail_dout) ? tail_dout[0] : 0);
+}
+
+int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target, const float *q_source,
+                                const float *e_term, int32_t n_tail, const int32_t *tail_dout, const int32_t *tail_act,
+                                const float *const *tail_weight, const float *const *tail_bias, int32_t aggr, const float *dout,
+                                float *dp_target, float *dq_source, float *de_term, float *const *dtail_weight,
+                                float *const *dtail_bias, void *workspace, size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: graph is NULL");
+  int32_t st = check_act("ngpde_edge_mlp_backward", act1);
+  if (st) return st;
+  NGPDE_REQUIRE(n_tail == 0 || (n_tail == 1 && tail_dout && tail_act && tail_weight && dtail_weight && tail_weight[0] && dtail_weight[0]),
+                NGPDE_ERR_UNSUPPORTED, "ngpde_edge_mlp_backward: 0 or 1 layer after the first (with its weight and gradient buffers)");
+  if (n_tail && (st = check_act("ngpde_edge_mlp_backward", tail_act[0]))) return st;
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(dout != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: dout is NULL");
+  EdgeMlpBwdArgs a;
+  a.h1 = h1; a.act1 = act1; a.aggr = aggr; a.n_tail = n_tail;
+  a.P = p_target; a.Q = q_source; a.Eterm = e_term; a.dout = dout;
+  if (n_tail) {
+    a.dw = tail_dout[0]; a.act2 = tail_act[0]; a.wt = tail_weight[0]; a.bias = tail_bias ? tail_bias[0] : nullptr;
+    a.dwt = dtail_weight[0]; a.dbias = dtail_bias ? dtail_bias[0] : nullptr;
+  }
+  a.dP = dp_target; a.dQ = dq_source; a.dE = de_term; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+  return launch_edge_mlp_fused_bwd(g, a, (hipStream_t)stream);
+}
+
 int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, float *a, ngpde_stream_t stream) {
   int32_t st = check_act("ngpde_activation_forward", act);
   if (st) return st;

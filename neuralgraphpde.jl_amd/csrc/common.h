@@ -223,6 +223,18 @@ struct EdgeMlpArgs {
   float *out = nullptr;
   float *save_z[4] = {nullptr, nullptr, nullptr, nullptr};
 };
+struct EdgeMlpBwdArgs {
+  int h1 = 0, act1 = 0, aggr = 0, n_tail = 0, dw = 0, act2 = 0;
+  const float *P = nullptr, *Q = nullptr, *Eterm = nullptr, *wt = nullptr, *bias = nullptr, *dout = nullptr;
+  float *dP = nullptr, *dQ = nullptr, *dE = nullptr, *dwt = nullptr, *dbias = nullptr;
+  void *workspace = nullptr;
+  size_t workspace_bytes = 0;
+};
+bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int dw, int aggr);
+size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw);
+int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream);
+int32_t launch_dense_weight_reduce(int nchunk, int din, int dout, const float *partial, float *dwt, float *db, hipStream_t stream);
+int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_edge, float *out, hipStream_t stream);
 bool edge_mlp_fused_supported(const ngpde_graph *g, const EdgeMlpArgs &a);
 int32_t launch_edge_mlp_fused_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
 int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, hipStream_t stream);

@@ -536,6 +536,13 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
 
 // row chunks of the weight pullback: enough (tile x chunk) workgroups to cover the chip several times over (the chunk
 // loop is a dependent global-load chain, ~16 rows per trip), at least 64 rows per chunk, at most 1024 partial slabs
+int32_t launch_dense_weight_reduce(int nchunk, int din, int dout, const float *partial, float *dwt, float *db, hipStream_t stream) {
+  const int total = (din + 1) * dout;
+  hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nchunk, din, dout, partial, dwt, db);
+  NGPDE_LAUNCH_CHECK("dense_weight_reduce_kernel");
+  return NGPDE_OK;
+}
+
 int dense_weight_chunks(int64_t n, int din, int dout) {
   const int64_t tiles = (int64_t)std::max(1, (din + BM - 1) / BM) * std::max(1, (dout + BN - 1) / BN);
   const int64_t want = (4096 + tiles - 1) / tiles;

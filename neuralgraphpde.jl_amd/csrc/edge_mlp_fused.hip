@@ -292,6 +292,310 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
   }
 }
 
+// ---- fused pullback of the message path (0 or 1 Dense layer after the first) -------------------------------------------------
+// Same tiling, staging and register layout as the forward kernel.  Per 16-edge wave slice, all in registers:
+//   z1 = P[t] + Q[s] + E, a1 = act1(z1)                         (recomputed: nothing per-edge was saved by the forward)
+//   z2^T = W2^T a1^T + b2            (MFMA, transposed product)   dz2 = g[t] * act2'(z2),  g = dout / deg (mean) or dout (+)
+//   da1^T = W2 dz2^T                 (MFMA, transposed product)   dz1 = da1 * act1'(z1)
+//   dW2 += a1^T dz2                  (MFMA over the wave's 16 edges; the two operands are transposed through a wave-private
+//                                     4 KB LDS tile; 16 accumulator tiles per wave live for the whole kernel)
+// dz1 goes to HBM once ([E][h1], p order: it is dE and the input of the by-source sum that gives dQ) and through LDS into
+// the in-tile segmented sum that gives dP.  At the end the 8 waves fold their dW2 / db2 accumulators into one slab per
+// workgroup in a fixed order; a reduce kernel sums the slabs.  No atomics.
+struct EdgeMlpBwdK {
+  const int4 *sched;
+  const int2 *halo;
+  const uint8_t *slots;
+  int n_tiles, h1, act1, aggr, halo_rows, n_tail, dw, act2;   // dw = width of the tail layer's output (NTAIL = 1)
+  const float *P, *Q, *Eterm, *wt, *bias, *dout;
+  float *dP, *dE, *partial;   // partial: [n_workgroups][(h1 + 1)][dw]  (row h1 = bias gradient)
+};
+
+template <int NTAIL>
+__global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlpBwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
+  float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]
+  float *ldsG = ldsP + kGroups * kTS;                             // [32][kTS]  incoming gradient rows (already / deg for mean)
+  float *ldsS = ldsG + kGroups * kTS;                             // [kChunk][kTS]  wave-private transposes, then dz1 of the chunk
+  float *ldsWf = ldsS + kChunk * kTS;                             // [64 out][kTS]  W2^T   (NTAIL = 1)
+  float *ldsWb = ldsWf + (NTAIL ? kW * kTS : 0);                  // [64 in][kTS]   W2
+  __shared__ int ldsOff[kGroups + 1], ldsRs[kGroups];
+  __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kGroups * 8];
+  __shared__ uint8_t ldsRowOf[kGroups * kSlotWidth];
+  __shared__ __attribute__((aligned(16))) float ldsBias[kW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = tid >> 4, q = tid & 15;
+  const int ei = lane & 15, kq = lane >> 4;
+  const int h1 = p.h1, zero_slot = p.halo_rows, dw = NTAIL ? p.dw : p.h1;
+
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const int range_len = p.n_tiles / 8 + (xcd < p.n_tiles % 8 ? 1 : 0);
+  const int range_lo = xcd * (p.n_tiles / 8) + min(xcd, p.n_tiles % 8);
+
+  auto fetch_meta = [&](int tile, TileMeta &m) {
+    m.sc = p.sched[(size_t)tile * kTileRows + grp];
+    m.s0 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2];
+    m.s1 = reinterpret_cast<const uint4 *>(p.slots)[((size_t)tile * kTileRows + grp) * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) m.he[k] = p.halo[(size_t)tile * kHaloCap + min(grp + k * kGroups, kHaloCap - 1)];
+  };
+
+  if (NTAIL) {
+    const int j = tid % kW, kg0 = tid / kW;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int k = 4 * (kg0 + 8 * ps);
+      float t[4], u[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t[r] = (k + r < h1 && j < dw) ? p.wt[(size_t)(k + r) * dw + j] : 0.f;        // W2^T row j (output), inputs k..k+3
+        u[r] = (j < h1 && k + r < dw) ? p.wt[(size_t)j * dw + k + r] : 0.f;          // W2 row j (input), outputs k..k+3
+      }
+      *reinterpret_cast<float4 *>(&ldsWf[j * kTS + k]) = make_float4(t[0], t[1], t[2], t[3]);
+      *reinterpret_cast<float4 *>(&ldsWb[j * kTS + k]) = make_float4(u[0], u[1], u[2], u[3]);
+    }
+    if (tid < kW) ldsBias[tid] = (p.bias && tid < dw) ? p.bias[tid] : 0.f;
+  }
+  if (grp == 0) *reinterpret_cast<float4 *>(&ldsQ[zero_slot * kTS + 4 * q]) = f4_zero();
+
+  // dW2 accumulators of this wave: tile (ct, mt) <-> rows 16 ct .. + 15 (inputs) x columns 16 mt .. + 15 (outputs)
+  f32x4 accW[NTAIL ? 4 : 1][NTAIL ? 4 : 1];
+  float4 dbacc[NTAIL ? 4 : 1];
+#pragma unroll
+  for (int a = 0; a < (NTAIL ? 4 : 1); ++a) {
+    dbacc[a] = f4_zero();
+#pragma unroll
+    for (int b = 0; b < (NTAIL ? 4 : 1); ++b) accW[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  TileMeta meta;
+  int jt = wg_in_xcd;
+  if (jt < range_len) fetch_meta(range_lo + jt, meta);
+
+  for (; jt < range_len; jt += wgs_per_xcd) {
+    const int4 sc = meta.sc;
+    // ---- stage the tile: Q halo rows, P rows, gradient rows (the loads of a tile are issued here; the next tile's metadata
+    // is prefetched below)
+    {
+      const int node = max(sc.x, 0);
+      const float4 prow = (p.P && 4 * q < h1) ? *reinterpret_cast<const float4 *>(p.P + (size_t)node * h1 + 4 * q) : f4_zero();
+      float4 hv[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        hv[k] = (p.Q && grp + k * kGroups < p.halo_rows && 4 * q < h1)
+                    ? *reinterpret_cast<const float4 *>(p.Q + (size_t)meta.he[k].x * h1 + 4 * q) : f4_zero();
+      float4 grow = (sc.x >= 0 && 4 * q < dw) ? *reinterpret_cast<const float4 *>(p.dout + (size_t)node * dw + 4 * q) : f4_zero();
+      if (p.aggr == NGPDE_AGGR_MEAN) grow = sc.z > 0 ? f4_scale(1.0f / (float)sc.z, grow) : f4_zero();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int hh = grp + k * kGroups;
+        if (hh < p.halo_rows) *reinterpret_cast<float4 *>(&ldsQ[hh * kTS + 4 * q]) = hv[k];
+      }
+      *reinterpret_cast<float4 *>(&ldsP[grp * kTS + 4 * q]) = prow;
+      *reinterpret_cast<float4 *>(&ldsG[grp * kTS + 4 * q]) = grow;
+    }
+    if (q == 0) {
+      ldsOff[grp + 1] = sc.x >= 0 ? sc.z : 0;
+      ldsRs[grp] = sc.y;
+      if (grp == 0) ldsOff[0] = 0;
+    }
+    if (q < 8) {
+      const unsigned w[8] = {meta.s0.x, meta.s0.y, meta.s0.z, meta.s0.w, meta.s1.x, meta.s1.y, meta.s1.z, meta.s1.w};
+      unsigned v = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v = (q == j) ? w[j] : v;
+      ldsSlots[grp * 8 + q] = v;
+    }
+    const int jn = jt + wgs_per_xcd;
+    if (jn < range_len) fetch_meta(range_lo + jn, meta);
+    __syncthreads();
+    if (tid < kGroups) {
+      int v = ldsOff[tid + 1];
+#pragma unroll
+      for (int o = 1; o < kGroups; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (tid >= o) v += u;
+      }
+      ldsOff[tid + 1] = v;
+    }
+    __syncthreads();
+    const int total = ldsOff[kGroups];
+    const int my_lo = ldsOff[grp], my_hi = ldsOff[grp + 1];
+    for (int k = my_lo + q; k < my_hi; k += 16) ldsRowOf[k] = (uint8_t)grp;
+    float4 racc = f4_zero();
+    __syncthreads();
+
+    for (int c0 = 0; c0 < total; c0 += kChunk) {
+      const bool wave_on = c0 + wave * 16 < total;   // wave-uniform
+      const int k = c0 + wave * 16 + ei;
+      const bool valid = k < total;
+      int r = 0, slot = zero_slot;
+      size_t pe = 0;
+      if (valid) {
+        r = ldsRowOf[k];
+        const int j = k - ldsOff[r];
+        slot = (ldsSlots[r * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff;
+        pe = (size_t)(ldsRs[r] + j);
+      }
+      float *mine = ldsS + (size_t)(wave * 16) * kTS;          // this wave's 16 rows of the staging tile
+      float4 dz1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+      if (wave_on) {
+        float4 z1[4], a1[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int f = 16 * ct + 4 * kq;
+          float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
+          if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
+          z1[ct] = z;
+          a1[ct] = (valid && f < h1) ? f4_act(p.act1, z) : f4_zero();
+        }
+        float4 gz[4];                                          // NTAIL = 0: g itself; NTAIL = 1: dz2 = g * act2'(z2)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int f = 16 * mt + 4 * kq;
+          gz[mt] = (valid && f < dw) ? *reinterpret_cast<const float4 *>(&ldsG[r * kTS + f]) : f4_zero();
+        }
+        if (NTAIL) {
+          const int n_ct = (h1 + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
+          // ---- z2 (transposed product), dz2
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            if (mt < n_mt) {
+              f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+              const float *wl = ldsWf + (mt * 16 + ei) * kTS + 4 * kq;
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) {
+                if (ct < n_ct) {
+                  const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * ct);
+                  acc = mfma16(w4.x, a1[ct].x, acc);
+                  acc = mfma16(w4.y, a1[ct].y, acc);
+                  acc = mfma16(w4.z, a1[ct].z, acc);
+                  acc = mfma16(w4.w, a1[ct].w, acc);
+                }
+              }
+              const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
+              const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+              gz[mt] = f4_mul(gz[mt], f4_dact(p.act2, z2));      // g is zero for invalid edges / padded features
+              dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
+            }
+          }
+          // ---- dW2 += a1^T dz2 over this wave's 16 edges: both operands transposed through the wave's LDS rows
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * ct + 4 * kq]) = a1[ct];
+          float a1T[4][4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) a1T[ct][sI] = mine[(4 * sI + kq) * kTS + 16 * ct + ei];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * mt + 4 * kq]) = gz[mt];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            if (mt < n_mt) {
+              float dzT[4];
+#pragma unroll
+              for (int sI = 0; sI < 4; ++sI) dzT[sI] = mine[(4 * sI + kq) * kTS + 16 * mt + ei];
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) {
+                if (ct < n_ct) {
+#pragma unroll
+                  for (int sI = 0; sI < 4; ++sI) accW[ct][mt] = mfma16(a1T[ct][sI], dzT[sI], accW[ct][mt]);
+                }
+              }
+            }
+          }
+          // ---- da1 (transposed product with W2), dz1
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            if (ct < n_ct) {
+              f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+              const float *wl = ldsWb + (ct * 16 + ei) * kTS + 4 * kq;
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) {
+                if (mt < n_mt) {
+                  const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * mt);
+                  acc = mfma16(w4.x, gz[mt].x, acc);
+                  acc = mfma16(w4.y, gz[mt].y, acc);
+                  acc = mfma16(w4.z, gz[mt].z, acc);
+                  acc = mfma16(w4.w, gz[mt].w, acc);
+                }
+              }
+              dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), f4_dact(p.act1, z1[ct]));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) dz1[ct] = f4_mul(gz[ct], f4_dact(p.act1, z1[ct]));
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int f = 16 * ct + 4 * kq;
+          if (!(valid && f < h1)) dz1[ct] = f4_zero();
+          else if (p.dE) *reinterpret_cast<float4 *>(p.dE + pe * h1 + f) = dz1[ct];
+        }
+      }
+      // ---- dz1 of the chunk -> LDS, lane group g sums the rows of target g in edge order (= dP)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * ct + 4 * kq]) = dz1[ct];
+      __syncthreads();
+      {
+        const int lo = max(my_lo, c0), hi = min(my_hi, c0 + kChunk);
+        for (int kk = lo; kk < hi; ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(&ldsS[(kk - c0) * kTS + 4 * q]));
+      }
+      __syncthreads();
+    }
+    if (p.dP && sc.x >= 0 && 4 * q < h1) *reinterpret_cast<float4 *>(p.dP + (size_t)sc.x * h1 + 4 * q) = racc;
+  }
+
+  // ---- fold the waves' dW2 / db2 accumulators into this workgroup's slab, wave by wave (fixed order), then write it out
+  if (NTAIL) {
+    float *slab = ldsS;                                            // [(h1 + 1)][dw], needs 65 * 64 floats <= kChunk * kTS
+    __syncthreads();
+    for (int idx = tid; idx < (h1 + 1) * dw; idx += kT) slab[idx] = 0.f;
+    // db: sum the 16 edge lanes of each k-quarter inside the wave first
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float v[4] = {dbacc[mt].x, dbacc[mt].y, dbacc[mt].z, dbacc[mt].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v[c] += __shfl_xor(v[c], o);
+      }
+      dbacc[mt] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    for (int w = 0; w < kT / 64; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kin = 16 * ct + 4 * kq + r, o = 16 * mt + ei;
+              if (kin < h1 && o < dw) slab[kin * dw + o] += accW[ct][mt][r];
+            }
+        if (ei == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int o = 16 * mt + 4 * kq;
+            if (o < dw) {
+              slab[h1 * dw + o] += dbacc[mt].x; slab[h1 * dw + o + 1] += dbacc[mt].y;
+              slab[h1 * dw + o + 2] += dbacc[mt].z; slab[h1 * dw + o + 3] += dbacc[mt].w;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float *dst = p.partial + (size_t)blockIdx.x * (h1 + 1) * dw;
+    for (int idx = tid; idx < (h1 + 1) * dw; idx += kT) dst[idx] = slab[idx];
+  }
+}
+
 __global__ void activation_fwd_kernel(int64_t count, int act, const float *__restrict__ z, float *__restrict__ a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     a[i] = act_apply(act, z[i]);
@@ -361,6 +665,56 @@ extern "C" int32_t ngpde_debug_set_edge_stamps(unsigned long long *buf) {
 }
 namespace ngpde {
 #endif
+
+static int edge_bwd_grid(const ngpde_graph *g) {
+  const int n_tiles = (int)(g->n_sched / kTileRows);
+  return 8 * std::max(1, std::min(32, (n_tiles + 7) / 8));   // one persistent workgroup per CU, a multiple of the 8 XCDs
+}
+
+bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int dw, int aggr) {
+  if (!g || !g->has_norm || !g->by_t.halo_ok) return false;
+  if (h1 <= 0 || h1 > kW || h1 % 4) return false;
+  if (n_tail < 0 || n_tail > 1) return false;                 // deeper message MLPs take the primitives' pullback
+  if (n_tail == 1 && (dw <= 0 || dw > kW || dw % 4)) return false;
+  return aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN;
+}
+
+size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw) {
+  return n_tail ? (size_t)edge_bwd_grid(g) * (h1 + 1) * dw * sizeof(float) + 256 : 256;
+}
+
+int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
+  NGPDE_REQUIRE(edge_mlp_fused_bwd_supported(g, a.h1, a.n_tail, a.dw, a.aggr), NGPDE_ERR_UNSUPPORTED,
+                "fused edge-MLP pullback needs widths <= 64 and multiples of 4, at most one layer after the first, + or mean "
+                "aggregation and a graph whose tiles fit the LDS halo");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  const size_t need = edge_mlp_fused_bwd_workspace(g, a.h1, a.n_tail, a.dw);
+  NGPDE_REQUIRE(a.workspace && a.workspace_bytes >= need, NGPDE_ERR_WORKSPACE, "fused edge-MLP pullback: workspace too small (%zu < %zu bytes)",
+                a.workspace_bytes, need);
+  NGPDE_REQUIRE(a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
+  EdgeMlpBwdK k;
+  k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
+  k.n_tiles = (int)(g->n_sched / kTileRows); k.h1 = a.h1; k.act1 = a.act1; k.aggr = a.aggr; k.n_tail = a.n_tail;
+  k.dw = a.n_tail ? a.dw : a.h1; k.act2 = a.act2;
+  k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
+  k.P = a.P; k.Q = a.Q; k.Eterm = a.Eterm; k.wt = a.wt; k.bias = a.bias; k.dout = a.dout;
+  k.dP = a.dP; k.dE = a.dE; k.partial = (float *)a.workspace;
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + 2 * (size_t)kGroups * kTS + (size_t)kChunk * kTS + (a.n_tail ? 2 * (size_t)kW * kTS : 0)) * sizeof(float);
+  const dim3 grid(edge_bwd_grid(g)), block(kT);
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, k);
+    return hipSuccess;
+  };
+  const hipError_t le = a.n_tail ? launch(edge_mlp_fused_bwd_kernel<1>) : launch(edge_mlp_fused_bwd_kernel<0>);
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp_fused_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
+  NGPDE_LAUNCH_CHECK("edge_mlp_fused_bwd_kernel");
+  int32_t st;
+  if (a.n_tail && (st = launch_dense_weight_reduce((int)grid.x, a.h1, a.dw, k.partial, a.dwt, a.dbias, stream))) return st;
+  if (a.dQ && (st = launch_edge_sum_by_source(g, a.h1, a.dE, a.dQ, stream))) return st;
+  return NGPDE_OK;
+}
 
 int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, hipStream_t stream) {
   if (count == 0) return NGPDE_OK;

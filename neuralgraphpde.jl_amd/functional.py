@@ -4,6 +4,8 @@ row-major float32 on the GPU (= a Julia (D x N) matrix), weights [in][out] (= Ju
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -398,7 +400,10 @@ class _EdgeMlpFusedFn(torch.autograd.Function):
         douts = [w.shape[1] for w in wts]
         need = any(ctx.needs_input_grad)
         widths = [h1] + douts
-        saves = [torch.empty((n_edges, w), dtype=torch.float32, device=dev) if need else None for w in widths]
+        # fused pullback available: it recomputes the per-edge activations, so the forward saves nothing per edge
+        fused_bwd = need and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(lib.ngpde_edge_mlp_backward_supported(
+            handle.ptr, h1, n_tail, _int_array(douts) if n_tail else None, aggr))
+        saves = [torch.empty((n_edges, w), dtype=torch.float32, device=dev) if (need and not fused_bwd) else None for w in widths]
         out = torch.empty((n_nodes, widths[-1]), dtype=torch.float32, device=dev)
         _lib.check(lib.ngpde_edge_mlp_forward(handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,
                                               _int_array(douts) if n_tail else None, _int_array(acts) if n_tail else None,
@@ -407,7 +412,12 @@ class _EdgeMlpFusedFn(torch.autograd.Function):
         ctx.handle, ctx.meta = handle, (act1, aggr, n_nodes, n_edges, tuple(acts), h1, tuple(douts))
         ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None,
                       [b is not None for b in bs])
-        ctx.save_for_backward(*wts, *[s for s in saves if s is not None])
+        ctx.fused_bwd = fused_bwd
+        if fused_bwd:
+            ctx.present = (P is not None, Q is not None, Eterm is not None)
+            ctx.save_for_backward(*wts, *[b for b in bs if b is not None], *[t for t in (P, Q, Eterm) if t is not None])
+        else:
+            ctx.save_for_backward(*wts, *[s for s in saves if s is not None])
         return out
 
     @staticmethod
@@ -415,6 +425,8 @@ class _EdgeMlpFusedFn(torch.autograd.Function):
         lib = _lib.load()
         act1, aggr, n_nodes, n_edges, acts, h1, douts = ctx.meta
         n_tail = len(douts)
+        if ctx.fused_bwd:
+            return _EdgeMlpFusedFn._fused_backward(ctx, dout)
         saved = ctx.saved_tensors
         wts, zs = saved[:n_tail], saved[n_tail:]
         pshape, qshape, has_e, has_b = ctx.shapes
@@ -445,6 +457,46 @@ class _EdgeMlpFusedFn(torch.autograd.Function):
         _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, h1, act1, _lib.ptr(dM), _lib.ptr(zs[0]), _lib.ptr(dz),
                                                    _lib.ptr(dP), _lib.ptr(dQ), stream))
         return (dP, dQ, dz if has_e else None, None, None, None, None, None, None, *grads_wb)
+
+
+def _edge_mlp_fused_backward(ctx, dout):
+    """ngpde_edge_mlp_backward: one fused launch (+ slab reduce + by-source sum)"""
+    lib = _lib.load()
+    act1, aggr, n_nodes, n_edges, acts, h1, douts = ctx.meta
+    n_tail = len(douts)
+    pshape, qshape, has_e, has_b = ctx.shapes
+    saved = list(ctx.saved_tensors)
+    wts = saved[:n_tail]
+    nb = sum(has_b)
+    bs_present = saved[n_tail:n_tail + nb]
+    bs, it = [], iter(bs_present)
+    for hb in has_b:
+        bs.append(next(it) if hb else None)
+    rest = iter(saved[n_tail + nb:])
+    P = next(rest) if ctx.present[0] else None
+    Q = next(rest) if ctx.present[1] else None
+    Eterm = next(rest) if ctx.present[2] else None
+    dev = dout.device
+    dout = dout.contiguous()
+    dP = torch.empty(pshape, dtype=torch.float32, device=dev) if pshape is not None else None
+    dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if qshape is not None else None
+    dE = torch.empty((n_edges, h1), dtype=torch.float32, device=dev)
+    dwts = [torch.empty_like(w) for w in wts]
+    dbs = [torch.empty((douts[l],), dtype=torch.float32, device=dev) if has_b[l] else None for l in range(n_tail)]
+    ws = _ws(lib.ngpde_edge_mlp_backward_workspace_bytes(ctx.handle.ptr, h1, n_tail, _int_array(list(douts)) if n_tail else None), dev)
+    _lib.check(lib.ngpde_edge_mlp_backward(ctx.handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,
+                                           _int_array(list(douts)) if n_tail else None, _int_array(list(acts)) if n_tail else None,
+                                           _ptr_array(wts) if n_tail else None, _ptr_array(bs) if n_tail else None, aggr,
+                                           _lib.ptr(dout), _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dE),
+                                           _ptr_array(dwts) if n_tail else None, _ptr_array(dbs) if n_tail else None,
+                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    grads_wb = []
+    for l in range(n_tail):
+        grads_wb += [dwts[l], dbs[l]]
+    return (dP, dQ, dE if has_e else None, None, None, None, None, None, None, *grads_wb)
+
+
+_EdgeMlpFusedFn._fused_backward = staticmethod(_edge_mlp_fused_backward)
 
 
 def edge_mlp_supported(handle, h1, tail_douts):
