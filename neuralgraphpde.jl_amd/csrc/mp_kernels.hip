@@ -103,7 +103,16 @@ __global__ __launch_bounds__(256) void edge_sum_by_source_kernel(int n_nodes, in
   const int rs = rowptr_s[row], re = rowptr_s[row + 1];
   for (int f = lane; f < h; f += 64) {
     float s = 0.f;
-    for (int q = rs; q < re; ++q) s += dz[(size_t)xpos[q] * h + f];
+    for (int q0 = rs; q0 < re; q0 += 8) {   // 8 independent row reads in flight, summed in list order
+      int pp[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pp[u] = (q0 + u < re) ? xpos[q0 + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (pp[u] >= 0) ? dz[(size_t)pp[u] * h + f] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
     dQ[(size_t)row * h + f] = s;
   }
 }
