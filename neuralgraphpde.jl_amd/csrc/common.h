@@ -17,6 +17,14 @@ namespace ngpde {
 std::string &last_error();
 int32_t fail(int32_t code, const char *fmt, ...);
 
+// after a kernel launch inside a function that returns an ngpde status
+#define NGPDE_LAUNCH_CHECK(name)                                                                    \
+  do {                                                                                              \
+    hipError_t _le = hipGetLastError();                                                             \
+    if (_le != hipSuccess)                                                                          \
+      return ::ngpde::fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_le));    \
+  } while (0)
+
 #define NGPDE_HIP_CHECK(expr)                                                                     \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \

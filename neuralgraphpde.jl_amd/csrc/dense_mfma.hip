@@ -14,12 +14,6 @@ namespace ngpde {
 
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 constexpr int BM = 64, BN = 64, BK = 16, LS = BK + 4;   // LDS row stride 20 floats: 16-byte aligned b128 rows
 
 // rows are < 2^31 (host-checked), so the per-graph row division is a 32-bit one and only taken when a block asks for it

@@ -18,12 +18,6 @@ namespace ngpde {
 
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 constexpr int kT = 512, kW = 64, kTS = kW + 4, kChunk = 128, kGroups = 32;   // kChunk = 8 waves x 16 edges
 
 #ifdef NGPDE_STAMPS

@@ -738,12 +738,6 @@ CombDev to_dev(const Comb &c) {
   return d;
 }
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 // NGPDE_NO_HALO=1 forces the per-row global gather (A/B measurements and tests of the fallback path)
 inline bool no_halo_env() {
   static const bool v = [] { const char *e = std::getenv("NGPDE_NO_HALO"); return e && e[0] == '1'; }();

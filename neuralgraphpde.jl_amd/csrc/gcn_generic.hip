@@ -11,12 +11,6 @@ namespace ngpde {
 
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 // ---------------------------------------------------------------------------------------------------
 // generic kernels (any feature width)
 // ---------------------------------------------------------------------------------------------------

@@ -26,12 +26,6 @@ std::vector<int32_t> locality_order_host(int64_t n, const std::vector<int32_t> &
 
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 constexpr int kB = 256;
 inline unsigned blocks_for(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + kB - 1) / kB); }
 

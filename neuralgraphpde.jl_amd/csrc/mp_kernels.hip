@@ -21,12 +21,6 @@ namespace ngpde {
 
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 // ---- concat-free dense:  y = act([X1 | X2 | ...] Wt + b) ------------------------------------------------
 // The reference builds vcat(...) temporaries ((sum D) x E, 1.66 GB per GPU shard at C4); here the blocks are
 // read in place.  A block with row_div > 1 is a per-graph feature: row r reads row r / row_div

@@ -7,12 +7,6 @@
 namespace ngpde {
 namespace {
 
-#define NGPDE_LAUNCH_CHECK(name)                                                         \
-  do {                                                                                   \
-    hipError_t _e = hipGetLastError();                                                   \
-    if (_e != hipSuccess) return fail(NGPDE_ERR_HIP, "%s launch failed: %s", name, hipGetErrorString(_e)); \
-  } while (0)
-
 // [UPSTREAM Optimisers.jl Adam]: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 //                               x -= eta * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
 __global__ void adam_kernel(int64_t n, float *__restrict__ x, const float *__restrict__ g, float *__restrict__ m,

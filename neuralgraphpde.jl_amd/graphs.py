@@ -183,10 +183,10 @@ class GNNGraph:
     def handle(self, norm=None):
         """ngpde_graph_t for this structure; `norm` = (add_self_loops, edge_weight or None,
         weighted_degree) selects a handle carrying that GCN normalisation."""
-        key = None
-        if norm is not None:
-            w = norm[1]
-            key = (bool(norm[0]), None if w is None else id(w), bool(norm[2]))
+        if norm is None:
+            norm = (False, None, False)   # the plain handle carries the tile schedule too (the fused edge kernels walk it)
+        w = norm[1]
+        key = (bool(norm[0]), None if w is None else id(w), bool(norm[2]))
         h = self._handles.get(key)
         if h is None:
             h = _Handle(self, norm)

@@ -12,6 +12,8 @@ slicing (tiny (out x in) matrices) is done with torch views so autograd reassemb
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -54,7 +56,6 @@ def _message_path(g, P, Q, Et, stack, aggr):
     needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
     aggr_code = _lib.AGGR[aggr]
-    import os
     if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or not needs_grad):
         fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
         if F.edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
@@ -282,7 +283,6 @@ class GNOConv(AbstractGNNContainerLayer):
         z = F.edge_combine(P, Q, Et, handle, l1.act, E)
         last, plast = stack[-1]
         kdim = _wt_b(plast)[0].shape[0]
-        import os
         if (len(stack) >= 2 and last.act == 0 and os.environ.get("NGPDE_GNO_MATERIALIZE") != "1"
                 and F.gno_apply_supported(self.out_chs, kdim)):
             # reassociated: K_e h_j = T_j z_e + B2 h_j with T_j = W2 (x) h_j at node level; K is never formed
