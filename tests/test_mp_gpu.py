@@ -454,6 +454,43 @@ def test_segment_reduce_edge_cases():
     assert torch.equal(F.edge_permute(Mp, h, inverse=True), M)
 
 
+def test_gat_as_ode_right_hand_side_generic_solver_path():
+    # BASELINE config 3 "as ODE RHS": du/dt = GATConv(64 => 4 x 16, concat)(u), stepped by NeuralODE's generic path (explicit
+    # RK through the layer's kernels, gradients by autograd through every stage) against rk_solve / rk_adjoint of the oracle
+    N, E, H, C = 300, 2400, 4, 16
+    rng = np.random.default_rng(17)
+    g, og = rgraph(N, E, 17)
+    l = ng.GATConv((H * C, C), "tanh", heads=H, concat=True, initialgraph=g)
+    node = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05)
+    ps, st = ng.setup(17, node)
+    ps = prep(ps, 17)
+    u0 = torch.randn(H * C, N, device=DEV, requires_grad=True)
+    uT, _ = node(u0, ps, st)
+    pw = lambda k: ps[k].detach().cpu().double().numpy()
+    W, a, b = pw("weight"), pw("a"), pw("bias")
+
+    def rhs(u):
+        return O.gat_conv(u, W, a, b, og, H, C, "tanh", concat=True)
+
+    acc = dict(weight=np.zeros_like(W), a=np.zeros_like(a), bias=np.zeros_like(b))
+
+    def vjp(cache, kbar):
+        gr = O.gat_conv_backward(cache, kbar)
+        return gr["x"], gr
+
+    def accumulate(gr):
+        for k in acc:
+            acc[k] += np.asarray(gr[k]).reshape(acc[k].shape)
+
+    uTo, tape = O.rk_solve(rhs, u0.detach().cpu().double().numpy(), O.TABLEAUS["tsit5"], 0.05, 2)
+    close(uT, uTo, rtol=2e-4)
+    du0 = O.rk_adjoint(vjp, tape, np.ones_like(uTo), O.TABLEAUS["tsit5"], 0.05, accumulate)
+    uT.sum().backward()
+    close(u0.grad, du0, rtol=5e-4, atol=1e-4)
+    for k in acc:
+        close(ps[k].grad, acc[k], rtol=5e-4, atol=5e-4, what=k)
+
+
 # ---- fused message path (one launch) against the primitives and the oracle -------------------------------------------------
 
 @pytest.mark.parametrize("aggr", ["mean", "+", "max", "min"])
