@@ -574,6 +574,63 @@ def test_fused_message_path_layer_counts_and_ragged_rows(widths, acts):
     check_grads(ps, (names, ogr), x, gr["x"])
 
 
+@pytest.mark.parametrize("phi_widths", [(8,), (12, 8)])
+def test_fused_paths_with_edge_features_and_fused_pullback(phi_widths, monkeypatch):
+    # MPPDEConv with per-edge features (the E term of the split first layer) and a per-graph theta on a local graph whose
+    # tiles fit the LDS halo: fused forward AND fused pullback (0 / 1 layer after the first) against the oracle, and the
+    # fused pullback against the primitives' pullback
+    n, G, h = 96, 2, 8
+    rng = np.random.default_rng(41)
+    idx = np.arange(n)
+    offs = (-4, -2, -1, 1, 3)
+    s1 = np.concatenate([idx for k in offs]); t1 = np.concatenate([(idx + k) % n for k in offs])
+    gs, ogs = [], []
+    for _ in range(G):
+        nd = {"u": rng.random((1, n)), "x": rng.random((1, n))}
+        ed = {"e": rng.random((2, s1.size))}
+        gd = {"θ": rng.random(2)}
+        gs.append(ng.GNNGraph(s1, t1, num_nodes=n, index_base=0, ndata=nd, edata=ed, gdata=gd))
+        ogs.append(O.Graph(s1, t1, num_nodes=n, index_base=0, ndata=nd, edata=ed, gdata=gd))
+    g, og = ng.batch(gs), O.batch(ogs)
+    dims = [2 * h + 2 + 2 + 2] + list(phi_widths)
+    acts = ["swish"] * len(phi_widths)
+    phi = ng.Chain(*[ng.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(phi_widths))]) if len(phi_widths) > 1 \
+        else ng.Dense(dims[0], dims[1], acts[0])
+    psi = ng.Dense(h + phi_widths[-1] + 2, h, "tanh")
+    l = ng.MPPDEConv(phi, psi, initialgraph=g, aggr="mean")
+    ps, st = ng.setup(41, l)
+    ps = prep(ps, 41)
+    from ngpde_amd import functional as F
+    assert F.edge_mlp_supported(g.handle(), phi_widths[0], list(phi_widths[1:]))
+    R = rng.normal(size=(h, n * G))
+    Rt = torch.as_tensor(R, dtype=torch.float32, device=DEV)
+
+    def run():
+        for v in [t for _, t in leaves(ps)]:
+            v.grad = None
+        x = xin.clone().requires_grad_(True)
+        y, _ = l(x, ps, st)
+        (y * Rt).sum().backward()
+        return y.detach(), x.grad.clone(), {k: t.grad.clone() for k, t in leaves(ps)}
+
+    xin = torch.randn(h, n * G, device=DEV)
+    y, dx, gp = run()
+    yo, c = O.mppde_conv(xin.cpu().double().numpy(), omlp(phi, ps["ϕ"]), omlp(psi, ps["ψ"]), og, "mean")
+    close(y, yo)
+    gr = O.mppde_conv_backward(c, R)
+    close(dx, gr["x"], rtol=5e-4, atol=1e-4)
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+    n2, o2 = mlp_grad_pairs(ps["ψ"], gr["psi"], psi)
+    for (name, p), ogv in zip(n1 + n2, o1 + o2):
+        close(p.grad, ogv, rtol=5e-4, atol=2e-4, what=name)
+    monkeypatch.setenv("NGPDE_NO_FUSED_EDGE_BWD", "1")
+    y2, dx2, gp2 = run()
+    assert torch.equal(y, y2)
+    close(dx, dx2.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    for k in gp:
+        close(gp[k], gp2[k].cpu().double().numpy(), rtol=5e-5, atol=5e-6, what=k)
+
+
 def test_fused_message_path_falls_back_when_unsupported():
     from ngpde_amd import functional as F
     g = ng.rand_graph(50, 200, seed=1)
