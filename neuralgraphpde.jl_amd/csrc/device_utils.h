@@ -64,11 +64,55 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 v, float4 c) {
 __device__ __forceinline__ float4 f4_scale(float a, float4 v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// vector forms: ONE uniform switch per call (a switch per element costs a scalar branch chain per element, which -- not the
+// transcendentals -- dominated the VALU-side time of the fused edge kernels)
+template <int ACT>
+__device__ __forceinline__ float act_c(float z) { return act_apply(ACT, z); }   // ACT constant: the switch folds away
+template <int ACT>
+__device__ __forceinline__ float dact_c(float z) { return act_deriv(ACT, z); }
+
+#define NGPDE_ACT_DISPATCH(act, F, ...)                              \
+  switch (act) {                                                     \
+    case NGPDE_ACT_RELU: F<NGPDE_ACT_RELU>(__VA_ARGS__); break;       \
+    case NGPDE_ACT_TANH: F<NGPDE_ACT_TANH>(__VA_ARGS__); break;       \
+    case NGPDE_ACT_SIGMOID: F<NGPDE_ACT_SIGMOID>(__VA_ARGS__); break; \
+    case NGPDE_ACT_SWISH: F<NGPDE_ACT_SWISH>(__VA_ARGS__); break;     \
+    case NGPDE_ACT_GELU: F<NGPDE_ACT_GELU>(__VA_ARGS__); break;       \
+    case NGPDE_ACT_LEAKYRELU: F<NGPDE_ACT_LEAKYRELU>(__VA_ARGS__); break; \
+    case NGPDE_ACT_ELU: F<NGPDE_ACT_ELU>(__VA_ARGS__); break;         \
+    case NGPDE_ACT_SOFTPLUS: F<NGPDE_ACT_SOFTPLUS>(__VA_ARGS__); break; \
+    default: F<NGPDE_ACT_IDENTITY>(__VA_ARGS__); break;               \
+  }
+
+template <int ACT, int N>
+__device__ __forceinline__ void act_n(float4 (&z)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) z[i] = make_float4(act_c<ACT>(z[i].x), act_c<ACT>(z[i].y), act_c<ACT>(z[i].z), act_c<ACT>(z[i].w));
+}
+template <int ACT, int N>
+__device__ __forceinline__ void dact_n(float4 (&z)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) z[i] = make_float4(dact_c<ACT>(z[i].x), dact_c<ACT>(z[i].y), dact_c<ACT>(z[i].z), dact_c<ACT>(z[i].w));
+}
+// z[i] <- act(z[i]) / act'(z[i]) for N float4, one uniform switch
+template <int N>
+__device__ __forceinline__ void f4n_act(int act, float4 (&z)[N]) {
+  NGPDE_ACT_DISPATCH(act, act_n, z)
+}
+template <int N>
+__device__ __forceinline__ void f4n_dact(int act, float4 (&z)[N]) {
+  NGPDE_ACT_DISPATCH(act, dact_n, z)
+}
+
 __device__ __forceinline__ float4 f4_act(int act, float4 z) {
-  return make_float4(act_apply(act, z.x), act_apply(act, z.y), act_apply(act, z.z), act_apply(act, z.w));
+  float4 v[1] = {z};
+  f4n_act<1>(act, v);
+  return v[0];
 }
 __device__ __forceinline__ float4 f4_dact(int act, float4 z) {
-  return make_float4(act_deriv(act, z.x), act_deriv(act, z.y), act_deriv(act, z.z), act_deriv(act, z.w));
+  float4 v[1] = {z};
+  f4n_dact<1>(act, v);
+  return v[0];
 }
 
 // ---- CSR segmented aggregation of whole feature rows --------------------------------------------

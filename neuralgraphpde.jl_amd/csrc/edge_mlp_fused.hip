@@ -214,8 +214,12 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
         float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
         if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
         if (p.save_z[0] && valid && f < h1) *reinterpret_cast<float4 *>(p.save_z[0] + pe * h1 + f) = z;
-        a[ct] = (valid && f < h1) ? f4_act(p.act1, z) : f4_zero();
+        a[ct] = z;
       }
+      f4n_act<4>(p.act1, a);                           // one uniform activation switch for the 16 values
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (!(valid && 16 * ct + 4 * kq < h1)) a[ct] = f4_zero();
       }
       if (c0 == 0) EDGE_STAMP(2);
       if (has_next && !rows_fetched) {   // the next tile's rows: in flight across this tile's MFMAs
@@ -252,8 +256,12 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
           const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[l * kW + f]);
           const float4 z = make_float4(acc[mt][0] + b4.x, acc[mt][1] + b4.y, acc[mt][2] + b4.z, acc[mt][3] + b4.w);
           if (p.save_z[l + 1] && valid && f < dw) *reinterpret_cast<float4 *>(p.save_z[l + 1] + pe * dw + f) = z;
-          a[mt] = (valid && f < dw) ? f4_act(p.act[l], z) : f4_zero();
+          a[mt] = z;
         }
+        f4n_act<4>(p.act[l], a);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          if (!(valid && 16 * mt + 4 * kq < dw)) a[mt] = f4_zero();
       }
       }
       if (c0 == 0) EDGE_STAMP(3);
@@ -444,8 +452,13 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
           float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
           if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
           z1[ct] = z;
-          a1[ct] = (valid && f < h1) ? f4_act(p.act1, z) : f4_zero();
+          a1[ct] = z;
         }
+        f4n_act<4>(p.act1, a1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (!(valid && 16 * ct + 4 * kq < h1)) a1[ct] = f4_zero();
+        f4n_dact<4>(p.act1, z1);                       // z1 <- act1'(z1): only the derivative is needed from here on
         float4 gz[4];                                          // NTAIL = 0: g itself; NTAIL = 1: dz2 = g * act2'(z2)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -455,6 +468,7 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
         if (NTAIL) {
           const int n_ct = (h1 + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
           // ---- z2 (transposed product), dz2
+          float4 z2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             if (mt < n_mt) {
@@ -471,10 +485,14 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
                 }
               }
               const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
-              const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
-              gz[mt] = f4_mul(gz[mt], f4_dact(p.act2, z2));      // g is zero for invalid edges / padded features
-              dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
+              z2[mt] = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
             }
+          }
+          f4n_dact<4>(p.act2, z2);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            gz[mt] = f4_mul(gz[mt], z2[mt]);                  // g is zero for invalid edges / padded features
+            dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
           }
           // ---- dW2 += a1^T dz2 over this wave's 16 edges: both operands transposed through the wave's LDS rows
 #pragma unroll
@@ -517,12 +535,12 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
                   acc = mfma16(w4.w, gz[mt].w, acc);
                 }
               }
-              dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), f4_dact(p.act1, z1[ct]));
+              dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), z1[ct]);
             }
           }
         } else {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) dz1[ct] = f4_mul(gz[ct], f4_dact(p.act1, z1[ct]));
+          for (int ct = 0; ct < 4; ++ct) dz1[ct] = f4_mul(gz[ct], z1[ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
