@@ -271,23 +271,28 @@ __global__ __launch_bounds__(256) void dense_wide_fwd_kernel(int64_t n, SegTable
   float b[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) b[j] = (bias && col0 + oc + j < dout) ? bias[col0 + oc + j] : 0.f;
+  float4 zz[8], aa[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    const int rl = (tid >> 4) + 16 * p;
-    const int64_t r = row0 + rl;
+    const float4 v = *reinterpret_cast<const float4 *>(&lds[((tid >> 4) + 16 * p) * OS2 + oc]);
+    zz[p] = make_float4(v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]);
+    aa[p] = zz[p];
+  }
+  f4n_act<8>(act, aa);   // one uniform activation switch for the thread's 32 values
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int64_t r = row0 + (tid >> 4) + 16 * p;
     if (r >= n || col0 + oc >= dout) continue;
-    const float4 v = *reinterpret_cast<const float4 *>(&lds[rl * OS2 + oc]);
-    const float z[4] = {v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]};
     if (vec) {   // dout % 4 == 0: the four columns exist and the address is 16-byte aligned
-      if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + col0 + oc) = make_float4(z[0], z[1], z[2], z[3]);
-      *reinterpret_cast<float4 *>(y + r * dout + col0 + oc) =
-          make_float4(act_apply(act, z[0]), act_apply(act, z[1]), act_apply(act, z[2]), act_apply(act, z[3]));
+      if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + col0 + oc) = zz[p];
+      *reinterpret_cast<float4 *>(y + r * dout + col0 + oc) = aa[p];
     } else {
+      const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (col0 + oc + j < dout) {
           if (save_z) save_z[r * dout + col0 + oc + j] = z[j];
-          y[r * dout + col0 + oc + j] = act_apply(act, z[j]);
+          y[r * dout + col0 + oc + j] = a4[j];
         }
     }
   }
