@@ -546,17 +546,29 @@ struct BwdK {
 
 // Slab layout (per workgroup): dW as [tile tt = mt * CT + nt][lane][4] (each lane's four MFMA result
 // registers contiguous -> one 16-byte read-modify-write per tile), db as [D].
-template <int D, bool AGG, int ACT, bool HALO>
-__global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(const BwdK p) {
+//
+// PAIR: a 1024-thread workgroup = two independent 512-thread halves, each with its own tile and LDS region, that fold their
+// dW / db partials into ONE slab (half 1 hands its accumulators to half 0 through LDS).  Halves the slab read-modify-write
+// traffic of every backward launch (16.8 MB of the 36-55 MB a launch moves at C2) at the price of one more barrier.
+template <int D, bool AGG, int ACT, bool HALO, bool PAIR>
+__global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(const BwdK p) {
   using G = Geo<D>;
   constexpr int kXZ = (AGG && HALO && G::XH > kTM * G::TS) ? G::XH : kTM * G::TS;
-  __shared__ __attribute__((aligned(16))) float lds[kXZ + kTM * G::TS * 2 + D * G::TS];
+  constexpr int kRegion = kXZ + kTM * G::TS * 2 + D * G::TS;
+  __shared__ __attribute__((aligned(16))) float lds_all[(PAIR ? 2 : 1) * kRegion];
+  const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) : 0;
+  float *lds = lds_all + half * kRegion;
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXZ, *ldsX = lds + kXZ + kTM * G::TS,
         *ldsBt = lds + kXZ + 2 * kTM * G::TS;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = PAIR ? (threadIdx.x & (kThreads - 1)) : threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / G::LPR, q = tid % G::LPR;
-  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  // PAIR: workgroup b owns tiles 2 b' and 2 b' + 1 (b' XCD-mapped); the second half of an odd last pair repeats the last
+  // tile with every row masked out (it contributes zeros and stores nothing)
+  const int n_wg = PAIR ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const int tile_raw = PAIR ? 2 * xcd_tile(blockIdx.x, n_wg) + half : xcd_tile(blockIdx.x, n_wg);
+  const bool tile_ok = tile_raw < p.n_tiles;
+  const int tile = tile_ok ? tile_raw : p.n_tiles - 1;
   const int act = ACT >= 0 ? ACT : p.act;
   const bool active = grp * G::R < kTM;
   const float4 *G4 = reinterpret_cast<const float4 *>(p.g_in);
@@ -577,6 +589,10 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
   } else {
     load_sched<D>(p.sched, tile, grp, active, sc);
   }
+  if (PAIR && !tile_ok) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) sc[r].x = -1;
+  }
   // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
   float4 wreg[G::W4];
   // slab fragments of this wave's dW tiles and this thread's db column: consumed after the MFMAs
@@ -594,9 +610,9 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
 #pragma unroll
     for (int m = 0; m < G::DWT; ++m) {
       const int tt = wave_u + G::WAVES * m;
-      sl[m] = (tt < NT) ? slab4[tt * 64 + lane] : f4_zero();
+      sl[m] = (tt < NT && half == 0) ? slab4[tt * 64 + lane] : f4_zero();
     }
-    if (dbpart == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
+    if (dbpart == 0 && half == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
   }
   // saved activations of this thread's rows (node-local, HBM-resident tape)
   float4 zrow[G::R], xrow[G::R], cterm[G::R][8];
@@ -678,7 +694,8 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
       f32x4 acc = (f32x4){sl[m].x, sl[m].y, sl[m].z, sl[m].w};
 #pragma unroll
       for (int ks = 0; ks < kTM / 4; ++ks) acc = mfma16(a[ks], b[ks], acc);
-      slab4[tt * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      sl[m] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (!PAIR) slab4[tt * 64 + lane] = sl[m];
     }
   }
   // db += column sums of the dZ tile: DBP adjacent lanes hold row-partials of one column
@@ -688,17 +705,39 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_bwd_ker
     for (int n = dbpart; n < kTM; n += G::DBP) s += ldsDZ[n * G::TS + dbc];
 #pragma unroll
     for (int o = 1; o < G::DBP; o <<= 1) s += __shfl_xor(s, o);
-    if (dbpart == 0) p.slab_db[(size_t)blockIdx.x * D + dbc] = dbv + s;
+    dbv += s;
+    if (!PAIR && dbpart == 0) p.slab_db[(size_t)blockIdx.x * D + dbc] = dbv;
   }
   NGPDE_STAMP(4);
   __syncthreads();
   NGPDE_STAMP(5);
+  // PAIR: half 1 parks its dW tiles and db partials in its (now idle) W^T region
+  float *park = lds_all + (PAIR ? 1 : 0) * kRegion + kXZ + 2 * kTM * G::TS;   // [NT][64 lanes][4] + [D]
+  if (PAIR && half == 1) {
+#pragma unroll
+    for (int m = 0; m < G::DWT; ++m) {
+      const int tt = wave_u + G::WAVES * m;
+      if (tt < NT) reinterpret_cast<float4 *>(park)[tt * 64 + lane] = sl[m];
+    }
+    if (dbpart == 0) park[NT * 256 + dbc] = dbv;
+  }
   if (active) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       if (sc[r].x < 0) continue;
       reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q] =
           *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
+    }
+  }
+  if (PAIR) {
+    __syncthreads();
+    if (half == 0) {   // fixed order: (slab + half 0) + half 1
+#pragma unroll
+      for (int m = 0; m < G::DWT; ++m) {
+        const int tt = wave_u + G::WAVES * m;
+        if (tt < NT) slab4[tt * 64 + lane] = f4_add(sl[m], reinterpret_cast<const float4 *>(park)[tt * 64 + lane]);
+      }
+      if (dbpart == 0) p.slab_db[(size_t)blockIdx.x * D + dbc] = dbv + park[NT * 256 + dbc];
     }
   }
   NGPDE_STAMP(6);
@@ -742,6 +781,12 @@ CombDev to_dev(const Comb &c) {
 inline bool no_halo_env() {
   static const bool v = [] { const char *e = std::getenv("NGPDE_NO_HALO"); return e && e[0] == '1'; }();
   return v;
+}
+
+// paired workgroups for the backward kernels (D <= 64: two 60 KB regions fit the CU's LDS); NGPDE_NO_PAIR=1 for A/B runs
+inline bool fused_bwd_pairs(int d) {
+  static const bool off = [] { const char *e = std::getenv("NGPDE_NO_PAIR"); return e && e[0] == '1'; }();
+  return d <= 64 && !off;
 }
 
 // activations with a compiled-in fast path; everything else takes the runtime switch (ACT = -1)
@@ -821,10 +866,13 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
   NGPDE_STAMP_SET(k, k.n_tiles)
   const bool use_halo = g->by_s.halo_ok && !no_halo_env();
-  const dim3 grid(k.n_tiles), block(kThreads);
+  const bool pair = fused_bwd_pairs(a.d);
+  const dim3 grid(pair ? (k.n_tiles + 1) / 2 : k.n_tiles), block(pair ? 2 * kThreads : kThreads);
+#define NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, PP)                                                                     \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP>), grid, block, 0, stream, k);
 #define NGPDE_BWD_LAUNCH2(DD, AG, AA, HH)                                                                         \
-  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH>), grid, block, 0, stream, k);
+  if (DD <= 64 && pair) { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, (DD <= 64)) } else { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, false) }
 #define NGPDE_BWD_LAUNCH(DD, AG, AA)                                                                              \
   if (AG && Geo<DD>::HALO && use_halo) { NGPDE_BWD_LAUNCH2(DD, AG, AA, (AG && Geo<DD>::HALO)) } else { NGPDE_BWD_LAUNCH2(DD, AG, AA, false) }
 #define NGPDE_BWD_ACT(DD, AG)                                                         \
@@ -847,6 +895,7 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
 #undef NGPDE_BWD_ACT
 #undef NGPDE_BWD_LAUNCH
 #undef NGPDE_BWD_LAUNCH2
+#undef NGPDE_BWD_LAUNCH3
   NGPDE_LAUNCH_CHECK("gcn_fused_bwd_kernel");
   return NGPDE_OK;
 }
