@@ -391,6 +391,101 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(int n_nodes, int heads, in
   }
 }
 
+// Same layer, restructured for short rows (heads a power of two <= 16): one wave per target row, lanes laid out as
+// (edge slot, head) so that a block of 64 / heads edges computes all its logits at once; max, sum and the attention
+// coefficients stay in registers (cross-lane shuffles), alpha is written once (coalesced) for the pullback, and the
+// aggregation reads each edge's coefficient with a shuffle and issues the block's Wx row loads before the first FMA.
+// Summation order = edge order inside the row, as the reference's scatter.
+template <int HEADS>
+__global__ __launch_bounds__(256) void gat_fwd_blocked_kernel(int n_nodes, int c, float slope, const int *__restrict__ rowptr,
+                                                              const int *__restrict__ col, const float *__restrict__ wx,
+                                                              const float *__restrict__ al, const float *__restrict__ ar,
+                                                              float *__restrict__ out, float *__restrict__ alpha) {
+  constexpr int EPB = 64 / HEADS;                    // edges per block
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int hc = HEADS * c;
+  const int ke = lane % HEADS, le = lane / HEADS;
+  const float ali = al[(size_t)row * HEADS + ke];
+  auto score = [&](int pp, int &cj) {
+    cj = col[pp];
+    const float v = ali + ar[(size_t)cj * HEADS + ke];
+    return v > 0.f ? v : slope * v;
+  };
+  auto over_edges_max = [&](float v) {
+#pragma unroll
+    for (int o = HEADS; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+  };
+  auto over_edges_sum = [&](float v) {
+#pragma unroll
+    for (int o = HEADS; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  const bool one_block = re - rs <= EPB;              // wave-uniform: the whole row in one block => ONE gather chain
+  // pass 1: row maximum per head; pass 2: denominator (a one-block row keeps its scores in registers)
+  float mx = -INFINITY, v0 = -INFINITY;
+  int cj0 = 0;
+  if (one_block) {
+    if (rs + le < re) v0 = score(rs + le, cj0);
+    mx = v0;
+  } else {
+    for (int p0 = rs; p0 < re; p0 += EPB) {
+      int cj;
+      if (p0 + le < re) mx = fmaxf(mx, score(p0 + le, cj));
+    }
+  }
+  mx = over_edges_max(mx);
+  float sum = 0.f, e0 = 0.f;
+  if (one_block) {
+    if (rs + le < re) e0 = fast_exp(v0 - mx);
+    sum = e0;
+  } else {
+    for (int p0 = rs; p0 < re; p0 += EPB) {
+      int cj;
+      if (p0 + le < re) sum += fast_exp(score(p0 + le, cj) - mx);
+    }
+  }
+  sum = over_edges_sum(sum);
+  const float inv = fast_rcp(sum);
+  // pass 3: coefficients of a block in registers, aggregation of the block's rows
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};               // features lane, lane + 64, ... (hc <= 256)
+  for (int p0 = rs; p0 < re; p0 += EPB) {
+    const int nb = min(EPB, re - p0);
+    int cj = cj0;
+    float a = 0.f;
+    if (le < nb) {
+      a = (one_block ? e0 : fast_exp(score(p0 + le, cj) - mx)) * inv;
+      alpha[(size_t)(p0 + le) * HEADS + ke] = a;       // = alpha[rs * HEADS + lane ...]: contiguous over the wave
+    }
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+      if (64 * fb >= hc) break;                        // wave-uniform
+      const bool fok = lane + 64 * fb < hc;            // no divergence around the shuffles: every lane is a shuffle source
+      const int f = fok ? lane + 64 * fb : 0;
+      const int kf = f / c;
+      float w[EPB];
+#pragma unroll
+      for (int e = 0; e < EPB; ++e) {
+        const int ce = __shfl(cj, e * HEADS);
+        w[e] = (e < nb && fok) ? wx[(size_t)ce * hc + f] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPB; ++e) {
+        const float ae = __shfl(a, e * HEADS + kf);
+        acc[fb] = fmaf(ae, w[e], acc[fb]);             // ae = 0 past the block's last edge
+      }
+    }
+  }
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb) {
+    const int f = lane + 64 * fb;
+    if (f < hc) out[(size_t)row * hc + f] = acc[fb];
+  }
+}
+
 // backward, target side: dalpha_p = <dout[i], Wx[s_p]>_head; dlogit = alpha (dalpha - sum alpha dalpha);
 // dscore_p = dlogit * leakyrelu'(score); dal[i] = sum_p dscore_p.  Stores dscore (for the source side).
 __global__ __launch_bounds__(256) void gat_bwd_target_kernel(int n_nodes, int heads, int c, float slope,
@@ -453,6 +548,110 @@ __global__ __launch_bounds__(256) void gat_bwd_source_kernel(int n_nodes, int he
     for (int q = rs; q < re; ++q) s += dscore[(size_t)xpos[q] * heads + k];
     dar[(size_t)row * heads + k] = s;
   }
+}
+
+// Blocked forms of the two pullback kernels (heads a power of two <= 16, c a multiple of 4): lanes = (edge slot, head).
+// Target side: every (edge, head) dot product <dout_i, Wx_j>_head is one lane's c/4 16-byte loads; the softmax pullback
+// (row sum of alpha * dalpha per head) and dal are cross-lane sums; dscore is written once, coalesced.
+template <int HEADS>
+__global__ __launch_bounds__(256) void gat_bwd_target_blocked_kernel(int n_nodes, int c, float slope, const int *__restrict__ rowptr,
+                                                                     const int *__restrict__ col, const float *__restrict__ wx,
+                                                                     const float *__restrict__ al, const float *__restrict__ ar,
+                                                                     const float *__restrict__ alpha, const float *__restrict__ dout,
+                                                                     float *__restrict__ dscore, float *__restrict__ dal) {
+  constexpr int EPB = 64 / HEADS;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int hc = HEADS * c;
+  const int ke = lane % HEADS, le = lane / HEADS;
+  const float ali = al[(size_t)row * HEADS + ke];
+  const float4 *d4 = reinterpret_cast<const float4 *>(dout + (size_t)row * hc + ke * c);
+  auto over_edges_sum = [&](float v) {
+#pragma unroll
+    for (int o = HEADS; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  auto dalpha = [&](int pp) {            // <dout[row], Wx[col_pp]> over this lane's head
+    const float4 *w4 = reinterpret_cast<const float4 *>(wx + (size_t)col[pp] * hc + ke * c);
+    float da = 0.f;
+    for (int cc = 0; cc < c / 4; ++cc) {
+      const float4 a = d4[cc], b = w4[cc];
+      da = fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, da))));
+    }
+    return da;
+  };
+  // pass 1: sum_p alpha_p dalpha_p per head
+  float dot_sum = 0.f;
+  for (int p0 = rs; p0 < re; p0 += EPB)
+    if (p0 + le < re) dot_sum = fmaf(alpha[(size_t)(p0 + le) * HEADS + ke], dalpha(p0 + le), dot_sum);
+  dot_sum = over_edges_sum(dot_sum);
+  // pass 2: dscore, dal  (rows of up to 64 / HEADS edges recompute nothing: the loop body runs once per pass)
+  float s = 0.f;
+  for (int p0 = rs; p0 < re; p0 += EPB) {
+    if (p0 + le < re) {
+      const int pp = p0 + le;
+      const float dl = alpha[(size_t)pp * HEADS + ke] * (dalpha(pp) - dot_sum);
+      const float sc = ali + ar[(size_t)col[pp] * HEADS + ke];
+      const float g = dl * (sc > 0.f ? 1.0f : slope);
+      dscore[(size_t)pp * HEADS + ke] = g;
+      s += g;
+    }
+  }
+  s = over_edges_sum(s);
+  if (le == 0) dal[(size_t)row * HEADS + ke] = s;
+}
+
+// Source side: dWx[j] = sum_{p leaving j} alpha_p dout[t_p];  dar[j] = sum_p dscore_p, the block's loads issued before
+// the first FMA, coefficients fetched once per (edge, head) and broadcast with shuffles.
+template <int HEADS>
+__global__ __launch_bounds__(256) void gat_bwd_source_blocked_kernel(int n_nodes, int c, const int *__restrict__ rowptr_s,
+                                                                     const int *__restrict__ col_s, const int *__restrict__ xpos,
+                                                                     const float *__restrict__ alpha, const float *__restrict__ dout,
+                                                                     const float *__restrict__ dscore, float *__restrict__ dwx,
+                                                                     float *__restrict__ dar) {
+  constexpr int EPB = 64 / HEADS;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr_s[row], re = rowptr_s[row + 1];
+  const int hc = HEADS * c;
+  const int ke = lane % HEADS, le = lane / HEADS;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float sdar = 0.f;
+  for (int q0 = rs; q0 < re; q0 += EPB) {
+    const int nb = min(EPB, re - q0);
+    int ct = 0;
+    float a = 0.f;
+    if (le < nb) {
+      const int pp = xpos[q0 + le];
+      ct = col_s[q0 + le];
+      a = alpha[(size_t)pp * HEADS + ke];
+      sdar += dscore[(size_t)pp * HEADS + ke];
+    }
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+      if (64 * fb >= hc) break;                        // wave-uniform
+      const bool fok = lane + 64 * fb < hc;
+      const int f = fok ? lane + 64 * fb : 0;
+      const int kf = f / c;
+      float w[EPB];
+#pragma unroll
+      for (int e = 0; e < EPB; ++e) {
+        const int te = __shfl(ct, e * HEADS);
+        w[e] = (e < nb && fok) ? dout[(size_t)te * hc + f] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPB; ++e) acc[fb] = fmaf(__shfl(a, e * HEADS + kf), w[e], acc[fb]);
+    }
+  }
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb)
+    if (lane + 64 * fb < hc) dwx[(size_t)row * hc + lane + 64 * fb] = acc[fb];
+#pragma unroll
+  for (int o = HEADS; o < 64; o <<= 1) sdar += __shfl_xor(sdar, o);
+  if (le == 0) dar[(size_t)row * HEADS + ke] = sdar;
 }
 
 // score halves: al[n][k] = sum_c a[c][k] Wx[n][k*C + c];  ar with a[C + c][k]   (a is (2C x H) column-major)
@@ -653,8 +852,20 @@ int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const fl
 int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                        float *out, float *alpha, hipStream_t stream) {
   if (g->n_nodes == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(gat_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, heads, c, slope,
-                     g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha);
+  const dim3 grid(rows4(g->n_nodes)), block(256);
+  const int n = (int)g->n_nodes;
+  if (heads * c <= 256 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16)) {
+    switch (heads) {
+      case 1: hipLaunchKernelGGL(gat_fwd_blocked_kernel<1>, grid, block, 0, stream, n, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha); break;
+      case 2: hipLaunchKernelGGL(gat_fwd_blocked_kernel<2>, grid, block, 0, stream, n, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha); break;
+      case 4: hipLaunchKernelGGL(gat_fwd_blocked_kernel<4>, grid, block, 0, stream, n, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha); break;
+      case 8: hipLaunchKernelGGL(gat_fwd_blocked_kernel<8>, grid, block, 0, stream, n, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha); break;
+      default: hipLaunchKernelGGL(gat_fwd_blocked_kernel<16>, grid, block, 0, stream, n, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha); break;
+    }
+    NGPDE_LAUNCH_CHECK("gat_fwd_blocked_kernel");
+    return NGPDE_OK;
+  }
+  hipLaunchKernelGGL(gat_fwd_kernel, grid, block, 0, stream, n, heads, c, slope, g->by_t.rowptr, g->by_t.col, wx, al, ar, out, alpha);
   NGPDE_LAUNCH_CHECK("gat_fwd_kernel");
   return NGPDE_OK;
 }
@@ -664,12 +875,31 @@ int32_t launch_gat_bwd(const ngpde_graph *g, int heads, int c, float slope, cons
                        float *dwx, float *da, hipStream_t stream) {
   if (g->n_nodes == 0) return NGPDE_OK;
   const int n = (int)g->n_nodes;
-  hipLaunchKernelGGL(gat_bwd_target_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, slope, g->by_t.rowptr,
-                     g->by_t.col, wx, al, ar, alpha, dout, dscore, dal);
-  NGPDE_LAUNCH_CHECK("gat_bwd_target_kernel");
-  hipLaunchKernelGGL(gat_bwd_source_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, g->by_s.rowptr, g->by_s.col,
-                     g->by_s.xpos, alpha, dout, dscore, dwx, dar);
-  NGPDE_LAUNCH_CHECK("gat_bwd_source_kernel");
+  const bool blocked = heads * c <= 256 && c % 4 == 0 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) &&
+                       ((reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+  if (blocked) {
+#define NGPDE_GAT_BWD(HH)                                                                                                  \
+  hipLaunchKernelGGL(gat_bwd_target_blocked_kernel<HH>, dim3(rows4(n)), dim3(256), 0, stream, n, c, slope, g->by_t.rowptr, \
+                     g->by_t.col, wx, al, ar, alpha, dout, dscore, dal);                                                     \
+  hipLaunchKernelGGL(gat_bwd_source_blocked_kernel<HH>, dim3(rows4(n)), dim3(256), 0, stream, n, c, g->by_s.rowptr,        \
+                     g->by_s.col, g->by_s.xpos, alpha, dout, dscore, dwx, dar);
+    switch (heads) {
+      case 1: NGPDE_GAT_BWD(1) break;
+      case 2: NGPDE_GAT_BWD(2) break;
+      case 4: NGPDE_GAT_BWD(4) break;
+      case 8: NGPDE_GAT_BWD(8) break;
+      default: NGPDE_GAT_BWD(16) break;
+    }
+#undef NGPDE_GAT_BWD
+    NGPDE_LAUNCH_CHECK("gat_bwd_*_blocked_kernel");
+  } else {
+    hipLaunchKernelGGL(gat_bwd_target_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, slope, g->by_t.rowptr,
+                       g->by_t.col, wx, al, ar, alpha, dout, dscore, dal);
+    NGPDE_LAUNCH_CHECK("gat_bwd_target_kernel");
+    hipLaunchKernelGGL(gat_bwd_source_kernel, dim3(rows4(n)), dim3(256), 0, stream, n, heads, c, g->by_s.rowptr, g->by_s.col,
+                       g->by_s.xpos, alpha, dout, dscore, dwx, dar);
+    NGPDE_LAUNCH_CHECK("gat_bwd_source_kernel");
+  }
   hipLaunchKernelGGL(gat_scores_bwd_dwx_kernel, dim3(blocks_for((int64_t)n * heads * c)), dim3(256), 0, stream, (int64_t)n,
                      heads, c, a, dal, dar, dwx);
   NGPDE_LAUNCH_CHECK("gat_scores_bwd_dwx_kernel");

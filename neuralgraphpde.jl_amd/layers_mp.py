@@ -351,6 +351,7 @@ class GATConv(AbstractGNNLayer):
         self.in_chs, self.out_chs = int(ch[0]), int(ch[1])
         self.heads, self.concat = int(heads), bool(concat)
         self.negative_slope, self.add_self_loops, self.bias = float(negative_slope), bool(add_self_loops), bool(bias)
+        self._mix = {}
         self.activation, self.act = _act_code(activation)
         self.init_weight, self.init_bias = init_weight, init_bias
         self.initialgraph = wrapgraph(initialgraph if initialgraph is not None else (lambda: EMPTYGRAPH))
@@ -384,9 +385,12 @@ class GATConv(AbstractGNNLayer):
         out = F.gat_aggregate(wx, rows_of(ps["a"]), handle, h, c, self.negative_slope, gs.num_edges)
         b = ps["bias"].reshape(-1) if "bias" in ps else None
         dev = xr.device
-        if self.concat:
-            mix = torch.eye(c * h, dtype=torch.float32, device=dev)
-        else:                                                                       # mean over heads
-            mix = torch.eye(c, dtype=torch.float32, device=dev).repeat(h, 1) / h
+        mix = self._mix.get(str(dev))                                               # built once per device
+        if mix is None:
+            if self.concat:
+                mix = torch.eye(c * h, dtype=torch.float32, device=dev)
+            else:                                                                   # mean over heads
+                mix = torch.eye(c, dtype=torch.float32, device=dev).repeat(h, 1) / h
+            self._mix[str(dev)] = mix
         y = F.dense([out], mix, b, self.act)
         return y.T, st
