@@ -120,12 +120,19 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NGPDE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
+    # collective goes through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("NGPDE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
     g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
