@@ -151,6 +151,9 @@ int fused_num_blocks(int64_t n_nodes);
 int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
 // ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream);
+bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
+int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
+                             float *out, float *alpha, hipStream_t stream);
 
 // generic (any feature width) building blocks
 int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr,

@@ -743,6 +743,91 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   NGPDE_STAMP(6);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GAT-style softmax aggregation on the same tile / halo machinery (heads * c == 64, heads in {1, 2, 4}):
+//   out_i = sum_{e: t_e = i} alpha_e Wx[s_e],   alpha = softmax over the row of leakyrelu(al_i + ar_{s_e}) per head
+// The tile's distinct source rows of Wx and their ar scores are staged in LDS once; lane group g owns row g, lane q the
+// features 4q..4q+3 (all of one head); max / denominator / weighted sum are three short LDS passes over the row's slots.
+// alpha is written once (p order) for the pullback.  [GraphNeuralNetworks.jl GATConv; BASELINE config 3]
+// ---------------------------------------------------------------------------------------------------
+struct GatK {
+  const float *wx, *al, *ar;
+  const int4 *sched;
+  const int2 *halo;
+  const uint8_t *slots;
+  int n_tiles, heads;
+  float slope;
+  float *out, *alpha;
+};
+
+__global__ __launch_bounds__(kThreads, 4) void gat_fused_fwd_kernel(const GatK p) {
+  constexpr int D = 64;
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * D];
+  __shared__ __attribute__((aligned(16))) float ldsAr[(kHaloCap + 1) * 4];
+  const int tid = threadIdx.x;
+  const int grp = tid / G::LPR, q = tid % G::LPR;
+  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  const bool active = grp * G::R < kTM;
+  const float4 *X4 = reinterpret_cast<const float4 *>(p.wx);
+  const int H = p.heads, kh = (4 * q) / (D / H);      // this lane's head
+
+  HaloRegs<D> hr;
+  int4 sc[G::R];
+  halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), nullptr, tile, grp, active, hr);
+  load_sched<D>(p.sched, tile, grp, active, sc);
+  halo_round2<D>(X4, q, hr);
+  // ar of the halo nodes (lanes q < H fetch one score each), al of this row's head
+  float arv[G::HI];
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) arv[k] = (q < H) ? p.ar[(size_t)hr.he[k].x * H + q] : 0.f;
+  float ali[G::R];
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) ali[r] = p.al[(size_t)max(sc[r].x, 0) * H + kh];
+
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) {
+    const int hh = grp + k * G::GROUPS;
+    if (hh < kHaloCap) {
+      Xh4[hh * G::LPR + q] = hr.hv[k];
+      if (q < 4) ldsAr[hh * 4 + q] = arv[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    if (!active || sc[r].x < 0) continue;
+    const unsigned w[8] = {hr.sl[r][0].x, hr.sl[r][0].y, hr.sl[r][0].z, hr.sl[r][0].w,
+                           hr.sl[r][1].x, hr.sl[r][1].y, hr.sl[r][1].z, hr.sl[r][1].w};
+    const int deg = sc[r].z;
+    auto slot_of = [&](int j) {
+      unsigned word = 0;
+#pragma unroll
+      for (int jw = 0; jw < 8; ++jw) word = (jw == (j >> 2)) ? w[jw] : word;
+      return (int)((word >> (8 * (j & 3))) & 0xff);
+    };
+    auto score = [&](int sl) {
+      const float v = ali[r] + ldsAr[sl * 4 + kh];
+      return v > 0.f ? v : p.slope * v;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j < deg; ++j) mx = fmaxf(mx, score(slot_of(j)));
+    float sum = 0.f;
+    float4 acc = f4_zero();
+    for (int j = 0; j < deg; ++j) {
+      const int sl = slot_of(j);
+      const float e = fast_exp(score(sl) - mx);
+      sum += e;
+      acc = f4_fma(e, Xh4[sl * G::LPR + q], acc);
+    }
+    const float inv = deg > 0 ? fast_rcp(sum) : 0.f;
+    reinterpret_cast<float4 *>(p.out)[(size_t)sc[r].x * G::LPR + q] = f4_scale(inv, acc);
+    if ((4 * q) % (D / H) == 0)                      // one lane per head writes the row's coefficients
+      for (int j = 0; j < deg; ++j) p.alpha[(size_t)(sc[r].y + j) * H + kh] = fast_exp(score(slot_of(j)) - mx) * inv;
+  }
+}
+
 // out (row-major dWt[i][o], or db[o] when ct == 0) = sum over slabs; 4 partial sums per element
 __global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len, int ct,
                                     float *__restrict__ out) {
@@ -897,6 +982,23 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
 #undef NGPDE_BWD_LAUNCH2
 #undef NGPDE_BWD_LAUNCH3
   NGPDE_LAUNCH_CHECK("gcn_fused_bwd_kernel");
+  return NGPDE_OK;
+}
+
+bool gat_fused_supported(const ngpde_graph *g, int heads, int c) {
+  return g && g->has_norm && g->by_t.halo_ok && heads * c == 64 && (heads == 1 || heads == 2 || heads == 4) &&
+         (uint64_t)g->n_nodes * 64 * 4 < (1ull << 32);
+}
+
+int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
+                             float *out, float *alpha, hipStream_t stream) {
+  NGPDE_REQUIRE(gat_fused_supported(g, heads, c), NGPDE_ERR_UNSUPPORTED, "fused GAT aggregation needs heads * c == 64, heads in {1,2,4}, tiles that fit the LDS halo");
+  if (g->n_nodes == 0) return NGPDE_OK;
+  GatK k;
+  k.wx = wx; k.al = al; k.ar = ar; k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
+  k.n_tiles = fused_num_blocks(g->n_nodes); k.heads = heads; k.slope = slope; k.out = out; k.alpha = alpha;
+  hipLaunchKernelGGL(gat_fused_fwd_kernel, dim3(k.n_tiles), dim3(kThreads), 0, stream, k);
+  NGPDE_LAUNCH_CHECK("gat_fused_fwd_kernel");
   return NGPDE_OK;
 }
 

@@ -13,6 +13,7 @@
 // First correct versions: one wave per row, lanes stride the feature axis; no atomics, fixed summation
 // order (bitwise reproducible).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "device_utils.h"
@@ -852,6 +853,8 @@ int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const fl
 int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                        float *out, float *alpha, hipStream_t stream) {
   if (g->n_nodes == 0) return NGPDE_OK;
+  const bool no_fused = getenv("NGPDE_NO_FUSED_GAT") != nullptr;   // read per call: tests switch it at run time
+  if (!no_fused && gat_fused_supported(g, heads, c)) return launch_gat_fused_fwd(g, heads, c, slope, wx, al, ar, out, alpha, stream);
   const dim3 grid(rows4(g->n_nodes)), block(256);
   const int n = (int)g->n_nodes;
   if (heads * c <= 256 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16)) {

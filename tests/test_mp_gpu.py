@@ -454,6 +454,40 @@ def test_segment_reduce_edge_cases():
     assert torch.equal(F.edge_permute(Mp, h, inverse=True), M)
 
 
+@pytest.mark.parametrize("heads", [1, 2, 4])
+def test_gat_fused_halo_forward_and_grads(heads, monkeypatch):
+    # a local graph whose tiles fit the LDS halo: the softmax aggregation runs on the tile / halo kernel (heads * c == 64);
+    # forward, gradients (the pullback consumes the alpha the fused kernel wrote) and agreement with the row-per-wave kernel
+    n, C = 203, 64 // heads
+    rng = np.random.default_rng(51)
+    ss, tt = [], []
+    for i in range(n):
+        for off in rng.choice(np.arange(-6, 7), size=rng.integers(0, 11), replace=False):
+            if off != 0:
+                ss.append((i + off) % n); tt.append(i)
+    s, t = np.array(ss), np.array(tt)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    og = O.Graph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((24, C), "tanh", heads=heads, concat=True, initialgraph=g)
+    ps, st = ng.setup(51, l)
+    ps = prep(ps, 51)
+    x = torch.randn(24, n, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    pw = lambda k: ps[k].detach().cpu().double().numpy()
+    yo, c = O.gat_conv(x.detach().cpu().double().numpy(), pw("weight"), pw("a"), pw("bias"), og, heads, C, "tanh", concat=True)
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.gat_conv_backward(c, R)
+    close(x.grad, gr["x"], rtol=5e-4, atol=1e-4)
+    for k in ("weight", "a", "bias"):
+        close(ps[k].grad, np.asarray(gr[k]).reshape(tuple(ps[k].shape)), rtol=5e-4, atol=2e-4, what=k)
+    monkeypatch.setenv("NGPDE_NO_FUSED_GAT", "1")       # the row-per-wave kernel
+    with torch.no_grad():
+        y2, _ = l(x, ps, st)
+    close(y2, y.detach().cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_gat_as_ode_right_hand_side_generic_solver_path():
     # BASELINE config 3 "as ODE RHS": du/dt = GATConv(64 => 4 x 16, concat)(u), stepped by NeuralODE's generic path (explicit
     # RK through the layer's kernels, gradients by autograd through every stage) against rk_solve / rk_adjoint of the oracle
