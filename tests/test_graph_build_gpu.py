@@ -213,3 +213,52 @@ def test_batch_reuses_member_orders_and_layers_agree(monkeypatch):
     gh = ng.GNNGraph(s, t, num_nodes=gb.num_nodes, index_base=0, num_graphs=3)
     y_host, _ = l(x, ps, ng.updategraph(st, gh))
     assert torch.equal(y_dev, y_host)       # per-row summation order does not depend on the schedule
+
+
+def _boundary_cases():
+    # exactly at / one past the two capacity limits of the LDS halo path
+    n = 160
+    def star(deg):                                   # node 0 receives `deg` edges from nodes 40.. (far from tile 0)
+        return np.arange(40, 40 + deg), np.zeros(deg, int)
+    yield "degree-32", *star(32), n                  # the widest row the slot bytes can describe
+    yield "degree-33", *star(33), n                  # one more: the tile must report 'does not fit'
+    # tile 0 = nodes 0..31 (identity-like order is not guaranteed, so only the flags / oracle equality are asserted)
+    s = np.concatenate([np.arange(32, 32 + 64), np.arange(100, 101)])
+    t = np.concatenate([np.repeat(np.arange(32), 2), np.array([0])])
+    yield "distinct-near-cap", s, t, n
+
+
+@pytest.mark.parametrize("name,s,t,n", list(_boundary_cases()), ids=[c[0] for c in _boundary_cases()])
+def test_capacity_boundaries_match_oracle(name, s, t, n):
+    od = O.derived_graph(s, t, n, None, True, None, False)
+    hd, hh = create_device(s, t, n, (True, None, False)), create_host(s, t, n, (True, None, False))
+    try:
+        compare_with_oracle(hd, od, "device " + name)
+        compare_with_oracle(hh, od, "host " + name)
+        if name == "degree-32":
+            assert od["t"]["halo_ok"]
+        if name == "degree-33":
+            assert not od["t"]["halo_ok"]
+    finally:
+        destroy(hd); destroy(hh)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_structures_device_builder_matches_oracle(seed):
+    # a sweep over sizes, densities and locality: every array bit-equal to the numpy restatement
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1, 400))
+    m = int(rng.integers(0, 6 * n))
+    if seed % 3 == 0:                                # local structure (tiles fit), otherwise uniform random (they do not)
+        t = rng.integers(0, n, m)
+        s = (t + rng.integers(-5, 6, m)) % n
+    else:
+        s, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    w = (0.25 + rng.random(m)).astype(np.float32)
+    nm = [(True, None, False), (False, None, False), (True, w, True)][seed % 3]
+    od = O.derived_graph(s, t, n, None, nm[0], nm[1], nm[2])
+    h = create_device(s, t, n, nm)
+    try:
+        compare_with_oracle(h, od, f"seed {seed}")
+    finally:
+        destroy(h)
