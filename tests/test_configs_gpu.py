@@ -102,6 +102,47 @@ def test_c2_two_tsit5_steps_against_the_c_port():
     close(ps["layer_2"]["bias"].grad, outs[5], 1e-3, 1e-2, "db2")
 
 
+def test_c2_full_bench_workload_against_the_c_port():
+    # the bench workload in full (50 Tsit5 steps, forward + adjoint) against the reference-faithful C port on the host
+    # cores (~10 s at its best OpenMP team size): u(T), du0 and all parameter gradients
+    s, t, D, params, u0 = c2_inputs()
+    path = os.path.join(ODIR, "libngpde_oracle_omp.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ODIR])
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(min(16, os.cpu_count() or 1))
+    except OSError:
+        pass
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.ngo_node_gcn2.argtypes = [C.c_int64, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int] + [vp] * 11
+    lib.ngo_node_gcn2.restype = C.c_int
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    u = f32(u0.T)
+    w = [f32(params[k]["weight"].T) for k in range(2)]
+    b = [f32(params[k]["bias"].reshape(-1)) for k in range(2)]
+    outs = [np.zeros_like(u), np.zeros_like(u), np.zeros_like(w[0]), np.zeros_like(b[0]), np.zeros_like(w[1]), np.zeros_like(b[1])]
+    s64, t64 = np.ascontiguousarray(s, np.int64), np.ascontiguousarray(t, np.int64)
+    P = lambda a: a.ctypes.data
+    assert lib.ngo_node_gcn2(16384, s64.size, P(s64), P(t64), D, 1, 1, 50, 1.0 / 50, 1, P(u), P(w[0]), P(b[0]), P(w[1]), P(b[1]),
+                             *[P(o) for o in outs]) == 0
+    g = ng.GNNGraph(s, t, num_nodes=16384, index_base=0)
+    node, ps, st = gcn2_node(g, D, "tsit5", 50, 1.0 / 50, params)
+    ut = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(ut, ps, st)
+    # Tolerances: the C port sums the parameter gradients serially in float32 over 16 384 nodes x 300 evaluations and is
+    # the LESS accurate side -- measured against the float64 numpy oracle at this size (tools/three_way_accuracy.py, 4 min):
+    # u(T) 1.3e-6 (both), du0 8.6e-4 (both: relu mask flips), dW 1.8e-5 / 1.5e-5 (HIP) vs 4.6e-4 / 3.8e-3 (C port),
+    # db 4.0e-6 / 4.7e-6 (HIP) vs 3.6e-3 / 6.7e-3 (C port)
+    close(uT, outs[0].T, 2e-5, what="u(T) after 50 steps")
+    uT.sum().backward()
+    close(ut.grad, outs[1].T, 2e-3, 1e-4, "du0")
+    close(ps["layer_1"]["weight"].grad, outs[2].T, 2e-3, 5e-2, "dW1")
+    close(ps["layer_2"]["weight"].grad, outs[4].T, 8e-3, 5e-2, "dW2")
+    close(ps["layer_1"]["bias"].grad, outs[3], 8e-3, 5e-2, "db1")
+    close(ps["layer_2"]["bias"].grad, outs[5], 1.5e-2, 5e-2, "db2")
+
+
 def test_c2_full_solve_properties():
     # the full 50-step solve + adjoint: deterministic replay, adjoint linear in the seed, exact fixed point for a zero field
     s, t, D, params, u0 = c2_inputs()
