@@ -38,12 +38,16 @@ a = stamps.cpu().numpy().reshape(nl, nb, 8, 2)
 nf = 2 * 6 * STEPS
 def report(name, idx, nph, labels):
     clk = a[idx][:, :, :nph + 1, 0].astype(np.float64); wall = a[idx][:, :, :nph + 1, 1].astype(np.float64)
+    used = wall[0, :, 0] > 0                       # paired backward workgroups stamp only n_tiles / 2 slots
+    clk, wall = clk[:, used], wall[:, used]
     d = np.diff(clk, axis=2)
     med = np.median(d, axis=(0, 1))
     dur = (wall[:, :, nph].max(axis=1) - wall[:, :, 0].min(axis=1)) * 10.0   # ns, kernel span by wall clock
-    print(f"{name}: kernel span (first WG start -> last WG end) median {np.median(dur)/1000:.2f} us over {len(idx)} launches")
+    print(f"{name}: kernel span (first WG start -> last WG end) median {np.median(dur)/1000:.2f} us over {len(idx)} launches, {int(used.sum())} workgroups")
     for l, m in zip(labels, med): print(f"    {l:26s} {m:8.0f} cycles")
-    print(f"    {'WG total':26s} {np.median(clk[:, :, nph] - clk[:, :, 0]):8.0f} cycles;  start skew {np.median((wall[:, :, 0].max(axis=1) - wall[:, :, 0].min(axis=1)) * 10):.0f} ns")
+    tot = clk[:, :, nph] - clk[:, :, 0]
+    wtot = (wall[:, :, nph] - wall[:, :, 0]) * 10.0
+    print(f"    {'WG total':26s} {np.median(tot):8.0f} cycles = {np.median(wtot):.0f} ns;  start skew {np.median((wall[:, :, 0].max(axis=1) - wall[:, :, 0].min(axis=1)) * 10):.0f} ns")
 raw = stamps.cpu().numpy().reshape(nl, nb, 16)
 sub = raw[list(range(0, nf, 2))][:, :, 10:15].astype(np.float64)
 t0 = raw[list(range(0, nf, 2))][:, :, 0].astype(np.float64)
