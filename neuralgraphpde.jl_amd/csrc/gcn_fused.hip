@@ -416,6 +416,9 @@ struct FwdK {
   int has_comb;
   CombDev comb;
   float *comb_out;
+  int order;   // bit 0: W fetched after the aggregation, bit 1: stage terms fetched after the aggregation.  Both on by default:
+               // everything issued at kernel start competes in the memory system with the halo rows the workgroup waits for
+               // (measured at C2: layer-1 5.98 -> 5.85 us, layer-2 + stage 7.46 -> 7.06 us)
   NGPDE_STAMP_FIELD
 };
 
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   // W: B[k = in][j = out] = wt[in][out], stored transposed in LDS: 4 dword loads down a column
   // (coalesced across lanes) -> one ds_write_b128
   float4 wreg[G::NPASS];
-  {
+  auto load_w = [&]() {
     const int j = tid % D, kg0 = tid / D;
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
@@ -462,7 +465,8 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
         wreg[ps] = make_float4(w[0], w[D], w[2 * D], w[3 * D]);
       }
     }
-  }
+  };
+  if (!(p.order & 1)) load_w();
   const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();   // uniform condition
   __builtin_amdgcn_sched_barrier(0);
   // ---- round 2: addresses from round 1 -- the tile's distinct rows, then the node-local stage terms
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
     halo_round2<D>(X4, q, hr);
   }
   float4 cterm[G::R][8];
-  if (HALO && active && p.has_comb) {
+  if (HALO && active && p.has_comb && !(p.order & 2)) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
   }
@@ -484,6 +488,11 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
     aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
   }
   NGPDE_STAMP(1);
+  if (p.order & 1) load_w();
+  if (HALO && active && p.has_comb && (p.order & 2)) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
+  }
   if (!HALO && active && p.has_comb) {   // the per-row gather keeps 16 rows in flight: stage terms only afterwards
 #pragma unroll
     for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
@@ -538,7 +547,7 @@ struct BwdK {
   CombDev comb;
   float *store_t, *store_v;
   float v_scale;
-  int do_dense, tape_late;
+  int do_dense, tape_late, order;
   const float *z, *saved_agg, *wt;
   float *g_out, *slab_dw, *slab_db;
   NGPDE_STAMP_FIELD
@@ -601,13 +610,16 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   float4 sl[G::DWT];
   const int dbc = tid / G::DBP, dbpart = tid % G::DBP;
   float dbv = 0.f;
-  if (p.do_dense) {
+  auto load_w = [&]() {
+    if (p.do_dense) {
 #pragma unroll
-    for (int k = 0; k < G::W4; ++k) {
-      const int idx = tid + k * kThreads;
-      wreg[k] = (idx < D * D / 4) ? reinterpret_cast<const float4 *>(p.wt)[idx] : f4_zero();
+      for (int k = 0; k < G::W4; ++k) {
+        const int idx = tid + k * kThreads;
+        wreg[k] = (idx < D * D / 4) ? reinterpret_cast<const float4 *>(p.wt)[idx] : f4_zero();
+      }
     }
-  }
+  };
+  if (!(p.order & 1)) load_w();
   auto load_slab = [&]() {   // consumed only after the dW MFMAs
     if (p.do_dense) {
 #pragma unroll
@@ -618,7 +630,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       if (dbpart == 0 && half == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
     }
   };
-  load_slab();
+  if (!(p.order & 2)) load_slab();
   float4 zrow[G::R], xrow[G::R], cterm[G::R][8];
   auto load_tape = [&]() {   // saved activations of this thread's rows (node-local, HBM-resident tape)
     if (active && p.do_dense) {
@@ -646,6 +658,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   }
   NGPDE_STAMP(1);
   if (p.tape_late) load_tape();
+  if (p.order & 1) load_w();
+  if (p.order & 2) load_slab();
   if (active && p.has_comb) {   // adjoint stage terms: one batch of independent node-local loads
 #pragma unroll
     for (int r = 0; r < G::R; ++r) comb_prefetch(p.comb, (size_t)max(sc[r].x, 0) * G::LPR + q, cterm[r]);
@@ -916,6 +930,10 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
+  {   // default 3; NGPDE_FWD_ORDER=0..3 for A/B runs of the load placement
+    static const int ord = [] { const char *e = std::getenv("NGPDE_FWD_ORDER"); return e ? atoi(e) : 3; }();
+    k.order = ord;
+  }
   NGPDE_STAMP_SET(k, k.n_tiles)
   const bool use_halo = g->by_t.halo_ok && !no_halo_env();
   const dim3 grid(k.n_tiles), block(kThreads);
@@ -960,6 +978,11 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;
   k.do_dense = a.do_dense ? 1 : 0; k.z = a.z; k.saved_agg = a.saved_agg; k.wt = a.wt;
   k.tape_late = a.has_comb ? 0 : 1;
+  {
+    static const int ord = [] { const char *e = std::getenv("NGPDE_BWD_ORDER"); return e ? atoi(e) : 1; }();
+    k.order = ord;
+    if (ord & 4) k.tape_late = 1;
+  }
   k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
   NGPDE_STAMP_SET(k, k.n_tiles)
   const bool use_halo = g->by_s.halo_ok && !no_halo_env();
