@@ -104,8 +104,9 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
       b.g = g; b.d = din; b.act = act; b.aggregate = true; b.g_in = gbuf; b.do_dense = false; b.store_t = dx;
       if ((st = launch_fused_bwd(b, stream))) return st;
     }
-    if ((st = launch_reduce_slabs(slab_dw, (int)nb, din * dout, din / 16, dweight, stream))) return st;
-    if (dbias && (st = launch_reduce_slabs(slab_db, (int)nb, dout, 0, dbias, stream))) return st;
+    const int ns = fused_num_slabs(n, din);
+    if ((st = launch_reduce_slabs(slab_dw, ns, din * dout, din / 16, dweight, stream))) return st;
+    if (dbias && (st = launch_reduce_slabs(slab_db, ns, dout, 0, dbias, stream))) return st;
     return NGPDE_OK;
   }
   const size_t dmax = (size_t)std::max(din, dout);

@@ -148,6 +148,7 @@ struct FusedBwdArgs {
 };
 int fused_tile_rows();
 int fused_num_blocks(int64_t n_nodes);
+int fused_num_slabs(int64_t n_nodes, int d);   // <= fused_num_blocks: slabs the backward launches actually write
 int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
 // ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream);

@@ -853,19 +853,30 @@ __global__ __launch_bounds__(kThreads, 4) void gat_fused_fwd_kernel(const GatK p
   }
 }
 
-// out (row-major dWt[i][o], or db[o] when ct == 0) = sum over slabs; 4 partial sums per element
-__global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len, int ct,
-                                    float *__restrict__ out) {
-  __shared__ float part[4][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part_id = threadIdx.x >> 6;
-  float s = 0.f;
-  if (e < len)
-    for (int b = part_id; b < n_slabs; b += 4) s += slab[(size_t)b * len + e];
-  part[part_id][threadIdx.x & 63] = s;
+// out (row-major dWt[i][o], or db[o] when ct == 0) = sum over slabs: 64 elements x 16 slab lanes per workgroup, four
+// independent partial sums per lane, combined in a fixed order
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len, int ct,
+                                                            float *__restrict__ out) {
+  __shared__ float part[16][64];
+  const int el = threadIdx.x & 63, part_id = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < len) {
+    int b = part_id;
+    for (; b + 48 < n_slabs; b += 64) {
+      s0 += slab[(size_t)b * len + e];
+      s1 += slab[(size_t)(b + 16) * len + e];
+      s2 += slab[(size_t)(b + 32) * len + e];
+      s3 += slab[(size_t)(b + 48) * len + e];
+    }
+    for (; b < n_slabs; b += 16) s0 += slab[(size_t)b * len + e];
+  }
+  part[part_id][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (part_id == 0 && e < len) {
-    const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][el];
     int dst = e;
     if (ct > 0) {  // e = (tt * 64 + lane) * 4 + reg  ->  dWt[(mt*16 + 4*kq + reg) * D + nt*16 + i]
       const int reg = e & 3, ln = (e >> 2) & 63, tt = e >> 8;
@@ -916,6 +927,11 @@ extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf, int32_t m
 bool fused_supported(int din, int dout) { return din == dout && (din == 16 || din == 32 || din == 64 || din == 128); }
 int fused_tile_rows() { return kTM; }
 int fused_num_blocks(int64_t n_nodes) { return (int)((n_nodes + kTM - 1) / kTM); }
+// slabs the backward launches write (paired workgroups share one)
+int fused_num_slabs(int64_t n_nodes, int d) {
+  const int nb = fused_num_blocks(n_nodes);
+  return fused_bwd_pairs(d) ? (nb + 1) / 2 : nb;
+}
 
 int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
@@ -1039,7 +1055,7 @@ int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope
 
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream) {
   if (len == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + 63) / 64), dim3(256), 0, stream, slab, n_slabs, len, ct, out);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + 63) / 64), dim3(1024), 0, stream, slab, n_slabs, len, ct, out);
   NGPDE_LAUNCH_CHECK("reduce_slabs_kernel");
   return NGPDE_OK;
 }

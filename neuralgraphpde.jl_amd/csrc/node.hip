@@ -237,10 +237,11 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
     }
   }
   const int dd = p->d * p->d;
-  if ((st = launch_reduce_slabs(p->slab_dw1, p->nb, dd, p->d / 16, p->dw1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db1, p->nb, p->d, 0, p->db1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_dw2, p->nb, dd, p->d / 16, p->dw2, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db2, p->nb, p->d, 0, p->db2, stream))) return st;
+  const int ns = fused_num_slabs(p->n, p->d);   // the slabs beyond it stay zero
+  if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db1, ns, p->d, 0, p->db1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_dw2, ns, dd, p->d / 16, p->dw2, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db2, ns, p->d, 0, p->db2, stream))) return st;
   count += 4;
   if (launches) *launches = count;
   return NGPDE_OK;
