@@ -75,8 +75,8 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
   if (st) return st;
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: dweight is NULL");
   if (g->n_nodes == 0) {  // empty graph: zero gradients
-    NGPDE_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)din * dout * 4, (hipStream_t)stream_));
-    if (dbias) NGPDE_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)dout * 4, (hipStream_t)stream_));
+    { const int32_t zs = launch_zero(dweight, (size_t)din * dout * 4, (hipStream_t)stream_); if (zs) return zs; }
+    if (dbias) { const int32_t zs = launch_zero(dbias, (size_t)dout * 4, (hipStream_t)stream_); if (zs) return zs; }
     return NGPDE_OK;
   }
   NGPDE_REQUIRE(weight && z && dy, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: weight/z/dy is NULL");
@@ -93,7 +93,7 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
     float *slab_dw = (float *)ws;
     float *slab_db = (float *)(ws + align256(nb * (size_t)din * dout * 4));
     float *gbuf = (float *)((char *)slab_db + align256(nb * (size_t)dout * 4));
-    NGPDE_HIP_CHECK(hipMemsetAsync(slab_dw, 0, (size_t)((char *)gbuf - ws), stream));
+    { const int32_t zs = launch_zero(slab_dw, (size_t)((char *)gbuf - ws), stream); if (zs) return zs; }
     FusedBwdArgs a;
     a.g = g; a.d = din; a.act = act; a.aggregate = false; a.g_in = dy;
     a.do_dense = true; a.z = z; a.saved_agg = saved_agg; a.wt = weight; a.g_out = gbuf;

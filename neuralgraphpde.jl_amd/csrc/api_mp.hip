@@ -73,8 +73,8 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_backward: dweight is NULL");
   NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), NGPDE_ERR_DIMENSION_MISMATCH, "ngpde_dense_backward: rows must be in [0, 2^31)");
   if (n == 0) {
-    NGPDE_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)din * dout * 4, stream));
-    if (dbias) NGPDE_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)dout * 4, stream));
+    { const int32_t zs = launch_zero(dweight, (size_t)din * dout * 4, stream); if (zs) return zs; }
+    if (dbias) { const int32_t zs = launch_zero(dbias, (size_t)dout * 4, stream); if (zs) return zs; }
     return NGPDE_OK;
   }
   NGPDE_REQUIRE(weight && dy && (z || act == NGPDE_ACT_IDENTITY), NGPDE_ERR_INVALID_ARGUMENT,
@@ -168,7 +168,7 @@ int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_backward: graph is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   if (g->n_edges == 0) {
-    if (dh && g->n_nodes) NGPDE_HIP_CHECK(hipMemsetAsync(dh, 0, (size_t)g->n_nodes * cin * 4, stream));
+    if (dh && g->n_nodes) { const int32_t zs = launch_zero(dh, (size_t)g->n_nodes * cin * 4, stream); if (zs) return zs; }
     return NGPDE_OK;
   }
   NGPDE_REQUIRE(cin > 0 && cout > 0 && k && h && dm, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_backward: bad arguments");

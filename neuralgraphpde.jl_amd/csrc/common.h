@@ -152,6 +152,7 @@ int fused_num_slabs(int64_t n_nodes, int d);   // <= fused_num_blocks: slabs the
 int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
 // ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream);
+int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-capture-safe replacement of hipMemsetAsync(ptr, 0, bytes)
 bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
 int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                              float *out, float *alpha, hipStream_t stream);

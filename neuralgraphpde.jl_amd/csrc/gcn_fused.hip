@@ -1053,6 +1053,23 @@ int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope
   return NGPDE_OK;
 }
 
+namespace {
+__global__ void zero_bytes_kernel(unsigned *__restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+// Zero a 4-byte-aligned device buffer with a KERNEL.  Used instead of hipMemsetAsync wherever a caller may capture the call
+// into a HIP graph: a memset node was observed not to be ordered reliably against the neighbouring kernel nodes on replays.
+int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE((reinterpret_cast<uintptr_t>(ptr) & 3) == 0 && bytes % 4 == 0, NGPDE_ERR_INVALID_ARGUMENT, "launch_zero: unaligned buffer");
+  const size_t n = bytes / 4;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, (unsigned *)ptr, n);
+  NGPDE_LAUNCH_CHECK("zero_bytes_kernel");
+  return NGPDE_OK;
+}
+
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream) {
   if (len == 0) return NGPDE_OK;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + 63) / 64), dim3(1024), 0, stream, slab, n_slabs, len, ct, out);

@@ -112,11 +112,6 @@ struct Prof {
   }
 };
 
-__global__ void zero_kernel(float4 *__restrict__ p, size_t n4) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 int32_t dev_alloc(float **p, size_t elems) {
   *p = nullptr;
   NGPDE_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(elems, 1) * sizeof(float)));
@@ -189,8 +184,7 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
   // zero the slabs with a kernel, not hipMemsetAsync: a memset node captured into the graph is not reliably ordered before
   // the first kernel node on replays after the first (observed: dW drifting in the 7th digit from the second replay on,
   // garbage with unpaired workgroups; eager launches were always right)
-  hipLaunchKernelGGL(zero_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<float4 *>(p->slabs), p->slab_bytes / 16);
-  NGPDE_LAUNCH_CHECK("zero_kernel");
+  if ((st = launch_zero(p->slabs, p->slab_bytes, stream))) return st;
   {  // K-bar of the last stage of the last step, then layer 2's dense backward
     FusedBwdArgs a;
     a.g = p->g; a.d = p->d; a.act = p->act;
