@@ -107,6 +107,8 @@ class NeuralODE(AbstractExplicitLayer):
         return self.model.statelength()
 
     # -- is the right-hand side the tutorial's two-GCNConv chain on one graph? ---------------------
+    max_plans = 2   # device-resident solver plans kept per NeuralODE (forward-only and forward+backward of the current graph)
+
     def _gcn2(self, ps, st):
         m = self.model
         if not (isinstance(m, Chain) and len(m.chain) == 2 and all(isinstance(l, GCNConv) for l in m.chain)):
@@ -134,6 +136,10 @@ class NeuralODE(AbstractExplicitLayer):
         if plan is None:
             plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward)
             self._plans[key] = plan
+            while len(self._plans) > self.max_plans:        # a plan owns its tape (GBs): keep only the most recent ones
+                self._plans.pop(next(iter(self._plans)))     # (a training loop that swaps the graph every minibatch)
+        else:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
         return plan
 
     def __call__(self, x, ps, st):
