@@ -72,6 +72,10 @@ class _Handle:
                     w = np.ascontiguousarray(_to_numpy(w), dtype=np.float32)
                     wp = w.ctypes.data
                 _lib.check(lib.ngpde_graph_set_gcn_norm(self.ptr, int(add_self_loops), wp, int(weighted)))
+            if g._shared.get("order") is None:
+                order = np.empty(g.num_nodes, dtype=np.int32)
+                _lib.check(lib.ngpde_graph_node_order(self.ptr, order.ctypes.data))
+                g._shared["order"] = order
             return
         if not torch.cuda.is_available():
             raise _lib.NgpdeError(_lib.ERR_HIP, "no HIP device: the derived-graph handle lives in HBM (there is no CPU fallback)")

@@ -197,6 +197,9 @@ def test_full_size_host_and_device_builders_agree(which):
 
 
 def test_batch_reuses_member_orders_and_layers_agree(monkeypatch):
+    import os
+    if os.environ.get("NGPDE_HOST_GRAPH_BUILD") == "1":
+        pytest.skip("order reuse is a feature of the device builder path")
     g1 = ng.rand_graph(150, 900, seed=1)
     g2 = ng.rand_graph(90, 500, seed=2)
     gb = ng.batch([g1, g2, g1])

@@ -529,6 +529,7 @@ def test_gat_as_ode_right_hand_side_generic_solver_path():
 
 @pytest.mark.parametrize("aggr", ["mean", "+", "max", "min"])
 def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_FUSED_EDGE", raising=False)      # (the suite may run under that switch)
     # MPPDE shape of BASELINE config 4 at test size: h = 64, phi 132 => 64 => 64 swish, periodic mesh, 3 trajectories
     n, G, h = 256, 3, 64
     idx = np.arange(n)
