@@ -46,7 +46,9 @@ typedef enum {
   NGPDE_ERR_STATE = -6               /* call order violated (e.g. norm not set, backward before forward) */
 } ngpde_status_t;
 
-/* NNlib activation names used by the reference's layers (src/layers.jl:180, Lux Dense). */
+/* NNlib activation names used by the reference's layers (src/layers.jl:180, Lux Dense).  exp / log / reciprocal are the
+ * hardware v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp): tanh, sigmoid, swish, gelu (tanh form, as NNlib 0.8), elu and softplus
+ * are within ~2e-7 absolute of the libm forms, two orders below the parity tolerance of 1e-4. */
 typedef enum {
   NGPDE_ACT_IDENTITY = 0, NGPDE_ACT_RELU = 1, NGPDE_ACT_TANH = 2, NGPDE_ACT_SIGMOID = 3,
   NGPDE_ACT_SWISH = 4, NGPDE_ACT_GELU = 5, NGPDE_ACT_LEAKYRELU = 6, NGPDE_ACT_ELU = 7,
