@@ -115,6 +115,7 @@ struct FusedFwdArgs {
   float *y = nullptr;            // [N][d] act(z)
   float *save_agg = nullptr;     // [N][d] or null
   float *save_z = nullptr;       // [N][d] or null
+  uint8_t *save_mask = nullptr;  // [fused_mask_bytes] or null: 4 sign bits of z per thread and row (relu' for the pullback)
   // optional Runge-Kutta stage combination evaluated on the freshly computed rows of y
   bool has_comb = false;
   Comb comb;
@@ -138,7 +139,8 @@ struct FusedBwdArgs {
   float v_scale = 1.f;           // K-bar = v_scale * V
   // dense part (skipped when do_dense == false)
   bool do_dense = true;
-  const float *z = nullptr;      // [N][d] saved pre-activation (or y for relu/identity)
+  const float *z = nullptr;      // [N][d] saved pre-activation (or y for relu/identity); unused when mask is given
+  const uint8_t *mask = nullptr; // sign bits written by the forward launch (same tile / thread layout), relu only
   const float *saved_agg = nullptr;  // [N][d]
   const float *wt = nullptr;     // [d][d]
   float *g_out = nullptr;        // [N][d]  dZ * W
@@ -148,6 +150,7 @@ struct FusedBwdArgs {
 };
 int fused_tile_rows();
 int fused_num_blocks(int64_t n_nodes);
+size_t fused_mask_bytes(int64_t n_nodes, int d);   // bytes of one sign-bit mask (FusedFwdArgs::save_mask)
 int fused_num_slabs(int64_t n_nodes, int d);   // <= fused_num_blocks: slabs the backward launches actually write
 int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
 // ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum

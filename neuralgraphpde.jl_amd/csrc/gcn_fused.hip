@@ -416,6 +416,7 @@ struct FwdK {
   int has_comb;
   CombDev comb;
   float *comb_out;
+  uint8_t *save_mask;
   int order;   // bit 0: W fetched after the aggregation, bit 1: stage terms fetched after the aggregation.  Both on by default:
                // everything issued at kernel start competes in the memory system with the halo rows the workgroup waits for
                // (measured at C2: layer-1 5.98 -> 5.85 us, layer-2 + stage 7.46 -> 7.06 us)
@@ -525,6 +526,9 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
       const size_t idx4 = (size_t)sc[r].x * G::LPR + q;
       const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[(grp * G::R + r) * G::TS + 4 * q]), b4);
       if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
+      if (p.save_mask)   // relu'(z) for the pullback: 4 bits instead of re-reading 16 bytes of y
+        p.save_mask[((size_t)tile * G::R + r) * kThreads + tid] =
+            (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
       const float4 yv = f4_act(act, z);
       reinterpret_cast<float4 *>(p.y)[idx4] = yv;
       if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_finish(p.comb, yv, cterm[r]);
@@ -549,6 +553,7 @@ struct BwdK {
   float v_scale;
   int do_dense, tape_late, order;
   const float *z, *saved_agg, *wt;
+  const uint8_t *mask;
   float *g_out, *slab_dw, *slab_db;
   NGPDE_STAMP_FIELD
 };
@@ -602,6 +607,10 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
 #pragma unroll
     for (int r = 0; r < G::R; ++r) sc[r].x = -1;
   }
+  // relu sign bits written by the forward launch of the same layer evaluation: addressed by (tile, thread), no dependency
+  unsigned mk[G::R];
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) mk[r] = (p.mask && p.do_dense) ? p.mask[((size_t)tile * G::R + r) * kThreads + tid] : 0u;
   // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
   float4 wreg[G::W4];
   // slab fragments of this wave's dW tiles and this thread's db column: consumed after the MFMAs
@@ -637,7 +646,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
 #pragma unroll
       for (int r = 0; r < G::R; ++r) {
         const size_t idx4 = (size_t)max(sc[r].x, 0) * G::LPR + q;
-        zrow[r] = load_stream4(&reinterpret_cast<const float4 *>(p.z)[idx4]);
+        if (!p.mask) zrow[r] = load_stream4(&reinterpret_cast<const float4 *>(p.z)[idx4]);
         xrow[r] = load_stream4(&reinterpret_cast<const float4 *>(p.saved_agg)[idx4]);
       }
     }
@@ -681,7 +690,11 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       if (p.do_dense) {
         float4 dz = f4_zero(), xa = f4_zero();
         if (ok) {
-          dz = f4_mul(kbar, f4_dact(act, zrow[r]));
+          if (p.mask)
+            dz = make_float4((mk[r] & 1u) ? kbar.x : 0.f, (mk[r] & 2u) ? kbar.y : 0.f, (mk[r] & 4u) ? kbar.z : 0.f,
+                             (mk[r] & 8u) ? kbar.w : 0.f);
+          else
+            dz = f4_mul(kbar, f4_dact(act, zrow[r]));
           xa = xrow[r];
         }
         *reinterpret_cast<float4 *>(&ldsDZ[(grp * G::R + r) * G::TS + 4 * q]) = dz;
@@ -927,6 +940,10 @@ extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf, int32_t m
 bool fused_supported(int din, int dout) { return din == dout && (din == 16 || din == 32 || din == 64 || din == 128); }
 int fused_tile_rows() { return kTM; }
 int fused_num_blocks(int64_t n_nodes) { return (int)((n_nodes + kTM - 1) / kTM); }
+size_t fused_mask_bytes(int64_t n_nodes, int d) {
+  const int lpr = d / 4, groups = kThreads / lpr, r = (kTM + groups - 1) / groups;   // Geo<d>::R
+  return (size_t)fused_num_blocks(n_nodes) * r * kThreads;
+}
 // slabs the backward launches write (paired workgroups share one)
 int fused_num_slabs(int64_t n_nodes, int d) {
   const int nb = fused_num_blocks(n_nodes);
@@ -946,6 +963,7 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
+  k.save_mask = a.save_mask;
   {   // default 3; NGPDE_FWD_ORDER=0..3 for A/B runs of the load placement
     static const int ord = [] { const char *e = std::getenv("NGPDE_FWD_ORDER"); return e ? atoi(e) : 3; }();
     k.order = ord;
@@ -993,6 +1011,8 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb);
   k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;
   k.do_dense = a.do_dense ? 1 : 0; k.z = a.z; k.saved_agg = a.saved_agg; k.wt = a.wt;
+  k.mask = a.mask;
+  NGPDE_REQUIRE(!a.mask || a.act == NGPDE_ACT_RELU, NGPDE_ERR_INVALID_ARGUMENT, "sign-bit masks carry relu' only");
   k.tape_late = a.has_comb ? 0 : 1;
   {
     static const int ord = [] { const char *e = std::getenv("NGPDE_BWD_ORDER"); return e ? atoi(e) : 1; }();

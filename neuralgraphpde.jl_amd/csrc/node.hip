@@ -70,6 +70,12 @@ struct ngpde_node {
   float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
   float *tape = nullptr;
   size_t tape_bytes = 0;
+  // relu with backward: the pullback needs only the sign of z, so each evaluation keeps two aggregated inputs on the tape
+  // plus two 4-bit-per-value masks; the layer outputs live in 2 S buffers that every step re-uses
+  bool mask_mode = false;
+  float *ybuf = nullptr;         // [S][2][row_elems]
+  uint8_t *masks = nullptr;      // [n_steps][S][2][mask_bytes]
+  size_t mask_bytes = 0;
   float *lam = nullptr, *g1 = nullptr, *g2 = nullptr;
   std::vector<float *> ubar;
   float *slabs = nullptr;
@@ -87,7 +93,14 @@ struct ngpde_node {
   // 4 = Z1, 5 = Z2 (only for activations whose derivative needs the pre-activation)
   float *slot(int step, int stage, int k) const {
     const int s = with_bwd ? step : 0;
+    if (mask_mode) {
+      if (k == 1 || k == 3) return ybuf + ((size_t)stage * 2 + (k == 3 ? 1 : 0)) * row_elems;
+      return tape + ((size_t)(s * tb.S + stage) * 2 + (k == 2 ? 1 : 0)) * row_elems;
+    }
     return tape + ((size_t)(s * tb.S + stage) * slots + k) * row_elems;
+  }
+  uint8_t *mask_slot(int step, int stage, int layer) const {
+    return masks + ((size_t)(step * tb.S + stage) * 2 + (layer - 1)) * mask_bytes;
   }
 };
 
@@ -131,6 +144,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f1.y = p->slot(n, i, 1);
       f1.save_agg = p->with_bwd ? p->slot(n, i, 0) : nullptr;
       f1.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 4) : nullptr;
+      f1.save_mask = p->mask_mode ? p->mask_slot(n, i, 1) : nullptr;
       if (prof) prof->want(0, &f1.ev_start, &f1.ev_stop);
       if ((st = launch_fused_fwd(f1, stream))) return st;
       FusedFwdArgs f2;
@@ -140,6 +154,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f2.y = p->slot(n, i, 3);
       f2.save_agg = p->with_bwd ? p->slot(n, i, 2) : nullptr;
       f2.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 5) : nullptr;
+      f2.save_mask = p->mask_mode ? p->mask_slot(n, i, 2) : nullptr;
       // epilogue: next stage input, or the step update after the last stage
       const bool last = (i == tb.S - 1);
       const std::vector<double> &row = last ? tb.b : tb.a[i + 1];
@@ -165,6 +180,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
 
 void fill_dense(const ngpde_node *p, FusedBwdArgs &a, int layer, int step, int stage) {
   a.do_dense = true;
+  if (p->mask_mode) a.mask = p->mask_slot(step, stage, layer);
   if (layer == 2) {
     a.z = p->needs_z ? p->slot(step, stage, 5) : p->slot(step, stage, 3);
     a.saved_agg = p->slot(step, stage, 2);
@@ -288,6 +304,8 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
     if (b) (void)hipFree(b);
   for (float *b : p->ubar)
     if (b) (void)hipFree(b);
+  if (p->ybuf) (void)hipFree(p->ybuf);
+  if (p->masks) (void)hipFree(p->masks);
   delete p;
   return NGPDE_OK;
 }
@@ -315,7 +333,9 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   p->n = g->n_nodes;
   p->row_elems = (size_t)p->n * d;
   p->nb = fused_num_blocks(p->n);
-  p->slots = p->with_bwd ? (p->needs_z ? 6 : 4) : 4;
+  p->mask_mode = p->with_bwd && act == NGPDE_ACT_RELU && std::getenv("NGPDE_NO_MASK") == nullptr;
+  p->slots = p->mask_mode ? 2 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4);
+  p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
   const int S = p->tb.S;
@@ -330,6 +350,14 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->row_elems;
   p->tape_bytes = tape_elems * sizeof(float);
   A(&p->tape, tape_elems);
+  if (p->mask_mode) {
+    A(&p->ybuf, (size_t)S * 2 * p->row_elems);
+    if (st == NGPDE_OK) {
+      const size_t mb = (size_t)n_steps * S * 2 * p->mask_bytes;
+      if (hipMalloc((void **)&p->masks, std::max<size_t>(mb, 1)) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipMalloc of the sign-bit masks failed");
+      else p->tape_bytes += mb + (size_t)S * 2 * p->row_elems * sizeof(float);
+    }
+  }
   if (p->with_bwd) {
     A(&p->lam, p->row_elems); A(&p->g1, p->row_elems); A(&p->g2, p->row_elems);
     p->ubar.assign(S, nullptr);
