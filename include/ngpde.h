@@ -98,6 +98,34 @@ enum {
 int32_t ngpde_graph_array(const ngpde_graph_t *g, int32_t direction, int32_t which, const void **ptr, size_t *bytes);
 int32_t ngpde_graph_destroy(ngpde_graph_t *g);
 int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_graphs);
+/* ------------------------------------------------------------------------------------------------
+ * Neighbour search on the device: the COO lists that GNNGraphs.radius_graph(points, r; graph_indicator, self_loops, dir)
+ * and knn_graph(points, k; ...) build on the host with NearestNeighbors.jl trees ([UPSTREAM] GraphNeuralNetworks.jl,
+ * re-exported at src/NeuralGraphPDE.jl:4); the BASELINE workloads C2 and C5 are such graphs.
+ *   points     device float, (dim x n) column-major = [n][dim], dim = 1, 2 or 3
+ *   graph_id   device int32[n] or NULL: only points of the same graph are connected (ids id_base .. id_base+n_graphs-1)
+ *   dir_out    0 = dir :in (neighbours are the sources, the point is the target; the default), 1 = :out
+ *   s, t       device int32 outputs with index_base added, ordered by point; the neighbours of a point ascending by index
+ *              (radius graph) or by (distance, index) (k-NN).  The reference's edge order is the tree's traversal order;
+ *              the edge SET is the same.
+ * Distances are sums of float squares in coordinate order without fused multiply-add; a pair is connected iff
+ * d2 <= r*r (float).  ngpde_radius_graph with s == t == NULL only counts; otherwise `capacity` entries are available and
+ * *n_edges (host) receives the number written.  k-NN writes exactly n*k entries; coincident points are ordered by index
+ * (the reference keeps a point's own entry only while it is among the k+1 nearest).  Both synchronise `stream`.
+ * ngpde_spatial_order: a node permutation (device int32[n]) along a space-filling curve through the points -- Hilbert in
+ * 2-D, Morton in 3-D, the coordinate in 1-D, graph by graph -- usable as `order` of ngpde_graph_create_device, so that a
+ * structure never seen before gets its locality schedule without a host traversal.
+ * ---------------------------------------------------------------------------------------------- */
+#define NGPDE_KNN_MAX_K 128
+int32_t ngpde_radius_graph(int64_t n, int32_t dim, const float *points, float r, const int32_t *graph_id, int32_t n_graphs,
+                           int32_t id_base, int32_t self_loops, int32_t dir_out, int32_t index_base, int64_t capacity, int32_t *s,
+                           int32_t *t, int64_t *n_edges, ngpde_stream_t stream);
+int32_t ngpde_knn_graph(int64_t n, int32_t dim, const float *points, int32_t k, const int32_t *graph_id, int32_t n_graphs,
+                        int32_t id_base, int32_t self_loops, int32_t dir_out, int32_t index_base, int32_t *s, int32_t *t,
+                        ngpde_stream_t stream);
+int32_t ngpde_spatial_order(int64_t n, int32_t dim, const float *points, const int32_t *graph_id, int32_t n_graphs, int32_t id_base,
+                            int32_t *order, ngpde_stream_t stream);
+
 /* Device arrays of the derived graph (for callers that batch / inspect): CSR by target.
  * rowptr: int32[n_nodes+1]; col: int32[n_edges] source node of each entry; eid: int32[n_edges]
  * position of the entry in the caller's COO list. */

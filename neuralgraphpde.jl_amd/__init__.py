@@ -6,7 +6,7 @@ Everything that computes goes through libngpde_hip.so (include/ngpde.h); there i
 """
 from . import _lib
 from ._lib import ArgumentError, DimensionMismatch, NgpdeError
-from .graphs import EMPTYGRAPH, GNNGraph, batch, rand_graph
+from .graphs import EMPTYGRAPH, GNNGraph, batch, knn_graph, radius_graph, rand_graph
 from .utils import drop, updategraph, wrapgraph
 from .layers import (AbstractExplicitLayer, AbstractGNNContainerLayer, AbstractGNNLayer, Chain, Dense,
                      GCNConv, apply, glorot_normal, glorot_uniform, setup, to_device, zeros32)
@@ -18,5 +18,5 @@ __all__ = [
     "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",
     "ExplicitEdgeConv", "VMHConv", "MPPDEConv", "GNOConv", "SpectralConv", "GATConv",
     "setup", "apply", "to_device", "updategraph", "wrapgraph", "drop", "GNNGraph", "EMPTYGRAPH", "rand_graph",
-    "batch", "glorot_uniform", "glorot_normal", "zeros32", "NgpdeError", "DimensionMismatch", "ArgumentError",
+    "batch", "radius_graph", "knn_graph", "glorot_uniform", "glorot_normal", "zeros32", "NgpdeError", "DimensionMismatch", "ArgumentError",
 ]

@@ -46,6 +46,9 @@ SIGNATURES = {
     "ngpde_graph_create": (_i32, [_i64, _i64, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "ngpde_graph_create_device": (_i32, [_i64, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_vp)]),
     "ngpde_graph_node_order": (_i32, [_vp, _vp]),
+    "ngpde_radius_graph": (_i32, [_i64, _i32, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
+    "ngpde_knn_graph": (_i32, [_i64, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ngpde_spatial_order": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "ngpde_graph_set_gcn_norm_device": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "ngpde_graph_array": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "ngpde_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),

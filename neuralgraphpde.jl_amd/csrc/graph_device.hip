@@ -228,6 +228,15 @@ __global__ void all_fit_kernel(int64_t n_tiles, const int2 *__restrict__ info, i
   else atomicMax(bad + 2, info[i].x);
 }
 
+// a caller-supplied node order must be a permutation of 0..n-1: the schedule kernels index with it
+__global__ void order_check_kernel(int64_t n, const int32_t *__restrict__ order, int32_t *__restrict__ seen, int32_t *__restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t o = order[i];
+  if (o < 0 || o >= n) atomicOr(bad, 1);
+  else if (atomicAdd(&seen[o], 1) != 0) atomicOr(bad, 1);
+}
+
 template <class T>
 int32_t dalloc(T **p, size_t count) {
   *p = nullptr;
@@ -412,6 +421,18 @@ int32_t graph_create_device(int64_t n_nodes, int64_t n_edges, const I *s, const 
   g->max_out_degree = h_max[1];
   if ((st = dalloc(&g->order, (size_t)n_nodes))) return bail(st);
   if (order_dev) {
+    int32_t *seen = nullptr;
+    if ((st = sc.get(&seen, (size_t)n_nodes + 1))) return bail(st);
+    if (hipMemsetAsync(seen, 0, ((size_t)n_nodes + 1) * sizeof(int32_t), stream) != hipSuccess)
+      return bail(fail(NGPDE_ERR_HIP, "hipMemsetAsync failed"));
+    int32_t h_seen = 0;
+    if (n_nodes) {
+      hipLaunchKernelGGL(order_check_kernel, dim3(blocks_for(n_nodes)), dim3(kB), 0, stream, n_nodes, order_dev, seen, seen + n_nodes);
+      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h_seen, seen + n_nodes, sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+          hipStreamSynchronize(stream) != hipSuccess)
+        return bail(fail(NGPDE_ERR_HIP, "checking the node order failed"));
+    }
+    if (h_seen) return bail(fail(NGPDE_ERR_INVALID_ARGUMENT, "order is not a permutation of the %lld nodes", (long long)n_nodes));
     if (n_nodes && hipMemcpyAsync(g->order, order_dev, (size_t)n_nodes * sizeof(int32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return bail(fail(NGPDE_ERR_HIP, "copying the node order failed"));
   } else {   // the one sequential step: BFS-grown clusters on the host, from the downloaded lists

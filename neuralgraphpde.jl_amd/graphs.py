@@ -265,6 +265,82 @@ def rand_graph(n, m, *, bidirected=True, seed=None):
     return GNNGraph(s, t, num_nodes=n, index_base=0)
 
 
+def _device_points(points):
+    """(dim x n) array / tensor -> contiguous float32 [n][dim] tensor on the current HIP device"""
+    if not torch.cuda.is_available():
+        raise _lib.NgpdeError(_lib.ERR_HIP, "no HIP device: the neighbour search runs on the GPU (there is no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = points if isinstance(points, torch.Tensor) else torch.as_tensor(np.asarray(points))
+    if t.dim() == 1:
+        t = t.reshape(1, -1)
+    if t.dim() != 2:
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "DimensionMismatch: points must be a (dim x n) matrix")
+    return t.to(dev, torch.float32).T.contiguous(), dev
+
+
+def _device_indicator(graph_indicator, n, dev):
+    if graph_indicator is None:
+        return None, 1
+    gi = graph_indicator if isinstance(graph_indicator, torch.Tensor) else torch.as_tensor(np.asarray(graph_indicator))
+    gi = gi.reshape(-1).to(dev, torch.int32).contiguous()
+    if gi.numel() != n:
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     f"DimensionMismatch: graph_indicator has {gi.numel()} entries for {n} points")
+    return gi, (int(gi.max().item()) if n else 1)      # 1-based ids as in GNNGraphs: the number of graphs is the largest id
+
+
+def _graph_from_device_coo(s, t, n, num_graphs, dev, pts, gi, locality):
+    g = GNNGraph(s.cpu().numpy(), t.cpu().numpy(), num_nodes=n, index_base=0, num_graphs=num_graphs)
+    g._shared[("coo", str(dev))] = (s, t)            # the handle builder takes the device lists as they are
+    if locality == "spatial" and n:
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().ngpde_spatial_order(n, pts.shape[1], _lib.ptr(pts), _lib.ptr(gi), num_graphs, 1, _lib.ptr(order),
+                                                   _lib.current_stream()))
+        g._shared["order"] = order.cpu().numpy()
+    elif locality != "bfs":
+        raise ValueError("locality must be 'bfs' or 'spatial'")
+    return g
+
+
+def radius_graph(points, r, *, graph_indicator=None, self_loops=False, dir="in", locality="bfs"):
+    """[UPSTREAM GNNGraphs.radius_graph(points, r; graph_indicator, self_loops, dir), re-exported at
+    /root/reference/src/NeuralGraphPDE.jl:4] every point is linked to the points within distance r (<=) of its own graph.
+    points: (dim x n), dim <= 3; graph_indicator: 1-based graph id per point.  Searched on the device
+    (ngpde_radius_graph); edges come ordered by point, neighbours ascending.  locality="spatial" takes the tile
+    schedule from a space-filling curve through the points instead of a host traversal of the graph."""
+    pts, dev = _device_points(points)
+    n, dim = pts.shape
+    gi, num_graphs = _device_indicator(graph_indicator, n, dev)
+    lib = _lib.load()
+    ne = C.c_int64(0)
+    if dir not in ("in", "out"):
+        raise ValueError("dir must be 'in' or 'out'")
+    args = (n, dim, _lib.ptr(pts), float(r), _lib.ptr(gi), num_graphs, 1, int(bool(self_loops)), int(dir == "out"), 0)
+    _lib.check(lib.ngpde_radius_graph(*args, 0, None, None, C.byref(ne), _lib.current_stream()))
+    m = int(ne.value)
+    s = torch.empty(m, dtype=torch.int32, device=dev)
+    t = torch.empty(m, dtype=torch.int32, device=dev)
+    if m:
+        _lib.check(lib.ngpde_radius_graph(*args, m, _lib.ptr(s), _lib.ptr(t), C.byref(ne), _lib.current_stream()))
+    return _graph_from_device_coo(s, t, n, num_graphs, dev, pts, gi, locality)
+
+
+def knn_graph(points, k, *, graph_indicator=None, self_loops=False, dir="in", locality="bfs"):
+    """[UPSTREAM GNNGraphs.knn_graph(points, k; graph_indicator, self_loops, dir)] every point is linked to its k nearest
+    points of its own graph (itself included only with self_loops=true).  Searched on the device (ngpde_knn_graph); the
+    neighbours of a point come nearest first, coincident distances by index."""
+    pts, dev = _device_points(points)
+    n, dim = pts.shape
+    gi, num_graphs = _device_indicator(graph_indicator, n, dev)
+    if dir not in ("in", "out"):
+        raise ValueError("dir must be 'in' or 'out'")
+    s = torch.empty(n * int(k), dtype=torch.int32, device=dev)
+    t = torch.empty(n * int(k), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().ngpde_knn_graph(n, dim, _lib.ptr(pts), int(k), _lib.ptr(gi), num_graphs, 1, int(bool(self_loops)),
+                                           int(dir == "out"), 0, _lib.ptr(s), _lib.ptr(t), _lib.current_stream()))
+    return _graph_from_device_coo(s, t, n, num_graphs, dev, pts, gi, locality)
+
+
 def batch(graphs):
     """MLUtils.batch(::Vector{GNNGraph}) [UPSTREAM]: block-diagonal union; features concatenated
     along the last dimension (test/runtests.jl:92)."""

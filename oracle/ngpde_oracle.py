@@ -834,6 +834,131 @@ def derived_graph(s, t, n, order=None, add_self_loops_=True, edge_weight=None, w
 
 
 # --------------------------------------------------------------------------------------------
+# Neighbour search: GNNGraphs.radius_graph / knn_graph [UPSTREAM GraphNeuralNetworks.jl, re-exported at
+# src/NeuralGraphPDE.jl:4; NearestNeighbors.jl inrange / knn underneath], restated as brute force over all pairs.
+# float32 arithmetic spelled out so that the device search can be compared bit for bit: d2 = sum over coordinates,
+# in order, of (p_i - p_j)^2, each operation rounded to float32; neighbours iff d2 <= r*r (float32 product).
+# Canonical edge order (the reference's is the tree's traversal order): by point, neighbours ascending by index
+# (radius) or by (d2, index) (k-NN).  dir="in": neighbours are sources.  parity unpinned (no Julia here): checked
+# against scipy's cKDTree in float64 away from the threshold (tests/test_oracle.py).
+# --------------------------------------------------------------------------------------------
+
+
+def _pair_d2_f32(P, Q):
+    d2 = np.zeros((P.shape[0], Q.shape[0]), dtype=np.float32)
+    for d in range(P.shape[1]):
+        df = P[:, None, d] - Q[None, :, d]
+        d2 = d2 + df * df
+    return d2
+
+
+def _points_rows(points):
+    P = np.asarray(points, dtype=np.float32)
+    if P.ndim == 1:
+        P = P.reshape(1, -1)
+    return np.ascontiguousarray(P.T)          # [n][dim]
+
+
+def radius_graph(points, r, graph_indicator=None, self_loops=False, dir="in", chunk=1024):
+    """(s, t) 0-based.  points (dim x n)."""
+    P = _points_rows(points)
+    n = P.shape[0]
+    gi = None if graph_indicator is None else np.asarray(graph_indicator).reshape(-1)
+    r2 = np.float32(r) * np.float32(r)
+    me, nb = [], []
+    for a in range(0, n, chunk):
+        d2 = _pair_d2_f32(P[a:a + chunk], P)
+        hit = d2 <= r2
+        if gi is not None:
+            hit &= gi[a:a + chunk, None] == gi[None, :]
+        if not self_loops:
+            rows = np.arange(a, min(a + chunk, n))
+            hit[rows - a, rows] = False
+        i, j = np.nonzero(hit)                 # row-major: by point, neighbours ascending
+        me.append(i + a)
+        nb.append(j)
+    me = np.concatenate(me) if me else np.zeros(0, np.int64)
+    nb = np.concatenate(nb) if nb else np.zeros(0, np.int64)
+    return (nb, me) if dir == "in" else (me, nb)
+
+
+def knn_graph(points, k, graph_indicator=None, self_loops=False, dir="in", chunk=1024):
+    """(s, t) 0-based, exactly n*k edges; the k smallest (d2, index) pairs per point."""
+    P = _points_rows(points)
+    n = P.shape[0]
+    gi = None if graph_indicator is None else np.asarray(graph_indicator).reshape(-1)
+    me, nb = [], []
+    for a in range(0, n, chunk):
+        d2 = _pair_d2_f32(P[a:a + chunk], P).astype(np.float64)
+        if gi is not None:
+            d2[gi[a:a + chunk, None] != gi[None, :]] = np.inf
+        if not self_loops:
+            rows = np.arange(a, min(a + chunk, n))
+            d2[rows - a, rows] = np.inf
+        idx = np.argsort(d2, axis=1, kind="stable")[:, :k]     # stable: ties by index
+        if np.isinf(np.take_along_axis(d2, idx, axis=1)).any():
+            raise ValueError("knn_graph: a graph has fewer than k (+1) points")
+        me.append(np.repeat(np.arange(a, a + d2.shape[0]), k))
+        nb.append(idx.reshape(-1))
+    me = np.concatenate(me) if me else np.zeros(0, np.int64)
+    nb = np.concatenate(nb) if nb else np.zeros(0, np.int64)
+    return (nb, me) if dir == "in" else (me, nb)
+
+
+def _hilbert2(x, y, bits):
+    x, y = x.astype(np.uint64), y.astype(np.uint64)
+    d = np.zeros(x.shape, dtype=np.uint64)
+    side = np.uint64(1 << bits)
+    s = 1 << (bits - 1)
+    while s > 0:
+        su = np.uint64(s)
+        rx = ((x & su) > 0).astype(np.uint64)
+        ry = ((y & su) > 0).astype(np.uint64)
+        d += su * su * ((np.uint64(3) * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, side - np.uint64(1) - x, x)
+        y = np.where(flip, side - np.uint64(1) - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s >>= 1
+    return d
+
+
+def _spread3(v):
+    v = v.astype(np.uint64) & np.uint64(0x3ff)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x030000ff)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x0300f00f)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x030c30c3)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+    return v
+
+
+def spatial_order(points, graph_indicator=None, id_base=0):
+    """node permutation along a space-filling curve (Hilbert 2-D, Morton 3-D, the coordinate 1-D), graph by graph;
+    coordinates quantised in float32 exactly as the device does; ties by index (stable sort)."""
+    P = _points_rows(points)
+    n, dim = P.shape
+    if n == 0:
+        return np.zeros(0, np.int32)
+    bits = {1: 30, 2: 16, 3: 10}[dim]
+    lo = P.min(axis=0)
+    ext = (P.max(axis=0) - lo).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        scale = np.where(ext > 0, np.float32(1 << bits) / ext, np.float32(0)).astype(np.float32)
+    q = ((P - lo).astype(np.float32) * scale).astype(np.float32)
+    q = np.clip(q.astype(np.int64), 0, (1 << bits) - 1)
+    if dim == 1:
+        code = q[:, 0].astype(np.uint64)
+    elif dim == 2:
+        code = _hilbert2(q[:, 0], q[:, 1], bits)
+    else:
+        code = (_spread3(q[:, 0]) << np.uint64(2)) | (_spread3(q[:, 1]) << np.uint64(1)) | _spread3(q[:, 2])
+    g = np.zeros(n, np.uint64) if graph_indicator is None else (np.asarray(graph_indicator).reshape(-1) - id_base).astype(np.uint64)
+    key = (g << np.uint64(32)) | code
+    return np.argsort(key, kind="stable").astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------
 # Optimiser rules on the flat parameter vector [UPSTREAM Optimisers.jl Adam / Rprop, published update rules;
 # reference call sites docs/src/tutorials/graph_node.md:122-129, VMH.md:97].  float32 arithmetic, as the
 # reference's Float32 ComponentArray.  parity unpinned (no Julia here); checked against closed forms in tests.

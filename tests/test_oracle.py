@@ -365,3 +365,76 @@ def test_optimiser_rules_closed_forms():
     xr2, rs = O.rprop_step(xr, np.array([5.0, 3.0, 1.0], np.float32), rs)
     np.testing.assert_allclose(rs["step"], [0.12, 0.05, 0.1], rtol=1e-6)
     np.testing.assert_allclose(xr2 - xr, [-0.12, 0.0, -0.1], rtol=1e-6, atol=1e-9)
+
+
+# ---- neighbour search restatement (radius_graph / knn_graph / spatial_order) -------------------------------------
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_radius_and_knn_restatement_against_kdtree(dim):
+    """the brute-force float32 restatement against scipy's cKDTree on the same points in float64, with the radius
+    chosen in a gap of the pair-distance distribution so that float32 rounding cannot move a pair across it"""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(dim)
+    n = 700
+    P = rng.random((dim, n)).astype(np.float32)
+    P64 = P.T.astype(np.float64)
+    tree = cKDTree(P64)
+    r0 = {1: 0.004, 2: 0.06, 3: 0.15}[dim]
+    dd = np.sort(np.sqrt(((P64[:, None, :] - P64[None, :, :]) ** 2).sum(-1)).reshape(-1))
+    k0 = np.searchsorted(dd, r0)
+    gaps = dd[k0:k0 + 200][1:] - dd[k0:k0 + 200][:-1]
+    j = int(np.argmax(gaps))
+    r = float(0.5 * (dd[k0 + j] + dd[k0 + j + 1]))
+    assert gaps[j] > 1e-6 * r
+    s, t = O.radius_graph(P, r)
+    pairs = tree.query_pairs(r, output_type="ndarray")
+    want = set(map(tuple, pairs.tolist())) | set(map(tuple, pairs[:, ::-1].tolist()))
+    assert set(zip(s.tolist(), t.tolist())) == want
+    assert np.array_equal(np.lexsort((s, t)), np.arange(s.size))               # by target, sources ascending
+    so, to = O.radius_graph(P, r, dir="out")
+    assert np.array_equal(so, t) and np.array_equal(to, s)
+    sl, tl = O.radius_graph(P, r, self_loops=True)
+    assert sl.size == s.size + n
+    # k-NN: same neighbours, nearest first (distinct distances with probability one)
+    k = 7
+    s2, t2 = O.knn_graph(P, k)
+    _, idx = tree.query(P64, k=k + 1)
+    assert np.array_equal(t2, np.repeat(np.arange(n), k))
+    assert np.array_equal(s2.reshape(n, k), idx[:, 1:])
+    s3, _ = O.knn_graph(P, k, self_loops=True)
+    assert np.array_equal(s3.reshape(n, k), idx[:, :k])
+    # graph_indicator: the batch is the union of its members
+    gi = np.repeat([1, 2], n // 2)
+    sb, tb = O.radius_graph(P, r, graph_indicator=gi)
+    a = O.radius_graph(P[:, :n // 2], r)
+    b = O.radius_graph(P[:, n // 2:], r)
+    assert np.array_equal(sb, np.r_[a[0], b[0] + n // 2]) and np.array_equal(tb, np.r_[a[1], b[1] + n // 2])
+    with pytest.raises(ValueError):
+        O.knn_graph(P[:, :5], 5)
+
+
+def test_spatial_order_restatement_properties():
+    rng = np.random.default_rng(0)
+    for dim in (1, 2, 3):
+        P = rng.random((dim, 4096)).astype(np.float32)
+        gi = np.sort(rng.integers(0, 3, 4096))
+        o = O.spatial_order(P, gi)
+        assert sorted(o.tolist()) == list(range(4096))
+        assert np.array_equal(gi[o], np.sort(gi))                             # graph by graph
+        if dim == 1:
+            assert np.all(np.diff(P[0, O.spatial_order(P)]) >= -1e-6)         # the coordinate itself (30-bit quantisation)
+    # Hilbert curve on the full 2^k x 2^k lattice: consecutive cells are edge neighbours
+    k = 5
+    xs, ys = np.meshgrid(np.arange(1 << k), np.arange(1 << k), indexing="ij")
+    d = O._hilbert2(xs.reshape(-1), ys.reshape(-1), k)
+    assert sorted(d.tolist()) == list(range(1 << (2 * k)))
+    o = np.argsort(d)
+    step = np.abs(np.diff(xs.reshape(-1)[o])) + np.abs(np.diff(ys.reshape(-1)[o]))
+    assert np.all(step == 1)
+    # locality: on uniform points 32 consecutive nodes span far less than a random 32-subset
+    P = rng.random((2, 16384)).astype(np.float32)
+    o = O.spatial_order(P)
+    tiles = P[:, o].reshape(2, -1, 32)
+    span = (tiles.max(axis=2) - tiles.min(axis=2)).max(axis=0)
+    assert np.median(span) < 0.1
