@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched", type=int, default=8,
+                    help="N=1 only: after the BASELINE measurement, also time this many trajectories per GPU as one batched "
+                         "graph (reported under 'batched', never in 'value'); 0 = skip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,70 +139,80 @@ def main():
 
     s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
     g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
-    handle = g.handle((True, None, False))
-    plan = _Plan(handle, D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
     lib = _lib.load()
     dv = lambda a: torch.as_tensor(a, device=dev)
-    u0 = dv(u0_h)
-    # parameters as ONE flat vector [w1 | b1 | w2 | b2] (the reference's ComponentArray), gradients likewise
-    pflat = torch.cat([dv(w1_h).reshape(-1), dv(b1_h), dv(w2_h).reshape(-1), dv(b2_h)]).contiguous()
-    w1, b1 = pflat[:D * D], pflat[D * D:D * D + D]
-    w2, b2 = pflat[D * D + D:2 * D * D + D], pflat[2 * D * D + D:]
-    adam_m, adam_v = torch.zeros_like(pflat), torch.zeros_like(pflat)
-    uT, du0 = torch.empty_like(u0), torch.empty_like(u0)
-    seed_grad = torch.ones_like(u0)                       # d sum(u(T)) / d u(T)
-    flat = torch.empty(2 * (D * D + D), dtype=torch.float32, device=dev)   # [dw1 | db1 | dw2 | db2]
-    dw1, db1 = flat[:D * D], flat[D * D:D * D + D]
-    dw2, db2 = flat[D * D + D:2 * D * D + D], flat[2 * D * D + D:]
     stream = torch.cuda.current_stream().cuda_stream
     p = _lib.ptr
-
-    it = [0]
-
-    def step():
-        # one training step: solve, discrete adjoint, gradient all-reduce, fused Adam on the flat vector (1/world folded in)
-        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
-        _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
-        if dist is not None:
-            dist.all_reduce(flat)
-        it[0] += 1
-        _lib.check(lib.ngpde_adam_step(flat.numel(), p(pflat), p(flat), p(adam_m), p(adam_v), 1e-5, 0.9, 0.999, 1e-8, it[0],
-                                       1.0 / world, stream))
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def job(traj, n_steps, n_warmup):
+        """`traj` independent trajectories on this GPU as ONE block-diagonal batched graph (traj = 1: the BASELINE workload).
+        Returns (elapsed seconds of n_steps bench steps, max over ranks; forward / backward ms of one solve; plan)."""
+        gb = g if traj == 1 else ng.batch([g] * traj)
+        handle = gb.handle((True, None, False))
+        plan = _Plan(handle, D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
+        u0 = dv(u0_h) if traj == 1 else torch.cat(
+            [dv(S.normal(1000 + rank + 97 * k, D * N_NODES).reshape(N_NODES, D).astype(np.float32)) for k in range(traj)])
+        # parameters as ONE flat vector [w1 | b1 | w2 | b2] (the reference's ComponentArray), gradients likewise
+        pflat = torch.cat([dv(w1_h).reshape(-1), dv(b1_h), dv(w2_h).reshape(-1), dv(b2_h)]).contiguous()
+        w1, b1 = pflat[:D * D], pflat[D * D:D * D + D]
+        w2, b2 = pflat[D * D + D:2 * D * D + D], pflat[2 * D * D + D:]
+        adam_m, adam_v = torch.zeros_like(pflat), torch.zeros_like(pflat)
+        uT, du0 = torch.empty_like(u0), torch.empty_like(u0)
+        seed_grad = torch.ones_like(u0)                       # d sum(u(T)) / d u(T)
+        flat = torch.empty(2 * (D * D + D), dtype=torch.float32, device=dev)   # [dw1 | db1 | dw2 | db2]
+        dw1, db1 = flat[:D * D], flat[D * D:D * D + D]
+        dw2, db2 = flat[D * D + D:2 * D * D + D], flat[2 * D * D + D:]
+        it = [0]
 
-    # forward / backward split of one solve, by HIP events on the launch stream (outside the timed region)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
-    ev[1].record()
-    _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
-    ev[2].record()
-    torch.cuda.synchronize()
-    ms_fwd, ms_bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        def step():
+            # one training step: solve, discrete adjoint, gradient all-reduce, fused Adam on the flat vector (1/world folded in)
+            _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+            _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+            if dist is not None:
+                dist.all_reduce(flat)
+            it[0] += 1
+            _lib.check(lib.ngpde_adam_step(flat.numel(), p(pflat), p(flat), p(adam_m), p(adam_v), 1e-5, 0.9, 0.999, 1e-8, it[0],
+                                           1.0 / world, stream))
 
-    out = None
-    if rank == 0:
+        for _ in range(n_warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        # forward / backward split of one solve, by HIP events on the launch stream (outside the timed region)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+        ev[1].record()
+        _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+        ev[2].record()
+        torch.cuda.synchronize()
+        return elapsed, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), plan
+
+    def launch_profile(plan):
         # per-launch DEVICE time of the four kernel roles, from start/stop events attached to the dispatches
         us = (C.c_float * 4)()
         cnt = (C.c_int32 * 4)()
         _lib.check(lib.ngpde_node_profile(plan.ptr, 1, us, cnt, stream))
+        return us, cnt
+
+    elapsed, ms_fwd, ms_bwd, plan = job(1, args.steps, args.warmup)
+
+    out = None
+    if rank == 0:
+        us, cnt = launch_profile(plan)
         roles = ["fwd_layer1", "fwd_layer2_stage", "bwd_layer1", "bwd_stage_layer2"]
         algo = [BYTES_FWD_LAYER, BYTES_FWD_LAYER, BYTES_BWD_LAYER, BYTES_BWD_LAYER]
         kernels = {r: {"avg_us": round(float(us[i]), 3), "launches_per_solve": int(cnt[i]),
@@ -238,6 +251,27 @@ def main():
                          "avg_launch_us": round(float(us[dom]), 3)},
             "kernels": kernels,
         }
+        if world == 1 and args.batched > 1:
+            # Secondary: the same kernels when a launch is no longer ONE wave of workgroups.  `traj` trajectories of the
+            # BASELINE workload on this GPU as one block-diagonal batched GNNGraph (test/runtests.jl:89-102); each launch
+            # then processes traj x the algorithmic bytes.  Not the headline: `value` above is one trajectory per GPU.
+            plan = None
+            nb = max(2, args.steps // 3)
+            eb, fb, bb, planb = job(args.batched, nb, 1)
+            usb, cntb = launch_profile(planb)
+            totb = [float(usb[i]) * int(cntb[i]) for i in range(4)]
+            db = int(np.argmax(totb))
+            out["batched"] = {
+                "trajectories_per_gpu": args.batched, "nodes": args.batched * N_NODES,
+                "value": round(args.batched * ODE_STEPS * nb / eb, 1), "unit": "trajectory ODE-steps/s",
+                "ms_forward_solve": round(fb, 3), "ms_backward_solve": round(bb, 3),
+                "tape_GB": round(planb.tape_bytes() / 1e9, 3),
+                "roofline": {"kernel": roles[db], "avg_launch_us": round(float(usb[db]), 3),
+                             "achieved": round(args.batched * algo[db] / (float(usb[db]) * 1e-6) / 1e9, 1), "unit": "GB/s",
+                             "frac": round(args.batched * algo[db] / (float(usb[db]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                "kernels_avg_us": {r: round(float(usb[i]), 3) for i, r in enumerate(roles)},
+            }
+            planb = None
         if world == 1 and not args.no_cpu_baseline:
             cb, outs = cpu_baseline(s, t, u0_h, w1_h, b1_h, w2_h, b2_h)
             out["cpu_baseline"] = cb

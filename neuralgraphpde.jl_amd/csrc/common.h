@@ -116,6 +116,7 @@ struct FusedFwdArgs {
   float *save_agg = nullptr;     // [N][d] or null
   float *save_z = nullptr;       // [N][d] or null
   uint8_t *save_mask = nullptr;  // [fused_mask_bytes] or null: 4 sign bits of z per thread and row (relu' for the pullback)
+  bool pre = false;              // pre-scaled pipeline: x holds c .* x, y / comb_out are written as c .* y (see fused_prescaled_supported)
   // optional Runge-Kutta stage combination evaluated on the freshly computed rows of y
   bool has_comb = false;
   Comb comb;
@@ -124,6 +125,7 @@ struct FusedFwdArgs {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool fused_supported(int din, int dout);
+bool fused_prescaled_supported(const ngpde_graph *g, int d);
 int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream);
 
 struct FusedBwdArgs {
@@ -141,6 +143,7 @@ struct FusedBwdArgs {
   bool do_dense = true;
   const float *z = nullptr;      // [N][d] saved pre-activation (or y for relu/identity); unused when mask is given
   const uint8_t *mask = nullptr; // sign bits written by the forward launch (same tile / thread layout), relu only
+  bool pre = false;              // pre-scaled pipeline: g_in holds c .* G, T is dL/d(c .* x), g_out is written as c .* G
   const float *saved_agg = nullptr;  // [N][d]
   const float *wt = nullptr;     // [d][d]
   float *g_out = nullptr;        // [N][d]  dZ * W

@@ -282,26 +282,49 @@ __device__ __forceinline__ void load_sched(const int4 *__restrict__ sched, int t
 
 // round 2: the tile's distinct rows.  Issue this BEFORE any other load of the kernel that is consumed later:
 // vmcnt retires in order, so an older, slower load (HBM tape) would otherwise sit in front of these.
-template <int D>
-__device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q, HaloRegs<D> &h) {
+//
+// DMA: the rows go memory -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane; a wave's
+// 64 / LPR groups stage consecutive halo slots, so its 1 KiB lands contiguously at Xh4[hh * LPR + q]).  No VGPR round trip
+// and no ds_write_b128 (13 cycles per wave-instruction on the store path: two workgroups' 25 KB cost ~650 cycles there).
+// Only for rows that need no scaling on the way in (PRE: the producer stored them already multiplied by c[node]).
+template <int D, bool DMA>
+__device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q, int grp, float *ldsXh, HaloRegs<D> &h) {
   using G = Geo<D>;
 #pragma unroll
-  for (int k = 0; k < G::HI; ++k) h.hv[k] = load_row4<G::LPR>(X4, h.he[k].x, q);
+  for (int k = 0; k < G::HI; ++k) {
+    if constexpr (DMA) {
+      const int hh = grp + k * G::GROUPS;
+      if (hh < kHaloCap) {   // wave-uniform: kHaloCap is a multiple of the groups per wave
+        const unsigned off = (unsigned)h.he[k].x * (unsigned)(G::LPR * 16) + (unsigned)(q * 16);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X4) + off),
+            (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsXh) + hh * G::LPR + q), 16, 0, 0);
+      }
+    } else {
+      h.hv[k] = load_row4<G::LPR>(X4, h.he[k].x, q);
+    }
+  }
 }
 
 // stage the rows (pre-scaled by c[node]; padding entries have c = 0) and sum every row's neighbours from LDS
-template <int D>
+// DMA: the rows were sent to LDS by halo_round2 (nothing to write here; the barrier's vmcnt(0) retires them).
+// POST: multiply the row sums by c[row] (forward; the pullback of the pre-scaled form has no such factor).
+// after_barrier(): loads the caller wants in flight during the LDS pass but NOT in front of the barrier's wait.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int D, bool DMA = false, bool POST = true, class Hook = NoHook, bool SCALE = true>
 __device__ __forceinline__ void halo_finish(const HaloRegs<D> &h, bool weighted, int self_loops, int grp, int q,
                                             float *ldsXh, const int4 (&sc)[Geo<D>::R], float4 (&acc)[Geo<D>::R],
-                                            unsigned long long *dbg = nullptr) {
+                                            unsigned long long *dbg = nullptr, Hook &&after_barrier = NoHook()) {
   using G = Geo<D>;
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
-  NGPDE_USE(h.hv[0].x); NGPDE_USE(h.hv[G::HI - 1].x);
-  NGPDE_SUBSTAMP(dbg, 1);   // halo rows arrived
+  if constexpr (!DMA) {
+    NGPDE_USE(h.hv[0].x); NGPDE_USE(h.hv[G::HI - 1].x);
+    NGPDE_SUBSTAMP(dbg, 1);   // halo rows arrived
 #pragma unroll
-  for (int k = 0; k < G::HI; ++k) {
-    const int hh = grp + k * G::GROUPS;
-    if (hh < kHaloCap) Xh4[hh * G::LPR + q] = f4_scale(__int_as_float(h.he[k].y), h.hv[k]);
+    for (int k = 0; k < G::HI; ++k) {
+      const int hh = grp + k * G::GROUPS;
+      if (hh < kHaloCap) Xh4[hh * G::LPR + q] = SCALE ? f4_scale(__int_as_float(h.he[k].y), h.hv[k]) : h.hv[k];
+    }
   }
   if (grp == 0) Xh4[kHaloCap * G::LPR + q] = f4_zero();
   int wmax = 0;
@@ -318,6 +341,7 @@ __device__ __forceinline__ void halo_finish(const HaloRegs<D> &h, bool weighted,
   NGPDE_SUBSTAMP(dbg, 2);   // LDS written
   __syncthreads();
   NGPDE_SUBSTAMP(dbg, 3);   // barrier passed
+  after_barrier();
 #pragma unroll
   for (int r = 0; r < G::R; ++r) {
     const unsigned w[8] = {h.sl[r][0].x, h.sl[r][0].y, h.sl[r][0].z, h.sl[r][0].w,
@@ -339,7 +363,7 @@ __device__ __forceinline__ void halo_finish(const HaloRegs<D> &h, bool weighted,
     }
     const float ci = __int_as_float(sc[r].w);
     if (self_loops) a = f4_add(a, Xh4[min(grp * G::R + r, kTM - 1) * G::LPR + q]);   // own row = slot (position in tile)
-    acc[r] = f4_scale(ci, a);
+    acc[r] = POST ? f4_scale(ci, a) : a;
   }
   NGPDE_USE(acc[0].x);
   NGPDE_SUBSTAMP(dbg, 4);   // LDS aggregation done
@@ -423,8 +447,15 @@ struct FwdK {
   NGPDE_STAMP_FIELD
 };
 
-template <int D, int ACT, bool HALO>
-__global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_kernel(const FwdK p) {
+// PRE (HALO only): every feature array of the caller's pipeline is stored multiplied by c[row] (x~ = c .* x), so the
+// halo rows need no scaling when staged and go to LDS by DMA; y and the stage combination are written in the same form.
+template <int D, int ACT, bool HALO, bool PRE>
+__global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_kernel(
+    // what the first two rounds of loads need, as leading scalar arguments: they are preloaded into SGPRs at wave launch
+    // (-mllvm -amdgpu-kernarg-preload-count, Makefile), so the gather chain does not start behind a kernarg fetch
+    const int2 *__restrict__ h_halo, const uint8_t *__restrict__ h_slots, const int4 *__restrict__ h_sched,
+    const float *__restrict__ h_x, const float *__restrict__ h_slot_w, int h_n_tiles, const FwdK p) {
+  static_assert(!PRE || HALO, "the pre-scaled form exists for the LDS-staged aggregation only");
   using G = Geo<D>;
   // the halo region is dead once the aggregation is done and is re-used for the MFMA output tile
   constexpr int kXZ = (HALO && G::XH > kTM * G::TS) ? G::XH : kTM * G::TS;
@@ -433,10 +464,10 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / G::LPR, q = tid % G::LPR;
-  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  const int tile = xcd_tile(blockIdx.x, h_n_tiles);
   const int act = ACT >= 0 ? ACT : p.act;
   const bool active = grp * G::R < kTM;
-  const float4 *X4 = reinterpret_cast<const float4 *>(p.x);
+  const float4 *X4 = reinterpret_cast<const float4 *>(h_x);
   NGPDE_STAMP(0);
 
   // ---- round 1: every load whose address depends on nothing loaded; the gather chain first, pinned in this order
@@ -445,11 +476,11 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   float4 selfv[G::R];
   HaloRegs<D> hr;
   if (HALO) {
-    halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
+    halo_round1<D>(h_halo, reinterpret_cast<const uint4 *>(h_slots), reinterpret_cast<const float4 *>(h_slot_w), tile, grp,
                    active, hr);
-    load_sched<D>(p.sched, tile, grp, active, sc);
+    load_sched<D>(h_sched, tile, grp, active, sc);
   } else {
-    tile_prologue<D>(p.sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
+    tile_prologue<D>(h_sched, p.ell, p.ent, X4, tile, grp, q, active, sc, ecol, ecf, selfv);
   }
   __builtin_amdgcn_sched_barrier(0);
   // W: B[k = in][j = out] = wt[in][out], stored transposed in LDS: 4 dword loads down a column
@@ -474,7 +505,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   if (HALO) {
     NGPDE_USE(hr.he[0].x);
     NGPDE_SUBSTAMP(NGPDE_STAMP_PTR(p), 0);   // round-1 data arrived
-    halo_round2<D>(X4, q, hr);
+    halo_round2<D, PRE>(X4, q, grp, ldsXh, hr);
   }
   float4 cterm[G::R][8];
   if (HALO && active && p.has_comb && !(p.order & 2)) {
@@ -484,7 +515,7 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   __builtin_amdgcn_sched_barrier(0);
   float4 acc[G::R];
   if (HALO) {
-    halo_finish<D>(hr, p.slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, acc, NGPDE_STAMP_PTR(p));
+    halo_finish<D, PRE, true>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, acc, NGPDE_STAMP_PTR(p));
   } else {
     aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
   }
@@ -529,7 +560,8 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
       if (p.save_mask)   // relu'(z) for the pullback: 4 bits instead of re-reading 16 bytes of y
         p.save_mask[((size_t)tile * G::R + r) * kThreads + tid] =
             (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
-      const float4 yv = f4_act(act, z);
+      float4 yv = f4_act(act, z);
+      if (PRE) yv = f4_scale(__int_as_float(sc[r].w), yv);
       reinterpret_cast<float4 *>(p.y)[idx4] = yv;
       if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_finish(p.comb, yv, cterm[r]);
     }
@@ -564,28 +596,43 @@ struct BwdK {
 // PAIR: a 1024-thread workgroup = two independent 512-thread halves, each with its own tile and LDS region, that fold their
 // dW / db partials into ONE slab (half 1 hands its accumulators to half 0 through LDS).  Halves the slab read-modify-write
 // traffic of every backward launch (16.8 MB of the 36-55 MB a launch moves at C2) at the price of one more barrier.
-template <int D, bool AGG, int ACT, bool HALO, bool PAIR>
-__global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(const BwdK p) {
+//
+// PRE: the pre-scaled form of the caller's pipeline (see the forward kernel): g_in holds c .* G, so the halo rows go to LDS
+// by DMA and the row sums carry no c factor; c[row] enters where dL/dy = c .* dL/dy~ (before the mask) and where the
+// product G is stored for the next gather.
+template <int D, bool AGG, int ACT, bool HALO, bool PAIR, bool PRE>
+__global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2)) void gcn_fused_bwd_kernel(
+    const int2 *__restrict__ h_halo, const uint8_t *__restrict__ h_slots, const int4 *__restrict__ h_sched,
+    const float *__restrict__ h_x, const float *__restrict__ h_slot_w, int h_n_tiles, const BwdK p) {
   using G = Geo<D>;
+  static_assert(!PRE || !AGG || HALO, "the pre-scaled form exists for the LDS-staged aggregation only");
+#ifdef NGPDE_PRE_NO_BWD_DMA
+  constexpr bool DMA = false;
+#else
+  constexpr bool DMA = PRE && AGG && HALO;
+#endif
   constexpr int kXZ = (AGG && HALO && G::XH > kTM * G::TS) ? G::XH : kTM * G::TS;
   constexpr int kRegion = kXZ + kTM * G::TS * 2 + D * G::TS;
   __shared__ __attribute__((aligned(16))) float lds_all[(PAIR ? 2 : 1) * kRegion];
   const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) : 0;
-  float *lds = lds_all + half * kRegion;
-  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXZ, *ldsX = lds + kXZ + kTM * G::TS,
-        *ldsBt = lds + kXZ + 2 * kTM * G::TS;
+  // the halo regions of both halves first: an LDS-DMA destination is a 16-bit offset (M0[15:0]), it must stay below 64 KiB
+  constexpr int kRest = kRegion - kXZ;
+  float *ldsXh = lds_all + half * kXZ, *ldsG = ldsXh;
+  float *rest = lds_all + (PAIR ? 2 : 1) * kXZ + half * kRest;
+  float *ldsDZ = rest, *ldsX = rest + kTM * G::TS, *ldsBt = rest + 2 * kTM * G::TS;
+  static_assert(!DMA || (PAIR ? 2 : 1) * kXZ * sizeof(float) <= 65536, "LDS-DMA destinations must lie in the first 64 KiB");
   const int tid = PAIR ? (threadIdx.x & (kThreads - 1)) : threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / G::LPR, q = tid % G::LPR;
   // PAIR: workgroup b owns tiles 2 b' and 2 b' + 1 (b' XCD-mapped); the second half of an odd last pair repeats the last
   // tile with every row masked out (it contributes zeros and stores nothing)
-  const int n_wg = PAIR ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const int n_wg = PAIR ? (h_n_tiles + 1) / 2 : h_n_tiles;
   const int tile_raw = PAIR ? 2 * xcd_tile(blockIdx.x, n_wg) + half : xcd_tile(blockIdx.x, n_wg);
-  const bool tile_ok = tile_raw < p.n_tiles;
-  const int tile = tile_ok ? tile_raw : p.n_tiles - 1;
+  const bool tile_ok = tile_raw < h_n_tiles;
+  const int tile = tile_ok ? tile_raw : h_n_tiles - 1;
   const int act = ACT >= 0 ? ACT : p.act;
   const bool active = grp * G::R < kTM;
-  const float4 *G4 = reinterpret_cast<const float4 *>(p.g_in);
+  const float4 *G4 = reinterpret_cast<const float4 *>(h_x);
   NGPDE_STAMP(0);
 
   // ---- round 1 / round 2 of the gather chain first (vmcnt retires in order: slower loads must not sit in front)
@@ -594,14 +641,14 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   float4 selfv[G::R];
   HaloRegs<D> hr;
   if (AGG && HALO) {
-    halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), reinterpret_cast<const float4 *>(p.slot_w), tile, grp,
+    halo_round1<D>(h_halo, reinterpret_cast<const uint4 *>(h_slots), reinterpret_cast<const float4 *>(h_slot_w), tile, grp,
                    active, hr);
-    load_sched<D>(p.sched, tile, grp, active, sc);
-    halo_round2<D>(G4, q, hr);
+    load_sched<D>(h_sched, tile, grp, active, sc);
+    halo_round2<D, DMA>(G4, q, grp, ldsXh, hr);
   } else if (AGG) {
-    tile_prologue<D>(p.sched, p.ell, p.ent, G4, tile, grp, q, active, sc, ecol, ecf, selfv);
+    tile_prologue<D>(h_sched, p.ell, p.ent, G4, tile, grp, q, active, sc, ecol, ecf, selfv);
   } else {
-    load_sched<D>(p.sched, tile, grp, active, sc);
+    load_sched<D>(h_sched, tile, grp, active, sc);
   }
   if (PAIR && !tile_ok) {
 #pragma unroll
@@ -609,8 +656,14 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   }
   // relu sign bits written by the forward launch of the same layer evaluation: addressed by (tile, thread), no dependency
   unsigned mk[G::R];
+  auto load_mask = [&]() {
 #pragma unroll
-  for (int r = 0; r < G::R; ++r) mk[r] = (p.mask && p.do_dense) ? p.mask[((size_t)tile * G::R + r) * kThreads + tid] : 0u;
+    for (int r = 0; r < G::R; ++r) mk[r] = (p.mask && p.do_dense) ? p.mask[((size_t)tile * G::R + r) * kThreads + tid] : 0u;
+  };
+  // DMA: the barrier that publishes the staged rows waits for EVERY outstanding load of the wave (vmcnt(0)), so the
+  // node-local loads that register staging issues up front go out right behind that barrier instead and fly during
+  // the LDS pass.
+  if (!DMA) load_mask();
   // B = Wt^T : B[k = o][j = i] = wt[i][o]  ->  Bt[j = i][k = o] = wt[i][o]: a straight copy
   float4 wreg[G::W4];
   // slab fragments of this wave's dW tiles and this thread's db column: consumed after the MFMAs
@@ -628,7 +681,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       }
     }
   };
-  if (!(p.order & 1)) load_w();
+  if (!DMA && !(p.order & 1)) load_w();
   auto load_slab = [&]() {   // consumed only after the dW MFMAs
     if (p.do_dense) {
 #pragma unroll
@@ -639,7 +692,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       if (dbpart == 0 && half == 0) dbv = p.slab_db[(size_t)blockIdx.x * D + dbc];
     }
   };
-  if (!(p.order & 2)) load_slab();
+  if (!DMA && !(p.order & 2)) load_slab();
   float4 zrow[G::R], xrow[G::R], cterm[G::R][8];
   auto load_tape = [&]() {   // saved activations of this thread's rows (node-local, HBM-resident tape)
     if (active && p.do_dense) {
@@ -654,11 +707,19 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   // Without stage terms the tape rows are fetched only after the aggregation: issued up front they queue in the memory
   // system in front of the halo rows the whole workgroup waits for (measured: -0.7 us per launch); with stage terms
   // (a later batch of node-local loads anyway) fetching them early is the faster order.
-  if (!p.tape_late) load_tape();
+  if (!DMA && !p.tape_late) load_tape();
 
   float4 t[G::R];
   if (AGG && HALO) {
-    halo_finish<D>(hr, p.slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t);
+    if constexpr (DMA) {
+      halo_finish<D, true, false>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t, nullptr, [&]() {
+        load_mask();
+        if (!(p.order & 2)) load_slab();
+        if (!p.tape_late) load_tape();
+      });
+    } else {
+      halo_finish<D, false, !PRE, NoHook, !PRE>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t);
+    }
   } else if (AGG) {
     aggregate_rows<G::LPR, G::R, G::U>(G4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, t);
   } else {
@@ -667,7 +728,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   }
   NGPDE_STAMP(1);
   if (p.tape_late) load_tape();
-  if (p.order & 1) load_w();
+  if (DMA || (p.order & 1)) load_w();
   if (p.order & 2) load_slab();
   if (active && p.has_comb) {   // adjoint stage terms: one batch of independent node-local loads
 #pragma unroll
@@ -689,6 +750,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       }
       if (p.do_dense) {
         float4 dz = f4_zero(), xa = f4_zero();
+        if (PRE) kbar = f4_scale(__int_as_float(sc[r].w), kbar);   // dL/dy = c .* dL/dy~
         if (ok) {
           if (p.mask)
             dz = make_float4((mk[r] & 1u) ? kbar.x : 0.f, (mk[r] & 2u) ? kbar.y : 0.f, (mk[r] & 4u) ? kbar.z : 0.f,
@@ -750,7 +812,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   __syncthreads();
   NGPDE_STAMP(5);
   // PAIR: half 1 parks its dW tiles and db partials in its (now idle) W^T region
-  float *park = lds_all + (PAIR ? 1 : 0) * kRegion + kXZ + 2 * kTM * G::TS;   // [NT][64 lanes][4] + [D]
+  float *park = lds_all + (PAIR ? 2 : 1) * kXZ + (PAIR ? 1 : 0) * kRest + 2 * kTM * G::TS;   // half 1's W^T region: [NT][64 lanes][4] + [D]
   if (PAIR && half == 1) {
 #pragma unroll
     for (int m = 0; m < G::DWT; ++m) {
@@ -763,8 +825,9 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
       if (sc[r].x < 0) continue;
-      reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q] =
-          *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
+      float4 gv = *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
+      if (PRE) gv = f4_scale(__int_as_float(sc[r].w), gv);   // stored as c .* G: the next launch gathers it raw
+      reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q] = gv;
     }
   }
   if (PAIR) {
@@ -814,7 +877,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_fused_fwd_kernel(const GatK p
   int4 sc[G::R];
   halo_round1<D>(p.halo, reinterpret_cast<const uint4 *>(p.slots), nullptr, tile, grp, active, hr);
   load_sched<D>(p.sched, tile, grp, active, sc);
-  halo_round2<D>(X4, q, hr);
+  halo_round2<D, true>(X4, q, grp, ldsXh, hr);   // Wx rows are staged as they are: straight to LDS
   // ar of the halo nodes (lanes q < H fetch one score each), al of this row's head
   float arv[G::HI];
 #pragma unroll
@@ -827,10 +890,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_fused_fwd_kernel(const GatK p
 #pragma unroll
   for (int k = 0; k < G::HI; ++k) {
     const int hh = grp + k * G::GROUPS;
-    if (hh < kHaloCap) {
-      Xh4[hh * G::LPR + q] = hr.hv[k];
-      if (q < 4) ldsAr[hh * 4 + q] = arv[k];
-    }
+    if (hh < kHaloCap && q < 4) ldsAr[hh * 4 + q] = arv[k];
   }
   __syncthreads();
 #pragma unroll
@@ -937,6 +997,12 @@ extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf, int32_t m
 }
 #endif
 
+// the pre-scaled pipeline (rows stored as c .* x, gathered raw by LDS-DMA): every tile staged from LDS in both directions,
+// and c finite and positive (self loops: degree >= 1)
+bool fused_prescaled_supported(const ngpde_graph *g, int d) {
+  return g && g->has_norm && g->self_loops && d <= 64 && fused_supported(d, d) && g->by_t.halo_ok && g->by_s.halo_ok &&
+         !no_halo_env();
+}
 bool fused_supported(int din, int dout) { return din == dout && (din == 16 || din == 32 || din == 64 || din == 128); }
 int fused_tile_rows() { return kTM; }
 int fused_num_blocks(int64_t n_nodes) { return (int)((n_nodes + kTM - 1) / kTM); }
@@ -970,12 +1036,17 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   }
   NGPDE_STAMP_SET(k, k.n_tiles)
   const bool use_halo = g->by_t.halo_ok && !no_halo_env();
+  NGPDE_REQUIRE(!a.pre || fused_prescaled_supported(g, a.d), NGPDE_ERR_UNSUPPORTED,
+                "the pre-scaled form needs self loops and tiles that fit the LDS halo in both directions");
   const dim3 grid(k.n_tiles), block(kThreads);
-#define NGPDE_FWD_LAUNCH2(DD, AA, HH)                                                                              \
-  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-  else hipLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH>), grid, block, 0, stream, k);
+#define NGPDE_FWD_LAUNCH2(DD, AA, HH, PP)                                                                          \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH, PP>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, \
+                                        k.halo, k.slots, k.sched, k.x, k.slot_w, k.n_tiles, k);                       \
+  else hipLaunchKernelGGL((gcn_fused_fwd_kernel<DD, AA, HH, PP>), grid, block, 0, stream, k.halo, k.slots, k.sched, k.x, k.slot_w, k.n_tiles, k);
 #define NGPDE_FWD_LAUNCH(DD, AA)                                                                                   \
-  if (Geo<DD>::HALO && use_halo) { NGPDE_FWD_LAUNCH2(DD, AA, (Geo<DD>::HALO)) } else { NGPDE_FWD_LAUNCH2(DD, AA, false) }
+  if (Geo<DD>::HALO && a.pre) { NGPDE_FWD_LAUNCH2(DD, AA, (Geo<DD>::HALO), (Geo<DD>::HALO)) }                      \
+  else if (Geo<DD>::HALO && use_halo) { NGPDE_FWD_LAUNCH2(DD, AA, (Geo<DD>::HALO), false) }                        \
+  else { NGPDE_FWD_LAUNCH2(DD, AA, false, false) }
 #define NGPDE_FWD_CASE(DD)                                                            \
   case DD:                                                                            \
     switch (act_template(a.act)) {                                                    \
@@ -1022,15 +1093,20 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   k.g_out = a.g_out; k.slab_dw = a.slab_dw; k.slab_db = a.slab_db;
   NGPDE_STAMP_SET(k, k.n_tiles)
   const bool use_halo = g->by_s.halo_ok && !no_halo_env();
+  NGPDE_REQUIRE(!a.pre || fused_prescaled_supported(g, a.d), NGPDE_ERR_UNSUPPORTED,
+                "the pre-scaled form needs self loops and tiles that fit the LDS halo in both directions");
   const bool pair = fused_bwd_pairs(a.d);
   const dim3 grid(pair ? (k.n_tiles + 1) / 2 : k.n_tiles), block(pair ? 2 * kThreads : kThreads);
-#define NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, PP)                                                                     \
-  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP>), grid, block, 0, stream, k);
-#define NGPDE_BWD_LAUNCH2(DD, AG, AA, HH)                                                                         \
-  if (DD <= 64 && pair) { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, (DD <= 64)) } else { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, false) }
+#define NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, PP, SS)                                                                 \
+  if (a.ev_start) hipExtLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP, SS>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, \
+                                        k.halo, k.slots, k.sched, k.g_in, k.slot_w, k.n_tiles, k);                    \
+  else hipLaunchKernelGGL((gcn_fused_bwd_kernel<DD, AG, AA, HH, PP, SS>), grid, block, 0, stream, k.halo, k.slots, k.sched, k.g_in, k.slot_w, k.n_tiles, k);
+#define NGPDE_BWD_LAUNCH2(DD, AG, AA, HH, SS)                                                                     \
+  if (DD <= 64 && pair) { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, (DD <= 64), SS) } else { NGPDE_BWD_LAUNCH3(DD, AG, AA, HH, false, SS) }
 #define NGPDE_BWD_LAUNCH(DD, AG, AA)                                                                              \
-  if (AG && Geo<DD>::HALO && use_halo) { NGPDE_BWD_LAUNCH2(DD, AG, AA, (AG && Geo<DD>::HALO)) } else { NGPDE_BWD_LAUNCH2(DD, AG, AA, false) }
+  if (Geo<DD>::HALO && a.pre) { NGPDE_BWD_LAUNCH2(DD, AG, AA, (AG && Geo<DD>::HALO), (Geo<DD>::HALO)) }            \
+  else if (AG && Geo<DD>::HALO && use_halo) { NGPDE_BWD_LAUNCH2(DD, AG, AA, (AG && Geo<DD>::HALO), false) }        \
+  else { NGPDE_BWD_LAUNCH2(DD, AG, AA, false, false) }
 #define NGPDE_BWD_ACT(DD, AG)                                                         \
   switch (act_template(a.act)) {                                                      \
     case NGPDE_ACT_RELU: NGPDE_BWD_LAUNCH(DD, AG, NGPDE_ACT_RELU) break;              \

@@ -49,6 +49,26 @@ Tableau make_tableau(int which) {
   return t;
 }
 
+// dst[i][:] = src[i][:] * c[i]   (invert: / c[i]) -- entry to / exit from the pre-scaled form of the pipeline
+__global__ void scale_rows_kernel(size_t n4, int lpr, int invert, const float4 *__restrict__ src, const float *__restrict__ c,
+                                  float4 *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float ci = c[i / lpr];
+  const float f = invert ? 1.0f / ci : ci;
+  const float4 v = src[i];
+  dst[i] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+}
+
+int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t n, int d, bool invert, hipStream_t stream) {
+  const size_t n4 = (size_t)n * d / 4;
+  if (n4 == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, d / 4, invert ? 1 : 0,
+                     reinterpret_cast<const float4 *>(src), c, reinterpret_cast<float4 *>(dst));
+  NGPDE_LAUNCH_CHECK("scale_rows_kernel");
+  return NGPDE_OK;
+}
+
 bool act_needs_z(int act) {
   return !(act == NGPDE_ACT_IDENTITY || act == NGPDE_ACT_RELU || act == NGPDE_ACT_LEAKYRELU);
 }
@@ -73,6 +93,10 @@ struct ngpde_node {
   // relu with backward: the pullback needs only the sign of z, so each evaluation keeps two aggregated inputs on the tape
   // plus two 4-bit-per-value masks; the layer outputs live in 2 S buffers that every step re-uses
   bool mask_mode = false;
+  // pre-scaled form: u, the stage inputs, the layer outputs and the adjoint products g1 / g2 are held multiplied by c[row]
+  // (u~ = c .* u), so that no kernel scales a row while staging it and the halo rows go to LDS by DMA; lambda and the
+  // stage adjoints are derivatives with respect to u~.  u0 is scaled on entry, u(T) and du0 on exit.
+  bool pre = false;
   float *ybuf = nullptr;         // [S][2][row_elems]
   uint8_t *masks = nullptr;      // [n_steps][S][2][mask_bytes]
   size_t mask_bytes = 0;
@@ -145,6 +169,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f1.save_agg = p->with_bwd ? p->slot(n, i, 0) : nullptr;
       f1.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 4) : nullptr;
       f1.save_mask = p->mask_mode ? p->mask_slot(n, i, 1) : nullptr;
+      f1.pre = p->pre;
       if (prof) prof->want(0, &f1.ev_start, &f1.ev_stop);
       if ((st = launch_fused_fwd(f1, stream))) return st;
       FusedFwdArgs f2;
@@ -155,6 +180,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f2.save_agg = p->with_bwd ? p->slot(n, i, 2) : nullptr;
       f2.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 5) : nullptr;
       f2.save_mask = p->mask_mode ? p->mask_slot(n, i, 2) : nullptr;
+      f2.pre = p->pre;
       // epilogue: next stage input, or the step update after the last stage
       const bool last = (i == tb.S - 1);
       const std::vector<double> &row = last ? tb.b : tb.a[i + 1];
@@ -180,6 +206,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
 
 void fill_dense(const ngpde_node *p, FusedBwdArgs &a, int layer, int step, int stage) {
   a.do_dense = true;
+  a.pre = p->pre;
   if (p->mask_mode) a.mask = p->mask_slot(step, stage, layer);
   if (layer == 2) {
     a.z = p->needs_z ? p->slot(step, stage, 5) : p->slot(step, stage, 3);
@@ -248,6 +275,7 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
           fill_dense(p, e, 2, n - 1, S - 1);
         } else {
           e.do_dense = false;
+          e.pre = p->pre;
         }
       }
       if (prof && e.do_dense) prof->want(3, &e.ev_start, &e.ev_stop);
@@ -336,6 +364,7 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   p->mask_mode = p->with_bwd && act == NGPDE_ACT_RELU && std::getenv("NGPDE_NO_MASK") == nullptr;
   p->slots = p->mask_mode ? 2 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4);
   p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
+  p->pre = fused_prescaled_supported(g, d) && std::getenv("NGPDE_NO_PRESCALE") == nullptr;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
   const int S = p->tb.S;
@@ -408,7 +437,12 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   NGPDE_REQUIRE(u0 && w1 && w2 && uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: NULL argument");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (p->pre) {
+    int32_t st = launch_scale_rows(u0, p->g->c, p->u, p->n, p->d, false, stream);
+    if (st) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
@@ -422,7 +456,12 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   } else {
     NGPDE_HIP_CHECK(hipGraphLaunch(p->fwd_exec, stream));
   }
-  NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (p->pre) {
+    int32_t st = launch_scale_rows(p->u, p->g->c, uT, p->n, p->d, true, stream);
+    if (st) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
   p->forward_done = true;
   return NGPDE_OK;
 }
@@ -435,14 +474,24 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   NGPDE_REQUIRE(duT != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_backward: duT is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (p->pre) {   // u(T) = u~(T) ./ c  =>  dL/du~(T) = duT ./ c
+    int32_t st = launch_scale_rows(duT, p->g->c, p->lam, p->n, p->d, true, stream);
+    if (st) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
   if (p->eager) {
     int32_t st = enqueue_backward(p, stream, nullptr);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipGraphLaunch(p->bwd_exec, stream));
   }
-  if (du0) NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (du0 && p->pre) {   // u~0 = c .* u0  =>  du0 = c .* dL/du~0
+    int32_t st = launch_scale_rows(p->lam, p->g->c, du0, p->n, p->d, false, stream);
+    if (st) return st;
+  } else if (du0) {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
   if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
   if (db1) NGPDE_HIP_CHECK(hipMemcpyAsync(db1, p->db1, db, hipMemcpyDeviceToDevice, stream));
   if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));
@@ -458,9 +507,13 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   hipStream_t stream = (hipStream_t)stream_;
   Prof prof;
   prof.stride = stride;
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  int32_t st = enqueue_forward(p, stream, nullptr, &prof);
-  if (st) return st;
+  int32_t st;
+  if (p->pre) {
+    if ((st = launch_scale_rows(p->u0keep, p->g->c, p->u, p->n, p->d, false, stream))) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  if ((st = enqueue_forward(p, stream, nullptr, &prof))) return st;
   if (p->with_bwd) {
     // adjoint seed of loss = sum(u(T)): ones
     std::vector<float> ones(p->row_elems, 1.0f);

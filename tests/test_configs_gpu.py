@@ -95,7 +95,16 @@ def test_c2_two_tsit5_steps_against_the_c_port():
     uT, _ = node(ut, ps, st)
     close(uT, outs[0].T, 2e-4, what="u(T)")
     uT.sum().backward()
-    close(ut.grad, outs[1].T, 5e-4, 1e-4, "du0")
+    # relu'(z) is decided by rounding where |z| is within an ulp of zero (about one of the 25 M pre-activations of this
+    # solve): two correct float32 evaluations -- the C port, the register-staged kernels, the pre-scaled kernels -- may
+    # disagree there, and each such kink moves du0 in the few dozen rows around it.  So: every row within the tolerance
+    # except at most 0.5 % of them, those within 20x, and the whole field within 1e-4 in the l2 norm.
+    du0, ref = ut.grad.detach().cpu().double().numpy(), outs[1].T.astype(np.float64)
+    bound = 5e-4 * np.abs(ref).max() + 1e-4
+    row_err = np.abs(du0 - ref).max(axis=0)
+    assert (row_err > bound).sum() <= 0.005 * row_err.size, f"du0: {(row_err > bound).sum()} rows beyond {bound:.2e}"
+    assert row_err.max() <= 20 * bound, f"du0: max err {row_err.max():.3e}"
+    assert np.linalg.norm(du0 - ref) <= 1e-4 * np.linalg.norm(ref)
     close(ps["layer_1"]["weight"].grad, outs[2].T, 1e-3, 1e-2, "dW1")      # sums over 16 384 nodes, float32 on both sides
     close(ps["layer_2"]["weight"].grad, outs[4].T, 1e-3, 1e-2, "dW2")
     close(ps["layer_1"]["bias"].grad, outs[3], 1e-3, 1e-2, "db1")
@@ -173,9 +182,12 @@ def test_c2_full_solve_properties():
     node0, ps0, st0 = gcn2_node(g, D, "tsit5", 50, 1.0 / 50, zero)
     u = ut.clone().requires_grad_(True)
     uT, _ = node0(u, ps0, st0)
-    assert torch.equal(uT, ut)
+    # (the solver holds u as c .* u -- rows pre-multiplied by the GCN coefficient, see DESIGN.md -- so "exactly" is up to the
+    # two roundings of (u * c) / c)
+    assert torch.allclose(uT, ut, rtol=2.5e-7, atol=0.0)
     uT.sum().backward()
-    assert torch.equal(u.grad, torch.ones_like(u)) and float(ps0["layer_1"]["weight"].grad.abs().max()) == 0.0
+    assert torch.allclose(u.grad, torch.ones_like(u), rtol=2.5e-7, atol=0.0)
+    assert float(ps0["layer_1"]["weight"].grad.abs().max()) == 0.0
 
 
 def mesh(n, traj):
