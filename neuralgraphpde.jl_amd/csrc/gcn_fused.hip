@@ -563,6 +563,8 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
       float4 yv = f4_act(act, z);
       if (PRE) yv = f4_scale(__int_as_float(sc[r].w), yv);
       reinterpret_cast<float4 *>(p.y)[idx4] = yv;
+      // (written non-temporally the stage input leaves this launch 0.35 us earlier and reaches the next launch's gather
+      // 0.3 us later: a wash, unlike g_out in the pullback)
       if (p.has_comb) reinterpret_cast<float4 *>(p.comb_out)[idx4] = comb_finish(p.comb, yv, cterm[r]);
     }
   }
@@ -827,7 +829,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       if (sc[r].x < 0) continue;
       float4 gv = *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
       if (PRE) gv = f4_scale(__int_as_float(sc[r].w), gv);   // stored as c .* G: the next launch gathers it raw
-      reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q] = gv;
+store_stream4(&reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q], gv);   // gathered once by the next launch
     }
   }
   if (PAIR) {
