@@ -139,14 +139,6 @@ def main():
 
     s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
     g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
-    if os.environ.get("NGPDE_BENCH_DEGSORT") == "1":      # experiment: rows of a tile in descending degree
-        o = g.node_order().copy()
-        deg = np.bincount(t, minlength=N_NODES) + np.bincount(s, minlength=N_NODES)
-        for k in range(0, N_NODES, 32):
-            c = o[k:k + 32]
-            o[k:k + 32] = c[np.argsort(-deg[c], kind="stable")]
-        g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
-        g._shared["order"] = o.astype(np.int32)
     lib = _lib.load()
     dv = lambda a: torch.as_tensor(a, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
