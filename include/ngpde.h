@@ -301,6 +301,10 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *plan, const float *duT, float *du
 /* Names and average device time of the plan's kernels are visible to rocprofv3 --kernel-trace;
  * this returns the number of kernel launches one forward (+ backward) solve enqueues. */
 int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);
+/* which internal forms the plan chose: bit 0 = pre-scaled arrays (rows held as c .* x, halo rows staged by LDS-DMA),
+ * bit 1 = relu sign-bit masks instead of saved layer outputs, bit 2 = eager launches (no HIP-graph replay) */
+enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4 };
+int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
  * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ngpde_node_gcn2_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_node_gcn2_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_node_launch_count": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ngpde_node_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "ngpde_node_profile": (_i32, [_vp, _i32, C.POINTER(_f32), C.POINTER(_i32), _vp]),
 }
 

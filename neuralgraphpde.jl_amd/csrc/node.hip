@@ -431,6 +431,12 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t
   return NGPDE_OK;
 }
 
+int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
+  NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
+  *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0);
+  return NGPDE_OK;
+}
+
 int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w1, const float *b1, const float *w2,
                                 const float *b2, float *uT, ngpde_stream_t stream_) {
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: plan is NULL");

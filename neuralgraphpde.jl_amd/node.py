@@ -47,6 +47,12 @@ class _Plan:
         _lib.check(self.lib.ngpde_node_launch_count(self.ptr, C.byref(f), C.byref(b)))
         return f.value, b.value
 
+    def flags(self):
+        """{'prescaled', 'sign_masks', 'eager'}: the internal forms the plan chose (ngpde_node_flags)"""
+        f = C.c_int32()
+        _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
+        return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager")) if f.value & bit}
+
     def __del__(self):
         try:
             if self.ptr:

@@ -254,6 +254,52 @@ def test_node_forward_backward_parity(tab, d, act):
         close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
 
 
+@pytest.mark.parametrize("d,act,graph", [(16, "tanh", "knn"), (32, "swish", "radius"), (64, "tanh", "knn"), (64, "relu", "radius"),
+                                         (32, "relu", "knn")])
+def test_node_prescaled_pipeline_parity(d, act, graph, monkeypatch):
+    """The solver plan on graphs whose tiles fit the LDS halo holds its arrays as c .* x and stages halo rows by LDS-DMA
+    (ngpde_node_flags: prescaled).  Same parity bar as the register-staged form, on a symmetric radius graph and on a
+    directed k-NN graph (in- and out-lists differ: forward and pullback walk different halos), and bit-for-bit agreement
+    is NOT required between the two forms -- they round differently -- only agreement within the tolerance."""
+    N, nsteps, dt = 2048, 3, 0.1
+    rng = np.random.default_rng(d)
+    P = rng.random((2, N)).astype(np.float32)
+    g = ng.radius_graph(P, 0.035) if graph == "radius" else ng.knn_graph(P, 6)
+    s, t = g.edge_index(0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    params = [dict(weight=S.glorot_uniform(d + 10 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    u0 = rng.normal(size=(d, N))
+    uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, og, u0, O.TABLEAUS["tsit5"], dt, nsteps, act)
+    results = {}
+    for form in ("prescaled", "plain"):
+        if form == "plain":
+            monkeypatch.setenv("NGPDE_NO_PRESCALE", "1")
+        rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+        node = ng.NeuralODE(rhs, solver="tsit5", n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        plan = node.plan_for(ps, st, True)
+        assert ("prescaled" in plan.flags()) == (form == "prescaled")
+        close(uT, uTo, rtol=2e-4, what=f"{form} u(T)")
+        uT.sum().backward()
+        # relu: a pre-activation within an ulp of zero may fall on either side of the kink (see test_configs_gpu.py)
+        loose = 20.0 if act == "relu" else 1.0
+        close(u.grad, du0o, rtol=5e-4 * loose, atol=1e-4 * loose, what=f"{form} du0")
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            close(ps[name]["weight"].grad, acc[k]["weight"], rtol=5e-4 * loose, atol=1e-3, what=f"{form} dW{k + 1}")
+            close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4 * loose, atol=1e-3, what=f"{form} db{k + 1}")
+        results[form] = uT.detach().cpu().numpy()
+    assert np.allclose(results["prescaled"], results["plain"], rtol=1e-4, atol=1e-5)
+
+
 def test_node_matches_layerwise_euler_step():
     # one Euler step through the plan == u + dt * Chain(GCNConv, GCNConv)(u) through the layer API
     N, d = 200, 32
