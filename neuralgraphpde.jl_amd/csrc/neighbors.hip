@@ -433,6 +433,9 @@ Grid make_grid(int dim, const float *lo, const float *hi, float want, int64_t bu
   return g;
 }
 
+// total cells over all graphs: ~4 per point, and (graph, cell) keys must fit 32 bits
+inline int64_t cell_budget(int64_t n) { return std::min<int64_t>(std::max<int64_t>(4 * n, 1 << 16), (int64_t)1 << 30); }
+
 struct Sorted {
   unsigned *key = nullptr;    // sorted (graph, cell) keys
   int32_t *idx = nullptr;     // original index per sorted position
@@ -473,7 +476,7 @@ int32_t radius_graph_impl(int64_t n, const float *pts, float r, const int32_t *g
   float lo[3], hi[3];
   int32_t st;
   if ((st = bounding_box(n, DIM, pts, gid, id_base, n_graphs, stream, sc, lo, hi))) return st;
-  const Grid g = make_grid(DIM, lo, hi, r * 1.01f, std::max<int64_t>(4 * n, 1 << 16), n_graphs);
+  const Grid g = make_grid(DIM, lo, hi, r * 1.01f, cell_budget(n), n_graphs);
   Sorted so;
   if ((st = sort_into_cells<DIM>(n, g, n_graphs, pts, gid, id_base, stream, sc, so))) return st;
   int32_t *deg = nullptr, *rowptr = nullptr;
@@ -529,7 +532,7 @@ int32_t knn_graph_impl(int64_t n, const float *pts, int k, const int32_t *gid, i
   for (int d = 0; d < DIM; ++d) vol *= std::max((double)hi[d] - (double)lo[d], 1e-30);
   const double per_graph = std::max(1.0, (double)n / n_graphs);
   const float want = (float)std::pow(vol * std::max(1.0, 0.5 * k) / per_graph, 1.0 / DIM);
-  const Grid g = make_grid(DIM, lo, hi, want, std::max<int64_t>(4 * n, 1 << 16), n_graphs);
+  const Grid g = make_grid(DIM, lo, hi, want, cell_budget(n), n_graphs);
   Sorted so;
   if ((st = sort_into_cells<DIM>(n, g, n_graphs, pts, gid, id_base, stream, sc, so))) return st;
   int *short_rows = nullptr;
