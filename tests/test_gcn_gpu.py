@@ -4,6 +4,8 @@ the C ABI) against the float64 numpy oracle on the same seeded inputs.
 Tolerances: forward  max|y - y_oracle| <= 1e-4 * max|y_oracle| + 1e-5,
 gradients 2e-4 relative (segmented sums of <= ~150 fp32 terms; fp32 MFMA is an exact fmaf chain).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -271,6 +273,7 @@ def test_node_prescaled_pipeline_parity(d, act, graph, monkeypatch):
     u0 = rng.normal(size=(d, N))
     uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, og, u0, O.TABLEAUS["tsit5"], dt, nsteps, act)
     results = {}
+    switched_off = bool(os.environ.get("NGPDE_NO_PRESCALE") or os.environ.get("NGPDE_NO_HALO"))   # suite run under a switch
     for form in ("prescaled", "plain"):
         if form == "plain":
             monkeypatch.setenv("NGPDE_NO_PRESCALE", "1")
@@ -287,7 +290,7 @@ def test_node_prescaled_pipeline_parity(d, act, graph, monkeypatch):
         u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
         uT, _ = node(u, ps, st)
         plan = node.plan_for(ps, st, True)
-        assert ("prescaled" in plan.flags()) == (form == "prescaled")
+        assert ("prescaled" in plan.flags()) == (form == "prescaled" and not switched_off)
         close(uT, uTo, rtol=2e-4, what=f"{form} u(T)")
         uT.sum().backward()
         # relu: a pre-activation within an ulp of zero may fall on either side of the kink (see test_configs_gpu.py)
