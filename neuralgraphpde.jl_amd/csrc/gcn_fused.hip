@@ -717,7 +717,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       halo_finish<D, true, false>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t, nullptr, [&]() {
         load_mask();
         if (!(p.order & 2)) load_slab();
-        if (!p.tape_late) load_tape();
+        load_tape();
       });
     } else {
       halo_finish<D, false, !PRE, NoHook, !PRE>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t);
@@ -729,7 +729,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
     for (int r = 0; r < G::R; ++r) t[r] = G4[(size_t)max(sc[r].x, 0) * G::LPR + q];
   }
   NGPDE_STAMP(1);
-  if (p.tape_late) load_tape();
+  if (!DMA && p.tape_late) load_tape();
   if (DMA || (p.order & 1)) load_w();
   if (p.order & 2) load_slab();
   if (active && p.has_comb) {   // adjoint stage terms: one batch of independent node-local loads
