@@ -1,0 +1,33 @@
+"""The boundary called from plain C: tests/c_abi/gcn_roundtrip.c is compiled with gcc against include/ngpde.h, linked with
+libngpde_hip.so, the HIP runtime and the C oracle (the checker), and run on the GPU -- no Python, torch or C++ on the
+calling side.  This is the shape of the ccall binding INTEGRATION.md sketches for the Julia package."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("c_abi") / "gcn_roundtrip")
+    lib_dir = os.path.join(ROOT, "neuralgraphpde.jl_amd")
+    odir = os.path.join(ROOT, "oracle")
+    if not os.path.exists(os.path.join(odir, "libngpde_oracle.so")):
+        subprocess.check_call(["make", "-C", odir])
+    cmd = ["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", "gcn_roundtrip.c"), "-o", out,
+           os.path.join(lib_dir, "libngpde_hip.so"), os.path.join(odir, "libngpde_oracle.so"),
+           "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{odir}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return out
+
+
+@pytest.mark.parametrize("d", [64, 24])
+def test_gcn_roundtrip_from_plain_c(exe, d):
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0.1.0" in r.stdout
