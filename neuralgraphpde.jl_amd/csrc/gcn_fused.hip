@@ -779,7 +779,19 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
   NGPDE_STAMP(2);
   // G = dZ x Wt^T  (gradient w.r.t. the aggregated input)
   mfma_rows_times_bt<D>(ldsDZ, ldsBt, ldsG, wave_u, lane);
+  __syncthreads();   // G complete in LDS; W^T no longer needed
   NGPDE_STAMP(3);
+  // the product rows leave for memory now and drain under the dW product instead of at the end of the launch
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < G::R; ++r) {
+      if (sc[r].x < 0) continue;
+      float4 gv = *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
+      if (PRE) gv = f4_scale(__int_as_float(sc[r].w), gv);   // stored as c .* G: the next launch gathers it raw
+      store_stream4(&reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q], gv);   // gathered once by the next launch
+    }
+  }
+  NGPDE_STAMP(4);
   // dWt[i][o] += sum_n X3[n][i] dZ[n][o]   (K = kTM rows of this tile)
   const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -810,29 +822,18 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
     dbv += s;
     if (!PAIR && dbpart == 0) p.slab_db[(size_t)blockIdx.x * D + dbc] = dbv;
   }
-  NGPDE_STAMP(4);
-  __syncthreads();
   NGPDE_STAMP(5);
-  // PAIR: half 1 parks its dW tiles and db partials in its (now idle) W^T region
-  float *park = lds_all + (PAIR ? 2 : 1) * kXZ + (PAIR ? 1 : 0) * kRest + 2 * kTM * G::TS;   // half 1's W^T region: [NT][64 lanes][4] + [D]
-  if (PAIR && half == 1) {
-#pragma unroll
-    for (int m = 0; m < G::DWT; ++m) {
-      const int tt = wave_u + G::WAVES * m;
-      if (tt < NT) reinterpret_cast<float4 *>(park)[tt * 64 + lane] = sl[m];
-    }
-    if (dbpart == 0) park[NT * 256 + dbc] = dbv;
-  }
-  if (active) {
-#pragma unroll
-    for (int r = 0; r < G::R; ++r) {
-      if (sc[r].x < 0) continue;
-      float4 gv = *reinterpret_cast<const float4 *>(&ldsG[(grp * G::R + r) * G::TS + 4 * q]);
-      if (PRE) gv = f4_scale(__int_as_float(sc[r].w), gv);   // stored as c .* G: the next launch gathers it raw
-store_stream4(&reinterpret_cast<float4 *>(p.g_out)[(size_t)sc[r].x * G::LPR + q], gv);   // gathered once by the next launch
-    }
-  }
   if (PAIR) {
+    // half 1 parks its dW tiles and db partials in its W^T region (idle since the barrier above), half 0 folds them in
+    float *park = lds_all + 2 * kXZ + kRest + 2 * kTM * G::TS;   // [NT][64 lanes][4] + [D]
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < G::DWT; ++m) {
+        const int tt = wave_u + G::WAVES * m;
+        if (tt < NT) reinterpret_cast<float4 *>(park)[tt * 64 + lane] = sl[m];
+      }
+      if (dbpart == 0) park[NT * 256 + dbc] = dbv;
+    }
     __syncthreads();
     if (half == 0) {   // fixed order: (slab + half 0) + half 1
 #pragma unroll

@@ -59,6 +59,6 @@ for k, nme in enumerate(names):
 fl = ["sched+W issue+aggregate", "LDS stage+sync", "MFMA+sync", "epilogue"]
 report("fwd layer1", list(range(0, nf, 2)), 4, fl)
 report("fwd layer2+stage", list(range(1, nf, 2)), 4, fl)
-bl = ["sched+W issue+aggregate", "comb+mask+LDS stage+sync", "G MFMA", "dW MFMA+slab RMW+db", "sync", "G store"]
+bl = ["sched+W issue+aggregate", "comb+mask+LDS stage+sync", "G MFMA+sync", "G rows out", "dW MFMA+db", "fold+slab store"]
 report("bwd layer1", list(range(nf + 1, nl - 1, 2)), 6, bl)
 report("bwd stage+layer2", list(range(nf + 2, nl - 1, 2)), 6, bl)
