@@ -691,6 +691,52 @@ def gcn2_node_loss_and_grads(params, g, u0, tableau, dt, nsteps, activation="rel
     return uT, du0, acc
 
 
+def gcn2_node_prescaled(params, g, u0, tableau, dt, nsteps, activation="relu"):
+    """The same solve and discrete adjoint written in the variables the HIP solver plan keeps (DESIGN.md section 5,
+    "pre-scaled pipeline"): every feature array multiplied by c[row] = 1/sqrt(degree),  u~ = u .* c',  y~ = y .* c',
+    adjoint products G~ = G .* c'.  With A~ = A + I (0/1 adjacency with self loops, A~[i, j] = 1 for an edge j -> i):
+        forward   a = (x~ A~') .* c'        (plain sums of stored rows, one factor c_i per row)
+                  z = W a + b ,  y~ = act(z) .* c'
+        pullback  dz = (dy~ .* c') .* act'(z) ,  dW = dz a' ,  db = sum dz ,  G~ = (W' dz) .* c' ,  dx~ = G~ A~
+    Entry u~0 = u0 .* c', exit u(T) = u~(T) ./ c', seed lambda~ = dL/du(T) ./ c', du0 = lambda~0 .* c'.
+    Checker of the algebra only (dense adjacency: small graphs); returns (uT, du0, [grads layer1, grads layer2])."""
+    ga = add_self_loops(g)
+    n = g.num_nodes
+    At = np.zeros((n, n))
+    np.add.at(At, (ga.t, ga.s), 1.0)                      # At[i, j] = number of edges j -> i (self loops included)
+    c = (1.0 / np.sqrt(At.sum(axis=1)))[None, :]          # c' as a row: scales columns (nodes)
+
+    def layer(xs, p):
+        a = (xs @ At.T) * c
+        z = p["weight"] @ a + p["bias"]
+        return act(activation, z) * c, (a, z, p)
+
+    def layer_vjp(cache, dys):
+        a, z, p = cache
+        dz = (dys * c) * dact(activation, z)
+        return ((p["weight"].T @ dz) * c) @ At, dict(weight=dz @ a.T, bias=dz.sum(axis=1, keepdims=True))
+
+    def rhs(us):
+        y1, c1 = layer(us, params[0])
+        y2, c2 = layer(y1, params[1])
+        return y2, (c1, c2)
+
+    def vjp(cache, kbar):
+        d1, g2 = layer_vjp(cache[1], kbar)
+        d0, g1 = layer_vjp(cache[0], d1)
+        return d0, [g1, g2]
+
+    uTs, tape = rk_solve(rhs, u0 * c, tableau, dt, nsteps)
+    acc = [dict(weight=np.zeros_like(p["weight"]), bias=np.zeros_like(p["bias"])) for p in params]
+
+    def accumulate(pg):
+        for A, G in zip(acc, pg):
+            A["weight"] += G["weight"]
+            A["bias"] += G["bias"].reshape(A["bias"].shape)
+    lam0 = rk_adjoint(vjp, tape, np.ones_like(uTs) / c, tableau, dt, accumulate)
+    return uTs / c, lam0 * c, acc
+
+
 # --------------------------------------------------------------------------------------------
 # Derived-graph handle (integer / byte work; the HIP library's ngpde_graph_t, include/ngpde.h).
 # Restates what the kernels are specified to read: CSR lists by target / by source in COO order

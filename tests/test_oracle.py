@@ -438,3 +438,26 @@ def test_spatial_order_restatement_properties():
     tiles = P[:, o].reshape(2, -1, 32)
     span = (tiles.max(axis=2) - tiles.min(axis=2)).max(axis=0)
     assert np.median(span) < 0.1
+
+
+# ---- the pre-scaled form of the solver plan is the same function ------------------------------------------------
+
+
+@pytest.mark.parametrize("tab,activation", [("euler", "relu"), ("tsit5", "tanh"), ("tsit5", "swish"), ("tsit5", "relu")])
+def test_prescaled_pipeline_algebra(tab, activation):
+    """the HIP solver plan keeps u, the layer outputs and the adjoint products multiplied by
+    c[row].  In float64 that form must reproduce the plain solve and its discrete adjoint to rounding, on a DIRECTED
+    graph (forward walks the in-lists, the pullback the out-lists) with multi-edges and pre-existing self loops."""
+    rng = np.random.default_rng(7)
+    n, d, m = 40, 6, 170
+    s, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    g = O.Graph(s, t, num_nodes=n, index_base=0)
+    params = [dict(weight=rng.normal(size=(d, d)) * 0.5, bias=rng.normal(size=(d, 1)) * 0.2) for _ in range(2)]
+    u0 = rng.normal(size=(d, n))
+    ref = O.gcn2_node_loss_and_grads(params, g, u0, O.TABLEAUS[tab], 0.1, 3, activation)
+    pre = O.gcn2_node_prescaled(params, g, u0, O.TABLEAUS[tab], 0.1, 3, activation)
+    assert np.allclose(pre[0], ref[0], rtol=1e-11, atol=1e-12)
+    assert np.allclose(pre[1], ref[1], rtol=1e-10, atol=1e-12)
+    for k in range(2):
+        assert np.allclose(pre[2][k]["weight"], ref[2][k]["weight"], rtol=1e-10, atol=1e-11)
+        assert np.allclose(pre[2][k]["bias"], ref[2][k]["bias"], rtol=1e-10, atol=1e-11)
