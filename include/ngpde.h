@@ -298,6 +298,15 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *plan, const float *u0, const float
 /* duT: adjoint of u(T).  Outputs: du0 [N][d], dw1,dw2 (d x d) column-major, db1,db2 [d]. */
 int32_t ngpde_node_gcn2_backward(ngpde_node_t *plan, const float *duT, float *du0, float *dw1,
                                  float *db1, float *dw2, float *db2, ngpde_stream_t stream);
+/* ONE solve in flight per plan: the plan owns a single tape, u0 copy and parameter copies, so a second
+ * ngpde_node_gcn2_forward overwrites what the first one's backward needs.  Every forward stamps a new generation (1, 2, ...);
+ * a caller that may interleave solves (an autograd tape holding two forwards) records the generation after its forward and
+ * calls ngpde_node_expect_generation right before its backward: NGPDE_ERR_STATE when another forward has run on the plan
+ * since.  *backward_pending = 1 while a forward of a with_backward plan has not been followed by its backward (take another
+ * plan for the next solve then).  A plan must be used from one stream at a time: its buffers are shared by whatever streams
+ * the calls are given and carry no cross-stream ordering. */
+int32_t ngpde_node_generation(const ngpde_node_t *plan, uint64_t *generation, int32_t *backward_pending);
+int32_t ngpde_node_expect_generation(const ngpde_node_t *plan, uint64_t generation);
 /* Names and average device time of the plan's kernels are visible to rocprofv3 --kernel-trace;
  * this returns the number of kernel launches one forward (+ backward) solve enqueues. */
 int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);

@@ -111,6 +111,10 @@ struct ngpde_node {
   hipGraph_t fwd_graph = nullptr, bwd_graph = nullptr;
   hipGraphExec_t fwd_exec = nullptr, bwd_exec = nullptr;
   bool forward_done = false;
+  // The plan owns ONE tape: a second forward overwrites what the first one's backward needs.  Every forward stamps a new
+  // generation; a caller that may interleave solves (autograd) records it and has it checked before the backward.
+  uint64_t generation = 0;
+  bool backward_pending = false;
   int fwd_launches = 0, bwd_launches = 0;
 
   // tape slot k of (step, stage): 0 = A1 (aggregated input of layer 1), 1 = Y1, 2 = A2, 3 = Y2 = k_i,
@@ -304,9 +308,16 @@ int32_t capture(ngpde_node *p, bool backward) {
     if (graph) (void)hipGraphDestroy(graph);
     return st;
   }
-  if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(NGPDE_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  }
   hipGraphExec_t exec = nullptr;
-  NGPDE_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return fail(NGPDE_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
   if (backward) {
     p->bwd_graph = graph; p->bwd_exec = exec; p->bwd_launches = count;
   } else {
@@ -469,6 +480,24 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
     NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   p->forward_done = true;
+  ++p->generation;
+  p->backward_pending = p->with_bwd;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_generation(const ngpde_node_t *p, uint64_t *generation, int32_t *backward_pending) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_generation: plan is NULL");
+  if (generation) *generation = p->generation;
+  if (backward_pending) *backward_pending = p->backward_pending ? 1 : 0;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_expect_generation(const ngpde_node_t *p, uint64_t generation) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_expect_generation: plan is NULL");
+  NGPDE_REQUIRE(p->generation == generation, NGPDE_ERR_STATE,
+                "the plan's tape belongs to solve %llu, not %llu: another forward ran on this plan before this backward "
+                "(one solve in flight per plan; use one plan per outstanding solve)",
+                (unsigned long long)p->generation, (unsigned long long)generation);
   return NGPDE_OK;
 }
 
@@ -498,6 +527,7 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   } else if (du0) {
     NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
+  p->backward_pending = false;
   if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
   if (db1) NGPDE_HIP_CHECK(hipMemcpyAsync(db1, p->db1, db, hipMemcpyDeviceToDevice, stream));
   if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));

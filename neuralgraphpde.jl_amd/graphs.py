@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -190,13 +191,31 @@ class GNNGraph:
         if norm is None:
             norm = (False, None, False)   # the plain handle carries the tile schedule too (the fused edge kernels walk it)
         w = norm[1]
-        key = (bool(norm[0]), None if w is None else id(w), bool(norm[2]))
-        h = self._handles.get(key)
+        if w is None:
+            key = (bool(norm[0]), None, bool(norm[2]))
+            h = self._handles.get(key)
+            if h is None:
+                h = self._handles[key] = (_Handle(self, norm), norm)
+            return h[0]
+        # Weighted normalisations: a small LRU keyed on the weights' identity AND content version, so that a caller passing
+        # `edge_weight` on every call (an ODE right-hand side: ~300 calls per solve) re-uses one handle while the weights
+        # are unchanged and never accumulates handles (each is a full CSR / halo build in HBM).  The entry keeps `w` alive,
+        # so data_ptr / id stay unique while it is cached.
+        if isinstance(w, torch.Tensor):
+            key = (bool(norm[0]), ("tensor", w.data_ptr(), w._version, tuple(w.shape), str(w.device)), bool(norm[2]))
+        else:
+            key = (bool(norm[0]), ("object", id(w)), bool(norm[2]))
+        lru = self._shared.setdefault("weighted_handles", OrderedDict())
+        h = lru.get(key)
         if h is None:
-            h = _Handle(self, norm)
-            self._handles[key] = (h, norm)   # keep `norm` alive so id(w) stays unique
-            return h
+            h = lru[key] = (_Handle(self, norm), norm)
+            while len(lru) > self.max_weighted_handles:
+                lru.popitem(last=False)         # the evicted _Handle frees its ngpde_graph_t when its last user lets go
+        else:
+            lru.move_to_end(key)
         return h[0]
+
+    max_weighted_handles = 4
 
     def node_order(self):
         """the locality order of this structure (int32 permutation), computed with the first handle and cached"""

@@ -260,7 +260,10 @@ class GCNConv(AbstractGNNLayer):
             if n_w != g.num_edges:                     # :207
                 raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT,
                                          f"Wrong number of edge weights (expected {g.num_edges} but given {n_w})")
-            w = edge_weight.detach().cpu().numpy() if isinstance(edge_weight, torch.Tensor) else edge_weight
+            # The weights stay where they are (no download): the handle cache keys on their identity and version
+            # (GNNGraph.handle).  They are constants of the layer call: no gradient reaches `edge_weight` (the reference
+            # would differentiate through e_mul_xj and degree; none of its callers does).
+            w = edge_weight.detach() if isinstance(edge_weight, torch.Tensor) else edge_weight
             norm = (self.add_self_loops, w, True)      # :224 degree uses the given weights
         elif self.use_edge_weight:
             if g.edge_weight is None:

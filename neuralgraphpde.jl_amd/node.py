@@ -11,6 +11,7 @@ layers' own kernels.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -28,6 +29,10 @@ _TSIT5_A = [
 _TSIT5_B = [0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
             2.324710524099774]
 TABLEAUS = {"euler": ([[]], [1.0]), "tsit5": (_TSIT5_A, _TSIT5_B)}
+
+
+class _Token:
+    __slots__ = ("__weakref__",)
 
 
 class _Plan:
@@ -53,6 +58,24 @@ class _Plan:
         _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
         return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager")) if f.value & bit}
 
+    def claim(self):
+        """token held by the autograd node of the solve that now owns the tape; the plan is busy while that node is alive
+        and its backward has not run"""
+        self._token = _Token()
+        self._token_ref = weakref.ref(self._token)
+        token, self._token = self._token, None
+        return token
+
+    def busy(self):
+        ref = getattr(self, "_token_ref", None)
+        return ref is not None and ref() is not None and self.generation()[1]
+
+    def generation(self):
+        """(generation of the last forward, is its backward still outstanding?) -- ngpde_node_generation"""
+        gen, pend = C.c_uint64(), C.c_int32()
+        _lib.check(self.lib.ngpde_node_generation(self.ptr, C.byref(gen), C.byref(pend)))
+        return gen.value, bool(pend.value)
+
     def __del__(self):
         try:
             if self.ptr:
@@ -71,6 +94,8 @@ class _NodeGCN2Fn(torch.autograd.Function):
         _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, _lib.ptr(u), _lib.ptr(w1t), _lib.ptr(b1), _lib.ptr(w2t),
                                                _lib.ptr(b2), _lib.ptr(uT), _lib.current_stream()))
         ctx.plan = plan
+        ctx.token = plan.claim()                   # dies with this autograd node: a solve nobody can differentiate any more
+        ctx.generation = plan.generation()[0]      # the plan's single tape now belongs to THIS solve
         ctx.shapes = (u.shape, w1t.shape, None if b1 is None else b1.shape, None if b2 is None else b2.shape)
         ctx.dev = u.device
         return uT
@@ -82,6 +107,9 @@ class _NodeGCN2Fn(torch.autograd.Function):
         mk = lambda s: None if s is None else torch.empty(s, dtype=torch.float32, device=ctx.dev)
         du0, dw1, dw2, db1, db2 = mk(us), mk(ws), mk(ws), mk(b1s), mk(b2s)
         duT = duT.contiguous()
+        # NGPDE_ERR_STATE if another forward has overwritten this solve's tape (cannot happen through NeuralODE.__call__,
+        # which takes a free plan for every outstanding solve; a second backward of the same solve is fine: the tape is kept)
+        _lib.check(lib.ngpde_node_expect_generation(ctx.plan.ptr, ctx.generation))
         _lib.check(lib.ngpde_node_gcn2_backward(ctx.plan.ptr, _lib.ptr(duT), _lib.ptr(du0), _lib.ptr(dw1), _lib.ptr(db1),
                                                 _lib.ptr(dw2), _lib.ptr(db2), _lib.current_stream()))
         return du0, dw1, db1, dw2, db2, None
@@ -113,7 +141,8 @@ class NeuralODE(AbstractExplicitLayer):
         return self.model.statelength()
 
     # -- is the right-hand side the tutorial's two-GCNConv chain on one graph? ---------------------
-    max_plans = 2   # device-resident solver plans kept per NeuralODE (forward-only and forward+backward of the current graph)
+    max_plans = 2   # cached solver-plan keys per NeuralODE (forward-only and forward+backward of the current graph)
+    max_outstanding = 8   # plans per key: one per solve whose backward is still outstanding (each owns a tape)
 
     def _gcn2(self, ps, st):
         m = self.model
@@ -127,7 +156,8 @@ class NeuralODE(AbstractExplicitLayer):
         if not same or d not in (16, 32, 64, 128):
             return None
         g1, g2 = st["layer_1"]["graph"], st["layer_2"]["graph"]
-        if g1 is not g2 and g1 != g2:
+        # copies made by wrapgraph / updategraph share one handle cache: same structure without comparing arrays
+        if g1 is not g2 and g1._handles is not g2._handles and g1 != g2:
             return None
         return l1, g1, d
 
@@ -138,14 +168,22 @@ class NeuralODE(AbstractExplicitLayer):
         l1, g, d = info
         handle = g.handle((l1.add_self_loops, None, False))
         key = (id(handle), d, l1.act, bool(with_backward))
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward)
-            self._plans[key] = plan
+        pool = self._plans.get(key)
+        if pool is None:
+            pool = self._plans[key] = []
             while len(self._plans) > self.max_plans:        # a plan owns its tape (GBs): keep only the most recent ones
                 self._plans.pop(next(iter(self._plans)))     # (a training loop that swaps the graph every minibatch)
         else:
             self._plans[key] = self._plans.pop(key)          # most recently used last
+        # a plan holds ONE solve's tape: `y1 = node(u1); y2 = node(u2); (y1 + y2).backward()` needs two
+        for plan in pool:
+            if not (with_backward and plan.busy()):
+                return plan
+        if len(pool) >= self.max_outstanding:
+            raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
+                                                  "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
+        plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward)
+        pool.append(plan)
         return plan
 
     def __call__(self, x, ps, st):

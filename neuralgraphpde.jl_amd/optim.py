@@ -109,7 +109,10 @@ def setup(rule, flat):
 def update(st_opt, flat, group=None, average=True):
     """Optimisers.update(st_opt, ps, gs) on the flat vector, in place: one all-reduce(sum) of the flat gradient over the
     data-parallel group (if initialised), then ONE kernel that scales, updates the moments and the parameters.
-    Leaves the gradient buffer untouched (call flat.zero_grad() before the next backward)."""
+    With more than one rank `flat.grad` is overwritten IN PLACE by the cross-rank SUM (the 1/world factor of `average` is
+    applied inside the kernel only): anything that reads flat.grad afterwards -- logging, clipping, a second optimiser --
+    sees the sum, world times the mean.  The kernel itself does not modify the buffer; call flat.zero_grad() before the
+    next backward."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
         dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)

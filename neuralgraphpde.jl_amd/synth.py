@@ -77,3 +77,30 @@ def closest_pairs_graph(n_nodes, n_pairs, seed):
 def glorot_uniform(seed, out_dims, in_dims):
     lim = np.sqrt(6.0 / (in_dims + out_dims))
     return ((uniform01(seed, out_dims * in_dims) * 2.0 - 1.0) * lim).reshape(out_dims, in_dims)
+
+
+def preferential_pairs_graph(n_nodes, n_pairs, seed, exponent=0.5):
+    """C1 graph: n_pairs distinct undirected pairs (no self loops) as symmetric directed edges, drawn with a
+    preferential-attachment bias -- endpoint i with probability ~ (i + 1)^-exponent -- so that degrees are skewed the way
+    Cora's are (Cora itself is not on disk): at 2 708 nodes / 5 278 pairs the largest degree is ~100, the median 3.
+    Deterministic given seed (splitmix64 streams; duplicates and self pairs are dropped in draw order)."""
+    w = (np.arange(n_nodes, dtype=np.float64) + 1.0) ** (-exponent)
+    cdf = np.cumsum(w) / w.sum()
+    chosen, seen, rnd = [], set(), 0
+    while len(chosen) < n_pairs:
+        m = 2 * n_pairs
+        a = np.minimum(np.searchsorted(cdf, uniform01(seed + 7919 * rnd, m)), n_nodes - 1)
+        b = np.minimum(np.searchsorted(cdf, uniform01(seed + 7919 * rnd + 1, m)), n_nodes - 1)
+        for i, j in zip(a.tolist(), b.tolist()):
+            if i == j:
+                continue
+            key = (min(i, j), max(i, j))
+            if key in seen:
+                continue
+            seen.add(key)
+            chosen.append(key)
+            if len(chosen) == n_pairs:
+                break
+        rnd += 2
+    pa = np.array(chosen, dtype=np.int64)
+    return np.concatenate([pa[:, 0], pa[:, 1]]), np.concatenate([pa[:, 1], pa[:, 0]])

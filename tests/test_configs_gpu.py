@@ -38,19 +38,21 @@ def gcn2_node(g, d, tableau, nsteps, dt, params, act="relu"):
 
 def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
     # C1: 2 708 nodes, 5 278 symmetric pairs -> 10 556 directed edges, D = 32, 2 x GCNConv relu, Euler x 10, dt = 0.1
+    # The graph has Cora's degree skew (preferential attachment; largest degree ~100, median 3), so its tiles
+    # do NOT fit the LDS halo (degree > 32) and the per-row global-gather kernels run at config size.
     N, PAIRS, D = 2708, 5278, 32
     rng = np.random.default_rng(1)
-    pairs = set()
-    while len(pairs) < PAIRS:
-        a, b = rng.integers(0, N, 2)
-        if a != b:
-            pairs.add((min(a, b), max(a, b)))
-    pa = np.array(sorted(pairs))
-    s, t = np.concatenate([pa[:, 0], pa[:, 1]]), np.concatenate([pa[:, 1], pa[:, 0]])
+    s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
+    deg = np.bincount(t, minlength=N)
+    assert s.size == 2 * PAIRS and deg.max() > 64 and np.median(deg) <= 4
     params = [dict(weight=S.glorot_uniform(40 + k, D, D), bias=rng.normal(size=(D, 1)) * 0.1) for k in range(2)]
     u0 = rng.normal(size=(D, N))
     g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
     node, ps, st = gcn2_node(g, D, "euler", 10, 0.1, params)
+    halo_ok = C.c_size_t()
+    from ngpde_amd import _lib
+    _lib.check(_lib.load().ngpde_graph_array(g.handle((True, None, False)).ptr, 0, 13, None, C.byref(halo_ok)))   # NGPDE_GRAPH_HALO_OK
+    assert halo_ok.value == 0, "C1 is meant to exercise the global-gather path"
     u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
     uT, _ = node(u, ps, st)
     uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, O.Graph(s, t, num_nodes=N, index_base=0), u0, O.TABLEAUS["euler"], 0.1, 10, "relu")
@@ -273,3 +275,211 @@ def test_c5_full_size_gno_is_linear_in_the_input_and_matches_the_literal_contrac
         finally:
             del os.environ["NGPDE_GNO_MATERIALIZE"]
     close(ya, yb.cpu().double().numpy(), 1e-4, what="reassociated vs materialised")
+
+
+# ---- forward AND backward at config size (C3, C4, C5) ---------------------------------------------------------------------------
+
+def _leaves(ps, prefix=""):
+    for k, v in ps.items():
+        if isinstance(v, dict):
+            yield from _leaves(v, prefix + k + ".")
+        else:
+            yield prefix + k, v
+
+
+def _grad_params(ps):
+    ps = ng.to_device(ps, DEV)
+    for _, v in _leaves(ps):
+        v.requires_grad_(True)
+    return ps
+
+
+def _omlp(layer, ps):
+    return [dict(weight=ps[nm]["weight"].detach().cpu().double().numpy(),
+                 bias=ps[nm]["bias"].detach().cpu().double().numpy() if "bias" in ps[nm] else None, act=d.activation)
+            for nm, d in zip(layer.names(), layer.chain)]
+
+
+def test_c3_gat_full_size_forward_and_backward_against_oracle():
+    # BASELINE config 3: GATConv 64 => 4 heads x 16 on the C2 graph (16 384 nodes, 131 072 edges + self loops), values and
+    # ALL gradients against the float64 oracle
+    _, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
+    N = 16384
+    g, og = ng.GNNGraph(s, t, num_nodes=N, index_base=0), O.Graph(s, t, num_nodes=N, index_base=0)
+    l = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+    ps, st = ng.setup(3, l)
+    ps["bias"] = torch.as_tensor(S.normal(35, 64).reshape(64, 1).astype(np.float32) * 0.2)
+    ps = _grad_params(ps)
+    x = torch.as_tensor(S.normal(33, 64 * N).reshape(64, N).astype(np.float32), device=DEV).requires_grad_(True)
+    y, _ = l(x, ps, st)
+    p = lambda k: ps[k].detach().cpu().double().numpy()
+    yo, c = O.gat_conv(x.detach().cpu().double().numpy(), p("weight"), p("a"), p("bias"), og, 4, 16, "relu")
+    close(y, yo, 1e-4, what="C3 forward")
+    R = S.normal(34, 64 * N).reshape(64, N)
+    (y * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+    gr = O.gat_conv_backward(c, R)
+    close(x.grad, gr["x"], 5e-4, 1e-4, "C3 dx")
+    close(ps["weight"].grad, gr["weight"], 5e-4, 2e-3, "C3 dW")      # sums over 16 384 nodes in fp32
+    close(ps["a"].grad, gr["a"], 5e-4, 2e-3, "C3 da")
+    close(ps["bias"].grad, gr["bias"].reshape(-1, 1), 5e-4, 2e-3, "C3 db")
+
+
+def test_c4_shard_backward_per_trajectory_oracle_and_batch_sum_rule():
+    # C4 per-GPU shard (64 trajectories x 8 192-node periodic mesh = 524 288 nodes, 3 145 728 edges), forward + backward:
+    #  (a) a cotangent supported on ONE trajectory: dx and every parameter gradient of the batched launch equal the float64
+    #      oracle's on that trajectory alone (trajectories are independent blocks; theta is per graph);
+    #  (b) the same trajectory evaluated alone through the HIP path gives the same gradients as the batched launch;
+    #  (c) a full random cotangent: the batch's parameter gradients are the sum of the per-trajectory ones, its dx their
+    #      concatenation (every trajectory run alone on the GPU).
+    n, traj, h = 8192, 64, 64
+    rng = np.random.default_rng(4)
+    S_, T_ = mesh(n, traj)
+    N = n * traj
+    u = rng.random((1, N)).astype(np.float32)
+    xs = np.tile(np.arange(n) / n, traj)[None, :].astype(np.float32)
+    th = rng.random((2, traj)).astype(np.float32)
+    g = ng.GNNGraph(S_, T_, num_nodes=N, index_base=0, num_graphs=traj, ndata={"u": u, "x": xs}, gdata={"θ": th})
+    phi = ng.Chain(ng.Dense(132, 64, "swish"), ng.Dense(64, 64, "swish"))
+    psi = ng.Chain(ng.Dense(130, 64, "swish"), ng.Dense(64, 64))
+    l = ng.MPPDEConv(phi, psi, initialgraph=g)
+    ps, st = ng.setup(4, l)
+    ps = _grad_params(ps)
+    x0 = torch.randn(N, h, device=DEV)
+    s1, t1 = mesh(n, 1)
+
+    def grads(layer_state, xin, R):
+        for _, v in _leaves(ps):
+            v.grad = None
+        xin = xin.clone().requires_grad_(True)
+        y, _ = l(xin.T, ps, layer_state)
+        (y * R.T).sum().backward()
+        return y.detach(), xin.grad.detach().clone(), {k: v.grad.detach().clone() for k, v in _leaves(ps)}
+
+    def single_state(k):
+        sl = slice(k * n, (k + 1) * n)
+        g1 = ng.GNNGraph(s1, t1, num_nodes=n, index_base=0, ndata={"u": u[:, sl], "x": xs[:, sl]}, gdata={"θ": th[:, k]})
+        return ng.updategraph(st, g1), sl
+
+    # (a) + (b)
+    k = traj - 1
+    st1, sl = single_state(k)
+    R = torch.zeros(N, h, device=DEV)
+    R[sl] = torch.randn(n, h, device=DEV)
+    yb, dxb, gb = grads(st, x0, R)
+    assert float(dxb[:k * n].abs().max()) == 0.0                      # nothing leaks into the other trajectories
+    og = O.Graph(s1, t1, num_nodes=n, index_base=0, ndata={"u": u[:, sl].astype(np.float64), "x": xs[:, sl].astype(np.float64)},
+                 gdata={"θ": th[:, k].astype(np.float64)})
+    yo, cache = O.mppde_conv(x0[sl].T.cpu().double().numpy(), _omlp(phi, ps["ϕ"]), _omlp(psi, ps["ψ"]), og, "mean")
+    close(yb[:, sl], yo, 1e-4, what="C4 forward, last trajectory")
+    gr = O.mppde_conv_backward(cache, R[sl].T.cpu().double().numpy())
+    close(dxb[sl].T, gr["x"], 5e-4, 1e-4, "C4 dx")
+    for sub, key, layer in (("ϕ", "phi", phi), ("ψ", "psi", psi)):
+        for nm, og_l in zip(layer.names(), gr[key]):
+            close(gb[f"{sub}.{nm}.weight"], og_l["weight"], 5e-4, 2e-3, f"C4 d{sub}.{nm}.weight")
+            close(gb[f"{sub}.{nm}.bias"], og_l["bias"], 5e-4, 2e-3, f"C4 d{sub}.{nm}.bias")
+    y1, dx1, g1 = grads(st1, x0[sl], R[sl])
+    assert torch.equal(y1, yb[:, sl])
+    assert torch.allclose(dx1, dxb[sl], rtol=1e-5, atol=1e-6)
+    for name in gb:
+        scale = float(gb[name].abs().max())
+        assert torch.allclose(g1[name], gb[name], rtol=1e-4, atol=1e-5 * scale + 1e-7), name
+    # (c)
+    R = torch.randn(N, h, device=DEV)
+    yb, dxb, gb = grads(st, x0, R)
+    acc = {name: torch.zeros_like(v, dtype=torch.float64) for name, v in gb.items()}
+    for k in range(traj):
+        st1, sl = single_state(k)
+        y1, dx1, g1 = grads(st1, x0[sl], R[sl])
+        assert torch.equal(y1, yb[:, sl])
+        assert torch.allclose(dx1, dxb[sl], rtol=1e-5, atol=1e-6), k
+        for name in acc:
+            acc[name] += g1[name].double()
+    for name in acc:
+        close(gb[name], acc[name].cpu().numpy(), 5e-4, 1e-4, f"C4 batch sum rule {name}")
+
+
+def _grid_radius_graph(k, radius):
+    cell = int(np.ceil(radius * k)) + 1
+    ii, jj = np.divmod(np.arange(k * k), k)
+    ss, tt = [], []
+    for di in range(-cell, cell + 1):
+        for dj in range(-cell, cell + 1):
+            if di == 0 and dj == 0:
+                continue
+            ni, nj = ii + di, jj + dj
+            ok = (ni >= 0) & (ni < k) & (nj >= 0) & (nj < k) & ((di / k) ** 2 + (dj / k) ** 2 < radius ** 2)
+            ss.append((ni * k + nj)[ok]); tt.append(np.arange(k * k)[ok])
+    return np.concatenate(ss), np.concatenate(tt)
+
+
+@pytest.mark.parametrize("radius", [0.05, 0.1])
+def test_c5_full_size_gno_forward_and_backward(radius):
+    # C5: 64 x 64 grid, radius graph, GNOConv 128 => 128, phi 6 => 64 => 16 384, mean aggregation, forward + backward at
+    # config size (the literal kernel tensor would be 7.2 / 29.6 GB in fp32, twice that for the float64 oracle):
+    #  (a) cotangent supported on a SUBSET of target nodes: y on the subset, dx and every parameter gradient equal the
+    #      float64 oracle evaluated on the sub-graph of the edges INTO the subset (the literal reshape / batched_mul form,
+    #      src/layers.jl:516-536; a mean over a node's complete set of incoming edges is unchanged, other nodes have zero
+    #      cotangent), while the HIP path runs its full-size launches;
+    #  (b) full random cotangent, adjoint identities of the maps that are linear: <R, J_x v> = <J_x^T R, v> (the layer with
+    #      identity activation is affine in x) and <R, y(W2 + dW2) - y(W2)> = <dL/dW2, dW2> (affine in phi's last layer).
+    k, width = 64, 128
+    N = k * k
+    gx, gy = np.meshgrid((np.arange(k) + 0.5) / k, (np.arange(k) + 0.5) / k, indexing="ij")
+    pts = np.stack([gx.ravel(), gy.ravel()])
+    s, t = _grid_radius_graph(k, radius)
+    rng = np.random.default_rng(5)
+    nd = {"a": rng.random((1, N)).astype(np.float32), "x": pts.astype(np.float32)}
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, ndata=nd)
+    phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, width * width))
+    l = ng.GNOConv((width, width), phi, "identity", initialgraph=g)
+    ps, st = ng.setup(5, l)
+    ps["linear"]["bias"] = torch.as_tensor(rng.normal(size=(width, 1)).astype(np.float32) * 0.1)
+    ps = _grad_params(ps)
+    x0 = torch.randn(N, width, device=DEV)
+
+    def run(R, xin=None, params=None):
+        P = ps if params is None else params
+        for _, v in _leaves(P):
+            v.grad = None
+        xin = (x0 if xin is None else xin).clone().requires_grad_(True)
+        y, _ = l(xin.T, P, st)
+        if R is None:
+            return y.detach()
+        (y * R.T).sum().backward()
+        return y.detach(), xin.grad.detach().clone(), {kk: v.grad.detach().clone() for kk, v in _leaves(P)}
+
+    # (a) 48 target nodes spread over the grid (corners and edges included: ragged degrees)
+    sub = np.unique(np.concatenate([[0, k - 1, N - k, N - 1], rng.choice(N, 44, replace=False)]))
+    R = torch.zeros(N, width, device=DEV)
+    R[torch.as_tensor(sub, device=DEV)] = torch.randn(sub.size, width, device=DEV)
+    y, dx, gp = run(R)
+    keep = np.isin(t, sub)
+    og = O.Graph(s[keep], t[keep], num_nodes=N, index_base=0, ndata={kk: v.astype(np.float64) for kk, v in nd.items()})
+    W = ps["linear"]["weight"].detach().cpu().double().numpy()
+    b = ps["linear"]["bias"].detach().cpu().double().numpy()
+    yo, cache = O.gno_conv(x0.T.cpu().double().numpy(), _omlp(phi, ps["ϕ"]), W, b, og, width, width, "identity")
+    close(y[:, sub], yo[:, sub], 1e-4, what="C5 forward on the subset")
+    gr = O.gno_conv_backward(cache, R.T.cpu().double().numpy())
+    close(dx.T, gr["x"], 5e-4, 1e-4, "C5 dx")
+    close(gp["linear.weight"], gr["weight"], 5e-4, 1e-4, "C5 dW")
+    close(gp["linear.bias"], gr["bias"], 5e-4, 1e-4, "C5 db")
+    for nm, og_l in zip(phi.names(), gr["phi"]):
+        close(gp[f"ϕ.{nm}.weight"], og_l["weight"], 5e-4, 2e-4, f"C5 dϕ.{nm}.weight")
+        close(gp[f"ϕ.{nm}.bias"], og_l["bias"], 5e-4, 2e-4, f"C5 dϕ.{nm}.bias")
+    del cache, gr, yo
+    # (b) adjoint identities at full size with a full random cotangent, all on the GPU (double accumulation of the dot products)
+    R = torch.randn(N, width, device=DEV)
+    y, dx, gp = run(R)
+    dot = lambda a, b_: float((a.double() * b_.double()).sum())
+    v = torch.randn(N, width, device=DEV)
+    yv = run(None, xin=x0 + v)
+    lhs, rhs = dot(R.T, yv - y), dot(dx, v)
+    assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), abs(rhs)) + 1e-5 * float(R.norm() * (yv - y).norm()), (lhs, rhs)
+    dW2 = torch.randn_like(ps["ϕ"]["layer_2"]["weight"]) * 0.05
+    P2 = {"ϕ": {"layer_1": ps["ϕ"]["layer_1"], "layer_2": {"weight": (ps["ϕ"]["layer_2"]["weight"].detach() + dW2),
+                                                             "bias": ps["ϕ"]["layer_2"]["bias"].detach()}},
+          "linear": ps["linear"]}
+    with torch.no_grad():
+        y2, _ = l(x0.T, P2, st)
+    lhs, rhs = dot(R.T, y2 - y), dot(gp["ϕ.layer_2.weight"], dW2)
+    assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), abs(rhs)) + 1e-5 * float(R.norm() * (y2 - y).norm()), (lhs, rhs)

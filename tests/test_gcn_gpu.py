@@ -330,3 +330,96 @@ def test_node_replay_is_deterministic_and_reusable():
     assert torch.equal(a, b)
     c, _ = node(2 * u, ps, st)
     assert not torch.equal(a, c)
+
+
+def test_node_two_forwards_then_one_backward_matches_the_oracle():
+    # y1 = node(u1); y2 = node(u2); (y1.sum() + y2.sum()).backward(): each solve keeps its own tape (one plan per outstanding
+    # solve), so du1 / du2 are each solve's own adjoint and the parameter gradients are the sum of both
+    N, E, d, nsteps, dt = 257, 1900, 32, 3, 0.1
+    g, og, params, u0 = node_case(N, E, d, "tsit5", nsteps, dt, "relu", seed=77)
+    u0b = np.random.default_rng(78).normal(size=(d, N))
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver="tsit5", n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    u1 = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    u2 = torch.as_tensor(u0b.astype(np.float32), device=DEV).requires_grad_(True)
+    y1, _ = node(u1, ps, st)
+    y2, _ = node(u2, ps, st)
+    assert sum(len(pool) for pool in node._plans.values()) == 2          # the second solve did not take the first one's tape
+    (y1.sum() + y2.sum()).backward()
+    o1 = O.gcn2_node_loss_and_grads(params, og, u0, O.TABLEAUS["tsit5"], dt, nsteps, "relu")
+    o2 = O.gcn2_node_loss_and_grads(params, og, u0b, O.TABLEAUS["tsit5"], dt, nsteps, "relu")
+    close(y1, o1[0], rtol=2e-4, what="u1(T)")
+    close(y2, o2[0], rtol=2e-4, what="u2(T)")
+    close(u1.grad, o1[1], rtol=5e-4, atol=1e-4, what="du1")
+    close(u2.grad, o2[1], rtol=5e-4, atol=1e-4, what="du2")
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, o1[2][k]["weight"] + o2[2][k]["weight"], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, o1[2][k]["bias"] + o2[2][k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+    # both plans are free again: the next solve re-uses one of them
+    y3, _ = node(u1, ps, st)
+    assert sum(len(pool) for pool in node._plans.values()) == 2
+    del y3
+
+
+def test_node_plan_rejects_a_backward_whose_tape_was_overwritten():
+    # straight through the C ABI: forward(u1), forward(u2), then the backward of the FIRST solve -> NGPDE_ERR_STATE
+    import ctypes as C
+    from ngpde_amd import _lib
+    from ngpde_amd.node import _Plan
+    N, d = 128, 16
+    g = ng.rand_graph(N, 800, seed=9)
+    plan = _Plan(g.handle((True, None, False)), d, _lib.ACT["relu"], "euler", 2, 0.1, True)
+    lib, p = _lib.load(), _lib.ptr
+    u1, u2 = torch.randn(N, d, device=DEV), torch.randn(N, d, device=DEV)
+    w, b, out = torch.randn(d, d, device=DEV) * 0.1, torch.zeros(d, device=DEV), torch.empty(N, d, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u1), p(w), p(b), p(w), p(b), p(out), stream))
+    gen1, pending = plan.generation()
+    assert pending and gen1 == 1
+    _lib.check(lib.ngpde_node_expect_generation(plan.ptr, gen1))
+    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u2), p(w), p(b), p(w), p(b), p(out), stream))
+    with pytest.raises(ng.NgpdeError, match="another forward ran on this plan"):
+        _lib.check(lib.ngpde_node_expect_generation(plan.ptr, gen1))
+    gen2, _ = plan.generation()
+    _lib.check(lib.ngpde_node_expect_generation(plan.ptr, gen2))
+    _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(torch.ones(N, d, device=DEV)), p(out), None, None, None, None, stream))
+    assert plan.generation() == (gen2, False)
+    torch.cuda.synchronize()
+
+
+def test_gcn_edge_weight_argument_reuses_one_handle_and_stays_bounded():
+    # GCNConv(x, ps, st, edge_weight) as an ODE right-hand side passes the same weights on every call: one derived-graph
+    # handle, no download of the weights, and a bounded cache when the weights do change
+    N, E, d = 300, 2500, 16
+    s, t = make_graph(N, E, 3)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    l = ng.GCNConv((d, d), "relu", initialgraph=g)
+    ps, st = ng.setup(0, l)
+    ps = ng.to_device(ps, DEV)
+    x = torch.randn(d, N, device=DEV)
+    ew = torch.rand(E, device=DEV) + 0.5
+    y0, _ = l(x, ps, st, ew)
+    lru = st["graph"]._shared["weighted_handles"]
+    assert len(lru) == 1
+    h0 = next(iter(lru.values()))[0]
+    for _ in range(20):
+        y, _ = l(x, ps, st, ew)
+    assert len(lru) == 1 and next(iter(lru.values()))[0] is h0 and torch.equal(y, y0)
+    ew.mul_(2.0)                                   # in-place change: new content version -> a new normalisation
+    y2, _ = l(x, ps, st, ew)
+    assert len(lru) == 2 and not torch.equal(y2, y0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    yo, _ = O.gcn_conv(x.cpu().double().numpy(), ps["weight"].cpu().double().numpy(), ps["bias"].cpu().double().numpy(), og, "relu",
+                       True, False, edge_weight=ew.cpu().double().numpy())
+    close(y2, yo, what="weights changed in place")
+    for k in range(10):                            # fresh weight tensors every call: the cache stays at its cap
+        l(x, ps, st, torch.rand(E, device=DEV) + 0.5)
+    assert len(lru) <= ng.GNNGraph.max_weighted_handles
