@@ -311,15 +311,23 @@ int32_t ngpde_node_expect_generation(const ngpde_node_t *plan, uint64_t generati
  * this returns the number of kernel launches one forward (+ backward) solve enqueues. */
 int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);
 /* which internal forms the plan chose: bit 0 = pre-scaled arrays (rows held as c .* x, halo rows staged by LDS-DMA),
- * bit 1 = relu sign-bit masks instead of saved layer outputs, bit 2 = eager launches (no HIP-graph replay) */
-enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4 };
+ * bit 1 = relu sign-bit masks instead of saved layer outputs, bit 2 = eager launches (no HIP-graph replay), bits 3 / 4 = the
+ * forward solve / the adjoint run as ONE persistent launch each (graphs of at most two 32-row tiles per CU, d = 64, relu,
+ * unweighted: the BASELINE workload), tiles synchronised inside the launch by per-tile phase flags.  A persistent launch
+ * needs all its workgroups resident at once: run one such solve at a time per device (NGPDE_NO_PERSISTENT=1 selects the
+ * replayed plan otherwise).  Its waits are bounded; a launch that gives up writes NaN outputs and raises the plan's fault
+ * flag, which ngpde_node_fault reads (synchronises `stream`). */
+enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4, NGPDE_NODE_PERSISTENT_FWD = 8,
+       NGPDE_NODE_PERSISTENT_BWD = 16 };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
+int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
  * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity
  * rocprofv3 --kernel-trace reports -- for the four kernel roles:
  *   out_us[0] forward layer 1, out_us[1] forward layer 2 + stage combination,
  *   out_us[2] backward layer 1, out_us[3] backward stage combination + layer 2.
+ * A persistent plan has one launch per direction: out_us[0] = the forward solve, out_us[2] = the adjoint, the others 0.
  * out_count[4] (nullable) receives the number of sampled launches per role.  Synchronises `stream`. */
 int32_t ngpde_node_profile(ngpde_node_t *plan, int32_t stride, float *out_us, int32_t *out_count,
                            ngpde_stream_t stream);

@@ -159,6 +159,44 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream);
 // ct > 0: dW slabs in MFMA-fragment order (ct = D/16 column tiles) -> row-major [in][out]; ct == 0: plain sum
 int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, float *out, hipStream_t stream);
 int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-capture-safe replacement of hipMemsetAsync(ptr, 0, bytes)
+// ---- persistent solver launches (node_persistent.hip): the whole forward solve / adjoint of the 2 x GCNConv(64 => 64) plan as
+// ONE launch each, tiles synchronised by per-tile phase flags
+struct NodePersist {
+  int n_tiles = 0;
+  int *nbr = nullptr;          // [n_tiles][64] wait lists, -1 padded
+  unsigned *sync = nullptr;    // [n_tiles + 1] 128-byte lines: phase flag per tile, then the abort word
+  size_t sync_bytes = 0;
+  unsigned *fault = nullptr;   // sticky: some persistent launch of this plan gave up waiting
+  float *coef = nullptr;       // device tables indexed by the stage: forward cf[6][6], adjoint dtb[6], cu[6][6] (78 floats)
+};
+struct NodePersistFwd {
+  const ngpde_graph *g = nullptr;
+  const NodePersist *ps = nullptr;
+  int n_steps = 0, S = 0, act = 0;
+  const float *u_in = nullptr;
+  float *u_out = nullptr, *bufA = nullptr, *bufB = nullptr;
+  const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+  float *tape = nullptr;
+  uint8_t *masks = nullptr;
+  size_t row_elems = 0, mask_bytes = 0;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+struct NodePersistBwd {
+  const ngpde_graph *g = nullptr;
+  const NodePersist *ps = nullptr;
+  int n_steps = 0, S = 0;
+  float *lam = nullptr, *g1 = nullptr, *g2 = nullptr;
+  const float *w1 = nullptr, *w2 = nullptr, *tape = nullptr;
+  const uint8_t *masks = nullptr;
+  size_t row_elems = 0, mask_bytes = 0;
+  float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [78] */, NodePersist *ps);
+void node_persistent_free(NodePersist *ps);
+int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
+int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);
 bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
 int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                              float *out, float *alpha, hipStream_t stream);

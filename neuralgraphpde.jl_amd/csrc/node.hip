@@ -107,6 +107,13 @@ struct ngpde_node {
   float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
   float *dw1 = nullptr, *db1 = nullptr, *dw2 = nullptr, *db2 = nullptr;
 
+  // Persistent form (node_persistent.hip): the whole forward solve / the whole adjoint as ONE launch each, tiles
+  // synchronised by per-tile phase flags.  Chosen when the graph is one co-resident wave of tiles (<= 2 per CU), d = 64,
+  // relu (adjoint), unweighted, pre-scaled form available; NGPDE_NO_PERSISTENT=1 or NGPDE_PERSISTENT=fwd|bwd restrict it.
+  bool persist_fwd = false, persist_bwd = false;
+  NodePersist persist;
+  float *pbuf = nullptr;     // layer-1 output exchanged between tiles in the persistent forward
+
   hipStream_t cap_stream = nullptr;
   hipGraph_t fwd_graph = nullptr, bwd_graph = nullptr;
   hipGraphExec_t fwd_exec = nullptr, bwd_exec = nullptr;
@@ -298,6 +305,38 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
   return NGPDE_OK;
 }
 
+// the persistent forms: ONE launch for the whole solve / the whole adjoint (node_persistent.hip)
+int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  NodePersistFwd a;
+  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.act = p->act;
+  a.u_in = p->u; a.u_out = p->u;     // a tile writes its rows of u(T) only after all its readers are past phase 1
+  a.bufA = p->ustage; a.bufB = p->pbuf;
+  a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
+  if (p->with_bwd) {
+    a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
+  }
+  a.ev_start = ev0; a.ev_stop = ev1;
+  return launch_node_fwd_persistent(a, stream);
+}
+
+int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  NodePersistBwd a;
+  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S;
+  a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
+  a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
+  a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
+  a.ev_start = ev0; a.ev_stop = ev1;
+  int32_t st;
+  if ((st = launch_node_bwd_persistent(a, stream))) return st;
+  const int dd = p->d * p->d;
+  const int ns = p->persist.n_tiles;   // one slab per tile, each written once at the end of the launch
+  if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db1, ns, p->d, 0, p->db1, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_dw2, ns, dd, p->d / 16, p->dw2, stream))) return st;
+  if ((st = launch_reduce_slabs(p->slab_db2, ns, p->d, 0, p->db2, stream))) return st;
+  return NGPDE_OK;
+}
+
 int32_t capture(ngpde_node *p, bool backward) {
   hipGraph_t graph = nullptr;
   NGPDE_HIP_CHECK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
@@ -345,6 +384,8 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
     if (b) (void)hipFree(b);
   if (p->ybuf) (void)hipFree(p->ybuf);
   if (p->masks) (void)hipFree(p->masks);
+  if (p->pbuf) (void)hipFree(p->pbuf);
+  node_persistent_free(&p->persist);
   delete p;
   return NGPDE_OK;
 }
@@ -414,15 +455,38 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
     }
     A(&p->dw1, dd); A(&p->db1, d); A(&p->dw2, dd); A(&p->db2, d);
   }
-  if (st == NGPDE_OK && !p->eager) {
+  if (st == NGPDE_OK && p->pre && (!p->with_bwd || p->mask_mode) && node_persistent_supported(g, d, act, p->with_bwd)) {
+    const char *only = std::getenv("NGPDE_PERSISTENT");
+    p->persist_fwd = !(only && std::strcmp(only, "bwd") == 0);
+    p->persist_bwd = p->with_bwd && !(only && std::strcmp(only, "fwd") == 0);
+    // stage-indexed coefficient tables (device memory): forward cf[i][j], adjoint dtb[j], cu[i][j]
+    float coef[78] = {0};
+    const Tableau &tb = p->tb;
+    for (int i = 0; i < S; ++i) {
+      const std::vector<double> &row = (i == S - 1) ? tb.b : tb.a[i + 1];
+      for (int j = 0; j <= i; ++j) coef[i * 6 + j] = (float)(dt * row[j]);
+      coef[36 + i] = (float)(dt * tb.b[i]);
+    }
+    for (int i = 1; i < S; ++i)
+      for (int j = i; j < S; ++j) coef[42 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
+    st = node_persistent_setup(g, coef, &p->persist);
+    if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave: keep the replayed plan
+      st = NGPDE_OK;
+      p->persist_fwd = p->persist_bwd = false;
+    }
+    if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, p->row_elems);
+  }
+  if (st == NGPDE_OK && !p->eager && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd))) {
     hipError_t e = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
     if (e != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-    if (st == NGPDE_OK) st = capture(p, false);
-    if (st == NGPDE_OK && p->with_bwd) st = capture(p, true);
+    if (st == NGPDE_OK && !p->persist_fwd) st = capture(p, false);
+    if (st == NGPDE_OK && p->with_bwd && !p->persist_bwd) st = capture(p, true);
   } else if (st == NGPDE_OK) {
     p->fwd_launches = 2 * S * n_steps;
     p->bwd_launches = p->with_bwd ? 1 + 2 * S * n_steps + 4 : 0;
   }
+  if (p->persist_fwd) p->fwd_launches = 3;                    // flag reset, the solve, fault latch
+  if (p->persist_bwd) p->bwd_launches = 3 + 4;                // ... + the four slab reductions
   if (st != NGPDE_OK) {
     std::string keep = last_error();
     ngpde_node_destroy(p);
@@ -444,7 +508,19 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t
 
 int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
-  *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0);
+  *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
+           (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0);
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_fault(ngpde_node_t *p, ngpde_stream_t stream_, int32_t *fault) {
+  NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_fault: NULL argument");
+  *fault = 0;
+  if (!p->persist.fault) return NGPDE_OK;
+  unsigned f = 0;
+  NGPDE_HIP_CHECK(hipMemcpyAsync(&f, p->persist.fault, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+  NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  *fault = f ? 1 : 0;
   return NGPDE_OK;
 }
 
@@ -467,7 +543,10 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   else NGPDE_HIP_CHECK(hipMemsetAsync(p->b1, 0, db, stream));
   if (b2) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b2, b2, db, hipMemcpyDeviceToDevice, stream));
   else NGPDE_HIP_CHECK(hipMemsetAsync(p->b2, 0, db, stream));
-  if (p->eager) {
+  if (p->persist_fwd) {
+    int32_t st = enqueue_forward_persistent(p, stream);
+    if (st) return st;
+  } else if (p->eager) {
     int32_t st = enqueue_forward(p, stream, nullptr);
     if (st) return st;
   } else {
@@ -515,7 +594,10 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  if (p->eager) {
+  if (p->persist_bwd) {
+    int32_t st = enqueue_backward_persistent(p, stream);
+    if (st) return st;
+  } else if (p->eager) {
     int32_t st = enqueue_backward(p, stream, nullptr);
     if (st) return st;
   } else {
@@ -549,13 +631,21 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  if ((st = enqueue_forward(p, stream, nullptr, &prof))) return st;
+  hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (p->persist_fwd) {
+    prof.want(0, &pe[0], &pe[1]);
+    if ((st = enqueue_forward_persistent(p, stream, pe[0], pe[1]))) return st;
+  } else if ((st = enqueue_forward(p, stream, nullptr, &prof))) return st;
   if (p->with_bwd) {
     // adjoint seed of loss = sum(u(T)): ones
     std::vector<float> ones(p->row_elems, 1.0f);
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, ones.data(), p->row_elems * sizeof(float), hipMemcpyHostToDevice, stream));
     NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
-    if ((st = enqueue_backward(p, stream, nullptr, &prof))) return st;
+    if (p->persist_bwd) {
+      prof.counter = 0;
+      prof.want(2, &pe[2], &pe[3]);
+      if ((st = enqueue_backward_persistent(p, stream, pe[2], pe[3]))) return st;
+    } else if ((st = enqueue_backward(p, stream, nullptr, &prof))) return st;
   }
   NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
   double sum[4] = {0, 0, 0, 0};

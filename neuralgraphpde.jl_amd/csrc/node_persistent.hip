@@ -1,0 +1,609 @@
+// node_persistent.hip -- the fixed-step neural graph ODE over Chain(GCNConv(64 => 64, relu), GCNConv(64 => 64, relu)) as TWO
+// persistent launches (forward solve, discrete adjoint) instead of 1205 kernel launches replayed from HIP graphs.
+// [caller of the hot path in the reference: docs/src/tutorials/graph_node.md:44-66, :78; layer: src/layers.jl:200-239]
+//
+// Why: at the BASELINE size (16 384 nodes = 512 tiles of 32 rows) every launch of the replayed plan is exactly one wave of
+// co-resident workgroups, the tile -> workgroup map never changes, and each launch pays the platform's dependent-launch floor
+// (1.87 us, tools/launch_floor.hip) plus a cold start in which halo lists, slot bytes, schedule entries and W are fetched again
+// -- 1205 times.  Here a workgroup keeps its tile for the whole solve:
+//   * in registers: the tile's own rows of u and of the six stage derivatives k_j (forward) / of lambda and the stage adjoints
+//     U-bar_j (adjoint), the dW / db accumulators of both layers for the whole adjoint (no slab read-modify-write), slot bytes,
+//     halo node ids, c;
+//   * in LDS: both W^T, the biases, the tile's own rows of the array being exchanged (halo slots 0..31);
+//   * exchanged through memory: only the 32 rows a tile produces per phase (sc1 = write-through stores) and the <= 64 rows of
+//     OTHER tiles its halo references (sc1 loads straight into LDS by LDS-DMA).
+// A grid-wide barrier costs 9.2 us per phase on this chip (tools/persistent_floor.hip, mode 3); the dependency is local, so a
+// tile waits only for the tiles its halo references: one flag word per tile holding the last finished phase, written by one
+// lane after every wave has drained its stores (s_waitcnt vmcnt(0)) and the workgroup has met at a barrier, polled relaxed by
+// one wave of the consumer.  Measured floor of that hand-off with this geometry: 2.3-2.5 us per phase, every payload word
+// checked (mode 1 of the same tool; the launch-boundary form is 1.87 us + the cold start).  The wait list is the symmetric
+// closure of "my halo references a row of yours" over BOTH directions of the graph: a tile that waits for its readers of the
+// previous phase also may overwrite the array they read (the two exchanged arrays ping-pong).
+// Every spin is bounded (abort word + ~2 s timeout); an aborted solve poisons its outputs with NaN and raises the plan's
+// fault flag (ngpde_node_fault).  All workgroups must be co-resident: the host checks the grid against the occupancy of the
+// kernels and otherwise keeps the replayed plan (node.hip).  Two persistent solves in flight on one device (two processes or
+// two streams) can starve each other of residency: one solve at a time per device, NGPDE_NO_PERSISTENT=1 for anything else.
+//
+// Arithmetic is that of the pre-scaled replayed plan (gcn_fused.hip, PRE = true) operation for operation: same aggregation
+// order (slot bytes, then the own row), same fp32 MFMA products, same stage combinations in the same order.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "device_utils.h"
+#include "gcn_tile.h"
+
+namespace ngpde {
+
+namespace {
+
+constexpr int PD = 64;
+using PG = Geo<PD>;
+static_assert(PG::R == 1 && PG::GROUPS == kTM && PG::LPR == 16, "one 16-lane group per tile row");
+constexpr int kXhF = (kHaloCap + 1) * PD;   // halo region (floats), +1: the all-zero row
+constexpr int kTileF = kTM * PG::TS;        // one 32-row MFMA operand / result tile
+constexpr int kWF = PD * PG::TS;            // one transposed weight matrix
+constexpr int kNbrStride = 64;              // wait-list entries per tile (one lane of the polling wave each)
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// write-through row store: visible to sc1 loads of every XCD once drained.  Scalar base + 32-bit byte offset (one VGPR of
+// address instead of a 64-bit pair per array: the adjoint kernel sits at the 128-VGPR edge)
+__device__ __forceinline__ void store_sc1(float *base, unsigned byte_off, float4 v) {
+  f4v t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
+}
+template <class T>
+__device__ __forceinline__ T *at_bytes(T *base, unsigned byte_off) {   // base + offset with the base kept scalar
+  return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+
+__device__ __forceinline__ bool spin_ok(unsigned long long t0, unsigned *abort_word) {
+  if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s of the 100 MHz counter: the whole solve takes ~6 ms
+    __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  return true;
+}
+
+struct TileCtx {
+  int tid, lane, wave_u, grp, q, tile, node, hcount, wmax, my_nbr;
+  bool valid;
+  float ci;
+  unsigned w[8];      // 32 slot bytes of this thread's row
+  int hnode[2];       // halo node ids of this group's two foreign DMA slots (grp + 32, grp + 64)
+};
+
+struct TileMeta {
+  const int2 *halo;
+  const uint8_t *slots;
+  const int4 *sched;
+  const int2 *tile_info;
+  const int *nbr;
+  unsigned *flags, *abort_word;
+  int n_tiles;
+};
+
+__device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c) {
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave_u = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.grp = c.tid >> 4;
+  c.q = c.tid & 15;
+  c.tile = xcd_tile(blockIdx.x, m.n_tiles);
+  const size_t pos = (size_t)c.tile * kTM + c.grp;
+  const int4 sc = m.sched[pos];
+  c.valid = sc.x >= 0;
+  c.node = max(sc.x, 0);
+  c.ci = c.valid ? __int_as_float(sc.w) : 0.f;
+  const uint4 s0 = reinterpret_cast<const uint4 *>(m.slots)[pos * 2], s1 = reinterpret_cast<const uint4 *>(m.slots)[pos * 2 + 1];
+  c.w[0] = s0.x; c.w[1] = s0.y; c.w[2] = s0.z; c.w[3] = s0.w;
+  c.w[4] = s1.x; c.w[5] = s1.y; c.w[6] = s1.z; c.w[7] = s1.w;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c.hnode[k] = m.halo[(size_t)c.tile * kHaloCap + c.grp + 32 * (k + 1)].x;
+  c.hcount = __builtin_amdgcn_readfirstlane(m.tile_info[c.tile].x);
+  int wm = c.valid ? sc.z : 0;
+  wm = max(wm, __shfl_xor(wm, 16));
+  wm = max(wm, __shfl_xor(wm, 32));
+  c.wmax = __builtin_amdgcn_readfirstlane(wm);
+  c.my_nbr = m.nbr[(size_t)c.tile * kNbrStride + c.lane];
+}
+
+// Wait until every tile of the wait list has finished phase ph - 1 (wave 0 polls, one flag per lane; everybody meets at the
+// barrier).  Returns false when the solve was aborted.
+__device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok) {
+  if (ph <= 1) return true;
+  if (c.wave_u == 0) {
+    const unsigned need = (unsigned)(ph - 1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (;;) {
+      unsigned f = need;
+      if (c.my_nbr >= 0) f = __hip_atomic_load(m.flags + 32 * c.my_nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(f >= need))) break;
+      if (!spin_ok(t0, m.abort_word)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (c.lane == 0) *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// every storing wave drains, the workgroup meets, ONE lane publishes (Guideline 16, R1)
+__device__ __forceinline__ void tile_publish(const TileMeta &m, const TileCtx &c, int ph) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the rows of OTHER tiles this tile's halo references: memory -> LDS slots 32.., sc1 (the producers stored them write-through
+// in the previous phase; sc1 loads bypass this CU's L1, which may hold the same addresses from two phases ago)
+__device__ __forceinline__ void tile_gather_foreign(const TileCtx &c, const float *X, float *ldsXh) {
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (4 * c.wave_u + 32 * (k + 1) < c.hcount) {   // wave-uniform: a wave's four groups stage four consecutive slots
+      const unsigned off = (unsigned)c.hnode[k] * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X) + off),
+                                       (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * (k + 1)) * PG::LPR + c.q), 16, 0, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// sum of the row's neighbours (slot bytes, in CSR order) + its own row (self loop), all from LDS
+__device__ __forceinline__ float4 tile_aggregate(const TileCtx &c, const float *ldsXh) {
+  const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
+  float4 a = f4_zero();
+#pragma unroll
+  for (int jw = 0; jw < 8; ++jw) {
+    if (jw * 4 < c.wmax) {   // wave-uniform
+      float4 v[4];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((c.w[jw] >> (8 * jb)) & 0xff) * PG::LPR + c.q];
+      a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+    }
+  }
+  return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+}
+
+// W (row-major [in][out]) -> LDS, transposed (forward: B[k = in][j = out], stored Bt[j][k]) or straight (pullback: Bt[j = in][k = out])
+__device__ __forceinline__ void load_weight_lds(const float *wt, float *ldsBt, int tid, bool transpose) {
+  if (transpose) {
+    const int j = tid % PD, kg0 = tid / PD;
+#pragma unroll
+    for (int ps = 0; ps < PG::NPASS; ++ps) {
+      const int kg = kg0 + ps * PG::KGP;
+      if (kg < PD / 4) {
+        const float *w = wt + (size_t)(4 * kg) * PD + j;
+        *reinterpret_cast<float4 *>(&ldsBt[j * PG::TS + 4 * kg]) = make_float4(w[0], w[PD], w[2 * PD], w[3 * PD]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PG::W4; ++k) {
+      const int idx = tid + k * kThreads;
+      if (idx < PD * PD / 4) {
+        const int wi = (idx * 4) / PD, wo = (idx * 4) % PD;
+        *reinterpret_cast<float4 *>(&ldsBt[wi * PG::TS + wo]) = reinterpret_cast<const float4 *>(wt)[idx];
+      }
+    }
+  }
+}
+
+// component-wise select: `cond ? a : b` on two float4 LVALUES is an lvalue select (clang picks an ADDRESS and copies), which
+// keeps both operands in scratch memory
+__device__ __forceinline__ float4 f4_sel(bool cnd, float4 a, float4 b) {
+  return make_float4(cnd ? a.x : b.x, cnd ? a.y : b.y, cnd ? a.z : b.z, cnd ? a.w : b.w);
+}
+
+__device__ __forceinline__ float4 f4_nan() {
+  const float n = __int_as_float(0x7fc00000);
+  return make_float4(n, n, n, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward solve
+// ---------------------------------------------------------------------------------------------------------------------
+struct PFwdK {
+  TileMeta m;          // lists by TARGET
+  int n_steps, S, act;
+  const float *u_in;   // [N][64]  c .* u0
+  float *u_out;        // [N][64]  c .* u(T)
+  float *bufA, *bufB;  // exchanged arrays: stage input (A), layer-1 output (B)
+  const float *w1, *b1, *w2, *b2;
+  float *tape;         // [n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
+  uint8_t *masks;      // [n_steps][S][2][mask_bytes] relu sign bits
+  size_t row_elems, mask_bytes;
+  const float *cf;     // [6][6] device table: cf[i][j], j <= i: coefficient of k_j in the array written after stage i (next
+                       // stage input / step update); in memory, not in the by-value argument: it is indexed by the stage
+};
+
+template <int ACT, bool TAPE>
+__global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const PFwdK p) {
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + 4];
+  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = ldsW1 + kWF, *ldsB = ldsW2 + kWF;
+  int *s_ok = reinterpret_cast<int *>(ldsB + 2 * PD);
+  TileCtx c;
+  tile_ctx_init(p.m, c);
+  const int act = ACT >= 0 ? ACT : p.act;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  load_weight_lds(p.w1, ldsW1, c.tid, true);
+  load_weight_lds(p.w2, ldsW2, c.tid, true);
+  if (c.tid < PD) ldsB[c.tid] = p.b1 ? p.b1[c.tid] : 0.f;
+  else if (c.tid < 2 * PD) ldsB[c.tid] = p.b2 ? p.b2[c.tid - PD] : 0.f;
+  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (c.tid == 0) *s_ok = 1;
+  const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);   // byte offset of this thread's 16 bytes in a [N][64] array
+  float4 u = f4_sel(c.valid, *at_bytes(reinterpret_cast<const float4 *>(p.u_in), own), f4_zero());
+  // six named values written through component-wise selects (f4_sel): an array written as `k[j] = (j == i) ? yv : k[j]` ends
+  // up in scratch memory
+  float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
+  Xh4[c.grp * PG::LPR + c.q] = u;
+  __syncthreads();
+  const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[c.q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[c.q];
+  bool ok = true;
+  int ph = 0;
+  for (int n = 0; n < p.n_steps && ok; ++n) {
+    for (int i = 0; i < p.S && ok; ++i) {
+#pragma unroll
+      for (int layer = 0; layer < 2; ++layer) {
+        ++ph;
+        const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
+        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        tile_gather_foreign(c, X, ldsXh);
+        float4 acc = f4_scale(c.ci, tile_aggregate(c, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
+        *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
+        const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
+        if (TAPE && c.valid) store_stream4(at_bytes(reinterpret_cast<float4 *>(p.tape + ev * p.row_elems), own), acc);
+        __syncthreads();
+        mfma_rows_times_bt<PD>(ldsT, layer == 0 ? ldsW1 : ldsW2, ldsZ, c.wave_u, c.lane);
+        __syncthreads();
+        const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
+        if (TAPE)
+          *at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid) =
+              (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
+        float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());   // stored as c .* y
+        if (layer == 0) {
+          if (c.valid) store_sc1(p.bufB, own, yv);
+          Xh4[c.grp * PG::LPR + c.q] = yv;
+        } else {
+          // k_i = yv; next stage input (or the step update) = u + sum_j cf[i][j] k_j -- same order as the replayed plan:
+          // coef_self * k_i first, then u, then k_0 .. k_{i-1}
+          k0 = f4_sel(i == 0, yv, k0); k1 = f4_sel(i == 1, yv, k1); k2 = f4_sel(i == 2, yv, k2);
+          k3 = f4_sel(i == 3, yv, k3); k4 = f4_sel(i == 4, yv, k4); k5 = f4_sel(i == 5, yv, k5);
+          float4 v = f4_scale(p.cf[i * 6 + i], yv);
+          v = f4_fma(1.0f, u, v);
+#define NGPDE_PF_TERM(J, KJ)                                                                 \
+  if (J < i && p.cf[i * 6 + J] != 0.f) v = f4_fma(p.cf[i * 6 + J], KJ, v);   /* uniform */
+          NGPDE_PF_TERM(0, k0) NGPDE_PF_TERM(1, k1) NGPDE_PF_TERM(2, k2) NGPDE_PF_TERM(3, k3) NGPDE_PF_TERM(4, k4)
+#undef NGPDE_PF_TERM
+          if (i == p.S - 1) u = v;
+          if (c.valid) store_sc1(p.bufA, own, v);
+          Xh4[c.grp * PG::LPR + c.q] = v;
+        }
+        tile_publish(p.m, c, ph);
+      }
+    }
+  }
+  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.u_out), own) = f4_sel(ok, u, f4_nan());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// discrete adjoint
+// ---------------------------------------------------------------------------------------------------------------------
+struct PBwdK {
+  TileMeta m;          // lists by SOURCE
+  int n_steps, S;
+  float *lam;          // in: dL/du~(T) (adjoint seed ./ c); out: dL/du~0
+  float *g1, *g2;      // exchanged arrays: c .* (dZ1 W1^T), c .* (dZ2 W2^T)
+  const float *w1, *w2;
+  const float *tape;
+  const uint8_t *masks;
+  size_t row_elems, mask_bytes;
+  float *slab_dw1, *slab_db1, *slab_dw2, *slab_db2;   // [n_tiles][...] written ONCE, at the end
+  const float *dtb;    // [6] device table: dt * b[j]
+  const float *cu;     // [6][6] device table: cu[i][j], i >= 1, j >= i: dt * a[j][i-1], the weight of U-bar_j in K-bar_{i-1}
+};
+
+__global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const PBwdK p) {
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 4];
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
+  int *s_ok = reinterpret_cast<int *>(ldsW2 + kWF);
+  TileCtx c;
+  tile_ctx_init(p.m, c);
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  load_weight_lds(p.w1, ldsW1, c.tid, false);
+  load_weight_lds(p.w2, ldsW2, c.tid, false);
+  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (c.tid == 0) *s_ok = 1;
+  const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+  float4 lam = f4_sel(c.valid, *at_bytes(reinterpret_cast<const float4 *>(p.lam), own), f4_zero());
+  float4 ub1 = f4_zero(), ub2 = f4_zero(), ub3 = f4_zero(), ub4 = f4_zero(), ub5 = f4_zero();   // named, not an array (see the forward kernel)
+  constexpr int NT = PG::CT * PG::CT;
+  f32x4 dw1[PG::DWT], dw2[PG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.f, db2 = 0.f;
+  const int dbc = c.tid / PG::DBP, dbpart = c.tid % PG::DBP;
+  const int S = p.S;
+  __syncthreads();
+
+  // the dense half of a phase: dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the next gather,
+  // dW += A^T dZ, db += column sums; then publish and keep the own rows of G in the halo slots
+  auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, unsigned mk, float4 xrow, float *gout) {
+    kbar = f4_scale(c.ci, kbar);
+    const float4 dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f,
+                                            (mk & 8u) ? kbar.w : 0.f)
+                              : f4_zero();
+    *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
+    *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
+    __syncthreads();
+    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
+    __syncthreads();
+    const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
+    if (c.valid) store_sc1(gout, own, gv);
+    // dWt[i][o] += sum_n A[n][i] dZ[n][o] over the tile's 32 rows: runs while the row stores drain
+    const int i16 = c.lane & 15, kq = c.lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = c.wave_u + PG::WAVES * mm;
+      if (tt < NT) {   // wave-uniform
+        const int mt = tt / PG::CT, nt = tt % PG::CT;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {   // two halves of the 32-row contraction: 8 operand registers live instead of 16
+          float a[kTM / 8], b[kTM / 8];
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) {
+            a[ks] = ldsX[(4 * (ks + 4 * kh) + kq) * PG::TS + mt * 16 + i16];
+            b[ks] = ldsDZ[(4 * (ks + 4 * kh) + kq) * PG::TS + nt * 16 + i16];
+          }
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) dwl[mm] = mfma16(a[ks], b[ks], dwl[mm]);
+        }
+      }
+    }
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int nn = dbpart; nn < kTM; nn += PG::DBP) s += ldsDZ[nn * PG::TS + dbc];
+#pragma unroll
+      for (int o = 1; o < PG::DBP; o <<= 1) s += __shfl_xor(s, o);
+      dbl += s;
+    }
+    tile_publish(p.m, c, ph);
+    Xh4[c.grp * PG::LPR + c.q] = gv;   // behind the barrier: every thread has read its row of G (same LDS region)
+  };
+  auto tape_row = [&](size_t ev) { return load_stream4(at_bytes(reinterpret_cast<const float4 *>(p.tape + ev * p.row_elems), own)); };
+  auto mask_of = [&](size_t ev) { return (unsigned)*at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
+
+  bool ok = true;
+  int ph = 1;
+  {   // phase 1: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half
+    const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
+    dense(ph, ldsW2, dw2, db2, f4_scale(p.dtb[S - 1], lam), mask_of(ev), tape_row(ev), p.g2);
+  }
+  for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+    for (int i = S - 1; i >= 0 && ok; --i) {
+      {   // layer 1 of stage i: dL/dy1 = A^T g2
+        ++ph;
+        const size_t ev = (size_t)(n * S + i) * 2;
+        const unsigned mk = mask_of(ev);          // own-row loads: in flight during the wait
+        const float4 xrow = tape_row(ev);
+        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        tile_gather_foreign(c, p.g2, ldsXh);
+        const float4 t = tile_aggregate(c, ldsXh);
+        dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1);
+      }
+      {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
+        ++ph;
+        const bool last = (i == 0 && n == 0);
+        const size_t ev = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;
+        unsigned mk = 0;
+        float4 xrow = f4_zero();
+        if (!last) {
+          mk = mask_of(ev);
+          xrow = tape_row(ev);
+        }
+        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        tile_gather_foreign(c, p.g1, ldsXh);
+        const float4 t = tile_aggregate(c, ldsXh);
+        float4 kbar;
+        if (i >= 1) {
+          // same order as the replayed plan: coef_self * t, then lambda, then U-bar_{i+1} ..
+          ub1 = f4_sel(i == 1, t, ub1); ub2 = f4_sel(i == 2, t, ub2); ub3 = f4_sel(i == 3, t, ub3);
+          ub4 = f4_sel(i == 4, t, ub4); ub5 = f4_sel(i == 5, t, ub5);
+          float4 v = f4_scale(p.cu[i * 6 + i], t);
+          v = f4_fma(p.dtb[i - 1], lam, v);
+#define NGPDE_PB_TERM(J, UJ)                                                                                      \
+  if (J > i && J < S && p.cu[i * 6 + J] != 0.f) v = f4_fma(p.cu[i * 6 + J], UJ, v);   /* uniform */
+          NGPDE_PB_TERM(2, ub2) NGPDE_PB_TERM(3, ub3) NGPDE_PB_TERM(4, ub4) NGPDE_PB_TERM(5, ub5)
+#undef NGPDE_PB_TERM
+          kbar = v;
+        } else {
+          float4 v = f4_scale(1.0f, t);
+          v = f4_fma(1.0f, lam, v);
+          if (1 < S) v = f4_fma(1.0f, ub1, v);   // uniform
+          if (2 < S) v = f4_fma(1.0f, ub2, v);
+          if (3 < S) v = f4_fma(1.0f, ub3, v);
+          if (4 < S) v = f4_fma(1.0f, ub4, v);
+          if (5 < S) v = f4_fma(1.0f, ub5, v);
+          lam = v;
+          kbar = f4_scale(p.dtb[S - 1], v);
+        }
+        if (last) break;
+        dense(ph, ldsW2, dw2, db2, kbar, mk, xrow, p.g2);
+      }
+    }
+  }
+  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.lam), own) = f4_sel(ok, lam, f4_nan());
+  // the tile's contribution to the parameter gradients: one slab per tile, summed by reduce_slabs_kernel
+  const float bad = __int_as_float(0x7fc00000);
+  auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
+    float4 *slab4 = reinterpret_cast<float4 *>(slab_dw + (size_t)blockIdx.x * PD * PD);
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = c.wave_u + PG::WAVES * mm;
+      if (tt < NT) slab4[tt * 64 + c.lane] = f4_sel(ok, make_float4(dwl[mm][0], dwl[mm][1], dwl[mm][2], dwl[mm][3]), f4_nan());
+    }
+    if (dbpart == 0) slab_db[(size_t)blockIdx.x * PD + dbc] = ok ? dbl : bad;
+  };
+  write_slab(dw1, db1, p.slab_dw1, p.slab_db1);
+  write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+
+bool node_persistent_disabled_env() {   // read at every plan creation: tests switch it per plan
+  const char *e = std::getenv("NGPDE_NO_PERSISTENT");
+  return e && e[0] == '1';
+}
+
+// Wait lists: tile T waits for every tile that owns a row of T's halo in either direction, and for every tile whose halo holds
+// a row of T (they read what T is about to overwrite).  [n_tiles][kNbrStride], -1 padded.  Returns false when a list overflows.
+static bool build_wait_lists(const ngpde_graph *g, std::vector<int> &out) {
+  const int nt = g->n_sched / kTileRows;
+  std::vector<int32_t> order((size_t)g->n_nodes);
+  if (!g->h_order.empty()) order = g->h_order;
+  else if (hipMemcpy(order.data(), g->order, order.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  std::vector<int32_t> tile_of((size_t)g->n_nodes, 0);
+  for (int64_t pos = 0; pos < g->n_nodes; ++pos) tile_of[order[pos]] = (int32_t)(pos / kTileRows);
+  std::vector<std::vector<int>> nb(nt);
+  for (const Csr *c : {&g->by_t, &g->by_s}) {
+    std::vector<int2> halo((size_t)nt * kHaloCap), info(nt);
+    if (hipMemcpy(halo.data(), c->halo, halo.size() * sizeof(int2), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(info.data(), c->tile_info, info.size() * sizeof(int2), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (int t = 0; t < nt; ++t)
+      for (int k = kTileRows; k < info[t].x; ++k) {
+        const int u = tile_of[halo[(size_t)t * kHaloCap + k].x];
+        if (u == t) continue;
+        nb[t].push_back(u);
+        nb[u].push_back(t);
+      }
+  }
+  out.assign((size_t)nt * kNbrStride, -1);
+  for (int t = 0; t < nt; ++t) {
+    std::sort(nb[t].begin(), nb[t].end());
+    nb[t].erase(std::unique(nb[t].begin(), nb[t].end()), nb[t].end());
+    if ((int)nb[t].size() > kNbrStride) return false;
+    for (size_t k = 0; k < nb[t].size(); ++k) out[(size_t)t * kNbrStride + k] = nb[t][k];
+  }
+  return true;
+}
+
+// can the plan run as two persistent launches?  (same conditions as the pre-scaled replayed plan, plus: d = 64, relu, unweighted,
+// one tile per workgroup with ALL workgroups co-resident)
+bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) {
+  if (node_persistent_disabled_env()) return false;
+  if (!g || d != PD || !fused_prescaled_supported(g, d)) return false;
+  if (g->by_t.slot_w || g->by_s.slot_w) return false;
+  if (with_bwd && act != NGPDE_ACT_RELU) return false;
+  int dev = 0, cus = 0, occ_f = 0, occ_b = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, true>, kThreads, 0) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, node_bwd_persistent_kernel, kThreads, 0) != hipSuccess) return false;
+  const int nt = g->n_sched / kTileRows;
+  return nt >= 1 && nt <= cus * std::min(occ_f, occ_b);
+}
+
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps) {
+  std::vector<int> lists;
+  NGPDE_REQUIRE(build_wait_lists(g, lists), NGPDE_ERR_UNSUPPORTED, "persistent solver: a tile's wait list exceeds %d tiles", kNbrStride);
+  const int nt = g->n_sched / kTileRows;
+  ps->n_tiles = nt;
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->nbr, lists.size() * sizeof(int)));
+  NGPDE_HIP_CHECK(hipMemcpy(ps->nbr, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
+  // flag words: one 128-byte line per tile, + one line for the abort word; zeroed (by a kernel) before every launch
+  ps->sync_bytes = (size_t)(nt + 1) * 128;
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->sync, ps->sync_bytes));
+  NGPDE_HIP_CHECK(hipMemset(ps->sync, 0, ps->sync_bytes));
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->coef, 78 * sizeof(float)));
+  NGPDE_HIP_CHECK(hipMemcpy(ps->coef, coef_host, 78 * sizeof(float), hipMemcpyHostToDevice));
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->fault, 128));
+  NGPDE_HIP_CHECK(hipMemset(ps->fault, 0, 128));
+  return NGPDE_OK;
+}
+
+void node_persistent_free(NodePersist *ps) {
+  if (ps->nbr) (void)hipFree(ps->nbr);
+  if (ps->sync) (void)hipFree(ps->sync);
+  if (ps->fault) (void)hipFree(ps->fault);
+  if (ps->coef) (void)hipFree(ps->coef);
+  ps->nbr = nullptr; ps->sync = nullptr; ps->fault = nullptr; ps->coef = nullptr;
+}
+
+namespace {
+// fault |= abort word of the launch that just ran (sticky, read by ngpde_node_fault)
+__global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
+  if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
+}
+TileMeta make_meta(const Csr &c, const NodePersist &ps) {
+  TileMeta m;
+  m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr;
+  m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 32; m.n_tiles = ps.n_tiles;
+  return m;
+}
+}  // namespace
+
+int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  PFwdK k;
+  k.m = make_meta(g->by_t, ps);
+  k.n_steps = a.n_steps; k.S = a.S; k.act = a.act;
+  k.u_in = a.u_in; k.u_out = a.u_out; k.bufA = a.bufA; k.bufB = a.bufB;
+  k.w1 = a.w1; k.b1 = a.b1; k.w2 = a.w2; k.b2 = a.b2;
+  k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
+  k.cf = ps.coef;
+  const dim3 grid(ps.n_tiles), block(kThreads);
+#define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
+  if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
+  if (a.tape) {
+    NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU && a.masks, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a tape is relu-only");
+    NGPDE_PF_LAUNCH(NGPDE_ACT_RELU, true)
+  } else if (a.act == NGPDE_ACT_RELU) {
+    NGPDE_PF_LAUNCH(NGPDE_ACT_RELU, false)
+  } else {
+    NGPDE_PF_LAUNCH(-1, false)
+  }
+#undef NGPDE_PF_LAUNCH
+  NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel");
+  hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  PBwdK k;
+  k.m = make_meta(g->by_s, ps);
+  k.n_steps = a.n_steps; k.S = a.S;
+  k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
+  k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
+  k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;
+  k.dtb = ps.coef + 36;
+  k.cu = ps.coef + 42;
+  const dim3 grid(ps.n_tiles), block(kThreads);
+  if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+  else hipLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, k);
+  NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
+  hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde

@@ -53,10 +53,18 @@ class _Plan:
         return f.value, b.value
 
     def flags(self):
-        """{'prescaled', 'sign_masks', 'eager'}: the internal forms the plan chose (ngpde_node_flags)"""
+        """subset of {'prescaled', 'sign_masks', 'eager', 'persistent_fwd', 'persistent_bwd'}: the internal forms the plan
+        chose (ngpde_node_flags)"""
         f = C.c_int32()
         _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
-        return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager")) if f.value & bit}
+        return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"),
+                                       (16, "persistent_bwd")) if f.value & bit}
+
+    def fault(self):
+        """True when a persistent launch of this plan gave up waiting (its outputs are NaN).  Synchronises."""
+        f = C.c_int32()
+        _lib.check(self.lib.ngpde_node_fault(self.ptr, _lib.current_stream(), C.byref(f)))
+        return bool(f.value)
 
     def claim(self):
         """token held by the autograd node of the solve that now owns the tape; the plan is busy while that node is alive

@@ -49,9 +49,9 @@ def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
     u0 = rng.normal(size=(D, N))
     g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
     node, ps, st = gcn2_node(g, D, "euler", 10, 0.1, params)
-    halo_ok = C.c_size_t()
+    halo_ok, unused = C.c_size_t(), C.c_void_p()
     from ngpde_amd import _lib
-    _lib.check(_lib.load().ngpde_graph_array(g.handle((True, None, False)).ptr, 0, 13, None, C.byref(halo_ok)))   # NGPDE_GRAPH_HALO_OK
+    _lib.check(_lib.load().ngpde_graph_array(g.handle((True, None, False)).ptr, 0, 13, C.byref(unused), C.byref(halo_ok)))   # NGPDE_GRAPH_HALO_OK
     assert halo_ok.value == 0, "C1 is meant to exercise the global-gather path"
     u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
     uT, _ = node(u, ps, st)
