@@ -126,6 +126,10 @@ def main():
     # NGPDE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
     # collective goes through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU
     backend = os.environ.get("NGPDE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        # rehearsal: the ranks share one device, and two persistent solver launches in flight on one device can starve each
+        # other of residency (include/ngpde.h, ngpde_node_flags) -- take the replayed plan there
+        os.environ.setdefault("NGPDE_NO_PERSISTENT", "1")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -210,17 +214,28 @@ def main():
 
     elapsed, ms_fwd, ms_bwd, plan = job(1, args.steps, args.warmup)
 
+    def role_table(plan, traj):
+        """kernel roles of a plan, their SURVEY 8(d) algorithmic bytes per launch and their measured device time per launch"""
+        us, cnt = launch_profile(plan)
+        evals = 6 * ODE_STEPS                                  # right-hand-side evaluations (= pullbacks) per solve
+        if "persistent_fwd" in plan.flags():                   # ONE launch per direction: 2 layer evaluations per RHS evaluation
+            roles = ["fwd_persistent_solve", None, "bwd_persistent_adjoint", None]
+            algo = [2 * evals * BYTES_FWD_LAYER, 0.0, 2 * evals * BYTES_BWD_LAYER, 0.0]
+        else:
+            roles = ["fwd_layer1", "fwd_layer2_stage", "bwd_layer1", "bwd_stage_layer2"]
+            algo = [BYTES_FWD_LAYER, BYTES_FWD_LAYER, BYTES_BWD_LAYER, BYTES_BWD_LAYER]
+        algo = [traj * a for a in algo]
+        kernels = {r: {"avg_us": round(float(us[i]), 3), "launches_per_solve": int(cnt[i]),
+                       "algorithmic_MB": round(algo[i] / 1e6, 2),
+                       "achieved_GBs": round(algo[i] / (float(us[i]) * 1e-6) / 1e9, 1) if us[i] > 0 else None}
+                   for i, r in enumerate(roles) if r is not None}
+        tot = [float(us[i]) * int(cnt[i]) if roles[i] else 0.0 for i in range(4)]
+        dom = int(np.argmax(tot))
+        return roles, algo, us, kernels, dom
+
     out = None
     if rank == 0:
-        us, cnt = launch_profile(plan)
-        roles = ["fwd_layer1", "fwd_layer2_stage", "bwd_layer1", "bwd_stage_layer2"]
-        algo = [BYTES_FWD_LAYER, BYTES_FWD_LAYER, BYTES_BWD_LAYER, BYTES_BWD_LAYER]
-        kernels = {r: {"avg_us": round(float(us[i]), 3), "launches_per_solve": int(cnt[i]),
-                       "algorithmic_MB": algo[i] / 1e6,
-                       "achieved_GBs": round(algo[i] / (float(us[i]) * 1e-6) / 1e9, 1) if us[i] > 0 else None}
-                   for i, r in enumerate(roles)}
-        tot = [float(us[i]) * int(cnt[i]) for i in range(4)]
-        dom = int(np.argmax(tot))
+        roles, algo, us, kernels, dom = role_table(plan, 1)
         achieved = algo[dom] / (float(us[dom]) * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
@@ -248,8 +263,12 @@ def main():
                        "parallelism": f"dp{world} (independent trajectories, all-reduce of 8320-float grads)"},
             "roofline": {"bound": "hbm", "kernel": roles[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "static: profiles/traffic.json, the rocprofv3 --pmc passes of tools/profile_round.sh "
+                                           "(FETCH_SIZE x 2 + WRITE_SIZE per launch), not collected in this run",
+                         "algorithmic_MB_per_launch": round(algo[dom] / 1e6, 2),
                          "avg_launch_us": round(float(us[dom]), 3)},
             "kernels": kernels,
+            "plan": sorted(plan.flags()), "fault": bool(plan.fault()),
         }
         if world == 1 and args.batched > 1:
             # Secondary: the same kernels when a launch is no longer ONE wave of workgroups.  `traj` trajectories of the
@@ -258,18 +277,17 @@ def main():
             plan = None
             nb = max(2, args.steps // 3)
             eb, fb, bb, planb = job(args.batched, nb, 1)
-            usb, cntb = launch_profile(planb)
-            totb = [float(usb[i]) * int(cntb[i]) for i in range(4)]
-            db = int(np.argmax(totb))
+            rolesb, algob, usb, kernelsb, db = role_table(planb, args.batched)
             out["batched"] = {
                 "trajectories_per_gpu": args.batched, "nodes": args.batched * N_NODES,
                 "value": round(args.batched * ODE_STEPS * nb / eb, 1), "unit": "trajectory ODE-steps/s",
                 "ms_forward_solve": round(fb, 3), "ms_backward_solve": round(bb, 3),
                 "tape_GB": round(planb.tape_bytes() / 1e9, 3),
-                "roofline": {"kernel": roles[db], "avg_launch_us": round(float(usb[db]), 3),
-                             "achieved": round(args.batched * algo[db] / (float(usb[db]) * 1e-6) / 1e9, 1), "unit": "GB/s",
-                             "frac": round(args.batched * algo[db] / (float(usb[db]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                "kernels_avg_us": {r: round(float(usb[i]), 3) for i, r in enumerate(roles)},
+                "roofline": {"kernel": rolesb[db], "avg_launch_us": round(float(usb[db]), 3),
+                             "achieved": round(algob[db] / (float(usb[db]) * 1e-6) / 1e9, 1), "unit": "GB/s",
+                             "frac": round(algob[db] / (float(usb[db]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                "kernels_avg_us": {r: round(float(usb[i]), 3) for i, r in enumerate(rolesb) if r is not None},
+                "plan": sorted(planb.flags()),
             }
             planb = None
         if world == 1 and not args.no_cpu_baseline:
