@@ -167,7 +167,7 @@ struct NodePersist {
   unsigned *sync = nullptr;    // [n_tiles + 1] 128-byte lines: phase flag per tile, then the abort word
   size_t sync_bytes = 0;
   unsigned *fault = nullptr;   // sticky: some persistent launch of this plan gave up waiting
-  float *coef = nullptr;       // device tables indexed by the stage: forward cf[6][6], adjoint dtb[6], cu[6][6] (78 floats)
+  float *coef = nullptr;       // device tables indexed by the stage: forward [42], adjoint [48] (layout: node.hip)
 };
 struct NodePersistFwd {
   const ngpde_graph *g = nullptr;
@@ -193,7 +193,7 @@ struct NodePersistBwd {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
-int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [78] */, NodePersist *ps);
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps);
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);

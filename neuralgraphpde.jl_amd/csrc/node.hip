@@ -460,15 +460,19 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
     p->persist_fwd = !(only && std::strcmp(only, "bwd") == 0);
     p->persist_bwd = p->with_bwd && !(only && std::strcmp(only, "fwd") == 0);
     // stage-indexed coefficient tables (device memory): forward cf[i][j], adjoint dtb[j], cu[i][j]
-    float coef[78] = {0};
+    float coef[90] = {0};   // forward: cf[i][j] (j < i) at i * 6 + j, self weights at 36 + i; adjoint: dt b at 42 + j,
+                            // cu[i][j] (j > i >= 1) at 48 + i * 6 + j, self weights at 84 + i  (node_persistent.hip)
     const Tableau &tb = p->tb;
     for (int i = 0; i < S; ++i) {
       const std::vector<double> &row = (i == S - 1) ? tb.b : tb.a[i + 1];
-      for (int j = 0; j <= i; ++j) coef[i * 6 + j] = (float)(dt * row[j]);
-      coef[36 + i] = (float)(dt * tb.b[i]);
+      for (int j = 0; j < i; ++j) coef[i * 6 + j] = (float)(dt * row[j]);
+      coef[36 + i] = (float)(dt * row[i]);
+      coef[42 + i] = (float)(dt * tb.b[i]);
     }
-    for (int i = 1; i < S; ++i)
-      for (int j = i; j < S; ++j) coef[42 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
+    for (int i = 1; i < S; ++i) {
+      for (int j = i + 1; j < S; ++j) coef[48 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
+      coef[84 + i] = (float)(dt * tb.a[i][i - 1]);
+    }
     st = node_persistent_setup(g, coef, &p->persist);
     if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave: keep the replayed plan
       st = NGPDE_OK;

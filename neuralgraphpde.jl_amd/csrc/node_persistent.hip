@@ -49,6 +49,21 @@ constexpr int kNbrStride = 64;              // wait-list entries per tile (one l
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/stamps_persistent.py): shader-clock stamps of thread 0 at 8 points of the first g_pst_max phases
+unsigned long long *g_pst_base = nullptr;
+int g_pst_max = 0;
+#define NGPDE_PST_FIELD unsigned long long *stamps; int stamps_max;
+#define NGPDE_PST(m, ph, k)                                                                                   \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && (m).stamps && (ph) <= (m).stamps_max)                                             \
+      (m).stamps[((size_t)blockIdx.x * (m).stamps_max + ((ph) - 1)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define NGPDE_PST_FIELD
+#define NGPDE_PST(m, ph, k)
+#endif
+
 // write-through row store: visible to sc1 loads of every XCD once drained.  Scalar base + 32-bit byte offset (one VGPR of
 // address instead of a 64-bit pair per array: the adjoint kernel sits at the 128-VGPR edge)
 __device__ __forceinline__ void store_sc1(float *base, unsigned byte_off, float4 v) {
@@ -73,9 +88,12 @@ struct TileCtx {
   int tid, lane, wave_u, grp, q, tile, node, hcount, wmax, my_nbr;
   bool valid;
   float ci;
-  unsigned w[8];      // 32 slot bytes of this thread's row
-  int hnode[2];       // halo node ids of this group's two foreign DMA slots (grp + 32, grp + 64)
+  // kept in LDS, not in registers (the 16 lanes of a group would each hold the same 8 words): the 32 slot bytes of every row
+  // [32][8] and the node ids of the 64 foreign halo slots
+  const unsigned *lds_slots;
+  const int *lds_hnode;
 };
+constexpr int kMetaF = kTM * 8 + 2 * kTM;   // floats of LDS the two tables take
 
 struct TileMeta {
   const int2 *halo;
@@ -85,9 +103,10 @@ struct TileMeta {
   const int *nbr;
   unsigned *flags, *abort_word;
   int n_tiles;
+  NGPDE_PST_FIELD
 };
 
-__device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c) {
+__device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, float *lds_meta) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave_u = __builtin_amdgcn_readfirstlane(c.tid >> 6);
@@ -99,11 +118,12 @@ __device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c) {
   c.valid = sc.x >= 0;
   c.node = max(sc.x, 0);
   c.ci = c.valid ? __int_as_float(sc.w) : 0.f;
-  const uint4 s0 = reinterpret_cast<const uint4 *>(m.slots)[pos * 2], s1 = reinterpret_cast<const uint4 *>(m.slots)[pos * 2 + 1];
-  c.w[0] = s0.x; c.w[1] = s0.y; c.w[2] = s0.z; c.w[3] = s0.w;
-  c.w[4] = s1.x; c.w[5] = s1.y; c.w[6] = s1.z; c.w[7] = s1.w;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) c.hnode[k] = m.halo[(size_t)c.tile * kHaloCap + c.grp + 32 * (k + 1)].x;
+  unsigned *ls = reinterpret_cast<unsigned *>(lds_meta);
+  int *lh = reinterpret_cast<int *>(lds_meta + kTM * 8);
+  if (c.q < 8) ls[c.grp * 8 + c.q] = reinterpret_cast<const unsigned *>(m.slots)[pos * 8 + c.q];
+  if (c.q >= 8 && c.q < 10) lh[c.grp + 32 * (c.q - 8)] = m.halo[(size_t)c.tile * kHaloCap + c.grp + 32 * (c.q - 7)].x;
+  c.lds_slots = ls;
+  c.lds_hnode = lh;
   c.hcount = __builtin_amdgcn_readfirstlane(m.tile_info[c.tile].x);
   int wm = c.valid ? sc.z : 0;
   wm = max(wm, __shfl_xor(wm, 16));
@@ -147,7 +167,7 @@ __device__ __forceinline__ void tile_gather_foreign(const TileCtx &c, const floa
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (4 * c.wave_u + 32 * (k + 1) < c.hcount) {   // wave-uniform: a wave's four groups stage four consecutive slots
-      const unsigned off = (unsigned)c.hnode[k] * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      const unsigned off = (unsigned)c.lds_hnode[c.grp + 32 * k] * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X) + off),
                                        (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * (k + 1)) * PG::LPR + c.q), 16, 0, 16);
     }
@@ -157,15 +177,23 @@ __device__ __forceinline__ void tile_gather_foreign(const TileCtx &c, const floa
 }
 
 // sum of the row's neighbours (slot bytes, in CSR order) + its own row (self loop), all from LDS
-__device__ __forceinline__ float4 tile_aggregate(const TileCtx &c, const float *ldsXh) {
+// the row's 32 slot bytes, fetched from LDS BEFORE the wait (one address per 16-lane group: broadcast reads): they are live
+// only across the wait and the gather, where registers are plentiful, and the aggregation does not start with a dependent read
+__device__ __forceinline__ void tile_slot_words(const TileCtx &c, unsigned (&w)[8]) {
+  const uint4 a = reinterpret_cast<const uint4 *>(c.lds_slots)[c.grp * 2], b = reinterpret_cast<const uint4 *>(c.lds_slots)[c.grp * 2 + 1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+
+__device__ __forceinline__ float4 tile_aggregate(const TileCtx &c, const unsigned (&sw)[8], const float *ldsXh) {
   const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
   float4 a = f4_zero();
 #pragma unroll
   for (int jw = 0; jw < 8; ++jw) {
     if (jw * 4 < c.wmax) {   // wave-uniform
+      const unsigned w = sw[jw];
       float4 v[4];
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((c.w[jw] >> (8 * jb)) & 0xff) * PG::LPR + c.q];
+      for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q];
       a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
     }
   }
@@ -220,17 +248,19 @@ struct PFwdK {
   float *tape;         // [n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
   uint8_t *masks;      // [n_steps][S][2][mask_bytes] relu sign bits
   size_t row_elems, mask_bytes;
-  const float *cf;     // [6][6] device table: cf[i][j], j <= i: coefficient of k_j in the array written after stage i (next
-                       // stage input / step update); in memory, not in the by-value argument: it is indexed by the stage
+  const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
+                       // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
 };
 
 template <int ACT, bool TAPE>
 __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + kMetaF + 48 + 4];
   float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = ldsW1 + kWF, *ldsB = ldsW2 + kWF;
-  int *s_ok = reinterpret_cast<int *>(ldsB + 2 * PD);
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   TileCtx c;
-  tile_ctx_init(p.m, c);
+  tile_ctx_init(p.m, c, ldsMeta);
+  if (c.tid < 42) ldsC[c.tid] = p.cf[c.tid];
   const int act = ACT >= 0 ? ACT : p.act;
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
   load_weight_lds(p.w1, ldsW1, c.tid, true);
@@ -255,19 +285,24 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
       for (int layer = 0; layer < 2; ++layer) {
         ++ph;
         const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
+        NGPDE_PST(p.m, ph, 0);
+        unsigned sw[8];
+        tile_slot_words(c, sw);
         if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        NGPDE_PST(p.m, ph, 1);
         tile_gather_foreign(c, X, ldsXh);
-        float4 acc = f4_scale(c.ci, tile_aggregate(c, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
+        NGPDE_PST(p.m, ph, 2);
+        float4 acc = f4_scale(c.ci, tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
         const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
         if (TAPE && c.valid) store_stream4(at_bytes(reinterpret_cast<float4 *>(p.tape + ev * p.row_elems), own), acc);
         __syncthreads();
+        NGPDE_PST(p.m, ph, 3);
         mfma_rows_times_bt<PD>(ldsT, layer == 0 ? ldsW1 : ldsW2, ldsZ, c.wave_u, c.lane);
         __syncthreads();
+        NGPDE_PST(p.m, ph, 4);
         const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
-        if (TAPE)
-          *at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid) =
-              (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
+        const uint8_t sign_bits = (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
         float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());   // stored as c .* y
         if (layer == 0) {
           if (c.valid) store_sc1(p.bufB, own, yv);
@@ -277,17 +312,20 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
           // coef_self * k_i first, then u, then k_0 .. k_{i-1}
           k0 = f4_sel(i == 0, yv, k0); k1 = f4_sel(i == 1, yv, k1); k2 = f4_sel(i == 2, yv, k2);
           k3 = f4_sel(i == 3, yv, k3); k4 = f4_sel(i == 4, yv, k4); k5 = f4_sel(i == 5, yv, k5);
-          float4 v = f4_scale(p.cf[i * 6 + i], yv);
+          // (terms with a zero coefficient add an exact zero: k_j is finite, stale values of later stages included)
+          float4 v = f4_scale(ldsC[36 + i], yv);
           v = f4_fma(1.0f, u, v);
-#define NGPDE_PF_TERM(J, KJ)                                                                 \
-  if (J < i && p.cf[i * 6 + J] != 0.f) v = f4_fma(p.cf[i * 6 + J], KJ, v);   /* uniform */
-          NGPDE_PF_TERM(0, k0) NGPDE_PF_TERM(1, k1) NGPDE_PF_TERM(2, k2) NGPDE_PF_TERM(3, k3) NGPDE_PF_TERM(4, k4)
-#undef NGPDE_PF_TERM
+          v = f4_fma(ldsC[i * 6 + 0], k0, v); v = f4_fma(ldsC[i * 6 + 1], k1, v); v = f4_fma(ldsC[i * 6 + 2], k2, v);
+          v = f4_fma(ldsC[i * 6 + 3], k3, v); v = f4_fma(ldsC[i * 6 + 4], k4, v);
           if (i == p.S - 1) u = v;
           if (c.valid) store_sc1(p.bufA, own, v);
           Xh4[c.grp * PG::LPR + c.q] = v;
         }
+        NGPDE_PST(p.m, ph, 5);
         tile_publish(p.m, c, ph);
+        NGPDE_PST(p.m, ph, 6);
+        // relu' for the adjoint: only the adjoint launch reads it, so it leaves after the rows are published
+        if (TAPE) *at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid) = sign_bits;
       }
     }
   }
@@ -307,16 +345,18 @@ struct PBwdK {
   const uint8_t *masks;
   size_t row_elems, mask_bytes;
   float *slab_dw1, *slab_db1, *slab_dw2, *slab_db2;   // [n_tiles][...] written ONCE, at the end
-  const float *dtb;    // [6] device table: dt * b[j]
-  const float *cu;     // [6][6] device table: cu[i][j], i >= 1, j >= i: dt * a[j][i-1], the weight of U-bar_j in K-bar_{i-1}
+  const float *cb;     // device table [6 + 36 + 6], copied to LDS: cb[j] = dt * b[j]; cb[6 + i * 6 + j], j > i >= 1: dt * a[j][i-1], the
+                       // weight of U-bar_j in K-bar_{i-1}, 0 elsewhere; cb[42 + i] = dt * a[i][i-1], the weight of U-bar_i itself
 };
 
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const PBwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + kMetaF + 48 + 4];
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
-  int *s_ok = reinterpret_cast<int *>(ldsW2 + kWF);
+  float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   TileCtx c;
-  tile_ctx_init(p.m, c);
+  tile_ctx_init(p.m, c, ldsMeta);
+  if (c.tid < 48) ldsC[c.tid] = p.cb[c.tid];
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
   load_weight_lds(p.w1, ldsW1, c.tid, false);
   load_weight_lds(p.w2, ldsW2, c.tid, false);
@@ -344,11 +384,20 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
     __syncthreads();
+    NGPDE_PST(p.m, ph, 3);
     mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
     __syncthreads();
+    NGPDE_PST(p.m, ph, 4);
     const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
     if (c.valid) store_sc1(gout, own, gv);
-    // dWt[i][o] += sum_n A[n][i] dZ[n][o] over the tile's 32 rows: runs while the row stores drain
+    NGPDE_PST(p.m, ph, 5);
+    tile_publish(p.m, c, ph);
+    NGPDE_PST(p.m, ph, 6);
+    Xh4[c.grp * PG::LPR + c.q] = gv;   // behind the barrier: every thread has read its row of G (same LDS region)
+    // The parameter-gradient products run AFTER the rows are published: nobody waits for them, so they fill the time the
+    // neighbours need to see the flag and this tile needs to see theirs.  (The operand tiles stay intact until the next
+    // phase's dense half, two barriers away.)
+    // dWt[i][o] += sum_n A[n][i] dZ[n][o] over the tile's 32 rows
     const int i16 = c.lane & 15, kq = c.lane >> 4;
 #pragma unroll
     for (int mm = 0; mm < PG::DWT; ++mm) {
@@ -376,8 +425,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
       for (int o = 1; o < PG::DBP; o <<= 1) s += __shfl_xor(s, o);
       dbl += s;
     }
-    tile_publish(p.m, c, ph);
-    Xh4[c.grp * PG::LPR + c.q] = gv;   // behind the barrier: every thread has read its row of G (same LDS region)
+    NGPDE_PST(p.m, ph, 7);
   };
   auto tape_row = [&](size_t ev) { return load_stream4(at_bytes(reinterpret_cast<const float4 *>(p.tape + ev * p.row_elems), own)); };
   auto mask_of = [&](size_t ev) { return (unsigned)*at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
@@ -386,18 +434,23 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
   int ph = 1;
   {   // phase 1: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half
     const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
-    dense(ph, ldsW2, dw2, db2, f4_scale(p.dtb[S - 1], lam), mask_of(ev), tape_row(ev), p.g2);
+    dense(ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev), tape_row(ev), p.g2);
   }
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
     for (int i = S - 1; i >= 0 && ok; --i) {
       {   // layer 1 of stage i: dL/dy1 = A^T g2
         ++ph;
         const size_t ev = (size_t)(n * S + i) * 2;
+        NGPDE_PST(p.m, ph, 0);
         const unsigned mk = mask_of(ev);          // own-row loads: in flight during the wait
         const float4 xrow = tape_row(ev);
+        unsigned sw[8];
+        tile_slot_words(c, sw);
         if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        NGPDE_PST(p.m, ph, 1);
         tile_gather_foreign(c, p.g2, ldsXh);
-        const float4 t = tile_aggregate(c, ldsXh);
+        NGPDE_PST(p.m, ph, 2);
+        const float4 t = tile_aggregate(c, sw, ldsXh);
         dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1);
       }
       {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
@@ -410,31 +463,31 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
           mk = mask_of(ev);
           xrow = tape_row(ev);
         }
+        NGPDE_PST(p.m, ph, 0);
+        unsigned sw[8];
+        tile_slot_words(c, sw);
         if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+        NGPDE_PST(p.m, ph, 1);
         tile_gather_foreign(c, p.g1, ldsXh);
-        const float4 t = tile_aggregate(c, ldsXh);
+        NGPDE_PST(p.m, ph, 2);
+        const float4 t = tile_aggregate(c, sw, ldsXh);
         float4 kbar;
         if (i >= 1) {
           // same order as the replayed plan: coef_self * t, then lambda, then U-bar_{i+1} ..
           ub1 = f4_sel(i == 1, t, ub1); ub2 = f4_sel(i == 2, t, ub2); ub3 = f4_sel(i == 3, t, ub3);
           ub4 = f4_sel(i == 4, t, ub4); ub5 = f4_sel(i == 5, t, ub5);
-          float4 v = f4_scale(p.cu[i * 6 + i], t);
-          v = f4_fma(p.dtb[i - 1], lam, v);
-#define NGPDE_PB_TERM(J, UJ)                                                                                      \
-  if (J > i && J < S && p.cu[i * 6 + J] != 0.f) v = f4_fma(p.cu[i * 6 + J], UJ, v);   /* uniform */
-          NGPDE_PB_TERM(2, ub2) NGPDE_PB_TERM(3, ub3) NGPDE_PB_TERM(4, ub4) NGPDE_PB_TERM(5, ub5)
-#undef NGPDE_PB_TERM
+          float4 v = f4_scale(ldsC[42 + i], t);
+          v = f4_fma(ldsC[i - 1], lam, v);
+          v = f4_fma(ldsC[6 + i * 6 + 2], ub2, v); v = f4_fma(ldsC[6 + i * 6 + 3], ub3, v);   // zero weights add an exact zero
+          v = f4_fma(ldsC[6 + i * 6 + 4], ub4, v); v = f4_fma(ldsC[6 + i * 6 + 5], ub5, v);
           kbar = v;
         } else {
           float4 v = f4_scale(1.0f, t);
           v = f4_fma(1.0f, lam, v);
-          if (1 < S) v = f4_fma(1.0f, ub1, v);   // uniform
-          if (2 < S) v = f4_fma(1.0f, ub2, v);
-          if (3 < S) v = f4_fma(1.0f, ub3, v);
-          if (4 < S) v = f4_fma(1.0f, ub4, v);
-          if (5 < S) v = f4_fma(1.0f, ub5, v);
+          v = f4_fma(1.0f, ub1, v); v = f4_fma(1.0f, ub2, v); v = f4_fma(1.0f, ub3, v);   // stage adjoints beyond S stay zero
+          v = f4_fma(1.0f, ub4, v); v = f4_fma(1.0f, ub5, v);
           lam = v;
-          kbar = f4_scale(p.dtb[S - 1], v);
+          kbar = f4_scale(ldsC[S - 1], v);
         }
         if (last) break;
         dense(ph, ldsW2, dw2, db2, kbar, mk, xrow, p.g2);
@@ -525,8 +578,8 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
   ps->sync_bytes = (size_t)(nt + 1) * 128;
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->sync, ps->sync_bytes));
   NGPDE_HIP_CHECK(hipMemset(ps->sync, 0, ps->sync_bytes));
-  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->coef, 78 * sizeof(float)));
-  NGPDE_HIP_CHECK(hipMemcpy(ps->coef, coef_host, 78 * sizeof(float), hipMemcpyHostToDevice));
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->coef, 90 * sizeof(float)));
+  NGPDE_HIP_CHECK(hipMemcpy(ps->coef, coef_host, 90 * sizeof(float), hipMemcpyHostToDevice));
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->fault, 128));
   NGPDE_HIP_CHECK(hipMemset(ps->fault, 0, 128));
   return NGPDE_OK;
@@ -549,9 +602,20 @@ TileMeta make_meta(const Csr &c, const NodePersist &ps) {
   TileMeta m;
   m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr;
   m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 32; m.n_tiles = ps.n_tiles;
+#ifdef NGPDE_STAMPS
+  m.stamps = g_pst_base; m.stamps_max = g_pst_max;
+#endif
   return m;
 }
 }  // namespace
+
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_persistent_stamps(unsigned long long *dev_buf, int32_t max_phases) {
+  g_pst_base = dev_buf;   // [n_tiles][max_phases][8], or NULL
+  g_pst_max = max_phases;
+  return NGPDE_OK;
+}
+#endif
 
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
@@ -595,8 +659,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
   k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;
-  k.dtb = ps.coef + 36;
-  k.cu = ps.coef + 42;
+  k.cb = ps.coef + 42;
   const dim3 grid(ps.n_tiles), block(kThreads);
   if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
   else hipLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, k);
