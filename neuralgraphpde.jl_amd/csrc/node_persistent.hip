@@ -45,7 +45,8 @@ static_assert(PG::R == 1 && PG::GROUPS == kTM && PG::LPR == 16, "one 16-lane gro
 constexpr int kXhF = (kHaloCap + 1) * PD;   // halo region (floats), +1: the all-zero row
 constexpr int kTileF = kTM * PG::TS;        // one 32-row MFMA operand / result tile
 constexpr int kWF = PD * PG::TS;            // one transposed weight matrix
-constexpr int kNbrStride = 64;              // wait-list entries per tile (one lane of the polling wave each)
+constexpr int kNbrStride = 64;              // wait-list stride per tile; at most 63 entries (one lane of the polling wave each,
+                                            // lane 63 watches the abort word)
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -73,15 +74,6 @@ __device__ __forceinline__ void store_sc1(float *base, unsigned byte_off, float4
 template <class T>
 __device__ __forceinline__ T *at_bytes(T *base, unsigned byte_off) {   // base + offset with the base kept scalar
   return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + byte_off);
-}
-
-__device__ __forceinline__ bool spin_ok(unsigned long long t0, unsigned *abort_word) {
-  if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-  if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s of the 100 MHz counter: the whole solve takes ~6 ms
-    __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-  }
-  return true;
 }
 
 struct TileCtx {
@@ -132,20 +124,28 @@ __device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, flo
   c.my_nbr = m.nbr[(size_t)c.tile * kNbrStride + c.lane];
 }
 
-// Wait until every tile of the wait list has finished phase ph - 1 (wave 0 polls, one flag per lane; everybody meets at the
-// barrier).  Returns false when the solve was aborted.
+// Wait until every tile of the wait list has finished phase ph - 1: wave 0 polls, one flag per lane (lanes 0..62) and the abort
+// word on lane 63, ONE load per lane and round (a second dependent load per round would double the polling period, which is
+// the granularity a published flag is seen with); everybody meets at the barrier.  Returns false when the solve was aborted.
+// Bounded: after ~2 s of the 100 MHz counter (the whole solve takes ~6 ms) the wave raises the abort word itself.
 __device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok) {
   if (ph <= 1) return true;
   if (c.wave_u == 0) {
     const unsigned need = (unsigned)(ph - 1);
+    const unsigned *addr = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? m.flags + 32 * c.my_nbr : nullptr);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     bool ok = true;
-    for (;;) {
+    for (unsigned it = 1;; ++it) {
       unsigned f = need;
-      if (c.my_nbr >= 0) f = __hip_atomic_load(m.flags + 32 * c.my_nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all((int)(f >= need))) break;
-      if (!spin_ok(t0, m.abort_word)) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(1);
+      if (addr) f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__any((int)(c.lane == 63 && f != 0))) { ok = false; break; }              // somebody gave up
+      if (__all((int)(c.lane == 63 || f >= need))) break;
+      if ((it & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (c.lane == 0) __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);   // (2 / 4 / 8 measured: no difference beyond run-to-run noise; the polling period is not what a phase waits for)
     }
     if (c.lane == 0) *s_ok = ok ? 1 : 0;
   }
@@ -545,7 +545,7 @@ static bool build_wait_lists(const ngpde_graph *g, std::vector<int> &out) {
   for (int t = 0; t < nt; ++t) {
     std::sort(nb[t].begin(), nb[t].end());
     nb[t].erase(std::unique(nb[t].begin(), nb[t].end()), nb[t].end());
-    if ((int)nb[t].size() > kNbrStride) return false;
+    if ((int)nb[t].size() > kNbrStride - 1) return false;
     for (size_t k = 0; k < nb[t].size(); ++k) out[(size_t)t * kNbrStride + k] = nb[t][k];
   }
   return true;
