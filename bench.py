@@ -156,9 +156,14 @@ def main():
     def job(traj, n_steps, n_warmup):
         """`traj` independent trajectories on this GPU as ONE block-diagonal batched graph (traj = 1: the BASELINE workload).
         Returns (elapsed seconds of n_steps bench steps, max over ranks; forward / backward ms of one solve; plan)."""
-        gb = g if traj == 1 else ng.batch([g] * traj)
-        handle = gb.handle((True, None, False))
-        plan = _Plan(handle, D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
+        # traj > 1: a block-diagonal batch of `traj` graphs with ONE structure.  The persistent plan solves its members one
+        # after the other on the member's handle; where it is not available the batch becomes one big derived graph.
+        try:
+            plan = _Plan(g.handle((True, None, False)), D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True, members=traj)
+        except _lib.NgpdeError as e:
+            if traj == 1 or e.code != _lib.ERR_UNSUPPORTED:
+                raise
+            plan = _Plan(ng.batch([g] * traj).handle((True, None, False)), D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
         u0 = dv(u0_h) if traj == 1 else torch.cat(
             [dv(S.normal(1000 + rank + 97 * k, D * N_NODES).reshape(N_NODES, D).astype(np.float32)) for k in range(traj)])
         # parameters as ONE flat vector [w1 | b1 | w2 | b2] (the reference's ComponentArray), gradients likewise

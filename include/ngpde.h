@@ -290,6 +290,14 @@ int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float
  * ---------------------------------------------------------------------------------------------- */
 int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, int32_t tableau,
                                int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out);
+/* The same plan for a block-diagonal batch of `members` graphs that all have the structure of `member` ("all graphs need to
+ * have the same structure", src/layers.jl:359-361; MLUtils.batch, test/runtests.jl:89-102): u0 / uT / duT / du0 are
+ * [members * N][d], member after member; the parameter gradients are the sums over the members.  The trajectories are solved
+ * one after the other inside the persistent launches (a tile keeps a trajectory's state in registers, see ngpde_node_flags), so
+ * the derived-graph handle, the wait lists and the exchanged arrays are those of ONE member.  NGPDE_ERR_UNSUPPORTED when the
+ * persistent plan is not available for this graph / width / activation: batch the graphs into one handle then. */
+int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *member, int32_t members, int32_t d, int32_t act, int32_t tableau,
+                                     int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out);
 int32_t ngpde_node_destroy(ngpde_node_t *plan);
 size_t ngpde_node_tape_bytes(const ngpde_node_t *plan);
 /* u0 [N][d]; w1,w2 (d x d) column-major; b1,b2 [d]; uT [N][d].  Enqueues the whole solve. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ngpde_activation_forward": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "ngpde_spectral_weights": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "ngpde_node_gcn2_create": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, C.POINTER(_vp)]),
+    "ngpde_node_gcn2_create_batch": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, C.POINTER(_vp)]),
     "ngpde_node_destroy": (_i32, [_vp]),
     "ngpde_node_tape_bytes": (_sz, [_vp]),
     "ngpde_node_gcn2_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -172,7 +172,7 @@ struct NodePersist {
 struct NodePersistFwd {
   const ngpde_graph *g = nullptr;
   const NodePersist *ps = nullptr;
-  int n_steps = 0, S = 0, act = 0;
+  int n_steps = 0, S = 0, act = 0, n_members = 1;
   const float *u_in = nullptr;
   float *u_out = nullptr, *bufA = nullptr, *bufB = nullptr;
   const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
@@ -184,7 +184,7 @@ struct NodePersistFwd {
 struct NodePersistBwd {
   const ngpde_graph *g = nullptr;
   const NodePersist *ps = nullptr;
-  int n_steps = 0, S = 0;
+  int n_steps = 0, S = 0, n_members = 1;
   float *lam = nullptr, *g1 = nullptr, *g2 = nullptr;
   const float *w1 = nullptr, *w2 = nullptr, *tape = nullptr;
   const uint8_t *masks = nullptr;

@@ -51,20 +51,21 @@ Tableau make_tableau(int which) {
 
 // dst[i][:] = src[i][:] * c[i]   (invert: / c[i]) -- entry to / exit from the pre-scaled form of the pipeline
 __global__ void scale_rows_kernel(size_t n4, int lpr, int invert, const float4 *__restrict__ src, const float *__restrict__ c,
-                                  float4 *__restrict__ dst) {
+                                  size_t n_nodes, float4 *__restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const float ci = c[i / lpr];
+  const float ci = c[(i / lpr) % n_nodes];   // (a batch of identical graphs repeats the member's coefficients)
   const float f = invert ? 1.0f / ci : ci;
   const float4 v = src[i];
   dst[i] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
 }
 
-int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t n, int d, bool invert, hipStream_t stream) {
-  const size_t n4 = (size_t)n * d / 4;
+int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t n, int d, bool invert, hipStream_t stream,
+                          int members = 1) {
+  const size_t n4 = (size_t)n * members * d / 4;
   if (n4 == 0) return NGPDE_OK;
   hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, d / 4, invert ? 1 : 0,
-                     reinterpret_cast<const float4 *>(src), c, reinterpret_cast<float4 *>(dst));
+                     reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst));
   NGPDE_LAUNCH_CHECK("scale_rows_kernel");
   return NGPDE_OK;
 }
@@ -83,6 +84,9 @@ struct ngpde_node {
   Tableau tb;
   int64_t n = 0;
   size_t row_elems = 0;  // n * d
+  int members = 1;       // > 1: a block-diagonal batch of `members` graphs with this structure, solved one after the other by the
+                         // persistent launches (u0 / uT / du0 are [members * n][d])
+  size_t all_elems = 0;  // members * row_elems
   int nb = 0;            // workgroups of the fused kernels (= slabs)
   int slots = 0;         // tape slots per stage evaluation
 
@@ -308,7 +312,7 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
 // the persistent forms: ONE launch for the whole solve / the whole adjoint (node_persistent.hip)
 int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   NodePersistFwd a;
-  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.act = p->act;
+  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.act = p->act; a.n_members = p->members;
   a.u_in = p->u; a.u_out = p->u;     // a tile writes its rows of u(T) only after all its readers are past phase 1
   a.bufA = p->ustage; a.bufB = p->pbuf;
   a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
@@ -321,7 +325,7 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
 
 int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   NodePersistBwd a;
-  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S;
+  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.n_members = p->members;
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
@@ -392,7 +396,13 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
 
 int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, int32_t tableau, int32_t n_steps,
                                float dt, int32_t with_backward, ngpde_node_t **out) {
+  return ngpde_node_gcn2_create_batch(g, 1, d, act, tableau, n_steps, dt, with_backward, out);
+}
+
+int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, int32_t d, int32_t act, int32_t tableau,
+                                     int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out) {
   NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: out is NULL");
+  NGPDE_REQUIRE(members >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create_batch: members must be >= 1");
   *out = nullptr;
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: graph is NULL");
   NGPDE_REQUIRE(g->has_norm, NGPDE_ERR_STATE, "ngpde_node_gcn2_create: GCN normalisation not set");
@@ -411,7 +421,9 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   p->needs_z = p->with_bwd && act_needs_z(act);
   p->tb = make_tableau(tableau);
   p->n = g->n_nodes;
+  p->members = members;
   p->row_elems = (size_t)p->n * d;
+  p->all_elems = (size_t)members * p->row_elems;
   p->nb = fused_num_blocks(p->n);
   p->mask_mode = p->with_bwd && act == NGPDE_ACT_RELU && std::getenv("NGPDE_NO_MASK") == nullptr;
   p->slots = p->mask_mode ? 2 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4);
@@ -424,23 +436,23 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   auto A = [&](float **ptr, size_t elems) {
     if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
   };
-  A(&p->u, p->row_elems);
+  A(&p->u, p->all_elems);
   A(&p->ustage, p->row_elems);
-  A(&p->u0keep, p->row_elems);
+  A(&p->u0keep, p->all_elems);
   A(&p->w1, (size_t)d * d); A(&p->b1, d); A(&p->w2, (size_t)d * d); A(&p->b2, d);
-  const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->row_elems;
+  const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->all_elems;
   p->tape_bytes = tape_elems * sizeof(float);
   A(&p->tape, tape_elems);
   if (p->mask_mode) {
     A(&p->ybuf, (size_t)S * 2 * p->row_elems);
     if (st == NGPDE_OK) {
-      const size_t mb = (size_t)n_steps * S * 2 * p->mask_bytes;
+      const size_t mb = (size_t)members * n_steps * S * 2 * p->mask_bytes;
       if (hipMalloc((void **)&p->masks, std::max<size_t>(mb, 1)) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipMalloc of the sign-bit masks failed");
       else p->tape_bytes += mb + (size_t)S * 2 * p->row_elems * sizeof(float);
     }
   }
   if (p->with_bwd) {
-    A(&p->lam, p->row_elems); A(&p->g1, p->row_elems); A(&p->g2, p->row_elems);
+    A(&p->lam, p->all_elems); A(&p->g1, p->row_elems); A(&p->g2, p->row_elems);
     p->ubar.assign(S, nullptr);
     for (int j = 1; j < S; ++j) A(&p->ubar[j], p->row_elems);
     const size_t dd = (size_t)d * d;
@@ -480,6 +492,9 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
     }
     if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, p->row_elems);
   }
+  if (st == NGPDE_OK && members > 1 && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd)))
+    st = fail(NGPDE_ERR_UNSUPPORTED, "ngpde_node_gcn2_create_batch: the member-by-member solve exists for the persistent plan only "
+                                     "(d = 64, relu, unweighted, at most two 32-row tiles per CU); batch the graphs into one handle instead");
   if (st == NGPDE_OK && !p->eager && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd))) {
     hipError_t e = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
     if (e != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -535,12 +550,12 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
   if (p->pre) {
-    int32_t st = launch_scale_rows(u0, p->g->c, p->u, p->n, p->d, false, stream);
+    int32_t st = launch_scale_rows(u0, p->g->c, p->u, p->n, p->d, false, stream, p->members);
     if (st) return st;
   } else {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
   NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
   if (b1) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b1, b1, db, hipMemcpyDeviceToDevice, stream));
@@ -557,10 +572,10 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
     NGPDE_HIP_CHECK(hipGraphLaunch(p->fwd_exec, stream));
   }
   if (p->pre) {
-    int32_t st = launch_scale_rows(p->u, p->g->c, uT, p->n, p->d, true, stream);
+    int32_t st = launch_scale_rows(p->u, p->g->c, uT, p->n, p->d, true, stream, p->members);
     if (st) return st;
   } else {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   p->forward_done = true;
   ++p->generation;
@@ -593,10 +608,10 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
   if (p->pre) {   // u(T) = u~(T) ./ c  =>  dL/du~(T) = duT ./ c
-    int32_t st = launch_scale_rows(duT, p->g->c, p->lam, p->n, p->d, true, stream);
+    int32_t st = launch_scale_rows(duT, p->g->c, p->lam, p->n, p->d, true, stream, p->members);
     if (st) return st;
   } else {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   if (p->persist_bwd) {
     int32_t st = enqueue_backward_persistent(p, stream);
@@ -608,10 +623,10 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
     NGPDE_HIP_CHECK(hipGraphLaunch(p->bwd_exec, stream));
   }
   if (du0 && p->pre) {   // u~0 = c .* u0  =>  du0 = c .* dL/du~0
-    int32_t st = launch_scale_rows(p->lam, p->g->c, du0, p->n, p->d, false, stream);
+    int32_t st = launch_scale_rows(p->lam, p->g->c, du0, p->n, p->d, false, stream, p->members);
     if (st) return st;
   } else if (du0) {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   p->backward_pending = false;
   if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
@@ -631,9 +646,9 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   prof.stride = stride;
   int32_t st;
   if (p->pre) {
-    if ((st = launch_scale_rows(p->u0keep, p->g->c, p->u, p->n, p->d, false, stream))) return st;
+    if ((st = launch_scale_rows(p->u0keep, p->g->c, p->u, p->n, p->d, false, stream, p->members))) return st;
   } else {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->row_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
   if (p->persist_fwd) {
@@ -642,8 +657,8 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   } else if ((st = enqueue_forward(p, stream, nullptr, &prof))) return st;
   if (p->with_bwd) {
     // adjoint seed of loss = sum(u(T)): ones
-    std::vector<float> ones(p->row_elems, 1.0f);
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, ones.data(), p->row_elems * sizeof(float), hipMemcpyHostToDevice, stream));
+    std::vector<float> ones(p->all_elems, 1.0f);
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, ones.data(), p->all_elems * sizeof(float), hipMemcpyHostToDevice, stream));
     NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
     if (p->persist_bwd) {
       prof.counter = 0;

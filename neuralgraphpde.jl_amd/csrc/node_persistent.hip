@@ -241,12 +241,13 @@ __device__ __forceinline__ float4 f4_nan() {
 struct PFwdK {
   TileMeta m;          // lists by TARGET
   int n_steps, S, act;
-  const float *u_in;   // [N][64]  c .* u0
-  float *u_out;        // [N][64]  c .* u(T)
+  int n_members;       // trajectories solved one after the other on the same structure (a block-diagonal batch of identical graphs)
+  const float *u_in;   // [n_members][N][64]  c .* u0
+  float *u_out;        // [n_members][N][64]  c .* u(T)
   float *bufA, *bufB;  // exchanged arrays: stage input (A), layer-1 output (B)
   const float *w1, *b1, *w2, *b2;
-  float *tape;         // [n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
-  uint8_t *masks;      // [n_steps][S][2][mask_bytes] relu sign bits
+  float *tape;         // [n_members][n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
+  uint8_t *masks;      // [n_members][n_steps][S][2][mask_bytes] relu sign bits
   size_t row_elems, mask_bytes;
   const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
                        // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
@@ -270,21 +271,24 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);   // byte offset of this thread's 16 bytes in a [N][64] array
-  float4 u = f4_sel(c.valid, *at_bytes(reinterpret_cast<const float4 *>(p.u_in), own), f4_zero());
-  // six named values written through component-wise selects (f4_sel): an array written as `k[j] = (j == i) ? yv : k[j]` ends
-  // up in scratch memory
-  float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
-  Xh4[c.grp * PG::LPR + c.q] = u;
   __syncthreads();
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[c.q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[c.q];
   bool ok = true;
-  int ph = 0;
+  int ph = 0;   // phases count on across the members: a tile starts the next trajectory while its neighbours finish this one
+  for (int mb = 0; mb < p.n_members; ++mb) {
+  const float *u_in = p.u_in + (size_t)mb * p.row_elems;
+  const size_t ev0 = (size_t)mb * p.n_steps * p.S * 2;
+  float4 u = f4_sel(c.valid && ok, *at_bytes(reinterpret_cast<const float4 *>(u_in), own), f4_zero());
+  // six named values written through component-wise selects (f4_sel): an array written as `k[j] = (j == i) ? yv : k[j]` ends
+  // up in scratch memory
+  float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
+  Xh4[c.grp * PG::LPR + c.q] = u;   // (nobody reads the halo slots between a publish and the next gather's barrier)
   for (int n = 0; n < p.n_steps && ok; ++n) {
     for (int i = 0; i < p.S && ok; ++i) {
 #pragma unroll
       for (int layer = 0; layer < 2; ++layer) {
         ++ph;
-        const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
+        const float *X = layer == 0 ? ((n == 0 && i == 0) ? u_in : p.bufA) : p.bufB;
         NGPDE_PST(p.m, ph, 0);
         unsigned sw[8];
         tile_slot_words(c, sw);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         NGPDE_PST(p.m, ph, 2);
         float4 acc = f4_scale(c.ci, tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
-        const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
+        const size_t ev = ev0 + (size_t)(n * p.S + i) * 2 + layer;
         if (TAPE && c.valid) store_stream4(at_bytes(reinterpret_cast<float4 *>(p.tape + ev * p.row_elems), own), acc);
         __syncthreads();
         NGPDE_PST(p.m, ph, 3);
@@ -329,7 +333,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
       }
     }
   }
-  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.u_out), own) = f4_sel(ok, u, f4_nan());
+  // (a tile writes its rows of u(T) only after all readers of its u0 rows are past that member's first phase)
+  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.u_out + (size_t)mb * p.row_elems), own) = f4_sel(ok, u, f4_nan());
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -337,8 +343,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
 // ---------------------------------------------------------------------------------------------------------------------
 struct PBwdK {
   TileMeta m;          // lists by SOURCE
-  int n_steps, S;
-  float *lam;          // in: dL/du~(T) (adjoint seed ./ c); out: dL/du~0
+  int n_steps, S, n_members;
+  float *lam;          // [n_members][N][64] in: dL/du~(T) (adjoint seed ./ c); out: dL/du~0
   float *g1, *g2;      // exchanged arrays: c .* (dZ1 W1^T), c .* (dZ2 W2^T)
   const float *w1, *w2;
   const float *tape;
@@ -363,8 +369,6 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-  float4 lam = f4_sel(c.valid, *at_bytes(reinterpret_cast<const float4 *>(p.lam), own), f4_zero());
-  float4 ub1 = f4_zero(), ub2 = f4_zero(), ub3 = f4_zero(), ub4 = f4_zero(), ub5 = f4_zero();   // named, not an array (see the forward kernel)
   constexpr int NT = PG::CT * PG::CT;
   f32x4 dw1[PG::DWT], dw2[PG::DWT];
 #pragma unroll
@@ -431,16 +435,23 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
   auto mask_of = [&](size_t ev) { return (unsigned)*at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
 
   bool ok = true;
-  int ph = 1;
-  {   // phase 1: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half
-    const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
+  int ph = 0;   // phases count on across the members (the parameter-gradient accumulators too: the gradient of a batch is the sum)
+  for (int mb = 0; mb < p.n_members; ++mb) {
+  float *lam_g = p.lam + (size_t)mb * p.row_elems;
+  const size_t ev0 = (size_t)mb * p.n_steps * S * 2;
+  float4 lam = f4_sel(c.valid && ok, *at_bytes(reinterpret_cast<const float4 *>(lam_g), own), f4_zero());
+  float4 ub1 = f4_zero(), ub2 = f4_zero(), ub3 = f4_zero(), ub4 = f4_zero(), ub5 = f4_zero();   // named, not an array (see the forward kernel)
+  if (ok) {   // first phase of a member: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather:
+              // g2 was last read two phases ago, so no wait either)
+    ++ph;
+    const size_t ev = ev0 + (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
     dense(ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev), tape_row(ev), p.g2);
   }
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
     for (int i = S - 1; i >= 0 && ok; --i) {
       {   // layer 1 of stage i: dL/dy1 = A^T g2
         ++ph;
-        const size_t ev = (size_t)(n * S + i) * 2;
+        const size_t ev = ev0 + (size_t)(n * S + i) * 2;
         NGPDE_PST(p.m, ph, 0);
         const unsigned mk = mask_of(ev);          // own-row loads: in flight during the wait
         const float4 xrow = tape_row(ev);
@@ -456,14 +467,14 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
       {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
         ++ph;
         const bool last = (i == 0 && n == 0);
-        const size_t ev = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;
+        const size_t ev = ev0 + ((i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1);
         unsigned mk = 0;
         float4 xrow = f4_zero();
+        NGPDE_PST(p.m, ph, 0);
         if (!last) {
           mk = mask_of(ev);
           xrow = tape_row(ev);
         }
-        NGPDE_PST(p.m, ph, 0);
         unsigned sw[8];
         tile_slot_words(c, sw);
         if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
@@ -489,12 +500,13 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
           lam = v;
           kbar = f4_scale(ldsC[S - 1], v);
         }
-        if (last) break;
+        if (last) break;   // (this phase writes nothing other tiles read: no flag; the next member's first phase publishes ph + 1)
         dense(ph, ldsW2, dw2, db2, kbar, mk, xrow, p.g2);
       }
     }
   }
-  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.lam), own) = f4_sel(ok, lam, f4_nan());
+  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(lam_g), own) = f4_sel(ok, lam, f4_nan());
+  }
   // the tile's contribution to the parameter gradients: one slab per tile, summed by reduce_slabs_kernel
   const float bad = __int_as_float(0x7fc00000);
   auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
@@ -624,7 +636,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
   k.m = make_meta(g->by_t, ps);
-  k.n_steps = a.n_steps; k.S = a.S; k.act = a.act;
+  k.n_steps = a.n_steps; k.S = a.S; k.act = a.act; k.n_members = a.n_members;
   k.u_in = a.u_in; k.u_out = a.u_out; k.bufA = a.bufA; k.bufB = a.bufB;
   k.w1 = a.w1; k.b1 = a.b1; k.w2 = a.w2; k.b2 = a.b2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
@@ -655,7 +667,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
   k.m = make_meta(g->by_s, ps);
-  k.n_steps = a.n_steps; k.S = a.S;
+  k.n_steps = a.n_steps; k.S = a.S; k.n_members = a.n_members;
   k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
   k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;

@@ -132,7 +132,9 @@ class GNNGraph:
             self.edata = g.edata if edata is None else _normalize(edata, "e", self.num_edges, "edge")
             self.gdata = g.gdata if gdata is None else _normalize(gdata, "u", self.num_graphs, "graph")
             self._packs = {}
+            self._members = getattr(g, "_members", None)
             return
+        self._members = None
         s0 = np.asarray(s, dtype=np.int64).reshape(-1) - index_base
         t0 = np.asarray(t, dtype=np.int64).reshape(-1) - index_base
         if s0.shape != t0.shape:
@@ -388,6 +390,7 @@ def batch(graphs):
     out.ndata = cat([g.ndata for g in graphs], lambda g: g.num_nodes)
     out.edata = cat([g.edata for g in graphs], lambda g: g.num_edges)
     out.gdata = cat([g.gdata for g in graphs], lambda g: g.num_graphs, gdata=True)
+    out._members = graphs if all(g.num_graphs == 1 for g in graphs) else None   # (solver plans look for identical members)
     if graphs and graphs[0].edge_weight is not None:
         out.edge_weight = np.concatenate([np.asarray(g.edge_weight) for g in graphs])
     # the batch's locality order = its members' cached orders, offset: no graph traversal per minibatch

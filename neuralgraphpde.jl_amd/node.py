@@ -36,12 +36,17 @@ class _Token:
 
 
 class _Plan:
-    def __init__(self, handle, d, act, tableau, n_steps, dt, with_backward):
+    def __init__(self, handle, d, act, tableau, n_steps, dt, with_backward, members=1):
+        """members > 1: `handle` is ONE member of a block-diagonal batch of `members` identical structures; the plan takes
+        [members * N][d] arrays and solves the members one after the other (ngpde_node_gcn2_create_batch; raises NgpdeError
+        with code ERR_UNSUPPORTED when the persistent plan does not cover the case)"""
         self.lib = _lib.load()
         self.handle = handle            # keeps the graph handle alive
+        self.ptr = None
+        self.members = int(members)
         out = C.c_void_p()
-        _lib.check(self.lib.ngpde_node_gcn2_create(handle.ptr, d, act, _lib.TABLEAU[tableau], n_steps, dt,
-                                                   int(with_backward), C.byref(out)))
+        _lib.check(self.lib.ngpde_node_gcn2_create_batch(handle.ptr, self.members, d, act, _lib.TABLEAU[tableau], n_steps, dt,
+                                                         int(with_backward), C.byref(out)))
         self.ptr = out
 
     def tape_bytes(self):
@@ -138,6 +143,7 @@ class NeuralODE(AbstractExplicitLayer):
         self.model, self.solver, self.tspan, self.n_steps = model, solver, tuple(tspan), int(n_steps)
         self.dt = float(dt) if dt is not None else (self.tspan[1] - self.tspan[0]) / self.n_steps
         self._plans = {}
+        self._no_member_plan = False
 
     def initialparameters(self, rng):
         return self.model.initialparameters(rng)
@@ -174,8 +180,14 @@ class NeuralODE(AbstractExplicitLayer):
         if info is None:
             return None
         l1, g, d = info
-        handle = g.handle((l1.add_self_loops, None, False))
-        key = (id(handle), d, l1.act, bool(with_backward))
+        norm = (l1.add_self_loops, None, False)
+        # a batch of graphs that share ONE structure (batch([g, g, ...]) or copies of g with other features): the plan is built on
+        # the member and solves the trajectories one after the other inside its persistent launches
+        members = getattr(g, "_members", None)
+        member_plan = (members is not None and len(members) > 1 and all(m._handles is members[0]._handles for m in members)
+                       and not self._no_member_plan)
+        handle = members[0].handle(norm) if member_plan else g.handle(norm)
+        key = (id(handle), d, l1.act, bool(with_backward), len(members) if member_plan else 1)
         pool = self._plans.get(key)
         if pool is None:
             pool = self._plans[key] = []
@@ -190,7 +202,15 @@ class NeuralODE(AbstractExplicitLayer):
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
-        plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward)
+        try:
+            plan = _Plan(handle, d, l1.act, self.solver, self.n_steps, self.dt, with_backward,
+                         members=len(members) if member_plan else 1)
+        except _lib.NgpdeError as e:
+            if not (member_plan and e.code == _lib.ERR_UNSUPPORTED):
+                raise
+            self._no_member_plan = True     # not a case of the persistent plan: one handle for the whole batch instead
+            self._plans.pop(key, None)
+            return self.plan_for(ps, st, with_backward)
         pool.append(plan)
         return plan
 

@@ -423,3 +423,156 @@ def test_gcn_edge_weight_argument_reuses_one_handle_and_stays_bounded():
     for k in range(10):                            # fresh weight tensors every call: the cache stays at its cap
         l(x, ps, st, torch.rand(E, device=DEV) + 0.5)
     assert len(lru) <= ng.GNNGraph.max_weighted_handles
+
+
+def spatial_case(N, pairs, d, seed):
+    """closest-pairs graph on N uniform points (the C2 construction at test size; N need not be a multiple of the tile height)"""
+    _, s, t = S.closest_pairs_graph(N, pairs, seed=seed)
+    rng = np.random.default_rng(seed)
+    params = [dict(weight=S.glorot_uniform(seed + 10 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0), O.Graph(s, t, num_nodes=N, index_base=0), params
+
+
+def _oracle_node_with_seed(params, og, u0, seed, tableau, dt, nsteps, act="relu"):
+    """solve + discrete adjoint of loss = sum(seed .* u(T)) with the oracle's own pieces (gcn2_rhs, rk_solve, rk_adjoint)"""
+    rhs, vjp = O.gcn2_rhs(params, og, act)
+    uT, tape = O.rk_solve(rhs, u0, tableau, dt, nsteps)
+    acc = [dict(weight=np.zeros_like(p["weight"]), bias=np.zeros_like(p["bias"])) for p in params]
+
+    def accumulate(pg):
+        for A, G in zip(acc, pg):
+            A["weight"] += G["weight"]
+            A["bias"] += G["bias"].reshape(A["bias"].shape)
+    du0 = O.rk_adjoint(vjp, tape, seed.copy(), tableau, dt, accumulate)
+    return uT, du0, acc
+
+
+@pytest.mark.parametrize("tab,persistent", [("tsit5", True), ("euler", True), ("tsit5", False)])
+def test_node_batch_of_identical_graphs_member_by_member(tab, persistent, monkeypatch):
+    # batch([g, g, g]) (test/runtests.jl:89-102; "all graphs need to have the same structure", src/layers.jl:359-361): the
+    # persistent plan solves the members one after the other on the member's handle.  Every member against the float64 oracle of
+    # that member alone, parameter gradients against the sum over the members; the same through the one-big-handle path.
+    if not persistent:
+        monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+    N, d, K, nsteps, dt = 1000, 64, 3, 2, 0.1
+    g, og, params = spatial_case(N, 4 * N, d, seed=91)      # a radius-style graph: its tiles fit the LDS halo (persistent plan)
+    gb = ng.batch([g, g.copy(), g])
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=gb), ng.GCNConv((d, d), "relu", initialgraph=gb))
+    node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    rng = np.random.default_rng(92)
+    u0 = rng.normal(size=(d, K * N))
+    R = rng.normal(size=(d, K * N))
+    u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    plan = next(iter(node._plans.values()))[0]
+    assert plan.members == (K if persistent else 1)
+    assert ("persistent_fwd" in plan.flags()) == persistent
+    (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+    assert not plan.fault()
+    accW = [np.zeros((d, d)), np.zeros((d, d))]
+    accb = [np.zeros((d, 1)), np.zeros((d, 1))]
+    for m in range(K):
+        sl = slice(m * N, (m + 1) * N)
+        uTo, du0o, acc = _oracle_node_with_seed(params, og, u0[:, sl], R[:, sl], O.TABLEAUS[tab], dt, nsteps)
+        close(uT[:, sl], uTo, rtol=2e-4, what=f"u(T) member {m}")
+        close(u.grad[:, sl], du0o, rtol=5e-4, atol=1e-4, what=f"du0 member {m}")
+        for k in range(2):
+            accW[k] += acc[k]["weight"]
+            accb[k] += acc[k]["bias"]
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, accW[k], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, accb[k], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+
+
+@pytest.mark.parametrize("tab,N,nsteps", [("tsit5", 1000, 3), ("euler", 2048, 5), ("tsit5", 77, 2)])
+def test_node_persistent_plan_against_oracle(tab, N, nsteps):
+    # the persistent plan (one launch per direction, tiles synchronised by phase flags) on graphs whose tiles fit the LDS halo:
+    # u(T), du0 and the parameter gradients against the float64 oracle; a last tile with padding rows (N = 1000, 77)
+    d, dt = 64, 0.1
+    g, og, params = spatial_case(N, 4 * N, d, seed=N)
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    rng = np.random.default_rng(N + 1)
+    u0, R = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+    u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    plan = next(iter(node._plans.values()))[0]
+    assert {"persistent_fwd", "persistent_bwd"} <= plan.flags()
+    assert plan.launch_count() == (3, 7)
+    (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+    assert not plan.fault()
+    uTo, du0o, acc = _oracle_node_with_seed(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps)
+    close(uT, uTo, rtol=2e-4, what="u(T)")
+    close(u.grad, du0o, rtol=5e-4, atol=1e-4, what="du0")
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, acc[k]["weight"], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_node_persistent_forward_only_plan_any_activation(act):
+    # without gradients the persistent forward launch takes any activation (the adjoint launch is relu-only: sign-bit tape)
+    N, d, nsteps, dt = 1500, 64, 4, 0.05
+    g, og, params = spatial_case(N, 4 * N, d, seed=5)
+    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+    node = ng.NeuralODE(rhs, solver="tsit5", n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    u0 = np.random.default_rng(6).normal(size=(d, N))
+    with torch.no_grad():
+        uT, _ = node(torch.as_tensor(u0.astype(np.float32), device=DEV), ps, st)
+    plan = next(iter(node._plans.values()))[0]
+    assert "persistent_fwd" in plan.flags() and "persistent_bwd" not in plan.flags()
+    rhs_o, _ = O.gcn2_rhs(params, og, act)
+    uTo, _ = O.rk_solve(rhs_o, u0, O.TABLEAUS["tsit5"], dt, nsteps)
+    close(uT, uTo, rtol=2e-4, what=f"u(T) {act}")
+
+
+def test_node_persistent_and_replayed_plans_agree_bitwise(monkeypatch):
+    # same arithmetic, operation for operation: u(T) and du0 of the persistent plan equal the replayed plan's bit for bit;
+    # the parameter gradients differ only in the order the per-tile partial sums are added
+    N, d, nsteps, dt = 4096, 64, 3, 0.02
+    g, og, params = spatial_case(N, 4 * N, d, seed=8)
+    rng = np.random.default_rng(9)
+    u0 = torch.as_tensor(rng.normal(size=(d, N)).astype(np.float32), device=DEV)
+    outs = {}
+    for mode in ("persistent", "replayed"):
+        if mode == "replayed":
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+        node = ng.NeuralODE(rhs, solver="tsit5", n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        assert ("persistent_fwd" in next(iter(node._plans.values()))[0].flags()) == (mode == "persistent")
+        uT.sum().backward()
+        outs[mode] = (uT.detach().clone(), u.grad.clone(), ps["layer_1"]["weight"].grad.clone(), ps["layer_2"]["bias"].grad.clone())
+    a, b = outs["persistent"], outs["replayed"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-5) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-5)
