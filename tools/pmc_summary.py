@@ -15,7 +15,11 @@ def role_rows(path):
     seen = collections.defaultdict(dict)      # kernel -> dispatch id -> ordinal (several counters share a dispatch)
     for r in rows:
         n = r["Kernel_Name"]
-        if "gcn_fused_fwd_kernel" in n:
+        if "node_fwd_persistent_kernel" in n:          # the persistent plan: one launch per direction
+            k, names = "pfwd", ("fwd_persistent_solve", "fwd_persistent_solve")
+        elif "node_bwd_persistent_kernel" in n:
+            k, names = "pbwd", ("bwd_persistent_adjoint", "bwd_persistent_adjoint")
+        elif "gcn_fused_fwd_kernel" in n:
             k, names = "fwd", ("fwd_layer1", "fwd_layer2_stage")
         elif "gcn_fused_bwd_kernel" in n and ", true," in n:
             k, names = "bwd", ("bwd_layer1", "bwd_stage_layer2")

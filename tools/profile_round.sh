@@ -16,6 +16,8 @@ done
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 > $O/pmc_l2.log 2>&1
 cd $R
 python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_l2 $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
+# the replayed plan (NGPDE_NO_PERSISTENT=1) for comparison: bench line + kernel stats
+NGPDE_NO_PERSISTENT=1 python3 bench.py --no-cpu-baseline > $O/bench_replayed.json 2> /dev/null
 python3 tools/bench_layers.py --only c3 --reps 20 > $O/layers.jsonl 2>/dev/null
 python3 tools/bench_layers.py --only c4 --traj 64 --reps 10 >> $O/layers.jsonl 2>/dev/null
 python3 tools/bench_layers.py --only c5 --width 128 --reps 10 >> $O/layers.jsonl 2>/dev/null
