@@ -106,12 +106,148 @@ def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
                       f"not the Julia package)"}, outs
 
 
+# ---- secondary workloads: one layer of BASELINE configs 3-5 (never in `value`) ---------------------------------------------
+FP32_MFMA_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense
+# algorithmic figures of ONE layer forward
+C3_FWD_BYTES = 9.50e6        # GATConv on the C2 graph: compulsory traffic
+C4_FWD_FLOP = 49.0e9         # MPPDEConv shard (64 trajectories), first-layer-split form
+C5_FWD_FLOP = {0.05: 10.6e9, 0.1: 16.8e9}   # GNOConv 128 => 128, reassociated form
+
+
+def _time_ms(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _layer_times(layer, x, ps, st, reps):
+    """ms of one forward (no autograd) and of forward + backward (gradients w.r.t. x and every parameter) through the layer API"""
+    x = x.detach().requires_grad_(True)
+    with torch.no_grad():
+        y0 = layer(x, ps, st)[0]
+        ms_f = _time_ms(lambda: layer(x, ps, st)[0], reps)
+    R = torch.randn(y0.shape[1], y0.shape[0], device=x.device).T      # cotangent in the output's (column-major) layout
+
+    def fb():
+        layer(x, ps, st)[0].backward(R)
+    return ms_f, _time_ms(fb, reps)
+
+
+def _grad_leaves(ps):
+    out = []
+    for v in ps.values():
+        out += _grad_leaves(v) if isinstance(v, dict) else [v]
+    return out
+
+
+def c4_layer(dev, traj, seed):
+    n, h = 8192, 64
+    s, t = S.periodic_mesh_batch(n, traj)
+    N = n * traj
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, num_graphs=traj,
+                    ndata={"u": S.uniform01(40 + seed, N).reshape(1, N).astype(np.float32),
+                           "x": np.tile(np.arange(n) / n, traj)[None, :].astype(np.float32)},
+                    gdata={"θ": S.uniform01(41 + seed, 2 * traj).reshape(2, traj).astype(np.float32)})
+    phi = ng.Chain(ng.Dense(132, 64, "swish"), ng.Dense(64, 64, "swish"))
+    psi = ng.Chain(ng.Dense(130, 64, "swish"), ng.Dense(64, 64))
+    layer = ng.MPPDEConv(phi, psi, initialgraph=g)
+    ps, st = ng.setup(4, layer)
+    x = torch.as_tensor(S.normal(42 + seed, h * N).reshape(N, h).astype(np.float32), device=dev).T
+    return layer, ps, st, x, int(s.size)
+
+
+def secondary(dev, world, rank, dist):
+    """One layer forward / forward + backward of BASELINE configs 3, 4 (per-GPU shard) and 5 through the layer API, with the
+    roofline that bounds each.  N > 1: the C4 leg only, as a data-parallel training step (64 trajectories per
+    rank, replicated parameters, bucketed all-reduce of the flat gradient overlapped with the pullback, fused Adam)."""
+    out = {}
+    if world == 1:
+        _, s, t = S.closest_pairs_graph(N_NODES, N_PAIRS, seed=GRAPH_SEED)
+        g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
+        layer = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+        ps, st = ng.setup(3, layer)
+        ps = ng.to_device(ps, dev)
+        for v in _grad_leaves(ps):
+            v.requires_grad_(True)
+        x = torch.as_tensor(S.normal(33, 64 * N_NODES).reshape(N_NODES, 64).astype(np.float32), device=dev).T
+        f, fb = _layer_times(layer, x, ps, st, 20)
+        ach = C3_FWD_BYTES / (f * 1e-3) / 1e9
+        out["C3_gat_4x16_layer"] = {"ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
+                                    "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_MB_forward": C3_FWD_BYTES / 1e6}}
+    # C4: the per-GPU shard of the 512-trajectory config
+    layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
+    flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))
+    if world == 1:
+        f, fb = _layer_times(layer, x, psv, st, 10)
+        ach = C4_FWD_FLOP / (f * 1e-3) / 1e12
+        out["C4_mppde_shard_layer"] = {"trajectories": 64, "nodes": 64 * 8192, "edges": n_edges, "ms_forward": round(f, 4),
+                                       "ms_forward_backward": round(fb, 4),
+                                       "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
+                                                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
+                                                    "algorithmic_GFLOP_forward": C4_FWD_FLOP / 1e9}}
+    else:
+        st_opt = ng.optim.setup(ng.optim.Adam(1e-4), flat)
+        red = ng.dist.OverlappedGradReduce(flat, psv, [("ψ.",), ("ϕ.",)])     # psi's gradient is final first: its collective
+        xin = x.detach().requires_grad_(True)                                   # runs under phi's pullback
+        R = torch.ones(x.shape[1], x.shape[0], device=dev).T
+
+        def step():
+            flat.zero_grad()
+            layer(xin, psv, st)[0].backward(R)
+            red.finish()
+            ng.optim.update(st_opt, flat, reduced=True)
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = 1e3 * float(tt.item()) / reps
+        out["C4_mppde_data_parallel_step"] = {"trajectories_per_rank": 64, "ranks": world, "ms_step": round(ms, 4),
+                                              "value": round(world * 64 / (ms * 1e-3), 1), "unit": "trajectory-layers/s (fwd+bwd+all-reduce+Adam)",
+                                              "gradient_floats": int(flat.numel()), "scaling": "weak"}
+    if world == 1:
+        for radius in (0.05, 0.1):
+            pts, s5, t5 = S.grid_radius_graph(64, radius)
+            g5 = ng.GNNGraph(s5, t5, num_nodes=4096, index_base=0,
+                             ndata={"a": S.uniform01(50, 4096).reshape(1, 4096).astype(np.float32), "x": pts.astype(np.float32)})
+            phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, 128 * 128))
+            l5 = ng.GNOConv((128, 128), phi, "relu", initialgraph=g5)
+            ps5, st5 = ng.setup(5, l5)
+            ps5 = ng.to_device(ps5, dev)
+            for v in _grad_leaves(ps5):
+                v.requires_grad_(True)
+            x5 = torch.as_tensor(S.normal(51, 128 * 4096).reshape(4096, 128).astype(np.float32), device=dev).T
+            f, fb = _layer_times(l5, x5, ps5, st5, 10)
+            ach = C5_FWD_FLOP[radius] / (f * 1e-3) / 1e12
+            out[f"C5_gno_128_r{radius}_layer"] = {"edges": int(s5.size), "ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
+                                                  "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
+                                                               "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
+                                                               "algorithmic_GFLOP_forward": C5_FWD_FLOP[radius] / 1e9}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5 layer measurements ('secondary')")
     ap.add_argument("--batched", type=int, default=8,
                     help="N=1 only: after the BASELINE measurement, also time this many trajectories per GPU as one batched "
                          "graph (reported under 'batched', never in 'value'); 0 = skip")
@@ -300,6 +436,11 @@ def main():
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
+    plan = None
+    if not args.no_secondary:
+        sec = secondary(dev, world, rank, dist)          # every rank takes part (N > 1: the data-parallel C4 step)
+        if out is not None:
+            out["secondary"] = sec
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -49,3 +49,81 @@ def allreduce_gradients(tree, group=None, average=False):
         g.copy_(flat[off:off + n].view_as(g))
         off += n
     return tree
+
+
+class OverlappedGradReduce:
+    """All-reduce of the flat gradient in buckets, each launched on a side stream as soon as autograd has finished the last
+    leaf of the bucket -- so that the collective of the gradients that are final EARLY in the backward pass (MPPDEConv: the
+    node update psi, whose pullback runs first) overlaps the rest of the pullback (the message MLP phi).  GNOConv's ~4 MB
+    gradient is bandwidth- rather than latency-bound on the xGMI ring, which is where the overlap pays; the 33 KB of the GCN
+    solver is one latency-bound collective either way.
+
+        flat, ps = optim.flatten_parameters(ps)
+        red = OverlappedGradReduce(flat, [("psi.", ...), ("phi.", ...)])     # name prefixes, in the order they become final
+        loss.backward(); red.finish()                                         # the current stream now sees the reduced sums
+        optim.update(st_opt, flat, reduced=True)
+
+    Without an initialised process group (or world size 1) it does nothing."""
+
+    def __init__(self, flat, ps_views, bucket_prefixes, group=None):
+        self.flat, self.group = flat, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.cuda = flat.grad.is_cuda
+        self.side = torch.cuda.Stream() if (self.active and self.cuda) else None
+        named = {}
+
+        def walk(t, prefix):
+            for k, v in t.items():
+                if isinstance(v, dict):
+                    walk(v, prefix + k + ".")
+                else:
+                    named[prefix + k] = v
+        walk(ps_views, "")
+        self.buckets = []
+        taken = set()
+        for prefixes in bucket_prefixes:
+            prefixes = (prefixes,) if isinstance(prefixes, str) else tuple(prefixes)
+            rows = [(name, off, n) for (name, off, shape) in flat.table for n in [int(torch.Size(shape).numel())]
+                    if name.startswith(prefixes) and name not in taken]
+            if not rows:
+                continue
+            taken.update(r[0] for r in rows)
+            lo, hi = min(r[1] for r in rows), max(r[1] + r[2] for r in rows)
+            if sum(r[2] for r in rows) != hi - lo:
+                raise ValueError(f"bucket {prefixes} is not a contiguous range of the flat vector")
+            self.buckets.append({"names": [r[0] for r in rows], "lo": lo, "hi": hi, "seen": 0, "work": None})
+        rest = [(name, off, int(torch.Size(shape).numel())) for (name, off, shape) in flat.table if name not in taken]
+        for name, off, n in rest:                      # leaves nobody named: one bucket each, reduced when they arrive
+            self.buckets.append({"names": [name], "lo": off, "hi": off + n, "seen": 0, "work": None})
+        self._hooks = []
+        if self.active:
+            for b in self.buckets:
+                for name in b["names"]:
+                    self._hooks.append(named[name].register_post_accumulate_grad_hook(lambda _p, b=b: self._arrived(b)))
+
+    def _launch(self, b):
+        seg = self.flat.grad[b["lo"]:b["hi"]]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())       # the gradient kernels of this bucket are enqueued
+            with torch.cuda.stream(self.side):
+                b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _arrived(self, b):
+        b["seen"] += 1
+        if b["seen"] == len(b["names"]):
+            self._launch(b)
+
+    def finish(self):
+        """reduce whatever has not been launched (leaves without a gradient this step), wait, reset"""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if b["work"] is None:
+                self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()
+            b["work"], b["seen"] = None, 0
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)

@@ -106,7 +106,7 @@ def setup(rule, flat):
     return {"rule": rule, "state": rule.init(flat)}
 
 
-def update(st_opt, flat, group=None, average=True):
+def update(st_opt, flat, group=None, average=True, reduced=False):
     """Optimisers.update(st_opt, ps, gs) on the flat vector, in place: one all-reduce(sum) of the flat gradient over the
     data-parallel group (if initialised), then ONE kernel that scales, updates the moments and the parameters.
     With more than one rank `flat.grad` is overwritten IN PLACE by the cross-rank SUM (the 1/world factor of `average` is
@@ -114,7 +114,7 @@ def update(st_opt, flat, group=None, average=True):
     sees the sum, world times the mean.  The kernel itself does not modify the buffer; call flat.zero_grad() before the
     next backward."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world > 1:
+    if world > 1 and not reduced:      # reduced=True: dist.OverlappedGradReduce has already summed flat.grad over the ranks
         dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
     with torch.no_grad():
         st_opt["state"] = st_opt["rule"].apply(st_opt["state"], flat, (1.0 / world) if average else 1.0)

@@ -104,3 +104,33 @@ def preferential_pairs_graph(n_nodes, n_pairs, seed, exponent=0.5):
         rnd += 2
     pa = np.array(chosen, dtype=np.int64)
     return np.concatenate([pa[:, 0], pa[:, 1]]), np.concatenate([pa[:, 1], pa[:, 0]])
+
+
+def periodic_mesh_batch(n, traj, reach=3):
+    """C4 graph: `traj` copies of an n-node periodic 1-D mesh, every node linked to its `reach` neighbours on each side
+    (2 * reach * n directed edges per trajectory), as one block-diagonal COO list (graph by graph)."""
+    idx = np.arange(n)
+    offs = [k for k in range(-reach, reach + 1) if k != 0]
+    s = np.concatenate([idx for _ in offs])
+    t = np.concatenate([(idx + k) % n for k in offs])
+    return (np.concatenate([s + i * n for i in range(traj)]).astype(np.int64),
+            np.concatenate([t + i * n for i in range(traj)]).astype(np.int64))
+
+
+def grid_radius_graph(k, radius):
+    """C5 graph: the k x k cell-centred grid on [0, 1]^2, every node linked to the nodes strictly within `radius` (no self
+    loops).  Returns (points (2 x k^2), s, t), edges grouped by offset."""
+    gx, gy = np.meshgrid((np.arange(k) + 0.5) / k, (np.arange(k) + 0.5) / k, indexing="ij")
+    pts = np.stack([gx.ravel(), gy.ravel()])
+    cell = int(np.ceil(radius * k)) + 1
+    ii, jj = np.divmod(np.arange(k * k), k)
+    ss, tt = [], []
+    for di in range(-cell, cell + 1):
+        for dj in range(-cell, cell + 1):
+            if di == 0 and dj == 0:
+                continue
+            ni, nj = ii + di, jj + dj
+            ok = (ni >= 0) & (ni < k) & (nj >= 0) & (nj < k) & ((di / k) ** 2 + (dj / k) ** 2 < radius ** 2)
+            ss.append((ni * k + nj)[ok])
+            tt.append(np.arange(k * k)[ok])
+    return pts, np.concatenate(ss).astype(np.int64), np.concatenate(tt).astype(np.int64)

@@ -87,3 +87,50 @@ def test_flatten_parameters_views_alias_the_flat_vector():
     assert flat.grad.tolist() == [2] * 6 + [1, 3]
     flat.data[0] = 42.0
     assert float(psv["a"]["weight"].detach()[0, 0]) == 42.0
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = {"ϕ": {"layer_1": {"weight": torch.ones(2, 3), "bias": torch.zeros(2, 1)}}, "ψ": {"layer_1": {"weight": torch.ones(4, 2)}},
+          "extra": torch.ones(2)}
+    flat, psv = ng.optim.flatten_parameters(ps)
+    red = ng.dist.OverlappedGradReduce(flat, psv, [("ψ.",), ("ϕ.",)])      # psi is final first in an MPPDE pullback
+    launched = []
+    orig = red._launch
+    red._launch = lambda b: (launched.append(tuple(b["names"])), orig(b))[1]
+    for step in range(2):                                                  # counters reset between steps
+        flat.zero_grad()
+        launched.clear()
+        loss = (psv["ψ"]["layer_1"]["weight"] * float(rank + 1)).sum()
+        loss = loss + (psv["ϕ"]["layer_1"]["weight"] * 10.0 * (rank + 1)).sum() + (psv["ϕ"]["layer_1"]["bias"] * 3.0).sum()
+        loss.backward()                                                    # "extra" gets no gradient: reduced by finish()
+        red.finish()
+        st = {"rule": _SgdRule(), "state": {}}
+        before = flat.data.clone()
+        ng.optim.update(st, flat, reduced=True)                            # no second all-reduce
+        out[(rank, step)] = (flat.grad.tolist(), sorted(launched), (before - flat.data).tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_reduce_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    # flat order: phi.weight (6), phi.bias (2), psi.weight (8), extra (2); sums over ranks 1 + 2
+    expect = [30.0] * 6 + [6.0] * 2 + [3.0] * 8 + [0.0] * 2
+    for key in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+        grad, launched, delta = out[key]
+        assert grad == expect
+        assert launched == sorted([("ψ.layer_1.weight",), ("ϕ.layer_1.weight", "ϕ.layer_1.bias"), ("extra",)])
+        assert delta == [0.5 * 0.5 * g for g in expect]                    # the mean over the two ranks, applied once
+
+
+def test_overlapped_reduce_without_process_group_is_inert():
+    flat, psv = ng.optim.flatten_parameters({"a": torch.ones(3)})
+    red = ng.dist.OverlappedGradReduce(flat, psv, [("a",)])
+    (psv["a"] * 2).sum().backward()
+    red.finish()
+    assert flat.grad.tolist() == [2.0, 2.0, 2.0]

@@ -9,11 +9,11 @@ mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batched 0 > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batched 0 --no-secondary > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 > $O/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 --no-secondary > $O/pmc_$c.log 2>&1
 done
-timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 > $O/pmc_l2.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 --no-secondary > $O/pmc_l2.log 2>&1
 cd $R
 python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_l2 $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
 # the replayed plan (NGPDE_NO_PERSISTENT=1) for comparison: bench line + kernel stats
