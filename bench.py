@@ -108,6 +108,8 @@ def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
 
 # ---- secondary workloads: one layer of BASELINE configs 3-5 (never in `value`) ---------------------------------------------
 FP32_MFMA_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense
+TIMING_NOTE = ("ms_forward / ms_forward_backward: the layer call (and its autograd pullback) captured once into a HIP graph and "
+               "replayed -- device-side time; *_eager_api: the same call issued from Python every time")
 # algorithmic figures of ONE layer forward
 C3_FWD_BYTES = 9.50e6        # GATConv on the C2 graph: compulsory traffic
 C4_FWD_FLOP = 49.0e9         # MPPDEConv shard (64 trajectories), first-layer-split form
@@ -127,17 +129,40 @@ def _time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def _graph_ms(fn, reps):
+    """ms per call of `fn` replayed from a HIP graph (torch.cuda.graph capture of the library's launches on the capture stream):
+    the device-side time of the layer, without the Python / autograd dispatch of the eager call"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        fn()
+    return _time_ms(gr.replay, reps)
+
+
 def _layer_times(layer, x, ps, st, reps):
-    """ms of one forward (no autograd) and of forward + backward (gradients w.r.t. x and every parameter) through the layer API"""
+    """ms of one forward (no autograd) and of forward + backward (gradients w.r.t. x and every parameter) through the layer
+    API: (eager forward, eager forward+backward, graph-replayed forward, graph-replayed forward+backward)"""
     x = x.detach().requires_grad_(True)
+    leaves = [x] + _grad_leaves(ps)
     with torch.no_grad():
         y0 = layer(x, ps, st)[0]
         ms_f = _time_ms(lambda: layer(x, ps, st)[0], reps)
+        ms_fg = _graph_ms(lambda: layer(x, ps, st)[0], reps)
     R = torch.randn(y0.shape[1], y0.shape[0], device=x.device).T      # cotangent in the output's (column-major) layout
 
     def fb():
+        for v in leaves:
+            v.grad = None                                              # gradients are written, not accumulated
         layer(x, ps, st)[0].backward(R)
-    return ms_f, _time_ms(fb, reps)
+    ms_fb = _time_ms(fb, reps)
+    ms_fbg = _graph_ms(fb, reps)
+    return ms_f, ms_fb, ms_fg, ms_fbg
 
 
 def _grad_leaves(ps):
@@ -177,19 +202,22 @@ def secondary(dev, world, rank, dist):
         for v in _grad_leaves(ps):
             v.requires_grad_(True)
         x = torch.as_tensor(S.normal(33, 64 * N_NODES).reshape(N_NODES, 64).astype(np.float32), device=dev).T
-        f, fb = _layer_times(layer, x, ps, st, 20)
+        fe, fbe, f, fb = _layer_times(layer, x, ps, st, 50)
         ach = C3_FWD_BYTES / (f * 1e-3) / 1e9
         out["C3_gat_4x16_layer"] = {"ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
+                                    "ms_forward_eager_api": round(fe, 4), "ms_forward_backward_eager_api": round(fbe, 4),
+                                    "timing": TIMING_NOTE,
                                     "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_MB_forward": C3_FWD_BYTES / 1e6}}
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))
     if world == 1:
-        f, fb = _layer_times(layer, x, psv, st, 10)
+        fe, fbe, f, fb = _layer_times(layer, x, psv, st, 10)
         ach = C4_FWD_FLOP / (f * 1e-3) / 1e12
         out["C4_mppde_shard_layer"] = {"trajectories": 64, "nodes": 64 * 8192, "edges": n_edges, "ms_forward": round(f, 4),
                                        "ms_forward_backward": round(fb, 4),
+                                       "ms_forward_eager_api": round(fe, 4), "ms_forward_backward_eager_api": round(fbe, 4),
                                        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
                                                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
                                                     "algorithmic_GFLOP_forward": C4_FWD_FLOP / 1e9}}
@@ -232,9 +260,10 @@ def secondary(dev, world, rank, dist):
             for v in _grad_leaves(ps5):
                 v.requires_grad_(True)
             x5 = torch.as_tensor(S.normal(51, 128 * 4096).reshape(4096, 128).astype(np.float32), device=dev).T
-            f, fb = _layer_times(l5, x5, ps5, st5, 10)
+            fe, fbe, f, fb = _layer_times(l5, x5, ps5, st5, 10)
             ach = C5_FWD_FLOP[radius] / (f * 1e-3) / 1e12
             out[f"C5_gno_128_r{radius}_layer"] = {"edges": int(s5.size), "ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
+                                                  "ms_forward_eager_api": round(fe, 4), "ms_forward_backward_eager_api": round(fbe, 4),
                                                   "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
                                                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
                                                                "algorithmic_GFLOP_forward": C5_FWD_FLOP[radius] / 1e9}}

@@ -55,8 +55,10 @@ typedef enum {
   NGPDE_ACT_SOFTPLUS = 8
 } ngpde_act_t;
 
-/* `aggr` of propagate(...) (src/layers.jl:90,303,384,496; default mean). */
-typedef enum { NGPDE_AGGR_SUM = 0, NGPDE_AGGR_MEAN = 1, NGPDE_AGGR_MAX = 2, NGPDE_AGGR_MIN = 3 } ngpde_aggr_t;
+/* `aggr` of propagate(...): +, mean, max, min, * (src/layers.jl:49,257,348,441; fields :90,303,384,496; default mean).
+ * The product of an empty neighbourhood is 1 (NNlib scatter(*) starts from the neutral element); its pullback gives every
+ * entry the product of the others.  The fused message kernel (ngpde_edge_mlp_forward) takes the first four. */
+typedef enum { NGPDE_AGGR_SUM = 0, NGPDE_AGGR_MEAN = 1, NGPDE_AGGR_MAX = 2, NGPDE_AGGR_MIN = 3, NGPDE_AGGR_MUL = 4 } ngpde_aggr_t;
 
 typedef enum { NGPDE_TABLEAU_EULER = 0, NGPDE_TABLEAU_TSIT5 = 1 } ngpde_tableau_t;
 
@@ -246,6 +248,35 @@ size_t ngpde_gat_workspace_bytes(const ngpde_graph_t *g, int32_t heads);
 int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
                            const float *a, const float *al, const float *ar, const float *alpha, const float *dout,
                            float *dwx, float *da, void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
+
+/* The whole GAT-style layer  y = act.(GAT(x) .+ b)  with W (heads*c x din), a (2c x heads), heads concatenated, in ONE launch
+ * (pullback: two launches + one reduction) when din == heads * c == 64, heads in {1, 2, 4} and the graph's tiles fit the LDS halo
+ * in both directions (ngpde_gat_layer_supported; BASELINE config 3 = 64 => 4 x 16): the logits come from the staged input rows
+ * (a_l . W x = (W^T a_l) . x), the messages are aggregated per head BEFORE the weight (sum_e alpha W x = W sum_e alpha x), so no
+ * W x array exists in memory.  Self loops are edges of g (the caller appends them, as GATConv's add_self_loops does).
+ *   save_alpha [E][heads] nullable: attention coefficients in p order, the sign bit carrying leakyrelu's branch (pullback only)
+ *   save_z     [N][64] nullable: pre-activation (the pullback of activations other than identity / relu needs it)
+ * backward: y_or_z = y for relu, z otherwise (ignored for identity); dx nullable; dweight (64 x 64) column-major, da (2c x heads),
+ * dbias [64] nullable.  workspace: ngpde_gat_layer_workspace_bytes. */
+int32_t ngpde_gat_layer_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c);
+size_t ngpde_gat_layer_workspace_bytes(const ngpde_graph_t *g, int32_t heads, int32_t c);
+int32_t ngpde_gat_layer_forward(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c, float negative_slope, int32_t act,
+                                const float *x, const float *weight, const float *a, const float *bias, float *y,
+                                float *save_alpha, float *save_z, ngpde_stream_t stream);
+int32_t ngpde_gat_layer_backward(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c, float negative_slope, int32_t act,
+                                 const float *x, const float *weight, const float *a, const float *y_or_z, const float *save_alpha,
+                                 const float *dy, float *dx, float *dweight, float *da, float *dbias, void *workspace,
+                                 size_t workspace_bytes, ngpde_stream_t stream);
+
+/* y = act.(a .+ addend .+ b): the tail of a layer whose linear part was computed elsewhere -- GNOConv's
+ * sigma(W x + m + b) (src/layers.jl:536-547) with a = aggregated messages, addend = W x; the GAT-style layer's bias + activation.
+ * a, y [n][d]; addend [n][d] nullable; bias [d] nullable; save_z nullable.  Backward: dz = dy .* act'(z) (the gradient of a AND
+ * of addend; for the identity dz may alias dy and the pass is skipped), dbias = column sums of dz (nullable; needs the workspace). */
+int32_t ngpde_bias_act_forward(int64_t n, int32_t d, int32_t act, const float *a, const float *addend, const float *bias, float *y,
+                               float *save_z, ngpde_stream_t stream);
+size_t ngpde_bias_act_workspace_bytes(int32_t d);
+int32_t ngpde_bias_act_backward(int64_t n, int32_t d, int32_t act, const float *dy, const float *z, float *dz, float *dbias,
+                                void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
 
 /* Fused message path  m_i = aggr_{e: t_e = i} phi(...)  for a message MLP whose first layer has been split into
  * node-level terms (ngpde_edge_combine_forward) and whose remaining layers are Dense, all widths <= 64 and

@@ -33,7 +33,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_DIMENSION_MISMATCH, ERR_HIP, ERR_UNSUPPORTED, ERR_
 
 ACT = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4, "gelu": 5, "leakyrelu": 6,
        "elu": 7, "softplus": 8}
-AGGR = {"+": 0, "sum": 0, "add": 0, "mean": 1, "max": 2, "min": 3}
+AGGR = {"+": 0, "sum": 0, "add": 0, "mean": 1, "max": 2, "min": 3, "*": 4, "mul": 4, "prod": 4}
 TABLEAU = {"euler": 0, "tsit5": 1}
 
 _vp, _i32, _i64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
@@ -78,6 +78,13 @@ SIGNATURES = {
     "ngpde_gat_forward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gat_workspace_bytes": (_sz, [_vp, _i32]),
     "ngpde_gat_backward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_gat_layer_supported": (_i32, [_vp, _i32, _i32, _i32]),
+    "ngpde_gat_layer_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "ngpde_gat_layer_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gat_layer_backward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_bias_act_forward": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_bias_act_workspace_bytes": (_sz, [_i32]),
+    "ngpde_bias_act_backward": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_edge_mlp_supported": (_i32, [_vp, _i32, _i32, _vp]),
     "ngpde_edge_mlp_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ngpde_edge_mlp_backward_supported": (_i32, [_vp, _i32, _i32, _vp, _i32]),

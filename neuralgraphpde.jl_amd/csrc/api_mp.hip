@@ -137,7 +137,7 @@ int32_t ngpde_edge_combine_backward(const ngpde_graph_t *g, int32_t h, int32_t a
 int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, float *out,
                                      ngpde_stream_t stream) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_forward: graph is NULL");
-  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_segment_reduce_forward: unknown aggregation %d", aggr);
   if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
   NGPDE_REQUIRE(out && (m || g->n_edges == 0), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_forward: NULL argument");
@@ -147,7 +147,7 @@ int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t 
 int32_t ngpde_segment_reduce_backward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, const float *out,
                                       const float *dout, float *dm, ngpde_stream_t stream) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_backward: graph is NULL");
-  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_segment_reduce_backward: unknown aggregation %d", aggr);
   if (g->n_edges == 0 || d == 0) return NGPDE_OK;
   NGPDE_REQUIRE(dout && dm, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_backward: NULL argument");
@@ -235,6 +235,75 @@ int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, flo
   float *dar = (float *)((char *)dal + align256((size_t)g->n_nodes * heads * 4));
   return launch_gat_bwd(g, heads, c, negative_slope, wx, a, al, ar, alpha, dout, dscore, dal, dar, dwx, da,
                         (hipStream_t)stream_);
+}
+
+int32_t ngpde_gat_layer_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c) {
+  return gat_layer_fused_supported(g, din, heads, c) ? 1 : 0;
+}
+
+size_t ngpde_gat_layer_workspace_bytes(const ngpde_graph_t *g, int32_t heads, int32_t c) {
+  (void)c;
+  return g ? gat_layer_workspace_bytes(g, heads) : 0;
+}
+
+int32_t ngpde_gat_layer_forward(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c, float negative_slope, int32_t act,
+                                const float *x, const float *weight, const float *a, const float *bias, float *y,
+                                float *save_alpha, float *save_z, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_forward: graph is NULL");
+  int32_t st = check_act("ngpde_gat_layer_forward", act);
+  if (st) return st;
+  NGPDE_REQUIRE(gat_layer_fused_supported(g, din, heads, c), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_gat_layer_forward: needs din == heads * c == 64, heads in {1, 2, 4} and a graph whose tiles fit the LDS "
+                "halo in both directions (got din = %d, heads = %d, c = %d); compose ngpde_dense_forward + ngpde_gat_forward", din, heads, c);
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(x && weight && a && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_forward: NULL argument");
+  return launch_gat_layer_fwd(g, heads, negative_slope, act, x, weight, a, bias, y, save_alpha, save_z, (hipStream_t)stream);
+}
+
+int32_t ngpde_gat_layer_backward(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c, float negative_slope, int32_t act,
+                                 const float *x, const float *weight, const float *a, const float *y_or_z, const float *save_alpha,
+                                 const float *dy, float *dx, float *dweight, float *da, float *dbias, void *workspace,
+                                 size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_backward: graph is NULL");
+  int32_t st = check_act("ngpde_gat_layer_backward", act);
+  if (st) return st;
+  NGPDE_REQUIRE(gat_layer_fused_supported(g, din, heads, c), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_gat_layer_backward: unsupported shape / graph (din = %d, heads = %d, c = %d)", din, heads, c);
+  NGPDE_REQUIRE(weight && a && dweight && da && (g->n_nodes == 0 || (x && dy && (save_alpha || g->n_edges == 0))) &&
+                    (act == NGPDE_ACT_IDENTITY || y_or_z || g->n_nodes == 0),
+                NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_backward: NULL argument");
+  return launch_gat_layer_bwd(g, heads, negative_slope, act, x, weight, a, y_or_z, save_alpha, dy, dx, dweight, da, dbias, workspace,
+                              workspace_bytes, (hipStream_t)stream);
+}
+
+int32_t ngpde_bias_act_forward(int64_t n, int32_t d, int32_t act, const float *a, const float *addend, const float *bias, float *y,
+                               float *save_z, ngpde_stream_t stream) {
+  int32_t st = check_act("ngpde_bias_act_forward", act);
+  if (st) return st;
+  NGPDE_REQUIRE(n >= 0 && d >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_bias_act_forward: negative size");
+  if (n == 0 || d == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(a && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_bias_act_forward: NULL argument");
+  return launch_bias_act2(n, d, act, a, addend, bias, y, save_z, (hipStream_t)stream);
+}
+
+size_t ngpde_bias_act_workspace_bytes(int32_t d) { return (size_t)kColsumChunks * (size_t)std::max(d, 1) * sizeof(float); }
+
+int32_t ngpde_bias_act_backward(int64_t n, int32_t d, int32_t act, const float *dy, const float *z, float *dz, float *dbias,
+                                void *workspace, size_t workspace_bytes, ngpde_stream_t stream) {
+  int32_t st = check_act("ngpde_bias_act_backward", act);
+  if (st) return st;
+  NGPDE_REQUIRE(n >= 0 && d >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_bias_act_backward: negative size");
+  if (d == 0) return NGPDE_OK;
+  NGPDE_REQUIRE((n == 0 || (dy && dz)) && (act == NGPDE_ACT_IDENTITY || z || n == 0), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_bias_act_backward: NULL argument");
+  NGPDE_REQUIRE(!dbias || (workspace && workspace_bytes >= ngpde_bias_act_workspace_bytes(d)), NGPDE_ERR_WORKSPACE,
+                "ngpde_bias_act_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, ngpde_bias_act_workspace_bytes(d));
+  if (n > 0 && !(act == NGPDE_ACT_IDENTITY && dz == dy)) {   // identity with dz aliasing dy: nothing to compute
+    st = launch_dense_dz(n * d, act, dy, z ? z : dy, dz, (hipStream_t)stream);   // identity: act' = 1 whatever z is
+    if (st) return st;
+  }
+  if (dbias) return launch_colsum2(n, d, dz, static_cast<float *>(workspace), dbias, (hipStream_t)stream);
+  return NGPDE_OK;
 }
 
 int32_t ngpde_edge_mlp_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout) {

@@ -270,6 +270,19 @@ int32_t launch_gat_bwd(const ngpde_graph *g, int heads, int c, float slope, cons
                        const float *ar, const float *alpha, const float *dout, float *dscore, float *dal, float *dar,
                        float *dwx, float *da, hipStream_t stream);
 int32_t launch_spectral_weights(int64_t n_edges, float nn, const float *e, float *w, hipStream_t stream);
+// ---- the whole GAT-style layer (gat_fused.hip)
+bool gat_layer_fused_supported(const ngpde_graph *g, int din, int heads, int c);
+size_t gat_layer_workspace_bytes(const ngpde_graph *g, int heads);
+int32_t launch_gat_layer_fwd(const ngpde_graph *g, int heads, float slope, int act, const float *x, const float *wt, const float *a,
+                             const float *bias, float *y, float *alpha, float *save_z, hipStream_t stream);
+int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int act, const float *x, const float *wt, const float *a,
+                             const float *yz, const float *alpha, const float *dy, float *dx, float *dwt, float *da, float *db,
+                             void *workspace, size_t workspace_bytes, hipStream_t stream);
+constexpr int kColsumChunks = 128;
+int32_t launch_colsum2(int64_t n, int d, const float *a, float *partial, float *out, hipStream_t stream);
+// y = act(a + addend + bias) (addend, bias nullable), 16-byte accesses when d % 4 == 0
+int32_t launch_bias_act2(int64_t n, int d, int act, const float *a, const float *addend, const float *bias, float *y, float *save_z,
+                         hipStream_t stream);
 
 // ---- fused edge-MLP forward (edge_mlp_fused.hip) ----------------------------------------------------------
 struct EdgeMlpArgs {

@@ -152,7 +152,68 @@ __global__ void bias_act_kernel(int64_t n, int d, int act, const float *__restri
   }
 }
 
+// y = act(a + addend + b), 16 bytes per thread (d % 4 == 0), optional pre-activation copy
+__global__ void bias_act4_kernel(int64_t count4, int d4, int act, const float4 *__restrict__ a, const float4 *__restrict__ addend,
+                                 const float4 *__restrict__ bias, float4 *__restrict__ y, float4 *__restrict__ save_z) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 z = a[i];
+    if (addend) z = f4_add(z, addend[i]);
+    if (bias) z = f4_add(z, bias[i % d4]);
+    if (save_z) save_z[i] = z;
+    y[i] = f4_act(act, z);
+  }
+}
+__global__ void bias_act1_kernel(int64_t count, int d, int act, const float *__restrict__ a, const float *__restrict__ addend,
+                                 const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ save_z) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const float z = a[i] + (addend ? addend[i] : 0.f) + (bias ? bias[i % d] : 0.f);
+    if (save_z) save_z[i] = z;
+    y[i] = act_apply(act, z);
+  }
+}
+
+// partial[chunk][o] = sum over the rows r = chunk, chunk + nchunk, ... of a[r][o]  (first stage of a column sum over many rows)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, int d, int nchunk, const float *__restrict__ a,
+                                                             float *__restrict__ partial) {
+  __shared__ float part[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pid = threadIdx.x >> 6, chunk = blockIdx.y;
+  float s = 0.f;
+  if (o < d)
+    for (int64_t r = chunk + (int64_t)pid * nchunk; r < n; r += 4 * (int64_t)nchunk) s += a[r * d + o];
+  part[pid][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pid == 0 && o < d)
+    partial[(size_t)chunk * d + o] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 }  // namespace
+
+int32_t launch_bias_act2(int64_t n, int d, int act, const float *a, const float *addend, const float *bias, float *y, float *save_z,
+                         hipStream_t stream) {
+  if (n * d == 0) return NGPDE_OK;
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (d % 4 == 0 && al16(a) && al16(addend) && al16(bias) && al16(y) && al16(save_z)) {
+    const int64_t c4 = n * d / 4;
+    hipLaunchKernelGGL(bias_act4_kernel, dim3((unsigned)std::min<int64_t>((c4 + 255) / 256, 4096)), dim3(256), 0, stream, c4, d / 4,
+                       act, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(addend),
+                       reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(y), reinterpret_cast<float4 *>(save_z));
+  } else {
+    hipLaunchKernelGGL(bias_act1_kernel, dim3((unsigned)std::min<int64_t>((n * d + 255) / 256, 4096)), dim3(256), 0, stream, n * d, d,
+                       act, a, addend, bias, y, save_z);
+  }
+  NGPDE_LAUNCH_CHECK("bias_act kernel");
+  return NGPDE_OK;
+}
+
+// column sums of a [n][d] array in two deterministic stages through `partial` ([kColsumChunks][d] floats)
+int32_t launch_colsum2(int64_t n, int d, const float *a, float *partial, float *out, hipStream_t stream) {
+  if (d == 0) return NGPDE_OK;
+  if (n <= 4 * kColsumChunks || partial == nullptr) return launch_colsum(n, d, a, out, stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((d + 63) / 64, kColsumChunks), dim3(256), 0, stream, n, d, kColsumChunks, a, partial);
+  NGPDE_LAUNCH_CHECK("colsum_partial_kernel");
+  return launch_colsum(kColsumChunks, d, partial, out, stream);
+}
 
 int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr, const float *x,
                             const float *edge_weight, float *out, hipStream_t stream) {

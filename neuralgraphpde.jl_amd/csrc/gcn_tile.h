@@ -59,6 +59,95 @@ __device__ __forceinline__ float4 load_stream4(const float4 *p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Row fetch with a scalar base and a 32-bit byte offset (saddr + voffset addressing: one VGPR per
+// in-flight load instead of a 64-bit pointer pair).  Callers guarantee n_nodes * D * 4 < 2^32.
+template <int LPR>
+__device__ __forceinline__ float4 load_row4(const float4 *__restrict__ X4, int row, int q) {
+  const unsigned off = (unsigned)row * (unsigned)(LPR * 16) + (unsigned)(q * 16);
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X4) + off);
+}
+
+// ---- LDS-staged aggregation ---------------------------------------------------------------------------------
+// The gather above moves ~280 KB per CU per launch through the L1/TA port (16 row slots x 64 rows x 256 B),
+// although a 32-row cluster tile references only ~57 distinct rows.  Here the workgroup stages those rows
+// once (3 x 16-byte loads per lane instead of 16), pre-scaled by c[node], and every row then sums its
+// neighbours out of LDS.  The chain stays flat: halo list, slot bytes and schedule entries are all
+// position-indexed (round 1), the halo rows are round 2.  Each lane reads its row's 16 slot bytes itself (a
+// 16-byte broadcast load), so no lane shuffles; unused slots name the all-zero row, so no masking.
+template <int D>
+struct HaloRegs {
+  int2 he[Geo<D>::HI];
+  uint4 sl[Geo<D>::R][2];
+  float4 sw[Geo<D>::R][8];
+  float4 hv[Geo<D>::HI];
+};
+
+// round 1: position-indexed halo entries and slot bytes (padded lists: no count, nothing to wait for first)
+template <int D>
+__device__ __forceinline__ void halo_round1(const int2 *__restrict__ halo, const uint4 *__restrict__ slots16,
+                                            const float4 *__restrict__ slot_w4, int tile, int grp, bool active,
+                                            HaloRegs<D> &h) {
+  using G = Geo<D>;
+  // unconditional loads from clamped positions (a `cond ? load : 0` becomes an exec-masked branch with its
+  // own full wait); inactive groups / padding slots are neutralised later
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) {
+    const int hh = min(grp + k * G::GROUPS, kHaloCap - 1);
+    h.he[k] = halo[(size_t)tile * kHaloCap + hh];
+  }
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const size_t pos = (size_t)tile * kTM + min(grp * G::R + r, kTM - 1);
+    h.sl[r][0] = slots16[pos * 2];
+    h.sl[r][1] = slots16[pos * 2 + 1];
+    if (slot_w4) {   // uniform
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h.sw[r][j] = slot_w4[pos * 8 + j];
+    }
+  }
+}
+
+// schedule entries of this thread's rows, same rule: load always, neutralise afterwards
+template <int D>
+__device__ __forceinline__ void load_sched(const int4 *__restrict__ sched, int tile, int grp, bool active,
+                                           int4 (&sc)[Geo<D>::R]) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int r = 0; r < G::R; ++r) {
+    const int4 v = sched[(size_t)tile * kTM + min(grp * G::R + r, kTM - 1)];
+    sc[r].x = active ? v.x : -1;
+    sc[r].y = active ? v.y : 0;
+    sc[r].z = active ? v.z : 0;
+    sc[r].w = active ? v.w : 0;
+  }
+}
+
+// round 2: the tile's distinct rows.  Issue this BEFORE any other load of the kernel that is consumed later:
+// vmcnt retires in order, so an older, slower load (HBM tape) would otherwise sit in front of these.
+//
+// DMA: the rows go memory -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane; a wave's
+// 64 / LPR groups stage consecutive halo slots, so its 1 KiB lands contiguously at Xh4[hh * LPR + q]).  No VGPR round trip
+// and no ds_write_b128 (13 cycles per wave-instruction on the store path: two workgroups' 25 KB cost ~650 cycles there).
+// Only for rows that need no scaling on the way in (PRE: the producer stored them already multiplied by c[node]).
+template <int D, bool DMA>
+__device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q, int grp, float *ldsXh, HaloRegs<D> &h) {
+  using G = Geo<D>;
+#pragma unroll
+  for (int k = 0; k < G::HI; ++k) {
+    if constexpr (DMA) {
+      const int hh = grp + k * G::GROUPS;
+      if (hh < kHaloCap) {   // wave-uniform: kHaloCap is a multiple of the groups per wave
+        const unsigned off = (unsigned)h.he[k].x * (unsigned)(G::LPR * 16) + (unsigned)(q * 16);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X4) + off),
+            (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsXh) + hh * G::LPR + q), 16, 0, 0);
+      }
+    } else {
+      h.hv[k] = load_row4<G::LPR>(X4, h.he[k].x, q);
+    }
+  }
+}
+
 // ---- fp32 MFMA tile products from LDS ------------------------------------------------------------------
 // Out[kTM][D] = A[kTM][D] x B, with A row-major (stride TS) and B stored TRANSPOSED, Bt[col][k] (stride
 // TS), so lane (i = l&15, kq = l>>4) feeds four consecutive k-steps of v_mfma_f32_16x16x4_f32 from ONE

@@ -123,11 +123,13 @@ __global__ __launch_bounds__(256) void segment_reduce_fwd_kernel(int n_nodes, in
     float acc;
     if (aggr == NGPDE_AGGR_MAX) acc = -INFINITY;
     else if (aggr == NGPDE_AGGR_MIN) acc = INFINITY;
+    else if (aggr == NGPDE_AGGR_MUL) acc = 1.f;     // scatter(*) starts from the neutral element: an empty neighbourhood gives 1
     else acc = 0.f;
     for (int p = rs; p < re; ++p) {
       const float v = M[(size_t)p * d + f];
       if (aggr == NGPDE_AGGR_MAX) acc = fmaxf(acc, v);
       else if (aggr == NGPDE_AGGR_MIN) acc = fminf(acc, v);
+      else if (aggr == NGPDE_AGGR_MUL) acc *= v;
       else acc += v;
     }
     if (aggr == NGPDE_AGGR_MEAN) acc = (re > rs) ? acc / (float)(re - rs) : 0.f;   // mean of an empty neighbourhood is 0
@@ -149,6 +151,11 @@ __global__ __launch_bounds__(256) void segment_reduce_bwd_kernel(int n_nodes, in
     for (int p = rs; p < re; ++p) {
       float v = g * scale;
       if (aggr == NGPDE_AGGR_MAX || aggr == NGPDE_AGGR_MIN) v = (M[(size_t)p * d + f] == ext) ? g : 0.f;  // NNlib: every extremal entry
+      if (aggr == NGPDE_AGGR_MUL) {   // d(prod)/dM[p] = product of the row's other entries (NNlib: dout .* out ./ M, without the division)
+        float others = 1.f;
+        for (int p2 = rs; p2 < re; ++p2) others *= (p2 == p) ? 1.f : M[(size_t)p2 * d + f];
+        v = g * others;
+      }
       dM[(size_t)p * d + f] = v;
     }
   }

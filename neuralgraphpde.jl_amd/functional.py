@@ -353,6 +353,93 @@ def gat_aggregate(wx, a, handle, heads, c, slope, n_edges):
     return _GatFn.apply(wx, a, handle, heads, c, float(slope), n_edges)
 
 
+class _GatLayerFn(torch.autograd.Function):
+    """The whole GAT-style layer in one launch (ngpde_gat_layer_forward), pullback in two launches + one reduction."""
+
+    @staticmethod
+    def forward(ctx, x, wt, a, bias, handle, heads, c, slope, act, n_edges):
+        lib = _lib.load()
+        _need_cuda(x, wt, a, bias)
+        x, wt, a = x.contiguous(), wt.contiguous(), a.contiguous()
+        n, dev = x.shape[0], x.device
+        need = any(ctx.needs_input_grad)
+        y = torch.empty((n, heads * c), dtype=torch.float32, device=dev)
+        alpha = torch.empty((max(n_edges, 1), heads), dtype=torch.float32, device=dev) if need else None
+        z = torch.empty_like(y) if (need and act not in (0, 1)) else None       # identity / relu: y is enough
+        _lib.check(lib.ngpde_gat_layer_forward(handle.ptr, x.shape[1], heads, c, slope, act, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(a),
+                                               _lib.ptr(bias), _lib.ptr(y), _lib.ptr(alpha), _lib.ptr(z), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (heads, c, slope, act, bias is not None)
+        ctx.save_for_backward(x, wt, a, alpha, z if z is not None else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, wt, a, alpha, yz = ctx.saved_tensors
+        heads, c, slope, act, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dwt, da = torch.empty_like(wt), torch.empty_like(a)
+        db = torch.empty((heads * c,), dtype=torch.float32, device=dev) if has_bias else None
+        ws = _ws(lib.ngpde_gat_layer_workspace_bytes(ctx.handle.ptr, heads, c), dev)
+        _lib.check(lib.ngpde_gat_layer_backward(ctx.handle.ptr, x.shape[1], heads, c, slope, act, _lib.ptr(x), _lib.ptr(wt),
+                                                _lib.ptr(a), _lib.ptr(yz), _lib.ptr(alpha), _lib.ptr(dy), _lib.ptr(dx),
+                                                _lib.ptr(dwt), _lib.ptr(da), _lib.ptr(db), _lib.ptr(ws), ws.numel(),
+                                                _lib.current_stream()))
+        return dx, dwt, da, db, None, None, None, None, None, None
+
+
+def gat_layer_supported(handle, din, heads, c):
+    return bool(_lib.load().ngpde_gat_layer_supported(handle.ptr, int(din), int(heads), int(c)))
+
+
+def gat_layer(x, wt, a, bias, handle, heads, c, slope, act, n_edges):
+    """x [N][64], wt [64][heads*c], a (2c x heads) column-major as [heads][2c], bias [heads*c] or None -> y [N][heads*c]"""
+    return _GatLayerFn.apply(x, wt, a, bias, handle, int(heads), int(c), float(slope), int(act), int(n_edges))
+
+
+class _BiasActFn(torch.autograd.Function):
+    """y = act(a + addend + b) (ngpde_bias_act_forward): the tail of a layer whose linear part was computed elsewhere."""
+
+    @staticmethod
+    def forward(ctx, a, addend, bias, act):
+        lib = _lib.load()
+        _need_cuda(a, addend, bias)
+        a = a.contiguous()
+        addend = None if addend is None else addend.contiguous()
+        n, d = a.shape
+        need = any(ctx.needs_input_grad)
+        y = torch.empty_like(a)
+        z = torch.empty_like(a) if (need and act not in (0, 1)) else None
+        _lib.check(lib.ngpde_bias_act_forward(n, d, act, _lib.ptr(a), _lib.ptr(addend), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
+                                              _lib.current_stream()))
+        ctx.meta = (act, addend is not None, bias is not None)
+        ctx.save_for_backward(z if z is not None else (y if act == 1 else None))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (yz,) = ctx.saved_tensors
+        act, has_add, has_bias = ctx.meta
+        dy = dy.contiguous()
+        n, d = dy.shape
+        if act == 0 and not has_bias:
+            return dy, (dy if has_add else None), None, None
+        dz = torch.empty_like(dy) if act != 0 else dy
+        db = torch.empty((d,), dtype=torch.float32, device=dy.device) if has_bias else None
+        ws = _ws(lib.ngpde_bias_act_workspace_bytes(d), dy.device) if has_bias else None
+        # identity: dz aliases dy, the library skips the element-wise pass and only sums the columns
+        _lib.check(lib.ngpde_bias_act_backward(n, d, act, _lib.ptr(dy), _lib.ptr(yz), _lib.ptr(dz), _lib.ptr(db), _lib.ptr(ws),
+                                               ws.numel() if ws is not None else 0, _lib.current_stream()))
+        return dz, (dz if has_add else None), db, None
+
+
+def bias_act(a, addend, bias, act):
+    return _BiasActFn.apply(a, addend, bias, int(act))
+
+
 class _PropagateFn(torch.autograd.Function):
     """propagate(e_mul_xj / copy_xj, g, +) with its pullback (the transposed aggregation)."""
 

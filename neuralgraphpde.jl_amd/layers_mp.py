@@ -56,7 +56,7 @@ def _message_path(g, P, Q, Et, stack, aggr):
     needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
     aggr_code = _lib.AGGR[aggr]
-    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or not needs_grad):
+    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or (aggr_code in (2, 3) and not needs_grad)):
         fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
         if F.edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
             return F.edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)
@@ -297,8 +297,7 @@ class GNOConv(AbstractGNNContainerLayer):
             m = F.gno_contract(K, h, handle, self.in_chs, self.out_chs)            # :527-530
         agg = F.segment_reduce(m, handle, self.aggr, N)                            # :534
         lwt, lb = _wt_b(ps["linear"])
-        eye = torch.eye(self.out_chs, dtype=torch.float32, device=dev)
-        y = F.dense([h, agg], torch.cat([lwt, eye], dim=0), lb, self.linear.act)   # σ(W x + m + b)  (:536-547)
+        y = F.bias_act(agg, F.dense([h], lwt, None, 0), lb, self.linear.act)       # σ(W x + m + b)  (:536-547)
         return y.T, st
 
 
@@ -381,16 +380,20 @@ class GATConv(AbstractGNNLayer):
         gs = self._graph(g)
         handle = gs.handle()
         c, h = self.out_chs, self.heads
+        b = ps["bias"].reshape(-1) if "bias" in ps else None
+        if self.concat and F.gat_layer_supported(handle, xr.shape[1], h, c):
+            # 64 => heads x c = 64 on a graph whose tiles fit the LDS halo (BASELINE config 3): the whole layer is one launch
+            y = F.gat_layer(xr, rows_of(ps["weight"]), rows_of(ps["a"]), b, handle, h, c, self.negative_slope, self.act,
+                            gs.num_edges)
+            return y.T, st
         wx = F.dense([xr], rows_of(ps["weight"]), None, 0)                          # Wx = reshape(W x, c, heads, N)
         out = F.gat_aggregate(wx, rows_of(ps["a"]), handle, h, c, self.negative_slope, gs.num_edges)
-        b = ps["bias"].reshape(-1) if "bias" in ps else None
-        dev = xr.device
-        mix = self._mix.get(str(dev))                                               # built once per device
-        if mix is None:
-            if self.concat:
-                mix = torch.eye(c * h, dtype=torch.float32, device=dev)
-            else:                                                                   # mean over heads
-                mix = torch.eye(c, dtype=torch.float32, device=dev).repeat(h, 1) / h
-            self._mix[str(dev)] = mix
-        y = F.dense([out], mix, b, self.act)
+        if self.concat:
+            y = F.bias_act(out, None, b, self.act)
+        else:                                                                       # mean over heads: a genuine linear map
+            dev = xr.device
+            mix = self._mix.get(str(dev))                                           # built once per device
+            if mix is None:
+                mix = self._mix[str(dev)] = torch.eye(c, dtype=torch.float32, device=dev).repeat(h, 1) / h
+            y = F.dense([out], mix, b, self.act)
         return y.T, st

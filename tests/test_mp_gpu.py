@@ -203,6 +203,28 @@ def test_edgeconv_parity_and_grads(aggr):
     check_grads(ps, (names, ogr), x, gr["x"])
 
 
+def test_edgeconv_product_aggregation():
+    # aggr = * is one of the five the reference documents (src/layers.jl:49,257,348,441): a node without incoming edges gets
+    # the neutral element 1, the pullback gives every message the product of the row's other messages
+    N, E, h = 300, 700, 5
+    rng = np.random.default_rng(11)
+    g, og = rgraph(N, E, 11, ndata={"x": rng.random((2, N))})
+    assert (np.bincount(og.t, minlength=N) == 0).any()
+    phi = ng.Chain(ng.Dense(2 * h + 2, 12, "tanh"), ng.Dense(12, 7, "tanh"))
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr="*")
+    ps, st = ng.setup(5, l)
+    ps = prep(ps, 5)
+    x = torch.randn(h, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, "*")
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    check_grads(ps, (names, ogr), x, gr["x"])
+
+
 # ---- VMHConv ---------------------------------------------------------------------------------------------------------------
 
 def test_vmh_reference_fixture_and_parity():
@@ -486,6 +508,71 @@ def test_gat_fused_halo_forward_and_grads(heads, monkeypatch):
     with torch.no_grad():
         y2, _ = l(x, ps, st)
     close(y2, y.detach().cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def _local_graph(n, seed, max_deg=10, reach=6):
+    rng = np.random.default_rng(seed)
+    ss, tt = [], []
+    for i in range(n):
+        for off in rng.choice(np.arange(-reach, reach + 1), size=rng.integers(0, max_deg + 1), replace=False):
+            if off != 0:
+                ss.append((i + off) % n); tt.append(i)
+    return np.array(ss), np.array(tt)
+
+
+@pytest.mark.parametrize("heads,act,bias,loops", [(4, "relu", True, True), (4, "tanh", True, True), (4, "identity", False, True),
+                                                  (2, "relu", True, False), (1, "swish", True, True), (2, "identity", True, True)])
+def test_gat_layer_one_launch_forward_and_pullback(heads, act, bias, loops, monkeypatch):
+    # 64 => heads x c = 64 on a graph whose tiles fit the LDS halo: the WHOLE layer is ngpde_gat_layer_forward (logits from
+    # the staged input rows, per-head aggregation before the weight) and its two-launch pullback; values and all gradients
+    # against the oracle, and agreement with the composed path (Dense + softmax aggregation + bias/activation kernels).
+    # loops=False leaves nodes without incoming edges (empty softmax: the row is act(b)).
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    n, C = 333, 64 // heads
+    rng = np.random.default_rng(60 + heads)
+    s, t = _local_graph(n, 60 + heads)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    og = O.Graph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, C), act, heads=heads, concat=True, add_self_loops=loops, bias=bias, initialgraph=g)
+    ps, st = ng.setup(61, l)
+    ps = prep(ps, 61)
+    from ngpde_amd import functional as F
+    assert F.gat_layer_supported(l._graph(g).handle(), 64, heads, C)
+    x = torch.randn(64, n, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    pw = lambda k: ps[k].detach().cpu().double().numpy() if k in ps else None
+    yo, c = O.gat_conv(x.detach().cpu().double().numpy(), pw("weight"), pw("a"), pw("bias"), og, heads, C, act, concat=True,
+                       add_self_loops_=loops)
+    close(y, yo)
+    R = rng.normal(size=yo.shape)
+    Rt = torch.as_tensor(R, dtype=torch.float32, device=DEV)
+    (y * Rt).sum().backward()
+    gr = O.gat_conv_backward(c, R)
+    close(x.grad, gr["x"], rtol=5e-4, atol=1e-4, what="dx")
+    keys = ("weight", "a", "bias") if bias else ("weight", "a")
+    for k in keys:
+        close(ps[k].grad, np.asarray(gr[k]).reshape(tuple(ps[k].shape)), rtol=5e-4, atol=2e-4, what=k)
+    fused = {k: ps[k].grad.clone() for k in keys}
+    fused_dx, fused_y = x.grad.clone(), y.detach().clone()
+    # bitwise reproducible (no atomics): a second evaluation gives identical bits
+    x.grad = None
+    for k in keys:
+        ps[k].grad = None
+    y1, _ = l(x, ps, st)
+    (y1 * Rt).sum().backward()
+    assert torch.equal(y1.detach(), fused_y) and torch.equal(x.grad, fused_dx)
+    assert all(torch.equal(ps[k].grad, fused[k]) for k in keys)
+    # the composed path agrees to rounding
+    monkeypatch.setenv("NGPDE_NO_FUSED_GAT_LAYER", "1")
+    x.grad = None
+    for k in keys:
+        ps[k].grad = None
+    y2, _ = l(x, ps, st)
+    (y2 * Rt).sum().backward()
+    close(y2, fused_y.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    close(x.grad, fused_dx.cpu().double().numpy(), rtol=1e-4, atol=2e-5)
+    for k in keys:
+        close(ps[k].grad, fused[k].cpu().double().numpy(), rtol=1e-4, atol=5e-5, what=k)
 
 
 def test_gat_as_ode_right_hand_side_generic_solver_path():

@@ -168,7 +168,7 @@ def test_gcn_backward_fd(dims, weighted):
     fd_check(lambda bb: (O.gcn_conv(X, W, bb, g, "swish", edge_weight=ew)[0] * R).sum(), b, gr["bias"])
 
 
-@pytest.mark.parametrize("aggr", ["mean", "+", "max"])
+@pytest.mark.parametrize("aggr", ["mean", "+", "max", "*"])
 def test_mppde_backward_fd(aggr):
     N, E, G = 8, 24, 2
     base = rand_graph(4, 12, ndata={"u": RNG.random((2, 4)), "x": RNG.random((1, 4))},
