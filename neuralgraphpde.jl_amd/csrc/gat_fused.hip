@@ -117,7 +117,7 @@ template <int H>
 __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwdK p) {
   constexpr int C = GD / H;
   // the halo region first: an LDS-DMA destination is a 16-bit offset
-  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];     // staged input rows; later W^T
+  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];     // staged input rows
   __shared__ __attribute__((aligned(16))) float ldsS[kTM * kSlotWidth * 4];      // alpha per (row, entry, head); later the output tile
   __shared__ __attribute__((aligned(16))) float ldsA[kTM * kATS];                // per-head aggregates
   __shared__ __attribute__((aligned(16))) float ldsAr[(kHaloCap + 1) * 4];
@@ -130,27 +130,35 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 
   TileMeta m;
   tile_meta(p.halo, p.slots, p.sched, p.x, tile, grp, q, ldsXh, m);
-  // v_which,k[i] = sum_c a[which*C + c][k] W[k*C + c][i]   (thread: which = tid >> 8, head, input feature i)
+  // v_which,k[i] = sum_c a[which*C + c][k] W[k*C + c][i]: the workgroup reads W once, coalesced (thread: input feature i =
+  // tid >> 3, eight consecutive output columns), and the C / 8 adjacent lanes of one (i, head) add their partial dots
   {
-    const int which = tid >> 8, hk = (tid >> 6) & 3, i = tid & 63;
-    float v = 0.f;
-    if (hk < H) {
-      const float4 *w4 = reinterpret_cast<const float4 *>(p.wt + (size_t)i * GD + hk * C);
-      const float4 *a4 = reinterpret_cast<const float4 *>(p.a + (size_t)hk * 2 * C + which * C);
-#pragma unroll 4
-      for (int cc = 0; cc < C / 4; ++cc) v += dot4(w4[cc], a4[cc]);
-    }
-    ldsV[tid] = v;
-  }
-  // W: B[k = in][j = out] = wt[in][out], kept transposed for the product (4 dword loads down a column -> one ds_write_b128)
-  float4 wreg[GG::NPASS];
-  {
-    const int j = tid % GD, kg0 = tid / GD;
+    const int i = tid >> 3, part = tid & 7;
+    const int hk = (part * 8) / C, c0 = (part * 8) % C;
+    const float4 *w4 = reinterpret_cast<const float4 *>(p.wt + (size_t)i * GD + part * 8);
+    const float4 *l4 = reinterpret_cast<const float4 *>(p.a + (size_t)hk * 2 * C + c0);
+    const float4 *r4 = reinterpret_cast<const float4 *>(p.a + (size_t)hk * 2 * C + C + c0);
+    const float4 w0 = w4[0], w1 = w4[1];
+    float pl = dot4(w0, l4[0]) + dot4(w1, l4[1]), pr = dot4(w0, r4[0]) + dot4(w1, r4[1]);
 #pragma unroll
-    for (int ps = 0; ps < GG::NPASS; ++ps) {
-      const float *w = p.wt + (size_t)(4 * (kg0 + ps * GG::KGP)) * GD + j;
-      wreg[ps] = make_float4(w[0], w[GD], w[2 * GD], w[3 * GD]);
+    for (int o = 1; o < C / 8; o <<= 1) {
+      pl += __shfl_xor(pl, o);
+      pr += __shfl_xor(pr, o);
     }
+    if (part % (C / 8) == 0) {
+      ldsV[hk * GD + i] = pl;
+      ldsV[4 * GD + hk * GD + i] = pr;
+    }
+  }
+  // B operand of this wave's output tile straight from memory (W is 16 KB, cache resident): lane (i, kq) of column tile ct
+  // needs wt[16 kb + 4 kq + r][ct * 16 + i] -- 16 dwords, in flight from the start; no W^T copy in LDS
+  float breg[4][4];
+  {
+    const int ct = wave_u >> 1, i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) breg[kb][r] = p.wt[(size_t)(16 * kb + 4 * kq + r) * GD + ct * 16 + i];
   }
   const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
   if (grp == 0) {
@@ -257,19 +265,22 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 #pragma unroll
     for (int k = 0; k < H; ++k) *reinterpret_cast<float4 *>(&ldsA[grp * kATS + k * GD + 4 * q]) = acc[k];
   }
-  __syncthreads();   // aggregates complete; staged rows and coefficients dead
-  float *ldsBt = ldsXh, *ldsZ = ldsS;
-  {
-    const int j = tid % GD, kg0 = tid / GD;
-#pragma unroll
-    for (int ps = 0; ps < GG::NPASS; ++ps) *reinterpret_cast<float4 *>(&ldsBt[j * GG::TS + 4 * (kg0 + ps * GG::KGP)]) = wreg[ps];
-  }
-  __syncthreads();
+  __syncthreads();   // aggregates complete; the coefficients are dead: their region takes the output tile
+  float *ldsZ = ldsS;
   {   // out[:, ct*16..] = A_head(ct) x W[:, ct*16..]: 2 row tiles x 4 column tiles = one tile per wave
     const int rt = wave_u & 1, ct = wave_u >> 1;
     const int i = lane & 15, kq = lane >> 4;
     const int head = (ct * 16) / C;
-    const f32x4 acc = mfma_block<GD>(ldsA + (rt * 16 + i) * kATS + head * GD + 4 * kq, ldsBt + (ct * 16 + i) * GG::TS + 4 * kq);
+    const float *pa = ldsA + (rt * 16 + i) * kATS + head * GD + 4 * kq;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 av4 = *reinterpret_cast<const float4 *>(pa + kb * 16);
+      acc = mfma16(av4.x, breg[kb][0], acc);
+      acc = mfma16(av4.y, breg[kb][1], acc);
+      acc = mfma16(av4.z, breg[kb][2], acc);
+      acc = mfma16(av4.w, breg[kb][3], acc);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) ldsZ[(rt * 16 + 4 * kq + reg) * GG::TS + ct * 16 + i] = acc[reg];
   }
@@ -299,11 +310,10 @@ template <int H>
 __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const GatBwdTK p) {
   constexpr int C = GD / H;
   __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];
-  // W (row-major, as stored) and the dz tile feed the product; its result, the per-head [32][H*64] tile, overlays both
-  constexpr int kIn = GD * GG::TS + kTM * GG::TS;
-  constexpr int kRest = (kTM * kATS > kIn) ? kTM * kATS : kIn;
-  __shared__ __attribute__((aligned(16))) float ldsR[kRest];
-  float *ldsW = ldsR, *ldsDZ = ldsR + GD * GG::TS, *ldsDA = ldsR;
+  // the dz tile feeds the product (its B operand, blocks of W, comes straight from memory); the result is the per-head
+  // [32][H*64] tile
+  __shared__ __attribute__((aligned(16))) float ldsDZ[kTM * GG::TS];
+  __shared__ __attribute__((aligned(16))) float ldsDA[kTM * kATS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid / GG::LPR, q = tid % GG::LPR;
@@ -312,9 +322,19 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
 
   TileMeta m;
   tile_meta(p.halo, p.slots, p.sched, p.x, tile, grp, q, ldsXh, m);
-  float4 wreg[GG::W4];
+  // B operand of this wave's H output tiles: lane (i, kq) of tile (head, jt) needs wt[jt*16 + i][head*C + 16 kb + 4 kq + r],
+  // r = 0..3 contiguous: C / 16 float4 per tile, in flight from the start (W is 16 KB, cache resident)
+  float4 breg[H][C / 16];
+  {
+    const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-  for (int k = 0; k < GG::W4; ++k) wreg[k] = reinterpret_cast<const float4 *>(p.wt)[tid + k * kThreads];
+    for (int t = 0; t < H; ++t) {
+      const int ctile = (wave_u + GG::WAVES * t) >> 1, head = ctile >> 2, jt = ctile & 3;
+#pragma unroll
+      for (int kb = 0; kb < C / 16; ++kb)
+        breg[t][kb] = *reinterpret_cast<const float4 *>(p.wt + (size_t)(jt * 16 + i) * GD + head * C + 16 * kb + 4 * kq);
+    }
+  }
   const bool ok = m.sc.x >= 0;
   const int deg = ok ? m.sc.z : 0;
   const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
@@ -339,11 +359,6 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
   if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
   if (ok && p.dz) reinterpret_cast<float4 *>(p.dz)[idx4] = dz;
   *reinterpret_cast<float4 *>(&ldsDZ[grp * GG::TS + 4 * q]) = dz;
-#pragma unroll
-  for (int k = 0; k < GG::W4; ++k) {
-    const int idx = tid + k * kThreads;
-    *reinterpret_cast<float4 *>(&ldsW[((idx * 4) / GD) * GG::TS + (idx * 4) % GD]) = wreg[k];
-  }
   __syncthreads();
   {   // db partial: column sums of the dz tile (8 adjacent lanes hold row-partials of one column)
     const int dbc = tid / GG::DBP, dbpart = tid % GG::DBP;
@@ -355,23 +370,23 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
     if (dbpart == 0) p.slab_db[(size_t)tile * GD + dbc] = s;
   }
   // dA[i][k*64 + j] = sum_c dz[i][k*C + c] W[j][k*C + c]: 2 row tiles x (4 H) column tiles, H tiles per wave
-  f32x4 acc[H];
   {
     const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int t = 0; t < H; ++t) {
-      const int id = wave_u + GG::WAVES * t, rt = id & 1, ctile = id >> 1, head = ctile >> 2, jt = ctile & 3;
-      acc[t] = mfma_block<C>(ldsDZ + (rt * 16 + i) * GG::TS + head * C + 4 * kq, ldsW + (jt * 16 + i) * GG::TS + head * C + 4 * kq);
-    }
-  }
-  __syncthreads();   // every wave has read W / dz: the result may overlay them
-  {
-    const int i = lane & 15, kq = lane >> 4;
+      const int id = wave_u + GG::WAVES * t, rt = id & 1, ctile = id >> 1, head = ctile >> 2;
+      const float *pa = ldsDZ + (rt * 16 + i) * GG::TS + head * C + 4 * kq;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < H; ++t) {
-      const int id = wave_u + GG::WAVES * t, rt = id & 1, ctile = id >> 1;
+      for (int kb = 0; kb < C / 16; ++kb) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(pa + kb * 16);
+        acc = mfma16(a4.x, breg[t][kb].x, acc);
+        acc = mfma16(a4.y, breg[t][kb].y, acc);
+        acc = mfma16(a4.z, breg[t][kb].z, acc);
+        acc = mfma16(a4.w, breg[t][kb].w, acc);
+      }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) ldsDA[(rt * 16 + 4 * kq + reg) * kATS + ctile * 16 + i] = acc[t][reg];
+      for (int reg = 0; reg < 4; ++reg) ldsDA[(rt * 16 + 4 * kq + reg) * kATS + ctile * 16 + i] = acc[reg];
     }
   }
   __syncthreads();
@@ -559,58 +574,52 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_source_kernel(const
     const int t2 = wave_u + GG::WAVES * mm;
     if (t2 < NT) slab4[t2 * 64 + lane] = make_float4(dw[mm][0], dw[mm][1], dw[mm][2], dw[mm][3]);
   }
-  p.slab_u[(size_t)wg * kThreads + tid] = uacc;
+  // this workgroup's share of da:  da[(which*C + c) + 2C k] = sum_i W[k*C + c][i] u_which,k[i]   (linear in u: summed over the
+  // workgroups by the reduction kernel)
+  ldsS[tid] = uacc;
+  __syncthreads();
+  if (tid < 2 * GD) {
+    const int k = tid / (2 * C), r = tid % (2 * C), which = r / C, cc = r % C;
+    float sacc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < GD; ++i) sacc = fmaf(ldsBt[i * GG::TS + k * C + cc], ldsS[which * 256 + k * 64 + i], sacc);
+    p.slab_u[(size_t)wg * 2 * GD + tid] = sacc;
+  }
 }
 
-// slabs -> dWt (row-major [in][out]), db, da.  Blocks 0 .. 63: 64 elements of dW each; block 64: db; block 65: u and da.
+// slabs -> dWt (row-major [in][out]), db, da.  Blocks 0 .. 63: 64 elements of dW each; block 64: db; blocks 65, 66: da.
 __global__ __launch_bounds__(1024) void gat_layer_reduce_kernel(const float *__restrict__ slab_dw, int n_wg,
                                                                 const float *__restrict__ slab_db, int n_tiles,
-                                                                const float *__restrict__ slab_u, const float *__restrict__ wt,
-                                                                int heads, float *__restrict__ dwt, float *__restrict__ db,
-                                                                float *__restrict__ da) {
+                                                                const float *__restrict__ slab_da, float *__restrict__ dwt,
+                                                                float *__restrict__ db, float *__restrict__ da) {
   __shared__ float part[16][64];
-  __shared__ float u[512];
   const int el = threadIdx.x & 63, pid = threadIdx.x >> 6;
   const int b = blockIdx.x;
-  if (b <= 64) {
-    const float *slab = b < 64 ? slab_dw : slab_db;
-    const int n = b < 64 ? n_wg : n_tiles, len = b < 64 ? GD * GD : GD, e = (b < 64 ? b : 0) * 64 + el;
-    if (b == 64 && db == nullptr) return;
-    float s0 = 0.f, s1 = 0.f;
-    int k = pid;
-    for (; k + 16 < n; k += 32) {
-      s0 += slab[(size_t)k * len + e];
-      s1 += slab[(size_t)(k + 16) * len + e];
-    }
-    for (; k < n; k += 16) s0 += slab[(size_t)k * len + e];
-    part[pid][el] = s0 + s1;
-    __syncthreads();
-    if (pid == 0) {
-      float v = 0.f;
-#pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) v += part[k2][el];
-      if (b == 64) {
-        db[el] = v;
-      } else {   // e = (tt * 64 + lane) * 4 + reg  ->  dWt[(mt*16 + 4*kq + reg) * 64 + nt*16 + i]
-        const int reg = e & 3, ln = (e >> 2) & 63, tt = e >> 8, mt = tt / GG::CT, nt = tt % GG::CT;
-        dwt[(mt * 16 + 4 * (ln >> 4) + reg) * GD + nt * 16 + (ln & 15)] = v;
-      }
-    }
-    return;
+  const float *slab = b < 64 ? slab_dw : b == 64 ? slab_db : slab_da;
+  const int n = b == 64 ? n_tiles : n_wg, len = b < 64 ? GD * GD : b == 64 ? GD : 2 * GD;
+  const int e = (b < 64 ? b : b == 64 ? 0 : b - 65) * 64 + el;
+  if (b == 64 && db == nullptr) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = pid;
+  for (; k + 16 < n; k += 32) {
+    s0 += slab[(size_t)k * len + e];
+    s1 += slab[(size_t)(k + 16) * len + e];
   }
-  // u = sum of the workgroups' partials; da[(which*C + c) + 2C k] = sum_i W[k*C + c][i] u_which,k[i]
-  if (threadIdx.x < 512) {
-    float s = 0.f;
-    for (int k = 0; k < n_wg; ++k) s += slab_u[(size_t)k * 512 + threadIdx.x];
-    u[threadIdx.x] = s;
-  }
+  for (; k < n; k += 16) s0 += slab[(size_t)k * len + e];
+  part[pid][el] = s0 + s1;
   __syncthreads();
-  const int c = GD / heads;
-  if ((int)threadIdx.x < 2 * GD) {   // 2 C heads = 128 outputs
-    const int k = threadIdx.x / (2 * c), r = threadIdx.x % (2 * c), which = r / c, cc = r % c;
-    float s = 0.f;
-    for (int i = 0; i < GD; ++i) s = fmaf(wt[(size_t)i * GD + k * c + cc], u[which * 256 + k * 64 + i], s);
-    da[threadIdx.x] = s;
+  if (pid == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) v += part[k2][el];
+    if (b == 64) {
+      db[el] = v;
+    } else if (b > 64) {
+      da[e] = v;
+    } else {   // e = (tt * 64 + lane) * 4 + reg  ->  dWt[(mt*16 + 4*kq + reg) * 64 + nt*16 + i]
+      const int reg = e & 3, ln = (e >> 2) & 63, tt = e >> 8, mt = tt / GG::CT, nt = tt % GG::CT;
+      dwt[(mt * 16 + 4 * (ln >> 4) + reg) * GD + nt * 16 + (ln & 15)] = v;
+    }
   }
 }
 
@@ -633,7 +642,7 @@ inline GatWs gat_ws(const ngpde_graph *g, int heads) {
   w.dal = o; o += up((size_t)g->n_nodes * heads * 4);
   w.slab_db = o; o += up((size_t)fused_num_blocks(g->n_nodes) * GD * 4);
   w.slab_dw = o; o += up((size_t)src_wgs(g) * GD * GD * 4);
-  w.slab_u = o; o += up((size_t)src_wgs(g) * kThreads * 4);
+  w.slab_u = o; o += up((size_t)src_wgs(g) * 2 * GD * 4);
   w.total = o;
   return w;
 }
@@ -701,8 +710,8 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
     }
     NGPDE_LAUNCH_CHECK("gat_layer_bwd kernels");
   }
-  hipLaunchKernelGGL(gat_layer_reduce_kernel, dim3(66), dim3(1024), 0, stream, slab_dw, g->n_nodes > 0 ? n_wg : 0, slab_db,
-                     g->n_nodes > 0 ? n_tiles : 0, slab_u, wt, heads, dwt, db, da);
+  hipLaunchKernelGGL(gat_layer_reduce_kernel, dim3(67), dim3(1024), 0, stream, slab_dw, g->n_nodes > 0 ? n_wg : 0, slab_db,
+                     g->n_nodes > 0 ? n_tiles : 0, slab_u, dwt, db, da);
   NGPDE_LAUNCH_CHECK("gat_layer_reduce_kernel");
   return NGPDE_OK;
 }
