@@ -11,6 +11,25 @@ namespace {
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// one block of the Dense kernels' segmented-input table
+SegTable one_seg(const float *ptr, int width) {
+  SegTable t;
+  t.n = 1;
+  t.ptr[0] = ptr;
+  t.width[0] = width;
+  t.vec[0] = (width % 4 == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0) ? 1 : 0;
+  for (int i = 1; i <= 4; ++i) t.offset[i] = width;
+  return t;
+}
+SegGrad one_grad(float *ptr, int width) {
+  SegGrad t;
+  t.n = 1;
+  t.ptr[0] = ptr;
+  t.width[0] = width;
+  for (int i = 1; i <= 4; ++i) t.offset[i] = width;
+  return t;
+}
+
 int32_t check_common(const char *fn, const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "%s: graph is NULL", fn);
   NGPDE_REQUIRE(din > 0 && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH, "%s: DimensionMismatch: din=%d dout=%d", fn, din, dout);
@@ -32,9 +51,14 @@ size_t ngpde_gcn_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t do
     const size_t nb = (size_t)fused_num_blocks(g->n_nodes);
     return align256(nb * (size_t)din * dout * 4) + align256(nb * (size_t)dout * 4) + align256(n * din * 4) + 256;
   }
+  // any-width path: the Dense part on the fp32-MFMA kernels of dense_mfma.hip.  Forward: the aggregated input (dout >= din) or
+  // the split-K partial products of W x (dout < din); backward: dz, one [N][max] buffer, the weight-pullback slabs.
   const size_t dmax = (size_t)std::max(din, dout);
-  if (!backward) return align256(n * dmax * 4) + 256;
-  return 2 * align256(n * dmax * 4) + 256;
+  if (!backward) {
+    const size_t parts = dout < din ? (size_t)dense_fwd_split_count(din, dense_fwd_splits((int64_t)n, din, dout)) : 1;
+    return align256(n * (dout < din ? (size_t)dout * parts : dmax) * 4) + 256;
+  }
+  return 2 * align256(n * dmax * 4) + align256((size_t)dense_weight_chunks((int64_t)n, din, dout) * (din + 1) * dout * 4) + 256;
 }
 
 int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
@@ -59,12 +83,14 @@ int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int
   if (dout >= din) {  // aggregate, then multiply (src/layers.jl:235-237)
     float *agg = save_agg ? save_agg : tmp;
     if ((st = launch_spmm_generic(g, false, true, din, NGPDE_AGGR_SUM, x, nullptr, agg, stream))) return st;
-    return launch_dense_fwd(n, din, dout, act, agg, weight, bias, y, save_z, stream);
+    return launch_dense_seg_fwd(n, one_seg(agg, din), din, dout, act, weight, bias, y, save_z, stream);
   }
-  // multiply first (src/layers.jl:220-223), then aggregate, then bias + activation
-  if ((st = launch_dense_fwd(n, din, dout, NGPDE_ACT_IDENTITY, x, weight, nullptr, tmp, nullptr, stream))) return st;
-  if ((st = launch_spmm_generic(g, false, true, dout, NGPDE_AGGR_SUM, tmp, nullptr, y, stream))) return st;
-  return launch_bias_act(n, dout, act, y, bias, y, save_z, stream);
+  // multiply first (src/layers.jl:220-223) -- split over the input features when the row tiles alone cannot fill the chip,
+  // the partial products summed in slab order --, then ONE launch: aggregation + bias + activation
+  const int nsplit = dense_fwd_splits(n, din, dout);
+  if ((st = launch_dense_seg_fwd_splitk(n, one_seg(x, din), din, dout, weight, tmp, nsplit, stream))) return st;
+  if ((st = launch_sum_partials(n * dout, dense_fwd_split_count(din, nsplit), (size_t)n * dout, tmp, stream))) return st;
+  return launch_spmm_gcn_tail(g, dout, tmp, bias, act, y, save_z, stream);
 }
 
 int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
@@ -112,19 +138,21 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
   const size_t dmax = (size_t)std::max(din, dout);
   float *dz = (float *)ws;
   float *tmp = (float *)(ws + align256((size_t)n * dmax * 4));
+  float *partial = (float *)(ws + 2 * align256((size_t)n * dmax * 4));
   if ((st = launch_act_bwd(n * dout, act, dy, z, dz, stream))) return st;
-  if (dbias && (st = launch_colsum(n, dout, dz, dbias, stream))) return st;
-  if (dout >= din) {
-    if ((st = launch_dense_bwd_weight(n, din, dout, saved_agg, dz, dweight, stream))) return st;
+  if (dout >= din) {   // y = act(agg W + b): dW = agg^T dz, db = column sums of dz (the weight pullback's bias row), dx = A^T (dz W^T)
+    if ((st = launch_dense_seg_bwd_weight(n, one_seg(saved_agg, din), din, dout, dz, dweight, dbias, partial, stream))) return st;
     if (dx) {
-      if ((st = launch_dense_bwd_input(n, din, dout, dz, weight, tmp, stream))) return st;
+      if ((st = launch_dense_seg_bwd_input(n, one_grad(tmp, din), din, dout, dz, weight, stream))) return st;
       if ((st = launch_spmm_generic(g, true, true, din, NGPDE_AGGR_SUM, tmp, nullptr, dx, stream))) return st;
     }
     return NGPDE_OK;
   }
+  // y = act(A (x W) + b): db from dz; g = A^T dz; dW = x^T g; dx = g W^T
+  if (dbias && (st = launch_colsum2(n, dout, dz, partial, dbias, stream))) return st;
   if ((st = launch_spmm_generic(g, true, true, dout, NGPDE_AGGR_SUM, dz, nullptr, tmp, stream))) return st;
-  if ((st = launch_dense_bwd_weight(n, din, dout, x, tmp, dweight, stream))) return st;
-  if (dx) return launch_dense_bwd_input(n, din, dout, tmp, weight, dx, stream);
+  if ((st = launch_dense_seg_bwd_weight(n, one_seg(x, din), din, dout, tmp, dweight, nullptr, partial, stream))) return st;
+  if (dx) return launch_dense_seg_bwd_input(n, one_grad(dx, din), din, dout, tmp, weight, stream);
   return NGPDE_OK;
 }
 

@@ -204,22 +204,10 @@ int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope
 // generic (any feature width) building blocks
 int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr,
                             const float *x, const float *edge_weight, float *out, hipStream_t stream);
-// y[n][o] = act(sum_i x[n][i] * wt[i][o] + bias[o]); optionally also stores z
-int32_t launch_dense_fwd(int64_t n, int din, int dout, int act, const float *x, const float *wt,
-                         const float *bias, float *y, float *save_z, hipStream_t stream);
 // dz = dy * act'(z)
 int32_t launch_act_bwd(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
-// dx[n][i] = sum_o dz[n][o] * wt[i][o]
-int32_t launch_dense_bwd_input(int64_t n, int din, int dout, const float *dz, const float *wt, float *dx,
-                               hipStream_t stream);
-// dwt[i][o] = sum_n x[n][i] * dz[n][o]
-int32_t launch_dense_bwd_weight(int64_t n, int din, int dout, const float *x, const float *dz, float *dwt,
-                                hipStream_t stream);
 // out[o] = sum_n a[n][o]
 int32_t launch_colsum(int64_t n, int d, const float *a, float *out, hipStream_t stream);
-// y = act(a + bias)
-int32_t launch_bias_act(int64_t n, int d, int act, const float *a, const float *bias, float *y, float *save_z,
-                        hipStream_t stream);
 
 // ---- message-passing primitives (mp_kernels.hip) -------------------------------------------------------
 struct SegTable {   // virtual concatenation [X1 | X2 | ...] of up to 4 row-major blocks
@@ -238,6 +226,13 @@ struct SegGrad {
 };
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream);
+int dense_fwd_splits(int64_t n, int din, int dout);
+int dense_fwd_split_count(int din, int nsplit);
+int32_t launch_dense_seg_fwd_splitk(int64_t n, const SegTable &segs, int din, int dout, const float *wt, float *partial, int nsplit,
+                                    hipStream_t stream);
+int32_t launch_sum_partials(int64_t count, int nparts, size_t stride, float *x, hipStream_t stream);
+int32_t launch_spmm_gcn_tail(const ngpde_graph *g, int d, const float *x, const float *bias, int act, float *out, float *save_z,
+                             hipStream_t stream);
 int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
                                    hipStream_t stream);

@@ -60,14 +60,21 @@ __device__ __forceinline__ void mfma_chunk(const float *ldsA, const float *ldsBt
 }
 
 // ---- forward: y[n][o] = act(sum_k X[n][k] wt[k][o] + b[o]) -----------------------------------------------------
-__global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable segs, int din, int dout, int act,
+// Split-K (part_stride > 0): workgroup z contracts the features [z * kper, (z + 1) * kper) only and writes its raw partial
+// products to y + z * part_stride (no bias, no activation); the caller sums the partials (the GCN path does it inside the
+// aggregation that follows, src/layers.jl:220-223).  For tall-K / few-row shapes such as GCNConv(1433 => 16) on a 2.7k-node
+// graph: 43 row tiles alone would leave 5/6 of the chip idle behind 90 dependent K steps each.
+__global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable segs, int din_all, int dout, int act,
                                                              const float *__restrict__ wt, const float *__restrict__ bias,
-                                                             float *__restrict__ y, float *__restrict__ save_z) {
+                                                             float *__restrict__ y, float *__restrict__ save_z, int kper,
+                                                             size_t part_stride) {
   __shared__ __attribute__((aligned(16))) float ldsA[BM * LS], ldsBt[BN * LS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int col0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * kper, din = min(din_all, kbeg + kper);   // this workgroup's feature range [kbeg, din)
+  if (part_stride) { y += (size_t)blockIdx.z * part_stride; bias = nullptr; save_z = nullptr; act = NGPDE_ACT_IDENTITY; }
   // staging roles: A element (row = tid / 16 + 16 p, k = tid % 16), B element (k = tid / 64 + 4 p, col = tid % 64)
   const int ar = tid >> 4, ak = tid & 15, bk = tid >> 6, bc = tid & 63;
   float areg[4], breg[4];
@@ -83,8 +90,8 @@ __global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  fetch(0);
-  for (int k0 = 0; k0 < din; k0 += BK) {
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < din; k0 += BK) {
     __syncthreads();   // previous chunk fully consumed
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -513,9 +520,34 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
     return NGPDE_OK;
   }
   hipLaunchKernelGGL(dense_mfma_fwd_kernel, dim3((unsigned)((n + BM - 1) / BM), (dout + BN - 1) / BN), dim3(256), 0, stream,
-                     n, segs, din, dout, act, wt, bias, y, save_z);
+                     n, segs, din, dout, act, wt, bias, y, save_z, din, (size_t)0);
   NGPDE_LAUNCH_CHECK("dense_mfma_fwd_kernel");
   return NGPDE_OK;
+}
+
+// number of K splits worth taking for X[n][din] x W[din][dout]: only when the row tiles alone leave most of the chip idle and
+// the contraction is long; every split gets a multiple of BK features
+int dense_fwd_splits(int64_t n, int din, int dout) {
+  const int64_t tiles = ((n + BM - 1) / BM) * ((dout + BN - 1) / BN);
+  if (tiles >= 256 || din < 256) return 1;
+  const int64_t want = (512 + tiles - 1) / tiles;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(want, din / 64));
+}
+
+// partial[z][n][dout] = X[:, range z] x W[range z, :], z < nsplit (nsplit from dense_fwd_splits)
+int32_t launch_dense_seg_fwd_splitk(int64_t n, const SegTable &segs, int din, int dout, const float *wt, float *partial, int nsplit,
+                                    hipStream_t stream) {
+  if (n == 0 || dout == 0) return NGPDE_OK;
+  const int kper = ((din + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+  hipLaunchKernelGGL(dense_mfma_fwd_kernel, dim3((unsigned)((n + BM - 1) / BM), (dout + BN - 1) / BN, (din + kper - 1) / kper),
+                     dim3(256), 0, stream, n, segs, din, dout, NGPDE_ACT_IDENTITY, wt, nullptr, partial, nullptr, kper,
+                     (size_t)n * dout);
+  NGPDE_LAUNCH_CHECK("dense_mfma_fwd_kernel (split-K)");
+  return NGPDE_OK;
+}
+int dense_fwd_split_count(int din, int nsplit) {   // partial slabs launch_dense_seg_fwd_splitk actually writes
+  const int kper = ((din + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+  return (din + kper - 1) / kper;
 }
 
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,

@@ -1,6 +1,7 @@
 // gcn_generic.hip -- any-feature-width building blocks of the GCNConv path
 // (/root/reference/src/layers.jl:200-239) for shapes outside the fused kernels: CSR aggregation
-// (propagate(copy_xj / w_mul_xj, g, +) and its transpose), dense forward / backward, bias + activation.
+// (propagate(copy_xj / w_mul_xj, g, +) and its transpose, with the layer's bias + activation tail), element-wise
+// activation pullback, column sums, bias + activation.  The Dense part of that path runs on dense_mfma.hip.
 // No atomics: every output element has one writer and a fixed summation order.
 #include <algorithm>
 
@@ -15,116 +16,107 @@ namespace {
 // generic kernels (any feature width)
 // ---------------------------------------------------------------------------------------------------
 
-// one wave per destination row; lanes stride over the features; CSR order summation, no atomics
+// optional epilogue of the aggregation: out = act(agg + bias) with the pre-activation kept (the tail of the multiply-first
+// GCNConv order, src/layers.jl:220-226)
+struct SpmmTail {
+  const float *bias = nullptr;
+  int act = NGPDE_ACT_IDENTITY;
+  float *save_z = nullptr;
+};
+// One wave per destination row.  Narrow rows (d <= 32) give the wave's lanes to several list entries at once -- lane =
+// (entry slot, feature) -- and every lane keeps four entries in flight, so a hub row of a skewed graph (Cora-like: degree
+// > 100 next to a median of 3) is a dozen load rounds instead of a hundred dependent ones; the slots' partial sums are
+// combined in a fixed order (deterministic, no atomics).
+template <int DP>   // features per entry slot: 64 (one slot, lanes stride over d), 32, 16, 8
 __global__ __launch_bounds__(256) void spmm_generic_kernel(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                            const int *__restrict__ eid, const int2 *__restrict__ ent,
                                                            const float *__restrict__ cnorm, int self_loops, int gcn_norm,
                                                            int mean, const float *__restrict__ edge_weight, int n_nodes,
-                                                           int d, const float *__restrict__ x, float *__restrict__ out) {
+                                                           int d, const float *__restrict__ x, float *__restrict__ out,
+                                                           const SpmmTail tail) {
+  constexpr int SLOTS = 64 / DP;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_nodes) return;
   const int rs = rowptr[row], re = rowptr[row + 1];
-  for (int f = lane; f < d; f += 64) {
-    float acc = 0.f;
-    for (int p = rs; p < re; ++p) {
-      float w;
-      int c;
+  const int slot = lane / DP, fl = lane % DP;
+  auto xat = [&](size_t idx) { return x[idx]; };
+  auto load_entries = [&](int base, int &cl, float &wl) {   // ONE coalesced load per lane for the next 64 list entries
+    const int pl = base + lane;
+    cl = 0;
+    wl = 0.f;      // past the end of the row: weight 0 on the (valid) row 0
+    if (pl < re) {
       if (gcn_norm) {
-        const int2 v = ent[p];
-        c = v.x;
-        w = __int_as_float(v.y);
+        const int2 v = ent[pl];
+        cl = v.x;
+        wl = __int_as_float(v.y);
       } else {
-        c = col[p];
-        w = edge_weight ? edge_weight[eid[p]] : 1.0f;
+        cl = col[pl];
+        wl = edge_weight ? edge_weight[eid[pl]] : 1.0f;
       }
-      acc = fmaf(w, x[(size_t)c * d + f], acc);
     }
-    if (gcn_norm) {
-      const float ci = cnorm[row];
-      if (self_loops) acc = fmaf(ci, x[(size_t)row * d + f], acc);
-      acc *= ci;
-    } else if (mean) {
-      const int cnt = re - rs;
-      acc = cnt > 0 ? acc / (float)cnt : 0.f;
+  };
+  constexpr int EPL = 64 / SLOTS;                 // entries per lane and 64-entry batch
+  constexpr int U = EPL < 16 ? EPL : 16;          // row fetches in flight per lane
+  for (int f0 = 0; f0 < d; f0 += DP) {
+    const int f = f0 + fl;
+    const bool fok = f < d;
+    const int fc = fok ? f : 0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cl, cn = 0;
+    float wl, wn = 0.f;
+    load_entries(rs, cl, wl);
+    for (int base = rs; base < re; base += 64) {
+      if (base + 64 < re) load_entries(base + 64, cn, wn);   // next batch in flight under this batch's row fetches
+      const int cnt = min(64, re - base);
+      // entries handed out by lane shuffles; all U fetches of a round are issued before the first is consumed (weight 0 and
+      // row 0 for the slots past the row's end: no branch around the loads)
+      for (int e0 = 0; e0 * SLOTS < cnt; e0 += U) {          // wave-uniform trip count
+        float xv[U], wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = ((e0 + u) * SLOTS + slot) & 63;
+          wv[u] = __shfl(wl, e);
+          xv[u] = xat((size_t)__shfl(cl, e) * d + fc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u & 3] = fmaf(wv[u], xv[u], acc[u & 3]);
+      }
+      cl = cn;
+      wl = wn;
     }
-    out[(size_t)row * d + f] = acc;
+    float a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int o = DP; o < 64; o <<= 1) a += __shfl_xor(a, o);
+    if (slot == 0 && fok) {
+      if (gcn_norm) {
+        const float ci = cnorm[row];
+        if (self_loops) a = fmaf(ci, xat((size_t)row * d + f), a);
+        a *= ci;
+      } else if (mean) {
+        const int cnt = re - rs;
+        a = cnt > 0 ? a / (float)cnt : 0.f;
+      }
+      if (tail.bias) a += tail.bias[f];
+      if (tail.save_z) tail.save_z[(size_t)row * d + f] = a;
+      out[(size_t)row * d + f] = act_apply(tail.act, a);
+    }
   }
 }
 
-// y[n][o] = act(sum_i x[n][i] wt[i][o] + b[o]);  16x16 output tile per workgroup, K staged through LDS
-__global__ __launch_bounds__(256) void dense_fwd_kernel(int64_t n, int din, int dout, int act,
-                                                        const float *__restrict__ x, const float *__restrict__ wt,
-                                                        const float *__restrict__ bias, float *__restrict__ y,
-                                                        float *__restrict__ save_z) {
-  __shared__ float xs[16][17], ws[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
-  const int o = blockIdx.y * 16 + tx;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < din; k0 += 16) {
-    xs[ty][tx] = (row < n && k0 + tx < din) ? x[row * din + k0 + tx] : 0.f;
-    ws[ty][tx] = (k0 + ty < din && o < dout) ? wt[(size_t)(k0 + ty) * dout + o] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(xs[ty][k], ws[k][tx], acc);
-    __syncthreads();
-  }
-  if (row < n && o < dout) {
-    const float z = acc + (bias ? bias[o] : 0.f);
-    if (save_z) save_z[row * dout + o] = z;
-    y[row * dout + o] = act_apply(act, z);
-  }
-}
+#define NGPDE_SPMM_LAUNCH(...)                                                                                       \
+  do {                                                                                                               \
+    const dim3 grid_((unsigned)((g->n_nodes + 3) / 4)), block_(256);                                                 \
+    if (d <= 8) hipLaunchKernelGGL(spmm_generic_kernel<8>, grid_, block_, 0, stream, __VA_ARGS__);                   \
+    else if (d <= 16) hipLaunchKernelGGL(spmm_generic_kernel<16>, grid_, block_, 0, stream, __VA_ARGS__);            \
+    else if (d <= 32) hipLaunchKernelGGL(spmm_generic_kernel<32>, grid_, block_, 0, stream, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(spmm_generic_kernel<64>, grid_, block_, 0, stream, __VA_ARGS__);                         \
+  } while (0)
 
 __global__ void act_bwd_kernel(int64_t count, int act, const float *__restrict__ dy, const float *__restrict__ z,
                                float *__restrict__ dz) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     dz[i] = dy[i] * act_deriv(act, z[i]);
-}
-
-// dx[n][i] = sum_o dz[n][o] wt[i][o]
-__global__ __launch_bounds__(256) void dense_bwd_input_kernel(int64_t n, int din, int dout,
-                                                              const float *__restrict__ dz,
-                                                              const float *__restrict__ wt, float *__restrict__ dx) {
-  __shared__ float zs[16][17], ws[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + ty;
-  const int i = blockIdx.y * 16 + tx;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < dout; k0 += 16) {
-    zs[ty][tx] = (row < n && k0 + tx < dout) ? dz[row * dout + k0 + tx] : 0.f;
-    // ws[k][j] = wt[i0 + j][k0 + k]
-    const int wi = blockIdx.y * 16 + ty;
-    ws[tx][ty] = (wi < din && k0 + tx < dout) ? wt[(size_t)wi * dout + k0 + tx] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(zs[ty][k], ws[k][tx], acc);
-    __syncthreads();
-  }
-  if (row < n && i < din) dx[row * din + i] = acc;
-}
-
-// dwt[i][o] = sum_n x[n][i] dz[n][o]; one workgroup per 16x16 tile of dwt, loops over all rows
-// (deterministic: fixed summation order)
-__global__ __launch_bounds__(256) void dense_bwd_weight_kernel(int64_t n, int din, int dout,
-                                                               const float *__restrict__ x,
-                                                               const float *__restrict__ dz, float *__restrict__ dwt) {
-  __shared__ float xs[16][17], zs[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + ty;   // row of dwt
-  const int o = blockIdx.y * 16 + tx;   // col of dwt
-  float acc = 0.f;
-  for (int64_t n0 = 0; n0 < n; n0 += 16) {
-    // xs[k][j] = x[n0 + k][i0 + j];  zs[k][j] = dz[n0 + k][o0 + j]
-    xs[ty][tx] = (n0 + ty < n && blockIdx.x * 16 + tx < din) ? x[(n0 + ty) * din + blockIdx.x * 16 + tx] : 0.f;
-    zs[ty][tx] = (n0 + ty < n && o < dout) ? dz[(n0 + ty) * dout + o] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(xs[k][ty], zs[k][tx], acc);
-    __syncthreads();
-  }
-  if (i < din && o < dout) dwt[(size_t)i * dout + o] = acc;
 }
 
 // out[o] = sum_n a[n][o]   (bias gradient); 4 row-partials per column combined through LDS
@@ -139,17 +131,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t n, int d, const flo
   part[pid][threadIdx.x & 63] = s;
   __syncthreads();
   if (pid == 0 && o < d) out[o] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-}
-
-// y = act(a + b) row-wise bias, optional pre-activation copy (generic dout < din path)
-__global__ void bias_act_kernel(int64_t n, int d, int act, const float *__restrict__ a, const float *__restrict__ bias,
-                                float *__restrict__ y, float *__restrict__ save_z) {
-  const int64_t count = n * d;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-    const float z = a[i] + (bias ? bias[i % d] : 0.f);
-    if (save_z) save_z[i] = z;
-    y[i] = act_apply(act, z);
-  }
 }
 
 // y = act(a + addend + b), 16 bytes per thread (d % 4 == 0), optional pre-activation copy
@@ -223,19 +204,44 @@ int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm,
                 "aggregation %d not supported by the copy_xj path", aggr);
   if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
   const Csr &c = by_source ? g->by_s : g->by_t;
-  hipLaunchKernelGGL(spmm_generic_kernel, dim3((unsigned)((g->n_nodes + 3) / 4)), dim3(256), 0, stream, c.rowptr,
-                     c.col, c.eid, c.ent, g->c, g->self_loops, gcn_norm ? 1 : 0, aggr == NGPDE_AGGR_MEAN ? 1 : 0,
-                     edge_weight, (int)g->n_nodes, d, x, out);
+  NGPDE_SPMM_LAUNCH(c.rowptr, c.col, c.eid, c.ent, g->c, g->self_loops, gcn_norm ? 1 : 0, aggr == NGPDE_AGGR_MEAN ? 1 : 0, edge_weight,
+                    (int)g->n_nodes, d, x, out, SpmmTail());
   NGPDE_LAUNCH_CHECK("spmm_generic_kernel");
   return NGPDE_OK;
 }
 
-int32_t launch_dense_fwd(int64_t n, int din, int dout, int act, const float *x, const float *wt, const float *bias,
-                         float *y, float *save_z, hipStream_t stream) {
-  if (n == 0 || dout == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3((unsigned)((n + 15) / 16), (dout + 15) / 16), dim3(256), 0, stream, n, din,
-                     dout, act, x, wt, bias, y, save_z);
-  NGPDE_LAUNCH_CHECK("dense_fwd_kernel");
+// x[i] += x[stride + i] + x[2 stride + i] + ...  (split-K partial products -> their sum, in slab order)
+__global__ void sum_partials_kernel(int64_t count, int nparts, size_t stride, float *__restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float s0 = x[i], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 1;
+    for (; z + 3 <= nparts; z += 3) {
+      s1 += x[(size_t)z * stride + i];
+      s2 += x[(size_t)(z + 1) * stride + i];
+      s3 += x[(size_t)(z + 2) * stride + i];
+    }
+    for (; z < nparts; ++z) s1 += x[(size_t)z * stride + i];
+    x[i] = (s0 + s1) + (s2 + s3);
+  }
+}
+int32_t launch_sum_partials(int64_t count, int nparts, size_t stride, float *x, hipStream_t stream) {
+  if (count == 0 || nparts <= 1) return NGPDE_OK;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256), 0, stream, count,
+                     nparts, stride, x);
+  NGPDE_LAUNCH_CHECK("sum_partials_kernel");
+  return NGPDE_OK;
+}
+
+// GCN aggregation with the layer's tail: out = act(C (A+I) C x + bias)
+int32_t launch_spmm_gcn_tail(const ngpde_graph *g, int d, const float *x, const float *bias, int act, float *out, float *save_z,
+                             hipStream_t stream) {
+  NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
+  if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
+  const Csr &c = g->by_t;
+  SpmmTail t;
+  t.bias = bias; t.act = act; t.save_z = save_z;
+  NGPDE_SPMM_LAUNCH(c.rowptr, c.col, c.eid, c.ent, g->c, g->self_loops, 1, 0, (const float *)nullptr, (int)g->n_nodes, d, x, out, t);
+  NGPDE_LAUNCH_CHECK("spmm_generic_kernel (tail)");
   return NGPDE_OK;
 }
 
@@ -247,37 +253,10 @@ int32_t launch_act_bwd(int64_t count, int act, const float *dy, const float *z, 
   return NGPDE_OK;
 }
 
-int32_t launch_dense_bwd_input(int64_t n, int din, int dout, const float *dz, const float *wt, float *dx,
-                               hipStream_t stream) {
-  if (n == 0 || din == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(dense_bwd_input_kernel, dim3((unsigned)((n + 15) / 16), (din + 15) / 16), dim3(256), 0, stream, n,
-                     din, dout, dz, wt, dx);
-  NGPDE_LAUNCH_CHECK("dense_bwd_input_kernel");
-  return NGPDE_OK;
-}
-
-int32_t launch_dense_bwd_weight(int64_t n, int din, int dout, const float *x, const float *dz, float *dwt,
-                                hipStream_t stream) {
-  if (din == 0 || dout == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(dense_bwd_weight_kernel, dim3((din + 15) / 16, (dout + 15) / 16), dim3(256), 0, stream, n, din,
-                     dout, x, dz, dwt);
-  NGPDE_LAUNCH_CHECK("dense_bwd_weight_kernel");
-  return NGPDE_OK;
-}
-
 int32_t launch_colsum(int64_t n, int d, const float *a, float *out, hipStream_t stream) {
   if (d == 0) return NGPDE_OK;
   hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, stream, n, d, a, out);
   NGPDE_LAUNCH_CHECK("colsum_kernel");
-  return NGPDE_OK;
-}
-
-int32_t launch_bias_act(int64_t n, int d, int act, const float *a, const float *bias, float *y, float *save_z,
-                        hipStream_t stream) {
-  if (n * d == 0) return NGPDE_OK;
-  const int blocks = (int)std::min<int64_t>((n * d + 255) / 256, 2048);
-  hipLaunchKernelGGL(bias_act_kernel, dim3(blocks), dim3(256), 0, stream, n, d, act, a, bias, y, save_z);
-  NGPDE_LAUNCH_CHECK("bias_act_kernel");
   return NGPDE_OK;
 }
 

@@ -64,6 +64,37 @@ def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
         close(ps[f"layer_{k + 1}"]["bias"].grad, acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
 
 
+@pytest.mark.parametrize("dims,act", [((1433, 16), "relu"), ((16, 1433), "tanh")])
+def test_cora_sized_first_layer_any_width_path(dims, act):
+    # the tutorial's input layer GCNConv(nin => 16) at Cora size (docs/src/tutorials/graph_node.md:83: nin = 1433 bag-of-words
+    # features, 2 708 nodes) and its mirror image: the any-width path -- W applied before the aggregation when dout < din
+    # (src/layers.jl:220-223: split-K fp32-MFMA Dense, then one aggregation + bias + activation launch), after it otherwise
+    # (:235-237) -- values and all gradients against the float64 oracle
+    N, PAIRS = 2708, 5278
+    din, dout = dims
+    rng = np.random.default_rng(7)
+    s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    l = ng.GCNConv((din, dout), act, initialgraph=g)
+    ps, st = ng.setup(7, l)
+    W = S.glorot_uniform(70, dout, din)
+    b = rng.normal(size=(dout, 1)) * 0.1
+    ps = {"weight": torch.as_tensor(W.astype(np.float32), device=DEV).requires_grad_(True),
+          "bias": torch.as_tensor(b.astype(np.float32), device=DEV).requires_grad_(True)}
+    x0 = (rng.random((din, N)) < 0.05).astype(np.float64) if din > dout else rng.normal(size=(din, N))   # sparse 0/1 features
+    x = torch.as_tensor(x0.astype(np.float32), device=DEV).requires_grad_(True)
+    y, _ = l(x, ps, st)
+    yo, c = O.gcn_conv(x0, W.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64), og, act)
+    close(y, yo, 1e-4, 1e-5, "y")
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.gcn_conv_backward(c, R)
+    close(x.grad, gr["x"], 3e-4, 1e-5, "dx")
+    close(ps["weight"].grad, gr["weight"], 3e-4, 1e-4, "dW")
+    close(ps["bias"].grad, gr["bias"], 3e-4, 1e-4, "db")
+
+
 def c2_inputs():
     _, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
     D = 64
