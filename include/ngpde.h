@@ -371,6 +371,15 @@ int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fau
 int32_t ngpde_node_profile(ngpde_node_t *plan, int32_t stride, float *out_us, int32_t *out_count,
                            ngpde_stream_t stream);
 
+/* Runge-Kutta combination for right-hand sides evaluated by ARBITRARY layers (a GAT-style layer, NeuralODE(VMHConv) of
+ * docs/src/tutorials/VMH.md:85-89, ...):  out = c_self * base + sum_k coefs[k] * terms[k]  over `count` floats, n_terms <= 8
+ * (Tsit5 has at most six stage terms).  It is the stage input u + dt sum_j a_ij k_j, the step update u + dt sum_i b_i k_i, and in
+ * the discrete adjoint K-bar_i = dt b_i lambda + dt sum_{j>i} a_ji U-bar_j, lambda += sum_j U-bar_j and the accumulation of the
+ * parameter gradients over the stages.  terms / coefs are HOST arrays (of device pointers / floats); base may be NULL
+ * (c_self ignored); out may alias base or a term.  One launch, no allocation: graph-capture safe. */
+int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, int32_t n_terms, const float *const *terms,
+                               const float *coefs, float *out, ngpde_stream_t stream);
+
 /* Optimiser step on the flat parameter vector, one launch behind the gradient all-reduce on the same stream
  * [UPSTREAM Optimisers.jl Adam / Rprop; reference call sites docs/src/tutorials/graph_node.md:90,122-129, VMH.md:97].
  * grad_scale multiplies the (reduced) gradient first: 1/world_size for a mean over data-parallel ranks.

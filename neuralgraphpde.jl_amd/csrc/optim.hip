@@ -2,7 +2,10 @@
 // the parameters as one ComponentArray and call Optimisers.update on it (/root/reference/docs/src/tutorials/
 // graph_node.md:90,122-129 Adam; VMH.md:97 Rprop).  One launch right behind the gradient all-reduce on the same stream;
 // the 1/world averaging of the reduced gradient is folded into the kernel (grad_scale).
+#include <algorithm>
+
 #include "common.h"
+#include "device_utils.h"
 
 namespace ngpde {
 namespace {
@@ -36,12 +39,77 @@ __global__ void rprop_kernel(int64_t n, float *__restrict__ x, const float *__re
   }
 }
 
+// out = c_self * base + sum_k coef[k] * term[k]: the Runge-Kutta stage input u + dt sum_j a_ij k_j, the step update, and the
+// combinations of the discrete adjoint, for a right-hand side whose stages are evaluated by arbitrary layers.  float4 path when
+// everything is 16-byte aligned.
+struct CombK {
+  const float *term[8];
+  float coef[8];
+};
+template <int N, class T>
+__global__ void rk_combine_kernel(int64_t count, float c_self, const T *__restrict__ base, const CombK k, T *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    T t[N > 0 ? N : 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = reinterpret_cast<const T *>(k.term[j])[i];   // all loads first
+    T v;
+    if constexpr (sizeof(T) == 16) {
+      v = base ? f4_scale(c_self, base[i]) : f4_zero();
+#pragma unroll
+      for (int j = 0; j < N; ++j) v = f4_fma(k.coef[j], t[j], v);
+    } else {
+      v = base ? c_self * base[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < N; ++j) v = fmaf(k.coef[j], t[j], v);
+    }
+    out[i] = v;
+  }
+}
+
+template <class T>
+void launch_rk_combine(int n_terms, int64_t count, float c_self, const float *base, const CombK &k, float *out, hipStream_t stream) {
+  const dim3 grid((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), block(256);
+  const T *b = reinterpret_cast<const T *>(base);
+  T *o = reinterpret_cast<T *>(out);
+  switch (n_terms) {
+    case 0: hipLaunchKernelGGL((rk_combine_kernel<0, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 1: hipLaunchKernelGGL((rk_combine_kernel<1, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 2: hipLaunchKernelGGL((rk_combine_kernel<2, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 3: hipLaunchKernelGGL((rk_combine_kernel<3, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 4: hipLaunchKernelGGL((rk_combine_kernel<4, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 5: hipLaunchKernelGGL((rk_combine_kernel<5, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 6: hipLaunchKernelGGL((rk_combine_kernel<6, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    case 7: hipLaunchKernelGGL((rk_combine_kernel<7, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+    default: hipLaunchKernelGGL((rk_combine_kernel<8, T>), grid, block, 0, stream, count, c_self, b, k, o); break;
+  }
+}
+
 }  // namespace
 }  // namespace ngpde
 
 using namespace ngpde;
 
 extern "C" {
+
+int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, int32_t n_terms, const float *const *terms,
+                               const float *coefs, float *out, ngpde_stream_t stream) {
+  NGPDE_REQUIRE(count >= 0 && n_terms >= 0 && n_terms <= 8, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_rk_stage_combine: count >= 0 and 0 <= n_terms <= 8 required (got %lld, %d)", (long long)count, n_terms);
+  if (count == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(out && (n_terms == 0 || (terms && coefs)), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rk_stage_combine: NULL argument");
+  CombK k;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base);
+  for (int j = 0; j < 8; ++j) {
+    k.term[j] = j < n_terms ? terms[j] : nullptr;
+    k.coef[j] = j < n_terms ? coefs[j] : 0.f;
+    NGPDE_REQUIRE(j >= n_terms || terms[j], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rk_stage_combine: term %d is NULL", j);
+    bits |= reinterpret_cast<uintptr_t>(k.term[j]);
+  }
+  if (count % 4 == 0 && (bits & 15) == 0) launch_rk_combine<float4>(n_terms, count / 4, c_self, base, k, out, (hipStream_t)stream);
+  else launch_rk_combine<float>(n_terms, count, c_self, base, k, out, (hipStream_t)stream);
+  NGPDE_LAUNCH_CHECK("rk_combine_kernel");
+  return NGPDE_OK;
+}
 
 int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float *v, float eta, float beta1, float beta2,
                         float eps, int64_t step, float grad_scale, ngpde_stream_t stream) {

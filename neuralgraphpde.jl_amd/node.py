@@ -5,8 +5,10 @@ this integrator is fixed-step and its pullback is the discrete adjoint.
 
 When the right-hand side is Chain(GCNConv(d => d, act), GCNConv(d => d, act)) on one graph (the
 tutorial's `node_chain`, graph_node.md:78) the whole solve and its adjoint run device-resident from
-HIP graphs (ngpde_node_gcn2_*).  Any other right-hand side is stepped stage by stage through the
-layers' own kernels.
+HIP graphs (ngpde_node_gcn2_*).  Any other right-hand side (a GAT-style layer, VMHConv as in
+docs/src/tutorials/VMH.md:85-89, ...) is stepped stage by stage through the layers' own kernels with
+every Runge-Kutta combination -- forward and in the discrete adjoint -- as one ngpde_rk_stage_combine
+launch (_NodeGenericFn): no torch element-wise kernel on the path.
 """
 from __future__ import annotations
 
@@ -128,6 +130,127 @@ class _NodeGCN2Fn(torch.autograd.Function):
         return du0, dw1, db1, dw2, db2, None
 
 
+# ---- any right-hand side: explicit RK stepping with every combination as ONE library launch ---------------------------------
+
+
+def _combine(base, c_self, terms, coefs, out=None):
+    """out = c_self * base + sum_k coefs[k] * terms[k]  (ngpde_rk_stage_combine; row-major [N][D] float32 tensors of one size)"""
+    lib = _lib.load()
+    ref = base if base is not None else terms[0]
+    if out is None:
+        out = torch.empty_like(ref, memory_format=torch.contiguous_format)
+    arr = (C.c_void_p * max(len(terms), 1))(*[t.data_ptr() for t in terms])
+    cf = (C.c_float * max(len(coefs), 1))(*[float(c) for c in coefs])
+    _lib.check(lib.ngpde_rk_stage_combine(ref.numel(), float(c_self), _lib.ptr(base), len(terms), arr, cf, _lib.ptr(out),
+                                          _lib.current_stream()))
+    return out
+
+
+def _dense(t):
+    """a view of `t` whose memory order is its index order (the cotangent of a (out x in) weight arrives as the transpose of
+    the kernels' [in][out] array): element-wise combinations then need no copy"""
+    if t.is_contiguous():
+        return t
+    if t.dim() == 2 and t.T.is_contiguous():
+        return t.T
+    return t.contiguous()
+
+
+def _leaves(tree):
+    out = []
+    for v in tree.values():
+        if isinstance(v, dict):
+            out += _leaves(v)
+        else:
+            out.append(v)
+    return out
+
+
+def _rebuild(tree, it):
+    return {k: (_rebuild(v, it) if isinstance(v, dict) else next(it)) for k, v in tree.items()}
+
+
+class _NodeGenericFn(torch.autograd.Function):
+    """Fixed-step explicit Runge-Kutta solve of du/dt = model(u) for ANY model made of this package's layers, and its discrete
+    adjoint.  Forward: the stage inputs u + dt sum_j a_ij k_j and the step update are one ngpde_rk_stage_combine launch each,
+    the stages are the layers' own kernels; every stage keeps its (input, output) pair with the layer's pullback closure.
+    Backward: per stage, in reverse, K-bar_i = dt b_i lambda + dt sum_{j>i} a_ji U-bar_j (one launch), U-bar_i and the parameter
+    cotangents from the stage's pullback (the layers' backward kernels), parameter gradients accumulated by one launch each,
+    lambda += sum_j U-bar_j (one launch).  No torch element-wise kernel takes part.
+    [docs/src/tutorials/VMH.md:85-89 NeuralODE(VMHConv); graph_node.md:44-66; BASELINE config 3 "GAT as ODE RHS"]"""
+
+    @staticmethod
+    def forward(ctx, u, node, ps, st, *leaves):
+        a, b = TABLEAUS[node.solver]
+        dt, S = node.dt, len(b)
+        needs = any(ctx.needs_input_grad)
+        ucur = u.detach().contiguous()
+        tape = []
+        if needs:   # the stages' pullbacks are taken w.r.t. aliases of the parameters that are leaves of the inner graphs
+            inner = [p.detach().requires_grad_(p.requires_grad) if isinstance(p, torch.Tensor) else p for p in leaves]
+            ps_in = _rebuild(ps, iter(inner))
+        else:
+            inner, ps_in = list(leaves), ps
+        st_out = st
+        with (torch.enable_grad() if needs else torch.no_grad()):
+            for _ in range(node.n_steps):
+                ks, pairs = [], []
+                for i in range(S):
+                    terms = [ks[j] for j in range(i) if a[i][j] != 0.0]
+                    coefs = [dt * a[i][j] for j in range(i) if a[i][j] != 0.0]
+                    U = _combine(ucur, 1.0, terms, coefs) if terms else ucur
+                    if needs:
+                        U = U.detach().requires_grad_(True)
+                    k, st_out = node.model(U.T, ps_in, st_out)
+                    k = rows_of(k)
+                    if k.shape != ucur.shape:
+                        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                                     f"DimensionMismatch: the right-hand side maps {tuple(ucur.shape[::-1])} to "
+                                                     f"{tuple(k.shape[::-1])}; du/dt must have the shape of u")
+                    ks.append(k.detach())
+                    pairs.append((U, k))
+                ucur = _combine(ucur, 1.0, ks, [dt * bi for bi in b])
+                tape.append(pairs)
+        ctx.node, ctx.tape, ctx.inner, ctx.needs = node, tape if needs else None, inner, needs
+        ctx.st_out = st_out
+        return ucur
+
+    @staticmethod
+    def backward(ctx, duT):
+        node = ctx.node
+        a, b = TABLEAUS[node.solver]
+        dt, S = node.dt, len(b)
+        params = [p for p in ctx.inner if isinstance(p, torch.Tensor) and p.requires_grad]
+        acc = [None] * len(params)
+        lam = duT.contiguous()
+        for pairs in reversed(ctx.tape):
+            ubar = [None] * S
+            for i in reversed(range(S)):
+                terms = [ubar[j] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
+                coefs = [dt * a[j][i] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
+                if b[i] == 0.0 and not terms:
+                    continue
+                kbar = _combine(lam, dt * b[i], terms, coefs)
+                U, k = pairs[i]
+                grads = torch.autograd.grad(k, [U] + params, kbar, allow_unused=True)
+                if grads[0] is not None:
+                    ubar[i] = grads[0].contiguous()
+                for n, g in enumerate(grads[1:]):
+                    if g is None:
+                        continue
+                    if acc[n] is None:
+                        acc[n] = g
+                    else:       # same layout for every stage's cotangent of one parameter: combine in memory order
+                        _combine(_dense(acc[n]), 1.0, [_dense(g)], [1.0], out=_dense(acc[n]))
+            live = [x for x in ubar if x is not None]
+            if live:
+                lam = _combine(lam, 1.0, live, [1.0] * len(live))
+        ctx.tape = None
+        it = iter(acc)
+        out = [next(it) if (isinstance(p, torch.Tensor) and p.requires_grad) else None for p in ctx.inner]
+        return (lam, None, None, None, *out)
+
+
 class NeuralODE(AbstractExplicitLayer):
     """NeuralODE(model; solver="tsit5", tspan=(0, 1), n_steps=..., dt=None)
 
@@ -227,18 +350,9 @@ class NeuralODE(AbstractExplicitLayer):
             b2 = p2["bias"].reshape(-1) if "bias" in p2 else None
             uT = _NodeGCN2Fn.apply(u, rows_of(p1["weight"]), b1, rows_of(p2["weight"]), b2, plan)
             return uT.T, st
-        # generic right-hand side: explicit RK stepping through the layers' kernels
-        a, b = TABLEAUS[self.solver]
-        ucur = x
-        for _ in range(self.n_steps):
-            ks = []
-            for i in range(len(b)):
-                U = ucur
-                for j in range(i):
-                    if a[i][j] != 0.0:
-                        U = U + (self.dt * a[i][j]) * ks[j]
-                k, st = self.model(U, ps, st)
-                ks.append(k)
-            for i in range(len(b)):
-                ucur = ucur + (self.dt * b[i]) * ks[i]
-        return ucur, st
+        # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
+        # every combination of the discrete adjoint) one library launch
+        if not u.is_cuda:
+            raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, "NeuralODE: inputs must live on the GPU (no CPU fallback)")
+        uT = _NodeGenericFn.apply(u, self, ps, st, *_leaves(ps))
+        return uT.T, st

@@ -612,6 +612,91 @@ def test_gat_as_ode_right_hand_side_generic_solver_path():
         close(ps[k].grad, acc[k], rtol=5e-4, atol=5e-4, what=k)
 
 
+def _rk_oracle(rhs_fwd, rhs_bwd, names, shapes, u0, tab, dt, steps):
+    """u(T), du0 and summed parameter cotangents of loss = sum(u(T)) through the oracle's rk_solve / rk_adjoint"""
+    acc = {k: np.zeros(shapes[k]) for k in names}
+
+    def vjp(cache, kbar):
+        gr = rhs_bwd(cache, kbar)
+        return gr["x"], gr
+
+    def accumulate(gr):
+        for k in names:
+            acc[k] += np.asarray(gr[k]).reshape(acc[k].shape)
+    uT, tape = O.rk_solve(rhs_fwd, u0, O.TABLEAUS[tab], dt, steps)
+    du0 = O.rk_adjoint(vjp, tape, np.ones_like(uT), O.TABLEAUS[tab], dt, accumulate)
+    return uT, du0, acc
+
+
+@pytest.mark.parametrize("solver,steps", [("tsit5", 2), ("euler", 3)])
+def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps):
+    # BASELINE config 3 "as ODE RHS" on a graph whose tiles fit the LDS halo: every right-hand-side evaluation is the one-launch
+    # GAT layer, every Runge-Kutta combination (and every combination of the discrete adjoint) one ngpde_rk_stage_combine launch
+    n, H, C_ = 300, 4, 16
+    s, t = _local_graph(n, 77)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    og = O.Graph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, C_), "tanh", heads=H, concat=True, initialgraph=g)
+    node = ng.NeuralODE(l, solver=solver, n_steps=steps, dt=0.05)
+    ps, st = ng.setup(77, node)
+    ps = prep(ps, 77)
+    from ngpde_amd import functional as F
+    assert F.gat_layer_supported(l._graph(g).handle(), 64, H, C_)
+    u0 = torch.randn(64, n, device=DEV, requires_grad=True)
+    uT, _ = node(u0, ps, st)
+    pw = lambda k: ps[k].detach().cpu().double().numpy()
+    W, a, b = pw("weight"), pw("a"), pw("bias")
+    uTo, du0, acc = _rk_oracle(lambda u: O.gat_conv(u, W, a, b, og, H, C_, "tanh", concat=True), O.gat_conv_backward,
+                               ("weight", "a", "bias"), dict(weight=W.shape, a=a.shape, bias=b.shape),
+                               u0.detach().cpu().double().numpy(), solver, 0.05, steps)
+    close(uT, uTo, rtol=2e-4)
+    uT.sum().backward()
+    close(u0.grad, du0, rtol=5e-4, atol=1e-4)
+    for k in acc:
+        close(ps[k].grad, acc[k], rtol=5e-4, atol=5e-4, what=k)
+    # inference call (no tape) gives the same bits
+    with torch.no_grad():
+        uT2, _ = node(u0, ps, st)
+    assert torch.equal(uT2, uT.detach())
+
+
+def test_vmh_as_ode_right_hand_side():
+    # docs/src/tutorials/VMH.md:85-89: NeuralODE(VMHConv(phi, gamma)) -- the layer maps h features to h features and is
+    # integrated as du/dt; values and all gradients of two Tsit5 steps against the oracle's rk_solve / rk_adjoint
+    N, E, h = 250, 1800, 3
+    rng = np.random.default_rng(23)
+    g, og = rgraph(N, E, 23, ndata={"x": rng.random((2, N))})
+    phi = ng.Chain(ng.Dense(2 * h + 2, 24, "tanh"), ng.Dense(24, 16, "tanh"))
+    gam = ng.Chain(ng.Dense(h + 16, 20, "tanh"), ng.Dense(20, h))
+    l = ng.VMHConv(phi, gam, initialgraph=g)
+    node = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.1)
+    ps, st = ng.setup(23, node)
+    ps = prep(ps, 23)
+    u0 = torch.randn(h, N, device=DEV, requires_grad=True)
+    uT, _ = node(u0, ps, st)
+    ophi, ogam = omlp(phi, ps["ϕ"]), omlp(gam, ps["γ"])
+    tab, dt = O.TABLEAUS["tsit5"], 0.1
+    gphi = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ophi]
+    ggam = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ogam]
+
+    def vjp(cache, kbar):
+        gr = O.vmh_conv_backward(cache, kbar)
+        return gr["x"], gr
+
+    def accumulate(gr):
+        for dst, src in ((gphi, gr["phi"]), (ggam, gr["gamma"])):
+            for d_, s_ in zip(dst, src):
+                d_["weight"] += s_["weight"]
+                d_["bias"] += np.asarray(s_["bias"]).reshape(d_["bias"].shape)
+    uTo, tape = O.rk_solve(lambda u: O.vmh_conv(u, ophi, ogam, og), u0.detach().cpu().double().numpy(), tab, dt, 2)
+    close(uT, uTo, rtol=2e-4)
+    du0 = O.rk_adjoint(vjp, tape, np.ones_like(uTo), tab, dt, accumulate)
+    uT.sum().backward()
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gphi, phi)
+    n2, o2 = mlp_grad_pairs(ps["γ"], ggam, gam)
+    check_grads(ps, (n1 + n2, o1 + o2), u0, du0)
+
+
 # ---- fused message path (one launch) against the primitives and the oracle -------------------------------------------------
 
 @pytest.mark.parametrize("aggr", ["mean", "+", "max", "min"])
