@@ -170,6 +170,74 @@ def _rebuild(tree, it):
     return {k: (_rebuild(v, it) if isinstance(v, dict) else next(it)) for k, v in tree.items()}
 
 
+def _rk_forward(node, u, ps_in, st, needs, fresh=False):
+    """u(T) of the fixed-step solve; with `needs` also the tape: per step and stage the (stage input, stage output) pair whose
+    autograd closure is the layers' pullback.  fresh: the stage inputs get version counters of their own (a captured solve
+    refills its static input buffer before every replay; the closures are only ever run at capture time)"""
+    a, b = TABLEAUS[node.solver]
+    dt, S = node.dt, len(b)
+    ucur, tape, st_out = u, [], st
+    with (torch.enable_grad() if needs else torch.no_grad()):
+        for _ in range(node.n_steps):
+            ks, pairs = [], []
+            for i in range(S):
+                terms = [ks[j] for j in range(i) if a[i][j] != 0.0]
+                coefs = [dt * a[i][j] for j in range(i) if a[i][j] != 0.0]
+                U = _combine(ucur, 1.0, terms, coefs) if terms else ucur
+                if needs:
+                    U = (U.data if fresh else U.detach()).requires_grad_(True)
+                k, st_out = node.model(U.T, ps_in, st_out)
+                k = rows_of(k)
+                if k.shape != ucur.shape:
+                    raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                                 f"DimensionMismatch: the right-hand side maps {tuple(ucur.shape[::-1])} to "
+                                                 f"{tuple(k.shape[::-1])}; du/dt must have the shape of u")
+                ks.append(k.detach())
+                pairs.append((U, k))
+            ucur = _combine(ucur, 1.0, ks, [dt * bi for bi in b])
+            if needs:
+                tape.append(pairs)
+    return ucur, tape, st_out
+
+
+def _rk_backward(node, tape, duT, params, retain=False):
+    """discrete adjoint of _rk_forward: (du0, cotangents of `params`)"""
+    a, b = TABLEAUS[node.solver]
+    dt, S = node.dt, len(b)
+    acc = [None] * len(params)
+    lam = duT
+    for pairs in reversed(tape):
+        ubar = [None] * S
+        for i in reversed(range(S)):
+            terms = [ubar[j] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
+            coefs = [dt * a[j][i] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
+            if b[i] == 0.0 and not terms:
+                continue
+            kbar = _combine(lam, dt * b[i], terms, coefs)
+            U, k = pairs[i]
+            grads = torch.autograd.grad(k, [U] + params, kbar, allow_unused=True, retain_graph=retain)
+            if grads[0] is not None:
+                ubar[i] = grads[0].contiguous()
+            for n, g in enumerate(grads[1:]):
+                if g is None:
+                    continue
+                if acc[n] is None:
+                    acc[n] = g
+                else:       # same layout for every stage's cotangent of one parameter: combine in memory order
+                    _combine(_dense(acc[n]), 1.0, [_dense(g)], [1.0], out=_dense(acc[n]))
+        live = [x for x in ubar if x is not None]
+        if live:
+            lam = _combine(lam, 1.0, live, [1.0] * len(live))
+    return lam, acc
+
+
+def _inner_params(ps, leaves, fresh=False):
+    """aliases of the parameters that are leaves of the stages' autograd closures, and the tree holding them (fresh: with
+    version counters of their own, so that an optimiser's in-place update between the captures does not invalidate them)"""
+    inner = [(p.data if fresh else p.detach()).requires_grad_(p.requires_grad) if isinstance(p, torch.Tensor) else p for p in leaves]
+    return inner, _rebuild(ps, iter(inner))
+
+
 class _NodeGenericFn(torch.autograd.Function):
     """Fixed-step explicit Runge-Kutta solve of du/dt = model(u) for ANY model made of this package's layers, and its discrete
     adjoint.  Forward: the stage inputs u + dt sum_j a_ij k_j and the step update are one ngpde_rk_stage_combine launch each,
@@ -181,74 +249,77 @@ class _NodeGenericFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, node, ps, st, *leaves):
-        a, b = TABLEAUS[node.solver]
-        dt, S = node.dt, len(b)
         needs = any(ctx.needs_input_grad)
-        ucur = u.detach().contiguous()
-        tape = []
-        if needs:   # the stages' pullbacks are taken w.r.t. aliases of the parameters that are leaves of the inner graphs
-            inner = [p.detach().requires_grad_(p.requires_grad) if isinstance(p, torch.Tensor) else p for p in leaves]
-            ps_in = _rebuild(ps, iter(inner))
-        else:
-            inner, ps_in = list(leaves), ps
-        st_out = st
-        with (torch.enable_grad() if needs else torch.no_grad()):
-            for _ in range(node.n_steps):
-                ks, pairs = [], []
-                for i in range(S):
-                    terms = [ks[j] for j in range(i) if a[i][j] != 0.0]
-                    coefs = [dt * a[i][j] for j in range(i) if a[i][j] != 0.0]
-                    U = _combine(ucur, 1.0, terms, coefs) if terms else ucur
-                    if needs:
-                        U = U.detach().requires_grad_(True)
-                    k, st_out = node.model(U.T, ps_in, st_out)
-                    k = rows_of(k)
-                    if k.shape != ucur.shape:
-                        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
-                                                     f"DimensionMismatch: the right-hand side maps {tuple(ucur.shape[::-1])} to "
-                                                     f"{tuple(k.shape[::-1])}; du/dt must have the shape of u")
-                    ks.append(k.detach())
-                    pairs.append((U, k))
-                ucur = _combine(ucur, 1.0, ks, [dt * bi for bi in b])
-                tape.append(pairs)
-        ctx.node, ctx.tape, ctx.inner, ctx.needs = node, tape if needs else None, inner, needs
-        ctx.st_out = st_out
-        return ucur
+        inner, ps_in = _inner_params(ps, leaves) if needs else (list(leaves), ps)
+        uT, tape, _ = _rk_forward(node, u.detach().contiguous(), ps_in, st, needs)
+        ctx.node, ctx.tape, ctx.inner = node, tape if needs else None, inner
+        return uT
 
     @staticmethod
     def backward(ctx, duT):
-        node = ctx.node
-        a, b = TABLEAUS[node.solver]
-        dt, S = node.dt, len(b)
         params = [p for p in ctx.inner if isinstance(p, torch.Tensor) and p.requires_grad]
-        acc = [None] * len(params)
-        lam = duT.contiguous()
-        for pairs in reversed(ctx.tape):
-            ubar = [None] * S
-            for i in reversed(range(S)):
-                terms = [ubar[j] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
-                coefs = [dt * a[j][i] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
-                if b[i] == 0.0 and not terms:
-                    continue
-                kbar = _combine(lam, dt * b[i], terms, coefs)
-                U, k = pairs[i]
-                grads = torch.autograd.grad(k, [U] + params, kbar, allow_unused=True)
-                if grads[0] is not None:
-                    ubar[i] = grads[0].contiguous()
-                for n, g in enumerate(grads[1:]):
-                    if g is None:
-                        continue
-                    if acc[n] is None:
-                        acc[n] = g
-                    else:       # same layout for every stage's cotangent of one parameter: combine in memory order
-                        _combine(_dense(acc[n]), 1.0, [_dense(g)], [1.0], out=_dense(acc[n]))
-            live = [x for x in ubar if x is not None]
-            if live:
-                lam = _combine(lam, 1.0, live, [1.0] * len(live))
+        lam, acc = _rk_backward(ctx.node, ctx.tape, duT.contiguous(), params)
         ctx.tape = None
         it = iter(acc)
         out = [next(it) if (isinstance(p, torch.Tensor) and p.requires_grad) else None for p in ctx.inner]
         return (lam, None, None, None, *out)
+
+
+class _CapturedSolve:
+    """The generic solve as two HIP graphs (NeuralODE(..., capture=True)): the forward stepping loop -- every layer launch
+    and every Runge-Kutta combination of all steps -- is captured once and replayed per call, and so is the whole discrete
+    adjoint the first time a backward pass asks for it.  Static buffers: the input is copied in, u(T) and the cotangents are
+    the graphs' own buffers (valid until the next call of the same NeuralODE on the same arguments).  The captures bake in the
+    addresses of the parameters and of the graph's derived arrays: a call with other parameter tensors, another graph or
+    another input shape captures anew (NeuralODE keeps the most recent few)."""
+
+    def __init__(self, node, u, ps, st, leaves, needs):
+        self.node, self.needs = node, needs
+        self.leaves = list(leaves)                         # keeps the captured addresses alive
+        self.inner, self.ps_in = _inner_params(ps, leaves, fresh=True) if needs else (list(leaves), ps)
+        self.params = [p for p in self.inner if isinstance(p, torch.Tensor) and p.requires_grad] if needs else []
+        self.u_static = u.detach().clone()
+        self.st = st
+        # one eager solve on a side stream first: graph handles, workspaces and lazily built tables exist before the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _rk_forward(node, self.u_static, self.ps_in, st, False)
+        torch.cuda.current_stream().wait_stream(side)
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.uT_static, self.tape, _ = _rk_forward(node, self.u_static, self.ps_in, st, needs, fresh=True)
+        self.bwd_graph = None
+
+    def forward(self, u):
+        self.u_static.copy_(u)
+        self.fwd_graph.replay()
+        return self.uT_static
+
+    def backward(self, duT):
+        if self.bwd_graph is None:
+            self.duT_static = duT.detach().clone()
+            self.bwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
+                self.lam_static, self.acc_static = _rk_backward(self.node, self.tape, self.duT_static, self.params, retain=True)
+        else:
+            self.duT_static.copy_(duT)
+        self.bwd_graph.replay()
+        return self.lam_static, self.acc_static
+
+
+class _NodeCapturedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, solve, *leaves):
+        ctx.solve = solve
+        return solve.forward(u.detach().contiguous()).clone()
+
+    @staticmethod
+    def backward(ctx, duT):
+        lam, acc = ctx.solve.backward(duT.contiguous())
+        it = iter(acc)
+        out = [next(it) if (isinstance(p, torch.Tensor) and p.requires_grad) else None for p in ctx.solve.inner]
+        return (lam.clone(), None, *[None if g is None else g.clone() for g in out])
 
 
 class NeuralODE(AbstractExplicitLayer):
@@ -256,10 +327,12 @@ class NeuralODE(AbstractExplicitLayer):
 
     A Lux container with the single field `model`, so `ps` and `st` are the model's own
     (graph_node.md:44-52, :59-66).  `solver` is "euler" or "tsit5"; the step is fixed:
-    dt = (tspan[1] - tspan[0]) / n_steps unless given.
+    dt = (tspan[1] - tspan[0]) / n_steps unless given.  capture=True (an extension, for right-hand sides other than the
+    two-GCNConv chain, which is always device-resident): the whole solve and its adjoint are captured into HIP graphs at
+    the first call and replayed afterwards (_CapturedSolve).
     """
 
-    def __init__(self, model, *, solver="tsit5", tspan=(0.0, 1.0), n_steps=10, dt=None):
+    def __init__(self, model, *, solver="tsit5", tspan=(0.0, 1.0), n_steps=10, dt=None, capture=False):
         solver = solver.lower()
         if solver not in TABLEAUS:
             raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, f"unknown solver {solver!r}; one of {list(TABLEAUS)}")
@@ -267,6 +340,8 @@ class NeuralODE(AbstractExplicitLayer):
         self.dt = float(dt) if dt is not None else (self.tspan[1] - self.tspan[0]) / self.n_steps
         self._plans = {}
         self._no_member_plan = False
+        self.capture = bool(capture)      # generic right-hand sides: replay the whole solve / adjoint from HIP graphs
+        self._captured = {}
 
     def initialparameters(self, rng):
         return self.model.initialparameters(rng)
@@ -354,5 +429,17 @@ class NeuralODE(AbstractExplicitLayer):
         # every combination of the discrete adjoint) one library launch
         if not u.is_cuda:
             raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, "NeuralODE: inputs must live on the GPU (no CPU fallback)")
-        uT = _NodeGenericFn.apply(u, self, ps, st, *_leaves(ps))
+        leaves = _leaves(ps)
+        if self.capture:
+            needs = torch.is_grad_enabled() and (u.requires_grad or any(isinstance(p, torch.Tensor) and p.requires_grad for p in leaves))
+            g = st.get("graph") if isinstance(st, dict) else None
+            key = (tuple(u.shape), needs, id(g), tuple(p.data_ptr() if isinstance(p, torch.Tensor) else id(p) for p in leaves))
+            solve = self._captured.get(key)
+            if solve is None:
+                solve = self._captured[key] = _CapturedSolve(self, u, ps, st, leaves, needs)
+                while len(self._captured) > self.max_plans:
+                    self._captured.pop(next(iter(self._captured)))
+            uT = _NodeCapturedFn.apply(u, solve, *leaves)
+            return uT.T, st
+        uT = _NodeGenericFn.apply(u, self, ps, st, *leaves)
         return uT.T, st

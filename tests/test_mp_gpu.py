@@ -660,6 +660,45 @@ def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps):
     assert torch.equal(uT2, uT.detach())
 
 
+def test_captured_generic_solve_replays_and_follows_parameter_updates():
+    # NeuralODE(..., capture=True): the whole stepping loop and the whole discrete adjoint are HIP graphs captured at the first
+    # call; replays must reproduce the eager path bit for bit, for new inputs and after an in-place parameter update
+    n, H, C_ = 300, 4, 16
+    s, t = _local_graph(n, 78)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, C_), "tanh", heads=H, concat=True, initialgraph=g)
+    eager = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05)
+    captured = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05, capture=True)
+    ps, st = ng.setup(78, eager)
+    ps = prep(ps, 78)
+
+    def run(node, u):
+        for v in ps.values():
+            v.grad = None
+        u = u.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * uT).sum().backward()
+        return uT.detach().clone(), u.grad.clone(), {k: v.grad.clone() for k, v in ps.items()}
+
+    for trial in range(3):
+        u = torch.randn(64, n, device=DEV)
+        if trial == 2:
+            with torch.no_grad():
+                ps["bias"].mul_(0.5)
+                ps["weight"].add_(0.01)
+        ref = run(eager, u)
+        got = run(captured, u)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"trial {trial}"
+        for k in ps:
+            assert torch.equal(got[2][k], ref[2][k]), (trial, k)
+    assert len(captured._captured) == 1
+    with torch.no_grad():                       # inference capture (no tape) next to the training capture
+        u = torch.randn(64, n, device=DEV)
+        a1, _ = captured(u, ps, st)
+        a2, _ = eager(u, ps, st)
+    assert torch.equal(a1, a2) and len(captured._captured) == 2
+
+
 def test_vmh_as_ode_right_hand_side():
     # docs/src/tutorials/VMH.md:85-89: NeuralODE(VMHConv(phi, gamma)) -- the layer maps h features to h features and is
     # integrated as du/dt; values and all gradients of two Tsit5 steps against the oracle's rk_solve / rk_adjoint
