@@ -100,10 +100,67 @@ def cpu_baseline(s, t, u0, w1, b1, w2, b2, budget_s=12.0):
         best_t = run(1)
     n = int(max(1, min(ODE_STEPS, budget_s / max(best_t, 1e-6))))
     tn = run(n) if n > 1 else best_t
-    return {"value": n / tn, "unit": "ODE-steps/s", "cores": best_n, "kind": "port",
-            "sample": f"{n} Tsit5 step(s) fwd+bwd of the same C2 workload (C restatement of the reference "
-                      f"algorithm, OpenMP, fastest of the probed team sizes = {best_n} of {cores} host threads; "
-                      f"not the Julia package)"}, outs
+    out = {"value": n / tn, "unit": "ODE-steps/s", "cores": best_n, "kind": "port",
+           "sample": f"{n} Tsit5 step(s) fwd+bwd of the same C2 workload (C restatement of the reference "
+                     f"algorithm, OpenMP, fastest of the probed team sizes = {best_n} of {cores} host threads; "
+                     f"not the Julia package)", "variants": {}}
+    # variant (i) of SURVEY 8(d): serial gather / scatter / sparse product (NNlib 0.8 on CPU) + threaded dense products
+    if gomp is not None and hasattr(lib, "ngo_set_serial_sparse"):
+        lib.ngo_set_serial_sparse(1)
+        t1 = run(1)
+        k = int(max(1, min(10, 4.0 / max(t1, 1e-6))))
+        tk = run(k) if k > 1 else t1
+        lib.ngo_set_serial_sparse(0)
+        out["variants"]["serial_sparse_threaded_gemm"] = {
+            "value": k / tk, "unit": "ODE-steps/s", "cores": best_n,
+            "sample": f"{k} Tsit5 step(s): sparse products on one thread (NNlib 0.8's serial gather / scatter), dense products on "
+                      f"{best_n} threads"}
+    try:
+        out["variants"]["torch_cpu"] = torch_cpu_point(s, t, u0, w1, b1, w2, b2)
+    except Exception as ex:          # an independent third point: never fails the bench
+        out["variants"]["torch_cpu"] = {"error": repr(ex)[:200]}
+    return out, outs
+
+
+def torch_cpu_point(s, t, u0, w1, b1, w2, b2, budget_s=4.0):
+    """An independent CPU point: the same two-layer GCN right-hand side and Tsit5 steps written with torch CPU ops (index_add_
+    aggregation, mm, autograd for the discrete adjoint), float32, torch's own thread pool"""
+    a = [[], [0.161], [-0.008480655492356989, 0.335480655492357], [2.8971530571054935, -6.359448489975075, 4.3622954328695815],
+         [5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525],
+         [5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383]]
+    b = [0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774]
+    n = u0.shape[0]
+    ss = torch.as_tensor(np.concatenate([s, np.arange(n)]), dtype=torch.int64)
+    tt = torch.as_tensor(np.concatenate([t, np.arange(n)]), dtype=torch.int64)
+    deg = torch.zeros(n).index_add_(0, tt, torch.ones(tt.numel()))
+    c = deg.rsqrt().unsqueeze(1)
+    W = [torch.tensor(w1, requires_grad=True), torch.tensor(w2, requires_grad=True)]
+    B = [torch.tensor(b1, requires_grad=True), torch.tensor(b2, requires_grad=True)]
+
+    def layer(x, k):
+        agg = torch.zeros_like(x).index_add_(0, tt, (x * c)[ss]) * c
+        return torch.relu(agg @ W[k] + B[k])
+
+    def steps(k):
+        u = torch.tensor(u0, requires_grad=True)
+        t0 = time.perf_counter()
+        x = u
+        for _ in range(k):
+            ks = []
+            for i in range(6):
+                U = x
+                for j in range(i):
+                    U = U + (DT * a[i][j]) * ks[j]
+                ks.append(layer(layer(U, 0), 1))
+            for i in range(6):
+                x = x + (DT * b[i]) * ks[i]
+        x.sum().backward()
+        return time.perf_counter() - t0
+    t1 = steps(1)
+    k = int(max(1, min(10, budget_s / max(t1, 1e-6))))
+    tk = steps(k) if k > 1 else t1
+    return {"value": k / tk, "unit": "ODE-steps/s", "cores": torch.get_num_threads(),
+            "sample": f"{k} Tsit5 step(s) fwd+bwd, torch CPU ops (index_add_ + mm + autograd), {torch.get_num_threads()} threads"}
 
 
 # ---- secondary workloads: one layer of BASELINE configs 3-5 (never in `value`) ---------------------------------------------
@@ -356,11 +413,15 @@ def main():
         for _ in range(n_warmup):
             step()
         fence()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]   # per-step device time, for the median
         t0 = time.perf_counter()
-        for _ in range(n_steps):
+        marks[0].record()
+        for k in range(n_steps):
             step()
+            marks[k + 1].record()
         fence()
         elapsed = time.perf_counter() - t0
+        job.step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(n_steps))
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -383,6 +444,7 @@ def main():
         return us, cnt
 
     elapsed, ms_fwd, ms_bwd, plan = job(1, args.steps, args.warmup)
+    step_ms = list(job.step_ms)      # this rank's per-step device times of the timed region (`value` stays K steps / wall time)
 
     def role_table(plan, traj):
         """kernel roles of a plan, their SURVEY 8(d) algorithmic bytes per launch and their measured device time per launch"""
@@ -420,6 +482,8 @@ def main():
             "metric": "ODE-steps/sec (fwd+bwd) on 16k-node graph, 64-d feats",
             "value": round(value, 2), "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
+            "median_ms_per_step": round(float(np.median(step_ms)), 4),
+            "median_value": round(world * ODE_STEPS / (float(np.median(step_ms)) * 1e-3), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: 16384-node / 131072-edge closest-pairs radius graph, 64-d feats, "

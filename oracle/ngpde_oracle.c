@@ -31,6 +31,11 @@
 
 enum { ACT_IDENTITY = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_SWISH = 4 };
 
+/* bench.py's CPU-baseline variant (i): NNlib 0.8's gather / scatter and the sparse product are serial loops while BLAS gemm is
+ * threaded -- with this flag set the OpenMP build keeps the sparse products on one thread and threads only the dense products */
+static int g_serial_sparse = 0;
+void ngo_set_serial_sparse(int on) { g_serial_sparse = on; }
+
 static float actf(int a, float z) {
   switch (a) {
     case ACT_RELU: return z > 0.f ? z : 0.f;
@@ -144,7 +149,7 @@ static void norm_spmm(int64_t n, int d, const int64_t *ptr, const int64_t *idx, 
   float *x1 = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1) * d);       /* x .* c' temporary (:226) */
   for (int64_t i = 0; i < n; ++i)
     for (int f = 0; f < d; ++f) x1[i * d + f] = x[i * d + f] * c[i];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (!g_serial_sparse)
   for (int64_t j = 0; j < n; ++j) {
     float *o = out + j * d;
     for (int f = 0; f < d; ++f) o[f] = 0.f;

@@ -1,0 +1,255 @@
+/* A second plain-C caller of the drop-in boundary (include/ngpde.h), for the entries beyond GCNConv: the fixed-step solver
+ * plan (ngpde_node_gcn2_*), the message path of the edge-function layers (ngpde_dense_forward, ngpde_edge_mlp_forward next to
+ * the primitives ngpde_edge_combine_forward / ngpde_segment_reduce_forward), the reassociated and the literal GNOConv message
+ * (ngpde_gno_apply_forward / ngpde_gno_contract_forward), the one-launch GAT layer next to its composition
+ * (ngpde_gat_layer_forward vs ngpde_dense_forward + ngpde_gat_forward + ngpde_bias_act_forward) and ngpde_rk_stage_combine.
+ * No Python, torch or C++ on the calling side.  Checkers: the C restatement of the reference solver (oracle/ngpde_oracle.c) and
+ * plain double-precision loops over the CSR lists the library hands out.  Exit code 0 = every comparison within tolerance.
+ * Built and run by tests/test_c_abi_gpu.py. */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ngpde.h"
+
+int ngo_node_gcn2(int64_t n, int64_t e, const int64_t *s, const int64_t *t, int d, int act, int tableau, int nsteps, float dt,
+                  int with_grad, const float *u0, const float *w1, const float *b1, const float *w2, const float *b2, float *uT,
+                  float *du0, float *dw1, float *db1, float *dw2, float *db2);
+
+#define CHECK_HIP(x)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } \
+  } while (0)
+#define CHECK_NG(x)                                                                   \
+  do {                                                                                \
+    int32_t s_ = (x);                                                                 \
+    if (s_ != NGPDE_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, s_, ngpde_last_error()); return 3; } \
+  } while (0)
+
+static uint64_t rng_state = 0x2545F4914F6CDD1Dull;
+static float rnd(void) {
+  rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+  return (float)((double)(rng_state >> 11) / 9007199254740992.0 * 2.0 - 1.0);
+}
+static float *host_rand(size_t n, float scale) {
+  float *h = malloc(sizeof(float) * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) h[i] = rnd() * scale;
+  return h;
+}
+static float *dev_copy(const float *h, size_t n) {
+  float *d = NULL;
+  if (hipMalloc((void **)&d, (n ? n : 1) * sizeof(float)) != hipSuccess) return NULL;
+  if (h && n && hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return NULL;
+  return d;
+}
+static float *host_copy(const float *d, size_t n) {
+  float *h = malloc(sizeof(float) * (n ? n : 1));
+  if (hipMemcpy(h, d, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return NULL;
+  return h;
+}
+static double max_rel(const float *a, const float *b, size_t n) {
+  double err = 0, ref = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double d = fabs((double)a[i] - (double)b[i]);
+    if (d > err) err = d;
+    if (fabs((double)b[i]) > ref) ref = fabs((double)b[i]);
+  }
+  return err / (ref > 1e-30 ? ref : 1e-30);
+}
+static int fails = 0;
+static void report(const char *what, double err, double tol) {
+  printf("%-34s %.2e (tol %.0e)%s\n", what, err, tol, err <= tol ? "" : "   <-- FAIL");
+  if (!(err <= tol)) ++fails;
+}
+
+int main(void) {
+  const int64_t n = 1024, e = 5 * n;
+  int64_t *s = malloc(sizeof(int64_t) * e), *t = malloc(sizeof(int64_t) * e);
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {   /* ring with chords; the last one directed */
+    const int64_t a = (i + 1) % n, b = (i + 5) % n, c = (i + 9) % n;
+    s[m] = i; t[m++] = a; s[m] = a; t[m++] = i;
+    s[m] = i; t[m++] = b; s[m] = b; t[m++] = i;
+    s[m] = i; t[m++] = c;
+  }
+  printf("%s\n", ngpde_version());
+  ngpde_graph_t *g = NULL;
+  CHECK_NG(ngpde_graph_create(n, e, s, t, /*index_base=*/0, 1, &g));
+  CHECK_NG(ngpde_graph_set_gcn_norm(g, /*add_self_loops=*/1, NULL, 0));
+
+  /* ---- 1. solver plan: 3 Tsit5 steps of du/dt = GCNConv(GCNConv(u)), forward + discrete adjoint of sum(u(T)) ---- */
+  {
+    const int d = 64, steps = 3;
+    const float dt = 0.1f;
+    float *u0 = host_rand(n * d, 1.f), *w1 = host_rand(d * d, 0.2f), *w2 = host_rand(d * d, 0.2f), *b1 = host_rand(d, 0.1f),
+          *b2 = host_rand(d, 0.1f), *ones = malloc(sizeof(float) * n * d);
+    for (int64_t i = 0; i < n * d; ++i) ones[i] = 1.f;
+    float *u0_d = dev_copy(u0, n * d), *w1_d = dev_copy(w1, d * d), *w2_d = dev_copy(w2, d * d), *b1_d = dev_copy(b1, d),
+          *b2_d = dev_copy(b2, d), *ones_d = dev_copy(ones, n * d), *uT_d = dev_copy(NULL, n * d), *du0_d = dev_copy(NULL, n * d),
+          *dw1_d = dev_copy(NULL, d * d), *dw2_d = dev_copy(NULL, d * d), *db1_d = dev_copy(NULL, d), *db2_d = dev_copy(NULL, d);
+    ngpde_node_t *plan = NULL;
+    CHECK_NG(ngpde_node_gcn2_create(g, d, NGPDE_ACT_RELU, NGPDE_TABLEAU_TSIT5, steps, dt, 1, &plan));
+    int32_t fl = 0, bl = 0, flags = 0, pending = 0, fault = 0;
+    uint64_t gen = 0;
+    CHECK_NG(ngpde_node_launch_count(plan, &fl, &bl));
+    CHECK_NG(ngpde_node_flags(plan, &flags));
+    CHECK_NG(ngpde_node_gcn2_forward(plan, u0_d, w1_d, b1_d, w2_d, b2_d, uT_d, NULL));
+    CHECK_NG(ngpde_node_generation(plan, &gen, &pending));
+    if (gen != 1 || !pending) { fprintf(stderr, "generation %llu pending %d\n", (unsigned long long)gen, pending); return 4; }
+    CHECK_NG(ngpde_node_expect_generation(plan, gen));
+    if (ngpde_node_expect_generation(plan, gen + 1) != NGPDE_ERR_STATE) return 4;      /* the error convention */
+    CHECK_NG(ngpde_node_gcn2_backward(plan, ones_d, du0_d, dw1_d, db1_d, dw2_d, db2_d, NULL));
+    CHECK_NG(ngpde_node_fault(plan, NULL, &fault));
+    CHECK_HIP(hipDeviceSynchronize());
+    printf("plan: %d + %d launches, flags 0x%x, tape %.1f MB, fault %d\n", fl, bl, flags, ngpde_node_tape_bytes(plan) / 1e6, fault);
+    if (fault) return 4;
+    float *uT = host_copy(uT_d, n * d), *du0 = host_copy(du0_d, n * d), *dw1 = host_copy(dw1_d, d * d), *dw2 = host_copy(dw2_d, d * d),
+          *db1 = host_copy(db1_d, d), *db2 = host_copy(db2_d, d);
+    float *uTo = malloc(sizeof(float) * n * d), *du0o = malloc(sizeof(float) * n * d), *dw1o = malloc(sizeof(float) * d * d),
+          *dw2o = malloc(sizeof(float) * d * d), *db1o = malloc(sizeof(float) * d), *db2o = malloc(sizeof(float) * d);
+    if (ngo_node_gcn2(n, e, s, t, d, NGPDE_ACT_RELU, 1, steps, dt, 1, u0, w1, b1, w2, b2, uTo, du0o, dw1o, db1o, dw2o, db2o)) return 5;
+    report("node_gcn2 u(T)", max_rel(uT, uTo, n * d), 2e-4);
+    report("node_gcn2 du0", max_rel(du0, du0o, n * d), 1e-3);
+    report("node_gcn2 dW1", max_rel(dw1, dw1o, d * d), 1e-3);
+    report("node_gcn2 dW2", max_rel(dw2, dw2o, d * d), 1e-3);
+    report("node_gcn2 db1", max_rel(db1, db1o, d), 1e-3);
+    report("node_gcn2 db2", max_rel(db2, db2o, d), 1e-3);
+    CHECK_NG(ngpde_node_destroy(plan));
+  }
+
+  /* the lists by target (p order) as the library holds them, for the loop checkers below */
+  const int32_t *rp_d = NULL, *col_d = NULL, *eid_d = NULL;
+  CHECK_NG(ngpde_graph_csr_by_target(g, &rp_d, &col_d, &eid_d));
+  int32_t *rp = malloc(sizeof(int32_t) * (n + 1)), *col = malloc(sizeof(int32_t) * e);
+  CHECK_HIP(hipMemcpy(rp, rp_d, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(col, col_d, sizeof(int32_t) * e, hipMemcpyDeviceToHost));
+
+  /* ---- 2. message path of an edge-function layer: m_i = mean_e tanh(W2 tanh(P[t] + Q[s]) + b2), P = Dense(x), Q = Dense(x) ---- */
+  {
+    const int din = 12, h1 = 32, dw = 16;
+    float *x = host_rand(n * din, 1.f), *wp = host_rand(din * h1, 0.3f), *wq = host_rand(din * h1, 0.3f), *bp = host_rand(h1, 0.1f),
+          *w2 = host_rand(h1 * dw, 0.3f), *b2 = host_rand(dw, 0.1f);
+    float *x_d = dev_copy(x, n * din), *wp_d = dev_copy(wp, din * h1), *wq_d = dev_copy(wq, din * h1), *bp_d = dev_copy(bp, h1),
+          *w2_d = dev_copy(w2, h1 * dw), *b2_d = dev_copy(b2, dw), *P_d = dev_copy(NULL, n * h1), *Q_d = dev_copy(NULL, n * h1),
+          *out_d = dev_copy(NULL, n * dw), *a1_d = dev_copy(NULL, e * h1), *m_d = dev_copy(NULL, e * dw), *out2_d = dev_copy(NULL, n * dw);
+    const float *seg[1] = {x_d};
+    const int32_t wdt[1] = {din}, rdv[1] = {1};
+    CHECK_NG(ngpde_dense_forward(n, 1, seg, wdt, rdv, h1, NGPDE_ACT_IDENTITY, wp_d, bp_d, P_d, NULL, NULL));
+    CHECK_NG(ngpde_dense_forward(n, 1, seg, wdt, rdv, h1, NGPDE_ACT_IDENTITY, wq_d, NULL, Q_d, NULL, NULL));
+    const int32_t tdout[1] = {dw}, tact[1] = {NGPDE_ACT_TANH};
+    const float *tw[1] = {w2_d}, *tb[1] = {b2_d};
+    float *saves[2] = {NULL, NULL};
+    if (!ngpde_edge_mlp_supported(g, h1, 1, tdout)) { fprintf(stderr, "fused message path not available\n"); return 6; }
+    CHECK_NG(ngpde_edge_mlp_forward(g, h1, NGPDE_ACT_TANH, P_d, Q_d, NULL, 1, tdout, tact, tw, tb, NGPDE_AGGR_MEAN, out_d, saves, NULL));
+    /* the same through the primitives */
+    CHECK_NG(ngpde_edge_combine_forward(g, h1, NGPDE_ACT_TANH, P_d, Q_d, NULL, a1_d, NULL, NULL));
+    const float *seg2[1] = {a1_d};
+    const int32_t wdt2[1] = {h1};
+    CHECK_NG(ngpde_dense_forward(e, 1, seg2, wdt2, rdv, dw, NGPDE_ACT_TANH, w2_d, b2_d, m_d, NULL, NULL));
+    CHECK_NG(ngpde_segment_reduce_forward(g, dw, NGPDE_AGGR_MEAN, m_d, out2_d, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float *out = host_copy(out_d, n * dw), *out2 = host_copy(out2_d, n * dw), *ref = calloc(n * dw, sizeof(float));
+    double *P = calloc(n * h1, sizeof(double)), *Q = calloc(n * h1, sizeof(double));
+    for (int64_t i = 0; i < n; ++i)
+      for (int o = 0; o < h1; ++o) {
+        double sp = bp[o], sq = 0;
+        for (int k = 0; k < din; ++k) { sp += (double)x[i * din + k] * wp[k * h1 + o]; sq += (double)x[i * din + k] * wq[k * h1 + o]; }
+        P[i * h1 + o] = sp; Q[i * h1 + o] = sq;
+      }
+    for (int64_t i = 0; i < n; ++i) {
+      double acc[64] = {0};
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+        double a1[64];
+        for (int o = 0; o < h1; ++o) a1[o] = tanh(P[i * h1 + o] + Q[(int64_t)col[p] * h1 + o]);
+        for (int o = 0; o < dw; ++o) {
+          double z = b2[o];
+          for (int k = 0; k < h1; ++k) z += a1[k] * w2[k * dw + o];
+          acc[o] += tanh(z);
+        }
+      }
+      for (int o = 0; o < dw; ++o) ref[i * dw + o] = (float)(rp[i + 1] > rp[i] ? acc[o] / (rp[i + 1] - rp[i]) : 0.0);
+    }
+    report("edge_mlp_forward (one launch)", max_rel(out, ref, n * dw), 2e-4);
+    report("primitives (combine/dense/reduce)", max_rel(out2, ref, n * dw), 2e-4);
+  }
+
+  /* ---- 3. GNOConv message: m_p = reshape(K_p, out, in) h[s_p]; reassociated form m_p = T[s_p] z_p + Bh[s_p] ---- */
+  {
+    const int cin = 8, cout = 8, kdim = 16;
+    float *h = host_rand(n * cin, 1.f), *z = host_rand(e * kdim, 1.f), *w2 = host_rand(kdim * cin * cout, 0.3f), *b2 = host_rand(cin * cout, 0.2f);
+    /* K_p = W2^T z_p + b2 (element o + cout*i), T_j[o][k] = sum_i W2[k][o + cout*i] h_j[i], Bh_j[o] = sum_i b2[o + cout*i] h_j[i] */
+    float *K = malloc(sizeof(float) * e * cin * cout), *T = malloc(sizeof(float) * n * cout * kdim), *Bh = malloc(sizeof(float) * n * cout);
+    for (int64_t p = 0; p < e; ++p)
+      for (int r = 0; r < cin * cout; ++r) {
+        double v = b2[r];
+        for (int k = 0; k < kdim; ++k) v += (double)z[p * kdim + k] * w2[k * cin * cout + r];
+        K[p * cin * cout + r] = (float)v;
+      }
+    for (int64_t j = 0; j < n; ++j)
+      for (int o = 0; o < cout; ++o) {
+        double bh = 0;
+        for (int i = 0; i < cin; ++i) bh += (double)b2[o + cout * i] * h[j * cin + i];
+        Bh[j * cout + o] = (float)bh;
+        for (int k = 0; k < kdim; ++k) {
+          double v = 0;
+          for (int i = 0; i < cin; ++i) v += (double)w2[k * cin * cout + o + cout * i] * h[j * cin + i];
+          T[(j * cout + o) * kdim + k] = (float)v;
+        }
+      }
+    float *h_d = dev_copy(h, n * cin), *z_d = dev_copy(z, e * kdim), *K_d = dev_copy(K, e * cin * cout), *T_d = dev_copy(T, n * cout * kdim),
+          *Bh_d = dev_copy(Bh, n * cout), *m1_d = dev_copy(NULL, e * cout), *m2_d = dev_copy(NULL, e * cout);
+    if (!ngpde_gno_apply_supported(cout, kdim)) return 7;
+    CHECK_NG(ngpde_gno_apply_forward(g, cout, kdim, T_d, Bh_d, z_d, m1_d, NULL));
+    CHECK_NG(ngpde_gno_contract_forward(g, cin, cout, K_d, h_d, m2_d, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float *m1 = host_copy(m1_d, e * cout), *m2 = host_copy(m2_d, e * cout), *ref = malloc(sizeof(float) * e * cout);
+    for (int64_t p = 0; p < e; ++p)
+      for (int o = 0; o < cout; ++o) {
+        double v = 0;
+        for (int i = 0; i < cin; ++i) v += (double)K[p * cin * cout + o + cout * i] * h[(int64_t)col[p] * cin + i];
+        ref[p * cout + o] = (float)v;
+      }
+    report("gno_contract_forward (literal)", max_rel(m2, ref, e * cout), 2e-4);
+    report("gno_apply_forward (reassociated)", max_rel(m1, ref, e * cout), 2e-4);
+  }
+
+  /* ---- 4. GAT layer in one launch vs its composition, and the Runge-Kutta combination ---- */
+  {
+    const int d = 64, heads = 4, c = 16;
+    /* self loops are edges of the GAT graph: a second handle with them appended */
+    int64_t *s2 = malloc(sizeof(int64_t) * (e + n)), *t2 = malloc(sizeof(int64_t) * (e + n));
+    memcpy(s2, s, sizeof(int64_t) * e); memcpy(t2, t, sizeof(int64_t) * e);
+    for (int64_t i = 0; i < n; ++i) { s2[e + i] = i; t2[e + i] = i; }
+    ngpde_graph_t *g2 = NULL;
+    CHECK_NG(ngpde_graph_create(n, e + n, s2, t2, 0, 1, &g2));
+    CHECK_NG(ngpde_graph_set_gcn_norm(g2, 0, NULL, 0));
+    float *x = host_rand(n * d, 1.f), *w = host_rand(d * d, 0.2f), *a = host_rand(2 * c * heads, 0.3f), *b = host_rand(d, 0.1f);
+    float *x_d = dev_copy(x, n * d), *w_d = dev_copy(w, d * d), *a_d = dev_copy(a, 2 * c * heads), *b_d = dev_copy(b, d);
+    float *y1_d = dev_copy(NULL, n * d), *y2_d = dev_copy(NULL, n * d), *wx_d = dev_copy(NULL, n * d), *agg_d = dev_copy(NULL, n * d),
+          *alpha_d = dev_copy(NULL, (e + n) * heads), *al_d = dev_copy(NULL, n * heads), *ar_d = dev_copy(NULL, n * heads);
+    if (!ngpde_gat_layer_supported(g2, d, heads, c)) { fprintf(stderr, "one-launch GAT layer not available\n"); return 8; }
+    CHECK_NG(ngpde_gat_layer_forward(g2, d, heads, c, 0.2f, NGPDE_ACT_RELU, x_d, w_d, a_d, b_d, y1_d, NULL, NULL, NULL));
+    const float *seg[1] = {x_d};
+    const int32_t wdt[1] = {d}, rdv[1] = {1};
+    CHECK_NG(ngpde_dense_forward(n, 1, seg, wdt, rdv, d, NGPDE_ACT_IDENTITY, w_d, NULL, wx_d, NULL, NULL));
+    CHECK_NG(ngpde_gat_forward(g2, heads, c, 0.2f, wx_d, a_d, agg_d, alpha_d, al_d, ar_d, NULL));
+    CHECK_NG(ngpde_bias_act_forward(n, d, NGPDE_ACT_RELU, agg_d, NULL, b_d, y2_d, NULL, NULL));
+    /* u + 0.5 y1 - 0.25 y2 by ngpde_rk_stage_combine */
+    float *comb_d = dev_copy(NULL, n * d);
+    const float *terms[2] = {y1_d, y2_d};
+    const float coefs[2] = {0.5f, -0.25f};
+    CHECK_NG(ngpde_rk_stage_combine(n * d, 1.0f, x_d, 2, terms, coefs, comb_d, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float *y1 = host_copy(y1_d, n * d), *y2 = host_copy(y2_d, n * d), *cb = host_copy(comb_d, n * d), *ref = malloc(sizeof(float) * n * d);
+    for (int64_t i = 0; i < n * d; ++i) ref[i] = x[i] + 0.5f * y1[i] - 0.25f * y2[i];
+    report("gat_layer_forward vs composition", max_rel(y1, y2, n * d), 1e-4);
+    report("rk_stage_combine", max_rel(cb, ref, n * d), 1e-6);
+    CHECK_NG(ngpde_graph_destroy(g2));
+  }
+  CHECK_NG(ngpde_graph_destroy(g));
+  return fails ? 1 : 0;
+}

@@ -1,4 +1,6 @@
-"""The boundary called from plain C: tests/c_abi/gcn_roundtrip.c is compiled with gcc against include/ngpde.h, linked with
+"""The boundary called from plain C: tests/c_abi/gcn_roundtrip.c (GCNConv forward + pullback) and tests/c_abi/mp_roundtrip.c
+(the solver plan, the edge-function message path fused and on the primitives, both GNOConv message forms, the one-launch GAT
+layer against its composition, ngpde_rk_stage_combine) are compiled with gcc against include/ngpde.h, linked with
 libngpde_hip.so, the HIP runtime and the C oracle (the checker), and run on the GPU -- no Python, torch or C++ on the
 calling side.  This is the shape of the ccall binding INTEGRATION.md sketches for the Julia package."""
 import os
@@ -10,15 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("c_abi") / "gcn_roundtrip")
+def build(tmp_path_factory, name):
+    out = str(tmp_path_factory.mktemp("c_abi") / name)
     lib_dir = os.path.join(ROOT, "neuralgraphpde.jl_amd")
     odir = os.path.join(ROOT, "oracle")
     if not os.path.exists(os.path.join(odir, "libngpde_oracle.so")):
         subprocess.check_call(["make", "-C", odir])
-    cmd = ["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
-           os.path.join(ROOT, "tests", "c_abi", "gcn_roundtrip.c"), "-o", out,
+    cmd = ["gcc", "-O1", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", name + ".c"), "-o", out,
            os.path.join(lib_dir, "libngpde_hip.so"), os.path.join(odir, "libngpde_oracle.so"),
            "-L/opt/rocm/lib", "-lamdhip64", "-lm",
            f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{odir}", "-Wl,-rpath,/opt/rocm/lib"]
@@ -26,8 +27,24 @@ def exe(tmp_path_factory):
     return out
 
 
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    return build(tmp_path_factory, "gcn_roundtrip")
+
+
+@pytest.fixture(scope="module")
+def exe_mp(tmp_path_factory):
+    return build(tmp_path_factory, "mp_roundtrip")
+
+
 @pytest.mark.parametrize("d", [64, 24])
 def test_gcn_roundtrip_from_plain_c(exe, d):
     r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0.1.0" in r.stdout
+
+
+def test_solver_plan_message_path_gno_gat_from_plain_c(exe_mp):
+    r = subprocess.run([exe_mp], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout and "node_gcn2 u(T)" in r.stdout and "gat_layer_forward" in r.stdout
