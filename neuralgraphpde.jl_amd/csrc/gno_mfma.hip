@@ -1,0 +1,252 @@
+// gno_mfma.hip -- the reassociated GNOConv message (/root/reference/src/layers.jl:509-547) on the matrix pipe.
+//   m_e = T_{s_e} z_e + Bh_{s_e},   T_j [out][k] = sum_i W2[o + out i][k] h_j[i]  (node level, ngpde_dense_forward)
+// Grouped by SOURCE node the message is a real GEMM: the deg_out(j) edges leaving j share T_j,
+//   M_j^T [deg][out] = Z_j [deg][k] x T_j^T [k][out]
+// so one workgroup per source node multiplies 16-edge tiles of its gathered z rows with T_j on v_mfma_f32_16x16x4_f32 (exact
+// fp32).  T_j never touches LDS in the forward: lane (o, kq) of an output-column tile reads its four consecutive k of row o
+// straight from memory (16 bytes) and keeps them for all edge tiles.  BASELINE config 5 (128 => 128, k = 64, radius 0.1: 110
+// edges per node): 7 edge tiles x 8 column tiles x 16 products per node.
+// Pullback per source node:  dz_e = T_j^T dm_e  (DZ [deg][k] = DM [deg][out] x T_j),  dT_j = sum_e dm_e z_e^T  (DM^T x Z, the edge
+// index contracted, accumulators in registers over the node's edge tiles),  dBh_j = sum_e dm_e.
+// Used when out is a multiple of 16 (<= 256) and k is 16, 32 or 64; other shapes keep the register-tile kernels of
+// mp_kernels.hip.  No atomics; every output row has one writer.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace ngpde {
+
+namespace {
+
+constexpr int kET = 16;      // edges per MFMA tile
+constexpr int kEB = 64;      // edges staged per pass of the forward (4 tiles)
+constexpr int kEBb = 32;     // ... of the pullback (z and dm rows beside T^T: 59 KB at 128 x 64, two workgroups per CU)
+
+// rows of a per-edge array ([E][w], p order) of the edges q0 .. q0 + nb of the source's list -> LDS [kEB][w + 4], zero rows
+// beyond nb; 16-byte loads (w % 4 == 0)
+template <int EB>
+__device__ __forceinline__ void stage_edge_rows(float *dst, const float *__restrict__ src, const int *pl, int nb, int w, int tid) {
+  const int w4 = w / 4, ls = w + 4;
+  for (int idx = tid; idx < EB * w4; idx += 256) {
+    const int e = idx / w4, c4 = idx - e * w4;
+    const float4 v = e < nb ? reinterpret_cast<const float4 *>(src + (size_t)pl[e] * w)[c4] : f4_zero();
+    *reinterpret_cast<float4 *>(&dst[e * ls + 4 * c4]) = v;
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------
+template <int KD>   // kdim (multiple of 16)
+__global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
+                                                                 const float *__restrict__ T, const float *__restrict__ Bh,
+                                                                 const float *__restrict__ z, float *__restrict__ m) {
+  constexpr int ZS = KD + 4;
+  __shared__ __attribute__((aligned(16))) float zl[kEB * ZS];
+  __shared__ int pl[kEB];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rs = rowptr_s[j], re = rowptr_s[j + 1];
+  if (rs == re) return;
+  const int i = lane & 15, kq = lane >> 4;
+  const int nct = cout / 16;                       // output-column tiles; wave w owns tiles w, w + 4, ... (at most 4: cout <= 256)
+  // B operand: T_j[o = ct*16 + i][16 kb + 4 kq .. + 3], kept for the node's whole edge list
+  float4 breg[4][KD / 16];
+  float bias[4];
+  const float *Tj = T + (size_t)j * cout * KD;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ct = wave + 4 * c;
+    bias[c] = 0.f;
+    if (ct < nct) {   // wave-uniform
+#pragma unroll
+      for (int kb = 0; kb < KD / 16; ++kb)
+        breg[c][kb] = *reinterpret_cast<const float4 *>(Tj + (size_t)(ct * 16 + i) * KD + 16 * kb + 4 * kq);
+      if (Bh) bias[c] = Bh[(size_t)j * cout + ct * 16 + i];
+    }
+  }
+  for (int q0 = rs; q0 < re; q0 += kEB) {
+    const int nb = min(kEB, re - q0);
+    __syncthreads();                                // the previous pass's tiles are consumed
+    if (tid < kEB) pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+    __syncthreads();
+    stage_edge_rows<kEB>(zl, z, pl, nb, KD, tid);
+    __syncthreads();
+    for (int et = 0; et * kET < nb; ++et) {         // uniform
+      float4 a4[KD / 16];
+#pragma unroll
+      for (int kb = 0; kb < KD / 16; ++kb) a4[kb] = *reinterpret_cast<const float4 *>(&zl[(et * kET + i) * ZS + 16 * kb + 4 * kq]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ct = wave + 4 * c;
+        if (ct >= nct) break;                       // wave-uniform
+        f32x4 acc = (f32x4){bias[c], bias[c], bias[c], bias[c]};
+#pragma unroll
+        for (int kb = 0; kb < KD / 16; ++kb) {
+          acc = mfma16(a4[kb].x, breg[c][kb].x, acc);
+          acc = mfma16(a4[kb].y, breg[c][kb].y, acc);
+          acc = mfma16(a4[kb].z, breg[c][kb].z, acc);
+          acc = mfma16(a4[kb].w, breg[c][kb].w, acc);
+        }
+        // D[edge 4 kq + r][out ct*16 + i]: 16 lanes write 64 contiguous bytes of one edge's row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = et * kET + 4 * kq + r;
+          if (e < nb) m[(size_t)pl[e] * cout + ct * 16 + i] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+// ---- pullback -------------------------------------------------------------------------------------------------------------
+template <int KD>
+__global__ __launch_bounds__(256) void gno_apply_mfma_bwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
+                                                                 const float *__restrict__ T, const float *__restrict__ z,
+                                                                 const float *__restrict__ dm, float *__restrict__ dT,
+                                                                 float *__restrict__ dBh, float *__restrict__ dz) {
+  constexpr int ZS = KD + 4;
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int DS = cout + 4;
+  float *zl = sh;                                   // [kEBb][KD + 4]
+  float *dml = zl + kEBb * ZS;                       // [kEBb][cout + 4]
+  float *Ttl = dml + kEBb * DS;                      // [KD][cout + 4]   T_j transposed: the contraction index of dz = T^T dm contiguous
+  __shared__ int pl[kEBb];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rs = rowptr_s[j], re = rowptr_s[j + 1];
+  const int i = lane & 15, kq = lane >> 4;
+  const int nct = cout / 16;
+  constexpr int NKT = KD / 16;                      // k tiles
+  // dT tiles (out tile ot, k tile kt): id = ot * NKT + kt, wave w owns ids w, w + 4, ...: at most (256/16) * (128/16) / 4 = 32
+  constexpr int MAXT = 8;                           // tiles per wave kept in registers per sweep (cout * KD <= 128 * 64 in one sweep)
+  const int ntile = nct * NKT;
+  const float *Tj = T + (size_t)j * cout * KD;
+  if (dz && rs < re) {
+    for (int idx = tid; idx < cout * (KD / 4); idx += 256) {
+      const int o = idx / (KD / 4), k4 = idx - o * (KD / 4);
+      const float4 v = reinterpret_cast<const float4 *>(Tj + (size_t)o * KD)[k4];
+      Ttl[(4 * k4 + 0) * DS + o] = v.x; Ttl[(4 * k4 + 1) * DS + o] = v.y; Ttl[(4 * k4 + 2) * DS + o] = v.z; Ttl[(4 * k4 + 3) * DS + o] = v.w;
+    }
+  }
+  float bsum = 0.f;                                 // dBh: thread tid < cout sums column tid of the dm rows
+  for (int sweep = 0; sweep * 4 * MAXT < ntile; ++sweep) {   // one sweep over the edge list per 32 dT tiles (a single sweep at 128 x 64)
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q0 = rs; q0 < re; q0 += kEBb) {
+      const int nb = min(kEBb, re - q0);
+      __syncthreads();
+      if (tid < kEBb) pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+      __syncthreads();
+      stage_edge_rows<kEBb>(zl, z, pl, nb, KD, tid);
+      stage_edge_rows<kEBb>(dml, dm, pl, nb, cout, tid);
+      __syncthreads();
+      const int net = (nb + kET - 1) / kET;
+      if (sweep == 0) {
+        if (dBh && tid < cout)
+          for (int e = 0; e < nb; ++e) bsum += dml[e * DS + tid];
+        if (dz) {
+          // DZ[edge][kk] = sum_o DM[edge][o] T[o][kk]: tiles (edge tile et, k tile kt), spread over the waves
+          for (int id = wave; id < net * NKT; id += 4) {
+            const int et = id / NKT, kt = id - et * NKT;
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ob = 0; ob < nct; ++ob) {
+              const float4 a4 = *reinterpret_cast<const float4 *>(&dml[(et * kET + i) * DS + 16 * ob + 4 * kq]);
+              const float4 b4 = *reinterpret_cast<const float4 *>(&Ttl[(kt * 16 + i) * DS + 16 * ob + 4 * kq]);
+              d = mfma16(a4.x, b4.x, d);
+              d = mfma16(a4.y, b4.y, d);
+              d = mfma16(a4.z, b4.z, d);
+              d = mfma16(a4.w, b4.w, d);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = et * kET + 4 * kq + r;
+              if (e < nb) dz[(size_t)pl[e] * KD + kt * 16 + i] = d[r];
+            }
+          }
+        }
+      }
+      if (dT) {
+        // dT[o][kk] += sum_e DM[e][o] Z[e][kk]: the edge index is the contraction (zero rows beyond nb add nothing)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int id = wave + 4 * (t + MAXT * sweep);
+          if (id < ntile) {   // wave-uniform
+            const int ot = id / NKT, kt = id - ot * NKT;
+            for (int es = 0; es < net * 4; ++es) {  // 4-edge contraction steps
+              const int e = 4 * es + kq;
+              acc[t] = mfma16(dml[e * DS + ot * 16 + i], zl[e * ZS + kt * 16 + i], acc[t]);
+            }
+          }
+        }
+      }
+    }
+    if (dT) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int id = wave + 4 * (t + MAXT * sweep);
+        if (id < ntile) {
+          const int ot = id / NKT, kt = id - ot * NKT;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dT[(size_t)j * cout * KD + (size_t)(ot * 16 + 4 * kq + r) * KD + kt * 16 + i] = acc[t][r];
+        }
+      }
+    }
+  }
+  if (dBh && tid < cout) dBh[(size_t)j * cout + tid] = bsum;
+}
+
+inline bool no_gno_mfma_env() {
+  const char *e = std::getenv("NGPDE_NO_GNO_MFMA");
+  return e && e[0] == '1';
+}
+inline size_t gno_mfma_bwd_lds(int cout, int kdim) { return (size_t)(kEBb * (kdim + 4) + kEBb * (cout + 4) + kdim * (cout + 4)) * sizeof(float); }
+
+}  // namespace
+
+bool gno_apply_mfma_supported(int cout, int kdim) {
+  return !no_gno_mfma_env() && cout % 16 == 0 && cout >= 16 && cout <= 256 && (kdim == 16 || kdim == 32 || kdim == 64) &&
+         gno_mfma_bwd_lds(cout, kdim) <= 150 * 1024;
+}
+
+int32_t launch_gno_apply_mfma_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z, float *m,
+                                  hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  const dim3 grid((unsigned)g->n_nodes), block(256);
+#define NGPDE_GNO_F(KK) hipLaunchKernelGGL(gno_apply_mfma_fwd_kernel<KK>, grid, block, 0, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m)
+  switch (kdim) {
+    case 16: NGPDE_GNO_F(16); break;
+    case 32: NGPDE_GNO_F(32); break;
+    default: NGPDE_GNO_F(64); break;
+  }
+#undef NGPDE_GNO_F
+  NGPDE_LAUNCH_CHECK("gno_apply_mfma_fwd_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm, float *dT,
+                                  float *dBh, float *dz, hipStream_t stream) {
+  if (g->n_nodes == 0) return NGPDE_OK;
+  const dim3 grid((unsigned)g->n_nodes), block(256);
+  const size_t lds = gno_mfma_bwd_lds(cout, kdim);
+#define NGPDE_GNO_B(KK)                                                                                                          \
+  do {                                                                                                                           \
+    static bool attr_set = false;                                                                                                \
+    if (!attr_set) {                                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                                           \
+    }                                                                                                                            \
+    hipLaunchKernelGGL(gno_apply_mfma_bwd_kernel<KK>, grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, dBh, dz); \
+  } while (0)
+  switch (kdim) {
+    case 16: NGPDE_GNO_B(16); break;
+    case 32: NGPDE_GNO_B(32); break;
+    default: NGPDE_GNO_B(64); break;
+  }
+#undef NGPDE_GNO_B
+  NGPDE_LAUNCH_CHECK("gno_apply_mfma_bwd_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde

@@ -833,6 +833,7 @@ bool gno_apply_supported(int cout, int kdim) {
 int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z,
                              float *m, hipStream_t stream) {
   if (g->n_edges == 0) return NGPDE_OK;
+  if (gno_apply_mfma_supported(cout, kdim)) return launch_gno_apply_mfma_fwd(g, cout, kdim, T, Bh, z, m, stream);
   hipLaunchKernelGGL(gno_apply_fwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), gno_lds_bytes(cout, kdim, false), stream,
                      (int)g->n_nodes, cout, kdim, g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m);
   NGPDE_LAUNCH_CHECK("gno_apply_fwd_kernel");
@@ -842,6 +843,7 @@ int32_t launch_gno_apply_fwd(const ngpde_graph *g, int cout, int kdim, const flo
 int32_t launch_gno_apply_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm,
                              float *dT, float *dBh, float *dz, hipStream_t stream) {
   if (g->n_nodes == 0) return NGPDE_OK;
+  if (gno_apply_mfma_supported(cout, kdim)) return launch_gno_apply_mfma_bwd(g, cout, kdim, T, z, dm, dT, dBh, dz, stream);
   hipLaunchKernelGGL(gno_apply_bwd_kernel, dim3((unsigned)g->n_nodes), dim3(256), gno_lds_bytes(cout, kdim, true), stream,
                      (int)g->n_nodes, cout, kdim, gno_kp_log2(kdim), gno_rows_per_thread(cout, kdim), g->by_s.rowptr,
                      g->by_s.xpos, T, z, dm, dT, dBh, dz);

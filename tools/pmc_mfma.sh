@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES"; do
   n=$(echo $grp | tr ' ' '_')
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c2_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 > $O/c2_$n.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c2_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 --no-secondary > $O/c2_$n.log 2>&1
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c4_$n -- python3 $R/tools/bench_layers.py --only c4 --traj 64 --reps 2 > $O/c4_$n.log 2>&1
 done
 cd $R

@@ -19,6 +19,9 @@ for (cfg, k), cs in sorted(acc.items()):
         row["mfma_busy_cycles"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"])
         row["sq_busy_cycles"] = round(m["SQ_BUSY_CYCLES"])
         row["mfma_busy_over_sq_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"], 4)
+        # SQ_BUSY_CYCLES sums over the 32 shader engines (= 32 x the kernel's duration in cycles), the MFMA counter over the
+        # 1024 SIMDs: share of the SIMD-cycles in which the matrix pipe was busy = mfma / (1024 * sq / 32)
+        row["matrix_pipe_busy_fraction"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"]), 4)
     if "SQ_LDS_IDX_ACTIVE" in m and m["SQ_LDS_IDX_ACTIVE"]:
         row["lds_bank_conflict_share"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"], 4)
     for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVE_CYCLES"):

@@ -22,6 +22,14 @@ python3 tools/bench_layers.py --only c3 --reps 20 > $O/layers.jsonl 2>/dev/null
 python3 tools/bench_layers.py --only c4 --traj 64 --reps 10 >> $O/layers.jsonl 2>/dev/null
 python3 tools/bench_layers.py --only c5 --width 128 --reps 10 >> $O/layers.jsonl 2>/dev/null
 python3 tools/bench_layers.py --only c5 --width 128 --radius 0.1 --reps 10 >> $O/layers.jsonl 2>/dev/null
+# the C3 layer's kernels (one-launch GAT layer + two-launch pullback), the any-width GCN path, the generic NeuralODE path
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -o k -- python3 $R/tools/bench_layers.py --only c3 --reps 50 > $O/c3_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gnode_stats -o k -- python3 $R/tools/trace_generic_node.py 10 > $O/gnode_stats.log 2>&1
+cd $R
+python3 tools/bench_gcn_anywidth.py > $O/gcn_anywidth.jsonl 2>/dev/null
+python3 tools/trace_generic_node.py 50 > $O/generic_node.jsonl 2>/dev/null
+python3 tools/trace_generic_node.py 50 capture >> $O/generic_node.jsonl 2>/dev/null
 python3 tools/bench_graph_build.py > $O/graph_build.jsonl 2>/dev/null
 NGPDE_HOST_GRAPH_BUILD=1 python3 tools/bench_graph_build.py | sed 's/"graph"/"builder": "host", "graph"/' >> $O/graph_build.jsonl 2>/dev/null
 python3 tools/bench_dense.py > $O/dense.jsonl 2>/dev/null
