@@ -232,11 +232,9 @@ int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, cons
   const size_t lds = gno_mfma_bwd_lds(cout, kdim);
 #define NGPDE_GNO_B(KK)                                                                                                          \
   do {                                                                                                                           \
-    static bool attr_set = false;                                                                                                \
-    if (!attr_set) {                                                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                                           \
-    }                                                                                                                            \
+    if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit: raise it for this kernel (cheap, idempotent) */               \
+      NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK>),                        \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
     hipLaunchKernelGGL(gno_apply_mfma_bwd_kernel<KK>, grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, dBh, dz); \
   } while (0)
   switch (kdim) {
