@@ -58,7 +58,8 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
 
 size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout) {
   return align256((size_t)std::max<int64_t>(n, 1) * dout * 4) +
-         align256((size_t)dense_weight_chunks(n, din_total, dout) * (din_total + 1) * dout * 4) + 256;
+         align256((size_t)dense_weight_chunks(n, din_total, dout) * (din_total + 1) * dout * 4) +
+         align256(dense_bwd_input_split_bytes(n, din_total, dout)) + 256;
 }
 
 int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
@@ -100,7 +101,10 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
       any = any || gsg.ptr[i];
     }
     for (int i = 0; i <= 4; ++i) gsg.offset[i] = t.offset[i];
-    if (any && (st = launch_dense_seg_bwd_input(n, gsg, din, dout, dz, weight, stream))) return st;
+    if (any && t.n == 1 && dense_bwd_input_splits(n, din, dout) > 1) {   // few rows, very wide output: split the contraction
+      float *split_part = (float *)((char *)partial + align256((size_t)dense_weight_chunks(n, din, dout) * (din + 1) * dout * 4));
+      if ((st = launch_dense_bwd_input_splitk(n, gsg.ptr[0], din, dout, dz, weight, split_part, stream))) return st;
+    } else if (any && (st = launch_dense_seg_bwd_input(n, gsg, din, dout, dz, weight, stream))) return st;
   }
   return NGPDE_OK;
 }

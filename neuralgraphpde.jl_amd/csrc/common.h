@@ -237,6 +237,10 @@ int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z,
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
                                    hipStream_t stream);
 int dense_weight_chunks(int64_t n, int din, int dout);
+int dense_bwd_input_splits(int64_t n, int din, int dout);
+size_t dense_bwd_input_split_bytes(int64_t n, int din, int dout);
+int32_t launch_dense_bwd_input_splitk(int64_t n, float *dx, int din, int dout, const float *dz, const float *wt, float *part,
+                                      hipStream_t stream);
 int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, int dout, const float *dz, float *dwt,
                                     float *db, float *partial, hipStream_t stream);
 int32_t launch_edge_permute(const ngpde_graph *g, int d, bool inverse, const float *src, float *dst, hipStream_t stream);

@@ -120,14 +120,21 @@ __global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable
 }
 
 // ---- input pullback: dX[n][k] = sum_o dz[n][o] wt[k][o], written into the blocks that ask for it -------------------
-__global__ __launch_bounds__(256) void dense_mfma_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
+// Split over the OUTPUT features (the contraction of this product) when `part` is given: workgroup z contracts
+// [z * oper, (z + 1) * oper); z = 0 writes into the gradient block itself, z >= 1 into part + (z - 1) * part_stride, summed
+// afterwards (single-block inputs only).  For the pullback of a few-row x very-wide Dense such as GNOConv's T = W2 (x) h
+// (4096 rows, 8192 outputs): 128 workgroups behind 512 dependent K steps otherwise.
+__global__ __launch_bounds__(256) void dense_mfma_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout_all,
                                                                    const float *__restrict__ dz,
-                                                                   const float *__restrict__ wt) {
+                                                                   const float *__restrict__ wt, int oper, float *part,
+                                                                   size_t part_stride) {
   __shared__ __attribute__((aligned(16))) float ldsA[BM * LS], ldsBt[BN * LS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int col0 = blockIdx.y * BN;          // columns of dX = input features k
+  const int obeg = blockIdx.z * oper, dout = min(dout_all, obeg + oper);   // this workgroup's output-feature range [obeg, dout)
+  if (blockIdx.z > 0) segs.ptr[0] = part + (size_t)(blockIdx.z - 1) * part_stride;
   const int ar = tid >> 4, ak = tid & 15;    // A = dz: (row, o)
   const int bcol = tid >> 2, bo4 = (tid & 3) * 4;   // Bt[col = k][o]: thread loads 4 consecutive o of one k row
   float areg[4];
@@ -136,19 +143,19 @@ __global__ __launch_bounds__(256) void dense_mfma_bwd_input_kernel(int64_t n, Se
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int64_t r = row0 + ar + 16 * p;
-      areg[p] = (r < n && o0 + ak < dout) ? dz[r * dout + o0 + ak] : 0.f;
+      areg[p] = (r < n && o0 + ak < dout) ? dz[r * dout_all + o0 + ak] : 0.f;
     }
     const int k = col0 + bcol;
     float t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = (k < din && o0 + bo4 + j < dout) ? wt[(size_t)k * dout + o0 + bo4 + j] : 0.f;
+    for (int j = 0; j < 4; ++j) t[j] = (k < din && o0 + bo4 + j < dout) ? wt[(size_t)k * dout_all + o0 + bo4 + j] : 0.f;
     breg = make_float4(t[0], t[1], t[2], t[3]);
   };
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  fetch(0);
-  for (int o0 = 0; o0 < dout; o0 += BK) {
+  fetch(obeg);
+  for (int o0 = obeg; o0 < dout; o0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) ldsA[(ar + 16 * p) * LS + ak] = areg[p];
@@ -560,8 +567,57 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
     return NGPDE_OK;
   }
   hipLaunchKernelGGL(dense_mfma_bwd_input_kernel, dim3((unsigned)((n + BM - 1) / BM), (din + BN - 1) / BN), dim3(256), 0,
-                     stream, n, segs, din, dout, dz, wt);
+                     stream, n, segs, din, dout, dz, wt, dout, (float *)nullptr, (size_t)0);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_input_kernel");
+  return NGPDE_OK;
+}
+
+namespace {
+// out[i] += parts[i] + parts[stride + i] + ... (nparts slabs, in slab order)
+__global__ void add_partials_kernel(int64_t count, int nparts, size_t stride, const float *__restrict__ parts, float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float s0 = out[i], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 <= nparts; z += 3) {
+      s1 += parts[(size_t)z * stride + i];
+      s2 += parts[(size_t)(z + 1) * stride + i];
+      s3 += parts[(size_t)(z + 2) * stride + i];
+    }
+    for (; z < nparts; ++z) s1 += parts[(size_t)z * stride + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+  }
+}
+}  // namespace
+
+// splits of the input pullback over the output features (see dense_mfma_bwd_input_kernel): 1 = none
+int dense_bwd_input_splits(int64_t n, int din, int dout) {
+  const int64_t tiles = ((n + BM - 1) / BM) * ((din + BN - 1) / BN);
+  if (tiles >= 256 || dout < 512) return 1;
+  return (int)std::max<int64_t>(1, std::min<int64_t>((768 + tiles - 1) / tiles, dout / 128));
+}
+size_t dense_bwd_input_split_bytes(int64_t n, int din, int dout) {
+  const int ns = dense_bwd_input_splits(n, din, dout);
+  return ns > 1 ? (size_t)(ns - 1) * (size_t)n * din * sizeof(float) : 0;
+}
+// single-block input pullback, split over the output features; `part` holds dense_bwd_input_split_bytes
+int32_t launch_dense_bwd_input_splitk(int64_t n, float *dx, int din, int dout, const float *dz, const float *wt, float *part,
+                                      hipStream_t stream) {
+  if (n == 0 || din == 0) return NGPDE_OK;
+  const int ns = dense_bwd_input_splits(n, din, dout);
+  const int oper = ((dout + ns - 1) / ns + BK - 1) / BK * BK;
+  const int nz = (dout + oper - 1) / oper;
+  SegGrad segs;
+  segs.n = 1; segs.ptr[0] = dx; segs.width[0] = din;
+  for (int i = 1; i <= 4; ++i) segs.offset[i] = din;
+  hipLaunchKernelGGL(dense_mfma_bwd_input_kernel, dim3((unsigned)((n + BM - 1) / BM), (din + BN - 1) / BN, nz), dim3(256), 0, stream,
+                     n, segs, din, dout, dz, wt, oper, part, (size_t)n * din);
+  NGPDE_LAUNCH_CHECK("dense_mfma_bwd_input_kernel (split)");
+  if (nz > 1) {
+    const int64_t count = n * din;
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256), 0, stream, count,
+                       nz - 1, (size_t)n * din, part, dx);
+    NGPDE_LAUNCH_CHECK("add_partials_kernel");
+  }
   return NGPDE_OK;
 }
 

@@ -69,6 +69,127 @@ __global__ __launch_bounds__(256) void edge_combine_fwd_kernel(int n_nodes, int 
   }
 }
 
+// ---- 16-byte forms of the per-row edge kernels (feature width a multiple of 4) -------------------------------------------
+// One wave per target row; the wave's lanes are (entry slot, float4 column): DPL lanes cover one entry's row, 64 / DPL
+// entries are processed at once and every lane keeps four entries in flight.  A row's entries are contiguous in p order, so
+// the per-edge arrays stream; partial sums of the slots are combined in a fixed order.
+template <int DPL>
+__global__ __launch_bounds__(256) void edge_combine_fwd4_kernel(int n_nodes, int c4n, int act, const int *__restrict__ rowptr,
+                                                                const int *__restrict__ col, const float4 *__restrict__ P,
+                                                                const float4 *__restrict__ Q, const float4 *__restrict__ Eterm,
+                                                                float4 *__restrict__ a_out, float4 *__restrict__ z_out) {
+  constexpr int SLOTS = 64 / DPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int slot = lane / DPL, c4 = lane % DPL;
+  if (c4 >= c4n) return;
+  const float4 pv = P ? P[(size_t)row * c4n + c4] : f4_zero();
+  for (int p0 = rs + slot; p0 < re; p0 += 4 * SLOTS) {
+    float4 z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = min(p0 + u * SLOTS, re - 1);
+      z[u] = pv;
+      if (Q) z[u] = f4_add(z[u], Q[(size_t)col[p] * c4n + c4]);
+      if (Eterm) z[u] = f4_add(z[u], Eterm[(size_t)p * c4n + c4]);
+    }
+    float4 a[4] = {z[0], z[1], z[2], z[3]};
+    f4n_act<4>(act, a);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * SLOTS;
+      if (p < re) {
+        if (z_out) z_out[(size_t)p * c4n + c4] = z[u];
+        a_out[(size_t)p * c4n + c4] = a[u];
+      }
+    }
+  }
+}
+
+// sum / mean of the row's entries
+template <int DPL>
+__global__ __launch_bounds__(256) void segment_sum4_kernel(int n_nodes, int c4n, int mean, const int *__restrict__ rowptr,
+                                                           const float4 *__restrict__ M, float4 *__restrict__ out) {
+  constexpr int SLOTS = 64 / DPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int slot = lane / DPL, c4 = min(lane % DPL, c4n - 1);
+  float4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+  for (int p0 = rs + slot; p0 < re; p0 += 4 * SLOTS) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * SLOTS;
+      v[u] = p < re ? M[(size_t)p * c4n + c4] : f4_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f4_add(acc[u], v[u]);
+  }
+  float4 a = f4_add(f4_add(acc[0], acc[1]), f4_add(acc[2], acc[3]));
+#pragma unroll
+  for (int o = DPL; o < 64; o <<= 1)
+    a = f4_add(a, make_float4(__shfl_xor(a.x, o), __shfl_xor(a.y, o), __shfl_xor(a.z, o), __shfl_xor(a.w, o)));
+  if (mean) a = re > rs ? f4_scale(1.0f / (float)(re - rs), a) : f4_zero();
+  if (slot == 0 && lane % DPL < c4n) out[(size_t)row * c4n + c4] = a;
+}
+
+// dz_p = da_p * act'(z_p);  dP[t] = sum over the row
+template <int DPL>
+__global__ __launch_bounds__(256) void edge_combine_bwd_target4_kernel(int n_nodes, int c4n, int act, const int *__restrict__ rowptr,
+                                                                       const float4 *__restrict__ da, const float4 *__restrict__ z,
+                                                                       float4 *__restrict__ dz, float4 *__restrict__ dP) {
+  constexpr int SLOTS = 64 / DPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  const int slot = lane / DPL, c4 = min(lane % DPL, c4n - 1);
+  const bool cok = lane % DPL < c4n;
+  float4 acc = f4_zero();
+  for (int p0 = rs + slot; p0 < re; p0 += 4 * SLOTS) {
+    float4 g[4], zz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = min(p0 + u * SLOTS, re - 1);
+      g[u] = da[(size_t)p * c4n + c4];
+      zz[u] = z ? z[(size_t)p * c4n + c4] : f4_zero();
+    }
+    if (z) {
+      f4n_dact<4>(act, zz);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = f4_mul(g[u], zz[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * SLOTS;
+      if (p < re) {
+        if (cok) dz[(size_t)p * c4n + c4] = g[u];
+        acc = f4_add(acc, g[u]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = DPL; o < 64; o <<= 1)
+    acc = f4_add(acc, make_float4(__shfl_xor(acc.x, o), __shfl_xor(acc.y, o), __shfl_xor(acc.z, o), __shfl_xor(acc.w, o)));
+  if (dP && slot == 0 && cok) dP[(size_t)row * c4n + c4] = acc;
+}
+
+// lanes per entry for a row of c4n float4: the next power of two (4 .. 64)
+inline int dpl_for(int c4n) { return c4n <= 4 ? 4 : c4n <= 8 ? 8 : c4n <= 16 ? 16 : c4n <= 32 ? 32 : 64; }
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+#define NGPDE_DPL_DISPATCH(KERNEL, c4n, grid, stream, ...)                                               \
+  switch (dpl_for(c4n)) {                                                                                \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, stream, __VA_ARGS__); break;                \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, stream, __VA_ARGS__); break;                \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(256), 0, stream, __VA_ARGS__); break;              \
+    case 32: hipLaunchKernelGGL(KERNEL<32>, grid, dim3(256), 0, stream, __VA_ARGS__); break;              \
+    default: hipLaunchKernelGGL(KERNEL<64>, grid, dim3(256), 0, stream, __VA_ARGS__); break;              \
+  }
+
 // dz_p = da_p * act'(z_p) (in place into dz);  dP[t] = sum over the row
 __global__ __launch_bounds__(256) void edge_combine_bwd_target_kernel(int n_nodes, int h, int act, const int *__restrict__ rowptr,
                                                                       const float *__restrict__ da, const float *__restrict__ z,
@@ -743,6 +864,13 @@ int32_t launch_edge_permute(const ngpde_graph *g, int d, bool inverse, const flo
 int32_t launch_edge_combine_fwd(const ngpde_graph *g, int h, int act, const float *P, const float *Q, const float *Eterm,
                                 float *a_out, float *z_out, hipStream_t stream) {
   if (g->n_nodes == 0 || h == 0) return NGPDE_OK;
+  if (h % 4 == 0 && h <= 256 && al16(P) && al16(Q) && al16(Eterm) && al16(a_out) && al16(z_out)) {
+    NGPDE_DPL_DISPATCH(edge_combine_fwd4_kernel, h / 4, dim3(rows4(g->n_nodes)), stream, (int)g->n_nodes, h / 4, act, g->by_t.rowptr,
+                       g->by_t.col, reinterpret_cast<const float4 *>(P), reinterpret_cast<const float4 *>(Q),
+                       reinterpret_cast<const float4 *>(Eterm), reinterpret_cast<float4 *>(a_out), reinterpret_cast<float4 *>(z_out))
+    NGPDE_LAUNCH_CHECK("edge_combine_fwd4_kernel");
+    return NGPDE_OK;
+  }
   hipLaunchKernelGGL(edge_combine_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h, act,
                      g->by_t.rowptr, g->by_t.col, P, Q, Eterm, a_out, z_out);
   NGPDE_LAUNCH_CHECK("edge_combine_fwd_kernel");
@@ -752,8 +880,14 @@ int32_t launch_edge_combine_fwd(const ngpde_graph *g, int h, int act, const floa
 int32_t launch_edge_combine_bwd(const ngpde_graph *g, int h, int act, const float *da, const float *z, float *dz, float *dP,
                                 float *dQ, hipStream_t stream) {
   if (g->n_nodes == 0 || h == 0) return NGPDE_OK;
-  hipLaunchKernelGGL(edge_combine_bwd_target_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h, act,
-                     g->by_t.rowptr, da, z, dz, dP);
+  if (h % 4 == 0 && h <= 256 && al16(da) && al16(z) && al16(dz) && al16(dP)) {
+    NGPDE_DPL_DISPATCH(edge_combine_bwd_target4_kernel, h / 4, dim3(rows4(g->n_nodes)), stream, (int)g->n_nodes, h / 4, act,
+                       g->by_t.rowptr, reinterpret_cast<const float4 *>(da), reinterpret_cast<const float4 *>(z),
+                       reinterpret_cast<float4 *>(dz), reinterpret_cast<float4 *>(dP))
+  } else {
+    hipLaunchKernelGGL(edge_combine_bwd_target_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h, act,
+                       g->by_t.rowptr, da, z, dz, dP);
+  }
   NGPDE_LAUNCH_CHECK("edge_combine_bwd_target_kernel");
   if (dQ) {
     hipLaunchKernelGGL(edge_sum_by_source_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, h,
@@ -773,6 +907,12 @@ int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_
 
 int32_t launch_segment_reduce_fwd(const ngpde_graph *g, int d, int aggr, const float *M, float *out, hipStream_t stream) {
   if (g->n_nodes == 0 || d == 0) return NGPDE_OK;
+  if ((aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN) && d % 4 == 0 && d <= 256 && al16(M) && al16(out)) {
+    NGPDE_DPL_DISPATCH(segment_sum4_kernel, d / 4, dim3(rows4(g->n_nodes)), stream, (int)g->n_nodes, d / 4, aggr == NGPDE_AGGR_MEAN ? 1 : 0,
+                       g->by_t.rowptr, reinterpret_cast<const float4 *>(M), reinterpret_cast<float4 *>(out))
+    NGPDE_LAUNCH_CHECK("segment_sum4_kernel");
+    return NGPDE_OK;
+  }
   hipLaunchKernelGGL(segment_reduce_fwd_kernel, dim3(rows4(g->n_nodes)), dim3(256), 0, stream, (int)g->n_nodes, d, aggr,
                      g->by_t.rowptr, M, out);
   NGPDE_LAUNCH_CHECK("segment_reduce_fwd_kernel");
