@@ -15,7 +15,12 @@
 //   2  neighbour flags with plain stores + agent release fence, agent acquire fence + plain loads
 //   3  grid barrier (8 sharded arrival counters, every workgroup polls all shards), sc1 stores / sc1 loads
 //   4  grid barrier, plain stores + release fence, acquire fence + plain loads
-// argv: [mode or -1] [phases] [work in 10 ns ticks] [foreign rows only 0/1] [poll without s_sleep 0/1]
+//   5  tagged packets, no flags at all: every exchanged dword travels as an 8-byte packet {value, phase tag} (sc1 stores, two
+//      dwordx4 per lane = four packets); the consumer's lanes poll THEIR OWN packets of the foreign halo rows (sc1 loads) until
+//      all four tags carry the producer's phase, then put the values into LDS.  One fabric traversal per phase instead of
+//      flag-then-rows; needs a symmetric halo relation (a tile that reads a neighbour's rows is read by it) for the
+//      write-after-read safety of the two ping-pong buffers.  Own rows stay in LDS (foreign rows only).
+// argv: [mode or -1] [phases] [work in 10 ns ticks] [foreign rows only 0/1] [poll without s_sleep 0/1] [mode 5: s_sleep between polls]
 // Every payload word carries (phase, row), every gathered word is checked, and every spin is bounded (abort word + timeout).
 // build + run:  hipcc -O2 --offload-arch=gfx950 tools/persistent_floor.hip -o /tmp/persistent_floor && /tmp/persistent_floor
 #include <hip/hip_runtime.h>
@@ -33,6 +38,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 struct Params {
   float *buf[2];
+  float *pbuf[2];       // mode 5: [rows][64][2] {value, tag} packets
   unsigned *flags;      // [kTiles] last finished phase + 1, one 128-B line each
   unsigned *shards;     // [8] arrival counters, one 128-B line each
   unsigned *abort_word; // != 0: somebody timed out
@@ -43,6 +49,7 @@ struct Params {
   int work_ticks;    // simulated arithmetic between the gather and the stores, in 10 ns ticks (s_memrealtime)
   int foreign_only;  // gather only the 24 rows of OTHER tiles (a persistent kernel keeps its own rows on chip)
   int no_sleep;
+  int poll_sleep;    // mode 5: s_sleep argument between polling rounds (64 clocks each)
 };
 
 __device__ __forceinline__ int xcd_tile(int b, int nb) {
@@ -81,6 +88,73 @@ __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p)
   unsigned bad = 0;
   if (tid == 0) s_ok = 1;
   __syncthreads();
+  if (p.mode == 5) {
+    // ---- tagged packets: no flags, no drain, no publish ----
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    for (int ph = 1; ph <= p.phases; ++ph) {
+      const unsigned *src = reinterpret_cast<const unsigned *>(p.pbuf[(ph + 1) & 1]);
+      unsigned *dst = reinterpret_cast<unsigned *>(p.pbuf[ph & 1]);
+      if (ph > 1) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool done[2] = {false, false};
+        const unsigned want = (unsigned)(ph - 1);
+        bool ok = true;
+        for (unsigned it = 1;; ++it) {
+          bool all_done = true;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int hh = grp + 32 * k;
+            const bool mine = hh >= kRows && hh < kHalo;         // foreign rows only: slots 32 .. 55
+            if (mine && !done[k]) {
+              const unsigned *g = src + (size_t)hrow[k] * (2 * kD) + q * 8;
+              u4v a, b;
+              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(a), "=&v"(b) : "v"(g) : "memory");
+              if (a[1] == want && a[3] == want && b[1] == want && b[3] == want) {
+                done[k] = true;
+                f4v v = {__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(b[0]), __uint_as_float(b[2])};
+                reinterpret_cast<f4v *>(lds)[hh * kLpr + q] = v;
+              } else {
+                all_done = false;
+              }
+            }
+          }
+          if (!__any((int)!all_done)) break;
+          if ((it & 255u) == 0 && !spin_ok(t0, p.abort_word)) { ok = false; break; }
+          for (int sl = 0; sl < p.poll_sleep; ++sl) __builtin_amdgcn_s_sleep(1);   // back-off between polling rounds (64 clocks each)
+        }
+        if (!ok) s_ok = 0;
+        __syncthreads();
+        if (!s_ok) break;
+        if (p.check) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int hh = grp + 32 * k;
+            if (hh >= kRows && hh < kHalo) {
+              const f4v v = reinterpret_cast<const f4v *>(lds)[hh * kLpr + q];
+              const int row = p.halo[tile * kHalo + hh];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bad += (__float_as_uint(v[c]) != payload(ph - 1, row, 4 * q + c));
+            }
+          }
+        }
+      }
+      if (p.work_ticks > 0) {
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - w0 < (unsigned long long)p.work_ticks) __builtin_amdgcn_s_sleep(2);
+      }
+      {
+        const int row = tile * kRows + grp;
+        u4v a = {payload(ph, row, 4 * q), (unsigned)ph, payload(ph, row, 4 * q + 1), (unsigned)ph};
+        u4v b = {payload(ph, row, 4 * q + 2), (unsigned)ph, payload(ph, row, 4 * q + 3), (unsigned)ph};
+        unsigned *d = dst + (size_t)row * (2 * kD) + q * 8;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(d), "v"(a), "v"(b) : "memory");
+      }
+      __syncthreads();   // everybody is done with the LDS halo before the next phase refills it
+    }
+    if (bad) atomicAdd(p.errors, bad);
+    return;
+  }
   for (int ph = 1; ph <= p.phases; ++ph) {
     const float *src = p.buf[(ph + 1) & 1];
     float *dst = p.buf[ph & 1];
@@ -172,10 +246,13 @@ int main(int argc, char **argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;
   const int phases = argc > 2 ? atoi(argv[2]) : 1200;
   const int work = argc > 3 ? atoi(argv[3]) : 0, foreign = argc > 4 ? atoi(argv[4]) : 0, no_sleep = argc > 5 ? atoi(argv[5]) : 0;
+  const int poll_sleep = argc > 6 ? atoi(argv[6]) : 0;
   const size_t elems = (size_t)kTiles * kRows * kD;
   Params p{};
   CK(hipMalloc(&p.buf[0], elems * 4));
   CK(hipMalloc(&p.buf[1], elems * 4));
+  CK(hipMalloc(&p.pbuf[0], elems * 8));
+  CK(hipMalloc(&p.pbuf[1], elems * 8));
   CK(hipMalloc(&p.flags, kTiles * 128));
   CK(hipMalloc(&p.shards, 8 * 128));
   CK(hipMalloc(&p.abort_word, 128));
@@ -199,7 +276,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_nbr, nbr.size() * 4));
   CK(hipMemcpy(d_halo, halo.data(), halo.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
-  p.halo = d_halo; p.nbr = d_nbr; p.phases = phases; p.work_ticks = work; p.foreign_only = foreign; p.no_sleep = no_sleep;
+  p.halo = d_halo; p.nbr = d_nbr; p.phases = phases; p.work_ticks = work; p.foreign_only = foreign; p.no_sleep = no_sleep; p.poll_sleep = poll_sleep;
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1;
@@ -207,8 +284,9 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e1));
   const char *names[] = {"free-running (no sync, data movement only)", "neighbour flags, sc1 stores + sc1 loads",
                          "neighbour flags, plain stores + release / acquire fences", "grid barrier (8 shards), sc1 stores + sc1 loads",
-                         "grid barrier (8 shards), plain stores + release / acquire fences"};
-  for (int mode = 0; mode < 5; ++mode) {
+                         "grid barrier (8 shards), plain stores + release / acquire fences",
+                         "tagged 8-byte packets {value, phase}, no flags (foreign rows only)"};
+  for (int mode = 0; mode < 6; ++mode) {
     if (only >= 0 && mode != only) continue;
     for (int check = 1; check >= 0; --check) {
       p.mode = mode; p.check = check;
@@ -217,6 +295,8 @@ int main(int argc, char **argv) {
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipMemsetAsync(p.buf[0], 0, elems * 4, s));
         CK(hipMemsetAsync(p.buf[1], 0, elems * 4, s));
+        CK(hipMemsetAsync(p.pbuf[0], 0, elems * 8, s));
+        CK(hipMemsetAsync(p.pbuf[1], 0, elems * 8, s));
         CK(hipMemsetAsync(p.flags, 0, kTiles * 128, s));
         CK(hipMemsetAsync(p.shards, 0, 8 * 128, s));
         CK(hipMemsetAsync(p.abort_word, 0, 128, s));
@@ -235,8 +315,8 @@ int main(int argc, char **argv) {
         if (a) break;
       }
       printf("{\"mode\": %d, \"what\": \"%s\", \"grid\": %d, \"block\": %d, \"phases\": %d, \"payload_check\": %d, "
-             "\"work_us\": %.2f, \"foreign_rows_only\": %d, \"no_sleep\": %d, \"us_per_phase\": %.3f, \"bad_words\": %u, \"aborted\": %u}\n",
-             mode, names[mode], kTiles, kThreads, phases, check, work * 0.01, foreign, no_sleep, best * 1000.f / phases, err, ab);
+             "\"work_us\": %.2f, \"foreign_rows_only\": %d, \"no_sleep\": %d, \"poll_sleep\": %d, \"us_per_phase\": %.3f, \"bad_words\": %u, \"aborted\": %u}\n",
+             mode, names[mode], kTiles, kThreads, phases, check, work * 0.01, foreign, no_sleep, poll_sleep, best * 1000.f / phases, err, ab);
       fflush(stdout);
     }
   }
