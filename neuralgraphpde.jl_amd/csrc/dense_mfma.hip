@@ -235,9 +235,12 @@ __device__ __forceinline__ void acc_to_lds(float *out, int wave, int lane, const
       for (int reg = 0; reg < 4; ++reg) out[(wave * 32 + rt * 16 + 4 * kq + reg) * OS2 + ct * 16 + i] = acc[rt][ct][reg];
 }
 
-__global__ __launch_bounds__(256) void dense_wide_fwd_kernel(int64_t n, SegTable segs, int din, int dout, int act,
+// din_main <= din: the leading features contracted on the matrix pipe; the (few, narrow) trailing ones -- node coordinates, the
+// per-graph parameters theta of MPPDEConv (src/layers.jl:409-418) -- enter as a rank-(din - din_main) update in the epilogue, so
+// that a 64 + 2 + 2 wide input costs two 32-deep K steps, not three with a ragged, scalar-loaded last one.
+__global__ __launch_bounds__(256, 4) void dense_wide_fwd_kernel(int64_t n, SegTable segs, int din_all, int dout, int act,
                                                              const float *__restrict__ wt, const float *__restrict__ bias,
-                                                             float *__restrict__ y, float *__restrict__ save_z) {
+                                                             float *__restrict__ y, float *__restrict__ save_z, int din) {
   __shared__ __attribute__((aligned(16))) float lds[kWideLds];
   float *ldsA = lds, *ldsBt = lds + BM2 * LS2;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -290,8 +293,20 @@ __global__ __launch_bounds__(256) void dense_wide_fwd_kernel(int64_t n, SegTable
   for (int p = 0; p < 8; ++p) {
     const float4 v = *reinterpret_cast<const float4 *>(&lds[((tid >> 4) + 16 * p) * OS2 + oc]);
     zz[p] = make_float4(v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]);
-    aa[p] = zz[p];
   }
+  for (int k = din; k < din_all; ++k) {   // the narrow trailing features (uniform trip count, usually 0, 2 or 4)
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (col0 + oc + j < dout) ? wt[(size_t)k * dout + col0 + oc + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t r = row0 + (tid >> 4) + 16 * p;
+      const float xv = r < n ? seg_load(segs, r, k) : 0.f;
+      zz[p] = make_float4(fmaf(xv, w[0], zz[p].x), fmaf(xv, w[1], zz[p].y), fmaf(xv, w[2], zz[p].z), fmaf(xv, w[3], zz[p].w));
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) aa[p] = zz[p];
   f4n_act<8>(act, aa);   // one uniform activation switch for the thread's 32 values
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -521,8 +536,12 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
                              const float *bias, float *y, float *save_z, hipStream_t stream) {
   if (n == 0 || dout == 0) return NGPDE_OK;
   if (use_wide_tiles(n, dout)) {
+    // trailing narrow blocks (<= 8 features in total behind a multiple of 32) leave the K loop: see dense_wide_fwd_kernel
+    int din_main = din;
+    for (int i = segs.n - 1; i >= 1 && din - segs.offset[i] <= 8; --i)
+      if (segs.offset[i] % BK2 == 0) din_main = segs.offset[i];
     hipLaunchKernelGGL(dense_wide_fwd_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (dout + BN - 1) / BN), dim3(256), 0, stream,
-                       n, segs, din, dout, act, wt, bias, y, save_z);
+                       n, segs, din, dout, act, wt, bias, y, save_z, din_main);
     NGPDE_LAUNCH_CHECK("dense_wide_fwd_kernel");
     return NGPDE_OK;
   }
