@@ -103,7 +103,20 @@ __device__ __forceinline__ f32x4 mfma_block(const float *pa, const float *pb) {
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/stamps_gat.py): shader-clock stamps of thread 0 of every workgroup
+unsigned long long *g_gat_stamps = nullptr;
+#define NGPDE_GST(k) do { if (threadIdx.x == 0 && p.stamps) { p.stamps[(size_t)blockIdx.x * 16 + (k)] = clock64(); if ((k) == 0 || (k) == 10) p.stamps[(size_t)blockIdx.x * 16 + 11 + (k) / 10] = wall_clock64(); } } while (0)
+#define NGPDE_GST_FIELD unsigned long long *stamps;
+#define NGPDE_GST_SET(kk) kk.stamps = g_gat_stamps;
+#else
+#define NGPDE_GST(k)
+#define NGPDE_GST_FIELD
+#define NGPDE_GST_SET(kk)
+#endif
+
 struct GatFwdK {
+  NGPDE_GST_FIELD
   const float *x, *wt, *a, *bias;
   const int4 *sched;
   const int2 *halo;
@@ -128,6 +141,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
   const int tile = xcd_tile(blockIdx.x, p.n_tiles);
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
 
+  NGPDE_GST(0);
   TileMeta m;
   tile_meta(p.halo, p.slots, p.sched, p.x, tile, grp, q, ldsXh, m);
   // v_which,k[i] = sum_c a[which*C + c][k] W[k*C + c][i]: the workgroup reads W once, coalesced (thread: input feature i =
@@ -165,7 +179,9 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
     Xh4[kHaloCap * GG::LPR + q] = f4_zero();
     if (q < 4) ldsAr[kHaloCap * 4 + q] = 0.f;
   }
+  NGPDE_GST(1);
   __syncthreads();   // staged rows (DMA) and v vectors visible
+  NGPDE_GST(2);
 
   // ---- score halves from the staged rows: ar of every staged row, al of the own row (= slot `grp`)
   float al[4] = {0.f, 0.f, 0.f, 0.f};
@@ -189,7 +205,9 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 #pragma unroll
     for (int k = 0; k < H; ++k) al[k] = row_sum16(dot4(xo, vl[k]));
   }
+  NGPDE_GST(3);
   __syncthreads();
+  NGPDE_GST(4);
 
   // ---- softmax over the row's entries: lane q owns entries q and q + 16, all heads
   const int deg = m.sc.x >= 0 ? m.sc.z : 0;
@@ -243,6 +261,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  NGPDE_GST(5);
   // ---- per-head aggregates of the staged rows (one LDS row read serves all heads)
   {
     const int wmax = wave_max_deg(deg);
@@ -265,7 +284,9 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 #pragma unroll
     for (int k = 0; k < H; ++k) *reinterpret_cast<float4 *>(&ldsA[grp * kATS + k * GD + 4 * q]) = acc[k];
   }
+  NGPDE_GST(6);
   __syncthreads();   // aggregates complete; the coefficients are dead: their region takes the output tile
+  NGPDE_GST(7);
   float *ldsZ = ldsS;
   {   // out[:, ct*16..] = A_head(ct) x W[:, ct*16..]: 2 row tiles x 4 column tiles = one tile per wave
     const int rt = wave_u & 1, ct = wave_u >> 1;
@@ -284,13 +305,16 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) ldsZ[(rt * 16 + 4 * kq + reg) * GG::TS + ct * 16 + i] = acc[reg];
   }
+  NGPDE_GST(8);
   __syncthreads();
+  NGPDE_GST(9);
   if (m.sc.x >= 0) {
     const size_t idx4 = (size_t)m.sc.x * GG::LPR + q;
     const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[grp * GG::TS + 4 * q]), b4);
     if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
     reinterpret_cast<float4 *>(p.y)[idx4] = f4_act(p.act, z);
   }
+  NGPDE_GST(10);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -649,6 +673,13 @@ inline GatWs gat_ws(const ngpde_graph *g, int heads) {
 
 }  // namespace
 
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_gat_stamps(unsigned long long *dev_buf) {   // [n_tiles][16] or NULL
+  g_gat_stamps = dev_buf;
+  return NGPDE_OK;
+}
+#endif
+
 bool gat_layer_fused_supported(const ngpde_graph *g, int din, int heads, int c) {
   return g && g->has_norm && g->by_t.halo_ok && g->by_s.halo_ok && din == GD && heads * c == GD &&
          (heads == 1 || heads == 2 || heads == 4) && (uint64_t)g->n_nodes * GD * 4 < (1ull << 32) && !no_fused_gat_layer_env();
@@ -662,6 +693,7 @@ int32_t launch_gat_layer_fwd(const ngpde_graph *g, int heads, float slope, int a
   GatFwdK k;
   k.x = x; k.wt = wt; k.a = a; k.bias = bias; k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
   k.n_tiles = fused_num_blocks(g->n_nodes); k.act = act; k.slope = slope; k.y = y; k.alpha = alpha; k.save_z = save_z;
+  NGPDE_GST_SET(k)
   const dim3 grid(k.n_tiles), block(kThreads);
   switch (heads) {
     case 1: hipLaunchKernelGGL(gat_layer_fwd_kernel<1>, grid, block, 0, stream, k); break;
