@@ -162,7 +162,7 @@ def case_gno(gname, g, cin, cout, phi, act, aggr, seed):
     save(f"gno_{gname}", dict(layer="gno", aggr=aggr, act=act, cin=cin, cout=cout, phi=acts(phi)), arr)
 
 
-def case_gat(gname, g, din, heads, c, act, concat, seed):
+def case_gat(gname, g, din, heads, c, act, concat, seed, tag=""):
     og = ograph(g)
     x = val((din, g["n"]), seed)
     W, a = val((c * heads, din), seed + 1, 1 / np.sqrt(din)), val((2 * c, heads), seed + 2, 0.5)
@@ -173,7 +173,7 @@ def case_gat(gname, g, din, heads, c, act, concat, seed):
     arr = graph_arrays(g)
     arr.update({"x": x, "p.weight": W, "p.a": a, "p.bias": b, "R": R, "y": y, "d.x": gr["x"], "d.weight": gr["weight"],
                 "d.a": gr["a"], "d.bias": gr["bias"]})
-    save(f"gat_{gname}" + ("" if concat else "_mean"), dict(layer="gat", act=act, din=din, heads=heads, c=c, concat=concat), arr)
+    save(f"gat_{gname}" + ("" if concat else "_mean") + tag, dict(layer="gat", act=act, din=din, heads=heads, c=c, concat=concat), arr)
 
 
 def case_spectral():
@@ -222,6 +222,11 @@ def main():
     # GAT-style aggregation
     case_gat("rad64", r64, 8, 2, 3, "relu", True, 22)
     case_gat("rad64", r64, 8, 2, 3, "identity", False, 23)
+    # BASELINE config 3's shape (64 => 4 heads x 16): on the GPU this is the one-launch layer (ngpde_gat_layer_forward)
+    case_gat("rad64", r64, 64, 4, 16, "tanh", True, 26, tag="_c3shape")
+    # product aggregation (src/layers.jl:49) and a GNO shape whose message runs on the matrix pipe (out = 16, k = 16)
+    case_edgeconv("rad64_prod", r64, 4, 2, [dense(10, 8, "tanh", 27), dense(8, 5, "tanh", 28)], "*", 27)
+    case_gno("rad64_mfma", r64, 8, 16, [dense(6, 16, "relu", 29), dense(16, 128, "identity", 30)], "identity", "mean", 29)
     case_spectral()
     case_node(r64, 8, "tsit5", 3, 0.1, 24)
     case_node(r64, 8, "euler", 4, 0.05, 25)

@@ -63,6 +63,8 @@ ACT = {"identity": lambda z: z, "relu": torch.relu, "tanh": torch.tanh, "sigmoid
 
 
 def scatter_t(op, M, idx, n):
+    if op == "*":                                          # scatter(*): neutral element 1 for an empty neighbourhood
+        return torch.ones(M.shape[0], n, dtype=M.dtype).index_reduce(1, idx, M, "prod", include_self=True)
     out = torch.zeros(M.shape[0], n, dtype=M.dtype).index_add(1, idx, M)
     if op == "mean":
         cnt = torch.zeros(n, dtype=M.dtype).index_add(0, idx, torch.ones(idx.numel(), dtype=M.dtype))
