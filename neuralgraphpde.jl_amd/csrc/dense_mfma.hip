@@ -327,6 +327,131 @@ __global__ __launch_bounds__(256, 4) void dense_wide_fwd_kernel(int64_t n, SegTa
   }
 }
 
+// ---- streaming form of the wide forward for a 64-deep contraction and <= 64 outputs (the node-level Dense of the edge-function
+// layers: h => 64, [h | d | theta] => 64).  Persistent workgroups (one resident wave of them, three per CU) walk the 128-row
+// tiles; W^T is staged once per workgroup; the WHOLE 128 x 64 input tile goes memory -> LDS by LDS-DMA in one burst (32 KB in
+// flight per workgroup, no register staging), then eight waves of 16 rows run 64 MFMAs each without another global load.  The
+// DMA writes four 256-byte rows linearly per instruction, which as a plain row-major image would put the 16 rows of an MFMA
+// operand read on the same banks; so lane s of a row fetches chunk s ^ (row & 15) of that row -- still one coalesced 256-byte row
+// per 16 lanes -- and the operand read of chunk k4 of row r looks at slot k4 ^ (r & 15): conflict-free.  Trailing narrow
+// features enter in the epilogue as in dense_wide_fwd_kernel.
+// Measured at 524 288 x 64 => 64 (tools/bench_dense.py; the matrix-pipe floor is 27 us, a copy of the same bytes 37 us):
+// 128-row tiles through registers 82 us -> four waves per SIMD 76 -> whole tile by LDS-DMA, one workgroup per tile 75-79 ->
+// persistent 68.  By the SQ counters (tools/pmc_dense.sh) the waves are 56 % issue-stalled and 32 % parked with the matrix
+// pipe 38 % busy; staggering the resident workgroups by thirds of a tile period changed nothing, and a barrier-free form in
+// which every wave pipelines its own 16 rows and stores from the accumulator registers (64-byte segments) was slower (98 us).
+constexpr int kStreamThreads = 512;
+constexpr int kStreamLds = BM2 * OS2 + BN * (64 + 4);   // [input tile, later the output tile (128 x 68)] [W^T, resident]
+__global__ __launch_bounds__(kStreamThreads, 6) void dense_stream64_fwd_kernel(int64_t n, SegTable segs, int din_all, int dout, int act,
+                                                                               const float *__restrict__ wt, const float *__restrict__ bias,
+                                                                               float *__restrict__ y, float *__restrict__ save_z, int n_tiles) {
+  constexpr int KM = 64, BS = KM + 4;
+  __shared__ __attribute__((aligned(16))) float lds[kStreamLds];
+  float *ldsA = lds, *ldsBt = lds + BM2 * OS2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {   // W -> Bt[col][k], transposed through registers (coalesced dword loads down the columns), once per workgroup
+    const int bc = tid & 63, bk = 8 * (tid >> 6);
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (bc < dout) ? wt[(size_t)(bk + j) * dout + bc] : 0.f;
+    *reinterpret_cast<float4 *>(&ldsBt[bc * BS + bk]) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4 *>(&ldsBt[bc * BS + bk + 4]) = make_float4(w[4], w[5], w[6], w[7]);
+  }
+  const int i = lane & 15, kq = lane >> 4;
+  const int oc = 4 * (tid & 15);
+  const bool vec = (dout % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(save_z)) & 15) == 0;
+  float b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = (bias && oc + j < dout) ? bias[oc + j] : 0.f;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * BM2;
+    __syncthreads();   // the previous tile's output rows have left the LDS tile that the next rows overwrite (first pass: W^T written)
+    {   // input tile: four DMA instructions per wave, four rows each
+      const int rl = lane >> 4, s16 = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + rl;
+        const int64_t gr = min(row0 + r, n - 1);                  // rows past the end read the last row (never stored)
+        const int k = 4 * (s16 ^ (r & 15));
+        const SegRef sr = seg_find(segs, k);
+        const float *g = sr.ptr + seg_row(gr, sr.row_div) * sr.width + (k - sr.offset);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsA) + ((wave * 4 + j) * 4) * 16 + lane),
+                                         16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const int r = wave * 16 + i;
+#pragma unroll
+      for (int kh = 0; kh < KM / 16; ++kh) {
+        const float4 a4 = reinterpret_cast<const float4 *>(ldsA)[r * 16 + ((4 * kh + kq) ^ (r & 15))];
+        float4 b4[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const float4 *>(&ldsBt[(ct * 16 + i) * BS + 16 * kh + 4 * kq]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const float bv[4] = {b4[ct].x, b4[ct].y, b4[ct].z, b4[ct].w};
+            acc[ct] = mfma16(av[rr], bv[rr], acc[ct]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) lds[(wave * 16 + 4 * kq + reg) * OS2 + ct * 16 + i] = acc[ct][reg];
+    __syncthreads();
+    // epilogue: thread (row = tid / 16 + 32 p, columns 4 (tid % 16) .. + 3)
+    float4 zz[4], aa[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float4 v = *reinterpret_cast<const float4 *>(&lds[((tid >> 4) + 32 * p) * OS2 + oc]);
+      zz[p] = make_float4(v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]);
+    }
+    for (int k = KM; k < din_all; ++k) {   // the narrow trailing features
+      float w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (oc + j < dout) ? wt[(size_t)k * dout + oc + j] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int64_t r = row0 + (tid >> 4) + 32 * p;
+        const float xv = r < n ? seg_load(segs, r, k) : 0.f;
+        zz[p] = make_float4(fmaf(xv, w[0], zz[p].x), fmaf(xv, w[1], zz[p].y), fmaf(xv, w[2], zz[p].z), fmaf(xv, w[3], zz[p].w));
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) aa[p] = zz[p];
+    f4n_act<4>(act, aa);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t r = row0 + (tid >> 4) + 32 * p;
+      if (r >= n || oc >= dout) continue;
+      if (vec) {
+        if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + oc) = zz[p];
+        *reinterpret_cast<float4 *>(y + r * dout + oc) = aa[p];
+      } else {
+        const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (oc + j < dout) {
+            if (save_z) save_z[r * dout + oc + j] = z[j];
+            y[r * dout + oc + j] = a4[j];
+          }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
                                                                    const float *__restrict__ dz,
                                                                    const float *__restrict__ wt) {
@@ -540,6 +665,25 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
     int din_main = din;
     for (int i = segs.n - 1; i >= 1 && din - segs.offset[i] <= 8; --i)
       if (segs.offset[i] % BK2 == 0) din_main = segs.offset[i];
+    // a 64-deep contraction over 16-byte-loadable blocks: the streaming form (whole input tile by LDS-DMA in one burst)
+    static const bool no_stream = getenv("NGPDE_DENSE_NO_STREAM") != nullptr;
+    bool stream_ok = !no_stream && din_main == 64 && dout <= 64;
+    for (int i = 0; i < segs.n && segs.offset[i] < din_main; ++i) stream_ok = stream_ok && segs.vec[i] && segs.offset[i + 1] <= din_main;
+    if (stream_ok) {
+      static int cus = 0, per_cu = 0;
+      if (cus == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_stream64_fwd_kernel, kStreamThreads, 0);
+        cus = std::max(cus, 1); per_cu = std::max(per_cu, 1);
+      }
+      const int n_tiles = (int)((n + BM2 - 1) / BM2);
+      hipLaunchKernelGGL(dense_stream64_fwd_kernel, dim3((unsigned)std::min(n_tiles, cus * per_cu)), dim3(kStreamThreads), 0, stream,
+                         n, segs, din, dout, act, wt, bias, y, save_z, n_tiles);
+      NGPDE_LAUNCH_CHECK("dense_stream64_fwd_kernel");
+      return NGPDE_OK;
+    }
     hipLaunchKernelGGL(dense_wide_fwd_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (dout + BN - 1) / BN), dim3(256), 0, stream,
                        n, segs, din, dout, act, wt, bias, y, save_z, din_main);
     NGPDE_LAUNCH_CHECK("dense_wide_fwd_kernel");
