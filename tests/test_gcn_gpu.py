@@ -447,12 +447,24 @@ def _oracle_node_with_seed(params, og, u0, seed, tableau, dt, nsteps, act="relu"
     return uT, du0, acc
 
 
+def needs_persistent_plan(monkeypatch=None):
+    """The persistent solver plan is what these tests are about: they lift a suite-wide NGPDE_NO_PERSISTENT (read at every plan
+    creation) and skip under NGPDE_NO_HALO, which the library reads once and which leaves no plan it could run on."""
+    import os
+    if os.environ.get("NGPDE_NO_HALO") == "1":
+        pytest.skip("NGPDE_NO_HALO=1: no LDS-staged tiles, so no persistent plan")
+    if monkeypatch is not None:
+        monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+
+
 @pytest.mark.parametrize("tab,persistent", [("tsit5", True), ("euler", True), ("tsit5", False)])
 def test_node_batch_of_identical_graphs_member_by_member(tab, persistent, monkeypatch):
     # batch([g, g, g]) (test/runtests.jl:89-102; "all graphs need to have the same structure", src/layers.jl:359-361): the
     # persistent plan solves the members one after the other on the member's handle.  Every member against the float64 oracle of
     # that member alone, parameter gradients against the sum over the members; the same through the one-big-handle path.
-    if not persistent:
+    if persistent:
+        needs_persistent_plan(monkeypatch)
+    else:
         monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
     N, d, K, nsteps, dt = 1000, 64, 3, 2, 0.1
     g, og, params = spatial_case(N, 4 * N, d, seed=91)      # a radius-style graph: its tiles fit the LDS halo (persistent plan)
@@ -493,7 +505,8 @@ def test_node_batch_of_identical_graphs_member_by_member(tab, persistent, monkey
 
 
 @pytest.mark.parametrize("tab,N,nsteps", [("tsit5", 1000, 3), ("euler", 2048, 5), ("tsit5", 77, 2)])
-def test_node_persistent_plan_against_oracle(tab, N, nsteps):
+def test_node_persistent_plan_against_oracle(tab, N, nsteps, monkeypatch):
+    needs_persistent_plan(monkeypatch)
     # the persistent plan (one launch per direction, tiles synchronised by phase flags) on graphs whose tiles fit the LDS halo:
     # u(T), du0 and the parameter gradients against the float64 oracle; a last tile with padding rows (N = 1000, 77)
     d, dt = 64, 0.1
@@ -526,7 +539,8 @@ def test_node_persistent_plan_against_oracle(tab, N, nsteps):
 
 
 @pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_node_persistent_forward_only_plan_any_activation(act):
+def test_node_persistent_forward_only_plan_any_activation(act, monkeypatch):
+    needs_persistent_plan(monkeypatch)
     # without gradients the persistent forward launch takes any activation (the adjoint launch is relu-only: sign-bit tape)
     N, d, nsteps, dt = 1500, 64, 4, 0.05
     g, og, params = spatial_case(N, 4 * N, d, seed=5)
@@ -548,6 +562,7 @@ def test_node_persistent_forward_only_plan_any_activation(act):
 
 
 def test_node_persistent_and_replayed_plans_agree_bitwise(monkeypatch):
+    needs_persistent_plan(monkeypatch)
     # same arithmetic, operation for operation: u(T) and du0 of the persistent plan equal the replayed plan's bit for bit;
     # the parameter gradients differ only in the order the per-tile partial sums are added
     N, d, nsteps, dt = 4096, 64, 3, 0.02

@@ -629,7 +629,8 @@ def _rk_oracle(rhs_fwd, rhs_bwd, names, shapes, u0, tab, dt, steps):
 
 
 @pytest.mark.parametrize("solver,steps", [("tsit5", 2), ("euler", 3)])
-def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps):
+def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps, monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)       # (the suite may run under that switch)
     # BASELINE config 3 "as ODE RHS" on a graph whose tiles fit the LDS halo: every right-hand-side evaluation is the one-launch
     # GAT layer, every Runge-Kutta combination (and every combination of the discrete adjoint) one ngpde_rk_stage_combine launch
     n, H, C_ = 300, 4, 16
@@ -660,7 +661,8 @@ def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps):
     assert torch.equal(uT2, uT.detach())
 
 
-def test_captured_generic_solve_replays_and_follows_parameter_updates():
+def test_captured_generic_solve_replays_and_follows_parameter_updates(monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
     # NeuralODE(..., capture=True): the whole stepping loop and the whole discrete adjoint are HIP graphs captured at the first
     # call; replays must reproduce the eager path bit for bit, for new inputs and after an in-place parameter update
     n, H, C_ = 300, 4, 16
