@@ -15,6 +15,8 @@
 //   2  neighbour flags with plain stores + agent release fence, agent acquire fence + plain loads
 //   3  grid barrier (8 sharded arrival counters, every workgroup polls all shards), sc1 stores / sc1 loads
 //   4  grid barrier, plain stores + release fence, acquire fence + plain loads
+//   6  as 1, with `pollers` (argv[7]) waves polling out of step; the first that sees every flag releases the others through LDS
+//   7  inbox counters: every producer atomic-adds 1 to the (phase-parity) inbox word of each of its readers; a consumer polls ONE word
 //   5  tagged packets, no flags at all: every exchanged dword travels as an 8-byte packet {value, phase tag} (sc1 stores, two
 //      dwordx4 per lane = four packets); the consumer's lanes poll THEIR OWN packets of the foreign halo rows (sc1 loads) until
 //      all four tags carry the producer's phase, then put the values into LDS.  One fabric traversal per phase instead of
@@ -49,7 +51,8 @@ struct Params {
   int work_ticks;    // simulated arithmetic between the gather and the stores, in 10 ns ticks (s_memrealtime)
   int foreign_only;  // gather only the 24 rows of OTHER tiles (a persistent kernel keeps its own rows on chip)
   int no_sleep;
-  int poll_sleep;    // mode 5: s_sleep argument between polling rounds (64 clocks each)
+  int poll_sleep;    // mode 5: s_sleep rounds between polls; mode 6: start offset of polling wave k = k * poll_sleep sleeps
+  int pollers;       // mode 6: polling waves
 };
 
 __device__ __forceinline__ int xcd_tile(int b, int nb) {
@@ -75,18 +78,18 @@ __device__ __forceinline__ bool spin_ok(unsigned long long t0, unsigned *abort_w
 
 __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p) {
   __shared__ __attribute__((aligned(16))) float lds[(kHalo + 8) * kD];
-  __shared__ int s_ok;
+  __shared__ int s_ok, s_go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = tid / kLpr, q = tid % kLpr;
   const int tile = xcd_tile(blockIdx.x, kTiles);
-  const bool sc1 = (p.mode == 1 || p.mode == 3), fences = (p.mode == 2 || p.mode == 4);
+  const bool sc1 = (p.mode == 1 || p.mode == 3 || p.mode == 6 || p.mode == 7), fences = (p.mode == 2 || p.mode == 4);
   // metadata stays in registers for the whole launch: halo row ids of this thread's DMA slots, the flags this lane polls
   int hrow[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) hrow[k] = p.halo[tile * kHalo + min(grp + 32 * k, kHalo - 1)];
   const int my_nbr = (lane < kNbr) ? p.nbr[tile * kNbr + lane] : tile;
   unsigned bad = 0;
-  if (tid == 0) s_ok = 1;
+  if (tid == 0) { s_ok = 1; s_go = 0; }
   __syncthreads();
   if (p.mode == 5) {
     // ---- tagged packets: no flags, no drain, no publish ----
@@ -159,7 +162,39 @@ __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p)
     const float *src = p.buf[(ph + 1) & 1];
     float *dst = p.buf[ph & 1];
     // ---- wait for the producers of this phase's halo rows (they finished phase ph - 1) ----
-    if (ph > 1 && p.mode != 0) {
+    if (ph > 1 && p.mode == 7) {
+      // inbox counters: one word per tile and phase parity, every producer adds 1 to the inbox of each tile that reads it; the
+      // consumer polls ONE word (its own inbox of the previous phase's parity) instead of one flag per neighbour
+      if (wave == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned need = (unsigned)kNbr * (unsigned)(ph / 2);      // phases 1 .. ph - 1 with the parity of ph - 1: ph / 2 of them
+        bool ok = true;
+        for (;;) {
+          const unsigned f = __hip_atomic_load(p.flags + 32 * tile + ((ph - 1) & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (f >= need) break;
+          if (!spin_ok(t0, p.abort_word)) { ok = false; break; }
+          if (!p.no_sleep) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && lane == 0) s_ok = 0;
+      }
+      __syncthreads();
+      if (!s_ok) break;
+    } else if (ph > 1 && p.mode == 6) {
+      // several polling waves, out of step with each other: the first one that sees every flag releases the others through LDS
+      // (a poll round is a fabric round trip; with one poller a flag that lands right after a poll was issued waits a whole round)
+      if (wave < p.pollers) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int sl = 0; sl < wave * p.poll_sleep; ++sl) __builtin_amdgcn_s_sleep(1);
+        for (;;) {
+          if (*(volatile int *)&s_go == ph) break;
+          const unsigned f = __hip_atomic_load(p.flags + 32 * my_nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((int)(f >= (unsigned)(ph - 1)))) { if (lane == 0) *(volatile int *)&s_go = ph; break; }
+          if (!spin_ok(t0, p.abort_word)) { if (lane == 0) { s_ok = 0; *(volatile int *)&s_go = ph; } break; }
+        }
+      }
+      __syncthreads();
+      if (!s_ok) break;
+    } else if (ph > 1 && p.mode != 0) {
       if (wave == 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         bool ok = true;
@@ -230,12 +265,14 @@ __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p)
     // ---- publish ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
     __syncthreads();                                    // (also: everybody is done reading the LDS halo)
-    if (p.mode != 0 && tid == 0) {
+    if (p.mode == 7 && tid < kNbr)
+      __hip_atomic_fetch_add(p.flags + 32 * p.nbr[tile * kNbr + tid] + (ph & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.mode != 0 && p.mode != 7 && tid == 0) {
       if (fences) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (p.mode == 1 || p.mode == 2) __hip_atomic_store(p.flags + 32 * tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.mode == 1 || p.mode == 2 || p.mode == 6) __hip_atomic_store(p.flags + 32 * tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else __hip_atomic_fetch_add(p.shards + 32 * (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -246,7 +283,7 @@ int main(int argc, char **argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;
   const int phases = argc > 2 ? atoi(argv[2]) : 1200;
   const int work = argc > 3 ? atoi(argv[3]) : 0, foreign = argc > 4 ? atoi(argv[4]) : 0, no_sleep = argc > 5 ? atoi(argv[5]) : 0;
-  const int poll_sleep = argc > 6 ? atoi(argv[6]) : 0;
+  const int poll_sleep = argc > 6 ? atoi(argv[6]) : 0, pollers = argc > 7 ? atoi(argv[7]) : 2;
   const size_t elems = (size_t)kTiles * kRows * kD;
   Params p{};
   CK(hipMalloc(&p.buf[0], elems * 4));
@@ -276,7 +313,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_nbr, nbr.size() * 4));
   CK(hipMemcpy(d_halo, halo.data(), halo.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
-  p.halo = d_halo; p.nbr = d_nbr; p.phases = phases; p.work_ticks = work; p.foreign_only = foreign; p.no_sleep = no_sleep; p.poll_sleep = poll_sleep;
+  p.halo = d_halo; p.nbr = d_nbr; p.phases = phases; p.work_ticks = work; p.foreign_only = foreign; p.no_sleep = no_sleep; p.poll_sleep = poll_sleep; p.pollers = pollers;
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1;
@@ -285,8 +322,10 @@ int main(int argc, char **argv) {
   const char *names[] = {"free-running (no sync, data movement only)", "neighbour flags, sc1 stores + sc1 loads",
                          "neighbour flags, plain stores + release / acquire fences", "grid barrier (8 shards), sc1 stores + sc1 loads",
                          "grid barrier (8 shards), plain stores + release / acquire fences",
-                         "tagged 8-byte packets {value, phase}, no flags (foreign rows only)"};
-  for (int mode = 0; mode < 6; ++mode) {
+                         "tagged 8-byte packets {value, phase}, no flags (foreign rows only)",
+                         "neighbour flags, sc1, several polling waves out of step",
+                         "inbox counters (one polled word per tile, producers atomic-add), sc1"};
+  for (int mode = 0; mode < 8; ++mode) {
     if (only >= 0 && mode != only) continue;
     for (int check = 1; check >= 0; --check) {
       p.mode = mode; p.check = check;
