@@ -121,3 +121,25 @@ def test_no_cpu_fallback_for_the_hot_path():
         pytest.skip("GPU box: covered by the gpu tests")
     with pytest.raises((ng.NgpdeError, RuntimeError)):
         l(torch.zeros(3, 3), ps, st)                           # CPU tensors are rejected, never silently computed
+
+
+def test_neuralode_generic_path_host_helpers():
+    # the parameter-tree helpers of the generic NeuralODE path (node.py): leaves in insertion order (ComponentArray order), rebuilt
+    # trees keep the structure; a weight's cotangent that arrives transposed is combined through its dense view, not copied
+    import torch
+    from ngpde_amd.node import _dense, _leaves, _rebuild, NeuralODE, TABLEAUS
+    tree = {"ϕ": {"layer_1": {"weight": torch.zeros(3, 2), "bias": torch.zeros(3, 1)}, "layer_2": {"weight": torch.ones(1, 3)}},
+            "γ": {"weight": torch.full((2, 2), 2.0)}, "empty": {}}
+    lv = _leaves(tree)
+    assert [tuple(t.shape) for t in lv] == [(3, 2), (3, 1), (1, 3), (2, 2)]
+    rb = _rebuild(tree, iter([t + 1 for t in lv]))
+    assert list(rb) == ["ϕ", "γ", "empty"] and list(rb["ϕ"]["layer_1"]) == ["weight", "bias"] and rb["empty"] == {}
+    assert torch.equal(rb["γ"]["weight"], torch.full((2, 2), 3.0))
+    w = torch.arange(6.0).reshape(2, 3)
+    assert _dense(w) is w and _dense(w.T).data_ptr() == w.data_ptr() and _dense(w.T).is_contiguous()
+    assert _dense(w[:, ::2]).is_contiguous()                            # anything else: a contiguous copy
+    # every row of a tableau sums to its node: consistency of the coefficients the combinations use
+    a, b = TABLEAUS["tsit5"]
+    assert abs(sum(b) - 1.0) < 1e-14 and len(a) == len(b) == 6
+    node = NeuralODE(object(), solver="Tsit5", n_steps=7, tspan=(0.0, 2.0), capture=True)
+    assert node.solver == "tsit5" and abs(node.dt - 2.0 / 7) < 1e-15 and node.capture

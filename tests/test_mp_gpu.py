@@ -887,3 +887,53 @@ def test_fused_message_path_falls_back_when_unsupported():
     assert not F.edge_mlp_supported(fh, 64, [9])        # not a multiple of 4
     assert not F.edge_mlp_supported(fh, 64, [64, 64, 64, 64])   # more than 3 further layers
     assert F.edge_mlp_supported(fh, 60, [60, 60, 40])   # the VMH tutorial's message MLP
+
+
+# ---- small primitives added in round 2 ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("count", [4096, 4099])
+def test_rk_stage_combine_all_term_counts_and_aliasing(count):
+    # out = c_self * base + sum_k coefs[k] * terms[k] for 0 .. 8 terms, 16-byte and scalar paths, base = NULL, out aliasing base
+    from ngpde_amd.node import _combine
+    rng = np.random.default_rng(count)
+    base = torch.as_tensor(rng.normal(size=count).astype(np.float32), device=DEV)
+    terms = [torch.as_tensor(rng.normal(size=count).astype(np.float32), device=DEV) for _ in range(8)]
+    coefs = [float(c) for c in rng.normal(size=8)]
+    for n in range(9):
+        got = _combine(base, 0.75, terms[:n], coefs[:n])
+        ref = 0.75 * base.double()
+        for t, c in zip(terms[:n], coefs[:n]):
+            ref = ref + np.float32(c).astype(np.float64) * t.double()
+        close(got, ref.cpu().numpy(), rtol=2e-6, atol=1e-6, what=f"{n} terms")
+    got = _combine(None, 0.0, terms[:3], coefs[:3])
+    ref = sum(np.float32(c).astype(np.float64) * t.double() for t, c in zip(terms[:3], coefs[:3]))
+    close(got, ref.cpu().numpy(), rtol=2e-6, atol=1e-6, what="no base")
+    acc = base.clone()
+    _combine(acc, 1.0, [terms[0]], [1.0], out=acc)                      # in place: the parameter-gradient accumulation
+    assert torch.equal(acc, base + terms[0])
+    from ngpde_amd import _lib
+    with pytest.raises(_lib.NgpdeError):
+        _combine(base, 1.0, terms + [terms[0]], coefs + [1.0])          # more than 8 terms: status, not a crash
+
+
+@pytest.mark.parametrize("act", ["identity", "relu", "swish"])
+@pytest.mark.parametrize("d", [128, 7])
+def test_bias_act_tail_forward_and_pullback(act, d):
+    # y = act(a + addend + b): GNOConv's sigma(W x + m + b) tail (src/layers.jl:536-547); 16-byte and scalar paths
+    from ngpde_amd import functional as F
+    n = 1000
+    rng = np.random.default_rng(d)
+    mk = lambda *s: torch.as_tensor(rng.normal(size=s).astype(np.float32), device=DEV).requires_grad_(True)
+    a, add, b = mk(n, d), mk(n, d), mk(d)
+    code = ng.layers._act_code(act)[1]
+    y = F.bias_act(a, add, b, code)
+    z = (a + add + b).detach().cpu().double().numpy()
+    close(y, O.act(act, z))
+    R = rng.normal(size=(n, d))
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    dz = R * O.dact(act, z)
+    close(a.grad, dz, rtol=2e-4)
+    close(add.grad, dz, rtol=2e-4)
+    close(b.grad, dz.sum(axis=0), rtol=3e-4, atol=1e-3)
+    y2 = F.bias_act(a.detach(), None, None, code)                       # no addend, no bias
+    close(y2, O.act(act, a.detach().cpu().double().numpy()))
