@@ -238,6 +238,16 @@ int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kd
 int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *z,
                                  const float *dm, float *dt, float *dbh, float *dz, ngpde_stream_t stream);
 
+/* The reassociated message with its per-edge input formed in the same launch:  z_e = act1(P[t_e] + Q[s_e] + E_e)  (the first Dense
+ * of phi split into node-level terms, as ngpde_edge_combine_forward),  m_e = T_{s_e} z_e + Bh_{s_e}; the message is a per-source
+ * GEMM on the matrix pipe (out a multiple of 16, k in {16, 32, 64}: ngpde_gno_message_supported).  z_out [E][k] (p order,
+ * nullable) keeps the ACTIVATED input for the pullback, which is ngpde_gno_apply_backward followed by
+ * ngpde_edge_combine_backward (for identity / relu the activated value serves as `z` there). */
+int32_t ngpde_gno_message_supported(int32_t cout, int32_t kdim);
+int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t act1, const float *p_target,
+                                  const float *q_source, const float *e_term, const float *t, const float *bh, float *z_out, float *m,
+                                  ngpde_stream_t stream);
+
 /* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
  * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);
  * alpha = softmax over the incoming edges of each node; out[N][heads*c] = sum_e alpha_e Wx[s_e].

@@ -206,6 +206,22 @@ int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t k
   return launch_gno_apply_bwd(g, cout, kdim, t, z, dm, dt, dbh, dz, (hipStream_t)stream);
 }
 
+int32_t ngpde_gno_message_supported(int32_t cout, int32_t kdim) { return gno_apply_mfma_supported(cout, kdim) ? 1 : 0; }
+
+int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t act1, const float *p_target,
+                                  const float *q_source, const float *e_term, const float *t, const float *bh, float *z_out, float *m,
+                                  ngpde_stream_t stream) {
+  NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_forward: graph is NULL");
+  int32_t st = check_act("ngpde_gno_message_forward", act1);
+  if (st) return st;
+  NGPDE_REQUIRE(gno_apply_mfma_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_gno_message_forward: needs out a multiple of 16 (<= 256) and k in {16, 32, 64}, got out = %d, k = %d; compose "
+                "ngpde_edge_combine_forward + ngpde_gno_apply_forward", cout, kdim);
+  if (g->n_edges == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(t && m && (p_target || q_source || e_term), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_forward: NULL argument");
+  return launch_gno_message_mfma_fwd(g, cout, kdim, act1, p_target, q_source, e_term, t, bh, z_out, m, (hipStream_t)stream);
+}
+
 int32_t ngpde_gat_forward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
                           const float *a, float *out, float *alpha, float *al, float *ar, ngpde_stream_t stream_) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_forward: graph is NULL");

@@ -264,6 +264,8 @@ int32_t launch_gno_apply_bwd(const ngpde_graph *g, int cout, int kdim, const flo
 bool gno_apply_mfma_supported(int cout, int kdim);   // gno_mfma.hip: the same message on the matrix pipe
 int32_t launch_gno_apply_mfma_fwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *Bh, const float *z, float *m,
                                   hipStream_t stream);
+int32_t launch_gno_message_mfma_fwd(const ngpde_graph *g, int cout, int kdim, int act1, const float *P, const float *Q, const float *E,
+                                    const float *T, const float *Bh, float *z_out, float *m, hipStream_t stream);
 int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm, float *dT,
                                   float *dBh, float *dz, hipStream_t stream);
 int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const float *a, float *al, float *ar,

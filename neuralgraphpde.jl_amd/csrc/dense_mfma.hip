@@ -452,18 +452,22 @@ __global__ __launch_bounds__(kStreamThreads, 6) void dense_stream64_fwd_kernel(i
   }
 }
 
-__global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout,
+// (oper, part, part_stride: the same split over the output features as in dense_mfma_bwd_input_kernel; oper = dout_all: none)
+__global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout_all,
                                                                    const float *__restrict__ dz,
-                                                                   const float *__restrict__ wt) {
+                                                                   const float *__restrict__ wt, int oper, float *part,
+                                                                   size_t part_stride) {
   __shared__ __attribute__((aligned(16))) float lds[kWideLds];
   float *ldsA = lds, *ldsBt = lds + BM2 * LS2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * BM2;
   const int col0 = blockIdx.y * BN;          // columns of dX = input features k
+  const int obeg = blockIdx.z * oper, dout = min(dout_all, obeg + oper);   // this workgroup's output-feature range [obeg, dout)
+  if (blockIdx.z > 0) segs.ptr[0] = part + (size_t)(blockIdx.z - 1) * part_stride;
   const int ar = tid >> 3, ak = 4 * (tid & 7);       // A = dz: float4 (row, o)
   const int bcol = tid >> 2, bo = 8 * (tid & 3);     // Bt[col = k][o]: 8 consecutive o of one weight row
-  const bool avec = (dout % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(wt)) & 15) == 0;
+  const bool avec = (dout_all % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(wt)) & 15) == 0;
   float4 areg[4], breg[2];
   auto fetch = [&](int o0) {
 #pragma unroll
@@ -471,11 +475,11 @@ __global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, Se
       const int64_t r = row0 + ar + 32 * p;
       const int o = o0 + ak;
       if (r < n && avec && o + 4 <= dout) {
-        areg[p] = *reinterpret_cast<const float4 *>(dz + r * dout + o);
+        areg[p] = *reinterpret_cast<const float4 *>(dz + r * dout_all + o);
       } else {
         float t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (r < n && o + j < dout) ? dz[r * dout + o + j] : 0.f;
+        for (int j = 0; j < 4; ++j) t[j] = (r < n && o + j < dout) ? dz[r * dout_all + o + j] : 0.f;
         areg[p] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
@@ -484,11 +488,11 @@ __global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, Se
     for (int h = 0; h < 2; ++h) {
       const int o = o0 + bo + 4 * h;
       if (k < din && avec && o + 4 <= dout) {
-        breg[h] = *reinterpret_cast<const float4 *>(wt + (size_t)k * dout + o);
+        breg[h] = *reinterpret_cast<const float4 *>(wt + (size_t)k * dout_all + o);
       } else {
         float t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (k < din && o + j < dout) ? wt[(size_t)k * dout + o + j] : 0.f;
+        for (int j = 0; j < 4; ++j) t[j] = (k < din && o + j < dout) ? wt[(size_t)k * dout_all + o + j] : 0.f;
         breg[h] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
@@ -498,8 +502,8 @@ __global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, Se
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  fetch(0);
-  for (int o0 = 0; o0 < dout; o0 += BK2) {
+  fetch(obeg);
+  for (int o0 = obeg; o0 < dout; o0 += BK2) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) *reinterpret_cast<float4 *>(&ldsA[(ar + 32 * p) * LS2 + ak]) = areg[p];
@@ -725,7 +729,7 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
   if (n == 0 || din == 0) return NGPDE_OK;
   if (use_wide_tiles(n, din)) {
     hipLaunchKernelGGL(dense_wide_bwd_input_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (din + BN - 1) / BN), dim3(256), 0,
-                       stream, n, segs, din, dout, dz, wt);
+                       stream, n, segs, din, dout, dz, wt, dout, (float *)nullptr, (size_t)0);
     NGPDE_LAUNCH_CHECK("dense_wide_bwd_input_kernel");
     return NGPDE_OK;
   }
@@ -754,9 +758,10 @@ __global__ void add_partials_kernel(int64_t count, int nparts, size_t stride, co
 
 // splits of the input pullback over the output features (see dense_mfma_bwd_input_kernel): 1 = none
 int dense_bwd_input_splits(int64_t n, int din, int dout) {
-  const int64_t tiles = ((n + BM - 1) / BM) * ((din + BN - 1) / BN);
+  const int64_t tiles = ((n + BM2 - 1) / BM2) * ((din + BN - 1) / BN);
   if (tiles >= 256 || dout < 512) return 1;
-  return (int)std::max<int64_t>(1, std::min<int64_t>((768 + tiles - 1) / tiles, dout / 128));
+  // enough workgroups for a few rounds of the chip, each still with a dozen or more K steps (the partial slabs cost a pass too)
+  return (int)std::max<int64_t>(1, std::min<int64_t>((2048 + tiles - 1) / tiles, dout / 256));
 }
 size_t dense_bwd_input_split_bytes(int64_t n, int din, int dout) {
   const int ns = dense_bwd_input_splits(n, din, dout);
@@ -767,12 +772,13 @@ int32_t launch_dense_bwd_input_splitk(int64_t n, float *dx, int din, int dout, c
                                       hipStream_t stream) {
   if (n == 0 || din == 0) return NGPDE_OK;
   const int ns = dense_bwd_input_splits(n, din, dout);
-  const int oper = ((dout + ns - 1) / ns + BK - 1) / BK * BK;
+  const int oper = ((dout + ns - 1) / ns + BK2 - 1) / BK2 * BK2;
   const int nz = (dout + oper - 1) / oper;
   SegGrad segs;
   segs.n = 1; segs.ptr[0] = dx; segs.width[0] = din;
   for (int i = 1; i <= 4; ++i) segs.offset[i] = din;
-  hipLaunchKernelGGL(dense_mfma_bwd_input_kernel, dim3((unsigned)((n + BM - 1) / BM), (din + BN - 1) / BN, nz), dim3(256), 0, stream,
+  // the 128-row tile kernel: 16-byte loads of dz and W rows (the 64-row kernel reads dz in 64-byte pieces)
+  hipLaunchKernelGGL(dense_wide_bwd_input_kernel, dim3((unsigned)((n + BM2 - 1) / BM2), (din + BN - 1) / BN, nz), dim3(256), 0, stream,
                      n, segs, din, dout, dz, wt, oper, part, (size_t)n * din);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_input_kernel (split)");
   if (nz > 1) {

@@ -37,13 +37,22 @@ __device__ __forceinline__ void stage_edge_rows(float *dst, const float *__restr
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
-template <int KD>   // kdim (multiple of 16)
+// FUSED: the per-edge input z_e = act1(P[t_e] + Q[j] + E_e) of the message (apply_edges with the first Dense of phi split into
+// node-level terms, src/layers.jl:523) is formed while the rows are staged instead of being read back from an [E][k] array that a
+// separate launch wrote; z_out (nullable) keeps it for the pullback.
+struct GnoFuse {
+  const float *P, *Q, *E;      // [N][k] at the target, [N][k] at the source, [E][k] in p order; each nullable
+  const int *col_s;            // target node of every entry of the by-source list
+  float *z_out;                // [E][k] p order, nullable
+  int act1;
+};
+template <int KD, bool FUSED>   // kdim (multiple of 16)
 __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
                                                                  const float *__restrict__ T, const float *__restrict__ Bh,
-                                                                 const float *__restrict__ z, float *__restrict__ m) {
+                                                                 const float *__restrict__ z, float *__restrict__ m, const GnoFuse fz) {
   constexpr int ZS = KD + 4;
   __shared__ __attribute__((aligned(16))) float zl[kEB * ZS];
-  __shared__ int pl[kEB];
+  __shared__ int pl[kEB], tl[kEB];
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rs = rowptr_s[j], re = rowptr_s[j + 1];
@@ -68,9 +77,28 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const
   for (int q0 = rs; q0 < re; q0 += kEB) {
     const int nb = min(kEB, re - q0);
     __syncthreads();                                // the previous pass's tiles are consumed
-    if (tid < kEB) pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+    if (tid < kEB) {
+      pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+      if (FUSED) tl[tid] = tid < nb ? fz.col_s[q0 + tid] : 0;
+    }
     __syncthreads();
-    stage_edge_rows<kEB>(zl, z, pl, nb, KD, tid);
+    if constexpr (FUSED) {
+      constexpr int W4 = KD / 4;
+      for (int idx = tid; idx < kEB * W4; idx += 256) {
+        const int e = idx / W4, c4 = idx - e * W4;
+        float4 v[1] = {f4_zero()};
+        if (e < nb) {
+          if (fz.P) v[0] = reinterpret_cast<const float4 *>(fz.P + (size_t)tl[e] * KD)[c4];
+          if (fz.Q) v[0] = f4_add(v[0], reinterpret_cast<const float4 *>(fz.Q + (size_t)j * KD)[c4]);
+          if (fz.E) v[0] = f4_add(v[0], reinterpret_cast<const float4 *>(fz.E + (size_t)pl[e] * KD)[c4]);
+          f4n_act<1>(fz.act1, v);
+          if (fz.z_out) reinterpret_cast<float4 *>(fz.z_out + (size_t)pl[e] * KD)[c4] = v[0];
+        }
+        *reinterpret_cast<float4 *>(&zl[e * ZS + 4 * c4]) = v[0];
+      }
+    } else {
+      stage_edge_rows<kEB>(zl, z, pl, nb, KD, tid);
+    }
     __syncthreads();
     for (int et = 0; et * kET < nb; ++et) {         // uniform
       float4 a4[KD / 16];
@@ -214,7 +242,8 @@ int32_t launch_gno_apply_mfma_fwd(const ngpde_graph *g, int cout, int kdim, cons
                                   hipStream_t stream) {
   if (g->n_edges == 0) return NGPDE_OK;
   const dim3 grid((unsigned)g->n_nodes), block(256);
-#define NGPDE_GNO_F(KK) hipLaunchKernelGGL(gno_apply_mfma_fwd_kernel<KK>, grid, block, 0, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m)
+  const GnoFuse nofuse{};
+#define NGPDE_GNO_F(KK) hipLaunchKernelGGL((gno_apply_mfma_fwd_kernel<KK, false>), grid, block, 0, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, Bh, z, m, nofuse)
   switch (kdim) {
     case 16: NGPDE_GNO_F(16); break;
     case 32: NGPDE_GNO_F(32); break;
@@ -222,6 +251,24 @@ int32_t launch_gno_apply_mfma_fwd(const ngpde_graph *g, int cout, int kdim, cons
   }
 #undef NGPDE_GNO_F
   NGPDE_LAUNCH_CHECK("gno_apply_mfma_fwd_kernel");
+  return NGPDE_OK;
+}
+
+// the same with the message's per-edge input formed in the kernel: z_e = act1(P[t_e] + Q[s_e] + E_e)
+int32_t launch_gno_message_mfma_fwd(const ngpde_graph *g, int cout, int kdim, int act1, const float *P, const float *Q, const float *E,
+                                    const float *T, const float *Bh, float *z_out, float *m, hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  const dim3 grid((unsigned)g->n_nodes), block(256);
+  GnoFuse fz;
+  fz.P = P; fz.Q = Q; fz.E = E; fz.col_s = g->by_s.col; fz.z_out = z_out; fz.act1 = act1;
+#define NGPDE_GNO_FF(KK) hipLaunchKernelGGL((gno_apply_mfma_fwd_kernel<KK, true>), grid, block, 0, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, Bh, (const float *)nullptr, m, fz)
+  switch (kdim) {
+    case 16: NGPDE_GNO_FF(16); break;
+    case 32: NGPDE_GNO_FF(32); break;
+    default: NGPDE_GNO_FF(64); break;
+  }
+#undef NGPDE_GNO_FF
+  NGPDE_LAUNCH_CHECK("gno_apply_mfma_fwd_kernel (fused input)");
   return NGPDE_OK;
 }
 

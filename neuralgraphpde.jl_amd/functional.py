@@ -317,6 +317,61 @@ def gno_apply(T, Bh, z, handle, cout, kdim):
     return _GnoApplyFn.apply(T, Bh, z, handle, cout, kdim)
 
 
+class _GnoMessageFn(torch.autograd.Function):
+    """m_e = T_{s_e} act1(P[t_e] + Q[s_e] + E_e) + Bh_{s_e} in ONE launch (ngpde_gno_message_forward): the per-edge input of the
+    reassociated GNOConv message is formed while the per-source GEMM stages its rows.  act1 in {identity, relu}: the activated
+    input kept for the pullback also tells act1' (pullback = ngpde_gno_apply_backward + ngpde_edge_combine_backward)."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, T, Bh)
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        T = T.contiguous()
+        Bh = None if Bh is None else Bh.contiguous()
+        dev = T.device
+        need = any(ctx.needs_input_grad)
+        a = torch.empty((n_edges, kdim), dtype=torch.float32, device=dev) if need else None
+        m = torch.empty((n_edges, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_message_forward(handle.ptr, cout, kdim, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(T),
+                                                 _lib.ptr(Bh), _lib.ptr(a), _lib.ptr(m), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (act1, cout, kdim)
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None, Bh is not None)
+        ctx.save_for_backward(T, a)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        T, a = ctx.saved_tensors
+        act1, cout, kdim = ctx.meta
+        pshape, qshape, has_e, has_bh = ctx.shapes
+        dm = dm.contiguous()
+        dev = dm.device
+        stream = _lib.current_stream()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
+        dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None
+        da = torch.empty_like(a)
+        _lib.check(lib.ngpde_gno_apply_backward(ctx.handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(a), _lib.ptr(dm), _lib.ptr(dT),
+                                                _lib.ptr(dBh), _lib.ptr(da), stream))
+        dz = torch.empty_like(a)
+        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if (pshape is not None and ctx.needs_input_grad[0]) else None
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if (qshape is not None and ctx.needs_input_grad[1]) else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, kdim, act1, _lib.ptr(da), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dP),
+                                                   _lib.ptr(dQ), stream))
+        return dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), dT, dBh, None, None, None, None, None
+
+
+def gno_message_supported(cout, kdim, act1):
+    return act1 in (0, 1) and bool(_lib.load().ngpde_gno_message_supported(int(cout), int(kdim)))
+
+
+def gno_message(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges):
+    return _GnoMessageFn.apply(P, Q, Eterm, T, Bh, handle, int(act1), int(cout), int(kdim), int(n_edges))
+
+
 class _GatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, wx, a, handle, heads, c, slope, n_edges):

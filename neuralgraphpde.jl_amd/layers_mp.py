@@ -280,20 +280,25 @@ class GNOConv(AbstractGNNContainerLayer):
         if kout != self.in_chs * self.out_chs:
             raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
                                          f"DimensionMismatch: ϕ must output in_chs*out_chs = {self.in_chs * self.out_chs} rows, got {kout}")
-        z = F.edge_combine(P, Q, Et, handle, l1.act, E)
         last, plast = stack[-1]
         kdim = _wt_b(plast)[0].shape[0]
-        if (len(stack) >= 2 and last.act == 0 and os.environ.get("NGPDE_GNO_MATERIALIZE") != "1"
-                and F.gno_apply_supported(self.out_chs, kdim)):
+        reassoc = (len(stack) >= 2 and last.act == 0 and os.environ.get("NGPDE_GNO_MATERIALIZE") != "1"
+                   and F.gno_apply_supported(self.out_chs, kdim))
+        if reassoc:
             # reassociated: K_e h_j = T_j z_e + B2 h_j with T_j = W2 (x) h_j at node level; K is never formed
-            z = _tail(stack[:-1], z)
             w2, b2 = _wt_b(plast)                                                  # [k][in*out], [in*out]; row r = o + out*i
             wr = w2.view(kdim, self.in_chs, self.out_chs).permute(1, 2, 0).reshape(self.in_chs, self.out_chs * kdim)
             T = F.dense([h], wr, None, 0)
             Bh = F.dense([h], b2.view(self.in_chs, self.out_chs), None, 0) if b2 is not None else None
+        if (reassoc and len(stack) == 2 and E > 0 and os.environ.get("NGPDE_NO_GNO_MFMA") != "1"
+                and F.gno_message_supported(self.out_chs, kdim, l1.act)):
+            # two-layer phi: the per-edge input act1(P[t] + Q[s] + E) is formed inside the message launch
+            m = F.gno_message(P, Q, Et, T, Bh, handle, l1.act, self.out_chs, kdim, E)
+        elif reassoc:
+            z = _tail(stack[:-1], F.edge_combine(P, Q, Et, handle, l1.act, E))
             m = F.gno_apply(T, Bh, z, handle, self.out_chs, kdim)
         else:
-            K = _tail(stack, z)
+            K = _tail(stack, F.edge_combine(P, Q, Et, handle, l1.act, E))
             m = F.gno_contract(K, h, handle, self.in_chs, self.out_chs)            # :527-530
         agg = F.segment_reduce(m, handle, self.aggr, N)                            # :534
         lwt, lb = _wt_b(ps["linear"])
