@@ -314,5 +314,8 @@ int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_
 bool edge_mlp_fused_supported(const ngpde_graph *g, const EdgeMlpArgs &a);
 int32_t launch_edge_mlp_fused_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
 int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, hipStream_t stream);
+// edge_mlp64.hip: software-pipelined specialisations for the 64-wide two-layer message MLP (BASELINE config 4's shape)
+bool edge_mlp64_fwd_applicable(const ngpde_graph *g, const EdgeMlpArgs &a);
+int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
 
 }  // namespace ngpde

@@ -1,0 +1,487 @@
+// edge_mlp64.hip -- the message path of the edge-function layers for the 64-wide two-layer message MLP
+//   m_i = aggr_{e: t_e = i}  act2( W2^T act1( P[t_e] + Q[s_e] ) + b2 )      (/root/reference/src/layers.jl:409-416, :316-326,
+//                                                                            :103-111 with the first Dense split at node level)
+// in the shape BASELINE's config 4 runs (MPPDEConv, h = 64, phi = Dense(. => 64) -> Dense(64 => 64)), as a software-pipelined
+// specialisation of edge_mlp_fused.hip: widths and activations are compile-time constants, so the steady state of the edge loop is
+// ONE basic block in which a wave's 64 v_mfma_f32_16x16x4_f32 of slice s run beside the bias + activation + LDS store of slice
+// s - 1 and the gather + first activation of slice s + 1.  The general kernel walks the same phases one after the other with every
+// wave of the SIMD in the same phase (identical waves stay in step), so its matrix pipe idles during the activations and its
+// VALU during the products (matrix pipe 39 % busy at config 4); and its 128-edge chunks pad a 192-edge tile to 256.
+//
+// A workgroup = 4 waves owns a 32-row tile of the locality schedule and walks the tile's edges 64 (4 x 16) at a time; tile
+// metadata, P rows and the distinct Q rows (halo) of the NEXT tile are in flight in registers under the current tile's arithmetic
+// (edge_mlp_fused.hip's scheme).  Register layout of a slice, transposed products and the in-tile segmented reduction in edge
+// (= COO) order are those of edge_mlp_fused.hip: no atomics, bitwise reproducible, and bitwise equal to the general kernel.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace ngpde {
+
+namespace {
+
+template <int S, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (S < N) {
+    f(std::integral_constant<int, S>{});
+    static_for<S + 1, N>(f);
+  }
+}
+
+// Pins a value to this point of the instruction stream: the (empty) volatile asm is ordered against the other pins and the
+// sched_barriers of the pipelined block, so what computes the value stays before it and what uses it after it.  Without the pins
+// instruction selection places pure arithmetic next to its use -- the whole activation of the next slice behind the last MFMA.
+#define PIN(x) asm volatile("" : "+v"(x))
+// LDS reads issued by hand (the compiler does not track them: the consumer waits with an explicit s_waitcnt that takes the
+// destination registers as operands, so nothing that uses them can move above it)
+__device__ __forceinline__ unsigned lds_addr(const void *ptr) { return (unsigned)(uintptr_t)ptr; }   // low half of a generic LDS pointer
+#define lds_read4(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define lds_read_u16(dst, addr) asm volatile("ds_read_u16 %0, %1" : "=v"(dst) : "v"(addr))
+
+constexpr int kT4 = 256, kW = 64, kTS = kW + 4, kSlice = 16, kChunk4 = 64, kRows = 32;
+
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/stamps_edge64.py): phase timestamps of one steady-state tile per workgroup, [n_blocks][16] words
+unsigned long long *g_edge64_stamps = nullptr;
+#define E64_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && p.stamps && stamp_tile) {                                                         \
+      p.stamps[(size_t)blockIdx.x * 16 + (k)] = clock64();                                                    \
+      if ((k) == 0 || (k) == 13) p.stamps[(size_t)blockIdx.x * 16 + 14 + ((k) ? 1 : 0)] = wall_clock64();     \
+    }                                                                                                         \
+  } while (0)
+#else
+#define E64_STAMP(k)
+#endif
+
+struct EdgeMlp64K {
+  const int4 *sched;
+  const int2 *halo;
+  const uint8_t *slots;
+  int n_tiles, halo_rows, aggr;
+  const float *P, *Q, *wt, *bias;
+  float *out;
+#ifdef NGPDE_STAMPS
+  unsigned long long *stamps;
+#endif
+};
+
+struct Meta64 {
+  int4 sc0, sc1;       // schedule rows g16 and g16 + 16
+  unsigned sw0, sw1;   // slot word (q & 7) of those rows
+  int he[6];           // node ids of halo rows g16 + 16 k
+};
+struct Rows64 {
+  float px[8];   // P rows g16 and g16 + 16
+  float4 hv[6];
+};
+
+template <int ACT1, int ACT2>
+__global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
+  float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]
+  float *ldsWt = ldsP + kRows * kTS;                              // [64 out][kTS]   W2^T
+  float *ldsMsg = ldsWt + kW * kTS;                               // [64 edges][kTS]
+  __shared__ int ldsOff[kRows + 1];
+  __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kRows * 8];
+  __shared__ uint16_t ldsEdge[kRows * kSlotWidth];   // tile edge k -> {row of the tile, halo slot << 8}
+  __shared__ __attribute__((aligned(16))) float ldsBias[kW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g16 = tid >> 4, q = tid & 15;           // staging / reduction role: rows g16 and g16 + 16, features 4q .. 4q + 3
+  const int ei = lane & 15, kq = lane >> 4;         // MFMA role
+  const int zero_slot = p.halo_rows;
+
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const int range_len = p.n_tiles / 8 + (xcd < p.n_tiles % 8 ? 1 : 0);
+  const int range_lo = xcd * (p.n_tiles / 8) + min(xcd, p.n_tiles % 8);
+
+  auto fetch_meta = [&](int tile, Meta64 &m) {
+    const size_t row = (size_t)tile * kTileRows + g16;
+    m.sc0 = p.sched[row];
+    m.sc1 = p.sched[row + 16];
+    m.sw0 = reinterpret_cast<const unsigned *>(p.slots)[row * 8 + (q & 7)];
+    m.sw1 = reinterpret_cast<const unsigned *>(p.slots)[(row + 16) * 8 + (q & 7)];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m.he[k] = p.halo[(size_t)tile * kHaloCap + min(g16 + 16 * k, kHaloCap - 1)].x;
+  };
+  auto fetch_rows = [&](const Meta64 &m, Rows64 &r) {
+    const float4 p0 = *reinterpret_cast<const float4 *>(p.P + (size_t)max(m.sc0.x, 0) * kW + 4 * q);
+    const float4 p1 = *reinterpret_cast<const float4 *>(p.P + (size_t)max(m.sc1.x, 0) * kW + 4 * q);
+    r.px[0] = p0.x; r.px[1] = p0.y; r.px[2] = p0.z; r.px[3] = p0.w;
+    r.px[4] = p1.x; r.px[5] = p1.y; r.px[6] = p1.z; r.px[7] = p1.w;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      r.hv[k] = (g16 + 16 * k < p.halo_rows) ? *reinterpret_cast<const float4 *>(p.Q + (size_t)m.he[k] * kW + 4 * q) : f4_zero();
+  };
+
+  // ---- once per workgroup: W2^T rows (output j, contiguous inputs), bias, the all-zero halo row
+  {
+    const int j = tid & 63, kg0 = tid >> 6;   // output column j, input quads kg0 + 4 ps
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int k = 4 * (kg0 + 4 * ps);
+      *reinterpret_cast<float4 *>(&ldsWt[j * kTS + k]) =
+          make_float4(p.wt[(size_t)k * kW + j], p.wt[(size_t)(k + 1) * kW + j], p.wt[(size_t)(k + 2) * kW + j], p.wt[(size_t)(k + 3) * kW + j]);
+    }
+    if (tid < kW) ldsBias[tid] = p.bias ? p.bias[tid] : 0.f;
+    if (g16 == 0) *reinterpret_cast<float4 *>(&ldsQ[zero_slot * kTS + 4 * q]) = f4_zero();
+  }
+
+  // ---- the activation in stages: y = fin(x, tr2(mid(tr1(pre(x))))) with the two quarter-rate transcendentals (tr1, tr2) as
+  // separate steps, so that the pipelined block below can put exactly one of them behind every MFMA.  Same operations in the
+  // same order as act_apply (device_utils.h): bitwise the same values.
+  auto pre = [](auto act, float x) -> float {
+    constexpr int A = decltype(act)::value;
+    if (A == NGPDE_ACT_SWISH) return (-x) * 1.4426950408889634f;
+    if (A == NGPDE_ACT_TANH) return (2.0f * x) * 1.4426950408889634f;
+    return x;
+  };
+  auto tr1 = [](auto act, float t) -> float {
+    constexpr int A = decltype(act)::value;
+    return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? __builtin_amdgcn_exp2f(t) : t;
+  };
+  auto mid = [](auto act, float e) -> float {
+    constexpr int A = decltype(act)::value;
+    return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? 1.0f + e : e;
+  };
+  auto tr2 = [](auto act, float d) -> float {
+    constexpr int A = decltype(act)::value;
+    return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? __builtin_amdgcn_rcpf(d) : d;
+  };
+  auto fin = [](auto act, float x, float r) -> float {
+    constexpr int A = decltype(act)::value;
+    if (A == NGPDE_ACT_SWISH) return x * r;
+    if (A == NGPDE_ACT_TANH) return 1.0f - 2.0f * r;
+    if (A == NGPDE_ACT_RELU) return fmaxf(x, 0.0f);
+    return x;
+  };
+  const std::integral_constant<int, ACT1> act1_c{};
+  const std::integral_constant<int, ACT2> act2_c{};
+
+  // permanent registers: the bias of the lane's 16 output features, the W2^T fragments of the first 16 input features
+  float bias_r[16];
+  f32x4 w0[4];
+  {
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
+      bias_r[4 * mt] = b4.x; bias_r[4 * mt + 1] = b4.y; bias_r[4 * mt + 2] = b4.z; bias_r[4 * mt + 3] = b4.w;
+      const float4 w4 = *reinterpret_cast<const float4 *>(&ldsWt[(mt * 16 + ei) * kTS + 4 * kq]);
+      w0[mt] = (f32x4){w4.x, w4.y, w4.z, w4.w};
+    }
+  }
+  auto comp = [](const f32x4 &v, int r) -> float { return v[r]; };
+  const unsigned wt_addr = lds_addr(ldsWt + ei * kTS + 4 * kq);   // W2^T fragment (mt, ct) at + (mt * 16 * kTS + 16 * ct) floats
+
+  // ---- one pipelined block = 64 slots.  Slot s: MFMA s of the current slice (ct = s / 16, r = (s / 4) % 4, mt = s % 4: four
+  // independent accumulator chains) and one stage of the activation of a pair of values -- pairs 0..7 (slots 0..31) are the
+  // messages of the PREVIOUS slice (bias + act2, stored to LDS as each float4 completes), pairs 8..15 (slots 32..63) the first
+  // activation of the NEXT slice (P[row] + Q[slot]).  LDS reads are issued by hand in fixed slots and collected by three waits
+  // that each sit several slots behind the last issue: slot 0 the lane's edge word, 1..4 the W2^T fragments of input block 1,
+  // wait at 7; 17..20 fragments of block 2, 21..24 the P / Q rows of feature blocks 0 and 1, wait at 31; 33..36 the rows of
+  // feature blocks 2 and 3, 37..40 the fragments of block 3, wait at 47.  A sched_barrier after every slot and the pins keep
+  // this order through instruction selection and scheduling.
+  //   MF: the products run; PUB: there is a previous slice to publish; ASM: assemble the slice `it_next`.
+  auto block = [&](auto mf_c, auto pub_c, auto asm_c, int it_next, int total, f32x4 (&a)[4], f32x4 (&accp)[4]) __attribute__((always_inline)) {
+    constexpr bool MF = decltype(mf_c)::value, PUB = decltype(pub_c)::value, ASM = decltype(asm_c)::value;
+    f32x4 acc[4];
+    f32x4 wf[4][4];
+    float xs[32], ts[32];
+    f32x4 pr[4], qr[4];
+    unsigned eword = 0, p_addr = 0, q_addr = 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wf[0][mt] = w0[mt];
+    static_for<0, 64>([&](auto s_c) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr int ct = s >> 4, rr = (s >> 2) & 3, mt = s & 3;
+      if (MF) {
+        const f32x4 c0 = (ct == 0 && rr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt];
+        acc[mt] = mfma16(comp(wf[ct][mt], rr), comp(a[ct], rr), c0);
+        PIN(acc[mt]);
+        if (s >= 1 && s <= 4) lds_read4(wf[1][s - 1], wt_addr + ((s - 1) * 16 * kTS + 16) * 4);
+        if (s >= 17 && s <= 20) lds_read4(wf[2][s - 17], wt_addr + ((s - 17) * 16 * kTS + 32) * 4);
+        if (s >= 37 && s <= 40) lds_read4(wf[3][s - 37], wt_addr + ((s - 37) * 16 * kTS + 48) * 4);
+      }
+      if (ASM) {   // the next slice's edge word {row of the tile, halo slot}, then its P / Q rows
+        if (s == 0) {
+          const int k = min(it_next * kChunk4 + wave * kSlice + ei, total - 1);
+          lds_read_u16(eword, lds_addr(ldsEdge) + 2 * k);
+        }
+        if (s == 8) {
+          p_addr = lds_addr(ldsP) + ((eword & 0xff) * kTS + 4 * kq) * 4;
+          q_addr = lds_addr(ldsQ) + ((eword >> 8) * kTS + 4 * kq) * 4;
+          PIN(p_addr);
+          PIN(q_addr);
+        }
+        if (s == 21) lds_read4(pr[0], p_addr);
+        if (s == 22) lds_read4(qr[0], q_addr);
+        if (s == 23) lds_read4(pr[1], p_addr + 64);
+        if (s == 24) lds_read4(qr[1], q_addr + 64);
+        if (s == 33) lds_read4(pr[2], p_addr + 128);
+        if (s == 34) lds_read4(qr[2], q_addr + 128);
+        if (s == 35) lds_read4(pr[3], p_addr + 192);
+        if (s == 36) lds_read4(qr[3], q_addr + 192);
+      }
+      // the three collection points
+      if (s == 7) {
+        if (MF && ASM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[1][2]), "+v"(wf[1][3]), "+v"(eword));
+        else if (MF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[1][2]), "+v"(wf[1][3]));
+        else if (ASM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eword));
+      }
+      if (s == 31) {
+        if (MF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[2][2]), "+v"(wf[2][3]));
+        if (ASM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]), "+v"(qr[0]), "+v"(pr[1]), "+v"(qr[1]));
+      }
+      if (s == 47) {
+        if (MF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[3][2]), "+v"(wf[3][3]));
+        if (ASM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[2]), "+v"(qr[2]), "+v"(pr[3]), "+v"(qr[3]));
+      }
+      {
+        constexpr int pp = s >> 2, ph = s & 3, e0 = 2 * pp, e1 = e0 + 1;
+        constexpr bool pub_pair = pp < 8;
+        if constexpr (ph == 0 && pp > 0) {   // last step of the previous pair's second value
+          constexpr bool prev_pub = (pp - 1) < 8;
+          if (prev_pub ? PUB : ASM) {
+            xs[e0 - 1] = prev_pub ? fin(act2_c, xs[e0 - 1], ts[e0 - 1]) : fin(act1_c, xs[e0 - 1], ts[e0 - 1]);
+            PIN(xs[e0 - 1]);
+          }
+        }
+        if constexpr (PUB && pub_pair && ph == 1 && (pp & 1) == 0 && pp > 0) {   // float4 mt = pp / 2 - 1 of the messages is complete
+          constexpr int m = pp / 2 - 1;
+          *reinterpret_cast<float4 *>(&ldsMsg[(wave * kSlice + ei) * kTS + 16 * m + 4 * kq]) =
+              make_float4(xs[4 * m], xs[4 * m + 1], xs[4 * m + 2], xs[4 * m + 3]);
+        }
+        if (PUB && s == 33)
+          *reinterpret_cast<float4 *>(&ldsMsg[(wave * kSlice + ei) * kTS + 48 + 4 * kq]) = make_float4(xs[12], xs[13], xs[14], xs[15]);
+        if constexpr (pub_pair ? PUB : ASM) {
+          if constexpr (ph == 0) {
+            if constexpr (pub_pair) {
+              xs[e0] = accp[e0 >> 2][e0 & 3] + bias_r[e0];
+              xs[e1] = accp[e1 >> 2][e1 & 3] + bias_r[e1];
+              ts[e0] = tr1(act2_c, pre(act2_c, xs[e0]));
+            } else {
+              constexpr int f0 = e0 - 16, f1 = e1 - 16;
+              xs[e0] = comp(pr[f0 >> 2], f0 & 3) + comp(qr[f0 >> 2], f0 & 3);
+              xs[e1] = comp(pr[f1 >> 2], f1 & 3) + comp(qr[f1 >> 2], f1 & 3);
+              ts[e0] = tr1(act1_c, pre(act1_c, xs[e0]));
+            }
+            PIN(xs[e1]);
+            PIN(ts[e0]);
+          } else if constexpr (ph == 1) {
+            ts[e1] = pub_pair ? tr1(act2_c, pre(act2_c, xs[e1])) : tr1(act1_c, pre(act1_c, xs[e1]));
+            ts[e0] = pub_pair ? mid(act2_c, ts[e0]) : mid(act1_c, ts[e0]);
+            PIN(ts[e1]);
+            PIN(ts[e0]);
+          } else if constexpr (ph == 2) {
+            ts[e0] = pub_pair ? tr2(act2_c, ts[e0]) : tr2(act1_c, ts[e0]);
+            ts[e1] = pub_pair ? mid(act2_c, ts[e1]) : mid(act1_c, ts[e1]);
+            PIN(ts[e0]);
+            PIN(ts[e1]);
+          } else {
+            ts[e1] = pub_pair ? tr2(act2_c, ts[e1]) : tr2(act1_c, ts[e1]);
+            xs[e0] = pub_pair ? fin(act2_c, xs[e0], ts[e0]) : fin(act1_c, xs[e0], ts[e0]);
+            PIN(ts[e1]);
+            PIN(xs[e0]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (ASM) {
+      xs[31] = fin(act1_c, xs[31], ts[31]);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) a[ct] = (f32x4){xs[16 + 4 * ct], xs[17 + 4 * ct], xs[18 + 4 * ct], xs[19 + 4 * ct]};
+    }
+    if (MF) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) accp[mt] = acc[mt];
+    }
+  };
+  const std::true_type yes{};
+  const std::false_type no{};
+
+  Meta64 meta;
+  Rows64 rows;
+  int jt = wg_in_xcd;
+  if (jt < range_len) {
+    fetch_meta(range_lo + jt, meta);
+    fetch_rows(meta, rows);
+  }
+
+  for (; jt < range_len; jt += wgs_per_xcd) {
+#ifdef NGPDE_STAMPS
+    const bool stamp_tile = (jt == wg_in_xcd + 4 * wgs_per_xcd);   // a tile in steady state (the fifth of the workgroup)
+#endif
+    E64_STAMP(0);
+    // ---- stage this tile (fetched under the previous tile's arithmetic)
+    const int4 sc0 = meta.sc0, sc1 = meta.sc1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int hh = g16 + 16 * k;
+      if (hh < p.halo_rows) *reinterpret_cast<float4 *>(&ldsQ[hh * kTS + 4 * q]) = rows.hv[k];
+    }
+    *reinterpret_cast<float4 *>(&ldsP[g16 * kTS + 4 * q]) = make_float4(rows.px[0], rows.px[1], rows.px[2], rows.px[3]);
+    *reinterpret_cast<float4 *>(&ldsP[(g16 + 16) * kTS + 4 * q]) = make_float4(rows.px[4], rows.px[5], rows.px[6], rows.px[7]);
+    if (q == 0) {
+      ldsOff[g16 + 1] = sc0.x >= 0 ? sc0.z : 0;
+      ldsOff[g16 + 17] = sc1.x >= 0 ? sc1.z : 0;
+      if (g16 == 0) ldsOff[0] = 0;
+    }
+    if (q < 8) {
+      ldsSlots[g16 * 8 + q] = meta.sw0;
+      ldsSlots[(g16 + 16) * 8 + q] = meta.sw1;
+    }
+    const int jn = jt + wgs_per_xcd;
+    const bool has_next = jn < range_len;       // workgroup-uniform
+    if (has_next) fetch_meta(range_lo + jn, meta);
+    __syncthreads();
+    if (tid < kRows) {   // inclusive scan of the 32 degrees inside wave 0
+      int v = ldsOff[tid + 1];
+#pragma unroll
+      for (int o = 1; o < kRows; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (tid >= o) v += u;
+      }
+      ldsOff[tid + 1] = v;
+    }
+    __syncthreads();
+    const int total = ldsOff[kRows];
+    const int lo0 = ldsOff[g16], hi0 = ldsOff[g16 + 1], lo1 = ldsOff[g16 + 16], hi1 = ldsOff[g16 + 17];
+    for (int k = lo0 + q; k < hi0; k += 16) {
+      const int j = k - lo0;
+      ldsEdge[k] = (uint16_t)(g16 | (((ldsSlots[g16 * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff) << 8));
+    }
+    for (int k = lo1 + q; k < hi1; k += 16) {
+      const int j = k - lo1;
+      ldsEdge[k] = (uint16_t)((g16 + 16) | (((ldsSlots[(g16 + 16) * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff) << 8));
+    }
+    float4 racc0 = f4_zero(), racc1 = f4_zero();
+    __syncthreads();
+
+    E64_STAMP(1);
+    const int n_it = (total + kChunk4 - 1) / kChunk4;
+    auto reduce = [&](int it) {   // lane group g16 sums the messages of rows g16 and g16 + 16 that lie in chunk `it`, edge order
+      const int c0 = it * kChunk4;
+      const float *base = ldsMsg + 4 * q - c0 * kTS;
+      auto row_sum = [&](int lo, int hi, float4 &racc) {
+        int kk = max(lo, c0);
+        const int end = min(hi, c0 + kChunk4);
+        for (; kk + 4 <= end; kk += 4) {   // four independent LDS reads, added in edge order
+          const float4 m0 = *reinterpret_cast<const float4 *>(base + kk * kTS), m1 = *reinterpret_cast<const float4 *>(base + (kk + 1) * kTS);
+          const float4 m2 = *reinterpret_cast<const float4 *>(base + (kk + 2) * kTS), m3 = *reinterpret_cast<const float4 *>(base + (kk + 3) * kTS);
+          racc = f4_add(f4_add(f4_add(f4_add(racc, m0), m1), m2), m3);
+        }
+        for (; kk < end; ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * kTS));
+      };
+      row_sum(lo0, hi0, racc0);
+      row_sum(lo1, hi1, racc1);
+    };
+    if (n_it > 0) {
+      f32x4 a[4], accp[4];
+      block(no, no, yes, 0, total, a, accp);          // a1 of slice 0
+      E64_STAMP(2);
+      block(yes, no, yes, 1, total, a, accp);         // products of slice 0 | a1 of slice 1
+      E64_STAMP(3);
+      if (has_next) fetch_rows(meta, rows);           // the next tile's rows: in flight across this tile's remaining arithmetic
+      E64_STAMP(4);
+      for (int it = 1; it < n_it; ++it) {
+        block(yes, yes, yes, it + 1, total, a, accp);   // products of slice it | messages of slice it - 1 | a1 of slice it + 1
+        if (it == 1) E64_STAMP(5);
+        __syncthreads();
+        if (it == 1) E64_STAMP(6);
+        reduce(it - 1);
+        if (it == 1) E64_STAMP(7);
+        __syncthreads();
+        if (it == 1) E64_STAMP(8);
+        if (it == 2) E64_STAMP(9);
+      }
+      E64_STAMP(10);
+      block(no, yes, no, 0, total, a, accp);          // messages of the last slice
+      E64_STAMP(11);
+      __syncthreads();
+      reduce(n_it - 1);
+      __syncthreads();
+      E64_STAMP(12);
+    } else if (has_next) {
+      fetch_rows(meta, rows);
+    }
+    if (sc0.x >= 0) {
+      const int deg = hi0 - lo0;
+      if (p.aggr == NGPDE_AGGR_MEAN) racc0 = deg > 0 ? f4_scale(1.0f / (float)deg, racc0) : f4_zero();
+      *reinterpret_cast<float4 *>(p.out + (size_t)sc0.x * kW + 4 * q) = racc0;
+    }
+    if (sc1.x >= 0) {
+      const int deg = hi1 - lo1;
+      if (p.aggr == NGPDE_AGGR_MEAN) racc1 = deg > 0 ? f4_scale(1.0f / (float)deg, racc1) : f4_zero();
+      *reinterpret_cast<float4 *>(p.out + (size_t)sc1.x * kW + 4 * q) = racc1;
+    }
+    E64_STAMP(13);
+  }
+}
+
+bool env_off(const char *name) {
+  const char *e = std::getenv(name);
+  return e && e[0] == '1';
+}
+
+}  // namespace
+
+// The specialised launch applies to: P and Q present, no per-edge term, h1 = 64, one further Dense 64 => 64, nothing saved per
+// edge, + / mean, and an activation pair that is instantiated below.  NGPDE_NO_EDGE64=1 keeps the general kernel (read per call:
+// the tests switch it at run time).
+bool edge_mlp64_fwd_applicable(const ngpde_graph *g, const EdgeMlpArgs &a) {
+  if (env_off("NGPDE_NO_EDGE64")) return false;
+  if (!a.P || !a.Q || a.Eterm || a.h1 != kW || a.n_tail != 1 || a.din[0] != kW || a.dout[0] != kW) return false;
+  for (int l = 0; l < 4; ++l)
+    if (a.save_z[l]) return false;
+  if (a.aggr != NGPDE_AGGR_SUM && a.aggr != NGPDE_AGGR_MEAN) return false;
+  const bool a1 = a.act1 == NGPDE_ACT_SWISH || a.act1 == NGPDE_ACT_RELU || a.act1 == NGPDE_ACT_TANH;
+  const bool a2 = a.act[0] == a.act1 || a.act[0] == NGPDE_ACT_IDENTITY;
+  return a1 && a2;
+}
+
+int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream) {
+  EdgeMlp64K k;
+  k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
+  k.n_tiles = (int)(g->n_sched / kTileRows); k.aggr = a.aggr;
+  k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
+  k.P = a.P; k.Q = a.Q; k.wt = a.wt[0]; k.bias = a.bias[0]; k.out = a.out;
+#ifdef NGPDE_STAMPS
+  k.stamps = g_edge64_stamps;
+#endif
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kW * kTS + (size_t)kChunk4 * kTS) * sizeof(float);
+  const int per_xcd = std::max(1, std::min(64, (k.n_tiles + 7) / 8));   // two persistent workgroups per CU, a multiple of the 8 XCDs
+  const dim3 grid(8 * per_xcd), block(kT4);
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, k);
+    return hipSuccess;
+  };
+  hipError_t le;
+  const bool same = a.act[0] == a.act1;
+  switch (a.act1) {
+    case NGPDE_ACT_SWISH: le = same ? launch(edge_mlp64_fwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_SWISH>) : launch(edge_mlp64_fwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_IDENTITY>); break;
+    case NGPDE_ACT_RELU: le = same ? launch(edge_mlp64_fwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_RELU>) : launch(edge_mlp64_fwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_IDENTITY>); break;
+    default: le = same ? launch(edge_mlp64_fwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_TANH>) : launch(edge_mlp64_fwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_IDENTITY>); break;
+  }
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp64_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
+  NGPDE_LAUNCH_CHECK("edge_mlp64_fwd_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde
+
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_edge64_stamps(unsigned long long *buf) {
+  ngpde::g_edge64_stamps = buf;
+  return 0;
+}
+#endif

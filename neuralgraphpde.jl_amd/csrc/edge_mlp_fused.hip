@@ -632,6 +632,7 @@ int32_t launch_edge_mlp_fused_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hi
                 "fused edge-MLP path needs widths <= 64 and multiples of 4, <= 3 layers after the first, and a graph whose "
                 "tiles fit the LDS halo (degree <= %d, <= %d distinct sources per 32-row tile)", kSlotWidth, kHaloCap);
   if (g->n_nodes == 0) return NGPDE_OK;
+  if (edge_mlp64_fwd_applicable(g, a)) return launch_edge_mlp64_fwd(g, a, stream);
   EdgeMlpK k;
   k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
   k.n_tiles = (int)(g->n_sched / kTileRows); k.h1 = a.h1; k.act1 = a.act1; k.aggr = a.aggr;

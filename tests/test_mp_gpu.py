@@ -822,6 +822,44 @@ def test_fused_message_path_layer_counts_and_ragged_rows(widths, acts):
     check_grads(ps, (names, ogr), x, gr["x"])
 
 
+@pytest.mark.parametrize("acts", [("swish", "swish"), ("swish", "identity"), ("relu", "relu"), ("tanh", "tanh"), ("tanh", "identity")])
+@pytest.mark.parametrize("aggr", ["mean", "+"])
+def test_pipelined_message_kernel_64_equals_general_kernel(acts, aggr, monkeypatch):
+    # edge_mlp64.hip (software-pipelined specialisation for the 64-wide two-layer message MLP, BASELINE config 4's shape) against
+    # the general fused kernel (NGPDE_NO_EDGE64=1) -- same operations in the same order, so bit for bit -- and the oracle, on rows
+    # of varying degree (0..9: tiles of 0 / 1 / several 64-edge chunks with ragged tails), a ragged last tile, isolated nodes
+    monkeypatch.delenv("NGPDE_NO_FUSED_EDGE", raising=False)
+    monkeypatch.delenv("NGPDE_NO_EDGE64", raising=False)
+    n, h = 1003, 64
+    rng = np.random.default_rng(47)
+    ss, tt = [], []
+    for i in range(n):
+        if 300 <= i < 340:                      # a run of isolated nodes: a whole tile without edges
+            continue
+        for off in rng.choice(np.arange(-5, 6), size=rng.integers(0, 10), replace=False):
+            if off != 0:
+                ss.append((i + off) % n); tt.append(i)
+    s, t = np.array(ss), np.array(tt)
+    nd = {"x": rng.random((2, n))}
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0, ndata=nd)
+    og = O.Graph(s, t, num_nodes=n, index_base=0, ndata=nd)
+    phi = ng.Chain(ng.Dense(2 * h + 2, 64, acts[0]), ng.Dense(64, 64, acts[1]))
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr=aggr)
+    ps, st = ng.setup(47, l)
+    ps = prep(ps, 47)
+    x = torch.randn(h, n, device=DEV)
+    with torch.no_grad():
+        y64, _ = l(x, ps, st)
+        y64b, _ = l(x, ps, st)
+        monkeypatch.setenv("NGPDE_NO_EDGE64", "1")
+        ygen, _ = l(x, ps, st)
+        monkeypatch.delenv("NGPDE_NO_EDGE64")
+    assert torch.equal(y64, y64b)
+    assert torch.equal(y64, ygen)
+    yo, _ = O.explicit_edge_conv(x.cpu().double().numpy(), omlp(phi, ps), og, aggr)
+    close(y64, yo)
+
+
 @pytest.mark.parametrize("phi_widths", [(8,), (12, 8)])
 def test_fused_paths_with_edge_features_and_fused_pullback(phi_widths, monkeypatch):
     # MPPDEConv with per-edge features (the E term of the split first layer) and a per-graph theta on a local graph whose
