@@ -237,6 +237,10 @@ int32_t launch_dense_dz(int64_t count, int act, const float *dy, const float *z,
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,
                                    hipStream_t stream);
 int dense_weight_chunks(int64_t n, int din, int dout);
+// dense_stream_bwd.hip: the whole Dense pullback (dz, input and weight pullbacks, bias) as one streaming launch; grid 0 = not applicable
+int dense_stream_bwd_grid(int64_t n, const SegTable &t, int din, int dout, float *const *dseg);
+int32_t launch_dense_stream_bwd(int64_t n, const SegTable &t, int din, int act, const float *wt, const float *z, const float *dy,
+                                float *const *dseg, float *dwt, float *dbias, float *slabs, int grid, hipStream_t stream);
 int dense_bwd_input_splits(int64_t n, int din, int dout);
 size_t dense_bwd_input_split_bytes(int64_t n, int din, int dout);
 int32_t launch_dense_bwd_input_splitk(int64_t n, float *dx, int din, int dout, const float *dz, const float *wt, float *part,

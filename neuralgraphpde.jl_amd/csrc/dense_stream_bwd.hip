@@ -1,0 +1,277 @@
+// dense_stream_bwd.hip -- the whole pullback of a node-level Dense with 64 outputs in ONE streaming launch
+//   dz = dy . act'(z),   dX_b = dz W_b^T  (per 64-wide input block b),   dW = [X1 | X2 | narrow]^T dz,   db = colsum(dz)
+// for the shapes the edge-function layers put at node level (/root/reference/src/layers.jl:409-418 after the first-layer
+// split: [h | d | theta] => 64, [h | d] => 64, [h | m | theta] => 64, 64 => 64): one or two 64-wide blocks plus up to four
+// narrow features (coordinates, per-graph theta) that carry no gradient.  The composed path (dense_dz + weight pullback +
+// input pullback, dense_mfma.hip) reads dz three times and X once in three launches of 64-row K steps: 0.30 ms per layer at
+// BASELINE config 4's shard (524 288 rows) against 0.10 ms for the 402 MB this launch moves.
+//
+// Persistent workgroups of 4 waves walk 64-row tiles.  Per tile: dy (and z) come through registers -- dz is formed there, feeds
+// the rank-1 accumulations of the narrow features and the bias, and is written to LDS --, the 64 x 64 tile of X_b goes memory ->
+// LDS by LDS-DMA (dense_stream64_fwd_kernel's scheme); then every wave runs 64 MFMAs of X_b^T dz (its 16 input features x all
+// 64 outputs, contraction over the tile's rows, accumulators live in registers for the whole launch) and 64 MFMAs of dz W_b^T
+// (its 16 rows), whose result leaves through the X tile's LDS image as full 256-byte rows.  Both tiles use one XOR swizzle
+// of the 16-byte chunk index, slot = chunk ^ R(row), R = the row's low two bit pairs swapped, which makes BOTH access
+// patterns bank-conflict free: 16-byte row reads (16 rows x one chunk) and the 4-byte transposed reads of the weight product
+// (rows 4s .. 4s + 3 x 16 consecutive columns).  The next tile's dy / z / narrow features are in flight during the MFMAs.
+// Per-workgroup dW / db slabs are summed by dense_weight_reduce_kernel in a fixed order: no atomics, reproducible.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace ngpde {
+
+namespace {
+
+constexpr int kBT = 256, kTR = 64, kD = 64, kPS = kD + 4, kMaxNarrow = 4;
+
+struct DenseBwdK {
+  int64_t n;
+  int n_tiles, n_narrow, din, act;
+  const float *x[2];       // the 64-wide blocks [n][64]
+  float *dx[2];            // their gradients, or NULL
+  int main_off[2];         // first feature of each block in the virtual vcat (= row of W / dW)
+  const float *nx[kMaxNarrow];   // narrow feature f lives at nx[f][(row / ndiv[f]) * nwidth[f]]
+  int nwidth[kMaxNarrow], ndiv[kMaxNarrow], nfeat[kMaxNarrow];
+  const float *wt, *z, *dy;
+  float *partial;          // [gridDim.x][din + 1][64]
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }   // R(row & 15)
+__device__ __forceinline__ int sw_addr(int row, int col) { return row * kD + 4 * ((col >> 2) ^ swz(row)) + (col & 3); }
+
+template <int NMAIN>
+__global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseBwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *ldsDz = lds;                    // [64][64], swizzled
+  float *ldsX = ldsDz + kTR * kD;        // [64][64] swizzled DMA image of X_b, later [64][68] dX_b on its way out
+  float *ldsW = ldsX + kTR * kPS;        // [NMAIN][64 k][68]  W_b, row-major (k, o)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int rg = tid >> 4, qc = tid & 15;   // staging role: rows rg + 16 p, columns 4 qc .. 4 qc + 3
+
+#pragma unroll
+  for (int b = 0; b < NMAIN; ++b)
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int k = rg + 16 * pp;
+      *reinterpret_cast<float4 *>(&ldsW[(b * kD + k) * kPS + 4 * qc]) =
+          *reinterpret_cast<const float4 *>(p.wt + (size_t)(p.main_off[b] + k) * kD + 4 * qc);
+    }
+
+  f32x4 accW[NMAIN][4];
+#pragma unroll
+  for (int b = 0; b < NMAIN; ++b)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) accW[b][ob] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 nacc[kMaxNarrow], bacc = f4_zero();
+#pragma unroll
+  for (int f = 0; f < kMaxNarrow; ++f) nacc[f] = f4_zero();
+
+  float4 dyr[4], zr[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+  float nxr[4][kMaxNarrow];
+  auto fetch = [&](int tile) {   // dy, z and the narrow features of the thread's four rows (32-bit offsets from uniform bases)
+    const uint32_t row0 = (uint32_t)tile * kTR;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const uint32_t r = row0 + rg + 16 * pp;
+      const uint32_t rc = min(r, (uint32_t)(p.n - 1));
+      const uint32_t e = rc * kD + 4 * qc;
+      dyr[pp] = *reinterpret_cast<const float4 *>(p.dy + e);
+      if (r >= (uint32_t)p.n) dyr[pp] = f4_zero();   // rows past the end contribute nothing
+      if (p.z) zr[pp] = *reinterpret_cast<const float4 *>(p.z + e);
+#pragma unroll
+      for (int f = 0; f < kMaxNarrow; ++f) nxr[pp][f] = p.nx[f][(rc / (uint32_t)p.ndiv[f]) * (uint32_t)p.nwidth[f]];   // (unused slots alias X)
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.n_tiles) fetch(tile);
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * kTR;
+    int opaque0;   // a zero the compiler cannot see through: keeps the ~100 LDS addresses of the products from being hoisted out of
+                   // the tile loop into registers (they are a few VALU instructions each, recomputed per tile)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+    __syncthreads();   // the previous tile's LDS images are consumed (first pass: W is in place)
+    auto dma_x = [&](int b) {   // X_b tile: four DMA instructions per wave, four rows each
+      const int rl = lane >> 4, s16 = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + rl;
+        const uint32_t gr = min((uint32_t)row0 + r, (uint32_t)(p.n - 1));
+        const int c = s16 ^ swz(r);
+        const float *g = p.x[b] + (gr * kD + 4 * c);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsX) + ((wave * 4 + j) * 4) * 16 + lane),
+                                         16, 0, 0);
+      }
+    };
+    dma_x(0);
+    // dz of the thread's rows -> LDS; bias and narrow-feature accumulations (rank-1 updates on the VALU)
+    if (p.z) {   // dz = dy . act'(z): one uniform activation switch for the 16 values
+      f4n_dact<4>(p.act, zr);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) dyr[pp] = f4_mul(dyr[pp], zr[pp]);
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const float4 dz = dyr[pp];
+      const int r = rg + 16 * pp;
+      *reinterpret_cast<float4 *>(&ldsDz[r * kD + 4 * (qc ^ swz(r))]) = dz;
+      bacc = f4_add(bacc, dz);
+#pragma unroll
+      for (int f = 0; f < kMaxNarrow; ++f) nacc[f] = f4_fma(nxr[pp][f], dz, nacc[f]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tnext = tile + gridDim.x;
+    if (tnext < p.n_tiles) fetch(tnext);   // in flight during the MFMAs
+
+#pragma unroll
+    for (int b = 0; b < NMAIN; ++b) {
+      if (b > 0) {   // the second block's tile takes the place of the first one's outgoing dX
+        __syncthreads();
+        dma_x(b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also collects the prefetch: second blocks are the rarer case)
+        __syncthreads();
+      }
+      // ---- dW_b += X_b^T dz: this wave's 16 input features x 64 outputs, contraction over the tile's rows 4 s + kq
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int r = 4 * s + kq + opaque0;
+        const float av = ldsX[sw_addr(r, 16 * wave + i)];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) accW[b][ob] = mfma16(av, ldsDz[sw_addr(r, 16 * ob + i)], accW[b][ob]);
+      }
+      if (p.dx[b] == nullptr) continue;   // (workgroup-uniform)
+      // ---- dX_b = dz W_b^T: this wave's 16 rows x 64 input features
+      f32x4 accX[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) accX[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      {
+        const int r = 16 * wave + i + opaque0;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(&ldsDz[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
+          float4 b4[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const float4 *>(&ldsW[(b * kD + 16 * ct + i) * kPS + 16 * kh + 4 * kq]);
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              const float bv[4] = {b4[ct].x, b4[ct].y, b4[ct].z, b4[ct].w};
+              accX[ct] = mfma16(av[rr], bv[rr], accX[ct]);
+            }
+          }
+        }
+      }
+      __syncthreads();   // every wave is done with the X image
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ldsX[(16 * wave + 4 * kq + reg) * kPS + 16 * ct + i] = accX[ct][reg];
+      __syncthreads();
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int r = rg + 16 * pp;
+        if (row0 + r < p.n)
+          *reinterpret_cast<float4 *>(p.dx[b] + (row0 + r) * kD + 4 * qc) = *reinterpret_cast<const float4 *>(&ldsX[r * kPS + 4 * qc]);
+      }
+    }
+  }
+
+  // ---- this workgroup's slab: the MFMA accumulators directly, narrow features and bias after a fixed-order sum over the
+  // 16 row groups
+  float *slab = p.partial + (size_t)blockIdx.x * (p.din + 1) * kD;
+#pragma unroll
+  for (int b = 0; b < NMAIN; ++b)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) slab[(size_t)(p.main_off[b] + 16 * wave + 4 * kq + reg) * kD + 16 * ob + i] = accW[b][ob][reg];
+  __syncthreads();
+  float *red = lds;   // [16 row groups][5][64]
+#pragma unroll
+  for (int f = 0; f < kMaxNarrow; ++f) *reinterpret_cast<float4 *>(&red[(rg * 5 + f) * kD + 4 * qc]) = nacc[f];
+  *reinterpret_cast<float4 *>(&red[(rg * 5 + 4) * kD + 4 * qc]) = bacc;
+  __syncthreads();
+  for (int idx = tid; idx < 5 * kD; idx += kBT) {
+    const int f = idx / kD, o = idx % kD;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[(g * 5 + f) * kD + o];
+    if (f == 4) slab[(size_t)p.din * kD + o] = s;
+    else if (f < p.n_narrow) slab[(size_t)p.nfeat[f] * kD + o] = s;
+  }
+}
+
+bool env_on(const char *name) {
+  const char *e = std::getenv(name);
+  return e && e[0] == '1';
+}
+
+}  // namespace
+
+// Applies when: 64 outputs, one or two blocks of exactly 64 features (row_div 1, 16-byte aligned), every other feature
+// narrow (<= 4 in total) and without a gradient request, enough rows for a resident wave of tiles, and the slabs fit the dz
+// area of the caller's workspace.  NGPDE_DENSE_NO_STREAM_BWD=1 keeps the composed path (read per call).
+int dense_stream_bwd_grid(int64_t n, const SegTable &t, int din, int dout, float *const *dseg) {
+  if (env_on("NGPDE_DENSE_NO_STREAM_BWD") || dout != kD || n < 32768 || n > (1 << 24)) return 0;   // (32-bit byte offsets)
+  int n_main = 0, n_narrow = 0;
+  for (int b = 0; b < t.n; ++b) {
+    const bool grad = dseg && dseg[b] && t.row_div[b] == 1;
+    if (t.width[b] == kD && t.row_div[b] == 1 && (reinterpret_cast<uintptr_t>(t.ptr[b]) & 15) == 0 &&
+        (!grad || (reinterpret_cast<uintptr_t>(dseg[b]) & 15) == 0)) {
+      ++n_main;
+    } else {
+      if (grad) return 0;
+      n_narrow += t.width[b];
+    }
+  }
+  if (n_main < 1 || n_main > 2 || n_narrow > kMaxNarrow) return 0;
+  const int n_tiles = (int)((n + kTR - 1) / kTR);
+  int grid = std::min(n_tiles, 256 * 2);
+  grid = (int)std::min<int64_t>(grid, n / (din + 1));   // slabs live in the [n][64] dz area of the workspace
+  return grid >= 256 ? grid : 0;
+}
+
+int32_t launch_dense_stream_bwd(int64_t n, const SegTable &t, int din, int act, const float *wt, const float *z, const float *dy,
+                                float *const *dseg, float *dwt, float *dbias, float *slabs, int grid, hipStream_t stream) {
+  DenseBwdK k{};
+  k.n = n; k.n_tiles = (int)((n + kTR - 1) / kTR); k.din = din; k.act = act;
+  k.wt = wt; k.z = (act == NGPDE_ACT_IDENTITY) ? nullptr : z; k.dy = dy; k.partial = slabs;
+  int n_main = 0;
+  for (int b = 0; b < t.n; ++b) {
+    const bool grad = dseg && dseg[b] && t.row_div[b] == 1;
+    if (t.width[b] == kD && t.row_div[b] == 1 && (reinterpret_cast<uintptr_t>(t.ptr[b]) & 15) == 0 &&
+        (!grad || (reinterpret_cast<uintptr_t>(dseg[b]) & 15) == 0)) {
+      k.x[n_main] = t.ptr[b]; k.dx[n_main] = grad ? dseg[b] : nullptr; k.main_off[n_main] = t.offset[b];
+      ++n_main;
+    } else {
+      for (int c = 0; c < t.width[b]; ++c) {
+        k.nx[k.n_narrow] = t.ptr[b] + c; k.nwidth[k.n_narrow] = t.width[b]; k.ndiv[k.n_narrow] = t.row_div[b];
+        k.nfeat[k.n_narrow] = t.offset[b] + c;
+        ++k.n_narrow;
+      }
+    }
+  }
+  for (int f = k.n_narrow; f < kMaxNarrow; ++f) { k.nx[f] = k.x[0]; k.nwidth[f] = kD; k.ndiv[f] = 1; k.nfeat[f] = 0; }
+  const size_t lds = ((size_t)kTR * kD + (size_t)kTR * kPS + (size_t)n_main * kD * kPS) * sizeof(float);
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBT), lds, stream, k);
+    return hipSuccess;
+  };
+  const hipError_t le = n_main == 1 ? launch(dense_stream64_bwd_kernel<1>) : launch(dense_stream64_bwd_kernel<2>);
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_stream64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
+  NGPDE_LAUNCH_CHECK("dense_stream64_bwd_kernel");
+  return launch_dense_weight_reduce(grid, din, kD, slabs, dwt, dbias, stream);
+}
+
+}  // namespace ngpde

@@ -159,6 +159,57 @@ def test_dense_wide_tiles_segmented(widths, dout, act):
         o += w
 
 
+@pytest.mark.parametrize("widths,grads,act", [((64,), (True,), "identity"), ((64, 2), (True, False), "swish"),
+                                              ((64, 1, 1, 2), (True, False, False, False), "swish"),
+                                              ((64, 64, 2), (True, True, False), "swish"), ((2, 64, 64), (False, False, True), "relu"),
+                                              ((64,), (False,), "tanh")])
+def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
+    # dense_stream_bwd.hip: dz, input pullbacks, weight pullback and bias gradient of a 64-output Dense in one launch (one or two
+    # 64-wide blocks + narrow blocks without gradient, the last block per graph as MPPDEConv's theta, src/layers.jl:397, :418);
+    # ragged last tile; against the oracle and against the composed path (NGPDE_DENSE_NO_STREAM_BWD=1)
+    from ngpde_amd import functional as F
+    monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD", raising=False)
+    n, per_graph, dout = 70001, 10000, 64
+    rng = np.random.default_rng(33)
+    res = []
+    for mode in (0, 1):
+        rng = np.random.default_rng(33)
+        blocks, divs = [], []
+        for i, (w, gq) in enumerate(zip(widths, grads)):
+            rd = per_graph if (w == 2 and len(widths) >= 3 and i in (0, len(widths) - 1) and not gq and widths.count(64) >= 1 and i == len(widths) - 1) else 1
+            rows = (n + rd - 1) // rd
+            blocks.append(torch.as_tensor(rng.normal(size=(rows, w)), dtype=torch.float32, device=DEV).requires_grad_(gq))
+            divs.append(rd)
+        din = sum(widths)
+        wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+        b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True)
+        R = rng.normal(size=(dout, n))
+        if mode == 1:
+            monkeypatch.setenv("NGPDE_DENSE_NO_STREAM_BWD", "1")
+        y = F.dense(blocks, wt, b, ng.layers._act_code(act)[1], row_divs=divs, n=n)
+        (y * torch.as_tensor(R.T, dtype=torch.float32, device=DEV)).sum().backward()
+        if mode == 1:
+            monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD")
+        res.append((blocks, wt, b))
+    (blocks, wt, b), (blocks2, wt2, b2) = res
+    X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+    layer = [dict(weight=wt.detach().cpu().double().numpy().T, bias=b.detach().cpu().double().numpy(), act=act)]
+    yo, cache = O.mlp_forward(layer, X.T)
+    dx, gr = O.mlp_backward(layer, cache, R)
+    close(wt.grad, gr[0]["weight"].T, rtol=3e-4)
+    close(b.grad, gr[0]["bias"].reshape(-1), rtol=3e-4)
+    close(wt.grad, wt2.grad.cpu().double().numpy(), rtol=3e-4)
+    close(b.grad, b2.grad.cpu().double().numpy(), rtol=3e-4)
+    o = 0
+    for bl, bl2, gq, w in zip(blocks, blocks2, grads, widths):
+        if gq:
+            close(bl.grad, dx[o:o + w].T)
+            close(bl.grad, bl2.grad.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+        else:
+            assert bl.grad is None
+        o += w
+
+
 # ---- ExplicitEdgeConv ---------------------------------------------------------------------------------------------------
 
 def test_edgeconv_reference_fixture():
