@@ -188,6 +188,24 @@ int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr,
 int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
                             const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight,
                             const float *bias, float *y, float *save_z, ngpde_stream_t stream);
+/* Two Dense layers that share their leading input block, y_a = Dense_a(vcat(X, ...)), y_b = Dense_b(vcat(X, ...)), in one pass
+ * over X: the two node-level halves of a message MLP's first layer (the `vcat(xi..., xj..., ...)` of src/layers.jl:106, :316,
+ * :409-410 split into a target term and a source term).  Exactly two ngpde_dense_forward calls in effect; one launch when X
+ * is 64 wide, both outputs <= 64 wide and the other blocks narrow. */
+int32_t ngpde_dense_pair_forward(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                 const int32_t *seg_row_div_a, int32_t dout_a, int32_t act_a, const float *weight_a, const float *bias_a,
+                                 float *y_a, float *save_z_a, int32_t n_seg_b, const float *const *seg_ptr_b,
+                                 const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout_b, int32_t act_b,
+                                 const float *weight_b, const float *bias_b, float *y_b, float *save_z_b, ngpde_stream_t stream);
+/* Chain(Dense(. => dmid, act1), Dense(dmid => dout, act2)) on a virtual vcat -- the node update psi / gamma of MPPDEConv /
+ * VMHConv (src/layers.jl:418, :328).  a1 (the first layer's activations, [n][dmid]) and the save_* arrays are nullable when
+ * ngpde_dense_chain2_fused(...) == 1: the intermediate then stays on chip (one launch); otherwise a1 is required. */
+int32_t ngpde_dense_chain2_fused(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                                 const int32_t *seg_row_div, int32_t dmid, int32_t dout);
+int32_t ngpde_dense_chain2_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                                   const int32_t *seg_row_div, int32_t dmid, int32_t act1, const float *weight1, const float *bias1,
+                                   float *a1, float *save_z1, int32_t dout, int32_t act2, const float *weight2, const float *bias2,
+                                   float *y, float *save_z2, ngpde_stream_t stream);
 size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout);
 /* dseg_ptr[i] nullable: gradient block for X_i (never written for row_div > 1 blocks: graph-level features
  * are @ignore_derivatives in the reference, :397,:418).  dweight (dout x sum width) column-major, dbias nullable. */

@@ -63,6 +63,10 @@ SIGNATURES = {
     "ngpde_gcn_backward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_propagate_copy_xj": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ngpde_dense_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_pair_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
+                                        _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_chain2_fused": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32]),
+    "ngpde_dense_chain2_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_dense_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "ngpde_dense_backward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_edge_permute": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),

@@ -56,6 +56,60 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
   return launch_dense_seg_fwd(n, t, din, dout, act, weight, bias, y, save_z, (hipStream_t)stream);
 }
 
+int32_t ngpde_dense_pair_forward(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                 const int32_t *seg_row_div_a, int32_t dout_a, int32_t act_a, const float *weight_a, const float *bias_a,
+                                 float *y_a, float *save_z_a, int32_t n_seg_b, const float *const *seg_ptr_b,
+                                 const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout_b, int32_t act_b,
+                                 const float *weight_b, const float *bias_b, float *y_b, float *save_z_b, ngpde_stream_t stream) {
+  SegTable ta, tb;
+  int dina = 0, dinb = 0;
+  int32_t st = make_segs("ngpde_dense_pair_forward", n_seg_a, seg_ptr_a, seg_width_a, seg_row_div_a, ta, &dina);
+  if (st || (st = make_segs("ngpde_dense_pair_forward", n_seg_b, seg_ptr_b, seg_width_b, seg_row_div_b, tb, &dinb))) return st;
+  if ((st = check_act("ngpde_dense_pair_forward", act_a)) || (st = check_act("ngpde_dense_pair_forward", act_b))) return st;
+  NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && dout_a > 0 && dout_b > 0, NGPDE_ERR_DIMENSION_MISMATCH,
+                "ngpde_dense_pair_forward: DimensionMismatch (rows must be in [0, 2^31), dout > 0)");
+  if (n == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(weight_a && y_a && weight_b && y_b, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_pair_forward: weight/y is NULL");
+  if (dense_pair_fwd_applicable(n, ta, dina, dout_a, tb, dinb, dout_b))
+    return launch_dense_pair_fwd(n, ta, dina, dout_a, act_a, weight_a, bias_a, y_a, save_z_a, tb, dinb, dout_b, act_b, weight_b, bias_b,
+                                 y_b, save_z_b, (hipStream_t)stream);
+  if ((st = launch_dense_seg_fwd(n, ta, dina, dout_a, act_a, weight_a, bias_a, y_a, save_z_a, (hipStream_t)stream))) return st;
+  return launch_dense_seg_fwd(n, tb, dinb, dout_b, act_b, weight_b, bias_b, y_b, save_z_b, (hipStream_t)stream);
+}
+
+int32_t ngpde_dense_chain2_fused(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                                 const int32_t *seg_row_div, int32_t dmid, int32_t dout) {
+  SegTable t;
+  int din = 0;
+  if (make_segs("ngpde_dense_chain2_fused", n_seg, seg_ptr, seg_width, seg_row_div, t, &din)) return 0;
+  return (n > 0 && n < ((int64_t)1 << 31) && dense_chain_fwd_applicable(n, t, din, dmid, dout)) ? 1 : 0;
+}
+
+int32_t ngpde_dense_chain2_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
+                                   const int32_t *seg_row_div, int32_t dmid, int32_t act1, const float *weight1, const float *bias1,
+                                   float *a1, float *save_z1, int32_t dout, int32_t act2, const float *weight2, const float *bias2,
+                                   float *y, float *save_z2, ngpde_stream_t stream) {
+  SegTable t;
+  int din = 0;
+  int32_t st = make_segs("ngpde_dense_chain2_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
+  if (st || (st = check_act("ngpde_dense_chain2_forward", act1)) || (st = check_act("ngpde_dense_chain2_forward", act2))) return st;
+  NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && dmid > 0 && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH,
+                "ngpde_dense_chain2_forward: DimensionMismatch (rows must be in [0, 2^31), widths > 0)");
+  if (n == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(weight1 && weight2 && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_chain2_forward: weight/y is NULL");
+  if (dense_chain_fwd_applicable(n, t, din, dmid, dout))
+    return launch_dense_chain_fwd(n, t, din, act1, weight1, bias1, a1, save_z1, dout, act2, weight2, bias2, y, save_z2, (hipStream_t)stream);
+  NGPDE_REQUIRE(a1 != nullptr, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_dense_chain2_forward: this shape runs as two launches and needs the [n][dmid] buffer a1 (ngpde_dense_chain2_fused)");
+  if ((st = launch_dense_seg_fwd(n, t, din, dmid, act1, weight1, bias1, a1, save_z1, (hipStream_t)stream))) return st;
+  SegTable t2;
+  const float *p2[1] = {a1};
+  const int32_t w2[1] = {dmid};
+  int din2 = 0;
+  if ((st = make_segs("ngpde_dense_chain2_forward", 1, p2, w2, nullptr, t2, &din2))) return st;
+  return launch_dense_seg_fwd(n, t2, din2, dout, act2, weight2, bias2, y, save_z2, (hipStream_t)stream);
+}
+
 size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout) {
   return align256((size_t)std::max<int64_t>(n, 1) * dout * 4) +
          align256((size_t)dense_weight_chunks(n, din_total, dout) * (din_total + 1) * dout * 4) +

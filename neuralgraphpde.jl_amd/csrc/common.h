@@ -227,6 +227,14 @@ struct SegGrad {
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream);
 int dense_fwd_splits(int64_t n, int din, int dout);
+// two Dense layers in one streaming launch (dense_mfma.hip): two outputs from one 64-wide input block / a two-layer chain
+bool dense_pair_fwd_applicable(int64_t n, const SegTable &ta, int dina, int douta, const SegTable &tb, int dinb, int doutb);
+int32_t launch_dense_pair_fwd(int64_t n, const SegTable &ta, int dina, int douta, int acta, const float *wta, const float *ba, float *ya,
+                              float *za, const SegTable &tb, int dinb, int doutb, int actb, const float *wtb, const float *bb, float *yb,
+                              float *zb, hipStream_t stream);
+bool dense_chain_fwd_applicable(int64_t n, const SegTable &t1, int din1, int dmid, int dout2);
+int32_t launch_dense_chain_fwd(int64_t n, const SegTable &t1, int din1, int act1, const float *wt1, const float *b1, float *a1, float *z1,
+                               int dout2, int act2, const float *wt2, const float *b2, float *y, float *z2, hipStream_t stream);
 int dense_fwd_split_count(int din, int nsplit);
 int32_t launch_dense_seg_fwd_splitk(int64_t n, const SegTable &segs, int din, int dout, const float *wt, float *partial, int nsplit,
                                     hipStream_t stream);

@@ -452,6 +452,254 @@ __global__ __launch_bounds__(kStreamThreads, 6) void dense_stream64_fwd_kernel(i
   }
 }
 
+// ---- two Dense layers in one streaming launch, weights in registers ------------------------------------------------------------
+// dense_pair_fwd_kernel: y_a = act_a([X | narrow_a] Wa + ba), y_b = act_b([X | narrow_b] Wb + bb) from ONE pass over the 64-wide
+// block X -- the two node-level first-layer terms P, Q of the edge-function layers (/root/reference/src/layers.jl:409-410 split
+// at node level: P from [h_i; d_i; theta], Q from [h_j; -d_j]).  dense_chain_fwd_kernel: y = act2(act1([X0 | X1 | narrow] W1 +
+// b1) W2 + b2) with the 64-wide intermediate kept in LDS -- the node update psi of MPPDEConv / gamma of VMHConv (:418, :328).
+// Both walk 128-row tiles with persistent workgroups of 8 waves as dense_stream64_fwd_kernel does (input tiles by LDS-DMA into
+// XOR-swizzled images, narrow trailing features and bias in the epilogue), but wave w owns 16 OUTPUT COLUMNS (w % 4) of 64 rows
+// (w / 4) and keeps its W^T fragments -- 16 registers per 64-deep input block -- for the whole launch: no weight copy in LDS, so
+// two workgroups fit a CU beside 35-67 KB of tiles, and the only LDS reads of the products are the 16 A fragments per tile.
+struct StreamOut {
+  SegTable segs;   // the Dense's whole virtual vcat (leading blocks: the 64-wide ones; trailing: narrow features)
+  int din_all, dout, act;
+  const float *wt, *bias;
+  float *y, *save_z;
+};
+
+__device__ __forceinline__ void load_wfrag(const float *__restrict__ wt, int dout, int k0, int col, int kq, f32x4 (&breg)[4]) {
+#pragma unroll
+  for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) breg[kh][r] = (col < dout) ? wt[(size_t)(k0 + 16 * kh + 4 * kq + r) * dout + col] : 0.f;
+}
+
+// TR x 64 tile memory -> LDS image (slot = chunk ^ (row & 15)), TR / 32 DMA instructions per wave
+template <int TR>
+__device__ __forceinline__ void dma_tile(const float *__restrict__ x, int64_t row0, int64_t n, float *img, int wave, int lane) {
+  const int rl = lane >> 4, s16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < TR / 32; ++j) {
+    const int r = (wave * (TR / 32) + j) * 4 + rl;
+    const int64_t gr = min(row0 + r, n - 1);   // rows past the end read the last row (never stored)
+    const float *g = x + gr * 64 + 4 * (s16 ^ (r & 15));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(img) + ((wave * (TR / 32) + j) * 4) * 16 + lane),
+                                     16, 0, 0);
+  }
+}
+
+// acc[rt] += rows ((TR / 2) half + 16 rt ..) of a swizzled image (SWZ) or of a row-major tile of stride OS2 x the wave's fragments
+template <int TR, bool SWZ>
+__device__ __forceinline__ void mfma_rows_regs(const float *t, int half, int lane, const f32x4 (&breg)[4], f32x4 (&acc)[TR / 32]) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < TR / 32; ++rt) {
+    const int r = (TR / 2) * half + 16 * rt + i;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const float4 a4 = SWZ ? reinterpret_cast<const float4 *>(t)[r * 16 + ((4 * kh + kq) ^ (r & 15))]
+                            : *reinterpret_cast<const float4 *>(&t[r * OS2 + 16 * kh + 4 * kq]);
+      acc[rt] = mfma16(a4.x, breg[kh][0], acc[rt]);
+      acc[rt] = mfma16(a4.y, breg[kh][1], acc[rt]);
+      acc[rt] = mfma16(a4.z, breg[kh][2], acc[rt]);
+      acc[rt] = mfma16(a4.w, breg[kh][3], acc[rt]);
+    }
+  }
+}
+template <int TR>
+__device__ __forceinline__ void stage_cols(float *tile, int half, int ct, int lane, const f32x4 (&acc)[TR / 32]) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < TR / 32; ++rt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) tile[((TR / 2) * half + 16 * rt + 4 * kq + reg) * OS2 + 16 * ct + i] = acc[rt][reg];
+}
+
+// Narrow features (<= kNarrow per Dense) travel through two small LDS tables: wn[f][64] = their weight rows (once per
+// workgroup), xn[row][kNarrowAll] = their values on the tile's rows (one or two loads per thread at the top of the tile, in
+// flight under the products) -- the epilogue then has no global load of its own.
+constexpr int kNarrow = 4, kNarrowAll = 8;
+__device__ __forceinline__ void narrow_weights(const StreamOut &o, int kmain, float *wn, int tid) {
+  for (int idx = tid; idx < kNarrow * 64; idx += kStreamThreads) {
+    const int f = idx >> 6, c = idx & 63;
+    wn[idx] = (kmain + f < o.din_all && c < o.dout) ? o.wt[(size_t)(kmain + f) * o.dout + c] : 0.f;
+  }
+}
+__device__ __forceinline__ float narrow_value(const StreamOut &o, int kmain, int f, int64_t r, int64_t n) {
+  return (kmain + f < o.din_all && r < n) ? seg_load(o.segs, r, kmain + f) : 0.f;
+}
+
+// epilogue of one Dense on a staged TR x 64 tile: thread (row = tid / 16 + 32 p, columns 4 (tid % 16) .. + 3) adds bias and the
+// narrow features (tables xn / wn), saves z, applies the activation, stores y; WRITEBACK: the activations replace the tile
+// (input of a second layer)
+template <int TR, bool WRITEBACK>
+__device__ __forceinline__ void stream_epilogue(const StreamOut &o, int n_narrow, const float *xn, const float *wn, float *tile,
+                                                int64_t row0, int64_t n, int tid, const float (&b)[4]) {
+  const int oc = 4 * (tid & 15);
+  const bool vec = (o.dout % 4 == 0) && ((reinterpret_cast<uintptr_t>(o.y) | reinterpret_cast<uintptr_t>(o.save_z)) & 15) == 0;
+  float4 zz[TR / 32], aa[TR / 32];
+#pragma unroll
+  for (int p = 0; p < TR / 32; ++p) {
+    const float4 v = *reinterpret_cast<const float4 *>(&tile[((tid >> 4) + 32 * p) * OS2 + oc]);
+    zz[p] = make_float4(v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]);
+  }
+  for (int f = 0; f < n_narrow; ++f) {
+    const float4 w = *reinterpret_cast<const float4 *>(&wn[f * 64 + oc]);
+#pragma unroll
+    for (int p = 0; p < TR / 32; ++p) {
+      const float xv = xn[((tid >> 4) + 32 * p) * kNarrowAll + f];
+      zz[p] = make_float4(fmaf(xv, w.x, zz[p].x), fmaf(xv, w.y, zz[p].y), fmaf(xv, w.z, zz[p].z), fmaf(xv, w.w, zz[p].w));
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < TR / 32; ++p) aa[p] = zz[p];
+  f4n_act<TR / 32>(o.act, aa);
+#pragma unroll
+  for (int p = 0; p < TR / 32; ++p) {
+    if (WRITEBACK) *reinterpret_cast<float4 *>(&tile[((tid >> 4) + 32 * p) * OS2 + oc]) = aa[p];
+    const int64_t r = row0 + (tid >> 4) + 32 * p;
+    if (r >= n || oc >= o.dout) continue;
+    if (vec) {
+      if (o.save_z) *reinterpret_cast<float4 *>(o.save_z + r * o.dout + oc) = zz[p];
+      if (o.y) *reinterpret_cast<float4 *>(o.y + r * o.dout + oc) = aa[p];
+    } else {
+      const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (oc + j < o.dout) {
+          if (o.save_z) o.save_z[r * o.dout + oc + j] = z[j];
+          if (o.y) o.y[r * o.dout + oc + j] = a4[j];
+        }
+    }
+  }
+}
+
+// Both kernels double-buffer the input images: the DMA of tile t + 1 is issued at the top of tile t into the buffer tile t - 1
+// left behind, and collected at the top of tile t + 1 -- a whole tile of arithmetic later.
+constexpr int kPairTR = 64;
+__global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64_t n, int n_tiles, const float *__restrict__ x,
+                                                                           const StreamOut a, const StreamOut b) {
+  constexpr int TR = kPairTR;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  // dyn: two buffers [TR][OS2], each the X image of a tile, then each output on its way out
+  float *wn = dyn + 2 * TR * OS2;                  // [2][kNarrow][64]
+  float *xn = wn + 2 * kNarrow * 64;               // [TR][kNarrowAll]: features 0..3 of a, 4..7 of b
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, half = wave >> 2;
+  f32x4 wa[4], wb[4];
+  load_wfrag(a.wt, a.dout, 0, 16 * ct + (lane & 15), lane >> 4, wa);
+  load_wfrag(b.wt, b.dout, 0, 16 * ct + (lane & 15), lane >> 4, wb);
+  narrow_weights(a, 64, wn, tid);
+  narrow_weights(b, 64, wn + kNarrow * 64, tid);
+  const int na = a.din_all - 64, nb = b.din_all - 64;
+  const int oc = 4 * (tid & 15);
+  float ba[4], bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ba[j] = (a.bias && oc + j < a.dout) ? a.bias[oc + j] : 0.f;
+    bb[j] = (b.bias && oc + j < b.dout) ? b.bias[oc + j] : 0.f;
+  }
+  int t = blockIdx.x, it = 0;
+  if (t < n_tiles) dma_tile<TR>(x, (int64_t)t * TR, n, dyn, wave, lane);
+  for (; t < n_tiles; t += gridDim.x, ++it) {
+    const int64_t row0 = (int64_t)t * TR;
+    float *cur = dyn + (it & 1) * (TR * OS2), *nxt = dyn + ((it + 1) & 1) * (TR * OS2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this tile's image has landed; the previous tile's second output has left the other buffer
+    // narrow features of this tile's rows, then the next tile's image
+    const int nr = tid >> 3, nf = tid & 7;   // (64 rows x 8 features: one value per thread)
+    const float xv = nf < 4 ? narrow_value(a, 64, nf, row0 + nr, n) : narrow_value(b, 64, nf - 4, row0 + nr, n);
+    if (t + (int)gridDim.x < n_tiles) dma_tile<TR>(x, (int64_t)(t + gridDim.x) * TR, n, nxt, wave, lane);
+    f32x4 acca[TR / 32], accb[TR / 32];
+#pragma unroll
+    for (int rt = 0; rt < TR / 32; ++rt) acca[rt] = accb[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows_regs<TR, true>(cur, half, lane, wa, acca);
+    mfma_rows_regs<TR, true>(cur, half, lane, wb, accb);
+    xn[nr * kNarrowAll + nf] = xv;
+    __syncthreads();
+    stage_cols<TR>(cur, half, ct, lane, acca);
+    __syncthreads();
+    stream_epilogue<TR, false>(a, na, xn, wn, cur, row0, n, tid, ba);
+    __syncthreads();
+    stage_cols<TR>(cur, half, ct, lane, accb);
+    __syncthreads();
+    stream_epilogue<TR, false>(b, nb, xn + 4, wn + kNarrow * 64, cur, row0, n, tid, bb);
+  }
+}
+
+// l1.y (the activations a1) and l1.save_z may be NULL (inference); l1.dout == 64.  64-row tiles (128-row ones spill at the 128
+// registers two workgroups per CU leave a wave).
+template <int NIN>
+__global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int64_t n, int n_tiles, const float *__restrict__ x0,
+                                                                            const float *__restrict__ x1, const StreamOut l1,
+                                                                            const StreamOut l2) {
+  constexpr int TR = 64;
+  constexpr int kBuf = TR * OS2 + (NIN == 2 ? TR * 64 : 0);   // [TR][OS2]: X0 image, then z1 / a1, then y; [TR][64]: X1 image
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float *wn = dyn + 2 * kBuf;                      // [kNarrow][64]
+  float *xn = wn + kNarrow * 64;                   // [TR][kNarrowAll]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, half = wave >> 2;
+  f32x4 w1[NIN][4], w2[4];
+#pragma unroll
+  for (int bI = 0; bI < NIN; ++bI) load_wfrag(l1.wt, 64, 64 * bI, 16 * ct + (lane & 15), lane >> 4, w1[bI]);
+  load_wfrag(l2.wt, l2.dout, 0, 16 * ct + (lane & 15), lane >> 4, w2);
+  narrow_weights(l1, 64 * NIN, wn, tid);
+  const int nn = l1.din_all - 64 * NIN;
+  const int oc = 4 * (tid & 15);
+  float *bl = xn + TR * kNarrowAll;                // [2][64]: the two bias vectors (kept out of the registers)
+  if (tid < 128) {
+    const int c = tid & 63;
+    bl[tid] = tid < 64 ? (l1.bias ? l1.bias[c] : 0.f) : ((l2.bias && c < l2.dout) ? l2.bias[c] : 0.f);
+  }
+  auto dma_in = [&](int tile, float *bufp) {
+    dma_tile<TR>(x0, (int64_t)tile * TR, n, bufp, wave, lane);
+    if (NIN == 2) dma_tile<TR>(x1, (int64_t)tile * TR, n, bufp + TR * OS2, wave, lane);
+  };
+  int t = blockIdx.x, it = 0;
+  if (t < n_tiles) dma_in(t, dyn);
+  for (; t < n_tiles; t += gridDim.x, ++it) {
+    const int64_t row0 = (int64_t)t * TR;
+    float *cur = dyn + (it & 1) * kBuf, *nxt = dyn + ((it + 1) & 1) * kBuf;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // narrow features of this tile's rows: thread -> (row tid / 8, feature tid % 8 < 4)
+    const int nr = tid >> 3, nf = tid & 7;
+    const float xv = nf < kNarrow ? narrow_value(l1, 64 * NIN, nf, row0 + nr, n) : 0.f;
+    if (t + (int)gridDim.x < n_tiles) dma_in(t + gridDim.x, nxt);
+    f32x4 acc[TR / 32];
+#pragma unroll
+    for (int rt = 0; rt < TR / 32; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows_regs<TR, true>(cur, half, lane, w1[0], acc);
+    if (NIN == 2) mfma_rows_regs<TR, true>(cur + TR * OS2, half, lane, w1[NIN - 1], acc);
+    if (nf < kNarrow) xn[nr * kNarrowAll + nf] = xv;
+    __syncthreads();
+    stage_cols<TR>(cur, half, ct, lane, acc);
+    __syncthreads();
+    {
+      const float4 bv = *reinterpret_cast<const float4 *>(&bl[oc]);
+      const float b1[4] = {bv.x, bv.y, bv.z, bv.w};
+      stream_epilogue<TR, true>(l1, nn, xn, wn, cur, row0, n, tid, b1);   // z1 -> a1 in place (+ saves)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < TR / 32; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows_regs<TR, false>(cur, half, lane, w2, acc);
+    __syncthreads();
+    stage_cols<TR>(cur, half, ct, lane, acc);
+    __syncthreads();
+    {
+      const float4 bv = *reinterpret_cast<const float4 *>(&bl[64 + oc]);
+      const float b2[4] = {bv.x, bv.y, bv.z, bv.w};
+      stream_epilogue<TR, false>(l2, 0, xn, wn, cur, row0, n, tid, b2);
+    }
+  }
+}
+
 // (oper, part, part_stride: the same split over the output features as in dense_mfma_bwd_input_kernel; oper = dout_all: none)
 __global__ __launch_bounds__(256) void dense_wide_bwd_input_kernel(int64_t n, SegGrad segs, int din, int dout_all,
                                                                    const float *__restrict__ dz,
@@ -817,6 +1065,71 @@ int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, in
   hipLaunchKernelGGL(dense_weight_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nchunk, din, dout, partial,
                      dwt, db);
   NGPDE_LAUNCH_CHECK("dense_weight_reduce_kernel");
+  return NGPDE_OK;
+}
+
+
+// ---- launches of the two-layer streaming forwards ----------------------------------------------------------------------------------
+static int stream_grid(const void *kernel, size_t dyn_lds, int n_tiles) {
+  int dev = 0, cus = 0, per_cu = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kStreamThreads, dyn_lds);
+  return std::min(n_tiles, std::max(cus, 1) * std::max(per_cu, 1));
+}
+// leading blocks of exactly 64 features that LDS-DMA can fetch (row_div 1, 16-byte aligned); the rest must be narrow
+static int stream_main_blocks(const SegTable &t, int din) {
+  int nm = 0;
+  while (nm < t.n && t.width[nm] == 64 && t.row_div[nm] == 1 && t.vec[nm]) ++nm;
+  return (nm >= 1 && din - 64 * nm <= kNarrow) ? nm : 0;
+}
+static bool stream2_enabled(int64_t n) {
+  const char *e = getenv("NGPDE_DENSE_NO_STREAM2");   // read per call: the tests switch it at run time
+  return !(e && e[0] == '1') && (n + BM2 - 1) / BM2 >= 512;
+}
+
+bool dense_pair_fwd_applicable(int64_t n, const SegTable &ta, int dina, int douta, const SegTable &tb, int dinb, int doutb) {
+  return stream2_enabled(n) && douta <= 64 && doutb <= 64 && stream_main_blocks(ta, dina) == 1 && stream_main_blocks(tb, dinb) == 1 &&
+         ta.ptr[0] == tb.ptr[0];
+}
+int32_t launch_dense_pair_fwd(int64_t n, const SegTable &ta, int dina, int douta, int acta, const float *wta, const float *ba, float *ya,
+                              float *za, const SegTable &tb, int dinb, int doutb, int actb, const float *wtb, const float *bb, float *yb,
+                              float *zb, hipStream_t stream) {
+  StreamOut a{ta, dina, douta, acta, wta, ba, ya, za}, b{tb, dinb, doutb, actb, wtb, bb, yb, zb};
+  const int n_tiles = (int)((n + kPairTR - 1) / kPairTR);
+  const size_t lds = ((size_t)2 * kPairTR * OS2 + 2 * kNarrow * 64 + (size_t)kPairTR * kNarrowAll) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_pair_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_pair_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(e));
+  const int grid = stream_grid(reinterpret_cast<const void *>(dense_pair_fwd_kernel), lds, n_tiles);
+  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b);
+  NGPDE_LAUNCH_CHECK("dense_pair_fwd_kernel");
+  return NGPDE_OK;
+}
+
+bool dense_chain_fwd_applicable(int64_t n, const SegTable &t1, int din1, int dmid, int dout2) {
+  const int nm = stream_main_blocks(t1, din1);
+  return stream2_enabled(n) && dmid == 64 && dout2 <= 64 && (nm == 1 || nm == 2);
+}
+int32_t launch_dense_chain_fwd(int64_t n, const SegTable &t1, int din1, int act1, const float *wt1, const float *b1, float *a1, float *z1,
+                               int dout2, int act2, const float *wt2, const float *b2, float *y, float *z2, hipStream_t stream) {
+  SegTable t2;
+  t2.n = 1; t2.width[0] = 64; t2.offset[1] = t2.offset[2] = t2.offset[3] = t2.offset[4] = 64;
+  StreamOut l1{t1, din1, 64, act1, wt1, b1, a1, z1}, l2{t2, 64, dout2, act2, wt2, b2, y, z2};
+  const int nm = stream_main_blocks(t1, din1);
+  const int tr = 64;
+  const int n_tiles = (int)((n + tr - 1) / tr);
+  const size_t lds = ((size_t)2 * (tr * OS2 + (nm == 2 ? tr * 64 : 0)) + kNarrow * 64 + (size_t)tr * kNarrowAll + 128) * sizeof(float);
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int grid = stream_grid(reinterpret_cast<const void *>(kernel), lds, n_tiles);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, t1.ptr[0], nm == 2 ? t1.ptr[1] : nullptr,
+                       l1, l2);
+    return hipSuccess;
+  };
+  const hipError_t le = nm == 2 ? launch(dense_chain_fwd_kernel<2>) : launch(dense_chain_fwd_kernel<1>);
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_chain_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
+  NGPDE_LAUNCH_CHECK("dense_chain_fwd_kernel");
   return NGPDE_OK;
 }
 

@@ -153,6 +153,125 @@ def dense(blocks, wt, bias, act, row_divs=None, n=None):
     return _DenseFn.apply(wt, bias, act, tuple(row_divs), int(n), *blocks)
 
 
+def _check_blocks(blocks, row_divs, n, wt):
+    widths = [b.shape[1] for b in blocks]
+    if wt.shape[0] != sum(widths):
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     f"DimensionMismatch: Dense expects {wt.shape[0]} input features, got {sum(widths)}")
+    for b, rd in zip(blocks, row_divs):
+        if b.shape[0] * rd != n and not (rd > 1 and b.shape[0] * rd >= n):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: block with {b.shape[0]} rows (x{rd}) does not cover {n} rows")
+    return widths
+
+
+def _dense_backward_call(lib, n, blocks, widths, row_divs, dout, act, wt, z, dy, want, has_bias):
+    """one ngpde_dense_backward: returns (dwt, db, [dblock or None])"""
+    dev = wt.device
+    dwt = torch.empty_like(wt)
+    db = torch.empty((dout,), dtype=torch.float32, device=dev) if has_bias else None
+    dblocks = [torch.empty_like(b) if (w and rd == 1) else None for b, w, rd in zip(blocks, want, row_divs)]
+    ws = _ws(lib.ngpde_dense_workspace_bytes(n, sum(widths), dout), dev)
+    _lib.check(lib.ngpde_dense_backward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs),
+                                        dout, act, _lib.ptr(wt), _lib.ptr(z), _lib.ptr(dy), _ptr_array(dblocks),
+                                        _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    return dwt, db, dblocks
+
+
+class _DensePairFn(torch.autograd.Function):
+    """(ya, yb) = (Dense_a(blocks_a), Dense_b(blocks_b)): ngpde_dense_pair_forward -- one pass over a shared leading 64-wide
+    block (the node-level target / source halves of a message MLP's first layer), two launches otherwise."""
+
+    @staticmethod
+    def forward(ctx, wta, ba, acta, rda, wtb, bb, actb, rdb, n, na, *blocks):
+        lib = _lib.load()
+        _need_cuda(wta, ba, wtb, bb, *blocks)
+        blocks = [b.contiguous() for b in blocks]
+        wta, wtb = wta.contiguous(), wtb.contiguous()
+        A, B = blocks[:na], blocks[na:]
+        wa, wb = _check_blocks(A, rda, n, wta), _check_blocks(B, rdb, n, wtb)
+        dev = wta.device
+        ya = torch.empty((n, wta.shape[1]), dtype=torch.float32, device=dev)
+        yb = torch.empty((n, wtb.shape[1]), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        za = torch.empty_like(ya) if (need and acta != 0) else None
+        zb = torch.empty_like(yb) if (need and actb != 0) else None
+        _lib.check(lib.ngpde_dense_pair_forward(
+            n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), wta.shape[1], acta, _lib.ptr(wta), _lib.ptr(ba), _lib.ptr(ya),
+            _lib.ptr(za), len(B), _ptr_array(B), _int_array(wb), _int_array(rdb), wtb.shape[1], actb, _lib.ptr(wtb), _lib.ptr(bb),
+            _lib.ptr(yb), _lib.ptr(zb), _lib.current_stream()))
+        ctx.meta = (acta, tuple(rda), actb, tuple(rdb), n, na, wa, wb, ba is not None, bb is not None)
+        ctx.save_for_backward(wta, wtb, za, zb, *blocks)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        lib = _lib.load()
+        acta, rda, actb, rdb, n, na, wa, wb, has_ba, has_bb = ctx.meta
+        wta, wtb, za, zb, *blocks = ctx.saved_tensors
+        A, B = blocks[:na], blocks[na:]
+        want = ctx.needs_input_grad[10:]
+        dwta, dba, dA = _dense_backward_call(lib, n, A, wa, rda, wta.shape[1], acta, wta, za, dya.contiguous(), want[:na], has_ba)
+        dwtb, dbb, dB = _dense_backward_call(lib, n, B, wb, rdb, wtb.shape[1], actb, wtb, zb, dyb.contiguous(), want[na:], has_bb)
+        return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, *dA, *dB)
+
+
+def dense_pair(blocks_a, wta, ba, acta, blocks_b, wtb, bb, actb, row_divs_a=None, row_divs_b=None, n=None):
+    """Two Dense layers whose block lists start with the same tensor; returns (ya, yb)."""
+    rda = list(row_divs_a) if row_divs_a is not None else [1] * len(blocks_a)
+    rdb = list(row_divs_b) if row_divs_b is not None else [1] * len(blocks_b)
+    if n is None:
+        n = next(b.shape[0] for b, rd in zip(blocks_a, rda) if rd == 1)
+    return _DensePairFn.apply(wta, ba, acta, tuple(rda), wtb, bb, actb, tuple(rdb), int(n), len(blocks_a), *blocks_a, *blocks_b)
+
+
+class _DenseChain2Fn(torch.autograd.Function):
+    """y = act2(act1([X1 | ...] W1t + b1) W2t + b2): ngpde_dense_chain2_forward -- the intermediate stays on chip when the shape
+    allows (inference: nothing but y is written; training keeps z1 / a1 for the two pullbacks)."""
+
+    @staticmethod
+    def forward(ctx, wt1, b1, act1, wt2, b2, act2, row_divs, n, *blocks):
+        lib = _lib.load()
+        _need_cuda(wt1, b1, wt2, b2, *blocks)
+        blocks = [b.contiguous() for b in blocks]
+        wt1, wt2 = wt1.contiguous(), wt2.contiguous()
+        widths = _check_blocks(blocks, row_divs, n, wt1)
+        dmid, dout = wt1.shape[1], wt2.shape[1]
+        if wt2.shape[0] != dmid:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: second Dense expects {wt2.shape[0]} input features, got {dmid}")
+        dev = wt1.device
+        need = any(ctx.needs_input_grad)
+        fused = bool(lib.ngpde_dense_chain2_fused(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs), dmid, dout))
+        y = torch.empty((n, dout), dtype=torch.float32, device=dev)
+        a1 = torch.empty((n, dmid), dtype=torch.float32, device=dev) if (need or not fused) else None
+        z1 = torch.empty((n, dmid), dtype=torch.float32, device=dev) if (need and act1 != 0) else None
+        z2 = torch.empty_like(y) if (need and act2 != 0) else None
+        _lib.check(lib.ngpde_dense_chain2_forward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs), dmid, act1,
+                                                  _lib.ptr(wt1), _lib.ptr(b1), _lib.ptr(a1), _lib.ptr(z1), dout, act2, _lib.ptr(wt2),
+                                                  _lib.ptr(b2), _lib.ptr(y), _lib.ptr(z2), _lib.current_stream()))
+        ctx.meta = (act1, act2, tuple(row_divs), n, widths, dmid, dout, b1 is not None, b2 is not None)
+        ctx.save_for_backward(wt1, wt2, a1, z1, z2, *blocks)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        act1, act2, row_divs, n, widths, dmid, dout, has_b1, has_b2 = ctx.meta
+        wt1, wt2, a1, z1, z2, *blocks = ctx.saved_tensors
+        dwt2, db2, (da1,) = _dense_backward_call(lib, n, [a1], [dmid], [1], dout, act2, wt2, z2, dy.contiguous(), [True], has_b2)
+        dwt1, db1, dblocks = _dense_backward_call(lib, n, blocks, widths, row_divs, dmid, act1, wt1, z1, da1, ctx.needs_input_grad[8:], has_b1)
+        return (dwt1, db1, None, dwt2, db2, None, None, None, *dblocks)
+
+
+def dense_chain2(blocks, wt1, b1, act1, wt2, b2, act2, row_divs=None, n=None):
+    """Chain(Dense, Dense) on a virtual vcat of blocks; returns [n][dout2]."""
+    row_divs = list(row_divs) if row_divs is not None else [1] * len(blocks)
+    if n is None:
+        n = next(b.shape[0] for b, rd in zip(blocks, row_divs) if rd == 1)
+    return _DenseChain2Fn.apply(wt1, b1, act1, wt2, b2, act2, tuple(row_divs), int(n), *blocks)
+
+
 class _EdgePermuteFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, handle, inverse):

@@ -46,6 +46,18 @@ def _tail(stack, a):
     return a
 
 
+def _node_update(stack, blocks, row_divs, n):
+    """a Dense stack (psi / gamma) on a virtual vcat of node-level blocks: the first two layers as one chained call"""
+    l1, p1 = stack[0]
+    wt1, b1 = _wt_b(p1)
+    if len(stack) >= 2:
+        l2, p2 = stack[1]
+        wt2, b2 = _wt_b(p2)
+        y = F.dense_chain2(blocks, wt1, b1, l1.act, wt2, b2, l2.act, row_divs=row_divs, n=n)
+        return _tail(stack[1:], y)
+    return F.dense(blocks, wt1, b1, l1.act, row_divs=row_divs, n=n)
+
+
 def _message_path(g, P, Q, Et, stack, aggr):
     """aggr_e phi(...) given the node-level first-layer terms: ONE fused launch when the message MLP fits the fused
     kernel (widths <= 64, multiples of 4, <= 3 further Dense layers, tiles fit the LDS halo; max/min only without
@@ -141,8 +153,7 @@ class ExplicitEdgeConv(AbstractGNNContainerLayer):
         wt, b = _wt_b(p1)
         dh = sum(hb.shape[1] for hb in hblocks)
         wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; hj...; xj - xi]
-        P = F.dense(hblocks + [pos], _cat_rows([wa, -wc]), b, 0)
-        Q = F.dense(hblocks + [pos], _cat_rows([wb, wc]), None, 0)
+        P, Q = F.dense_pair(hblocks + [pos], _cat_rows([wa, -wc]), b, 0, hblocks + [pos], _cat_rows([wb, wc]), None, 0)
         y = _message_path(g, P, Q, None, stack, self.aggr)                          # propagate(message, g, aggr)  (:111)
         return y.T, st
 
@@ -175,14 +186,11 @@ class VMHConv(AbstractGNNContainerLayer):
         wt, b = _wt_b(p1)
         dh = sum(hb.shape[1] for hb in hblocks)
         wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; (hj - hi)...; xj - xi]  (:316)
-        P = F.dense(hblocks + [pos], _cat_rows([wa - wb, -wc]), b, 0)
-        Q = F.dense(hblocks + [pos], _cat_rows([wb, wc]), None, 0)
+        P, Q = F.dense_pair(hblocks + [pos], _cat_rows([wa - wb, -wc]), b, 0, hblocks + [pos], _cat_rows([wb, wc]), None, 0)
         m = _message_path(g, P, Q, None, stack, self.aggr)                          # :326
         gstack = _dense_stack(self.γ, ps["γ"], "γ")
-        g1, gp1 = gstack[0]
-        gwt, gb = _wt_b(gp1)
-        y = F.dense(list(xn.values()) + [m], gwt, gb, g1.act)                     # γ(vcat(values(x)..., m))  (:328)
-        y = _tail(gstack, y)
+        blocks = list(xn.values()) + [m]
+        y = _node_update(gstack, blocks, [1] * len(blocks), m.shape[0])           # γ(vcat(values(x)..., m))  (:328)
         return y.T, st
 
 
@@ -223,18 +231,15 @@ class MPPDEConv(AbstractGNNContainerLayer):
             tb.append(d); tw.append(wc); trd.append(1)
         if dth:
             tb.append(theta); tw.append(we); trd.append(N // G)                    # θ of the target's graph = the edge's graph
-        P = F.dense(tb, _cat_rows(tw), b, 0, row_divs=trd, n=N)
-        Q = F.dense([h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0)
+        P, Q = F.dense_pair(tb, _cat_rows(tw), b, 0, [h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0,
+                            row_divs_a=trd, n=N)          # one pass over h when the shapes allow
         Et = F.dense([e_p], wd, None, 0) if de else None
         m = _message_path(g, P, Q, Et, stack, self.aggr)                            # :416
         pstack = _dense_stack(self.ψ, ps["ψ"], "ψ")
-        q1, qp1 = pstack[0]
-        qwt, qb = _wt_b(qp1)
         blocks, rd = [h, m], [1, 1]
         if dth:
             blocks.append(theta); rd.append(N // G)
-        y = F.dense(blocks, qwt, qb, q1.act, row_divs=rd, n=N)                     # ψ(vcat(x, m, repeat(θ)))  (:418)
-        y = _tail(pstack, y)
+        y = _node_update(pstack, blocks, rd, N)                                    # ψ(vcat(x, m, repeat(θ)))  (:418)
         return y.T, st
 
 

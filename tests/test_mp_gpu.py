@@ -210,6 +210,101 @@ def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
         o += w
 
 
+@pytest.mark.parametrize("nwa,nwb,douts", [((2, 2), (2,), (64, 64)), ((), (), (64, 48)), ((1, 3, 2), (3,), (40, 64))])
+def test_dense_pair_streaming_forward(nwa, nwb, douts, monkeypatch):
+    # ngpde_dense_pair_forward: two Dense layers from one pass over their shared 64-wide block (dense_pair_fwd_kernel, weights in
+    # registers), against the oracle and the two-launch path (NGPDE_DENSE_NO_STREAM2=1); ragged last tile, a per-graph block
+    from ngpde_amd import functional as F
+    monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2", raising=False)
+    n, per_graph = 70001, 10000
+    rng = np.random.default_rng(71)
+    x = torch.as_tensor(rng.normal(size=(n, 64)), dtype=torch.float32, device=DEV).requires_grad_(True)
+
+    def side(nw, dout, last_per_graph):
+        blocks, divs = [x], [1]
+        for i, w in enumerate(nw):
+            rd = per_graph if (last_per_graph and i == len(nw) - 1) else 1
+            blocks.append(torch.as_tensor(rng.normal(size=((n + rd - 1) // rd, w)), dtype=torch.float32, device=DEV))
+            divs.append(rd)
+        din = 64 + sum(nw)
+        wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+        b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True)
+        return blocks, divs, wt, b
+
+    A, B = side(nwa, douts[0], True), side(nwb, douts[1], False)
+    ya, yb = F.dense_pair(A[0], A[2], A[3], 4, B[0], B[2], None, 0, row_divs_a=A[1], row_divs_b=B[1], n=n)
+    monkeypatch.setenv("NGPDE_DENSE_NO_STREAM2", "1")
+    with torch.no_grad():
+        ya2, yb2 = F.dense_pair(A[0], A[2], A[3], 4, B[0], B[2], None, 0, row_divs_a=A[1], row_divs_b=B[1], n=n)
+    monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2")
+    close(ya, ya2.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    close(yb, yb2.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    outs, caches, layers = [], [], []
+    for (blocks, divs, wt, b), act, bias in ((A, "swish", True), (B, "identity", False)):
+        X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+        layer = [dict(weight=wt.detach().cpu().double().numpy().T, bias=b.detach().cpu().double().numpy() if bias else None, act=act)]
+        yo, cache = O.mlp_forward(layer, X.T)
+        outs.append(yo); caches.append(cache); layers.append(layer)
+    close(ya, outs[0].T)
+    close(yb, outs[1].T)
+    Ra, Rb = rng.normal(size=outs[0].shape), rng.normal(size=outs[1].shape)
+    ((ya * torch.as_tensor(Ra.T, dtype=torch.float32, device=DEV)).sum() + (yb * torch.as_tensor(Rb.T, dtype=torch.float32, device=DEV)).sum()).backward()
+    dxa, gra = O.mlp_backward(layers[0], caches[0], Ra)
+    dxb, grb = O.mlp_backward(layers[1], caches[1], Rb)
+    close(x.grad, (dxa[:64] + dxb[:64]).T)
+    close(A[2].grad, gra[0]["weight"].T, rtol=3e-4)
+    close(B[2].grad, grb[0]["weight"].T, rtol=3e-4)
+    close(A[3].grad, gra[0]["bias"].reshape(-1), rtol=3e-4)
+
+
+@pytest.mark.parametrize("widths,dout,acts", [((64, 64, 2), 64, ("swish", "identity")), ((64,), 64, ("tanh", "relu")),
+                                              ((64, 3), 40, ("swish", "swish")), ((60, 4), 64, ("swish", "identity"))])
+def test_dense_chain2_streaming_forward(widths, dout, acts, monkeypatch):
+    # ngpde_dense_chain2_forward: Chain(Dense(. => 64), Dense(64 => dout)) with the intermediate on chip (dense_chain_fwd_kernel),
+    # inference (nothing saved) and training (z1 / a1 kept, both pullbacks), against the oracle and the two-launch path; the last
+    # case (no 64-wide leading block) takes the two-launch path by itself
+    from ngpde_amd import functional as F
+    monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2", raising=False)
+    n, per_graph = 70001, 10000
+    rng = np.random.default_rng(73)
+    blocks, divs = [], []
+    for i, w in enumerate(widths):
+        rd = per_graph if (len(widths) == 3 and i == 2) else 1
+        blocks.append(torch.as_tensor(rng.normal(size=((n + rd - 1) // rd, w)), dtype=torch.float32, device=DEV).requires_grad_(rd == 1 and w >= 60))
+        divs.append(rd)
+    din = sum(widths)
+    wt1 = torch.as_tensor(rng.normal(size=(din, 64)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+    b1 = torch.as_tensor(rng.normal(size=64), dtype=torch.float32, device=DEV).requires_grad_(True)
+    wt2 = torch.as_tensor(rng.normal(size=(64, dout)) / 8.0, dtype=torch.float32, device=DEV).requires_grad_(True)
+    b2 = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True)
+    a1c, a2c = ng.layers._act_code(acts[0])[1], ng.layers._act_code(acts[1])[1]
+    with torch.no_grad():
+        y_inf = F.dense_chain2(blocks, wt1, b1, a1c, wt2, b2, a2c, row_divs=divs, n=n)
+        monkeypatch.setenv("NGPDE_DENSE_NO_STREAM2", "1")
+        y_two = F.dense_chain2(blocks, wt1, b1, a1c, wt2, b2, a2c, row_divs=divs, n=n)
+        monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2")
+    y = F.dense_chain2(blocks, wt1, b1, a1c, wt2, b2, a2c, row_divs=divs, n=n)
+    assert torch.equal(y.detach(), y_inf)
+    close(y, y_two.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+    layers = [dict(weight=wt1.detach().cpu().double().numpy().T, bias=b1.detach().cpu().double().numpy(), act=acts[0]),
+              dict(weight=wt2.detach().cpu().double().numpy().T, bias=b2.detach().cpu().double().numpy(), act=acts[1])]
+    yo, cache = O.mlp_forward(layers, X.T)
+    close(y, yo.T)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R.T, dtype=torch.float32, device=DEV)).sum().backward()
+    dx, gr = O.mlp_backward(layers, cache, R)
+    close(wt1.grad, gr[0]["weight"].T, rtol=3e-4)
+    close(b1.grad, gr[0]["bias"].reshape(-1), rtol=3e-4)
+    close(wt2.grad, gr[1]["weight"].T, rtol=3e-4)
+    close(b2.grad, gr[1]["bias"].reshape(-1), rtol=3e-4)
+    o = 0
+    for bl, w in zip(blocks, widths):
+        if bl.requires_grad:
+            close(bl.grad, dx[o:o + w].T)
+        o += w
+
+
 # ---- ExplicitEdgeConv ---------------------------------------------------------------------------------------------------
 
 def test_edgeconv_reference_fixture():
