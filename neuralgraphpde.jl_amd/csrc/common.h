@@ -329,5 +329,8 @@ int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, 
 // edge_mlp64.hip: software-pipelined specialisations for the 64-wide two-layer message MLP (BASELINE config 4's shape)
 bool edge_mlp64_fwd_applicable(const ngpde_graph *g, const EdgeMlpArgs &a);
 int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
+bool edge_mlp64_bwd_applicable(const ngpde_graph *g, const EdgeMlpBwdArgs &a);
+size_t edge_mlp64_bwd_workspace(const ngpde_graph *g);
+int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream);
 
 }  // namespace ngpde

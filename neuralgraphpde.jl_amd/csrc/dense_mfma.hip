@@ -607,8 +607,8 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
   for (; t < n_tiles; t += gridDim.x, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * (TR * OS2), *nxt = dyn + ((it + 1) & 1) * (TR * OS2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // this tile's image has landed; the previous tile's second output has left the other buffer
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this tile's image has landed (collected below, a tile ago); the previous tile's outputs have left LDS
     // narrow features of this tile's rows, then the next tile's image
     const int nr = tid >> 3, nf = tid & 7;   // (64 rows x 8 features: one value per thread)
     const float xv = nf < 4 ? narrow_value(a, 64, nf, row0 + nr, n) : narrow_value(b, 64, nf - 4, row0 + nr, n);
@@ -618,6 +618,9 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     for (int rt = 0; rt < TR / 32; ++rt) acca[rt] = accb[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mfma_rows_regs<TR, true>(cur, half, lane, wa, acca);
     mfma_rows_regs<TR, true>(cur, half, lane, wb, accb);
+    // collect the next tile's image HERE, behind the products and before this tile's stores are issued: a wait at the top of the
+    // next tile would also wait for those stores (vmcnt counts them) -- a full store latency per tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();
     stage_cols<TR>(cur, half, ct, lane, acca);
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
   for (; t < n_tiles; t += gridDim.x, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * kBuf, *nxt = dyn + ((it + 1) & 1) * kBuf;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // narrow features of this tile's rows: thread -> (row tid / 8, feature tid % 8 < 4)
     const int nr = tid >> 3, nf = tid & 7;
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
     for (int rt = 0; rt < TR / 32; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mfma_rows_regs<TR, true>(cur, half, lane, w1[0], acc);
     if (NIN == 2) mfma_rows_regs<TR, true>(cur + TR * OS2, half, lane, w1[NIN - 1], acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's images, before this tile's stores (see dense_pair_fwd_kernel)
     if (nf < kNarrow) xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();
     stage_cols<TR>(cur, half, ct, lane, acc);

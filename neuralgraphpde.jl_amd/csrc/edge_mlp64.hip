@@ -426,6 +426,308 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
   }
 }
 
+// ---- pullback of the same message path (edge_mlp_fused_bwd_kernel's algorithm, specialised) -------------------------------------
+// Per 16-edge wave slice, all in registers: z1 = P[t] + Q[s], s1 = sigma(z1) once for a1 = act1(z1) AND act1'(z1); z2^T = W2^T
+// a1^T + b2 (MFMA); dz2 = g[t] . act2'(z2); dW2 += a1^T dz2 (MFMA over the slice's edges, operands transposed through the wave's
+// 4 KB of LDS); da1^T = W2 dz2^T (MFMA); dz1 = da1 . act1'(z1) -> dE (memory, once) and through LDS into the per-target sum dP.
+// What differs from the general kernel: 4 waves per workgroup and 64-edge chunks (a 192-edge tile is three full chunks; the
+// general kernel's 128-edge chunks leave half of its waves idle in every second one), TWO workgroups per CU whose phases drift
+// apart (one's tile loads and reductions under the other's products), the incoming gradient rows read where they are used
+// instead of staged (that is what lets two workgroups fit the LDS), compile-time widths and activations, and one sigmoid per
+// value where activation and derivative both need it.
+struct EdgeMlp64BwdK {
+  const int4 *sched;
+  const int2 *halo;
+  const uint8_t *slots;
+  int n_tiles, halo_rows, aggr;
+  const float *P, *Q, *wt, *bias, *dout;
+  float *dP, *dE, *partial;   // partial: [n_workgroups][65][64]  (row 64 = bias gradient)
+};
+
+// a = act(z), d = act'(z) with the shared transcendental evaluated once (same operations as act_apply / act_deriv)
+template <int ACT>
+__device__ __forceinline__ void act_both(float z, float &a, float &d) {
+  if (ACT == NGPDE_ACT_SWISH) {
+    const float s = sigmoidf_(z);
+    a = z * s;
+    d = s * (1.0f + z * (1.0f - s));
+  } else if (ACT == NGPDE_ACT_TANH) {
+    const float t = tanhf_(z);
+    a = t;
+    d = 1.0f - t * t;
+  } else if (ACT == NGPDE_ACT_RELU) {
+    a = fmaxf(z, 0.0f);
+    d = z > 0.f ? 1.0f : 0.0f;
+  } else {
+    a = z;
+    d = 1.0f;
+  }
+}
+
+template <int ACT1, int ACT2>
+__global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64BwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
+  float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]
+  float *ldsS = ldsP + kRows * kTS;                               // [64][kTS]  wave-private transposes, then dz1 of the chunk
+  float *ldsWf = ldsS + kChunk4 * kTS;                            // [64 out][kTS]  W2^T
+  float *ldsWb = ldsWf + kW * kTS;                                // [64 in][kTS]   W2
+  __shared__ int ldsOff[kRows + 1], ldsRs[kRows], ldsNode[kRows];
+  __shared__ float ldsInv[kRows];
+  __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kRows * 8];
+  __shared__ uint16_t ldsEdge[kRows * kSlotWidth];
+  __shared__ __attribute__((aligned(16))) float ldsBias[kW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g16 = tid >> 4, q = tid & 15;
+  const int ei = lane & 15, kq = lane >> 4;
+  const int zero_slot = p.halo_rows;
+
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const int range_len = p.n_tiles / 8 + (xcd < p.n_tiles % 8 ? 1 : 0);
+  const int range_lo = xcd * (p.n_tiles / 8) + min(xcd, p.n_tiles % 8);
+
+  auto fetch_meta = [&](int tile, Meta64 &m) {
+    const size_t row = (size_t)tile * kTileRows + g16;
+    m.sc0 = p.sched[row];
+    m.sc1 = p.sched[row + 16];
+    m.sw0 = reinterpret_cast<const unsigned *>(p.slots)[row * 8 + (q & 7)];
+    m.sw1 = reinterpret_cast<const unsigned *>(p.slots)[(row + 16) * 8 + (q & 7)];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m.he[k] = p.halo[(size_t)tile * kHaloCap + min(g16 + 16 * k, kHaloCap - 1)].x;
+  };
+
+  {   // W2^T and W2 rows, bias, the all-zero halo row
+    const int j = tid & 63, kg0 = tid >> 6;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int k = 4 * (kg0 + 4 * ps);
+      *reinterpret_cast<float4 *>(&ldsWf[j * kTS + k]) =
+          make_float4(p.wt[(size_t)k * kW + j], p.wt[(size_t)(k + 1) * kW + j], p.wt[(size_t)(k + 2) * kW + j], p.wt[(size_t)(k + 3) * kW + j]);
+      *reinterpret_cast<float4 *>(&ldsWb[j * kTS + k]) = *reinterpret_cast<const float4 *>(p.wt + (size_t)j * kW + k);
+    }
+    if (tid < kW) ldsBias[tid] = p.bias ? p.bias[tid] : 0.f;
+    if (g16 == 0) *reinterpret_cast<float4 *>(&ldsQ[zero_slot * kTS + 4 * q]) = f4_zero();
+  }
+
+  // dW2 accumulators of this wave: tile (ct, mt) <-> rows 16 ct .. + 15 (inputs) x columns 16 mt .. + 15 (outputs)
+  f32x4 accW[4][4];
+  float4 dbacc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    dbacc[a] = f4_zero();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accW[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  Meta64 meta;
+  int jt = wg_in_xcd;
+  if (jt < range_len) fetch_meta(range_lo + jt, meta);
+
+  for (; jt < range_len; jt += wgs_per_xcd) {
+    const int4 sc0 = meta.sc0, sc1 = meta.sc1;
+    {   // stage the tile: P rows and the distinct Q rows (the other workgroup of the CU computes meanwhile)
+      const float4 p0 = *reinterpret_cast<const float4 *>(p.P + (size_t)max(sc0.x, 0) * kW + 4 * q);
+      const float4 p1 = *reinterpret_cast<const float4 *>(p.P + (size_t)max(sc1.x, 0) * kW + 4 * q);
+      float4 hv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        hv[k] = (g16 + 16 * k < p.halo_rows) ? *reinterpret_cast<const float4 *>(p.Q + (size_t)meta.he[k] * kW + 4 * q) : f4_zero();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int hh = g16 + 16 * k;
+        if (hh < p.halo_rows) *reinterpret_cast<float4 *>(&ldsQ[hh * kTS + 4 * q]) = hv[k];
+      }
+      *reinterpret_cast<float4 *>(&ldsP[g16 * kTS + 4 * q]) = p0;
+      *reinterpret_cast<float4 *>(&ldsP[(g16 + 16) * kTS + 4 * q]) = p1;
+    }
+    if (q == 0) {
+      const int d0 = sc0.x >= 0 ? sc0.z : 0, d1 = sc1.x >= 0 ? sc1.z : 0;
+      ldsOff[g16 + 1] = d0;
+      ldsOff[g16 + 17] = d1;
+      ldsRs[g16] = sc0.y;
+      ldsRs[g16 + 16] = sc1.y;
+      ldsNode[g16] = max(sc0.x, 0);
+      ldsNode[g16 + 16] = max(sc1.x, 0);
+      ldsInv[g16] = p.aggr == NGPDE_AGGR_MEAN ? (d0 > 0 ? 1.0f / (float)d0 : 0.f) : 1.0f;
+      ldsInv[g16 + 16] = p.aggr == NGPDE_AGGR_MEAN ? (d1 > 0 ? 1.0f / (float)d1 : 0.f) : 1.0f;
+      if (g16 == 0) ldsOff[0] = 0;
+    }
+    if (q < 8) {
+      ldsSlots[g16 * 8 + q] = meta.sw0;
+      ldsSlots[(g16 + 16) * 8 + q] = meta.sw1;
+    }
+    const int jn = jt + wgs_per_xcd;
+    if (jn < range_len) fetch_meta(range_lo + jn, meta);
+    __syncthreads();
+    if (tid < kRows) {
+      int v = ldsOff[tid + 1];
+#pragma unroll
+      for (int o = 1; o < kRows; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (tid >= o) v += u;
+      }
+      ldsOff[tid + 1] = v;
+    }
+    __syncthreads();
+    const int total = ldsOff[kRows];
+    const int lo0 = ldsOff[g16], hi0 = ldsOff[g16 + 1], lo1 = ldsOff[g16 + 16], hi1 = ldsOff[g16 + 17];
+    for (int k = lo0 + q; k < hi0; k += 16) {
+      const int j = k - lo0;
+      ldsEdge[k] = (uint16_t)(g16 | (((ldsSlots[g16 * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff) << 8));
+    }
+    for (int k = lo1 + q; k < hi1; k += 16) {
+      const int j = k - lo1;
+      ldsEdge[k] = (uint16_t)((g16 + 16) | (((ldsSlots[(g16 + 16) * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff) << 8));
+    }
+    float4 racc0 = f4_zero(), racc1 = f4_zero();
+    __syncthreads();
+
+    for (int c0 = 0; c0 < total; c0 += kChunk4) {
+      const bool wave_on = c0 + wave * kSlice < total;   // wave-uniform
+      const int k = c0 + wave * kSlice + ei;
+      const bool valid = k < total;
+      float *mine = ldsS + (size_t)(wave * kSlice) * kTS;          // this wave's 16 rows of the staging tile
+      float4 dz1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+      if (wave_on) {
+        const unsigned ew = ldsEdge[valid ? k : 0];
+        const int r = ew & 0xff, slot = valid ? (int)(ew >> 8) : zero_slot;
+        const size_t pe = (size_t)(ldsRs[r] + (k - ldsOff[r]));
+        // incoming gradient rows of the edge's target (g = dout / deg for mean): issued now, used behind the first product
+        float4 gz[4];
+        {
+          const float *grow = p.dout + (size_t)ldsNode[r] * kW + 4 * kq;
+          const float inv = valid ? ldsInv[r] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) gz[mt] = f4_scale(inv, *reinterpret_cast<const float4 *>(grow + 16 * mt));
+        }
+        float4 a1[4], d1[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int f = 16 * ct + 4 * kq;
+          const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
+          act_both<ACT1>(z.x, a1[ct].x, d1[ct].x);
+          act_both<ACT1>(z.y, a1[ct].y, d1[ct].y);
+          act_both<ACT1>(z.z, a1[ct].z, d1[ct].z);
+          act_both<ACT1>(z.w, a1[ct].w, d1[ct].w);
+          if (!valid) a1[ct] = f4_zero();
+        }
+        // ---- z2 (transposed product), dz2 = g . act2'(z2)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float *wl = ldsWf + (mt * 16 + ei) * kTS + 4 * kq;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * ct);
+            acc = mfma16(w4.x, a1[ct].x, acc);
+            acc = mfma16(w4.y, a1[ct].y, acc);
+            acc = mfma16(w4.z, a1[ct].z, acc);
+            acc = mfma16(w4.w, a1[ct].w, acc);
+          }
+          const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
+          const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+          gz[mt] = f4_mul(gz[mt], make_float4(dact_c<ACT2>(z2.x), dact_c<ACT2>(z2.y), dact_c<ACT2>(z2.z), dact_c<ACT2>(z2.w)));
+          dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
+        }
+        // ---- dW2 += a1^T dz2 over this wave's 16 edges: both operands transposed through the wave's LDS rows
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * ct + 4 * kq]) = a1[ct];
+        float a1T[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) a1T[ct][sI] = mine[(4 * sI + kq) * kTS + 16 * ct + ei];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * mt + 4 * kq]) = gz[mt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float dzT[4];
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) dzT[sI] = mine[(4 * sI + kq) * kTS + 16 * mt + ei];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) accW[ct][mt] = mfma16(a1T[ct][sI], dzT[sI], accW[ct][mt]);
+        }
+        // ---- da1 (transposed product with W2), dz1 = da1 . act1'(z1)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float *wl = ldsWb + (ct * 16 + ei) * kTS + 4 * kq;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * mt);
+            acc = mfma16(w4.x, gz[mt].x, acc);
+            acc = mfma16(w4.y, gz[mt].y, acc);
+            acc = mfma16(w4.z, gz[mt].z, acc);
+            acc = mfma16(w4.w, gz[mt].w, acc);
+          }
+          dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), d1[ct]);
+          if (valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];
+        }
+      }
+      // ---- dz1 of the chunk -> LDS, lane group g16 sums the rows of targets g16 and g16 + 16 in edge order (= dP)
+      {
+        float *mine2 = ldsS + (size_t)(wave * kSlice) * kTS;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<float4 *>(&mine2[ei * kTS + 16 * ct + 4 * kq]) = dz1[ct];
+      }
+      __syncthreads();
+      {
+        const float *base = ldsS + 4 * q - c0 * kTS;
+        for (int kk = max(lo0, c0); kk < min(hi0, c0 + kChunk4); ++kk) racc0 = f4_add(racc0, *reinterpret_cast<const float4 *>(base + kk * kTS));
+        for (int kk = max(lo1, c0); kk < min(hi1, c0 + kChunk4); ++kk) racc1 = f4_add(racc1, *reinterpret_cast<const float4 *>(base + kk * kTS));
+      }
+      __syncthreads();
+    }
+    if (p.dP) {
+      if (sc0.x >= 0) *reinterpret_cast<float4 *>(p.dP + (size_t)sc0.x * kW + 4 * q) = racc0;
+      if (sc1.x >= 0) *reinterpret_cast<float4 *>(p.dP + (size_t)sc1.x * kW + 4 * q) = racc1;
+    }
+  }
+
+  // ---- fold the waves' dW2 / db2 accumulators into this workgroup's slab, wave by wave (fixed order), then write it out
+  {
+    float *slab = ldsS;                                            // [65][64] <= [64][kTS]
+    __syncthreads();
+    for (int idx = tid; idx < (kW + 1) * kW; idx += kT4) slab[idx] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {   // db: sum the 16 edge lanes of each k-quarter inside the wave first
+      float v[4] = {dbacc[mt].x, dbacc[mt].y, dbacc[mt].z, dbacc[mt].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v[c] += __shfl_xor(v[c], o);
+      }
+      dbacc[mt] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    for (int w = 0; w < kT4 / 64; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(16 * ct + 4 * kq + r) * kW + 16 * mt + ei] += accW[ct][mt][r];
+        if (ei == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int o = 16 * mt + 4 * kq;
+            slab[kW * kW + o] += dbacc[mt].x; slab[kW * kW + o + 1] += dbacc[mt].y;
+            slab[kW * kW + o + 2] += dbacc[mt].z; slab[kW * kW + o + 3] += dbacc[mt].w;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float *dst = p.partial + (size_t)blockIdx.x * (kW + 1) * kW;
+    for (int idx = tid; idx < (kW + 1) * kW; idx += kT4) dst[idx] = slab[idx];
+  }
+}
+
 bool env_off(const char *name) {
   const char *e = std::getenv(name);
   return e && e[0] == '1';
@@ -474,6 +776,52 @@ int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStr
   }
   if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp64_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
   NGPDE_LAUNCH_CHECK("edge_mlp64_fwd_kernel");
+  return NGPDE_OK;
+}
+
+// ---- pullback launch.  Same conditions as the forward specialisation (the activation pairs instantiated below); workspace =
+// one [65][64] slab per workgroup (edge_mlp64_bwd_grid).
+static int edge64_bwd_grid(const ngpde_graph *g) {
+  const int n_tiles = (int)(g->n_sched / kTileRows);
+  return 8 * std::max(1, std::min(64, (n_tiles + 7) / 8));   // two persistent workgroups per CU, a multiple of the 8 XCDs
+}
+bool edge_mlp64_bwd_applicable(const ngpde_graph *g, const EdgeMlpBwdArgs &a) {
+  if (env_off("NGPDE_NO_EDGE64")) return false;
+  if (!a.P || !a.Q || a.Eterm || a.h1 != kW || a.n_tail != 1 || a.dw != kW) return false;
+  if (a.aggr != NGPDE_AGGR_SUM && a.aggr != NGPDE_AGGR_MEAN) return false;
+  const bool a1 = a.act1 == NGPDE_ACT_SWISH || a.act1 == NGPDE_ACT_RELU || a.act1 == NGPDE_ACT_TANH;
+  const bool a2 = a.act2 == a.act1 || a.act2 == NGPDE_ACT_IDENTITY;
+  return a1 && a2;
+}
+size_t edge_mlp64_bwd_workspace(const ngpde_graph *g) { return (size_t)edge64_bwd_grid(g) * (kW + 1) * kW * sizeof(float) + 256; }
+
+int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
+  EdgeMlp64BwdK k;
+  k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
+  k.n_tiles = (int)(g->n_sched / kTileRows); k.aggr = a.aggr;
+  k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
+  k.P = a.P; k.Q = a.Q; k.wt = a.wt; k.bias = a.bias; k.dout = a.dout;
+  k.dP = a.dP; k.dE = a.dE; k.partial = (float *)a.workspace;
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kChunk4 * kTS + 2 * (size_t)kW * kTS) * sizeof(float);
+  const int grid = (lds + 4096 <= 80 * 1024) ? edge64_bwd_grid(g) : std::max(8, edge64_bwd_grid(g) / 2);
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kT4), lds, stream, k);
+    return hipSuccess;
+  };
+  hipError_t le;
+  const bool same = a.act2 == a.act1;
+  switch (a.act1) {
+    case NGPDE_ACT_SWISH: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_SWISH>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_IDENTITY>); break;
+    case NGPDE_ACT_RELU: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_RELU>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_IDENTITY>); break;
+    default: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_TANH>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_IDENTITY>); break;
+  }
+  if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
+  NGPDE_LAUNCH_CHECK("edge_mlp64_bwd_kernel");
+  int32_t st;
+  if ((st = launch_dense_weight_reduce(grid, kW, kW, k.partial, a.dwt, a.dbias, stream))) return st;
+  if (a.dQ && (st = launch_edge_sum_by_source(g, kW, a.dE, a.dQ, stream))) return st;
   return NGPDE_OK;
 }
 

@@ -693,7 +693,8 @@ bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int 
 }
 
 size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw) {
-  return n_tail ? (size_t)edge_bwd_grid(g) * (h1 + 1) * dw * sizeof(float) + 256 : 256;
+  const size_t general = n_tail ? (size_t)edge_bwd_grid(g) * (h1 + 1) * dw * sizeof(float) + 256 : 256;
+  return std::max(general, (h1 == kW && n_tail == 1 && dw == kW) ? edge_mlp64_bwd_workspace(g) : (size_t)0);   // (edge_mlp64.hip)
 }
 
 int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
@@ -705,6 +706,7 @@ int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a,
   NGPDE_REQUIRE(a.workspace && a.workspace_bytes >= need, NGPDE_ERR_WORKSPACE, "fused edge-MLP pullback: workspace too small (%zu < %zu bytes)",
                 a.workspace_bytes, need);
   NGPDE_REQUIRE(a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
+  if (edge_mlp64_bwd_applicable(g, a)) return launch_edge_mlp64_bwd(g, a, stream);
   EdgeMlpBwdK k;
   k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
   k.n_tiles = (int)(g->n_sched / kTileRows); k.h1 = a.h1; k.act1 = a.act1; k.aggr = a.aggr; k.n_tail = a.n_tail;

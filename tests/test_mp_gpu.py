@@ -43,6 +43,13 @@ def leaves(ps, prefix=""):
             yield prefix + k, v
 
 
+def grad_leaves(ps):
+    out = []
+    for v in ps.values():
+        out += grad_leaves(v) if isinstance(v, dict) else [v]
+    return out
+
+
 def prep(ps, seed):
     """device copy with random biases and requires_grad"""
     rng = np.random.default_rng(seed)
@@ -1002,8 +1009,35 @@ def test_pipelined_message_kernel_64_equals_general_kernel(acts, aggr, monkeypat
         monkeypatch.delenv("NGPDE_NO_EDGE64")
     assert torch.equal(y64, y64b)
     assert torch.equal(y64, ygen)
-    yo, _ = O.explicit_edge_conv(x.cpu().double().numpy(), omlp(phi, ps), og, aggr)
+    yo, c = O.explicit_edge_conv(x.cpu().double().numpy(), omlp(phi, ps), og, aggr)
     close(y64, yo)
+    # the pullback (edge_mlp64_bwd_kernel: 64-edge chunks, two workgroups per CU) against the oracle and the general kernel
+    R = rng.normal(size=yo.shape)
+    Rt = torch.as_tensor(R, dtype=torch.float32, device=DEV)
+    grads = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("NGPDE_NO_EDGE64", "1")
+        leaves = [v for v in grad_leaves(ps)]
+        for v in leaves:
+            v.grad = None
+        xg = x.clone().requires_grad_(True)
+        yg, _ = l(xg, ps, st)
+        (yg * Rt).sum().backward()
+        grads.append((xg.grad.clone(), [v.grad.clone() for v in leaves]))
+        if general:
+            monkeypatch.delenv("NGPDE_NO_EDGE64")
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    xg = x.clone().requires_grad_(True)
+    for v in grad_leaves(ps):
+        v.grad = None
+    yg, _ = l(xg, ps, st)
+    (yg * Rt).sum().backward()
+    check_grads(ps, (names, ogr), xg, gr["x"])
+    close(grads[0][0], grads[1][0].cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    for a, b in zip(grads[0][1], grads[1][1]):
+        close(a, b.cpu().double().numpy(), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("phi_widths", [(8,), (12, 8)])
