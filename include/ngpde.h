@@ -197,6 +197,19 @@ int32_t ngpde_dense_pair_forward(int64_t n, int32_t n_seg_a, const float *const 
                                  float *y_a, float *save_z_a, int32_t n_seg_b, const float *const *seg_ptr_b,
                                  const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout_b, int32_t act_b,
                                  const float *weight_b, const float *bias_b, float *y_b, float *save_z_b, ngpde_stream_t stream);
+/* Pullback of such a pair when neither layer has an activation of its own (the first-layer halves of a message MLP: the
+ * activation is applied per edge) and dout = 64: dx = dy_a Wa^T + dy_b Wb^T [+ dx_addend] for the shared leading block (one
+ * array, already summed; dx_addend nullable, may alias dx), both weight / bias gradients; other blocks get no gradient.
+ * ngpde_dense_pair_backward_workspace_bytes returns 0 for shapes that need two ngpde_dense_backward calls instead. */
+size_t ngpde_dense_pair_backward_workspace_bytes(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                                 const int32_t *seg_row_div_a, int32_t n_seg_b, const float *const *seg_ptr_b,
+                                                 const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout);
+int32_t ngpde_dense_pair_backward(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                  const int32_t *seg_row_div_a, const float *weight_a, const float *dy_a, float *dweight_a,
+                                  float *dbias_a, int32_t n_seg_b, const float *const *seg_ptr_b, const int32_t *seg_width_b,
+                                  const int32_t *seg_row_div_b, const float *weight_b, const float *dy_b, float *dweight_b,
+                                  float *dbias_b, int32_t dout, float *dx, const float *dx_addend, void *workspace,
+                                  size_t workspace_bytes, ngpde_stream_t stream);
 /* Chain(Dense(. => dmid, act1), Dense(dmid => dout, act2)) on a virtual vcat -- the node update psi / gamma of MPPDEConv /
  * VMHConv (src/layers.jl:418, :328).  a1 (the first layer's activations, [n][dmid]) and the save_* arrays are nullable when
  * ngpde_dense_chain2_fused(...) == 1: the intermediate then stays on chip (one launch); otherwise a1 is required. */

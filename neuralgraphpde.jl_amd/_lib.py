@@ -65,6 +65,9 @@ SIGNATURES = {
     "ngpde_dense_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_dense_pair_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_pair_backward_workspace_bytes": (_sz, [_i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
+    "ngpde_dense_pair_backward": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                         _vp, _vp, _vp, _sz, _vp]),
     "ngpde_dense_chain2_fused": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32]),
     "ngpde_dense_chain2_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_dense_workspace_bytes": (_sz, [_i64, _i32, _i32]),

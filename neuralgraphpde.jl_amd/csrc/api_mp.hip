@@ -110,6 +110,40 @@ int32_t ngpde_dense_chain2_forward(int64_t n, int32_t n_seg, const float *const 
   return launch_dense_seg_fwd(n, t2, din2, dout, act2, weight2, bias2, y, save_z2, (hipStream_t)stream);
 }
 
+size_t ngpde_dense_pair_backward_workspace_bytes(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                                 const int32_t *seg_row_div_a, int32_t n_seg_b, const float *const *seg_ptr_b,
+                                                 const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout) {
+  SegTable ta, tb;
+  int dina = 0, dinb = 0;
+  if (make_segs("ngpde_dense_pair_backward", n_seg_a, seg_ptr_a, seg_width_a, seg_row_div_a, ta, &dina) ||
+      make_segs("ngpde_dense_pair_backward", n_seg_b, seg_ptr_b, seg_width_b, seg_row_div_b, tb, &dinb) || dout != 64)
+    return 0;
+  const int grid = dense_pair_bwd_grid(n, ta, dina, tb, dinb);
+  return grid ? dense_pair_bwd_workspace(grid, dina, dinb) : 0;
+}
+
+int32_t ngpde_dense_pair_backward(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
+                                  const int32_t *seg_row_div_a, const float *weight_a, const float *dy_a, float *dweight_a,
+                                  float *dbias_a, int32_t n_seg_b, const float *const *seg_ptr_b, const int32_t *seg_width_b,
+                                  const int32_t *seg_row_div_b, const float *weight_b, const float *dy_b, float *dweight_b,
+                                  float *dbias_b, int32_t dout, float *dx, const float *dx_addend, void *workspace,
+                                  size_t workspace_bytes, ngpde_stream_t stream) {
+  SegTable ta, tb;
+  int dina = 0, dinb = 0;
+  int32_t st = make_segs("ngpde_dense_pair_backward", n_seg_a, seg_ptr_a, seg_width_a, seg_row_div_a, ta, &dina);
+  if (st || (st = make_segs("ngpde_dense_pair_backward", n_seg_b, seg_ptr_b, seg_width_b, seg_row_div_b, tb, &dinb))) return st;
+  const int grid = (dout == 64 && n > 0) ? dense_pair_bwd_grid(n, ta, dina, tb, dinb) : 0;
+  NGPDE_REQUIRE(grid > 0, NGPDE_ERR_UNSUPPORTED,
+                "ngpde_dense_pair_backward: needs 64 outputs, a shared 16-byte aligned 64-wide leading block, <= 4 narrow features per "
+                "side and >= 32768 rows (ngpde_dense_pair_backward_workspace_bytes returns 0 otherwise): use two ngpde_dense_backward calls");
+  NGPDE_REQUIRE(weight_a && weight_b && dy_a && dy_b && dweight_a && dweight_b && dx, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_dense_pair_backward: NULL argument");
+  NGPDE_REQUIRE(workspace && workspace_bytes >= dense_pair_bwd_workspace(grid, dina, dinb), NGPDE_ERR_WORKSPACE,
+                "ngpde_dense_pair_backward: workspace too small");
+  return launch_dense_pair_bwd(n, ta, dina, weight_a, dy_a, dweight_a, dbias_a, tb, dinb, weight_b, dy_b, dweight_b, dbias_b, dx, dx_addend,
+                               workspace, grid, (hipStream_t)stream);
+}
+
 size_t ngpde_dense_workspace_bytes(int64_t n, int32_t din_total, int32_t dout) {
   return align256((size_t)std::max<int64_t>(n, 1) * dout * 4) +
          align256((size_t)dense_weight_chunks(n, din_total, dout) * (din_total + 1) * dout * 4) +

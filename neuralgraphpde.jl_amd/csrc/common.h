@@ -247,6 +247,11 @@ int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int 
 int dense_weight_chunks(int64_t n, int din, int dout);
 // dense_stream_bwd.hip: the whole Dense pullback (dz, input and weight pullbacks, bias) as one streaming launch; grid 0 = not applicable
 int dense_stream_bwd_grid(int64_t n, const SegTable &t, int din, int dout, float *const *dseg);
+int dense_pair_bwd_grid(int64_t n, const SegTable &ta, int dina, const SegTable &tb, int dinb);
+size_t dense_pair_bwd_workspace(int grid, int dina, int dinb);
+int32_t launch_dense_pair_bwd(int64_t n, const SegTable &ta, int dina, const float *wta, const float *dya, float *dwta, float *dba,
+                              const SegTable &tb, int dinb, const float *wtb, const float *dyb, float *dwtb, float *dbb, float *dx,
+                              const float *dx_add, void *workspace, int grid, hipStream_t stream);
 int32_t launch_dense_stream_bwd(int64_t n, const SegTable &t, int din, int act, const float *wt, const float *z, const float *dy,
                                 float *const *dseg, float *dwt, float *dbias, float *slabs, int grid, hipStream_t stream);
 int dense_bwd_input_splits(int64_t n, int din, int dout);

@@ -210,6 +210,184 @@ __global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseB
   }
 }
 
+// ---- the pullbacks of TWO Dense layers that share their 64-wide leading block (ngpde_dense_pair_forward's pair: the target and
+// source halves P, Q of a message MLP's first layer; no activation of their own -- it is applied per edge) in one launch:
+//   dX = dy_a Wa^T + dy_b Wb^T [+ addend],   dWa = [X | narrow_a]^T dy_a,   dWb = [X | narrow_b]^T dy_b,   db_a, db_b
+// X is read once and its gradient written once, already summed (the composed path: two launches, two gradient arrays, an add).
+// Same tiles, swizzle and slabs as dense_stream64_bwd_kernel; the wave that owns input features 16 w .. + 15 for the weight
+// products also owns those COLUMNS of dX, with its 16 rows of Wa and Wb in registers (no weight copy in LDS).
+struct DensePairBwdK {
+  int64_t n;
+  int n_tiles;
+  const float *x, *dx_add;
+  float *dx;
+  int din[2], main_off[2], n_narrow[2];
+  const float *wt[2], *dy[2];
+  const float *nx[2][kMaxNarrow];
+  int nwidth[2][kMaxNarrow], ndiv[2][kMaxNarrow], nfeat[2][kMaxNarrow];
+  float *partial[2];   // [gridDim.x][din_s + 1][64]
+};
+
+__global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePairBwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *ldsDz0 = lds, *ldsDz1 = lds + kTR * kD;   // [64][64] each, swizzled
+  float *ldsX = ldsDz1 + kTR * kD;                 // [64][64] swizzled DMA image of X, later [64][68] dX on its way out
+  float *ldsN = ldsX + kTR * kPS;                  // [2][64][16]: per side the narrow features (columns 0..3), a column of ones
+                                                   // (4: the bias gradient), zeros -- a 16-wide "input block" for the matrix pipe
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int rg = tid >> 4, qc = tid & 15;
+
+  f32x4 wf[2][4];   // W_s[main_off_s + 16 wave + i][16 kh + 4 kq .. + 3]
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const float4 w4 = *reinterpret_cast<const float4 *>(p.wt[sd] + (size_t)(p.main_off[sd] + 16 * wave + i) * kD + 16 * kh + 4 * kq);
+      wf[sd][kh] = (f32x4){w4.x, w4.y, w4.z, w4.w};
+    }
+  for (int idx = tid; idx < 2 * kTR * 16; idx += kBT) ldsN[idx] = ((idx & 15) == 4) ? 1.0f : 0.f;
+  f32x4 accW[2][4], accN[2];
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    accN[sd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) accW[sd][ob] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // prefetch roles: dy rows (rg + 16 pp, columns 4 qc ..) of both sides; narrow values: thread -> (side, row, feature pair)
+  const int nsd = tid >> 7, nrow = (tid >> 1) & 63, nf = 2 * (tid & 1);
+  float4 dyr[2][4];
+  float nv0 = 0.f, nv1 = 0.f;
+  auto fetch = [&](int tile) {
+    const uint32_t row0 = (uint32_t)tile * kTR;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const uint32_t r = row0 + rg + 16 * pp;
+      const uint32_t e = min(r, (uint32_t)(p.n - 1)) * kD + 4 * qc;
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd) {
+        dyr[sd][pp] = *reinterpret_cast<const float4 *>(p.dy[sd] + e);
+        if (r >= (uint32_t)p.n) dyr[sd][pp] = f4_zero();   // rows past the end contribute nothing
+      }
+    }
+    const uint32_t rc = min(row0 + nrow, (uint32_t)(p.n - 1));
+    const float *b0 = nsd ? (nf ? p.nx[1][2] : p.nx[1][0]) : (nf ? p.nx[0][2] : p.nx[0][0]);
+    const float *b1 = nsd ? (nf ? p.nx[1][3] : p.nx[1][1]) : (nf ? p.nx[0][3] : p.nx[0][1]);
+    const int w0 = nsd ? (nf ? p.nwidth[1][2] : p.nwidth[1][0]) : (nf ? p.nwidth[0][2] : p.nwidth[0][0]);
+    const int w1 = nsd ? (nf ? p.nwidth[1][3] : p.nwidth[1][1]) : (nf ? p.nwidth[0][3] : p.nwidth[0][1]);
+    const int d0 = nsd ? (nf ? p.ndiv[1][2] : p.ndiv[1][0]) : (nf ? p.ndiv[0][2] : p.ndiv[0][0]);
+    const int d1 = nsd ? (nf ? p.ndiv[1][3] : p.ndiv[1][1]) : (nf ? p.ndiv[0][3] : p.ndiv[0][1]);
+    nv0 = b0[(rc / (uint32_t)d0) * (uint32_t)w0];   // (unused slots alias X: their dW rows are never written)
+    nv1 = b1[(rc / (uint32_t)d1) * (uint32_t)w1];
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.n_tiles) fetch(tile);
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * kTR;
+    int opaque0;   // see dense_stream64_bwd_kernel
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+    __syncthreads();
+    {   // X tile by LDS-DMA
+      const int rl = lane >> 4, s16 = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + rl;
+        const uint32_t gr = min((uint32_t)row0 + r, (uint32_t)(p.n - 1));
+        const float *g = p.x + (gr * kD + 4 * (s16 ^ swz(r)));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsX) + ((wave * 4 + j) * 4) * 16 + lane),
+                                         16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int r = rg + 16 * pp;
+      *reinterpret_cast<float4 *>(&ldsDz0[r * kD + 4 * (qc ^ swz(r))]) = dyr[0][pp];
+      *reinterpret_cast<float4 *>(&ldsDz1[r * kD + 4 * (qc ^ swz(r))]) = dyr[1][pp];
+    }
+    *reinterpret_cast<float2 *>(&ldsN[(nsd * kTR + nrow) * 16 + nf]) = make_float2(nv0, nv1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tnext = tile + gridDim.x;
+    if (tnext < p.n_tiles) fetch(tnext);
+
+    // ---- dW_s += X^T dy_s: this wave's 16 input features x 64 outputs, both sides from one read of X; the narrow block
+    // (features + ones) x this wave's 16 outputs
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int r = 4 * s + kq + opaque0;
+      const float av = ldsX[sw_addr(r, 16 * wave + i)];
+      float d0[4], d1[4];
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        d0[ob] = ldsDz0[sw_addr(r, 16 * ob + i)];
+        d1[ob] = ldsDz1[sw_addr(r, 16 * ob + i)];
+      }
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        accW[0][ob] = mfma16(av, d0[ob], accW[0][ob]);
+        accW[1][ob] = mfma16(av, d1[ob], accW[1][ob]);
+      }
+      accN[0] = mfma16(ldsN[r * 16 + i], ldsDz0[sw_addr(r, 16 * wave + i)], accN[0]);
+      accN[1] = mfma16(ldsN[(kTR + r) * 16 + i], ldsDz1[sw_addr(r, 16 * wave + i)], accN[1]);
+    }
+    // ---- dX[:, 16 w .. + 15] = dy_a Wa^T + dy_b Wb^T: all 64 rows, this wave's 16 columns, weights from registers
+    f32x4 accX[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      accX[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int r = 16 * rt + i + opaque0;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(&ldsDz0[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
+        const float4 a1 = *reinterpret_cast<const float4 *>(&ldsDz1[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
+        accX[rt] = mfma16(a0.x, wf[0][kh][0], accX[rt]);
+        accX[rt] = mfma16(a0.y, wf[0][kh][1], accX[rt]);
+        accX[rt] = mfma16(a0.z, wf[0][kh][2], accX[rt]);
+        accX[rt] = mfma16(a0.w, wf[0][kh][3], accX[rt]);
+        accX[rt] = mfma16(a1.x, wf[1][kh][0], accX[rt]);
+        accX[rt] = mfma16(a1.y, wf[1][kh][1], accX[rt]);
+        accX[rt] = mfma16(a1.z, wf[1][kh][2], accX[rt]);
+        accX[rt] = mfma16(a1.w, wf[1][kh][3], accX[rt]);
+      }
+    }
+    __syncthreads();   // every wave is done with the X image
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) ldsX[(16 * rt + 4 * kq + reg) * kPS + 16 * wave + i] = accX[rt][reg];
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int r = rg + 16 * pp;
+      if (row0 + r < p.n) {
+        float4 v = *reinterpret_cast<const float4 *>(&ldsX[r * kPS + 4 * qc]);
+        if (p.dx_add) v = f4_add(v, *reinterpret_cast<const float4 *>(p.dx_add + (row0 + r) * kD + 4 * qc));
+        *reinterpret_cast<float4 *>(p.dx + (row0 + r) * kD + 4 * qc) = v;
+      }
+    }
+  }
+
+  // ---- slabs of both sides: the accumulators directly (row 4 of the narrow block = the bias gradient)
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    float *slab = p.partial[sd] + (size_t)blockIdx.x * (p.din[sd] + 1) * kD;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) slab[(size_t)(p.main_off[sd] + 16 * wave + 4 * kq + reg) * kD + 16 * ob + i] = accW[sd][ob][reg];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int f = 4 * kq + reg;
+      if (f < p.n_narrow[sd]) slab[(size_t)p.nfeat[sd][f < kMaxNarrow ? f : 0] * kD + 16 * wave + i] = accN[sd][reg];
+      else if (f == 4) slab[(size_t)p.din[sd] * kD + 16 * wave + i] = accN[sd][reg];
+    }
+  }
+}
+
 bool env_on(const char *name) {
   const char *e = std::getenv(name);
   return e && e[0] == '1';
@@ -272,6 +450,51 @@ int32_t launch_dense_stream_bwd(int64_t n, const SegTable &t, int din, int act, 
   if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_stream64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
   NGPDE_LAUNCH_CHECK("dense_stream64_bwd_kernel");
   return launch_dense_weight_reduce(grid, din, kD, slabs, dwt, dbias, stream);
+}
+
+// ---- the pair pullback: both sides one 64-wide leading block at the SAME address + narrow blocks, 64 outputs, no activation
+static bool pair_side_ok(const SegTable &t, int din) {
+  if (t.n < 1 || t.width[0] != kD || t.row_div[0] != 1 || (reinterpret_cast<uintptr_t>(t.ptr[0]) & 15)) return false;
+  return din - kD <= kMaxNarrow;
+}
+int dense_pair_bwd_grid(int64_t n, const SegTable &ta, int dina, const SegTable &tb, int dinb) {
+  if (env_on("NGPDE_DENSE_NO_STREAM_BWD") || n < 32768 || n > (1 << 24)) return 0;
+  if (!pair_side_ok(ta, dina) || !pair_side_ok(tb, dinb) || ta.ptr[0] != tb.ptr[0]) return 0;
+  return std::min((int)((n + kTR - 1) / kTR), 256 * 2);
+}
+size_t dense_pair_bwd_workspace(int grid, int dina, int dinb) { return (size_t)grid * (dina + dinb + 2) * kD * sizeof(float) + 512; }
+
+int32_t launch_dense_pair_bwd(int64_t n, const SegTable &ta, int dina, const float *wta, const float *dya, float *dwta, float *dba,
+                              const SegTable &tb, int dinb, const float *wtb, const float *dyb, float *dwtb, float *dbb, float *dx,
+                              const float *dx_add, void *workspace, int grid, hipStream_t stream) {
+  DensePairBwdK k{};
+  k.n = n; k.n_tiles = (int)((n + kTR - 1) / kTR); k.x = ta.ptr[0]; k.dx = dx; k.dx_add = dx_add;
+  const SegTable *ts[2] = {&ta, &tb};
+  const int dins[2] = {dina, dinb};
+  const float *wts[2] = {wta, wtb}, *dys[2] = {dya, dyb};
+  float *slabs = (float *)workspace;
+  for (int sd = 0; sd < 2; ++sd) {
+    const SegTable &t = *ts[sd];
+    k.din[sd] = dins[sd]; k.main_off[sd] = t.offset[0]; k.wt[sd] = wts[sd]; k.dy[sd] = dys[sd];
+    k.partial[sd] = slabs;
+    slabs += (size_t)grid * (dins[sd] + 1) * kD;
+    int nn = 0;
+    for (int b = 1; b < t.n; ++b)
+      for (int c = 0; c < t.width[b]; ++c) {
+        k.nx[sd][nn] = t.ptr[b] + c; k.nwidth[sd][nn] = t.width[b]; k.ndiv[sd][nn] = t.row_div[b]; k.nfeat[sd][nn] = t.offset[b] + c;
+        ++nn;
+      }
+    k.n_narrow[sd] = nn;
+    for (int f = nn; f < kMaxNarrow; ++f) { k.nx[sd][f] = k.x; k.nwidth[sd][f] = kD; k.ndiv[sd][f] = 1; k.nfeat[sd][f] = 0; }
+  }
+  const size_t lds = ((size_t)2 * kTR * kD + (size_t)kTR * kPS + (size_t)2 * kTR * 16) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_pair64_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_pair64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(dense_pair64_bwd_kernel, dim3(grid), dim3(kBT), lds, stream, k);
+  NGPDE_LAUNCH_CHECK("dense_pair64_bwd_kernel");
+  int32_t st;
+  if ((st = launch_dense_weight_reduce(grid, dina, kD, k.partial[0], dwta, dba, stream))) return st;
+  return launch_dense_weight_reduce(grid, dinb, kD, k.partial[1], dwtb, dbb, stream);
 }
 
 }  // namespace ngpde

@@ -179,13 +179,17 @@ def _dense_backward_call(lib, n, blocks, widths, row_divs, dout, act, wt, z, dy,
 
 
 class _DensePairFn(torch.autograd.Function):
-    """(ya, yb) = (Dense_a(blocks_a), Dense_b(blocks_b)): ngpde_dense_pair_forward -- one pass over a shared leading 64-wide
-    block (the node-level target / source halves of a message MLP's first layer), two launches otherwise."""
+    """(ya, yb[, x]) = (Dense_a(blocks_a), Dense_b(blocks_b)[, blocks_a[0]]): ngpde_dense_pair_forward -- one pass over a shared
+    leading 64-wide block (the node-level target / source halves of a message MLP's first layer), two launches otherwise.
+    passthrough: the shared block comes back as a third output; a consumer that reads it through that output (the node update
+    psi of MPPDEConv) delivers its gradient HERE, where ngpde_dense_pair_backward adds it while it writes the block's gradient --
+    no separate accumulation pass over the [N][64] arrays."""
 
     @staticmethod
-    def forward(ctx, wta, ba, acta, rda, wtb, bb, actb, rdb, n, na, *blocks):
+    def forward(ctx, wta, ba, acta, rda, wtb, bb, actb, rdb, n, na, passthrough, *blocks):
         lib = _lib.load()
         _need_cuda(wta, ba, wtb, bb, *blocks)
+        x_in = blocks[0]
         blocks = [b.contiguous() for b in blocks]
         wta, wtb = wta.contiguous(), wtb.contiguous()
         A, B = blocks[:na], blocks[na:]
@@ -200,29 +204,69 @@ class _DensePairFn(torch.autograd.Function):
             n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), wta.shape[1], acta, _lib.ptr(wta), _lib.ptr(ba), _lib.ptr(ya),
             _lib.ptr(za), len(B), _ptr_array(B), _int_array(wb), _int_array(rdb), wtb.shape[1], actb, _lib.ptr(wtb), _lib.ptr(bb),
             _lib.ptr(yb), _lib.ptr(zb), _lib.current_stream()))
-        ctx.meta = (acta, tuple(rda), actb, tuple(rdb), n, na, wa, wb, ba is not None, bb is not None)
+        ctx.meta = (acta, tuple(rda), actb, tuple(rdb), n, na, wa, wb, ba is not None, bb is not None, passthrough)
+        ctx.set_materialize_grads(False)   # an unused pass-through output must not cost a zero array and an addend read
         ctx.save_for_backward(wta, wtb, za, zb, *blocks)
+        if passthrough:
+            return ya, yb, x_in.view_as(x_in)
         return ya, yb
 
     @staticmethod
-    def backward(ctx, dya, dyb):
+    def backward(ctx, dya, dyb, dxp=None):
         lib = _lib.load()
-        acta, rda, actb, rdb, n, na, wa, wb, has_ba, has_bb = ctx.meta
+        acta, rda, actb, rdb, n, na, wa, wb, has_ba, has_bb, passthrough = ctx.meta
         wta, wtb, za, zb, *blocks = ctx.saved_tensors
         A, B = blocks[:na], blocks[na:]
-        want = ctx.needs_input_grad[10:]
-        dwta, dba, dA = _dense_backward_call(lib, n, A, wa, rda, wta.shape[1], acta, wta, za, dya.contiguous(), want[:na], has_ba)
-        dwtb, dbb, dB = _dense_backward_call(lib, n, B, wb, rdb, wtb.shape[1], actb, wtb, zb, dyb.contiguous(), want[na:], has_bb)
-        return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, *dA, *dB)
+        want = ctx.needs_input_grad[11:]
+        dev = wta.device
+        if dya is None:
+            dya = torch.zeros((n, wta.shape[1]), dtype=torch.float32, device=dev)
+        if dyb is None:
+            dyb = torch.zeros((n, wtb.shape[1]), dtype=torch.float32, device=dev)
+        dya, dyb = dya.contiguous(), dyb.contiguous()
+        if dxp is not None:
+            dxp = dxp.contiguous()
+        # one launch for both pullbacks when the pair shares its 64-wide leading block and only that block wants a gradient:
+        # dx arrives already summed, the pass-through consumer's gradient included (ngpde_dense_pair_backward)
+        shared = (acta == 0 and actb == 0 and wta.shape[1] == 64 and wtb.shape[1] == 64 and A[0].data_ptr() == B[0].data_ptr()
+                  and (want[0] or want[na]) and not any(w and rd == 1 for w, rd in zip(want[1:na], rda[1:]))
+                  and not any(w and rd == 1 for w, rd in zip(want[na + 1:], rdb[1:])))
+        if shared:
+            wsb = int(lib.ngpde_dense_pair_backward_workspace_bytes(n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), len(B),
+                                                                    _ptr_array(B), _int_array(wb), _int_array(rdb), 64))
+            if wsb > 0:
+                dwta, dwtb = torch.empty_like(wta), torch.empty_like(wtb)
+                dba = torch.empty((64,), dtype=torch.float32, device=dev) if has_ba else None
+                dbb = torch.empty((64,), dtype=torch.float32, device=dev) if has_bb else None
+                dx = torch.empty_like(A[0])
+                ws = _ws(wsb, dev)
+                _lib.check(lib.ngpde_dense_pair_backward(
+                    n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), _lib.ptr(wta), _lib.ptr(dya), _lib.ptr(dwta), _lib.ptr(dba),
+                    len(B), _ptr_array(B), _int_array(wb), _int_array(rdb), _lib.ptr(wtb), _lib.ptr(dyb), _lib.ptr(dwtb), _lib.ptr(dbb),
+                    64, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+                dA, dB = [None] * len(A), [None] * len(B)
+                if want[0]:
+                    dA[0] = dx
+                else:
+                    dB[0] = dx
+                return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, None, *dA, *dB)
+        dwta, dba, dA = _dense_backward_call(lib, n, A, wa, rda, wta.shape[1], acta, wta, za, dya, want[:na], has_ba)
+        dwtb, dbb, dB = _dense_backward_call(lib, n, B, wb, rdb, wtb.shape[1], actb, wtb, zb, dyb, want[na:], has_bb)
+        if dxp is not None and want[0]:
+            dA[0] = dxp if dA[0] is None else dA[0] + dxp
+        return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, None, *dA, *dB)
 
 
-def dense_pair(blocks_a, wta, ba, acta, blocks_b, wtb, bb, actb, row_divs_a=None, row_divs_b=None, n=None):
-    """Two Dense layers whose block lists start with the same tensor; returns (ya, yb)."""
+def dense_pair(blocks_a, wta, ba, acta, blocks_b, wtb, bb, actb, row_divs_a=None, row_divs_b=None, n=None, passthrough=False):
+    """Two Dense layers whose block lists start with the same tensor; returns (ya, yb), with passthrough=True (ya, yb, x) where x
+    is blocks_a[0] routed through this node (use it for further consumers of the block: their gradient is then folded into the
+    block's gradient by the pair's own pullback launch)."""
     rda = list(row_divs_a) if row_divs_a is not None else [1] * len(blocks_a)
     rdb = list(row_divs_b) if row_divs_b is not None else [1] * len(blocks_b)
     if n is None:
         n = next(b.shape[0] for b, rd in zip(blocks_a, rda) if rd == 1)
-    return _DensePairFn.apply(wta, ba, acta, tuple(rda), wtb, bb, actb, tuple(rdb), int(n), len(blocks_a), *blocks_a, *blocks_b)
+    return _DensePairFn.apply(wta, ba, acta, tuple(rda), wtb, bb, actb, tuple(rdb), int(n), len(blocks_a), bool(passthrough),
+                              *blocks_a, *blocks_b)
 
 
 class _DenseChain2Fn(torch.autograd.Function):

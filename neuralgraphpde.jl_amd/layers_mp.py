@@ -231,8 +231,10 @@ class MPPDEConv(AbstractGNNContainerLayer):
             tb.append(d); tw.append(wc); trd.append(1)
         if dth:
             tb.append(theta); tw.append(we); trd.append(N // G)                    # θ of the target's graph = the edge's graph
-        P, Q = F.dense_pair(tb, _cat_rows(tw), b, 0, [h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0,
-                            row_divs_a=trd, n=N)          # one pass over h when the shapes allow
+        # one pass over h when the shapes allow; h comes back routed through the pair so that psi's gradient w.r.t. h is added
+        # inside the pair's pullback launch
+        P, Q, h = F.dense_pair(tb, _cat_rows(tw), b, 0, [h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0,
+                               row_divs_a=trd, n=N, passthrough=True)
         Et = F.dense([e_p], wd, None, 0) if de else None
         m = _message_path(g, P, Q, Et, stack, self.aggr)                            # :416
         pstack = _dense_stack(self.ψ, ps["ψ"], "ψ")

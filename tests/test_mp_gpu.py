@@ -217,6 +217,56 @@ def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
         o += w
 
 
+@pytest.mark.parametrize("nwa,nwb", [((2, 2), (2,)), ((), ()), ((1, 1, 2), (3,))])
+def test_dense_pair_streaming_backward(nwa, nwb, monkeypatch):
+    # ngpde_dense_pair_backward: both pullbacks of an activation-free pair in one launch (dx already summed, narrow features and
+    # bias on the matrix pipe as a 16-wide block), against the oracle and the composed path
+    from ngpde_amd import functional as F
+    monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD", raising=False)
+    n, per_graph = 70001, 10000
+    res = []
+    for mode in (0, 1):
+        rng = np.random.default_rng(79)
+        x = torch.as_tensor(rng.normal(size=(n, 64)), dtype=torch.float32, device=DEV).requires_grad_(True)
+
+        def side(nw, last_per_graph):
+            blocks, divs = [x], [1]
+            for i, w in enumerate(nw):
+                rd = per_graph if (last_per_graph and i == len(nw) - 1) else 1
+                blocks.append(torch.as_tensor(rng.normal(size=((n + rd - 1) // rd, w)), dtype=torch.float32, device=DEV))
+                divs.append(rd)
+            din = 64 + sum(nw)
+            wt = torch.as_tensor(rng.normal(size=(din, 64)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+            b = torch.as_tensor(rng.normal(size=64), dtype=torch.float32, device=DEV).requires_grad_(True)
+            return blocks, divs, wt, b
+
+        A, B = side(nwa, True), side(nwb, False)
+        Ra, Rb = rng.normal(size=(64, n)), rng.normal(size=(64, n))
+        if mode == 1:
+            monkeypatch.setenv("NGPDE_DENSE_NO_STREAM_BWD", "1")
+        ya, yb = F.dense_pair(A[0], A[2], A[3], 0, B[0], B[2], None, 0, row_divs_a=A[1], row_divs_b=B[1], n=n)
+        ((ya * torch.as_tensor(Ra.T, dtype=torch.float32, device=DEV)).sum() + (yb * torch.as_tensor(Rb.T, dtype=torch.float32, device=DEV)).sum()).backward()
+        if mode == 1:
+            monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD")
+        res.append((x, A, B, Ra, Rb))
+    (x, A, B, Ra, Rb), (x2, A2, B2, _, _) = res
+    close(x.grad, x2.grad.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
+    close(A[2].grad, A2[2].grad.cpu().double().numpy(), rtol=3e-4)
+    close(B[2].grad, B2[2].grad.cpu().double().numpy(), rtol=3e-4)
+    close(A[3].grad, A2[3].grad.cpu().double().numpy(), rtol=3e-4)
+    dxs = []
+    for (blocks, divs, wt, b), R, bias in ((A, Ra, True), (B, Rb, False)):
+        X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+        layer = [dict(weight=wt.detach().cpu().double().numpy().T, bias=b.detach().cpu().double().numpy() if bias else None, act="identity")]
+        yo, cache = O.mlp_forward(layer, X.T)
+        dx, gr = O.mlp_backward(layer, cache, R)
+        dxs.append(dx[:64])
+        close(wt.grad, gr[0]["weight"].T, rtol=3e-4)
+        if bias:
+            close(b.grad, gr[0]["bias"].reshape(-1), rtol=3e-4)
+    close(x.grad, (dxs[0] + dxs[1]).T)
+
+
 @pytest.mark.parametrize("nwa,nwb,douts", [((2, 2), (2,), (64, 64)), ((), (), (64, 48)), ((1, 3, 2), (3,), (40, 64))])
 def test_dense_pair_streaming_forward(nwa, nwb, douts, monkeypatch):
     # ngpde_dense_pair_forward: two Dense layers from one pass over their shared 64-wide block (dense_pair_fwd_kernel, weights in
