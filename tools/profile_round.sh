@@ -27,6 +27,12 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -o k -- python3 $R/tools/bench_layers.py --only c3 --reps 50 > $O/c3_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gnode_stats -o k -- python3 $R/tools/trace_generic_node.py 10 > $O/gnode_stats.log 2>&1
 cd $R
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -o k -- python3 $R/tools/bench_layers.py --only c4 --traj 64 --reps 10 > $O/c4_stats.log 2>&1
+cd $R
+# does the fp32 matrix instruction run beside the VALU?
+hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o /tmp/ovl 2>/dev/null && timeout 120 /tmp/ovl > $O/mfma_valu_overlap.jsonl 2>/dev/null
+[ -f neuralgraphpde.jl_amd/libngpde_diag.so ] && timeout 200 python3 tools/stamps_edge64.py 64 > $O/edge64_stamps.txt 2>/dev/null
 python3 tools/bench_gcn_anywidth.py > $O/gcn_anywidth.jsonl 2>/dev/null
 python3 tools/trace_generic_node.py 50 > $O/generic_node.jsonl 2>/dev/null
 python3 tools/trace_generic_node.py 50 capture >> $O/generic_node.jsonl 2>/dev/null
