@@ -2,7 +2,8 @@
  * plan (ngpde_node_gcn2_*), the message path of the edge-function layers (ngpde_dense_forward, ngpde_edge_mlp_forward next to
  * the primitives ngpde_edge_combine_forward / ngpde_segment_reduce_forward), the reassociated and the literal GNOConv message
  * (ngpde_gno_apply_forward / ngpde_gno_contract_forward), the one-launch GAT layer next to its composition
- * (ngpde_gat_layer_forward vs ngpde_dense_forward + ngpde_gat_forward + ngpde_bias_act_forward) and ngpde_rk_stage_combine.
+ * (ngpde_gat_layer_forward vs ngpde_dense_forward + ngpde_gat_forward + ngpde_bias_act_forward), ngpde_rk_stage_combine, and the
+ * node-level Dense pair / chain launches (ngpde_dense_pair_forward / _backward, ngpde_dense_chain2_forward) at a streaming size.
  * No Python, torch or C++ on the calling side.  Checkers: the C restatement of the reference solver (oracle/ngpde_oracle.c) and
  * plain double-precision loops over the CSR lists the library hands out.  Exit code 0 = every comparison within tolerance.
  * Built and run by tests/test_c_abi_gpu.py. */
@@ -249,6 +250,84 @@ int main(void) {
     report("gat_layer_forward vs composition", max_rel(y1, y2, n * d), 1e-4);
     report("rk_stage_combine", max_rel(cb, ref, n * d), 1e-6);
     CHECK_NG(ngpde_graph_destroy(g2));
+  }
+  /* ---- 5. node-level Dense layers of the edge-function layers at a streaming size: the pair (P, Q from one pass over h) and its
+   *         pullback in one launch, the two-layer chain (psi); checked on a sample of rows / all weights against double loops ---- */
+  {
+    const int64_t nn = 70001;
+    const int dh = 64, dn = 2, din = dh + dn, hw = 64;
+    float *h = host_rand(nn * dh, 1.0f), *dd = host_rand(nn * dn, 1.0f), *wp = host_rand(din * hw, 0.12f), *wq = host_rand(din * hw, 0.12f),
+          *bp = host_rand(hw, 0.3f), *w2 = host_rand(hw * hw, 0.12f), *b2 = host_rand(hw, 0.3f), *gP = host_rand(nn * hw, 1.0f),
+          *gQ = host_rand(nn * hw, 1.0f);
+    float *h_d = dev_copy(h, nn * dh), *d_d = dev_copy(dd, nn * dn), *wp_d = dev_copy(wp, din * hw), *wq_d = dev_copy(wq, din * hw),
+          *bp_d = dev_copy(bp, hw), *w2_d = dev_copy(w2, hw * hw), *b2_d = dev_copy(b2, hw), *P_d = dev_copy(NULL, nn * hw),
+          *Q_d = dev_copy(NULL, nn * hw), *y_d = dev_copy(NULL, nn * hw), *gP_d = dev_copy(gP, nn * hw), *gQ_d = dev_copy(gQ, nn * hw),
+          *dh_d = dev_copy(NULL, nn * dh), *dwp_d = dev_copy(NULL, din * hw), *dwq_d = dev_copy(NULL, din * hw), *dbp_d = dev_copy(NULL, hw);
+    const float *seg[2] = {h_d, d_d};
+    const int32_t wdt[2] = {dh, dn}, rdv[2] = {1, 1};
+    CHECK_NG(ngpde_dense_pair_forward(nn, 2, seg, wdt, rdv, hw, NGPDE_ACT_IDENTITY, wp_d, bp_d, P_d, NULL, 2, seg, wdt, rdv, hw,
+                                      NGPDE_ACT_IDENTITY, wq_d, NULL, Q_d, NULL, NULL));
+    /* psi-like chain on [h | d]: swish then identity; inference form (no a1 / z1 / z2 buffers) when the library fuses it */
+    const int fused = ngpde_dense_chain2_fused(nn, 2, seg, wdt, rdv, hw, hw);
+    float *a1_d = fused ? NULL : dev_copy(NULL, nn * hw);
+    CHECK_NG(ngpde_dense_chain2_forward(nn, 2, seg, wdt, rdv, hw, NGPDE_ACT_SWISH, wp_d, bp_d, a1_d, NULL, hw, NGPDE_ACT_IDENTITY, w2_d, b2_d,
+                                        y_d, NULL, NULL));
+    const size_t wsb = ngpde_dense_pair_backward_workspace_bytes(nn, 2, seg, wdt, rdv, 2, seg, wdt, rdv, hw);
+    if (!wsb) { fprintf(stderr, "pair pullback not available at this size\n"); return 9; }
+    void *ws_d = NULL;
+    CHECK_HIP(hipMalloc(&ws_d, wsb));
+    CHECK_NG(ngpde_dense_pair_backward(nn, 2, seg, wdt, rdv, wp_d, gP_d, dwp_d, dbp_d, 2, seg, wdt, rdv, wq_d, gQ_d, dwq_d, NULL, hw, dh_d,
+                                       NULL, ws_d, wsb, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float *P = host_copy(P_d, nn * hw), *Q = host_copy(Q_d, nn * hw), *y = host_copy(y_d, nn * hw), *dhh = host_copy(dh_d, nn * dh),
+          *dwp = host_copy(dwp_d, din * hw), *dwq = host_copy(dwq_d, din * hw), *dbp = host_copy(dbp_d, hw);
+    const int64_t ns = 2048;   /* sampled rows: every 34th + the ragged tail */
+    float *rP = malloc(sizeof(float) * ns * hw), *rQ = malloc(sizeof(float) * ns * hw), *ry = malloc(sizeof(float) * ns * hw),
+          *rdh = malloc(sizeof(float) * ns * dh), *oP = malloc(sizeof(float) * ns * hw), *oQ = malloc(sizeof(float) * ns * hw),
+          *oy = malloc(sizeof(float) * ns * hw), *odh = malloc(sizeof(float) * ns * dh);
+    for (int64_t q = 0; q < ns; ++q) {
+      const int64_t i = q < ns - 64 ? q * 34 : nn - (ns - q);
+      double x[66], a1[64];
+      for (int k = 0; k < dh; ++k) x[k] = h[i * dh + k];
+      for (int k = 0; k < dn; ++k) x[dh + k] = dd[i * dn + k];
+      for (int o = 0; o < hw; ++o) {
+        double sp = bp[o], sq = 0;
+        for (int k = 0; k < din; ++k) { sp += x[k] * wp[k * hw + o]; sq += x[k] * wq[k * hw + o]; }
+        rP[q * hw + o] = (float)sp; rQ[q * hw + o] = (float)sq;
+        a1[o] = sp / (1.0 + exp(-sp));
+        oP[q * hw + o] = P[i * hw + o]; oQ[q * hw + o] = Q[i * hw + o]; oy[q * hw + o] = y[i * hw + o];
+      }
+      for (int o = 0; o < hw; ++o) {
+        double z = b2[o];
+        for (int k = 0; k < hw; ++k) z += a1[k] * w2[k * hw + o];
+        ry[q * hw + o] = (float)z;
+      }
+      for (int k = 0; k < dh; ++k) {
+        double sg = 0;
+        for (int o = 0; o < hw; ++o) sg += (double)gP[i * hw + o] * wp[k * hw + o] + (double)gQ[i * hw + o] * wq[k * hw + o];
+        rdh[q * dh + k] = (float)sg; odh[q * dh + k] = dhh[i * dh + k];
+      }
+    }
+    double *aw = calloc((size_t)din * hw * 2 + hw, sizeof(double));
+    for (int64_t i = 0; i < nn; ++i)
+      for (int k = 0; k < din; ++k) {
+        const double xv = k < dh ? h[i * dh + k] : dd[i * dn + (k - dh)];
+        for (int o = 0; o < hw; ++o) {
+          aw[(size_t)k * hw + o] += xv * gP[i * hw + o];
+          aw[(size_t)din * hw + (size_t)k * hw + o] += xv * gQ[i * hw + o];
+          if (k == 0) aw[(size_t)2 * din * hw + o] += gP[i * hw + o];
+        }
+      }
+    float *rwp = malloc(sizeof(float) * din * hw), *rwq = malloc(sizeof(float) * din * hw), *rbp = malloc(sizeof(float) * hw);
+    for (int k = 0; k < din * hw; ++k) { rwp[k] = (float)aw[k]; rwq[k] = (float)aw[(size_t)din * hw + k]; }
+    for (int o = 0; o < hw; ++o) rbp[o] = (float)aw[(size_t)2 * din * hw + o];
+    report("dense_pair_forward P", max_rel(oP, rP, ns * hw), 1e-4);
+    report("dense_pair_forward Q", max_rel(oQ, rQ, ns * hw), 1e-4);
+    report(fused ? "dense_chain2_forward (one launch)" : "dense_chain2_forward (two launches)", max_rel(oy, ry, ns * hw), 1e-4);
+    report("dense_pair_backward dh", max_rel(odh, rdh, ns * dh), 2e-4);
+    report("dense_pair_backward dWp", max_rel(dwp, rwp, din * hw), 3e-4);
+    report("dense_pair_backward dWq", max_rel(dwq, rwq, din * hw), 3e-4);
+    report("dense_pair_backward dbp", max_rel(dbp, rbp, hw), 3e-4);
   }
   CHECK_NG(ngpde_graph_destroy(g));
   return fails ? 1 : 0;
