@@ -327,6 +327,106 @@ __global__ __launch_bounds__(256, 4) void dense_wide_fwd_kernel(int64_t n, SegTa
   }
 }
 
+// ---- 128 x 128 output tiles for wide outputs (GNOConv's node-level T = W2 (x) h: 4096 x 128 => 8192, 8.6 GFLOP at config 5) ------
+// Four waves as 2 x 2, each 64 x 64 outputs = 16 accumulator tiles: 64 MFMAs per 16-deep K chunk from 4 + 4 operand reads (the
+// 128 x 64 tiles above: 64 MFMAs from 12 reads and half the outputs per weight element fetched), K chunks double-buffered in LDS
+// (one barrier per chunk), the next chunk's global loads in flight during the products; every wave takes its output out
+// through a private 16 x 64 LDS patch, row tile by row tile, as full 256-byte row segments.  Single 16-byte-loadable input
+// block, din % 16 == 0, dout % 4 == 0.
+constexpr int BG = 128, BKG = 16, LSG = BKG + 4;
+__global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, const float *__restrict__ x, int din, int dout, int act,
+                                                                const float *__restrict__ wt, const float *__restrict__ bias,
+                                                                float *__restrict__ y, float *__restrict__ save_z) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BG * LSG];   // [buffer][A | Bt][128][LSG]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * BG;
+  const int col0 = blockIdx.y * BG;
+  // staging roles: A float4 (row = tid / 4 + 64 p, k = 4 (tid % 4)); B float4 (k = tid / 32 + 8 p, columns 4 (tid % 32) .. + 3)
+  const int ar = tid >> 2, ak = 4 * (tid & 3), bk = tid >> 5, bc = 4 * (tid & 31);
+  // (named registers: float4 arrays captured by the lambdas end up in scratch memory, with a wait in front of every store)
+  float4 areg0, areg1, breg0, breg1;
+  const float *xa0 = x + min(row0 + ar, n - 1) * din + ak, *xa1 = x + min(row0 + ar + 64, n - 1) * din + ak;   // rows past the end
+  const float *wb0 = wt + (size_t)bk * dout + min(col0 + bc, dout - 4), *wb1 = wb0 + (size_t)8 * dout;        // read the last one
+  auto fetch = [&](int k0) {
+    areg0 = *reinterpret_cast<const float4 *>(xa0 + k0);
+    areg1 = *reinterpret_cast<const float4 *>(xa1 + k0);
+    breg0 = *reinterpret_cast<const float4 *>(wb0 + (size_t)k0 * dout);
+    breg1 = *reinterpret_cast<const float4 *>(wb1 + (size_t)k0 * dout);
+  };
+  auto stage = [&](int buf) {
+    float *A = lds + buf * (2 * BG * LSG), *Bt = A + BG * LSG;
+    *reinterpret_cast<float4 *>(&A[ar * LSG + ak]) = areg0;
+    *reinterpret_cast<float4 *>(&A[(ar + 64) * LSG + ak]) = areg1;
+    Bt[(bc + 0) * LSG + bk] = breg0.x; Bt[(bc + 1) * LSG + bk] = breg0.y; Bt[(bc + 2) * LSG + bk] = breg0.z; Bt[(bc + 3) * LSG + bk] = breg0.w;
+    Bt[(bc + 0) * LSG + bk + 8] = breg1.x; Bt[(bc + 1) * LSG + bk + 8] = breg1.y; Bt[(bc + 2) * LSG + bk + 8] = breg1.z;
+    Bt[(bc + 3) * LSG + bk + 8] = breg1.w;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  const int nk = din / BKG;
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) fetch((kc + 1) * BKG);   // in flight during the MFMAs
+    const float *A = lds + (kc & 1) * (2 * BG * LSG), *Bt = A + BG * LSG;
+    float4 a4[4], b4[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a4[rt] = *reinterpret_cast<const float4 *>(&A[(64 * wr + 16 * rt + i) * LSG + 4 * kq]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const float4 *>(&Bt[(64 * wc + 16 * ct + i) * LSG + 4 * kq]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float av = r == 0 ? a4[rt].x : r == 1 ? a4[rt].y : r == 2 ? a4[rt].z : a4[rt].w;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const float bv = r == 0 ? b4[ct].x : r == 1 ? b4[ct].y : r == 2 ? b4[ct].z : b4[ct].w;
+          acc[rt][ct] = mfma16(av, bv, acc[rt][ct]);
+        }
+      }
+    if (kc + 1 < nk) stage((kc + 1) & 1);   // the other buffer: last read in chunk kc - 1, before the barrier below
+    __syncthreads();
+  }
+  // epilogue: this wave's 64 x 64 outputs, 16 rows at a time through its own LDS patch
+  float *patch = lds + wave * (16 * OS2);
+  const int pc = 4 * (lane & 15);
+  float b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = (bias && col0 + 64 * wc + pc + j < dout) ? bias[col0 + 64 * wc + pc + j] : 0.f;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) patch[(4 * kq + reg) * OS2 + 16 * ct + i] = acc[rt][ct][reg];
+    float4 zz[4], aa[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const float4 v = *reinterpret_cast<const float4 *>(&patch[((lane >> 4) + 4 * pp) * OS2 + pc]);
+      zz[pp] = make_float4(v.x + b[0], v.y + b[1], v.z + b[2], v.w + b[3]);
+      aa[pp] = zz[pp];
+    }
+    f4n_act<4>(act, aa);
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int64_t r = row0 + 64 * wr + 16 * rt + (lane >> 4) + 4 * pp;
+      const int c = col0 + 64 * wc + pc;
+      if (r < n && c < dout) {
+        if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + c) = zz[pp];
+        *reinterpret_cast<float4 *>(y + r * dout + c) = aa[pp];
+      }
+    }
+  }
+}
+
 // ---- streaming form of the wide forward for a 64-deep contraction and <= 64 outputs (the node-level Dense of the edge-function
 // layers: h => 64, [h | d | theta] => 64).  Persistent workgroups (one resident wave of them, three per CU) walk the 128-row
 // tiles; W^T is staged once per workgroup; the WHOLE 128 x 64 input tile goes memory -> LDS by LDS-DMA in one burst (32 KB in
@@ -916,6 +1016,17 @@ static bool use_wide_tiles(int64_t n, int cols) {
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream) {
   if (n == 0 || dout == 0) return NGPDE_OK;
+  {   // wide outputs from one 16-byte-loadable block: 128 x 128 tiles
+    static const bool no_gemm = getenv("NGPDE_DENSE_NO_GEMM128") != nullptr;
+    const int64_t tiles = ((n + BG - 1) / BG) * ((dout + BG - 1) / BG);
+    if (!no_gemm && segs.n == 1 && segs.vec[0] && segs.row_div[0] == 1 && din % BKG == 0 && dout % 4 == 0 && dout >= BG && tiles >= 512 &&
+        ((reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(save_z)) & 15) == 0) {
+      hipLaunchKernelGGL(dense_gemm128_fwd_kernel, dim3((unsigned)((n + BG - 1) / BG), (dout + BG - 1) / BG), dim3(256), 0, stream, n,
+                         segs.ptr[0], din, dout, act, wt, bias, y, save_z);
+      NGPDE_LAUNCH_CHECK("dense_gemm128_fwd_kernel");
+      return NGPDE_OK;
+    }
+  }
   if (use_wide_tiles(n, dout)) {
     // trailing narrow blocks (<= 8 features in total behind a multiple of 32) leave the K loop: see dense_wide_fwd_kernel
     int din_main = din;
