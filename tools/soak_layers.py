@@ -1,6 +1,7 @@
 """Race screen for the round-2 kernels whose lanes hand data to each other through LDS inside a wave or across a workgroup without
 a library-level barrier in between -- the one-launch GAT layer (group-private coefficient table, LDS-DMA staged rows) and its
-two-launch pullback, the GNO message on the matrix pipe and its pullback -- and for the persistent solver: every repetition of
+two-launch pullback, the GNO message on the matrix pipe and its pullback, the C4 kernels of DESIGN 5.7 -- and for the persistent
+solver: every repetition of
 forward + backward must reproduce the first one bit for bit.  usage: python tools/soak_layers.py [repetitions]"""
 import json, os, sys
 import numpy as np, torch
@@ -62,4 +63,19 @@ rhs = ng.Chain(ng.GCNConv((64, 64), "relu", initialgraph=g), ng.GCNConv((64, 64)
 node = ng.NeuralODE(rhs, solver="tsit5", n_steps=50, dt=0.02)
 psn, stn = ng.setup(0, node)
 bad += soak("C2 NeuralODE (persistent solver, through the layer API)", node, torch.randn(16384, 64, device=DEV).T, psn, stn)
+# MPPDEConv in BASELINE config 4's shape (8 trajectories x 8192-node periodic mesh = 65 536 nodes): the streaming Dense kernels
+# (pair, chain, one-launch pullbacks) and the specialised message kernels with their hand-placed LDS reads and waits
+n4, traj = 8192, 8
+idx = np.arange(n4)
+s4 = np.concatenate([idx for k in (-3, -2, -1, 1, 2, 3)]); t4 = np.concatenate([(idx + k) % n4 for k in (-3, -2, -1, 1, 2, 3)])
+S4, T4 = np.concatenate([s4 + i * n4 for i in range(traj)]), np.concatenate([t4 + i * n4 for i in range(traj)])
+N4 = n4 * traj
+g4 = ng.GNNGraph(S4, T4, num_nodes=N4, index_base=0, num_graphs=traj,
+                 ndata={"u": torch.rand(1, N4), "x": torch.as_tensor(np.tile(idx / n4, traj)[None, :].astype(np.float32))},
+                 gdata={"θ": torch.rand(2, traj)})
+mp = ng.MPPDEConv(ng.Chain(ng.Dense(132, 64, "swish"), ng.Dense(64, 64, "swish")), ng.Chain(ng.Dense(130, 64, "swish"), ng.Dense(64, 64)),
+                  initialgraph=g4)
+psm, stm = ng.setup(4, mp)
+bad += soak("C4-shaped MPPDEConv, 8 trajectories (pair / chain Dense launches, one-launch pullbacks, specialised message kernels)", mp,
+            torch.randn(N4, 64, device=DEV).T, psm, stm)
 sys.exit(1 if bad else 0)
