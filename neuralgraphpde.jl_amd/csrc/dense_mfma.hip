@@ -1215,7 +1215,9 @@ int32_t launch_dense_pair_fwd(int64_t n, const SegTable &ta, int dina, int douta
   const size_t lds = ((size_t)2 * kPairTR * OS2 + 2 * kNarrow * 64 + (size_t)kPairTR * kNarrowAll) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_pair_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_pair_fwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(e));
-  const int grid = stream_grid(reinterpret_cast<const void *>(dense_pair_fwd_kernel), lds, n_tiles);
+  static int cap = 0;   // resident workgroups of this kernel on this device (one occupancy query per process)
+  if (!cap) cap = stream_grid(reinterpret_cast<const void *>(dense_pair_fwd_kernel), lds, 1 << 30);
+  const int grid = std::min(n_tiles, cap);
   hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b);
   NGPDE_LAUNCH_CHECK("dense_pair_fwd_kernel");
   return NGPDE_OK;
@@ -1237,7 +1239,9 @@ int32_t launch_dense_chain_fwd(int64_t n, const SegTable &t1, int din1, int act1
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int grid = stream_grid(reinterpret_cast<const void *>(kernel), lds, n_tiles);
+    static int cap[3] = {0, 0, 0};
+    if (!cap[nm]) cap[nm] = stream_grid(reinterpret_cast<const void *>(kernel), lds, 1 << 30);
+    const int grid = std::min(n_tiles, cap[nm]);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, t1.ptr[0], nm == 2 ? t1.ptr[1] : nullptr,
                        l1, l2);
     return hipSuccess;

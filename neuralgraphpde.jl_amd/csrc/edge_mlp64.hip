@@ -41,6 +41,8 @@ __device__ __forceinline__ unsigned lds_addr(const void *ptr) { return (unsigned
 #define lds_read4(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 #define lds_read_u16(dst, addr) asm volatile("ds_read_u16 %0, %1" : "=v"(dst) : "v"(addr))
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kT4 = 256, kW = 64, kTS = kW + 4, kSlice = 16, kChunk4 = 64, kRows = 32;
 
 #ifdef NGPDE_STAMPS
@@ -134,45 +136,46 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
   }
 
   // ---- the activation in stages: y = fin(x, tr2(mid(tr1(pre(x))))) with the two quarter-rate transcendentals (tr1, tr2) as
-  // separate steps, so that the pipelined block below can put exactly one of them behind every MFMA.  Same operations in the
-  // same order as act_apply (device_utils.h): bitwise the same values.
-  auto pre = [](auto act, float x) -> float {
-    constexpr int A = decltype(act)::value;
-    if (A == NGPDE_ACT_SWISH) return (-x) * 1.4426950408889634f;
-    if (A == NGPDE_ACT_TANH) return (2.0f * x) * 1.4426950408889634f;
-    return x;
-  };
+  // separate steps, so that the pipelined block below can put exactly one of them behind every MFMA; pre / mid / fin on pairs of
+  // values (packed instructions).  Same operations in the same order as act_apply (device_utils.h): bitwise the same values.
   auto tr1 = [](auto act, float t) -> float {
     constexpr int A = decltype(act)::value;
     return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? __builtin_amdgcn_exp2f(t) : t;
-  };
-  auto mid = [](auto act, float e) -> float {
-    constexpr int A = decltype(act)::value;
-    return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? 1.0f + e : e;
   };
   auto tr2 = [](auto act, float d) -> float {
     constexpr int A = decltype(act)::value;
     return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? __builtin_amdgcn_rcpf(d) : d;
   };
-  auto fin = [](auto act, float x, float r) -> float {
+  // the packed (two-value) forms of the non-transcendental steps: the same operations on both halves
+  auto pre2 = [](auto act, f32x2 x) -> f32x2 {
+    constexpr int A = decltype(act)::value;
+    if (A == NGPDE_ACT_SWISH) return (-x) * 1.4426950408889634f;
+    if (A == NGPDE_ACT_TANH) return (2.0f * x) * 1.4426950408889634f;
+    return x;
+  };
+  auto mid2 = [](auto act, f32x2 e) -> f32x2 {
+    constexpr int A = decltype(act)::value;
+    return (A == NGPDE_ACT_SWISH || A == NGPDE_ACT_TANH) ? 1.0f + e : e;
+  };
+  auto fin2 = [](auto act, f32x2 x, f32x2 r) -> f32x2 {
     constexpr int A = decltype(act)::value;
     if (A == NGPDE_ACT_SWISH) return x * r;
     if (A == NGPDE_ACT_TANH) return 1.0f - 2.0f * r;
-    if (A == NGPDE_ACT_RELU) return fmaxf(x, 0.0f);
+    if (A == NGPDE_ACT_RELU) return (f32x2){fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
     return x;
   };
   const std::integral_constant<int, ACT1> act1_c{};
   const std::integral_constant<int, ACT2> act2_c{};
 
   // permanent registers: the bias of the lane's 16 output features, the W2^T fragments of the first 16 input features
-  float bias_r[16];
+  f32x2 bias2[8];   // bias2[2 mt + h] = bias of features 16 mt + 4 kq + 2 h, + 1
   f32x4 w0[4];
   {
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
-      bias_r[4 * mt] = b4.x; bias_r[4 * mt + 1] = b4.y; bias_r[4 * mt + 2] = b4.z; bias_r[4 * mt + 3] = b4.w;
+      bias2[2 * mt] = (f32x2){b4.x, b4.y}; bias2[2 * mt + 1] = (f32x2){b4.z, b4.w};
       const float4 w4 = *reinterpret_cast<const float4 *>(&ldsWt[(mt * 16 + ei) * kTS + 4 * kq]);
       w0[mt] = (f32x4){w4.x, w4.y, w4.z, w4.w};
     }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
     constexpr bool MF = decltype(mf_c)::value, PUB = decltype(pub_c)::value, ASM = decltype(asm_c)::value;
     f32x4 acc[4];
     f32x4 wf[4][4];
-    float xs[32], ts[32];
+    f32x2 xs2[16], ts2[16];
     f32x4 pr[4], qr[4];
     unsigned eword = 0, p_addr = 0, q_addr = 0;
 #pragma unroll
@@ -244,60 +247,60 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
         if (ASM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[2]), "+v"(qr[2]), "+v"(pr[3]), "+v"(qr[3]));
       }
       {
-        constexpr int pp = s >> 2, ph = s & 3, e0 = 2 * pp, e1 = e0 + 1;
+        // values travel in PAIRS (two consecutive features of the lane): the non-transcendental steps are one packed instruction
+        // per pair (v_pk_add_f32 / v_pk_mul_f32) -- with the matrix instruction unable to run beside the VALU every such
+        // instruction is a matrix-pipe bubble.  Pair pp, slots 4 pp .. 4 pp + 3: {source + pre-scale, tr1(e0)} {tr1(e1)}
+        // {mid, tr2(e0)} {tr2(e1)}; its last step (fin) opens the next pair's first slot.
+        constexpr int pp = s >> 2, ph = s & 3;
         constexpr bool pub_pair = pp < 8;
-        if constexpr (ph == 0 && pp > 0) {   // last step of the previous pair's second value
+        if constexpr (ph == 0 && pp > 0) {
           constexpr bool prev_pub = (pp - 1) < 8;
           if (prev_pub ? PUB : ASM) {
-            xs[e0 - 1] = prev_pub ? fin(act2_c, xs[e0 - 1], ts[e0 - 1]) : fin(act1_c, xs[e0 - 1], ts[e0 - 1]);
-            PIN(xs[e0 - 1]);
+            xs2[pp - 1] = prev_pub ? fin2(act2_c, xs2[pp - 1], ts2[pp - 1]) : fin2(act1_c, xs2[pp - 1], ts2[pp - 1]);
+            PIN(xs2[pp - 1]);
           }
         }
         if constexpr (PUB && pub_pair && ph == 1 && (pp & 1) == 0 && pp > 0) {   // float4 mt = pp / 2 - 1 of the messages is complete
           constexpr int m = pp / 2 - 1;
           *reinterpret_cast<float4 *>(&ldsMsg[(wave * kSlice + ei) * kTS + 16 * m + 4 * kq]) =
-              make_float4(xs[4 * m], xs[4 * m + 1], xs[4 * m + 2], xs[4 * m + 3]);
+              make_float4(xs2[2 * m][0], xs2[2 * m][1], xs2[2 * m + 1][0], xs2[2 * m + 1][1]);
         }
         if (PUB && s == 33)
-          *reinterpret_cast<float4 *>(&ldsMsg[(wave * kSlice + ei) * kTS + 48 + 4 * kq]) = make_float4(xs[12], xs[13], xs[14], xs[15]);
+          *reinterpret_cast<float4 *>(&ldsMsg[(wave * kSlice + ei) * kTS + 48 + 4 * kq]) = make_float4(xs2[6][0], xs2[6][1], xs2[7][0], xs2[7][1]);
         if constexpr (pub_pair ? PUB : ASM) {
           if constexpr (ph == 0) {
             if constexpr (pub_pair) {
-              xs[e0] = accp[e0 >> 2][e0 & 3] + bias_r[e0];
-              xs[e1] = accp[e1 >> 2][e1 & 3] + bias_r[e1];
-              ts[e0] = tr1(act2_c, pre(act2_c, xs[e0]));
+              constexpr int mt_ = pp >> 1, h_ = 2 * (pp & 1);
+              xs2[pp] = (f32x2){accp[mt_][h_], accp[mt_][h_ + 1]} + bias2[pp];
+              ts2[pp] = pre2(act2_c, xs2[pp]);
+              ts2[pp][0] = tr1(act2_c, ts2[pp][0]);
             } else {
-              constexpr int f0 = e0 - 16, f1 = e1 - 16;
-              xs[e0] = comp(pr[f0 >> 2], f0 & 3) + comp(qr[f0 >> 2], f0 & 3);
-              xs[e1] = comp(pr[f1 >> 2], f1 & 3) + comp(qr[f1 >> 2], f1 & 3);
-              ts[e0] = tr1(act1_c, pre(act1_c, xs[e0]));
+              constexpr int c_ = (pp - 8) >> 1, h_ = 2 * (pp & 1);
+              xs2[pp] = (f32x2){pr[c_][h_], pr[c_][h_ + 1]} + (f32x2){qr[c_][h_], qr[c_][h_ + 1]};
+              ts2[pp] = pre2(act1_c, xs2[pp]);
+              ts2[pp][0] = tr1(act1_c, ts2[pp][0]);
             }
-            PIN(xs[e1]);
-            PIN(ts[e0]);
+            PIN(xs2[pp]);
+            PIN(ts2[pp]);
           } else if constexpr (ph == 1) {
-            ts[e1] = pub_pair ? tr1(act2_c, pre(act2_c, xs[e1])) : tr1(act1_c, pre(act1_c, xs[e1]));
-            ts[e0] = pub_pair ? mid(act2_c, ts[e0]) : mid(act1_c, ts[e0]);
-            PIN(ts[e1]);
-            PIN(ts[e0]);
+            ts2[pp][1] = pub_pair ? tr1(act2_c, ts2[pp][1]) : tr1(act1_c, ts2[pp][1]);
+            PIN(ts2[pp]);
           } else if constexpr (ph == 2) {
-            ts[e0] = pub_pair ? tr2(act2_c, ts[e0]) : tr2(act1_c, ts[e0]);
-            ts[e1] = pub_pair ? mid(act2_c, ts[e1]) : mid(act1_c, ts[e1]);
-            PIN(ts[e0]);
-            PIN(ts[e1]);
+            ts2[pp] = pub_pair ? mid2(act2_c, ts2[pp]) : mid2(act1_c, ts2[pp]);
+            ts2[pp][0] = pub_pair ? tr2(act2_c, ts2[pp][0]) : tr2(act1_c, ts2[pp][0]);
+            PIN(ts2[pp]);
           } else {
-            ts[e1] = pub_pair ? tr2(act2_c, ts[e1]) : tr2(act1_c, ts[e1]);
-            xs[e0] = pub_pair ? fin(act2_c, xs[e0], ts[e0]) : fin(act1_c, xs[e0], ts[e0]);
-            PIN(ts[e1]);
-            PIN(xs[e0]);
+            ts2[pp][1] = pub_pair ? tr2(act2_c, ts2[pp][1]) : tr2(act1_c, ts2[pp][1]);
+            PIN(ts2[pp]);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     if (ASM) {
-      xs[31] = fin(act1_c, xs[31], ts[31]);
+      xs2[15] = fin2(act1_c, xs2[15], ts2[15]);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) a[ct] = (f32x4){xs[16 + 4 * ct], xs[17 + 4 * ct], xs[18 + 4 * ct], xs[19 + 4 * ct]};
+      for (int ct = 0; ct < 4; ++ct) a[ct] = (f32x4){xs2[8 + 2 * ct][0], xs2[8 + 2 * ct][1], xs2[9 + 2 * ct][0], xs2[9 + 2 * ct][1]};
     }
     if (MF) {
 #pragma unroll

@@ -1,6 +1,7 @@
 // tools/mfma_valu_overlap.hip -- does a SIMD of gfx950 run VALU / transcendental instructions beside its matrix instructions?
 // One wave per SIMD slot (grid = 256 CUs x 4 SIMDs x W waves), each wave runs N iterations of
 //   mode 0: 16 independent MFMAs                      mode 1: 16 x (v_exp_f32 + 2 v_fma_f32)        mode 2: both, interleaved 1 : 1
+//   modes 3-6: four plain FMAs per slot / one transcendental per slot, alone and beside the fp32 matrix instruction
 // for the fp32 matrix instruction (v_mfma_f32_16x16x4_f32) and the bf16 one (v_mfma_f32_16x16x32_bf16).  If mode 2 takes
 // max(mode 0, mode 1) the pipes overlap; if it takes the sum they share issue / datapath.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o /tmp/ovl && /tmp/ovl
@@ -15,6 +16,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define M32(i) "v_mfma_f32_16x16x4_f32 %" #i ", %8, %9, %" #i "\n"
 #define MBF(i) "v_mfma_f32_16x16x32_bf16 %" #i ", %8, %9, %" #i "\n"
 #define VAL(i) "v_exp_f32 %" #i ", %" #i "\n s_nop 0\n v_fma_f32 %" #i ", %" #i ", %10, %11\n v_fma_f32 %" #i ", %" #i ", %12, %13\n"
+#define FMA(i) "v_fma_f32 %" #i ", %" #i ", %10, %11\n v_fma_f32 %" #i ", %" #i ", %12, %13\n v_fma_f32 %" #i ", %" #i ", %10, %11\n v_fma_f32 %" #i ", %" #i ", %12, %13\n"
+#define EXP(i) "v_exp_f32 %" #i ", %" #i "\n s_nop 0\n"
 #define SLOTS4(M, V) M(0) V(4) M(1) V(5) M(2) V(6) M(3) V(7)
 #define NONE(i) ""
 template <int MODE, int KIND>
@@ -35,6 +38,10 @@ __global__ __launch_bounds__(256) void k(int n, float *out) {
     if (MODE == 2 && KIND == 0) BODY(SLOTS4(M32, VAL), a, b);
     if (MODE == 0 && KIND == 1) BODY(SLOTS4(MBF, NONE), ab, bb);
     if (MODE == 2 && KIND == 1) BODY(SLOTS4(MBF, VAL), ab, bb);
+    if (MODE == 3) BODY(SLOTS4(NONE, FMA), a, b);          // four plain VALU instructions per slot, alone
+    if (MODE == 4) BODY(SLOTS4(M32, FMA), a, b);           // ... beside the fp32 matrix instruction
+    if (MODE == 5) BODY(SLOTS4(NONE, EXP), a, b);          // one transcendental per slot, alone
+    if (MODE == 6) BODY(SLOTS4(M32, EXP), a, b);           // ... beside the fp32 matrix instruction
   }
   float r = v0 + v1 + v2 + v3;
   r += acc0[0] + acc1[1] + acc2[2] + acc3[3];
@@ -64,8 +71,10 @@ int main() {
     const float f0 = run<0, 0>(w, n, out), f1 = run<1, 0>(w, n, out), f2 = run<2, 0>(w, n, out);
     const float b0 = run<0, 1>(w, n, out), b2 = run<2, 1>(w, n, out);
     const double per = 1e6 / (double)n / 16.0;   // ns per slot
+    const float v4 = run<3, 0>(w, n, out), m4 = run<4, 0>(w, n, out), t1 = run<5, 0>(w, n, out), mt = run<6, 0>(w, n, out);
     printf("{\"waves_per_simd\": %d, \"ns_per_slot\": {\"fp32_mfma\": %.2f, \"valu_exp_2fma\": %.2f, \"fp32_mfma+valu\": %.2f, "
-           "\"bf16_mfma\": %.2f, \"bf16_mfma+valu\": %.2f}}\n", w, f0 * per, f1 * per, f2 * per, b0 * per, b2 * per);
+           "\"bf16_mfma\": %.2f, \"bf16_mfma+valu\": %.2f, \"4fma\": %.2f, \"fp32_mfma+4fma\": %.2f, \"exp\": %.2f, "
+           "\"fp32_mfma+exp\": %.2f}}\n", w, f0 * per, f1 * per, f2 * per, b0 * per, b2 * per, v4 * per, m4 * per, t1 * per, mt * per);
   }
   return 0;
 }
