@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
   float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
   float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]
   float *ldsWt = ldsP + kRows * kTS;                              // [64 out][kTS]   W2^T
-  float *ldsMsg = ldsWt + kW * kTS;                               // [64 edges][kTS]
+  float *ldsMsg0 = ldsWt + kW * kTS;                              // [2][64 edges][kTS]: the messages of chunk c go to buffer c & 1, so
+                                                                  // that one barrier per chunk orders them against the reduction
   __shared__ int ldsOff[kRows + 1];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kRows * 8];
   __shared__ uint16_t ldsEdge[kRows * kSlotWidth];   // tile edge k -> {row of the tile, halo slot << 8}
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
   // feature blocks 2 and 3, 37..40 the fragments of block 3, wait at 47.  A sched_barrier after every slot and the pins keep
   // this order through instruction selection and scheduling.
   //   MF: the products run; PUB: there is a previous slice to publish; ASM: assemble the slice `it_next`.
-  auto block = [&](auto mf_c, auto pub_c, auto asm_c, int it_next, int total, f32x4 (&a)[4], f32x4 (&accp)[4]) __attribute__((always_inline)) {
+  auto block = [&](auto mf_c, auto pub_c, auto asm_c, int it_next, int total, float *ldsMsg, f32x4 (&a)[4], f32x4 (&accp)[4]) __attribute__((always_inline)) {
     constexpr bool MF = decltype(mf_c)::value, PUB = decltype(pub_c)::value, ASM = decltype(asm_c)::value;
     f32x4 acc[4];
     f32x4 wf[4][4];
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
     const int n_it = (total + kChunk4 - 1) / kChunk4;
     auto reduce = [&](int it) {   // lane group g16 sums the messages of rows g16 and g16 + 16 that lie in chunk `it`, edge order
       const int c0 = it * kChunk4;
-      const float *base = ldsMsg + 4 * q - c0 * kTS;
+      const float *base = ldsMsg0 + (it & 1) * (kChunk4 * kTS) + 4 * q - c0 * kTS;
       auto row_sum = [&](int lo, int hi, float4 &racc) {
         int kk = max(lo, c0);
         const int end = min(hi, c0 + kChunk4);
@@ -388,25 +389,25 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_fwd_kernel(const EdgeMlp64K
     };
     if (n_it > 0) {
       f32x4 a[4], accp[4];
-      block(no, no, yes, 0, total, a, accp);          // a1 of slice 0
+      block(no, no, yes, 0, total, ldsMsg0, a, accp);          // a1 of slice 0
       E64_STAMP(2);
-      block(yes, no, yes, 1, total, a, accp);         // products of slice 0 | a1 of slice 1
+      block(yes, no, yes, 1, total, ldsMsg0, a, accp);         // products of slice 0 | a1 of slice 1
       E64_STAMP(3);
       if (has_next) fetch_rows(meta, rows);           // the next tile's rows: in flight across this tile's remaining arithmetic
       E64_STAMP(4);
       for (int it = 1; it < n_it; ++it) {
-        block(yes, yes, yes, it + 1, total, a, accp);   // products of slice it | messages of slice it - 1 | a1 of slice it + 1
+        // products of slice it | messages of slice it - 1 (-> buffer (it - 1) & 1) | a1 of slice it + 1
+        block(yes, yes, yes, it + 1, total, ldsMsg0 + ((it - 1) & 1) * (kChunk4 * kTS), a, accp);
         if (it == 1) E64_STAMP(5);
         __syncthreads();
         if (it == 1) E64_STAMP(6);
-        reduce(it - 1);
+        reduce(it - 1);   // (no second barrier: the next block writes the other buffer)
         if (it == 1) E64_STAMP(7);
-        __syncthreads();
         if (it == 1) E64_STAMP(8);
         if (it == 2) E64_STAMP(9);
       }
       E64_STAMP(10);
-      block(no, yes, no, 0, total, a, accp);          // messages of the last slice
+      block(no, yes, no, 0, total, ldsMsg0 + ((n_it - 1) & 1) * (kChunk4 * kTS), a, accp);   // messages of the last slice
       E64_STAMP(11);
       __syncthreads();
       reduce(n_it - 1);
@@ -761,8 +762,9 @@ int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStr
 #ifdef NGPDE_STAMPS
   k.stamps = g_edge64_stamps;
 #endif
-  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kW * kTS + (size_t)kChunk4 * kTS) * sizeof(float);
-  const int per_xcd = std::max(1, std::min(64, (k.n_tiles + 7) / 8));   // two persistent workgroups per CU, a multiple of the 8 XCDs
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kW * kTS + 2 * (size_t)kChunk4 * kTS) * sizeof(float);
+  const int per_xcd = std::max(1, std::min(lds + 4096 <= 80 * 1024 ? 64 : 32, (k.n_tiles + 7) / 8));   // two persistent workgroups per CU (one when the halo
+                                                                                                   // region is large), a multiple of the 8 XCDs
   const dim3 grid(8 * per_xcd), block(kT4);
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
