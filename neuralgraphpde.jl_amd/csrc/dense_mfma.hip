@@ -337,7 +337,8 @@ constexpr int BG = 128, BKG = 16, LSG = BKG + 4;
 __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, const float *__restrict__ x, int din, int dout, int act,
                                                                 const float *__restrict__ wt, const float *__restrict__ bias,
                                                                 float *__restrict__ y, float *__restrict__ save_z) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BG * LSG];   // [buffer][A | Bt][128][LSG]
+  constexpr int BS = BG + 4, kBuf = BG * LSG + BKG * BS;   // per buffer: A [128][LSG], B [16][BS] row-major (k, col)
+  __shared__ __attribute__((aligned(16))) float lds[2 * kBuf];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -356,13 +357,15 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, co
     breg0 = *reinterpret_cast<const float4 *>(wb0 + (size_t)k0 * dout);
     breg1 = *reinterpret_cast<const float4 *>(wb1 + (size_t)k0 * dout);
   };
+  // B stays row-major in LDS (16-byte stores, no transposition: scalar stores into a transposed tile would hit 4 of the 64
+  // banks); the operand reads are four 4-byte reads per fragment, conflict-free with the row stride 132 (rows 4 kq + r land 16
+  // banks apart, the 16 columns of a lane group side by side)
   auto stage = [&](int buf) {
-    float *A = lds + buf * (2 * BG * LSG), *Bt = A + BG * LSG;
+    float *A = lds + buf * kBuf, *B = A + BG * LSG;
     *reinterpret_cast<float4 *>(&A[ar * LSG + ak]) = areg0;
     *reinterpret_cast<float4 *>(&A[(ar + 64) * LSG + ak]) = areg1;
-    Bt[(bc + 0) * LSG + bk] = breg0.x; Bt[(bc + 1) * LSG + bk] = breg0.y; Bt[(bc + 2) * LSG + bk] = breg0.z; Bt[(bc + 3) * LSG + bk] = breg0.w;
-    Bt[(bc + 0) * LSG + bk + 8] = breg1.x; Bt[(bc + 1) * LSG + bk + 8] = breg1.y; Bt[(bc + 2) * LSG + bk + 8] = breg1.z;
-    Bt[(bc + 3) * LSG + bk + 8] = breg1.w;
+    *reinterpret_cast<float4 *>(&B[bk * BS + bc]) = breg0;
+    *reinterpret_cast<float4 *>(&B[(bk + 8) * BS + bc]) = breg1;
   };
   f32x4 acc[4][4];
 #pragma unroll
@@ -375,22 +378,22 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, co
   const int nk = din / BKG;
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) fetch((kc + 1) * BKG);   // in flight during the MFMAs
-    const float *A = lds + (kc & 1) * (2 * BG * LSG), *Bt = A + BG * LSG;
-    float4 a4[4], b4[4];
+    const float *A = lds + (kc & 1) * kBuf, *B = A + BG * LSG;
+    float4 a4[4];
+    float bv[4][4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) a4[rt] = *reinterpret_cast<const float4 *>(&A[(64 * wr + 16 * rt + i) * LSG + 4 * kq]);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const float4 *>(&Bt[(64 * wc + 16 * ct + i) * LSG + 4 * kq]);
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bv[r][ct] = B[(4 * kq + r) * BS + 64 * wc + 16 * ct + i];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const float av = r == 0 ? a4[rt].x : r == 1 ? a4[rt].y : r == 2 ? a4[rt].z : a4[rt].w;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const float bv = r == 0 ? b4[ct].x : r == 1 ? b4[ct].y : r == 2 ? b4[ct].z : b4[ct].w;
-          acc[rt][ct] = mfma16(av, bv, acc[rt][ct]);
-        }
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = mfma16(av, bv[r][ct], acc[rt][ct]);
       }
     if (kc + 1 < nk) stage((kc + 1) & 1);   // the other buffer: last read in chunk kc - 1, before the barrier below
     __syncthreads();
