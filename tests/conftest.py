@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A per-test time limit for the GPU tests (pytest-timeout, thread method: dumps every thread's stack, names the test and ends
+    the run): a kernel that never returns then fails ONE named test instead of holding the box until the caller's limit.  The
+    slowest GPU test takes ~10 s; NGPDE_TEST_TIMEOUT overrides the 300 s."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    limit = float(os.environ.get("NGPDE_TEST_TIMEOUT", "300"))
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(limit, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
