@@ -244,12 +244,16 @@ def test_dense_pair_streaming_backward(nwa, nwb, monkeypatch):
         Ra, Rb = rng.normal(size=(64, n)), rng.normal(size=(64, n))
         if mode == 1:
             monkeypatch.setenv("NGPDE_DENSE_NO_STREAM_BWD", "1")
-        ya, yb = F.dense_pair(A[0], A[2], A[3], 0, B[0], B[2], None, 0, row_divs_a=A[1], row_divs_b=B[1], n=n)
-        ((ya * torch.as_tensor(Ra.T, dtype=torch.float32, device=DEV)).sum() + (yb * torch.as_tensor(Rb.T, dtype=torch.float32, device=DEV)).sum()).backward()
+        # the shared block also comes back routed through the pair (passthrough): a further consumer's gradient w.r.t. it is
+        # added inside the pair's pullback launch (dx_addend)
+        Rx = rng.normal(size=(n, 64))
+        ya, yb, xp = F.dense_pair(A[0], A[2], A[3], 0, B[0], B[2], None, 0, row_divs_a=A[1], row_divs_b=B[1], n=n, passthrough=True)
+        ((ya * torch.as_tensor(Ra.T, dtype=torch.float32, device=DEV)).sum() + (yb * torch.as_tensor(Rb.T, dtype=torch.float32, device=DEV)).sum()
+         + (xp * torch.as_tensor(Rx, dtype=torch.float32, device=DEV)).sum()).backward()
         if mode == 1:
             monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD")
-        res.append((x, A, B, Ra, Rb))
-    (x, A, B, Ra, Rb), (x2, A2, B2, _, _) = res
+        res.append((x, A, B, Ra, Rb, Rx))
+    (x, A, B, Ra, Rb, Rx), (x2, A2, B2, _, _, _) = res
     close(x.grad, x2.grad.cpu().double().numpy(), rtol=2e-5, atol=2e-6)
     close(A[2].grad, A2[2].grad.cpu().double().numpy(), rtol=3e-4)
     close(B[2].grad, B2[2].grad.cpu().double().numpy(), rtol=3e-4)
@@ -264,7 +268,7 @@ def test_dense_pair_streaming_backward(nwa, nwb, monkeypatch):
         close(wt.grad, gr[0]["weight"].T, rtol=3e-4)
         if bias:
             close(b.grad, gr[0]["bias"].reshape(-1), rtol=3e-4)
-    close(x.grad, (dxs[0] + dxs[1]).T)
+    close(x.grad, (dxs[0] + dxs[1]).T + Rx)
 
 
 @pytest.mark.parametrize("nwa,nwb,douts", [((2, 2), (2,), (64, 64)), ((), (), (64, 48)), ((1, 3, 2), (3,), (40, 64))])
