@@ -682,8 +682,18 @@ __device__ __forceinline__ void stream_epilogue(const StreamOut &o, int n_narrow
 // Both kernels double-buffer the input images: the DMA of tile t + 1 is issued at the top of tile t into the buffer tile t - 1
 // left behind, and collected at the top of tile t + 1 -- a whole tile of arithmetic later.
 constexpr int kPairTR = 64;
+#ifdef NGPDE_STAMPS
+unsigned long long *g_pair_stamps = nullptr;   // diagnostic build only (tools/stamps_pair.py): [n_blocks][16], the workgroup's 4th tile
+#define PAIR_STAMP(k) do { if (threadIdx.x == 0 && stamps && it == 3) stamps[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#else
+#define PAIR_STAMP(k)
+#endif
 __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64_t n, int n_tiles, const float *__restrict__ x,
-                                                                           const StreamOut a, const StreamOut b) {
+                                                                           const StreamOut a, const StreamOut b
+#ifdef NGPDE_STAMPS
+                                                                           , unsigned long long *stamps
+#endif
+                                                                           ) {
   constexpr int TR = kPairTR;
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   // dyn: two buffers [TR][OS2], each the X image of a tile, then each output on its way out
@@ -710,8 +720,10 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
   for (; t < n_tiles; t += gridDim.x, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * (TR * OS2), *nxt = dyn + ((it + 1) & 1) * (TR * OS2);
+    PAIR_STAMP(0);
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // this tile's image has landed (collected below, a tile ago); the previous tile's outputs have left LDS
+    PAIR_STAMP(1);
     // narrow features of this tile's rows, then the next tile's image
     const int nr = tid >> 3, nf = tid & 7;   // (64 rows x 8 features: one value per thread)
     const float xv = nf < 4 ? narrow_value(a, 64, nf, row0 + nr, n) : narrow_value(b, 64, nf - 4, row0 + nr, n);
@@ -721,18 +733,25 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     for (int rt = 0; rt < TR / 32; ++rt) acca[rt] = accb[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mfma_rows_regs<TR, true>(cur, half, lane, wa, acca);
     mfma_rows_regs<TR, true>(cur, half, lane, wb, accb);
+    PAIR_STAMP(2);
     // collect the next tile's image HERE, behind the products and before this tile's stores are issued: a wait at the top of the
     // next tile would also wait for those stores (vmcnt counts them) -- a full store latency per tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PAIR_STAMP(3);
     xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();
+    PAIR_STAMP(4);
     stage_cols<TR>(cur, half, ct, lane, acca);
     __syncthreads();
+    PAIR_STAMP(5);
     stream_epilogue<TR, false>(a, na, xn, wn, cur, row0, n, tid, ba);
+    PAIR_STAMP(6);
     __syncthreads();
     stage_cols<TR>(cur, half, ct, lane, accb);
     __syncthreads();
+    PAIR_STAMP(7);
     stream_epilogue<TR, false>(b, nb, xn + 4, wn + kNarrow * 64, cur, row0, n, tid, bb);
+    PAIR_STAMP(8);
   }
 }
 
@@ -1221,7 +1240,11 @@ int32_t launch_dense_pair_fwd(int64_t n, const SegTable &ta, int dina, int douta
   static int cap = 0;   // resident workgroups of this kernel on this device (one occupancy query per process)
   if (!cap) cap = stream_grid(reinterpret_cast<const void *>(dense_pair_fwd_kernel), lds, 1 << 30);
   const int grid = std::min(n_tiles, cap);
+#ifdef NGPDE_STAMPS
+  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b, g_pair_stamps);
+#else
   hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b);
+#endif
   NGPDE_LAUNCH_CHECK("dense_pair_fwd_kernel");
   return NGPDE_OK;
 }
@@ -1256,3 +1279,10 @@ int32_t launch_dense_chain_fwd(int64_t n, const SegTable &t1, int din1, int act1
 }
 
 }  // namespace ngpde
+
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_pair_stamps(unsigned long long *buf) {
+  ngpde::g_pair_stamps = buf;
+  return 0;
+}
+#endif
