@@ -665,8 +665,8 @@ __device__ __forceinline__ void stream_epilogue(const StreamOut &o, int n_narrow
     const int64_t r = row0 + (tid >> 4) + 32 * p;
     if (r >= n || oc >= o.dout) continue;
     if (vec) {
-      if (o.save_z) *reinterpret_cast<float4 *>(o.save_z + r * o.dout + oc) = zz[p];
-      if (o.y) *reinterpret_cast<float4 *>(o.y + r * o.dout + oc) = aa[p];
+      if (o.save_z) nt_store4(o.save_z + r * o.dout + oc, zz[p]);
+      if (o.y) nt_store4(o.y + r * o.dout + oc, aa[p]);
     } else {
       const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
 #pragma unroll

@@ -185,6 +185,14 @@ __device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, co
   }
 }
 
+// streaming (non-temporal) 16-byte store for outputs far larger than the L2s that a later launch reads (pair / chain Dense
+// forwards: 143 -> 132 us and 173 -> 168 us at config 4; the pullback kernels' gradient arrays, consumed by the next launch, were
+// 0-3 % slower with it and keep plain stores)
+__device__ __forceinline__ void nt_store4(float *ptr, float4 v) {
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((v4f_){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_ *>(ptr));
+}
+
 // ---- fp32 MFMA -------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[l&15][l>>4], B[l>>4][l&15];
 // result register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (bitwise an fmaf chain), 256 FLOP/clk/CU.

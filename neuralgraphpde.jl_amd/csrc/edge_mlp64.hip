@@ -669,7 +669,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
             acc = mfma16(w4.w, gz[mt].w, acc);
           }
           dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), d1[ct]);
-          if (valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];
+          if (valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];   // (a non-temporal store here: +3 %)
         }
       }
       // ---- dz1 of the chunk -> LDS, lane group g16 sums the rows of targets g16 and g16 + 16 in edge order (= dP)
