@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256, 4) void dense_wide_fwd_kernel(int64_t n, SegTa
     const int64_t r = row0 + (tid >> 4) + 16 * p;
     if (r >= n || col0 + oc >= dout) continue;
     if (vec) {   // dout % 4 == 0: the four columns exist and the address is 16-byte aligned
-      if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + col0 + oc) = zz[p];
-      *reinterpret_cast<float4 *>(y + r * dout + col0 + oc) = aa[p];
+      if (save_z) nt_store4(save_z + r * dout + col0 + oc, zz[p]);
+      nt_store4(y + r * dout + col0 + oc, aa[p]);
     } else {
       const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
 #pragma unroll
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, co
       const int64_t r = row0 + 64 * wr + 16 * rt + (lane >> 4) + 4 * pp;
       const int c = col0 + 64 * wc + pc;
       if (r < n && c < dout) {
-        if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + c) = zz[pp];
-        *reinterpret_cast<float4 *>(y + r * dout + c) = aa[pp];
+        if (save_z) nt_store4(save_z + r * dout + c, zz[pp]);
+        nt_store4(y + r * dout + c, aa[pp]);
       }
     }
   }
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(kStreamThreads, 6) void dense_stream64_fwd_kernel(i
       const int64_t r = row0 + (tid >> 4) + 32 * p;
       if (r >= n || oc >= dout) continue;
       if (vec) {
-        if (save_z) *reinterpret_cast<float4 *>(save_z + r * dout + oc) = zz[p];
-        *reinterpret_cast<float4 *>(y + r * dout + oc) = aa[p];
+        if (save_z) nt_store4(save_z + r * dout + oc, zz[p]);
+        nt_store4(y + r * dout + oc, aa[p]);
       } else {
         const float z[4] = {zz[p].x, zz[p].y, zz[p].z, zz[p].w}, a4[4] = {aa[p].x, aa[p].y, aa[p].z, aa[p].w};
 #pragma unroll
