@@ -611,6 +611,30 @@ __device__ __forceinline__ void mfma_rows_regs(const float *t, int half, int lan
     }
   }
 }
+// Products of a tile with the NEXT tile's image(s) on their way by LDS-DMA.  The compiler puts s_waitcnt vmcnt(0) in front of
+// every LDS access it cannot prove disjoint from the destination of a global_load_lds in flight -- with both buffers carved
+// from one dynamic LDS array that is every access: the products would wait for the very prefetch they are meant to cover (and
+// for the previous tile's stores with it).  Issued inside a function whose image and destination pointers are __restrict__,
+// the DMA and the reads carry scoped no-alias information and the wait is not emitted; the caller collects the DMA itself
+// (s_waitcnt vmcnt(0), then a barrier) before anyone reads the destination.
+__device__ __forceinline__ unsigned lds_byte_addr(const void *ptr) { return (unsigned)(uintptr_t)ptr; }   // low half of a generic LDS pointer
+template <int TR, int NIMG, int NW>
+__device__ __forceinline__ void products_beside_dma(const float *__restrict__ cur, float *__restrict__ nxt, int img_stride, bool has_next,
+                                                    const float *x0, const float *x1, int64_t next_row0, int64_t n, int wave, int lane,
+                                                    int half, const f32x4 (&w0)[4], const f32x4 (&w1)[4], f32x4 (&acc0)[TR / 32],
+                                                    f32x4 (&acc1)[TR / 32]) {
+  if (has_next) {
+    dma_tile<TR>(x0, next_row0, n, nxt, wave, lane);
+    if (NIMG == 2) dma_tile<TR>(x1, next_row0, n, nxt + img_stride, wave, lane);
+  }
+  if (NIMG == 1) {   // one image, NW weight sets -> NW outputs
+    mfma_rows_regs<TR, true>(cur, half, lane, w0, acc0);
+    if (NW == 2) mfma_rows_regs<TR, true>(cur, half, lane, w1, acc1);
+  } else {           // two images, one weight set each -> one output
+    mfma_rows_regs<TR, true>(cur, half, lane, w0, acc0);
+    mfma_rows_regs<TR, true>(cur + img_stride, half, lane, w1, acc0);
+  }
+}
 template <int TR>
 __device__ __forceinline__ void stage_cols(float *tile, int half, int ct, int lane, const f32x4 (&acc)[TR / 32]) {
   const int i = lane & 15, kq = lane >> 4;
@@ -630,8 +654,21 @@ __device__ __forceinline__ void narrow_weights(const StreamOut &o, int kmain, fl
     wn[idx] = (kmain + f < o.din_all && c < o.dout) ? o.wt[(size_t)(kmain + f) * o.dout + c] : 0.f;
   }
 }
-__device__ __forceinline__ float narrow_value(const StreamOut &o, int kmain, int f, int64_t r, int64_t n) {
-  return (kmain + f < o.din_all && r < n) ? seg_load(o.segs, r, kmain + f) : 0.f;
+// A thread's narrow feature value on a row: where the feature lives is resolved once (narrow_ref), then one load per tile.
+// (Resolved per tile in the two arms of a branch -- features of Dense a in some lanes, of Dense b in others -- the two loads
+// target the same register, and the compiler waits for the first to land before it issues the second: a whole memory latency at
+// the top of every tile.)
+struct NarrowRef {
+  const float *ptr;   // column of the feature in its block (NULL: no such feature)
+  int width, row_div;
+};
+__device__ __forceinline__ NarrowRef narrow_ref(const StreamOut &o, int kmain, int f) {
+  if (kmain + f >= o.din_all) return NarrowRef{nullptr, 0, 1};
+  const SegRef r = seg_find(o.segs, kmain + f);
+  return NarrowRef{r.ptr + (kmain + f - r.offset), r.width, r.row_div};
+}
+__device__ __forceinline__ float narrow_fetch(const NarrowRef &q, int64_t r, int64_t n) {
+  return (q.ptr && r < n) ? q.ptr[seg_row(r, q.row_div) * q.width] : 0.f;
 }
 
 // epilogue of one Dense on a staged TR x 64 tile: thread (row = tid / 16 + 32 p, columns 4 (tid % 16) .. + 3) adds bias and the
@@ -683,6 +720,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamOut &o, int n_narrow
 // left behind, and collected at the top of tile t + 1 -- a whole tile of arithmetic later.
 constexpr int kPairTR = 64;
 #ifdef NGPDE_STAMPS
+extern unsigned long long *g_pair_stamps;
 unsigned long long *g_pair_stamps = nullptr;   // diagnostic build only (tools/stamps_pair.py): [n_blocks][16], the workgroup's 4th tile
 #define PAIR_STAMP(k) do { if (threadIdx.x == 0 && stamps && it == 3) stamps[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
 #else
@@ -715,9 +753,16 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     ba[j] = (a.bias && oc + j < a.dout) ? a.bias[oc + j] : 0.f;
     bb[j] = (b.bias && oc + j < b.dout) ? b.bias[oc + j] : 0.f;
   }
+  const int nr = tid >> 3, nf = tid & 7;   // (64 rows x 8 narrow features, 0..3 of a and 4..7 of b: one value per thread)
+  NarrowRef nq = narrow_ref(a, 64, nf & 3);
+  {
+    const NarrowRef nqb = narrow_ref(b, 64, nf & 3);
+    if (nf >= 4) nq = nqb;
+  }
+  const int G = (int)gridDim.x;
   int t = blockIdx.x, it = 0;
   if (t < n_tiles) dma_tile<TR>(x, (int64_t)t * TR, n, dyn, wave, lane);
-  for (; t < n_tiles; t += gridDim.x, ++it) {
+  for (; t < n_tiles; t += G, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * (TR * OS2), *nxt = dyn + ((it + 1) & 1) * (TR * OS2);
     PAIR_STAMP(0);
@@ -725,14 +770,11 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     __syncthreads();   // this tile's image has landed (collected below, a tile ago); the previous tile's outputs have left LDS
     PAIR_STAMP(1);
     // narrow features of this tile's rows, then the next tile's image
-    const int nr = tid >> 3, nf = tid & 7;   // (64 rows x 8 features: one value per thread)
-    const float xv = nf < 4 ? narrow_value(a, 64, nf, row0 + nr, n) : narrow_value(b, 64, nf - 4, row0 + nr, n);
-    if (t + (int)gridDim.x < n_tiles) dma_tile<TR>(x, (int64_t)(t + gridDim.x) * TR, n, nxt, wave, lane);
+    const float xv = narrow_fetch(nq, row0 + nr, n);
     f32x4 acca[TR / 32], accb[TR / 32];
 #pragma unroll
     for (int rt = 0; rt < TR / 32; ++rt) acca[rt] = accb[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows_regs<TR, true>(cur, half, lane, wa, acca);
-    mfma_rows_regs<TR, true>(cur, half, lane, wb, accb);
+    products_beside_dma<TR, 1, 2>(cur, nxt, 0, t + G < n_tiles, x, nullptr, (int64_t)(t + G) * TR, n, wave, lane, half, wa, wb, acca, accb);
     PAIR_STAMP(2);
     // collect the next tile's image HERE, behind the products and before this tile's stores are issued: a wait at the top of the
     // next tile would also wait for those stores (vmcnt counts them) -- a full store latency per tile
@@ -785,22 +827,23 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
     dma_tile<TR>(x0, (int64_t)tile * TR, n, bufp, wave, lane);
     if (NIN == 2) dma_tile<TR>(x1, (int64_t)tile * TR, n, bufp + TR * OS2, wave, lane);
   };
+  // narrow features of a tile's rows: thread -> (row tid / 8, feature tid % 8 < 4), resolved once
+  const int nr = tid >> 3, nf = tid & 7;
+  const NarrowRef nq = nf < kNarrow ? narrow_ref(l1, 64 * NIN, nf) : NarrowRef{nullptr, 0, 1};
+  const int G = (int)gridDim.x;
   int t = blockIdx.x, it = 0;
   if (t < n_tiles) dma_in(t, dyn);
-  for (; t < n_tiles; t += gridDim.x, ++it) {
+  for (; t < n_tiles; t += G, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * kBuf, *nxt = dyn + ((it + 1) & 1) * kBuf;
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // narrow features of this tile's rows: thread -> (row tid / 8, feature tid % 8 < 4)
-    const int nr = tid >> 3, nf = tid & 7;
-    const float xv = nf < kNarrow ? narrow_value(l1, 64 * NIN, nf, row0 + nr, n) : 0.f;
-    if (t + (int)gridDim.x < n_tiles) dma_in(t + gridDim.x, nxt);
+    const float xv = narrow_fetch(nq, row0 + nr, n);
     f32x4 acc[TR / 32];
 #pragma unroll
     for (int rt = 0; rt < TR / 32; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows_regs<TR, true>(cur, half, lane, w1[0], acc);
-    if (NIN == 2) mfma_rows_regs<TR, true>(cur + TR * OS2, half, lane, w1[NIN - 1], acc);
+    products_beside_dma<TR, NIN, 1>(cur, nxt, TR * OS2, t + G < n_tiles, x0, x1, (int64_t)(t + G) * TR, n, wave, lane, half,
+                                    w1[0], w1[NIN - 1], acc, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's images, before this tile's stores (see dense_pair_fwd_kernel)
     if (nf < kNarrow) xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();

@@ -228,11 +228,77 @@ struct DensePairBwdK {
   float *partial[2];   // [gridDim.x][din_s + 1][64]
 };
 
+// X tile of the rows row0 .. row0 + 63 -> swizzled LDS image: four DMA instructions per wave, four rows each
+__device__ __forceinline__ void dma_x_tile(const float *x, uint32_t row0, uint32_t n, float *img, int wave, int lane) {
+  const int rl = lane >> 4, s16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 4 + rl;
+    const uint32_t gr = min(row0 + r, n - 1);
+    const float *g = x + (gr * kD + 4 * (s16 ^ swz(r)));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(img) + ((wave * 4 + j) * 4) * 16 + lane),
+                                     16, 0, 0);
+  }
+}
+
+// The products of one tile of dense_pair64_bwd_kernel with the NEXT tile's X image on its way by LDS-DMA.  The pointers are
+// __restrict__ so that the DMA and the LDS reads carry no-alias information: without it the compiler puts s_waitcnt vmcnt(0) in
+// front of the first LDS read behind a global_load_lds (the read might alias the DMA's destination), i.e. waits for the
+// prefetch at once (dense_mfma.hip, products_beside_dma).
+__device__ __forceinline__ void pair_bwd_products(const float *__restrict__ ximg, float *__restrict__ xnext, const float *__restrict__ dz0,
+                                                  const float *__restrict__ dz1, const float *__restrict__ nblk, bool has_next,
+                                                  const float *x, uint32_t next_row0, uint32_t n, int wave, int lane, int opaque0,
+                                                  const f32x4 (&wf)[2][4], f32x4 (&accW)[2][4], f32x4 (&accN)[2], f32x4 (&accX)[4]) {
+  const int i = lane & 15, kq = lane >> 4;
+  if (has_next) dma_x_tile(x, next_row0, n, xnext, wave, lane);
+  // ---- dW_s += X^T dy_s: this wave's 16 input features x 64 outputs, both sides from one read of X; the narrow block
+  // (features + ones) x this wave's 16 outputs
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const int r = 4 * s + kq + opaque0;
+    const float av = ximg[sw_addr(r, 16 * wave + i)];
+    float d0[4], d1[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      d0[ob] = dz0[sw_addr(r, 16 * ob + i)];
+      d1[ob] = dz1[sw_addr(r, 16 * ob + i)];
+    }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      accW[0][ob] = mfma16(av, d0[ob], accW[0][ob]);
+      accW[1][ob] = mfma16(av, d1[ob], accW[1][ob]);
+    }
+    accN[0] = mfma16(nblk[r * 16 + i], dz0[sw_addr(r, 16 * wave + i)], accN[0]);
+    accN[1] = mfma16(nblk[(kTR + r) * 16 + i], dz1[sw_addr(r, 16 * wave + i)], accN[1]);
+  }
+  // ---- dX[:, 16 w .. + 15] = dy_a Wa^T + dy_b Wb^T: all 64 rows, this wave's 16 columns, weights from registers
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    accX[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = 16 * rt + i + opaque0;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(&dz0[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
+      const float4 a1 = *reinterpret_cast<const float4 *>(&dz1[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
+      accX[rt] = mfma16(a0.x, wf[0][kh][0], accX[rt]);
+      accX[rt] = mfma16(a0.y, wf[0][kh][1], accX[rt]);
+      accX[rt] = mfma16(a0.z, wf[0][kh][2], accX[rt]);
+      accX[rt] = mfma16(a0.w, wf[0][kh][3], accX[rt]);
+      accX[rt] = mfma16(a1.x, wf[1][kh][0], accX[rt]);
+      accX[rt] = mfma16(a1.y, wf[1][kh][1], accX[rt]);
+      accX[rt] = mfma16(a1.z, wf[1][kh][2], accX[rt]);
+      accX[rt] = mfma16(a1.w, wf[1][kh][3], accX[rt]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePairBwdK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *ldsDz0 = lds, *ldsDz1 = lds + kTR * kD;   // [64][64] each, swizzled
-  float *ldsX = ldsDz1 + kTR * kD;                 // [64][64] swizzled DMA image of X, later [64][68] dX on its way out
-  float *ldsN = ldsX + kTR * kPS;                  // [2][64][16]: per side the narrow features (columns 0..3), a column of ones
+  float *ldsX0 = ldsDz1 + kTR * kD;                // two [64][64] swizzled DMA images of X (this tile's, the next one's on its
+  float *ldsX1 = ldsX0 + kTR * kPS;                // way); this tile's becomes [64][68] dX on its way out
+  float *ldsN = ldsX1 + kTR * kPS;                 // [2][64][16]: per side the narrow features (columns 0..3), a column of ones
                                                    // (4: the bias gradient), zeros -- a 16-wide "input block" for the matrix pipe
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,25 +349,21 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
     nv1 = b1[(rc / (uint32_t)d1) * (uint32_t)w1];
   };
 
-  int tile = blockIdx.x;
-  if (tile < p.n_tiles) fetch(tile);
-  for (; tile < p.n_tiles; tile += gridDim.x) {
+  // Per tile: the tile's dy rows and narrow values (registers, loaded a tile ago) -> LDS; then, with the next tile's loads
+  // and X image in flight, the products; the loads are collected BEFORE this tile's dX stores are issued (vmcnt counts stores
+  // too: collected at the top of the next tile they would cost a store latency per tile).
+  int tile = blockIdx.x, it = 0;
+  if (tile < p.n_tiles) {
+    fetch(tile);
+    dma_x_tile(p.x, (uint32_t)tile * kTR, (uint32_t)p.n, ldsX0, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (; tile < p.n_tiles; tile += gridDim.x, ++it) {
     const int64_t row0 = (int64_t)tile * kTR;
+    float *cur = (it & 1) ? ldsX1 : ldsX0, *nxt = (it & 1) ? ldsX0 : ldsX1;
     int opaque0;   // see dense_stream64_bwd_kernel
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
-    __syncthreads();
-    {   // X tile by LDS-DMA
-      const int rl = lane >> 4, s16 = lane & 15;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 4 + rl;
-        const uint32_t gr = min((uint32_t)row0 + r, (uint32_t)(p.n - 1));
-        const float *g = p.x + (gr * kD + 4 * (s16 ^ swz(r)));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsX) + ((wave * 4 + j) * 4) * 16 + lane),
-                                         16, 0, 0);
-      }
-    }
+    __syncthreads();   // the previous tile's dz tiles and outgoing dX are consumed
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       const int r = rg + 16 * pp;
@@ -309,65 +371,32 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
       *reinterpret_cast<float4 *>(&ldsDz1[r * kD + 4 * (qc ^ swz(r))]) = dyr[1][pp];
     }
     *reinterpret_cast<float2 *>(&ldsN[(nsd * kTR + nrow) * 16 + nf]) = make_float2(nv0, nv1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int tnext = tile + gridDim.x;
     if (tnext < p.n_tiles) fetch(tnext);
-
-    // ---- dW_s += X^T dy_s: this wave's 16 input features x 64 outputs, both sides from one read of X; the narrow block
-    // (features + ones) x this wave's 16 outputs
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int r = 4 * s + kq + opaque0;
-      const float av = ldsX[sw_addr(r, 16 * wave + i)];
-      float d0[4], d1[4];
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob) {
-        d0[ob] = ldsDz0[sw_addr(r, 16 * ob + i)];
-        d1[ob] = ldsDz1[sw_addr(r, 16 * ob + i)];
-      }
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob) {
-        accW[0][ob] = mfma16(av, d0[ob], accW[0][ob]);
-        accW[1][ob] = mfma16(av, d1[ob], accW[1][ob]);
-      }
-      accN[0] = mfma16(ldsN[r * 16 + i], ldsDz0[sw_addr(r, 16 * wave + i)], accN[0]);
-      accN[1] = mfma16(ldsN[(kTR + r) * 16 + i], ldsDz1[sw_addr(r, 16 * wave + i)], accN[1]);
-    }
-    // ---- dX[:, 16 w .. + 15] = dy_a Wa^T + dy_b Wb^T: all 64 rows, this wave's 16 columns, weights from registers
     f32x4 accX[4];
+    pair_bwd_products(cur, nxt, ldsDz0, ldsDz1, ldsN, tnext < p.n_tiles, p.x, (uint32_t)tnext * kTR, (uint32_t)p.n, wave, lane, opaque0, wf,
+                      accW, accN, accX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 addv[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};   // the addend's rows: in flight while dX is staged
+    if (p.dx_add) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      accX[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int r = 16 * rt + i + opaque0;
-#pragma unroll
-      for (int kh = 0; kh < 4; ++kh) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(&ldsDz0[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
-        const float4 a1 = *reinterpret_cast<const float4 *>(&ldsDz1[r * kD + 4 * ((4 * kh + kq) ^ swz(r))]);
-        accX[rt] = mfma16(a0.x, wf[0][kh][0], accX[rt]);
-        accX[rt] = mfma16(a0.y, wf[0][kh][1], accX[rt]);
-        accX[rt] = mfma16(a0.z, wf[0][kh][2], accX[rt]);
-        accX[rt] = mfma16(a0.w, wf[0][kh][3], accX[rt]);
-        accX[rt] = mfma16(a1.x, wf[1][kh][0], accX[rt]);
-        accX[rt] = mfma16(a1.y, wf[1][kh][1], accX[rt]);
-        accX[rt] = mfma16(a1.z, wf[1][kh][2], accX[rt]);
-        accX[rt] = mfma16(a1.w, wf[1][kh][3], accX[rt]);
+      for (int pp = 0; pp < 4; ++pp) {
+        const int64_t r = min(row0 + rg + 16 * pp, p.n - 1);
+        addv[pp] = *reinterpret_cast<const float4 *>(p.dx_add + r * kD + 4 * qc);
       }
     }
     __syncthreads();   // every wave is done with the X image
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) ldsX[(16 * rt + 4 * kq + reg) * kPS + 16 * wave + i] = accX[rt][reg];
+      for (int reg = 0; reg < 4; ++reg) cur[(16 * rt + 4 * kq + reg) * kPS + 16 * wave + i] = accX[rt][reg];
     __syncthreads();
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       const int r = rg + 16 * pp;
-      if (row0 + r < p.n) {
-        float4 v = *reinterpret_cast<const float4 *>(&ldsX[r * kPS + 4 * qc]);
-        if (p.dx_add) v = f4_add(v, *reinterpret_cast<const float4 *>(p.dx_add + (row0 + r) * kD + 4 * qc));
-        *reinterpret_cast<float4 *>(p.dx + (row0 + r) * kD + 4 * qc) = v;
-      }
+      if (row0 + r < p.n)
+        *reinterpret_cast<float4 *>(p.dx + (row0 + r) * kD + 4 * qc) = f4_add(*reinterpret_cast<const float4 *>(&cur[r * kPS + 4 * qc]), addv[pp]);
     }
   }
 
@@ -487,7 +516,7 @@ int32_t launch_dense_pair_bwd(int64_t n, const SegTable &ta, int dina, const flo
     k.n_narrow[sd] = nn;
     for (int f = nn; f < kMaxNarrow; ++f) { k.nx[sd][f] = k.x; k.nwidth[sd][f] = kD; k.ndiv[sd][f] = 1; k.nfeat[sd][f] = 0; }
   }
-  const size_t lds = ((size_t)2 * kTR * kD + (size_t)kTR * kPS + (size_t)2 * kTR * 16) * sizeof(float);
+  const size_t lds = ((size_t)2 * kTR * kD + (size_t)2 * kTR * kPS + (size_t)2 * kTR * 16) * sizeof(float);   // 74.8 KB: two per CU
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_pair64_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return fail(NGPDE_ERR_HIP, "dense_pair64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(e));
   hipLaunchKernelGGL(dense_pair64_bwd_kernel, dim3(grid), dim3(kBT), lds, stream, k);
