@@ -599,13 +599,13 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
         const int r = ew & 0xff, slot = valid ? (int)(ew >> 8) : zero_slot;
         const size_t pe = (size_t)(ldsRs[r] + (k - ldsOff[r]));
         // incoming gradient rows of the edge's target (g = dout / deg for mean): issued now, used behind the first product
+        // (kept raw until then: scaled at the load, the compiler loads them one after the other into one register
+        // quad, each waited for before the next is issued -- three exposed round trips per slice)
         float4 gz[4];
-        {
-          const float *grow = p.dout + (size_t)ldsNode[r] * kW + 4 * kq;
-          const float inv = valid ? ldsInv[r] : 0.f;
+        const float *grow = p.dout + (size_t)ldsNode[r] * kW + 4 * kq;
+        const float inv = valid ? ldsInv[r] : 0.f;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) gz[mt] = f4_scale(inv, *reinterpret_cast<const float4 *>(grow + 16 * mt));
-        }
+        for (int mt = 0; mt < 4; ++mt) gz[mt] = *reinterpret_cast<const float4 *>(grow + 16 * mt);
         float4 a1[4], d1[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
           }
           const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
           const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
-          gz[mt] = f4_mul(gz[mt], make_float4(dact_c<ACT2>(z2.x), dact_c<ACT2>(z2.y), dact_c<ACT2>(z2.z), dact_c<ACT2>(z2.w)));
+          gz[mt] = f4_mul(f4_scale(inv, gz[mt]), make_float4(dact_c<ACT2>(z2.x), dact_c<ACT2>(z2.y), dact_c<ACT2>(z2.z), dact_c<ACT2>(z2.w)));
           dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
         }
         // ---- dW2 += a1^T dz2 over this wave's 16 edges: both operands transposed through the wave's LDS rows
