@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kStreamThreads, 6) void dense_stream64_fwd_kernel(i
                                          16, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt0();
     __syncthreads();
     f32x4 acc[4];
 #pragma unroll
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * (TR * OS2), *nxt = dyn + ((it + 1) & 1) * (TR * OS2);
     PAIR_STAMP(0);
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it == 0) wait_vmcnt0();
     __syncthreads();   // this tile's image has landed (collected below, a tile ago); the previous tile's outputs have left LDS
     PAIR_STAMP(1);
     // narrow features of this tile's rows, then the next tile's image
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     PAIR_STAMP(2);
     // collect the next tile's image HERE, behind the products and before this tile's stores are issued: a wait at the top of the
     // next tile would also wait for those stores (vmcnt counts them) -- a full store latency per tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt0();
     PAIR_STAMP(3);
     xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
   for (; t < n_tiles; t += G, ++it) {
     const int64_t row0 = (int64_t)t * TR;
     float *cur = dyn + (it & 1) * kBuf, *nxt = dyn + ((it + 1) & 1) * kBuf;
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it == 0) wait_vmcnt0();
     __syncthreads();
     const float xv = narrow_fetch(nq, row0 + nr, n);
     f32x4 acc[TR / 32];
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
     for (int rt = 0; rt < TR / 32; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     products_beside_dma<TR, NIN, 1>(cur, nxt, TR * OS2, t + G < n_tiles, x0, x1, (int64_t)(t + G) * TR, n, wave, lane, half,
                                     w1[0], w1[NIN - 1], acc, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's images, before this tile's stores (see dense_pair_fwd_kernel)
+    wait_vmcnt0();   // the next tile's images, before this tile's stores (see dense_pair_fwd_kernel)
     if (nf < kNarrow) xn[nr * kNarrowAll + nf] = xv;
     __syncthreads();
     stage_cols<TR>(cur, half, ct, lane, acc);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseB
 #pragma unroll
       for (int f = 0; f < kMaxNarrow; ++f) nacc[f] = f4_fma(nxr[pp][f], dz, nacc[f]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt0();
     __syncthreads();
     const int tnext = tile + gridDim.x;
     if (tnext < p.n_tiles) fetch(tnext);   // in flight during the MFMAs
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseB
       if (b > 0) {   // the second block's tile takes the place of the first one's outgoing dX
         __syncthreads();
         dma_x(b);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also collects the prefetch: second blocks are the rarer case)
+        wait_vmcnt0();   // (also collects the prefetch: second blocks are the rarer case)
         __syncthreads();
       }
       // ---- dW_b += X_b^T dz: this wave's 16 input features x 64 outputs, contraction over the tile's rows 4 s + kq
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
     fetch(tile);
     dma_x_tile(p.x, (uint32_t)tile * kTR, (uint32_t)p.n, ldsX0, wave, lane);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt0();
   for (; tile < p.n_tiles; tile += gridDim.x, ++it) {
     const int64_t row0 = (int64_t)tile * kTR;
     float *cur = (it & 1) ? ldsX1 : ldsX0, *nxt = (it & 1) ? ldsX0 : ldsX1;
@@ -377,13 +377,18 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
     f32x4 accX[4];
     pair_bwd_products(cur, nxt, ldsDz0, ldsDz1, ldsN, tnext < p.n_tiles, p.x, (uint32_t)tnext * kTR, (uint32_t)p.n, wave, lane, opaque0, wf,
                       accW, accN, accX);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float4 addv[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};   // the addend's rows: in flight while dX is staged
+    wait_vmcnt0();   // (tracked by the compiler: behind an asm wait it would drain vmcnt again at the next barrier, with the addend
+                     // loads below in flight)
+    // the addend's rows: in flight while dX is staged.  Inline loads: written as C++ loads the compiler sinks each of them
+    // into the guarded store below -- load, wait (for the previous store with it), add, store, four times in a row
+    f32x4 addv[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) addv[pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.dx_add) {
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
-        const int64_t r = min(row0 + rg + 16 * pp, p.n - 1);
-        addv[pp] = *reinterpret_cast<const float4 *>(p.dx_add + r * kD + 4 * qc);
+        const float *src = p.dx_add + min(row0 + rg + 16 * pp, p.n - 1) * kD + 4 * qc;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(addv[pp]) : "v"(src));
       }
     }
     __syncthreads();   // every wave is done with the X image
@@ -392,11 +397,14 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) cur[(16 * rt + 4 * kq + reg) * kPS + 16 * wave + i] = accX[rt][reg];
     __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(addv[0]), "+v"(addv[1]), "+v"(addv[2]), "+v"(addv[3]) : : "memory");
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       const int r = rg + 16 * pp;
-      if (row0 + r < p.n)
-        *reinterpret_cast<float4 *>(p.dx + (row0 + r) * kD + 4 * qc) = f4_add(*reinterpret_cast<const float4 *>(&cur[r * kPS + 4 * qc]), addv[pp]);
+      if (row0 + r < p.n) {
+        const float4 v = *reinterpret_cast<const float4 *>(&cur[r * kPS + 4 * qc]);
+        *reinterpret_cast<float4 *>(p.dx + (row0 + r) * kD + 4 * qc) = make_float4(v.x + addv[pp][0], v.y + addv[pp][1], v.z + addv[pp][2], v.w + addv[pp][3]);
+      }
     }
   }
 

@@ -193,6 +193,15 @@ __device__ __forceinline__ void nt_store4(float *ptr, float4 v) {
   __builtin_nontemporal_store((v4f_){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_ *>(ptr));
 }
 
+// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count pass tracks.  An asm s_waitcnt is invisible to it: it keeps
+// counting an LDS-DMA (global_load_lds) as pending and drains vmcnt again at the next barrier or LDS access -- with whatever
+// loads and stores are in flight by then.  (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15.)
+__device__ __forceinline__ void wait_vmcnt0() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
+}
+
 // ---- fp32 MFMA -------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[l&15][l>>4], B[l>>4][l&15];
 // result register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (bitwise an fmaf chain), 256 FLOP/clk/CU.
