@@ -22,7 +22,7 @@ namespace {
 
 constexpr int kET = 16;      // edges per MFMA tile
 constexpr int kEB = 64;      // edges staged per pass of the forward (4 tiles)
-constexpr int kEBb = 32;     // ... of the pullback (z and dm rows beside T^T: 59 KB at 128 x 64, two workgroups per CU)
+constexpr int kEBb = 32;     // ... of the pullback (z and dm rows: 25 KB at 128 x 64)
 
 // rows of a per-edge array ([E][w], p order) of the edges q0 .. q0 + nb of the source's list -> LDS [kEB][w + 4], zero rows
 // beyond nb; 16-byte loads (w % 4 == 0)
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const
 }
 
 // ---- pullback -------------------------------------------------------------------------------------------------------------
-template <int KD>
-__global__ __launch_bounds__(256) void gno_apply_mfma_bwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
+template <int KD, int NOB>   // NOB: bound on cout / 16 (8 or 16) -- sizes the register copy of T_j's columns
+__global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
                                                                  const float *__restrict__ T, const float *__restrict__ z,
                                                                  const float *__restrict__ dm, float *__restrict__ dT,
                                                                  float *__restrict__ dBh, float *__restrict__ dz) {
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_bwd_kernel(int cout, const
   const int DS = cout + 4;
   float *zl = sh;                                   // [kEBb][KD + 4]
   float *dml = zl + kEBb * ZS;                       // [kEBb][cout + 4]
-  float *Ttl = dml + kEBb * DS;                      // [KD][cout + 4]   T_j transposed: the contraction index of dz = T^T dm contiguous
   __shared__ int pl[kEBb];
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,12 +149,19 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_bwd_kernel(int cout, const
   constexpr int MAXT = 8;                           // tiles per wave kept in registers per sweep (cout * KD <= 128 * 64 in one sweep)
   const int ntile = nct * NKT;
   const float *Tj = T + (size_t)j * cout * KD;
+  // dz = DM x T_j: the (edge tile, k tile) ids a wave takes (wave, wave + 4, ...) all have k tile wave % NKT (NKT divides 4), so
+  // the wave keeps ITS 16 columns of T_j in registers for the node's whole edge list -- bT[ob][r] = T_j[16 ob + 4 kq + r][16 kt + i],
+  // 4 registers per 16 outputs -- and T_j never touches LDS (a transposed copy of it there was 34 of the workgroup's 59 KB at
+  // 128 x 64: two workgroups per CU; without it five fit)
+  const int ktw = wave % NKT;
+  float bT[NOB][4];
   if (dz && rs < re) {
-    for (int idx = tid; idx < cout * (KD / 4); idx += 256) {
-      const int o = idx / (KD / 4), k4 = idx - o * (KD / 4);
-      const float4 v = reinterpret_cast<const float4 *>(Tj + (size_t)o * KD)[k4];
-      Ttl[(4 * k4 + 0) * DS + o] = v.x; Ttl[(4 * k4 + 1) * DS + o] = v.y; Ttl[(4 * k4 + 2) * DS + o] = v.z; Ttl[(4 * k4 + 3) * DS + o] = v.w;
-    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+      if (ob < nct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bT[ob][r] = Tj[(size_t)(16 * ob + 4 * kq + r) * KD + 16 * ktw + i];
+      }
   }
   float bsum = 0.f;                                 // dBh: thread tid < cout sums column tid of the dm rows
   for (int sweep = 0; sweep * 4 * MAXT < ntile; ++sweep) {   // one sweep over the edge list per 32 dT tiles (a single sweep at 128 x 64)
@@ -177,20 +183,21 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_bwd_kernel(int cout, const
         if (dz) {
           // DZ[edge][kk] = sum_o DM[edge][o] T[o][kk]: tiles (edge tile et, k tile kt), spread over the waves
           for (int id = wave; id < net * NKT; id += 4) {
-            const int et = id / NKT, kt = id - et * NKT;
+            const int et = id / NKT;   // (k tile: ktw)
             f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int ob = 0; ob < nct; ++ob) {
-              const float4 a4 = *reinterpret_cast<const float4 *>(&dml[(et * kET + i) * DS + 16 * ob + 4 * kq]);
-              const float4 b4 = *reinterpret_cast<const float4 *>(&Ttl[(kt * 16 + i) * DS + 16 * ob + 4 * kq]);
-              d = mfma16(a4.x, b4.x, d);
-              d = mfma16(a4.y, b4.y, d);
-              d = mfma16(a4.z, b4.z, d);
-              d = mfma16(a4.w, b4.w, d);
-            }
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+              if (ob < nct) {   // uniform
+                const float4 a4 = *reinterpret_cast<const float4 *>(&dml[(et * kET + i) * DS + 16 * ob + 4 * kq]);
+                d = mfma16(a4.x, bT[ob][0], d);
+                d = mfma16(a4.y, bT[ob][1], d);
+                d = mfma16(a4.z, bT[ob][2], d);
+                d = mfma16(a4.w, bT[ob][3], d);
+              }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int e = et * kET + 4 * kq + r;
-              if (e < nb) dz[(size_t)pl[e] * KD + kt * 16 + i] = d[r];
+              if (e < nb) dz[(size_t)pl[e] * KD + ktw * 16 + i] = d[r];
             }
           }
         }
@@ -229,7 +236,7 @@ inline bool no_gno_mfma_env() {
   const char *e = std::getenv("NGPDE_NO_GNO_MFMA");
   return e && e[0] == '1';
 }
-inline size_t gno_mfma_bwd_lds(int cout, int kdim) { return (size_t)(kEBb * (kdim + 4) + kEBb * (cout + 4) + kdim * (cout + 4)) * sizeof(float); }
+inline size_t gno_mfma_bwd_lds(int cout, int kdim) { return (size_t)(kEBb * (kdim + 4) + kEBb * (cout + 4)) * sizeof(float); }
 
 }  // namespace
 
@@ -277,17 +284,26 @@ int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, cons
   if (g->n_nodes == 0) return NGPDE_OK;
   const dim3 grid((unsigned)g->n_nodes), block(256);
   const size_t lds = gno_mfma_bwd_lds(cout, kdim);
-#define NGPDE_GNO_B(KK)                                                                                                          \
+#define NGPDE_GNO_B(KK, NOB)                                                                                                     \
   do {                                                                                                                           \
     if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit: raise it for this kernel (cheap, idempotent) */               \
-      NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK>),                        \
+      NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK, NOB>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL(gno_apply_mfma_bwd_kernel<KK>, grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, dBh, dz); \
+    hipLaunchKernelGGL((gno_apply_mfma_bwd_kernel<KK, NOB>), grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, \
+                       dBh, dz);                                                                                                 \
   } while (0)
-  switch (kdim) {
-    case 16: NGPDE_GNO_B(16); break;
-    case 32: NGPDE_GNO_B(32); break;
-    default: NGPDE_GNO_B(64); break;
+  if (cout <= 128) {
+    switch (kdim) {
+      case 16: NGPDE_GNO_B(16, 8); break;
+      case 32: NGPDE_GNO_B(32, 8); break;
+      default: NGPDE_GNO_B(64, 8); break;
+    }
+  } else {
+    switch (kdim) {
+      case 16: NGPDE_GNO_B(16, 16); break;
+      case 32: NGPDE_GNO_B(32, 16); break;
+      default: NGPDE_GNO_B(64, 16); break;
+    }
   }
 #undef NGPDE_GNO_B
   NGPDE_LAUNCH_CHECK("gno_apply_mfma_bwd_kernel");
