@@ -430,6 +430,125 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, co
   }
 }
 
+// ---- the same 128 x 128 tiles for the two pullbacks of such a layer, with the contraction split over workgroups -----------------
+//   input pullback   dX [n][din]   = dz [n][dout] x Wt^T          (contraction over dout: both operands contraction-contiguous)
+//   weight pullback  dWt[din][dout] = X^T [din][n] x dz [n][dout]  (contraction over the rows: both operands row-major in k)
+// C [M][N] (+)= A x B over k in [z kper, (z + 1) kper), z = blockIdx.z: split 0 writes c0, split z > 0 writes cpart + (z - 1)
+// part_stride (the callers' add_partials / dense_weight_reduce passes sum the slabs in a fixed order).  A_MN: A is stored
+// [k][lda] with m contiguous (else [m][lda], k contiguous); B_K: B is stored [n][ldb] with k contiguous (else [k][ldb]).  A
+// contraction-contiguous operand is staged as [128][16 + 4] and read as one 16-byte fragment per 16 x 4 block; the other kind
+// stays row-major [16][128 + 4] and is read 4 bytes at a time (dense_gemm128_fwd_kernel's two forms).  K, kper multiples of 16;
+// M, N multiples of 4.
+template <bool A_MN, bool B_K>
+__global__ __launch_bounds__(256, 3) void dense_gemm128_split_kernel(int M, int N, int K, int kper, const float *__restrict__ A, int lda,
+                                                                     const float *__restrict__ B, int ldb, float *__restrict__ c0,
+                                                                     float *__restrict__ cpart, size_t part_stride, int ldc) {
+  constexpr int BS = BG + 4, kOp = BG * LSG, kBuf = 2 * kOp;   // per buffer: two operand tiles of at most 128 x 20 floats
+  __shared__ __attribute__((aligned(16))) float lds[2 * kBuf];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * BG, n0 = blockIdx.y * BG;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  float *C = blockIdx.z == 0 ? c0 : cpart + (size_t)(blockIdx.z - 1) * part_stride;
+  // staging roles: contraction-contiguous operand: float4 (row = tid / 4 + 64 p, k = 4 (tid % 4)); row-major-in-k operand: float4
+  // (k = tid / 32 + 8 p, column 4 (tid % 32) .. + 3); rows / columns past the end re-read the last ones (never stored)
+  const int kr = tid >> 2, kk = 4 * (tid & 3), rk = tid >> 5, rc = 4 * (tid & 31);
+  const float *pa0, *pa1, *pb0, *pb1;
+  if (A_MN) { pa0 = A + (size_t)rk * lda + min(m0 + rc, M - 4); pa1 = pa0 + (size_t)8 * lda; }
+  else { pa0 = A + (size_t)min(m0 + kr, M - 1) * lda + kk; pa1 = A + (size_t)min(m0 + kr + 64, M - 1) * lda + kk; }
+  if (B_K) { pb0 = B + (size_t)min(n0 + kr, N - 1) * ldb + kk; pb1 = B + (size_t)min(n0 + kr + 64, N - 1) * ldb + kk; }
+  else { pb0 = B + (size_t)rk * ldb + min(n0 + rc, N - 4); pb1 = pb0 + (size_t)8 * ldb; }
+  float4 areg0, areg1, breg0, breg1;
+  auto fetch = [&](int k0) {
+    areg0 = *reinterpret_cast<const float4 *>(A_MN ? pa0 + (size_t)k0 * lda : pa0 + k0);
+    areg1 = *reinterpret_cast<const float4 *>(A_MN ? pa1 + (size_t)k0 * lda : pa1 + k0);
+    breg0 = *reinterpret_cast<const float4 *>(B_K ? pb0 + k0 : pb0 + (size_t)k0 * ldb);
+    breg1 = *reinterpret_cast<const float4 *>(B_K ? pb1 + k0 : pb1 + (size_t)k0 * ldb);
+  };
+  auto stage = [&](int buf) {
+    float *At = lds + buf * kBuf, *Bt = At + kOp;
+    if (A_MN) {
+      *reinterpret_cast<float4 *>(&At[rk * BS + rc]) = areg0;
+      *reinterpret_cast<float4 *>(&At[(rk + 8) * BS + rc]) = areg1;
+    } else {
+      *reinterpret_cast<float4 *>(&At[kr * LSG + kk]) = areg0;
+      *reinterpret_cast<float4 *>(&At[(kr + 64) * LSG + kk]) = areg1;
+    }
+    if (B_K) {
+      *reinterpret_cast<float4 *>(&Bt[kr * LSG + kk]) = breg0;
+      *reinterpret_cast<float4 *>(&Bt[(kr + 64) * LSG + kk]) = breg1;
+    } else {
+      *reinterpret_cast<float4 *>(&Bt[rk * BS + rc]) = breg0;
+      *reinterpret_cast<float4 *>(&Bt[(rk + 8) * BS + rc]) = breg1;
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = kend > kbeg ? (kend - kbeg) / BKG : 0;   // (an empty split writes zeros: the reduce passes read every slab)
+  if (nk > 0) {
+    fetch(kbeg);
+    stage(0);
+  }
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) fetch(kbeg + (kc + 1) * BKG);   // in flight during the MFMAs
+    const float *At = lds + (kc & 1) * kBuf, *Bt = At + kOp;
+    float av[4][4], bv[4][4];   // [r][tile]
+    if (A_MN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[r][rt] = At[(4 * kq + r) * BS + 64 * wr + 16 * rt + i];
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(&At[(64 * wr + 16 * rt + i) * LSG + 4 * kq]);
+        av[0][rt] = a4.x; av[1][rt] = a4.y; av[2][rt] = a4.z; av[3][rt] = a4.w;
+      }
+    }
+    if (B_K) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(&Bt[(64 * wc + 16 * ct + i) * LSG + 4 * kq]);
+        bv[0][ct] = b4.x; bv[1][ct] = b4.y; bv[2][ct] = b4.z; bv[3][ct] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bv[r][ct] = Bt[(4 * kq + r) * BS + 64 * wc + 16 * ct + i];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = mfma16(av[r][rt], bv[r][ct], acc[rt][ct]);
+    if (kc + 1 < nk) stage((kc + 1) & 1);
+    __syncthreads();
+  }
+  // this wave's 64 x 64 outputs, 16 rows at a time through its own LDS patch, as full 256-byte row segments
+  float *patch = lds + wave * (16 * OS2);
+  const int pc = 4 * (lane & 15);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) patch[(4 * kq + reg) * OS2 + 16 * ct + i] = acc[rt][ct][reg];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int r = m0 + 64 * wr + 16 * rt + (lane >> 4) + 4 * pp, c = n0 + 64 * wc + pc;
+      if (r < M && c < N) *reinterpret_cast<float4 *>(C + (size_t)r * ldc + c) = *reinterpret_cast<const float4 *>(&patch[((lane >> 4) + 4 * pp) * OS2 + pc]);
+    }
+  }
+}
+
 // ---- streaming form of the wide forward for a 64-deep contraction and <= 64 outputs (the node-level Dense of the edge-function
 // layers: h => 64, [h | d | theta] => 64).  Persistent workgroups (one resident wave of them, three per CU) walk the 128-row
 // tiles; W^T is staged once per workgroup; the WHOLE 128 x 64 input tile goes memory -> LDS by LDS-DMA in one burst (32 KB in
@@ -1202,6 +1321,20 @@ int32_t launch_dense_bwd_input_splitk(int64_t n, float *dx, int din, int dout, c
   const int ns = dense_bwd_input_splits(n, din, dout);
   const int oper = ((dout + ns - 1) / ns + BK2 - 1) / BK2 * BK2;
   const int nz = (dout + oper - 1) / oper;
+  {   // 128 x 128 tiles (GNOConv's T = W2 (x) h: 4096 x 128 <= 8192)
+    static const bool no_gemm = getenv("NGPDE_DENSE_NO_GEMM128") != nullptr;
+    if (!no_gemm && nz > 1 && din >= BG && din % 4 == 0 && dout % BKG == 0 && oper % BKG == 0 && n < (1 << 30) &&
+        ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(part)) & 15) == 0) {
+      hipLaunchKernelGGL((dense_gemm128_split_kernel<false, true>), dim3((unsigned)((n + BG - 1) / BG), (din + BG - 1) / BG, nz), dim3(256), 0,
+                         stream, (int)n, din, dout, oper, dz, dout, wt, dout, dx, part, (size_t)n * din, din);
+      NGPDE_LAUNCH_CHECK("dense_gemm128_split_kernel (input pullback)");
+      const int64_t count = n * din;
+      hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256), 0, stream, count,
+                         nz - 1, (size_t)n * din, part, dx);
+      NGPDE_LAUNCH_CHECK("add_partials_kernel");
+      return NGPDE_OK;
+    }
+  }
   SegGrad segs;
   segs.n = 1; segs.ptr[0] = dx; segs.width[0] = din;
   for (int i = 1; i <= 4; ++i) segs.offset[i] = din;
@@ -1238,6 +1371,18 @@ int32_t launch_dense_seg_bwd_weight(int64_t n, const SegTable &segs, int din, in
   if (dout == 0) return NGPDE_OK;
   const int nchunk = dense_weight_chunks(n, din, dout);
   const int64_t rpc = std::max<int64_t>(BK, (((n + nchunk - 1) / nchunk) + BK - 1) / BK * BK);
+  {   // 128 x 128 tiles for a wide layer without bias gradient (GNOConv's T): slabs in the layout dense_weight_reduce_kernel sums
+    static const bool no_gemm = getenv("NGPDE_DENSE_NO_GEMM128") != nullptr;
+    if (!no_gemm && db == nullptr && nchunk > 1 && segs.n == 1 && segs.vec[0] && segs.row_div[0] == 1 && din >= BG && din % 4 == 0 &&
+        dout >= BG && dout % 4 == 0 && n % BKG == 0 && n < (1 << 30) &&
+        ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0) {
+      const size_t slab = (size_t)(din + 1) * dout;
+      hipLaunchKernelGGL((dense_gemm128_split_kernel<true, false>), dim3((din + BG - 1) / BG, (dout + BG - 1) / BG, nchunk), dim3(256), 0, stream,
+                         din, dout, (int)n, (int)rpc, segs.ptr[0], din, dz, dout, partial, partial + slab, slab, dout);
+      NGPDE_LAUNCH_CHECK("dense_gemm128_split_kernel (weight pullback)");
+      return launch_dense_weight_reduce(nchunk, din, dout, partial, dwt, db, stream);
+    }
+  }
   hipLaunchKernelGGL(dense_mfma_bwd_weight_kernel, dim3(std::max(1, (din + BM - 1) / BM), (dout + BN - 1) / BN, nchunk), dim3(256), 0,
                      stream, n, segs, din, dout, dz, rpc, partial);
   NGPDE_LAUNCH_CHECK("dense_mfma_bwd_weight_kernel");

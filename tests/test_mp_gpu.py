@@ -166,6 +166,30 @@ def test_dense_wide_tiles_segmented(widths, dout, act):
         o += w
 
 
+@pytest.mark.parametrize("n,din,dout,bias", [(4096, 128, 8192, False), (1040, 132, 2052, False), (4096, 128, 8192, True),
+                                             (2048, 256, 4096, False)])
+def test_dense_few_rows_wide_output_pullbacks(n, din, dout, bias, monkeypatch):
+    # GNOConv's node-level T = W2 (x) h (src/layers.jl:523-530 reassociated): 4096 x 128 => 8192.  Forward on 128 x 128 tiles;
+    # both pullbacks on the same tiles with the contraction split over workgroups (dense_gemm128_split_kernel: input pullback
+    # over the 8192 outputs, weight pullback over the rows) when the layer has no bias gradient -- against float64, and against
+    # the older kernels (NGPDE_DENSE_NO_GEMM128 is read once per process, so that comparison is with the float64 values only)
+    from ngpde_amd import functional as F
+    rng = np.random.default_rng(n + din)
+    x = torch.as_tensor(rng.normal(size=(n, din)), dtype=torch.float32, device=DEV).requires_grad_(True)
+    wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+    b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True) if bias else None
+    y = F.dense([x], wt, b, 0)
+    X, W = x.detach().cpu().double().numpy(), wt.detach().cpu().double().numpy()
+    yo = X @ W + (b.detach().cpu().double().numpy() if bias else 0.0)
+    close(y, yo)
+    R = rng.normal(size=yo.shape) / np.sqrt(dout)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    close(x.grad, R @ W.T, rtol=3e-4)
+    close(wt.grad, X.T @ R, rtol=3e-4)
+    if bias:
+        close(b.grad, R.sum(axis=0), rtol=3e-4)
+
+
 @pytest.mark.parametrize("widths,grads,act", [((64,), (True,), "identity"), ((64, 2), (True, False), "swish"),
                                               ((64, 1, 1, 2), (True, False, False, False), "swish"),
                                               ((64, 64, 2), (True, True, False), "swish"), ((2, 64, 64), (False, False, True), "relu"),
