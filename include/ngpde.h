@@ -279,6 +279,16 @@ int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t 
                                   const float *q_source, const float *e_term, const float *t, const float *bh, float *z_out, float *m,
                                   ngpde_stream_t stream);
 
+/* Pullback of the reassociated message FOLLOWED BY the sum / mean aggregation over targets (aggregate_neighbors(g, aggr, m),
+ * /root/reference/src/layers.jl:534), from the node-level gradient dagg [N][out]: dm_e = dagg[t_e] (sum) or dagg[t_e] / deg(t_e)
+ * (mean) is formed while the per-source launch stages its rows, so the [E][out] array ngpde_segment_reduce_backward would
+ * write (231 MB at BASELINE config 5, r = 0.1) is neither written nor read.  Outputs as ngpde_gno_apply_backward: dt [N][out][k],
+ * dbh [N][out] (nullable), dz [E][k] (p order, nullable).  NGPDE_ERR_UNSUPPORTED for max / min / mul and for shapes outside
+ * ngpde_gno_message_supported. */
+int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, const float *t,
+                                              const float *z, const float *dagg, float *dt, float *dbh, float *dz,
+                                              ngpde_stream_t stream);
+
 /* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
  * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);
  * alpha = softmax over the incoming edges of each node; out[N][heads*c] = sum_e alpha_e Wx[s_e].

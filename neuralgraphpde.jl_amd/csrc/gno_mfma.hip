@@ -128,17 +128,27 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const
 }
 
 // ---- pullback -------------------------------------------------------------------------------------------------------------
-template <int KD, int NOB>   // NOB: bound on cout / 16 (8 or 16) -- sizes the register copy of T_j's columns
+// NODE: the message gradient is not read from an [E][out] array but formed while the rows are staged, from the gradient of the
+// sum / mean aggregation over targets: dm_e = dagg[t_e] (* 1 / deg(t_e) for mean) -- a gather from a node-level array that lives
+// in L2 instead of a 231 MB stream (config 5, r = 0.1) that a separate launch wrote.
+struct GnoNodeGrad {
+  const float *dagg;      // [N][out]
+  const int *col_s;       // target node of every entry of the by-source list
+  const int *rowptr_t;    // by-target row pointers (in-degrees), read for mean only
+  int mean;
+};
+template <int KD, int NOB, bool NODE>   // NOB: bound on cout / 16 (8 or 16) -- sizes the register copy of T_j's columns
 __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
                                                                  const float *__restrict__ T, const float *__restrict__ z,
                                                                  const float *__restrict__ dm, float *__restrict__ dT,
-                                                                 float *__restrict__ dBh, float *__restrict__ dz) {
+                                                                 float *__restrict__ dBh, float *__restrict__ dz, const GnoNodeGrad ng) {
   constexpr int ZS = KD + 4;
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int DS = cout + 4;
   float *zl = sh;                                   // [kEBb][KD + 4]
   float *dml = zl + kEBb * ZS;                       // [kEBb][cout + 4]
-  __shared__ int pl[kEBb];
+  __shared__ int pl[kEBb], tl[kEBb];
+  __shared__ float invl[kEBb];
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rs = rowptr_s[j], re = rowptr_s[j + 1];
@@ -171,10 +181,35 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
     for (int q0 = rs; q0 < re; q0 += kEBb) {
       const int nb = min(kEBb, re - q0);
       __syncthreads();
-      if (tid < kEBb) pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+      if (tid < kEBb) {
+        pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+        if (NODE) {
+          const int t = tid < nb ? ng.col_s[q0 + tid] : 0;
+          tl[tid] = t;
+          float inv = 1.0f;
+          if (ng.mean) {
+            const int deg = ng.rowptr_t[t + 1] - ng.rowptr_t[t];
+            inv = 1.0f / (float)max(deg, 1);
+          }
+          invl[tid] = inv;
+        }
+      }
       __syncthreads();
       stage_edge_rows<kEBb>(zl, z, pl, nb, KD, tid);
-      stage_edge_rows<kEBb>(dml, dm, pl, nb, cout, tid);
+      if (NODE) {
+        const int w4 = cout / 4;
+        for (int idx = tid; idx < kEBb * w4; idx += 256) {
+          const int e = idx / w4, c4 = idx - e * w4;
+          float4 v = f4_zero();
+          if (e < nb) {
+            v = reinterpret_cast<const float4 *>(ng.dagg + (size_t)tl[e] * cout)[c4];
+            if (ng.mean) v = f4_scale(invl[e], v);
+          }
+          *reinterpret_cast<float4 *>(&dml[e * DS + 4 * c4]) = v;
+        }
+      } else {
+        stage_edge_rows<kEBb>(dml, dm, pl, nb, cout, tid);
+      }
       __syncthreads();
       const int net = (nb + kET - 1) / kET;
       if (sweep == 0) {
@@ -280,17 +315,23 @@ int32_t launch_gno_message_mfma_fwd(const ngpde_graph *g, int cout, int kdim, in
 }
 
 int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm, float *dT,
-                                  float *dBh, float *dz, hipStream_t stream) {
+                                  float *dBh, float *dz, hipStream_t stream, const float *dagg, int mean) {
   if (g->n_nodes == 0) return NGPDE_OK;
   const dim3 grid((unsigned)g->n_nodes), block(256);
   const size_t lds = gno_mfma_bwd_lds(cout, kdim);
-#define NGPDE_GNO_B(KK, NOB)                                                                                                     \
+  const GnoNodeGrad ng{dagg, g->by_s.col, g->by_t.rowptr, mean};
+#define NGPDE_GNO_B2(KK, NOB, NODE)                                                                                              \
   do {                                                                                                                           \
     if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit: raise it for this kernel (cheap, idempotent) */               \
-      NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK, NOB>),                   \
+      NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gno_apply_mfma_bwd_kernel<KK, NOB, NODE>),             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL((gno_apply_mfma_bwd_kernel<KK, NOB>), grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, dm, dT, \
-                       dBh, dz);                                                                                                 \
+    hipLaunchKernelGGL((gno_apply_mfma_bwd_kernel<KK, NOB, NODE>), grid, block, lds, stream, cout, g->by_s.rowptr, g->by_s.xpos, T, z, \
+                       dm, dT, dBh, dz, ng);                                                                                     \
+  } while (0)
+#define NGPDE_GNO_B(KK, NOB)                                                                                                     \
+  do {                                                                                                                           \
+    if (dagg) NGPDE_GNO_B2(KK, NOB, true);                                                                                       \
+    else NGPDE_GNO_B2(KK, NOB, false);                                                                                           \
   } while (0)
   if (cout <= 128) {
     switch (kdim) {
@@ -305,6 +346,7 @@ int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, cons
       default: NGPDE_GNO_B(64, 16); break;
     }
   }
+#undef NGPDE_GNO_B2
 #undef NGPDE_GNO_B
   NGPDE_LAUNCH_CHECK("gno_apply_mfma_bwd_kernel");
   return NGPDE_OK;

@@ -527,6 +527,64 @@ class _GnoMessageFn(torch.autograd.Function):
         return dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), dT, dBh, None, None, None, None, None
 
 
+class _GnoMessageAggFn(torch.autograd.Function):
+    """agg = aggregate_neighbors(g, aggr, m) of the fused message above, aggr in {+, mean} (src/layers.jl:527-534): forward = the
+    message launch + the segmented reduction; the pullback forms dm_e = dagg[t_e] (/ deg) inside the per-source launch
+    (ngpde_gno_message_backward_from_nodes) instead of writing and re-reading an [E][out] array."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, T, Bh)
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        T = T.contiguous()
+        Bh = None if Bh is None else Bh.contiguous()
+        dev = T.device
+        stream = _lib.current_stream()
+        need = any(ctx.needs_input_grad)
+        a = torch.empty((n_edges, kdim), dtype=torch.float32, device=dev) if need else None
+        m = torch.empty((n_edges, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_message_forward(handle.ptr, cout, kdim, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(T),
+                                                 _lib.ptr(Bh), _lib.ptr(a), _lib.ptr(m), stream))
+        agg = torch.empty((n_nodes, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_segment_reduce_forward(handle.ptr, cout, aggr, _lib.ptr(m), _lib.ptr(agg), stream))
+        ctx.handle, ctx.meta = handle, (act1, cout, kdim, aggr)
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None, Bh is not None)
+        ctx.save_for_backward(T, a)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        lib = _lib.load()
+        T, a = ctx.saved_tensors
+        act1, cout, kdim, aggr = ctx.meta
+        pshape, qshape, has_e, has_bh = ctx.shapes
+        dagg = dagg.contiguous()
+        dev = dagg.device
+        stream = _lib.current_stream()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
+        dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None
+        da = torch.empty_like(a)
+        _lib.check(lib.ngpde_gno_message_backward_from_nodes(ctx.handle.ptr, cout, kdim, aggr, _lib.ptr(T), _lib.ptr(a), _lib.ptr(dagg),
+                                                             _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(da), stream))
+        dz = torch.empty_like(a)
+        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if (pshape is not None and ctx.needs_input_grad[0]) else None
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if (qshape is not None and ctx.needs_input_grad[1]) else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, kdim, act1, _lib.ptr(da), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dP),
+                                                   _lib.ptr(dQ), stream))
+        return (dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), dT, dBh) + (None,) * 7
+
+
+def gno_message_aggregate(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):
+    """Fused message + sum / mean aggregation (aggr: name or code); other aggregations: gno_message + segment_reduce."""
+    code = _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr)
+    if code not in (_lib.AGGR["+"], _lib.AGGR["mean"]):
+        return segment_reduce(gno_message(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges), handle, code, n_nodes)
+    return _GnoMessageAggFn.apply(P, Q, Eterm, T, Bh, handle, int(act1), int(cout), int(kdim), int(n_edges), code, int(n_nodes))
+
+
 def gno_message_supported(cout, kdim, act1):
     return act1 in (0, 1) and bool(_lib.load().ngpde_gno_message_supported(int(cout), int(kdim)))
 

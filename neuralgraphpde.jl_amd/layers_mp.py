@@ -300,14 +300,16 @@ class GNOConv(AbstractGNNContainerLayer):
         if (reassoc and len(stack) == 2 and E > 0 and os.environ.get("NGPDE_NO_GNO_MFMA") != "1"
                 and F.gno_message_supported(self.out_chs, kdim, l1.act)):
             # two-layer phi: the per-edge input act1(P[t] + Q[s] + E) is formed inside the message launch
-            m = F.gno_message(P, Q, Et, T, Bh, handle, l1.act, self.out_chs, kdim, E)
+            agg = F.gno_message_aggregate(P, Q, Et, T, Bh, handle, l1.act, self.out_chs, kdim, E, self.aggr, N)   # :527-534
+            m = None
         elif reassoc:
             z = _tail(stack[:-1], F.edge_combine(P, Q, Et, handle, l1.act, E))
             m = F.gno_apply(T, Bh, z, handle, self.out_chs, kdim)
         else:
             K = _tail(stack, F.edge_combine(P, Q, Et, handle, l1.act, E))
             m = F.gno_contract(K, h, handle, self.in_chs, self.out_chs)            # :527-530
-        agg = F.segment_reduce(m, handle, self.aggr, N)                            # :534
+        if m is not None:
+            agg = F.segment_reduce(m, handle, self.aggr, N)                        # :534
         lwt, lb = _wt_b(ps["linear"])
         y = F.bias_act(agg, F.dense([h], lwt, None, 0), lb, self.linear.act)       # σ(W x + m + b)  (:536-547)
         return y.T, st

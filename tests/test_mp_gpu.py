@@ -642,6 +642,39 @@ def test_gno_parity_and_grads(variant, monkeypatch):
     check_grads(ps, (names, o1 + [gr["weight"], gr["bias"]]), x, gr["x"])
 
 
+@pytest.mark.parametrize("aggr", ["+", "mean", "max"])
+def test_gno_message_aggregate_pullback_from_node_gradient(aggr):
+    # ngpde_gno_message_backward_from_nodes: the pullback of message + sum / mean aggregation (src/layers.jl:527-534) formed from the
+    # node-level gradient inside the per-source launch -- the same arithmetic as ngpde_segment_reduce_backward followed by
+    # ngpde_gno_apply_backward, so every output must be bit-identical to the composed path; isolated nodes included; max takes
+    # the composed path through the same entry point
+    from ngpde_amd import functional as F
+    N, E, cout, kdim = 300, 2600, 32, 16
+    rng = np.random.default_rng(5)
+    s, t = rng.integers(0, N - 7, size=E), rng.integers(0, N - 7, size=E)          # the last 7 nodes are isolated
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    h = g.handle((False, None, False))
+    mk = lambda *shape: torch.as_tensor(rng.normal(size=shape), dtype=torch.float32, device=DEV)
+    leaves = [mk(N, kdim), mk(N, kdim), mk(E, kdim), mk(N, cout * kdim) * 0.2, mk(N, cout)]
+    R = mk(N, cout)
+
+    def run(fused):
+        xs = [v.clone().requires_grad_(True) for v in leaves]
+        P, Q, Et, T, Bh = xs
+        if fused:
+            agg = F.gno_message_aggregate(P, Q, Et, T, Bh, h, 1, cout, kdim, E, aggr, N)
+        else:
+            agg = F.segment_reduce(F.gno_message(P, Q, Et, T, Bh, h, 1, cout, kdim, E), h, aggr, N)
+        (agg * R).sum().backward()
+        return [agg.detach()] + [v.grad for v in xs]
+
+    assert F.gno_message_supported(cout, kdim, 1)
+    a, b = run(True), run(False)
+    for u, v, name in zip(a, b, ["agg", "dP", "dQ", "dE", "dT", "dBh"]):
+        assert torch.equal(u, v), name
+    assert float(a[4].abs().sum()) > 0 and bool(torch.isfinite(a[1]).all())
+
+
 # ---- GAT-style layer -----------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("concat", [True, False])
