@@ -279,15 +279,18 @@ int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t 
                                   const float *q_source, const float *e_term, const float *t, const float *bh, float *z_out, float *m,
                                   ngpde_stream_t stream);
 
-/* Pullback of the reassociated message FOLLOWED BY the sum / mean aggregation over targets (aggregate_neighbors(g, aggr, m),
- * /root/reference/src/layers.jl:534), from the node-level gradient dagg [N][out]: dm_e = dagg[t_e] (sum) or dagg[t_e] / deg(t_e)
- * (mean) is formed while the per-source launch stages its rows, so the [E][out] array ngpde_segment_reduce_backward would
- * write (231 MB at BASELINE config 5, r = 0.1) is neither written nor read.  Outputs as ngpde_gno_apply_backward: dt [N][out][k],
- * dbh [N][out] (nullable), dz [E][k] (p order, nullable).  NGPDE_ERR_UNSUPPORTED for max / min / mul and for shapes outside
- * ngpde_gno_message_supported. */
-int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, const float *t,
-                                              const float *z, const float *dagg, float *dt, float *dbh, float *dz,
-                                              ngpde_stream_t stream);
+/* Pullback of ngpde_gno_message_forward FOLLOWED BY the sum / mean aggregation over targets (aggregate_neighbors(g, aggr, m),
+ * /root/reference/src/layers.jl:527-534), from the node-level gradient dagg [N][out]: dm_e = dagg[t_e] (sum) or dagg[t_e] /
+ * deg(t_e) (mean) is formed while the per-source launch stages its rows, so the [E][out] array ngpde_segment_reduce_backward
+ * would write (231 MB at BASELINE config 5, r = 0.1) is neither written nor read.  z [E][k] = z_out of the forward (the
+ * ACTIVATED per-edge input), act1 identity or relu.  Outputs: dt [N][out][k], dbh [N][out] (nullable) as
+ * ngpde_gno_apply_backward; dz [E][k] (p order, nullable) is the gradient of the PRE-activation, T_s^T dm_e . act1'(z_e) -- so
+ * dE = dz, dP = its sums by target (ngpde_segment_reduce_forward with NGPDE_AGGR_SUM) --; dq [N][k] (nullable, needs dz) = its
+ * sums by source, formed in the launch (every edge of a workgroup has the same source).  NGPDE_ERR_UNSUPPORTED for max / min /
+ * mul, other activations, and shapes outside ngpde_gno_message_supported. */
+int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, int32_t act1,
+                                              const float *t, const float *z, const float *dagg, float *dt, float *dbh, float *dz,
+                                              float *dq, ngpde_stream_t stream);
 
 /* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
  * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);

@@ -296,10 +296,13 @@ int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t k
   return launch_gno_apply_bwd(g, cout, kdim, t, z, dm, dt, dbh, dz, (hipStream_t)stream);
 }
 
-int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, const float *t,
-                                              const float *z, const float *dagg, float *dt, float *dbh, float *dz,
-                                              ngpde_stream_t stream) {
+int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, int32_t act1,
+                                              const float *t, const float *z, const float *dagg, float *dt, float *dbh, float *dz,
+                                              float *dq, ngpde_stream_t stream) {
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_backward_from_nodes: graph is NULL");
+  NGPDE_REQUIRE(act1 == NGPDE_ACT_IDENTITY || act1 == NGPDE_ACT_RELU, NGPDE_ERR_UNSUPPORTED,
+                "ngpde_gno_message_backward_from_nodes: act1 must be identity or relu (the activated input stands for the "
+                "pre-activation), got %d", act1);
   NGPDE_REQUIRE(aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN, NGPDE_ERR_UNSUPPORTED,
                 "ngpde_gno_message_backward_from_nodes: aggregation %d has no node-level form (sum and mean do); use "
                 "ngpde_segment_reduce_backward + ngpde_gno_apply_backward", aggr);
@@ -307,8 +310,10 @@ int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t co
                 "ngpde_gno_message_backward_from_nodes: needs out a multiple of 16 (<= 256) and k in {16, 32, 64}, got out = %d, k = %d",
                 cout, kdim);
   if (g->n_nodes == 0) return NGPDE_OK;
-  NGPDE_REQUIRE(t && (g->n_edges == 0 || (z && dagg)), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_backward_from_nodes: NULL argument");
-  return launch_gno_apply_mfma_bwd(g, cout, kdim, t, z, nullptr, dt, dbh, dz, (hipStream_t)stream, dagg, aggr == NGPDE_AGGR_MEAN ? 1 : 0);
+  NGPDE_REQUIRE(t && (g->n_edges == 0 || (z && dagg)) && (dz || !dq), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_gno_message_backward_from_nodes: NULL argument (dq needs dz)");
+  return launch_gno_apply_mfma_bwd(g, cout, kdim, t, z, nullptr, dt, dbh, dz, (hipStream_t)stream, dagg, aggr == NGPDE_AGGR_MEAN ? 1 : 0,
+                                   act1, dq);
 }
 
 int32_t ngpde_gno_message_supported(int32_t cout, int32_t kdim) { return gno_apply_mfma_supported(cout, kdim) ? 1 : 0; }

@@ -283,9 +283,11 @@ int32_t launch_gno_apply_mfma_fwd(const ngpde_graph *g, int cout, int kdim, cons
                                   hipStream_t stream);
 int32_t launch_gno_message_mfma_fwd(const ngpde_graph *g, int cout, int kdim, int act1, const float *P, const float *Q, const float *E,
                                     const float *T, const float *Bh, float *z_out, float *m, hipStream_t stream);
-// dagg != NULL: dm is not read; dm_e = dagg[t_e] (* 1 / deg(t_e) if mean) is formed in the launch (gno_mfma.hip, GnoNodeGrad)
+// dagg != NULL: dm is not read; dm_e = dagg[t_e] (* 1 / deg(t_e) if mean) is formed in the launch, dz leaves multiplied by
+// act1'(z) (identity / relu on the activated z) and dq [N][k] (nullable) = its sums by source  (gno_mfma.hip, GnoNodeGrad)
 int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm, float *dT,
-                                  float *dBh, float *dz, hipStream_t stream, const float *dagg = nullptr, int mean = 0);
+                                  float *dBh, float *dz, hipStream_t stream, const float *dagg = nullptr, int mean = 0, int act1 = 0,
+                                  float *dq = nullptr);
 int32_t launch_gat_scores(int64_t n, int heads, int c, const float *wx, const float *a, float *al, float *ar,
                           hipStream_t stream);
 int32_t launch_gat_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,

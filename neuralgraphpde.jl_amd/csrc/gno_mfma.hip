@@ -131,11 +131,16 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const
 // NODE: the message gradient is not read from an [E][out] array but formed while the rows are staged, from the gradient of the
 // sum / mean aggregation over targets: dm_e = dagg[t_e] (* 1 / deg(t_e) for mean) -- a gather from a node-level array that lives
 // in L2 instead of a 231 MB stream (config 5, r = 0.1) that a separate launch wrote.
+// With it the launch also finishes the pullback of the message's per-edge input z = act1(P[t] + Q[j] + E) (act1 identity / relu,
+// `z` = the activated value): dz leaves already multiplied by act1'(z), and dq[j] = sum of the node's dz rows -- every edge of
+// the workgroup has source j -- is formed on the way (the composed path: a by-source gather launch over the [E][k] array).
 struct GnoNodeGrad {
   const float *dagg;      // [N][out]
   const int *col_s;       // target node of every entry of the by-source list
   const int *rowptr_t;    // by-target row pointers (in-degrees), read for mean only
   int mean;
+  int act1;               // NGPDE_ACT_IDENTITY or NGPDE_ACT_RELU
+  float *dq;              // [N][k], nullable
 };
 template <int KD, int NOB, bool NODE>   // NOB: bound on cout / 16 (8 or 16) -- sizes the register copy of T_j's columns
 __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kernel(int cout, const int *__restrict__ rowptr_s, const int *__restrict__ xpos,
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
   float *zl = sh;                                   // [kEBb][KD + 4]
   float *dml = zl + kEBb * ZS;                       // [kEBb][cout + 4]
   __shared__ int pl[kEBb], tl[kEBb];
-  __shared__ float invl[kEBb];
+  __shared__ float invl[kEBb < 64 ? 64 : kEBb];
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rs = rowptr_s[j], re = rowptr_s[j + 1];
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
       }
   }
   float bsum = 0.f;                                 // dBh: thread tid < cout sums column tid of the dm rows
+  float qsum = 0.f;                                 // dq (NODE): this lane's share of column 16 ktw + i (its rows 4 kq + r of every tile)
   for (int sweep = 0; sweep * 4 * MAXT < ntile; ++sweep) {   // one sweep over the edge list per 32 dT tiles (a single sweep at 128 x 64)
     f32x4 acc[MAXT];
 #pragma unroll
@@ -232,7 +238,14 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int e = et * kET + 4 * kq + r;
-              if (e < nb) dz[(size_t)pl[e] * KD + ktw * 16 + i] = d[r];
+              if (e < nb) {
+                float v = d[r];
+                if (NODE) {
+                  if (ng.act1 == NGPDE_ACT_RELU && !(zl[e * ZS + ktw * 16 + i] > 0.f)) v = 0.f;
+                  qsum += v;
+                }
+                dz[(size_t)pl[e] * KD + ktw * 16 + i] = v;
+              }
             }
           }
         }
@@ -265,6 +278,19 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
     }
   }
   if (dBh && tid < cout) dBh[(size_t)j * cout + tid] = bsum;
+  if (NODE && ng.dq) {   // the four row groups of a wave by shuffles, then the waves that share a k tile through LDS, in wave order
+    qsum += __shfl_xor(qsum, 16);
+    qsum += __shfl_xor(qsum, 32);
+    __syncthreads();
+    if (kq == 0) invl[wave * 16 + i] = qsum;       // (64 floats of the staging tables, free by now)
+    __syncthreads();
+    if (tid < KD) {
+      const int kt = tid >> 4;
+      float sq = 0.f;
+      for (int w = kt; w < 4; w += NKT) sq += invl[w * 16 + (tid & 15)];
+      ng.dq[(size_t)j * KD + tid] = rs < re ? sq : 0.f;
+    }
+  }
 }
 
 inline bool no_gno_mfma_env() {
@@ -315,11 +341,11 @@ int32_t launch_gno_message_mfma_fwd(const ngpde_graph *g, int cout, int kdim, in
 }
 
 int32_t launch_gno_apply_mfma_bwd(const ngpde_graph *g, int cout, int kdim, const float *T, const float *z, const float *dm, float *dT,
-                                  float *dBh, float *dz, hipStream_t stream, const float *dagg, int mean) {
+                                  float *dBh, float *dz, hipStream_t stream, const float *dagg, int mean, int act1, float *dq) {
   if (g->n_nodes == 0) return NGPDE_OK;
   const dim3 grid((unsigned)g->n_nodes), block(256);
   const size_t lds = gno_mfma_bwd_lds(cout, kdim);
-  const GnoNodeGrad ng{dagg, g->by_s.col, g->by_t.rowptr, mean};
+  const GnoNodeGrad ng{dagg, g->by_s.col, g->by_t.rowptr, mean, act1, dq};
 #define NGPDE_GNO_B2(KK, NOB, NODE)                                                                                              \
   do {                                                                                                                           \
     if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit: raise it for this kernel (cheap, idempotent) */               \

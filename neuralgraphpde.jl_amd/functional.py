@@ -566,15 +566,18 @@ class _GnoMessageAggFn(torch.autograd.Function):
         stream = _lib.current_stream()
         dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
         dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None
-        da = torch.empty_like(a)
-        _lib.check(lib.ngpde_gno_message_backward_from_nodes(ctx.handle.ptr, cout, kdim, aggr, _lib.ptr(T), _lib.ptr(a), _lib.ptr(dagg),
-                                                             _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(da), stream))
-        dz = torch.empty_like(a)
-        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if (pshape is not None and ctx.needs_input_grad[0]) else None
-        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if (qshape is not None and ctx.needs_input_grad[1]) else None
-        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, kdim, act1, _lib.ptr(da), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dP),
-                                                   _lib.ptr(dQ), stream))
-        return (dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), dT, dBh) + (None,) * 7
+        want_p = pshape is not None and ctx.needs_input_grad[0]
+        want_q = qshape is not None and ctx.needs_input_grad[1]
+        want_e = has_e and ctx.needs_input_grad[2]
+        dz = torch.empty_like(a) if (want_p or want_q or want_e) else None     # gradient of the pre-activation P[t] + Q[s] + E
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if want_q else None
+        _lib.check(lib.ngpde_gno_message_backward_from_nodes(ctx.handle.ptr, cout, kdim, aggr, act1, _lib.ptr(T), _lib.ptr(a),
+                                                             _lib.ptr(dagg), _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(dz), _lib.ptr(dQ), stream))
+        dP = None
+        if want_p:                                                               # dP = sums of dz by target
+            dP = torch.empty(pshape, dtype=torch.float32, device=dev)
+            _lib.check(lib.ngpde_segment_reduce_forward(ctx.handle.ptr, kdim, _lib.AGGR["+"], _lib.ptr(dz), _lib.ptr(dP), stream))
+        return (dP, dQ, (dz if want_e else None), dT, dBh) + (None,) * 7
 
 
 def gno_message_aggregate(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):

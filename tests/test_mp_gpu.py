@@ -671,7 +671,10 @@ def test_gno_message_aggregate_pullback_from_node_gradient(aggr):
     assert F.gno_message_supported(cout, kdim, 1)
     a, b = run(True), run(False)
     for u, v, name in zip(a, b, ["agg", "dP", "dQ", "dE", "dT", "dBh"]):
-        assert torch.equal(u, v), name
+        if name == "dQ" and aggr != "max":     # summed over the source's edges inside the launch: another order of the same terms
+            close(u, v.cpu().double().numpy(), rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(u, v), name
     assert float(a[4].abs().sum()) > 0 and bool(torch.isfinite(a[1]).all())
 
 
