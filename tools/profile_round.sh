@@ -29,7 +29,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gnode_sta
 cd $R
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -o k -- python3 $R/tools/bench_layers.py --only c4 --traj 64 --reps 10 > $O/c4_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -o k -- python3 $R/tools/bench_layers.py --only c5 --width 128 --radius 0.1 --reps 10 > $O/c5_stats.log 2>&1
 cd $R
+python3 tools/hbm_rw_probe.py > $O/hbm_rw_probe.jsonl 2>/dev/null
+[ -f neuralgraphpde.jl_amd/libngpde_diag.so ] && timeout 200 python3 tools/stamps_pair.py > $O/pair_stamps.txt 2>/dev/null
 # does the fp32 matrix instruction run beside the VALU?
 hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o /tmp/ovl 2>/dev/null && timeout 120 /tmp/ovl > $O/mfma_valu_overlap.jsonl 2>/dev/null
 [ -f neuralgraphpde.jl_amd/libngpde_diag.so ] && timeout 200 python3 tools/stamps_edge64.py 64 > $O/edge64_stamps.txt 2>/dev/null
