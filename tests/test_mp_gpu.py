@@ -668,7 +668,8 @@ def test_gno_message_aggregate_pullback_from_node_gradient(aggr):
         (agg * R).sum().backward()
         return [agg.detach()] + [v.grad for v in xs]
 
-    assert F.gno_message_supported(cout, kdim, 1)
+    if not F.gno_message_supported(cout, kdim, 1):
+        pytest.skip("the matrix-pipe GNO kernels are switched off (NGPDE_NO_GNO_MFMA): this entry point has no other form")
     a, b = run(True), run(False)
     for u, v, name in zip(a, b, ["agg", "dP", "dQ", "dE", "dT", "dBh"]):
         if name == "dQ" and aggr != "max":     # summed over the source's edges inside the launch: another order of the same terms
