@@ -74,12 +74,23 @@ __global__ __launch_bounds__(256) void gno_apply_mfma_fwd_kernel(int cout, const
       if (Bh) bias[c] = Bh[(size_t)j * cout + ct * 16 + i];
     }
   }
+  // the pass's edge positions (and targets) are loaded a pass ahead, under the previous pass's products
+  int npl = 0, ntl = 0;
+  if (tid < kEB && rs + tid < re) {
+    npl = xpos[rs + tid];
+    if (FUSED) ntl = fz.col_s[rs + tid];
+  }
   for (int q0 = rs; q0 < re; q0 += kEB) {
     const int nb = min(kEB, re - q0);
     __syncthreads();                                // the previous pass's tiles are consumed
     if (tid < kEB) {
-      pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
-      if (FUSED) tl[tid] = tid < nb ? fz.col_s[q0 + tid] : 0;
+      pl[tid] = npl;
+      if (FUSED) tl[tid] = ntl;
+      npl = ntl = 0;
+      if (q0 + kEB + tid < re) {
+        npl = xpos[q0 + kEB + tid];
+        if (FUSED) ntl = fz.col_s[q0 + kEB + tid];
+      }
     }
     __syncthreads();
     if constexpr (FUSED) {
@@ -184,13 +195,20 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
     f32x4 acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the pass's edge positions and targets are loaded a pass ahead, under the previous pass's products (mean's 1 / deg hangs
+    // on the target and stays in the pass: callers that can pre-scale dagg pass it as a sum)
+    int npl = 0, ntl = 0;
+    if (tid < kEBb && rs + tid < re) {
+      npl = xpos[rs + tid];
+      if (NODE) ntl = ng.col_s[rs + tid];
+    }
     for (int q0 = rs; q0 < re; q0 += kEBb) {
       const int nb = min(kEBb, re - q0);
       __syncthreads();
       if (tid < kEBb) {
-        pl[tid] = tid < nb ? xpos[q0 + tid] : 0;
+        pl[tid] = npl;
         if (NODE) {
-          const int t = tid < nb ? ng.col_s[q0 + tid] : 0;
+          const int t = ntl;
           tl[tid] = t;
           float inv = 1.0f;
           if (ng.mean) {
@@ -198,6 +216,11 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
             inv = 1.0f / (float)max(deg, 1);
           }
           invl[tid] = inv;
+        }
+        npl = ntl = 0;
+        if (q0 + kEBb + tid < re) {
+          npl = xpos[q0 + kEBb + tid];
+          if (NODE) ntl = ng.col_s[q0 + kEBb + tid];
         }
       }
       __syncthreads();

@@ -561,8 +561,11 @@ class _GnoMessageAggFn(torch.autograd.Function):
         T, a = ctx.saved_tensors
         act1, cout, kdim, aggr = ctx.meta
         pshape, qshape, has_e, has_bh = ctx.shapes
-        dagg = dagg.contiguous()
         dev = dagg.device
+        if aggr == _lib.AGGR["mean"]:      # a node's 1 / deg once per node here, not once per edge in the launch (where it would hang
+            dagg = dagg * ctx.handle.inv_in_degree(dev)         # on the edge's target index: one more dependent load per pass)
+            aggr = _lib.AGGR["+"]
+        dagg = dagg.contiguous()
         stream = _lib.current_stream()
         dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
         dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None

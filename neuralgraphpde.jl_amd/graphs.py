@@ -60,6 +60,7 @@ class _Handle:
         out = C.c_void_p()
         self.lib = lib
         self.ptr = None
+        self._targets, self._n_nodes, self._inv_deg = g._t0, g.num_nodes, {}
         if os.environ.get("NGPDE_HOST_GRAPH_BUILD") == "1":
             s = np.ascontiguousarray(g._s0, dtype=np.int64)
             t = np.ascontiguousarray(g._t0, dtype=np.int64)
@@ -101,6 +102,16 @@ class _Handle:
                 wt = (w.detach() if isinstance(w, torch.Tensor) else torch.as_tensor(np.asarray(w))).to(dev, torch.float32).contiguous()
             _lib.check(lib.ngpde_graph_set_gcn_norm_device(self.ptr, int(add_self_loops), _lib.ptr(wt), int(weighted),
                                                            _lib.current_stream()))
+
+    def inv_in_degree(self, device):
+        """[N][1] float32 on `device`: 1 / max(in-degree, 1) -- what a mean aggregation's pullback multiplies a node's gradient by."""
+        key = str(device)
+        v = self._inv_deg.get(key)
+        if v is None:
+            deg = np.bincount(np.asarray(self._targets, dtype=np.int64), minlength=self._n_nodes).astype(np.float32)
+            v = torch.as_tensor((np.float32(1.0) / np.maximum(deg, np.float32(1.0))).reshape(-1, 1), device=device)
+            self._inv_deg[key] = v
+        return v
 
     def __del__(self):
         try:
