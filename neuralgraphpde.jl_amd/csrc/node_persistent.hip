@@ -71,9 +71,31 @@ __device__ __forceinline__ void store_sc1(float *base, unsigned byte_off, float4
   f4v t = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
 }
-template <class T>
-__device__ __forceinline__ T *at_bytes(T *base, unsigned byte_off) {   // base + offset with the base kept scalar
-  return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+// base + byte offset with the base kept scalar, as GLOBAL-address-space accesses: through a generic pointer rebuilt from an
+// integer they compile to flat_load / flat_store, which count on lgkmcnt as well, may alias LDS as far as the compiler knows,
+// and so get s_waitcnt vmcnt(0) lgkmcnt(0) in front of them while it counts an LDS-DMA as pending
+#define NGPDE_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ float4 ld4_g(const float *base, unsigned byte_off) {
+  const f4v t = *reinterpret_cast<NGPDE_GLOBAL_AS const f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_g(float *base, unsigned byte_off, float4 v) {
+  const f4v t = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off) = t;
+}
+__device__ __forceinline__ float4 ld4_stream_g(const float *base, unsigned byte_off) {   // touch-once rows (the tape): non-temporal
+  const f4v t = __builtin_nontemporal_load(reinterpret_cast<NGPDE_GLOBAL_AS const f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_stream_g(float *base, unsigned byte_off, float4 v) {
+  const f4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off));
+}
+__device__ __forceinline__ unsigned ldu8_g(const uint8_t *base, unsigned byte_off) {
+  return (unsigned)*reinterpret_cast<NGPDE_GLOBAL_AS const uint8_t *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+__device__ __forceinline__ void stu8_g(uint8_t *base, unsigned byte_off, uint8_t v) {
+  *reinterpret_cast<NGPDE_GLOBAL_AS uint8_t *>(reinterpret_cast<uintptr_t>(base) + byte_off) = v;
 }
 
 struct TileCtx {
@@ -155,7 +177,7 @@ __device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, i
 
 // every storing wave drains, the workgroup meets, ONE lane publishes (Guideline 16, R1)
 __device__ __forceinline__ void tile_publish(const TileMeta &m, const TileCtx &c, int ph) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt0();
   __syncthreads();
   if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -172,7 +194,7 @@ __device__ __forceinline__ void tile_gather_foreign(const TileCtx &c, const floa
                                        (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * (k + 1)) * PG::LPR + c.q), 16, 0, 16);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt0();
   __syncthreads();
 }
 
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   for (int mb = 0; mb < p.n_members; ++mb) {
   const float *u_in = p.u_in + (size_t)mb * p.row_elems;
   const size_t ev0 = (size_t)mb * p.n_steps * p.S * 2;
-  float4 u = f4_sel(c.valid && ok, *at_bytes(reinterpret_cast<const float4 *>(u_in), own), f4_zero());
+  float4 u = f4_sel(c.valid && ok, ld4_g(u_in, own), f4_zero());
   // six named values written through component-wise selects (f4_sel): an array written as `k[j] = (j == i) ? yv : k[j]` ends
   // up in scratch memory
   float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         float4 acc = f4_scale(c.ci, tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
         const size_t ev = ev0 + (size_t)(n * p.S + i) * 2 + layer;
-        if (TAPE && c.valid) store_stream4(at_bytes(reinterpret_cast<float4 *>(p.tape + ev * p.row_elems), own), acc);
+        if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
         __syncthreads();
         NGPDE_PST(p.m, ph, 3);
         mfma_rows_times_bt<PD>(ldsT, layer == 0 ? ldsW1 : ldsW2, ldsZ, c.wave_u, c.lane);
@@ -329,12 +351,12 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         tile_publish(p.m, c, ph);
         NGPDE_PST(p.m, ph, 6);
         // relu' for the adjoint: only the adjoint launch reads it, so it leaves after the rows are published
-        if (TAPE) *at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid) = sign_bits;
+        if (TAPE) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
       }
     }
   }
   // (a tile writes its rows of u(T) only after all readers of its u0 rows are past that member's first phase)
-  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(p.u_out + (size_t)mb * p.row_elems), own) = f4_sel(ok, u, f4_nan());
+  if (c.valid) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_sel(ok, u, f4_nan()));
   }
 }
 
@@ -431,15 +453,15 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     }
     NGPDE_PST(p.m, ph, 7);
   };
-  auto tape_row = [&](size_t ev) { return load_stream4(at_bytes(reinterpret_cast<const float4 *>(p.tape + ev * p.row_elems), own)); };
-  auto mask_of = [&](size_t ev) { return (unsigned)*at_bytes(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
+  auto tape_row = [&](size_t ev) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
+  auto mask_of = [&](size_t ev) { return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
 
   bool ok = true;
   int ph = 0;   // phases count on across the members (the parameter-gradient accumulators too: the gradient of a batch is the sum)
   for (int mb = 0; mb < p.n_members; ++mb) {
   float *lam_g = p.lam + (size_t)mb * p.row_elems;
   const size_t ev0 = (size_t)mb * p.n_steps * S * 2;
-  float4 lam = f4_sel(c.valid && ok, *at_bytes(reinterpret_cast<const float4 *>(lam_g), own), f4_zero());
+  float4 lam = f4_sel(c.valid && ok, ld4_g(lam_g, own), f4_zero());
   float4 ub1 = f4_zero(), ub2 = f4_zero(), ub3 = f4_zero(), ub4 = f4_zero(), ub5 = f4_zero();   // named, not an array (see the forward kernel)
   if (ok) {   // first phase of a member: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather:
               // g2 was last read two phases ago, so no wait either)
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
       }
     }
   }
-  if (c.valid) *at_bytes(reinterpret_cast<float4 *>(lam_g), own) = f4_sel(ok, lam, f4_nan());
+  if (c.valid) st4_g(lam_g, own, f4_sel(ok, lam, f4_nan()));
   }
   // the tile's contribution to the parameter gradients: one slab per tile, summed by reduce_slabs_kernel
   const float bad = __int_as_float(0x7fc00000);
