@@ -10,6 +10,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LD
   n=$(echo $grp | tr ' ' '_')
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c2_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 --no-secondary > $O/c2_$n.log 2>&1
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c4_$n -- python3 $R/tools/bench_layers.py --only c4 --traj 64 --reps 2 > $O/c4_$n.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/c5_$n -- python3 $R/tools/bench_layers.py --only c5 --width 128 --radius 0.1 --reps 2 > $O/c5_$n.log 2>&1
 done
 cd $R
 python3 tools/pmc_mfma_summary.py $O > $O/mfma_summary.json 2> $O/mfma_summary.err
