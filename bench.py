@@ -266,6 +266,27 @@ def secondary(dev, world, rank, dist):
                                     "timing": TIMING_NOTE,
                                     "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_MB_forward": C3_FWD_BYTES / 1e6}}
+        # BASELINE config 3 "as ODE RHS": NeuralODE(GATConv 64 => 4 x 16) on the C2 graph, Tsit5 x 50, forward + discrete adjoint,
+        # the generic solver path captured into two HIP graphs (every stage = the one-launch GAT layer, every Runge-Kutta
+        # combination one ngpde_rk_stage_combine launch)
+        lg = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+        nodeg = ng.NeuralODE(lg, solver="tsit5", n_steps=ODE_STEPS, dt=DT, capture=True)
+        psg, stg = ng.setup(3, nodeg)
+        psg = ng.to_device(psg, dev)
+        for v in _grad_leaves(psg):
+            v.requires_grad_(True)
+        leaves = [x] + _grad_leaves(psg)
+        xg = x.detach().requires_grad_(True)
+
+        def solve():
+            for v in [xg] + _grad_leaves(psg):
+                v.grad = None
+            uT, _ = nodeg(xg, psg, stg)
+            uT.sum().backward()
+        ms_node = _time_ms(solve, 5)
+        out["C3_gat_node_tsit5x50"] = {"ms_solve_forward_backward": round(ms_node, 3), "value": round(ODE_STEPS / (ms_node * 1e-3), 1),
+                                       "unit": "ODE-steps/s", "path": "NeuralODE(GATConv, capture=True): HIP-graph replay of the generic solver",
+                                       "rhs_evals_per_ode_step": 6}
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))
@@ -436,6 +457,14 @@ def main():
         torch.cuda.synchronize()
         return elapsed, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), plan
 
+    def pipeline_stats(plan):
+        # the interleaved batch solve (two members per workgroup): how many (tile, member, phase) units of the last launches
+        # found their halo rows gathered ahead of time, i.e. paid no exposed hand-off
+        af, ab, tot = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.ngpde_node_pipeline_stats(plan.ptr, stream, C.byref(af), C.byref(ab), C.byref(tot)))
+        return {"members_per_workgroup": 2 if (plan.members > 1 and os.environ.get("NGPDE_NO_INTERLEAVE") != "1") else 1,
+                "slot_phases": int(tot.value), "gathered_ahead_forward": int(af.value), "gathered_ahead_backward": int(ab.value)}
+
     def launch_profile(plan):
         # per-launch DEVICE time of the four kernel roles, from start/stop events attached to the dispatches
         us = (C.c_float * 4)()
@@ -443,7 +472,35 @@ def main():
         _lib.check(lib.ngpde_node_profile(plan.ptr, 1, us, cnt, stream))
         return us, cnt
 
+    def api_job(n_steps, n_warmup):
+        """The same bench step through the PUBLIC API (graph_node.md:118-132: model call, loss, gradient, Optimisers.update):
+        NeuralODE.__call__ (plan lookup, autograd node, output allocation) + .backward() + optim.update on the flat parameter
+        vector.  Returns seconds per step (wall, this rank)."""
+        rhs = ng.Chain(ng.GCNConv((D, D), "relu", initialgraph=g), ng.GCNConv((D, D), "relu", initialgraph=g))
+        node = ng.NeuralODE(rhs, solver="tsit5", n_steps=ODE_STEPS, dt=DT)
+        _, st = ng.setup(0, node)
+        ps0 = {"layer_1": {"weight": torch.as_tensor(np.ascontiguousarray(w1_h.T)), "bias": torch.as_tensor(b1_h).reshape(D, 1)},
+               "layer_2": {"weight": torch.as_tensor(np.ascontiguousarray(w2_h.T)), "bias": torch.as_tensor(b2_h).reshape(D, 1)}}
+        flat, ps = ng.optim.flatten_parameters(ps0, device=dev)
+        st_opt = ng.optim.setup(ng.optim.Adam(1e-5), flat)
+        u0 = dv(u0_h).T                                    # (D x N), the reference's layout: a column-major view, no copy
+
+        def step():
+            flat.zero_grad()
+            uT, _ = node(u0, ps, st)
+            uT.sum().backward()
+            ng.optim.update(st_opt, flat)
+        for _ in range(n_warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        return (time.perf_counter() - t0) / n_steps
+
     elapsed, ms_fwd, ms_bwd, plan = job(1, args.steps, args.warmup)
+    api_s = api_job(args.steps, args.warmup) if world == 1 else None
     step_ms = list(job.step_ms)      # this rank's per-step device times of the timed region (`value` stays K steps / wall time)
 
     def role_table(plan, traj):
@@ -504,6 +561,11 @@ def main():
             "kernels": kernels,
             "plan": sorted(plan.flags()), "fault": bool(plan.fault()),
         }
+        if api_s is not None:
+            # the headline drives the C ABI directly (the call sequence a Julia shim would make); this is the same step through
+            # the Python mirror of the reference's API -- plan pool, autograd, tensor allocation and loss included
+            out["api_ms_per_step"] = round(1000.0 * api_s, 4)
+            out["api_value"] = round(ODE_STEPS / api_s, 2)
         if world == 1 and args.batched > 1:
             # Secondary: the same kernels when a launch is no longer ONE wave of workgroups.  `traj` trajectories of the
             # BASELINE workload on this GPU as one block-diagonal batched GNNGraph (test/runtests.jl:89-102); each launch
@@ -522,6 +584,7 @@ def main():
                              "frac": round(algob[db] / (float(usb[db]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                 "kernels_avg_us": {r: round(float(usb[i]), 3) for i, r in enumerate(rolesb) if r is not None},
                 "plan": sorted(planb.flags()),
+                "pipeline": pipeline_stats(planb),
             }
             planb = None
         if world == 1 and not args.no_cpu_baseline:

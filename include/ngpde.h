@@ -414,6 +414,12 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
        NGPDE_NODE_PERSISTENT_BWD = 16 };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
+/* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`
+ * (tile, member, phase) units of the last forward / adjoint launch, how many found their halo rows gathered ahead of time, i.e.
+ * paid no exposed hand-off.  Zeros for plans without persistent launches.  Synchronises `stream`.  [no reference counterpart:
+ * the batch is test/runtests.jl:89-102] */
+int32_t ngpde_node_pipeline_stats(ngpde_node_t *plan, ngpde_stream_t stream, int64_t *ahead_forward, int64_t *ahead_backward,
+                                  int64_t *slot_phases);
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
  * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity

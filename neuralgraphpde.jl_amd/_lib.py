@@ -113,6 +113,7 @@ SIGNATURES = {
     "ngpde_node_launch_count": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngpde_node_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "ngpde_node_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ngpde_node_pipeline_stats": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "ngpde_node_generation": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i32)]),
     "ngpde_node_expect_generation": (_i32, [_vp, C.c_uint64]),
     "ngpde_node_profile": (_i32, [_vp, _i32, C.POINTER(_f32), C.POINTER(_i32), _vp]),

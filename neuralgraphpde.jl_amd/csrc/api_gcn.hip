@@ -58,7 +58,10 @@ size_t ngpde_gcn_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t do
     const size_t parts = dout < din ? (size_t)dense_fwd_split_count(din, dense_fwd_splits((int64_t)n, din, dout)) : 1;
     return align256(n * (dout < din ? (size_t)dout * parts : dmax) * 4) + 256;
   }
-  return 2 * align256(n * dmax * 4) + align256((size_t)dense_weight_chunks((int64_t)n, din, dout) * (din + 1) * dout * 4) + 256;
+  // the third region serves two users: the weight pullback's slabs (chunks x (din + 1) x dout) and, when dout < din, the two-stage
+  // column sums of the bias gradient (launch_colsum2: kColsumChunks x dout) -- with narrow layers the second is the larger one
+  const size_t slabs = (size_t)dense_weight_chunks((int64_t)n, din, dout) * (din + 1) * dout;
+  return 2 * align256(n * dmax * 4) + align256(std::max(slabs, (size_t)kColsumChunks * dout) * 4) + 256;
 }
 
 int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,

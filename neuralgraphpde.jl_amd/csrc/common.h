@@ -164,9 +164,10 @@ int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-cap
 struct NodePersist {
   int n_tiles = 0;
   int *nbr = nullptr;          // [n_tiles][64] wait lists, -1 padded
-  unsigned *sync = nullptr;    // [n_tiles + 1] 128-byte lines: phase flag per tile, then the abort word
+  unsigned *sync = nullptr;    // [2 n_tiles + 1] 128-byte lines: phase flag per tile for slot 0, for slot 1, then the abort word
   size_t sync_bytes = 0;
   unsigned *fault = nullptr;   // sticky: some persistent launch of this plan gave up waiting
+  int *stats = nullptr;        // [n_tiles][2]: slot-phases of the last forward / adjoint launch gathered ahead of time (interleaved kernels)
   float *coef = nullptr;       // device tables indexed by the stage: forward [42], adjoint [48] (layout: node.hip)
 };
 struct NodePersistFwd {
@@ -179,6 +180,7 @@ struct NodePersistFwd {
   float *tape = nullptr;
   uint8_t *masks = nullptr;
   size_t row_elems = 0, mask_bytes = 0;
+  bool interleave = false;     // two members of a batch at a time per workgroup: bufA / bufB hold two [N][64] arrays each
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 struct NodePersistBwd {
@@ -190,8 +192,11 @@ struct NodePersistBwd {
   const uint8_t *masks = nullptr;
   size_t row_elems = 0, mask_bytes = 0;
   float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
+  bool interleave = false;     // two members at a time: g1 / g2 hold two [N][64] arrays each, ubar = [2][5][N][64] scratch
+  float *ubar = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
+bool node_persistent_interleave_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
 int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps);
 void node_persistent_free(NodePersist *ps);

@@ -117,6 +117,10 @@ struct ngpde_node {
   bool persist_fwd = false, persist_bwd = false;
   NodePersist persist;
   float *pbuf = nullptr;     // layer-1 output exchanged between tiles in the persistent forward
+  // a batch (members > 1) runs two members at a time per workgroup (node_persistent.hip, "slots"): the exchanged arrays
+  // (ustage, pbuf, g1, g2) hold one [N][d] array per slot, pubar is the adjoint's stage-adjoint scratch [2][5][N][d]
+  bool interleave = false;
+  float *pubar = nullptr;
 
   hipStream_t cap_stream = nullptr;
   hipGraph_t fwd_graph = nullptr, bwd_graph = nullptr;
@@ -316,9 +320,11 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   a.u_in = p->u; a.u_out = p->u;     // a tile writes its rows of u(T) only after all its readers are past phase 1
   a.bufA = p->ustage; a.bufB = p->pbuf;
   a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
+  a.row_elems = p->row_elems;
   if (p->with_bwd) {
-    a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
+    a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes;
   }
+  a.interleave = p->interleave;
   a.ev_start = ev0; a.ev_stop = ev1;
   return launch_node_fwd_persistent(a, stream);
 }
@@ -329,6 +335,7 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
+  a.interleave = p->interleave; a.ubar = p->pubar;
   a.ev_start = ev0; a.ev_stop = ev1;
   int32_t st;
   if ((st = launch_node_bwd_persistent(a, stream))) return st;
@@ -389,6 +396,7 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
   if (p->ybuf) (void)hipFree(p->ybuf);
   if (p->masks) (void)hipFree(p->masks);
   if (p->pbuf) (void)hipFree(p->pbuf);
+  if (p->pubar) (void)hipFree(p->pubar);
   node_persistent_free(&p->persist);
   delete p;
   return NGPDE_OK;
@@ -431,13 +439,15 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   p->pre = fused_prescaled_supported(g, d) && std::getenv("NGPDE_NO_PRESCALE") == nullptr;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
+  p->interleave = members > 1 && node_persistent_interleave_env();
+  const size_t xslots = p->interleave ? 2 : 1;   // [N][d] arrays per exchanged buffer
   const int S = p->tb.S;
   int32_t st = NGPDE_OK;
   auto A = [&](float **ptr, size_t elems) {
     if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
   };
   A(&p->u, p->all_elems);
-  A(&p->ustage, p->row_elems);
+  A(&p->ustage, xslots * p->row_elems);
   A(&p->u0keep, p->all_elems);
   A(&p->w1, (size_t)d * d); A(&p->b1, d); A(&p->w2, (size_t)d * d); A(&p->b2, d);
   const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->all_elems;
@@ -452,7 +462,8 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
     }
   }
   if (p->with_bwd) {
-    A(&p->lam, p->all_elems); A(&p->g1, p->row_elems); A(&p->g2, p->row_elems);
+    A(&p->lam, p->all_elems); A(&p->g1, xslots * p->row_elems); A(&p->g2, xslots * p->row_elems);
+    if (p->interleave) A(&p->pubar, 2 * 5 * p->row_elems);
     p->ubar.assign(S, nullptr);
     for (int j = 1; j < S; ++j) A(&p->ubar[j], p->row_elems);
     const size_t dd = (size_t)d * d;
@@ -490,7 +501,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
       st = NGPDE_OK;
       p->persist_fwd = p->persist_bwd = false;
     }
-    if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, p->row_elems);
+    if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, xslots * p->row_elems);
   }
   if (st == NGPDE_OK && members > 1 && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd)))
     st = fail(NGPDE_ERR_UNSUPPORTED, "ngpde_node_gcn2_create_batch: the member-by-member solve exists for the persistent plan only "
@@ -540,6 +551,25 @@ int32_t ngpde_node_fault(ngpde_node_t *p, ngpde_stream_t stream_, int32_t *fault
   NGPDE_HIP_CHECK(hipMemcpyAsync(&f, p->persist.fault, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream_));
   NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
   *fault = f ? 1 : 0;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_pipeline_stats(ngpde_node_t *p, ngpde_stream_t stream_, int64_t *ahead_forward, int64_t *ahead_backward,
+                                  int64_t *slot_phases) {
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_pipeline_stats: plan is NULL");
+  if (ahead_forward) *ahead_forward = 0;
+  if (ahead_backward) *ahead_backward = 0;
+  if (slot_phases) *slot_phases = 0;
+  if (!p->persist.stats) return NGPDE_OK;
+  const int nt = p->persist.n_tiles;
+  std::vector<int> h((size_t)nt * 2);
+  NGPDE_HIP_CHECK(hipMemcpyAsync(h.data(), p->persist.stats, h.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+  NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  int64_t f = 0, b = 0;
+  for (int t = 0; t < nt; ++t) f += h[2 * t], b += h[2 * t + 1];
+  if (ahead_forward) *ahead_forward = f;
+  if (ahead_backward) *ahead_backward = b;
+  if (slot_phases) *slot_phases = (int64_t)nt * p->members * p->n_steps * p->tb.S * 2;
   return NGPDE_OK;
 }
 

@@ -67,9 +67,16 @@ int g_pst_max = 0;
 
 // write-through row store: visible to sc1 loads of every XCD once drained.  Scalar base + 32-bit byte offset (one VGPR of
 // address instead of a 64-bit pair per array: the adjoint kernel sits at the 128-VGPR edge)
+// The hazard recogniser does not look inside inline assembly.  Two of gfx9's software-managed hazards apply to this instruction:
+//  * "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states" -- the base may have been re-materialised just before the statement
+//    by an SGPR-spill reload (v_readlane_b32 sN, vM, lane: a VALU write of an SGPR; these kernels spill 20-50 SGPRs).  Without
+//    the s_nop 4 the store can go out with the register pair's PREVIOUS content as its base: rows land in another array.  (Seen
+//    as run-to-run differences in one slot of the interleaved kernels, and very likely round 2's unexplained GPU memory fault
+//    when a tape store was moved next to a flag store.)
+//  * "VMEM store of more than 64 bits followed by a write of its data VGPRs: 1 wait state" -- the s_nop 1 behind it.
 __device__ __forceinline__ void store_sc1(float *base, unsigned byte_off, float4 v) {
   f4v t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
 }
 // base + byte offset with the base kept scalar, as GLOBAL-address-space accesses: through a generic pointer rebuilt from an
 // integer they compile to flat_load / flat_store, which count on lgkmcnt as well, may alias LDS as far as the compiler knows,
@@ -117,6 +124,7 @@ struct TileMeta {
   const int *nbr;
   unsigned *flags, *abort_word;
   int n_tiles;
+  int *stats;   // [n_tiles][2] (forward, adjoint): slot-phases of the last launch whose halo rows were gathered ahead of time
   NGPDE_PST_FIELD
 };
 
@@ -150,11 +158,11 @@ __device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, flo
 // word on lane 63, ONE load per lane and round (a second dependent load per round would double the polling period, which is
 // the granularity a published flag is seen with); everybody meets at the barrier.  Returns false when the solve was aborted.
 // Bounded: after ~2 s of the 100 MHz counter (the whole solve takes ~6 ms) the wave raises the abort word itself.
-__device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok) {
+__device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok, const unsigned *flags) {
   if (ph <= 1) return true;
   if (c.wave_u == 0) {
     const unsigned need = (unsigned)(ph - 1);
-    const unsigned *addr = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? m.flags + 32 * c.my_nbr : nullptr);
+    const unsigned *addr = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? flags + 32 * c.my_nbr : nullptr);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     bool ok = true;
     for (unsigned it = 1;; ++it) {
@@ -174,13 +182,15 @@ __device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, i
   __syncthreads();
   return *s_ok != 0;
 }
+__device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok) { return tile_wait(m, c, ph, s_ok, m.flags); }
 
 // every storing wave drains, the workgroup meets, ONE lane publishes (Guideline 16, R1)
-__device__ __forceinline__ void tile_publish(const TileMeta &m, const TileCtx &c, int ph) {
+__device__ __forceinline__ void tile_publish(const TileCtx &c, int ph, unsigned *flags) {
   wait_vmcnt0();
   __syncthreads();
-  if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c.tid == 0) __hip_atomic_store(flags + 32 * c.tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void tile_publish(const TileMeta &m, const TileCtx &c, int ph) { tile_publish(c, ph, m.flags); }
 
 // the rows of OTHER tiles this tile's halo references: memory -> LDS slots 32.., sc1 (the producers stored them write-through
 // in the previous phase; sc1 loads bypass this CU's L1, which may hold the same addresses from two phases ago)
@@ -221,6 +231,21 @@ __device__ __forceinline__ float4 tile_aggregate(const TileCtx &c, const unsigne
   }
   return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
 }
+// the same sums in the same order with the slot words read from LDS round by round (8 fewer registers across the rounds; for the
+// interleaved adjoint, which is at the 128-register edge)
+__device__ __forceinline__ float4 tile_aggregate_lean(const TileCtx &c, const float *ldsXh) {
+  const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
+  float4 a = f4_zero();
+#pragma unroll 1
+  for (int jw = 0; jw * 4 < c.wmax; ++jw) {   // wave-uniform
+    const unsigned w = c.lds_slots[c.grp * 8 + jw];
+    float4 v[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q];
+    a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+  }
+  return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+}
 
 // W (row-major [in][out]) -> LDS, transposed (forward: B[k = in][j = out], stored Bt[j][k]) or straight (pullback: Bt[j = in][k = out])
 __device__ __forceinline__ void load_weight_lds(const float *wt, float *ldsBt, int tid, bool transpose) {
@@ -242,6 +267,49 @@ __device__ __forceinline__ void load_weight_lds(const float *wt, float *ldsBt, i
         const int wi = (idx * 4) / PD, wo = (idx * 4) % PD;
         *reinterpret_cast<float4 *>(&ldsBt[wi * PG::TS + wo]) = reinterpret_cast<const float4 *>(wt)[idx];
       }
+    }
+  }
+}
+
+// ---- pieces of the interleaved kernels' software pipeline -------------------------------------------------------------------
+// wave 0: one flag load per lane of the wait list (lane 63: the abort word), NOT waited for
+__device__ __forceinline__ unsigned poll_issue(const TileMeta &m, const TileCtx &c, const unsigned *flags) {
+  const unsigned *addr = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? flags + 32 * c.my_nbr : nullptr);
+  unsigned f = (c.lane == 63) ? 0u : 0xffffffffu;
+  if (addr) f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f;
+}
+// wave 0: did every tile of the wait list show phase ph - 1 (and nobody give up)?
+__device__ __forceinline__ bool poll_ready(const TileCtx &c, unsigned f, int ph) {
+  const unsigned need = (unsigned)(ph - 1);
+  return __all((int)(c.lane == 63 ? f == 0u : f >= need)) != 0;
+}
+// a slot's own rows into halo slots 0..31 and the LDS-DMA of the foreign rows (tile_gather_foreign without its wait).  `halo`
+// is __restrict__ so that LDS reads of OTHER regions issued behind it are not made to wait for the DMA (see dense_mfma.hip,
+// products_beside_dma: behind a global_load_lds the wait-count pass otherwise drains vmcnt in front of every LDS access)
+__device__ __forceinline__ void halo_fill_ahead(const TileCtx &c, const float *X, float *__restrict__ halo, float4 xown) {
+  float4 *Xh4 = reinterpret_cast<float4 *>(halo);
+  Xh4[c.grp * PG::LPR + c.q] = xown;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (4 * c.wave_u + 32 * (k + 1) < c.hcount) {   // wave-uniform
+      const unsigned off = (unsigned)c.lds_hnode[c.grp + 32 * k] * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X) + off),
+                                       (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * (k + 1)) * PG::LPR + c.q), 16, 0, 16);
+    }
+  }
+}
+// the same with the slot's OWN rows fetched as well (halo slots 0..31 = the tile's rows: one more DMA per wave; they were stored
+// write-through at least a slot-phase earlier).  For kernels that keep no copy of them in registers.
+__device__ __forceinline__ void halo_fill_all(const TileCtx &c, const float *X, float *__restrict__ halo) {
+  float4 *Xh4 = reinterpret_cast<float4 *>(halo);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k == 0 || 4 * c.wave_u + 32 * k < c.hcount) {   // wave-uniform
+      const unsigned row = k == 0 ? (unsigned)c.node : (unsigned)c.lds_hnode[c.grp + 32 * (k - 1)];
+      const unsigned off = row * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X) + off),
+                                       (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * k) * PG::LPR + c.q), 16, 0, 16);
     }
   }
 }
@@ -271,6 +339,7 @@ struct PFwdK {
   float *tape;         // [n_members][n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
   uint8_t *masks;      // [n_members][n_steps][S][2][mask_bytes] relu sign bits
   size_t row_elems, mask_bytes;
+  size_t flag_stride;  // two-slot kernels: slot s uses bufA / bufB + s * row_elems and the flag words m.flags + s * flag_stride
   const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
                        // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
 };
@@ -360,6 +429,197 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward solve, TWO trajectories of a batch interleaved in one workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+// A block-diagonal batch of identical structures (test/runtests.jl:89-102, src/layers.jl:359-361) solved member after member
+// pays the exposed hand-off (drain -> flag -> detect -> gather, ~2.4 us of a 4.1 us phase) once per member and phase: the CU idles
+// while the rows travel.  Here a workgroup keeps the SAME tile of two members ("slots") and alternates between them phase by
+// phase: while slot 0's rows and flag cross the fabric the workgroup aggregates, multiplies and stores slot 1's phase, and vice
+// versa.  Each slot has its own exchanged arrays (bufA / bufB + slot * row_elems) and its own flag line per tile
+// (flags + slot * flag_stride); wait lists, halo lists, slot bytes and W are shared.  The members are taken in pairs (0, 1),
+// (2, 3), ...; an odd last member runs alone in slot 0.  Per-slot state in registers: u, k_0..k_5 and the slot's own row of the
+// array it last published (the LDS halo region is shared by the slots, so the own rows are re-written at every phase start).
+// Arithmetic per member is that of node_fwd_persistent_kernel operation for operation: u(T) is bitwise equal.
+struct FSlot {
+  float4 u, k0, k1, k2, k3, k4, k5, xown;
+};
+
+// What the fabric costs a slot-phase when its steps are simply run one after the other: the poll (a load that must reach memory),
+// the gather of the foreign rows, the drain of the row stores in front of the flag -- three dependent round trips, ~2 us of a
+// 3.8 us slot-phase, and alternating the slots alone hides none of them (measured: 18.3 ms for 8 members against 19.2 one by
+// one).  So the round trips of the NEXT slot-phase are taken off the instruction stream of the current one:
+//   T0  s_waitcnt vmcnt(0) + barrier: this slot-phase's halo rows have landed (gathered during the previous slot-phase) and the
+//       previous slot-phase's row stores are drained -> ITS flag is published here (deferred publish: no wait of its own)
+//   T1  LDS aggregation, operand tile, tape row
+//   T2  barrier; wave 0 issues the flag loads of the NEXT slot-phase's wait list (not waited for)
+//   T3  MFMA
+//   T4  wave 0 looks at the flags it fetched; barrier
+//   T5  if they were all there: the next slot-phase's own rows and the LDS-DMA of its foreign rows go out now (the halo region has
+//       been free since T2) and fly during the epilogue; then bias, activation, stage combination, row stores (not drained)
+// A next slot-phase whose flags were not there yet (or that does not exist: the last one, a single slot) takes the blocking
+// path at its T0: publish what is pending, poll, gather -- the round-2 sequence.
+struct FNext {          // the slot-phase after this one
+  bool exists;
+  int ph;               // its phase number
+  const float *X;       // the array its halo rows come from
+  const unsigned *flags;
+};
+
+template <int ACT, bool TAPE>
+__device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c, FSlot &S, FSlot &Snext, const int sl, const int ph, const int n,
+                                               const int i, const int layer, const float *X, const size_t ev0, const int act,
+                                               const unsigned own, bool &pre, int &n_ahead, unsigned *&pend_flags, int &pend_ph, const FNext nx,
+                                               float *ldsXh, float *ldsT, float *ldsZ, const float *ldsW, const float *ldsBias,
+                                               const float *ldsC, int *s_ok, int *s_pre) {
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  float *bufA = p.bufA + (size_t)sl * p.row_elems, *bufB = p.bufB + (size_t)sl * p.row_elems;
+  unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+  NGPDE_PST(p.m, ph, 0);
+  // T0
+  wait_vmcnt0();
+  __syncthreads();
+  unsigned sw[8];
+  tile_slot_words(c, sw);
+  n_ahead += pre ? 1 : 0;
+  if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  pend_flags = nullptr;
+  if (!pre) {
+    Xh4[c.grp * PG::LPR + c.q] = S.xown;   // (behind the barrier: nobody is still aggregating from the halo region)
+    if (!tile_wait(p.m, c, ph, s_ok, flags)) return false;
+    NGPDE_PST(p.m, ph, 1);
+    tile_gather_foreign(c, X, ldsXh);
+  }
+  NGPDE_PST(p.m, ph, 2);
+  // T1
+  float4 acc = f4_scale(c.ci, tile_aggregate(c, sw, ldsXh));
+  *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
+  const size_t ev = ev0 + (size_t)(n * p.S + i) * 2 + layer;
+  if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
+  // T2
+  __syncthreads();
+  unsigned f1 = 0;
+  if (nx.exists && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
+  NGPDE_PST(p.m, ph, 3);
+  // T3
+  mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, c.wave_u, c.lane);
+  // T4.  (A workgroup that runs AHEAD of its neighbours looks too early -- their flags of the phase before are published at the
+  // top of their current slot-phase -- and takes the blocking path at its next T0, after which it is behind and finds them; a
+  // second look behind the epilogue's arithmetic was measured: the barrier and the wait for the second load cost what the saved
+  // blocking paths gave, 14.9 against 14.1 ms for 8 members.)
+  if (c.wave_u == 0) {
+    const bool hit = nx.exists && poll_ready(c, f1, nx.ph);
+    if (c.lane == 0) *s_pre = hit ? 1 : 0;
+  }
+  __syncthreads();
+  NGPDE_PST(p.m, ph, 4);
+  // T5.  Every LDS read of the epilogue comes BEFORE a DMA is issued (see halo_fill_ahead)
+  pre = *s_pre != 0;
+  const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), reinterpret_cast<const float4 *>(ldsBias)[c.q]);
+  const float cself = ldsC[36 + i], cf0 = ldsC[i * 6 + 0], cf1 = ldsC[i * 6 + 1], cf2 = ldsC[i * 6 + 2], cf3 = ldsC[i * 6 + 3],
+              cf4 = ldsC[i * 6 + 4];
+  if (pre) halo_fill_ahead(c, nx.X, ldsXh, Snext.xown);
+  const uint8_t sign_bits = (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
+  const float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());
+  float4 v = f4_zero();
+  if (layer != 0) {
+    v = f4_scale(cself, yv);
+    v = f4_fma(1.0f, S.u, v);
+    // (k_i = yv enters with the zero weight cf[i][i], as in node_fwd_persistent_kernel, where it is assigned first)
+    v = f4_fma(cf0, f4_sel(i == 0, yv, S.k0), v); v = f4_fma(cf1, f4_sel(i == 1, yv, S.k1), v); v = f4_fma(cf2, f4_sel(i == 2, yv, S.k2), v);
+    v = f4_fma(cf3, f4_sel(i == 3, yv, S.k3), v); v = f4_fma(cf4, f4_sel(i == 4, yv, S.k4), v);
+  }
+  if (layer == 0) {
+    if (c.valid) store_sc1(bufB, own, yv);
+    S.xown = yv;
+  } else {
+    S.k0 = f4_sel(i == 0, yv, S.k0); S.k1 = f4_sel(i == 1, yv, S.k1); S.k2 = f4_sel(i == 2, yv, S.k2);
+    S.k3 = f4_sel(i == 3, yv, S.k3); S.k4 = f4_sel(i == 4, yv, S.k4); S.k5 = f4_sel(i == 5, yv, S.k5);
+    if (i == p.S - 1) S.u = v;
+    if (c.valid) store_sc1(bufA, own, v);
+    S.xown = v;
+  }
+  NGPDE_PST(p.m, ph, 5);
+  pend_flags = flags;     // published at the next T0 (or behind the loops)
+  pend_ph = ph;
+  if (TAPE) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
+  NGPDE_PST(p.m, ph, 6);
+  return true;
+}
+
+template <int ACT, bool TAPE>
+__global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const PFwdK p) {
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + kMetaF + 48 + 4];
+  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = ldsW1 + kWF, *ldsB = ldsW2 + kWF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
+  TileCtx c;
+  tile_ctx_init(p.m, c, ldsMeta);
+  if (c.tid < 42) ldsC[c.tid] = p.cf[c.tid];
+  const int act = ACT >= 0 ? ACT : p.act;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  load_weight_lds(p.w1, ldsW1, c.tid, true);
+  load_weight_lds(p.w2, ldsW2, c.tid, true);
+  if (c.tid < PD) ldsB[c.tid] = p.b1 ? p.b1[c.tid] : 0.f;
+  else if (c.tid < 2 * PD) ldsB[c.tid] = p.b2 ? p.b2[c.tid - PD] : 0.f;
+  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (c.tid == 0) *s_ok = 1, *s_pre = 0;
+  const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+  __syncthreads();
+  bool ok = true;
+  int ph = 0;   // both slots run the same phase numbers; the count runs on across the pairs
+  bool pre = false;
+  int n_ahead = 0;
+  unsigned *pend_flags = nullptr;
+  int pend_ph = 0;
+  const int NP = p.n_steps * p.S * 2;   // phases of one member
+  for (int mb = 0; mb < p.n_members && ok; mb += 2) {
+    const bool two = mb + 1 < p.n_members;
+    const float *u_in0 = p.u_in + (size_t)mb * p.row_elems, *u_in1 = u_in0 + (two ? p.row_elems : 0);
+    const size_t ev00 = (size_t)mb * NP, ev01 = ev00 + NP;
+    FSlot s0, s1;
+    s0.u = f4_sel(c.valid, ld4_g(u_in0, own), f4_zero());
+    s1.u = f4_sel(c.valid && two, ld4_g(u_in1, own), f4_zero());
+    s0.k0 = s0.k1 = s0.k2 = s0.k3 = s0.k4 = s0.k5 = f4_zero();
+    s1.k0 = s1.k1 = s1.k2 = s1.k3 = s1.k4 = s1.k5 = f4_zero();
+    s0.xown = s0.u;
+    s1.xown = s1.u;
+    int n = 0, i = 0;
+    for (int P = 0; P < NP && ok; P += 2) {   // P: layer-1 phase of stage evaluation (n, i); P + 1: its layer-2 phase
+#pragma unroll
+      for (int layer = 0; layer < 2; ++layer) {
+        ++ph;
+        const float *ldsW = layer == 0 ? ldsW1 : ldsW2, *ldsBias = layer == 0 ? ldsB : ldsB + PD;
+        // the arrays the halo rows of this phase / of the next phase come from, per slot
+        const float *X0 = layer == 0 ? (P == 0 ? u_in0 : p.bufA) : p.bufB;
+        const float *X1 = layer == 0 ? (P == 0 ? u_in1 : p.bufA + p.row_elems) : p.bufB + p.row_elems;
+        FNext nx0, nx1;   // after (phase, slot 0): (phase, slot 1) if there are two slots; after (phase, slot 1): (phase + 1, slot 0)
+        nx0.exists = two; nx0.ph = ph; nx0.X = X1; nx0.flags = p.m.flags + p.flag_stride;
+        nx1.exists = P + layer + 1 < NP; nx1.ph = ph + 1; nx1.X = layer == 0 ? p.bufB : p.bufA; nx1.flags = p.m.flags;
+        if (!fwd_slot_phase<ACT, TAPE>(p, c, s0, s1, 0, ph, n, i, layer, X0, ev00, act, own, pre, n_ahead, pend_flags, pend_ph, nx0, ldsXh, ldsT, ldsZ, ldsW,
+                                       ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
+        if (two && !fwd_slot_phase<ACT, TAPE>(p, c, s1, s0, 1, ph, n, i, layer, X1, ev01, act, own, pre, n_ahead, pend_flags, pend_ph, nx1, ldsXh, ldsT, ldsZ,
+                                              ldsW, ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
+      }
+      if (++i == p.S) i = 0, ++n;
+    }
+    // the last slot-phase's flag (the next pair's first phases wait for it; nothing was gathered ahead: pre is false here)
+    wait_vmcnt0();
+    __syncthreads();
+    if (ok && pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_flags = nullptr;
+    // (a tile writes its rows of u(T) only after all readers of its u0 rows are past that member's first phase)
+    if (c.valid) {
+      st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_sel(ok, s0.u, f4_nan()));
+      if (two) st4_g(p.u_out + (size_t)(mb + 1) * p.row_elems, own, f4_sel(ok, s1.u, f4_nan()));
+    }
+  }
+  if (!ok && c.valid)   // an aborted solve poisons every member's output
+    for (int mb = 0; mb < p.n_members; ++mb) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_nan());
+  if (c.tid == 0 && p.m.stats) p.m.stats[2 * c.tile] = n_ahead;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // discrete adjoint
 // ---------------------------------------------------------------------------------------------------------------------
@@ -373,6 +633,8 @@ struct PBwdK {
   const uint8_t *masks;
   size_t row_elems, mask_bytes;
   float *slab_dw1, *slab_db1, *slab_dw2, *slab_db2;   // [n_tiles][...] written ONCE, at the end
+  size_t flag_stride;  // two-slot kernel: slot s uses g1 / g2 + s * row_elems, the flag words m.flags + s * flag_stride and
+  float *ubar;         // the stage-adjoint scratch ubar + s * 5 * row_elems ([slot][5][N][64])
   const float *cb;     // device table [6 + 36 + 6], copied to LDS: cb[j] = dt * b[j]; cb[6 + i * 6 + j], j > i >= 1: dt * a[j][i-1], the
                        // weight of U-bar_j in K-bar_{i-1}, 0 elsewhere; cb[42 + i] = dt * a[i][i-1], the weight of U-bar_i itself
 };
@@ -544,6 +806,299 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
   write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// discrete adjoint, TWO trajectories of a batch interleaved in one workgroup (see node_fwd_persistent2_kernel)
+// ---------------------------------------------------------------------------------------------------------------------
+// Registers are what this kernel is short of (128 per thread at two workgroups per CU; the parameter-gradient accumulators of
+// both layers take 16, the matrix products ~40), so NO per-slot state stays in them between slot-phases:
+//   * lambda lives in p.lam (its own array, [member][N][64]) and the stage adjoints U-bar_1..5 in a scratch array (p.ubar:
+//     [slot][5][N][64]) -- rows private to the thread that owns them, written when formed, fetched at the top of the slot-phase
+//     that combines them and dead again before the matrix products;
+//   * a slot's own rows of the exchanged array come back by the same LDS-DMA as the foreign ones (they were stored write-through
+//     a slot-phase earlier and are drained by then).
+// Same products, same order of additions per member as node_bwd_persistent_kernel: du0 is bitwise equal; the parameter gradients
+// are summed over the members in interleaved order (equal to rounding).
+struct BNext {          // the slot-phase after this one (see fwd_slot_phase): what can be fetched for it ahead of time
+  bool gather;          // it gathers halo rows (from X, after the flags of its wait list show ph - 1)
+  int ph;
+  const float *X;
+  const unsigned *flags;
+  bool tape;            // it reads a tape row and sign bits (event ev)
+  size_t ev;
+};
+
+__global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const PBwdK p) {
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + kMetaF + 48 + 4];
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
+  float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
+  TileCtx c;
+  tile_ctx_init(p.m, c, ldsMeta);
+  if (c.tid < 48) ldsC[c.tid] = p.cb[c.tid];
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  load_weight_lds(p.w1, ldsW1, c.tid, false);
+  load_weight_lds(p.w2, ldsW2, c.tid, false);
+  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (c.tid == 0) *s_ok = 1, s_pre[0] = 0, s_pre[1] = 0;
+  const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+  constexpr int NT = PG::CT * PG::CT;
+  f32x4 dw1[PG::DWT], dw2[PG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.f, db2 = 0.f;
+  const int dbc = c.tid / PG::DBP, dbpart = c.tid % PG::DBP;
+  const int S = p.S;
+  __syncthreads();
+
+  // state of the software pipeline (uniform): was the coming slot-phase's halo gathered ahead; the flag still to be published;
+  // the tape row and sign bits fetched ahead for the coming slot-phase
+  bool pre = false;
+  int n_ahead = 0;
+  unsigned *pend_flags = nullptr;
+  int pend_ph = 0;
+  unsigned pf_mk = 0;
+  float4 pf_x = f4_zero();
+
+  // T0 of a slot-phase: everything this wave has in flight lands (halo rows gathered ahead, the previous slot-phase's row
+  // stores), the workgroup meets, the previous slot-phase's flag goes out
+  auto t0_publish = [&]() {
+    wait_vmcnt0();
+    __syncthreads();
+    if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_flags = nullptr;
+  };
+
+  // dWt[i][o] += sum_n A[n][i] dZ[n][o] over the tile's 32 rows; db += column sums of dZ.  The operand tiles are __restrict__ so that
+  // these LDS reads do not wait for a DMA issued just before them into the halo region (halo_fill_ahead)
+  auto dw_products = [&](const float *__restrict__ tX, const float *__restrict__ tDZ, f32x4 (&dwl)[PG::DWT], float &dbl) {
+    const int i16 = c.lane & 15, kq = c.lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = c.wave_u + PG::WAVES * mm;
+      if (tt < NT) {   // wave-uniform
+        const int mt = tt / PG::CT, nt = tt % PG::CT;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {   // two halves of the 32-row contraction: 8 operand registers live instead of 16
+          float a[kTM / 8], b[kTM / 8];
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) {
+            a[ks] = tX[(4 * (ks + 4 * kh) + kq) * PG::TS + mt * 16 + i16];
+            b[ks] = tDZ[(4 * (ks + 4 * kh) + kq) * PG::TS + nt * 16 + i16];
+          }
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) dwl[mm] = mfma16(a[ks], b[ks], dwl[mm]);
+        }
+      }
+    }
+    float sdb = 0.f;
+#pragma unroll
+    for (int nn = dbpart; nn < kTM; nn += PG::DBP) sdb += tDZ[nn * PG::TS + dbc];
+#pragma unroll
+    for (int o = 1; o < PG::DBP; o <<= 1) sdb += __shfl_xor(sdb, o);
+    dbl += sdb;
+  };
+
+  // the dense half of a slot-phase (T1's tail .. T5): dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the
+  // next gather (not drained: the flag goes out at the next T0), dW += A^T dZ, db += column sums; the next slot-phase's flags are
+  // looked at under the matrix products and, if they are all there, its halo rows go out before the row stores
+  auto dense = [&](unsigned *flags, int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar,
+                   unsigned mk, float4 xrow, float *gout, const BNext &nx) {
+    kbar = f4_scale(c.ci, kbar);
+    const float4 dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f,
+                                            (mk & 8u) ? kbar.w : 0.f)
+                              : f4_zero();
+    *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
+    *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
+    __syncthreads();   // T2
+    unsigned f1 = 0, f2 = 0;
+    if (nx.gather && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
+    if (nx.tape) {     // the next slot-phase's tape row and sign bits: a slot-phase ahead, so that they are there at its T0
+      pf_mk = ldu8_g(p.masks + nx.ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+      pf_x = ld4_stream_g(p.tape + nx.ev * p.row_elems, own);
+    }
+    NGPDE_PST(p.m, ph, 3);
+    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);   // T3 (the halo region has been free since T2)
+    if (c.wave_u == 0) {   // first look; a second one is on its way if that was too early (see fwd_slot_phase)
+      const bool hit = nx.gather && poll_ready(c, f1, nx.ph);
+      if (nx.gather && !hit) f2 = poll_issue(p.m, c, nx.flags);
+      if (c.lane == 0) *s_pre = hit ? 1 : 0;
+    }
+    __syncthreads();   // T4
+    NGPDE_PST(p.m, ph, 4);
+    const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
+    pre = *s_pre != 0;
+    __syncthreads();   // every thread has read its row of G: the region is the halo again
+    if (pre) halo_fill_all(c, nx.X, ldsXh);   // ... and flies under the parameter-gradient products
+    dw_products(ldsX, ldsDZ, dwl, dbl);
+    if (nx.gather && !pre) {   // uniform: the second look (its own LDS word: a slow wave may not have read the first answer yet)
+      if (c.wave_u == 0) {
+        const bool hit = poll_ready(c, f2, nx.ph);
+        if (c.lane == 0) s_pre[1] = hit ? 1 : 0;
+      }
+      __syncthreads();
+      pre = s_pre[1] != 0;
+      if (pre) halo_fill_all(c, nx.X, ldsXh);
+    }
+    if (c.valid) store_sc1(gout, own, gv);
+    NGPDE_PST(p.m, ph, 5);
+    pend_flags = flags;
+    pend_ph = ph;
+  };
+
+  // the gathering half: T0, then (unless the rows were gathered ahead) own rows + blocking wait + gather
+  auto top = [&](const unsigned *flags, int ph, const float *X) -> bool {
+    t0_publish();
+    n_ahead += pre ? 1 : 0;
+    if (!pre) {
+      if (!tile_wait(p.m, c, ph, s_ok, flags)) return false;
+      NGPDE_PST(p.m, ph, 1);
+      halo_fill_all(c, X, ldsXh);
+      wait_vmcnt0();
+      __syncthreads();
+    }
+    NGPDE_PST(p.m, ph, 2);
+    return true;
+  };
+
+  // layer 1 of stage i of one slot: dL/dy1 = A^T g2
+  auto phase_l1 = [&](int sl, int ph, const BNext &nx) -> bool {
+    float *g1 = p.g1 + (size_t)sl * p.row_elems, *g2 = p.g2 + (size_t)sl * p.row_elems;
+    unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+    NGPDE_PST(p.m, ph, 0);
+    const unsigned mk = pf_mk;
+    const float4 xrow = pf_x;
+    if (!top(flags, ph, g2)) return false;
+    const float4 t = tile_aggregate_lean(c, ldsXh);
+    dense(flags, ph, ldsW1, dw1, db1, t, mk, xrow, g1, nx);
+    return true;
+  };
+
+  // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half.  `last`: the member's
+  // final phase (no dense half, nothing published)
+  auto phase_l2 = [&](int sl, float *lam_g, int ph, int i, bool last, const BNext &nx) -> bool {
+    float *g1 = p.g1 + (size_t)sl * p.row_elems, *g2 = p.g2 + (size_t)sl * p.row_elems;
+    float *ubar = p.ubar + (size_t)sl * 5 * p.row_elems;
+    unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+    NGPDE_PST(p.m, ph, 0);
+    const unsigned mk = pf_mk;
+    const float4 xrow = pf_x;
+    if (!top(flags, ph, g1)) return false;
+    // the stage adjoints this combination needs: U-bar_j, j > i, of THIS step (j < S); everything else enters as an exact zero
+    // (node_bwd_persistent_kernel keeps zeros / finished values with zero weights in those places).  ONE scalar base + 32-bit
+    // offsets the optimiser cannot see through: five bases per slot ended up as 64-bit vector addresses hoisted out of the loops
+    // and spilled
+    float4 ub1 = f4_zero(), ub2 = f4_zero(), ub3 = f4_zero(), ub4 = f4_zero(), ub5 = f4_zero();
+    const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+    unsigned uo = own;
+    asm volatile("" : "+v"(uo));
+    const float4 lam = f4_sel(c.valid, ld4_g(lam_g, uo), f4_zero());
+    if (i < 1 && 1 < S) ub1 = ld4_g(ubar, uo);
+    if (i < 2 && 2 < S) ub2 = ld4_g(ubar, uo + rowb);
+    if (i < 3 && 3 < S) ub3 = ld4_g(ubar, uo + 2 * rowb);
+    if (i < 4 && 4 < S) ub4 = ld4_g(ubar, uo + 3 * rowb);
+    if (i < 5 && 5 < S) ub5 = ld4_g(ubar, uo + 4 * rowb);
+    const float4 t = tile_aggregate_lean(c, ldsXh);
+    float4 kbar;
+    if (i >= 1) {
+      if (c.valid) st4_g(ubar, uo + (unsigned)(i - 1) * rowb, t);   // U-bar_i
+      float4 v = f4_scale(ldsC[42 + i], t);
+      v = f4_fma(ldsC[i - 1], lam, v);
+      v = f4_fma(ldsC[6 + i * 6 + 2], ub2, v); v = f4_fma(ldsC[6 + i * 6 + 3], ub3, v);
+      v = f4_fma(ldsC[6 + i * 6 + 4], ub4, v); v = f4_fma(ldsC[6 + i * 6 + 5], ub5, v);
+      kbar = v;
+    } else {
+      float4 v = f4_scale(1.0f, t);
+      v = f4_fma(1.0f, lam, v);
+      v = f4_fma(1.0f, ub1, v); v = f4_fma(1.0f, ub2, v); v = f4_fma(1.0f, ub3, v);
+      v = f4_fma(1.0f, ub4, v); v = f4_fma(1.0f, ub5, v);
+      if (c.valid) st4_g(lam_g, uo, v);   // lambda of the step before (the member's dL/du~0 at the end)
+      kbar = f4_scale(ldsC[S - 1], v);
+    }
+    if (!last) dense(flags, ph, ldsW2, dw2, db2, kbar, mk, xrow, g2, nx);
+    else pre = false;
+    return true;
+  };
+
+  bool ok = true;
+  int ph = 0;
+  const size_t per = (size_t)p.n_steps * S * 2;   // tape events of one member
+  for (int mb = 0; mb < p.n_members && ok; mb += 2) {
+    const bool two = mb + 1 < p.n_members;
+    float *lam_g0 = p.lam + (size_t)mb * p.row_elems, *lam_g1 = lam_g0 + (two ? p.row_elems : 0);
+    const size_t ev00 = (size_t)mb * per, ev01 = ev00 + per;
+    unsigned *flags0 = p.m.flags, *flags1 = p.m.flags + p.flag_stride;
+    const size_t e1_first = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2;   // layer-1 event of the first stage the adjoint visits
+    {   // first phase of a member: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather, no wait)
+      ++ph;
+      const size_t e = e1_first + 1;
+      BNext nx;
+      {
+        t0_publish();
+        const unsigned mk = ldu8_g(p.masks + (ev00 + e) * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+        const float4 xrow = ld4_stream_g(p.tape + (ev00 + e) * p.row_elems, own);
+        // next: the same phase of slot 1 (nothing to gather; its tape row is read there), or layer 1 of slot 0
+        nx.gather = !two; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !two; nx.ev = ev00 + e1_first;
+        const float4 lam = f4_sel(c.valid, ld4_g(lam_g0, own), f4_zero());
+        dense(flags0, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, nx);
+      }
+      if (two) {
+        t0_publish();
+        const unsigned mk = ldu8_g(p.masks + (ev01 + e) * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+        const float4 xrow = ld4_stream_g(p.tape + (ev01 + e) * p.row_elems, own);
+        nx.gather = true; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = true; nx.ev = ev00 + e1_first;
+        const float4 lam = f4_sel(c.valid, ld4_g(lam_g1, own), f4_zero());
+        dense(flags1, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2 + p.row_elems, nx);
+      }
+    }
+    for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+      for (int i = S - 1; i >= 0 && ok; --i) {
+        const bool last = (i == 0 && n == 0);
+        const size_t e1 = (size_t)(n * S + i) * 2;
+        const size_t e2 = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;
+        const size_t e1n = (i >= 1) ? (size_t)(n * S + i - 1) * 2 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2;   // layer-1 event of the stage after this one
+        BNext nx;
+        ++ph;   // layer 1
+        // after (L1, slot 0): (L1, slot 1) or, with one slot, (L2, slot 0); after (L1, slot 1): (L2, slot 0)
+        nx.gather = true; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g2 + p.row_elems : p.g1; nx.flags = two ? flags1 : flags0;
+        nx.tape = two ? true : !last; nx.ev = two ? ev01 + e1 : ev00 + e2;
+        if (!phase_l1(0, ph, nx)) { ok = false; break; }
+        if (two) {
+          nx.gather = true; nx.ph = ph + 1; nx.X = p.g1; nx.flags = flags0; nx.tape = !last; nx.ev = ev00 + e2;
+          if (!phase_l1(1, ph, nx)) { ok = false; break; }
+        }
+        ++ph;   // layer 2
+        // after (L2, slot 0): (L2, slot 1) or, with one slot, the next stage's (L1, slot 0); after (L2, slot 1): the next (L1, slot 0)
+        nx.gather = two ? true : !last; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g1 + p.row_elems : p.g2; nx.flags = two ? flags1 : flags0;
+        nx.tape = two ? !last : !last; nx.ev = two ? ev01 + e2 : ev00 + e1n;
+        if (!phase_l2(0, lam_g0, ph, i, last, nx)) { ok = false; break; }
+        if (two) {
+          nx.gather = !last; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !last; nx.ev = ev00 + e1n;
+          if (!phase_l2(1, lam_g1, ph, i, last, nx)) { ok = false; break; }
+        }
+      }
+    }
+    // the last published slot-phase's flag (the final phase of a member publishes nothing; the next pair's first phase publishes
+    // ph + 1 and waits for nothing)
+    t0_publish();
+  }
+  if (!ok && c.valid)
+    for (int mb = 0; mb < p.n_members; ++mb) st4_g(p.lam + (size_t)mb * p.row_elems, own, f4_nan());
+  const float bad = __int_as_float(0x7fc00000);
+  auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
+    float4 *slab4 = reinterpret_cast<float4 *>(slab_dw + (size_t)blockIdx.x * PD * PD);
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = c.wave_u + PG::WAVES * mm;
+      if (tt < NT) slab4[tt * 64 + c.lane] = f4_sel(ok, make_float4(dwl[mm][0], dwl[mm][1], dwl[mm][2], dwl[mm][3]), f4_nan());
+    }
+    if (dbpart == 0) slab_db[(size_t)blockIdx.x * PD + dbc] = ok ? dbl : bad;
+  };
+  write_slab(dw1, db1, p.slab_dw1, p.slab_db1);
+  write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
+  if (c.tid == 0 && p.m.stats) p.m.stats[2 * c.tile + 1] = n_ahead;
+}
+
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -595,10 +1150,30 @@ bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_b
   int dev = 0, cus = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, true>, kThreads, 0) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, node_bwd_persistent_kernel, kThreads, 0) != hipSuccess) return false;
+  // co-residency of the spin-waiting workgroups: the minimum over EVERY instantiation a plan of this kind can launch
+  occ_f = occ_b = 1 << 30;
+  auto take = [&](int &acc, auto kernel) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, kThreads, 0) != hipSuccess) o = 0;
+    acc = std::min(acc, o);
+  };
+  take(occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, true>);
+  take(occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, false>);
+  take(occ_f, node_fwd_persistent_kernel<-1, false>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, true>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, false>);
+  take(occ_f, node_fwd_persistent2_kernel<-1, false>);
+  take(occ_b, node_bwd_persistent_kernel);
+  take(occ_b, node_bwd_persistent2_kernel);
   const int nt = g->n_sched / kTileRows;
   return nt >= 1 && nt <= cus * std::min(occ_f, occ_b);
+}
+
+// NGPDE_NO_INTERLEAVE=1: a batch's members one after the other (the round-2 form) instead of two at a time -- the A/B switch and
+// the reference the interleaved kernels are compared with bit for bit
+bool node_persistent_interleave_env() {
+  const char *e = std::getenv("NGPDE_NO_INTERLEAVE");
+  return !(e && e[0] == '1');
 }
 
 int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps) {
@@ -608,14 +1183,17 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
   ps->n_tiles = nt;
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->nbr, lists.size() * sizeof(int)));
   NGPDE_HIP_CHECK(hipMemcpy(ps->nbr, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
-  // flag words: one 128-byte line per tile, + one line for the abort word; zeroed (by a kernel) before every launch
-  ps->sync_bytes = (size_t)(nt + 1) * 128;
+  // flag words: one 128-byte line per tile and slot (two slots: the interleaved kernels), + one line for the abort word; zeroed
+  // (by a kernel) before every launch
+  ps->sync_bytes = (size_t)(2 * nt + 1) * 128;
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->sync, ps->sync_bytes));
   NGPDE_HIP_CHECK(hipMemset(ps->sync, 0, ps->sync_bytes));
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->coef, 90 * sizeof(float)));
   NGPDE_HIP_CHECK(hipMemcpy(ps->coef, coef_host, 90 * sizeof(float), hipMemcpyHostToDevice));
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->fault, 128));
   NGPDE_HIP_CHECK(hipMemset(ps->fault, 0, 128));
+  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->stats, (size_t)nt * 2 * sizeof(int)));
+  NGPDE_HIP_CHECK(hipMemset(ps->stats, 0, (size_t)nt * 2 * sizeof(int)));
   return NGPDE_OK;
 }
 
@@ -624,6 +1202,8 @@ void node_persistent_free(NodePersist *ps) {
   if (ps->sync) (void)hipFree(ps->sync);
   if (ps->fault) (void)hipFree(ps->fault);
   if (ps->coef) (void)hipFree(ps->coef);
+  if (ps->stats) (void)hipFree(ps->stats);
+  ps->stats = nullptr;
   ps->nbr = nullptr; ps->sync = nullptr; ps->fault = nullptr; ps->coef = nullptr;
 }
 
@@ -635,7 +1215,8 @@ __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) 
 TileMeta make_meta(const Csr &c, const NodePersist &ps) {
   TileMeta m;
   m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr;
-  m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 32; m.n_tiles = ps.n_tiles;
+  m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 64; m.n_tiles = ps.n_tiles;   // [slot 0 | slot 1 | abort]
+  m.stats = ps.stats;
 #ifdef NGPDE_STAMPS
   m.stamps = g_pst_base; m.stamps_max = g_pst_max;
 #endif
@@ -662,10 +1243,14 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   k.u_in = a.u_in; k.u_out = a.u_out; k.bufA = a.bufA; k.bufB = a.bufB;
   k.w1 = a.w1; k.b1 = a.b1; k.w2 = a.w2; k.b2 = a.b2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
+  k.flag_stride = (size_t)ps.n_tiles * 32;
   k.cf = ps.coef;
   const dim3 grid(ps.n_tiles), block(kThreads);
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
-  if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+  if (a.interleave) {                                                                                                        \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT>), grid, block, 0, stream, k);                                \
+  } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
   else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
   if (a.tape) {
     NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU && a.masks, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a tape is relu-only");
@@ -694,8 +1279,14 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
   k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;
   k.cb = ps.coef + 42;
+  k.flag_stride = (size_t)ps.n_tiles * 32;
+  k.ubar = a.ubar;
   const dim3 grid(ps.n_tiles), block(kThreads);
-  if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+  if (a.interleave) {
+    NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "interleaved persistent adjoint without its stage-adjoint scratch");
+    if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+    else hipLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, k);
+  } else if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
   else hipLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, k);
   NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);

@@ -46,8 +46,10 @@ struct CombK {
   const float *term[8];
   float coef[8];
 };
+// `out` may alias `base` or a term (in-place accumulation of parameter cotangents: element i is read, then written, by one thread):
+// no __restrict__ on them
 template <int N, class T>
-__global__ void rk_combine_kernel(int64_t count, float c_self, const T *__restrict__ base, const CombK k, T *__restrict__ out) {
+__global__ void rk_combine_kernel(int64_t count, float c_self, const T *base, const CombK k, T *out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
     T t[N > 0 ? N : 1];
 #pragma unroll

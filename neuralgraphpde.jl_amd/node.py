@@ -18,6 +18,7 @@ import weakref
 import torch
 
 from . import _lib
+from .graphs import GNNGraph
 from .layers import AbstractExplicitLayer, Chain, GCNConv, rows_of
 
 _TSIT5_A = [
@@ -166,6 +167,18 @@ def _leaves(tree):
     return out
 
 
+def _graph_leaves(st):
+    """the GNNGraph leaves of a state tree, in traversal order (the leaves updategraph replaces, src/utils.jl:24-31)"""
+    out = []
+    if isinstance(st, dict):
+        for v in st.values():
+            if isinstance(v, GNNGraph):
+                out.append(v)
+            elif isinstance(v, dict):
+                out += _graph_leaves(v)
+    return out
+
+
 def _rebuild(tree, it):
     return {k: (_rebuild(v, it) if isinstance(v, dict) else next(it)) for k, v in tree.items()}
 
@@ -222,9 +235,16 @@ def _rk_backward(node, tape, duT, params, retain=False):
                 if g is None:
                     continue
                 if acc[n] is None:
-                    acc[n] = g
-                else:       # same layout for every stage's cotangent of one parameter: combine in memory order
+                    # own the accumulator in a layout _dense can view without a copy (an expanded / strided cotangent would make
+                    # _dense return a temporary, and the sum written into it would be lost)
+                    acc[n] = g if (g.is_contiguous() or (g.dim() == 2 and g.T.is_contiguous())) else g.contiguous()
+                elif acc[n].stride() == g.stride():
+                    # same layout for every stage's cotangent of one parameter: combine in memory order (out aliases base: the
+                    # kernel reads and writes element i only)
                     _combine(_dense(acc[n]), 1.0, [_dense(g)], [1.0], out=_dense(acc[n]))
+                else:       # layouts differ (one transposed, one not): index-wise sum in the accumulator's own layout
+                    _combine(_dense(acc[n]), 1.0, [_dense(g.contiguous() if acc[n].is_contiguous() else g.T.contiguous().T)], [1.0],
+                             out=_dense(acc[n]))
         live = [x for x in ubar if x is not None]
         if live:
             lam = _combine(lam, 1.0, live, [1.0] * len(live))
@@ -290,13 +310,20 @@ class _CapturedSolve:
         with torch.cuda.graph(self.fwd_graph):
             self.uT_static, self.tape, _ = _rk_forward(node, self.u_static, self.ps_in, st, needs, fresh=True)
         self.bwd_graph = None
+        self.generation = 0                                # forward replays so far: the single static tape belongs to the last one
 
     def forward(self, u):
         self.u_static.copy_(u)
         self.fwd_graph.replay()
+        self.generation += 1
         return self.uT_static
 
-    def backward(self, duT):
+    def backward(self, duT, generation):
+        if generation != self.generation:
+            # `y1 = node(u1); y2 = node(u2); (y1 + y2).backward()`: the second replay has overwritten the first solve's tape
+            raise _lib.NgpdeError(_lib.ERR_STATE, "NeuralODE(capture=True): another forward solve has replaced this solve's tape "
+                                                  "(a captured solve holds ONE tape); run each backward before the next forward "
+                                                  "on the same arguments, or use capture=False")
         if self.bwd_graph is None:
             self.duT_static = duT.detach().clone()
             self.bwd_graph = torch.cuda.CUDAGraph()
@@ -312,11 +339,13 @@ class _NodeCapturedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, solve, *leaves):
         ctx.solve = solve
-        return solve.forward(u.detach().contiguous()).clone()
+        uT = solve.forward(u.detach().contiguous()).clone()
+        ctx.generation = solve.generation
+        return uT
 
     @staticmethod
     def backward(ctx, duT):
-        lam, acc = ctx.solve.backward(duT.contiguous())
+        lam, acc = ctx.solve.backward(duT.contiguous(), ctx.generation)
         it = iter(acc)
         out = [next(it) if (isinstance(p, torch.Tensor) and p.requires_grad) else None for p in ctx.solve.inner]
         return (lam.clone(), None, *[None if g is None else g.clone() for g in out])
@@ -432,8 +461,11 @@ class NeuralODE(AbstractExplicitLayer):
         leaves = _leaves(ps)
         if self.capture:
             needs = torch.is_grad_enabled() and (u.requires_grad or any(isinstance(p, torch.Tensor) and p.requires_grad for p in leaves))
-            g = st.get("graph") if isinstance(st, dict) else None
-            key = (tuple(u.shape), needs, id(g), tuple(p.data_ptr() if isinstance(p, torch.Tensor) else id(p) for p in leaves))
+            # every GNNGraph leaf of the state tree (a container's graphs sit in st["layer_k"]["graph"]): the captures bake in
+            # the addresses of their derived arrays.  The entry keeps `st` -- and with it the graphs -- alive, so an id cannot be
+            # recycled while its key is cached.
+            key = (tuple(u.shape), needs, tuple(id(g) for g in _graph_leaves(st)),
+                   tuple(p.data_ptr() if isinstance(p, torch.Tensor) else id(p) for p in leaves))
             solve = self._captured.get(key)
             if solve is None:
                 solve = self._captured[key] = _CapturedSolve(self, u, ps, st, leaves, needs)

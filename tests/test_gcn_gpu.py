@@ -95,6 +95,35 @@ def test_gcn_generic_dims(din, dout):
     run_layer(61, 300, din, dout, "tanh", seed=din * 100 + dout)
 
 
+@pytest.mark.parametrize("din,dout,N", [(6, 3, 600), (4, 3, 600), (3, 2, 1000), (4, 3, 1999), (5, 9, 1000)])
+def test_gcn_narrow_layers_beyond_512_nodes(din, dout, N):
+    # dout < din with bias above 512 nodes: the bias gradient takes the two-stage column sum, whose partial sums share the
+    # workspace region of the weight pullback's slabs (once sized for the slabs alone: 1536 bytes written into 1024)
+    run_layer(N, 4 * N, din, dout, "tanh", seed=din * 1000 + dout)
+
+
+@pytest.mark.parametrize("din,dout,N", [(6, 3, 600), (4, 3, 600), (3, 2, 1000), (4, 3, 1999), (2, 1, 513)])
+def test_gcn_backward_stays_inside_the_queried_workspace(din, dout, N):
+    # the C ABI with a workspace of EXACTLY the queried size and a canary behind it
+    import ctypes as C
+    from ngpde_amd import _lib
+    lib = _lib.load()
+    s, t = make_graph(N, 4 * N, seed=3)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    h = g.handle((True, None, False))
+    x, wt = torch.randn(N, din, device=DEV), torch.randn(din, dout, device=DEV)
+    z, dy = torch.randn(N, dout, device=DEV), torch.randn(N, dout, device=DEV)
+    dx, dwt, db = torch.empty_like(x), torch.empty_like(wt), torch.empty(dout, device=DEV)
+    need = int(lib.ngpde_gcn_workspace_bytes(h.ptr, din, dout, 1))
+    guard = 1 << 16
+    buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ngpde_gcn_backward(h.ptr, din, dout, 1, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(z), None, _lib.ptr(dy), _lib.ptr(dx),
+                                      _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(buf), C.c_size_t(need), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0x5A).all()), "ngpde_gcn_backward wrote behind its workspace"
+    assert torch.isfinite(db).all() and torch.isfinite(dwt).all()
+
+
 @pytest.mark.parametrize("d", [16, 32, 64, 128])
 @pytest.mark.parametrize("act", ["relu", "swish"])
 def test_gcn_fused_dims(d, act):
@@ -591,3 +620,56 @@ def test_node_persistent_and_replayed_plans_agree_bitwise(monkeypatch):
     a, b = outs["persistent"], outs["replayed"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-5) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,N,tab,nsteps", [(2, 1000, "tsit5", 3), (3, 1000, "euler", 4), (8, 2048, "tsit5", 2), (2, 16384, "tsit5", 4)])
+def test_node_batch_interleaved_members_equal_member_by_member_bitwise(K, N, tab, nsteps, monkeypatch):
+    # a batch of identical structures runs two members at a time per workgroup (one computes while the other's rows travel);
+    # per member the arithmetic is that of the member-by-member launch (NGPDE_NO_INTERLEAVE=1) operation for operation: u(T)
+    # and du0 bit for bit, the parameter gradients to rounding (summed over the members in another order).  K = 3: an odd last
+    # member alone in slot 0; N = 16 384: the 512-tile / two-workgroups-per-CU regime of the bench's `batched` leg
+    needs_persistent_plan(monkeypatch)
+    d, dt = 64, 0.05
+    g, og, params = spatial_case(N, 4 * N, d, seed=300 + K)
+    rng = np.random.default_rng(301 + K)
+    u0 = torch.as_tensor(rng.normal(size=(d, K * N)).astype(np.float32), device=DEV)
+    R = torch.as_tensor(rng.normal(size=(d, K * N)).astype(np.float32), device=DEV)
+    outs = {}
+    for mode in ("interleaved", "member_by_member"):
+        if mode == "member_by_member":
+            monkeypatch.setenv("NGPDE_NO_INTERLEAVE", "1")
+        else:
+            monkeypatch.delenv("NGPDE_NO_INTERLEAVE", raising=False)
+        gb = ng.batch([g] + [g.copy() for _ in range(K - 1)])
+        rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=gb), ng.GCNConv((d, d), "relu", initialgraph=gb))
+        node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        plan = next(iter(node._plans.values()))[0]
+        assert plan.members == K and {"persistent_fwd", "persistent_bwd"} <= plan.flags()
+        (uT * R).sum().backward()
+        assert not plan.fault()
+        outs[mode] = [uT.detach().clone(), u.grad.clone()] + [ps[l][k].grad.clone() for l in ("layer_1", "layer_2") for k in ("weight", "bias")]
+        with torch.no_grad():                       # the forward-only plan (no tape) of the same batch
+            uT2, _ = node(u0, ps, st)
+        assert torch.equal(uT2, outs[mode][0])
+    a, b = outs["interleaved"], outs["member_by_member"]
+    assert torch.equal(a[0], b[0]), "u(T)"
+    assert torch.equal(a[1], b[1]), "du0"
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-5 * float(y.abs().max()))
+    # and member 0 / the last member against the float64 oracle of that member alone
+    for m in (0, K - 1):
+        sl = slice(m * N, (m + 1) * N)
+        uTo, du0o, _ = _oracle_node_with_seed(params, og, u0[:, sl].cpu().double().numpy(), R[:, sl].cpu().double().numpy(),
+                                              O.TABLEAUS[tab], dt, nsteps)
+        close(a[0][:, sl], uTo, rtol=2e-4, what=f"u(T) member {m}")
+        close(a[1][:, sl], du0o, rtol=5e-4, atol=1e-4, what=f"du0 member {m}")

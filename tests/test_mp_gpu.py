@@ -10,6 +10,7 @@ import torch
 
 import ngpde_amd as ng
 from oracle import ngpde_oracle as O
+from ngpde_amd import _lib
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -967,6 +968,38 @@ def test_captured_generic_solve_replays_and_follows_parameter_updates(monkeypatc
         a1, _ = captured(u, ps, st)
         a2, _ = eager(u, ps, st)
     assert torch.equal(a1, a2) and len(captured._captured) == 2
+
+
+def test_captured_solve_follows_updategraph_in_a_container_and_guards_its_single_tape():
+    # (i) a container right-hand side keeps its graphs in st["layer_k"]["graph"]: updategraph(st, g2) must capture anew instead of
+    # replaying launches with the old graph's arrays baked in; (ii) a captured solve holds ONE tape: the backward of a solve
+    # whose tape a later forward replaced raises instead of returning the other solve's gradients
+    n, H, C_ = 300, 4, 16
+    s1, t1 = _local_graph(n, 81)
+    s2, t2 = _local_graph(n, 82)
+    g1 = ng.GNNGraph(s1, t1, num_nodes=n, index_base=0)
+    g2 = ng.GNNGraph(s2, t2, num_nodes=n, index_base=0)
+    mk = lambda g: ng.Chain(ng.GATConv((64, C_), "tanh", heads=H, concat=True, initialgraph=g))
+    eager = ng.NeuralODE(mk(g1), solver="euler", n_steps=2, dt=0.05)
+    captured = ng.NeuralODE(mk(g1), solver="euler", n_steps=2, dt=0.05, capture=True)
+    ps, st = ng.setup(81, eager)
+    ps = prep(ps, 81)
+    u = torch.randn(64, n, device=DEV)
+    with torch.no_grad():
+        a1, _ = captured(u, ps, st)
+        r1, _ = eager(u, ps, st)
+        st2 = ng.updategraph(st, g2)
+        a2, _ = captured(u, ps, st2)
+        r2, _ = eager(u, ps, st2)
+    assert torch.equal(a1, r1) and torch.equal(a2, r2) and not torch.equal(r1, r2)
+    assert len(captured._captured) == 2
+    ua, ub = torch.randn(64, n, device=DEV, requires_grad=True), torch.randn(64, n, device=DEV, requires_grad=True)
+    ya, _ = captured(ua, ps, st)
+    yb, _ = captured(ub, ps, st)
+    with pytest.raises(_lib.NgpdeError, match="ONE tape"):
+        (ya.sum() + yb.sum()).backward()
+    yc, _ = captured(ua, ps, st)          # forward then backward, in order: fine
+    yc.sum().backward()
 
 
 def test_vmh_as_ode_right_hand_side():
