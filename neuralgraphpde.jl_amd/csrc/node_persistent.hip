@@ -183,6 +183,36 @@ __device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, i
   return *s_ok != 0;
 }
 __device__ __forceinline__ bool tile_wait(const TileMeta &m, const TileCtx &c, int ph, int *s_ok) { return tile_wait(m, c, ph, s_ok, m.flags); }
+// The same wait with its first round of flag loads issued earlier by the caller (poll_issue: `f` holds wave 0's samples, in flight
+// under whatever the workgroup did in between).  A workgroup that is level with its neighbours finds the flags in that sample
+// and only meets at the barrier; one that runs ahead spins here exactly as long as it leads.  (Used by the interleaved adjoint,
+// whose slot-phase is long enough for the flags to be there.  What the stamps of tools/stamps_interleaved.py say about the hand-off:
+// a flag store is seen by a poll from another XCD ~3-4 k cycles (1.2-1.5 us) after it was issued, a poll or a gather is a
+// ~1.5 k-cycle round trip, the drain in front of the flag ~1 k: with only two slots the ~2.4 us of hand-off exceed the ~1.7 us of
+// work the other slot offers in the forward kernel -- wherever the look is put, the difference is waited for.)
+__device__ __forceinline__ bool tile_wait_primed(const TileMeta &m, const TileCtx &c, int ph, int *s_ok, const unsigned *flags, unsigned f) {
+  if (c.wave_u == 0) {
+    const unsigned need = (unsigned)(ph - 1);
+    const unsigned *addr = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? flags + 32 * c.my_nbr : nullptr);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (unsigned it = 1;; ++it) {
+      if (__any((int)(c.lane == 63 && f != 0))) { ok = false; break; }
+      if (__all((int)(c.lane == 63 || f >= need))) break;
+      if ((it & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (c.lane == 0) __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      f = (c.lane == 63) ? 0u : need;
+      if (addr) f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (c.lane == 0) *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
 
 // every storing wave drains, the workgroup meets, ONE lane publishes (Guideline 16, R1)
 __device__ __forceinline__ void tile_publish(const TileCtx &c, int ph, unsigned *flags) {
@@ -840,7 +870,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   load_weight_lds(p.w1, ldsW1, c.tid, false);
   load_weight_lds(p.w2, ldsW2, c.tid, false);
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
-  if (c.tid == 0) *s_ok = 1, s_pre[0] = 0, s_pre[1] = 0;
+  if (c.tid == 0) *s_ok = 1, *s_pre = 0;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
   constexpr int NT = PG::CT * PG::CT;
   f32x4 dw1[PG::DWT], dw2[PG::DWT];
@@ -853,7 +883,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
 
   // state of the software pipeline (uniform): was the coming slot-phase's halo gathered ahead; the flag still to be published;
   // the tape row and sign bits fetched ahead for the coming slot-phase
-  bool pre = false;
+  bool pre = false, dead = false;   // dead: a wait inside a dense half was aborted
   int n_ahead = 0;
   unsigned *pend_flags = nullptr;
   int pend_ph = 0;
@@ -911,34 +941,30 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
     __syncthreads();   // T2
-    unsigned f1 = 0, f2 = 0;
-    if (nx.gather && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
     if (nx.tape) {     // the next slot-phase's tape row and sign bits: a slot-phase ahead, so that they are there at its T0
       pf_mk = ldu8_g(p.masks + nx.ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
       pf_x = ld4_stream_g(p.tape + nx.ev * p.row_elems, own);
     }
     NGPDE_PST(p.m, ph, 3);
-    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);   // T3 (the halo region has been free since T2)
-    if (c.wave_u == 0) {   // first look; a second one is on its way if that was too early (see fwd_slot_phase)
-      const bool hit = nx.gather && poll_ready(c, f1, nx.ph);
-      if (nx.gather && !hit) f2 = poll_issue(p.m, c, nx.flags);
-      if (c.lane == 0) *s_pre = hit ? 1 : 0;
+    // T3: both matrix products of the phase back to back (no barrier between them: they read the same operand tiles and write
+    // different things): G = dZ W^T into the halo region (free since T2), then dW += A^T dZ, db.  Wave 0 fetches the next
+    // slot-phase's flags between the two -- as late as it can be done with the answer still there when the products end
+    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
+    unsigned f1 = 0;
+    if (nx.gather && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
+    dw_products(ldsX, ldsDZ, dwl, dbl);
+    // T4: the next slot-phase's flags (wave 0 spins if this workgroup leads its neighbours; see tile_wait_primed), the barrier
+    if (nx.gather) {   // uniform
+      if (!tile_wait_primed(p.m, c, nx.ph, s_ok, nx.flags, f1)) { dead = true; return; }
+    } else {
+      __syncthreads();
     }
-    __syncthreads();   // T4
     NGPDE_PST(p.m, ph, 4);
     const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
-    pre = *s_pre != 0;
-    __syncthreads();   // every thread has read its row of G: the region is the halo again
-    if (pre) halo_fill_all(c, nx.X, ldsXh);   // ... and flies under the parameter-gradient products
-    dw_products(ldsX, ldsDZ, dwl, dbl);
-    if (nx.gather && !pre) {   // uniform: the second look (its own LDS word: a slow wave may not have read the first answer yet)
-      if (c.wave_u == 0) {
-        const bool hit = poll_ready(c, f2, nx.ph);
-        if (c.lane == 0) s_pre[1] = hit ? 1 : 0;
-      }
-      __syncthreads();
-      pre = s_pre[1] != 0;
-      if (pre) halo_fill_all(c, nx.X, ldsXh);
+    pre = nx.gather;
+    if (pre) {   // uniform
+      __syncthreads();   // every thread has read its row of G: the region is the halo again
+      halo_fill_all(c, nx.X, ldsXh);
     }
     if (c.valid) store_sc1(gout, own, gv);
     NGPDE_PST(p.m, ph, 5);
@@ -969,9 +995,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     const unsigned mk = pf_mk;
     const float4 xrow = pf_x;
     if (!top(flags, ph, g2)) return false;
-    const float4 t = tile_aggregate_lean(c, ldsXh);
+    const float4 t = tile_aggregate_lean(c, ldsXh);   // (the unrolled form with the slot words in registers: 24 spilled dwords)
     dense(flags, ph, ldsW1, dw1, db1, t, mk, xrow, g1, nx);
-    return true;
+    return !dead;
   };
 
   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half.  `last`: the member's
@@ -998,7 +1024,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     if (i < 3 && 3 < S) ub3 = ld4_g(ubar, uo + 2 * rowb);
     if (i < 4 && 4 < S) ub4 = ld4_g(ubar, uo + 3 * rowb);
     if (i < 5 && 5 < S) ub5 = ld4_g(ubar, uo + 4 * rowb);
-    const float4 t = tile_aggregate_lean(c, ldsXh);
+    const float4 t = tile_aggregate_lean(c, ldsXh);   // (the unrolled form with the slot words in registers: 24 spilled dwords)
     float4 kbar;
     if (i >= 1) {
       if (c.valid) st4_g(ubar, uo + (unsigned)(i - 1) * rowb, t);   // U-bar_i
@@ -1017,7 +1043,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     }
     if (!last) dense(flags, ph, ldsW2, dw2, db2, kbar, mk, xrow, g2, nx);
     else pre = false;
-    return true;
+    return !dead;
   };
 
   bool ok = true;
@@ -1038,17 +1064,21 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
         const unsigned mk = ldu8_g(p.masks + (ev00 + e) * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
         const float4 xrow = ld4_stream_g(p.tape + (ev00 + e) * p.row_elems, own);
         // next: the same phase of slot 1 (nothing to gather; its tape row is read there), or layer 1 of slot 0
-        nx.gather = !two; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !two; nx.ev = ev00 + e1_first;
+        // (one slot: nothing is gathered ahead -- the next slot-phase is this slot's own next phase, whose flags cannot be there
+        // before this one's is published -- only its tape row is fetched)
+        nx.gather = false; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !two; nx.ev = ev00 + e1_first;
         const float4 lam = f4_sel(c.valid, ld4_g(lam_g0, own), f4_zero());
         dense(flags0, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, nx);
+        if (dead) ok = false;
       }
-      if (two) {
+      if (two && ok) {
         t0_publish();
         const unsigned mk = ldu8_g(p.masks + (ev01 + e) * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
         const float4 xrow = ld4_stream_g(p.tape + (ev01 + e) * p.row_elems, own);
         nx.gather = true; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = true; nx.ev = ev00 + e1_first;
         const float4 lam = f4_sel(c.valid, ld4_g(lam_g1, own), f4_zero());
         dense(flags1, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2 + p.row_elems, nx);
+        if (dead) ok = false;
       }
     }
     for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
@@ -1060,7 +1090,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
         BNext nx;
         ++ph;   // layer 1
         // after (L1, slot 0): (L1, slot 1) or, with one slot, (L2, slot 0); after (L1, slot 1): (L2, slot 0)
-        nx.gather = true; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g2 + p.row_elems : p.g1; nx.flags = two ? flags1 : flags0;
+        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g2 + p.row_elems : p.g1; nx.flags = two ? flags1 : flags0;
         nx.tape = two ? true : !last; nx.ev = two ? ev01 + e1 : ev00 + e2;
         if (!phase_l1(0, ph, nx)) { ok = false; break; }
         if (two) {
@@ -1069,7 +1099,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
         }
         ++ph;   // layer 2
         // after (L2, slot 0): (L2, slot 1) or, with one slot, the next stage's (L1, slot 0); after (L2, slot 1): the next (L1, slot 0)
-        nx.gather = two ? true : !last; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g1 + p.row_elems : p.g2; nx.flags = two ? flags1 : flags0;
+        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g1 + p.row_elems : p.g2; nx.flags = two ? flags1 : flags0;
         nx.tape = two ? !last : !last; nx.ev = two ? ev01 + e2 : ev00 + e1n;
         if (!phase_l2(0, lam_g0, ph, i, last, nx)) { ok = false; break; }
         if (two) {
