@@ -179,6 +179,7 @@ struct NodePersistFwd {
   const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
   float *tape = nullptr;
   uint8_t *masks = nullptr;
+  float *ztape = nullptr;      // pre-activations (adjoint of an activation other than relu), same shape as tape
   size_t row_elems = 0, mask_bytes = 0;
   bool interleave = false;     // two members of a batch at a time per workgroup: bufA / bufB hold two [N][64] arrays each
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -186,9 +187,9 @@ struct NodePersistFwd {
 struct NodePersistBwd {
   const ngpde_graph *g = nullptr;
   const NodePersist *ps = nullptr;
-  int n_steps = 0, S = 0, n_members = 1;
+  int n_steps = 0, S = 0, n_members = 1, act = NGPDE_ACT_RELU;
   float *lam = nullptr, *g1 = nullptr, *g2 = nullptr;
-  const float *w1 = nullptr, *w2 = nullptr, *tape = nullptr;
+  const float *w1 = nullptr, *w2 = nullptr, *tape = nullptr, *ztape = nullptr;
   const uint8_t *masks = nullptr;
   size_t row_elems = 0, mask_bytes = 0;
   float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;

@@ -115,6 +115,10 @@ struct ngpde_node {
   // synchronised by per-tile phase flags.  Chosen when the graph is one co-resident wave of tiles (<= 2 per CU), d = 64,
   // relu (adjoint), unweighted, pre-scaled form available; NGPDE_NO_PERSISTENT=1 or NGPDE_PERSISTENT=fwd|bwd restrict it.
   bool persist_fwd = false, persist_bwd = false;
+  // persistent adjoint of an activation other than relu: the tape holds the aggregated inputs (first half) and the pre-activations
+  // (second half, `ztape`), two rows per stage evaluation each, indexed like the relu plan's tape
+  bool ztape_mode = false;
+  float *ztape = nullptr;
   NodePersist persist;
   float *pbuf = nullptr;     // layer-1 output exchanged between tiles in the persistent forward
   // a batch (members > 1) runs two members at a time per workgroup (node_persistent.hip, "slots"): the exchanged arrays
@@ -322,7 +326,7 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
   a.row_elems = p->row_elems;
   if (p->with_bwd) {
-    a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes;
+    a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   }
   a.interleave = p->interleave;
   a.ev_start = ev0; a.ev_stop = ev1;
@@ -331,9 +335,9 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
 
 int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   NodePersistBwd a;
-  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.n_members = p->members;
+  a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.n_members = p->members; a.act = p->act;
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
-  a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes;
+  a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
   a.interleave = p->interleave; a.ubar = p->pubar;
   a.ev_start = ev0; a.ev_stop = ev1;
@@ -434,15 +438,46 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   p->all_elems = (size_t)members * p->row_elems;
   p->nb = fused_num_blocks(p->n);
   p->mask_mode = p->with_bwd && act == NGPDE_ACT_RELU && std::getenv("NGPDE_NO_MASK") == nullptr;
-  p->slots = p->mask_mode ? 2 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4);
-  p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
   p->pre = fused_prescaled_supported(g, d) && std::getenv("NGPDE_NO_PRESCALE") == nullptr;
+  // The persistent form (node_persistent.hip) is decided here, before the tape is sized: with an activation other than relu its
+  // adjoint reads the pre-activations from a tape of its own layout.  (Interleaved batches: relu only.)
+  bool want_persist = p->pre && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1)) &&
+                      node_persistent_supported(g, d, act, p->with_bwd);
+  const int S = p->tb.S;
+  int32_t st = NGPDE_OK;
+  if (want_persist) {
+    const char *only = std::getenv("NGPDE_PERSISTENT");
+    p->persist_fwd = !(only && std::strcmp(only, "bwd") == 0);
+    p->persist_bwd = p->with_bwd && !(only && std::strcmp(only, "fwd") == 0);
+    // stage-indexed coefficient tables (device memory): forward cf[i][j], adjoint dtb[j], cu[i][j]
+    float coef[90] = {0};   // forward: cf[i][j] (j < i) at i * 6 + j, self weights at 36 + i; adjoint: dt b at 42 + j,
+                            // cu[i][j] (j > i >= 1) at 48 + i * 6 + j, self weights at 84 + i  (node_persistent.hip)
+    const Tableau &tb = p->tb;
+    for (int i = 0; i < S; ++i) {
+      const std::vector<double> &row = (i == S - 1) ? tb.b : tb.a[i + 1];
+      for (int j = 0; j < i; ++j) coef[i * 6 + j] = (float)(dt * row[j]);
+      coef[36 + i] = (float)(dt * row[i]);
+      coef[42 + i] = (float)(dt * tb.b[i]);
+    }
+    for (int i = 1; i < S; ++i) {
+      for (int j = i + 1; j < S; ++j) coef[48 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
+      coef[84 + i] = (float)(dt * tb.a[i][i - 1]);
+    }
+    st = node_persistent_setup(g, coef, &p->persist);
+    if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave: keep the replayed plan
+      st = NGPDE_OK;
+      p->persist_fwd = p->persist_bwd = false;
+    }
+  }
+  // activations other than relu: the persistent pair needs BOTH directions persistent (the tapes' layouts differ from the replayed plan's)
+  if (p->with_bwd && !p->mask_mode && !(p->persist_fwd && p->persist_bwd)) p->persist_fwd = p->persist_bwd = false;
+  p->ztape_mode = p->with_bwd && !p->mask_mode && p->persist_fwd && p->persist_bwd;
+  p->slots = p->mask_mode ? 2 : (p->ztape_mode ? 4 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4));
+  p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
   p->interleave = members > 1 && node_persistent_interleave_env();
   const size_t xslots = p->interleave ? 2 : 1;   // [N][d] arrays per exchanged buffer
-  const int S = p->tb.S;
-  int32_t st = NGPDE_OK;
   auto A = [&](float **ptr, size_t elems) {
     if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
   };
@@ -478,31 +513,8 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
     }
     A(&p->dw1, dd); A(&p->db1, d); A(&p->dw2, dd); A(&p->db2, d);
   }
-  if (st == NGPDE_OK && p->pre && (!p->with_bwd || p->mask_mode) && node_persistent_supported(g, d, act, p->with_bwd)) {
-    const char *only = std::getenv("NGPDE_PERSISTENT");
-    p->persist_fwd = !(only && std::strcmp(only, "bwd") == 0);
-    p->persist_bwd = p->with_bwd && !(only && std::strcmp(only, "fwd") == 0);
-    // stage-indexed coefficient tables (device memory): forward cf[i][j], adjoint dtb[j], cu[i][j]
-    float coef[90] = {0};   // forward: cf[i][j] (j < i) at i * 6 + j, self weights at 36 + i; adjoint: dt b at 42 + j,
-                            // cu[i][j] (j > i >= 1) at 48 + i * 6 + j, self weights at 84 + i  (node_persistent.hip)
-    const Tableau &tb = p->tb;
-    for (int i = 0; i < S; ++i) {
-      const std::vector<double> &row = (i == S - 1) ? tb.b : tb.a[i + 1];
-      for (int j = 0; j < i; ++j) coef[i * 6 + j] = (float)(dt * row[j]);
-      coef[36 + i] = (float)(dt * row[i]);
-      coef[42 + i] = (float)(dt * tb.b[i]);
-    }
-    for (int i = 1; i < S; ++i) {
-      for (int j = i + 1; j < S; ++j) coef[48 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
-      coef[84 + i] = (float)(dt * tb.a[i][i - 1]);
-    }
-    st = node_persistent_setup(g, coef, &p->persist);
-    if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave: keep the replayed plan
-      st = NGPDE_OK;
-      p->persist_fwd = p->persist_bwd = false;
-    }
-    if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, xslots * p->row_elems);
-  }
+  if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, xslots * p->row_elems);
+  if (st == NGPDE_OK && p->ztape_mode) p->ztape = p->tape + (size_t)n_steps * S * 2 * p->all_elems;
   if (st == NGPDE_OK && members > 1 && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd)))
     st = fail(NGPDE_ERR_UNSUPPORTED, "ngpde_node_gcn2_create_batch: the member-by-member solve exists for the persistent plan only "
                                      "(d = 64, relu, unweighted, at most two 32-row tiles per CU); batch the graphs into one handle instead");

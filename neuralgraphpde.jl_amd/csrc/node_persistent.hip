@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "device_utils.h"
@@ -368,6 +369,7 @@ struct PFwdK {
   const float *w1, *b1, *w2, *b2;
   float *tape;         // [n_members][n_steps][S][2][N][64] aggregated layer inputs, or null (forward-only plan)
   uint8_t *masks;      // [n_members][n_steps][S][2][mask_bytes] relu sign bits
+  float *ztape;        // same shape as tape: the pre-activations, kept instead of the sign bits when the activation is not relu
   size_t row_elems, mask_bytes;
   size_t flag_stride;  // two-slot kernels: slot s uses bufA / bufB + s * row_elems and the flag words m.flags + s * flag_stride
   const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
@@ -449,8 +451,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         NGPDE_PST(p.m, ph, 5);
         tile_publish(p.m, c, ph);
         NGPDE_PST(p.m, ph, 6);
-        // relu' for the adjoint: only the adjoint launch reads it, so it leaves after the rows are published
-        if (TAPE) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
+        // relu' for the adjoint (any other activation: the pre-activation itself): only the adjoint launch reads it, so it leaves
+        // after the rows are published
+        if constexpr (TAPE && ACT == NGPDE_ACT_RELU) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
+        else if (TAPE && c.valid) st4_stream_g(p.ztape + ev * p.row_elems, own, z);
       }
     }
   }
@@ -655,7 +659,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const
 // ---------------------------------------------------------------------------------------------------------------------
 struct PBwdK {
   TileMeta m;          // lists by SOURCE
-  int n_steps, S, n_members;
+  int n_steps, S, n_members, act;
+  const float *ztape;  // pre-activations (activations other than relu), or null
   float *lam;          // [n_members][N][64] in: dL/du~(T) (adjoint seed ./ c); out: dL/du~0
   float *g1, *g2;      // exchanged arrays: c .* (dZ1 W1^T), c .* (dZ2 W2^T)
   const float *w1, *w2;
@@ -669,7 +674,12 @@ struct PBwdK {
                        // weight of U-bar_j in K-bar_{i-1}, 0 elsewhere; cb[42 + i] = dt * a[i][i-1], the weight of U-bar_i itself
 };
 
+// ACT = NGPDE_ACT_RELU: relu' from the forward launch's sign bits; ACT = -1: any activation (p.act), act'(z) from the saved
+// pre-activations (one more tape row per phase)
+template <int ACT>
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const PBwdK p) {
+  constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
+  using Aux = typename std::conditional<RELU, unsigned, float4>::type;   // what act' is formed from: 4 sign bits / the row of z
   __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + kMetaF + 48 + 4];
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
   float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + kMetaF;
@@ -694,11 +704,15 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
 
   // the dense half of a phase: dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the next gather,
   // dW += A^T dZ, db += column sums; then publish and keep the own rows of G in the halo slots
-  auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, unsigned mk, float4 xrow, float *gout) {
+  auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout) {
     kbar = f4_scale(c.ci, kbar);
-    const float4 dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f,
-                                            (mk & 8u) ? kbar.w : 0.f)
-                              : f4_zero();
+    float4 dz;
+    if constexpr (RELU) {
+      dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f, (mk & 8u) ? kbar.w : 0.f)
+                   : f4_zero();
+    } else {
+      dz = f4_sel(c.valid, f4_mul(kbar, f4_dact(p.act, mk)), f4_zero());
+    }
     *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
     __syncthreads();
@@ -746,7 +760,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     NGPDE_PST(p.m, ph, 7);
   };
   auto tape_row = [&](size_t ev) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
-  auto mask_of = [&](size_t ev) { return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid); };
+  auto mask_of = [&](size_t ev) -> Aux {
+    if constexpr (RELU) return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+    else return ld4_stream_g(p.ztape + ev * p.row_elems, own);
+  };
 
   bool ok = true;
   int ph = 0;   // phases count on across the members (the parameter-gradient accumulators too: the gradient of a batch is the sum)
@@ -767,7 +784,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
         ++ph;
         const size_t ev = ev0 + (size_t)(n * S + i) * 2;
         NGPDE_PST(p.m, ph, 0);
-        const unsigned mk = mask_of(ev);          // own-row loads: in flight during the wait
+        const Aux mk = mask_of(ev);               // own-row loads: in flight during the wait
         const float4 xrow = tape_row(ev);
         unsigned sw[8];
         tile_slot_words(c, sw);
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
         ++ph;
         const bool last = (i == 0 && n == 0);
         const size_t ev = ev0 + ((i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1);
-        unsigned mk = 0;
+        Aux mk{};
         float4 xrow = f4_zero();
         NGPDE_PST(p.m, ph, 0);
         if (!last) {
@@ -1176,7 +1193,6 @@ bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_b
   if (node_persistent_disabled_env()) return false;
   if (!g || d != PD || !fused_prescaled_supported(g, d)) return false;
   if (g->by_t.slot_w || g->by_s.slot_w) return false;
-  if (with_bwd && act != NGPDE_ACT_RELU) return false;
   int dev = 0, cus = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -1193,7 +1209,9 @@ bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_b
   take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, true>);
   take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, false>);
   take(occ_f, node_fwd_persistent2_kernel<-1, false>);
-  take(occ_b, node_bwd_persistent_kernel);
+  take(occ_b, node_bwd_persistent_kernel<NGPDE_ACT_RELU>);
+  take(occ_b, node_bwd_persistent_kernel<-1>);
+  take(occ_f, node_fwd_persistent_kernel<-1, true>);
   take(occ_b, node_bwd_persistent2_kernel);
   const int nt = g->n_sched / kTileRows;
   return nt >= 1 && nt <= cus * std::min(occ_f, occ_b);
@@ -1282,9 +1300,14 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT>), grid, block, 0, stream, k);                                \
   } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
   else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
-  if (a.tape) {
-    NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU && a.masks, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a tape is relu-only");
+  k.ztape = a.ztape;
+  if (a.tape && a.act == NGPDE_ACT_RELU) {
+    NGPDE_REQUIRE(a.masks != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a relu tape needs the sign-bit masks");
     NGPDE_PF_LAUNCH(NGPDE_ACT_RELU, true)
+  } else if (a.tape) {
+    NGPDE_REQUIRE(a.ztape != nullptr && !a.interleave, NGPDE_ERR_INVALID_ARGUMENT,
+                  "persistent forward with a tape: activations other than relu keep the pre-activations (one member at a time)");
+    NGPDE_PF_LAUNCH(-1, true)
   } else if (a.act == NGPDE_ACT_RELU) {
     NGPDE_PF_LAUNCH(NGPDE_ACT_RELU, false)
   } else {
@@ -1304,7 +1327,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
   k.m = make_meta(g->by_s, ps);
-  k.n_steps = a.n_steps; k.S = a.S; k.n_members = a.n_members;
+  k.n_steps = a.n_steps; k.S = a.S; k.n_members = a.n_members; k.act = a.act; k.ztape = a.ztape;
   k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
   k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;
@@ -1316,8 +1339,12 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "interleaved persistent adjoint without its stage-adjoint scratch");
     if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
     else hipLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, k);
-  } else if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
-  else hipLaunchKernelGGL(node_bwd_persistent_kernel, grid, block, 0, stream, k);
+  } else if (a.act != NGPDE_ACT_RELU) {
+    NGPDE_REQUIRE(a.ztape != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
+    if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel<-1>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+    else hipLaunchKernelGGL(node_bwd_persistent_kernel<-1>, grid, block, 0, stream, k);
+  } else if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel<NGPDE_ACT_RELU>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+  else hipLaunchKernelGGL(node_bwd_persistent_kernel<NGPDE_ACT_RELU>, grid, block, 0, stream, k);
   NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");

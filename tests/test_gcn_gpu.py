@@ -533,14 +533,18 @@ def test_node_batch_of_identical_graphs_member_by_member(tab, persistent, monkey
         close(ps[name]["bias"].grad, accb[k], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
 
 
-@pytest.mark.parametrize("tab,N,nsteps", [("tsit5", 1000, 3), ("euler", 2048, 5), ("tsit5", 77, 2)])
-def test_node_persistent_plan_against_oracle(tab, N, nsteps, monkeypatch):
+@pytest.mark.parametrize("tab,N,nsteps,act", [("tsit5", 1000, 3, "relu"), ("euler", 2048, 5, "relu"), ("tsit5", 77, 2, "relu"),
+                                              ("tsit5", 1000, 3, "tanh"), ("euler", 2048, 4, "swish"), ("tsit5", 16384, 2, "tanh"),
+                                              ("tsit5", 500, 2, "leakyrelu"), ("tsit5", 500, 2, "identity")])
+def test_node_persistent_plan_against_oracle(tab, N, nsteps, act, monkeypatch):
     needs_persistent_plan(monkeypatch)
     # the persistent plan (one launch per direction, tiles synchronised by phase flags) on graphs whose tiles fit the LDS halo:
-    # u(T), du0 and the parameter gradients against the float64 oracle; a last tile with padding rows (N = 1000, 77)
+    # u(T), du0 and the parameter gradients against the float64 oracle; a last tile with padding rows (N = 1000, 77); activations
+    # other than relu (the tutorial's chain with tanh, graph_node.md:78 takes any NNlib activation): the adjoint launch forms
+    # act'(z) from the pre-activations the forward launch keeps instead of the sign bits
     d, dt = 64, 0.1
     g, og, params = spatial_case(N, 4 * N, d, seed=N)
-    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
     node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
     ps, st = ng.setup(0, node)
     for k, name in enumerate(["layer_1", "layer_2"]):
@@ -559,7 +563,7 @@ def test_node_persistent_plan_against_oracle(tab, N, nsteps, monkeypatch):
     assert plan.launch_count() == (3, 7)
     (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
     assert not plan.fault()
-    uTo, du0o, acc = _oracle_node_with_seed(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps)
+    uTo, du0o, acc = _oracle_node_with_seed(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps, act)
     close(uT, uTo, rtol=2e-4, what="u(T)")
     close(u.grad, du0o, rtol=5e-4, atol=1e-4, what="du0")
     for k, name in enumerate(["layer_1", "layer_2"]):
