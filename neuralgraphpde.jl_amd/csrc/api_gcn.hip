@@ -67,6 +67,7 @@ size_t ngpde_gcn_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t do
 int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
                           const float *weight, const float *bias, float *y, float *save_agg, float *save_z,
                           void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   int32_t st = check_common("ngpde_gcn_forward", g, din, dout, act);
   if (st) return st;
   if (g->n_nodes == 0) return NGPDE_OK;  // EMPTYGRAPH (src/layers.jl:14): zero columns in, zero columns out
@@ -100,6 +101,7 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
                            const float *weight, const float *z, const float *saved_agg, const float *dy, float *dx,
                            float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
                            ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   int32_t st = check_common("ngpde_gcn_backward", g, din, dout, act);
   if (st) return st;
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: dweight is NULL");
@@ -161,6 +163,7 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
 
 int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr, int32_t by_source, const float *x,
                                 const float *edge_weight, float *out, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_propagate_copy_xj: graph is NULL");
   NGPDE_REQUIRE(d > 0 && x && out, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_propagate_copy_xj: bad arguments");
   return launch_spmm_generic(g, by_source != 0, false, d, aggr, x, edge_weight, out, (hipStream_t)stream);

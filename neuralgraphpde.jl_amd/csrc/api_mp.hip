@@ -45,6 +45,7 @@ extern "C" {
 int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
                             const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight,
                             const float *bias, float *y, float *save_z, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   SegTable t;
   int din = 0;
   int32_t st = make_segs("ngpde_dense_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
@@ -61,6 +62,7 @@ int32_t ngpde_dense_pair_forward(int64_t n, int32_t n_seg_a, const float *const 
                                  float *y_a, float *save_z_a, int32_t n_seg_b, const float *const *seg_ptr_b,
                                  const int32_t *seg_width_b, const int32_t *seg_row_div_b, int32_t dout_b, int32_t act_b,
                                  const float *weight_b, const float *bias_b, float *y_b, float *save_z_b, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   SegTable ta, tb;
   int dina = 0, dinb = 0;
   int32_t st = make_segs("ngpde_dense_pair_forward", n_seg_a, seg_ptr_a, seg_width_a, seg_row_div_a, ta, &dina);
@@ -89,6 +91,7 @@ int32_t ngpde_dense_chain2_forward(int64_t n, int32_t n_seg, const float *const 
                                    const int32_t *seg_row_div, int32_t dmid, int32_t act1, const float *weight1, const float *bias1,
                                    float *a1, float *save_z1, int32_t dout, int32_t act2, const float *weight2, const float *bias2,
                                    float *y, float *save_z2, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   SegTable t;
   int din = 0;
   int32_t st = make_segs("ngpde_dense_chain2_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
@@ -128,6 +131,7 @@ int32_t ngpde_dense_pair_backward(int64_t n, int32_t n_seg_a, const float *const
                                   const int32_t *seg_row_div_b, const float *weight_b, const float *dy_b, float *dweight_b,
                                   float *dbias_b, int32_t dout, float *dx, const float *dx_addend, void *workspace,
                                   size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   SegTable ta, tb;
   int dina = 0, dinb = 0;
   int32_t st = make_segs("ngpde_dense_pair_backward", n_seg_a, seg_ptr_a, seg_width_a, seg_row_div_a, ta, &dina);
@@ -154,6 +158,7 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
                              const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight, const float *z,
                              const float *dy, float *const *dseg_ptr, float *dweight, float *dbias, void *workspace,
                              size_t workspace_bytes, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   SegTable t;
   int din = 0;
   int32_t st = make_segs("ngpde_dense_backward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
@@ -201,6 +206,7 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
 
 int32_t ngpde_edge_permute(const ngpde_graph_t *g, int32_t d, int32_t inverse, const float *src, float *dst,
                            ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_permute: graph is NULL");
   if (g->n_edges == 0 || d == 0) return NGPDE_OK;
   NGPDE_REQUIRE(src && dst && d > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_permute: bad arguments");
@@ -210,6 +216,7 @@ int32_t ngpde_edge_permute(const ngpde_graph_t *g, int32_t d, int32_t inverse, c
 int32_t ngpde_edge_combine_forward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *p_target,
                                    const float *q_source, const float *e_term, float *a_out, float *z_out,
                                    ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_forward: graph is NULL");
   int32_t st = check_act("ngpde_edge_combine_forward", act);
   if (st) return st;
@@ -220,6 +227,7 @@ int32_t ngpde_edge_combine_forward(const ngpde_graph_t *g, int32_t h, int32_t ac
 
 int32_t ngpde_edge_combine_backward(const ngpde_graph_t *g, int32_t h, int32_t act, const float *da, const float *z,
                                     float *dz, float *dp_target, float *dq_source, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_combine_backward: graph is NULL");
   int32_t st = check_act("ngpde_edge_combine_backward", act);
   if (st) return st;
@@ -230,6 +238,7 @@ int32_t ngpde_edge_combine_backward(const ngpde_graph_t *g, int32_t h, int32_t a
 
 int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, float *out,
                                      ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_forward: graph is NULL");
   NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_segment_reduce_forward: unknown aggregation %d", aggr);
@@ -240,6 +249,7 @@ int32_t ngpde_segment_reduce_forward(const ngpde_graph_t *g, int32_t d, int32_t 
 
 int32_t ngpde_segment_reduce_backward(const ngpde_graph_t *g, int32_t d, int32_t aggr, const float *m, const float *out,
                                       const float *dout, float *dm, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_segment_reduce_backward: graph is NULL");
   NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_segment_reduce_backward: unknown aggregation %d", aggr);
@@ -250,6 +260,7 @@ int32_t ngpde_segment_reduce_backward(const ngpde_graph_t *g, int32_t d, int32_t
 
 int32_t ngpde_gno_contract_forward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
                                    float *m, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_forward: graph is NULL");
   if (g->n_edges == 0) return NGPDE_OK;
   NGPDE_REQUIRE(cin > 0 && cout > 0 && k && h && m, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_forward: bad arguments");
@@ -259,6 +270,7 @@ int32_t ngpde_gno_contract_forward(const ngpde_graph_t *g, int32_t cin, int32_t 
 int32_t ngpde_gno_contract_backward(const ngpde_graph_t *g, int32_t cin, int32_t cout, const float *k, const float *h,
                                     const float *dm, float *dk, float *dh, void *workspace, size_t workspace_bytes,
                                     ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_contract_backward: graph is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   if (g->n_edges == 0) {
@@ -279,6 +291,7 @@ int32_t ngpde_gno_apply_supported(int32_t cout, int32_t kdim) { return gno_apply
 
 int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *bh,
                                 const float *z, float *m, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_forward: graph is NULL");
   NGPDE_REQUIRE(gno_apply_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED,
                 "ngpde_gno_apply_forward: out = %d, k = %d outside the reassociated path (out, k <= 256; T_j [k][out] must fit 60 KB of LDS)", cout, kdim);
@@ -289,6 +302,7 @@ int32_t ngpde_gno_apply_forward(const ngpde_graph_t *g, int32_t cout, int32_t kd
 
 int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, const float *t, const float *z,
                                  const float *dm, float *dt, float *dbh, float *dz, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_apply_backward: graph is NULL");
   NGPDE_REQUIRE(gno_apply_supported(cout, kdim), NGPDE_ERR_UNSUPPORTED, "ngpde_gno_apply_backward: unsupported out = %d, k = %d", cout, kdim);
   if (g->n_nodes == 0) return NGPDE_OK;
@@ -299,6 +313,7 @@ int32_t ngpde_gno_apply_backward(const ngpde_graph_t *g, int32_t cout, int32_t k
 int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t aggr, int32_t act1,
                                               const float *t, const float *z, const float *dagg, float *dt, float *dbh, float *dz,
                                               float *dq, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_backward_from_nodes: graph is NULL");
   NGPDE_REQUIRE(act1 == NGPDE_ACT_IDENTITY || act1 == NGPDE_ACT_RELU, NGPDE_ERR_UNSUPPORTED,
                 "ngpde_gno_message_backward_from_nodes: act1 must be identity or relu (the activated input stands for the "
@@ -321,6 +336,7 @@ int32_t ngpde_gno_message_supported(int32_t cout, int32_t kdim) { return gno_app
 int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t kdim, int32_t act1, const float *p_target,
                                   const float *q_source, const float *e_term, const float *t, const float *bh, float *z_out, float *m,
                                   ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_message_forward: graph is NULL");
   int32_t st = check_act("ngpde_gno_message_forward", act1);
   if (st) return st;
@@ -334,6 +350,7 @@ int32_t ngpde_gno_message_forward(const ngpde_graph_t *g, int32_t cout, int32_t 
 
 int32_t ngpde_gat_forward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
                           const float *a, float *out, float *alpha, float *al, float *ar, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_forward: graph is NULL");
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(heads > 0 && c > 0 && wx && a && out && al && ar && (alpha || g->n_edges == 0), NGPDE_ERR_INVALID_ARGUMENT,
@@ -352,6 +369,7 @@ size_t ngpde_gat_workspace_bytes(const ngpde_graph_t *g, int32_t heads) {
 int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, const float *wx,
                            const float *a, const float *al, const float *ar, const float *alpha, const float *dout,
                            float *dwx, float *da, void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_backward: graph is NULL");
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(heads > 0 && c > 0 && wx && a && al && ar && dout && dwx && da, NGPDE_ERR_INVALID_ARGUMENT,
@@ -379,6 +397,7 @@ size_t ngpde_gat_layer_workspace_bytes(const ngpde_graph_t *g, int32_t heads, in
 int32_t ngpde_gat_layer_forward(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c, float negative_slope, int32_t act,
                                 const float *x, const float *weight, const float *a, const float *bias, float *y,
                                 float *save_alpha, float *save_z, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_forward: graph is NULL");
   int32_t st = check_act("ngpde_gat_layer_forward", act);
   if (st) return st;
@@ -394,6 +413,7 @@ int32_t ngpde_gat_layer_backward(const ngpde_graph_t *g, int32_t din, int32_t he
                                  const float *x, const float *weight, const float *a, const float *y_or_z, const float *save_alpha,
                                  const float *dy, float *dx, float *dweight, float *da, float *dbias, void *workspace,
                                  size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gat_layer_backward: graph is NULL");
   int32_t st = check_act("ngpde_gat_layer_backward", act);
   if (st) return st;
@@ -408,6 +428,7 @@ int32_t ngpde_gat_layer_backward(const ngpde_graph_t *g, int32_t din, int32_t he
 
 int32_t ngpde_bias_act_forward(int64_t n, int32_t d, int32_t act, const float *a, const float *addend, const float *bias, float *y,
                                float *save_z, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_act("ngpde_bias_act_forward", act);
   if (st) return st;
   NGPDE_REQUIRE(n >= 0 && d >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_bias_act_forward: negative size");
@@ -420,6 +441,7 @@ size_t ngpde_bias_act_workspace_bytes(int32_t d) { return (size_t)kColsumChunks 
 
 int32_t ngpde_bias_act_backward(int64_t n, int32_t d, int32_t act, const float *dy, const float *z, float *dz, float *dbias,
                                 void *workspace, size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_act("ngpde_bias_act_backward", act);
   if (st) return st;
   NGPDE_REQUIRE(n >= 0 && d >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_bias_act_backward: negative size");
@@ -449,6 +471,7 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
                                const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,
                                const int32_t *tail_act, const float *const *tail_weight, const float *const *tail_bias,
                                int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_forward: graph is NULL");
   NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_edge_mlp_forward: unknown aggregation %d", aggr);
@@ -489,6 +512,7 @@ int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1
                                 const float *const *tail_weight, const float *const *tail_bias, int32_t aggr, const float *dout,
                                 float *dp_target, float *dq_source, float *de_term, float *const *dtail_weight,
                                 float *const *dtail_bias, void *workspace, size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: graph is NULL");
   int32_t st = check_act("ngpde_edge_mlp_backward", act1);
   if (st) return st;
@@ -509,6 +533,7 @@ int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1
 }
 
 int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, float *a, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_act("ngpde_activation_forward", act);
   if (st) return st;
   if (count == 0) return NGPDE_OK;
@@ -517,6 +542,7 @@ int32_t ngpde_activation_forward(int64_t count, int32_t act, const float *z, flo
 }
 
 int32_t ngpde_spectral_weights(int64_t n_edges, int32_t n, const float *e, float *w, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   if (n_edges == 0) return NGPDE_OK;
   NGPDE_REQUIRE(e && w && n > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_spectral_weights: bad arguments");
   return launch_spectral_weights(n_edges, (float)n, e, w, (hipStream_t)stream);

@@ -347,4 +347,26 @@ bool edge_mlp64_bwd_applicable(const ngpde_graph *g, const EdgeMlpBwdArgs &a);
 size_t edge_mlp64_bwd_workspace(const ngpde_graph *g);
 int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream);
 
+
+// ---- ROCTx ranges around the C-ABI entries (tracing).  rocprofv3 --marker-trace then attributes the
+// launches of a trace to the layer call that made them.  The marker library (rocprofiler-sdk-roctx) is looked up lazily at the
+// first entry and the ranges are no-ops when it is not there: the product library has no link-time dependency on a profiler.
+struct RoctxApi {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+};
+const RoctxApi &roctx_api();   // graph.hip
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *name) : on(roctx_api().push != nullptr) {
+    if (on) roctx_api().push(name);
+  }
+  ~RoctxRange() {
+    if (on) roctx_api().pop();
+  }
+  RoctxRange(const RoctxRange &) = delete;
+  RoctxRange &operator=(const RoctxRange &) = delete;
+};
+#define NGPDE_RANGE() ::ngpde::RoctxRange ngpde_roctx_range_(__func__)
+
 }  // namespace ngpde

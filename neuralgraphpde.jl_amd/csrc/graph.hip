@@ -8,6 +8,25 @@
 #include <new>
 
 #include "common.h"
+#include <dlfcn.h>
+
+namespace ngpde {
+const RoctxApi &roctx_api() {
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    const char *off = std::getenv("NGPDE_NO_ROCTX");
+    if (off && off[0] == '1') return a;
+    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return a;
+    a.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+    a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+    return a;
+  }();
+  return api;
+}
+}  // namespace ngpde
 
 namespace ngpde {
 
@@ -137,6 +156,7 @@ const char *ngpde_last_error(void) { return last_error().c_str(); }
 
 int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, const int64_t *t,
                            int32_t index_base, int32_t n_graphs, ngpde_graph_t **out) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create: out is NULL");
   *out = nullptr;
   NGPDE_REQUIRE(n_nodes >= 0 && n_edges >= 0, NGPDE_ERR_INVALID_ARGUMENT,
@@ -194,6 +214,7 @@ int32_t ngpde_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t *s, c
 }
 
 int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
+  NGPDE_RANGE();
   if (!g) return NGPDE_OK;
   free_csr(g->by_t);
   free_csr(g->by_s);
@@ -206,6 +227,7 @@ int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
 int32_t ngpde_graph_create_device(int64_t n_nodes, int64_t n_edges, const void *s, const void *t, int32_t index_bits,
                                   int32_t index_base, int32_t n_graphs, const int32_t *order, ngpde_stream_t stream,
                                   ngpde_graph_t **out) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_create_device: out is NULL");
   *out = nullptr;
   NGPDE_REQUIRE(n_nodes >= 0 && n_edges >= 0, NGPDE_ERR_INVALID_ARGUMENT,
@@ -226,6 +248,7 @@ int32_t ngpde_graph_create_device(int64_t n_nodes, int64_t n_edges, const void *
 }
 
 int32_t ngpde_graph_node_order(const ngpde_graph_t *g, int32_t *order_out) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr && (order_out != nullptr || g->n_nodes == 0), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_graph_node_order: NULL argument");
   if (g->n_nodes == 0) return NGPDE_OK;
@@ -239,6 +262,7 @@ int32_t ngpde_graph_node_order(const ngpde_graph_t *g, int32_t *order_out) {
 
 int32_t ngpde_graph_set_gcn_norm_device(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
                                         int32_t weighted_degree, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_set_gcn_norm_device: graph is NULL");
   NGPDE_REQUIRE(!(weighted_degree && !edge_weight && g->n_edges > 0), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_graph_set_gcn_norm_device: weighted_degree requires edge_weight");
@@ -246,6 +270,7 @@ int32_t ngpde_graph_set_gcn_norm_device(ngpde_graph_t *g, int32_t add_self_loops
 }
 
 int32_t ngpde_graph_array(const ngpde_graph_t *g, int32_t direction, int32_t which, const void **ptr, size_t *bytes) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g && ptr && bytes, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_array: NULL argument");
   NGPDE_REQUIRE(direction == 0 || direction == 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_array: direction must be 0 (by target) or 1 (by source)");
   const ngpde::Csr &c = direction == 0 ? g->by_t : g->by_s;
@@ -271,6 +296,7 @@ int32_t ngpde_graph_array(const ngpde_graph_t *g, int32_t direction, int32_t whi
 }
 
 int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_edges, int32_t *n_graphs) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_info: graph is NULL");
   if (n_nodes) *n_nodes = g->n_nodes;
   if (n_edges) *n_edges = g->n_edges;
@@ -280,6 +306,7 @@ int32_t ngpde_graph_info(const ngpde_graph_t *g, int64_t *n_nodes, int64_t *n_ed
 
 int32_t ngpde_graph_csr_by_target(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
                                   const int32_t **eid) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_csr_by_target: graph is NULL");
   if (rowptr) *rowptr = g->by_t.rowptr;
   if (col) *col = g->by_t.col;
@@ -289,6 +316,7 @@ int32_t ngpde_graph_csr_by_target(const ngpde_graph_t *g, const int32_t **rowptr
 
 int32_t ngpde_graph_csr_by_source(const ngpde_graph_t *g, const int32_t **rowptr, const int32_t **col,
                                   const int32_t **eid) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_csr_by_source: graph is NULL");
   if (rowptr) *rowptr = g->by_s.rowptr;
   if (col) *col = g->by_s.col;
@@ -298,6 +326,7 @@ int32_t ngpde_graph_csr_by_source(const ngpde_graph_t *g, const int32_t **rowptr
 
 int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const float *edge_weight,
                                  int32_t weighted_degree) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_graph_set_gcn_norm: graph is NULL");
   NGPDE_REQUIRE(!(weighted_degree && !edge_weight && g->n_edges > 0), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_graph_set_gcn_norm: weighted_degree requires edge_weight");

@@ -598,6 +598,7 @@ extern "C" {
 int32_t ngpde_radius_graph(int64_t n, int32_t dim, const float *points, float r, const int32_t *graph_id, int32_t n_graphs,
                            int32_t id_base, int32_t self_loops, int32_t dir_out, int32_t index_base, int64_t capacity, int32_t *s,
                            int32_t *t, int64_t *n_edges, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_common(n, dim, points, graph_id, n_graphs);
   if (st) return st;
   NGPDE_REQUIRE(n_edges != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "n_edges is NULL");
@@ -616,6 +617,7 @@ int32_t ngpde_radius_graph(int64_t n, int32_t dim, const float *points, float r,
 int32_t ngpde_knn_graph(int64_t n, int32_t dim, const float *points, int32_t k, const int32_t *graph_id, int32_t n_graphs,
                         int32_t id_base, int32_t self_loops, int32_t dir_out, int32_t index_base, int32_t *s, int32_t *t,
                         ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_common(n, dim, points, graph_id, n_graphs);
   if (st) return st;
   NGPDE_REQUIRE(k >= 0 && k <= NGPDE_KNN_MAX_K, NGPDE_ERR_UNSUPPORTED, "knn_graph supports 0 <= k <= %d, got %d", NGPDE_KNN_MAX_K, k);
@@ -634,6 +636,7 @@ int32_t ngpde_knn_graph(int64_t n, int32_t dim, const float *points, int32_t k, 
 
 int32_t ngpde_spatial_order(int64_t n, int32_t dim, const float *points, const int32_t *graph_id, int32_t n_graphs, int32_t id_base,
                             int32_t *order, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   int32_t st = check_common(n, dim, points, graph_id, n_graphs);
   if (st) return st;
   if (n == 0) return NGPDE_OK;

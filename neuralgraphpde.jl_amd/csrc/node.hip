@@ -385,6 +385,7 @@ int32_t capture(ngpde_node *p, bool backward) {
 extern "C" {
 
 int32_t ngpde_node_destroy(ngpde_node_t *p) {
+  NGPDE_RANGE();
   if (!p) return NGPDE_OK;
   if (p->fwd_exec) (void)hipGraphExecDestroy(p->fwd_exec);
   if (p->bwd_exec) (void)hipGraphExecDestroy(p->bwd_exec);
@@ -408,11 +409,13 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
 
 int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, int32_t tableau, int32_t n_steps,
                                float dt, int32_t with_backward, ngpde_node_t **out) {
+  NGPDE_RANGE();
   return ngpde_node_gcn2_create_batch(g, 1, d, act, tableau, n_steps, dt, with_backward, out);
 }
 
 int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, int32_t d, int32_t act, int32_t tableau,
                                      int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: out is NULL");
   NGPDE_REQUIRE(members >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create_batch: members must be >= 1");
   *out = nullptr;
@@ -542,6 +545,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
 size_t ngpde_node_tape_bytes(const ngpde_node_t *p) { return p ? p->tape_bytes : 0; }
 
 int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t *backward) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_launch_count: plan is NULL");
   if (forward) *forward = p->fwd_launches;
   if (backward) *backward = p->bwd_launches;
@@ -549,6 +553,7 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t
 }
 
 int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0);
@@ -556,6 +561,7 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
 }
 
 int32_t ngpde_node_fault(ngpde_node_t *p, ngpde_stream_t stream_, int32_t *fault) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_fault: NULL argument");
   *fault = 0;
   if (!p->persist.fault) return NGPDE_OK;
@@ -568,6 +574,7 @@ int32_t ngpde_node_fault(ngpde_node_t *p, ngpde_stream_t stream_, int32_t *fault
 
 int32_t ngpde_node_pipeline_stats(ngpde_node_t *p, ngpde_stream_t stream_, int64_t *ahead_forward, int64_t *ahead_backward,
                                   int64_t *slot_phases) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_pipeline_stats: plan is NULL");
   if (ahead_forward) *ahead_forward = 0;
   if (ahead_backward) *ahead_backward = 0;
@@ -587,6 +594,7 @@ int32_t ngpde_node_pipeline_stats(ngpde_node_t *p, ngpde_stream_t stream_, int64
 
 int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w1, const float *b1, const float *w2,
                                 const float *b2, float *uT, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: plan is NULL");
   NGPDE_REQUIRE(u0 && w1 && w2 && uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: NULL argument");
   hipStream_t stream = (hipStream_t)stream_;
@@ -626,6 +634,7 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
 }
 
 int32_t ngpde_node_generation(const ngpde_node_t *p, uint64_t *generation, int32_t *backward_pending) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_generation: plan is NULL");
   if (generation) *generation = p->generation;
   if (backward_pending) *backward_pending = p->backward_pending ? 1 : 0;
@@ -633,6 +642,7 @@ int32_t ngpde_node_generation(const ngpde_node_t *p, uint64_t *generation, int32
 }
 
 int32_t ngpde_node_expect_generation(const ngpde_node_t *p, uint64_t generation) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_expect_generation: plan is NULL");
   NGPDE_REQUIRE(p->generation == generation, NGPDE_ERR_STATE,
                 "the plan's tape belongs to solve %llu, not %llu: another forward ran on this plan before this backward "
@@ -643,6 +653,7 @@ int32_t ngpde_node_expect_generation(const ngpde_node_t *p, uint64_t generation)
 
 int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, float *dw1, float *db1, float *dw2,
                                  float *db2, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_backward: plan is NULL");
   NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: plan was created without backward");
   NGPDE_REQUIRE(p->forward_done, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: forward has not been run");
@@ -680,6 +691,7 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
 
 int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32_t *out_count,
                            ngpde_stream_t stream_) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && out_us != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_profile: NULL argument");
   NGPDE_REQUIRE(p->forward_done, NGPDE_ERR_STATE, "ngpde_node_profile: run a forward solve first");
   NGPDE_REQUIRE(stride >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_profile: stride must be >= 1");

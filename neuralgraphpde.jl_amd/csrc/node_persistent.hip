@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -1280,10 +1281,47 @@ extern "C" int32_t ngpde_debug_set_persistent_stamps(unsigned long long *dev_buf
 }
 #endif
 
+// A persistent launch needs ALL its workgroups resident, and two of them in flight on one device (two plans on two streams) can
+// starve each other of residency until both time out.  Inside one process they are therefore made to take turns: every persistent
+// launch first makes its stream wait for the event recorded behind the previous persistent launch on that device, whatever stream
+// that one ran on.  (Nothing can be done about another PROCESS on the same device: one rank per GPU, include/ngpde.h.)
+namespace {
+struct Turnstile {
+  std::mutex mu;
+  hipEvent_t last[16] = {};
+  bool used[16] = {};
+};
+Turnstile &turnstile() {
+  static Turnstile t;
+  return t;
+}
+int32_t turnstile_enter(hipStream_t stream, int *dev_out) {
+  int dev = 0;
+  NGPDE_HIP_CHECK(hipGetDevice(&dev));
+  *dev_out = dev;
+  if (dev < 0 || dev >= 16) return NGPDE_OK;
+  Turnstile &t = turnstile();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (t.used[dev]) NGPDE_HIP_CHECK(hipStreamWaitEvent(stream, t.last[dev], 0));
+  return NGPDE_OK;
+}
+int32_t turnstile_leave(hipStream_t stream, int dev) {
+  if (dev < 0 || dev >= 16) return NGPDE_OK;
+  Turnstile &t = turnstile();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (!t.last[dev]) NGPDE_HIP_CHECK(hipEventCreateWithFlags(&t.last[dev], hipEventDisableTiming));
+  NGPDE_HIP_CHECK(hipEventRecord(t.last[dev], stream));
+  t.used[dev] = true;
+  return NGPDE_OK;
+}
+}  // namespace
+
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
+  int dev = 0;
+  if ((st = turnstile_enter(stream, &dev))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
   k.m = make_meta(g->by_t, ps);
@@ -1317,13 +1355,15 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return NGPDE_OK;
+  return turnstile_leave(stream, dev);
 }
 
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
+  int dev = 0;
+  if ((st = turnstile_enter(stream, &dev))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
   k.m = make_meta(g->by_s, ps);
@@ -1348,7 +1388,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return NGPDE_OK;
+  return turnstile_leave(stream, dev);
 }
 
 }  // namespace ngpde

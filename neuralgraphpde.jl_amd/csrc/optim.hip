@@ -95,6 +95,7 @@ extern "C" {
 
 int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, int32_t n_terms, const float *const *terms,
                                const float *coefs, float *out, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(count >= 0 && n_terms >= 0 && n_terms <= 8, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_rk_stage_combine: count >= 0 and 0 <= n_terms <= 8 required (got %lld, %d)", (long long)count, n_terms);
   if (count == 0) return NGPDE_OK;
@@ -115,6 +116,7 @@ int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, i
 
 int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float *v, float eta, float beta1, float beta2,
                         float eps, int64_t step, float grad_scale, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(n >= 0 && step >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_adam_step: n >= 0 and step >= 1 required");
   if (n == 0) return NGPDE_OK;
   NGPDE_REQUIRE(x && grad && m && v, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_adam_step: NULL argument");
@@ -128,6 +130,7 @@ int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float 
 
 int32_t ngpde_rprop_step(int64_t n, float *x, const float *grad, float *grad_prev, float *step_size, float shrink, float grow,
                          float step_min, float step_max, float grad_scale, ngpde_stream_t stream) {
+  NGPDE_RANGE();
   NGPDE_REQUIRE(n >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rprop_step: n < 0");
   if (n == 0) return NGPDE_OK;
   NGPDE_REQUIRE(x && grad && grad_prev && step_size, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rprop_step: NULL argument");

@@ -69,3 +69,67 @@ def test_two_rank_c4_gradient_equals_the_single_rank_gradient_of_the_whole_batch
     assert np.array_equal(out[0], out[1])                           # both ranks hold the same reduced vector
     err = np.abs(out[0] - ref).max()
     assert err <= 2e-5 * np.abs(ref).max() + 1e-6, err              # sum of two half-batch gradients == whole-batch gradient
+
+
+def test_bench_n2_path_end_to_end_with_torchrun_and_gloo():
+    # the driver's N > 1 launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    # --master-port P bench.py --gpus N ...) rehearsed with two ranks sharing this box's one GPU: NGPDE_BENCH_BACKEND=gloo carries
+    # the collectives through the host (the measured configuration is nccl = RCCL, one rank per GPU).  Rendezvous, per-rank plans,
+    # gradient all-reduce, barrier + max over ranks, the C4 / C5 data-parallel legs and ONE JSON line from rank 0.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGPDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "ODE-steps/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["value"] == pytest.approx(2 * 50 * 2 / (d["ms_per_step"] * 1e-3 * 2), rel=1e-3)   # whole-job aggregate over both ranks
+    sec = d["secondary"]
+    assert sec["C4_mppde_data_parallel_step"]["ranks"] == 2 and sec["C5_gno_data_parallel_step"]["ranks"] == 2
+
+
+def test_two_persistent_plans_on_two_streams_take_turns():
+    # two persistent solves in flight on one device could starve each other of residency (every workgroup of a launch must be
+    # resident); inside a process the launches take turns (node_persistent.hip, turnstile): both finish, no fault, same bits as
+    # alone
+    import ngpde_amd as ng
+    from ngpde_amd import _lib, synth as S
+    from ngpde_amd.node import _Plan
+    if os.environ.get("NGPDE_NO_HALO") == "1" or os.environ.get("NGPDE_NO_PERSISTENT") == "1":
+        pytest.skip("no persistent plan under this switch")
+    lib, p = _lib.load(), _lib.ptr
+    N, D, STEPS = 16384, 64, 10
+    _, s, t = S.closest_pairs_graph(N, 4 * N, seed=2)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    h = g.handle((True, None, False))
+    dv = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device="cuda:0")
+    w1, w2 = dv(S.glorot_uniform(11, D, D).T), dv(S.glorot_uniform(12, D, D).T)
+    b1, b2 = torch.zeros(D, device="cuda:0"), torch.zeros(D, device="cuda:0")
+    plans = [_Plan(h, D, _lib.ACT["relu"], "tsit5", STEPS, 1.0 / 50, True) for _ in range(2)]
+    assert all("persistent_fwd" in pl.flags() for pl in plans)
+    u0 = [dv(S.normal(1000 + k, D * N).reshape(N, D)) for k in range(2)]
+    seed = torch.ones_like(u0[0])
+
+    def solve(k, stream):
+        outs = [torch.empty_like(u0[k]), torch.empty_like(u0[k]), torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)]
+        _lib.check(lib.ngpde_node_gcn2_forward(plans[k].ptr, p(u0[k]), p(w1), p(b1), p(w2), p(b2), p(outs[0]), stream))
+        _lib.check(lib.ngpde_node_gcn2_backward(plans[k].ptr, p(seed), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(outs[5]), stream))
+        return outs
+
+    cur = torch.cuda.current_stream().cuda_stream
+    alone = [solve(k, cur) for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for _ in range(5):
+        both = [solve(k, streams[k].cuda_stream) for k in range(2)]
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert not plans[k].fault()
+        assert all(torch.equal(a, b) for a, b in zip(alone[k], both[k]))
