@@ -170,7 +170,7 @@ TIMING_NOTE = ("ms_forward / ms_forward_backward: the layer call (and its autogr
 # algorithmic figures of ONE layer forward
 C3_FWD_BYTES = 9.50e6        # GATConv on the C2 graph: compulsory traffic
 C4_FWD_FLOP = 49.0e9         # MPPDEConv shard (64 trajectories), first-layer-split form
-C5_FWD_FLOP = {0.05: 10.6e9, 0.1: 16.8e9}   # GNOConv 128 => 128, reassociated form
+# (C5: c5_fwd_flop(E) -- SURVEY's 10.6 / 16.8 GFLOP are for E ~ 115 k / 492 k; the generator gives 140 860 / 480 784 edges)
 
 
 def _time_ms(fn, reps):
@@ -243,6 +243,26 @@ def c4_layer(dev, traj, seed):
     ps, st = ng.setup(4, layer)
     x = torch.as_tensor(S.normal(42 + seed, h * N).reshape(N, h).astype(np.float32), device=dev).T
     return layer, ps, st, x, int(s.size)
+
+
+def c5_layer(dev, radius, width=128, seed=0):
+    """GNOConv width => width on the 64 x 64 grid radius graph of BASELINE config 5: ndata = (a (1), x (2)),
+    phi = Dense(6 => 64, relu) -> Dense(64 => width^2).  Shared with tools/bench_layers.py so that profiles and bench line run
+    the same edges."""
+    pts, s5, t5 = S.grid_radius_graph(64, radius)
+    g5 = ng.GNNGraph(s5, t5, num_nodes=4096, index_base=0,
+                     ndata={"a": S.uniform01(50, 4096).reshape(1, 4096).astype(np.float32), "x": pts.astype(np.float32)})
+    phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, width * width))
+    l5 = ng.GNOConv((width, width), phi, "relu", initialgraph=g5)
+    ps5, st5 = ng.setup(5, l5)
+    x5 = torch.as_tensor(S.normal(51 + seed, width * 4096).reshape(4096, width).astype(np.float32), device=dev).T
+    return l5, ps5, st5, x5, int(s5.size)
+
+
+def c5_fwd_flop(n_edges, width=128, k=64, n=4096):
+    """SURVEY.md 8(d)'s official (reassociated) count for the edges actually run: node-level T = W2 (x) h (2 n in out k), per-edge
+    T_j z_e (2 out k E), the bias term B2 h (2 n in out)"""
+    return 2.0 * n * width * width * k + 2.0 * width * k * n_edges + 2.0 * n * width * width
 
 
 def secondary(dev, world, rank, dist):
@@ -329,15 +349,10 @@ def secondary(dev, world, rank, dist):
     if world > 1:
         # C5 replicas: every rank holds the same 64 x 64 grid graph (a single 4 096-node graph is never split) and its own input
         # field; GNOConv 128 => 128 forward + backward, one all-reduce of the flat gradient, fused Adam -- the C4 leg's scheme
-        pts, s5, t5 = S.grid_radius_graph(64, 0.1)
-        g5 = ng.GNNGraph(s5, t5, num_nodes=4096, index_base=0,
-                         ndata={"a": S.uniform01(50, 4096).reshape(1, 4096).astype(np.float32), "x": pts.astype(np.float32)})
-        phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, 128 * 128))
-        l5 = ng.GNOConv((128, 128), phi, "relu", initialgraph=g5)
-        ps5, st5 = ng.setup(5, l5)
+        l5, ps5, st5, x5, n_e5 = c5_layer(dev, 0.1, seed=rank)
         flat5, ps5v = ng.optim.flatten_parameters(ng.to_device(ps5, dev))
         opt5 = ng.optim.setup(ng.optim.Adam(1e-4), flat5)
-        x5 = torch.as_tensor(S.normal(51 + rank, 128 * 4096).reshape(4096, 128).astype(np.float32), device=dev).T.requires_grad_(True)
+        x5 = x5.detach().requires_grad_(True)
         R5 = torch.ones(4096, 128, device=dev).T
 
         def step5():
@@ -357,28 +372,23 @@ def secondary(dev, world, rank, dist):
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = 1e3 * float(tt.item()) / reps
-        out["C5_gno_data_parallel_step"] = {"replicas": world, "ranks": world, "edges": int(s5.size), "ms_step": round(ms, 4),
+        out["C5_gno_data_parallel_step"] = {"replicas": world, "ranks": world, "edges": n_e5, "ms_step": round(ms, 4),
                                             "value": round(world / (ms * 1e-3), 1), "unit": "layers/s (fwd+bwd+all-reduce+Adam)",
                                             "gradient_floats": int(flat5.numel()), "scaling": "weak"}
     if world == 1:
         for radius in (0.05, 0.1):
-            pts, s5, t5 = S.grid_radius_graph(64, radius)
-            g5 = ng.GNNGraph(s5, t5, num_nodes=4096, index_base=0,
-                             ndata={"a": S.uniform01(50, 4096).reshape(1, 4096).astype(np.float32), "x": pts.astype(np.float32)})
-            phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, 128 * 128))
-            l5 = ng.GNOConv((128, 128), phi, "relu", initialgraph=g5)
-            ps5, st5 = ng.setup(5, l5)
+            l5, ps5, st5, x5, n_e5 = c5_layer(dev, radius)
             ps5 = ng.to_device(ps5, dev)
             for v in _grad_leaves(ps5):
                 v.requires_grad_(True)
-            x5 = torch.as_tensor(S.normal(51, 128 * 4096).reshape(4096, 128).astype(np.float32), device=dev).T
             fe, fbe, f, fb = _layer_times(l5, x5, ps5, st5, 10)
-            ach = C5_FWD_FLOP[radius] / (f * 1e-3) / 1e12
-            out[f"C5_gno_128_r{radius}_layer"] = {"edges": int(s5.size), "ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
+            flop5 = c5_fwd_flop(n_e5)
+            ach = flop5 / (f * 1e-3) / 1e12
+            out[f"C5_gno_128_r{radius}_layer"] = {"edges": n_e5, "ms_forward": round(f, 4), "ms_forward_backward": round(fb, 4),
                                                   "ms_forward_eager_api": round(fe, 4), "ms_forward_backward_eager_api": round(fbe, 4),
                                                   "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
                                                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
-                                                               "algorithmic_GFLOP_forward": C5_FWD_FLOP[radius] / 1e9}}
+                                                               "algorithmic_GFLOP_forward": round(flop5 / 1e9, 2)}}
     return out
 
 

@@ -165,6 +165,15 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
                            const float *x, const float *weight, const float *z, const float *saved_agg,
                            const float *dy, float *dx, float *dweight, float *dbias, void *workspace,
                            size_t workspace_bytes, ngpde_stream_t stream);
+/* ngpde_gcn_backward plus the gradient w.r.t. the `edge_weight` ARGUMENT of the call, which the reference differentiates through
+ * e_mul_xj and through the weighted degree (src/layers.jl:206-231): dedge_weight[n_edges] in the caller's COO order (the ones
+ * appended for the self loops are constants).  The handle must carry that call's normalisation (ngpde_graph_set_gcn_norm with
+ * the weights and weighted_degree = 1).  x is always needed; bias only when dout < din (may be NULL for a layer without bias);
+ * dx may be NULL.  Workspace: ngpde_gcn_backward_ew_workspace_bytes. */
+size_t ngpde_gcn_backward_ew_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t dout);
+int32_t ngpde_gcn_backward_ew(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x, const float *weight,
+                              const float *bias, const float *z, const float *saved_agg, const float *dy, float *dx, float *dweight,
+                              float *dbias, float *dedge_weight, void *workspace, size_t workspace_bytes, ngpde_stream_t stream);
 
 /* Generic aggregation  out[:, i] = sum_{e: t_e = i} w_e * x[:, s_e]  (propagate(copy_xj / w_mul_xj, g, +),
  * src/layers.jl:228-232) and its transpose (by_source != 0), any feature width d.
@@ -188,6 +197,13 @@ int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr,
 int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
                             const int32_t *seg_row_div, int32_t dout, int32_t act, const float *weight,
                             const float *bias, float *y, float *save_z, ngpde_stream_t stream);
+/* Up to four INDEPENDENT Dense layers (ngpde_dense_forward's arguments as tables; the segment tables of the problems follow
+ * each other in seg_ptr / seg_width / seg_row_div) in ONE launch: GNOConv's node-level terms P, Q, B2 h, W h
+ * (src/layers.jl:523,536) are latency-bound launches of a few dozen workgroups each. */
+int32_t ngpde_dense_multi_forward(int32_t count, const int64_t *n, const int32_t *n_seg, const float *const *seg_ptr,
+                                  const int32_t *seg_width, const int32_t *seg_row_div, const int32_t *dout, const int32_t *act,
+                                  const float *const *weight, const float *const *bias, float *const *y, float *const *save_z,
+                                  ngpde_stream_t stream);
 /* Two Dense layers that share their leading input block, y_a = Dense_a(vcat(X, ...)), y_b = Dense_b(vcat(X, ...)), in one pass
  * over X: the two node-level halves of a message MLP's first layer (the `vcat(xi..., xj..., ...)` of src/layers.jl:106, :316,
  * :409-410 split into a target term and a source term).  Exactly two ngpde_dense_forward calls in effect; one launch when X
@@ -448,6 +464,24 @@ int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float 
                         float eps, int64_t step, float grad_scale, ngpde_stream_t stream);
 int32_t ngpde_rprop_step(int64_t n, float *x, const float *grad, float *grad_prev, float *step_size, float shrink, float grow,
                          float step_min, float step_max, float grad_scale, ngpde_stream_t stream);
+
+/* ---- weight-sized rearrangements around the edge-function layers (row_blocks.hip) ------------------------------------------
+ * The first Dense layer of phi is split by ROW BLOCKS of its [in][out] weight and the blocks are recombined with signs
+ * (src/layers.jl:106 ExplicitEdgeConv, :316 VMHConv, :409-410 MPPDEConv, :523 GNOConv).  ngpde_row_blocks_gather builds up to
+ * four recombined matrices in ONE launch: output o, rows dst_row0[s] .. + n_rows[s], += sign[s] * src rows src_row0[s] .. (rows no
+ * segment covers are zero; overlapping segments add, e.g. VMHConv's wa - wb).  ngpde_row_blocks_scatter is its pullback: the
+ * gradient of the source from the gradients of the outputs (a NULL entry of `douts` counts as zero), every source row written. */
+int32_t ngpde_row_blocks_gather(int32_t width, int32_t src_rows, const float *src, int32_t n_seg, const int32_t *out_index,
+                                const int32_t *dst_row0, const int32_t *src_row0, const int32_t *n_rows, const float *sign,
+                                int32_t n_out, float *const *outs, const int32_t *out_rows, ngpde_stream_t stream);
+int32_t ngpde_row_blocks_scatter(int32_t width, int32_t src_rows, float *dsrc, int32_t n_seg, const int32_t *out_index,
+                                 const int32_t *dst_row0, const int32_t *src_row0, const int32_t *n_rows, const float *sign,
+                                 int32_t n_out, float *const *douts, const int32_t *out_rows, ngpde_stream_t stream);
+/* dst [cols][rows] = transpose of src [rows][cols] (GNOConv's reassociated form reads phi's last weight transposed,
+ * src/layers.jl:527-530; its pullback transposes the gradient back) */
+int32_t ngpde_transpose(int32_t rows, int32_t cols, const float *src, float *dst, ngpde_stream_t stream);
+/* out[i][:] = x[i][:] * scale[i]  (mean aggregation's 1 / degree applied once per node to a cotangent, :534) */
+int32_t ngpde_rows_scale(int64_t n, int32_t d, const float *x, const float *scale, float *out, ngpde_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -61,8 +61,11 @@ SIGNATURES = {
     "ngpde_gcn_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "ngpde_gcn_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_gcn_backward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_gcn_backward_ew_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "ngpde_gcn_backward_ew": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_propagate_copy_xj": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ngpde_dense_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_dense_multi_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_dense_pair_forward": (_i32, [_i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_dense_pair_backward_workspace_bytes": (_sz, [_i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
@@ -113,6 +116,10 @@ SIGNATURES = {
     "ngpde_node_launch_count": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngpde_node_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "ngpde_node_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ngpde_row_blocks_gather": (_i32, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ngpde_row_blocks_scatter": (_i32, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ngpde_transpose": (_i32, [_i32, _i32, _vp, _vp, _vp]),
+    "ngpde_rows_scale": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp]),
     "ngpde_node_pipeline_stats": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "ngpde_node_generation": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i32)]),
     "ngpde_node_expect_generation": (_i32, [_vp, C.c_uint64]),
@@ -167,3 +174,37 @@ def ptr(t):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- destruction of library objects from Python finalisers -----------------------------------------------------------------
+# A finaliser can run at ANY allocation -- also in the middle of a HIP-graph capture (NeuralODE(capture=True), bench.py's
+# graph-replayed timings), where the hipFree inside ngpde_graph_destroy / ngpde_node_destroy is not a legal call: the capture is
+# invalidated and torch aborts the process.  Finalisers therefore hand their pointer to destroy_later(), which frees at once
+# when no capture is in progress on this thread and otherwise parks it until the next call that finds none.
+_pending_destroy = []
+
+
+def _capturing():
+    try:
+        import torch
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
+def flush_destroy():
+    if not _pending_destroy or _capturing():
+        return
+    lib = load()
+    while _pending_destroy:
+        fn, ptr = _pending_destroy.pop()
+        try:
+            getattr(lib, fn)(ptr)
+        except Exception:
+            pass
+
+
+def destroy_later(fn, ptr):
+    """fn: "ngpde_graph_destroy" | "ngpde_node_destroy"; ptr: the handle"""
+    _pending_destroy.append((fn, ptr))
+    flush_destroy()

@@ -97,14 +97,24 @@ int32_t ngpde_gcn_forward(const ngpde_graph_t *g, int32_t din, int32_t dout, int
   return launch_spmm_gcn_tail(g, dout, tmp, bias, act, y, save_z, stream);
 }
 
-int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
-                           const float *weight, const float *z, const float *saved_agg, const float *dy, float *dx,
-                           float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
-                           ngpde_stream_t stream_) {
-  NGPDE_RANGE();
-  int32_t st = check_common("ngpde_gcn_backward", g, din, dout, act);
+}  // extern "C"
+
+namespace {
+// extra bytes behind ngpde_gcn_workspace_bytes(.., 1) when the gradient w.r.t. the edge_weight argument is asked for: dx (the
+// caller may pass none), x W (Dout < Din: the array that entered the propagation), the per-node degree terms
+size_t ew_extra_bytes(const ngpde_graph_t *g, int32_t din, int32_t dout) {
+  const size_t n = (size_t)g->n_nodes;
+  return align256(n * din * 4) + align256(n * (size_t)std::min(din, dout) * 4) + align256(n * 4);
+}
+
+// bias: only read when dedge_weight is asked for and Dout < Din (x3 = z - bias there)
+int32_t gcn_backward_impl(const char *fn, const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x, const float *weight,
+                          const float *bias, const float *z, const float *saved_agg, const float *dy, float *dx, float *dweight, float *dbias,
+                          float *dedge_weight, void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  int32_t st = check_common(fn, g, din, dout, act);
   if (st) return st;
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: dweight is NULL");
+  if (dedge_weight && g->n_edges > 0 && g->n_nodes == 0) return fail(NGPDE_ERR_STATE, "edges without nodes");
   if (g->n_nodes == 0) {  // empty graph: zero gradients
     { const int32_t zs = launch_zero(dweight, (size_t)din * dout * 4, (hipStream_t)stream_); if (zs) return zs; }
     if (dbias) { const int32_t zs = launch_zero(dbias, (size_t)dout * 4, (hipStream_t)stream_); if (zs) return zs; }
@@ -115,10 +125,19 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
   NGPDE_REQUIRE(dout >= din || x, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward: x is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t n = g->n_nodes;
-  const size_t need = ngpde_gcn_workspace_bytes(g, din, dout, 1);
+  const size_t base = ngpde_gcn_workspace_bytes(g, din, dout, 1);
+  const size_t need = base + (dedge_weight ? ew_extra_bytes(g, din, dout) : 0);
   NGPDE_REQUIRE(workspace && workspace_bytes >= need, NGPDE_ERR_WORKSPACE,
                 "ngpde_gcn_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   char *ws = (char *)workspace;
+  float *ew_dx = nullptr, *ew_xw = nullptr, *ew_nd = nullptr;
+  if (dedge_weight) {
+    NGPDE_REQUIRE(x != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward_ew: x is NULL");
+    ew_dx = (float *)(ws + base);
+    ew_xw = (float *)(ws + base + align256((size_t)n * din * 4));
+    ew_nd = (float *)(ws + base + align256((size_t)n * din * 4) + align256((size_t)n * (size_t)std::min(din, dout) * 4));
+    if (!dx) dx = ew_dx;      // the degree term needs the layer's input gradient
+  }
   if (fused_supported(din, dout)) {
     const size_t nb = (size_t)fused_num_blocks(n);
     float *slab_dw = (float *)ws;
@@ -138,6 +157,8 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
     const int ns = fused_num_slabs(n, din);
     if ((st = launch_reduce_slabs(slab_dw, ns, din * dout, din / 16, dweight, stream))) return st;
     if (dbias && (st = launch_reduce_slabs(slab_db, ns, dout, 0, dbias, stream))) return st;
+    // gbuf = dz W^T = dL/dx3, saved_agg = x3, the propagated array is x itself
+    if (dedge_weight) return launch_gcn_edge_weight_grad(g, din, gbuf, saved_agg, nullptr, dx, x, ew_nd, dedge_weight, stream);
     return NGPDE_OK;
   }
   const size_t dmax = (size_t)std::max(din, dout);
@@ -150,6 +171,8 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
     if (dx) {
       if ((st = launch_dense_seg_bwd_input(n, one_grad(tmp, din), din, dout, dz, weight, stream))) return st;
       if ((st = launch_spmm_generic(g, true, true, din, NGPDE_AGGR_SUM, tmp, nullptr, dx, stream))) return st;
+      // tmp = dz W^T = dL/dx3, saved_agg = x3, the propagated array is x itself
+      if (dedge_weight) return launch_gcn_edge_weight_grad(g, din, tmp, saved_agg, nullptr, dx, x, ew_nd, dedge_weight, stream);
     }
     return NGPDE_OK;
   }
@@ -157,8 +180,39 @@ int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, in
   if (dbias && (st = launch_colsum2(n, dout, dz, partial, dbias, stream))) return st;
   if ((st = launch_spmm_generic(g, true, true, dout, NGPDE_AGGR_SUM, dz, nullptr, tmp, stream))) return st;
   if ((st = launch_dense_seg_bwd_weight(n, one_seg(x, din), din, dout, tmp, dweight, nullptr, partial, stream))) return st;
-  if (dx) return launch_dense_seg_bwd_input(n, one_grad(dx, din), din, dout, tmp, weight, stream);
+  if (dx && (st = launch_dense_seg_bwd_input(n, one_grad(dx, din), din, dout, tmp, weight, stream))) return st;
+  if (dedge_weight) {
+    // the propagated array was x W (recomputed), its gradient is tmp = A^T dz, dL/dx3 = dz and x3 = z - bias
+    if ((st = launch_dense_seg_fwd(n, one_seg(x, din), din, dout, NGPDE_ACT_IDENTITY, weight, nullptr, ew_xw, nullptr, stream))) return st;
+    return launch_gcn_edge_weight_grad(g, dout, dz, z, bias, tmp, ew_xw, ew_nd, dedge_weight, stream);
+  }
   return NGPDE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t ngpde_gcn_backward(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x,
+                           const float *weight, const float *z, const float *saved_agg, const float *dy, float *dx,
+                           float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
+                           ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  return gcn_backward_impl("ngpde_gcn_backward", g, din, dout, act, x, weight, nullptr, z, saved_agg, dy, dx, dweight, dbias, nullptr, workspace,
+                           workspace_bytes, stream_);
+}
+
+size_t ngpde_gcn_backward_ew_workspace_bytes(const ngpde_graph_t *g, int32_t din, int32_t dout) {
+  if (!g) return 0;
+  return ngpde_gcn_workspace_bytes(g, din, dout, 1) + ew_extra_bytes(g, din, dout);
+}
+
+int32_t ngpde_gcn_backward_ew(const ngpde_graph_t *g, int32_t din, int32_t dout, int32_t act, const float *x, const float *weight,
+                              const float *bias, const float *z, const float *saved_agg, const float *dy, float *dx, float *dweight,
+                              float *dbias, float *dedge_weight, void *workspace, size_t workspace_bytes, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(dedge_weight != nullptr || (g && g->n_edges == 0), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gcn_backward_ew: dedge_weight is NULL");
+  return gcn_backward_impl("ngpde_gcn_backward_ew", g, din, dout, act, x, weight, bias, z, saved_agg, dy, dx, dweight, dbias, dedge_weight, workspace,
+                           workspace_bytes, stream_);
 }
 
 int32_t ngpde_propagate_copy_xj(const ngpde_graph_t *g, int32_t d, int32_t aggr, int32_t by_source, const float *x,

@@ -57,6 +57,30 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
   return launch_dense_seg_fwd(n, t, din, dout, act, weight, bias, y, save_z, (hipStream_t)stream);
 }
 
+int32_t ngpde_dense_multi_forward(int32_t count, const int64_t *n, const int32_t *n_seg, const float *const *seg_ptr,
+                                  const int32_t *seg_width, const int32_t *seg_row_div, const int32_t *dout, const int32_t *act,
+                                  const float *const *weight, const float *const *bias, float *const *y, float *const *save_z,
+                                  ngpde_stream_t stream) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(count >= 1 && count <= 4, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_multi_forward: 1..4 problems (got %d)", count);
+  NGPDE_REQUIRE(n && n_seg && seg_ptr && seg_width && dout && act && weight && bias && y && save_z, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_dense_multi_forward: NULL table");
+  SegTable t[4];
+  int din[4], dd[4], aa[4];
+  int off = 0;
+  for (int q = 0; q < count; ++q) {
+    int32_t st = make_segs("ngpde_dense_multi_forward", n_seg[q], seg_ptr + off, seg_width + off, seg_row_div ? seg_row_div + off : nullptr,
+                           t[q], &din[q]);
+    if (st || (st = check_act("ngpde_dense_multi_forward", act[q]))) return st;
+    NGPDE_REQUIRE(n[q] >= 0 && n[q] < ((int64_t)1 << 31) && dout[q] > 0, NGPDE_ERR_DIMENSION_MISMATCH,
+                  "ngpde_dense_multi_forward: DimensionMismatch in problem %d (rows must be in [0, 2^31), dout > 0)", q);
+    NGPDE_REQUIRE(n[q] == 0 || (weight[q] && y[q]), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_multi_forward: weight/y of problem %d is NULL", q);
+    dd[q] = dout[q]; aa[q] = act[q];
+    off += n_seg[q];
+  }
+  return launch_dense_multi_fwd(count, n, t, din, dd, aa, weight, bias, y, save_z, (hipStream_t)stream);
+}
+
 int32_t ngpde_dense_pair_forward(int64_t n, int32_t n_seg_a, const float *const *seg_ptr_a, const int32_t *seg_width_a,
                                  const int32_t *seg_row_div_a, int32_t dout_a, int32_t act_a, const float *weight_a, const float *bias_a,
                                  float *y_a, float *save_z_a, int32_t n_seg_b, const float *const *seg_ptr_b,

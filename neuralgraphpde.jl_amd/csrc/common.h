@@ -210,6 +210,9 @@ int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope
 // generic (any feature width) building blocks
 int32_t launch_spmm_generic(const ngpde_graph *g, bool by_source, bool gcn_norm, int d, int aggr,
                             const float *x, const float *edge_weight, float *out, hipStream_t stream);
+// gradient w.r.t. GCNConv's edge_weight argument (gcn_generic.hip); nd_scratch: n_nodes floats
+int32_t launch_gcn_edge_weight_grad(const ngpde_graph *g, int d, const float *g3, const float *x3, const float *bias_or_null, const float *dxp,
+                                    const float *xp, float *nd_scratch, float *dw, hipStream_t stream);
 // dz = dy * act'(z)
 int32_t launch_act_bwd(int64_t count, int act, const float *dy, const float *z, float *dz, hipStream_t stream);
 // out[o] = sum_n a[n][o]
@@ -230,6 +233,8 @@ struct SegGrad {
   int width[4] = {0, 0, 0, 0};
   int offset[5] = {0, 0, 0, 0, 0};
 };
+int32_t launch_dense_multi_fwd(int count, const int64_t *n, const SegTable *segs, const int *din, const int *dout, const int *act,
+                               const float *const *wt, const float *const *bias, float *const *y, float *const *save_z, hipStream_t stream);
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream);
 int dense_fwd_splits(int64_t n, int din, int dout);

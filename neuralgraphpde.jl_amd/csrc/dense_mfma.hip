@@ -64,17 +64,17 @@ __device__ __forceinline__ void mfma_chunk(const float *ldsA, const float *ldsBt
 // products to y + z * part_stride (no bias, no activation); the caller sums the partials (the GCN path does it inside the
 // aggregation that follows, src/layers.jl:220-223).  For tall-K / few-row shapes such as GCNConv(1433 => 16) on a 2.7k-node
 // graph: 43 row tiles alone would leave 5/6 of the chip idle behind 90 dependent K steps each.
-__global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable segs, int din_all, int dout, int act,
-                                                             const float *__restrict__ wt, const float *__restrict__ bias,
-                                                             float *__restrict__ y, float *__restrict__ save_z, int kper,
-                                                             size_t part_stride) {
-  __shared__ __attribute__((aligned(16))) float ldsA[BM * LS], ldsBt[BN * LS];
+// (the body of one 64 x 64 output tile, shared by the single-problem kernel and the multi-problem one below)
+__device__ __forceinline__ void dense_mfma_fwd_tile(int64_t n, const SegTable &segs, int din_all, int dout, int act,
+                                                    const float *__restrict__ wt, const float *__restrict__ bias, float *__restrict__ y,
+                                                    float *__restrict__ save_z, int kper, size_t part_stride, int bx, int by, int bz,
+                                                    float *ldsA, float *ldsBt) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
-  const int col0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * kper, din = min(din_all, kbeg + kper);   // this workgroup's feature range [kbeg, din)
-  if (part_stride) { y += (size_t)blockIdx.z * part_stride; bias = nullptr; save_z = nullptr; act = NGPDE_ACT_IDENTITY; }
+  const int64_t row0 = (int64_t)bx * BM;
+  const int col0 = by * BN;
+  const int kbeg = bz * kper, din = min(din_all, kbeg + kper);   // this workgroup's feature range [kbeg, din)
+  if (part_stride) { y += (size_t)bz * part_stride; bias = nullptr; save_z = nullptr; act = NGPDE_ACT_IDENTITY; }
   // staging roles: A element (row = tid / 16 + 16 p, k = tid % 16), B element (k = tid / 64 + 4 p, col = tid % 64)
   const int ar = tid >> 4, ak = tid & 15, bk = tid >> 6, bc = tid & 63;
   float areg[4], breg[4];
@@ -117,6 +117,40 @@ __global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void dense_mfma_fwd_kernel(int64_t n, SegTable segs, int din_all, int dout, int act,
+                                                             const float *__restrict__ wt, const float *__restrict__ bias,
+                                                             float *__restrict__ y, float *__restrict__ save_z, int kper,
+                                                             size_t part_stride) {
+  __shared__ __attribute__((aligned(16))) float ldsA[BM * LS], ldsBt[BN * LS];
+  dense_mfma_fwd_tile(n, segs, din_all, dout, act, wt, bias, y, save_z, kper, part_stride, blockIdx.x, blockIdx.y, blockIdx.z, ldsA, ldsBt);
+}
+
+// Several INDEPENDENT small Dense layers in one launch (<= 4 problems; a 1-D grid over the 64 x 64 output tiles of all of them).
+// GNOConv's node-level terms P, Q, B2 h and W h (/root/reference/src/layers.jl:523,536: 4 096 rows each) are four launches of a
+// few dozen workgroups behind 2-8 dependent K chunks -- 8-16 us apiece, one after the other; together they are one such latency.
+struct MultiFwdK {
+  int count;
+  int tile0[5];       // first tile of problem q in the grid; tile0[count] = the grid size
+  int col_tiles[4];
+  struct Prob {
+    int64_t n;
+    SegTable segs;
+    int din, dout, act;
+    const float *wt, *bias;
+    float *y, *save_z;
+  } p[4];
+};
+__global__ __launch_bounds__(256) void dense_mfma_multi_fwd_kernel(const MultiFwdK mk) {
+  __shared__ __attribute__((aligned(16))) float ldsA[BM * LS], ldsBt[BN * LS];
+  const int b = blockIdx.x;
+  int q = 0;
+  while (q + 1 < mk.count && b >= mk.tile0[q + 1]) ++q;   // block-uniform
+  const int local = b - mk.tile0[q];
+  const MultiFwdK::Prob &pr = mk.p[q];
+  dense_mfma_fwd_tile(pr.n, pr.segs, pr.din, pr.dout, pr.act, pr.wt, pr.bias, pr.y, pr.save_z, pr.din, (size_t)0, local / mk.col_tiles[q],
+                      local % mk.col_tiles[q], 0, ldsA, ldsBt);
 }
 
 // ---- input pullback: dX[n][k] = sum_o dz[n][o] wt[k][o], written into the blocks that ask for it -------------------
@@ -1243,6 +1277,28 @@ int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout,
   hipLaunchKernelGGL(dense_mfma_fwd_kernel, dim3((unsigned)((n + BM - 1) / BM), (dout + BN - 1) / BN), dim3(256), 0, stream,
                      n, segs, din, dout, act, wt, bias, y, save_z, din, (size_t)0);
   NGPDE_LAUNCH_CHECK("dense_mfma_fwd_kernel");
+  return NGPDE_OK;
+}
+
+// count <= 4 independent problems in ONE launch of the 64 x 64-tile kernel (see dense_mfma_multi_fwd_kernel)
+int32_t launch_dense_multi_fwd(int count, const int64_t *n, const SegTable *segs, const int *din, const int *dout, const int *act,
+                               const float *const *wt, const float *const *bias, float *const *y, float *const *save_z, hipStream_t stream) {
+  MultiFwdK mk;
+  mk.count = 0;
+  int tiles = 0;
+  for (int q = 0; q < count; ++q) {
+    if (n[q] == 0 || dout[q] == 0) continue;
+    const int k = mk.count++;
+    mk.tile0[k] = tiles;
+    mk.col_tiles[k] = (dout[q] + BN - 1) / BN;
+    tiles += (int)((n[q] + BM - 1) / BM) * mk.col_tiles[k];
+    mk.p[k].n = n[q]; mk.p[k].segs = segs[q]; mk.p[k].din = din[q]; mk.p[k].dout = dout[q]; mk.p[k].act = act[q];
+    mk.p[k].wt = wt[q]; mk.p[k].bias = bias[q]; mk.p[k].y = y[q]; mk.p[k].save_z = save_z[q];
+  }
+  if (mk.count == 0) return NGPDE_OK;
+  mk.tile0[mk.count] = tiles;
+  hipLaunchKernelGGL(dense_mfma_multi_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, mk);
+  NGPDE_LAUNCH_CHECK("dense_mfma_multi_fwd_kernel");
   return NGPDE_OK;
 }
 

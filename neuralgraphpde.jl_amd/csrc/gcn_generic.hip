@@ -260,4 +260,56 @@ int32_t launch_colsum(int64_t n, int d, const float *a, float *out, hipStream_t 
   return NGPDE_OK;
 }
 
+// ---- gradient w.r.t. the edge_weight ARGUMENT of GCNConv (/root/reference/src/layers.jl:206-231) ------------------------------
+// With xp = the array entering the propagation (x, or x W when Dout < Din), x3 = c_i sum_e w_e c_s xp_s its output and g3 = dL/dx3:
+//   dL/dw_e = c_t c_s (g3_t . xp_s)  [through e_mul_xj, :228]  -  1/2 c_t^2 (g3_t . x3_t + dxp_t . xp_t)  [through the weighted
+//   degree d_t = sum w_e, c = d^(-1/2), :224-226 and :234], dxp = dL/dxp (the layer's own input gradient).
+// node_term: nd[i] = -1/2 c_i^2 (g3_i . x3_i + dxp_i . xp_i), one 16-lane group per node; x3 may be given as z - bias.
+__global__ void gcn_ew_node_term_kernel(int n, int d, const float *__restrict__ c, const float *__restrict__ g3, const float *__restrict__ x3,
+                                        const float *__restrict__ bias, const float *__restrict__ dxp, const float *__restrict__ xp,
+                                        float *__restrict__ nd) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, q = threadIdx.x & 15;
+  if (i >= n) return;   // (whole 16-lane groups leave together)
+  float s = 0.f;
+  for (int f = q; f < d; f += 16) {
+    const size_t k = (size_t)i * d + f;
+    s += g3[k] * (x3[k] - (bias ? bias[f] : 0.f)) + dxp[k] * xp[k];
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+  if (q == 0) nd[i] = -0.5f * c[i] * c[i] * s;
+}
+// one wave per target row: its four 16-lane groups take the row's entries in turn; dw[eid] = c_t c_s (g3_t . xp_s) + nd[t]
+__global__ void gcn_ew_edge_kernel(int n, int d, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ eid,
+                                   const float *__restrict__ c, const float *__restrict__ g3, const float *__restrict__ xp,
+                                   const float *__restrict__ nd, float *__restrict__ dw) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
+  const int p0 = rowptr[i], p1 = rowptr[i + 1];
+  const float ci = c[i], ndi = nd[i];
+  for (int p = p0 + grp; p < p1; p += 4) {
+    const int j = col[p];
+    float s = 0.f;
+    for (int f = q; f < d; f += 16) s += g3[(size_t)i * d + f] * xp[(size_t)j * d + f];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+    if (q == 0) dw[eid[p]] = ci * c[j] * s + ndi;
+  }
+}
+
+int32_t launch_gcn_edge_weight_grad(const ngpde_graph *g, int d, const float *g3, const float *x3, const float *bias_or_null, const float *dxp,
+                                    const float *xp, float *nd_scratch, float *dw, hipStream_t stream) {
+  NGPDE_REQUIRE(g && g->has_norm, NGPDE_ERR_STATE, "GCN normalisation not set (call ngpde_graph_set_gcn_norm)");
+  const int n = (int)g->n_nodes;
+  if (n == 0 || g->n_edges == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gcn_ew_node_term_kernel, dim3((unsigned)(((int64_t)n * 16 + 255) / 256)), dim3(256), 0, stream, n, d, g->c, g3, x3,
+                     bias_or_null, dxp, xp, nd_scratch);
+  NGPDE_LAUNCH_CHECK("gcn_ew_node_term_kernel");
+  hipLaunchKernelGGL(gcn_ew_edge_kernel, dim3((unsigned)(((int64_t)n * 64 + 255) / 256)), dim3(256), 0, stream, n, d, g->by_t.rowptr,
+                     g->by_t.col, g->by_t.eid, g->c, g3, xp, nd_scratch, dw);
+  NGPDE_LAUNCH_CHECK("gcn_ew_edge_kernel");
+  return NGPDE_OK;
+}
+
 }  // namespace ngpde

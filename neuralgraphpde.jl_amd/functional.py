@@ -25,10 +25,11 @@ def _ws(nbytes, device):
 
 
 class _GCNConvFn(torch.autograd.Function):
-    """y = act(W (x C (A+I) C) + b)  -- /root/reference/src/layers.jl:200-239."""
+    """y = act(W (x C (A+I) C) + b)  -- /root/reference/src/layers.jl:200-239.  `edge_weight`: the call's edge_weight argument
+    when a gradient is wanted for it (the handle already carries these weights; the tensor enters only as an autograd input)."""
 
     @staticmethod
-    def forward(ctx, x, wt, bias, handle, act):
+    def forward(ctx, x, wt, bias, handle, act, edge_weight=None):
         lib = _lib.load()
         _need_cuda(x, wt, bias)
         n, din = x.shape
@@ -36,10 +37,9 @@ class _GCNConvFn(torch.autograd.Function):
         if wt.shape[0] != din:
             raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
                                          f"DimensionMismatch: weight is ({dout} x {wt.shape[0]}), x has {din} features")
-        x = x.contiguous()
-        wt = wt.contiguous()
-        need_grad = any(ctx.needs_input_grad[:3])
+        x, wt = x.contiguous(), wt.contiguous()
         y = torch.empty((n, dout), dtype=torch.float32, device=x.device)
+        need_grad = any(ctx.needs_input_grad)
         agg = torch.empty((n, din), dtype=torch.float32, device=x.device) if (need_grad and dout >= din) else None
         z = torch.empty((n, dout), dtype=torch.float32, device=x.device) if need_grad else None
         ws = _ws(lib.ngpde_gcn_workspace_bytes(handle.ptr, din, dout, 0), x.device)
@@ -48,27 +48,36 @@ class _GCNConvFn(torch.autograd.Function):
                                          _lib.current_stream()))
         ctx.handle, ctx.act, ctx.dims = handle, act, (n, din, dout)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, wt, z, agg)
+        ctx.n_edges = None if edge_weight is None else int(edge_weight.numel())
+        ctx.save_for_backward(x, wt, z, agg, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wt, z, agg = ctx.saved_tensors
+        x, wt, z, agg, bias = ctx.saved_tensors
         n, din, dout = ctx.dims
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dwt = torch.empty_like(wt)
         db = torch.empty((dout,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        if ctx.n_edges is not None and ctx.needs_input_grad[5]:
+            dew = torch.empty((ctx.n_edges,), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.ngpde_gcn_backward_ew_workspace_bytes(ctx.handle.ptr, din, dout), x.device)
+            _lib.check(lib.ngpde_gcn_backward_ew(ctx.handle.ptr, din, dout, ctx.act, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(z),
+                                                 _lib.ptr(agg), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(dew),
+                                                 _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+            return dx, dwt, db, None, None, dew
         ws = _ws(lib.ngpde_gcn_workspace_bytes(ctx.handle.ptr, din, dout, 1), x.device)
         _lib.check(lib.ngpde_gcn_backward(ctx.handle.ptr, din, dout, ctx.act, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(z),
                                           _lib.ptr(agg), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dwt), _lib.ptr(db),
                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()))
-        return dx, dwt, db, None, None
+        return dx, dwt, db, None, None, None
 
 
-def gcn_conv(x, wt, bias, handle, act):
-    return _GCNConvFn.apply(x, wt, bias, handle, act)
+def gcn_conv(x, wt, bias, handle, act, edge_weight=None):
+    """edge_weight: pass the call's edge_weight tensor when it requires a gradient (src/layers.jl:206-231)"""
+    return _GCNConvFn.apply(x, wt, bias, handle, act, edge_weight)
 
 
 def propagate_copy_xj(x, handle, aggr="+", edge_weight=None, by_source=False):
@@ -253,7 +262,14 @@ class _DensePairFn(torch.autograd.Function):
         dwta, dba, dA = _dense_backward_call(lib, n, A, wa, rda, wta.shape[1], acta, wta, za, dya, want[:na], has_ba)
         dwtb, dbb, dB = _dense_backward_call(lib, n, B, wb, rdb, wtb.shape[1], actb, wtb, zb, dyb, want[na:], has_bb)
         if dxp is not None and want[0]:
-            dA[0] = dxp if dA[0] is None else dA[0] + dxp
+            if dA[0] is None:
+                dA[0] = dxp
+            else:                    # one library launch (the Runge-Kutta combination kernel: out = 1 * base + 1 * term), no torch add
+                import ctypes as C
+                out = torch.empty_like(dA[0])
+                _lib.check(lib.ngpde_rk_stage_combine(out.numel(), 1.0, _lib.ptr(dA[0].contiguous()), 1, (C.c_void_p * 1)(dxp.data_ptr()),
+                                                      (C.c_float * 1)(1.0), _lib.ptr(out), _lib.current_stream()))
+                dA[0] = out
         return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, None, *dA, *dB)
 
 
@@ -563,7 +579,7 @@ class _GnoMessageAggFn(torch.autograd.Function):
         pshape, qshape, has_e, has_bh = ctx.shapes
         dev = dagg.device
         if aggr == _lib.AGGR["mean"]:      # a node's 1 / deg once per node here, not once per edge in the launch (where it would hang
-            dagg = dagg * ctx.handle.inv_in_degree(dev)         # on the edge's target index: one more dependent load per pass)
+            dagg = rows_scale(dagg, ctx.handle.inv_in_degree(dev))   # on the edge's target index: one more dependent load per pass)
             aggr = _lib.AGGR["+"]
         dagg = dagg.contiguous()
         stream = _lib.current_stream()
@@ -880,3 +896,179 @@ def edge_mlp_fused(P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, tail):
         wb += [wt, b]
     return _EdgeMlpFusedFn.apply(P, Q, Eterm, handle, act1, _lib.AGGR[aggr] if isinstance(aggr, str) else aggr, n_nodes,
                                  n_edges, tuple(a for _, _, a in tail), *wb)
+
+
+# ---- weight-sized rearrangements as library launches (row_blocks.hip) ---------------------------------------------------------
+
+
+class _RowBlocksFn(torch.autograd.Function):
+    """Recombined row blocks of a [rows][width] weight: every output is a vertical stack of blocks, a block the signed sum of
+    equally long row ranges of the source (ExplicitEdgeConv [wa; -wc], VMHConv [wa - wb; -wc], MPPDEConv [wa; wc; we] ...).
+    ONE launch builds all outputs, ONE launch their pullback -- no slices, cat, neg, zero-fills or adds of slice gradients."""
+
+    @staticmethod
+    def forward(ctx, wt, spec):
+        import ctypes as C
+        lib = _lib.load()
+        wt = wt.contiguous()
+        rows, width = wt.shape
+        out_index, dst0, src0, nrows, sign, out_rows = [], [], [], [], [], []
+        for o, blocks in enumerate(spec):
+            r = 0
+            for n, terms in blocks:
+                for s0, sg in terms:
+                    out_index.append(o); dst0.append(r); src0.append(s0); nrows.append(n); sign.append(float(sg))
+                r += n
+            out_rows.append(r)
+        outs = [torch.empty((r, width), dtype=torch.float32, device=wt.device) for r in out_rows]
+        meta = (rows, width, _int_array(out_index), _int_array(dst0), _int_array(src0), _int_array(nrows),
+                (C.c_float * max(len(sign), 1))(*sign), len(out_index), _int_array(out_rows), len(outs))
+        _lib.check(lib.ngpde_row_blocks_gather(width, rows, _lib.ptr(wt), meta[7], meta[2], meta[3], meta[4], meta[5], meta[6], len(outs),
+                                               _ptr_array(outs), meta[8], _lib.current_stream()))
+        ctx.meta, ctx.dev = meta, wt.device
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        lib = _lib.load()
+        rows, width, out_index, dst0, src0, nrows, sign, n_seg, out_rows, n_out = ctx.meta
+        douts = [None if d is None else d.contiguous() for d in douts]
+        dwt = torch.empty((rows, width), dtype=torch.float32, device=ctx.dev)
+        _lib.check(lib.ngpde_row_blocks_scatter(width, rows, _lib.ptr(dwt), n_seg, out_index, dst0, src0, nrows, sign, n_out,
+                                                _ptr_array(douts), out_rows, _lib.current_stream()))
+        return dwt, None
+
+
+def row_blocks(wt, spec):
+    """spec: per output a list of blocks (n_rows, [(src_row0, sign), ...]); blocks with n_rows == 0 are dropped.  Returns the
+    list of output matrices ([sum n_rows][width] each)."""
+    spec = [[(int(n), list(terms)) for n, terms in blocks if n > 0] for blocks in spec]
+    return list(_RowBlocksFn.apply(wt, spec))
+
+
+class _TransposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        out = torch.empty((a.shape[1], a.shape[0]), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().ngpde_transpose(a.shape[0], a.shape[1], _lib.ptr(a), _lib.ptr(out), _lib.current_stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        out = torch.empty((d.shape[1], d.shape[0]), dtype=torch.float32, device=d.device)
+        _lib.check(_lib.load().ngpde_transpose(d.shape[0], d.shape[1], _lib.ptr(d), _lib.ptr(out), _lib.current_stream()))
+        return out
+
+
+def transpose(a):
+    """contiguous transpose of a 2-D float32 tensor as a library launch (its pullback: the transpose of the cotangent)"""
+    return _TransposeFn.apply(a)
+
+
+def rows_scale(x, scale):
+    """out[i][:] = x[i][:] * scale[i] (no autograd: used inside pullbacks)"""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().ngpde_rows_scale(x.shape[0], x.shape[1], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+# ---- several independent small Dense layers in one launch; fan-out of a tensor to several consumers ----------------------------
+
+
+def _sum_list(tensors):
+    """sum of equally shaped float32 tensors as ONE library launch (the Runge-Kutta combination kernel), no torch adds"""
+    import ctypes as C
+    tensors = [t.contiguous() for t in tensors]
+    if len(tensors) == 1:
+        return tensors[0]
+    out = torch.empty_like(tensors[0])
+    terms = tensors[1:]
+    _lib.check(_lib.load().ngpde_rk_stage_combine(out.numel(), 1.0, _lib.ptr(tensors[0]), len(terms),
+                                                  (C.c_void_p * len(terms))(*[t.data_ptr() for t in terms]),
+                                                  (C.c_float * len(terms))(*([1.0] * len(terms))), _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+class _FanoutFn(torch.autograd.Function):
+    """k aliases of one tensor for k consumers; the pullback sums their cotangents in ONE launch (autograd would add them pairwise
+    with torch kernels)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *ds):
+        ds = [d for d in ds if d is not None]
+        return (_sum_list(ds) if ds else None), None
+
+
+def fanout(x, k):
+    return list(_FanoutFn.apply(x, k)) if (k > 1 and x.requires_grad and torch.is_grad_enabled()) else [x] * k
+
+
+class _DenseMultiFn(torch.autograd.Function):
+    """Up to four independent Dense layers y_q = act_q(x_q W_q + b_q) (ONE input block each) in one launch
+    (ngpde_dense_multi_forward); the pullbacks are the single-problem launches; inputs that are the same tensor get the sum."""
+
+    @staticmethod
+    def forward(ctx, acts, *args):          # args: x_0, wt_0, b_0, x_1, wt_1, b_1, ...
+        import ctypes as C
+        lib = _lib.load()
+        q = len(acts)
+        xs = [args[3 * i].contiguous() for i in range(q)]
+        wts = [args[3 * i + 1].contiguous() for i in range(q)]
+        bs = [args[3 * i + 2] for i in range(q)]
+        _need_cuda(*xs, *wts, *bs)
+        for x, wt in zip(xs, wts):
+            if wt.shape[0] != x.shape[1]:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                             f"DimensionMismatch: Dense expects {wt.shape[0]} input features, got {x.shape[1]}")
+        dev = wts[0].device
+        need = any(ctx.needs_input_grad)
+        ys = [torch.empty((x.shape[0], wt.shape[1]), dtype=torch.float32, device=dev) for x, wt in zip(xs, wts)]
+        zs = [torch.empty_like(y) if (need and a != 0) else None for y, a in zip(ys, acts)]
+        n = (C.c_int64 * q)(*[x.shape[0] for x in xs])
+        _lib.check(lib.ngpde_dense_multi_forward(q, n, _int_array([1] * q), _ptr_array(xs), _int_array([x.shape[1] for x in xs]),
+                                                 _int_array([1] * q), _int_array([wt.shape[1] for wt in wts]), _int_array(acts),
+                                                 _ptr_array(wts), _ptr_array(bs), _ptr_array(ys), _ptr_array(zs), _lib.current_stream()))
+        ctx.acts = tuple(acts)
+        ctx.has_b = tuple(b is not None for b in bs)
+        ctx.same = [next(j for j in range(q) if args[3 * j] is args[3 * i]) for i in range(q)]   # first problem with the same input
+        ctx.save_for_backward(*xs, *wts, *[z if z is not None else torch.empty(0, device=dev) for z in zs])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        q = len(ctx.acts)
+        saved = ctx.saved_tensors
+        xs, wts, zs = saved[:q], saved[q:2 * q], saved[2 * q:]
+        grads = [None] * (3 * q)
+        dxs = [None] * q
+        for i in range(q):
+            if dys[i] is None:
+                continue
+            want_x = ctx.needs_input_grad[1 + 3 * i]
+            z = zs[i] if zs[i].numel() else None
+            dwt, db, dblocks = _dense_backward_call(lib, xs[i].shape[0], [xs[i]], [xs[i].shape[1]], [1], wts[i].shape[1], ctx.acts[i], wts[i],
+                                                    z, dys[i].contiguous(), [want_x], ctx.has_b[i])
+            grads[3 * i + 1], grads[3 * i + 2], dxs[i] = dwt, db, dblocks[0]
+        for i in range(q):                                   # one gradient per distinct input tensor
+            if ctx.same[i] != i or not ctx.needs_input_grad[1 + 3 * i]:
+                continue
+            parts = [dxs[j] for j in range(q) if ctx.same[j] == i and dxs[j] is not None]
+            grads[3 * i] = _sum_list(parts) if parts else None
+        return (None, *grads)
+
+
+def dense_multi(problems):
+    """problems: list of (x [n][k], wt [k][m], bias or None, act code); returns the list of outputs.  Empty inputs are allowed
+    (zero rows)."""
+    args = []
+    for x, wt, b, _ in problems:
+        args += [x, wt, b]
+    return list(_DenseMultiFn.apply([int(a) for *_, a in problems], *args))

@@ -57,6 +57,7 @@ class _Handle:
 
     def __init__(self, g, norm):
         lib = _lib.load()
+        _lib.flush_destroy()            # handles whose finaliser ran inside a HIP-graph capture
         out = C.c_void_p()
         self.lib = lib
         self.ptr = None
@@ -116,7 +117,7 @@ class _Handle:
     def __del__(self):
         try:
             if self.ptr:
-                self.lib.ngpde_graph_destroy(self.ptr)
+                _lib.destroy_later("ngpde_graph_destroy", self.ptr)     # (not inside a HIP-graph capture: see _lib.destroy_later)
                 self.ptr = None
         except Exception:
             pass

@@ -261,8 +261,8 @@ class GCNConv(AbstractGNNLayer):
                 raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT,
                                          f"Wrong number of edge weights (expected {g.num_edges} but given {n_w})")
             # The weights stay where they are (no download): the handle cache keys on their identity and version
-            # (GNNGraph.handle).  They are constants of the layer call: no gradient reaches `edge_weight` (the reference
-            # would differentiate through e_mul_xj and degree; none of its callers does).
+            # (GNNGraph.handle).  A weight tensor that requires a gradient gets one: the reference differentiates through
+            # e_mul_xj and the weighted degree (:224-231); ngpde_gcn_backward_ew.
             w = edge_weight.detach() if isinstance(edge_weight, torch.Tensor) else edge_weight
             norm = (self.add_self_loops, w, True)      # :224 degree uses the given weights
         elif self.use_edge_weight:
@@ -280,5 +280,8 @@ class GCNConv(AbstractGNNLayer):
                                          f"DimensionMismatch: x has {xr.shape[1]} rows, layer expects {self.in_chs}")
         wt = rows_of(ps["weight"])                     # (out x in) column-major -> [in][out]
         b = ps["bias"].reshape(-1) if "bias" in ps else None
-        y = F.gcn_conv(xr, wt, b, g.handle(norm), self.act)
+        ew_leaf = edge_weight if (isinstance(edge_weight, torch.Tensor) and edge_weight.requires_grad and torch.is_grad_enabled()) else None
+        if ew_leaf is not None and not ew_leaf.is_cuda:
+            raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, "GCNConv: an edge_weight that requires a gradient must live on the GPU")
+        y = F.gcn_conv(xr, wt, b, g.handle(norm), self.act, ew_leaf)
         return y.T, st

@@ -77,20 +77,16 @@ def _message_path(g, P, Q, Et, stack, aggr):
     return F.segment_reduce(_tail(stack, a), handle, aggr, g.num_nodes)
 
 
-def _split_rows(wt, sizes):
-    out, o = [], 0
+def _row_offsets(wt, sizes):
+    """first rows of the consecutive row blocks of the first-layer weight (the order of the message's vcat)"""
+    offs, o = [], 0
     for n in sizes:
-        out.append(wt[o:o + n])
+        offs.append(o)
         o += n
     if o != wt.shape[0]:
         raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
                                      f"DimensionMismatch: first layer expects {wt.shape[0]} input features, the message has {o}")
-    return out
-
-
-def _cat_rows(parts):
-    parts = [p for p in parts if p.shape[0] > 0]
-    return torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
+    return offs
 
 
 def _node_data(g, device, exclude=()):
@@ -152,8 +148,11 @@ class ExplicitEdgeConv(AbstractGNNContainerLayer):
         l1, p1 = stack[0]
         wt, b = _wt_b(p1)
         dh = sum(hb.shape[1] for hb in hblocks)
-        wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; hj...; xj - xi]
-        P, Q = F.dense_pair(hblocks + [pos], _cat_rows([wa, -wc]), b, 0, hblocks + [pos], _cat_rows([wb, wc]), None, 0)
+        dp = pos.shape[1]
+        oa, ob, oc = _row_offsets(wt, [dh, dh, dp])                               # [hi...; hj...; xj - xi]
+        wA, wB = F.row_blocks(wt, [[(dh, [(oa, 1)]), (dp, [(oc, -1)])], [(dh, [(ob, 1)]), (dp, [(oc, 1)])]])   # [wa; -wc], [wb; wc]
+        fan = [F.fanout(hb, 2) for hb in hblocks]         # target side / source side: their cotangents are summed in one launch
+        P, Q = F.dense_pair([f[0] for f in fan] + [pos], wA, b, 0, [f[1] for f in fan] + [pos], wB, None, 0)
         y = _message_path(g, P, Q, None, stack, self.aggr)                          # propagate(message, g, aggr)  (:111)
         return y.T, st
 
@@ -185,11 +184,16 @@ class VMHConv(AbstractGNNContainerLayer):
         l1, p1 = stack[0]
         wt, b = _wt_b(p1)
         dh = sum(hb.shape[1] for hb in hblocks)
-        wa, wb, wc = _split_rows(wt, [dh, dh, pos.shape[1]])                      # [hi...; (hj - hi)...; xj - xi]  (:316)
-        P, Q = F.dense_pair(hblocks + [pos], _cat_rows([wa - wb, -wc]), b, 0, hblocks + [pos], _cat_rows([wb, wc]), None, 0)
+        dp = pos.shape[1]
+        oa, ob, oc = _row_offsets(wt, [dh, dh, dp])                               # [hi...; (hj - hi)...; xj - xi]  (:316)
+        wA, wB = F.row_blocks(wt, [[(dh, [(oa, 1), (ob, -1)]), (dp, [(oc, -1)])],   # [wa - wb; -wc]
+                                   [(dh, [(ob, 1)]), (dp, [(oc, 1)])]])             # [wb; wc]
+        nx = len(xn)
+        fan = [F.fanout(hb, 3 if k < nx else 2) for k, hb in enumerate(hblocks)]   # target side, source side, (features:) γ
+        P, Q = F.dense_pair([f[0] for f in fan] + [pos], wA, b, 0, [f[1] for f in fan] + [pos], wB, None, 0)
         m = _message_path(g, P, Q, None, stack, self.aggr)                          # :326
         gstack = _dense_stack(self.γ, ps["γ"], "γ")
-        blocks = list(xn.values()) + [m]
+        blocks = [f[2] for f in fan[:nx]] + [m]
         y = _node_update(gstack, blocks, [1] * len(blocks), m.shape[0])           # γ(vcat(values(x)..., m))  (:328)
         return y.T, st
 
@@ -225,17 +229,19 @@ class MPPDEConv(AbstractGNNContainerLayer):
         stack = _dense_stack(self.ϕ, ps["ϕ"], "ϕ")
         l1, p1 = stack[0]
         wt, b = _wt_b(p1)
-        wa, wb, wc, wd, we = _split_rows(wt, [dh, dh, dd, de, dth])                # [hi; hj; di - dj; e; θ]  (:409-410)
-        tb, tw, trd = [h], [wa], [1]
+        oa, ob, oc, od, oe = _row_offsets(wt, [dh, dh, dd, de, dth])               # [hi; hj; di - dj; e; θ]  (:409-410)
+        tb, trd = [h], [1]
         if dd:
-            tb.append(d); tw.append(wc); trd.append(1)
+            tb.append(d); trd.append(1)
         if dth:
-            tb.append(theta); tw.append(we); trd.append(N // G)                    # θ of the target's graph = the edge's graph
+            tb.append(theta); trd.append(N // G)                                   # θ of the target's graph = the edge's graph
+        # the three recombined weights in one launch: target side [wa; wc; we], source side [wb; -wc], edge features wd
+        mats = F.row_blocks(wt, [[(dh, [(oa, 1)]), (dd, [(oc, 1)]), (dth, [(oe, 1)])], [(dh, [(ob, 1)]), (dd, [(oc, -1)])]] +
+                            ([[(de, [(od, 1)])]] if de else []))
         # one pass over h when the shapes allow; h comes back routed through the pair so that psi's gradient w.r.t. h is added
         # inside the pair's pullback launch
-        P, Q, h = F.dense_pair(tb, _cat_rows(tw), b, 0, [h] + ([d] if dd else []), _cat_rows([wb] + ([-wc] if dd else [])), None, 0,
-                               row_divs_a=trd, n=N, passthrough=True)
-        Et = F.dense([e_p], wd, None, 0) if de else None
+        P, Q, h = F.dense_pair(tb, mats[0], b, 0, [h] + ([d] if dd else []), mats[1], None, 0, row_divs_a=trd, n=N, passthrough=True)
+        Et = F.dense([e_p], mats[2], None, 0) if de else None
         m = _message_path(g, P, Q, Et, stack, self.aggr)                            # :416
         pstack = _dense_stack(self.ψ, ps["ψ"], "ψ")
         blocks, rd = [h, m], [1, 1]
@@ -279,10 +285,12 @@ class GNOConv(AbstractGNNContainerLayer):
         stack = _dense_stack(self.ϕ, ps["ϕ"], "ϕ")
         l1, p1 = stack[0]
         wt, b = _wt_b(p1)
-        wa, wb, wd = _split_rows(wt, [ds, ds, de])                                 # [si; sj; e]  (:523)
-        P = F.dense([s], wa, b, 0) if ds else None
-        Q = F.dense([s], wb, None, 0) if ds else None
+        oa, ob, od = _row_offsets(wt, [ds, ds, de])                                # [si; sj; e]  (:523)
+        mats = F.row_blocks(wt, ([[(ds, [(oa, 1)])], [(ds, [(ob, 1)])]] if ds else []) + ([[(de, [(od, 1)])]] if de else []))
+        wa, wb = (mats[0], mats[1]) if ds else (None, None)
+        wd = mats[-1] if de else None
         Et = F.dense([e_p], wd, b if not ds else None, 0) if de else None
+        P = Q = None                                                               # (node-level terms: below, in one launch)
         kout = _wt_b(stack[-1][1])[0].shape[1]
         if kout != self.in_chs * self.out_chs:
             raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
@@ -294,9 +302,21 @@ class GNOConv(AbstractGNNContainerLayer):
         if reassoc:
             # reassociated: K_e h_j = T_j z_e + B2 h_j with T_j = W2 (x) h_j at node level; K is never formed
             w2, b2 = _wt_b(plast)                                                  # [k][in*out], [in*out]; row r = o + out*i
-            wr = w2.view(kdim, self.in_chs, self.out_chs).permute(1, 2, 0).reshape(self.in_chs, self.out_chs * kdim)
-            T = F.dense([h], wr, None, 0)
-            Bh = F.dense([h], b2.view(self.in_chs, self.out_chs), None, 0) if b2 is not None else None
+            wr = F.transpose(w2).view(self.in_chs, self.out_chs * kdim)            # [in][out][k]: the transpose of [k][in * out]
+        lwt, lb = _wt_b(ps["linear"])
+        # h has up to three consumers (T, B2 h, W h): one fan-out node sums their cotangents in one launch.  The small node-level
+        # Dense layers -- P, Q on the node coordinates, B2 h, W h -- are latency-bound launches of a few dozen workgroups each:
+        # ONE launch for all of them (ngpde_dense_multi_forward)
+        hT, hS = F.fanout(h, 2) if reassoc else (None, h)
+        small = ([(s, wa, b, 0), (s, wb, None, 0)] if ds else []) + ([(hS, b2.view(self.in_chs, self.out_chs), None, 0)] if (reassoc and b2 is not None) else []) + [(hS, lwt, None, 0)]
+        outs = F.dense_multi(small)
+        if ds:
+            P, Q = outs[0], outs[1]
+        Wh = outs[-1]
+        Bh = None
+        if reassoc:
+            T = F.dense([hT], wr, None, 0)
+            Bh = outs[-2] if b2 is not None else None
         if (reassoc and len(stack) == 2 and E > 0 and os.environ.get("NGPDE_NO_GNO_MFMA") != "1"
                 and F.gno_message_supported(self.out_chs, kdim, l1.act)):
             # two-layer phi: the per-edge input act1(P[t] + Q[s] + E) is formed inside the message launch
@@ -310,8 +330,7 @@ class GNOConv(AbstractGNNContainerLayer):
             m = F.gno_contract(K, h, handle, self.in_chs, self.out_chs)            # :527-530
         if m is not None:
             agg = F.segment_reduce(m, handle, self.aggr, N)                        # :534
-        lwt, lb = _wt_b(ps["linear"])
-        y = F.bias_act(agg, F.dense([h], lwt, None, 0), lb, self.linear.act)       # σ(W x + m + b)  (:536-547)
+        y = F.bias_act(agg, Wh, lb, self.linear.act)                               # σ(W x + m + b)  (:536-547)
         return y.T, st
 
 

@@ -44,6 +44,7 @@ class _Plan:
         [members * N][d] arrays and solves the members one after the other (ngpde_node_gcn2_create_batch; raises NgpdeError
         with code ERR_UNSUPPORTED when the persistent plan does not cover the case)"""
         self.lib = _lib.load()
+        _lib.flush_destroy()            # plans whose finaliser ran inside a HIP-graph capture
         self.handle = handle            # keeps the graph handle alive
         self.ptr = None
         self.members = int(members)
@@ -95,7 +96,7 @@ class _Plan:
     def __del__(self):
         try:
             if self.ptr:
-                self.lib.ngpde_node_destroy(self.ptr)
+                _lib.destroy_later("ngpde_node_destroy", self.ptr)      # (not inside a HIP-graph capture: see _lib.destroy_later)
                 self.ptr = None
         except Exception:
             pass
@@ -307,7 +308,8 @@ class _CapturedSolve:
             _rk_forward(node, self.u_static, self.ps_in, st, False)
         torch.cuda.current_stream().wait_stream(side)
         self.fwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph):
+        # (relaxed: a finaliser that frees device memory in the middle of the capture must not invalidate it)
+        with torch.cuda.graph(self.fwd_graph, capture_error_mode="relaxed"):
             self.uT_static, self.tape, _ = _rk_forward(node, self.u_static, self.ps_in, st, needs, fresh=True)
         self.bwd_graph = None
         self.generation = 0                                # forward replays so far: the single static tape belongs to the last one
@@ -327,7 +329,7 @@ class _CapturedSolve:
         if self.bwd_graph is None:
             self.duT_static = duT.detach().clone()
             self.bwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
+            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="relaxed"):
                 self.lam_static, self.acc_static = _rk_backward(self.node, self.tape, self.duT_static, self.params, retain=True)
         else:
             self.duT_static.copy_(duT)

@@ -305,7 +305,7 @@ def gcn_conv(x, weight, bias, g, activation="identity", add_self_loops_=True,
     z = x + (0.0 if bias is None else bias.reshape(-1, 1))                    # :238
     y = act(activation, z)
     cache = dict(g=g, c=c, w=w, x_in=x_in, x3=x3, z=z, weight=weight, bias=bias,
-                 activation=activation)
+                 activation=activation, ew_arg=edge_weight is not None, self_loops=add_self_loops_)
     return y, cache
 
 
@@ -333,6 +333,27 @@ def gcn_conv_backward(cache, dy):
         dxw = agg_T(dz)
         grads["weight"] = dxw @ cache["x_in"].T
         grads["x"] = W.T @ dxw
+    if cache.get("ew_arg"):
+        # The `edge_weight` ARGUMENT (src/layers.jl:200-233) is differentiable in the reference: through e_mul_xj (:228) and through
+        # the weighted degree (:224).  With xp = the array entering the propagation (x, or W x when Dout < Din), x1 = xp .* c',
+        # x2 = sum_e w_e x1[:, s_e], x3 = x2 .* c', g3 = dL/dx3:
+        #   direct      dL/dw_e  = (g3 .* c')[:, t_e] . x1[:, s_e]
+        #   via degree  d_i = sum_{e: t_e = i} w_e,  c = d^(-1/2):  dL/dd_i = -1/2 c_i^3 dL/dc_i,
+        #               dL/dc_i = g3[:, i] . x2[:, i]  (x3 = c x2)  +  g1[:, i] . xp[:, i]  (x1 = xp c),  g1 = dL/dx1
+        # The ones appended for the self loops are constants: only the first num_edges entries are returned.
+        xp = cache["x_in"] if Dout >= Din else W @ cache["x_in"]
+        g3 = W.T @ dz if Dout >= Din else dz
+        g2 = g3 * c[None, :]
+        x1 = xp * c[None, :]
+        dw = (gather(g2, g.t) * gather(x1, g.s)).sum(axis=0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            x2 = cache["x3"] / c[None, :]
+        g1 = scatter("+", gather(g2, g.t) * w[None, :], g.s, g.num_nodes)
+        dc = (g3 * x2).sum(axis=0) + (g1 * xp).sum(axis=0)
+        dd = -0.5 * c ** 3 * dc
+        dw = dw + dd[g.t]
+        n_orig = g.num_edges - (g.num_nodes if cache["self_loops"] else 0)
+        grads["edge_weight"] = dw[:n_orig]
     return grads
 
 

@@ -88,7 +88,7 @@ def acts(layers):
     return [L["act"] for L in layers]
 
 
-def case_gcn(gname, g, din, dout, act, weighted, seed):
+def case_gcn(gname, g, din, dout, act, weighted, seed, tag=""):
     E = g["s"].size
     ew = (0.5 + np.abs(val((E,), seed + 3))) if weighted else None
     og = ograph(g)
@@ -98,7 +98,9 @@ def case_gcn(gname, g, din, dout, act, weighted, seed):
     gr = O.gcn_conv_backward(c, R)
     arr = graph_arrays(g, edge_weight=ew)
     arr.update({"x": x, "p.weight": W, "p.bias": b, "R": R, "y": y, "d.x": gr["x"], "d.weight": gr["weight"], "d.bias": gr["bias"]})
-    save(f"gcn_{gname}" + ("_weighted" if weighted else ""), dict(layer="gcn", act=act, din=din, dout=dout, weighted=weighted), arr)
+    if weighted:
+        arr["d.edge_weight"] = gr["edge_weight"]        # the edge_weight ARGUMENT is differentiable (src/layers.jl:206-231)
+    save(f"gcn_{gname}" + ("_weighted" if weighted else "") + tag, dict(layer="gcn", act=act, din=din, dout=dout, weighted=weighted), arr)
 
 
 def case_edgeconv(gname, g, h, dpos, phi, aggr, seed):
@@ -204,7 +206,9 @@ def main():
     # GCNConv(3 => 5) on the fixture (test/runtests.jl:15-24), wider + relu on the radius graph, an edge-weighted call (:227-231)
     case_gcn("fix3", f3, 3, 5, "identity", False, 1)
     case_gcn("rad64", r64, 8, 6, "relu", False, 2)
-    case_gcn("rad64", r64, 8, 6, "tanh", True, 3)
+    case_gcn("rad64", r64, 8, 6, "tanh", True, 3)                      # Dout < Din: W applied first (:220-223)
+    case_gcn("rad64", r64, 6, 8, "swish", True, 21, tag="_wide")        # Dout >= Din (:235-237)
+    case_gcn("rad64", r64, 16, 16, "relu", True, 22, tag="_fused")      # a width the fused kernels take
     # ExplicitEdgeConv(Dense(4+4+3, 5)) (test/runtests.jl:27-37)
     case_edgeconv("fix3", f3, 4, 3, [dense(11, 5, "identity", 4)], "mean", 4)
     case_edgeconv("rad64", r64, 6, 2, [dense(14, 16, "tanh", 5), dense(16, 9, "tanh", 6)], "+", 5)

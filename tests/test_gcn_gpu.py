@@ -166,6 +166,43 @@ def test_gcn_edge_weight_argument(d):
     run_layer(300, 2500, d, d, "relu", seed=5, weights="arg")
 
 
+@pytest.mark.parametrize("din,dout,loops", [(64, 64, True), (10, 10, True), (12, 5, True), (5, 12, False), (32, 32, False)])
+def test_gcn_gradient_wrt_the_edge_weight_argument(din, dout, loops):
+    # (l::GCNConv)(x, ps, st, edge_weight): the reference differentiates through e_mul_xj (:228) and the weighted degree (:224);
+    # fused widths (64, 32), the any-width path in both orders of W, with and without self loops; 2e-4 against the float64 oracle
+    N, E = 700, 5000
+    rng = np.random.default_rng(din * 100 + dout)
+    s, t = make_graph(N, E, seed=77)
+    if not loops:       # every node needs an incoming edge without self loops
+        s, t = np.concatenate([s, np.arange(N)]), np.concatenate([t, (np.arange(N) + 1) % N])
+    ew0 = (rng.random(s.size) + 0.5)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    l = ng.GCNConv((din, dout), "tanh", initialgraph=g, add_self_loops=loops)
+    ps, st = ng.setup(1, l)
+    ps = ng.to_device(ps, DEV)
+    ps["bias"] = torch.as_tensor(rng.normal(size=(dout, 1)).astype(np.float32), device=DEV)
+    for p in ps.values():
+        p.requires_grad_(True)
+    x = torch.as_tensor(rng.normal(size=(din, N)).astype(np.float32), device=DEV).requires_grad_(True)
+    ew = torch.as_tensor(ew0.astype(np.float32), device=DEV).requires_grad_(True)
+    y, _ = l(x, ps, st, ew)
+    R = rng.normal(size=(dout, N))
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    W, b = ps["weight"].detach().cpu().double().numpy(), ps["bias"].detach().cpu().double().numpy()
+    yo, cache = O.gcn_conv(x.detach().cpu().double().numpy(), W, b, og, "tanh", loops, edge_weight=ew0.astype(np.float32).astype(np.float64))
+    go = O.gcn_conv_backward(cache, R)
+    close(y, yo, what="y")
+    close(x.grad, go["x"], rtol=2e-4, what="dx")
+    close(ps["weight"].grad, go["weight"], rtol=2e-4, atol=1e-4, what="dW")
+    close(ew.grad, go["edge_weight"], rtol=2e-4, atol=1e-5, what="d edge_weight")
+    # without a gradient request the plain backward runs and x / W gradients are the same bits
+    x2 = x.detach().clone().requires_grad_(True)
+    y2, _ = l(x2, ps, st, ew.detach())
+    (y2 * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    assert torch.equal(x2.grad, x.grad)
+
+
 @pytest.mark.parametrize("d", [32, 9])
 def test_gcn_use_edge_weight_unweighted_degree_quirk(d):
     run_layer(300, 2500, d, d, "relu", seed=6, use_edge_weight=True)

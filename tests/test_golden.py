@@ -56,7 +56,7 @@ def test_oracle_regenerates_golden(tmp_path):
 
 # ---- torch float64 transcription of the reference semantics (autograd supplies every gradient) ----------------------------
 
-T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+T = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=torch.float64)
 
 ACT = {"identity": lambda z: z, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
        "swish": lambda z: z * torch.sigmoid(z)}
@@ -191,11 +191,18 @@ def test_autograd_transcription_matches_golden(case):
     meta, d = load(case)
     P = Params(d)
     x = T(d["x"]).requires_grad_(True)
+    ew = None
+    if "d.edge_weight" in d:           # the edge_weight ARGUMENT of GCNConv is a differentiable input (src/layers.jl:206-231)
+        ew = T(d["g.edge_weight"]).clone().requires_grad_(True)
+        d = dict(d)
+        d["g.edge_weight"] = ew
     y = FWD[meta["layer"]](meta, d, P, x)
     np.testing.assert_allclose(y.detach().numpy(), d["y"], rtol=1e-10, atol=1e-12, err_msg=case + ": y")
     (y * T(d["R"])).sum().backward()
     np.testing.assert_allclose(x.grad.numpy(), d["d.x"], rtol=1e-9, atol=1e-11, err_msg=case + ": dx")
-    stored = {k for k in d if k.startswith("d.") and k != "d.x"}
+    if ew is not None:
+        np.testing.assert_allclose(ew.grad.numpy(), d["d.edge_weight"], rtol=1e-9, atol=1e-11, err_msg=case + ": d edge_weight")
+    stored = {k for k in d if k.startswith("d.") and k not in ("d.x", "d.edge_weight")}
     assert stored == {grad_key(k) for k in P.leaves}, case
     for k, leaf in P.leaves.items():
         np.testing.assert_allclose(leaf.grad.numpy(), d[grad_key(k)].reshape(leaf.shape), rtol=1e-9, atol=1e-11, err_msg=f"{case}: {k}")

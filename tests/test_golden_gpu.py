@@ -108,13 +108,17 @@ def test_layer_matches_golden(case):
     layer, ps, pairs = build(meta, d)
     _, st = ng.setup(0, layer)
     x = f32(d["x"]).to(DEV).requires_grad_(True)
+    ew = None
     if meta["layer"] == "gcn" and meta["weighted"]:
-        y, _ = layer(x, ps, st, f32(d["g.edge_weight"]))
+        ew = f32(d["g.edge_weight"]).to(DEV).requires_grad_(True)       # the edge_weight argument is differentiable (src/layers.jl:206-231)
+        y, _ = layer(x, ps, st, ew)
     else:
         y, _ = layer(x, ps, st)
     close(y, d["y"], rtol=1e-4, what=case + ": y")
     y.backward(f32(d["R"]).to(DEV))
     close(x.grad, d["d.x"], rtol=2e-4, what=case + ": dx")
+    if ew is not None:
+        close(ew.grad, d["d.edge_weight"], rtol=2e-4, what=case + ": d edge_weight")
     for tensor, key in pairs:
         close(tensor.grad, d[key], rtol=2e-4, what=f"{case}: {key}")
 

@@ -41,7 +41,10 @@ def run(name, layer, x, ps, st, reps, extra):
     with torch.no_grad():
         y0 = fwd()
     R = colmajor(y0.shape[0], y0.shape[1])          # cotangent in the same layout as the output
+    leaves = [x] + grad_leaves(ps)
     def fb():
+        for v in leaves:
+            v.grad = None                               # gradients are written, not accumulated (no torch adds in the trace)
         y = layer(x, ps, st)[0]
         y.backward(R)
     with torch.no_grad():
@@ -60,36 +63,21 @@ def c3(reps):
 
 
 def c4(reps, traj, act="swish"):
-    n, h = 8192, 64
-    idx = np.arange(n)
-    s = np.concatenate([idx for k in (-3, -2, -1, 1, 2, 3)])
-    t = np.concatenate([(idx + k) % n for k in (-3, -2, -1, 1, 2, 3)])
-    S_, T_ = np.concatenate([s + i * n for i in range(traj)]), np.concatenate([t + i * n for i in range(traj)])
-    N = n * traj
-    rng = np.random.default_rng(4)
-    g = ng.GNNGraph(S_, T_, num_nodes=N, index_base=0, num_graphs=traj,
-                    ndata={"u": torch.rand(1, N), "x": torch.as_tensor(np.tile(idx / n, traj)[None, :].astype(np.float32))},
-                    gdata={"θ": torch.rand(2, traj)})
-    phi = ng.Chain(ng.Dense(132, 64, act), ng.Dense(64, 64, act))
-    psi = ng.Chain(ng.Dense(130, 64, act), ng.Dense(64, 64))
-    l = ng.MPPDEConv(phi, psi, initialgraph=g)
-    ps, st = ng.setup(4, l)
-    run(f"C4 MPPDEConv h=64, {traj} trajectories x 8192-node periodic mesh (6 neighbours)", l,
-        colmajor(h, N), ps, st, reps, dict(nodes=N, edges=int(S_.size), trajectories=traj))
+    # the bench line's own workload builder (bench.py: c4_layer), so that profiles and `secondary` run the same graph and data
+    import bench as B
+    if act != "swish":
+        raise SystemExit("bench.c4_layer is the configured (swish) layer")
+    l, ps, st, x, n_edges = B.c4_layer(DEV, traj, 0)
+    run(f"C4 MPPDEConv h=64, {traj} trajectories x 8192-node periodic mesh (6 neighbours)", l, x, ps, st, reps,
+        dict(nodes=8192 * traj, edges=n_edges, trajectories=traj))
 
 
 def c5(reps, width, radius):
-    gx, gy = np.meshgrid(np.linspace(0, 1, 64), np.linspace(0, 1, 64), indexing="ij")
-    pts = np.stack([gx.ravel(), gy.ravel()], 1)
-    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
-    s, t = np.nonzero((d2 <= radius * radius) & ~np.eye(4096, dtype=bool))
-    g = ng.GNNGraph(s, t, num_nodes=4096, index_base=0,
-                    ndata={"a": torch.rand(1, 4096), "x": torch.as_tensor(pts.T.astype(np.float32))})
-    phi = ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, width * width))
-    l = ng.GNOConv((width, width), phi, "relu", initialgraph=g)
-    ps, st = ng.setup(5, l)
-    run(f"C5 GNOConv {width}=>{width}, 64x64 grid radius {radius}", l, colmajor(width, 4096), ps, st, reps,
-        dict(nodes=4096, edges=int(s.size), kernel_tensor_GB=round(s.size * width * width * 4 / 1e9, 2)))
+    import bench as B
+    l, ps, st, x, n_edges = B.c5_layer(DEV, radius, width)          # synth.grid_radius_graph: the edges of bench.py's `secondary`
+    run(f"C5 GNOConv {width}=>{width}, 64x64 grid radius {radius}", l, x, ps, st, reps,
+        dict(nodes=4096, edges=n_edges, algorithmic_GFLOP_forward=round(B.c5_fwd_flop(n_edges, width) / 1e9, 2),
+             kernel_tensor_GB=round(n_edges * width * width * 4 / 1e9, 2)))
 
 
 if __name__ == "__main__":
