@@ -286,11 +286,19 @@ int main(int argc, char **argv) {
   const int poll_sleep = argc > 6 ? atoi(argv[6]) : 0, pollers = argc > 7 ? atoi(argv[7]) : 2;
   const size_t elems = (size_t)kTiles * kRows * kD;
   Params p{};
-  CK(hipMalloc(&p.buf[0], elems * 4));
-  CK(hipMalloc(&p.buf[1], elems * 4));
+  // FLOOR_MEM: how the flag lines (bit 0) and the exchanged arrays (bit 1) are allocated -- 0 / unset: hipMalloc; FLOOR_MEMKIND
+  // chooses the flavour for the selected ones: "fine" = hipDeviceMallocFinegrained, "uncached" = hipDeviceMallocUncached
+  const int mem_sel = getenv("FLOOR_MEM") ? atoi(getenv("FLOOR_MEM")) : 0;
+  const char *mem_kind = getenv("FLOOR_MEMKIND") ? getenv("FLOOR_MEMKIND") : "fine";
+  const unsigned mem_flag = (mem_kind[0] == 'u') ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+  auto alloc = [&](void **ptr, size_t bytes, bool special) -> hipError_t {
+    return special ? hipExtMallocWithFlags(ptr, bytes, mem_flag) : hipMalloc(ptr, bytes);
+  };
+  CK(alloc((void **)&p.buf[0], elems * 4, mem_sel & 2));
+  CK(alloc((void **)&p.buf[1], elems * 4, mem_sel & 2));
   CK(hipMalloc(&p.pbuf[0], elems * 8));
   CK(hipMalloc(&p.pbuf[1], elems * 8));
-  CK(hipMalloc(&p.flags, kTiles * 128));
+  CK(alloc((void **)&p.flags, kTiles * 128, mem_sel & 1));
   CK(hipMalloc(&p.shards, 8 * 128));
   CK(hipMalloc(&p.abort_word, 128));
   CK(hipMalloc(&p.errors, 128));
