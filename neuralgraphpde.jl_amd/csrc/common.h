@@ -163,6 +163,7 @@ int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-cap
 // ONE launch each, tiles synchronised by per-tile phase flags
 struct NodePersist {
   int n_tiles = 0;
+  int pair_wgs = 0;            // tile-pair mode: workgroups of a launch (each holds tiles t and t + pair_wgs), else 0
   int *nbr = nullptr;          // [n_tiles][64] wait lists, -1 padded
   unsigned *sync = nullptr;    // [2 n_tiles + 1] 128-byte lines: phase flag per tile for slot 0, for slot 1, then the abort word
   size_t sync_bytes = 0;
@@ -182,6 +183,7 @@ struct NodePersistFwd {
   float *ztape = nullptr;      // pre-activations (adjoint of an activation other than relu), same shape as tape
   size_t row_elems = 0, mask_bytes = 0;
   bool interleave = false;     // two members of a batch at a time per workgroup: bufA / bufB hold two [N][64] arrays each
+  bool pair = false;           // two TILES of the one member per workgroup (graphs of more tiles than co-resident workgroups)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 struct NodePersistBwd {
@@ -194,12 +196,14 @@ struct NodePersistBwd {
   size_t row_elems = 0, mask_bytes = 0;
   float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
   bool interleave = false;     // two members at a time: g1 / g2 hold two [N][64] arrays each, ubar = [2][5][N][64] scratch
+  bool pair = false;           // two tiles of the one member per workgroup (ubar = [5][N][64] scratch)
   float *ubar = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool node_persistent_interleave_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
-int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps);
+int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd);   // 0 none, 1 one tile per workgroup, 2 tile pairs
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps, bool pair = false);
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);

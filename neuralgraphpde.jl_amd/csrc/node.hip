@@ -124,6 +124,7 @@ struct ngpde_node {
   // a batch (members > 1) runs two members at a time per workgroup (node_persistent.hip, "slots"): the exchanged arrays
   // (ustage, pbuf, g1, g2) hold one [N][d] array per slot, pubar is the adjoint's stage-adjoint scratch [2][5][N][d]
   bool interleave = false;
+  bool pair = false;         // ONE member, two tiles per workgroup (graphs of up to twice the co-resident tile count)
   float *pubar = nullptr;
 
   hipStream_t cap_stream = nullptr;
@@ -328,7 +329,7 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   if (p->with_bwd) {
     a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   }
-  a.interleave = p->interleave;
+  a.interleave = p->interleave; a.pair = p->pair;
   a.ev_start = ev0; a.ev_stop = ev1;
   return launch_node_fwd_persistent(a, stream);
 }
@@ -339,12 +340,12 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
-  a.interleave = p->interleave; a.ubar = p->pubar;
+  a.interleave = p->interleave; a.pair = p->pair; a.ubar = p->pubar;
   a.ev_start = ev0; a.ev_stop = ev1;
   int32_t st;
   if ((st = launch_node_bwd_persistent(a, stream))) return st;
   const int dd = p->d * p->d;
-  const int ns = p->persist.n_tiles;   // one slab per tile, each written once at the end of the launch
+  const int ns = p->pair ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
   if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
   if ((st = launch_reduce_slabs(p->slab_db1, ns, p->d, 0, p->db1, stream))) return st;
   if ((st = launch_reduce_slabs(p->slab_dw2, ns, dd, p->d / 16, p->dw2, stream))) return st;
@@ -444,8 +445,9 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   p->pre = fused_prescaled_supported(g, d) && std::getenv("NGPDE_NO_PRESCALE") == nullptr;
   // The persistent form (node_persistent.hip) is decided here, before the tape is sized: with an activation other than relu its
   // adjoint reads the pre-activations from a tape of its own layout.  (Interleaved batches: relu only.)
-  bool want_persist = p->pre && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1)) &&
-                      node_persistent_supported(g, d, act, p->with_bwd);
+  const int pmode = p->pre ? node_persistent_mode(g, d, act, p->with_bwd) : 0;
+  p->pair = pmode == 2 && members == 1 && (!p->with_bwd || p->mask_mode);
+  bool want_persist = (pmode == 1 && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1))) || p->pair;
   const int S = p->tb.S;
   int32_t st = NGPDE_OK;
   if (want_persist) {
@@ -466,11 +468,15 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
       for (int j = i + 1; j < S; ++j) coef[48 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
       coef[84 + i] = (float)(dt * tb.a[i][i - 1]);
     }
-    st = node_persistent_setup(g, coef, &p->persist);
-    if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave: keep the replayed plan
+    st = node_persistent_setup(g, coef, &p->persist, p->pair);
+    if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave (or neighbouring tile pairs): the replayed plan
       st = NGPDE_OK;
       p->persist_fwd = p->persist_bwd = false;
     }
+    if (p->pair && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd))) {   // tile pairs: both directions or none
+      p->persist_fwd = p->persist_bwd = false;
+    }
+    if (!p->persist_fwd) p->pair = false;
   }
   // activations other than relu: the persistent pair needs BOTH directions persistent (the tapes' layouts differ from the replayed plan's)
   if (p->with_bwd && !p->mask_mode && !(p->persist_fwd && p->persist_bwd)) p->persist_fwd = p->persist_bwd = false;
@@ -501,7 +507,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   }
   if (p->with_bwd) {
     A(&p->lam, p->all_elems); A(&p->g1, xslots * p->row_elems); A(&p->g2, xslots * p->row_elems);
-    if (p->interleave) A(&p->pubar, 2 * 5 * p->row_elems);
+    if (p->interleave || p->pair) A(&p->pubar, 2 * 5 * p->row_elems);
     p->ubar.assign(S, nullptr);
     for (int j = 1; j < S; ++j) A(&p->ubar[j], p->row_elems);
     const size_t dd = (size_t)d * d;
@@ -556,7 +562,8 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
-           (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0);
+           (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
+           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0);
   return NGPDE_OK;
 }
 

@@ -130,13 +130,13 @@ struct TileMeta {
   NGPDE_PST_FIELD
 };
 
-__device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, float *lds_meta) {
+__device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, float *lds_meta, int tile = -1) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave_u = __builtin_amdgcn_readfirstlane(c.tid >> 6);
   c.grp = c.tid >> 4;
   c.q = c.tid & 15;
-  c.tile = xcd_tile(blockIdx.x, m.n_tiles);
+  c.tile = tile >= 0 ? tile : xcd_tile(blockIdx.x, m.n_tiles);
   const size_t pos = (size_t)c.tile * kTM + c.grp;
   const int4 sc = m.sched[pos];
   c.valid = sc.x >= 0;
@@ -373,6 +373,7 @@ struct PFwdK {
   float *ztape;        // same shape as tape: the pre-activations, kept instead of the sign bits when the activation is not relu
   size_t row_elems, mask_bytes;
   size_t flag_stride;  // two-slot kernels: slot s uses bufA / bufB + s * row_elems and the flag words m.flags + s * flag_stride
+  int pair_wgs;        // tile-pair mode of the two-slot kernels (PAIR): the grid; workgroup b holds tiles t and t + pair_wgs of ONE member
   const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
                        // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
 };
@@ -502,15 +503,18 @@ struct FNext {          // the slot-phase after this one
   const unsigned *flags;
 };
 
-template <int ACT, bool TAPE>
-__device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c, FSlot &S, FSlot &Snext, const int sl, const int ph, const int n,
+// PAIR = false: the slots are the SAME tile of two members of a batch (c and cn are one context).  PAIR = true: the slots are two
+// TILES of one member -- a graph of more tiles than co-resident workgroups (up to twice as many) -- with their own contexts; the
+// exchanged arrays and the flag array are then common to both slots.
+template <int ACT, bool TAPE, bool PAIR>
+__device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c, const TileCtx &cn, FSlot &S, FSlot &Snext, const int sl, const int ph, const int n,
                                                const int i, const int layer, const float *X, const size_t ev0, const int act,
                                                const unsigned own, bool &pre, int &n_ahead, unsigned *&pend_flags, int &pend_ph, const FNext nx,
                                                float *ldsXh, float *ldsT, float *ldsZ, const float *ldsW, const float *ldsBias,
                                                const float *ldsC, int *s_ok, int *s_pre) {
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
-  float *bufA = p.bufA + (size_t)sl * p.row_elems, *bufB = p.bufB + (size_t)sl * p.row_elems;
-  unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+  float *bufA = p.bufA + (PAIR ? 0 : (size_t)sl * p.row_elems), *bufB = p.bufB + (PAIR ? 0 : (size_t)sl * p.row_elems);
+  unsigned *flags = p.m.flags + (PAIR ? 0 : (size_t)sl * p.flag_stride);
   NGPDE_PST(p.m, ph, 0);
   // T0
   wait_vmcnt0();
@@ -518,7 +522,7 @@ __device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c,
   unsigned sw[8];
   tile_slot_words(c, sw);
   n_ahead += pre ? 1 : 0;
-  if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   pend_flags = nullptr;
   if (!pre) {
     Xh4[c.grp * PG::LPR + c.q] = S.xown;   // (behind the barrier: nobody is still aggregating from the halo region)
@@ -535,7 +539,7 @@ __device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c,
   // T2
   __syncthreads();
   unsigned f1 = 0;
-  if (nx.exists && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
+  if (nx.exists && c.wave_u == 0) f1 = poll_issue(p.m, cn, nx.flags);
   NGPDE_PST(p.m, ph, 3);
   // T3
   mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, c.wave_u, c.lane);
@@ -554,7 +558,7 @@ __device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c,
   const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), reinterpret_cast<const float4 *>(ldsBias)[c.q]);
   const float cself = ldsC[36 + i], cf0 = ldsC[i * 6 + 0], cf1 = ldsC[i * 6 + 1], cf2 = ldsC[i * 6 + 2], cf3 = ldsC[i * 6 + 3],
               cf4 = ldsC[i * 6 + 4];
-  if (pre) halo_fill_ahead(c, nx.X, ldsXh, Snext.xown);
+  if (pre) halo_fill_ahead(cn, nx.X, ldsXh, Snext.xown);
   const uint8_t sign_bits = (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
   const float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());
   float4 v = f4_zero();
@@ -576,21 +580,24 @@ __device__ __forceinline__ bool fwd_slot_phase(const PFwdK &p, const TileCtx &c,
     S.xown = v;
   }
   NGPDE_PST(p.m, ph, 5);
-  pend_flags = flags;     // published at the next T0 (or behind the loops)
+  pend_flags = flags + 32 * c.tile;     // published at the next T0 (or behind the loops)
   pend_ph = ph;
   if (TAPE) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
   NGPDE_PST(p.m, ph, 6);
   return true;
 }
 
-template <int ACT, bool TAPE>
+template <int ACT, bool TAPE, bool PAIR>
 __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + kMetaF + 48 + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + (PAIR ? 2 : 1) * kMetaF + 48 + 4];
   float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = ldsW1 + kWF, *ldsB = ldsW2 + kWF;
-  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + (PAIR ? 2 : 1) * kMetaF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
-  TileCtx c;
-  tile_ctx_init(p.m, c, ldsMeta);
+  TileCtx c, c1s;
+  tile_ctx_init(p.m, c, ldsMeta, PAIR ? xcd_tile(blockIdx.x, p.pair_wgs) : -1);
+  const bool has1 = !PAIR || c.tile + p.pair_wgs < p.m.n_tiles;   // (PAIR: an odd tile count leaves the last workgroups one tile)
+  if (PAIR) tile_ctx_init(p.m, c1s, ldsMeta + kMetaF, has1 ? c.tile + p.pair_wgs : c.tile);
+  const TileCtx &c1 = PAIR ? c1s : c;
   if (c.tid < 42) ldsC[c.tid] = p.cf[c.tid];
   const int act = ACT >= 0 ? ACT : p.act;
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
@@ -601,6 +608,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1, *s_pre = 0;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+  const unsigned own1 = (unsigned)c1.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
   __syncthreads();
   bool ok = true;
   int ph = 0;   // both slots run the same phase numbers; the count runs on across the pairs
@@ -610,12 +618,14 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const
   int pend_ph = 0;
   const int NP = p.n_steps * p.S * 2;   // phases of one member
   for (int mb = 0; mb < p.n_members && ok; mb += 2) {
-    const bool two = mb + 1 < p.n_members;
-    const float *u_in0 = p.u_in + (size_t)mb * p.row_elems, *u_in1 = u_in0 + (two ? p.row_elems : 0);
-    const size_t ev00 = (size_t)mb * NP, ev01 = ev00 + NP;
+    const bool two = PAIR ? has1 : mb + 1 < p.n_members;
+    const float *u_in0 = p.u_in + (size_t)mb * p.row_elems, *u_in1 = u_in0 + ((two && !PAIR) ? p.row_elems : 0);
+    const size_t ev00 = (size_t)mb * NP, ev01 = PAIR ? ev00 : ev00 + NP;
+    const size_t boff1 = PAIR ? 0 : p.row_elems;            // slot 1's offset in the exchanged arrays
+    unsigned *flags1 = p.m.flags + (PAIR ? 0 : p.flag_stride);
     FSlot s0, s1;
     s0.u = f4_sel(c.valid, ld4_g(u_in0, own), f4_zero());
-    s1.u = f4_sel(c.valid && two, ld4_g(u_in1, own), f4_zero());
+    s1.u = f4_sel(c1.valid && two, ld4_g(u_in1, own1), f4_zero());
     s0.k0 = s0.k1 = s0.k2 = s0.k3 = s0.k4 = s0.k5 = f4_zero();
     s1.k0 = s1.k1 = s1.k2 = s1.k3 = s1.k4 = s1.k5 = f4_zero();
     s0.xown = s0.u;
@@ -628,30 +638,33 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent2_kernel(const
         const float *ldsW = layer == 0 ? ldsW1 : ldsW2, *ldsBias = layer == 0 ? ldsB : ldsB + PD;
         // the arrays the halo rows of this phase / of the next phase come from, per slot
         const float *X0 = layer == 0 ? (P == 0 ? u_in0 : p.bufA) : p.bufB;
-        const float *X1 = layer == 0 ? (P == 0 ? u_in1 : p.bufA + p.row_elems) : p.bufB + p.row_elems;
+        const float *X1 = layer == 0 ? (P == 0 ? u_in1 : p.bufA + boff1) : p.bufB + boff1;
         FNext nx0, nx1;   // after (phase, slot 0): (phase, slot 1) if there are two slots; after (phase, slot 1): (phase + 1, slot 0)
-        nx0.exists = two; nx0.ph = ph; nx0.X = X1; nx0.flags = p.m.flags + p.flag_stride;
+        nx0.exists = two; nx0.ph = ph; nx0.X = X1; nx0.flags = flags1;
         nx1.exists = P + layer + 1 < NP; nx1.ph = ph + 1; nx1.X = layer == 0 ? p.bufB : p.bufA; nx1.flags = p.m.flags;
-        if (!fwd_slot_phase<ACT, TAPE>(p, c, s0, s1, 0, ph, n, i, layer, X0, ev00, act, own, pre, n_ahead, pend_flags, pend_ph, nx0, ldsXh, ldsT, ldsZ, ldsW,
-                                       ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
-        if (two && !fwd_slot_phase<ACT, TAPE>(p, c, s1, s0, 1, ph, n, i, layer, X1, ev01, act, own, pre, n_ahead, pend_flags, pend_ph, nx1, ldsXh, ldsT, ldsZ,
-                                              ldsW, ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
+        if (!fwd_slot_phase<ACT, TAPE, PAIR>(p, c, c1, s0, s1, 0, ph, n, i, layer, X0, ev00, act, own, pre, n_ahead, pend_flags, pend_ph, nx0, ldsXh,
+                                             ldsT, ldsZ, ldsW, ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
+        if (two && !fwd_slot_phase<ACT, TAPE, PAIR>(p, c1, c, s1, s0, 1, ph, n, i, layer, X1, ev01, act, own1, pre, n_ahead, pend_flags, pend_ph, nx1,
+                                                    ldsXh, ldsT, ldsZ, ldsW, ldsBias, ldsC, s_ok, s_pre)) { ok = false; break; }
       }
       if (++i == p.S) i = 0, ++n;
     }
     // the last slot-phase's flag (the next pair's first phases wait for it; nothing was gathered ahead: pre is false here)
     wait_vmcnt0();
     __syncthreads();
-    if (ok && pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok && pend_flags && c.tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_flags = nullptr;
     // (a tile writes its rows of u(T) only after all readers of its u0 rows are past that member's first phase)
-    if (c.valid) {
-      st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_sel(ok, s0.u, f4_nan()));
-      if (two) st4_g(p.u_out + (size_t)(mb + 1) * p.row_elems, own, f4_sel(ok, s1.u, f4_nan()));
+    if (c.valid) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_sel(ok, s0.u, f4_nan()));
+    if (two && c1.valid) st4_g(p.u_out + (PAIR ? 0 : (size_t)(mb + 1) * p.row_elems), own1, f4_sel(ok, s1.u, f4_nan()));
+    if (PAIR) break;   // one member
+  }
+  if (!ok) {   // an aborted solve poisons every member's output
+    for (int mb = 0; mb < p.n_members; ++mb) {
+      if (c.valid) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_nan());
+      if (PAIR && has1 && c1.valid) st4_g(p.u_out + (size_t)mb * p.row_elems, own1, f4_nan());
     }
   }
-  if (!ok && c.valid)   // an aborted solve poisons every member's output
-    for (int mb = 0; mb < p.n_members; ++mb) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_nan());
   if (c.tid == 0 && p.m.stats) p.m.stats[2 * c.tile] = n_ahead;
 }
 
@@ -669,6 +682,7 @@ struct PBwdK {
   const uint8_t *masks;
   size_t row_elems, mask_bytes;
   float *slab_dw1, *slab_db1, *slab_dw2, *slab_db2;   // [n_tiles][...] written ONCE, at the end
+  int pair_wgs;        // tile-pair mode (PAIR): the grid; workgroup b holds tiles t and t + pair_wgs of ONE member
   size_t flag_stride;  // two-slot kernel: slot s uses g1 / g2 + s * row_elems, the flag words m.flags + s * flag_stride and
   float *ubar;         // the stage-adjoint scratch ubar + s * 5 * row_elems ([slot][5][N][64])
   const float *cb;     // device table [6 + 36 + 6], copied to LDS: cb[j] = dt * b[j]; cb[6 + i * 6 + j], j > i >= 1: dt * a[j][i-1], the
@@ -876,13 +890,20 @@ struct BNext {          // the slot-phase after this one (see fwd_slot_phase): w
   size_t ev;
 };
 
+// PAIR: the slots are two TILES of one member (see fwd_slot_phase); a look at the next slot-phase's flags then never blocks -- with
+// cross-slot neighbours a workgroup spinning for a flag that its neighbour publishes only behind ITS spin would be a cycle -- and
+// a miss takes the blocking path at the next T0, which publishes what is pending first.
+template <bool PAIR>
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const PBwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + kMetaF + 48 + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + (PAIR ? 2 : 1) * kMetaF + 48 + 4];
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
-  float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + (PAIR ? 2 : 1) * kMetaF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
-  TileCtx c;
-  tile_ctx_init(p.m, c, ldsMeta);
+  TileCtx c, c1s;
+  tile_ctx_init(p.m, c, ldsMeta, PAIR ? xcd_tile(blockIdx.x, p.pair_wgs) : -1);
+  const bool has1 = !PAIR || c.tile + p.pair_wgs < p.m.n_tiles;
+  if (PAIR) tile_ctx_init(p.m, c1s, ldsMeta + kMetaF, has1 ? c.tile + p.pair_wgs : c.tile);
+  const TileCtx &c1 = PAIR ? c1s : c;
   if (c.tid < 48) ldsC[c.tid] = p.cb[c.tid];
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
   load_weight_lds(p.w1, ldsW1, c.tid, false);
@@ -890,6 +911,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1, *s_pre = 0;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+  const unsigned own1 = (unsigned)c1.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
   constexpr int NT = PG::CT * PG::CT;
   f32x4 dw1[PG::DWT], dw2[PG::DWT];
 #pragma unroll
@@ -913,7 +935,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   auto t0_publish = [&]() {
     wait_vmcnt0();
     __syncthreads();
-    if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags + 32 * c.tile, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pend_flags && c.tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_flags = nullptr;
   };
 
@@ -950,8 +972,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   // the dense half of a slot-phase (T1's tail .. T5): dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the
   // next gather (not drained: the flag goes out at the next T0), dW += A^T dZ, db += column sums; the next slot-phase's flags are
   // looked at under the matrix products and, if they are all there, its halo rows go out before the row stores
-  auto dense = [&](unsigned *flags, int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar,
-                   unsigned mk, float4 xrow, float *gout, const BNext &nx) {
+  // (c, own: this slot's tile; cn, ownn: the next slot-phase's)
+  auto dense = [&](const TileCtx &c, const TileCtx &cn, unsigned own, unsigned ownn, unsigned *flags, int ph, const float *ldsW,
+                   f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, unsigned mk, float4 xrow, float *gout, const BNext &nx) {
     kbar = f4_scale(c.ci, kbar);
     const float4 dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f,
                                             (mk & 8u) ? kbar.w : 0.f)
@@ -960,8 +983,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
     __syncthreads();   // T2
     if (nx.tape) {     // the next slot-phase's tape row and sign bits: a slot-phase ahead, so that they are there at its T0
-      pf_mk = ldu8_g(p.masks + nx.ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
-      pf_x = ld4_stream_g(p.tape + nx.ev * p.row_elems, own);
+      pf_mk = ldu8_g(p.masks + nx.ev * p.mask_bytes + (size_t)cn.tile * kThreads, (unsigned)c.tid);
+      pf_x = ld4_stream_g(p.tape + nx.ev * p.row_elems, ownn);
     }
     NGPDE_PST(p.m, ph, 3);
     // T3: both matrix products of the phase back to back (no barrier between them: they read the same operand tiles and write
@@ -969,29 +992,38 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
     // slot-phase's flags between the two -- as late as it can be done with the answer still there when the products end
     mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
     unsigned f1 = 0;
-    if (nx.gather && c.wave_u == 0) f1 = poll_issue(p.m, c, nx.flags);
+    if (nx.gather && c.wave_u == 0) f1 = poll_issue(p.m, cn, nx.flags);
     dw_products(ldsX, ldsDZ, dwl, dbl);
-    // T4: the next slot-phase's flags (wave 0 spins if this workgroup leads its neighbours; see tile_wait_primed), the barrier
-    if (nx.gather) {   // uniform
-      if (!tile_wait_primed(p.m, c, nx.ph, s_ok, nx.flags, f1)) { dead = true; return; }
+    // T4: the next slot-phase's flags (members: wave 0 spins if this workgroup leads its neighbours, see tile_wait_primed; tile
+    // pairs: one look, see the kernel's head), the barrier
+    if (nx.gather && !PAIR) {   // uniform
+      if (!tile_wait_primed(p.m, cn, nx.ph, s_ok, nx.flags, f1)) { dead = true; return; }
+      pre = true;
+    } else if (nx.gather) {
+      if (c.wave_u == 0) {
+        const bool hit = poll_ready(cn, f1, nx.ph);
+        if (c.lane == 0) *s_pre = hit ? 1 : 0;
+      }
+      __syncthreads();
+      pre = *s_pre != 0;
     } else {
       __syncthreads();
+      pre = false;
     }
     NGPDE_PST(p.m, ph, 4);
     const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
-    pre = nx.gather;
     if (pre) {   // uniform
       __syncthreads();   // every thread has read its row of G: the region is the halo again
-      halo_fill_all(c, nx.X, ldsXh);
+      halo_fill_all(cn, nx.X, ldsXh);
     }
     if (c.valid) store_sc1(gout, own, gv);
     NGPDE_PST(p.m, ph, 5);
-    pend_flags = flags;
+    pend_flags = flags + 32 * c.tile;
     pend_ph = ph;
   };
 
   // the gathering half: T0, then (unless the rows were gathered ahead) own rows + blocking wait + gather
-  auto top = [&](const unsigned *flags, int ph, const float *X) -> bool {
+  auto top = [&](const TileCtx &c, const unsigned *flags, int ph, const float *X) -> bool {
     t0_publish();
     n_ahead += pre ? 1 : 0;
     if (!pre) {
@@ -1006,28 +1038,29 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   };
 
   // layer 1 of stage i of one slot: dL/dy1 = A^T g2
-  auto phase_l1 = [&](int sl, int ph, const BNext &nx) -> bool {
-    float *g1 = p.g1 + (size_t)sl * p.row_elems, *g2 = p.g2 + (size_t)sl * p.row_elems;
-    unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+  auto phase_l1 = [&](const TileCtx &c, const TileCtx &cn, unsigned own, unsigned ownn, int sl, int ph, const BNext &nx) -> bool {
+    float *g1 = p.g1 + (PAIR ? 0 : (size_t)sl * p.row_elems), *g2 = p.g2 + (PAIR ? 0 : (size_t)sl * p.row_elems);
+    unsigned *flags = p.m.flags + (PAIR ? 0 : (size_t)sl * p.flag_stride);
     NGPDE_PST(p.m, ph, 0);
     const unsigned mk = pf_mk;
     const float4 xrow = pf_x;
-    if (!top(flags, ph, g2)) return false;
+    if (!top(c, flags, ph, g2)) return false;
     const float4 t = tile_aggregate_lean(c, ldsXh);   // (the unrolled form with the slot words in registers: 24 spilled dwords)
-    dense(flags, ph, ldsW1, dw1, db1, t, mk, xrow, g1, nx);
+    dense(c, cn, own, ownn, flags, ph, ldsW1, dw1, db1, t, mk, xrow, g1, nx);
     return !dead;
   };
 
   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half.  `last`: the member's
   // final phase (no dense half, nothing published)
-  auto phase_l2 = [&](int sl, float *lam_g, int ph, int i, bool last, const BNext &nx) -> bool {
-    float *g1 = p.g1 + (size_t)sl * p.row_elems, *g2 = p.g2 + (size_t)sl * p.row_elems;
-    float *ubar = p.ubar + (size_t)sl * 5 * p.row_elems;
-    unsigned *flags = p.m.flags + (size_t)sl * p.flag_stride;
+  auto phase_l2 = [&](const TileCtx &c, const TileCtx &cn, unsigned own, unsigned ownn, int sl, float *lam_g, int ph, int i, bool last,
+                      const BNext &nx) -> bool {
+    float *g1 = p.g1 + (PAIR ? 0 : (size_t)sl * p.row_elems), *g2 = p.g2 + (PAIR ? 0 : (size_t)sl * p.row_elems);
+    float *ubar = p.ubar + (PAIR ? 0 : (size_t)sl * 5 * p.row_elems);   // (tile pairs: the rows of one member)
+    unsigned *flags = p.m.flags + (PAIR ? 0 : (size_t)sl * p.flag_stride);
     NGPDE_PST(p.m, ph, 0);
     const unsigned mk = pf_mk;
     const float4 xrow = pf_x;
-    if (!top(flags, ph, g1)) return false;
+    if (!top(c, flags, ph, g1)) return false;
     // the stage adjoints this combination needs: U-bar_j, j > i, of THIS step (j < S); everything else enters as an exact zero
     // (node_bwd_persistent_kernel keeps zeros / finished values with zero weights in those places).  ONE scalar base + 32-bit
     // offsets the optimiser cannot see through: five bases per slot ended up as 64-bit vector addresses hoisted out of the loops
@@ -1059,7 +1092,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
       if (c.valid) st4_g(lam_g, uo, v);   // lambda of the step before (the member's dL/du~0 at the end)
       kbar = f4_scale(ldsC[S - 1], v);
     }
-    if (!last) dense(flags, ph, ldsW2, dw2, db2, kbar, mk, xrow, g2, nx);
+    if (!last) dense(c, cn, own, ownn, flags, ph, ldsW2, dw2, db2, kbar, mk, xrow, g2, nx);
     else pre = false;
     return !dead;
   };
@@ -1068,10 +1101,11 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   int ph = 0;
   const size_t per = (size_t)p.n_steps * S * 2;   // tape events of one member
   for (int mb = 0; mb < p.n_members && ok; mb += 2) {
-    const bool two = mb + 1 < p.n_members;
-    float *lam_g0 = p.lam + (size_t)mb * p.row_elems, *lam_g1 = lam_g0 + (two ? p.row_elems : 0);
-    const size_t ev00 = (size_t)mb * per, ev01 = ev00 + per;
-    unsigned *flags0 = p.m.flags, *flags1 = p.m.flags + p.flag_stride;
+    const bool two = PAIR ? has1 : mb + 1 < p.n_members;
+    float *lam_g0 = p.lam + (size_t)mb * p.row_elems, *lam_g1 = lam_g0 + ((two && !PAIR) ? p.row_elems : 0);
+    const size_t ev00 = (size_t)mb * per, ev01 = PAIR ? ev00 : ev00 + per;
+    const size_t goff1 = PAIR ? 0 : p.row_elems;            // slot 1's offset in the exchanged arrays
+    unsigned *flags0 = p.m.flags, *flags1 = p.m.flags + (PAIR ? 0 : p.flag_stride);
     const size_t e1_first = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2;   // layer-1 event of the first stage the adjoint visits
     {   // first phase of a member: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather, no wait)
       ++ph;
@@ -1086,16 +1120,16 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
         // before this one's is published -- only its tape row is fetched)
         nx.gather = false; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !two; nx.ev = ev00 + e1_first;
         const float4 lam = f4_sel(c.valid, ld4_g(lam_g0, own), f4_zero());
-        dense(flags0, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, nx);
+        dense(c, two ? c1 : c, own, two ? own1 : own, flags0, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, nx);
         if (dead) ok = false;
       }
       if (two && ok) {
         t0_publish();
-        const unsigned mk = ldu8_g(p.masks + (ev01 + e) * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
-        const float4 xrow = ld4_stream_g(p.tape + (ev01 + e) * p.row_elems, own);
+        const unsigned mk = ldu8_g(p.masks + (ev01 + e) * p.mask_bytes + (size_t)c1.tile * kThreads, (unsigned)c.tid);
+        const float4 xrow = ld4_stream_g(p.tape + (ev01 + e) * p.row_elems, own1);
         nx.gather = true; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = true; nx.ev = ev00 + e1_first;
-        const float4 lam = f4_sel(c.valid, ld4_g(lam_g1, own), f4_zero());
-        dense(flags1, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2 + p.row_elems, nx);
+        const float4 lam = f4_sel(c1.valid, ld4_g(lam_g1, own1), f4_zero());
+        dense(c1, c, own1, own, flags1, ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2 + goff1, nx);
         if (dead) ok = false;
       }
     }
@@ -1108,30 +1142,35 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
         BNext nx;
         ++ph;   // layer 1
         // after (L1, slot 0): (L1, slot 1) or, with one slot, (L2, slot 0); after (L1, slot 1): (L2, slot 0)
-        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g2 + p.row_elems : p.g1; nx.flags = two ? flags1 : flags0;
+        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g2 + goff1 : p.g1; nx.flags = two ? flags1 : flags0;
         nx.tape = two ? true : !last; nx.ev = two ? ev01 + e1 : ev00 + e2;
-        if (!phase_l1(0, ph, nx)) { ok = false; break; }
+        if (!phase_l1(c, two ? c1 : c, own, two ? own1 : own, 0, ph, nx)) { ok = false; break; }
         if (two) {
           nx.gather = true; nx.ph = ph + 1; nx.X = p.g1; nx.flags = flags0; nx.tape = !last; nx.ev = ev00 + e2;
-          if (!phase_l1(1, ph, nx)) { ok = false; break; }
+          if (!phase_l1(c1, c, own1, own, 1, ph, nx)) { ok = false; break; }
         }
         ++ph;   // layer 2
         // after (L2, slot 0): (L2, slot 1) or, with one slot, the next stage's (L1, slot 0); after (L2, slot 1): the next (L1, slot 0)
-        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g1 + p.row_elems : p.g2; nx.flags = two ? flags1 : flags0;
+        nx.gather = two; nx.ph = two ? ph : ph + 1; nx.X = two ? p.g1 + goff1 : p.g2; nx.flags = two ? flags1 : flags0;
         nx.tape = two ? !last : !last; nx.ev = two ? ev01 + e2 : ev00 + e1n;
-        if (!phase_l2(0, lam_g0, ph, i, last, nx)) { ok = false; break; }
+        if (!phase_l2(c, two ? c1 : c, own, two ? own1 : own, 0, lam_g0, ph, i, last, nx)) { ok = false; break; }
         if (two) {
           nx.gather = !last; nx.ph = ph + 1; nx.X = p.g2; nx.flags = flags0; nx.tape = !last; nx.ev = ev00 + e1n;
-          if (!phase_l2(1, lam_g1, ph, i, last, nx)) { ok = false; break; }
+          if (!phase_l2(c1, c, own1, own, 1, lam_g1, ph, i, last, nx)) { ok = false; break; }
         }
       }
     }
     // the last published slot-phase's flag (the final phase of a member publishes nothing; the next pair's first phase publishes
     // ph + 1 and waits for nothing)
     t0_publish();
+    if (PAIR) break;   // one member
   }
-  if (!ok && c.valid)
-    for (int mb = 0; mb < p.n_members; ++mb) st4_g(p.lam + (size_t)mb * p.row_elems, own, f4_nan());
+  if (!ok) {
+    for (int mb = 0; mb < p.n_members; ++mb) {
+      if (c.valid) st4_g(p.lam + (size_t)mb * p.row_elems, own, f4_nan());
+      if (PAIR && has1 && c1.valid) st4_g(p.lam + (size_t)mb * p.row_elems, own1, f4_nan());
+    }
+  }
   const float bad = __int_as_float(0x7fc00000);
   auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
     float4 *slab4 = reinterpret_cast<float4 *>(slab_dw + (size_t)blockIdx.x * PD * PD);
@@ -1188,15 +1227,16 @@ static bool build_wait_lists(const ngpde_graph *g, std::vector<int> &out) {
   return true;
 }
 
-// can the plan run as two persistent launches?  (same conditions as the pre-scaled replayed plan, plus: d = 64, relu, unweighted,
-// one tile per workgroup with ALL workgroups co-resident)
-bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) {
-  if (node_persistent_disabled_env()) return false;
-  if (!g || d != PD || !fused_prescaled_supported(g, d)) return false;
-  if (g->by_t.slot_w || g->by_s.slot_w) return false;
+// Can the plan run as two persistent launches?  (same conditions as the pre-scaled replayed plan, plus: d = 64, unweighted, ALL
+// workgroups co-resident.)  0: no.  1: one tile per workgroup (graphs of at most CUs x occupancy tiles).  2: two tiles per
+// workgroup through the two-slot kernels (up to twice as many tiles; relu when a backward is asked for).
+int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd) {
+  if (node_persistent_disabled_env()) return 0;
+  if (!g || d != PD || !fused_prescaled_supported(g, d)) return 0;
+  if (g->by_t.slot_w || g->by_s.slot_w) return 0;
   int dev = 0, cus = 0, occ_f = 0, occ_b = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   // co-residency of the spin-waiting workgroups: the minimum over EVERY instantiation a plan of this kind can launch
   occ_f = occ_b = 1 << 30;
   auto take = [&](int &acc, auto kernel) {
@@ -1207,16 +1247,26 @@ bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_b
   take(occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, true>);
   take(occ_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, false>);
   take(occ_f, node_fwd_persistent_kernel<-1, false>);
-  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, true>);
-  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, false>);
-  take(occ_f, node_fwd_persistent2_kernel<-1, false>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, true, false>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, false, false>);
+  take(occ_f, node_fwd_persistent2_kernel<-1, false, false>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, true, true>);
+  take(occ_f, node_fwd_persistent2_kernel<NGPDE_ACT_RELU, false, true>);
+  take(occ_f, node_fwd_persistent2_kernel<-1, false, true>);
   take(occ_b, node_bwd_persistent_kernel<NGPDE_ACT_RELU>);
   take(occ_b, node_bwd_persistent_kernel<-1>);
   take(occ_f, node_fwd_persistent_kernel<-1, true>);
-  take(occ_b, node_bwd_persistent2_kernel);
-  const int nt = g->n_sched / kTileRows;
-  return nt >= 1 && nt <= cus * std::min(occ_f, occ_b);
+  take(occ_b, node_bwd_persistent2_kernel<false>);
+  take(occ_b, node_bwd_persistent2_kernel<true>);
+  const int nt = g->n_sched / kTileRows, resident = cus * std::min(occ_f, occ_b);
+  if (nt < 1) return 0;
+  if (nt <= resident) return 1;
+  const char *no_pairs = std::getenv("NGPDE_NO_TILE_PAIRS");
+  if (no_pairs && no_pairs[0] == '1') return 0;
+  if (nt <= 2 * resident && (!with_bwd || act == NGPDE_ACT_RELU)) return 2;
+  return 0;
 }
+bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) { return node_persistent_mode(g, d, act, with_bwd) == 1; }
 
 // NGPDE_NO_INTERLEAVE=1: a batch's members one after the other (the round-2 form) instead of two at a time -- the A/B switch and
 // the reference the interleaved kernels are compared with bit for bit
@@ -1225,11 +1275,23 @@ bool node_persistent_interleave_env() {
   return !(e && e[0] == '1');
 }
 
-int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps) {
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps, bool pair) {
   std::vector<int> lists;
   NGPDE_REQUIRE(build_wait_lists(g, lists), NGPDE_ERR_UNSUPPORTED, "persistent solver: a tile's wait list exceeds %d tiles", kNbrStride);
   const int nt = g->n_sched / kTileRows;
   ps->n_tiles = nt;
+  ps->pair_wgs = 0;
+  if (pair) {
+    // workgroup b holds tiles t = xcd_tile(b, W) and t + W (W = ceil(nt / 2)): half a schedule apart, so never neighbours on a
+    // graph with any locality -- but it is checked: a tile waiting for its own workgroup's other tile would wait for a flag that is
+    // published only after the wait
+    const int W = (nt + 1) / 2;
+    for (int t = 0; t + W < nt; ++t)
+      for (int k = 0; k < kNbrStride; ++k)
+        NGPDE_REQUIRE(lists[(size_t)t * kNbrStride + k] != t + W, NGPDE_ERR_UNSUPPORTED,
+                      "persistent solver: tiles %d and %d of one workgroup are neighbours", t, t + W);
+    ps->pair_wgs = W;
+  }
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->nbr, lists.size() * sizeof(int)));
   NGPDE_HIP_CHECK(hipMemcpy(ps->nbr, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
   // flag words: one 128-byte line per tile and slot (two slots: the interleaved kernels), + one line for the abort word; zeroed
@@ -1330,12 +1392,17 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   k.w1 = a.w1; k.b1 = a.b1; k.w2 = a.w2; k.b2 = a.b2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
   k.flag_stride = (size_t)ps.n_tiles * 32;
+  k.pair_wgs = a.pair ? ps.pair_wgs : 0;
   k.cf = ps.coef;
-  const dim3 grid(ps.n_tiles), block(kThreads);
+  NGPDE_REQUIRE(!a.pair || (ps.pair_wgs > 0 && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE, "tile-pair launch without its setup");
+  const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
-  if (a.interleave) {                                                                                                        \
-    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-    else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT>), grid, block, 0, stream, k);                                \
+  if (a.pair) {                                                                                                              \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, true>), grid, block, 0, stream, k);                          \
+  } else if (a.interleave) {                                                                                                 \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, k);                         \
   } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
   else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
   k.ztape = a.ztape;
@@ -1343,7 +1410,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     NGPDE_REQUIRE(a.masks != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a relu tape needs the sign-bit masks");
     NGPDE_PF_LAUNCH(NGPDE_ACT_RELU, true)
   } else if (a.tape) {
-    NGPDE_REQUIRE(a.ztape != nullptr && !a.interleave, NGPDE_ERR_INVALID_ARGUMENT,
+    NGPDE_REQUIRE(a.ztape != nullptr && !a.interleave && !a.pair, NGPDE_ERR_INVALID_ARGUMENT,
                   "persistent forward with a tape: activations other than relu keep the pre-activations (one member at a time)");
     NGPDE_PF_LAUNCH(-1, true)
   } else if (a.act == NGPDE_ACT_RELU) {
@@ -1373,12 +1440,19 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   k.slab_dw1 = a.slab_dw1; k.slab_db1 = a.slab_db1; k.slab_dw2 = a.slab_dw2; k.slab_db2 = a.slab_db2;
   k.cb = ps.coef + 42;
   k.flag_stride = (size_t)ps.n_tiles * 32;
+  k.pair_wgs = a.pair ? ps.pair_wgs : 0;
   k.ubar = a.ubar;
-  const dim3 grid(ps.n_tiles), block(kThreads);
-  if (a.interleave) {
+  NGPDE_REQUIRE(!a.pair || (ps.pair_wgs > 0 && !a.interleave && a.n_members == 1 && a.act == NGPDE_ACT_RELU), NGPDE_ERR_STATE,
+                "tile-pair launch without its setup");
+  const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
+  if (a.pair) {
+    NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "tile-pair persistent adjoint without its stage-adjoint scratch");
+    if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel<true>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+    else hipLaunchKernelGGL(node_bwd_persistent2_kernel<true>, grid, block, 0, stream, k);
+  } else if (a.interleave) {
     NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "interleaved persistent adjoint without its stage-adjoint scratch");
-    if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
-    else hipLaunchKernelGGL(node_bwd_persistent2_kernel, grid, block, 0, stream, k);
+    if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel<false>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+    else hipLaunchKernelGGL(node_bwd_persistent2_kernel<false>, grid, block, 0, stream, k);
   } else if (a.act != NGPDE_ACT_RELU) {
     NGPDE_REQUIRE(a.ztape != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
     if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel<-1>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);

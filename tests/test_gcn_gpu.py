@@ -714,3 +714,56 @@ def test_node_batch_interleaved_members_equal_member_by_member_bitwise(K, N, tab
                                               O.TABLEAUS[tab], dt, nsteps)
         close(a[0][:, sl], uTo, rtol=2e-4, what=f"u(T) member {m}")
         close(a[1][:, sl], du0o, rtol=5e-4, atol=1e-4, what=f"du0 member {m}")
+
+
+@pytest.mark.parametrize("N,tab,nsteps", [(32768, "tsit5", 2), (20000, "euler", 3), (16416, "tsit5", 2)])
+def test_node_persistent_tile_pairs_beyond_512_tiles(N, tab, nsteps, monkeypatch):
+    # graphs of more 32-row tiles than co-resident workgroups (512 on the MI355X: 16 384 nodes) and at most twice as many: the
+    # two-slot kernels with the slots = two TILES of the one trajectory (workgroup b holds tiles t and t + W).  u(T) and du0 bit
+    # for bit equal to the replayed plan, everything against the float64 oracle; 20 000 nodes = 625 tiles (the last workgroup has
+    # one tile), 16 416 = 513 tiles (one workgroup has two)
+    needs_persistent_plan(monkeypatch)
+    d, dt = 64, 0.05
+    g, og, params = spatial_case(N, 4 * N, d, seed=N % 1000)
+    rng = np.random.default_rng(N)
+    u0n, Rn = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+    outs = {}
+    for mode in ("pairs", "replayed"):
+        if mode == "replayed":
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+        node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = torch.as_tensor(u0n.astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        plan = next(iter(node._plans.values()))[0]
+        if mode == "pairs":
+            assert {"persistent_fwd", "persistent_bwd", "tile_pairs"} <= plan.flags(), plan.flags()
+        else:
+            assert "persistent_fwd" not in plan.flags()
+        (uT * torch.as_tensor(Rn.astype(np.float32), device=DEV)).sum().backward()
+        assert not plan.fault()
+        outs[mode] = [uT.detach().clone(), u.grad.clone()] + [ps[l][k].grad.clone() for l in ("layer_1", "layer_2") for k in ("weight", "bias")]
+        with torch.no_grad():                       # the forward-only plan
+            uT2, _ = node(u.detach(), ps, st)
+        assert torch.equal(uT2, outs[mode][0])
+    a, b = outs["pairs"], outs["replayed"]
+    assert torch.equal(a[0], b[0]), "u(T)"
+    assert torch.equal(a[1], b[1]), "du0"
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-5 * float(y.abs().max()))
+    uTo, du0o, acc = _oracle_node_with_seed(params, og, u0n, Rn, O.TABLEAUS[tab], dt, nsteps)
+    close(a[0], uTo, rtol=2e-4, what="u(T)")
+    close(a[1], du0o, rtol=5e-4, atol=1e-4, what="du0")
+    # (relu'(z) is decided by rounding where |z| is within an ulp of zero -- one or two of the 10^8 pre-activations of these solves;
+    # each such kink moves a row of dW by |a_n| |K-bar| ~ 5e-2, in the oracle's float64 as much as here: the tight statement about
+    # the parameter gradients is the comparison with the replayed plan above)
+    for k in range(2):
+        close(a[2 + 2 * k], acc[k]["weight"], rtol=5e-3, atol=1e-3, what=f"dW{k + 1}")
