@@ -1,5 +1,7 @@
-"""Race screen for the solver plan's kernels (LDS-DMA staging, paired workgroups): replays the 50-step C2 solve + adjoint many
-times and requires every output to be bit-identical to the first run.  usage: python tools/soak_replay.py [replays]"""
+"""Race screen for the solver plan's kernels (LDS-DMA staging, paired workgroups, the flag hand-off of the persistent launches):
+replays the 50-step C2 solve + adjoint many times and requires every output to be bit-identical to the first run.
+usage: [N=16384] [MEMBERS=1] python tools/soak_replay.py [replays]     (MEMBERS > 1: the interleaved batch kernels; N > 16384: the
+tile-pair kernels)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,17 +10,18 @@ import ngpde_amd as ng
 from ngpde_amd import _lib, synth as S
 from ngpde_amd.node import _Plan
 lib = _lib.load()
-N, PAIRS, D = 16384, 65536, 64
+N, D, MEMBERS = int(os.environ.get("N", 16384)), 64, int(os.environ.get("MEMBERS", 1))
+PAIRS = 4 * N
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 _, s, t = S.closest_pairs_graph(N, PAIRS, seed=2)
 g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
-plan = _Plan(g.handle((True, None, False)), D, 1, "tsit5", 50, 0.02, True)
+plan = _Plan(g.handle((True, None, False)), D, 1, "tsit5", 50, 0.02, True, members=MEMBERS)
 print("plan flags:", plan.flags())
 dev = "cuda"
 torch.manual_seed(0)
-u0 = torch.randn(N, D, device=dev); w1 = torch.randn(D, D, device=dev) * 0.1; w2 = torch.randn(D, D, device=dev) * 0.1
+u0 = torch.randn(N * MEMBERS, D, device=dev); w1 = torch.randn(D, D, device=dev) * 0.1; w2 = torch.randn(D, D, device=dev) * 0.1
 b1 = torch.randn(D, device=dev) * 0.1; b2 = torch.randn(D, device=dev) * 0.1
-seed = torch.randn(N, D, device=dev)
+seed = torch.randn(N * MEMBERS, D, device=dev)
 st = torch.cuda.current_stream().cuda_stream; p = _lib.ptr
 first, bad = None, 0
 for r in range(reps):
@@ -30,5 +33,5 @@ for r in range(reps):
         first = [o.clone() for o in outs]
     elif not all(torch.equal(a, b) for a, b in zip(first, outs)):
         bad += 1
-print(f"{reps} replays, {reps * 1205} launches, {bad} replays differing from the first")
+print(f"N={N} members={MEMBERS}: {reps} replays, {bad} replays differing from the first; fault={plan.fault()}")
 sys.exit(1 if bad else 0)
