@@ -167,7 +167,8 @@ struct NodePersist {
   int *nbr = nullptr;          // [n_tiles][64] wait lists, -1 padded
   unsigned *sync = nullptr;    // [2 n_tiles + 1] 128-byte lines: phase flag per tile for slot 0, for slot 1, then the abort word
   size_t sync_bytes = 0;
-  unsigned *fault = nullptr;   // sticky: some persistent launch of this plan gave up waiting
+  unsigned *fault = nullptr;   // sticky: some persistent launch of this plan gave up waiting (device pointer of fault_host)
+  volatile unsigned *fault_host = nullptr;   // the same word in pinned host memory: readable without a synchronisation
   int *stats = nullptr;        // [n_tiles][2]: slot-phases of the last forward / adjoint launch gathered ahead of time (interleaved kernels)
   float *coef = nullptr;       // device tables indexed by the stage: forward [42], adjoint [48] (layout: node.hip)
 };

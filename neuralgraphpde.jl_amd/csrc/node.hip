@@ -571,11 +571,9 @@ int32_t ngpde_node_fault(ngpde_node_t *p, ngpde_stream_t stream_, int32_t *fault
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_fault: NULL argument");
   *fault = 0;
-  if (!p->persist.fault) return NGPDE_OK;
-  unsigned f = 0;
-  NGPDE_HIP_CHECK(hipMemcpyAsync(&f, p->persist.fault, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+  if (!p->persist.fault_host) return NGPDE_OK;
   NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
-  *fault = f ? 1 : 0;
+  *fault = *p->persist.fault_host ? 1 : 0;
   return NGPDE_OK;
 }
 
@@ -604,6 +602,10 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: plan is NULL");
   NGPDE_REQUIRE(u0 && w1 && w2 && uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_forward: NULL argument");
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_gcn2_forward: an earlier persistent launch of this plan gave up waiting for its neighbours (its outputs are NaN): "
+                "another kernel held the device's compute units, or two persistent solves of different processes shared the device; "
+                "create a new plan (NGPDE_NO_PERSISTENT=1 selects the replayed plan)");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
   if (p->pre) {
@@ -665,6 +667,9 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: plan was created without backward");
   NGPDE_REQUIRE(p->forward_done, NGPDE_ERR_STATE, "ngpde_node_gcn2_backward: forward has not been run");
   NGPDE_REQUIRE(duT != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_backward: duT is NULL");
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_gcn2_backward: a persistent launch of this plan gave up waiting for its neighbours (outputs are NaN); "
+                "create a new plan (NGPDE_NO_PERSISTENT=1 selects the replayed plan)");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
   if (p->pre) {   // u(T) = u~(T) ./ c  =>  dL/du~(T) = duT ./ c

@@ -1301,8 +1301,11 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
   NGPDE_HIP_CHECK(hipMemset(ps->sync, 0, ps->sync_bytes));
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->coef, 90 * sizeof(float)));
   NGPDE_HIP_CHECK(hipMemcpy(ps->coef, coef_host, 90 * sizeof(float), hipMemcpyHostToDevice));
-  NGPDE_HIP_CHECK(hipMalloc((void **)&ps->fault, 128));
-  NGPDE_HIP_CHECK(hipMemset(ps->fault, 0, 128));
+  // the sticky fault word lives in pinned, device-mapped HOST memory: the latch kernel writes it through the device pointer, and
+  // every later entry of the plan can look at it without a synchronisation (ngpde_node_gcn2_forward / _backward refuse to go on)
+  NGPDE_HIP_CHECK(hipHostMalloc((void **)&ps->fault_host, 128, hipHostMallocMapped));
+  *ps->fault_host = 0u;
+  NGPDE_HIP_CHECK(hipHostGetDevicePointer((void **)&ps->fault, const_cast<unsigned *>(ps->fault_host), 0));
   NGPDE_HIP_CHECK(hipMalloc((void **)&ps->stats, (size_t)nt * 2 * sizeof(int)));
   NGPDE_HIP_CHECK(hipMemset(ps->stats, 0, (size_t)nt * 2 * sizeof(int)));
   return NGPDE_OK;
@@ -1311,7 +1314,8 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
 void node_persistent_free(NodePersist *ps) {
   if (ps->nbr) (void)hipFree(ps->nbr);
   if (ps->sync) (void)hipFree(ps->sync);
-  if (ps->fault) (void)hipFree(ps->fault);
+  if (ps->fault_host) (void)hipHostFree(const_cast<unsigned *>(ps->fault_host));
+  ps->fault_host = nullptr;
   if (ps->coef) (void)hipFree(ps->coef);
   if (ps->stats) (void)hipFree(ps->stats);
   ps->stats = nullptr;
@@ -1320,6 +1324,10 @@ void node_persistent_free(NodePersist *ps) {
 
 namespace {
 // fault |= abort word of the launch that just ran (sticky, read by ngpde_node_fault)
+// NGPDE_DEBUG_FORCE_ABORT=1 (tests only): the launch starts with its abort word set, i.e. every workgroup gives up at its first wait
+__global__ void set_word_kernel(unsigned *w, unsigned v) {
+  if (threadIdx.x == 0) *w = v;
+}
 __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
   if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
 }
@@ -1387,6 +1395,10 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
   k.m = make_meta(g->by_t, ps);
+  {
+    const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
+    if (fa && fa[0] == '1') hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, 1u);
+  }
   k.n_steps = a.n_steps; k.S = a.S; k.act = a.act; k.n_members = a.n_members;
   k.u_in = a.u_in; k.u_out = a.u_out; k.bufA = a.bufA; k.bufB = a.bufB;
   k.w1 = a.w1; k.b1 = a.b1; k.w2 = a.w2; k.b2 = a.b2;

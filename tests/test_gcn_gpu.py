@@ -767,3 +767,33 @@ def test_node_persistent_tile_pairs_beyond_512_tiles(N, tab, nsteps, monkeypatch
     # the parameter gradients is the comparison with the replayed plan above)
     for k in range(2):
         close(a[2 + 2 * k], acc[k]["weight"], rtol=5e-3, atol=1e-3, what=f"dW{k + 1}")
+
+
+def test_node_persistent_abort_poisons_outputs_and_the_plan_refuses_further_work(monkeypatch):
+    # a persistent launch whose waits give up (forced here: NGPDE_DEBUG_FORCE_ABORT=1 starts the launch with its abort word set;
+    # in production: another kernel holding the compute units for ~2 s) writes NaN outputs and latches the plan's fault word,
+    # which lives in pinned host memory: the NEXT entry of the plan fails with ERR_STATE instead of computing on garbage
+    needs_persistent_plan(monkeypatch)
+    from ngpde_amd import _lib
+    from ngpde_amd.node import _Plan
+    N, d = 4096, 64
+    g, og, params = spatial_case(N, 4 * N, d, seed=12)
+    lib, p = _lib.load(), _lib.ptr
+    plan = _Plan(g.handle((True, None, False)), d, _lib.ACT["relu"], "tsit5", 3, 0.05, True)
+    assert "persistent_fwd" in plan.flags()
+    dv = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=DEV)
+    u0 = dv(np.random.default_rng(1).normal(size=(N, d)))
+    w1, w2, b = dv(params[0]["weight"].T), dv(params[1]["weight"].T), torch.zeros(d, device=DEV)
+    uT = torch.empty_like(u0)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b), p(w2), p(b), p(uT), st))
+    assert not plan.fault() and torch.isfinite(uT).all()
+    monkeypatch.setenv("NGPDE_DEBUG_FORCE_ABORT", "1")
+    _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b), p(w2), p(b), p(uT), st))
+    monkeypatch.delenv("NGPDE_DEBUG_FORCE_ABORT")
+    assert plan.fault() and torch.isnan(uT).all()
+    with pytest.raises(_lib.NgpdeError, match="gave up waiting"):
+        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b), p(w2), p(b), p(uT), st))
+    fresh = _Plan(g.handle((True, None, False)), d, _lib.ACT["relu"], "tsit5", 3, 0.05, True)      # a new plan works
+    _lib.check(lib.ngpde_node_gcn2_forward(fresh.ptr, p(u0), p(w1), p(b), p(w2), p(b), p(uT), st))
+    assert not fresh.fault() and torch.isfinite(uT).all()
