@@ -166,6 +166,8 @@ def test_gcn_backward_fd(dims, weighted):
     fd_check(lambda x: (O.gcn_conv(x, W, b, g, "swish", edge_weight=ew)[0] * R).sum(), X, gr["x"])
     fd_check(lambda w: (O.gcn_conv(X, w, b, g, "swish", edge_weight=ew)[0] * R).sum(), W, gr["weight"])
     fd_check(lambda bb: (O.gcn_conv(X, W, bb, g, "swish", edge_weight=ew)[0] * R).sum(), b, gr["bias"])
+    if weighted:   # the message factor and the weighted-degree normalisation (src/layers.jl:206-231), every edge
+        fd_check(lambda w_: (O.gcn_conv(X, W, b, g, "swish", edge_weight=w_)[0] * R).sum(), ew, gr["edge_weight"], ntries=E)
 
 
 @pytest.mark.parametrize("aggr", ["mean", "+", "max", "*"])
