@@ -34,6 +34,7 @@ extern "C" {
 
 typedef struct ngpde_graph ngpde_graph_t;     /* derived graph: CSR by target + CSR by source  */
 typedef struct ngpde_node ngpde_node_t;       /* fixed-step neural-ODE plan over 2 x GCNConv   */
+typedef struct ngpde_node_gat ngpde_node_gat_t; /* fixed-step neural-ODE plan over one GAT-style layer */
 typedef void *ngpde_stream_t;                 /* hipStream_t                                   */
 
 typedef enum {
@@ -436,6 +437,28 @@ int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fau
  * the batch is test/runtests.jl:89-102] */
 int32_t ngpde_node_pipeline_stats(ngpde_node_t *plan, ngpde_stream_t stream, int64_t *ahead_forward, int64_t *ahead_backward,
                                   int64_t *slot_phases);
+/* The same solve with ONE GAT-style layer (ngpde_gat_layer_*: din = heads * c = 64, heads in {1, 2, 4}, weight (64 x 64), a (2c x
+ * heads), bias [64] nullable, activation `act`) as the right-hand side  du/dt = act.(GAT(u) .+ b): one persistent launch for the
+ * forward solve, one for the discrete adjoint, per-tile phase flags between neighbouring tiles as in the GCN solver.  Runs the
+ * one-launch layer's own per-tile code and combines the stages with the coefficients float(dt * a_ij) in the order of
+ * ngpde_rk_stage_combine, so u(T) and du0 are bitwise those of the generic solver over ngpde_gat_layer_forward / _backward;
+ * parameter gradients agree to rounding (summed per tile over the whole adjoint).  [BASELINE config 3 "GAT as ODE RHS";
+ * /root/reference/docs/src/tutorials/VMH.md:85-89 NeuralODE(layer); softmax_edge_neighbors: src/NeuralGraphPDE.jl:7]
+ *   create:   ERR_UNSUPPORTED when ngpde_node_gat_supported is 0 (other widths / head counts, tiles that do not fit the LDS halo,
+ *             more tiles than the device keeps resident, NGPDE_NO_PERSISTENT=1): use the generic solver.
+ *   forward:  u0, uT [N][64]; with_backward plans keep the tape (stage inputs, y / z, alpha: ngpde_node_gat_tape_bytes).
+ *   backward: duT [N][64] -> du0 [N][64], dweight (64 x 64, layout of weight), da (2c x heads), dbias [64] nullable.
+ *   fault:    1 when a launch gave up waiting (outputs NaN); the plan then refuses further launches (ERR_STATE). */
+int32_t ngpde_node_gat_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c);
+int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, int32_t act, int32_t tableau,
+                              int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out);
+int32_t ngpde_node_gat_destroy(ngpde_node_gat_t *plan);
+size_t ngpde_node_gat_tape_bytes(const ngpde_node_gat_t *plan);
+int32_t ngpde_node_gat_fault(ngpde_node_gat_t *plan, ngpde_stream_t stream, int32_t *fault);
+int32_t ngpde_node_gat_forward(ngpde_node_gat_t *plan, const float *u0, const float *weight, const float *a, const float *bias,
+                               float *uT, ngpde_stream_t stream);
+int32_t ngpde_node_gat_backward(ngpde_node_gat_t *plan, const float *weight, const float *a, const float *duT, float *du0,
+                                float *dweight, float *da, float *dbias, ngpde_stream_t stream);
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
  * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity

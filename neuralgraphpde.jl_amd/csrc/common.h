@@ -202,12 +202,45 @@ struct NodePersistBwd {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool node_persistent_interleave_env();
+bool node_persistent_disabled_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
 int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd);   // 0 none, 1 one tile per workgroup, 2 tile pairs
 int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps, bool pair = false);
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);
+int32_t persistent_turnstile_enter(hipStream_t stream, int *dev_out);   // persistent launches of one process take turns per device
+int32_t persistent_turnstile_leave(hipStream_t stream, int dev);
+// the GAT-style layer (64 => heads x c = 64) as ODE right-hand side, device-resident (gat_fused.hip; plan: node_gat.hip)
+struct GatNodeFwd {
+  const ngpde_graph *g = nullptr;
+  const NodePersist *ps = nullptr;   // wait lists, flags, abort / fault words (node_persistent_setup)
+  int heads = 0, act = 0, n_steps = 0, S = 0;
+  float slope = 0.2f;
+  bool taped = false;
+  const float *u_in = nullptr, *wt = nullptr, *a = nullptr, *bias = nullptr;
+  float *u_out = nullptr, *xs = nullptr, *yz = nullptr, *alpha = nullptr, *kbuf = nullptr;
+  const float *cf = nullptr;         // device table [(S + 1)][8]
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+struct GatNodeBwd {
+  const ngpde_graph *g = nullptr;
+  const NodePersist *ps = nullptr;
+  int heads = 0, act = 0, n_steps = 0, S = 0;
+  float slope = 0.2f;
+  const float *wt = nullptr, *a = nullptr, *xs = nullptr, *yz = nullptr, *alpha = nullptr, *duT = nullptr;
+  float *lam = nullptr, *ubar = nullptr, *dzbuf = nullptr, *dscore = nullptr, *dal = nullptr;
+  float *slab_db = nullptr, *slab_dw = nullptr, *slab_u = nullptr;
+  const int *xpad = nullptr;
+  const float *cb = nullptr;         // device table [S][8]
+  float *dwt = nullptr, *da = nullptr, *db = nullptr;   // outputs (db nullable)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c);
+size_t gat_node_dscore_elems(const ngpde_graph *g);                       // floats of ONE padded dscore buffer
+int32_t launch_gat_node_xpad(const ngpde_graph *g, int *pad_of_p, int *xpad, hipStream_t stream);
+int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream);
+int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream);
 bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
 int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                              float *out, float *alpha, hipStream_t stream);

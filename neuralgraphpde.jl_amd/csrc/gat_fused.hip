@@ -70,17 +70,25 @@ struct TileMeta {
   unsigned w[8];        // the row's 32 slot bytes (every lane of the group holds them)
   int my[2];            // slot byte of list entries q and q + 16 of the row (this lane's two entries)
 };
-__device__ __forceinline__ void tile_meta(const int2 *halo, const uint8_t *slots, const int4 *sched, const float *rows, int tile,
-                                          int grp, int q, float *ldsXh, TileMeta &m) {
-  HaloRegs<GD> hr;
+// round 1 alone (static per tile: the persistent solver keeps the result), round 2 alone (per phase), and both (one-launch layer)
+__device__ __forceinline__ void tile_meta_load(const int2 *halo, const uint8_t *slots, const int4 *sched, int tile, int grp, int q,
+                                               HaloRegs<GD> &hr, TileMeta &m) {
   halo_round1<GD>(halo, reinterpret_cast<const uint4 *>(slots), nullptr, tile, grp, true, hr);
   const size_t pos = (size_t)tile * kTM + grp;
   m.sc = sched[pos];
   m.my[0] = slots[pos * kSlotWidth + q];
   m.my[1] = slots[pos * kSlotWidth + 16 + q];
-  halo_round2<GD, true>(reinterpret_cast<const float4 *>(rows), q, grp, ldsXh, hr);
+}
+__device__ __forceinline__ void tile_meta_words(const HaloRegs<GD> &hr, TileMeta &m) {
   m.w[0] = hr.sl[0][0].x; m.w[1] = hr.sl[0][0].y; m.w[2] = hr.sl[0][0].z; m.w[3] = hr.sl[0][0].w;
   m.w[4] = hr.sl[0][1].x; m.w[5] = hr.sl[0][1].y; m.w[6] = hr.sl[0][1].z; m.w[7] = hr.sl[0][1].w;
+}
+__device__ __forceinline__ void tile_meta(const int2 *halo, const uint8_t *slots, const int4 *sched, const float *rows, int tile,
+                                          int grp, int q, float *ldsXh, TileMeta &m) {
+  HaloRegs<GD> hr;
+  tile_meta_load(halo, slots, sched, tile, grp, q, hr, m);
+  halo_round2<GD, true>(reinterpret_cast<const float4 *>(rows), q, grp, ldsXh, hr);
+  tile_meta_words(hr, m);
 }
 
 // Out[32][head blocks] = A[32][heads * KIN] (x) per-head blocks of B, on v_mfma_f32_16x16x4_f32:
@@ -126,24 +134,36 @@ struct GatFwdK {
   float *y, *alpha, *save_z;
 };
 
-template <int H>
-__global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwdK p) {
-  constexpr int C = GD / H;
-  // the halo region first: an LDS-DMA destination is a 16-bit offset
-  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];     // staged input rows
-  __shared__ __attribute__((aligned(16))) float ldsS[kTM * kSlotWidth * 4];      // alpha per (row, entry, head); later the output tile
-  __shared__ __attribute__((aligned(16))) float ldsA[kTM * kATS];                // per-head aggregates
-  __shared__ __attribute__((aligned(16))) float ldsAr[(kHaloCap + 1) * 4];
-  __shared__ __attribute__((aligned(16))) float ldsV[2 * 4 * GD];                // v_l, v_r per head
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = tid / GG::LPR, q = tid % GG::LPR;
-  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
-  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+// The layer's forward in pieces, so that the one-launch layer and the persistent solver (gat_node_fwd_persistent_kernel) run the
+// SAME code: per-launch constants (v vectors, W fragments), the per-tile computation from the staged rows to the pre-activation.
+struct GatFwdLds {
+  float *Xh;    // [(kHaloCap + 1)][GD]   staged input rows (the halo region comes first: an LDS-DMA destination is a 16-bit offset)
+  float *S;     // [kTM][kSlotWidth][4]   alpha per (row, entry, head); later the output tile
+  float *A;     // [kTM][kATS]            per-head aggregates
+  float *Ar;    // [(kHaloCap + 1)][4]
+  float *V;     // [2][4][GD]             v_l, v_r per head
+};
+constexpr int kFwdXhF = (kHaloCap + 1) * GD, kFwdSF = kTM * kSlotWidth * 4, kFwdAF = kTM * kATS, kFwdArF = (kHaloCap + 1) * 4,
+              kFwdVF = 2 * 4 * GD;
+struct GatThread {
+  int tid, lane, wave_u, grp, q;
+};
+__device__ __forceinline__ GatThread gat_thread() {
+  GatThread t;
+  t.tid = threadIdx.x;
+  t.lane = t.tid & 63;
+  t.wave_u = __builtin_amdgcn_readfirstlane(t.tid >> 6);
+  t.grp = t.tid / GG::LPR;
+  t.q = t.tid % GG::LPR;
+  return t;
+}
 
-  NGPDE_GST(0);
-  TileMeta m;
-  tile_meta(p.halo, p.slots, p.sched, p.x, tile, grp, q, ldsXh, m);
+template <int H>
+__device__ __forceinline__ void gat_fwd_consts(const GatFwdK &p, const GatFwdLds &L, const GatThread &t, float (&breg)[4][4], float4 &b4) {
+  constexpr int C = GD / H;
+  const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
+  float *ldsV = L.V, *ldsAr = L.Ar;
+  float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
   // v_which,k[i] = sum_c a[which*C + c][k] W[k*C + c][i]: the workgroup reads W once, coalesced (thread: input feature i =
   // tid >> 3, eight consecutive output columns), and the C / 8 adjacent lanes of one (i, head) add their partial dots
   {
@@ -166,7 +186,6 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
   }
   // B operand of this wave's output tile straight from memory (W is 16 KB, cache resident): lane (i, kq) of column tile ct
   // needs wt[16 kb + 4 kq + r][ct * 16 + i] -- 16 dwords, in flight from the start; no W^T copy in LDS
-  float breg[4][4];
   {
     const int ct = wave_u >> 1, i = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -174,11 +193,21 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 #pragma unroll
       for (int r = 0; r < 4; ++r) breg[kb][r] = p.wt[(size_t)(16 * kb + 4 * kq + r) * GD + ct * 16 + i];
   }
-  const float4 b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
+  b4 = p.bias ? reinterpret_cast<const float4 *>(p.bias)[q] : f4_zero();
   if (grp == 0) {
     Xh4[kHaloCap * GG::LPR + q] = f4_zero();
     if (q < 4) ldsAr[kHaloCap * 4 + q] = 0.f;
   }
+}
+
+// from the barrier that makes the staged rows visible to the tile's pre-activation row of this thread (bias added)
+template <int H>
+__device__ __forceinline__ float4 gat_fwd_compute(const GatFwdK &p, const GatFwdLds &L, const GatThread &t, const TileMeta &m,
+                                                  const float (&breg)[4][4], float4 b4) {
+  constexpr int C = GD / H;
+  const int lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
+  float *ldsS = L.S, *ldsA = L.A, *ldsAr = L.Ar, *ldsV = L.V;
+  float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
   NGPDE_GST(1);
   __syncthreads();   // staged rows (DMA) and v vectors visible
   NGPDE_GST(2);
@@ -308,9 +337,28 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
   NGPDE_GST(8);
   __syncthreads();
   NGPDE_GST(9);
+  return f4_add(*reinterpret_cast<const float4 *>(&ldsZ[grp * GG::TS + 4 * q]), b4);
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwdK p) {
+  __shared__ __attribute__((aligned(16))) float ldsXh[kFwdXhF];
+  __shared__ __attribute__((aligned(16))) float ldsS[kFwdSF];
+  __shared__ __attribute__((aligned(16))) float ldsA[kFwdAF];
+  __shared__ __attribute__((aligned(16))) float ldsAr[kFwdArF];
+  __shared__ __attribute__((aligned(16))) float ldsV[kFwdVF];
+  const GatFwdLds L = {ldsXh, ldsS, ldsA, ldsAr, ldsV};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  NGPDE_GST(0);
+  TileMeta m;
+  tile_meta(p.halo, p.slots, p.sched, p.x, tile, t.grp, t.q, ldsXh, m);
+  float breg[4][4];
+  float4 b4;
+  gat_fwd_consts<H>(p, L, t, breg, b4);
+  const float4 z = gat_fwd_compute<H>(p, L, t, m, breg, b4);
   if (m.sc.x >= 0) {
-    const size_t idx4 = (size_t)m.sc.x * GG::LPR + q;
-    const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[grp * GG::TS + 4 * q]), b4);
+    const size_t idx4 = (size_t)m.sc.x * GG::LPR + t.q;
     if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
     reinterpret_cast<float4 *>(p.y)[idx4] = f4_act(p.act, z);
   }
@@ -330,22 +378,41 @@ struct GatBwdTK {
   float *dz, *dscore, *dal, *slab_db;
 };
 
-template <int H>
-__global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const GatBwdTK p) {
-  constexpr int C = GD / H;
-  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];
-  // the dz tile feeds the product (its B operand, blocks of W, comes straight from memory); the result is the per-head
-  // [32][H*64] tile
-  __shared__ __attribute__((aligned(16))) float ldsDZ[kTM * GG::TS];
-  __shared__ __attribute__((aligned(16))) float ldsDA[kTM * kATS];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = tid / GG::LPR, q = tid % GG::LPR;
-  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
-  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+// write-through store (see node_persistent.hip: store_sc1 -- the s_nop 4 covers an SGPR base re-materialised by a spill reload right
+// in front of the asm, the s_nop 1 the rewrite of the data registers): rows / entries another workgroup of the SAME launch reads
+typedef float gat_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gat_store_sc1(float *base, unsigned byte_off, float4 v) {
+  gat_f4v t = {v.x, v.y, v.z, v.w};
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
+}
+// agent-scope (sc1) loads of four consecutive floats written by another workgroup of the same launch
+__device__ __forceinline__ float4 gat_load4_sc1(const float *ptr) {
+  float4 v;
+  v.x = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(ptr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(ptr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(ptr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
 
-  TileMeta m;
-  tile_meta(p.halo, p.slots, p.sched, p.x, tile, grp, q, ldsXh, m);
+struct GatBwdTLds {
+  float *Xh;   // [(kHaloCap + 1)][GD] staged input rows
+  float *DZ;   // [kTM][TS]  the dz tile (A operand of the product; its B operand, blocks of W, comes straight from memory)
+  float *DA;   // [kTM][kATS] the per-head [32][H*64] result
+};
+constexpr int kBwdDZF = kTM * GG::TS, kBwdDAF = kTM * kATS;
+
+// The by-target half of the pullback for one tile, from the thread's dz row (staged input rows in flight or landed) to dscore / dal;
+// returns this thread's partial of db (valid where tid % DBP == 0: column tid / DBP).  PAD: dscore goes to the tile's own
+// 128-byte-aligned block [tile][32 rows][32 entries][H] with write-through stores instead of the by-target list order -- the
+// persistent solver's by-source half reads it in the same launch, and entries of two tiles must not share a cache line.
+template <int H, bool PAD>
+__device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const GatBwdTLds &L, const GatThread &t, const TileMeta &m,
+                                                        int tile, float4 dz) {
+  constexpr int C = GD / H;
+  const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
+  float *ldsDZ = L.DZ, *ldsDA = L.DA;
+  float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
   // B operand of this wave's H output tiles: lane (i, kq) of tile (head, jt) needs wt[jt*16 + i][head*C + 16 kb + 4 kq + r],
   // r = 0..3 contiguous: C / 16 float4 per tile, in flight from the start (W is 16 KB, cache resident)
   float4 breg[H][C / 16];
@@ -361,10 +428,6 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
   }
   const bool ok = m.sc.x >= 0;
   const int deg = ok ? m.sc.z : 0;
-  const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
-  float4 dz = reinterpret_cast<const float4 *>(p.dy)[idx4];
-  if (p.yz) dz = f4_mul(dz, f4_dact(p.act, reinterpret_cast<const float4 *>(p.yz)[idx4]));
-  if (!ok) dz = f4_zero();
   // this lane's two entries of the row: saved coefficients (sign = leakyrelu branch)
   float as[2][4];
 #pragma unroll
@@ -381,9 +444,9 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
     for (int k = 0; k < 4; ++k) as[s][k] = v[k];
   }
   if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
-  if (ok && p.dz) reinterpret_cast<float4 *>(p.dz)[idx4] = dz;
   *reinterpret_cast<float4 *>(&ldsDZ[grp * GG::TS + 4 * q]) = dz;
   __syncthreads();
+  float db_part;
   {   // db partial: column sums of the dz tile (8 adjacent lanes hold row-partials of one column)
     const int dbc = tid / GG::DBP, dbpart = tid % GG::DBP;
     float s = 0.f;
@@ -391,7 +454,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
     for (int n = dbpart; n < kTM; n += GG::DBP) s += ldsDZ[n * GG::TS + dbc];
 #pragma unroll
     for (int o = 1; o < GG::DBP; o <<= 1) s += __shfl_xor(s, o);
-    if (dbpart == 0) p.slab_db[(size_t)tile * GD + dbc] = s;
+    db_part = s;
   }
   // dA[i][k*64 + j] = sum_c dz[i][k*C + c] W[j][k*C + c]: 2 row tiles x (4 H) column tiles, H tiles per wave
   {
@@ -453,13 +516,39 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (q + 16 * s < deg) {
-      float *dst = p.dscore + (size_t)(m.sc.y + q + 16 * s) * H;
-      if (H == 4) *reinterpret_cast<float4 *>(dst) = make_float4(dsc[s][0], dsc[s][1], dsc[s][2], dsc[s][3]);
-      else if (H == 2) *reinterpret_cast<float2 *>(dst) = make_float2(dsc[s][0], dsc[s][1]);
-      else dst[0] = dsc[s][0];
+      const float4 v4 = make_float4(dsc[s][0], H > 1 ? dsc[s][1] : 0.f, H > 2 ? dsc[s][2] : 0.f, H > 2 ? dsc[s][3] : 0.f);
+      if constexpr (PAD) {
+        gat_store_sc1(p.dscore, (unsigned)((((size_t)tile * kTM + grp) * kSlotWidth + q + 16 * s) * 4 * sizeof(float)), v4);
+      } else {
+        float *dst = p.dscore + (size_t)(m.sc.y + q + 16 * s) * H;
+        if (H == 4) *reinterpret_cast<float4 *>(dst) = v4;
+        else if (H == 2) *reinterpret_cast<float2 *>(dst) = make_float2(dsc[s][0], dsc[s][1]);
+        else dst[0] = dsc[s][0];
+      }
     }
   }
   if (ok && q < H) p.dal[(size_t)m.sc.x * H + q] = sel4(dalv, q);
+  return db_part;
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const GatBwdTK p) {
+  __shared__ __attribute__((aligned(16))) float ldsXh[kFwdXhF];
+  __shared__ __attribute__((aligned(16))) float ldsDZ[kBwdDZF];
+  __shared__ __attribute__((aligned(16))) float ldsDA[kBwdDAF];
+  const GatBwdTLds L = {ldsXh, ldsDZ, ldsDA};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.n_tiles);
+  TileMeta m;
+  tile_meta(p.halo, p.slots, p.sched, p.x, tile, t.grp, t.q, ldsXh, m);
+  const bool ok = m.sc.x >= 0;
+  const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + t.q;
+  float4 dz = reinterpret_cast<const float4 *>(p.dy)[idx4];
+  if (p.yz) dz = f4_mul(dz, f4_dact(p.act, reinterpret_cast<const float4 *>(p.yz)[idx4]));
+  if (!ok) dz = f4_zero();
+  if (ok && p.dz) reinterpret_cast<float4 *>(p.dz)[idx4] = dz;
+  const float db_part = gat_bwd_target_compute<H, false>(p, L, t, m, tile, dz);
+  if (t.tid % GG::DBP == 0) p.slab_db[(size_t)tile * GD + t.tid / GG::DBP] = db_part;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -471,133 +560,137 @@ struct GatBwdSK {
   const int2 *halo;
   const uint8_t *slots;
   const int *xpos;
+  const int *xpad;   // by-source list position -> entry of the padded dscore blocks (persistent solver), else null
   int n_tiles;
   float *dx, *slab_dw, *slab_u;
 };
 
-template <int H>
-__global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_source_kernel(const GatBwdSK p) {
-  constexpr int C = GD / H;
-  __shared__ __attribute__((aligned(16))) float ldsXh[(kHaloCap + 1) * GD];     // staged dz rows; later the dx tile
-  __shared__ __attribute__((aligned(16))) float ldsS[kTM * kSlotWidth * 4];
-  __shared__ __attribute__((aligned(16))) float ldsDWX[kTM * GG::TS];
-  __shared__ __attribute__((aligned(16))) float ldsXT[kTM * GG::TS];
-  __shared__ __attribute__((aligned(16))) float ldsBt[GD * GG::TS];
-  __shared__ __attribute__((aligned(16))) float ldsDD[kTM * 8];                  // dal | dar of the tile's rows
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = tid / GG::LPR, q = tid % GG::LPR;
-  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
-  const int n_wg = (p.n_tiles + kSrcTiles - 1) / kSrcTiles;
-  const int wg = xcd_tile(blockIdx.x, n_wg);
-  const int hq = (4 * q) / C;                                                    // this lane's head
-  // dx = dWx x B with B[k = out feature][j = in feature] = wt[j][k]: Bt[j][k] = wt[j][k], a straight copy, resident for all tiles
+struct GatBwdSLds {
+  float *Xh;    // [(kHaloCap + 1)][GD] staged dz rows; later the dx tile
+  float *S;     // [kTM][kSlotWidth][4]
+  float *DWX;   // [kTM][TS]
+  float *XT;    // [kTM][TS]
+  float *Bt;    // [GD][TS]   W, a straight copy
+  float *DD;    // [kTM][8]   dal | dar of the tile's rows
+};
+constexpr int kBwdSF = kTM * kSlotWidth * 4, kBwdTileF = kTM * GG::TS, kBwdBtF = GD * GG::TS, kBwdDDF = kTM * 8;
+
+// dx = dWx x B with B[k = out feature][j = in feature] = wt[j][k]: Bt[j][k] = wt[j][k], a straight copy
+__device__ __forceinline__ void gat_load_bt(const float *wt, float *ldsBt, int tid) {
 #pragma unroll
   for (int k = 0; k < GG::W4; ++k) {
     const int idx = tid + k * kThreads;
-    *reinterpret_cast<float4 *>(&ldsBt[((idx * 4) / GD) * GG::TS + (idx * 4) % GD]) = reinterpret_cast<const float4 *>(p.wt)[idx];
+    *reinterpret_cast<float4 *>(&ldsBt[((idx * 4) / GD) * GG::TS + (idx * 4) % GD]) = reinterpret_cast<const float4 *>(wt)[idx];
   }
-  const float4 al4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + (4 * q) % C);
-  const float4 ar4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + C + (4 * q) % C);
-  constexpr int NT = GG::CT * GG::CT;
-  f32x4 dw[GG::DWT];
-#pragma unroll
-  for (int mm = 0; mm < GG::DWT; ++mm) dw[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float uacc = 0.f;
+}
 
-  for (int tt = 0; tt < kSrcTiles; ++tt) {
-    const int tile = wg * kSrcTiles + tt;
-    if (tile >= p.n_tiles) break;   // uniform
-    TileMeta m;
-    tile_meta(p.halo, p.slots, p.sched, p.gz, tile, grp, q, ldsXh, m);
-    const bool ok = m.sc.x >= 0;
-    const int deg = ok ? m.sc.z : 0;
-    const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
-    float4 xo = reinterpret_cast<const float4 *>(p.x)[idx4];
-    if (!ok) xo = f4_zero();
-    float dalq = (ok && q < H) ? p.dal[(size_t)m.sc.x * H + q] : 0.f;
-    // this lane's two outgoing entries: coefficient and dscore of the same edge in the by-target list
-    float av[2][4], ds[2][4];
+// The by-source half of the pullback for one tile whose dz halo rows are staged (in flight or landed): returns this thread's quad of
+// the tile's dx row; dW / u accumulate in the caller's registers.  Ends with the barrier after which the LDS regions may be reused.
+template <int H, bool PAD>
+__device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, const GatBwdSLds &L, const GatThread &t, const TileMeta &m,
+                                                         float4 al4, float4 ar4, f32x4 (&dw)[GG::DWT], float &uacc) {
+  constexpr int C = GD / H;
+  constexpr int NT = GG::CT * GG::CT;
+  const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
+  float *ldsXh = L.Xh, *ldsS = L.S, *ldsDWX = L.DWX, *ldsXT = L.XT, *ldsBt = L.Bt, *ldsDD = L.DD;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  const int hq = (4 * q) / C;                                                    // this lane's head
+  const bool ok = m.sc.x >= 0;
+  const int deg = ok ? m.sc.z : 0;
+  const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
+  float4 xo = reinterpret_cast<const float4 *>(p.x)[idx4];
+  if (!ok) xo = f4_zero();
+  float dalq = (ok && q < H) ? p.dal[(size_t)m.sc.x * H + q] : 0.f;
+  // this lane's two outgoing entries: coefficient and dscore of the same edge in the by-target list
+  float av[2][4], ds[2][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bool valid = q + 16 * s < deg;
-      const int pp = valid ? p.xpos[m.sc.y + q + 16 * s] : 0;
-      float va[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        if (H == 4) {
-          const float4 t = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp * 4), u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pp * 4);
-          va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; vd[0] = u.x; vd[1] = u.y; vd[2] = u.z; vd[3] = u.w;
-        } else if (H == 2) {
-          const float2 t = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp * 2), u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pp * 2);
-          va[0] = t.x; va[1] = t.y; vd[0] = u.x; vd[1] = u.y;
-        } else {
-          va[0] = p.alpha[pp]; vd[0] = p.dscore[pp];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { av[s][k] = fabsf(va[k]); ds[s][k] = vd[k]; }
-      reinterpret_cast<float4 *>(ldsS)[grp * kSlotWidth + q + 16 * s] = make_float4(av[s][0], av[s][1], av[s][2], av[s][3]);
-    }
-    if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
-    float darv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < H; ++k) darv[k] = row_sum16(ds[0][k] + ds[1][k]);
-    // dal of the row's heads: lanes q < H hold one each
-    float dalv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dalv[k] = __shfl(dalq, k, GG::LPR);
-    __syncthreads();   // staged dz rows visible (coefficients are group-private, same wave)
-    float4 g = f4_zero();
-    {
-      const int wmax = wave_max_deg(deg);
-#pragma unroll
-      for (int jw = 0; jw < 8; ++jw) {
-        if (jw * 4 < wmax) {   // wave-uniform
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb) {
-            const float4 zv = Xh4[slot_byte(m.w, jw, jb) * GG::LPR + q];
-            g = f4_fma(ldsS[(grp * kSlotWidth + jw * 4 + jb) * 4 + hq], zv, g);
-          }
-        }
+  for (int s = 0; s < 2; ++s) {
+    const bool valid = q + 16 * s < deg;
+    const int pp = valid ? p.xpos[m.sc.y + q + 16 * s] : 0;
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid && PAD) {   // the persistent solver: alpha from the tape (list order), dscore from the target tile's padded block, sc1
+      const float4 u = gat_load4_sc1(p.dscore + (size_t)p.xpad[m.sc.y + q + 16 * s] * 4);
+      vd[0] = u.x; vd[1] = u.y; vd[2] = u.z; vd[3] = u.w;
+      if (H == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp * 4); va[0] = t4.x; va[1] = t4.y; va[2] = t4.z; va[3] = t4.w; }
+      else if (H == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp * 2); va[0] = t2.x; va[1] = t2.y; }
+      else va[0] = p.alpha[pp];
+    } else if (valid) {
+      if (H == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp * 4), u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pp * 4);
+        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; vd[0] = u.x; vd[1] = u.y; vd[2] = u.z; vd[3] = u.w;
+      } else if (H == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp * 2), u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pp * 2);
+        va[0] = t.x; va[1] = t.y; vd[0] = u.x; vd[1] = u.y;
+      } else {
+        va[0] = p.alpha[pp]; vd[0] = p.dscore[pp];
       }
     }
-    g = f4_fma(sel4(dalv, hq), al4, g);
-    g = f4_fma(sel4(darv, hq), ar4, g);
-    if (!ok) g = f4_zero();
-    *reinterpret_cast<float4 *>(&ldsDWX[grp * GG::TS + 4 * q]) = g;
-    *reinterpret_cast<float4 *>(&ldsXT[grp * GG::TS + 4 * q]) = xo;
-    if (q < 4) ldsDD[grp * 8 + q] = ok ? sel4(dalv, q) : 0.f;
-    else if (q < 8) ldsDD[grp * 8 + q] = ok ? sel4(darv, q - 4) : 0.f;
-    __syncthreads();   // tiles complete, staged rows dead
-    mfma_rows_times_bt<GD>(ldsDWX, ldsBt, ldsXh, wave_u, lane);
-    {   // dWt[i][o] += sum_n x[n][i] dWx[n][o]
-      const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-      for (int mm = 0; mm < GG::DWT; ++mm) {
-        const int t2 = wave_u + GG::WAVES * mm;
-        if (t2 < NT) {
-          const int mt = t2 / GG::CT, nt = t2 % GG::CT;
+    for (int k = 0; k < 4; ++k) { av[s][k] = fabsf(va[k]); ds[s][k] = vd[k]; }
+    reinterpret_cast<float4 *>(ldsS)[grp * kSlotWidth + q + 16 * s] = make_float4(av[s][0], av[s][1], av[s][2], av[s][3]);
+  }
+  if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
+  float darv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < kTM / 4; ++ks)
-            dw[mm] = mfma16(ldsXT[(4 * ks + kq) * GG::TS + mt * 16 + i], ldsDWX[(4 * ks + kq) * GG::TS + nt * 16 + i], dw[mm]);
+  for (int k = 0; k < H; ++k) darv[k] = row_sum16(ds[0][k] + ds[1][k]);
+  // dal of the row's heads: lanes q < H hold one each
+  float dalv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dalv[k] = __shfl(dalq, k, GG::LPR);
+  __syncthreads();   // staged dz rows visible (coefficients are group-private, same wave)
+  float4 g = f4_zero();
+  {
+    const int wmax = wave_max_deg(deg);
+#pragma unroll
+    for (int jw = 0; jw < 8; ++jw) {
+      if (jw * 4 < wmax) {   // wave-uniform
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const float4 zv = Xh4[slot_byte(m.w, jw, jb) * GG::LPR + q];
+          g = f4_fma(ldsS[(grp * kSlotWidth + jw * 4 + jb) * 4 + hq], zv, g);
         }
       }
     }
-    {   // u_which,k[i] += sum_n (dal | dar)[n][k] x[n][i]
-      const int which = tid >> 8, hk = (tid >> 6) & 3, i = tid & 63;
+  }
+  g = f4_fma(sel4(dalv, hq), al4, g);
+  g = f4_fma(sel4(darv, hq), ar4, g);
+  if (!ok) g = f4_zero();
+  *reinterpret_cast<float4 *>(&ldsDWX[grp * GG::TS + 4 * q]) = g;
+  *reinterpret_cast<float4 *>(&ldsXT[grp * GG::TS + 4 * q]) = xo;
+  if (q < 4) ldsDD[grp * 8 + q] = ok ? sel4(dalv, q) : 0.f;
+  else if (q < 8) ldsDD[grp * 8 + q] = ok ? sel4(darv, q - 4) : 0.f;
+  __syncthreads();   // tiles complete, staged rows dead
+  mfma_rows_times_bt<GD>(ldsDWX, ldsBt, ldsXh, wave_u, lane);
+  {   // dWt[i][o] += sum_n x[n][i] dWx[n][o]
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < GG::DWT; ++mm) {
+      const int t2 = wave_u + GG::WAVES * mm;
+      if (t2 < NT) {
+        const int mt = t2 / GG::CT, nt = t2 % GG::CT;
+#pragma unroll
+        for (int ks = 0; ks < kTM / 4; ++ks)
+          dw[mm] = mfma16(ldsXT[(4 * ks + kq) * GG::TS + mt * 16 + i], ldsDWX[(4 * ks + kq) * GG::TS + nt * 16 + i], dw[mm]);
+      }
+    }
+  }
+  {   // u_which,k[i] += sum_n (dal | dar)[n][k] x[n][i]
+    const int which = tid >> 8, hk = (tid >> 6) & 3, i = tid & 63;
 #pragma unroll 8
-      for (int n = 0; n < kTM; ++n) uacc = fmaf(ldsDD[n * 8 + which * 4 + hk], ldsXT[n * GG::TS + i], uacc);
-    }
-    __syncthreads();
-    if (ok && p.dx) reinterpret_cast<float4 *>(p.dx)[idx4] = *reinterpret_cast<const float4 *>(&ldsXh[grp * GG::TS + 4 * q]);
-    __syncthreads();   // the next tile's rows land where the dx tile is
+    for (int n = 0; n < kTM; ++n) uacc = fmaf(ldsDD[n * 8 + which * 4 + hk], ldsXT[n * GG::TS + i], uacc);
   }
-  float4 *slab4 = reinterpret_cast<float4 *>(p.slab_dw + (size_t)wg * GD * GD);
-#pragma unroll
-  for (int mm = 0; mm < GG::DWT; ++mm) {
-    const int t2 = wave_u + GG::WAVES * mm;
-    if (t2 < NT) slab4[t2 * 64 + lane] = make_float4(dw[mm][0], dw[mm][1], dw[mm][2], dw[mm][3]);
-  }
+  __syncthreads();
+  const float4 dxv = *reinterpret_cast<const float4 *>(&ldsXh[grp * GG::TS + 4 * q]);
+  __syncthreads();   // the next tile's rows land where the dx tile is
+  return dxv;
+}
+
+// this workgroup's share of da from its u accumulators (needs W in L.Bt)
+template <int H>
+__device__ __forceinline__ void gat_bwd_source_finish(float *slab_u_wg, const GatBwdSLds &L, const GatThread &t, float uacc) {
+  constexpr int C = GD / H;
+  const int tid = t.tid;
+  float *ldsS = L.S, *ldsBt = L.Bt;
   // this workgroup's share of da:  da[(which*C + c) + 2C k] = sum_i W[k*C + c][i] u_which,k[i]   (linear in u: summed over the
   // workgroups by the reduction kernel)
   ldsS[tid] = uacc;
@@ -607,8 +700,48 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_source_kernel(const
     float sacc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < GD; ++i) sacc = fmaf(ldsBt[i * GG::TS + k * C + cc], ldsS[which * 256 + k * 64 + i], sacc);
-    p.slab_u[(size_t)wg * 2 * GD + tid] = sacc;
+    slab_u_wg[tid] = sacc;
   }
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_source_kernel(const GatBwdSK p) {
+  constexpr int C = GD / H;
+  __shared__ __attribute__((aligned(16))) float ldsXh[kFwdXhF];
+  __shared__ __attribute__((aligned(16))) float ldsS[kBwdSF];
+  __shared__ __attribute__((aligned(16))) float ldsDWX[kBwdTileF];
+  __shared__ __attribute__((aligned(16))) float ldsXT[kBwdTileF];
+  __shared__ __attribute__((aligned(16))) float ldsBt[kBwdBtF];
+  __shared__ __attribute__((aligned(16))) float ldsDD[kBwdDDF];
+  const GatBwdSLds L = {ldsXh, ldsS, ldsDWX, ldsXT, ldsBt, ldsDD};
+  const GatThread t = gat_thread();
+  const int q = t.q;
+  const int n_wg = (p.n_tiles + kSrcTiles - 1) / kSrcTiles;
+  const int wg = xcd_tile(blockIdx.x, n_wg);
+  const int hq = (4 * q) / C;
+  gat_load_bt(p.wt, ldsBt, t.tid);
+  const float4 al4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + (4 * q) % C);
+  const float4 ar4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + C + (4 * q) % C);
+  constexpr int NT = GG::CT * GG::CT;
+  f32x4 dw[GG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) dw[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float uacc = 0.f;
+  for (int tt = 0; tt < kSrcTiles; ++tt) {
+    const int tile = wg * kSrcTiles + tt;
+    if (tile >= p.n_tiles) break;   // uniform
+    TileMeta m;
+    tile_meta(p.halo, p.slots, p.sched, p.gz, tile, t.grp, t.q, ldsXh, m);
+    const float4 dxv = gat_bwd_source_compute<H, false>(p, L, t, m, al4, ar4, dw, uacc);
+    if (m.sc.x >= 0 && p.dx) reinterpret_cast<float4 *>(p.dx)[(size_t)m.sc.x * GG::LPR + q] = dxv;
+  }
+  float4 *slab4 = reinterpret_cast<float4 *>(p.slab_dw + (size_t)wg * GD * GD);
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) {
+    const int t2 = t.wave_u + GG::WAVES * mm;
+    if (t2 < NT) slab4[t2 * 64 + t.lane] = make_float4(dw[mm][0], dw[mm][1], dw[mm][2], dw[mm][3]);
+  }
+  gat_bwd_source_finish<H>(p.slab_u + (size_t)wg * 2 * GD, L, t, uacc);
 }
 
 // slabs -> dWt (row-major [in][out]), db, da.  Blocks 0 .. 63: 64 elements of dW each; block 64: db; blocks 65, 66: da.
@@ -645,6 +778,254 @@ __global__ __launch_bounds__(1024) void gat_layer_reduce_kernel(const float *__r
       dwt[(mt * 16 + 4 * (ln >> 4) + reg) * GD + nt * 16 + (ln & 15)] = v;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The layer as the right-hand side of a fixed-step explicit Runge-Kutta solve, device-resident: ONE persistent launch for the
+// forward solve, ONE for the discrete adjoint (BASELINE config 3 "GAT as ODE RHS"; /root/reference/docs/src/tutorials/VMH.md:85-89
+// NeuralODE(layer), graph_node.md:44-66).  A workgroup keeps its tile for the whole solve and runs the SAME per-tile code as the
+// one-launch layer above (gat_fwd_compute, gat_bwd_target_compute, gat_bwd_source_compute), with the Runge-Kutta combinations
+// of its own rows in between -- in the order and with the coefficients of the generic solver (node.py: _rk_forward / _rk_backward
+// on ngpde_rk_stage_combine), so u(T) and du0 are bitwise those of the generic path.  Tiles synchronise through per-tile phase
+// flags as in node_persistent.hip (wait list = symmetric closure of "my halo references a row of yours" over both directions,
+// rows exchanged by write-through stores and sc1 LDS-DMA loads, bounded spins with an abort word):
+//   forward, phase (n, i):  wait for the neighbours' phase before; stage the input rows (own + halo) of stage i; the layer; the
+//     input of the next stage (or the step update) of the own rows -> the next slot of `xs`; publish.  One hand-off per
+//     right-hand side.  With a tape every phase has its own slot of xs (it IS the tape of stage inputs), else two slots ping-pong.
+//   adjoint, phase (n, i) in reverse:  K-bar_i of the own rows (lambda, U-bar_j: own rows, in memory, same thread writes and
+//     reads); by-target half -> dz rows and dscore blocks (write-through, double-buffered by phase parity); publish; wait for
+//     the neighbours' publish of the SAME phase; by-source half -> U-bar_i = dx.  One hand-off per right-hand side.
+//     dW / u / db accumulate in registers over the whole adjoint; one slab per tile at the end, reduced by gat_layer_reduce_kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kGatNbrStride = 64;   // = node_persistent.hip's wait-list stride (node_persistent_setup builds the lists)
+struct GatSync {
+  const int *nbr;        // [n_tiles][64] wait lists, -1 padded
+  unsigned *flags;       // one 128-byte line per tile: the last published phase
+  unsigned *abort_word;
+};
+
+// every tile of the wait list has published phase >= need (wave 0 polls: one flag per lane, lane 63 the abort word); false: aborted
+__device__ __forceinline__ bool gat_wait(const GatSync &s, const GatThread &t, int my_nbr, unsigned need, int *s_ok) {
+  if (need == 0) return true;
+  if (t.wave_u == 0) {
+    const unsigned *addr = (t.lane == 63) ? s.abort_word : (my_nbr >= 0 ? s.flags + 32 * my_nbr : nullptr);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (unsigned it = 1;; ++it) {
+      unsigned f = need;
+      if (addr) f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__any((int)(t.lane == 63 && f != 0))) { ok = false; break; }              // somebody gave up
+      if (__all((int)(t.lane == 63 || f >= need))) break;
+      if ((it & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // ~2 s of the 100 MHz counter
+        if (t.lane == 0) __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (t.lane == 0) *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+// every storing wave drains, the workgroup meets, ONE lane publishes
+__device__ __forceinline__ void gat_publish(const GatSync &s, const GatThread &t, int tile, unsigned ph) {
+  wait_vmcnt0();
+  __syncthreads();
+  if (t.tid == 0) __hip_atomic_store(s.flags + 32 * tile, ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define NGPDE_GAT_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float4 gat_ld4(const float *base, unsigned byte_off) {
+  const gat_f4v v = *reinterpret_cast<NGPDE_GAT_GLOBAL const gat_f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gat_st4(float *base, unsigned byte_off, float4 v) {
+  const gat_f4v w = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<NGPDE_GAT_GLOBAL gat_f4v *>(reinterpret_cast<uintptr_t>(base) + byte_off) = w;
+}
+__device__ __forceinline__ float4 gat_nan4() {
+  const float n = __int_as_float(0x7fc00000);
+  return make_float4(n, n, n, n);
+}
+
+struct GatNodeFwdK {
+  GatFwdK l;            // wt, a, bias, lists by target, n_tiles, act, slope (x, y, alpha, save_z are set per phase / unused)
+  GatSync s;
+  int n_steps, S, taped;
+  const float *u_in;    // [N][64]
+  float *u_out;         // [N][64]
+  float *xs;            // stage inputs [n_steps * S (taped) or 2][N][64]; slot 0 holds u0 at launch
+  float *yz;            // [n_steps * S][N][64]: y (relu) or z, or null (no tape / identity)
+  float *alpha;         // [n_steps * S][E][H] or null
+  float *kbuf;          // [S][N][64]: stage derivatives of the current step (own rows)
+  size_t row_elems, alpha_elems;
+  const float *cf;      // [(S + 1)][8]: row i < S: coefficient of k_j in the input of stage i; row S: in the step update
+};
+
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(const GatNodeFwdK p) {
+  __shared__ __attribute__((aligned(16))) float ldsXh[kFwdXhF];
+  __shared__ __attribute__((aligned(16))) float ldsS[kFwdSF];
+  __shared__ __attribute__((aligned(16))) float ldsA[kFwdAF];
+  __shared__ __attribute__((aligned(16))) float ldsAr[kFwdArF];
+  __shared__ __attribute__((aligned(16))) float ldsV[kFwdVF];
+  __shared__ float ldsC[64];
+  __shared__ int s_ok;
+  const GatFwdLds L = {ldsXh, ldsS, ldsA, ldsAr, ldsV};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.l.n_tiles);
+  TileMeta m;
+  HaloRegs<GD> hr;
+  tile_meta_load(p.l.halo, p.l.slots, p.l.sched, tile, t.grp, t.q, hr, m);
+  tile_meta_words(hr, m);
+  float breg[4][4];
+  float4 b4;
+  gat_fwd_consts<H>(p.l, L, t, breg, b4);
+  if (t.tid < 64) ldsC[t.tid] = p.cf[t.tid];
+  if (t.tid == 0) s_ok = 1;
+  const int my_nbr = p.s.nbr[(size_t)tile * kGatNbrStride + t.lane];
+  const bool ok = m.sc.x >= 0;
+  const unsigned own = (unsigned)max(m.sc.x, 0) * (unsigned)(GD * 4) + (unsigned)(t.q * 16);
+  float4 u = ok ? gat_ld4(p.u_in, own) : f4_zero();
+  const int S = p.S;
+  GatFwdK l = p.l;
+  bool dead = false;
+  unsigned ph = 0;
+  __syncthreads();
+  for (int n = 0; n < p.n_steps && !dead; ++n) {
+    for (int i = 0; i < S; ++i) {
+      ++ph;
+      const size_t e = ph - 1;
+      const float *X = p.xs + (p.taped ? e : (e & 1)) * p.row_elems;
+      if (!gat_wait(p.s, t, my_nbr, ph - 1, &s_ok)) { dead = true; break; }
+      halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
+      l.alpha = p.alpha ? p.alpha + e * p.alpha_elems : nullptr;
+      const float4 z = gat_fwd_compute<H>(l, L, t, m, breg, b4);
+      const float4 y = f4_act(l.act, z);
+      if (p.yz && ok) gat_st4(p.yz + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
+      // the input of the next stage / the step update, as ngpde_rk_stage_combine forms it: 1 * u, then the k_j in order
+      const int row = (i + 1 < S) ? i + 1 : S;
+      float4 v = f4_scale(1.0f, u);
+      for (int j = 0; j < i; ++j) v = f4_fma(ldsC[row * 8 + j], gat_ld4(p.kbuf + (size_t)j * p.row_elems, own), v);
+      v = f4_fma(ldsC[row * 8 + i], y, v);
+      if (i + 1 < S) gat_st4(p.kbuf + (size_t)i * p.row_elems, own, y);
+      else u = v;
+      const bool last = (n == p.n_steps - 1 && i == S - 1);
+      if (ok) {
+        if (last) gat_st4(p.u_out, own, v);
+        else gat_store_sc1(p.xs + (p.taped ? e + 1 : ((e + 1) & 1)) * p.row_elems, own, v);
+      }
+      if (!last) gat_publish(p.s, t, tile, ph);
+    }
+  }
+  if (dead && ok) gat_st4(p.u_out, own, gat_nan4());
+}
+
+struct GatNodeBwdK {
+  GatBwdTK t;           // wt, lists by target, n_tiles, act, slope, dal (x, alpha, dscore per phase; dy, yz, dz, slab_db unused)
+  GatBwdSK s;           // wt, a, dal, lists by source, xpos, xpad, n_tiles, slab_dw, slab_u (gz, x, alpha, dscore per phase; dx unused)
+  GatSync y;
+  int n_steps, S;
+  const float *xs, *yz, *alpha;   // the forward launch's tape
+  const float *duT;               // [N][64]
+  float *lam;                     // [N][64] out: du0
+  float *ubar;                    // [S][N][64]: stage adjoints of the current step (own rows)
+  float *dzbuf;                   // [2][N][64]
+  float *dscore;                  // [2][n_tiles][32][32][4]
+  float *slab_db;                 // [n_tiles][64]
+  size_t row_elems, alpha_elems, dscore_elems;
+  const float *cb;                // [S][8]: cb[i*8 + i] = dt b_i, cb[i*8 + j] (j > i) = dt a_ji
+};
+
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(const GatNodeBwdK p) {
+  constexpr int C = GD / H;
+  // one region for both halves: [Xh | DZ | DA] by target, [Xh | S | DWX | XT | Bt | DD] by source (W is copied into Bt before every
+  // by-source half, under the wait: Bt overlaps DA)
+  __shared__ __attribute__((aligned(16))) float lds[kFwdXhF + kBwdSF + 2 * kBwdTileF + kBwdBtF + kBwdDDF];
+  static_assert(kBwdDZF + kBwdDAF <= kBwdSF + 2 * kBwdTileF + kBwdBtF + kBwdDDF, "the by-target tiles fit the by-source layout");
+  __shared__ float ldsC[64];
+  __shared__ int s_ok;
+  float *ldsXh = lds;
+  const GatBwdTLds LT = {ldsXh, ldsXh + kFwdXhF, ldsXh + kFwdXhF + kBwdDZF};
+  float *o = ldsXh + kFwdXhF;
+  const GatBwdSLds LS = {ldsXh, o, o + kBwdSF, o + kBwdSF + kBwdTileF, o + kBwdSF + 2 * kBwdTileF, o + kBwdSF + 2 * kBwdTileF + kBwdBtF};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.t.n_tiles);
+  if (t.tid < 64) ldsC[t.tid] = p.cb[t.tid];
+  if (t.tid == 0) s_ok = 1;
+  const int my_nbr = p.y.nbr[(size_t)tile * kGatNbrStride + t.lane];
+  const int hq = (4 * t.q) / C;
+  const float4 al4 = *reinterpret_cast<const float4 *>(p.s.a + (size_t)hq * 2 * C + (4 * t.q) % C);
+  const float4 ar4 = *reinterpret_cast<const float4 *>(p.s.a + (size_t)hq * 2 * C + C + (4 * t.q) % C);
+  constexpr int NT = GG::CT * GG::CT;
+  f32x4 dw[GG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) dw[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float uacc = 0.f, dbacc = 0.f;
+  const int node = p.t.sched[(size_t)tile * kTM + t.grp].x;   // (the same node in both directions' schedules: checked by the host)
+  const bool ok = node >= 0;
+  const unsigned own = (unsigned)max(node, 0) * (unsigned)(GD * 4) + (unsigned)(t.q * 16);
+  float4 lam = ok ? gat_ld4(p.duT, own) : f4_zero();
+  const int S = p.S;
+  GatBwdTK tk = p.t;
+  GatBwdSK sk = p.s;
+  bool dead = false;
+  unsigned ph = 0;
+  __syncthreads();
+  for (int n = p.n_steps - 1; n >= 0 && !dead; --n) {
+    for (int i = S - 1; i >= 0; --i) {
+      ++ph;
+      const size_t e = (size_t)n * S + i;
+      const float *X = p.xs + e * p.row_elems;
+      // ---- by target.  K-bar_i = (dt b_i) lambda + sum_{j > i} (dt a_ji) U-bar_j, in ngpde_rk_stage_combine's order
+      TileMeta mt;
+      tile_meta(p.t.halo, p.t.slots, p.t.sched, X, tile, t.grp, t.q, ldsXh, mt);
+      float4 v = f4_scale(ldsC[i * 8 + i], lam);
+      for (int j = i + 1; j < S; ++j) v = f4_fma(ldsC[i * 8 + j], gat_ld4(p.ubar + (size_t)j * p.row_elems, own), v);
+      if (p.yz) v = f4_mul(v, f4_dact(tk.act, gat_ld4(p.yz + e * p.row_elems, own)));
+      if (!ok) v = f4_zero();
+      float *dzb = p.dzbuf + (size_t)(ph & 1) * p.row_elems;
+      if (ok) gat_store_sc1(dzb, own, v);
+      tk.alpha = p.alpha + e * p.alpha_elems;
+      tk.dscore = p.dscore + (size_t)(ph & 1) * p.dscore_elems;
+      dbacc += gat_bwd_target_compute<H, true>(tk, LT, t, mt, tile, v);
+      gat_publish(p.y, t, tile, ph);
+      // ---- by source
+      TileMeta ms;
+      HaloRegs<GD> hrs;
+      tile_meta_load(p.s.halo, p.s.slots, p.s.sched, tile, t.grp, t.q, hrs, ms);
+      tile_meta_words(hrs, ms);
+      gat_load_bt(p.s.wt, LS.Bt, t.tid);
+      if (!gat_wait(p.y, t, my_nbr, ph, &s_ok)) { dead = true; break; }
+      halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
+      sk.x = X;
+      sk.alpha = tk.alpha;
+      sk.dscore = tk.dscore;
+      const float4 dxv = gat_bwd_source_compute<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc);
+      if (i > 0) {
+        if (ok) gat_st4(p.ubar + (size_t)i * p.row_elems, own, dxv);
+      } else {   // lambda of the step before: 1 * lambda + sum_j 1 * U-bar_j, j ascending
+        float4 w = f4_scale(1.0f, lam);
+        w = f4_fma(1.0f, dxv, w);
+        for (int j = 1; j < S; ++j) w = f4_fma(1.0f, gat_ld4(p.ubar + (size_t)j * p.row_elems, own), w);
+        lam = ok ? w : f4_zero();
+      }
+    }
+  }
+  if (ok) gat_st4(p.lam, own, dead ? gat_nan4() : lam);
+  const float bad = __int_as_float(0x7fc00000);
+  float4 *slab4 = reinterpret_cast<float4 *>(p.s.slab_dw + (size_t)tile * GD * GD);
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) {
+    const int t2 = t.wave_u + GG::WAVES * mm;
+    if (t2 < NT) slab4[t2 * 64 + t.lane] = dead ? gat_nan4() : make_float4(dw[mm][0], dw[mm][1], dw[mm][2], dw[mm][3]);
+  }
+  if (t.tid % GG::DBP == 0) p.slab_db[(size_t)tile * GD + t.tid / GG::DBP] = dead ? bad : dbacc;
+  __syncthreads();
+  gat_load_bt(p.s.wt, LS.Bt, t.tid);
+  __syncthreads();
+  gat_bwd_source_finish<H>(p.s.slab_u + (size_t)tile * 2 * GD, LS, t, dead ? bad : uacc);
 }
 
 inline bool no_fused_gat_layer_env() {   // read on every call: tests flip it inside one process
@@ -724,7 +1105,7 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
     GatBwdSK s;
     s.gz = ident ? dy : dz; s.x = x; s.wt = wt; s.a = a; s.alpha = alpha; s.dscore = dscore; s.dal = dal; s.sched = g->by_s.sched;
     s.halo = g->by_s.halo; s.slots = g->by_s.slots; s.xpos = g->by_s.xpos; s.n_tiles = n_tiles; s.dx = dx; s.slab_dw = slab_dw;
-    s.slab_u = slab_u;
+    s.slab_u = slab_u; s.xpad = nullptr;
     const dim3 block(kThreads);
     switch (heads) {
       case 1:
@@ -746,6 +1127,150 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
                      g->n_nodes > 0 ? n_tiles : 0, slab_u, dwt, db, da);
   NGPDE_LAUNCH_CHECK("gat_layer_reduce_kernel");
   return NGPDE_OK;
+}
+
+
+// ---- the persistent solver's host side -------------------------------------------------------------------------------------
+namespace {
+__global__ void gat_pad_of_p_kernel(const int4 *__restrict__ sched_t, int n_sched, int *__restrict__ pad_of_p) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n_sched) return;
+  const int4 sc = sched_t[pos];
+  if (sc.x < 0) return;
+  for (int j = 0; j < sc.z && j < kSlotWidth; ++j) pad_of_p[sc.y + j] = pos * kSlotWidth + j;
+}
+__global__ void gat_xpad_kernel(const int *__restrict__ xpos_s, const int *__restrict__ pad_of_p, int64_t n_edges, int *__restrict__ xpad) {
+  const int64_t qq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (qq < n_edges) xpad[qq] = pad_of_p[xpos_s[qq]];
+}
+__global__ void gat_sched_same_kernel(const int4 *__restrict__ a, const int4 *__restrict__ b, int n, unsigned *bad) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos < n && a[pos].x != b[pos].x) *bad = 1u;
+}
+__global__ void gat_set_word_kernel(unsigned *w, unsigned v) {
+  if (threadIdx.x == 0) *w = v;
+}
+__global__ void gat_latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
+  if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
+}
+inline GatSync gat_sync(const NodePersist &ps) {
+  GatSync y;
+  y.nbr = ps.nbr; y.flags = ps.sync; y.abort_word = ps.sync + (size_t)ps.n_tiles * 64;   // node_persistent_setup's layout
+  return y;
+}
+}  // namespace
+
+size_t gat_node_dscore_elems(const ngpde_graph *g) { return (size_t)g->n_sched * kSlotWidth * 4; }
+
+bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c) {
+  if (node_persistent_disabled_env() || !gat_layer_fused_supported(g, GD, heads, c)) return false;
+  int dev = 0, cus = 0, occ = 1 << 30;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  auto take = [&](auto kernel) {   // every workgroup spins for its neighbours: all of them must be resident
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, kThreads, 0) != hipSuccess) o = 0;
+    occ = std::min(occ, o);
+  };
+  switch (heads) {
+    case 1: take(gat_node_fwd_persistent_kernel<1>); take(gat_node_bwd_persistent_kernel<1>); break;
+    case 2: take(gat_node_fwd_persistent_kernel<2>); take(gat_node_bwd_persistent_kernel<2>); break;
+    default: take(gat_node_fwd_persistent_kernel<4>); take(gat_node_bwd_persistent_kernel<4>); break;
+  }
+  const int nt = g->n_sched / kTileRows;
+  if (nt < 1 || nt > cus * occ) return false;
+  // both directions' schedules must name the same node at every position (the solver keeps per-thread state across the halves)
+  unsigned *bad = nullptr, h = 1;
+  if (hipMalloc((void **)&bad, sizeof(unsigned)) != hipSuccess) return false;
+  bool same = hipMemset(bad, 0, sizeof(unsigned)) == hipSuccess;
+  if (same) {
+    hipLaunchKernelGGL(gat_sched_same_kernel, dim3((g->n_sched + 255) / 256), dim3(256), 0, 0, g->by_t.sched, g->by_s.sched, g->n_sched, bad);
+    same = hipMemcpy(&h, bad, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && h == 0;
+  }
+  (void)hipFree(bad);
+  return same;
+}
+
+int32_t launch_gat_node_xpad(const ngpde_graph *g, int *pad_of_p, int *xpad, hipStream_t stream) {
+  if (g->n_edges == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(gat_pad_of_p_kernel, dim3((g->n_sched + 255) / 256), dim3(256), 0, stream, g->by_t.sched, g->n_sched, pad_of_p);
+  hipLaunchKernelGGL(gat_xpad_kernel, dim3((unsigned)((g->n_edges + 255) / 256)), dim3(256), 0, stream, g->by_s.xpos, pad_of_p, g->n_edges, xpad);
+  NGPDE_LAUNCH_CHECK("gat_xpad_kernel");
+  return NGPDE_OK;
+}
+
+int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  int dev = 0;
+  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  GatNodeFwdK k;
+  k.l.x = nullptr; k.l.wt = a.wt; k.l.a = a.a; k.l.bias = a.bias; k.l.sched = g->by_t.sched; k.l.halo = g->by_t.halo;
+  k.l.slots = g->by_t.slots; k.l.n_tiles = ps.n_tiles; k.l.act = a.act; k.l.slope = a.slope; k.l.y = nullptr; k.l.alpha = nullptr;
+  k.l.save_z = nullptr;
+  NGPDE_GST_SET(k.l)
+  k.s = gat_sync(ps);
+  {
+    const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
+    if (fa && fa[0] == '1') hipLaunchKernelGGL(gat_set_word_kernel, dim3(1), dim3(64), 0, stream, k.s.abort_word, 1u);
+  }
+  k.n_steps = a.n_steps; k.S = a.S; k.taped = a.taped ? 1 : 0; k.u_in = a.u_in; k.u_out = a.u_out; k.xs = a.xs; k.yz = a.yz;
+  k.alpha = a.alpha; k.kbuf = a.kbuf; k.row_elems = (size_t)g->n_nodes * GD; k.alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * a.heads;
+  k.cf = a.cf;
+  const dim3 grid(ps.n_tiles), block(kThreads);
+#define NGPDE_GN_LAUNCH(KERNEL)                                                                                   \
+  if (a.ev_start) hipExtLaunchKernelGGL(KERNEL, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);              \
+  else hipLaunchKernelGGL(KERNEL, grid, block, 0, stream, k);
+  switch (a.heads) {
+    case 1: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<1>) break;
+    case 2: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<2>) break;
+    default: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<4>) break;
+  }
+  NGPDE_LAUNCH_CHECK("gat_node_fwd_persistent_kernel");
+  hipLaunchKernelGGL(gat_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.s.abort_word, ps.fault);
+  NGPDE_LAUNCH_CHECK("gat_latch_fault_kernel");
+  return persistent_turnstile_leave(stream, dev);
+}
+
+int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
+  const ngpde_graph *g = a.g;
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  int dev = 0;
+  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  GatNodeBwdK k;
+  const bool ident = a.act == NGPDE_ACT_IDENTITY;
+  k.t.x = nullptr; k.t.wt = a.wt; k.t.dy = nullptr; k.t.yz = nullptr; k.t.alpha = nullptr; k.t.sched = g->by_t.sched; k.t.halo = g->by_t.halo;
+  k.t.slots = g->by_t.slots; k.t.n_tiles = ps.n_tiles; k.t.act = a.act; k.t.slope = a.slope; k.t.dz = nullptr; k.t.dscore = nullptr;
+  k.t.dal = a.dal; k.t.slab_db = nullptr;
+  k.s.gz = nullptr; k.s.x = nullptr; k.s.wt = a.wt; k.s.a = a.a; k.s.alpha = nullptr; k.s.dscore = nullptr; k.s.dal = a.dal;
+  k.s.sched = g->by_s.sched; k.s.halo = g->by_s.halo; k.s.slots = g->by_s.slots; k.s.xpos = g->by_s.xpos; k.s.xpad = a.xpad;
+  k.s.n_tiles = ps.n_tiles; k.s.dx = nullptr; k.s.slab_dw = a.slab_dw; k.s.slab_u = a.slab_u;
+  k.y = gat_sync(ps);
+  {
+    const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
+    if (fa && fa[0] == '1') hipLaunchKernelGGL(gat_set_word_kernel, dim3(1), dim3(64), 0, stream, k.y.abort_word, 1u);
+  }
+  k.n_steps = a.n_steps; k.S = a.S; k.xs = a.xs; k.yz = ident ? nullptr : a.yz; k.alpha = a.alpha; k.duT = a.duT; k.lam = a.lam;
+  k.ubar = a.ubar; k.dzbuf = a.dzbuf; k.dscore = a.dscore; k.slab_db = a.slab_db; k.row_elems = (size_t)g->n_nodes * GD;
+  k.alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * a.heads; k.dscore_elems = gat_node_dscore_elems(g); k.cb = a.cb;
+  NGPDE_REQUIRE(ident || a.yz, NGPDE_ERR_INVALID_ARGUMENT, "persistent GAT adjoint: the saved y / z rows are missing");
+  const dim3 grid(ps.n_tiles), block(kThreads);
+  switch (a.heads) {
+    case 1: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<1>) break;
+    case 2: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<2>) break;
+    default: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<4>) break;
+  }
+#undef NGPDE_GN_LAUNCH
+  NGPDE_LAUNCH_CHECK("gat_node_bwd_persistent_kernel");
+  hipLaunchKernelGGL(gat_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.y.abort_word, ps.fault);
+  hipLaunchKernelGGL(gat_layer_reduce_kernel, dim3(67), dim3(1024), 0, stream, a.slab_dw, ps.n_tiles, a.slab_db, ps.n_tiles, a.slab_u, a.dwt,
+                     a.db, a.da);
+  NGPDE_LAUNCH_CHECK("gat_layer_reduce_kernel");
+  return persistent_turnstile_leave(stream, dev);
 }
 
 }  // namespace ngpde

@@ -129,7 +129,8 @@ __device__ __forceinline__ void load_sched(const int4 *__restrict__ sched, int t
 // 64 / LPR groups stage consecutive halo slots, so its 1 KiB lands contiguously at Xh4[hh * LPR + q]).  No VGPR round trip
 // and no ds_write_b128 (13 cycles per wave-instruction on the store path: two workgroups' 25 KB cost ~650 cycles there).
 // Only for rows that need no scaling on the way in (PRE: the producer stored them already multiplied by c[node]).
-template <int D, bool DMA>
+// AUX: cache-policy bits of the DMA (16 = sc1: rows another workgroup of THIS launch stored write-through, gat persistent solver)
+template <int D, bool DMA, int AUX = 0>
 __device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q, int grp, float *ldsXh, HaloRegs<D> &h) {
   using G = Geo<D>;
 #pragma unroll
@@ -140,7 +141,7 @@ __device__ __forceinline__ void halo_round2(const float4 *__restrict__ X4, int q
         const unsigned off = (unsigned)h.he[k].x * (unsigned)(G::LPR * 16) + (unsigned)(q * 16);
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X4) + off),
-            (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsXh) + hh * G::LPR + q), 16, 0, 0);
+            (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(ldsXh) + hh * G::LPR + q), 16, 0, AUX);
       }
     } else {
       h.hv[k] = load_row4<G::LPR>(X4, h.he[k].x, q);

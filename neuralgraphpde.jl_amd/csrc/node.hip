@@ -748,4 +748,160 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   return NGPDE_OK;
 }
 
+
+/* ---- GAT-style layer as right-hand side: device-resident solve + discrete adjoint (gat_fused.hip) ---------------------------- */
+struct ngpde_node_gat {
+  const ngpde_graph *g = nullptr;
+  int heads = 0, c = 0, act = 0, S = 0, n_steps = 0;
+  float slope = 0.2f;
+  bool with_bwd = false, solved = false;
+  NodePersist persist;
+  float *cf = nullptr, *cb = nullptr;       // device coefficient tables [(S + 1)][8], [S][8]
+  float *xs = nullptr, *yz = nullptr, *alpha = nullptr, *kbuf = nullptr;
+  float *ubar = nullptr, *dzbuf = nullptr, *dscore = nullptr, *dal = nullptr, *slabs = nullptr;
+  int *xpad = nullptr;
+  size_t tape_bytes = 0, row_elems = 0, alpha_elems = 0;
+};
+
+static void node_gat_free(ngpde_node_gat *p) {
+  if (!p) return;
+  void *bufs[] = {p->cf, p->cb, p->xs, p->yz, p->alpha, p->kbuf, p->ubar, p->dzbuf, p->dscore, p->dal, p->slabs, p->xpad};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  node_persistent_free(&p->persist);
+  delete p;
+}
+
+int32_t ngpde_node_gat_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c) {
+  return (g && din == 64 && gat_node_persistent_supported(g, heads, c)) ? 1 : 0;
+}
+
+int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, int32_t act, int32_t tableau,
+                              int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(g != nullptr && out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_create: NULL argument");
+  *out = nullptr;
+  NGPDE_REQUIRE(tableau == NGPDE_TABLEAU_EULER || tableau == NGPDE_TABLEAU_TSIT5, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_node_gat_create: unknown tableau %d", tableau);
+  NGPDE_REQUIRE(n_steps >= 1 && act >= NGPDE_ACT_IDENTITY && act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_node_gat_create: n_steps >= 1 and a known activation required (got %d, %d)", n_steps, act);
+  NGPDE_REQUIRE(gat_node_persistent_supported(g, heads, c), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_node_gat_create: needs 64 => heads x c = 64 with heads in {1, 2, 4}, tiles that fit the LDS halo in both directions "
+                "and at most as many tiles as the device keeps resident (use the generic solver otherwise)");
+  ngpde_node_gat *p = new (std::nothrow) ngpde_node_gat();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_create: out of host memory");
+  p->g = g; p->heads = heads; p->c = c; p->act = act; p->slope = negative_slope; p->n_steps = n_steps; p->with_bwd = with_backward != 0;
+  const Tableau tb = make_tableau(tableau);
+  p->S = tb.S;
+  const int S = tb.S;
+  // the coefficients exactly as the generic solver passes them to ngpde_rk_stage_combine: float(dt * a_ij) formed in double
+  std::vector<float> cf((size_t)(S + 1) * 8, 0.f), cb((size_t)S * 8, 0.f);
+  for (int i = 0; i < S; ++i) {
+    for (int j = 0; j < i; ++j) cf[(size_t)i * 8 + j] = (float)(dt * tb.a[i][j]);
+    cf[(size_t)S * 8 + i] = (float)(dt * tb.b[i]);
+    cb[(size_t)i * 8 + i] = (float)(dt * tb.b[i]);
+    for (int j = i + 1; j < S; ++j) cb[(size_t)i * 8 + j] = (float)(dt * tb.a[j][i]);
+  }
+  p->row_elems = (size_t)g->n_nodes * 64;
+  p->alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * heads;
+  const size_t phases = (size_t)n_steps * S, nt = (size_t)g->n_sched / kTileRows;
+  auto alloc = [&](auto **ptr, size_t bytes) -> int32_t {
+    NGPDE_HIP_CHECK(hipMalloc((void **)ptr, std::max<size_t>(bytes, 256)));
+    return NGPDE_OK;
+  };
+  int32_t st = NGPDE_OK;
+  const float coef_unused[90] = {0.f};
+  auto step = [&](int32_t r) { if (st == NGPDE_OK) st = r; };
+  step(node_persistent_setup(g, coef_unused, &p->persist, false));
+  if (st == NGPDE_OK) step(alloc(&p->cf, cf.size() * 4));
+  if (st == NGPDE_OK) step(alloc(&p->cb, std::max<size_t>(cb.size(), 64) * 4));
+  if (st == NGPDE_OK) step(alloc(&p->kbuf, (size_t)S * p->row_elems * 4));
+  if (st == NGPDE_OK) step(alloc(&p->xs, (p->with_bwd ? phases : 2) * p->row_elems * 4));
+  p->tape_bytes = (p->with_bwd ? phases : 2) * p->row_elems * 4;
+  if (st == NGPDE_OK && p->with_bwd) {
+    if (act != NGPDE_ACT_IDENTITY) { step(alloc(&p->yz, phases * p->row_elems * 4)); p->tape_bytes += phases * p->row_elems * 4; }
+    if (st == NGPDE_OK) step(alloc(&p->alpha, phases * p->alpha_elems * 4));
+    p->tape_bytes += phases * p->alpha_elems * 4;
+    if (st == NGPDE_OK) step(alloc(&p->ubar, (size_t)S * p->row_elems * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dzbuf, 2 * p->row_elems * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dscore, 2 * gat_node_dscore_elems(g) * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dal, (size_t)g->n_nodes * heads * 4));
+    if (st == NGPDE_OK) step(alloc(&p->slabs, nt * (64 * 64 + 64 + 128) * 4));
+    if (st == NGPDE_OK) step(alloc(&p->xpad, (size_t)std::max<int64_t>(g->n_edges, 1) * 4));
+    if (st == NGPDE_OK) {
+      int *scratch = nullptr;
+      step(alloc(&scratch, (size_t)std::max<int64_t>(g->n_edges, 1) * 4));
+      if (st == NGPDE_OK) step(launch_gat_node_xpad(g, scratch, p->xpad, nullptr));
+      if (st == NGPDE_OK && hipStreamSynchronize(nullptr) != hipSuccess) st = NGPDE_ERR_HIP;
+      if (scratch) (void)hipFree(scratch);
+    }
+  }
+  if (st == NGPDE_OK && (hipMemcpy(p->cf, cf.data(), cf.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                         hipMemcpy(p->cb, cb.data(), cb.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+    last_error() = "ngpde_node_gat_create: copying the coefficient tables failed";
+    st = NGPDE_ERR_HIP;
+  }
+  if (st != NGPDE_OK) {
+    const std::string keep = last_error();
+    node_gat_free(p);
+    last_error() = keep;
+    return st;
+  }
+  *out = p;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_gat_destroy(ngpde_node_gat_t *p) {
+  NGPDE_RANGE();
+  node_gat_free(p);
+  return NGPDE_OK;
+}
+
+size_t ngpde_node_gat_tape_bytes(const ngpde_node_gat_t *p) { return p ? p->tape_bytes : 0; }
+
+int32_t ngpde_node_gat_fault(ngpde_node_gat_t *p, ngpde_stream_t stream_, int32_t *fault) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_fault: NULL argument");
+  NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  *fault = (p->persist.fault_host && *p->persist.fault_host) ? 1 : 0;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_gat_forward(ngpde_node_gat_t *p, const float *u0, const float *weight, const float *a, const float *bias, float *uT,
+                               ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_forward: plan is NULL");
+  if (p->g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(u0 && weight && a && uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_forward: NULL argument");
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_gat_forward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_gat_fault); destroy the plan");
+  hipStream_t stream = (hipStream_t)stream_;
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->xs, u0, p->row_elems * 4, hipMemcpyDeviceToDevice, stream));   // slot 0 = the input of phase 1
+  GatNodeFwd f;
+  f.g = p->g; f.ps = &p->persist; f.heads = p->heads; f.act = p->act; f.n_steps = p->n_steps; f.S = p->S; f.slope = p->slope;
+  f.taped = p->with_bwd; f.u_in = u0; f.wt = weight; f.a = a; f.bias = bias; f.u_out = uT; f.xs = p->xs; f.yz = p->yz; f.alpha = p->alpha;
+  f.kbuf = p->kbuf; f.cf = p->cf;
+  const int32_t st = launch_gat_node_fwd(f, stream);
+  if (st == NGPDE_OK) p->solved = true;
+  return st;
+}
+
+int32_t ngpde_node_gat_backward(ngpde_node_gat_t *p, const float *weight, const float *a, const float *duT, float *du0, float *dweight,
+                                float *da, float *dbias, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_backward: plan is NULL");
+  NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_gat_backward: the plan was created without a backward pass");
+  NGPDE_REQUIRE(p->solved, NGPDE_ERR_STATE, "ngpde_node_gat_backward: no forward solve has filled the tape");
+  NGPDE_REQUIRE(weight && a && duT && du0 && dweight && da, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_backward: NULL argument");
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_gat_backward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_gat_fault); destroy the plan");
+  const size_t nt = (size_t)p->g->n_sched / kTileRows;
+  GatNodeBwd b;
+  b.g = p->g; b.ps = &p->persist; b.heads = p->heads; b.act = p->act; b.n_steps = p->n_steps; b.S = p->S; b.slope = p->slope;
+  b.wt = weight; b.a = a; b.xs = p->xs; b.yz = p->yz; b.alpha = p->alpha; b.duT = duT; b.lam = du0; b.ubar = p->ubar; b.dzbuf = p->dzbuf;
+  b.dscore = p->dscore; b.dal = p->dal; b.slab_dw = p->slabs; b.slab_db = p->slabs + nt * 64 * 64; b.slab_u = b.slab_db + nt * 64;
+  b.xpad = p->xpad; b.cb = p->cb; b.dwt = dweight; b.da = da; b.db = dbias;
+  return launch_gat_node_bwd(b, (hipStream_t)stream_);
+}
+
 }  // extern "C"

@@ -1386,6 +1386,10 @@ int32_t turnstile_leave(hipStream_t stream, int dev) {
 }
 }  // namespace
 
+// (for the other persistent solver, gat_fused.hip)
+int32_t persistent_turnstile_enter(hipStream_t stream, int *dev_out) { return turnstile_enter(stream, dev_out); }
+int32_t persistent_turnstile_leave(hipStream_t stream, int dev) { return turnstile_leave(stream, dev); }
+
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;

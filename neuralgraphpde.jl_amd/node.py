@@ -20,6 +20,7 @@ import torch
 from . import _lib
 from .graphs import GNNGraph
 from .layers import AbstractExplicitLayer, Chain, GCNConv, rows_of
+from .layers_mp import GATConv
 
 _TSIT5_A = [
     [],
@@ -130,6 +131,83 @@ class _NodeGCN2Fn(torch.autograd.Function):
         _lib.check(lib.ngpde_node_gcn2_backward(ctx.plan.ptr, _lib.ptr(duT), _lib.ptr(du0), _lib.ptr(dw1), _lib.ptr(db1),
                                                 _lib.ptr(dw2), _lib.ptr(db2), _lib.current_stream()))
         return du0, dw1, db1, dw2, db2, None
+
+
+class _GatPlan:
+    """Device-resident solve + discrete adjoint with ONE GAT-style layer as the right-hand side (ngpde_node_gat_*): two persistent
+    launches.  Holds the tape of ONE solve (stage inputs, y / z rows, attention coefficients)."""
+
+    def __init__(self, handle, heads, c, slope, act, tableau, n_steps, dt, with_backward):
+        self.lib = _lib.load()
+        _lib.flush_destroy()
+        self.handle = handle
+        self.ptr = None
+        self.gen = 0
+        out = C.c_void_p()
+        _lib.check(self.lib.ngpde_node_gat_create(handle.ptr, int(heads), int(c), float(slope), int(act), _lib.TABLEAU[tableau],
+                                                  int(n_steps), float(dt), int(with_backward), C.byref(out)))
+        self.ptr = out
+
+    def tape_bytes(self):
+        return int(self.lib.ngpde_node_gat_tape_bytes(self.ptr))
+
+    def flags(self):
+        return {"persistent_fwd", "persistent_bwd", "gat"}
+
+    def fault(self):
+        f = C.c_int32()
+        _lib.check(self.lib.ngpde_node_gat_fault(self.ptr, _lib.current_stream(), C.byref(f)))
+        return bool(f.value)
+
+    def claim(self):
+        self._token = _Token()
+        self._token_ref = weakref.ref(self._token)
+        token, self._token = self._token, None
+        self._pending = True
+        return token
+
+    def busy(self):
+        ref = getattr(self, "_token_ref", None)
+        return ref is not None and ref() is not None and getattr(self, "_pending", False)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.destroy_later("ngpde_node_gat_destroy", self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _NodeGatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, wt, a, bias, plan):
+        lib = _lib.load()
+        u, wt, a = u.contiguous(), wt.contiguous(), a.contiguous()
+        uT = torch.empty_like(u)
+        _lib.check(lib.ngpde_node_gat_forward(plan.ptr, _lib.ptr(u), _lib.ptr(wt), _lib.ptr(a), _lib.ptr(bias), _lib.ptr(uT),
+                                              _lib.current_stream()))
+        plan.gen += 1
+        ctx.plan, ctx.gen, ctx.token = plan, plan.gen, plan.claim()
+        ctx.save_for_backward(wt, a)
+        ctx.has_bias, ctx.shape = bias is not None, u.shape
+        return uT
+
+    @staticmethod
+    def backward(ctx, duT):
+        lib = _lib.load()
+        plan = ctx.plan
+        if ctx.gen != plan.gen:
+            raise _lib.NgpdeError(_lib.ERR_STATE, "NeuralODE: another forward solve has replaced this solve's tape")
+        wt, a = ctx.saved_tensors
+        dev = wt.device
+        du0 = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+        dwt, da = torch.empty_like(wt), torch.empty_like(a)
+        db = torch.empty((wt.shape[1],), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        _lib.check(lib.ngpde_node_gat_backward(plan.ptr, _lib.ptr(wt), _lib.ptr(a), _lib.ptr(duT.contiguous()), _lib.ptr(du0),
+                                               _lib.ptr(dwt), _lib.ptr(da), _lib.ptr(db), _lib.current_stream()))
+        plan._pending = False
+        return du0, dwt, da, db, None
 
 
 # ---- any right-hand side: explicit RK stepping with every combination as ONE library launch ---------------------------------
@@ -443,6 +521,36 @@ class NeuralODE(AbstractExplicitLayer):
         pool.append(plan)
         return plan
 
+    def gat_plan_for(self, ps, st, u):
+        """the device-resident plan when the right-hand side is ONE GAT-style layer in the one-launch shape (64 => heads x c = 64,
+        concat, tiles fit the LDS halo) and the library takes it (ngpde_node_gat_supported); None otherwise"""
+        m = self.model
+        if not (isinstance(m, GATConv) and m.concat and u.is_cuda and m.in_chs == 64 and m.heads * m.out_chs == 64):
+            return None
+        g = st["graph"]
+        handle = m._graph(g).handle()
+        if not _lib.load().ngpde_node_gat_supported(handle.ptr, 64, m.heads, m.out_chs):
+            return None
+        with_backward = torch.is_grad_enabled() and (u.requires_grad or any(
+            isinstance(v, torch.Tensor) and v.requires_grad for v in ps.values()))
+        key = ("gat", id(handle), m.heads, m.act, m.negative_slope, bool(with_backward))
+        pool = self._plans.get(key)
+        if pool is None:
+            pool = self._plans[key] = []
+            while len(self._plans) > self.max_plans:
+                self._plans.pop(next(iter(self._plans)))
+        else:
+            self._plans[key] = self._plans.pop(key)
+        for plan in pool:
+            if not (with_backward and plan.busy()):
+                return plan
+        if len(pool) >= self.max_outstanding:
+            raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
+                                                  "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
+        plan = _GatPlan(handle, m.heads, m.out_chs, m.negative_slope, m.act, self.solver, self.n_steps, self.dt, with_backward)
+        pool.append(plan)
+        return plan
+
     def __call__(self, x, ps, st):
         u = rows_of(x)
         needs_grad = torch.is_grad_enabled() and (u.requires_grad or any(
@@ -455,6 +563,11 @@ class NeuralODE(AbstractExplicitLayer):
             b1 = p1["bias"].reshape(-1) if "bias" in p1 else None
             b2 = p2["bias"].reshape(-1) if "bias" in p2 else None
             uT = _NodeGCN2Fn.apply(u, rows_of(p1["weight"]), b1, rows_of(p2["weight"]), b2, plan)
+            return uT.T, st
+        gplan = self.gat_plan_for(ps, st, u)
+        if gplan is not None:
+            b = ps["bias"].reshape(-1) if "bias" in ps else None
+            uT = _NodeGatFn.apply(u, rows_of(ps["weight"]), rows_of(ps["a"]), b, gplan)
             return uT.T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch
