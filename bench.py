@@ -304,9 +304,29 @@ def secondary(dev, world, rank, dist):
             uT, _ = nodeg(xg, psg, stg)
             uT.sum().backward()
         ms_node = _time_ms(solve, 5)
+        gplans = [p for pool in nodeg._plans.values() for p in pool]
+        resident = bool(gplans) and all("gat" in p.flags() for p in gplans)
         out["C3_gat_node_tsit5x50"] = {"ms_solve_forward_backward": round(ms_node, 3), "value": round(ODE_STEPS / (ms_node * 1e-3), 1),
-                                       "unit": "ODE-steps/s", "path": "NeuralODE(GATConv, capture=True): HIP-graph replay of the generic solver",
+                                       "unit": "ODE-steps/s",
+                                       "path": ("NeuralODE(GATConv): device-resident solver, one persistent launch per direction (ngpde_node_gat_*)"
+                                                if resident else "NeuralODE(GATConv, capture=True): HIP-graph replay of the generic solver"),
+                                       "fault": any(p.fault() for p in gplans) if resident else False,
                                        "rhs_evals_per_ode_step": 6}
+        if resident:      # the generic solver (every stage the one-launch layer, captured into HIP graphs) on the same workload
+            os.environ["NGPDE_NO_PERSISTENT"] = "1"
+            try:
+                nodeg2 = ng.NeuralODE(lg, solver="tsit5", n_steps=ODE_STEPS, dt=DT, capture=True)
+
+                def solve2():
+                    for v in [xg] + _grad_leaves(psg):
+                        v.grad = None
+                    uT, _ = nodeg2(xg, psg, stg)
+                    uT.sum().backward()
+                ms2 = _time_ms(solve2, 5)
+                out["C3_gat_node_tsit5x50"]["generic_captured_ms"] = round(ms2, 3)
+                out["C3_gat_node_tsit5x50"]["generic_captured_value"] = round(ODE_STEPS / (ms2 * 1e-3), 1)
+            finally:
+                os.environ.pop("NGPDE_NO_PERSISTENT", None)
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import ngpde_amd as ng
+from ngpde_amd import synth as S
 from oracle import ngpde_oracle as O
 from ngpde_amd import _lib
 
@@ -928,6 +929,104 @@ def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps, monkeypatch)
     with torch.no_grad():
         uT2, _ = node(u0, ps, st)
     assert torch.equal(uT2, uT.detach())
+
+
+@pytest.mark.parametrize("heads,act,bias,loops,solver,steps", [(4, "relu", True, True, "tsit5", 3), (4, "tanh", True, True, "tsit5", 2),
+                                                               (2, "identity", False, True, "tsit5", 2), (1, "swish", True, True, "euler", 4),
+                                                               (2, "relu", True, False, "tsit5", 2), (4, "leakyrelu", True, True, "euler", 1)])
+def test_gat_device_resident_solver_equals_the_generic_solver(heads, act, bias, loops, solver, steps, monkeypatch):
+    # NeuralODE(GATConv 64 => heads x c = 64) on a graph whose tiles fit the LDS halo: ngpde_node_gat_* -- ONE persistent launch for the
+    # solve, ONE for the discrete adjoint, tiles synchronised by per-tile phase flags -- against the generic solver (every stage
+    # the one-launch layer, every combination ngpde_rk_stage_combine; NGPDE_NO_PERSISTENT=1).  Same per-tile code, same
+    # coefficients, same order: u(T) and du0 bit for bit; parameter gradients to rounding (summed per tile over the whole adjoint).
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    n, C_ = 700, 64 // heads
+    s, t = _local_graph(n, 90 + heads)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, C_), act, heads=heads, concat=True, add_self_loops=loops, bias=bias, initialgraph=g)
+    ps0, _ = ng.setup(91, l)
+    ps0 = prep(ps0, 91)
+    u0 = torch.randn(64, n, device=DEV)
+    R = torch.randn(64, n, device=DEV)
+
+    def run(resident):
+        if resident:
+            monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+        else:
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        node = ng.NeuralODE(l, solver=solver, n_steps=steps, dt=0.05)
+        _, st = ng.setup(91, node)
+        ps = {k: v.detach().clone().requires_grad_(True) for k, v in ps0.items()}
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * R).sum().backward()
+        plans = [p for pool in node._plans.values() for p in pool]
+        with torch.no_grad():
+            uT2, _ = node(u, ps, st)             # forward-only plan (two ping-pong slots instead of a tape)
+        assert torch.equal(uT2, uT.detach())
+        return uT.detach(), u.grad, {k: v.grad for k, v in ps.items()}, plans
+
+    a = run(True)
+    assert a[3] and all("gat" in p.flags() and not p.fault() for p in a[3]), [p.flags() for p in a[3]]
+    b = run(False)
+    assert not b[3]
+    assert torch.equal(a[0], b[0]), "u(T)"
+    assert torch.equal(a[1], b[1]), "du0"
+    for k in a[2]:
+        close(a[2][k], b[2][k].cpu().double().numpy(), rtol=2e-5, atol=1e-5, what=k)
+
+
+def test_gat_device_resident_solver_replays_are_bit_identical_at_c3_size(monkeypatch):
+    # the race screen: 12 solves + adjoints of BASELINE config 3 as ODE right-hand side (512 tiles, 50 Tsit5 steps = 300 hand-offs
+    # per direction), every output of every replay equal to the first, bit for bit; no launch gave up waiting
+    monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    _, s, t = S.closest_pairs_graph(16384, 65536, seed=2)
+    g = ng.GNNGraph(s, t, num_nodes=16384, index_base=0)
+    l = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+    node = ng.NeuralODE(l, solver="tsit5", n_steps=50, dt=0.02)
+    ps, st = ng.setup(5, node)
+    ps = prep(ps, 5)
+    u = torch.randn(64, 16384, device=DEV, requires_grad=True)
+    first = None
+    for rep in range(12):
+        for v in list(ps.values()) + [u]:
+            v.grad = None
+        uT, _ = node(u, ps, st)
+        uT.sum().backward()
+        got = [uT.detach().clone(), u.grad.clone()] + [ps[k].grad.clone() for k in sorted(ps)]
+        if first is None:
+            first = got
+            assert all(bool(torch.isfinite(x).all()) for x in got)
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(got, first)), f"replay {rep} differs"
+    plans = [p for pool in node._plans.values() for p in pool]
+    assert plans and all("gat" in p.flags() and not p.fault() for p in plans)
+
+
+def test_gat_device_resident_solver_abort_poisons_outputs_and_the_plan_refuses_further_work(monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    n = 700
+    s, t = _local_graph(n, 95)
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+    node = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05)
+    ps, st = ng.setup(95, node)
+    ps = prep(ps, 95)
+    u = torch.randn(64, n, device=DEV)
+    monkeypatch.setenv("NGPDE_DEBUG_FORCE_ABORT", "1")
+    with torch.no_grad():
+        uT, _ = node(u, ps, st)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("NGPDE_DEBUG_FORCE_ABORT")
+    plans = [p for pool in node._plans.values() for p in pool]
+    assert plans and plans[0].fault()
+    assert bool(torch.isnan(uT).all())
+    with pytest.raises(ng._lib.NgpdeError) as e:
+        with torch.no_grad():
+            node(u, ps, st)
+    assert e.value.code == ng._lib.ERR_STATE and "gave up waiting" in str(e.value)
 
 
 def test_captured_generic_solve_replays_and_follows_parameter_updates(monkeypatch):
