@@ -117,10 +117,14 @@ unsigned long long *g_gat_stamps = nullptr;
 #define NGPDE_GST(k) do { if (threadIdx.x == 0 && p.stamps) { p.stamps[(size_t)blockIdx.x * 16 + (k)] = clock64(); if ((k) == 0 || (k) == 10) p.stamps[(size_t)blockIdx.x * 16 + 11 + (k) / 10] = wall_clock64(); } } while (0)
 #define NGPDE_GST_FIELD unsigned long long *stamps;
 #define NGPDE_GST_SET(kk) kk.stamps = g_gat_stamps;
+#define NGPDE_GSTP(ptr, k) do { if (threadIdx.x == 0 && (ptr)) (ptr)[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#define NGPDE_GSTP_OF(kk) (kk).stamps
 #else
 #define NGPDE_GST(k)
 #define NGPDE_GST_FIELD
 #define NGPDE_GST_SET(kk)
+#define NGPDE_GSTP(ptr, k)
+#define NGPDE_GSTP_OF(kk) nullptr
 #endif
 
 struct GatFwdK {
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
 // pullback, by target:  dz, d alpha, softmax / leakyrelu pullback -> dscore, dal, db slabs
 // ---------------------------------------------------------------------------------------------------
 struct GatBwdTK {
+  NGPDE_GST_FIELD
   const float *x, *wt, *dy, *yz, *alpha;
   const int4 *sched;
   const int2 *halo;
@@ -446,6 +451,7 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
   if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
   *reinterpret_cast<float4 *>(&ldsDZ[grp * GG::TS + 4 * q]) = dz;
   __syncthreads();
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 7);
   float db_part;
   {   // db partial: column sums of the dz tile (8 adjacent lanes hold row-partials of one column)
     const int dbc = tid / GG::DBP, dbpart = tid % GG::DBP;
@@ -477,6 +483,7 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
     }
   }
   __syncthreads();
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 8);
   // d alpha of every entry of the row: <dA_k[i], x_s> per head, reduced over the group's 16 lanes; the lane that owns the
   // entry keeps it
   float4 dar[H];
@@ -501,6 +508,7 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
       }
     }
   }
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 9);
   // softmax pullback: dlogit = alpha (d alpha - sum alpha d alpha); leakyrelu' by the saved sign
   float dsc[2][4], dalv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -555,6 +563,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_bwd_target_kernel(const
 // pullback, by source:  dWx = sum alpha dz[t] + dal a_l + dar a_r;  dx = dWx W^T;  dW, u_l, u_r slabs
 // ---------------------------------------------------------------------------------------------------
 struct GatBwdSK {
+  NGPDE_GST_FIELD
   const float *gz, *x, *wt, *a, *alpha, *dscore, *dal;
   const int4 *sched;
   const int2 *halo;
@@ -637,7 +646,9 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
   float dalv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) dalv[k] = __shfl(dalq, k, GG::LPR);
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 10);
   __syncthreads();   // staged dz rows visible (coefficients are group-private, same wave)
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 11);
   float4 g = f4_zero();
   {
     const int wmax = wave_max_deg(deg);
@@ -659,7 +670,9 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
   *reinterpret_cast<float4 *>(&ldsXT[grp * GG::TS + 4 * q]) = xo;
   if (q < 4) ldsDD[grp * 8 + q] = ok ? sel4(dalv, q) : 0.f;
   else if (q < 8) ldsDD[grp * 8 + q] = ok ? sel4(darv, q - 4) : 0.f;
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 12);
   __syncthreads();   // tiles complete, staged rows dead
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 13);
   mfma_rows_times_bt<GD>(ldsDWX, ldsBt, ldsXh, wave_u, lane);
   {   // dWt[i][o] += sum_n x[n][i] dWx[n][o]
     const int i = lane & 15, kq = lane >> 4;
@@ -674,6 +687,7 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
       }
     }
   }
+  NGPDE_GSTP(NGPDE_GSTP_OF(p), 14);
   {   // u_which,k[i] += sum_n (dal | dar)[n][k] x[n][i]
     const int which = tid >> 8, hk = (tid >> 6) & 3, i = tid & 63;
 #pragma unroll 8
@@ -895,9 +909,11 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
   for (int n = 0; n < p.n_steps && !dead; ++n) {
     for (int i = 0; i < S; ++i) {
       ++ph;
+      NGPDE_GSTP(NGPDE_GSTP_OF(l), 0);
       const size_t e = ph - 1;
       const float *X = p.xs + (p.taped ? e : (e & 1)) * p.row_elems;
       if (!gat_wait(p.s, t, my_nbr, ph - 1, &s_ok)) { dead = true; break; }
+      NGPDE_GSTP(NGPDE_GSTP_OF(l), 13);
       halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
       l.alpha = p.alpha ? p.alpha + e * p.alpha_elems : nullptr;
       const float4 z = gat_fwd_compute<H>(l, L, t, m, breg, b4);
@@ -915,13 +931,16 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
         if (last) gat_st4(p.u_out, own, v);
         else gat_store_sc1(p.xs + (p.taped ? e + 1 : ((e + 1) & 1)) * p.row_elems, own, v);
       }
+      NGPDE_GSTP(NGPDE_GSTP_OF(l), 14);
       if (!last) gat_publish(p.s, t, tile, ph);
+      NGPDE_GSTP(NGPDE_GSTP_OF(l), 15);
     }
   }
   if (dead && ok) gat_st4(p.u_out, own, gat_nan4());
 }
 
 struct GatNodeBwdK {
+  NGPDE_GST_FIELD
   GatBwdTK t;           // wt, lists by target, n_tiles, act, slope, dal (x, alpha, dscore per phase; dy, yz, dz, slab_db unused)
   GatBwdSK s;           // wt, a, dal, lists by source, xpos, xpad, n_tiles, slab_dw, slab_u (gz, x, alpha, dscore per phase; dx unused)
   GatSync y;
@@ -976,6 +995,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(co
   for (int n = p.n_steps - 1; n >= 0 && !dead; --n) {
     for (int i = S - 1; i >= 0; --i) {
       ++ph;
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 0);
       const size_t e = (size_t)n * S + i;
       const float *X = p.xs + e * p.row_elems;
       // ---- by target.  K-bar_i = (dt b_i) lambda + sum_{j > i} (dt a_ji) U-bar_j, in ngpde_rk_stage_combine's order
@@ -989,20 +1009,26 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(co
       if (ok) gat_store_sc1(dzb, own, v);
       tk.alpha = p.alpha + e * p.alpha_elems;
       tk.dscore = p.dscore + (size_t)(ph & 1) * p.dscore_elems;
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 1);
       dbacc += gat_bwd_target_compute<H, true>(tk, LT, t, mt, tile, v);
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 2);
       gat_publish(p.y, t, tile, ph);
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 3);
       // ---- by source
       TileMeta ms;
       HaloRegs<GD> hrs;
       tile_meta_load(p.s.halo, p.s.slots, p.s.sched, tile, t.grp, t.q, hrs, ms);
       tile_meta_words(hrs, ms);
       gat_load_bt(p.s.wt, LS.Bt, t.tid);
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 4);
       if (!gat_wait(p.y, t, my_nbr, ph, &s_ok)) { dead = true; break; }
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 5);
       halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
       sk.x = X;
       sk.alpha = tk.alpha;
       sk.dscore = tk.dscore;
       const float4 dxv = gat_bwd_source_compute<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc);
+      NGPDE_GSTP(NGPDE_GSTP_OF(p), 6);
       if (i > 0) {
         if (ok) gat_st4(p.ubar + (size_t)i * p.row_elems, own, dxv);
       } else {   // lambda of the step before: 1 * lambda + sum_j 1 * U-bar_j, j ascending
@@ -1102,10 +1128,12 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
     t.x = x; t.wt = wt; t.dy = dy; t.yz = ident ? nullptr : yz; t.alpha = alpha; t.sched = g->by_t.sched; t.halo = g->by_t.halo;
     t.slots = g->by_t.slots; t.n_tiles = n_tiles; t.act = act; t.slope = slope; t.dz = ident ? nullptr : dz; t.dscore = dscore;
     t.dal = dal; t.slab_db = slab_db;
+    NGPDE_GST_SET(t)
     GatBwdSK s;
     s.gz = ident ? dy : dz; s.x = x; s.wt = wt; s.a = a; s.alpha = alpha; s.dscore = dscore; s.dal = dal; s.sched = g->by_s.sched;
     s.halo = g->by_s.halo; s.slots = g->by_s.slots; s.xpos = g->by_s.xpos; s.n_tiles = n_tiles; s.dx = dx; s.slab_dw = slab_dw;
     s.slab_u = slab_u; s.xpad = nullptr;
+    NGPDE_GST_SET(s)
     const dim3 block(kThreads);
     switch (heads) {
       case 1:
@@ -1250,6 +1278,9 @@ int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   k.s.sched = g->by_s.sched; k.s.halo = g->by_s.halo; k.s.slots = g->by_s.slots; k.s.xpos = g->by_s.xpos; k.s.xpad = a.xpad;
   k.s.n_tiles = ps.n_tiles; k.s.dx = nullptr; k.s.slab_dw = a.slab_dw; k.s.slab_u = a.slab_u;
   k.y = gat_sync(ps);
+  NGPDE_GST_SET(k)
+  NGPDE_GST_SET(k.t)
+  NGPDE_GST_SET(k.s)
   {
     const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
     if (fa && fa[0] == '1') hipLaunchKernelGGL(gat_set_word_kernel, dim3(1), dim3(64), 0, stream, k.y.abort_word, 1u);

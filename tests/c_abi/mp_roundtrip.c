@@ -249,6 +249,36 @@ int main(void) {
     for (int64_t i = 0; i < n * d; ++i) ref[i] = x[i] + 0.5f * y1[i] - 0.25f * y2[i];
     report("gat_layer_forward vs composition", max_rel(y1, y2, n * d), 1e-4);
     report("rk_stage_combine", max_rel(cb, ref, n * d), 1e-6);
+    /* the device-resident solver over the same layer (ngpde_node_gat_*): ONE Euler step of size dt is u + dt * layer(u), bit for
+     * bit what ngpde_rk_stage_combine makes of the layer's output; its adjoint of loss = sum(u(T)) must be finite */
+    if (ngpde_node_gat_supported(g2, d, heads, c)) {
+      const double dtg = 0.125;
+      ngpde_node_gat_t *gp = NULL;
+      CHECK_NG(ngpde_node_gat_create(g2, heads, c, 0.2f, NGPDE_ACT_RELU, NGPDE_TABLEAU_EULER, 1, dtg, 1, &gp));
+      float *uT_d = dev_copy(NULL, n * d), *eul_d = dev_copy(NULL, n * d), *du0_d = dev_copy(NULL, n * d), *dw_d = dev_copy(NULL, d * d),
+            *da_d = dev_copy(NULL, 2 * c * heads), *db_d = dev_copy(NULL, d);
+      float *ones = malloc(sizeof(float) * n * d);
+      for (int64_t i = 0; i < n * d; ++i) ones[i] = 1.0f;
+      float *ones_d = dev_copy(ones, n * d);
+      CHECK_NG(ngpde_node_gat_forward(gp, x_d, w_d, a_d, b_d, uT_d, NULL));
+      const float *t1[1] = {y1_d};
+      const float c1[1] = {(float)dtg};
+      CHECK_NG(ngpde_rk_stage_combine(n * d, 1.0f, x_d, 1, t1, c1, eul_d, NULL));
+      CHECK_NG(ngpde_node_gat_backward(gp, w_d, a_d, ones_d, du0_d, dw_d, da_d, db_d, NULL));
+      int32_t fault = 1;
+      CHECK_NG(ngpde_node_gat_fault(gp, NULL, &fault));
+      float *uT = host_copy(uT_d, n * d), *eul = host_copy(eul_d, n * d), *du0 = host_copy(du0_d, n * d), *dwh = host_copy(dw_d, d * d);
+      report("node_gat_forward (one Euler step) vs layer + combine", max_rel(uT, eul, n * d), 0.0);
+      int finite = !fault;
+      for (int64_t i = 0; i < n * d; ++i) finite &= isfinite(du0[i]) != 0;
+      for (int64_t i = 0; i < d * d; ++i) finite &= isfinite(dwh[i]) != 0;
+      report("node_gat_backward finite, no fault", finite ? 0.0 : 1.0, 0.5);
+      if (ngpde_node_gat_tape_bytes(gp) == 0) { fprintf(stderr, "node_gat: empty tape\n"); return 10; }
+      CHECK_NG(ngpde_node_gat_destroy(gp));
+    } else {
+      fprintf(stderr, "device-resident GAT solver not available on this graph\n");
+      return 11;
+    }
     CHECK_NG(ngpde_graph_destroy(g2));
   }
   /* ---- 5. node-level Dense layers of the edge-function layers at a streaming size: the pair (P, Q from one pass over h) and its

@@ -1031,6 +1031,7 @@ def test_gat_device_resident_solver_abort_poisons_outputs_and_the_plan_refuses_f
 
 def test_captured_generic_solve_replays_and_follows_parameter_updates(monkeypatch):
     monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")     # the GENERIC solver is the subject (a lone GATConv would take the device-resident one)
     # NeuralODE(..., capture=True): the whole stepping loop and the whole discrete adjoint are HIP graphs captured at the first
     # call; replays must reproduce the eager path bit for bit, for new inputs and after an in-place parameter update
     n, H, C_ = 300, 4, 16

@@ -5,7 +5,9 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ngpde_amd as ng
-from ngpde_amd import synth as S
+from ngpde_amd import synth as S, _lib
+if os.environ.get('NGPDE_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['NGPDE_LIB'])       # A/B runs of another build
 
 N = int(os.environ.get("N", 16384)); PAIRS = int(os.environ.get("PAIRS", 4 * N)); STEPS = int(os.environ.get("STEPS", 50))
 SOLVER = os.environ.get("SOLVER", "tsit5"); ACT = os.environ.get("ACT", "relu"); H = int(os.environ.get("HEADS", 4))
