@@ -452,6 +452,12 @@ int32_t ngpde_node_pipeline_stats(ngpde_node_t *plan, ngpde_stream_t stream, int
 int32_t ngpde_node_gat_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c);
 int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, int32_t act, int32_t tableau,
                               int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out);
+/* A block-diagonal batch of `members` identical structures (g is ONE member; test/runtests.jl:89-102): u0 / uT / duT / du0 are
+ * [members][N][64], the parameter gradients the sum over the members; two members at a time share a workgroup, one computing while
+ * the other's rows and flags travel. */
+int32_t ngpde_node_gat_create_batch(const ngpde_graph_t *g, int32_t members, int32_t heads, int32_t c, float negative_slope,
+                                    int32_t act, int32_t tableau, int32_t n_steps, double dt, int32_t with_backward,
+                                    ngpde_node_gat_t **out);
 int32_t ngpde_node_gat_destroy(ngpde_node_gat_t *plan);
 size_t ngpde_node_gat_tape_bytes(const ngpde_node_gat_t *plan);
 int32_t ngpde_node_gat_fault(ngpde_node_gat_t *plan, ngpde_stream_t stream, int32_t *fault);

@@ -126,6 +126,7 @@ SIGNATURES = {
     "ngpde_node_profile": (_i32, [_vp, _i32, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "ngpde_node_gat_supported": (_i32, [_vp, _i32, _i32, _i32]),
     "ngpde_node_gat_create": (_i32, [_vp, _i32, _i32, _f32, _i32, _i32, _i32, C.c_double, _i32, C.POINTER(_vp)]),
+    "ngpde_node_gat_create_batch": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, C.c_double, _i32, C.POINTER(_vp)]),
     "ngpde_node_gat_destroy": (_i32, [_vp]),
     "ngpde_node_gat_tape_bytes": (_sz, [_vp]),
     "ngpde_node_gat_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),

@@ -221,6 +221,8 @@ struct GatNodeFwd {
   const float *u_in = nullptr, *wt = nullptr, *a = nullptr, *bias = nullptr;
   float *u_out = nullptr, *xs = nullptr, *yz = nullptr, *alpha = nullptr, *kbuf = nullptr;
   const float *cf = nullptr;         // device table [(S + 1)][8]
+  int n_members = 1;                 // > 1: block-diagonal batch of identical structures; arrays [members][...] with the strides below
+  size_t xs_stride = 0, yz_stride = 0, alpha_stride = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 struct GatNodeBwd {
@@ -234,6 +236,8 @@ struct GatNodeBwd {
   const int *xpad = nullptr;
   const float *cb = nullptr;         // device table [S][8]
   float *dwt = nullptr, *da = nullptr, *db = nullptr;   // outputs (db nullable)
+  int n_members = 1;
+  size_t xs_stride = 0, yz_stride = 0, alpha_stride = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c);

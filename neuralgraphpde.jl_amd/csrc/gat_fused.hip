@@ -874,7 +874,85 @@ struct GatNodeFwdK {
   float *kbuf;          // [S][N][64]: stage derivatives of the current step (own rows)
   size_t row_elems, alpha_elems;
   const float *cf;      // [(S + 1)][8]: row i < S: coefficient of k_j in the input of stage i; row S: in the step update
+  // batches of identical structures (BATCH kernels): member mb reads u_in + mb * row_elems, owns xs / yz / alpha + mb * the
+  // strides below; two members at a time, slot sl = mb & 1 with its own flag words (s.flags + sl * flag_stride) and its own
+  // kbuf + sl * 7 * row_elems (rows 0..5: k_j, row 6: u of the current step)
+  int n_members;
+  size_t flag_stride, xs_stride, yz_stride, alpha_stride;
 };
+
+// BATCH: a block-diagonal batch of identical structures (test/runtests.jl:89-102), two members at a time per workgroup: while one
+// member's rows and flag travel to the neighbours the workgroup computes the other member's phase (the idea of node_persistent.hip's
+// two-slot kernels; here nothing but the accumulators lives in registers across phases, so the slots simply take turns).
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_batch_kernel(const GatNodeFwdK p) {
+  __shared__ __attribute__((aligned(16))) float ldsXh[kFwdXhF];
+  __shared__ __attribute__((aligned(16))) float ldsS[kFwdSF];
+  __shared__ __attribute__((aligned(16))) float ldsA[kFwdAF];
+  __shared__ __attribute__((aligned(16))) float ldsAr[kFwdArF];
+  __shared__ __attribute__((aligned(16))) float ldsV[kFwdVF];
+  __shared__ float ldsC[64];
+  __shared__ int s_ok;
+  const GatFwdLds L = {ldsXh, ldsS, ldsA, ldsAr, ldsV};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.l.n_tiles);
+  TileMeta m;
+  HaloRegs<GD> hr;
+  tile_meta_load(p.l.halo, p.l.slots, p.l.sched, tile, t.grp, t.q, hr, m);
+  tile_meta_words(hr, m);
+  float breg[4][4];
+  float4 b4;
+  gat_fwd_consts<H>(p.l, L, t, breg, b4);
+  if (t.tid < 64) ldsC[t.tid] = p.cf[t.tid];
+  if (t.tid == 0) s_ok = 1;
+  const int my_nbr = p.s.nbr[(size_t)tile * kGatNbrStride + t.lane];
+  const bool ok = m.sc.x >= 0;
+  const unsigned own = (unsigned)max(m.sc.x, 0) * (unsigned)(GD * 4) + (unsigned)(t.q * 16);
+  const int S = p.S;
+  const unsigned P = (unsigned)(p.n_steps * S);
+  GatFwdK l = p.l;
+  bool dead = false;
+  unsigned ph0 = 0;
+  __syncthreads();
+  for (int mb = 0; mb < p.n_members && !dead; mb += 2, ph0 += P) {
+    const int nsl = min(2, p.n_members - mb);
+    for (int sl = 0; sl < nsl; ++sl)   // u of the slot's member -> row 6 of the slot's scratch
+      if (ok) gat_st4(p.kbuf + (size_t)(sl * 7 + 6) * p.row_elems, own, gat_ld4(p.u_in + (size_t)(mb + sl) * p.row_elems, own));
+    for (int n = 0; n < p.n_steps && !dead; ++n) {
+      for (int i = 0; i < S && !dead; ++i) {
+        const unsigned lp = (unsigned)(n * S + i) + 1, ph = ph0 + lp;
+        const size_t e = lp - 1;
+        const bool last = lp == P;
+        for (int sl = 0; sl < nsl; ++sl) {
+          GatSync ys = p.s;
+          ys.flags = p.s.flags + (size_t)sl * p.flag_stride;
+          float *xs = p.xs + (size_t)(mb + sl) * p.xs_stride, *kb = p.kbuf + (size_t)sl * 7 * p.row_elems;
+          const float *X = xs + (p.taped ? e : (e & 1)) * p.row_elems;
+          if (!gat_wait(ys, t, my_nbr, lp > 1 ? ph - 1 : 0u, &s_ok)) { dead = true; break; }
+          halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
+          l.alpha = p.alpha ? p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems : nullptr;
+          const float4 z = gat_fwd_compute<H>(l, L, t, m, breg, b4);
+          const float4 y = f4_act(l.act, z);
+          if (p.yz && ok) gat_st4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
+          const int row = (i + 1 < S) ? i + 1 : S;
+          float4 v = f4_scale(1.0f, gat_ld4(kb + (size_t)6 * p.row_elems, own));
+          for (int j = 0; j < i; ++j) v = f4_fma(ldsC[row * 8 + j], gat_ld4(kb + (size_t)j * p.row_elems, own), v);
+          v = f4_fma(ldsC[row * 8 + i], y, v);
+          if (ok) {
+            if (i + 1 < S) gat_st4(kb + (size_t)i * p.row_elems, own, y);
+            else gat_st4(kb + (size_t)6 * p.row_elems, own, v);
+            if (last) gat_st4(p.u_out + (size_t)(mb + sl) * p.row_elems, own, v);
+            else gat_store_sc1(xs + (p.taped ? e + 1 : ((e + 1) & 1)) * p.row_elems, own, v);
+          }
+          if (!last) gat_publish(ys, t, tile, ph);
+          else __syncthreads();   // (the other slot's DMA must not land in rows this slot's waves still read)
+        }
+      }
+    }
+  }
+  if (dead && ok)
+    for (int mb = 0; mb < p.n_members; ++mb) gat_st4(p.u_out + (size_t)mb * p.row_elems, own, gat_nan4());
+}
 
 template <int H>
 __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(const GatNodeFwdK p) {
@@ -954,7 +1032,122 @@ struct GatNodeBwdK {
   float *slab_db;                 // [n_tiles][64]
   size_t row_elems, alpha_elems, dscore_elems;
   const float *cb;                // [S][8]: cb[i*8 + i] = dt b_i, cb[i*8 + j] (j > i) = dt a_ji
+  // batches (BATCH kernel): member mb owns xs / yz / alpha + mb * stride, duT / lam + mb * row_elems; slot sl = mb & 1 owns
+  // flags + sl * flag_stride, ubar + sl * 6 rows, dzbuf + sl * 2 rows arrays, dscore + sl * 2 blocks, dal + sl * dal_stride
+  int n_members;
+  size_t flag_stride, xs_stride, yz_stride, alpha_stride, dal_stride;
 };
+
+// BATCH adjoint: per phase, the by-target halves of both slots (each published as soon as its stores have drained), then the
+// by-source halves -- each slot's wait for its neighbours has the other slot's half in front of it.  lambda lives in p.lam (own
+// rows, same thread), the weight-gradient accumulators run on over slots and members.
+template <int H>
+__global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_batch_kernel(const GatNodeBwdK p) {
+  constexpr int C = GD / H;
+  __shared__ __attribute__((aligned(16))) float lds[kFwdXhF + kBwdSF + 2 * kBwdTileF + kBwdBtF + kBwdDDF];
+  __shared__ float ldsC[64];
+  __shared__ int s_ok;
+  float *ldsXh = lds;
+  const GatBwdTLds LT = {ldsXh, ldsXh + kFwdXhF, ldsXh + kFwdXhF + kBwdDZF};
+  float *o = ldsXh + kFwdXhF;
+  const GatBwdSLds LS = {ldsXh, o, o + kBwdSF, o + kBwdSF + kBwdTileF, o + kBwdSF + 2 * kBwdTileF, o + kBwdSF + 2 * kBwdTileF + kBwdBtF};
+  const GatThread t = gat_thread();
+  const int tile = xcd_tile(blockIdx.x, p.t.n_tiles);
+  if (t.tid < 64) ldsC[t.tid] = p.cb[t.tid];
+  if (t.tid == 0) s_ok = 1;
+  const int my_nbr = p.y.nbr[(size_t)tile * kGatNbrStride + t.lane];
+  const int hq = (4 * t.q) / C;
+  const float4 al4 = *reinterpret_cast<const float4 *>(p.s.a + (size_t)hq * 2 * C + (4 * t.q) % C);
+  const float4 ar4 = *reinterpret_cast<const float4 *>(p.s.a + (size_t)hq * 2 * C + C + (4 * t.q) % C);
+  constexpr int NT = GG::CT * GG::CT;
+  f32x4 dw[GG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) dw[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float uacc = 0.f, dbacc = 0.f;
+  const int node = p.t.sched[(size_t)tile * kTM + t.grp].x;
+  const bool ok = node >= 0;
+  const unsigned own = (unsigned)max(node, 0) * (unsigned)(GD * 4) + (unsigned)(t.q * 16);
+  const int S = p.S;
+  const unsigned P = (unsigned)(p.n_steps * S);
+  GatBwdTK tk = p.t;
+  GatBwdSK sk = p.s;
+  bool dead = false;
+  unsigned ph0 = 0;
+  __syncthreads();
+  for (int mb = 0; mb < p.n_members && !dead; mb += 2, ph0 += P) {
+    const int nsl = min(2, p.n_members - mb);
+    for (int sl = 0; sl < nsl; ++sl)
+      if (ok) gat_st4(p.lam + (size_t)(mb + sl) * p.row_elems, own, gat_ld4(p.duT + (size_t)(mb + sl) * p.row_elems, own));
+    unsigned lp = 0;
+    for (int n = p.n_steps - 1; n >= 0 && !dead; --n) {
+      for (int i = S - 1; i >= 0 && !dead; --i) {
+        ++lp;
+        const unsigned ph = ph0 + lp;
+        const size_t e = (size_t)n * S + i;
+        for (int sl = 0; sl < nsl; ++sl) {   // ---- by target
+          GatSync ys = p.y;
+          ys.flags = p.y.flags + (size_t)sl * p.flag_stride;
+          const float *X = p.xs + (size_t)(mb + sl) * p.xs_stride + e * p.row_elems;
+          float *lam = p.lam + (size_t)(mb + sl) * p.row_elems, *ub = p.ubar + (size_t)sl * 6 * p.row_elems;
+          TileMeta mt;
+          tile_meta(p.t.halo, p.t.slots, p.t.sched, X, tile, t.grp, t.q, ldsXh, mt);
+          float4 v = f4_scale(ldsC[i * 8 + i], ok ? gat_ld4(lam, own) : f4_zero());
+          for (int j = i + 1; j < S; ++j) v = f4_fma(ldsC[i * 8 + j], gat_ld4(ub + (size_t)j * p.row_elems, own), v);
+          if (p.yz) v = f4_mul(v, f4_dact(tk.act, gat_ld4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own)));
+          if (!ok) v = f4_zero();
+          float *dzb = p.dzbuf + (size_t)(sl * 2 + (ph & 1)) * p.row_elems;
+          if (ok) gat_store_sc1(dzb, own, v);
+          tk.alpha = p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems;
+          tk.dscore = p.dscore + (size_t)(sl * 2 + (ph & 1)) * p.dscore_elems;
+          tk.dal = p.t.dal + (size_t)sl * p.dal_stride;
+          dbacc += gat_bwd_target_compute<H, true>(tk, LT, t, mt, tile, v);
+          gat_publish(ys, t, tile, ph);
+        }
+        gat_load_bt(p.s.wt, LS.Bt, t.tid);   // (once per phase: the by-source half leaves it alone)
+        for (int sl = 0; sl < nsl; ++sl) {   // ---- by source
+          GatSync ys = p.y;
+          ys.flags = p.y.flags + (size_t)sl * p.flag_stride;
+          const float *X = p.xs + (size_t)(mb + sl) * p.xs_stride + e * p.row_elems;
+          float *lam = p.lam + (size_t)(mb + sl) * p.row_elems, *ub = p.ubar + (size_t)sl * 6 * p.row_elems;
+          const float *dzb = p.dzbuf + (size_t)(sl * 2 + (ph & 1)) * p.row_elems;
+          TileMeta ms;
+          HaloRegs<GD> hrs;
+          tile_meta_load(p.s.halo, p.s.slots, p.s.sched, tile, t.grp, t.q, hrs, ms);
+          tile_meta_words(hrs, ms);
+          if (!gat_wait(ys, t, my_nbr, ph, &s_ok)) { dead = true; break; }
+          halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
+          sk.x = X;
+          sk.alpha = p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems;
+          sk.dscore = p.dscore + (size_t)(sl * 2 + (ph & 1)) * p.dscore_elems;
+          sk.dal = p.s.dal + (size_t)sl * p.dal_stride;
+          const float4 dxv = gat_bwd_source_compute<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc);
+          if (i > 0) {
+            if (ok) gat_st4(ub + (size_t)i * p.row_elems, own, dxv);
+          } else {
+            float4 w = f4_scale(1.0f, ok ? gat_ld4(lam, own) : f4_zero());
+            w = f4_fma(1.0f, dxv, w);
+            for (int j = 1; j < S; ++j) w = f4_fma(1.0f, gat_ld4(ub + (size_t)j * p.row_elems, own), w);
+            if (ok) gat_st4(lam, own, w);
+          }
+        }
+      }
+    }
+  }
+  if (ok && dead)
+    for (int mb = 0; mb < p.n_members; ++mb) gat_st4(p.lam + (size_t)mb * p.row_elems, own, gat_nan4());
+  const float bad = __int_as_float(0x7fc00000);
+  float4 *slab4 = reinterpret_cast<float4 *>(p.s.slab_dw + (size_t)tile * GD * GD);
+#pragma unroll
+  for (int mm = 0; mm < GG::DWT; ++mm) {
+    const int t2 = t.wave_u + GG::WAVES * mm;
+    if (t2 < NT) slab4[t2 * 64 + t.lane] = dead ? gat_nan4() : make_float4(dw[mm][0], dw[mm][1], dw[mm][2], dw[mm][3]);
+  }
+  if (t.tid % GG::DBP == 0) p.slab_db[(size_t)tile * GD + t.tid / GG::DBP] = dead ? bad : dbacc;
+  __syncthreads();
+  gat_load_bt(p.s.wt, LS.Bt, t.tid);
+  __syncthreads();
+  gat_bwd_source_finish<H>(p.s.slab_u + (size_t)tile * 2 * GD, LS, t, dead ? bad : uacc);
+}
 
 template <int H>
 __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(const GatNodeBwdK p) {
@@ -1201,9 +1394,12 @@ bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c) {
     occ = std::min(occ, o);
   };
   switch (heads) {
-    case 1: take(gat_node_fwd_persistent_kernel<1>); take(gat_node_bwd_persistent_kernel<1>); break;
-    case 2: take(gat_node_fwd_persistent_kernel<2>); take(gat_node_bwd_persistent_kernel<2>); break;
-    default: take(gat_node_fwd_persistent_kernel<4>); take(gat_node_bwd_persistent_kernel<4>); break;
+    case 1: take(gat_node_fwd_persistent_kernel<1>); take(gat_node_bwd_persistent_kernel<1>);
+            take(gat_node_fwd_persistent_batch_kernel<1>); take(gat_node_bwd_persistent_batch_kernel<1>); break;
+    case 2: take(gat_node_fwd_persistent_kernel<2>); take(gat_node_bwd_persistent_kernel<2>);
+            take(gat_node_fwd_persistent_batch_kernel<2>); take(gat_node_bwd_persistent_batch_kernel<2>); break;
+    default: take(gat_node_fwd_persistent_kernel<4>); take(gat_node_bwd_persistent_kernel<4>);
+             take(gat_node_fwd_persistent_batch_kernel<4>); take(gat_node_bwd_persistent_batch_kernel<4>); break;
   }
   const int nt = g->n_sched / kTileRows;
   if (nt < 1 || nt > cus * occ) return false;
@@ -1247,14 +1443,24 @@ int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream) {
   k.n_steps = a.n_steps; k.S = a.S; k.taped = a.taped ? 1 : 0; k.u_in = a.u_in; k.u_out = a.u_out; k.xs = a.xs; k.yz = a.yz;
   k.alpha = a.alpha; k.kbuf = a.kbuf; k.row_elems = (size_t)g->n_nodes * GD; k.alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * a.heads;
   k.cf = a.cf;
+  k.n_members = a.n_members; k.flag_stride = (size_t)ps.n_tiles * 32; k.xs_stride = a.xs_stride; k.yz_stride = a.yz_stride;
+  k.alpha_stride = a.alpha_stride;
   const dim3 grid(ps.n_tiles), block(kThreads);
 #define NGPDE_GN_LAUNCH(KERNEL)                                                                                   \
   if (a.ev_start) hipExtLaunchKernelGGL(KERNEL, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);              \
   else hipLaunchKernelGGL(KERNEL, grid, block, 0, stream, k);
-  switch (a.heads) {
-    case 1: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<1>) break;
-    case 2: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<2>) break;
-    default: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<4>) break;
+  if (a.n_members > 1) {
+    switch (a.heads) {
+      case 1: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_batch_kernel<1>) break;
+      case 2: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_batch_kernel<2>) break;
+      default: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_batch_kernel<4>) break;
+    }
+  } else {
+    switch (a.heads) {
+      case 1: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<1>) break;
+      case 2: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<2>) break;
+      default: NGPDE_GN_LAUNCH(gat_node_fwd_persistent_kernel<4>) break;
+    }
   }
   NGPDE_LAUNCH_CHECK("gat_node_fwd_persistent_kernel");
   hipLaunchKernelGGL(gat_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.s.abort_word, ps.fault);
@@ -1288,12 +1494,22 @@ int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   k.n_steps = a.n_steps; k.S = a.S; k.xs = a.xs; k.yz = ident ? nullptr : a.yz; k.alpha = a.alpha; k.duT = a.duT; k.lam = a.lam;
   k.ubar = a.ubar; k.dzbuf = a.dzbuf; k.dscore = a.dscore; k.slab_db = a.slab_db; k.row_elems = (size_t)g->n_nodes * GD;
   k.alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * a.heads; k.dscore_elems = gat_node_dscore_elems(g); k.cb = a.cb;
+  k.n_members = a.n_members; k.flag_stride = (size_t)ps.n_tiles * 32; k.xs_stride = a.xs_stride; k.yz_stride = a.yz_stride;
+  k.alpha_stride = a.alpha_stride; k.dal_stride = (size_t)g->n_nodes * a.heads;
   NGPDE_REQUIRE(ident || a.yz, NGPDE_ERR_INVALID_ARGUMENT, "persistent GAT adjoint: the saved y / z rows are missing");
   const dim3 grid(ps.n_tiles), block(kThreads);
-  switch (a.heads) {
-    case 1: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<1>) break;
-    case 2: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<2>) break;
-    default: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<4>) break;
+  if (a.n_members > 1) {
+    switch (a.heads) {
+      case 1: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_batch_kernel<1>) break;
+      case 2: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_batch_kernel<2>) break;
+      default: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_batch_kernel<4>) break;
+    }
+  } else {
+    switch (a.heads) {
+      case 1: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<1>) break;
+      case 2: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<2>) break;
+      default: NGPDE_GN_LAUNCH(gat_node_bwd_persistent_kernel<4>) break;
+    }
   }
 #undef NGPDE_GN_LAUNCH
   NGPDE_LAUNCH_CHECK("gat_node_bwd_persistent_kernel");

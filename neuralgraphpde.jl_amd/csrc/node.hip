@@ -752,7 +752,7 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
 /* ---- GAT-style layer as right-hand side: device-resident solve + discrete adjoint (gat_fused.hip) ---------------------------- */
 struct ngpde_node_gat {
   const ngpde_graph *g = nullptr;
-  int heads = 0, c = 0, act = 0, S = 0, n_steps = 0;
+  int heads = 0, c = 0, act = 0, S = 0, n_steps = 0, members = 1;
   float slope = 0.2f;
   bool with_bwd = false, solved = false;
   NodePersist persist;
@@ -778,9 +778,15 @@ int32_t ngpde_node_gat_supported(const ngpde_graph_t *g, int32_t din, int32_t he
 
 int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, int32_t act, int32_t tableau,
                               int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out) {
+  return ngpde_node_gat_create_batch(g, 1, heads, c, negative_slope, act, tableau, n_steps, dt, with_backward, out);
+}
+
+int32_t ngpde_node_gat_create_batch(const ngpde_graph_t *g, int32_t members, int32_t heads, int32_t c, float negative_slope, int32_t act,
+                                    int32_t tableau, int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr && out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_create: NULL argument");
   *out = nullptr;
+  NGPDE_REQUIRE(members >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_create_batch: members >= 1 required (got %d)", members);
   NGPDE_REQUIRE(tableau == NGPDE_TABLEAU_EULER || tableau == NGPDE_TABLEAU_TSIT5, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_node_gat_create: unknown tableau %d", tableau);
   NGPDE_REQUIRE(n_steps >= 1 && act >= NGPDE_ACT_IDENTITY && act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT,
@@ -791,6 +797,7 @@ int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, 
   ngpde_node_gat *p = new (std::nothrow) ngpde_node_gat();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gat_create: out of host memory");
   p->g = g; p->heads = heads; p->c = c; p->act = act; p->slope = negative_slope; p->n_steps = n_steps; p->with_bwd = with_backward != 0;
+  p->members = members;
   const Tableau tb = make_tableau(tableau);
   p->S = tb.S;
   const int S = tb.S;
@@ -804,7 +811,7 @@ int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, 
   }
   p->row_elems = (size_t)g->n_nodes * 64;
   p->alpha_elems = (size_t)std::max<int64_t>(g->n_edges, 1) * heads;
-  const size_t phases = (size_t)n_steps * S, nt = (size_t)g->n_sched / kTileRows;
+  const size_t phases = (size_t)n_steps * S, nt = (size_t)g->n_sched / kTileRows, M = (size_t)members, slots = members > 1 ? 2 : 1;
   auto alloc = [&](auto **ptr, size_t bytes) -> int32_t {
     NGPDE_HIP_CHECK(hipMalloc((void **)ptr, std::max<size_t>(bytes, 256)));
     return NGPDE_OK;
@@ -815,17 +822,17 @@ int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, 
   step(node_persistent_setup(g, coef_unused, &p->persist, false));
   if (st == NGPDE_OK) step(alloc(&p->cf, cf.size() * 4));
   if (st == NGPDE_OK) step(alloc(&p->cb, std::max<size_t>(cb.size(), 64) * 4));
-  if (st == NGPDE_OK) step(alloc(&p->kbuf, (size_t)S * p->row_elems * 4));
-  if (st == NGPDE_OK) step(alloc(&p->xs, (p->with_bwd ? phases : 2) * p->row_elems * 4));
-  p->tape_bytes = (p->with_bwd ? phases : 2) * p->row_elems * 4;
+  if (st == NGPDE_OK) step(alloc(&p->kbuf, slots * 7 * p->row_elems * 4));   // per slot: k_0..k_5 and (batches) u
+  if (st == NGPDE_OK) step(alloc(&p->xs, M * (p->with_bwd ? phases : 2) * p->row_elems * 4));
+  p->tape_bytes = M * (p->with_bwd ? phases : 2) * p->row_elems * 4;
   if (st == NGPDE_OK && p->with_bwd) {
-    if (act != NGPDE_ACT_IDENTITY) { step(alloc(&p->yz, phases * p->row_elems * 4)); p->tape_bytes += phases * p->row_elems * 4; }
-    if (st == NGPDE_OK) step(alloc(&p->alpha, phases * p->alpha_elems * 4));
-    p->tape_bytes += phases * p->alpha_elems * 4;
-    if (st == NGPDE_OK) step(alloc(&p->ubar, (size_t)S * p->row_elems * 4));
-    if (st == NGPDE_OK) step(alloc(&p->dzbuf, 2 * p->row_elems * 4));
-    if (st == NGPDE_OK) step(alloc(&p->dscore, 2 * gat_node_dscore_elems(g) * 4));
-    if (st == NGPDE_OK) step(alloc(&p->dal, (size_t)g->n_nodes * heads * 4));
+    if (act != NGPDE_ACT_IDENTITY) { step(alloc(&p->yz, M * phases * p->row_elems * 4)); p->tape_bytes += M * phases * p->row_elems * 4; }
+    if (st == NGPDE_OK) step(alloc(&p->alpha, M * phases * p->alpha_elems * 4));
+    p->tape_bytes += M * phases * p->alpha_elems * 4;
+    if (st == NGPDE_OK) step(alloc(&p->ubar, slots * 6 * p->row_elems * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dzbuf, slots * 2 * p->row_elems * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dscore, slots * 2 * gat_node_dscore_elems(g) * 4));
+    if (st == NGPDE_OK) step(alloc(&p->dal, slots * (size_t)g->n_nodes * heads * 4));
     if (st == NGPDE_OK) step(alloc(&p->slabs, nt * (64 * 64 + 64 + 128) * 4));
     if (st == NGPDE_OK) step(alloc(&p->xpad, (size_t)std::max<int64_t>(g->n_edges, 1) * 4));
     if (st == NGPDE_OK) {
@@ -876,11 +883,14 @@ int32_t ngpde_node_gat_forward(ngpde_node_gat_t *p, const float *u0, const float
   NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
                 "ngpde_node_gat_forward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_gat_fault); destroy the plan");
   hipStream_t stream = (hipStream_t)stream_;
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->xs, u0, p->row_elems * 4, hipMemcpyDeviceToDevice, stream));   // slot 0 = the input of phase 1
+  const size_t phases = (size_t)p->n_steps * p->S, xs_stride = (p->with_bwd ? phases : 2) * p->row_elems;
+  for (int mb = 0; mb < p->members; ++mb)   // slot 0 of every member's stage-input array = the input of its phase 1
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->xs + (size_t)mb * xs_stride, u0 + (size_t)mb * p->row_elems, p->row_elems * 4, hipMemcpyDeviceToDevice, stream));
   GatNodeFwd f;
   f.g = p->g; f.ps = &p->persist; f.heads = p->heads; f.act = p->act; f.n_steps = p->n_steps; f.S = p->S; f.slope = p->slope;
   f.taped = p->with_bwd; f.u_in = u0; f.wt = weight; f.a = a; f.bias = bias; f.u_out = uT; f.xs = p->xs; f.yz = p->yz; f.alpha = p->alpha;
   f.kbuf = p->kbuf; f.cf = p->cf;
+  f.n_members = p->members; f.xs_stride = xs_stride; f.yz_stride = phases * p->row_elems; f.alpha_stride = phases * p->alpha_elems;
   const int32_t st = launch_gat_node_fwd(f, stream);
   if (st == NGPDE_OK) p->solved = true;
   return st;
@@ -901,6 +911,10 @@ int32_t ngpde_node_gat_backward(ngpde_node_gat_t *p, const float *weight, const 
   b.wt = weight; b.a = a; b.xs = p->xs; b.yz = p->yz; b.alpha = p->alpha; b.duT = duT; b.lam = du0; b.ubar = p->ubar; b.dzbuf = p->dzbuf;
   b.dscore = p->dscore; b.dal = p->dal; b.slab_dw = p->slabs; b.slab_db = p->slabs + nt * 64 * 64; b.slab_u = b.slab_db + nt * 64;
   b.xpad = p->xpad; b.cb = p->cb; b.dwt = dweight; b.da = da; b.db = dbias;
+  {
+    const size_t phases = (size_t)p->n_steps * p->S;
+    b.n_members = p->members; b.xs_stride = phases * p->row_elems; b.yz_stride = phases * p->row_elems; b.alpha_stride = phases * p->alpha_elems;
+  }
   return launch_gat_node_bwd(b, (hipStream_t)stream_);
 }
 

@@ -137,15 +137,17 @@ class _GatPlan:
     """Device-resident solve + discrete adjoint with ONE GAT-style layer as the right-hand side (ngpde_node_gat_*): two persistent
     launches.  Holds the tape of ONE solve (stage inputs, y / z rows, attention coefficients)."""
 
-    def __init__(self, handle, heads, c, slope, act, tableau, n_steps, dt, with_backward):
+    def __init__(self, handle, heads, c, slope, act, tableau, n_steps, dt, with_backward, members=1):
+        """members > 1: `handle` is ONE member of a block-diagonal batch of identical structures (ngpde_node_gat_create_batch)"""
         self.lib = _lib.load()
         _lib.flush_destroy()
         self.handle = handle
         self.ptr = None
         self.gen = 0
+        self.members = int(members)
         out = C.c_void_p()
-        _lib.check(self.lib.ngpde_node_gat_create(handle.ptr, int(heads), int(c), float(slope), int(act), _lib.TABLEAU[tableau],
-                                                  int(n_steps), float(dt), int(with_backward), C.byref(out)))
+        _lib.check(self.lib.ngpde_node_gat_create_batch(handle.ptr, self.members, int(heads), int(c), float(slope), int(act),
+                                                        _lib.TABLEAU[tableau], int(n_steps), float(dt), int(with_backward), C.byref(out)))
         self.ptr = out
 
     def tape_bytes(self):
@@ -528,12 +530,15 @@ class NeuralODE(AbstractExplicitLayer):
         if not (isinstance(m, GATConv) and m.concat and u.is_cuda and m.in_chs == 64 and m.heads * m.out_chs == 64):
             return None
         g = st["graph"]
-        handle = m._graph(g).handle()
+        # a batch of graphs that share ONE structure: the plan is built on the member, two members per workgroup
+        members = getattr(g, "_members", None)
+        member_plan = members is not None and len(members) > 1 and all(mm._handles is members[0]._handles for mm in members)
+        handle = m._graph(members[0] if member_plan else g).handle()
         if not _lib.load().ngpde_node_gat_supported(handle.ptr, 64, m.heads, m.out_chs):
             return None
         with_backward = torch.is_grad_enabled() and (u.requires_grad or any(
             isinstance(v, torch.Tensor) and v.requires_grad for v in ps.values()))
-        key = ("gat", id(handle), m.heads, m.act, m.negative_slope, bool(with_backward))
+        key = ("gat", id(handle), m.heads, m.act, m.negative_slope, bool(with_backward), len(members) if member_plan else 1)
         pool = self._plans.get(key)
         if pool is None:
             pool = self._plans[key] = []
@@ -547,7 +552,8 @@ class NeuralODE(AbstractExplicitLayer):
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
-        plan = _GatPlan(handle, m.heads, m.out_chs, m.negative_slope, m.act, self.solver, self.n_steps, self.dt, with_backward)
+        plan = _GatPlan(handle, m.heads, m.out_chs, m.negative_slope, m.act, self.solver, self.n_steps, self.dt, with_backward,
+                        members=len(members) if member_plan else 1)
         pool.append(plan)
         return plan
 

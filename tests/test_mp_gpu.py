@@ -976,6 +976,43 @@ def test_gat_device_resident_solver_equals_the_generic_solver(heads, act, bias, 
         close(a[2][k], b[2][k].cpu().double().numpy(), rtol=2e-5, atol=1e-5, what=k)
 
 
+@pytest.mark.parametrize("members", [2, 3])
+def test_gat_device_resident_solver_on_a_batch_of_identical_structures(members, monkeypatch):
+    # batch([g] * K) as ODE state (test/runtests.jl:89-102): ngpde_node_gat_create_batch on ONE member, two members at a time per
+    # workgroup (an odd last member alone) -- every member's u(T) and du0 bit for bit those of the generic solver on the
+    # block-diagonal graph, parameter gradients (summed over the members) to rounding
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    n, H, C_ = 500, 4, 16
+    s, t = _local_graph(n, 97)
+    g1 = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    g = ng.batch([g1] * members)
+    l = ng.GATConv((64, C_), "tanh", heads=H, initialgraph=g)
+    ps0, _ = ng.setup(97, l)
+    ps0 = prep(ps0, 97)
+    u0 = torch.randn(64, n * members, device=DEV)
+    R = torch.randn(64, n * members, device=DEV)
+
+    def run(resident):
+        if resident:
+            monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+        else:
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        node = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05)
+        _, st = ng.setup(97, node)
+        ps = {k: v.detach().clone().requires_grad_(True) for k, v in ps0.items()}
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * R).sum().backward()
+        return uT.detach(), u.grad, {k: v.grad for k, v in ps.items()}, [p for pool in node._plans.values() for p in pool]
+
+    a = run(True)
+    assert a[3] and all("gat" in p.flags() and p.members == members and not p.fault() for p in a[3])
+    b = run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        close(a[2][k], b[2][k].cpu().double().numpy(), rtol=2e-5, atol=1e-5, what=k)
+
+
 def test_gat_device_resident_solver_replays_are_bit_identical_at_c3_size(monkeypatch):
     # the race screen: 12 solves + adjoints of BASELINE config 3 as ODE right-hand side (512 tiles, 50 Tsit5 steps = 300 hand-offs
     # per direction), every output of every replay equal to the first, bit for bit; no launch gave up waiting

@@ -11,10 +11,13 @@ if os.environ.get('NGPDE_LIB'):
 
 N = int(os.environ.get("N", 16384)); PAIRS = int(os.environ.get("PAIRS", 4 * N)); STEPS = int(os.environ.get("STEPS", 50))
 SOLVER = os.environ.get("SOLVER", "tsit5"); ACT = os.environ.get("ACT", "relu"); H = int(os.environ.get("HEADS", 4))
+K = int(os.environ.get("MEMBERS", 1))     # > 1: a block-diagonal batch of K copies of the graph (two members per workgroup)
 DEV = "cuda"
 _, s, t = S.closest_pairs_graph(N, PAIRS, seed=2)
-g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+g1 = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+g = ng.batch([g1] * K) if K > 1 else g1
 layer = ng.GATConv((64, 64 // H), ACT, heads=H, initialgraph=g)
+N1, N = N, N * K
 
 
 def run(persistent, u0, ps0, capture=False):
@@ -71,4 +74,9 @@ def timeit(persistent, capture, reps=5):
     return (time.perf_counter() - t0) / reps * 1e3
 if os.environ.get("TIME", "1") == "1":
     tp = timeit(True, False); tg = timeit(False, True)
-    print(f"ms per solve + adjoint: persistent {tp:.3f} ({STEPS / tp * 1e3:.0f} ODE-steps/s), generic captured {tg:.3f} ({STEPS / tg * 1e3:.0f})")
+    print(f"ms per solve + adjoint ({K} member(s)): persistent {tp:.3f} ({K * STEPS / tp * 1e3:.0f} trajectory ODE-steps/s), generic captured {tg:.3f} ({K * STEPS / tg * 1e3:.0f})")
+    if K > 1:     # member by member on single plans
+        g, layer, N = g1, ng.GATConv((64, 64 // H), ACT, heads=H, initialgraph=g1), N1
+        u0 = u0[:N1].contiguous()
+        t1 = timeit(True, False)
+        print(f"one member on its own plan: {t1:.3f} ms -> {K} members one after the other {K * t1:.3f} ms ({STEPS / t1 * 1e3:.0f} trajectory ODE-steps/s)")
