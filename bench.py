@@ -312,6 +312,25 @@ def secondary(dev, world, rank, dist):
                                                 if resident else "NeuralODE(GATConv, capture=True): HIP-graph replay of the generic solver"),
                                        "fault": any(p.fault() for p in gplans) if resident else False,
                                        "rhs_evals_per_ode_step": 6}
+        if resident:      # 8 trajectories per GPU on this right-hand side: a block-diagonal batch of identical structures, two members per workgroup
+            traj = 8
+            lb = ng.GATConv((64, 16), "relu", heads=4, initialgraph=ng.batch([g] * traj))
+            nodeb = ng.NeuralODE(lb, solver="tsit5", n_steps=ODE_STEPS, dt=DT)
+            _, stb = ng.setup(3, nodeb)
+            xb = torch.as_tensor(S.normal(37, 64 * N_NODES * traj).reshape(N_NODES * traj, 64).astype(np.float32), device=dev).T.requires_grad_(True)
+
+            def solveb():
+                for v in [xb] + _grad_leaves(psg):
+                    v.grad = None
+                uT, _ = nodeb(xb, psg, stb)
+                uT.sum().backward()
+            msb = _time_ms(solveb, 3)
+            bplans = [p for pool in nodeb._plans.values() for p in pool]
+            out["C3_gat_node_tsit5x50"]["batched"] = {"trajectories_per_gpu": traj, "ms_solve_forward_backward": round(msb, 3),
+                                                      "value": round(traj * ODE_STEPS / (msb * 1e-3), 1), "unit": "trajectory ODE-steps/s",
+                                                      "device_resident": bool(bplans) and all("gat" in p.flags() for p in bplans),
+                                                      "fault": any(p.fault() for p in bplans)}
+            del nodeb, stb, xb, lb
         if resident:      # the generic solver (every stage the one-launch layer, captured into HIP graphs) on the same workload
             os.environ["NGPDE_NO_PERSISTENT"] = "1"
             try:
