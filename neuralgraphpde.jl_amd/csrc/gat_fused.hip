@@ -377,6 +377,7 @@ struct GatBwdTK {
   const float *x, *wt, *dy, *yz, *alpha;
   const int4 *sched;
   const int2 *halo;
+  const int2 *tile_info;   // [n_tiles] {rows staged, -}
   const uint8_t *slots;
   int n_tiles, act;
   float slope;
@@ -402,10 +403,11 @@ __device__ __forceinline__ float4 gat_load4_sc1(const float *ptr) {
 
 struct GatBwdTLds {
   float *Xh;   // [(kHaloCap + 1)][GD] staged input rows
-  float *DZ;   // [kTM][TS]  the dz tile (A operand of the product; its B operand, blocks of W, comes straight from memory)
-  float *DA;   // [kTM][kATS] the per-head [32][H*64] result
+  float *DZ;   // [kTM][TS]  the dz tile
+  float *DA;   // [(kHaloCap + 1)][TS] W x of the staged rows, then [kTM][kSlotWidth][4] d alpha per (row, entry, head)
 };
-constexpr int kBwdDZF = kTM * GG::TS, kBwdDAF = kTM * kATS;
+constexpr int kBwdWXF = (kHaloCap + 1) * GG::TS;
+constexpr int kBwdDZF = kTM * GG::TS, kBwdDAF = kBwdWXF + kTM * kSlotWidth * 4;
 
 // The by-target half of the pullback for one tile, from the thread's dz row (staged input rows in flight or landed) to dscore / dal;
 // returns this thread's partial of db (valid where tid % DBP == 0: column tid / DBP).  PAD: dscore goes to the tile's own
@@ -416,21 +418,22 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
                                                         int tile, float4 dz) {
   constexpr int C = GD / H;
   const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
-  float *ldsDZ = L.DZ, *ldsDA = L.DA;
+  float *ldsDZ = L.DZ, *ldsWX = L.DA, *ldsE = L.DA + kBwdWXF;
   float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
-  // B operand of this wave's H output tiles: lane (i, kq) of tile (head, jt) needs wt[jt*16 + i][head*C + 16 kb + 4 kq + r],
-  // r = 0..3 contiguous: C / 16 float4 per tile, in flight from the start (W is 16 KB, cache resident)
-  float4 breg[H][C / 16];
+  // d alpha_{e,k} = (W_k dz_{t,k}) . x_s = dz_{t,k} . (W x_s)_k: the products W x of the STAGED rows come off the matrix pipe once per
+  // tile ([rows staged][64] x [64][64], the layer's own W x) and every entry then costs one 4-float dot per lane and a sum over the
+  // C / 4 lanes of its head -- instead of a 64-float dot per head reduced over all 16 lanes of the row group (the VALU work that
+  // dominated this half).  B operand of this wave's column tile: lane (i, kq) needs wt[16 kb + 4 kq + r][ct*16 + i], in flight
+  // from the start (W is 16 KB, cache resident)
+  float bw[4][4];
   {
-    const int i = lane & 15, kq = lane >> 4;
+    const int ct = wave_u & 3, i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < H; ++t) {
-      const int ctile = (wave_u + GG::WAVES * t) >> 1, head = ctile >> 2, jt = ctile & 3;
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < C / 16; ++kb)
-        breg[t][kb] = *reinterpret_cast<const float4 *>(p.wt + (size_t)(jt * 16 + i) * GD + head * C + 16 * kb + 4 * kq);
-    }
+      for (int r = 0; r < 4; ++r) bw[kb][r] = p.wt[(size_t)(16 * kb + 4 * kq + r) * GD + ct * 16 + i];
   }
+  const int hc = __builtin_amdgcn_readfirstlane(p.tile_info[tile].x);   // rows staged (own rows first)
   const bool ok = m.sc.x >= 0;
   const int deg = ok ? m.sc.z : 0;
   // this lane's two entries of the row: saved coefficients (sign = leakyrelu branch)
@@ -462,35 +465,39 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
     for (int o = 1; o < GG::DBP; o <<= 1) s += __shfl_xor(s, o);
     db_part = s;
   }
-  // dA[i][k*64 + j] = sum_c dz[i][k*C + c] W[j][k*C + c]: 2 row tiles x (4 H) column tiles, H tiles per wave
+  // WX[hh][o] = sum_j x_hh[j] W[j][o] for the staged rows: <= 6 row tiles x 4 column tiles, wave w: column tile w & 3, row tiles
+  // (w >> 2), + 2, + 4
   {
-    const int i = lane & 15, kq = lane >> 4;
+    const int ct = wave_u & 3, i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < H; ++t) {
-      const int id = wave_u + GG::WAVES * t, rt = id & 1, ctile = id >> 1, head = ctile >> 2;
-      const float *pa = ldsDZ + (rt * 16 + i) * GG::TS + head * C + 4 * kq;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mm = 0; mm < 3; ++mm) {
+      const int rt = (wave_u >> 2) + 2 * mm;
+      if (rt * 16 < hc) {   // wave-uniform
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kb = 0; kb < C / 16; ++kb) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(pa + kb * 16);
-        acc = mfma16(a4.x, breg[t][kb].x, acc);
-        acc = mfma16(a4.y, breg[t][kb].y, acc);
-        acc = mfma16(a4.z, breg[t][kb].z, acc);
-        acc = mfma16(a4.w, breg[t][kb].w, acc);
+        for (int kb = 0; kb < 4; ++kb) {
+          const float4 a4 = Xh4[(rt * 16 + i) * GG::LPR + 4 * kb + kq];
+          acc = mfma16(a4.x, bw[kb][0], acc);
+          acc = mfma16(a4.y, bw[kb][1], acc);
+          acc = mfma16(a4.z, bw[kb][2], acc);
+          acc = mfma16(a4.w, bw[kb][3], acc);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ldsWX[(rt * 16 + 4 * kq + reg) * GG::TS + ct * 16 + i] = acc[reg];
       }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) ldsDA[(rt * 16 + 4 * kq + reg) * kATS + ctile * 16 + i] = acc[reg];
     }
+    if (grp == 0) *reinterpret_cast<float4 *>(&ldsWX[kHaloCap * GG::TS + 4 * q]) = f4_zero();   // the all-zero row's product
   }
   __syncthreads();
   NGPDE_GSTP(NGPDE_GSTP_OF(p), 8);
-  // d alpha of every entry of the row: <dA_k[i], x_s> per head, reduced over the group's 16 lanes; the lane that owns the
-  // entry keeps it
-  float4 dar[H];
-#pragma unroll
-  for (int k = 0; k < H; ++k) dar[k] = *reinterpret_cast<const float4 *>(&ldsDA[grp * kATS + k * GD + 4 * q]);
+  // d alpha of every entry of the row: lane q holds features 4q .. 4q + 3 of its row's dz, i.e. of head 4q / C; partial dot with the
+  // entry's W x row, summed over the C / 4 lanes of the head (quad permutes, then half-row / row mirrors); one lane per head
+  // writes it to the (row, entry, head) table, the lane that owns the entry reads its heads back
   float da[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   {
+    constexpr int LPH = C / 4;   // lanes per head: 4, 8 or 16
+    const int hq = (4 * q) / C;
+    const float4 dzo = *reinterpret_cast<const float4 *>(&ldsDZ[grp * GG::TS + 4 * q]);
     const int wmax = wave_max_deg(deg);
 #pragma unroll
     for (int jw = 0; jw < 8; ++jw) {
@@ -498,13 +505,25 @@ __device__ __forceinline__ float gat_bwd_target_compute(const GatBwdTK &p, const
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
           const int j = jw * 4 + jb;
-          const float4 xv = Xh4[slot_byte(m.w, jw, jb) * GG::LPR + q];
-#pragma unroll
-          for (int k = 0; k < H; ++k) {
-            const float s = row_sum16(dot4(dar[k], xv));
-            da[j >> 4][k] = (q == (j & 15)) ? s : da[j >> 4][k];
-          }
+          const float4 wx = *reinterpret_cast<const float4 *>(&ldsWX[slot_byte(m.w, jw, jb) * GG::TS + 4 * q]);
+          float sum = dot4(dzo, wx);
+          sum += dpp_mov<0xB1>(sum);                      // quad_perm [1, 0, 3, 2]
+          sum += dpp_mov<0x4E>(sum);                      // quad_perm [2, 3, 0, 1]
+          if (LPH >= 8) sum += dpp_mov<0x141>(sum);       // row_half_mirror
+          if (LPH == 16) sum += dpp_mov<0x140>(sum);      // row_mirror
+          if ((q & (LPH - 1)) == 0) ldsE[(grp * kSlotWidth + j) * 4 + hq] = sum;
         }
+      }
+    }
+    // the table is read back by lanes of the same group (= same wave): no workgroup barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      if (q + 16 * sI < wmax) {   // (entries beyond the wave's longest row were not written)
+        const float4 e4 = *reinterpret_cast<const float4 *>(&ldsE[(grp * kSlotWidth + q + 16 * sI) * 4]);
+        da[sI][0] = e4.x; da[sI][1] = e4.y; da[sI][2] = e4.z; da[sI][3] = e4.w;
       }
     }
   }
@@ -1319,6 +1338,7 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
   if (g->n_nodes > 0) {
     GatBwdTK t;
     t.x = x; t.wt = wt; t.dy = dy; t.yz = ident ? nullptr : yz; t.alpha = alpha; t.sched = g->by_t.sched; t.halo = g->by_t.halo;
+    t.tile_info = g->by_t.tile_info;
     t.slots = g->by_t.slots; t.n_tiles = n_tiles; t.act = act; t.slope = slope; t.dz = ident ? nullptr : dz; t.dscore = dscore;
     t.dal = dal; t.slab_db = slab_db;
     NGPDE_GST_SET(t)
@@ -1478,6 +1498,7 @@ int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   GatNodeBwdK k;
   const bool ident = a.act == NGPDE_ACT_IDENTITY;
   k.t.x = nullptr; k.t.wt = a.wt; k.t.dy = nullptr; k.t.yz = nullptr; k.t.alpha = nullptr; k.t.sched = g->by_t.sched; k.t.halo = g->by_t.halo;
+  k.t.tile_info = g->by_t.tile_info;
   k.t.slots = g->by_t.slots; k.t.n_tiles = ps.n_tiles; k.t.act = a.act; k.t.slope = a.slope; k.t.dz = nullptr; k.t.dscore = nullptr;
   k.t.dal = a.dal; k.t.slab_db = nullptr;
   k.s.gz = nullptr; k.s.x = nullptr; k.s.wt = a.wt; k.s.a = a.a; k.s.alpha = nullptr; k.s.dscore = nullptr; k.s.dal = a.dal;
