@@ -132,6 +132,7 @@ struct GatFwdK {
   const float *x, *wt, *a, *bias;
   const int4 *sched;
   const int2 *halo;
+  const int2 *tile_info;   // [n_tiles] {rows staged, -}
   const uint8_t *slots;
   int n_tiles, act;
   float slope;
@@ -164,34 +165,13 @@ __device__ __forceinline__ GatThread gat_thread() {
 
 template <int H>
 __device__ __forceinline__ void gat_fwd_consts(const GatFwdK &p, const GatFwdLds &L, const GatThread &t, float (&breg)[4][4], float4 &b4) {
-  constexpr int C = GD / H;
-  const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
-  float *ldsV = L.V, *ldsAr = L.Ar;
+  const int lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
+  float *ldsAr = L.Ar;
   float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
-  // v_which,k[i] = sum_c a[which*C + c][k] W[k*C + c][i]: the workgroup reads W once, coalesced (thread: input feature i =
-  // tid >> 3, eight consecutive output columns), and the C / 8 adjacent lanes of one (i, head) add their partial dots
+  // B operand of this wave's column tile of W x straight from memory (W is 16 KB, cache resident): lane (i, kq) of column tile
+  // ct = wave & 3 needs wt[16 kb + 4 kq + r][ct * 16 + i] -- 16 dwords, in flight from the start; no W^T copy in LDS
   {
-    const int i = tid >> 3, part = tid & 7;
-    const int hk = (part * 8) / C, c0 = (part * 8) % C;
-    const float4 *w4 = reinterpret_cast<const float4 *>(p.wt + (size_t)i * GD + part * 8);
-    const float4 *l4 = reinterpret_cast<const float4 *>(p.a + (size_t)hk * 2 * C + c0);
-    const float4 *r4 = reinterpret_cast<const float4 *>(p.a + (size_t)hk * 2 * C + C + c0);
-    const float4 w0 = w4[0], w1 = w4[1];
-    float pl = dot4(w0, l4[0]) + dot4(w1, l4[1]), pr = dot4(w0, r4[0]) + dot4(w1, r4[1]);
-#pragma unroll
-    for (int o = 1; o < C / 8; o <<= 1) {
-      pl += __shfl_xor(pl, o);
-      pr += __shfl_xor(pr, o);
-    }
-    if (part % (C / 8) == 0) {
-      ldsV[hk * GD + i] = pl;
-      ldsV[4 * GD + hk * GD + i] = pr;
-    }
-  }
-  // B operand of this wave's output tile straight from memory (W is 16 KB, cache resident): lane (i, kq) of column tile ct
-  // needs wt[16 kb + 4 kq + r][ct * 16 + i] -- 16 dwords, in flight from the start; no W^T copy in LDS
-  {
-    const int ct = wave_u >> 1, i = lane & 15, kq = lane >> 4;
+    const int ct = wave_u & 3, i = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -204,43 +184,86 @@ __device__ __forceinline__ void gat_fwd_consts(const GatFwdK &p, const GatFwdLds
   }
 }
 
-// from the barrier that makes the staged rows visible to the tile's pre-activation row of this thread (bias added)
+// sum over the C / 4 adjacent lanes that hold one head's features (4, 8 or 16 lanes of a 16-lane row group): quad permutes, then
+// the half-row / row mirrors; every lane of the head ends with the total
+template <int LPH>
+__device__ __forceinline__ float head_sum(float v) {
+  v += dpp_mov<0xB1>(v);                      // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);                      // quad_perm [2, 3, 0, 1]
+  if (LPH >= 8) v += dpp_mov<0x141>(v);       // row_half_mirror
+  if (LPH == 16) v += dpp_mov<0x140>(v);      // row_mirror
+  return v;
+}
+
+// From the barrier that makes the staged rows visible to the tile's pre-activation row of this thread (bias added).
+// Round 3: transform, then aggregate -- W x of the STAGED rows comes off the matrix pipe once per tile ([rows staged][64] x [64][64]:
+// <= 48 products per wave on a pipe that idles otherwise), the score halves are 4-float dots with a_l / a_r summed over the C / 4
+// lanes of a head, and an entry of the aggregation costs ONE fma4 per lane (its own head's coefficient times its quad of the
+// entry's W x row) instead of one per head; no [32][heads * 64] tile, no second product, two barriers fewer.  (Round 2 aggregated
+// the INPUT rows per head and multiplied afterwards: 16 fma per entry and lane and sixteen-lane reductions for the scores -- the
+// kernel was VALU-bound.)
 template <int H>
-__device__ __forceinline__ float4 gat_fwd_compute(const GatFwdK &p, const GatFwdLds &L, const GatThread &t, const TileMeta &m,
+__device__ __forceinline__ float4 gat_fwd_compute(const GatFwdK &p, const GatFwdLds &L, const GatThread &t, const TileMeta &m, int tile,
                                                   const float (&breg)[4][4], float4 b4) {
   constexpr int C = GD / H;
+  constexpr int LPH = C / 4;
   const int lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
-  float *ldsS = L.S, *ldsA = L.A, *ldsAr = L.Ar, *ldsV = L.V;
+  float *ldsS = L.S, *ldsWX = L.A, *ldsAr = L.Ar, *ldsAl = L.V;
   float4 *Xh4 = reinterpret_cast<float4 *>(L.Xh);
+  const int hq = (4 * q) / C;                                                    // this lane's head
+  const float4 al4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + (4 * q) % C);
+  const float4 ar4 = *reinterpret_cast<const float4 *>(p.a + (size_t)hq * 2 * C + C + (4 * q) % C);
+  const int hc = __builtin_amdgcn_readfirstlane(p.tile_info[tile].x);            // rows staged (own rows first)
   NGPDE_GST(1);
-  __syncthreads();   // staged rows (DMA) and v vectors visible
+  __syncthreads();   // staged rows (DMA) visible
   NGPDE_GST(2);
-
-  // ---- score halves from the staged rows: ar of every staged row, al of the own row (= slot `grp`)
-  float al[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- WX[hh][o] = sum_j x_hh[j] W[j][o]: <= 6 row tiles x 4 column tiles, wave w: column tile w & 3, row tiles (w >> 2), + 2, + 4
   {
-    float4 vr[H], vl[H];
+    const int ct = wave_u & 3, i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-      vl[k] = reinterpret_cast<const float4 *>(ldsV)[k * 16 + q];
-      vr[k] = reinterpret_cast<const float4 *>(ldsV)[(4 + k) * 16 + q];
+    for (int mm = 0; mm < 3; ++mm) {
+      const int rt = (wave_u >> 2) + 2 * mm;
+      if (rt * 16 < hc) {   // wave-uniform
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const float4 a4 = Xh4[(rt * 16 + i) * GG::LPR + 4 * kb + kq];
+          acc = mfma16(a4.x, breg[kb][0], acc);
+          acc = mfma16(a4.y, breg[kb][1], acc);
+          acc = mfma16(a4.z, breg[kb][2], acc);
+          acc = mfma16(a4.w, breg[kb][3], acc);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ldsWX[(rt * 16 + 4 * kq + reg) * GG::TS + ct * 16 + i] = acc[reg];
+      }
     }
-#pragma unroll
-    for (int r = 0; r < GG::HI; ++r) {
-      const int hh = grp + r * GG::GROUPS;
-      const float4 xv = Xh4[hh * GG::LPR + q];
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < H; ++k) s[k] = row_sum16(dot4(xv, vr[k]));
-      if (q < 4) ldsAr[hh * 4 + q] = sel4(s, q);
-    }
-    const float4 xo = Xh4[grp * GG::LPR + q];
-#pragma unroll
-    for (int k = 0; k < H; ++k) al[k] = row_sum16(dot4(xo, vl[k]));
+    if (grp == 0) *reinterpret_cast<float4 *>(&ldsWX[kHaloCap * GG::TS + 4 * q]) = f4_zero();   // the all-zero row's product
   }
   NGPDE_GST(3);
   __syncthreads();
   NGPDE_GST(4);
+  // ---- score halves: ar of every staged row (one lane per head writes it), al of the own row
+  float al[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+#pragma unroll
+    for (int r = 0; r < GG::HI; ++r) {
+      const int hh = grp + r * GG::GROUPS;
+      if (r * GG::GROUPS < hc) {   // wave-uniform (rows of tiles that were not formed are never referenced)
+        const float4 wx = *reinterpret_cast<const float4 *>(&ldsWX[hh * GG::TS + 4 * q]);
+        const float sr = head_sum<LPH>(dot4(wx, ar4));
+        if ((q & (LPH - 1)) == 0) ldsAr[hh * 4 + hq] = sr;
+        if (r == 0) {
+          const float sl = head_sum<LPH>(dot4(wx, al4));
+          if ((q & (LPH - 1)) == 0) ldsAl[grp * 4 + hq] = sl;
+        }
+      }
+    }
+  }
+  __syncthreads();   // ar of rows staged by other waves (and the own al) visible
+  {
+    const float4 a4 = *reinterpret_cast<const float4 *>(&ldsAl[grp * 4]);
+    al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+  }
 
   // ---- softmax over the row's entries: lane q owns entries q and q + 16, all heads
   const int deg = m.sc.x >= 0 ? m.sc.z : 0;
@@ -295,53 +318,23 @@ __device__ __forceinline__ float4 gat_fwd_compute(const GatFwdK &p, const GatFwd
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   NGPDE_GST(5);
-  // ---- per-head aggregates of the staged rows (one LDS row read serves all heads)
+  // ---- aggregation of the entries' W x rows, this lane's head
+  float4 acc = f4_zero();
   {
     const int wmax = wave_max_deg(deg);
-    float4 acc[H];
-#pragma unroll
-    for (int k = 0; k < H; ++k) acc[k] = f4_zero();
 #pragma unroll
     for (int jw = 0; jw < 8; ++jw) {
       if (jw * 4 < wmax) {   // wave-uniform
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
-          const float4 xv = Xh4[slot_byte(m.w, jw, jb) * GG::LPR + q];
-          const float4 cf = reinterpret_cast<const float4 *>(ldsS)[grp * kSlotWidth + jw * 4 + jb];
-          const float cfa[4] = {cf.x, cf.y, cf.z, cf.w};
-#pragma unroll
-          for (int k = 0; k < H; ++k) acc[k] = f4_fma(cfa[k], xv, acc[k]);
+          const float4 wx = *reinterpret_cast<const float4 *>(&ldsWX[slot_byte(m.w, jw, jb) * GG::TS + 4 * q]);
+          acc = f4_fma(ldsS[(grp * kSlotWidth + jw * 4 + jb) * 4 + hq], wx, acc);
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < H; ++k) *reinterpret_cast<float4 *>(&ldsA[grp * kATS + k * GD + 4 * q]) = acc[k];
   }
-  NGPDE_GST(6);
-  __syncthreads();   // aggregates complete; the coefficients are dead: their region takes the output tile
-  NGPDE_GST(7);
-  float *ldsZ = ldsS;
-  {   // out[:, ct*16..] = A_head(ct) x W[:, ct*16..]: 2 row tiles x 4 column tiles = one tile per wave
-    const int rt = wave_u & 1, ct = wave_u >> 1;
-    const int i = lane & 15, kq = lane >> 4;
-    const int head = (ct * 16) / C;
-    const float *pa = ldsA + (rt * 16 + i) * kATS + head * GD + 4 * kq;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float4 av4 = *reinterpret_cast<const float4 *>(pa + kb * 16);
-      acc = mfma16(av4.x, breg[kb][0], acc);
-      acc = mfma16(av4.y, breg[kb][1], acc);
-      acc = mfma16(av4.z, breg[kb][2], acc);
-      acc = mfma16(av4.w, breg[kb][3], acc);
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) ldsZ[(rt * 16 + 4 * kq + reg) * GG::TS + ct * 16 + i] = acc[reg];
-  }
-  NGPDE_GST(8);
-  __syncthreads();
   NGPDE_GST(9);
-  return f4_add(*reinterpret_cast<const float4 *>(&ldsZ[grp * GG::TS + 4 * q]), b4);
+  return f4_add(acc, b4);
 }
 
 template <int H>
@@ -360,7 +353,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_layer_fwd_kernel(const GatFwd
   float breg[4][4];
   float4 b4;
   gat_fwd_consts<H>(p, L, t, breg, b4);
-  const float4 z = gat_fwd_compute<H>(p, L, t, m, breg, b4);
+  const float4 z = gat_fwd_compute<H>(p, L, t, m, tile, breg, b4);
   if (m.sc.x >= 0) {
     const size_t idx4 = (size_t)m.sc.x * GG::LPR + t.q;
     if (p.save_z) reinterpret_cast<float4 *>(p.save_z)[idx4] = z;
@@ -950,7 +943,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_batch_ker
           if (!gat_wait(ys, t, my_nbr, lp > 1 ? ph - 1 : 0u, &s_ok)) { dead = true; break; }
           halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
           l.alpha = p.alpha ? p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems : nullptr;
-          const float4 z = gat_fwd_compute<H>(l, L, t, m, breg, b4);
+          const float4 z = gat_fwd_compute<H>(l, L, t, m, tile, breg, b4);
           const float4 y = f4_act(l.act, z);
           if (p.yz && ok) gat_st4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
           const int row = (i + 1 < S) ? i + 1 : S;
@@ -1013,7 +1006,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
       NGPDE_GSTP(NGPDE_GSTP_OF(l), 13);
       halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
       l.alpha = p.alpha ? p.alpha + e * p.alpha_elems : nullptr;
-      const float4 z = gat_fwd_compute<H>(l, L, t, m, breg, b4);
+      const float4 z = gat_fwd_compute<H>(l, L, t, m, tile, breg, b4);
       const float4 y = f4_act(l.act, z);
       if (p.yz && ok) gat_st4(p.yz + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
       // the input of the next stage / the step update, as ngpde_rk_stage_combine forms it: 1 * u, then the k_j in order
@@ -1311,6 +1304,7 @@ int32_t launch_gat_layer_fwd(const ngpde_graph *g, int heads, float slope, int a
   if (g->n_nodes == 0) return NGPDE_OK;
   GatFwdK k;
   k.x = x; k.wt = wt; k.a = a; k.bias = bias; k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
+  k.tile_info = g->by_t.tile_info;
   k.n_tiles = fused_num_blocks(g->n_nodes); k.act = act; k.slope = slope; k.y = y; k.alpha = alpha; k.save_z = save_z;
   NGPDE_GST_SET(k)
   const dim3 grid(k.n_tiles), block(kThreads);
@@ -1452,6 +1446,7 @@ int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream) {
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   GatNodeFwdK k;
   k.l.x = nullptr; k.l.wt = a.wt; k.l.a = a.a; k.l.bias = a.bias; k.l.sched = g->by_t.sched; k.l.halo = g->by_t.halo;
+  k.l.tile_info = g->by_t.tile_info;
   k.l.slots = g->by_t.slots; k.l.n_tiles = ps.n_tiles; k.l.act = a.act; k.l.slope = a.slope; k.l.y = nullptr; k.l.alpha = nullptr;
   k.l.save_z = nullptr;
   NGPDE_GST_SET(k.l)
