@@ -35,10 +35,10 @@ for rep in range(3):
     if rep == 2:
         bw = buf.cpu().numpy().reshape(512, 16).astype(np.float64).copy()
 lib.ngpde_debug_set_gat_stamps(None)
-# forward: 0 phase start, 13 after the wait, 1..9 inside the layer code (see tools/stamps_gat.py), 14 stores issued, 15 published
-order = [0, 13, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15]
-names = ["wait for the neighbours", "DMA issue", "barrier (rows land)", "score halves", "barrier", "softmax + coefficients", "per-head aggregation",
-         "barrier", "MFMA + tile store", "barrier", "activation, tape, combination, row store", "drain + barrier + flag"]
+# forward: 0 phase start, 13 after the wait, 1..5, 9 inside the layer code (gat_fwd_compute), 14 stores issued, 15 published
+order = [0, 13, 1, 2, 3, 4, 5, 9, 14, 15]
+names = ["wait for the neighbours", "DMA issue, a_l / a_r loads", "barrier (rows land)", "W x of the staged rows (MFMA)", "barrier",
+         "score halves, barrier, softmax + coefficients", "aggregation", "activation, tape, combination, row store", "drain + barrier + flag"]
 print("forward, last phase (cycles): " + "; ".join(f"{n}: {d:.0f}" for n, d in zip(names, mean_diffs(fw, order))) + f" | phase {float((fw[:, 15] - fw[:, 0]).mean()):.0f}")
 order = [0, 1, 7, 8, 9, 2, 3, 4, 5, 10, 11, 12, 13, 14, 6]
 names = ["by-target metadata, DMA issue, K-bar, dz store", "T: W / alpha loads, dz tile, barrier (rows land)", "T: db partial, MFMA, barrier", "T: d alpha loop",
