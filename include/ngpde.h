@@ -322,9 +322,8 @@ int32_t ngpde_gat_backward(const ngpde_graph_t *g, int32_t heads, int32_t c, flo
 
 /* The whole GAT-style layer  y = act.(GAT(x) .+ b)  with W (heads*c x din), a (2c x heads), heads concatenated, in ONE launch
  * (pullback: two launches + one reduction) when din == heads * c == 64, heads in {1, 2, 4} and the graph's tiles fit the LDS halo
- * in both directions (ngpde_gat_layer_supported; BASELINE config 3 = 64 => 4 x 16): the logits come from the staged input rows
- * (a_l . W x = (W^T a_l) . x), the messages are aggregated per head BEFORE the weight (sum_e alpha W x = W sum_e alpha x), so no
- * W x array exists in memory.  Self loops are edges of g (the caller appends them, as GATConv's add_self_loops does).
+ * in both directions (ngpde_gat_layer_supported; BASELINE config 3 = 64 => 4 x 16): W x of the rows a tile stages (its own and its
+ * halo) is formed on the matrix pipe inside the launch, logits and messages work on it per head; no W x array exists in memory.  Self loops are edges of g (the caller appends them, as GATConv's add_self_loops does).
  *   save_alpha [E][heads] nullable: attention coefficients in p order, the sign bit carrying leakyrelu's branch (pullback only)
  *   save_z     [N][64] nullable: pre-activation (the pullback of activations other than identity / relu needs it)
  * backward: y_or_z = y for relu, z otherwise (ignored for identity); dx nullable; dweight (64 x 64) column-major, da (2c x heads),

@@ -4,14 +4,15 @@
 // [GraphNeuralNetworks.jl GATConv on softmax_edge_neighbors, the primitive the reference re-exports at
 //  /root/reference/src/NeuralGraphPDE.jl:7; BASELINE config 3: GATConv 4 heads x 16 on the 16k-node graph.]
 //
-// The layer is evaluated in a reassociated form so that nothing per node is written but the output:
-//   * scores:  a_l,k . W_k x_i = v_l,k . x_i with v_l,k = W_k^T a_l,k (64 floats per head, rebuilt by every workgroup from W and
-//     a: 2 KB, 16 products per element), so the logits come straight from the staged INPUT rows;
-//   * messages:  sum_e alpha_{e,k} W_k x_s = W_k (sum_e alpha_{e,k} x_s): the tile aggregates its staged input rows once per
-//     head (the LDS row read is shared by the heads) into a [32][heads * 64] tile and ONE fp32-MFMA product per head block
-//     gives the output tile -- the same 32 x 64 x 64 product as a GCN layer, no W x array in memory.
+// Nothing per node is written but the output, and the per-edge work is kept off the VALU as far as it goes (round 3; round 2
+// took scores and aggregates from the INPUT rows -- v = W^T a, per-head aggregates, one product afterwards -- and was VALU-bound:
+// a 64-float dot reduced over 16 lanes for every score, 16 fma per entry and lane):
+//   * W x of the tile's STAGED rows (own + halo, <= 96) comes off the matrix pipe once per tile ([rows][64] x [64][64], <= 48
+//     v_mfma_f32_16x16x4_f32 per wave, B fragments of W straight from memory), into LDS; no W x array in memory;
+//   * scores:  a_l,k . (W x_i)_k as a 4-float dot per lane summed over the C / 4 lanes that hold head k (quad permutes + mirrors);
+//   * messages:  lane q of a row aggregates ITS head's coefficient times its quad of the entries' W x rows: one fma4 per entry.
 // Saved for the pullback: alpha ([E][heads], p order) with the sign bit carrying leakyrelu's branch (alpha >= 0).
-// Pullback:  (1) by target: dz = dy . act', d alpha_{e,k} = (W_k dz_i,k) . x_s with the 32 x (heads * 64) product on MFMA,
+// Pullback:  (1) by target: dz = dy . act', d alpha_{e,k} = dz_{i,k} . (W x_s)_k -- W x of the staged rows on MFMA, four-lane dots --,
 // softmax + leakyrelu pullback -> dscore [E][heads], dal [N][heads], db slabs;  (2) by source: dWx_j = sum_e alpha_e dz_{t_e} +
 // dal_j a_l + dar_j a_r (dar_j = sum of dscore over the outgoing edges), dx = dWx W^T and dW += x^T dWx on MFMA with the
 // accumulators of a workgroup's tiles kept in registers, u_l = sum_j dal_j x_j, u_r likewise;  (3) slabs -> dW, db, and
