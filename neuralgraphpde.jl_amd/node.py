@@ -453,6 +453,7 @@ class NeuralODE(AbstractExplicitLayer):
         self._no_member_plan = False
         self.capture = bool(capture)      # generic right-hand sides: replay the whole solve / adjoint from HIP graphs
         self._captured = {}
+        self._gat_ok = {}                 # (id(graph handle), heads) -> (handle, does the device-resident GAT solver take it?)
 
     def initialparameters(self, rng):
         return self.model.initialparameters(rng)
@@ -534,13 +535,21 @@ class NeuralODE(AbstractExplicitLayer):
         members = getattr(g, "_members", None)
         member_plan = members is not None and len(members) > 1 and all(mm._handles is members[0]._handles for mm in members)
         handle = m._graph(members[0] if member_plan else g).handle()
-        if not _lib.load().ngpde_node_gat_supported(handle.ptr, 64, m.heads, m.out_chs):
-            return None
         with_backward = torch.is_grad_enabled() and (u.requires_grad or any(
             isinstance(v, torch.Tensor) and v.requires_grad for v in ps.values()))
         key = ("gat", id(handle), m.heads, m.act, m.negative_slope, bool(with_backward), len(members) if member_plan else 1)
         pool = self._plans.get(key)
         if pool is None:
+            # asked once per (graph handle, head count) of this NeuralODE: the check compares the two directions' schedules on the
+            # device and synchronises (the entry keeps the handle alive, so its id cannot be recycled)
+            ok = self._gat_ok.get((id(handle), m.heads))
+            if ok is None:
+                ok = (handle, bool(_lib.load().ngpde_node_gat_supported(handle.ptr, 64, m.heads, m.out_chs)))
+                self._gat_ok[(id(handle), m.heads)] = ok
+                while len(self._gat_ok) > 8:
+                    self._gat_ok.pop(next(iter(self._gat_ok)))
+            if not ok[1]:
+                return None
             pool = self._plans[key] = []
             while len(self._plans) > self.max_plans:
                 self._plans.pop(next(iter(self._plans)))
