@@ -346,6 +346,33 @@ def secondary(dev, world, rank, dist):
                 out["C3_gat_node_tsit5x50"]["generic_captured_value"] = round(ODE_STEPS / (ms2 * 1e-3), 1)
             finally:
                 os.environ.pop("NGPDE_NO_PERSISTENT", None)
+    if world == 1:
+        # NeuralODE(VMHConv(phi, gamma)) of docs/src/tutorials/VMH.md:75-89 at the tutorial's size: 3 000 points in the unit square,
+        # the 6 nearest neighbours of every point (the tutorial links Delaunay neighbours), h = 1, positions as node data, phi = 4 =>
+        # 60 => 60 => 60 => 40 and gamma = 41 => 60 => 60 => 60 => 1, tanh.  Generic solver (every stage the layer's own kernels --
+        # phi is deeper than the fused message path takes --, every combination one launch), captured into HIP graphs.
+        nv, kv, steps_v = 3000, 6, 20
+        pts = torch.as_tensor(S.uniform01(41, 2 * nv).reshape(2, nv).astype(np.float32), device=dev)
+        gk = ng.knn_graph(pts, kv)
+        gv = ng.GNNGraph(gk, ndata={"x": pts})
+        phi = ng.Chain(ng.Dense(4, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 40))
+        gam = ng.Chain(ng.Dense(41, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 60, "tanh"), ng.Dense(60, 1))
+        nodev = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gv), solver="tsit5", n_steps=steps_v, dt=0.2 / steps_v, capture=True)
+        psv_, stv_ = ng.setup(4, nodev)
+        psv_ = ng.to_device(psv_, dev)
+        for v in _grad_leaves(psv_):
+            v.requires_grad_(True)
+        uv = torch.as_tensor(S.normal(42, nv).reshape(1, nv).astype(np.float32), device=dev).requires_grad_(True)
+
+        def solvev():
+            for v in [uv] + _grad_leaves(psv_):
+                v.grad = None
+            uT, _ = nodev(uv, psv_, stv_)
+            uT.sum().backward()
+        msv = _time_ms(solvev, 5)
+        out["VMH_node_tsit5x20"] = {"nodes": nv, "edges": int(gv.num_edges), "ode_steps": steps_v, "ms_solve_forward_backward": round(msv, 3),
+                                    "value": round(steps_v / (msv * 1e-3), 1), "unit": "ODE-steps/s",
+                                    "path": "NeuralODE(VMHConv, capture=True): HIP-graph replay of the generic solver"}
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))
