@@ -447,7 +447,8 @@ int32_t ngpde_node_pipeline_stats(ngpde_node_t *plan, ngpde_stream_t stream, int
  *             more tiles than the device keeps resident, NGPDE_NO_PERSISTENT=1): use the generic solver.
  *   forward:  u0, uT [N][64]; with_backward plans keep the tape (stage inputs, y / z, alpha: ngpde_node_gat_tape_bytes).
  *   backward: duT [N][64] -> du0 [N][64], dweight (64 x 64, layout of weight), da (2c x heads), dbias [64] nullable.
- *   fault:    1 when a launch gave up waiting (outputs NaN); the plan then refuses further launches (ERR_STATE). */
+ *   fault:    1 when a launch gave up waiting (outputs NaN); the plan then refuses further launches (ERR_STATE).
+ *   supported: compares the two directions' tile schedules on the device and SYNCHRONISES: ask once per graph handle, not per solve. */
 int32_t ngpde_node_gat_supported(const ngpde_graph_t *g, int32_t din, int32_t heads, int32_t c);
 int32_t ngpde_node_gat_create(const ngpde_graph_t *g, int32_t heads, int32_t c, float negative_slope, int32_t act, int32_t tableau,
                               int32_t n_steps, double dt, int32_t with_backward, ngpde_node_gat_t **out);
