@@ -845,6 +845,52 @@ def test_gat_layer_one_launch_forward_and_pullback(heads, act, bias, loops, monk
         close(ps[k].grad, fused[k].cpu().double().numpy(), rtol=1e-4, atol=5e-5, what=k)
 
 
+@pytest.mark.parametrize("heads", [4, 2, 1])
+def test_gat_layer_and_solver_with_long_rows(heads, monkeypatch):
+    # rows of up to 24 entries + the self loop (a slot list holds 32): the second half of every lane's entry pair (entries
+    # 16 .. 31) and halos near their capacity -- the layer against the oracle, the device-resident solver against the generic one
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+    n, C = 420, 64 // heads
+    s, t = _local_graph(n, 130 + heads, max_deg=24, reach=14)
+    deg = np.bincount(t, minlength=n)
+    assert deg.max() >= 20
+    g = ng.GNNGraph(s, t, num_nodes=n, index_base=0)
+    og = O.Graph(s, t, num_nodes=n, index_base=0)
+    l = ng.GATConv((64, C), "tanh", heads=heads, concat=True, initialgraph=g)
+    ps, st = ng.setup(131, l)
+    ps = prep(ps, 131)
+    from ngpde_amd import functional as F
+    assert F.gat_layer_supported(l._graph(g).handle(), 64, heads, C)
+    x = torch.randn(64, n, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    pw = lambda k: ps[k].detach().cpu().double().numpy()
+    yo, c = O.gat_conv(x.detach().cpu().double().numpy(), pw("weight"), pw("a"), pw("bias"), og, heads, C, "tanh", concat=True)
+    close(y, yo)
+    R = np.random.default_rng(132).normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.gat_conv_backward(c, R)
+    close(x.grad, gr["x"], rtol=5e-4, atol=1e-4, what="dx")
+    for k in ("weight", "a", "bias"):
+        close(ps[k].grad, np.asarray(gr[k]).reshape(tuple(ps[k].shape)), rtol=5e-4, atol=3e-4, what=k)
+
+    def run(resident):
+        if resident:
+            monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+        else:
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        node = ng.NeuralODE(l, solver="tsit5", n_steps=2, dt=0.05)
+        _, st2 = ng.setup(131, node)
+        p2 = {k: v.detach().clone().requires_grad_(True) for k, v in ps.items()}
+        u = x.detach().clone().requires_grad_(True)
+        uT, _ = node(u, p2, st2)
+        uT.sum().backward()
+        return uT.detach(), u.grad, [p for pool in node._plans.values() for p in pool]
+    a, b = run(True), run(False)
+    assert a[2] and "gat" in a[2][0].flags() and not a[2][0].fault() and not b[2]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_gat_as_ode_right_hand_side_generic_solver_path():
     # BASELINE config 3 "as ODE RHS": du/dt = GATConv(64 => 4 x 16, concat)(u), stepped by NeuralODE's generic path (explicit
     # RK through the layer's kernels, gradients by autograd through every stage) against rk_solve / rk_adjoint of the oracle
