@@ -528,6 +528,8 @@ class NeuralODE(AbstractExplicitLayer):
         """the device-resident plan when the right-hand side is ONE GAT-style layer in the one-launch shape (64 => heads x c = 64,
         concat, tiles fit the LDS halo) and the library takes it (ngpde_node_gat_supported); None otherwise"""
         m = self.model
+        if isinstance(m, Chain) and len(m.chain) == 1 and isinstance(m.chain[0], GATConv):    # Chain(GATConv(...)): the same solve
+            m, ps, st = m.chain[0], ps["layer_1"], st["layer_1"]
         if not (isinstance(m, GATConv) and m.concat and u.is_cuda and m.in_chs == 64 and m.heads * m.out_chs == 64):
             return None
         g = st["graph"]
@@ -581,8 +583,9 @@ class NeuralODE(AbstractExplicitLayer):
             return uT.T, st
         gplan = self.gat_plan_for(ps, st, u)
         if gplan is not None:
-            b = ps["bias"].reshape(-1) if "bias" in ps else None
-            uT = _NodeGatFn.apply(u, rows_of(ps["weight"]), rows_of(ps["a"]), b, gplan)
+            gps = ps["layer_1"] if isinstance(self.model, Chain) else ps
+            b = gps["bias"].reshape(-1) if "bias" in gps else None
+            uT = _NodeGatFn.apply(u, rows_of(gps["weight"]), rows_of(gps["a"]), b, gplan)
             return uT.T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch

@@ -1020,6 +1020,17 @@ def test_gat_device_resident_solver_equals_the_generic_solver(heads, act, bias, 
     assert torch.equal(a[1], b[1]), "du0"
     for k in a[2]:
         close(a[2][k], b[2][k].cpu().double().numpy(), rtol=2e-5, atol=1e-5, what=k)
+    if heads == 4 and act == "relu":      # Chain(GATConv(...)) is the same right-hand side: the same plan kind, the same bits
+        monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+        nodec = ng.NeuralODE(ng.Chain(l), solver=solver, n_steps=steps, dt=0.05)
+        _, stc = ng.setup(91, nodec)
+        psc = {"layer_1": {k: v.detach().clone().requires_grad_(True) for k, v in ps0.items()}}
+        uc = u0.clone().requires_grad_(True)
+        uTc, _ = nodec(uc, psc, stc)
+        (uTc * R).sum().backward()
+        plansc = [p for pool in nodec._plans.values() for p in pool]
+        assert plansc and all("gat" in p.flags() for p in plansc)
+        assert torch.equal(uTc.detach(), a[0]) and torch.equal(uc.grad, a[1])
 
 
 @pytest.mark.parametrize("members", [2, 3])
@@ -1153,7 +1164,8 @@ def test_captured_generic_solve_replays_and_follows_parameter_updates(monkeypatc
     assert torch.equal(a1, a2) and len(captured._captured) == 2
 
 
-def test_captured_solve_follows_updategraph_in_a_container_and_guards_its_single_tape():
+def test_captured_solve_follows_updategraph_in_a_container_and_guards_its_single_tape(monkeypatch):
+    monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")     # the captured GENERIC solver is the subject (Chain(GATConv) alone takes the device-resident one)
     # (i) a container right-hand side keeps its graphs in st["layer_k"]["graph"]: updategraph(st, g2) must capture anew instead of
     # replaying launches with the old graph's arrays baked in; (ii) a captured solve holds ONE tape: the backward of a solve
     # whose tape a later forward replaced raises instead of returning the other solve's gradients
