@@ -179,9 +179,19 @@ def ptr(t):
     return t.ctypes.data
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """hipStream_t of torch's current stream on the current device.  Through torch's raw accessors where this build has them:
+    torch.cuda.current_stream() builds a Stream object and resolves the device by name -- 25-30 us per call, more than the
+    one-launch GAT layer takes on the device"""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        _raw_stream = (lambda: get(dev())) if (get and dev) else (lambda: torch.cuda.current_stream().cuda_stream)
+    return _raw_stream()
 
 
 # ---- destruction of library objects from Python finalisers -----------------------------------------------------------------
