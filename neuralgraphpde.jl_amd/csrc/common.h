@@ -185,6 +185,8 @@ struct NodePersistFwd {
   size_t row_elems = 0, mask_bytes = 0;
   bool interleave = false;     // two members of a batch at a time per workgroup: bufA / bufB hold two [N][64] arrays each
   bool pair = false;           // two TILES of the one member per workgroup (graphs of more tiles than co-resident workgroups)
+  int k_tiles = 0;             // > 0: tile rounds -- k_tiles tiles per workgroup taking turns, their state in `state` [7][N][64]
+  float *state = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 struct NodePersistBwd {
@@ -198,13 +200,15 @@ struct NodePersistBwd {
   float *slab_dw1 = nullptr, *slab_db1 = nullptr, *slab_dw2 = nullptr, *slab_db2 = nullptr;
   bool interleave = false;     // two members at a time: g1 / g2 hold two [N][64] arrays each, ubar = [2][5][N][64] scratch
   bool pair = false;           // two tiles of the one member per workgroup (ubar = [5][N][64] scratch)
+  int k_tiles = 0;             // > 0: tile rounds (ubar = [5][N][64], lam holds lambda between the turns)
   float *ubar = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool node_persistent_interleave_env();
 bool node_persistent_disabled_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
-int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd);   // 0 none, 1 one tile per workgroup, 2 tile pairs
+int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd);   // 0 none, 1 one tile per workgroup, 2 tile pairs, 3 tile rounds
+int node_persistent_rounds(const ngpde_graph *g);                               // mode 3: tiles per workgroup
 int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps, bool pair = false);
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);

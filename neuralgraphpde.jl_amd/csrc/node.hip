@@ -125,6 +125,8 @@ struct ngpde_node {
   // (ustage, pbuf, g1, g2) hold one [N][d] array per slot, pubar is the adjoint's stage-adjoint scratch [2][5][N][d]
   bool interleave = false;
   bool pair = false;         // ONE member, two tiles per workgroup (graphs of up to twice the co-resident tile count)
+  int ktiles = 0;            // > 0: tile rounds -- ktiles tiles per workgroup taking turns (larger graphs still); kstate = their u, k_j rows
+  float *kstate = nullptr;
   float *pubar = nullptr;
 
   hipStream_t cap_stream = nullptr;
@@ -329,7 +331,7 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   if (p->with_bwd) {
     a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   }
-  a.interleave = p->interleave; a.pair = p->pair;
+  a.interleave = p->interleave; a.pair = p->pair; a.k_tiles = p->ktiles; a.state = p->kstate;
   a.ev_start = ev0; a.ev_stop = ev1;
   return launch_node_fwd_persistent(a, stream);
 }
@@ -340,12 +342,12 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
-  a.interleave = p->interleave; a.pair = p->pair; a.ubar = p->pubar;
+  a.interleave = p->interleave; a.pair = p->pair; a.ubar = p->pubar; a.k_tiles = p->ktiles;
   a.ev_start = ev0; a.ev_stop = ev1;
   int32_t st;
   if ((st = launch_node_bwd_persistent(a, stream))) return st;
   const int dd = p->d * p->d;
-  const int ns = p->pair ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
+  const int ns = (p->pair || p->ktiles) ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
   if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
   if ((st = launch_reduce_slabs(p->slab_db1, ns, p->d, 0, p->db1, stream))) return st;
   if ((st = launch_reduce_slabs(p->slab_dw2, ns, dd, p->d / 16, p->dw2, stream))) return st;
@@ -403,6 +405,7 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
   if (p->masks) (void)hipFree(p->masks);
   if (p->pbuf) (void)hipFree(p->pbuf);
   if (p->pubar) (void)hipFree(p->pubar);
+  if (p->kstate) (void)hipFree(p->kstate);
   node_persistent_free(&p->persist);
   delete p;
   return NGPDE_OK;
@@ -447,7 +450,8 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   // adjoint reads the pre-activations from a tape of its own layout.  (Interleaved batches: relu only.)
   const int pmode = p->pre ? node_persistent_mode(g, d, act, p->with_bwd) : 0;
   p->pair = pmode == 2 && members == 1 && (!p->with_bwd || p->mask_mode);
-  bool want_persist = (pmode == 1 && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1))) || p->pair;
+  p->ktiles = (pmode == 3 && members == 1) ? node_persistent_rounds(g) : 0;
+  bool want_persist = (pmode == 1 && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1))) || p->pair || p->ktiles > 0;
   const int S = p->tb.S;
   int32_t st = NGPDE_OK;
   if (want_persist) {
@@ -477,7 +481,12 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
       p->persist_fwd = p->persist_bwd = false;
     }
     if (!p->persist_fwd) p->pair = false;
+    if (p->ktiles > 0) {   // tile rounds: both directions or none; the grid is ceil(tiles / K)
+      if (p->persist_fwd && (p->persist_bwd || !p->with_bwd)) p->persist.pair_wgs = (p->persist.n_tiles + p->ktiles - 1) / p->ktiles;
+      else { p->persist_fwd = p->persist_bwd = false; p->ktiles = 0; }
+    }
   }
+  if (!p->persist_fwd) p->ktiles = 0;
   // activations other than relu: the persistent pair needs BOTH directions persistent (the tapes' layouts differ from the replayed plan's)
   if (p->with_bwd && !p->mask_mode && !(p->persist_fwd && p->persist_bwd)) p->persist_fwd = p->persist_bwd = false;
   p->ztape_mode = p->with_bwd && !p->mask_mode && p->persist_fwd && p->persist_bwd;
@@ -507,7 +516,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   }
   if (p->with_bwd) {
     A(&p->lam, p->all_elems); A(&p->g1, xslots * p->row_elems); A(&p->g2, xslots * p->row_elems);
-    if (p->interleave || p->pair) A(&p->pubar, 2 * 5 * p->row_elems);
+    if (p->interleave || p->pair || p->ktiles) A(&p->pubar, 2 * 5 * p->row_elems);
     p->ubar.assign(S, nullptr);
     for (int j = 1; j < S; ++j) A(&p->ubar[j], p->row_elems);
     const size_t dd = (size_t)d * d;
@@ -523,6 +532,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
     A(&p->dw1, dd); A(&p->db1, d); A(&p->dw2, dd); A(&p->db2, d);
   }
   if (st == NGPDE_OK && p->persist_fwd) A(&p->pbuf, xslots * p->row_elems);
+  if (st == NGPDE_OK && p->ktiles) A(&p->kstate, 7 * p->row_elems);
   if (st == NGPDE_OK && p->ztape_mode) p->ztape = p->tape + (size_t)n_steps * S * 2 * p->all_elems;
   if (st == NGPDE_OK && members > 1 && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd)))
     st = fail(NGPDE_ERR_UNSUPPORTED, "ngpde_node_gcn2_create_batch: the member-by-member solve exists for the persistent plan only "
@@ -563,7 +573,7 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
-           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0);
+           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0);
   return NGPDE_OK;
 }
 

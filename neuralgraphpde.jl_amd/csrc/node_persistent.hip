@@ -47,6 +47,7 @@ static_assert(PG::R == 1 && PG::GROUPS == kTM && PG::LPR == 16, "one 16-lane gro
 constexpr int kXhF = (kHaloCap + 1) * PD;   // halo region (floats), +1: the all-zero row
 constexpr int kTileF = kTM * PG::TS;        // one 32-row MFMA operand / result tile
 constexpr int kWF = PD * PG::TS;            // one transposed weight matrix
+constexpr int kMaxTileRounds = 8;            // tile rounds: at most this many tiles per workgroup
 constexpr int kNbrStride = 64;              // wait-list stride per tile; at most 63 entries (one lane of the polling wave each,
                                             // lane 63 watches the abort word)
 
@@ -374,6 +375,8 @@ struct PFwdK {
   size_t row_elems, mask_bytes;
   size_t flag_stride;  // two-slot kernels: slot s uses bufA / bufB + s * row_elems and the flag words m.flags + s * flag_stride
   int pair_wgs;        // tile-pair mode of the two-slot kernels (PAIR): the grid; workgroup b holds tiles t and t + pair_wgs of ONE member
+  int k_tiles;         // tile-round mode (node_fwd_persistentK_kernel): workgroup b holds tiles t, t + pair_wgs, ..., k_tiles of them
+  float *state;        // ... and keeps their state in memory: [7][N][64] own rows -- u, k_0 .. k_5 (k rows zero at launch)
   const float *cf;     // device table [36 + 6]: cf[i * 6 + j], j < i: coefficient of k_j in the array written after stage i (next
                        // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
 };
@@ -462,6 +465,104 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   }
   // (a tile writes its rows of u(T) only after all readers of its u0 rows are past that member's first phase)
   if (c.valid) st4_g(p.u_out + (size_t)mb * p.row_elems, own, f4_sel(ok, u, f4_nan()));
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward solve, K tiles per workgroup taking turns ("tile rounds"): graphs of more tiles than two per co-resident workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup b holds tiles t, t + W, ..., t + (K - 1) W (W = the grid) and walks them in that order in EVERY phase.  Nothing of a
+// tile lives in registers across its turns: u and the stage derivatives are own rows of p.state (the same thread writes and
+// reads them), the slot / halo tables are re-read per turn, and ONE layer's W^T is in LDS at a time (staged once per phase for
+// all K tiles).  No gather-ahead pipeline is needed: by the time a tile's turn comes again the workgroup has spent K - 1 turns on
+// its other tiles, and the neighbours' rows and flags of the previous phase have long arrived (what the GAT solver's batch kernels
+// showed, gat_fused.hip).  A workgroup's own tiles may even be neighbours: turn s of phase ph needs the others' phase ph - 1 only.
+// Arithmetic per tile is node_fwd_persistent_kernel's, operation for operation.
+template <int ACT, bool TAPE>
+__global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const PFwdK p) {
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMetaF + 48 + 4];
+  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW = ldsZ + kTileF, *ldsB = ldsW + kWF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48);
+  const int tid = threadIdx.x, q = tid & 15;
+  if (tid < 42) ldsC[tid] = p.cf[tid];
+  const int act = ACT >= 0 ? ACT : p.act;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  if (tid < PD) ldsB[tid] = p.b1 ? p.b1[tid] : 0.f;
+  else if (tid < 2 * PD) ldsB[tid] = p.b2 ? p.b2[tid - PD] : 0.f;
+  if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
+  if (tid == 0) *s_ok = 1;
+  const int W = p.pair_wgs, K = p.k_tiles;
+  const int t0 = xcd_tile(blockIdx.x, W);
+  const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  __syncthreads();
+  const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[q];
+  bool ok = true;
+  int ph = 0;
+  for (int n = 0; n < p.n_steps && ok; ++n) {
+    for (int i = 0; i < p.S && ok; ++i) {
+#pragma unroll 1
+      for (int layer = 0; layer < 2 && ok; ++layer) {
+        ++ph;
+        const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
+        const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
+        const bool last_phase = (n == p.n_steps - 1 && i == p.S - 1 && layer == 1);
+        load_weight_lds(layer == 0 ? p.w1 : p.w2, ldsW, tid, true);   // (every wave is past the previous phase's products: its last publish)
+        for (int s = 0; s < K; ++s) {
+          const int tile = t0 + s * W;
+          if (tile >= p.m.n_tiles) break;   // uniform
+          TileCtx c;
+          tile_ctx_init(p.m, c, ldsMeta, tile);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          __syncthreads();   // the turn's tables (and the phase's W) are in LDS
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          halo_fill_all(c, X, ldsXh);
+          wait_vmcnt0();
+          __syncthreads();
+          float4 acc = f4_scale(c.ci, tile_aggregate_lean(c, ldsXh));
+          *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
+          if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
+          __syncthreads();
+          mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, c.wave_u, c.lane);
+          __syncthreads();
+          const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
+          const uint8_t sign_bits = (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
+          const float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());
+          if (layer == 0) {
+            if (c.valid) store_sc1(p.bufB, own, yv);
+          } else {
+            // state rows: 0 = u, 1 + j = k_j (zero at launch, like the registers of the one-tile kernel); k_i is yv itself
+            const float4 u = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
+            const float4 k0 = i == 0 ? yv : ld4_g(p.state, own + rowb), k1 = i == 1 ? yv : ld4_g(p.state, own + 2 * rowb),
+                         k2 = i == 2 ? yv : ld4_g(p.state, own + 3 * rowb), k3 = i == 3 ? yv : ld4_g(p.state, own + 4 * rowb),
+                         k4 = i == 4 ? yv : ld4_g(p.state, own + 5 * rowb);
+            float4 v = f4_scale(ldsC[36 + i], yv);
+            v = f4_fma(1.0f, u, v);
+            v = f4_fma(ldsC[i * 6 + 0], k0, v); v = f4_fma(ldsC[i * 6 + 1], k1, v); v = f4_fma(ldsC[i * 6 + 2], k2, v);
+            v = f4_fma(ldsC[i * 6 + 3], k3, v); v = f4_fma(ldsC[i * 6 + 4], k4, v);
+            if (c.valid) {
+              st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);
+              if (i == p.S - 1) st4_g(p.state, own, v);
+              if (last_phase) st4_g(p.u_out, own, v);
+              store_sc1(p.bufA, own, v);
+            }
+          }
+          tile_publish(p.m, c, ph);
+          if constexpr (TAPE && ACT == NGPDE_ACT_RELU) stu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid, sign_bits);
+          else if (TAPE && c.valid) st4_stream_g(p.ztape + ev * p.row_elems, own, z);
+        }
+      }
+    }
+  }
+  if (!ok) {   // a wait was aborted: poison every row this workgroup owns
+    __syncthreads();
+    for (int s = 0; s < K; ++s) {
+      const int tile = t0 + s * W;
+      if (tile >= p.m.n_tiles) break;
+      const int4 sc = p.m.sched[(size_t)tile * kTM + (tid >> 4)];
+      if (sc.x >= 0) st4_g(p.u_out, (unsigned)sc.x * (unsigned)(PD * 4) + (unsigned)(q * 16), f4_nan());
+    }
   }
 }
 
@@ -683,6 +784,7 @@ struct PBwdK {
   size_t row_elems, mask_bytes;
   float *slab_dw1, *slab_db1, *slab_dw2, *slab_db2;   // [n_tiles][...] written ONCE, at the end
   int pair_wgs;        // tile-pair mode (PAIR): the grid; workgroup b holds tiles t and t + pair_wgs of ONE member
+  int k_tiles;         // tile-round mode (node_bwd_persistentK_kernel): k_tiles tiles per workgroup, state in lam / ubar (zero at launch)
   size_t flag_stride;  // two-slot kernel: slot s uses g1 / g2 + s * row_elems, the flag words m.flags + s * flag_stride and
   float *ubar;         // the stage-adjoint scratch ubar + s * 5 * row_elems ([slot][5][N][64])
   const float *cb;     // device table [6 + 36 + 6], copied to LDS: cb[j] = dt * b[j]; cb[6 + i * 6 + j], j > i >= 1: dt * a[j][i-1], the
@@ -1186,6 +1288,207 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
   if (c.tid == 0 && p.m.stats) p.m.stats[2 * c.tile + 1] = n_ahead;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// adjoint, K tiles per workgroup taking turns (see node_fwd_persistentK_kernel): lambda and the stage adjoints are own rows of
+// p.lam / p.ubar (zero at launch where the one-tile kernel starts from zero registers), one layer's W in LDS at a time, the
+// parameter-gradient accumulators in registers over all tiles and phases (one slab per WORKGROUP at the end).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const PBwdK p) {
+  constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
+  using Aux = typename std::conditional<RELU, unsigned, float4>::type;
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMetaF + 48 + 4];
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW = ldsX + kTileF;
+  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMetaF;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 48) ldsC[tid] = p.cb[tid];
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
+  if (tid == 0) *s_ok = 1;
+  constexpr int NT = PG::CT * PG::CT;
+  f32x4 dw1[PG::DWT], dw2[PG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.f, db2 = 0.f;
+  const int dbc = tid / PG::DBP, dbpart = tid % PG::DBP;
+  const int S = p.S, W = p.pair_wgs, K = p.k_tiles;
+  const int t0 = xcd_tile(blockIdx.x, W);
+  const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  __syncthreads();
+
+  // the dense half of a turn (node_bwd_persistent_kernel's, with the tile context as an argument)
+  auto dense = [&](const TileCtx &c, unsigned own, int ph, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout) {
+    kbar = f4_scale(c.ci, kbar);
+    float4 dz;
+    if constexpr (RELU) {
+      dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f, (mk & 8u) ? kbar.w : 0.f)
+                   : f4_zero();
+    } else {
+      dz = f4_sel(c.valid, f4_mul(kbar, f4_dact(p.act, mk)), f4_zero());
+    }
+    *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
+    *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
+    __syncthreads();
+    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
+    __syncthreads();
+    const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
+    if (c.valid) store_sc1(gout, own, gv);
+    tile_publish(p.m, c, ph);
+    const int i16 = c.lane & 15, kq = c.lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = c.wave_u + PG::WAVES * mm;
+      if (tt < NT) {   // wave-uniform
+        const int mt = tt / PG::CT, nt = tt % PG::CT;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          float a[kTM / 8], b[kTM / 8];
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) {
+            a[ks] = ldsX[(4 * (ks + 4 * kh) + kq) * PG::TS + mt * 16 + i16];
+            b[ks] = ldsDZ[(4 * (ks + 4 * kh) + kq) * PG::TS + nt * 16 + i16];
+          }
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) dwl[mm] = mfma16(a[ks], b[ks], dwl[mm]);
+        }
+      }
+    }
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int nn = dbpart; nn < kTM; nn += PG::DBP) s += ldsDZ[nn * PG::TS + dbc];
+#pragma unroll
+      for (int o = 1; o < PG::DBP; o <<= 1) s += __shfl_xor(s, o);
+      dbl += s;
+    }
+  };
+  auto tape_row = [&](size_t ev, unsigned own) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
+  auto mask_of = [&](size_t ev, const TileCtx &c, unsigned own) -> Aux {
+    if constexpr (RELU) return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+    else return ld4_stream_g(p.ztape + ev * p.row_elems, own);
+  };
+
+  bool ok = true;
+  int ph = 0;
+  {   // first phase: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather, no wait)
+    ++ph;
+    const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
+    load_weight_lds(p.w2, ldsW, tid, false);
+    for (int s = 0; s < K; ++s) {
+      const int tile = t0 + s * W;
+      if (tile >= p.m.n_tiles) break;
+      TileCtx c;
+      tile_ctx_init(p.m, c, ldsMeta, tile);
+      const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      __syncthreads();
+      const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
+      dense(c, own, ph, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev, c, own), tape_row(ev, own), p.g2);
+    }
+  }
+  for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+    for (int i = S - 1; i >= 0 && ok; --i) {
+      {   // layer 1 of stage i: dL/dy1 = A^T g2
+        ++ph;
+        const size_t ev = (size_t)(n * S + i) * 2;
+        __syncthreads();
+        load_weight_lds(p.w1, ldsW, tid, false);
+        for (int s = 0; s < K; ++s) {
+          const int tile = t0 + s * W;
+          if (tile >= p.m.n_tiles) break;
+          TileCtx c;
+          tile_ctx_init(p.m, c, ldsMeta, tile);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          __syncthreads();
+          const Aux mk = mask_of(ev, c, own);
+          const float4 xrow = tape_row(ev, own);
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          halo_fill_all(c, p.g2, ldsXh);
+          wait_vmcnt0();
+          __syncthreads();
+          const float4 t = tile_aggregate_lean(c, ldsXh);
+          __syncthreads();   // every thread has its sum: the region becomes the product's result tile
+          dense(c, own, ph, dw1, db1, t, mk, xrow, p.g1);
+        }
+        if (!ok) break;
+      }
+      {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
+        ++ph;
+        const bool last = (i == 0 && n == 0);
+        const size_t ev = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;
+        __syncthreads();
+        load_weight_lds(p.w2, ldsW, tid, false);
+        for (int s = 0; s < K; ++s) {
+          const int tile = t0 + s * W;
+          if (tile >= p.m.n_tiles) break;
+          TileCtx c;
+          tile_ctx_init(p.m, c, ldsMeta, tile);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          __syncthreads();
+          Aux mk{};
+          float4 xrow = f4_zero();
+          if (!last) {
+            mk = mask_of(ev, c, own);
+            xrow = tape_row(ev, own);
+          }
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          halo_fill_all(c, p.g1, ldsXh);
+          wait_vmcnt0();
+          __syncthreads();
+          const float4 t = tile_aggregate_lean(c, ldsXh);
+          __syncthreads();
+          // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5); U-bar_i is t itself
+          const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
+          const float4 ub1 = i == 1 ? t : ld4_g(p.ubar, own), ub2 = i == 2 ? t : ld4_g(p.ubar, own + rowb),
+                       ub3 = i == 3 ? t : ld4_g(p.ubar, own + 2 * rowb), ub4 = i == 4 ? t : ld4_g(p.ubar, own + 3 * rowb),
+                       ub5 = i == 5 ? t : ld4_g(p.ubar, own + 4 * rowb);
+          float4 kbar;
+          if (i >= 1) {
+            if (c.valid) st4_g(p.ubar, own + (unsigned)(i - 1) * rowb, t);
+            float4 v = f4_scale(ldsC[42 + i], t);
+            v = f4_fma(ldsC[i - 1], lam, v);
+            v = f4_fma(ldsC[6 + i * 6 + 2], ub2, v); v = f4_fma(ldsC[6 + i * 6 + 3], ub3, v);
+            v = f4_fma(ldsC[6 + i * 6 + 4], ub4, v); v = f4_fma(ldsC[6 + i * 6 + 5], ub5, v);
+            kbar = v;
+          } else {
+            float4 v = f4_scale(1.0f, t);
+            v = f4_fma(1.0f, lam, v);
+            v = f4_fma(1.0f, ub1, v); v = f4_fma(1.0f, ub2, v); v = f4_fma(1.0f, ub3, v);
+            v = f4_fma(1.0f, ub4, v); v = f4_fma(1.0f, ub5, v);
+            if (c.valid) st4_g(p.lam, own, v);
+            kbar = f4_scale(ldsC[S - 1], v);
+          }
+          if (!last) dense(c, own, ph, dw2, db2, kbar, mk, xrow, p.g2);
+          else __syncthreads();
+        }
+        if (!ok) break;
+      }
+    }
+  }
+  if (!ok) {
+    __syncthreads();
+    for (int s = 0; s < K; ++s) {
+      const int tile = t0 + s * W;
+      if (tile >= p.m.n_tiles) break;
+      const int4 sc = p.m.sched[(size_t)tile * kTM + (tid >> 4)];
+      if (sc.x >= 0) st4_g(p.lam, (unsigned)sc.x * (unsigned)(PD * 4) + (unsigned)((tid & 15) * 16), f4_nan());
+    }
+  }
+  const float bad = __int_as_float(0x7fc00000);
+  auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
+    float4 *slab4 = reinterpret_cast<float4 *>(slab_dw + (size_t)blockIdx.x * PD * PD);
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = wave_u + PG::WAVES * mm;
+      if (tt < NT) slab4[tt * 64 + lane] = f4_sel(ok, make_float4(dwl[mm][0], dwl[mm][1], dwl[mm][2], dwl[mm][3]), f4_nan());
+    }
+    if (dbpart == 0) slab_db[(size_t)blockIdx.x * PD + dbc] = ok ? dbl : bad;
+  };
+  write_slab(dw1, db1, p.slab_dw1, p.slab_db1);
+  write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
+}
+
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -1263,8 +1566,26 @@ int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd) {
   if (nt <= resident) return 1;
   const char *no_pairs = std::getenv("NGPDE_NO_TILE_PAIRS");
   if (no_pairs && no_pairs[0] == '1') return 0;
-  if (nt <= 2 * resident && (!with_bwd || act == NGPDE_ACT_RELU)) return 2;
+  const char *rounds = std::getenv("NGPDE_TILE_ROUNDS");   // 1: tile rounds also where tile pairs would do (A/B runs)
+  if (nt <= 2 * resident && (!with_bwd || act == NGPDE_ACT_RELU) && !(rounds && rounds[0] == '1')) return 2;
+  if (nt <= kMaxTileRounds * resident) return 3;   // K tiles per workgroup taking turns (node_*_persistentK_kernel)
   return 0;
+}
+int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per workgroup
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  int occ = 1 << 30;
+  auto take = [&](auto kernel) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, kThreads, 0) != hipSuccess) o = 0;
+    occ = std::min(occ, o);
+  };
+  take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false>);
+  take(node_fwd_persistentK_kernel<-1, true>); take(node_fwd_persistentK_kernel<-1, false>);
+  take(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>); take(node_bwd_persistentK_kernel<-1>);
+  const int nt = g->n_sched / kTileRows, resident = cus * occ;
+  if (resident < 1) return 0;
+  return (nt + resident - 1) / resident;
 }
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) { return node_persistent_mode(g, d, act, with_bwd) == 1; }
 
@@ -1411,6 +1732,25 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   k.pair_wgs = a.pair ? ps.pair_wgs : 0;
   k.cf = ps.coef;
   NGPDE_REQUIRE(!a.pair || (ps.pair_wgs > 0 && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE, "tile-pair launch without its setup");
+  k.k_tiles = a.k_tiles; k.state = a.state;
+  if (a.k_tiles > 0) {   // tile rounds: K tiles per workgroup, state in memory
+    NGPDE_REQUIRE(ps.pair_wgs > 0 && a.n_members == 1 && a.state, NGPDE_ERR_STATE, "tile-round launch without its setup");
+    k.pair_wgs = ps.pair_wgs; k.ztape = a.ztape;
+    if ((st = launch_zero(a.state + a.row_elems, 6 * a.row_elems * sizeof(float), stream))) return st;   // k_0 .. k_5 start from zero
+    const dim3 gridk(ps.pair_wgs), blockk(kThreads);
+#define NGPDE_PFK_LAUNCH(AA, TT)                                                                                                  \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+    else hipLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, k);
+    if (a.tape && a.act == NGPDE_ACT_RELU) { NGPDE_PFK_LAUNCH(NGPDE_ACT_RELU, true) }
+    else if (a.tape) { NGPDE_PFK_LAUNCH(-1, true) }
+    else if (a.act == NGPDE_ACT_RELU) { NGPDE_PFK_LAUNCH(NGPDE_ACT_RELU, false) }
+    else { NGPDE_PFK_LAUNCH(-1, false) }
+#undef NGPDE_PFK_LAUNCH
+    NGPDE_LAUNCH_CHECK("node_fwd_persistentK_kernel");
+    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+    return turnstile_leave(stream, dev);
+  }
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
   if (a.pair) {                                                                                                              \
@@ -1460,6 +1800,25 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   k.ubar = a.ubar;
   NGPDE_REQUIRE(!a.pair || (ps.pair_wgs > 0 && !a.interleave && a.n_members == 1 && a.act == NGPDE_ACT_RELU), NGPDE_ERR_STATE,
                 "tile-pair launch without its setup");
+  k.k_tiles = a.k_tiles;
+  if (a.k_tiles > 0) {   // tile rounds
+    NGPDE_REQUIRE(ps.pair_wgs > 0 && a.n_members == 1 && a.ubar, NGPDE_ERR_STATE, "tile-round launch without its setup");
+    NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
+    k.pair_wgs = ps.pair_wgs;
+    if ((st = launch_zero(a.ubar, 5 * a.row_elems * sizeof(float), stream))) return st;   // the stage adjoints start from zero
+    const dim3 gridk(ps.pair_wgs), blockk(kThreads);
+    if (a.act == NGPDE_ACT_RELU) {
+      if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>, gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>, gridk, blockk, 0, stream, k);
+    } else {
+      if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistentK_kernel<-1>, gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL(node_bwd_persistentK_kernel<-1>, gridk, blockk, 0, stream, k);
+    }
+    NGPDE_LAUNCH_CHECK("node_bwd_persistentK_kernel");
+    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+    return turnstile_leave(stream, dev);
+  }
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (a.pair) {
     NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "tile-pair persistent adjoint without its stage-adjoint scratch");
