@@ -769,6 +769,59 @@ def test_node_persistent_tile_pairs_beyond_512_tiles(N, tab, nsteps, monkeypatch
         close(a[2 + 2 * k], acc[k]["weight"], rtol=5e-3, atol=1e-3, what=f"dW{k + 1}")
 
 
+@pytest.mark.parametrize("N,tab,nsteps,act", [(40000, "tsit5", 2, "relu"), (33000, "euler", 3, "tanh"), (70000, "tsit5", 1, "relu")])
+def test_node_persistent_tile_rounds_beyond_1024_tiles(N, tab, nsteps, act, monkeypatch):
+    # graphs of more than two 32-row tiles per co-resident workgroup (> 32 768 nodes on the MI355X): k tiles per workgroup taking
+    # turns, their state in memory (node_*_persistentK_kernel).  40 000 nodes = 1 250 tiles = 3 per workgroup with the last
+    # workgroups short of one, 33 000 = 1 032 (just over the tile pairs' reach; tanh: the pre-activation tape), 70 000 = 2 188 = 5
+    # per workgroup.  u(T) and du0 bit for bit equal to the replayed plan; 40 000 also against the float64 oracle.
+    needs_persistent_plan(monkeypatch)
+    d, dt = 64, 0.05
+    g, og, params = spatial_case(N, 4 * N, d, seed=N % 1000)
+    rng = np.random.default_rng(N)
+    u0n, Rn = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+    outs = {}
+    for mode in ("rounds", "replayed"):
+        if mode == "replayed":
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+        node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = torch.as_tensor(u0n.astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        plan = next(iter(node._plans.values()))[0]
+        if mode == "rounds":
+            assert {"persistent_fwd", "persistent_bwd", "tile_rounds"} <= plan.flags(), plan.flags()
+        else:
+            assert "persistent_fwd" not in plan.flags()
+        (uT * torch.as_tensor(Rn.astype(np.float32), device=DEV)).sum().backward()
+        assert not plan.fault()
+        outs[mode] = [uT.detach().clone(), u.grad.clone()] + [ps[l][k].grad.clone() for l in ("layer_1", "layer_2") for k in ("weight", "bias")]
+        with torch.no_grad():                       # the forward-only plan
+            uT2, _ = node(u.detach(), ps, st)
+        assert torch.equal(uT2, outs[mode][0])
+    a, b = outs["rounds"], outs["replayed"]
+    assert torch.equal(a[0], b[0]), "u(T)"
+    assert torch.equal(a[1], b[1]), "du0"
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-5 * float(y.abs().max()))
+    if N == 40000:
+        uTo, du0o, acc = _oracle_node_with_seed(params, og, u0n, Rn, O.TABLEAUS[tab], dt, nsteps)
+        close(a[0], uTo, rtol=2e-4, what="u(T)")
+        # du0: relu' is decided by rounding where a pre-activation is within an ulp of zero (3e7 of them here: a few flip), and each
+        # kink moves du0 in the rows around it -- every node within 5e-4 of the largest entry except at most 0.5 % of them, those within 20x
+        dcol = np.abs(a[1].cpu().double().numpy() - du0o).max(axis=0)
+        bound = 5e-4 * np.abs(du0o).max() + 1e-4
+        assert (dcol > bound).sum() <= 0.005 * dcol.size and dcol.max() <= 20 * bound, f"du0: {(dcol > bound).sum()} nodes beyond {bound:.2e}, max {dcol.max():.2e}"
+
+
 def test_node_persistent_abort_poisons_outputs_and_the_plan_refuses_further_work(monkeypatch):
     # a persistent launch whose waits give up (forced here: NGPDE_DEBUG_FORCE_ABORT=1 starts the launch with its abort word set;
     # in production: another kernel holding the compute units for ~2 s) writes NaN outputs and latches the plan's fault word,
