@@ -729,6 +729,25 @@ def main():
                                                 "unit": "GB/s", "frac": round(bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "what": "whole solve + adjoint: algorithmic bytes of 2 x C2 per right-hand-side evaluation"}}
             plan2 = None
+            # ... and of FOUR times the size (65 536 nodes, 2 048 tiles): k tiles per workgroup taking turns ("tile rounds")
+            n4 = 4 * N_NODES
+            _, s4, t4 = S.closest_pairs_graph(n4, 4 * N_PAIRS, seed=GRAPH_SEED + 2)
+            g4 = ng.GNNGraph(s4, t4, num_nodes=n4, index_base=0)
+            plan4 = _Plan(g4.handle((True, None, False)), D, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
+            u4 = dv(S.normal(2001, D * n4).reshape(n4, D).astype(np.float32))
+            uT4, du4, seed4 = torch.empty_like(u4), torch.empty_like(u4), torch.ones_like(u4)
+
+            def solve4():
+                _lib.check(lib.ngpde_node_gcn2_forward(plan4.ptr, p(u4), p(w1d), p(b1d), p(w2d), p(b2d), p(uT4), stream))
+                _lib.check(lib.ngpde_node_gcn2_backward(plan4.ptr, p(seed4), p(du4), p(gw[0]), p(gw[1]), p(gw[2]), p(gw[3]), stream))
+            ms4 = _time_ms(solve4, 3)
+            bytes4 = 4.0 * 2 * 6 * ODE_STEPS * (BYTES_FWD_LAYER + BYTES_BWD_LAYER)
+            out["larger_graph"]["x4"] = {"nodes": n4, "edges": int(s4.size), "tiles": n4 // 32, "value": round(ODE_STEPS / (ms4 * 1e-3), 1),
+                                         "unit": "ODE-steps/s", "ms_per_solve_forward_backward": round(ms4, 3), "plan": sorted(plan4.flags()),
+                                         "fault": bool(plan4.fault()),
+                                         "roofline": {"bound": "hbm", "achieved": round(bytes4 / (ms4 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                      "unit": "GB/s", "frac": round(bytes4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            plan4 = None
         if world == 1 and not args.no_cpu_baseline:
             cb, outs = cpu_baseline(s, t, u0_h, w1_h, b1_h, w2_h, b2_h)
             out["cpu_baseline"] = cb
