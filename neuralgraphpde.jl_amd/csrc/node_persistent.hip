@@ -157,6 +157,45 @@ __device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, flo
   c.my_nbr = m.nbr[(size_t)c.tile * kNbrStride + c.lane];
 }
 
+// Tile rounds (node_*_persistentK_kernel): the tables of ALL the workgroup's tiles stay in LDS for the whole launch -- slot words,
+// halo node ids, schedule entries, wait list, halo count per tile -- so that a turn sets its context up from LDS instead of
+// re-reading five arrays from memory (one round trip and a barrier per turn).
+constexpr int kMetaKF = kMetaF + kTM * 4 + kNbrStride + 4;   // floats per tile
+__device__ __forceinline__ void tile_tables_to_lds(const TileMeta &m, int tile, float *base) {
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
+  const size_t pos = (size_t)tile * kTM + grp;
+  unsigned *ls = reinterpret_cast<unsigned *>(base);
+  int *lh = reinterpret_cast<int *>(base + kTM * 8);
+  int4 *lsc = reinterpret_cast<int4 *>(base + kMetaF);
+  int *ln = reinterpret_cast<int *>(base + kMetaF + kTM * 4);
+  if (q < 8) ls[grp * 8 + q] = reinterpret_cast<const unsigned *>(m.slots)[pos * 8 + q];
+  if (q >= 8 && q < 10) lh[grp + 32 * (q - 8)] = m.halo[(size_t)tile * kHaloCap + grp + 32 * (q - 7)].x;
+  if (q == 10) lsc[grp] = m.sched[pos];
+  if (tid < kNbrStride) ln[tid] = m.nbr[(size_t)tile * kNbrStride + tid];
+  if (tid == kNbrStride) ln[kNbrStride] = m.tile_info[tile].x;
+}
+__device__ __forceinline__ void tile_ctx_from_lds(TileCtx &c, int tile, const float *base) {
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave_u = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.grp = c.tid >> 4;
+  c.q = c.tid & 15;
+  c.tile = tile;
+  const int4 sc = reinterpret_cast<const int4 *>(base + kMetaF)[c.grp];
+  const int *ln = reinterpret_cast<const int *>(base + kMetaF + kTM * 4);
+  c.valid = sc.x >= 0;
+  c.node = max(sc.x, 0);
+  c.ci = c.valid ? __int_as_float(sc.w) : 0.f;
+  c.lds_slots = reinterpret_cast<const unsigned *>(base);
+  c.lds_hnode = reinterpret_cast<const int *>(base + kTM * 8);
+  c.hcount = __builtin_amdgcn_readfirstlane(ln[kNbrStride]);
+  int wm = c.valid ? sc.z : 0;
+  wm = max(wm, __shfl_xor(wm, 16));
+  wm = max(wm, __shfl_xor(wm, 32));
+  c.wmax = __builtin_amdgcn_readfirstlane(wm);
+  c.my_nbr = ln[c.lane];
+}
+
 // Wait until every tile of the wait list has finished phase ph - 1: wave 0 polls, one flag per lane (lanes 0..62) and the abort
 // word on lane 63, ONE load per lane and round (a second dependent load per round would double the polling period, which is
 // the granularity a published flag is seen with); everybody meets at the barrier.  Returns false when the solve was aborted.
@@ -481,9 +520,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
 // Arithmetic per tile is node_fwd_persistent_kernel's, operation for operation.
 template <int ACT, bool TAPE>
 __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMetaF + 48 + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMaxTileRounds * kMetaKF + 48 + 4];
   float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW = ldsZ + kTileF, *ldsB = ldsW + kWF;
-  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMaxTileRounds * kMetaKF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   const int tid = threadIdx.x, q = tid & 15;
   if (tid < 42) ldsC[tid] = p.cf[tid];
@@ -493,9 +532,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
   else if (tid < 2 * PD) ldsB[tid] = p.b2 ? p.b2[tid - PD] : 0.f;
   if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
   if (tid == 0) *s_ok = 1;
-  const int W = p.pair_wgs, K = p.k_tiles;
+  const int W = p.pair_wgs, K = min(p.k_tiles, kMaxTileRounds);
   const int t0 = xcd_tile(blockIdx.x, W);
   const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds(p.m, t0 + s * W, ldsMeta + s * kMetaKF);
   __syncthreads();
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[q];
   bool ok = true;
@@ -513,13 +553,20 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;   // uniform
           TileCtx c;
-          tile_ctx_init(p.m, c, ldsMeta, tile);
+          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-          __syncthreads();   // the turn's tables (and the phase's W) are in LDS
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           halo_fill_all(c, X, ldsXh);
+          // own rows of the state, in flight under the gather and the product: 0 = u, 1 + j = k_j (zero at launch, like the
+          // registers of the one-tile kernel)
+          float4 su = f4_zero(), sk0 = f4_zero(), sk1 = f4_zero(), sk2 = f4_zero(), sk3 = f4_zero(), sk4 = f4_zero();
+          if (layer == 1) {
+            su = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
+            sk0 = ld4_g(p.state, own + rowb); sk1 = ld4_g(p.state, own + 2 * rowb); sk2 = ld4_g(p.state, own + 3 * rowb);
+            sk3 = ld4_g(p.state, own + 4 * rowb); sk4 = ld4_g(p.state, own + 5 * rowb);
+          }
           wait_vmcnt0();
-          __syncthreads();
+          __syncthreads();   // halo rows landed (and the phase's W is in LDS)
           float4 acc = f4_scale(c.ci, tile_aggregate_lean(c, ldsXh));
           *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
           if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
@@ -532,13 +579,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
           if (layer == 0) {
             if (c.valid) store_sc1(p.bufB, own, yv);
           } else {
-            // state rows: 0 = u, 1 + j = k_j (zero at launch, like the registers of the one-tile kernel); k_i is yv itself
-            const float4 u = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
-            const float4 k0 = i == 0 ? yv : ld4_g(p.state, own + rowb), k1 = i == 1 ? yv : ld4_g(p.state, own + 2 * rowb),
-                         k2 = i == 2 ? yv : ld4_g(p.state, own + 3 * rowb), k3 = i == 3 ? yv : ld4_g(p.state, own + 4 * rowb),
-                         k4 = i == 4 ? yv : ld4_g(p.state, own + 5 * rowb);
+            const float4 k0 = i == 0 ? yv : sk0, k1 = i == 1 ? yv : sk1, k2 = i == 2 ? yv : sk2, k3 = i == 3 ? yv : sk3, k4 = i == 4 ? yv : sk4;   // k_i is yv itself
             float4 v = f4_scale(ldsC[36 + i], yv);
-            v = f4_fma(1.0f, u, v);
+            v = f4_fma(1.0f, su, v);
             v = f4_fma(ldsC[i * 6 + 0], k0, v); v = f4_fma(ldsC[i * 6 + 1], k1, v); v = f4_fma(ldsC[i * 6 + 2], k2, v);
             v = f4_fma(ldsC[i * 6 + 3], k3, v); v = f4_fma(ldsC[i * 6 + 4], k4, v);
             if (c.valid) {
@@ -1297,9 +1340,9 @@ template <int ACT>
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const PBwdK p) {
   constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
   using Aux = typename std::conditional<RELU, unsigned, float4>::type;
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMetaF + 48 + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMaxTileRounds * kMetaKF + 48 + 4];
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW = ldsX + kTileF;
-  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMaxTileRounds * kMetaKF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1313,9 +1356,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
   for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float db1 = 0.f, db2 = 0.f;
   const int dbc = tid / PG::DBP, dbpart = tid % PG::DBP;
-  const int S = p.S, W = p.pair_wgs, K = p.k_tiles;
+  const int S = p.S, W = p.pair_wgs, K = min(p.k_tiles, kMaxTileRounds);
   const int t0 = xcd_tile(blockIdx.x, W);
   const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds(p.m, t0 + s * W, ldsMeta + s * kMetaKF);
   __syncthreads();
 
   // the dense half of a turn (node_bwd_persistent_kernel's, with the tile context as an argument)
@@ -1380,9 +1424,9 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
       const int tile = t0 + s * W;
       if (tile >= p.m.n_tiles) break;
       TileCtx c;
-      tile_ctx_init(p.m, c, ldsMeta, tile);
+      tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
       const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-      __syncthreads();
+      __syncthreads();   // (the phase's W is in LDS; the previous turn's products are done with the operand tiles)
       const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
       dense(c, own, ph, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev, c, own), tape_row(ev, own), p.g2);
     }
@@ -1398,9 +1442,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;
           TileCtx c;
-          tile_ctx_init(p.m, c, ldsMeta, tile);
+          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-          __syncthreads();
           const Aux mk = mask_of(ev, c, own);
           const float4 xrow = tape_row(ev, own);
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
@@ -1423,9 +1466,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;
           TileCtx c;
-          tile_ctx_init(p.m, c, ldsMeta, tile);
+          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-          __syncthreads();
           Aux mk{};
           float4 xrow = f4_zero();
           if (!last) {
@@ -1434,15 +1476,16 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           }
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           halo_fill_all(c, p.g1, ldsXh);
+          // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5), in flight under the gather
+          const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
+          const float4 lb1 = ld4_g(p.ubar, own), lb2 = ld4_g(p.ubar, own + rowb), lb3 = ld4_g(p.ubar, own + 2 * rowb),
+                       lb4 = ld4_g(p.ubar, own + 3 * rowb), lb5 = ld4_g(p.ubar, own + 4 * rowb);
           wait_vmcnt0();
           __syncthreads();
           const float4 t = tile_aggregate_lean(c, ldsXh);
           __syncthreads();
-          // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5); U-bar_i is t itself
-          const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
-          const float4 ub1 = i == 1 ? t : ld4_g(p.ubar, own), ub2 = i == 2 ? t : ld4_g(p.ubar, own + rowb),
-                       ub3 = i == 3 ? t : ld4_g(p.ubar, own + 2 * rowb), ub4 = i == 4 ? t : ld4_g(p.ubar, own + 3 * rowb),
-                       ub5 = i == 5 ? t : ld4_g(p.ubar, own + 4 * rowb);
+          const float4 ub1 = i == 1 ? t : lb1, ub2 = i == 2 ? t : lb2, ub3 = i == 3 ? t : lb3, ub4 = i == 4 ? t : lb4,
+                       ub5 = i == 5 ? t : lb5;   // U-bar_i is t itself
           float4 kbar;
           if (i >= 1) {
             if (c.valid) st4_g(p.ubar, own + (unsigned)(i - 1) * rowb, t);
