@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
       float4 v = f4_scale(1.0f, u);
       for (int j = 0; j < i; ++j) v = f4_fma(ldsC[row * 8 + j], gat_ld4(p.kbuf + (size_t)j * p.row_elems, own), v);
       v = f4_fma(ldsC[row * 8 + i], y, v);
-      if (i + 1 < S) gat_st4(p.kbuf + (size_t)i * p.row_elems, own, y);
+      if (i + 1 < S && ok) gat_st4(p.kbuf + (size_t)i * p.row_elems, own, y);   // (a padding row's thread addresses node 0)
       else u = v;
       const bool last = (n == p.n_steps - 1 && i == S - 1);
       if (ok) {
