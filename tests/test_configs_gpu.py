@@ -269,7 +269,7 @@ def test_c2_full_bench_workload_against_the_c_port(monkeypatch):
     ut = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
     uT, _ = node(ut, ps, st)
     # Tolerances: the C port sums the parameter gradients serially in float32 over 16 384 nodes x 300 evaluations and is
-    # the LESS accurate side -- measured against the float64 numpy oracle at this size (tools/three_way_accuracy.py, 4 min):
+    # the LESS accurate side -- measured against the float64 numpy oracle at this size (tests/manual_three_way_accuracy.py, 4 min):
     # u(T) 1.3e-6 (both), du0 8.6e-4 (both: relu mask flips), dW 1.8e-5 / 1.5e-5 (HIP) vs 4.6e-4 / 3.8e-3 (C port),
     # db 4.0e-6 / 4.7e-6 (HIP) vs 3.6e-3 / 6.7e-3 (C port)
     close(uT, outs[0].T, 2e-5, what="u(T) after 50 steps")
