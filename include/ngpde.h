@@ -428,7 +428,8 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int3
  * flag, which ngpde_node_fault reads (synchronises `stream`). */
 enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4, NGPDE_NODE_PERSISTENT_FWD = 8,
        NGPDE_NODE_PERSISTENT_BWD = 16, NGPDE_NODE_TILE_PAIRS = 32 /* persistent launches with two tiles per workgroup */,
-       NGPDE_NODE_TILE_ROUNDS = 64 /* persistent launches with k tiles per workgroup taking turns (larger graphs) */ };
+       NGPDE_NODE_TILE_ROUNDS = 64 /* persistent launches with k tiles per workgroup taking turns (larger graphs) */,
+       NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`

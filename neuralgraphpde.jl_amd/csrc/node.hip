@@ -70,6 +70,42 @@ int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t 
   return NGPDE_OK;
 }
 
+// The same with a change of row width: dst rows are `d_out` wide, src rows `d_in` (columns beyond the narrower of the two are
+// written as zeros / dropped) -- entry to / exit from a plan that runs a narrow state on the 64-wide persistent kernels.
+__global__ void scale_rows_width_kernel(size_t n4, int lpr_in, int lpr_out, int invert, const float4 *__restrict__ src,
+                                        const float *__restrict__ c, size_t n_nodes, float4 *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of dst
+  if (i >= n4) return;
+  const size_t row = i / lpr_out;
+  const int q = (int)(i - row * lpr_out);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < lpr_in) {
+    const float ci = c[row % n_nodes];
+    const float f = invert ? 1.0f / ci : ci;
+    const float4 s = src[row * lpr_in + q];
+    v = make_float4(s.x * f, s.y * f, s.z * f, s.w * f);
+  }
+  dst[i] = v;
+}
+
+int32_t launch_scale_rows_width(const float *src, int d_in, const float *c, float *dst, int d_out, int64_t n, bool invert,
+                                hipStream_t stream, int members = 1) {
+  if (d_in == d_out) return launch_scale_rows(src, c, dst, n, d_in, invert, stream, members);
+  const size_t n4 = (size_t)n * members * d_out / 4;
+  if (n4 == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(scale_rows_width_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, d_in / 4, d_out / 4,
+                     invert ? 1 : 0, reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst));
+  NGPDE_LAUNCH_CHECK("scale_rows_width_kernel");
+  return NGPDE_OK;
+}
+
+// [h][w] block between matrices of row pitch spitch / dpitch (elements): the parameters of a widened plan
+int32_t copy_block(float *dst, int dpitch, const float *src, int spitch, int w, int h, hipStream_t stream) {
+  NGPDE_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)dpitch * sizeof(float), src, (size_t)spitch * sizeof(float), (size_t)w * sizeof(float),
+                                   (size_t)h, hipMemcpyDeviceToDevice, stream));
+  return NGPDE_OK;
+}
+
 bool act_needs_z(int act) {
   return !(act == NGPDE_ACT_IDENTITY || act == NGPDE_ACT_RELU || act == NGPDE_ACT_LEAKYRELU);
 }
@@ -79,6 +115,10 @@ bool act_needs_z(int act) {
 struct ngpde_node {
   const ngpde_graph *g = nullptr;
   int d = 0, act = 0, n_steps = 0;
+  // du < d: a WIDENED plan -- the caller's state and parameters are du wide (16 or 32) and run zero-padded on the 64-wide persistent
+  // kernels (a phase of those is a latency floor, not a byte count, so the padding is free where a native narrow kernel would sit on the
+  // same floor); padded columns of u stay decoupled from the real ones because the padded rows AND columns of W are zero
+  int du = 0;
   float dt = 0.f;
   bool with_bwd = false, needs_z = false, eager = false;
   Tableau tb;
@@ -417,9 +457,9 @@ int32_t ngpde_node_gcn2_create(const ngpde_graph_t *g, int32_t d, int32_t act, i
   return ngpde_node_gcn2_create_batch(g, 1, d, act, tableau, n_steps, dt, with_backward, out);
 }
 
-int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, int32_t d, int32_t act, int32_t tableau,
-                                     int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out) {
-  NGPDE_RANGE();
+// d: the width the kernels run at; du <= d: the caller's width (see ngpde_node::du)
+static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, int32_t du, int32_t act, int32_t tableau,
+                           int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out) {
   NGPDE_REQUIRE(out != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: out is NULL");
   NGPDE_REQUIRE(members >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create_batch: members must be >= 1");
   *out = nullptr;
@@ -435,7 +475,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   NGPDE_REQUIRE(g->n_nodes >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_gcn2_create: empty graph");
   ngpde_node *p = new (std::nothrow) ngpde_node();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "out of host memory");
-  p->g = g; p->d = d; p->act = act; p->n_steps = n_steps; p->dt = dt;
+  p->g = g; p->d = d; p->du = du; p->act = act; p->n_steps = n_steps; p->dt = dt;
   p->with_bwd = with_backward != 0;
   p->needs_z = p->with_bwd && act_needs_z(act);
   p->tb = make_tableau(tableau);
@@ -501,8 +541,14 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   };
   A(&p->u, p->all_elems);
   A(&p->ustage, xslots * p->row_elems);
-  A(&p->u0keep, p->all_elems);
+  A(&p->u0keep, (size_t)members * p->n * du);
   A(&p->w1, (size_t)d * d); A(&p->b1, d); A(&p->w2, (size_t)d * d); A(&p->b2, d);
+  if (st == NGPDE_OK && du != d) {   // the padding of a widened plan's parameters is written once, here
+    for (float *w : {p->w1, p->w2})
+      if (hipMemset(w, 0, (size_t)d * d * sizeof(float)) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipMemset failed");
+    for (float *b : {p->b1, p->b2})
+      if (hipMemset(b, 0, (size_t)d * sizeof(float)) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipMemset failed");
+  }
   const size_t tape_elems = (size_t)(p->with_bwd ? n_steps : 1) * S * p->slots * p->all_elems;
   p->tape_bytes = tape_elems * sizeof(float);
   A(&p->tape, tape_elems);
@@ -558,6 +604,25 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   return NGPDE_OK;
 }
 
+int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, int32_t d, int32_t act, int32_t tableau,
+                                     int32_t n_steps, float dt, int32_t with_backward, ngpde_node_t **out) {
+  NGPDE_RANGE();
+  // d = 16 / 32 where the 64-wide persistent solver can take the graph: run widened (NGPDE_NO_WIDEN=1: the native-width replayed plan)
+  const char *nw = std::getenv("NGPDE_NO_WIDEN");
+  if (out && g && (d == 16 || d == 32) && !(nw && nw[0] == '1') && g->has_norm && g->n_nodes >= 1 &&
+      node_persistent_mode(g, 64, act, with_backward != 0) != 0) {
+    ngpde_node_t *w = nullptr;
+    if (node_create(g, members, 64, d, act, tableau, n_steps, dt, with_backward, &w) == NGPDE_OK) {
+      if (w->persist_fwd && (w->persist_bwd || !w->with_bwd)) {
+        *out = w;
+        return NGPDE_OK;
+      }
+      ngpde_node_destroy(w);
+    }
+  }
+  return node_create(g, members, d, d, act, tableau, n_steps, dt, with_backward, out);
+}
+
 size_t ngpde_node_tape_bytes(const ngpde_node_t *p) { return p ? p->tape_bytes : 0; }
 
 int32_t ngpde_node_launch_count(const ngpde_node_t *p, int32_t *forward, int32_t *backward) {
@@ -573,7 +638,7 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
-           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0);
+           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0);
   return NGPDE_OK;
 }
 
@@ -617,16 +682,23 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
                 "another kernel held the device's compute units, or two persistent solves of different processes shared the device; "
                 "create a new plan (NGPDE_NO_PERSISTENT=1 selects the replayed plan)");
   hipStream_t stream = (hipStream_t)stream_;
-  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
+  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->du * sizeof(float);
+  const size_t user_bytes = (size_t)p->members * p->n * p->du * sizeof(float);
   if (p->pre) {
-    int32_t st = launch_scale_rows(u0, p->g->c, p->u, p->n, p->d, false, stream, p->members);
+    int32_t st = launch_scale_rows_width(u0, p->du, p->g->c, p->u, p->d, p->n, false, stream, p->members);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
+  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, user_bytes, hipMemcpyDeviceToDevice, stream));
+  if (p->du != p->d) {   // widened plan: the du x du blocks of the zero-padded d x d parameters
+    int32_t st;
+    if ((st = copy_block(p->w1, p->d, w1, p->du, p->du, p->du, stream))) return st;
+    if ((st = copy_block(p->w2, p->d, w2, p->du, p->du, p->du, stream))) return st;
+  } else {
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
+  }
   if (b1) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b1, b1, db, hipMemcpyDeviceToDevice, stream));
   else NGPDE_HIP_CHECK(hipMemsetAsync(p->b1, 0, db, stream));
   if (b2) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b2, b2, db, hipMemcpyDeviceToDevice, stream));
@@ -641,7 +713,7 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
     NGPDE_HIP_CHECK(hipGraphLaunch(p->fwd_exec, stream));
   }
   if (p->pre) {
-    int32_t st = launch_scale_rows(p->u, p->g->c, uT, p->n, p->d, true, stream, p->members);
+    int32_t st = launch_scale_rows_width(p->u, p->d, p->g->c, uT, p->du, p->n, true, stream, p->members);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -681,9 +753,9 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
                 "ngpde_node_gcn2_backward: a persistent launch of this plan gave up waiting for its neighbours (outputs are NaN); "
                 "create a new plan (NGPDE_NO_PERSISTENT=1 selects the replayed plan)");
   hipStream_t stream = (hipStream_t)stream_;
-  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->d * sizeof(float);
+  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->du * sizeof(float);
   if (p->pre) {   // u(T) = u~(T) ./ c  =>  dL/du~(T) = duT ./ c
-    int32_t st = launch_scale_rows(duT, p->g->c, p->lam, p->n, p->d, true, stream, p->members);
+    int32_t st = launch_scale_rows_width(duT, p->du, p->g->c, p->lam, p->d, p->n, true, stream, p->members);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -698,15 +770,21 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
     NGPDE_HIP_CHECK(hipGraphLaunch(p->bwd_exec, stream));
   }
   if (du0 && p->pre) {   // u~0 = c .* u0  =>  du0 = c .* dL/du~0
-    int32_t st = launch_scale_rows(p->lam, p->g->c, du0, p->n, p->d, false, stream, p->members);
+    int32_t st = launch_scale_rows_width(p->lam, p->d, p->g->c, du0, p->du, p->n, false, stream, p->members);
     if (st) return st;
   } else if (du0) {
     NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   p->backward_pending = false;
-  if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
+  if (p->du != p->d) {
+    int32_t st;
+    if (dw1 && (st = copy_block(dw1, p->du, p->dw1, p->d, p->du, p->du, stream))) return st;
+    if (dw2 && (st = copy_block(dw2, p->du, p->dw2, p->d, p->du, p->du, stream))) return st;
+  } else {
+    if (dw1) NGPDE_HIP_CHECK(hipMemcpyAsync(dw1, p->dw1, dd, hipMemcpyDeviceToDevice, stream));
+    if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));
+  }
   if (db1) NGPDE_HIP_CHECK(hipMemcpyAsync(db1, p->db1, db, hipMemcpyDeviceToDevice, stream));
-  if (dw2) NGPDE_HIP_CHECK(hipMemcpyAsync(dw2, p->dw2, dd, hipMemcpyDeviceToDevice, stream));
   if (db2) NGPDE_HIP_CHECK(hipMemcpyAsync(db2, p->db2, db, hipMemcpyDeviceToDevice, stream));
   return NGPDE_OK;
 }
@@ -722,7 +800,7 @@ int32_t ngpde_node_profile(ngpde_node_t *p, int32_t stride, float *out_us, int32
   prof.stride = stride;
   int32_t st;
   if (p->pre) {
-    if ((st = launch_scale_rows(p->u0keep, p->g->c, p->u, p->n, p->d, false, stream, p->members))) return st;
+    if ((st = launch_scale_rows_width(p->u0keep, p->du, p->g->c, p->u, p->d, p->n, false, stream, p->members))) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, p->u0keep, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }

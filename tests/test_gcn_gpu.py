@@ -608,6 +608,53 @@ def test_node_persistent_plan_against_oracle(tab, N, nsteps, act, monkeypatch):
         close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
 
 
+@pytest.mark.parametrize("d,tab,N,nsteps,act,members", [(32, "tsit5", 1000, 3, "relu", 1), (16, "tsit5", 2048, 2, "tanh", 1),
+                                                      (32, "euler", 16384, 3, "relu", 1), (16, "tsit5", 33000, 2, "relu", 1),
+                                                      (32, "tsit5", 40000, 2, "tanh", 1), (16, "tsit5", 700, 2, "sigmoid", 1),
+                                                      (32, "tsit5", 900, 2, "relu", 3)])
+def test_node_persistent_plan_narrow_widths_against_oracle(d, tab, N, nsteps, act, members, monkeypatch):
+    needs_persistent_plan(monkeypatch)
+    # d = 16 / 32 (graph_node.md:44-66 takes any width): the state and the parameters run zero-padded on the 64-wide persistent
+    # kernels -- one tile per workgroup, tile pairs (33 000) and tile rounds (40 000 with tanh) alike; sigmoid makes the padded
+    # columns of the state non-zero (sigmoid(0) = 0.5), which must not leak into the real ones; a block-diagonal batch of members
+    dt = 0.1
+    g, og, params = spatial_case(N, 4 * N, d, seed=N + d)
+    gg = ng.batch([g] + [g.copy() for _ in range(members - 1)]) if members > 1 else g
+    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=gg), ng.GCNConv((d, d), act, initialgraph=gg))
+    node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+    ps, st = ng.setup(0, node)
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    rng = np.random.default_rng(N + 1)
+    u0, R = rng.normal(size=(d, N * members)), rng.normal(size=(d, N * members))
+    u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    plan = next(iter(node._plans.values()))[0]
+    assert {"persistent_fwd", "persistent_bwd", "widened"} <= plan.flags(), plan.flags()
+    (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+    assert not plan.fault()
+    accW = [0, 0]; accb = [0, 0]
+    for m in range(members):
+        sl = slice(m * N, (m + 1) * N)
+        uTo, du0o, acc = _oracle_node_with_seed(params, og, u0[:, sl], R[:, sl], O.TABLEAUS[tab], dt, nsteps, act)
+        close(uT[:, sl], uTo, rtol=2e-4, what=f"u(T) member {m}")
+        if act == "relu":
+            bad = (torch.abs(u.grad[:, sl].double().cpu() - torch.as_tensor(du0o)) > 1e-4 + 5e-4 * torch.abs(torch.as_tensor(du0o))).any(0)
+            assert bad.double().mean() <= 5e-3, f"du0: {int(bad.sum())} of {N} nodes off (relu kinks allow a few)"
+        else:
+            close(u.grad[:, sl], du0o, rtol=5e-4, atol=1e-4, what=f"du0 member {m}")
+        for k in range(2):
+            accW[k] = accW[k] + acc[k]["weight"]; accb[k] = accb[k] + acc[k]["bias"]
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, accW[k], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, accb[k], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+
+
 @pytest.mark.parametrize("act", ["tanh", "relu"])
 def test_node_persistent_forward_only_plan_any_activation(act, monkeypatch):
     needs_persistent_plan(monkeypatch)
