@@ -810,7 +810,7 @@ extern "C" int32_t ngpde_debug_set_stamps(unsigned long long *dev_buf, int32_t m
 // the pre-scaled pipeline (rows stored as c .* x, gathered raw by LDS-DMA): every tile staged from LDS in both directions,
 // and c finite and positive (self loops: degree >= 1)
 bool fused_prescaled_supported(const ngpde_graph *g, int d) {
-  return g && g->has_norm && g->self_loops && d <= 64 && fused_supported(d, d) && g->by_t.halo_ok && g->by_s.halo_ok &&
+  return g && g->has_norm && g->self_loops && d <= 128 && fused_supported(d, d) && g->by_t.halo_ok && g->by_s.halo_ok &&
          !no_halo_env();
 }
 bool fused_supported(int din, int dout) { return din == dout && (din == 16 || din == 32 || din == 64 || din == 128); }

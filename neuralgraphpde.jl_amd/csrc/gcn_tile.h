@@ -31,7 +31,7 @@ struct Geo {
   static constexpr int CPW = (CT + CGRP - 1) / CGRP;         // column tiles per wave
   static constexpr int DWT = (CT * CT + WAVES - 1) / WAVES;  // dW tiles per wave
   static constexpr int DBP = kThreads / D;                   // row-partials per column in the db reduction
-  static constexpr bool HALO = (D <= 64);                    // LDS-staged aggregation (a 128-wide halo would not fit beside the tiles)
+  static constexpr bool HALO = (D <= 128);                   // LDS-staged aggregation (128 wide: 50 KB of halo rows, one workgroup per CU either way)
   static constexpr int HI = (kHaloCap + GROUPS - 1) / GROUPS; // halo rows staged per group
   static constexpr int XH = HALO ? (kHaloCap + 1) * D : 0;   // floats of the halo region (+1: the all-zero row)
 };
