@@ -116,6 +116,7 @@ struct TileCtx {
   // [32][8] and the node ids of the 64 foreign halo slots
   const unsigned *lds_slots;
   const int *lds_hnode;
+  const float *lds_w;   // weighted graphs (tile rounds only): the tile's slot weights [32][32], else unused
 };
 constexpr int kMetaF = kTM * 8 + 2 * kTM;   // floats of LDS the two tables take
 
@@ -125,6 +126,7 @@ struct TileMeta {
   const int4 *sched;
   const int2 *tile_info;
   const int *nbr;
+  const float *slot_w;   // [n_sched][kSlotWidth] edge weights in slot order, or NULL (unweighted)
   unsigned *flags, *abort_word;
   int n_tiles;
   int *stats;   // [n_tiles][2] (forward, adjoint): slot-phases of the last launch whose halo rows were gathered ahead of time
@@ -161,6 +163,13 @@ __device__ __forceinline__ void tile_ctx_init(const TileMeta &m, TileCtx &c, flo
 // halo node ids, schedule entries, wait list, halo count per tile -- so that a turn sets its context up from LDS instead of
 // re-reading five arrays from memory (one round trip and a barrier per turn).
 constexpr int kMetaKF = kMetaF + kTM * 4 + kNbrStride + 4;   // floats per tile
+// Weighted graphs (GCNConv's edge_weight, src/layers.jl:206-231) run on the tile-round kernels only: those keep ONE layer's W in LDS,
+// which leaves room for the 4 KB of slot weights per tile behind the tile's tables -- for at most kMaxTileRoundsW tiles per workgroup.
+constexpr int kMaxTileRoundsW = 3;
+constexpr int kSlotWF = kTM * kSlotWidth;
+template <bool WGT> constexpr int meta_stride() { return kMetaKF + (WGT ? kSlotWF : 0); }
+template <bool WGT> constexpr int meta_tiles() { return WGT ? kMaxTileRoundsW : kMaxTileRounds; }
+template <bool WGT = false>
 __device__ __forceinline__ void tile_tables_to_lds(const TileMeta &m, int tile, float *base) {
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
   const size_t pos = (size_t)tile * kTM + grp;
@@ -173,7 +182,12 @@ __device__ __forceinline__ void tile_tables_to_lds(const TileMeta &m, int tile, 
   if (q == 10) lsc[grp] = m.sched[pos];
   if (tid < kNbrStride) ln[tid] = m.nbr[(size_t)tile * kNbrStride + tid];
   if (tid == kNbrStride) ln[kNbrStride] = m.tile_info[tile].x;
+  if constexpr (WGT) {
+    float2 *lw = reinterpret_cast<float2 *>(base + kMetaKF);
+    lw[tid] = reinterpret_cast<const float2 *>(m.slot_w + (size_t)tile * kSlotWF)[tid];   // 512 threads x 2 floats = [32][32]
+  }
 }
+template <bool WGT = false>
 __device__ __forceinline__ void tile_ctx_from_lds(TileCtx &c, int tile, const float *base) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
@@ -194,6 +208,7 @@ __device__ __forceinline__ void tile_ctx_from_lds(TileCtx &c, int tile, const fl
   wm = max(wm, __shfl_xor(wm, 32));
   c.wmax = __builtin_amdgcn_readfirstlane(wm);
   c.my_nbr = ln[c.lane];
+  c.lds_w = WGT ? base + kMetaKF : nullptr;
 }
 
 // Wait until every tile of the wait list has finished phase ph - 1: wave 0 polls, one flag per lane (lanes 0..62) and the abort
@@ -317,6 +332,28 @@ __device__ __forceinline__ float4 tile_aggregate_lean(const TileCtx &c, const fl
     a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
   }
   return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+}
+
+// weighted rows: the replayed plan's order of operations (halo_finish, gcn_fused.hip: one fma per slot, in slot order); the four
+// weights of a round are one 16-byte LDS read that the row's 16 lanes share
+__device__ __forceinline__ float4 tile_aggregate_weighted(const TileCtx &c, const float *ldsXh) {
+  const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
+  float4 a = f4_zero();
+#pragma unroll 1
+  for (int jw = 0; jw * 4 < c.wmax; ++jw) {   // wave-uniform
+    const unsigned w = c.lds_slots[c.grp * 8 + jw];
+    const float4 wv = *reinterpret_cast<const float4 *>(c.lds_w + c.grp * kSlotWidth + 4 * jw);
+    float4 v[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q];
+    a = f4_fma(wv.x, v[0], a); a = f4_fma(wv.y, v[1], a); a = f4_fma(wv.z, v[2], a); a = f4_fma(wv.w, v[3], a);
+  }
+  return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+}
+template <bool WGT>
+__device__ __forceinline__ float4 tile_aggregate_rounds(const TileCtx &c, const float *ldsXh) {
+  if constexpr (WGT) return tile_aggregate_weighted(c, ldsXh);
+  else return tile_aggregate_lean(c, ldsXh);
 }
 
 // W (row-major [in][out]) -> LDS, transposed (forward: B[k = in][j = out], stored Bt[j][k]) or straight (pullback: Bt[j = in][k = out])
@@ -518,11 +555,13 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
 // its other tiles, and the neighbours' rows and flags of the previous phase have long arrived (what the GAT solver's batch kernels
 // showed, gat_fused.hip).  A workgroup's own tiles may even be neighbours: turn s of phase ph needs the others' phase ph - 1 only.
 // Arithmetic per tile is node_fwd_persistent_kernel's, operation for operation.
-template <int ACT, bool TAPE>
+template <int ACT, bool TAPE, bool WGT = false>
 __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMaxTileRounds * kMetaKF + 48 + 4];
+  constexpr int kMS = meta_stride<WGT>(), kMT = meta_tiles<WGT>();
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMT * kMS + 48 + 4];
+  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
   float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW = ldsZ + kTileF, *ldsB = ldsW + kWF;
-  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMaxTileRounds * kMetaKF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMT * kMS;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   const int tid = threadIdx.x, q = tid & 15;
   if (tid < 42) ldsC[tid] = p.cf[tid];
@@ -532,10 +571,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
   else if (tid < 2 * PD) ldsB[tid] = p.b2 ? p.b2[tid - PD] : 0.f;
   if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
   if (tid == 0) *s_ok = 1;
-  const int W = p.pair_wgs, K = min(p.k_tiles, kMaxTileRounds);
+  const int W = p.pair_wgs, K = min(p.k_tiles, kMT);
   const int t0 = xcd_tile(blockIdx.x, W);
   const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
-  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds(p.m, t0 + s * W, ldsMeta + s * kMetaKF);
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds<WGT>(p.m, t0 + s * W, ldsMeta + s * kMS);
   __syncthreads();
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[q];
   bool ok = true;
@@ -553,7 +592,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;   // uniform
           TileCtx c;
-          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
+          tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           halo_fill_all(c, X, ldsXh);
@@ -567,7 +606,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
           }
           wait_vmcnt0();
           __syncthreads();   // halo rows landed (and the phase's W is in LDS)
-          float4 acc = f4_scale(c.ci, tile_aggregate_lean(c, ldsXh));
+          float4 acc = f4_scale(c.ci, tile_aggregate_rounds<WGT>(c, ldsXh));
           *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
           if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
           __syncthreads();
@@ -1336,13 +1375,15 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent2_kernel(const
 // p.lam / p.ubar (zero at launch where the one-tile kernel starts from zero registers), one layer's W in LDS at a time, the
 // parameter-gradient accumulators in registers over all tiles and phases (one slab per WORKGROUP at the end).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ACT>
+template <int ACT, bool WGT = false>
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const PBwdK p) {
   constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
   using Aux = typename std::conditional<RELU, unsigned, float4>::type;
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMaxTileRounds * kMetaKF + 48 + 4];
+  constexpr int kMS = meta_stride<WGT>(), kMT = meta_tiles<WGT>();
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMT * kMS + 48 + 4];
+  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
   float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW = ldsX + kTileF;
-  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMaxTileRounds * kMetaKF;
+  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMT * kMS;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1356,10 +1397,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
   for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float db1 = 0.f, db2 = 0.f;
   const int dbc = tid / PG::DBP, dbpart = tid % PG::DBP;
-  const int S = p.S, W = p.pair_wgs, K = min(p.k_tiles, kMaxTileRounds);
+  const int S = p.S, W = p.pair_wgs, K = min(p.k_tiles, kMT);
   const int t0 = xcd_tile(blockIdx.x, W);
   const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
-  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds(p.m, t0 + s * W, ldsMeta + s * kMetaKF);
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) tile_tables_to_lds<WGT>(p.m, t0 + s * W, ldsMeta + s * kMS);
   __syncthreads();
 
   // the dense half of a turn (node_bwd_persistent_kernel's, with the tile context as an argument)
@@ -1424,7 +1465,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
       const int tile = t0 + s * W;
       if (tile >= p.m.n_tiles) break;
       TileCtx c;
-      tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
+      tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
       const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
       __syncthreads();   // (the phase's W is in LDS; the previous turn's products are done with the operand tiles)
       const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
@@ -1442,7 +1483,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;
           TileCtx c;
-          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
+          tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
           const Aux mk = mask_of(ev, c, own);
           const float4 xrow = tape_row(ev, own);
@@ -1450,7 +1491,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           halo_fill_all(c, p.g2, ldsXh);
           wait_vmcnt0();
           __syncthreads();
-          const float4 t = tile_aggregate_lean(c, ldsXh);
+          const float4 t = tile_aggregate_rounds<WGT>(c, ldsXh);
           __syncthreads();   // every thread has its sum: the region becomes the product's result tile
           dense(c, own, ph, dw1, db1, t, mk, xrow, p.g1);
         }
@@ -1466,7 +1507,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           const int tile = t0 + s * W;
           if (tile >= p.m.n_tiles) break;
           TileCtx c;
-          tile_ctx_from_lds(c, tile, ldsMeta + s * kMetaKF);
+          tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
           Aux mk{};
           float4 xrow = f4_zero();
@@ -1482,7 +1523,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
                        lb4 = ld4_g(p.ubar, own + 3 * rowb), lb5 = ld4_g(p.ubar, own + 4 * rowb);
           wait_vmcnt0();
           __syncthreads();
-          const float4 t = tile_aggregate_lean(c, ldsXh);
+          const float4 t = tile_aggregate_rounds<WGT>(c, ldsXh);
           __syncthreads();
           const float4 ub1 = i == 1 ? t : lb1, ub2 = i == 2 ? t : lb2, ub3 = i == 3 ? t : lb3, ub4 = i == 4 ? t : lb4,
                        ub5 = i == 5 ? t : lb5;   // U-bar_i is t itself
@@ -1579,7 +1620,8 @@ static bool build_wait_lists(const ngpde_graph *g, std::vector<int> &out) {
 int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd) {
   if (node_persistent_disabled_env()) return 0;
   if (!g || d != PD || !fused_prescaled_supported(g, d)) return 0;
-  if (g->by_t.slot_w || g->by_s.slot_w) return 0;
+  const bool weighted = g->by_t.slot_w || g->by_s.slot_w;
+  if (weighted && !(g->by_t.slot_w && g->by_s.slot_w)) return 0;
   int dev = 0, cus = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -1606,6 +1648,7 @@ int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd) {
   take(occ_b, node_bwd_persistent2_kernel<true>);
   const int nt = g->n_sched / kTileRows, resident = cus * std::min(occ_f, occ_b);
   if (nt < 1) return 0;
+  if (weighted) return nt <= kMaxTileRoundsW * resident ? 3 : 0;   // edge weights: the tile-round kernels hold them (LDS beside ONE W)
   if (nt <= resident) return 1;
   const char *no_pairs = std::getenv("NGPDE_NO_TILE_PAIRS");
   if (no_pairs && no_pairs[0] == '1') return 0;
@@ -1626,9 +1669,16 @@ int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per w
   take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false>);
   take(node_fwd_persistentK_kernel<-1, true>); take(node_fwd_persistentK_kernel<-1, false>);
   take(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>); take(node_bwd_persistentK_kernel<-1>);
+  if (g->by_t.slot_w) {
+    take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false, true>);
+    take(node_fwd_persistentK_kernel<-1, true, true>); take(node_fwd_persistentK_kernel<-1, false, true>);
+    take(node_bwd_persistentK_kernel<NGPDE_ACT_RELU, true>); take(node_bwd_persistentK_kernel<-1, true>);
+  }
   const int nt = g->n_sched / kTileRows, resident = cus * occ;
   if (resident < 1) return 0;
-  return (nt + resident - 1) / resident;
+  const int k = (nt + resident - 1) / resident;
+  if (g->by_t.slot_w && k > kMaxTileRoundsW) return 0;   // (the weighted kernels' occupancy is lower than node_persistent_mode assumed)
+  return k;
 }
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) { return node_persistent_mode(g, d, act, with_bwd) == 1; }
 
@@ -1697,7 +1747,7 @@ __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) 
 }
 TileMeta make_meta(const Csr &c, const NodePersist &ps) {
   TileMeta m;
-  m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr;
+  m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr; m.slot_w = c.slot_w;
   m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 64; m.n_tiles = ps.n_tiles;   // [slot 0 | slot 1 | abort]
   m.stats = ps.stats;
 #ifdef NGPDE_STAMPS
@@ -1781,8 +1831,12 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     k.pair_wgs = ps.pair_wgs; k.ztape = a.ztape;
     if ((st = launch_zero(a.state + a.row_elems, 6 * a.row_elems * sizeof(float), stream))) return st;   // k_0 .. k_5 start from zero
     const dim3 gridk(ps.pair_wgs), blockk(kThreads);
+    NGPDE_REQUIRE(!k.m.slot_w || a.k_tiles <= kMaxTileRoundsW, NGPDE_ERR_STATE, "weighted tile rounds: at most %d tiles per workgroup", kMaxTileRoundsW);
 #define NGPDE_PFK_LAUNCH(AA, TT)                                                                                                  \
-    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+    if (k.m.slot_w) {                                                                                                             \
+      if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT, true>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+      else hipLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT, true>), gridk, blockk, 0, stream, k);                           \
+    } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
     else hipLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, k);
     if (a.tape && a.act == NGPDE_ACT_RELU) { NGPDE_PFK_LAUNCH(NGPDE_ACT_RELU, true) }
     else if (a.tape) { NGPDE_PFK_LAUNCH(-1, true) }
@@ -1794,6 +1848,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turnstile_leave(stream, dev);
   }
+  NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
   if (a.pair) {                                                                                                              \
@@ -1850,18 +1905,22 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     k.pair_wgs = ps.pair_wgs;
     if ((st = launch_zero(a.ubar, 5 * a.row_elems * sizeof(float), stream))) return st;   // the stage adjoints start from zero
     const dim3 gridk(ps.pair_wgs), blockk(kThreads);
-    if (a.act == NGPDE_ACT_RELU) {
-      if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>, gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);
-      else hipLaunchKernelGGL(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>, gridk, blockk, 0, stream, k);
-    } else {
-      if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistentK_kernel<-1>, gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);
-      else hipLaunchKernelGGL(node_bwd_persistentK_kernel<-1>, gridk, blockk, 0, stream, k);
-    }
+    NGPDE_REQUIRE(!k.m.slot_w || a.k_tiles <= kMaxTileRoundsW, NGPDE_ERR_STATE, "weighted tile rounds: at most %d tiles per workgroup", kMaxTileRoundsW);
+#define NGPDE_PBK_LAUNCH(AA)                                                                                                      \
+    if (k.m.slot_w) {                                                                                                             \
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistentK_kernel<AA, true>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+      else hipLaunchKernelGGL((node_bwd_persistentK_kernel<AA, true>), gridk, blockk, 0, stream, k);                               \
+    } else if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistentK_kernel<AA, false>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+    else hipLaunchKernelGGL((node_bwd_persistentK_kernel<AA, false>), gridk, blockk, 0, stream, k);
+    if (a.act == NGPDE_ACT_RELU) { NGPDE_PBK_LAUNCH(NGPDE_ACT_RELU) }
+    else { NGPDE_PBK_LAUNCH(-1) }
+#undef NGPDE_PBK_LAUNCH
     NGPDE_LAUNCH_CHECK("node_bwd_persistentK_kernel");
     hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turnstile_leave(stream, dev);
   }
+  NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (a.pair) {
     NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "tile-pair persistent adjoint without its stage-adjoint scratch");

@@ -475,7 +475,7 @@ class NeuralODE(AbstractExplicitLayer):
         l1, l2 = m.chain
         d = l1.in_chs
         same = (l1.out_chs == d and l2.in_chs == d and l2.out_chs == d and l1.act == l2.act
-                and l1.add_self_loops == l2.add_self_loops and not l1.use_edge_weight and not l2.use_edge_weight
+                and l1.add_self_loops == l2.add_self_loops and l1.use_edge_weight == l2.use_edge_weight
                 and l1.bias == l2.bias)
         if not same or d not in (16, 32, 64, 128):
             return None
@@ -483,6 +483,8 @@ class NeuralODE(AbstractExplicitLayer):
         # copies made by wrapgraph / updategraph share one handle cache: same structure without comparing arrays
         if g1 is not g2 and g1._handles is not g2._handles and g1 != g2:
             return None
+        if l1.use_edge_weight and (g1.edge_weight is None or g2.edge_weight is not g1.edge_weight):
+            return None      # (the generic solver raises the layer's own error / handles two weight vectors)
         return l1, g1, d
 
     def plan_for(self, ps, st, with_backward):
@@ -490,12 +492,14 @@ class NeuralODE(AbstractExplicitLayer):
         if info is None:
             return None
         l1, g, d = info
-        norm = (l1.add_self_loops, None, False)
+        # use_edge_weight=true: the graph's stored weights in the messages, the unweighted degree in the normalisation
+        # (src/layers.jl:224 vs :230, as GCNConv.__call__ does); the plan's kernels read them from the handle's slot lists
+        norm = (l1.add_self_loops, g.edge_weight if l1.use_edge_weight else None, False)
         # a batch of graphs that share ONE structure (batch([g, g, ...]) or copies of g with other features): the plan is built on
         # the member and solves the trajectories one after the other inside its persistent launches
         members = getattr(g, "_members", None)
         member_plan = (members is not None and len(members) > 1 and all(m._handles is members[0]._handles for m in members)
-                       and not self._no_member_plan)
+                       and not self._no_member_plan and not l1.use_edge_weight)
         handle = members[0].handle(norm) if member_plan else g.handle(norm)
         key = (id(handle), d, l1.act, bool(with_backward), len(members) if member_plan else 1)
         pool = self._plans.get(key)

@@ -655,6 +655,83 @@ def test_node_persistent_plan_narrow_widths_against_oracle(d, tab, N, nsteps, ac
         close(ps[name]["bias"].grad, accb[k], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
 
 
+def _oracle_weighted_node(params, og, u0, seed, tableau, dt, nsteps, act):
+    """the chain of two GCNConv(use_edge_weight=true) as ODE right-hand side: messages weighted by the graph's stored weights
+    (src/layers.jl:230), unweighted degree in the normalisation (:224), from the oracle's layer and its pullback"""
+    def rhs(u):
+        y1, c1 = O.gcn_conv(u, params[0]["weight"], params[0]["bias"], og, act, True, True)
+        y2, c2 = O.gcn_conv(y1, params[1]["weight"], params[1]["bias"], og, act, True, True)
+        return y2, (c1, c2)
+
+    def vjp(cache, kbar):
+        g2 = O.gcn_conv_backward(cache[1], kbar)
+        g1 = O.gcn_conv_backward(cache[0], g2["x"])
+        return g1["x"], [dict(weight=g1["weight"], bias=g1.get("bias")), dict(weight=g2["weight"], bias=g2.get("bias"))]
+    uT, tape = O.rk_solve(rhs, u0, tableau, dt, nsteps)
+    acc = [dict(weight=np.zeros_like(p["weight"]), bias=np.zeros_like(p["bias"])) for p in params]
+
+    def accumulate(pg):
+        for A, G in zip(acc, pg):
+            A["weight"] += G["weight"]
+            A["bias"] += G["bias"].reshape(A["bias"].shape)
+    du0 = O.rk_adjoint(vjp, tape, seed.copy(), tableau, dt, accumulate)
+    return uT, du0, acc
+
+
+@pytest.mark.parametrize("d,tab,N,nsteps,act", [(64, "tsit5", 1000, 3, "relu"), (64, "euler", 2048, 4, "tanh"), (32, "tsit5", 1500, 2, "relu"),
+                                                (64, "tsit5", 16384, 2, "relu"), (64, "tsit5", 40000, 2, "tanh"), (64, "tsit5", 77, 2, "swish")])
+def test_node_persistent_plan_weighted_graph_against_oracle_and_replayed_plan(d, tab, N, nsteps, act, monkeypatch):
+    needs_persistent_plan(monkeypatch)
+    # GCNConv(use_edge_weight=true) on a graph with stored edge weights (src/layers.jl:206-231) as the chain of graph_node.md:78:
+    # the tile-round kernels keep the tile's slot weights in LDS (node_persistent.hip: WGT).  u(T), du0 and the parameter
+    # gradients against the float64 oracle; u(T) and du0 bitwise equal to the replayed plan (same order of operations per row).
+    dt = 0.1
+    _, s, t = S.closest_pairs_graph(N, 4 * N, seed=N + 3)
+    rng = np.random.default_rng(N + d)
+    ew = (0.25 + rng.random(s.size)).astype(np.float32)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+    og = O.Graph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+    params = [dict(weight=S.glorot_uniform(N + 10 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    u0, R = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+
+    def solve():
+        rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g, use_edge_weight=True), ng.GCNConv((d, d), act, initialgraph=g, use_edge_weight=True))
+        node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        plan = next(iter(node._plans.values()))[0]
+        (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+        assert not plan.fault()
+        return uT.detach(), u.grad, ps, plan.flags()
+
+    uT, du0, ps, flags = solve()
+    assert {"persistent_fwd", "persistent_bwd", "tile_rounds"} <= flags, flags
+    assert ("widened" in flags) == (d != 64)
+    uTo, du0o, acc = _oracle_weighted_node(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps, act)
+    close(uT, uTo, rtol=2e-4, what="u(T)")
+    if act == "relu":
+        bad = (torch.abs(du0.double().cpu() - torch.as_tensor(du0o)) > 1e-4 + 5e-4 * torch.abs(torch.as_tensor(du0o))).any(0)
+        assert bad.double().mean() <= 5e-3, f"du0: {int(bad.sum())} of {N} nodes off (relu kinks allow a few)"
+    else:
+        close(du0, du0o, rtol=5e-4, atol=1e-4, what="du0")
+    for k, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, acc[k]["weight"], rtol=5e-4, atol=1e-3, what=f"dW{k + 1}")
+        close(ps[name]["bias"].grad, acc[k]["bias"], rtol=5e-4, atol=1e-3, what=f"db{k + 1}")
+    if d == 64:
+        monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        uT2, du02, _, flags2 = solve()
+        assert "persistent_fwd" not in flags2
+        assert torch.equal(uT, uT2) and torch.equal(du0, du02)
+
+
 @pytest.mark.parametrize("act", ["tanh", "relu"])
 def test_node_persistent_forward_only_plan_any_activation(act, monkeypatch):
     needs_persistent_plan(monkeypatch)
