@@ -421,8 +421,10 @@ int32_t ngpde_node_expect_generation(const ngpde_node_t *plan, uint64_t generati
 int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int32_t *backward);
 /* which internal forms the plan chose: bit 0 = pre-scaled arrays (rows held as c .* x, halo rows staged by LDS-DMA),
  * bit 1 = relu sign-bit masks instead of saved layer outputs, bit 2 = eager launches (no HIP-graph replay), bits 3 / 4 = the
- * forward solve / the adjoint run as ONE persistent launch each (graphs of at most two 32-row tiles per CU, d = 64, relu,
- * unweighted: the BASELINE workload), tiles synchronised inside the launch by per-tile phase flags.  A persistent launch
+ * forward solve / the adjoint run as ONE persistent launch each, tiles synchronised inside the launch by per-tile phase flags:
+ * graphs whose tiles fit the LDS halo, d = 64 (d = 16 / 32 zero-padded onto it, bit 7), any activation; up to 2 tiles per
+ * co-resident workgroup in registers (bit 5), up to 8 taking turns (bit 6); graphs with edge weights on the turn-taking form with
+ * the slot weights in LDS (up to 3 tiles per workgroup).  d = 128 and tiles beyond the halo keep the replayed plan.  A persistent launch
  * needs all its workgroups resident at once: run one such solve at a time per device (NGPDE_NO_PERSISTENT=1 selects the
  * replayed plan otherwise).  Its waits are bounded; a launch that gives up writes NaN outputs and raises the plan's fault
  * flag, which ngpde_node_fault reads (synchronises `stream`). */
