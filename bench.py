@@ -748,6 +748,28 @@ def main():
                                          "roofline": {"bound": "hbm", "achieved": round(bytes4 / (ms4 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                                       "unit": "GB/s", "frac": round(bytes4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             plan4 = None
+            # The C2 solve in the shapes that are not the headline's: d = 16 / 32 (zero-padded on the 64-wide persistent kernels) and a
+            # graph WITH edge weights (GCNConv(use_edge_weight=true), src/layers.jl:206-231: tile-round kernels, slot weights in LDS)
+            variants = {}
+            ew = (0.25 + S.uniform01(77, int(s.size))).astype(np.float32)
+            gwt = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0, edge_weight=ew)
+            for name, dd, handle in (("d16", 16, g.handle((True, None, False))), ("d32", 32, g.handle((True, None, False))),
+                                     ("weighted_d64", D, gwt.handle((True, gwt.edge_weight, False)))):
+                planv = _Plan(handle, dd, _lib.ACT["relu"], "tsit5", ODE_STEPS, DT, True)
+                uv = dv(S.normal(3000 + dd, dd * N_NODES).reshape(N_NODES, dd).astype(np.float32))
+                uTv, duv, seedv = torch.empty_like(uv), torch.empty_like(uv), torch.ones_like(uv)
+                wv = [dv(S.glorot_uniform(50 + k, dd, dd).astype(np.float32)) for k in range(2)]
+                bv = [torch.zeros(dd, device=dev) for _ in range(2)]
+                gv = [torch.empty_like(wv[0]), torch.empty_like(bv[0]), torch.empty_like(wv[1]), torch.empty_like(bv[1])]
+
+                def solvev():
+                    _lib.check(lib.ngpde_node_gcn2_forward(planv.ptr, p(uv), p(wv[0]), p(bv[0]), p(wv[1]), p(bv[1]), p(uTv), stream))
+                    _lib.check(lib.ngpde_node_gcn2_backward(planv.ptr, p(seedv), p(duv), p(gv[0]), p(gv[1]), p(gv[2]), p(gv[3]), stream))
+                msv = _time_ms(solvev, 5)
+                variants[name] = {"d": dd, "value": round(ODE_STEPS / (msv * 1e-3), 1), "unit": "ODE-steps/s",
+                                  "ms_per_solve_forward_backward": round(msv, 3), "plan": sorted(planv.flags()), "fault": bool(planv.fault())}
+                planv = None
+            out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             cb, outs = cpu_baseline(s, t, u0_h, w1_h, b1_h, w2_h, b2_h)
             out["cpu_baseline"] = cb
