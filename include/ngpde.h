@@ -356,7 +356,8 @@ int32_t ngpde_bias_act_backward(int64_t n, int32_t d, int32_t act, const float *
  * (save_z[0]: z1 [E][h1]; save_z[l]: pre-activation of layer l [E][tail_dout[l-1]], p order) for the pullback.
  * Needs ngpde_graph_set_gcn_norm to have been called (it builds the tile schedule) and a graph whose tiles fit
  * the LDS halo; ngpde_edge_mlp_supported returns 1 when this entry can be used, otherwise compose the
- * primitives above.  out: [N][last width]. */
+ * primitives above.  aggr: + / mean / max / min / * (NGPDE_AGGR_MUL: an empty neighbourhood gives 1, like scatter(*)).
+ * out: [N][last width]. */
 int32_t ngpde_edge_mlp_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout);
 int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target,
                                const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,

@@ -497,7 +497,7 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
                                int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_forward: graph is NULL");
-  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MIN, NGPDE_ERR_INVALID_ARGUMENT,
+  NGPDE_REQUIRE(aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_edge_mlp_forward: unknown aggregation %d", aggr);
   int32_t st = check_act("ngpde_edge_mlp_forward", act1);
   if (st) return st;

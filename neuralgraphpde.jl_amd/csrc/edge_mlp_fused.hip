@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
     float4 racc;
     if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    else if (p.aggr == NGPDE_AGGR_MUL) racc = make_float4(1.f, 1.f, 1.f, 1.f);   // scatter(*): the neutral element (an empty neighbourhood gives 1)
     else racc = f4_zero();
     __syncthreads();
     EDGE_STAMP(1);
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
           const float4 m = *reinterpret_cast<const float4 *>(&ldsMsg[(kk - c0) * kTS + 4 * q]);
           if (p.aggr == NGPDE_AGGR_MAX) racc = make_float4(fmaxf(racc.x, m.x), fmaxf(racc.y, m.y), fmaxf(racc.z, m.z), fmaxf(racc.w, m.w));
           else if (p.aggr == NGPDE_AGGR_MIN) racc = make_float4(fminf(racc.x, m.x), fminf(racc.y, m.y), fminf(racc.z, m.z), fminf(racc.w, m.w));
+          else if (p.aggr == NGPDE_AGGR_MUL) racc = f4_mul(racc, m);
           else racc = f4_add(racc, m);
         }
       }

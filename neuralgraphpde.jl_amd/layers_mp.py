@@ -68,7 +68,7 @@ def _message_path(g, P, Q, Et, stack, aggr):
     needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
     aggr_code = _lib.AGGR[aggr]
-    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or (aggr_code in (2, 3) and not needs_grad)):
+    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or (aggr_code in (2, 3, 4) and not needs_grad)):
         fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
         if F.edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
             return F.edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)

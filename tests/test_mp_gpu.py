@@ -1271,7 +1271,7 @@ def test_vmh_as_ode_right_hand_side():
 
 # ---- fused message path (one launch) against the primitives and the oracle -------------------------------------------------
 
-@pytest.mark.parametrize("aggr", ["mean", "+", "max", "min"])
+@pytest.mark.parametrize("aggr", ["mean", "+", "max", "min", "*"])
 def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
     monkeypatch.delenv("NGPDE_NO_FUSED_EDGE", raising=False)      # (the suite may run under that switch)
     # MPPDE shape of BASELINE config 4 at test size: h = 64, phi 132 => 64 => 64 swish, periodic mesh, 3 trajectories
