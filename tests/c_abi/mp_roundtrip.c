@@ -83,8 +83,8 @@ int main(void) {
   CHECK_NG(ngpde_graph_set_gcn_norm(g, /*add_self_loops=*/1, NULL, 0));
 
   /* ---- 1. solver plan: 3 Tsit5 steps of du/dt = GCNConv(GCNConv(u)), forward + discrete adjoint of sum(u(T)) ---- */
-  {
-    const int d = 64, steps = 3;
+  for (int variant = 0; variant < 2; ++variant) {   /* d = 64, and d = 32: the state zero-padded onto the 64-wide persistent kernels */
+    const int d = variant ? 32 : 64, steps = 3;
     const float dt = 0.1f;
     float *u0 = host_rand(n * d, 1.f), *w1 = host_rand(d * d, 0.2f), *w2 = host_rand(d * d, 0.2f), *b1 = host_rand(d, 0.1f),
           *b2 = host_rand(d, 0.1f), *ones = malloc(sizeof(float) * n * d);
@@ -106,8 +106,12 @@ int main(void) {
     CHECK_NG(ngpde_node_gcn2_backward(plan, ones_d, du0_d, dw1_d, db1_d, dw2_d, db2_d, NULL));
     CHECK_NG(ngpde_node_fault(plan, NULL, &fault));
     CHECK_HIP(hipDeviceSynchronize());
-    printf("plan: %d + %d launches, flags 0x%x, tape %.1f MB, fault %d\n", fl, bl, flags, ngpde_node_tape_bytes(plan) / 1e6, fault);
+    printf("plan (d = %d): %d + %d launches, flags 0x%x, tape %.1f MB, fault %d\n", d, fl, bl, flags, ngpde_node_tape_bytes(plan) / 1e6, fault);
     if (fault) return 4;
+    if ((flags & NGPDE_NODE_PERSISTENT_FWD) && ((flags & NGPDE_NODE_WIDENED) != 0) != (d != 64)) {
+      fprintf(stderr, "d = %d: unexpected plan flags 0x%x\n", d, flags);
+      return 4;
+    }
     float *uT = host_copy(uT_d, n * d), *du0 = host_copy(du0_d, n * d), *dw1 = host_copy(dw1_d, d * d), *dw2 = host_copy(dw2_d, d * d),
           *db1 = host_copy(db1_d, d), *db2 = host_copy(db2_d, d);
     float *uTo = malloc(sizeof(float) * n * d), *du0o = malloc(sizeof(float) * n * d), *dw1o = malloc(sizeof(float) * d * d),
