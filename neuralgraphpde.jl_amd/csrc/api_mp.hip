@@ -202,6 +202,8 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
                 "ngpde_dense_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   if (const int sgrid = dense_stream_bwd_grid(n, t, din, dout, dseg_ptr))   // one streaming launch (slabs in the dz area)
     return launch_dense_stream_bwd(n, t, din, act, weight, z, dy, dseg_ptr, dweight, dbias, (float *)workspace, sgrid, stream);
+  if (const int sgrid = dense_small_bwd_grid(n, din, dout))                   // at most 64 x 64, latency-bound row counts: one launch too
+    return launch_dense_small_bwd(n, t, din, dout, act, weight, z, dy, dseg_ptr, dweight, dbias, (float *)workspace, sgrid, stream);
   float *dz = (float *)workspace;
   float *partial = (float *)((char *)workspace + align256((size_t)n * dout * 4));
   if (act == NGPDE_ACT_IDENTITY) {
