@@ -168,6 +168,44 @@ def test_dense_wide_tiles_segmented(widths, dout, act):
         o += w
 
 
+@pytest.mark.parametrize("n,widths,divs,dout,act", [
+    (18000, (60,), (1,), 60, "tanh"), (3000, (1, 40), (1, 1), 60, "tanh"), (3000, (60,), (1,), 1, "identity"), (3001, (2,), (1,), 60, "swish"),
+    (65, (7, 3), (1, 1), 5, "sigmoid"), (63, (64,), (1,), 64, "relu"), (1000, (33, 2, 29), (1, 100, 1), 37, "gelu"), (129, (1,), (1,), 1, "tanh"),
+    (40000, (17,), (1,), 64, "leakyrelu"), (512, (30, 4), (1, 512), 64, "elu")])
+def test_dense_small_pullback_one_launch(n, widths, divs, dout, act):
+    # dense_small_bwd.hip: the whole pullback of a Dense of at most 64 x 64 at latency-bound row counts in one launch -- the
+    # tutorial MLPs' shapes (VMH.md:75-79), ragged last tiles, fewer rows than a tile, widths that are no multiple of 4 or 16, blocks of
+    # a virtual vcat with and without a gradient (per-graph blocks, src/layers.jl:397), one input / one output -- against float64
+    from ngpde_amd import functional as F
+    rng = np.random.default_rng(n + dout)
+    blocks = []
+    for w, rd in zip(widths, divs):
+        rows = (n + rd - 1) // rd
+        blocks.append(torch.as_tensor(rng.normal(size=(rows, w)), dtype=torch.float32, device=DEV).requires_grad_(rd == 1))
+    din = sum(widths)
+    wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+    b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True)
+    y = F.dense(blocks, wt, b, ng.layers._act_code(act)[1], row_divs=list(divs), n=n)
+    X = np.concatenate([np.repeat(bl.detach().cpu().double().numpy(), rd, axis=0)[:n] for bl, rd in zip(blocks, divs)], axis=1)
+    layer = [dict(weight=wt.detach().cpu().double().numpy().T, bias=b.detach().cpu().double().numpy(), act=act)]
+    yo, cache = O.mlp_forward(layer, X.T)
+    close(y, yo.T)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R.T, dtype=torch.float32, device=DEV)).sum().backward()
+    dx, gr = O.mlp_backward(layer, cache, R)
+    close(wt.grad, gr[0]["weight"].T, rtol=3e-4, atol=1e-4)
+    close(b.grad, gr[0]["bias"].reshape(-1), rtol=3e-4, atol=1e-4)
+    o = 0
+    for bl, rd, w in zip(blocks, divs, widths):
+        if rd == 1:
+            close(bl.grad, dx[o:o + w].T)
+        o += w
+    y2 = F.dense(blocks, wt, b, ng.layers._act_code(act)[1], row_divs=list(divs), n=n)      # reproducible: fixed-order slab sums
+    g1 = wt.grad.clone(); wt.grad = None
+    (y2 * torch.as_tensor(R.T, dtype=torch.float32, device=DEV)).sum().backward()
+    assert torch.equal(wt.grad, g1)
+
+
 @pytest.mark.parametrize("n,din,dout,bias", [(4096, 128, 8192, False), (1040, 132, 2052, False), (4096, 128, 8192, True),
                                              (2048, 256, 4096, False)])
 def test_dense_few_rows_wide_output_pullbacks(n, din, dout, bias, monkeypatch):
