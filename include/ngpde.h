@@ -490,6 +490,11 @@ int32_t ngpde_node_profile(ngpde_node_t *plan, int32_t stride, float *out_us, in
 int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, int32_t n_terms, const float *const *terms,
                                const float *coefs, float *out, ngpde_stream_t stream);
 
+/* acc[k][i] += g[k][i], i < counts[k], for n_arrays arrays in one launch (per 24 arrays): the cotangents of ALL parameters of one
+ * right-hand-side pullback added to their accumulators over the stages of the discrete adjoint (the same arithmetic as
+ * ngpde_rk_stage_combine(count, 1, acc, 1, {g}, {1}, acc) per array: fma(1, g, 1 * acc)).  acc / g / counts are HOST arrays. */
+int32_t ngpde_accumulate_many(int32_t n_arrays, float *const *acc, const float *const *g, const int64_t *counts, ngpde_stream_t stream);
+
 /* Optimiser step on the flat parameter vector, one launch behind the gradient all-reduce on the same stream
  * [UPSTREAM Optimisers.jl Adam / Rprop; reference call sites docs/src/tutorials/graph_node.md:90,122-129, VMH.md:97].
  * grad_scale multiplies the (reduced) gradient first: 1/world_size for a mean over data-parallel ranks.

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ngpde_gat_workspace_bytes": (_sz, [_vp, _i32]),
     "ngpde_gat_backward": (_i32, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ngpde_rk_stage_combine": (_i32, [_i64, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ngpde_accumulate_many": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "ngpde_gno_message_supported": (_i32, [_i32, _i32]),
     "ngpde_gno_message_backward_from_nodes": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gno_message_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -68,6 +68,22 @@ __global__ void rk_combine_kernel(int64_t count, float c_self, const T *base, co
   }
 }
 
+// acc[k][i] += g[k][i] for up to kManyMax small arrays in one launch (blockIdx.y = array): the parameter cotangents of one
+// right-hand-side pullback added to their accumulators (out aliases base: a thread reads and writes element i only)
+constexpr int kManyMax = 24;
+struct ManyK {
+  float *acc[kManyMax];
+  const float *g[kManyMax];
+  int64_t count[kManyMax];
+};
+__global__ void accumulate_many_kernel(const ManyK k) {
+  const int a = blockIdx.y;
+  float *acc = k.acc[a];
+  const float *g = k.g[a];
+  const int64_t n = k.count[a];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc[i] = fmaf(1.0f, g[i], 1.0f * acc[i]);
+}
+
 template <class T>
 void launch_rk_combine(int n_terms, int64_t count, float c_self, const float *base, const CombK &k, float *out, hipStream_t stream) {
   const dim3 grid((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), block(256);
@@ -111,6 +127,29 @@ int32_t ngpde_rk_stage_combine(int64_t count, float c_self, const float *base, i
   if (count % 4 == 0 && (bits & 15) == 0) launch_rk_combine<float4>(n_terms, count / 4, c_self, base, k, out, (hipStream_t)stream);
   else launch_rk_combine<float>(n_terms, count, c_self, base, k, out, (hipStream_t)stream);
   NGPDE_LAUNCH_CHECK("rk_combine_kernel");
+  return NGPDE_OK;
+}
+
+int32_t ngpde_accumulate_many(int32_t n_arrays, float *const *acc, const float *const *g, const int64_t *counts, ngpde_stream_t stream) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(n_arrays >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_accumulate_many: n_arrays < 0");
+  if (n_arrays == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(acc && g && counts, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_accumulate_many: NULL argument");
+  for (int a0 = 0; a0 < n_arrays; a0 += kManyMax) {
+    ManyK k{};
+    const int m = std::min(kManyMax, n_arrays - a0);
+    int64_t longest = 0;
+    for (int a = 0; a < m; ++a) {
+      NGPDE_REQUIRE(counts[a0 + a] >= 0 && (counts[a0 + a] == 0 || (acc[a0 + a] && g[a0 + a])), NGPDE_ERR_INVALID_ARGUMENT,
+                    "ngpde_accumulate_many: array %d is NULL or has a negative count", a0 + a);
+      k.acc[a] = acc[a0 + a]; k.g[a] = g[a0 + a]; k.count[a] = counts[a0 + a];
+      longest = std::max(longest, counts[a0 + a]);
+    }
+    if (longest == 0) continue;
+    const dim3 grid((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), (unsigned)m);
+    hipLaunchKernelGGL(accumulate_many_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+    NGPDE_LAUNCH_CHECK("accumulate_many_kernel");
+  }
   return NGPDE_OK;
 }
 

@@ -294,6 +294,20 @@ def _rk_forward(node, u, ps_in, st, needs, fresh=False):
     return ucur, tape, st_out
 
 
+def _accumulate_many(pairs):
+    """acc += g for every (acc, g) pair of dense float32 tensors of equal size (ngpde_accumulate_many: one launch per 24 arrays)"""
+    if not pairs:
+        return
+    for a_, g_ in pairs:
+        if a_.numel() != g_.numel() or a_.dtype != torch.float32 or g_.dtype != torch.float32:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "parameter cotangent and its accumulator differ in size or type")
+    n = len(pairs)
+    accs = (C.c_void_p * n)(*[a_.data_ptr() for a_, _ in pairs])
+    gs = (C.c_void_p * n)(*[g_.data_ptr() for _, g_ in pairs])
+    cnt = (C.c_int64 * n)(*[a_.numel() for a_, _ in pairs])
+    _lib.check(_lib.load().ngpde_accumulate_many(n, accs, gs, cnt, _lib.current_stream()))
+
+
 def _rk_backward(node, tape, duT, params, retain=False):
     """discrete adjoint of _rk_forward: (du0, cotangents of `params`)"""
     a, b = TABLEAUS[node.solver]
@@ -312,6 +326,7 @@ def _rk_backward(node, tape, duT, params, retain=False):
             grads = torch.autograd.grad(k, [U] + params, kbar, allow_unused=True, retain_graph=retain)
             if grads[0] is not None:
                 ubar[i] = grads[0].contiguous()
+            pairs_ag = []
             for n, g in enumerate(grads[1:]):
                 if g is None:
                     continue
@@ -320,12 +335,11 @@ def _rk_backward(node, tape, duT, params, retain=False):
                     # _dense return a temporary, and the sum written into it would be lost)
                     acc[n] = g if (g.is_contiguous() or (g.dim() == 2 and g.T.is_contiguous())) else g.contiguous()
                 elif acc[n].stride() == g.stride():
-                    # same layout for every stage's cotangent of one parameter: combine in memory order (out aliases base: the
-                    # kernel reads and writes element i only)
-                    _combine(_dense(acc[n]), 1.0, [_dense(g)], [1.0], out=_dense(acc[n]))
+                    # same layout for every stage's cotangent of one parameter: add in memory order
+                    pairs_ag.append((_dense(acc[n]), _dense(g)))
                 else:       # layouts differ (one transposed, one not): index-wise sum in the accumulator's own layout
-                    _combine(_dense(acc[n]), 1.0, [_dense(g.contiguous() if acc[n].is_contiguous() else g.T.contiguous().T)], [1.0],
-                             out=_dense(acc[n]))
+                    pairs_ag.append((_dense(acc[n]), _dense(g.contiguous() if acc[n].is_contiguous() else g.T.contiguous().T)))
+            _accumulate_many(pairs_ag)      # ONE launch for all parameters of this stage (sixteen arrays in the VMH tutorial's model)
         live = [x for x in ubar if x is not None]
         if live:
             lam = _combine(lam, 1.0, live, [1.0] * len(live))
