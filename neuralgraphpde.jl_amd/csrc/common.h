@@ -389,6 +389,9 @@ int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a,
 int32_t launch_dense_weight_reduce(int nchunk, int din, int dout, const float *partial, float *dwt, float *db, hipStream_t stream);
 // the whole pullback of a Dense of at most 64 x 64 in one launch + the slab reduction (dense_small_bwd.hip)
 int dense_small_bwd_grid(int64_t n, int din, int dout);
+int dense_small_fwd_grid(int64_t n, int din, int dout);
+int32_t launch_dense_small_fwd(int64_t n, const SegTable &t, int din, int dout, int act, const float *wt, const float *bias, float *y,
+                               float *save_z, int grid, hipStream_t stream);
 int32_t launch_dense_small_bwd(int64_t n, const SegTable &t, int din, int dout, int act, const float *wt, const float *z, const float *dy,
                                float *const *dseg, float *dwt, float *dbias, float *slabs, int grid, hipStream_t stream);
 int32_t launch_edge_sum_by_source(const ngpde_graph *g, int h, const float *per_edge, float *out, hipStream_t stream);

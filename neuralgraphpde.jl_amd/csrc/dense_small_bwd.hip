@@ -170,7 +170,125 @@ __global__ __launch_bounds__(kT) void dense_small_bwd_kernel(const SmallBwdK p) 
   if (tid < kW && tid < dout) slab[(size_t)din * dout + tid] = (ldsDb[0][tid] + ldsDb[1][tid]) + (ldsDb[2][tid] + ldsDb[3][tid]);
 }
 
+// ---- forward of the same shapes: y = act(X W + b) with the whole contraction in one pass -----------------------------------------
+// (the general kernel walks the inputs in 16-feature steps with two barriers each: four to five dependent rounds at din = 60)
+struct SmallFwdK {
+  int64_t n;
+  int n_tiles, din, dout, act;
+  SegTable segs;
+  const float *wt, *bias;
+  float *y, *save_z;
+};
+
+template <int ACT>
+__device__ __forceinline__ void act16(float (&v)[16]) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = act_c<ACT>(v[s]);
+}
+
+__global__ __launch_bounds__(kT) void dense_small_fwd_kernel(const SmallFwdK p) {
+  __shared__ __attribute__((aligned(16))) float ldsW[kW * kSZ], ldsX[kR * kSZ];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int din = p.din, dout = p.dout;
+  const int c = tid & 63, rq = tid >> 6;
+  // B[k = in][j = o] = wt[in][o]  ->  Bt[j = o][k = in]: a transposing (zero-padded) copy, loads first
+  {
+    float wv[kW * kW / kT];
+#pragma unroll
+    for (int k = 0; k < kW * kW / kT; ++k) {
+      const int in = rq + 4 * k;
+      wv[k] = (in < din && c < dout) ? p.wt[(size_t)in * dout + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kW * kW / kT; ++k) ldsW[c * kSZ + rq + 4 * k] = wv[k];
+  }
+  const float *xbase = nullptr;
+  int xwidth = 0, xdiv = 1;
+#pragma unroll
+  for (int b = 3; b >= 0; --b)
+    if (b < p.segs.n && c < p.segs.offset[b + 1] && c >= p.segs.offset[b] && c < din) {
+      xbase = p.segs.ptr[b] + (c - p.segs.offset[b]);
+      xwidth = p.segs.width[b];
+      xdiv = p.segs.row_div[b];
+    }
+  float bo[4];   // bias of the columns this lane holds after the product (column 16 ct + i16)
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) bo[ct] = (p.bias && 16 * ct + i16 < dout) ? p.bias[16 * ct + i16] : 0.f;
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * kR;
+    float xv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int64_t r = row0 + rq + 4 * s;
+      xv[s] = (r < p.n && xbase) ? xbase[srow(r, xdiv) * xwidth] : 0.f;
+    }
+    __syncthreads();   // the previous tile's product is done with the X tile (and W is in LDS)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ldsX[(rq + 4 * s) * kSZ + c] = xv[s];
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(&ldsX[(wave * 16 + i16) * kSZ + 16 * kb + 4 * kq]);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(&ldsW[(ct * 16 + i16) * kSZ + 16 * kb + 4 * kq]);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct] = mfma16(av[r], bv[r], acc[ct]);
+      }
+    }
+    float zv[16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) zv[4 * ct + reg] = acc[ct][reg] + bo[ct];
+    if (p.save_z) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t r = row0 + wave * 16 + 4 * kq + reg;
+          const int o = 16 * ct + i16;
+          if (r < p.n && o < dout) p.save_z[r * dout + o] = zv[4 * ct + reg];
+        }
+    }
+    NGPDE_ACT_DISPATCH(p.act, act16, zv)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = row0 + wave * 16 + 4 * kq + reg;
+        const int o = 16 * ct + i16;
+        if (r < p.n && o < dout) p.y[r * dout + o] = zv[4 * ct + reg];
+      }
+  }
+}
+
 }  // namespace
+
+// the forward of the same shapes in one contraction pass (0: not this form's shape)
+int dense_small_fwd_grid(int64_t n, int din, int dout) {
+  static const bool off = std::getenv("NGPDE_DENSE_NO_SMALL_FWD") != nullptr;
+  if (off || din < 17 || din > kW || dout < 1 || dout > kW || n < 1 || n > 65536) return 0;   // (din <= 16 is ONE step of the general kernel)
+  return (int)std::min<int64_t>((n + kR - 1) / kR, 1024);
+}
+
+int32_t launch_dense_small_fwd(int64_t n, const SegTable &t, int din, int dout, int act, const float *wt, const float *bias, float *y,
+                               float *save_z, int grid, hipStream_t stream) {
+  SmallFwdK k{};
+  k.n = n; k.n_tiles = (int)((n + kR - 1) / kR); k.din = din; k.dout = dout; k.act = act;
+  k.segs = t; k.wt = wt; k.bias = bias; k.y = y; k.save_z = save_z;
+  hipLaunchKernelGGL(dense_small_fwd_kernel, dim3(grid), dim3(kT), 0, stream, k);
+  NGPDE_LAUNCH_CHECK("dense_small_fwd_kernel");
+  return NGPDE_OK;
+}
 
 // grid of the one-launch form, or 0 when the shape is not its own: widths up to 64, few enough rows that the composed path's
 // launches are latency-bound (beyond that its 16-byte / LDS-DMA loads win), and enough rows for the slabs to fit the [n][dout] dz
