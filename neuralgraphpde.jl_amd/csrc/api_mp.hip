@@ -54,8 +54,6 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
                 "ngpde_dense_forward: DimensionMismatch (rows must be in [0, 2^31), dout > 0)");
   if (n == 0) return NGPDE_OK;
   NGPDE_REQUIRE(weight && y, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_forward: weight/y is NULL");
-  if (const int sgrid = dense_small_fwd_grid(n, din, dout))   // 17 .. 64 inputs, at most 64 outputs, latency-bound row counts: one contraction pass
-    return launch_dense_small_fwd(n, t, din, dout, act, weight, bias, y, save_z, sgrid, (hipStream_t)stream);
   return launch_dense_seg_fwd(n, t, din, dout, act, weight, bias, y, save_z, (hipStream_t)stream);
 }
 

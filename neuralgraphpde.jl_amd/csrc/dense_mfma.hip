@@ -1243,6 +1243,8 @@ static bool use_wide_tiles(int64_t n, int cols) {
 int32_t launch_dense_seg_fwd(int64_t n, const SegTable &segs, int din, int dout, int act, const float *wt,
                              const float *bias, float *y, float *save_z, hipStream_t stream) {
   if (n == 0 || dout == 0) return NGPDE_OK;
+  if (const int sgrid = dense_small_fwd_grid(n, din, dout))   // 17 .. 64 inputs, at most 64 outputs, latency-bound row counts: one contraction pass
+    return launch_dense_small_fwd(n, segs, din, dout, act, wt, bias, y, save_z, sgrid, stream);
   {   // wide outputs from one 16-byte-loadable block: 128 x 128 tiles
     static const bool no_gemm = getenv("NGPDE_DENSE_NO_GEMM128") != nullptr;
     const int64_t tiles = ((n + BG - 1) / BG) * ((dout + BG - 1) / BG);
