@@ -662,3 +662,57 @@ def test_c5_full_size_gno_forward_and_backward(radius):
         y2, _ = l(x0.T, P2, st)
     lhs, rhs = dot(R.T, y2 - y), dot(gp["ϕ.layer_2.weight"], dW2)
     assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), abs(rhs)) + 1e-5 * float(R.norm() * (y2 - y).norm()), (lhs, rhs)
+
+
+@pytest.mark.parametrize("graph_kind", ["spatial", "citation"])
+def test_graph_node_tutorial_training_loop(graph_kind):
+    # docs/src/tutorials/graph_node.md end to end at Cora's size: model = Chain(GCNConv(nin => 16, relu), NeuralODE(Chain(GCNConv(16 => 16,
+    # relu), GCNConv(16 => 16, relu))), Dense(16, nout)) (:78-86), `updategraph` of the states (:91), parameters as ONE flat vector (:90),
+    # loss = logitcrossentropy on the training mask (:99-105), Optimisers.Adam(0.01) + update per epoch (:118-129).  Labels planted so
+    # that the graph is homophilous; the loop must bring the training loss down and the accuracy on held-out nodes above chance.
+    # "spatial": tiles fit the LDS halo -> the ODE block runs on the persistent solver (d = 16 zero-padded onto the 64-wide kernels);
+    # "citation": Cora's degree skew (hubs) -> the replayed plan.
+    from ngpde_amd import optim
+    N, nin, nhidden, nout = 2708, 1433, 16, 7
+    rng = np.random.default_rng(5)
+    if graph_kind == "spatial":
+        pts, s, t = S.closest_pairs_graph(N, 5278, seed=3)
+        cls = np.minimum((pts[:, 0] * nout).astype(np.int64), nout - 1)               # vertical stripes: neighbours share a class
+    else:
+        s, t = S.preferential_pairs_graph(N, 5278, seed=1)
+        cls = rng.integers(0, nout, size=N)
+        for _ in range(3):                                                            # label propagation: majority of the neighbours
+            votes = np.zeros((N, nout)); np.add.at(votes, (t, cls[s]), 1.0)
+            cls = np.where(votes.sum(1) > 0, votes.argmax(1), cls)
+    proto = rng.random((nout, nin)) < 0.02                                            # sparse bag-of-words prototypes + noise
+    Xh = ((rng.random((N, nin)) < 0.01) | (proto[cls] & (rng.random((N, nin)) < 0.6))).astype(np.float32)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    node = ng.NeuralODE(ng.Chain(ng.GCNConv((nhidden, nhidden), "relu"), ng.GCNConv((nhidden, nhidden), "relu")), solver="tsit5", n_steps=10, dt=0.1)
+    model = ng.Chain(ng.GCNConv((nin, nhidden), "relu"), node, ng.Dense(nhidden, nout))
+    ps, st = ng.setup(0, model)
+    st = ng.updategraph(st, g)
+    flat, ps = optim.flatten_parameters(ng.to_device(ps, DEV))
+    X = torch.as_tensor(Xh, device=DEV).T                                              # (nin x N), the reference's layout
+    y = torch.as_tensor(cls, device=DEV)
+    mask = torch.as_tensor(rng.random(N) < 0.3, device=DEV)
+    st_opt = optim.setup(optim.Adam(0.01), flat)
+
+    def loss_fn():
+        yhat, _ = model(X, ps, st)
+        return torch.nn.functional.cross_entropy(yhat.T[mask], y[mask]), yhat
+
+    losses = []
+    for epoch in range(40):
+        flat.zero_grad()
+        l, _ = loss_fn()
+        l.backward()
+        st_opt = optim.update(st_opt, flat)
+        losses.append(float(l.detach()))
+    with torch.no_grad():
+        l, yhat = loss_fn()
+        acc = float((yhat.T[~mask].argmax(1) == y[~mask]).double().mean())
+    plan = next(iter(node._plans.values()))[0]
+    assert ("persistent_fwd" in plan.flags()) == (graph_kind == "spatial"), plan.flags()
+    assert not plan.fault()
+    assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses[::8]
+    assert acc > 2.0 / nout, acc
