@@ -271,8 +271,10 @@ def _rk_forward(node, u, ps_in, st, needs, fresh=False):
     a, b = TABLEAUS[node.solver]
     dt, S = node.dt, len(b)
     ucur, tape, st_out = u, [], st
+    k_save = node.save_every
+    saves = [ucur] if (k_save and node.save_start) else []      # saveat: the states at t0 (+ j saveat), as DiffEq's sol.u
     with (torch.enable_grad() if needs else torch.no_grad()):
-        for _ in range(node.n_steps):
+        for n_step in range(node.n_steps):
             ks, pairs = [], []
             for i in range(S):
                 terms = [ks[j] for j in range(i) if a[i][j] != 0.0]
@@ -291,6 +293,13 @@ def _rk_forward(node, u, ps_in, st, needs, fresh=False):
             ucur = _combine(ucur, 1.0, ks, [dt * bi for bi in b])
             if needs:
                 tape.append(pairs)
+            if k_save and (n_step + 1) % k_save == 0:
+                saves.append(ucur)
+    if k_save:      # [T][N][D]: the memory layout of the reference's (D x N x T) array; rows written by library launches
+        out = torch.empty((len(saves),) + tuple(ucur.shape), dtype=ucur.dtype, device=ucur.device)
+        for j, s_ in enumerate(saves):
+            _combine(s_, 1.0, [], [], out=out[j])
+        ucur = out
     return ucur, tape, st_out
 
 
@@ -313,8 +322,10 @@ def _rk_backward(node, tape, duT, params, retain=False):
     a, b = TABLEAUS[node.solver]
     dt, S = node.dt, len(b)
     acc = [None] * len(params)
-    lam = duT
-    for pairs in reversed(tape):
+    k_save = node.save_every
+    off = 0 if node.save_start else -1           # saved state j is u after (j - off') steps: index of u_n is n / k_save + off
+    lam = duT[node.n_steps // k_save + off] if k_save else duT
+    for n_step, pairs in zip(range(len(tape) - 1, -1, -1), reversed(tape)):
         ubar = [None] * S
         for i in reversed(range(S)):
             terms = [ubar[j] for j in range(i + 1, S) if a[j][i] != 0.0 and ubar[j] is not None]
@@ -341,6 +352,8 @@ def _rk_backward(node, tape, duT, params, retain=False):
                     pairs_ag.append((_dense(acc[n]), _dense(g.contiguous() if acc[n].is_contiguous() else g.T.contiguous().T)))
             _accumulate_many(pairs_ag)      # ONE launch for all parameters of this stage (sixteen arrays in the VMH tutorial's model)
         live = [x for x in ubar if x is not None]
+        if k_save and n_step % k_save == 0 and n_step // k_save + off >= 0:
+            live.append(duT[n_step // k_save + off])          # lambda(t_n) also carries the cotangent of the state saved there
         if live:
             lam = _combine(lam, 1.0, live, [1.0] * len(live))
     return lam, acc
@@ -457,12 +470,21 @@ class NeuralODE(AbstractExplicitLayer):
     the first call and replayed afterwards (_CapturedSolve).
     """
 
-    def __init__(self, model, *, solver="tsit5", tspan=(0.0, 1.0), n_steps=10, dt=None, capture=False):
+    def __init__(self, model, *, solver="tsit5", tspan=(0.0, 1.0), n_steps=10, dt=None, capture=False, saveat=None, save_start=True):
         solver = solver.lower()
         if solver not in TABLEAUS:
             raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, f"unknown solver {solver!r}; one of {list(TABLEAUS)}")
         self.model, self.solver, self.tspan, self.n_steps = model, solver, tuple(tspan), int(n_steps)
         self.dt = float(dt) if dt is not None else (self.tspan[1] - self.tspan[0]) / self.n_steps
+        # saveat (VMH.md:85 `NeuralODE(gnn, tspan, Tsit5(); saveat=dt_train)`): the output is the solution at t0, t0 + saveat, ..., T --
+        # a (D x N x T) array -- instead of u(T).  The step is fixed, so saveat must be a whole number of steps.
+        self.save_every, self.save_start = 0, bool(save_start)
+        if saveat is not None:
+            k = round(float(saveat) / self.dt)
+            if k < 1 or abs(k * self.dt - float(saveat)) > 1e-6 * max(abs(float(saveat)), 1.0) or self.n_steps % k:
+                raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, f"NeuralODE: saveat = {saveat} must be a whole number of steps "
+                                                                  f"(dt = {self.dt}) that divides n_steps = {self.n_steps}")
+            self.save_every = k
         self._plans = {}
         self._no_member_plan = False
         self.capture = bool(capture)      # generic right-hand sides: replay the whole solve / adjoint from HIP graphs
@@ -589,8 +611,8 @@ class NeuralODE(AbstractExplicitLayer):
     def __call__(self, x, ps, st):
         u = rows_of(x)
         needs_grad = torch.is_grad_enabled() and (u.requires_grad or any(
-            v.requires_grad for lp in ps.values() if isinstance(lp, dict) for v in lp.values()))
-        plan = self.plan_for(ps, st, needs_grad)
+            isinstance(v, torch.Tensor) and v.requires_grad for v in _leaves(ps)))      # (parameter trees of any depth: VMHConv's phi / gamma chains)
+        plan = self.plan_for(ps, st, needs_grad) if not self.save_every else None
         if plan is not None:
             if not u.is_cuda:
                 raise _lib.ArgumentError(_lib.ERR_INVALID_ARGUMENT, "NeuralODE: inputs must live on the GPU (no CPU fallback)")
@@ -599,7 +621,7 @@ class NeuralODE(AbstractExplicitLayer):
             b2 = p2["bias"].reshape(-1) if "bias" in p2 else None
             uT = _NodeGCN2Fn.apply(u, rows_of(p1["weight"]), b1, rows_of(p2["weight"]), b2, plan)
             return uT.T, st
-        gplan = self.gat_plan_for(ps, st, u)
+        gplan = self.gat_plan_for(ps, st, u) if not self.save_every else None
         if gplan is not None:
             gps = ps["layer_1"] if isinstance(self.model, Chain) else ps
             b = gps["bias"].reshape(-1) if "bias" in gps else None
@@ -623,6 +645,6 @@ class NeuralODE(AbstractExplicitLayer):
                 while len(self._captured) > self.max_plans:
                     self._captured.pop(next(iter(self._captured)))
             uT = _NodeCapturedFn.apply(u, solve, *leaves)
-            return uT.T, st
+            return (uT.permute(2, 1, 0) if self.save_every else uT.T), st
         uT = _NodeGenericFn.apply(u, self, ps, st, *leaves)
-        return uT.T, st
+        return (uT.permute(2, 1, 0) if self.save_every else uT.T), st      # saveat: (D x N x T), the reference's array of the solution

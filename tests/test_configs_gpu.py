@@ -716,3 +716,50 @@ def test_graph_node_tutorial_training_loop(graph_kind):
     assert not plan.fault()
     assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses[::8]
     assert acc > 2.0 / nout, acc
+
+
+def test_vmh_tutorial_training_loop():
+    # docs/src/tutorials/VMH.md end to end at reduced size: model = NeuralODE(VMHConv(phi, gamma), tspan, Tsit5(); saveat = dt_train)
+    # with the tutorial's MLPs (:75-83), a minibatch = a batched point-cloud graph handed over by updategraph (:132-134), the input is
+    # u(t0) and the target the solution at every saved time (:135-139), loss = mse (:104-108), optimiser Rprop(1e-6, (0.5, 1.2),
+    # (1e-8, 10)) on the flat parameter vector (:97, :126-141).  The data: a heat-like decay towards the neighbourhood mean, which the
+    # model class can represent; the loop must bring the loss down.
+    from ngpde_amd import optim
+    npts, nsamples, T, dt_train, sub = 150, 4, 4, 0.1, 2        # 4 saved intervals, 2 solver steps each
+    rng = np.random.default_rng(9)
+    graphs, U = [], []
+    for k in range(nsamples):
+        pts = torch.as_tensor(S.uniform01(100 + k, 2 * npts).reshape(2, npts).astype(np.float32), device=DEV)
+        gk = ng.GNNGraph(ng.knn_graph(pts, 6), ndata={"x": pts})
+        s_, t_ = [np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a) for a in gk.edge_index(index_base=0)]
+        A = np.zeros((npts, npts)); A[t_, s_] = 1.0
+        P = A / np.maximum(A.sum(1, keepdims=True), 1.0)
+        u = np.sin(6.0 * pts[0].cpu().numpy()) * np.cos(4.0 * pts[1].cpu().numpy()) + 0.1 * rng.normal(size=npts)
+        traj = [u]
+        for _ in range(T):
+            for _ in range(10):
+                u = u + 0.01 * 3.0 * (P @ u - u)                   # du/dt = 3 (mean of the neighbours - u), fine Euler steps
+            traj.append(u)
+        graphs.append(gk); U.append(np.stack(traj, axis=1))           # (space_points, time_points)
+    g = ng.batch(graphs)
+    u_all = np.concatenate(U, axis=0).astype(np.float32)              # (space_points * num_samples, time_points)
+    act, nhidden, nout = "tanh", 60, 40
+    phi = ng.Chain(ng.Dense(4, nhidden, act), ng.Dense(nhidden, nhidden, act), ng.Dense(nhidden, nhidden, act), ng.Dense(nhidden, nout))
+    gam = ng.Chain(ng.Dense(nout + 1, nhidden, act), ng.Dense(nhidden, nhidden, act), ng.Dense(nhidden, nhidden, act), ng.Dense(nhidden, 1))
+    node = ng.NeuralODE(ng.VMHConv(phi, gam), solver="tsit5", tspan=(0.0, T * dt_train), n_steps=T * sub, saveat=dt_train)
+    ps, st = ng.setup(0, node)
+    flat, ps = optim.flatten_parameters(ng.to_device(ps, DEV))
+    st_opt = optim.setup(optim.Rprop(1e-6, (0.5, 1.2), (1e-8, 10.0)), flat)
+    u0 = torch.as_tensor(u_all[:, 0].reshape(1, -1), device=DEV)                        # (1, space_points * num_samples)
+    ut = torch.as_tensor(u_all.reshape(1, u_all.shape[0], T + 1), device=DEV)           # (1, nodes, time_points)
+    losses = []
+    for epoch in range(60):
+        st = ng.updategraph(st, g)
+        flat.zero_grad()
+        yhat, _ = node(u0, ps, st)
+        assert tuple(yhat.shape) == (1, g.num_nodes, T + 1)
+        l = torch.mean((yhat - ut) ** 2)
+        l.backward()
+        st_opt = optim.update(st_opt, flat)
+        losses.append(float(l.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::10]

@@ -974,3 +974,67 @@ def test_node_persistent_abort_poisons_outputs_and_the_plan_refuses_further_work
     fresh = _Plan(g.handle((True, None, False)), d, _lib.ACT["relu"], "tsit5", 3, 0.05, True)      # a new plan works
     _lib.check(lib.ngpde_node_gcn2_forward(fresh.ptr, p(u0), p(w1), p(b), p(w2), p(b), p(uT), st))
     assert not fresh.fault() and torch.isfinite(uT).all()
+
+
+@pytest.mark.parametrize("tab,capture,save_start", [("tsit5", False, True), ("euler", False, False), ("tsit5", True, True)])
+def test_node_saveat_returns_the_solution_at_the_saved_times(tab, capture, save_start):
+    # NeuralODE(model, tspan, Tsit5(); saveat = dt_train) of docs/src/tutorials/VMH.md:85: the output is the (D x N x T) array of the
+    # solution at t0, t0 + saveat, ..., and the loss reads every time point (VMH.md:104-108).  Against the float64 oracle solved segment
+    # by segment; the discrete adjoint carries the cotangent of every saved state into lambda at its time.
+    N, d, nsteps, k, dt = 300, 16, 6, 2, 0.1
+    g, og, params = spatial_case(N, 4 * N, d, seed=77)
+    rhs = ng.Chain(ng.GCNConv((d, d), "tanh", initialgraph=g), ng.GCNConv((d, d), "tanh", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt, saveat=k * dt, save_start=save_start, capture=capture)
+    ps, st = ng.setup(0, node)
+    for j, name in enumerate(["layer_1", "layer_2"]):
+        ps[name]["weight"] = torch.as_tensor(params[j]["weight"].astype(np.float32))
+        ps[name]["bias"] = torch.as_tensor(params[j]["bias"].astype(np.float32))
+    ps = ng.to_device(ps, DEV)
+    for lp in ps.values():
+        for v in lp.values():
+            v.requires_grad_(True)
+    rng = np.random.default_rng(78)
+    u0 = rng.normal(size=(d, N))
+    T = nsteps // k + (1 if save_start else 0)
+    R = rng.normal(size=(d, N, T))
+    for rep in range(2 if capture else 1):          # (captured: the second call replays the graphs)
+        for lp in ps.values():
+            for v in lp.values():
+                v.grad = None
+        u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+        Y, _ = node(u, ps, st)
+        assert tuple(Y.shape) == (d, N, T)
+        (Y * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
+    rhs_o, vjp_o = O.gcn2_rhs(params, og, "tanh")
+    states, tapes, cur = [u0], [], u0
+    for _ in range(nsteps // k):
+        cur, tape = O.rk_solve(rhs_o, cur, O.TABLEAUS[tab], dt, k)
+        states.append(cur); tapes.append(tape)
+    saved = states if save_start else states[1:]
+    for j in range(T):
+        close(Y[:, :, j], saved[j], rtol=2e-4, what=f"u(t_{j})")
+    acc = [dict(weight=np.zeros_like(p["weight"]), bias=np.zeros_like(p["bias"])) for p in params]
+
+    def accumulate(pg):
+        for A, G in zip(acc, pg):
+            A["weight"] += G["weight"]
+            A["bias"] += G["bias"].reshape(A["bias"].shape)
+    lam = R[:, :, T - 1].copy()
+    for seg in range(nsteps // k - 1, -1, -1):
+        lam = O.rk_adjoint(vjp_o, tapes[seg], lam, O.TABLEAUS[tab], dt, accumulate)
+        j = seg if save_start else seg - 1
+        if j >= 0:
+            lam = lam + R[:, :, j]
+    close(u.grad, lam, rtol=5e-4, atol=1e-4, what="du0")
+    for j, name in enumerate(["layer_1", "layer_2"]):
+        close(ps[name]["weight"].grad, acc[j]["weight"], rtol=5e-4, atol=1e-3, what=f"dW{j + 1}")
+        close(ps[name]["bias"].grad, acc[j]["bias"], rtol=5e-4, atol=1e-3, what=f"db{j + 1}")
+
+
+def test_node_saveat_must_be_a_whole_number_of_steps():
+    rhs = ng.Chain(ng.GCNConv((4, 4), "tanh"), ng.GCNConv((4, 4), "tanh"))
+    with pytest.raises(ng.ArgumentError, match="whole number of steps"):
+        ng.NeuralODE(rhs, n_steps=10, dt=0.1, saveat=0.25)
+    with pytest.raises(ng.ArgumentError, match="whole number of steps"):
+        ng.NeuralODE(rhs, n_steps=10, dt=0.1, saveat=0.3)
+    assert ng.NeuralODE(rhs, n_steps=10, dt=0.1, saveat=0.5).save_every == 5
