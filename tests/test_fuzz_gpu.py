@@ -86,3 +86,56 @@ def test_random_gat_and_weighted_gcn_layers_against_the_oracle(seed):
             failures.append((case, name, n, act, loops, errs))
     assert not failures, failures
 
+
+
+@pytest.mark.parametrize("seed", [3, 17])
+def test_random_small_dense_layers_against_float64(seed):
+    # the one-launch Dense kernels for widths up to 64 (dense_small_bwd.hip: forward in one contraction pass, the whole pullback in one
+    # launch) and the general kernels around their limits: random row counts (fewer than a tile, ragged, up to 70 000), widths 1 .. 70,
+    # one to three blocks of a virtual vcat of which per-graph blocks carry no gradient, every activation, with and without bias --
+    # y, dW, db and the blocks' gradients against a float64 restatement with torch
+    from ngpde_amd import functional as F
+    rng = np.random.default_rng(seed)
+    ACTS = ["identity", "relu", "tanh", "sigmoid", "swish", "gelu", "leakyrelu", "elu", "softplus"]
+    REF = {"identity": lambda z: z, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "swish": lambda z: z * torch.sigmoid(z),
+           "gelu": lambda z: torch.nn.functional.gelu(z, approximate="tanh"), "leakyrelu": lambda z: torch.nn.functional.leaky_relu(z, 0.01),
+           "elu": torch.nn.functional.elu, "softplus": torch.nn.functional.softplus}
+    failures = []
+    for case in range(40):
+        n = int(rng.choice([1, 7, 63, 64, 65, 200, 1000, 3000, 18000, 65536, 65537, 70000]))
+        nb = int(rng.integers(1, 4))
+        widths = [int(rng.integers(1, 30)) for _ in range(nb)]
+        if rng.integers(0, 3) == 0:
+            widths = [int(rng.choice([16, 17, 60, 64, 65, 70]))]
+        divs = [1] + [int(rng.choice([1, max(n // 3, 1)])) for _ in range(len(widths) - 1)]
+        dout = int(rng.choice([1, 3, 16, 40, 60, 64, 65]))
+        act = str(rng.choice(ACTS))
+        bias = bool(rng.integers(0, 2))
+        blocks = [torch.as_tensor(rng.normal(size=((n + rd - 1) // rd, w)), dtype=torch.float32, device=DEV).requires_grad_(rd == 1)
+                  for w, rd in zip(widths, divs)]
+        din = sum(widths)
+        wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
+        b = torch.as_tensor(rng.normal(size=dout), dtype=torch.float32, device=DEV).requires_grad_(True) if bias else None
+        R = torch.as_tensor(rng.normal(size=(n, dout)), dtype=torch.float32, device=DEV)
+        y = F.dense(blocks, wt, b, ng.layers._act_code(act)[1], row_divs=divs, n=n)
+        (y * R).sum().backward()
+        # float64 restatement
+        blocks64 = [bl.detach().double().requires_grad_(rd == 1) for bl, rd in zip(blocks, divs)]
+        X = torch.cat([bl.repeat_interleave(rd, dim=0)[:n] if rd > 1 else bl for bl, rd in zip(blocks64, divs)], dim=1)
+        w64 = wt.detach().double().requires_grad_(True)
+        b64 = b.detach().double().requires_grad_(True) if bias else None
+        y64 = REF[act](X @ w64 + (b64 if bias else 0.0))
+        (y64 * R.double()).sum().backward()
+
+        def rel(a, ref):
+            return float((a.double() - ref).abs().max() / (ref.abs().max() + 1e-12))
+        errs = {"y": rel(y.detach(), y64.detach()), "dW": rel(wt.grad, w64.grad)}
+        if bias:
+            errs["db"] = rel(b.grad, b64.grad)
+        for k, (bl, bl64, rd) in enumerate(zip(blocks, blocks64, divs)):
+            if rd == 1:
+                errs[f"dx{k}"] = rel(bl.grad, bl64.grad)
+        bad = {k: v for k, v in errs.items() if not v < (2e-5 if k == "y" else 3e-4)}
+        if bad:
+            failures.append((case, n, widths, divs, dout, act, bias, bad))
+    assert not failures, failures
