@@ -115,19 +115,39 @@ __global__ __launch_bounds__(kT, (NTAIL <= 1 ? 4 : 2)) void edge_mlp_fused_fwd_k
   };
 
   // ---- once per workgroup: tail weights as W^T rows (output j, contiguous inputs) and biases in LDS
-#pragma unroll
-  for (int l = 0; l < NTAIL; ++l) {
+  // (all loads of all layers first, unconditional from clamped addresses, pinned, then selected and written: a `cond ? load : 0` is an
+  // exec-masked branch per load, and with one tile per workgroup -- a 3 000-node graph -- this prologue is most of the launch)
+  {
     const int j = tid % kW, kg0 = tid / kW;   // output column j, input quads kg0 and kg0 + 8
+    float t[NTAIL > 0 ? NTAIL : 1][2][4];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int k = 4 * (kg0 + 8 * ps);
-      float t[4];
+    for (int l = 0; l < NTAIL; ++l) {
+      const int dinl = p.din[l], doutl = p.dout[l];
+      const float *w = p.wt[l] + min(j, doutl - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        t[r] = (k + r < p.din[l] && j < p.dout[l]) ? p.wt[l][(size_t)(k + r) * p.dout[l] + j] : 0.f;
-      *reinterpret_cast<float4 *>(&ldsWt[l * kW * kTS + j * kTS + k]) = make_float4(t[0], t[1], t[2], t[3]);
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[l][ps][r] = w[min(4 * (kg0 + 8 * ps) + r, dinl - 1) * doutl];
     }
-    if (tid < kW) ldsBias[l * kW + tid] = (p.bias[l] && tid < p.dout[l]) ? p.bias[l][tid] : 0.f;
+#pragma unroll
+    for (int l = 0; l < NTAIL; ++l)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(t[l][ps][r]));
+#pragma unroll
+    for (int l = 0; l < NTAIL; ++l) {
+      const int dinl = p.din[l], doutl = p.dout[l];
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int k = 4 * (kg0 + 8 * ps);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (k + r < dinl && j < doutl) ? t[l][ps][r] : 0.f;
+        *reinterpret_cast<float4 *>(&ldsWt[l * kW * kTS + j * kTS + k]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (tid < kW) ldsBias[l * kW + tid] = (p.bias[l] && tid < doutl) ? p.bias[l][tid] : 0.f;
+    }
   }
   if (grp == 0) *reinterpret_cast<float4 *>(&ldsQ[zero_slot * kTS + 4 * q]) = f4_zero();   // the all-zero row
 
