@@ -583,7 +583,7 @@ struct GatBwdSK {
   const uint8_t *slots;
   const int *xpos;
   const int *xpad;   // by-source list position -> entry of the padded dscore blocks (persistent solver), else null
-  int n_tiles;
+  int n_tiles, n_edges;
   float *dx, *slab_dw, *slab_u;
 };
 
@@ -621,34 +621,69 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
   const int deg = ok ? m.sc.z : 0;
   const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
   float4 xo = reinterpret_cast<const float4 *>(p.x)[idx4];
-  if (!ok) xo = f4_zero();
-  float dalq = (ok && q < H) ? p.dal[(size_t)m.sc.x * H + q] : 0.f;
+  // Every load below is unconditional, from a clamped position, pinned after its batch and neutralised afterwards.  As
+  // `valid ? load : 0` each was an exec-masked branch whose join waits for the load, and the lane's two entries went one after the
+  // other: list position, wait, coefficient + dscore, wait, twice -- four round trips behind the row gather instead of two.
+  float dalq = p.dal[(size_t)max(m.sc.x, 0) * H + min(q, H - 1)];
   // this lane's two outgoing entries: coefficient and dscore of the same edge in the by-target list
   float av[2][4], ds[2][4];
+  const int elast = p.n_edges - 1;      // (>= 0: gat_layer_fused_supported refuses a graph without edges)
+  int ent[2], pp[2], xq[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // (a lane beyond its row's degree re-reads the row's first entry and drops it: the same address as lane 0, so no further request --
+    // reading on into the next rows' entries made the persistent adjoint 25 % slower, its dscore loads go to memory)
+    ent[s] = max(min(m.sc.y + (q + 16 * s < deg ? q + 16 * s : 0), elast), 0);
+    pp[s] = p.xpos[ent[s]];
+    xq[s] = PAD ? p.xpad[ent[s]] : 0;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    asm volatile("" : "+v"(pp[s]));
+    asm volatile("" : "+v"(xq[s]));
+  }
+  float va[2][4], vd[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) va[s][k] = vd[s][k] = 0.f;
+    if (PAD) {   // the persistent solver: alpha from the tape (list order), dscore from the target tile's padded block, sc1
+      const float4 u = gat_load4_sc1(p.dscore + (size_t)xq[s] * 4);
+      vd[s][0] = u.x; vd[s][1] = u.y; vd[s][2] = u.z; vd[s][3] = u.w;
+      if (H == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp[s] * 4); va[s][0] = t4.x; va[s][1] = t4.y; va[s][2] = t4.z; va[s][3] = t4.w; }
+      else if (H == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp[s] * 2); va[s][0] = t2.x; va[s][1] = t2.y; }
+      else va[s][0] = p.alpha[pp[s]];
+    } else {
+      if (H == 4) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp[s] * 4), u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pp[s] * 4);
+        va[s][0] = t4.x; va[s][1] = t4.y; va[s][2] = t4.z; va[s][3] = t4.w; vd[s][0] = u.x; vd[s][1] = u.y; vd[s][2] = u.z; vd[s][3] = u.w;
+      } else if (H == 2) {
+        const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp[s] * 2), u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pp[s] * 2);
+        va[s][0] = t2.x; va[s][1] = t2.y; vd[s][0] = u.x; vd[s][1] = u.y;
+      } else {
+        va[s][0] = p.alpha[pp[s]]; vd[s][0] = p.dscore[pp[s]];
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      asm volatile("" : "+v"(va[s][k]));
+      asm volatile("" : "+v"(vd[s][k]));
+    }
+  asm volatile("" : "+v"(dalq));
+  asm volatile("" : "+v"(xo.x)); asm volatile("" : "+v"(xo.y)); asm volatile("" : "+v"(xo.z)); asm volatile("" : "+v"(xo.w));
+  if (!ok) xo = f4_zero();
+  if (!(ok && q < H)) dalq = 0.f;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const bool valid = q + 16 * s < deg;
-    const int pp = valid ? p.xpos[m.sc.y + q + 16 * s] : 0;
-    float va[4] = {0.f, 0.f, 0.f, 0.f}, vd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (valid && PAD) {   // the persistent solver: alpha from the tape (list order), dscore from the target tile's padded block, sc1
-      const float4 u = gat_load4_sc1(p.dscore + (size_t)p.xpad[m.sc.y + q + 16 * s] * 4);
-      vd[0] = u.x; vd[1] = u.y; vd[2] = u.z; vd[3] = u.w;
-      if (H == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp * 4); va[0] = t4.x; va[1] = t4.y; va[2] = t4.z; va[3] = t4.w; }
-      else if (H == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp * 2); va[0] = t2.x; va[1] = t2.y; }
-      else va[0] = p.alpha[pp];
-    } else if (valid) {
-      if (H == 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp * 4), u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pp * 4);
-        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; vd[0] = u.x; vd[1] = u.y; vd[2] = u.z; vd[3] = u.w;
-      } else if (H == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp * 2), u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pp * 2);
-        va[0] = t.x; va[1] = t.y; vd[0] = u.x; vd[1] = u.y;
-      } else {
-        va[0] = p.alpha[pp]; vd[0] = p.dscore[pp];
-      }
-    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { av[s][k] = fabsf(va[k]); ds[s][k] = vd[k]; }
+    for (int k = 0; k < 4; ++k) {
+      av[s][k] = valid ? fabsf(va[s][k]) : 0.f;
+      ds[s][k] = valid ? vd[s][k] : 0.f;
+    }
     reinterpret_cast<float4 *>(ldsS)[grp * kSlotWidth + q + 16 * s] = make_float4(av[s][0], av[s][1], av[s][2], av[s][3]);
   }
   if (grp == 0) Xh4[kHaloCap * GG::LPR + q] = f4_zero();
@@ -1294,7 +1329,7 @@ extern "C" int32_t ngpde_debug_set_gat_stamps(unsigned long long *dev_buf) {   /
 #endif
 
 bool gat_layer_fused_supported(const ngpde_graph *g, int din, int heads, int c) {
-  return g && g->has_norm && g->by_t.halo_ok && g->by_s.halo_ok && din == GD && heads * c == GD &&
+  return g && g->has_norm && g->n_edges > 0 && g->by_t.halo_ok && g->by_s.halo_ok && din == GD && heads * c == GD &&
          (heads == 1 || heads == 2 || heads == 4) && (uint64_t)g->n_nodes * GD * 4 < (1ull << 32) && !no_fused_gat_layer_env();
 }
 
@@ -1339,7 +1374,7 @@ int32_t launch_gat_layer_bwd(const ngpde_graph *g, int heads, float slope, int a
     NGPDE_GST_SET(t)
     GatBwdSK s;
     s.gz = ident ? dy : dz; s.x = x; s.wt = wt; s.a = a; s.alpha = alpha; s.dscore = dscore; s.dal = dal; s.sched = g->by_s.sched;
-    s.halo = g->by_s.halo; s.slots = g->by_s.slots; s.xpos = g->by_s.xpos; s.n_tiles = n_tiles; s.dx = dx; s.slab_dw = slab_dw;
+    s.halo = g->by_s.halo; s.slots = g->by_s.slots; s.xpos = g->by_s.xpos; s.n_tiles = n_tiles; s.n_edges = (int)g->n_edges; s.dx = dx; s.slab_dw = slab_dw;
     s.slab_u = slab_u; s.xpad = nullptr;
     NGPDE_GST_SET(s)
     const dim3 block(kThreads);
@@ -1498,7 +1533,7 @@ int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   k.t.slots = g->by_t.slots; k.t.n_tiles = ps.n_tiles; k.t.act = a.act; k.t.slope = a.slope; k.t.dz = nullptr; k.t.dscore = nullptr;
   k.t.dal = a.dal; k.t.slab_db = nullptr;
   k.s.gz = nullptr; k.s.x = nullptr; k.s.wt = a.wt; k.s.a = a.a; k.s.alpha = nullptr; k.s.dscore = nullptr; k.s.dal = a.dal;
-  k.s.sched = g->by_s.sched; k.s.halo = g->by_s.halo; k.s.slots = g->by_s.slots; k.s.xpos = g->by_s.xpos; k.s.xpad = a.xpad;
+  k.s.sched = g->by_s.sched; k.s.halo = g->by_s.halo; k.s.slots = g->by_s.slots; k.s.xpos = g->by_s.xpos; k.s.xpad = a.xpad; k.s.n_edges = (int)g->n_edges;
   k.s.n_tiles = ps.n_tiles; k.s.dx = nullptr; k.s.slab_dw = a.slab_dw; k.s.slab_u = a.slab_u;
   k.y = gat_sync(ps);
   NGPDE_GST_SET(k)
