@@ -14,6 +14,8 @@ batch of synthetic input already resident in HBM.
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # the same: starts its own N ranks (one fresh process per GPU);
+                                                         # prints a {"skipped": true, ...} record when the box has < N devices
 
 Multi-GPU is data parallel over independent trajectories (different u0 per rank, same graph and
 parameters): per-GPU work is fixed ("weak"), one all-reduce(sum) of the 8320-float gradient per step.
@@ -458,6 +460,47 @@ def secondary(dev, world, rank, dist):
     return out
 
 
+def spawn_ranks(args, backend):
+    """`python3 bench.py --gpus N` typed as is (no torch.distributed.run around it): start the N ranks as fresh child processes
+    of this one -- which has made no GPU call and makes none -- with the rendezvous in the environment, relay rank 0's JSON
+    line, return non-zero if any rank fails.  With fewer than N devices under the nccl backend (RCCL refuses two ranks on one
+    device) print ONE record that says so instead of a measurement."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()        # (does not initialise the GPU)
+    if backend == "nccl" and have < n:
+        print(json.dumps({"metric": "ODE-steps/sec (fwd+bwd) on 16k-node graph, 64-d feats", "value": None, "unit": "ODE-steps/s",
+                          "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "skipped": True,
+                          "reason": f"--gpus {n} needs {n} devices for one RCCL rank per GPU; this box has {have}",
+                          "devices_visible": have, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic"}))
+        return 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for pr in procs[1:]:
+        try:
+            rcs.append(pr.wait(timeout=120 if rcs[0] == 0 else 5))
+        except subprocess.TimeoutExpired:
+            pr.kill()                           # (the exact child started above)
+            rcs.append(pr.wait())
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,15 +516,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     # NGPDE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
     # collective goes through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU
     backend = os.environ.get("NGPDE_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        # rehearsal: the ranks share one device, and two persistent solver launches in flight on one device can starve each
-        # other of residency (include/ngpde.h, ngpde_node_flags) -- take the replayed plan there
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python3 bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (counting devices
+        # does not initialise HIP on this image) and never will: the ranks are fresh child processes
+        sys.exit(spawn_ranks(args, backend))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    # Rehearsal on a shared device: two persistent solver launches in flight on one device can starve each other of residency
+    # (include/ngpde.h, ngpde_node_flags).  Either the ranks take turns on the device through a file lock
+    # (NGPDE_BENCH_SERIALISE=<lock file>: persistent plan + collective + Adam on one stream, one rank's solve at a time) or
+    # they take the replayed plan
+    lock_path = os.environ.get("NGPDE_BENCH_SERIALISE") if world > 1 else None
+    if backend != "nccl" and not lock_path:
         os.environ.setdefault("NGPDE_NO_PERSISTENT", "1")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -505,6 +555,24 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    class device_turn:
+        """NGPDE_BENCH_SERIALISE rehearsal only: the ranks share ONE device, and a persistent solve needs all of it -- a rank
+        holds the lock file from its first launch until its stream has drained.  A no-op in the measured configuration."""
+        def __enter__(self):
+            if lock_path:
+                import fcntl
+                self.f = open(lock_path, "a+")
+                fcntl.flock(self.f, fcntl.LOCK_EX)
+            return self
+
+        def __exit__(self, *exc):
+            if lock_path:
+                import fcntl
+                torch.cuda.synchronize()
+                fcntl.flock(self.f, fcntl.LOCK_UN)
+                self.f.close()
+            return False
 
     def job(traj, n_steps, n_warmup):
         """`traj` independent trajectories on this GPU as ONE block-diagonal batched graph (traj = 1: the BASELINE workload).
@@ -533,8 +601,9 @@ def main():
 
         def step():
             # one training step: solve, discrete adjoint, gradient all-reduce, fused Adam on the flat vector (1/world folded in)
-            _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
-            _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+            with device_turn():
+                _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+                _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
             if dist is not None:
                 dist.all_reduce(flat)
             it[0] += 1
@@ -559,11 +628,12 @@ def main():
             elapsed = float(tt.item())
         # forward / backward split of one solve, by HIP events on the launch stream (outside the timed region)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
-        ev[1].record()
-        _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
-        ev[2].record()
+        with device_turn():
+            ev[0].record()
+            _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
+            ev[1].record()
+            _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+            ev[2].record()
         torch.cuda.synchronize()
         return elapsed, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), plan
 
@@ -582,7 +652,8 @@ def main():
         cnt = (C.c_int32 * 4)()
         samples = []
         for _ in range(5 if "persistent_fwd" in plan.flags() else 1):
-            _lib.check(lib.ngpde_node_profile(plan.ptr, 1, us, cnt, stream))
+            with device_turn():
+                _lib.check(lib.ngpde_node_profile(plan.ptr, 1, us, cnt, stream))
             samples.append([float(us[i]) for i in range(4)])
         med = np.median(np.asarray(samples), axis=0)
         for i in range(4):

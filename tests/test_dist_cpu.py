@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -134,3 +135,22 @@ def test_overlapped_reduce_without_process_group_is_inert():
     (psv["a"] * 2).sum().backward()
     red.finish()
     assert flat.grad.tolist() == [2.0, 2.0, 2.0]
+
+
+def test_bench_gpus_n_without_enough_devices_prints_a_skip_record():
+    # `python3 bench.py --gpus 8` on a box with fewer devices (here: none): ONE JSON record that says so, exit code 0, and no GPU
+    # call on the way ("self-skips (and says so)")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has the 8 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NGPDE_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["skipped"] is True and d["n_gpus"] == 8 and d["value"] is None and d["steps"] == 5 and "8 devices" in d["reason"]

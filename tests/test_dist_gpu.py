@@ -95,6 +95,50 @@ def test_bench_n2_path_end_to_end_with_torchrun_and_gloo():
     assert sec["C4_mppde_data_parallel_step"]["ranks"] == 2 and sec["C5_gno_data_parallel_step"]["ranks"] == 2
 
 
+def _run_bench(extra_env, *argv, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_plain_launch_spawns_its_ranks():
+    # `python3 bench.py --gpus 2 ...` typed as is -- the command form the driver uses at N = 1 -- starts its own two ranks (fresh
+    # child processes; the launcher never touches the GPU), relays rank 0's ONE JSON line and exits 0
+    r, recs = _run_bench({"NGPDE_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-secondary")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(recs) == 1, r.stdout[-2000:]
+    d = recs[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and not d.get("skipped")
+    assert d["value"] == pytest.approx(2 * 50 * 2 / (d["ms_per_step"] * 1e-3 * 2), rel=1e-3)
+    assert "persistent_fwd" not in d["plan"]          # ranks sharing a device without taking turns: the replayed plan
+
+
+def test_bench_plain_launch_with_the_persistent_plan_serialised_per_rank(tmp_path):
+    # the same with the ranks taking turns on the one device through a lock file: persistent solve + adjoint, the gradient
+    # collective and the fused Adam step of every rank on its one stream -- the sequence of the measured nccl configuration
+    r, recs = _run_bench({"NGPDE_BENCH_BACKEND": "gloo", "NGPDE_BENCH_SERIALISE": str(tmp_path / "device.lock")},
+                         "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-secondary")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(recs) == 1, r.stdout[-2000:]
+    d = recs[0]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["fault"] is False
+    assert "persistent_fwd" in d["plan"] and "persistent_bwd" in d["plan"]
+
+
+def test_bench_more_gpus_than_devices_prints_a_skip_record():
+    n = torch.cuda.device_count() + 7
+    r, recs = _run_bench({}, "--gpus", str(n))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(recs) == 1 and recs[0]["skipped"] is True and recs[0]["n_gpus"] == n and recs[0]["value"] is None
+
+
 def test_two_persistent_plans_on_two_streams_take_turns():
     # two persistent solves in flight on one device could starve each other of residency (every workgroup of a launch must be
     # resident); inside a process the launches take turns (node_persistent.hip, turnstile): both finish, no fault, same bits as
