@@ -434,7 +434,7 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
        NGPDE_NODE_TILE_ROUNDS = 64 /* persistent launches with k tiles per workgroup taking turns (larger graphs) */,
        NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */,
        NGPDE_NODE_FUSED_RHS = 256 /* persistent launches with ONE hand-off per right-hand-side evaluation: both layers per tile from a
-                                     2-hop halo (relu, one tile per workgroup; NGPDE_NO_FUSED_RHS=1 turns it off) */ };
+                                     2-hop halo (relu, one tile per workgroup; opt-in: NGPDE_FUSED_RHS=1 -- measured slower than the one-hop plan) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`

@@ -682,9 +682,11 @@ int32_t upload_vec(T **dst, const std::vector<T> &v) {
   return NGPDE_OK;
 }
 
+// Opt-in (NGPDE_FUSED_RHS=1): measured SLOWER than the one-hop plan on the BASELINE graph -- the redundant
+// layer-1 work on the 1-hop halo and the spread of that work between tiles cost more than the saved hand-off
 bool fused_disabled_env() {
-  const char *e = std::getenv("NGPDE_NO_FUSED_RHS");
-  return e && e[0] == '1';
+  const char *e = std::getenv("NGPDE_FUSED_RHS");
+  return !(e && e[0] == '1');
 }
 
 #ifdef NGPDE_STAMPS

@@ -28,9 +28,9 @@ stream = torch.cuda.current_stream().cuda_stream
 
 def run(fused):
     if fused:
-        os.environ.pop("NGPDE_NO_FUSED_RHS", None)
+        os.environ["NGPDE_FUSED_RHS"] = "1"
     else:
-        os.environ["NGPDE_NO_FUSED_RHS"] = "1"
+        os.environ.pop("NGPDE_FUSED_RHS", None)
     plan = _Plan(g.handle((True, None, False)), D, _lib.ACT["relu"], TAB, STEPS, 1.0 / 50, True)
     outs = [torch.empty_like(u0), torch.empty_like(u0), torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)]
     tf, tb = [], []
