@@ -367,8 +367,13 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
  * per-edge activations inside the tile (nothing per-edge has to be saved by the forward), accumulates the tail layer's
  * weight / bias gradient on MFMA in per-workgroup slabs, writes dz1 once ([E][h1], p order: de_term, required -- it is the
  * gradient of the per-edge first-layer term and the input of the by-source sum that gives dq_source) and sums it per target
- * into dp_target.  dout: [N][last width] gradient of the aggregated messages. */
+ * into dp_target.  dout: [N][last width] gradient of the aggregated messages.
+ * Without a per-edge first-layer term (e_term NULL: MPPDEConv on graphs without edge features, src/layers.jl:407-410) the
+ * 64-wide two-layer specialisation sums dz1 by source inside its launch where every tile's halo has at most 48 rows (meshes):
+ * de_term may then be NULL and no [E][h1] array exists at all (ngpde_edge_mlp_backward_needs_edge_buffer returns 0). */
 int32_t ngpde_edge_mlp_backward_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout, int32_t aggr);
+int32_t ngpde_edge_mlp_backward_needs_edge_buffer(const ngpde_graph_t *g, int32_t h1, int32_t act1, int32_t has_e_term, int32_t n_tail,
+                                                   const int32_t *tail_dout, const int32_t *tail_act, int32_t aggr);
 size_t ngpde_edge_mlp_backward_workspace_bytes(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout);
 int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target, const float *q_source,
                                 const float *e_term, int32_t n_tail, const int32_t *tail_dout, const int32_t *tail_act,

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ngpde_edge_mlp_supported": (_i32, [_vp, _i32, _i32, _vp]),
     "ngpde_edge_mlp_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ngpde_edge_mlp_backward_supported": (_i32, [_vp, _i32, _i32, _vp, _i32]),
+    "ngpde_edge_mlp_backward_needs_edge_buffer": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32]),
     "ngpde_edge_mlp_backward_workspace_bytes": (_sz, [_vp, _i32, _i32, _vp]),
     "ngpde_edge_mlp_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _sz, _vp]),

@@ -533,6 +533,19 @@ size_t ngpde_edge_mlp_backward_workspace_bytes(const ngpde_graph_t *g, int32_t h
   return edge_mlp_fused_bwd_workspace(g, h1, n_tail, (n_tail == 1 && tail_dout) ? tail_dout[0] : 0);
 }
 
+int32_t ngpde_edge_mlp_backward_needs_edge_buffer(const ngpde_graph_t *g, int32_t h1, int32_t act1, int32_t has_e_term, int32_t n_tail,
+                                                   const int32_t *tail_dout, const int32_t *tail_act, int32_t aggr) {
+  if (!g || has_e_term) return 1;
+  EdgeMlpBwdArgs a;
+  static const float probe = 0.f;   // (pointers are only tested for NULL here)
+  a.h1 = h1; a.act1 = act1; a.aggr = aggr; a.n_tail = n_tail;
+  a.P = &probe; a.Q = &probe; a.Eterm = nullptr; a.dQ = const_cast<float *>(&probe);
+  if (n_tail == 1 && tail_dout && tail_act) {
+    a.dw = tail_dout[0]; a.act2 = tail_act[0];
+  }
+  return (edge_mlp64_bwd_applicable(g, a) && edge_mlp64_bwd_dq_in_launch(g, a)) ? 0 : 1;
+}
+
 int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1, const float *p_target, const float *q_source,
                                 const float *e_term, int32_t n_tail, const int32_t *tail_dout, const int32_t *tail_act,
                                 const float *const *tail_weight, const float *const *tail_bias, int32_t aggr, const float *dout,

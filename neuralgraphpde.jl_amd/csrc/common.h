@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,15 @@ struct Csr {
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
 
+// Inverse of the by-target halo lists, built on first use (graph_halo_inverse): for every node the (tile, halo slot) pairs that hold
+// it, as tile * stride + slot, ascending by tile.  Lets a kernel leave one partial row per (tile, slot) and a second pass add, per
+// node, the rows of the tiles that reference it -- a by-source sum without an [E][h] array (edge_mlp64.hip).
+struct HaloInverse {
+  int32_t *ptr = nullptr;   // [n_nodes + 1]
+  int32_t *ent = nullptr;   // [ptr[n_nodes]]
+  int stride = 0;
+};
+
 constexpr int kTileRows = 32;  // node rows per workgroup of the fused kernels
 constexpr int kHaloCap = 96;   // unique rows a tile may stage in LDS (24 KB at D = 64), plus one zero row
 constexpr int kSlotWidth = 32;  // slot bytes per row of the LDS-staged aggregation (rows with more: global gather)
@@ -86,6 +96,9 @@ struct ngpde_graph {
   int32_t *order = nullptr;   // the same permutation on the device
   bool device_built = false;  // built by ngpde_graph_create_device: no host copies of the CSR lists
   int32_t n_sched = 0;  // n_tiles * kTileRows
+  // derived on first use, under lazy_mu (the handle stays shareable between host threads)
+  mutable std::mutex lazy_mu;
+  mutable ngpde::HaloInverse halo_inv;
 };
 
 namespace ngpde {
@@ -95,6 +108,8 @@ template <class I>
 int32_t graph_create_device(int64_t n_nodes, int64_t n_edges, const I *s, const I *t, int index_base, int32_t n_graphs,
                             const int32_t *order_dev, hipStream_t stream, ngpde_graph **out);
 int32_t set_gcn_norm_device(ngpde_graph *g, int add_self_loops, const float *w_dev, int weighted_degree, hipStream_t stream);
+// the inverse of the by-target halo lists (built once per handle, synchronously, on the host; graph.hip)
+int32_t graph_halo_inverse(const ngpde_graph *g, int stride, const HaloInverse **out);
 
 // ---- launchers implemented in gcn_kernels.hip ---------------------------------------------------
 
@@ -418,6 +433,7 @@ int32_t launch_activation_fwd(int64_t count, int act, const float *z, float *a, 
 bool edge_mlp64_fwd_applicable(const ngpde_graph *g, const EdgeMlpArgs &a);
 int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStream_t stream);
 bool edge_mlp64_bwd_applicable(const ngpde_graph *g, const EdgeMlpBwdArgs &a);
+bool edge_mlp64_bwd_dq_in_launch(const ngpde_graph *g, const EdgeMlpBwdArgs &a);   // the by-source sum inside the launch: no [E][64] buffer needed
 size_t edge_mlp64_bwd_workspace(const ngpde_graph *g);
 int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream);
 

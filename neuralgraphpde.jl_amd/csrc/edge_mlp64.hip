@@ -446,7 +446,10 @@ struct EdgeMlp64BwdK {
   int n_tiles, halo_rows, aggr;
   const float *P, *Q, *wt, *bias, *dout;
   float *dP, *dE, *partial;   // partial: [n_workgroups][65][64]  (row 64 = bias gradient)
+  float *dqpart;              // DQ: [n_tiles][kDqStride][64] per-tile sums of dz1 by halo slot (the by-source sum, first half)
 };
+constexpr int kDqSlots = 3;                 // halo slots per 16-lane group whose sums stay in registers (DQ)
+constexpr int kDqStride = 16 * kDqSlots;    // = the largest halo the in-launch by-source sum takes (48 rows)
 
 // a = act(z), d = act'(z) with the shared transcendental evaluated once (same operations as act_apply / act_deriv)
 template <int ACT>
@@ -468,7 +471,12 @@ __device__ __forceinline__ void act_both(float z, float &a, float &d) {
   }
 }
 
-template <int ACT1, int ACT2>
+// DQ (no per-edge first-layer term, halos of at most kDqStride rows: meshes such as BASELINE config 4's): the [E][64] array dz1
+// is NOT written.  Its only reader would be the by-source sum dQ; instead each 16-lane group keeps the sums of dz1 over the edges of
+// "its" halo slots (slot = the edge's source row in the tile's halo list) in registers -- the edges of a chunk that carry a slot
+// are found by ballots over the chunk's slot ids and added in edge order, so the result is reproducible -- and writes one row per
+// slot and tile; edge64_dq_combine_kernel then adds, per node, the rows of the tiles whose halo holds it (graph handle: halo_inverse).
+template <int ACT1, int ACT2, bool DQ>
 __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64BwdK p) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
@@ -586,6 +594,9 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
       ldsEdge[k] = (uint16_t)((g16 + 16) | (((ldsSlots[(g16 + 16) * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff) << 8));
     }
     float4 racc0 = f4_zero(), racc1 = f4_zero();
+    float4 qacc[kDqSlots];
+#pragma unroll
+    for (int j = 0; j < kDqSlots; ++j) qacc[j] = f4_zero();
     __syncthreads();
 
     for (int c0 = 0; c0 < total; c0 += kChunk4) {
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
             acc = mfma16(w4.w, gz[mt].w, acc);
           }
           dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), d1[ct]);
-          if (valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];   // (a non-temporal store here: +3 %)
+          if (!DQ && valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];   // (a non-temporal store here: +3 %)
         }
       }
       // ---- dz1 of the chunk -> LDS, lane group g16 sums the rows of targets g16 and g16 + 16 in edge order (= dP)
@@ -684,7 +695,39 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
         for (int kk = max(lo0, c0); kk < min(hi0, c0 + kChunk4); ++kk) racc0 = f4_add(racc0, *reinterpret_cast<const float4 *>(base + kk * kTS));
         for (int kk = max(lo1, c0); kk < min(hi1, c0 + kChunk4); ++kk) racc1 = f4_add(racc1, *reinterpret_cast<const float4 *>(base + kk * kTS));
       }
+      if constexpr (DQ) {
+        // lane q of a group looks at the slot ids of edges c0 + 16 i + q of the chunk; a ballot per i gives every group the 16 match
+        // bits of its own slot; the set bits, lowest first, are the chunk's edges with that source in edge order
+        unsigned sl4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = c0 + 16 * i + q;
+          sl4[i] = kk < total ? (unsigned)(ldsEdge[kk] >> 8) : 0xffffu;
+        }
+        const int gsh = 16 * (g16 & 3);
+#pragma unroll
+        for (int j = 0; j < kDqSlots; ++j) {
+          const unsigned s = (unsigned)(g16 + 16 * j);
+          unsigned long long m = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) m |= ((__ballot(sl4[i] == s) >> gsh) & 0xffffull) << (16 * i);
+          float4 acc = qacc[j];
+          while (m) {   // (a two-edges-per-slot, three-slots-at-once form of this loop was measured: 1 075 against 988 us for the launch)
+            const int kk = __builtin_ctzll(m);
+            m &= m - 1;
+            acc = f4_add(acc, *reinterpret_cast<const float4 *>(ldsS + kk * kTS + 4 * q));
+          }
+          qacc[j] = acc;
+        }
+      }
       __syncthreads();
+    }
+    if constexpr (DQ) {
+#pragma unroll
+      for (int j = 0; j < kDqSlots; ++j) {
+        const int sl = g16 + 16 * j;
+        if (sl < p.halo_rows) *reinterpret_cast<float4 *>(p.dqpart + ((size_t)(range_lo + jt) * kDqStride + sl) * kW + 4 * q) = qacc[j];
+      }
     }
     if (p.dP) {
       if (sc0.x >= 0) *reinterpret_cast<float4 *>(p.dP + (size_t)sc0.x * kW + 4 * q) = racc0;
@@ -784,6 +827,17 @@ int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStr
   return NGPDE_OK;
 }
 
+// dQ[node] = sum over the tiles whose halo list holds the node of that tile's partial row (entries ascending by tile: fixed order)
+__global__ __launch_bounds__(256) void edge64_dq_combine_kernel(int n_nodes, const int *__restrict__ ptr, const int *__restrict__ ent,
+                                                                const float *__restrict__ part, float *__restrict__ dQ) {
+  const int node = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4), q = threadIdx.x & 15;
+  if (node >= n_nodes) return;
+  const int lo = ptr[node], hi = ptr[node + 1];
+  float4 a = f4_zero();
+  for (int e = lo; e < hi; ++e) a = f4_add(a, *reinterpret_cast<const float4 *>(part + (size_t)ent[e] * kW + 4 * q));
+  *reinterpret_cast<float4 *>(dQ + (size_t)node * kW + 4 * q) = a;
+}
+
 // ---- pullback launch.  Same conditions as the forward specialisation (the activation pairs instantiated below); workspace =
 // one [65][64] slab per workgroup (edge_mlp64_bwd_grid).
 static int edge64_bwd_grid(const ngpde_graph *g) {
@@ -798,7 +852,16 @@ bool edge_mlp64_bwd_applicable(const ngpde_graph *g, const EdgeMlpBwdArgs &a) {
   const bool a2 = a.act2 == a.act1 || a.act2 == NGPDE_ACT_IDENTITY;
   return a1 && a2;
 }
-size_t edge_mlp64_bwd_workspace(const ngpde_graph *g) { return (size_t)edge64_bwd_grid(g) * (kW + 1) * kW * sizeof(float) + 256; }
+static size_t edge64_slab_bytes(const ngpde_graph *g) { return ((size_t)edge64_bwd_grid(g) * (kW + 1) * kW * sizeof(float) + 255) / 256 * 256; }
+// the by-source sum inside the launch (no [E][64] array): no per-edge term, every halo within kDqStride rows
+bool edge_mlp64_bwd_dq_in_launch(const ngpde_graph *g, const EdgeMlpBwdArgs &a) {
+  if (env_off("NGPDE_EDGE64_NO_DQ")) return false;
+  return a.Eterm == nullptr && a.dQ != nullptr && g->by_t.halo_ok && g->by_t.max_halo <= kDqStride;
+}
+size_t edge_mlp64_bwd_workspace(const ngpde_graph *g) {
+  const size_t part = (g->by_t.halo_ok && g->by_t.max_halo <= kDqStride) ? (size_t)(g->n_sched / kTileRows) * kDqStride * kW * sizeof(float) : 0;
+  return edge64_slab_bytes(g) + part + 256;
+}
 
 int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
   EdgeMlp64BwdK k;
@@ -807,6 +870,14 @@ int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hip
   k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
   k.P = a.P; k.Q = a.Q; k.wt = a.wt; k.bias = a.bias; k.dout = a.dout;
   k.dP = a.dP; k.dE = a.dE; k.partial = (float *)a.workspace;
+  const bool dq = edge_mlp64_bwd_dq_in_launch(g, a);
+  const HaloInverse *hinv = nullptr;
+  if (dq) {
+    int32_t sti = graph_halo_inverse(g, kDqStride, &hinv);
+    if (sti) return sti;
+  }
+  NGPDE_REQUIRE(dq || a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
+  k.dqpart = dq ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.workspace) + edge64_slab_bytes(g)) : nullptr;
   const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kChunk4 * kTS + 2 * (size_t)kW * kTS) * sizeof(float);
   const int grid = (lds + 4096 <= 80 * 1024) ? edge64_bwd_grid(g) : std::max(8, edge64_bwd_grid(g) / 2);
   auto launch = [&](auto kernel) -> hipError_t {
@@ -817,15 +888,24 @@ int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hip
   };
   hipError_t le;
   const bool same = a.act2 == a.act1;
+#define NGPDE_E64B(A1, A2) (dq ? launch(edge_mlp64_bwd_kernel<A1, A2, true>) : launch(edge_mlp64_bwd_kernel<A1, A2, false>))
   switch (a.act1) {
-    case NGPDE_ACT_SWISH: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_SWISH>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_SWISH, NGPDE_ACT_IDENTITY>); break;
-    case NGPDE_ACT_RELU: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_RELU>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_RELU, NGPDE_ACT_IDENTITY>); break;
-    default: le = same ? launch(edge_mlp64_bwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_TANH>) : launch(edge_mlp64_bwd_kernel<NGPDE_ACT_TANH, NGPDE_ACT_IDENTITY>); break;
+    case NGPDE_ACT_SWISH: le = same ? NGPDE_E64B(NGPDE_ACT_SWISH, NGPDE_ACT_SWISH) : NGPDE_E64B(NGPDE_ACT_SWISH, NGPDE_ACT_IDENTITY); break;
+    case NGPDE_ACT_RELU: le = same ? NGPDE_E64B(NGPDE_ACT_RELU, NGPDE_ACT_RELU) : NGPDE_E64B(NGPDE_ACT_RELU, NGPDE_ACT_IDENTITY); break;
+    default: le = same ? NGPDE_E64B(NGPDE_ACT_TANH, NGPDE_ACT_TANH) : NGPDE_E64B(NGPDE_ACT_TANH, NGPDE_ACT_IDENTITY); break;
   }
+#undef NGPDE_E64B
   if (le != hipSuccess) return fail(NGPDE_ERR_HIP, "edge_mlp64_bwd_kernel: LDS request of %zu bytes refused: %s", lds, hipGetErrorString(le));
   NGPDE_LAUNCH_CHECK("edge_mlp64_bwd_kernel");
   int32_t st;
   if ((st = launch_dense_weight_reduce(grid, kW, kW, k.partial, a.dwt, a.dbias, stream))) return st;
+  if (dq) {
+    const int64_t threads = g->n_nodes * 16;
+    hipLaunchKernelGGL(edge64_dq_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (int)g->n_nodes, hinv->ptr, hinv->ent,
+                       k.dqpart, a.dQ);
+    NGPDE_LAUNCH_CHECK("edge64_dq_combine_kernel");
+    return NGPDE_OK;
+  }
   if (a.dQ && (st = launch_edge_sum_by_source(g, kW, a.dE, a.dQ, stream))) return st;
   return NGPDE_OK;
 }

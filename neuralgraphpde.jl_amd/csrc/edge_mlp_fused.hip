@@ -727,8 +727,8 @@ int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a,
   const size_t need = edge_mlp_fused_bwd_workspace(g, a.h1, a.n_tail, a.dw);
   NGPDE_REQUIRE(a.workspace && a.workspace_bytes >= need, NGPDE_ERR_WORKSPACE, "fused edge-MLP pullback: workspace too small (%zu < %zu bytes)",
                 a.workspace_bytes, need);
+  if (edge_mlp64_bwd_applicable(g, a)) return launch_edge_mlp64_bwd(g, a, stream);   // (checks dE itself: not needed when it sums by source in the launch)
   NGPDE_REQUIRE(a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
-  if (edge_mlp64_bwd_applicable(g, a)) return launch_edge_mlp64_bwd(g, a, stream);
   EdgeMlpBwdK k;
   k.sched = g->by_t.sched; k.halo = g->by_t.halo; k.slots = g->by_t.slots;
   k.n_tiles = (int)(g->n_sched / kTileRows); k.h1 = a.h1; k.act1 = a.act1; k.aggr = a.aggr; k.n_tail = a.n_tail;

@@ -627,7 +627,7 @@ struct Hop2Host {
 
 // The 2-hop halo of every tile: H2 = H1 (the handle's halo list, own rows first) followed by every other row the H1 rows
 // reference, in order of first appearance walking the H1 rows in slot order and each row's list in CSR order; per H1 row its
-// list as H2 slots + 1 (0: unused).  Returns false when a tile does not fit.  (Restated in oracle/ngpde_oracle.py: hop2_tables.)
+// list as H2 slots + 1 (0: unused).  Returns false when a tile does not fit.
 bool build_hop2(const ngpde_graph *g, const HostDir &h, Hop2Host &o) {
   const int nt = g->n_sched / kTileRows;
   o.slots2.assign((size_t)nt * kHaloCap * 8, 0u);

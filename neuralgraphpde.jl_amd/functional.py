@@ -865,7 +865,10 @@ def _edge_mlp_fused_backward(ctx, dout):
     dout = dout.contiguous()
     dP = torch.empty(pshape, dtype=torch.float32, device=dev) if pshape is not None else None
     dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if qshape is not None else None
-    dE = torch.empty((n_edges, h1), dtype=torch.float32, device=dev)
+    # the [E][h1] array dz1: not needed where the 64-wide kernel sums it by source inside its launch (no per-edge term, mesh-like halos)
+    need_de = has_e or dQ is None or bool(lib.ngpde_edge_mlp_backward_needs_edge_buffer(
+        ctx.handle.ptr, h1, act1, 0, n_tail, _int_array(list(douts)) if n_tail else None, _int_array(list(acts)) if n_tail else None, aggr))
+    dE = torch.empty((n_edges, h1), dtype=torch.float32, device=dev) if need_de else None
     dwts = [torch.empty_like(w) for w in wts]
     dbs = [torch.empty((douts[l],), dtype=torch.float32, device=dev) if has_b[l] else None for l in range(n_tail)]
     ws = _ws(lib.ngpde_edge_mlp_backward_workspace_bytes(ctx.handle.ptr, h1, n_tail, _int_array(list(douts)) if n_tail else None), dev)
