@@ -544,6 +544,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # NGPDE_BENCH_COMM=native: the gradient all-reduce + Adam through the library's own communicator (ngpde_comm_*, RCCL behind the
+    # C ABI: the call a Julia host makes) instead of torch.distributed's; same collective, same stream
+    native = None
+    if dist is not None and backend == "nccl" and os.environ.get("NGPDE_BENCH_COMM") == "native":
+        native = ng.dist.NativeComm.from_torch()
     s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
     g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
     lib = _lib.load()
@@ -604,9 +609,12 @@ def main():
             with device_turn():
                 _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u0), p(w1), p(b1), p(w2), p(b2), p(uT), stream))
                 _lib.check(lib.ngpde_node_gcn2_backward(plan.ptr, p(seed_grad), p(du0), p(dw1), p(db1), p(dw2), p(db2), stream))
+            it[0] += 1
+            if native is not None:
+                native.all_reduce_adam(pflat, flat, adam_m, adam_v, 1e-5, 0.9, 0.999, 1e-8, it[0])
+                return
             if dist is not None:
                 dist.all_reduce(flat)
-            it[0] += 1
             _lib.check(lib.ngpde_adam_step(flat.numel(), p(pflat), p(flat), p(adam_m), p(adam_v), 1e-5, 0.9, 0.999, 1e-8, it[0],
                                            1.0 / world, stream))
 
@@ -739,7 +747,9 @@ def main():
                        "launches_per_solve": {"forward": fl, "backward": bl},
                        "ms_forward_solve": round(ms_fwd, 3), "ms_backward_solve": round(ms_bwd, 3),
                        "tape_GB": round(plan.tape_bytes() / 1e9, 3),
-                       "parallelism": f"dp{world} (independent trajectories, all-reduce of 8320-float grads)"},
+                       "parallelism": f"dp{world} (independent trajectories, all-reduce of 8320-float grads)",
+                       "collective": ("ngpde_grad_allreduce_adam (RCCL behind the C ABI)" if native is not None else
+                                      ("torch.distributed all_reduce (" + backend + ")" if world > 1 else "none (one rank)"))},
             "roofline": {"bound": "hbm", "kernel": roles[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "static: profiles/traffic.json, the rocprofv3 --pmc passes of tools/profile_round.sh "

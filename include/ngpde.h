@@ -511,6 +511,24 @@ int32_t ngpde_adam_step(int64_t n, float *x, const float *grad, float *m, float 
 int32_t ngpde_rprop_step(int64_t n, float *x, const float *grad, float *grad_prev, float *step_size, float shrink, float grow,
                          float step_min, float step_max, float grad_scale, ngpde_stream_t stream);
 
+/* ---- data-parallel collective (comm.hip) -----------------------------------------------------------------------------------
+ * New functionality (the reference has no multi-GPU code): whole trajectories / graphs of a batch shard across one process per
+ * GPU (test/runtests.jl:89-102, src/layers.jl:359-361), parameters are replicated, and the flat parameter-gradient vector is
+ * summed over the ranks once per backward pass -- ncclAllReduce(sum, fp32) over RCCL / xGMI on the caller's stream, in place --
+ * optionally with the fused Adam step (1 / world folded in) as the next launch on that stream (graph_node.md:122-129).
+ *   ngpde_comm_unique_id: rank 0 makes the id (NGPDE_COMM_ID_BYTES bytes); the HOST ships it to the other ranks.
+ *   ngpde_comm_create:    every rank, on its current device; collective (returns when all ranks have joined).
+ * RCCL is looked up at the first call: NGPDE_ERR_UNSUPPORTED when librccl.so is absent.  One rank per device (RCCL refuses two). */
+typedef struct ngpde_comm ngpde_comm_t;
+#define NGPDE_COMM_ID_BYTES 128
+int32_t ngpde_comm_unique_id(void *id_out, size_t id_bytes);
+int32_t ngpde_comm_create(const void *unique_id, int32_t rank, int32_t world, ngpde_comm_t **out);
+int32_t ngpde_comm_destroy(ngpde_comm_t *comm);
+int32_t ngpde_comm_info(const ngpde_comm_t *comm, int32_t *rank, int32_t *world);
+int32_t ngpde_grad_allreduce(ngpde_comm_t *comm, float *flat, int64_t count, ngpde_stream_t stream);
+int32_t ngpde_grad_allreduce_adam(ngpde_comm_t *comm, int64_t n, float *x, float *grad, float *m, float *v, float eta, float beta1,
+                                  float beta2, float eps, int64_t step, ngpde_stream_t stream);
+
 /* ---- weight-sized rearrangements around the edge-function layers (row_blocks.hip) ------------------------------------------
  * The first Dense layer of phi is split by ROW BLOCKS of its [in][out] weight and the blocks are recombined with signs
  * (src/layers.jl:106 ExplicitEdgeConv, :316 VMHConv, :409-410 MPPDEConv, :523 GNOConv).  ngpde_row_blocks_gather builds up to

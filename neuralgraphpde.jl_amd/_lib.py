@@ -51,6 +51,12 @@ SIGNATURES = {
     "ngpde_spatial_order": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "ngpde_graph_set_gcn_norm_device": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "ngpde_graph_array": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "ngpde_comm_unique_id": (_i32, [_vp, _sz]),
+    "ngpde_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "ngpde_comm_destroy": (_i32, [_vp]),
+    "ngpde_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ngpde_grad_allreduce": (_i32, [_vp, _vp, _i64, _vp]),
+    "ngpde_grad_allreduce_adam": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp]),
     "ngpde_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "ngpde_rprop_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ngpde_graph_destroy": (_i32, [_vp]),

@@ -244,8 +244,22 @@ int32_t node_fused_setup(const ngpde_graph *g, NodePersist *ps);
 void node_fused_free(NodePersist *ps);
 int32_t launch_node_fwd_fused(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_fused(const NodePersistBwd &a, hipStream_t stream);
-int32_t persistent_turnstile_enter(hipStream_t stream, int *dev_out);   // persistent launches of one process take turns per device
-int32_t persistent_turnstile_leave(hipStream_t stream, int dev);
+// Persistent launches of one process take turns per device (node_persistent.hip): enter() takes the device's turnstile lock and makes
+// `stream` wait for the previous persistent launch on the device, leave() records this one and releases the lock; the lock is
+// held from enter to leave, so two host threads cannot both pass the wait and then launch side by side.  The destructor releases
+// a lock that an error path left behind.  On a stream that is being captured into a HIP graph the event wait / record is skipped
+// (a captured event would poison later eager launches): ordering inside the captured graph is the capture's own.
+struct PersistentTurn {
+  int dev = -1;
+  bool held = false;
+  hipStream_t stream = nullptr;
+  int32_t enter(hipStream_t s);
+  int32_t leave();
+  ~PersistentTurn();
+  PersistentTurn() = default;
+  PersistentTurn(const PersistentTurn &) = delete;
+  PersistentTurn &operator=(const PersistentTurn &) = delete;
+};
 // the GAT-style layer (64 => heads x c = 64) as ODE right-hand side, device-resident (gat_fused.hip; plan: node_gat.hip)
 struct GatNodeFwd {
   const ngpde_graph *g = nullptr;

@@ -1477,8 +1477,8 @@ int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
-  int dev = 0;
-  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   GatNodeFwdK k;
   k.l.x = nullptr; k.l.wt = a.wt; k.l.a = a.a; k.l.bias = a.bias; k.l.sched = g->by_t.sched; k.l.halo = g->by_t.halo;
@@ -1516,15 +1516,15 @@ int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream) {
   NGPDE_LAUNCH_CHECK("gat_node_fwd_persistent_kernel");
   hipLaunchKernelGGL(gat_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.s.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("gat_latch_fault_kernel");
-  return persistent_turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
-  int dev = 0;
-  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   GatNodeBwdK k;
   const bool ident = a.act == NGPDE_ACT_IDENTITY;
@@ -1569,7 +1569,7 @@ int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream) {
   hipLaunchKernelGGL(gat_layer_reduce_kernel, dim3(67), dim3(1024), 0, stream, a.slab_dw, ps.n_tiles, a.slab_db, ps.n_tiles, a.slab_u, a.dwt,
                      a.db, a.da);
   NGPDE_LAUNCH_CHECK("gat_layer_reduce_kernel");
-  return persistent_turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 }  // namespace ngpde

@@ -14,10 +14,18 @@ namespace ngpde {
 const RoctxApi &roctx_api() {
   static const RoctxApi api = [] {
     RoctxApi a;
+    // Ranges are for profiling runs: on when the marker library is ALREADY in the process (rocprofv3 preloads it: RTLD_NOLOAD finds
+    // it without loading anything) or when NGPDE_ROCTX=1 asks for it; a production process never pulls a profiler library in, and
+    // never with global symbol visibility.  NGPDE_NO_ROCTX=1 turns them off even under a profiler.
     const char *off = std::getenv("NGPDE_NO_ROCTX");
     if (off && off[0] == '1') return a;
-    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    const char *on = std::getenv("NGPDE_ROCTX");
+    if (!h && on && on[0] == '1') {
+      h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_LOCAL);
+      if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!h) return a;
     a.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
     a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));

@@ -802,8 +802,8 @@ int32_t launch_node_fwd_fused(const NodePersistFwd &a, hipStream_t stream) {
   NGPDE_REQUIRE(!a.tape || a.masks, NGPDE_ERR_INVALID_ARGUMENT, "fused forward with a tape needs the sign-bit masks");
   NGPDE_REQUIRE(!a.tape || a.mask_bytes >= (size_t)g->n_nodes * 8, NGPDE_ERR_INVALID_ARGUMENT, "fused forward: sign-bit masks too small");
   int32_t st;
-  int dev = 0;
-  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdF k;
   k.m = make_fmeta(g->by_t, ps.hop2[0], ps);
@@ -827,7 +827,7 @@ int32_t launch_node_fwd_fused(const NodePersistFwd &a, hipStream_t stream) {
   NGPDE_LAUNCH_CHECK("node_fwd_fused_kernel");
   hipLaunchKernelGGL(fused_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return persistent_turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 int32_t launch_node_bwd_fused(const NodePersistBwd &a, hipStream_t stream) {
@@ -836,8 +836,8 @@ int32_t launch_node_bwd_fused(const NodePersistBwd &a, hipStream_t stream) {
   NGPDE_REQUIRE(ps.nbr2 && a.act == NGPDE_ACT_RELU && !a.interleave && !a.pair && a.k_tiles == 0 && a.masks, NGPDE_ERR_STATE,
                 "fused right-hand-side adjoint launch without its setup");
   int32_t st;
-  int dev = 0;
-  if ((st = persistent_turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdF k;
   k.m = make_fmeta(g->by_s, ps.hop2[1], ps);
@@ -852,7 +852,7 @@ int32_t launch_node_bwd_fused(const NodePersistBwd &a, hipStream_t stream) {
   NGPDE_LAUNCH_CHECK("node_bwd_fused_kernel");
   hipLaunchKernelGGL(fused_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return persistent_turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 }  // namespace ngpde

@@ -1625,7 +1625,10 @@ int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per w
   const int nt = g->n_sched / kTileRows, resident = cus * occ;
   if (resident < 1) return 0;
   const int k = (nt + resident - 1) / resident;
-  if (g->by_t.slot_w && k > kMaxTileRoundsW) return 0;   // (the weighted kernels' occupancy is lower than node_persistent_mode assumed)
+  // (the K kernels' occupancy can be lower than what node_persistent_mode assumed from the one-tile kernels: a k beyond what the
+  // kernels' LDS tables hold would leave tiles unprocessed -- their neighbours would spin into the timeout -- so it is refused here
+  // and node_create keeps the replayed plan)
+  if (k > (g->by_t.slot_w ? kMaxTileRoundsW : kMaxTileRounds)) return 0;
   return k;
 }
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) { return node_persistent_mode(g, d, act, with_bwd) == 1; }
@@ -1728,37 +1731,48 @@ Turnstile &turnstile() {
   static Turnstile t;
   return t;
 }
-int32_t turnstile_enter(hipStream_t stream, int *dev_out) {
-  int dev = 0;
-  NGPDE_HIP_CHECK(hipGetDevice(&dev));
-  *dev_out = dev;
-  if (dev < 0 || dev >= 16) return NGPDE_OK;
-  Turnstile &t = turnstile();
-  std::lock_guard<std::mutex> lock(t.mu);
-  if (t.used[dev]) NGPDE_HIP_CHECK(hipStreamWaitEvent(stream, t.last[dev], 0));
-  return NGPDE_OK;
-}
-int32_t turnstile_leave(hipStream_t stream, int dev) {
-  if (dev < 0 || dev >= 16) return NGPDE_OK;
-  Turnstile &t = turnstile();
-  std::lock_guard<std::mutex> lock(t.mu);
-  if (!t.last[dev]) NGPDE_HIP_CHECK(hipEventCreateWithFlags(&t.last[dev], hipEventDisableTiming));
-  NGPDE_HIP_CHECK(hipEventRecord(t.last[dev], stream));
-  t.used[dev] = true;
-  return NGPDE_OK;
-}
 }  // namespace
 
-// (for the other persistent solver, gat_fused.hip)
-int32_t persistent_turnstile_enter(hipStream_t stream, int *dev_out) { return turnstile_enter(stream, dev_out); }
-int32_t persistent_turnstile_leave(hipStream_t stream, int dev) { return turnstile_leave(stream, dev); }
+int32_t PersistentTurn::enter(hipStream_t s) {
+  stream = s;
+  NGPDE_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return NGPDE_OK;
+  Turnstile &t = turnstile();
+  t.mu.lock();
+  held = true;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+  if (cs == hipStreamCaptureStatusNone && t.used[dev]) NGPDE_HIP_CHECK(hipStreamWaitEvent(stream, t.last[dev], 0));
+  return NGPDE_OK;
+}
+int32_t PersistentTurn::leave() {
+  if (!held) return NGPDE_OK;
+  Turnstile &t = turnstile();
+  int32_t st = NGPDE_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+  if (cs == hipStreamCaptureStatusNone) {
+    if (!t.last[dev] && hipEventCreateWithFlags(&t.last[dev], hipEventDisableTiming) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipEventCreate failed");
+    if (st == NGPDE_OK && hipEventRecord(t.last[dev], stream) != hipSuccess) st = fail(NGPDE_ERR_HIP, "hipEventRecord failed");
+    if (st == NGPDE_OK) t.used[dev] = true;
+  }
+  held = false;
+  t.mu.unlock();
+  return st;
+}
+PersistentTurn::~PersistentTurn() {
+  if (held) {
+    held = false;
+    turnstile().mu.unlock();
+  }
+}
 
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
-  int dev = 0;
-  if ((st = turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
   k.m = make_meta(g->by_t, ps);
@@ -1777,6 +1791,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   k.k_tiles = a.k_tiles; k.state = a.state;
   if (a.k_tiles > 0) {   // tile rounds: K tiles per workgroup, state in memory
     NGPDE_REQUIRE(ps.pair_wgs > 0 && a.n_members == 1 && a.state, NGPDE_ERR_STATE, "tile-round launch without its setup");
+    NGPDE_REQUIRE(a.k_tiles <= kMaxTileRounds, NGPDE_ERR_STATE, "tile rounds: at most %d tiles per workgroup", kMaxTileRounds);
     k.pair_wgs = ps.pair_wgs; k.ztape = a.ztape;
     if ((st = launch_zero(a.state + a.row_elems, 6 * a.row_elems * sizeof(float), stream))) return st;   // k_0 .. k_5 start from zero
     const dim3 gridk(ps.pair_wgs), blockk(kThreads);
@@ -1795,7 +1810,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     NGPDE_LAUNCH_CHECK("node_fwd_persistentK_kernel");
     hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-    return turnstile_leave(stream, dev);
+    return turn.leave();
   }
   NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
@@ -1825,15 +1840,15 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) {
   const ngpde_graph *g = a.g;
   const NodePersist &ps = *a.ps;
   int32_t st;
-  int dev = 0;
-  if ((st = turnstile_enter(stream, &dev))) return st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
   k.m = make_meta(g->by_s, ps);
@@ -1850,6 +1865,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   k.k_tiles = a.k_tiles;
   if (a.k_tiles > 0) {   // tile rounds
     NGPDE_REQUIRE(ps.pair_wgs > 0 && a.n_members == 1 && a.ubar, NGPDE_ERR_STATE, "tile-round launch without its setup");
+    NGPDE_REQUIRE(a.k_tiles <= kMaxTileRounds, NGPDE_ERR_STATE, "tile rounds: at most %d tiles per workgroup", kMaxTileRounds);
     NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
     k.pair_wgs = ps.pair_wgs;
     if ((st = launch_zero(a.ubar, 5 * a.row_elems * sizeof(float), stream))) return st;   // the stage adjoints start from zero
@@ -1867,7 +1883,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     NGPDE_LAUNCH_CHECK("node_bwd_persistentK_kernel");
     hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-    return turnstile_leave(stream, dev);
+    return turn.leave();
   }
   NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
@@ -1888,7 +1904,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
   hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
-  return turnstile_leave(stream, dev);
+  return turn.leave();
 }
 
 }  // namespace ngpde

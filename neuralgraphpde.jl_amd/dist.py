@@ -127,3 +127,60 @@ class OverlappedGradReduce:
             b["work"], b["seen"] = None, 0
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+
+
+class NativeComm:
+    """The library's own communicator (include/ngpde.h: ngpde_comm_*, RCCL over xGMI behind the C ABI) -- what a Julia host binds for
+    the data-parallel step; the Python host's default stays torch.distributed.  One rank per GPU, on the current device.
+
+    unique_id: bytes made by rank 0 (NativeComm.unique_id()) and shipped to the others by the host; with torch.distributed already
+    initialised, NativeComm.from_torch() does that with a broadcast."""
+
+    def __init__(self, unique_id, rank, world):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.lib = _lib.load()
+        self.ptr = None
+        out = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.lib.ngpde_comm_create(buf, int(rank), int(world), C.byref(out)))
+        self.ptr, self.rank, self.world = out, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().ngpde_comm_unique_id(buf, 128))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch(cls, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world)
+
+    def all_reduce(self, flat):
+        """in-place sum over the ranks of a contiguous fp32 device vector, on the current stream"""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        self._lib.check(self.lib.ngpde_grad_allreduce(self.ptr, self._lib.ptr(flat), flat.numel(), self._lib.current_stream()))
+        return flat
+
+    def all_reduce_adam(self, x, grad, m, v, eta, beta1, beta2, eps, step):
+        """all-reduce(sum) of grad, then the fused Adam step with 1 / world folded in: two launches on the current stream"""
+        p = self._lib.ptr
+        self._lib.check(self.lib.ngpde_grad_allreduce_adam(self.ptr, x.numel(), p(x), p(grad), p(m), p(v), eta, beta1, beta2, eps, int(step),
+                                                           self._lib.current_stream()))
+
+    def close(self):
+        if self.ptr is not None:
+            self.lib.ngpde_comm_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -39,6 +39,20 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
+def _check_plan_shapes(what, u, n_rows, d, weights, biases):
+    """DimensionMismatch (the reference's error for these: check_num_nodes / the matrix product) unless u is [n_rows][d], every
+    weight has its shape and every bias its length -- the device-resident plans' C entries take pointers only"""
+    if tuple(u.shape) != (n_rows, d):
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: {what}: the state is ({u.shape[1]} x {u.shape[0]}), "
+                                     f"the graph and layers need ({d} x {n_rows})")
+    for name, w, shape in weights:
+        if tuple(w.shape) != tuple(shape):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: {what}: {name} is {tuple(w.shape)[::-1]}, expected {shape[::-1]}")
+    for name, b, n in biases:
+        if b is not None and b.numel() != n:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: {what}: {name} has {b.numel()} entries, expected {n}")
+
+
 class _Plan:
     def __init__(self, handle, d, act, tableau, n_steps, dt, with_backward, members=1):
         """members > 1: `handle` is ONE member of a block-diagonal batch of `members` identical structures; the plan takes
@@ -49,6 +63,7 @@ class _Plan:
         self.handle = handle            # keeps the graph handle alive
         self.ptr = None
         self.members = int(members)
+        self.n_nodes = int(handle._n_nodes)     # rows of ONE member
         out = C.c_void_p()
         _lib.check(self.lib.ngpde_node_gcn2_create_batch(handle.ptr, self.members, d, act, _lib.TABLEAU[tableau], n_steps, dt,
                                                          int(with_backward), C.byref(out)))
@@ -145,6 +160,7 @@ class _GatPlan:
         self.ptr = None
         self.gen = 0
         self.members = int(members)
+        self.n_nodes = int(handle._n_nodes)
         out = C.c_void_p()
         _lib.check(self.lib.ngpde_node_gat_create_batch(handle.ptr, self.members, int(heads), int(c), float(slope), int(act),
                                                         _lib.TABLEAU[tableau], int(n_steps), float(dt), int(with_backward), C.byref(out)))
@@ -619,13 +635,26 @@ class NeuralODE(AbstractExplicitLayer):
             p1, p2 = ps["layer_1"], ps["layer_2"]
             b1 = p1["bias"].reshape(-1) if "bias" in p1 else None
             b2 = p2["bias"].reshape(-1) if "bias" in p2 else None
-            uT = _NodeGCN2Fn.apply(u, rows_of(p1["weight"]), b1, rows_of(p2["weight"]), b2, plan)
+            w1, w2 = rows_of(p1["weight"]), rows_of(p2["weight"])
+            # the plan's entries take no sizes (they walk the handle's rows): what GCNConv.__call__ would have checked
+            # (check_num_nodes, the matrix product's own DimensionMismatch) is checked here, before any kernel runs
+            d = self.model.chain[0].in_chs
+            _check_plan_shapes("NeuralODE(GCNConv, GCNConv)", u, plan.n_nodes * plan.members, d,
+                               [("layer_1.weight", w1, (d, d)), ("layer_2.weight", w2, (d, d))],
+                               [("layer_1.bias", b1, d), ("layer_2.bias", b2, d)])
+            uT = _NodeGCN2Fn.apply(u, w1, b1, w2, b2, plan)
             return uT.T, st
         gplan = self.gat_plan_for(ps, st, u) if not self.save_every else None
         if gplan is not None:
             gps = ps["layer_1"] if isinstance(self.model, Chain) else ps
+            gm = self.model.chain[0] if isinstance(self.model, Chain) else self.model
             b = gps["bias"].reshape(-1) if "bias" in gps else None
-            uT = _NodeGatFn.apply(u, rows_of(gps["weight"]), rows_of(gps["a"]), b, gplan)
+            w, a = rows_of(gps["weight"]), rows_of(gps["a"])
+            _check_plan_shapes("NeuralODE(GATConv)", u, gplan.n_nodes * gplan.members, 64, [("weight", w, (64, 64))], [("bias", b, 64)])
+            if a.numel() != 2 * gm.out_chs * gm.heads:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: NeuralODE(GATConv): attention vector has "
+                                             f"{a.numel()} entries, expected 2 x {gm.out_chs} x {gm.heads}")
+            uT = _NodeGatFn.apply(u, w, a, b, gplan)
             return uT.T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch

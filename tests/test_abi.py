@@ -64,3 +64,12 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in text and "import oracle" not in text and "oracle/" not in text.replace(
                     "never imports anything from oracle/", "").replace("Nothing here imports oracle/", ""), f
+
+
+def test_collective_entries_reject_null_arguments_without_a_gpu():
+    lib = _lib.load()
+    out = C.c_void_p()
+    assert lib.ngpde_comm_create(None, 0, 1, C.byref(out)) == _lib.ERR_INVALID_ARGUMENT and not out.value
+    assert lib.ngpde_comm_unique_id(None, 0) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.ngpde_grad_allreduce(None, None, 0, None) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.ngpde_comm_destroy(None) == 0

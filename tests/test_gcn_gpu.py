@@ -1087,3 +1087,38 @@ def test_node_saveat_must_be_a_whole_number_of_steps():
     with pytest.raises(ng.ArgumentError, match="whole number of steps"):
         ng.NeuralODE(rhs, n_steps=10, dt=0.1, saveat=0.3)
     assert ng.NeuralODE(rhs, n_steps=10, dt=0.1, saveat=0.5).save_every == 5
+
+
+def test_node_device_resident_plans_check_their_inputs_against_the_graph():
+    # the plans' C entries take pointers only and walk the handle's rows: a state with another node count or width, or a weight of
+    # another shape, must raise the reference's DimensionMismatch BEFORE a kernel reads or writes out of bounds (GCNConv.__call__
+    # would have raised it; the plan path skips the layer's own checks)
+    from ngpde_amd import _lib
+    N, d = 1024, 64
+    g, og, params = spatial_case(N, 4 * N, d, seed=21)
+    rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
+    node = ng.NeuralODE(rhs, solver="euler", n_steps=2, dt=0.1)
+    ps, st = ng.setup(0, node)
+    ps = ng.to_device(ps, DEV)
+    good = torch.zeros(d, N, device=DEV)
+    assert node(good, ps, st)[0].shape == (d, N)
+    for bad in (torch.zeros(d, N - 32, device=DEV), torch.zeros(d, N + 32, device=DEV), torch.zeros(d // 2, N, device=DEV)):
+        with pytest.raises(_lib.DimensionMismatch):
+            node(bad, ps, st)
+    ps_bad = {"layer_1": dict(ps["layer_1"]), "layer_2": dict(ps["layer_2"])}
+    ps_bad["layer_2"]["weight"] = torch.zeros(d, d // 2, device=DEV)
+    with pytest.raises(_lib.DimensionMismatch):
+        node(good, ps_bad, st)
+    # the GAT-style layer as right-hand side (ngpde_node_gat_*)
+    gat = ng.NeuralODE(ng.GATConv((64, 16), "relu", heads=4, initialgraph=g), solver="euler", n_steps=2, dt=0.1)
+    gps, gst = ng.setup(1, gat)
+    gps = ng.to_device(gps, DEV)
+    assert gat(good, gps, gst)[0].shape == (d, N)
+    if gat._plans and any(k[0] == "gat" for k in gat._plans if isinstance(k, tuple)):     # (the device-resident plan took it)
+        for bad in (torch.zeros(d, N - 32, device=DEV), torch.zeros(d, N + 64, device=DEV)):
+            with pytest.raises(_lib.DimensionMismatch):
+                gat(bad, gps, gst)
+        gbad = dict(gps)
+        gbad["a"] = torch.zeros(2 * 16, 3, device=DEV)
+        with pytest.raises(_lib.DimensionMismatch):
+            gat(good, gbad, gst)

@@ -92,3 +92,30 @@ def test_flat_views_collect_layer_gradients_and_one_step_updates_all():
 def test_optimiser_needs_device_parameters():
     with pytest.raises(ng.NgpdeError):
         optim.setup(optim.Adam(), optim.FlatParameters(torch.zeros(3), torch.zeros(3), []))
+
+
+def test_native_communicator_world_of_one_and_fused_adam():
+    # ngpde_comm_* / ngpde_grad_allreduce_adam (comm.hip): the data-parallel step behind the C ABI, RCCL on the caller's stream.  A
+    # 1-GPU box allows a world of one (RCCL refuses two ranks on one device; N > 1 is the driver's measurement): the all-reduce is
+    # then the identity and the fused step must equal ngpde_adam_step bit for bit.
+    import ngpde_amd as ng
+    from ngpde_amd import _lib
+    comm = ng.dist.NativeComm(ng.dist.NativeComm.unique_id(), 0, 1)
+    assert (comm.rank, comm.world) == (0, 1)
+    rng = np.random.default_rng(5)
+    n = 8320
+    x0 = torch.as_tensor(rng.normal(size=n).astype(np.float32), device="cuda:0")
+    g0 = torch.as_tensor(rng.normal(size=n).astype(np.float32), device="cuda:0")
+    g = g0.clone()
+    comm.all_reduce(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, g0)
+    lib, p = _lib.load(), _lib.ptr
+    xa, ma, va = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
+    xb, mb, vb = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
+    for step in (1, 2, 3):
+        comm.all_reduce_adam(xa, g0.clone(), ma, va, 1e-3, 0.9, 0.999, 1e-8, step)
+        _lib.check(lib.ngpde_adam_step(n, p(xb), p(g0), p(mb), p(vb), 1e-3, 0.9, 0.999, 1e-8, step, 1.0, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ma, mb) and torch.equal(va, vb) and not torch.equal(xa, x0)
+    comm.close()
