@@ -525,11 +525,13 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
 }
 
 int32_t ngpde_edge_mlp_backward_supported(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout, int32_t aggr) {
+  if (n_tail >= 2) return edge_mlp_deep_bwd_supported(g, h1, n_tail, tail_dout, aggr) ? 1 : 0;   // 3 / 4-layer message MLPs (edge_mlp_deep_bwd.hip)
   return edge_mlp_fused_bwd_supported(g, h1, n_tail, (n_tail == 1 && tail_dout) ? tail_dout[0] : 0, aggr) ? 1 : 0;
 }
 
 size_t ngpde_edge_mlp_backward_workspace_bytes(const ngpde_graph_t *g, int32_t h1, int32_t n_tail, const int32_t *tail_dout) {
   if (!g) return 0;
+  if (n_tail >= 2) return (n_tail <= 3 && tail_dout) ? edge_mlp_deep_bwd_workspace(g, h1, n_tail, tail_dout) : 0;
   return edge_mlp_fused_bwd_workspace(g, h1, n_tail, (n_tail == 1 && tail_dout) ? tail_dout[0] : 0);
 }
 
@@ -555,11 +557,26 @@ int32_t ngpde_edge_mlp_backward(const ngpde_graph_t *g, int32_t h1, int32_t act1
   NGPDE_REQUIRE(g != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: graph is NULL");
   int32_t st = check_act("ngpde_edge_mlp_backward", act1);
   if (st) return st;
-  NGPDE_REQUIRE(n_tail == 0 || (n_tail == 1 && tail_dout && tail_act && tail_weight && dtail_weight && tail_weight[0] && dtail_weight[0]),
-                NGPDE_ERR_UNSUPPORTED, "ngpde_edge_mlp_backward: 0 or 1 layer after the first (with its weight and gradient buffers)");
-  if (n_tail && (st = check_act("ngpde_edge_mlp_backward", tail_act[0]))) return st;
+  NGPDE_REQUIRE(n_tail >= 0 && n_tail <= 3, NGPDE_ERR_UNSUPPORTED, "ngpde_edge_mlp_backward: at most 3 layers after the first");
+  NGPDE_REQUIRE(n_tail == 0 || (tail_dout && tail_act && tail_weight && dtail_weight), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_edge_mlp_backward: the tail layers need their width / activation / weight / gradient arrays");
+  for (int l = 0; l < n_tail; ++l) {
+    NGPDE_REQUIRE(tail_weight[l] && dtail_weight[l], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: tail layer %d without its weight or gradient buffer", l);
+    if ((st = check_act("ngpde_edge_mlp_backward", tail_act[l]))) return st;
+  }
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(dout != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_mlp_backward: dout is NULL");
+  if (n_tail >= 2) {   // message MLPs of three / four layers
+    EdgeMlpDeepBwdArgs d;
+    d.h1 = h1; d.act1 = act1; d.aggr = aggr; d.n_tail = n_tail;
+    d.P = p_target; d.Q = q_source; d.Eterm = e_term; d.dout_grad = dout;
+    for (int l = 0; l < n_tail; ++l) {
+      d.dout[l] = tail_dout[l]; d.act[l] = tail_act[l]; d.wt[l] = tail_weight[l]; d.bias[l] = tail_bias ? tail_bias[l] : nullptr;
+      d.dwt[l] = dtail_weight[l]; d.dbias[l] = dtail_bias ? dtail_bias[l] : nullptr;
+    }
+    d.dP = dp_target; d.dQ = dq_source; d.dE = de_term; d.workspace = workspace; d.workspace_bytes = workspace_bytes;
+    return launch_edge_mlp_deep_bwd(g, d, (hipStream_t)stream);
+  }
   EdgeMlpBwdArgs a;
   a.h1 = h1; a.act1 = act1; a.aggr = aggr; a.n_tail = n_tail;
   a.P = p_target; a.Q = q_source; a.Eterm = e_term; a.dout = dout;

@@ -428,6 +428,20 @@ struct EdgeMlpBwdArgs {
   void *workspace = nullptr;
   size_t workspace_bytes = 0;
 };
+// edge_mlp_deep_bwd.hip: the same pullback for 2 or 3 Dense layers after the first (message MLPs of 3 / 4 layers)
+struct EdgeMlpDeepBwdArgs {
+  int h1 = 0, act1 = 0, aggr = 0, n_tail = 0;
+  int dout[3] = {0, 0, 0}, act[3] = {0, 0, 0};
+  const float *P = nullptr, *Q = nullptr, *Eterm = nullptr, *dout_grad = nullptr;
+  const float *wt[3] = {nullptr, nullptr, nullptr}, *bias[3] = {nullptr, nullptr, nullptr};
+  float *dP = nullptr, *dQ = nullptr, *dE = nullptr;
+  float *dwt[3] = {nullptr, nullptr, nullptr}, *dbias[3] = {nullptr, nullptr, nullptr};
+  void *workspace = nullptr;
+  size_t workspace_bytes = 0;
+};
+bool edge_mlp_deep_bwd_supported(const ngpde_graph *g, int h1, int n_tail, const int *dout, int aggr);
+size_t edge_mlp_deep_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, const int *dout);
+int32_t launch_edge_mlp_deep_bwd(const ngpde_graph *g, const EdgeMlpDeepBwdArgs &a, hipStream_t stream);
 bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int dw, int aggr);
 size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw);
 int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream);

@@ -536,6 +536,46 @@ def test_vmh_tutorial_shape_parity_and_grads():
     check_grads(ps, (n1 + n2, o1 + o2), x, gr["x"])
 
 
+@pytest.mark.parametrize("depth,aggr,N", [(3, "mean", 700), (4, "mean", 1000), (4, "+", 333)])
+def test_vmh_deep_message_mlp_fused_pullback_on_a_spatial_graph(depth, aggr, N, monkeypatch):
+    # message MLPs of three / four Dense layers (docs/src/tutorials/VMH.md:75-83: 4 => 60 => 60 => 60 => 40) on a graph whose
+    # tiles fit the LDS halo: forward in one launch without per-edge saves, pullback in one launch that recomputes the chain
+    # (edge_mlp_deep_bwd.hip) -- against the float64 oracle, and against the primitives' pullback (NGPDE_NO_FUSED_EDGE_BWD=1)
+    from ngpde_amd import _lib, synth as S
+    pts, s, t = S.closest_pairs_graph(N, 3 * N, seed=17 + depth)
+    nd = {"x": pts.T.copy()}
+    g, og = ng.GNNGraph(s, t, num_nodes=N, index_base=0, ndata=nd), O.Graph(s, t, num_nodes=N, index_base=0, ndata=nd)
+    hidden = [ng.Dense(60, 60, "tanh") for _ in range(depth - 2)]
+    phi = ng.Chain(ng.Dense(4, 60, "tanh"), *hidden, ng.Dense(60, 40))
+    gam = ng.Chain(ng.Dense(41, 60, "tanh"), ng.Dense(60, 1))
+    l = ng.VMHConv(phi, gam, aggr=aggr, initialgraph=g)
+    ps0, st = ng.setup(7, l)
+    lib = _lib.load()
+    import ctypes as C
+    douts = (C.c_int32 * (depth - 1))(*([60] * (depth - 2) + [40]))
+    assert lib.ngpde_edge_mlp_backward_supported(g.handle().ptr, 60, depth - 1, douts, _lib.AGGR[aggr]) == 1
+    rng = np.random.default_rng(5)
+    x0 = rng.normal(size=(1, N)).astype(np.float32)
+    yo, c = O.vmh_conv(x0.astype(np.float64), omlp(phi, prep(ps0, 5)["ϕ"]), omlp(gam, prep(ps0, 5)["γ"]), og, aggr=aggr)
+    R = rng.normal(size=yo.shape)
+    gr = O.vmh_conv_backward(c, R)
+    got = {}
+    for mode in ("fused", "primitives"):
+        if mode == "primitives":
+            monkeypatch.setenv("NGPDE_NO_FUSED_EDGE_BWD", "1")
+        ps = prep(ps0, 5)
+        x = torch.as_tensor(x0, device=DEV).requires_grad_(True)
+        y, _ = l(x, ps, st)
+        close(y, yo, rtol=2e-4)
+        (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+        n1, o1 = mlp_grad_pairs(ps["ϕ"], gr["phi"], phi)
+        n2, o2 = mlp_grad_pairs(ps["γ"], gr["gamma"], gam)
+        check_grads(ps, (n1 + n2, o1 + o2), x, gr["x"])
+        got[mode] = [x.grad.clone()] + [p.grad.clone() for _, p in n1]
+    for a, b in zip(got["fused"], got["primitives"]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5)
+
+
 # ---- MPPDEConv: the four variants of the reference's tests ----------------------------------------------------------------
 
 def mppde_case(gh, ogh, dphi_in, dpsi_in, N, seed=0, h=5):
