@@ -788,6 +788,13 @@ class _EdgeMlpFusedFn(torch.autograd.Function):
         # fused pullback available: it recomputes the per-edge activations, so the forward saves nothing per edge
         fused_bwd = need and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(lib.ngpde_edge_mlp_backward_supported(
             handle.ptr, h1, n_tail, _int_array(douts) if n_tail else None, aggr))
+        if fused_bwd and n_tail >= 2:
+            # message MLPs of three / four layers (edge_mlp_deep_bwd.hip): one 4-wave workgroup per CU walks a long dependent chain per
+            # tile, which pays where a workgroup has many tiles to amortise it over -- 262 144 nodes: 3.4 against 4.7 ms forward +
+            # backward; 3 000 nodes (the VMH tutorial): 105 us for the one launch against ~60 us of primitives' launches spread over
+            # the whole chip (tools/bench_deep_mlp.py, tools/bench_vmh_node.py).  NGPDE_DEEP_EDGE_BWD=1 / 0 forces it on / off.
+            force = os.environ.get("NGPDE_DEEP_EDGE_BWD")
+            fused_bwd = force == "1" or (force != "0" and n_nodes >= 32768)
         saves = [torch.empty((n_edges, w), dtype=torch.float32, device=dev) if (need and not fused_bwd) else None for w in widths]
         out = torch.empty((n_nodes, widths[-1]), dtype=torch.float32, device=dev)
         _lib.check(lib.ngpde_edge_mlp_forward(handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,

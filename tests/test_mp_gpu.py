@@ -560,6 +560,7 @@ def test_vmh_deep_message_mlp_fused_pullback_on_a_spatial_graph(depth, aggr, N, 
     R = rng.normal(size=yo.shape)
     gr = O.vmh_conv_backward(c, R)
     got = {}
+    monkeypatch.setenv("NGPDE_DEEP_EDGE_BWD", "1")       # (below 32 768 nodes the layer takes the primitives' pullback by default)
     for mode in ("fused", "primitives"):
         if mode == "primitives":
             monkeypatch.setenv("NGPDE_NO_FUSED_EDGE_BWD", "1")
