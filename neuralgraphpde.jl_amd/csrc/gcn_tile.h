@@ -205,5 +205,50 @@ __device__ __forceinline__ void mfma_rows_times_bt(const float *ldsA, const floa
   }
 }
 
+// The same product with B^T in LDS UNPADDED (row stride 64: 16 KB instead of 17) and XOR-swizzled so that the fragment reads stay
+// conflict-free: the four-float quad k4 of row j sits at quad k4 ^ (j & 15).  Same contraction order, same bits.  D = 64 only.
+__device__ __forceinline__ void mfma_rows_times_bswz64(const float *ldsA, const float *ldsBswz, float *ldsOut, int wave_u, int lane) {
+  using G = Geo<64>;
+  const int rt = wave_u % G::RT, ct = wave_u / G::RT;
+  const int i = lane & 15, kq = lane >> 4;
+  const float *pa = ldsA + (rt * 16 + i) * G::TS + 4 * kq;
+  const float *pb = ldsBswz + (ct * 16 + i) * 64;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const float4 a = *reinterpret_cast<const float4 *>(pa + kb * 16);
+    const float4 b = *reinterpret_cast<const float4 *>(pb + 4 * ((4 * kb + kq) ^ i));
+    acc = mfma16(a.x, b.x, acc);
+    acc = mfma16(a.y, b.y, acc);
+    acc = mfma16(a.z, b.z, acc);
+    acc = mfma16(a.w, b.w, acc);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) ldsOut[(rt * 16 + 4 * kq + reg) * G::TS + ct * 16 + i] = acc[reg];
+}
+
+// The same product with B as fragments in REGISTERS (b[4 kb + r] = Bt[column tile's column i][16 kb + 4 kq + r]): no copy of the
+// matrix in LDS.  Same contraction order, bit for bit the same result.  D = 64 only (one 16 x 16 block per wave).
+__device__ __forceinline__ void mfma_rows_times_bfrag64(const float *ldsA, const float (&b)[16], float *ldsOut, int wave_u, int lane) {
+  using G = Geo<64>;
+  const int rt = wave_u % G::RT, ct = wave_u / G::RT;
+  const int i = lane & 15, kq = lane >> 4;
+  const float *pa = ldsA + (rt * 16 + i) * G::TS + 4 * kq;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a_cur = *reinterpret_cast<const float4 *>(pa);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    float4 a_nxt = a_cur;
+    if (kb + 1 < 4) a_nxt = *reinterpret_cast<const float4 *>(pa + (kb + 1) * 16);
+    acc = mfma16(a_cur.x, b[4 * kb + 0], acc);
+    acc = mfma16(a_cur.y, b[4 * kb + 1], acc);
+    acc = mfma16(a_cur.z, b[4 * kb + 2], acc);
+    acc = mfma16(a_cur.w, b[4 * kb + 3], acc);
+    a_cur = a_nxt;
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) ldsOut[(rt * 16 + 4 * kq + reg) * G::TS + ct * 16 + i] = acc[reg];
+}
+
 }  // namespace
 }  // namespace ngpde

@@ -724,7 +724,7 @@ extern "C" int32_t ngpde_debug_set_fused_stamps(unsigned long long *dev_buf, int
 // Can the plan run with one hand-off per right-hand side?  The conditions of the one-tile-per-workgroup persistent plan
 // (node_persistent_mode == 1: checked by the caller), relu, and every workgroup of BOTH fused kernels co-resident.
 bool node_fused_rhs_possible(const ngpde_graph *g, int act, int n_evals) {
-  if (fused_disabled_env() || !g || act != NGPDE_ACT_RELU || n_evals < 2) return false;
+  if (fused_disabled_env() || !g || act != NGPDE_ACT_RELU || n_evals < 2 || g->by_t.slot_w || g->by_s.slot_w) return false;   // (unweighted graphs)
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;

@@ -405,10 +405,13 @@ struct PFwdK {
                        // stage input / step update), 0 elsewhere; cf[36 + i]: coefficient of k_i itself.  Copied to LDS.
 };
 
-template <int ACT, bool TAPE>
+// WGT (edge weights, src/layers.jl:206-231): the 4 KB of slot weights of the tile need LDS that two resident W^T do not leave, so layer 1's
+// W^T is B fragments in registers for the whole launch (16 per lane; the forward kernel has them to spare) and only W2^T is in LDS
+template <int ACT, bool TAPE, bool WGT = false>
 __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + 2 * PD + kMetaF + 48 + 4];
-  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = ldsW1 + kWF, *ldsB = ldsW2 + kWF;
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + kMetaF + 48 + 4];
+  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = WGT ? ldsW1 : ldsW1 + kWF;
+  float *ldsSW = ldsW2 + kWF, *ldsB = WGT ? ldsSW + kSlotWF : ldsSW;
   float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   TileCtx c;
@@ -416,7 +419,18 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   if (c.tid < 42) ldsC[c.tid] = p.cf[c.tid];
   const int act = ACT >= 0 ? ACT : p.act;
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
-  load_weight_lds(p.w1, ldsW1, c.tid, true);
+  float bw1[16];
+  if constexpr (WGT) {
+    reinterpret_cast<float2 *>(ldsSW)[c.tid] = reinterpret_cast<const float2 *>(p.m.slot_w + (size_t)c.tile * kSlotWF)[c.tid];   // [32][32]
+    c.lds_w = ldsSW;
+    const int i16 = c.lane & 15, kq = c.lane >> 4, ct = c.wave_u / PG::RT;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bw1[4 * kb + r] = p.w1[(16 * kb + 4 * kq + r) * PD + 16 * ct + i16];
+  } else {
+    load_weight_lds(p.w1, ldsW1, c.tid, true);
+  }
   load_weight_lds(p.w2, ldsW2, c.tid, true);
   if (c.tid < PD) ldsB[c.tid] = p.b1 ? p.b1[c.tid] : 0.f;
   else if (c.tid < 2 * PD) ldsB[c.tid] = p.b2 ? p.b2[c.tid - PD] : 0.f;
@@ -448,13 +462,14 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         NGPDE_PST(p.m, ph, 1);
         tile_gather_foreign(c, X, ldsXh);
         NGPDE_PST(p.m, ph, 2);
-        float4 acc = f4_scale(c.ci, tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
+        float4 acc = f4_scale(c.ci, WGT ? tile_aggregate_weighted(c, ldsXh) : tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
         const size_t ev = ev0 + (size_t)(n * p.S + i) * 2 + layer;
         if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
         __syncthreads();
         NGPDE_PST(p.m, ph, 3);
-        mfma_rows_times_bt<PD>(ldsT, layer == 0 ? ldsW1 : ldsW2, ldsZ, c.wave_u, c.lane);
+        if (WGT && layer == 0) mfma_rows_times_bfrag64(ldsT, bw1, ldsZ, c.wave_u, c.lane);
+        else mfma_rows_times_bt<PD>(ldsT, layer == 0 ? ldsW1 : ldsW2, ldsZ, c.wave_u, c.lane);
         __syncthreads();
         NGPDE_PST(p.m, ph, 4);
         const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
@@ -823,19 +838,37 @@ struct PBwdK {
 
 // ACT = NGPDE_ACT_RELU: relu' from the forward launch's sign bits; ACT = -1: any activation (p.act), act'(z) from the saved
 // pre-activations (one more tape row per phase)
-template <int ACT>
+// WGT: the tile's slot weights need 4 KB of LDS that two padded W do not leave (and the adjoint has no 16 registers to park
+// fragments in: fetched per phase they spill).  W1 is kept UNPADDED and XOR-swizzled instead (16 KB, conflict-free fragment reads:
+// gcn_tile.h, mfma_rows_times_bswz64), which makes exactly the room.
+template <int ACT, bool WGT = false>
 __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const PBwdK p) {
   constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
   using Aux = typename std::conditional<RELU, unsigned, float4>::type;   // what act' is formed from: 4 sign bits / the row of z
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + 2 * kWF + kMetaF + 48 + 4];
-  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + kWF;
-  float *ldsMeta = ldsW2 + kWF, *ldsC = ldsMeta + kMetaF;
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + (WGT ? PD * PD + kWF + kSlotWF : 2 * kWF) + kMetaF + 48 + 4];
+  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + (WGT ? PD * PD : kWF);
+  float *ldsSW = ldsW2 + kWF;
+  float *ldsMeta = WGT ? ldsSW + kSlotWF : ldsSW, *ldsC = ldsMeta + kMetaF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
   TileCtx c;
   tile_ctx_init(p.m, c, ldsMeta);
   if (c.tid < 48) ldsC[c.tid] = p.cb[c.tid];
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
-  load_weight_lds(p.w1, ldsW1, c.tid, false);
+  if constexpr (WGT) {
+    reinterpret_cast<float2 *>(ldsSW)[c.tid] = reinterpret_cast<const float2 *>(p.m.slot_w + (size_t)c.tile * kSlotWF)[c.tid];
+    c.lds_w = ldsSW;
+#pragma unroll
+    for (int k = 0; k < PG::W4; ++k) {   // W1 straight (B^T[j = in][k = out] = W1[j][k]), quad k4 of row j at quad k4 ^ (j & 15)
+      const int idx = c.tid + k * kThreads;
+      if (idx < PD * PD / 4) {
+        const int wi = (idx * 4) / PD, w4 = ((idx * 4) % PD) / 4;
+        *reinterpret_cast<float4 *>(&ldsW1[wi * PD + 4 * (w4 ^ (wi & 15))]) = reinterpret_cast<const float4 *>(p.w1)[idx];
+      }
+    }
+  } else {
+    load_weight_lds(p.w1, ldsW1, c.tid, false);
+  }
   load_weight_lds(p.w2, ldsW2, c.tid, false);
   if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1;
@@ -864,7 +897,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
     __syncthreads();
     NGPDE_PST(p.m, ph, 3);
-    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
+    if (WGT && ldsW == ldsW1) mfma_rows_times_bswz64(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);   // (layer 1 of a weighted graph: the unpadded, swizzled W1)
+    else mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
     __syncthreads();
     NGPDE_PST(p.m, ph, 4);
     const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
@@ -933,13 +967,22 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
         NGPDE_PST(p.m, ph, 0);
         const Aux mk = mask_of(ev);               // own-row loads: in flight during the wait
         const float4 xrow = tape_row(ev);
-        unsigned sw[8];
-        tile_slot_words(c, sw);
-        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
-        NGPDE_PST(p.m, ph, 1);
-        tile_gather_foreign(c, p.g2, ldsXh);
-        NGPDE_PST(p.m, ph, 2);
-        const float4 t = tile_aggregate(c, sw, ldsXh);
+        float4 t;
+        if constexpr (WGT) {
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, p.g2, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = tile_aggregate_weighted(c, ldsXh);
+        } else {
+          unsigned sw[8];
+          tile_slot_words(c, sw);
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, p.g2, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = tile_aggregate(c, sw, ldsXh);
+        }
         dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1);
       }
       {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
@@ -953,13 +996,22 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
           mk = mask_of(ev);
           xrow = tape_row(ev);
         }
-        unsigned sw[8];
-        tile_slot_words(c, sw);
-        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
-        NGPDE_PST(p.m, ph, 1);
-        tile_gather_foreign(c, p.g1, ldsXh);
-        NGPDE_PST(p.m, ph, 2);
-        const float4 t = tile_aggregate(c, sw, ldsXh);
+        float4 t;
+        if constexpr (WGT) {
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, p.g1, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = tile_aggregate_weighted(c, ldsXh);
+        } else {
+          unsigned sw[8];
+          tile_slot_words(c, sw);
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, p.g1, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = tile_aggregate(c, sw, ldsXh);
+        }
         float4 kbar;
         if (i >= 1) {
           // same order as the replayed plan: coef_self * t, then lambda, then U-bar_{i+1} ..
@@ -1596,7 +1648,20 @@ int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd) {
   take(occ_b, node_bwd_persistent2_kernel<true>);
   const int nt = g->n_sched / kTileRows, resident = cus * std::min(occ_f, occ_b);
   if (nt < 1) return 0;
-  if (weighted) return nt <= kMaxTileRoundsW * resident ? 3 : 0;   // edge weights: the tile-round kernels hold them (LDS beside ONE W)
+  if (weighted) {
+    // edge weights: one tile per workgroup on the WGT one-tile kernels (slot weights in the LDS of one W; W1 as register fragments)
+    // where the graph is one wave of workgroups, else the tile-round kernels (they keep one W in LDS anyway)
+    int ow_f = 1 << 30, ow_b = 1 << 30;
+    take(ow_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, true, true>);
+    take(ow_f, node_fwd_persistent_kernel<NGPDE_ACT_RELU, false, true>);
+    take(ow_f, node_fwd_persistent_kernel<-1, true, true>);
+    take(ow_f, node_fwd_persistent_kernel<-1, false, true>);
+    take(ow_b, node_bwd_persistent_kernel<NGPDE_ACT_RELU, true>);
+    take(ow_b, node_bwd_persistent_kernel<-1, true>);
+    const char *no1 = std::getenv("NGPDE_WEIGHTED_TILE_ROUNDS");   // 1: the tile-round kernels also where one tile per workgroup would do (A/B runs)
+    if (nt <= cus * std::min(ow_f, ow_b) && !(no1 && no1[0] == '1')) return 1;
+    return nt <= kMaxTileRoundsW * resident ? 3 : 0;
+  }
   if (nt <= resident) return 1;
   const char *no_pairs = std::getenv("NGPDE_NO_TILE_PAIRS");
   if (no_pairs && no_pairs[0] == '1') return 0;
@@ -1812,10 +1877,14 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turn.leave();
   }
-  NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
+  NGPDE_REQUIRE(!k.m.slot_w || (!a.pair && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE,
+                "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
-  if (a.pair) {                                                                                                              \
+  if (k.m.slot_w) {                                                                                                          \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, true>), grid, block, 0, stream, k);                           \
+  } else if (a.pair) {                                                                                                              \
     if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
     else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, true>), grid, block, 0, stream, k);                          \
   } else if (a.interleave) {                                                                                                 \
@@ -1885,9 +1954,19 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turn.leave();
   }
-  NGPDE_REQUIRE(!k.m.slot_w, NGPDE_ERR_STATE, "weighted graphs run on the tile-round kernels only");
+  NGPDE_REQUIRE(!k.m.slot_w || (!a.pair && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE,
+                "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
-  if (a.pair) {
+  if (k.m.slot_w) {
+    NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
+    if (a.act == NGPDE_ACT_RELU) {
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, true>), grid, block, 0, stream, k);
+    } else {
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<-1, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL((node_bwd_persistent_kernel<-1, true>), grid, block, 0, stream, k);
+    }
+  } else if (a.pair) {
     NGPDE_REQUIRE(a.ubar != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "tile-pair persistent adjoint without its stage-adjoint scratch");
     if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent2_kernel<true>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
     else hipLaunchKernelGGL(node_bwd_persistent2_kernel<true>, grid, block, 0, stream, k);

@@ -678,14 +678,21 @@ def _oracle_weighted_node(params, og, u0, seed, tableau, dt, nsteps, act):
     return uT, du0, acc
 
 
-@pytest.mark.parametrize("d,tab,N,nsteps,act", [(64, "tsit5", 1000, 3, "relu"), (64, "euler", 2048, 4, "tanh"), (32, "tsit5", 1500, 2, "relu"),
-                                                (64, "tsit5", 16384, 2, "relu"), (64, "tsit5", 40000, 2, "tanh"), (64, "tsit5", 77, 2, "swish")])
-def test_node_persistent_plan_weighted_graph_against_oracle_and_replayed_plan(d, tab, N, nsteps, act, monkeypatch):
+@pytest.mark.parametrize("d,tab,N,nsteps,act,rounds", [(64, "tsit5", 1000, 3, "relu", False), (64, "euler", 2048, 4, "tanh", False), (32, "tsit5", 1500, 2, "relu", False),
+                                                       (64, "tsit5", 16384, 2, "relu", False), (64, "tsit5", 16384, 2, "relu", True), (64, "tsit5", 40000, 2, "tanh", False),
+                                                       (64, "tsit5", 77, 2, "swish", False), (64, "euler", 1000, 3, "relu", True)])
+def test_node_persistent_plan_weighted_graph_against_oracle_and_replayed_plan(d, tab, N, nsteps, act, rounds, monkeypatch):
     needs_persistent_plan(monkeypatch)
-    # GCNConv(use_edge_weight=true) on a graph with stored edge weights (src/layers.jl:206-231) as the chain of graph_node.md:78:
-    # the tile-round kernels keep the tile's slot weights in LDS (node_persistent.hip: WGT).  u(T), du0 and the parameter
-    # gradients against the float64 oracle; u(T) and du0 bitwise equal to the replayed plan (same order of operations per row).
+    # GCNConv(use_edge_weight=true) on a graph with stored edge weights (src/layers.jl:206-231) as the chain of graph_node.md:78.
+    # Graphs of one wave of workgroups run on the one-tile kernels' WGT forms (slot weights in the LDS of one W: layer 1's W as
+    # register fragments in the forward, unpadded and swizzled in the adjoint), larger ones -- and `rounds` -- on the tile-round
+    # kernels.  u(T), du0 and the parameter gradients against the float64 oracle; u(T) and du0 bitwise equal to the replayed plan
+    # (same order of operations per row).
     dt = 0.1
+    if rounds:
+        monkeypatch.setenv("NGPDE_WEIGHTED_TILE_ROUNDS", "1")
+    else:
+        monkeypatch.delenv("NGPDE_WEIGHTED_TILE_ROUNDS", raising=False)
     _, s, t = S.closest_pairs_graph(N, 4 * N, seed=N + 3)
     rng = np.random.default_rng(N + d)
     ew = (0.25 + rng.random(s.size)).astype(np.float32)
@@ -713,7 +720,8 @@ def test_node_persistent_plan_weighted_graph_against_oracle_and_replayed_plan(d,
         return uT.detach(), u.grad, ps, plan.flags()
 
     uT, du0, ps, flags = solve()
-    assert {"persistent_fwd", "persistent_bwd", "tile_rounds"} <= flags, flags
+    assert {"persistent_fwd", "persistent_bwd"} <= flags, flags
+    assert ("tile_rounds" in flags) == (rounds or N > 16384), flags
     assert ("widened" in flags) == (d != 64)
     uTo, du0o, acc = _oracle_weighted_node(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps, act)
     close(uT, uTo, rtol=2e-4, what="u(T)")
