@@ -613,6 +613,165 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// forward solve, tile rounds with the NEXT turn's hand-off taken off the current turn's instruction stream
+// ---------------------------------------------------------------------------------------------------------------------
+// node_fwd_persistentK_kernel runs poll -> gather -> aggregate -> product -> epilogue -> drain -> flag one after the other for every
+// turn (4.8 us), with only the CU's other workgroup to fill the three fabric round trips.  But a workgroup's NEXT turn depends on
+// nothing this turn produces (turn s + 1 of a phase needs the neighbours' previous phase; turn 0 of the next phase needs what they
+// finished K - 1 turns ago), so, as in the two-slot kernels (fwd_slot_phase):
+//   T0  s_waitcnt vmcnt(0) + barrier: this turn's halo rows (gathered during the previous turn) have landed and the previous turn's
+//       row stores are drained -> ITS flag goes out here (deferred publish); wave 0 issues the flag loads of the NEXT turn's wait
+//       list (not waited for)
+//   T1  LDS aggregation, operand tile, tape row; wave 0 looks at the flags; barrier (the halo region is free from here)
+//   T2  if they were all there: the next turn's rows go out by LDS-DMA and travel under the product and the epilogue; product; barrier
+//   T5  bias, activation, stage combination, row / state stores (not drained); then the next turn's state rows are fetched into the
+//       registers this turn has just finished with
+// A next turn whose flags were not there takes the blocking path at its T0.  Arithmetic per tile is the tile-round kernel's.
+template <int ACT, bool TAPE>
+__global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(const PFwdK p) {
+  constexpr int kMS = meta_stride<false>(), kMT = meta_tiles<false>();
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + 2 * PD + kMT * kMS + 48 + 4];
+  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
+  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW = ldsZ + kTileF, *ldsB = ldsW + kWF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMT * kMS;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
+  const int tid = threadIdx.x, q = tid & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (tid < 42) ldsC[tid] = p.cf[tid];
+  const int act = ACT >= 0 ? ACT : p.act;
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  if (tid < PD) ldsB[tid] = p.b1 ? p.b1[tid] : 0.f;
+  else if (tid < 2 * PD) ldsB[tid] = p.b2 ? p.b2[tid - PD] : 0.f;
+  if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
+  if (tid == 0) *s_ok = 1, *s_pre = 0;
+  const int W = p.pair_wgs, K = min(p.k_tiles, kMT);
+  const int t0 = xcd_tile(blockIdx.x, W);
+  const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  int KT = 0;   // tiles this workgroup really holds (the last workgroups of a ragged grid hold one fewer)
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s, ++KT) tile_tables_to_lds<false>(p.m, t0 + s * W, ldsMeta + s * kMS);
+  __syncthreads();
+  const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[q];
+  bool ok = true, pre = false;
+  unsigned *pend_flags = nullptr;
+  int pend_ph = 0, n_ahead = 0;
+  // this turn's state rows (layer-2 turns): fetched at the end of the previous turn when its gather went out ahead, else at T0
+  float4 su = f4_zero(), sk0 = f4_zero(), sk1 = f4_zero(), sk2 = f4_zero(), sk3 = f4_zero(), sk4 = f4_zero();
+  auto load_state = [&](const TileCtx &c, unsigned own, int n) {
+    su = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
+    sk0 = ld4_g(p.state, own + rowb); sk1 = ld4_g(p.state, own + 2 * rowb); sk2 = ld4_g(p.state, own + 3 * rowb);
+    sk3 = ld4_g(p.state, own + 4 * rowb); sk4 = ld4_g(p.state, own + 5 * rowb);
+  };
+  int ph = 0;
+  for (int n = 0; n < p.n_steps && ok; ++n) {
+    for (int i = 0; i < p.S && ok; ++i) {
+#pragma unroll 1
+      for (int layer = 0; layer < 2 && ok; ++layer) {
+        ++ph;
+        const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
+        const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
+        const bool last_phase = (n == p.n_steps - 1 && i == p.S - 1 && layer == 1);
+        // (every wave is past the previous phase's last product: the barrier behind it.  The first product of this phase is
+        // behind two more barriers.)
+        load_weight_lds(layer == 0 ? p.w1 : p.w2, ldsW, tid, true);
+        for (int s = 0; s < KT; ++s) {
+          const int tile = t0 + s * W;
+          TileCtx c;
+          tile_ctx_from_lds<false>(c, tile, ldsMeta + s * kMS);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          // ---- T0
+          wait_vmcnt0();
+          __syncthreads();
+          n_ahead += pre ? 1 : 0;
+          if (pend_flags && tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pend_flags = nullptr;
+          if (!pre) {
+            if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+            halo_fill_all(c, X, ldsXh);
+            if (layer == 1) load_state(c, own, n);
+            wait_vmcnt0();
+            __syncthreads();
+          }
+          // ---- the turn after this one: the next tile of this phase, or this workgroup's first tile in the next phase
+          const bool same_phase = s + 1 < KT;
+          const int ns = same_phase ? s + 1 : 0, nph = same_phase ? ph : ph + 1, nlayer = same_phase ? layer : 1 - layer;
+          const int nn = (same_phase || layer == 0) ? n : ((i == p.S - 1) ? n + 1 : n);
+          const bool nexists = (same_phase || !last_phase) && KT > 1;   // (one tile: its own rows of the next phase are stored in THIS turn)
+          const float *nX = same_phase ? X : (nlayer == 0 ? p.bufA : p.bufB);   // (only the launch's very first phase reads u_in)
+          const float *nmeta = ldsMeta + ns * kMS;
+          // its flags: fetched now, looked at behind the aggregation (they were published K - 1 turns ago: one look is enough)
+          unsigned f1 = 0;
+          if (nexists && wave_u == 0) {
+            const int nb = reinterpret_cast<const int *>(nmeta + kMetaF + kTM * 4)[lane];
+            const unsigned *addr = (lane == 63) ? p.m.abort_word : (nb >= 0 ? p.m.flags + 32 * nb : nullptr);
+            f1 = (lane == 63) ? 0u : 0xffffffffu;
+            if (addr) f1 = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          // ---- T1
+          float4 acc = f4_scale(c.ci, tile_aggregate_lean(c, ldsXh));
+          *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
+          if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
+          if (wave_u == 0) {
+            const unsigned need = (unsigned)(nph - 1);
+            const bool hit = nexists && __all((int)(lane == 63 ? f1 == 0u : f1 >= need)) != 0;
+            if (lane == 0) *s_pre = hit ? 1 : 0;
+          }
+          __syncthreads();
+          // ---- T2: the halo region is free; the next turn's rows travel under the product and the epilogue
+          pre = *s_pre != 0;
+          TileCtx cn;
+          unsigned ownn = 0;
+          if (pre) {
+            tile_ctx_from_lds<false>(cn, t0 + ns * W, nmeta);
+            ownn = (unsigned)cn.node * (unsigned)(PD * 4) + (unsigned)(cn.q * 16);
+            halo_fill_all(cn, nX, ldsXh);
+          }
+          mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, wave_u, lane);
+          __syncthreads();
+          // ---- T5
+          const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
+          const float cself = ldsC[36 + i], cf0 = ldsC[i * 6 + 0], cf1 = ldsC[i * 6 + 1], cf2 = ldsC[i * 6 + 2], cf3 = ldsC[i * 6 + 3],
+                      cf4 = ldsC[i * 6 + 4];
+          const uint8_t sign_bits = (uint8_t)((z.x > 0.f ? 1 : 0) | (z.y > 0.f ? 2 : 0) | (z.z > 0.f ? 4 : 0) | (z.w > 0.f ? 8 : 0));
+          const float4 yv = f4_sel(c.valid, f4_scale(c.ci, f4_act(act, z)), f4_zero());
+          if (layer == 0) {
+            if (c.valid) store_sc1(p.bufB, own, yv);
+          } else {
+            const float4 k0 = i == 0 ? yv : sk0, k1 = i == 1 ? yv : sk1, k2 = i == 2 ? yv : sk2, k3 = i == 3 ? yv : sk3, k4 = i == 4 ? yv : sk4;
+            float4 v = f4_scale(cself, yv);
+            v = f4_fma(1.0f, su, v);
+            v = f4_fma(cf0, k0, v); v = f4_fma(cf1, k1, v); v = f4_fma(cf2, k2, v);
+            v = f4_fma(cf3, k3, v); v = f4_fma(cf4, k4, v);
+            if (c.valid) {
+              st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);
+              if (i == p.S - 1) st4_g(p.state, own, v);
+              if (last_phase) st4_g(p.u_out, own, v);
+              store_sc1(p.bufA, own, v);
+            }
+          }
+          if (pre && nlayer == 1) load_state(cn, ownn, nn);   // (this turn's state rows are dead from here)
+          pend_flags = p.m.flags + 32 * tile;
+          pend_ph = ph;
+          if constexpr (TAPE && ACT == NGPDE_ACT_RELU) stu8_g(p.masks + ev * p.mask_bytes + (size_t)tile * kThreads, (unsigned)tid, sign_bits);
+          else if (TAPE && c.valid) st4_stream_g(p.ztape + ev * p.row_elems, own, z);
+        }
+      }
+    }
+  }
+  wait_vmcnt0();
+  __syncthreads();
+  if (ok && pend_flags && tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!ok) {   // a wait was aborted: poison every row this workgroup owns
+    __syncthreads();
+    for (int s = 0; s < KT; ++s) {
+      const int4 sc = p.m.sched[(size_t)(t0 + s * W) * kTM + (tid >> 4)];
+      if (sc.x >= 0) st4_g(p.u_out, (unsigned)sc.x * (unsigned)(PD * 4) + (unsigned)(q * 16), f4_nan());
+    }
+  }
+  if (tid == 0 && p.m.stats) p.m.stats[2 * t0] = n_ahead;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // forward solve, TWO trajectories of a batch interleaved in one workgroup
 // ---------------------------------------------------------------------------------------------------------------------
 // A block-diagonal batch of identical structures (test/runtests.jl:89-102, src/layers.jl:359-361) solved member after member
@@ -1681,6 +1840,8 @@ int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per w
   };
   take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false>);
   take(node_fwd_persistentK_kernel<-1, true>); take(node_fwd_persistentK_kernel<-1, false>);
+  take(node_fwd_persistentKP_kernel<NGPDE_ACT_RELU, true>); take(node_fwd_persistentKP_kernel<NGPDE_ACT_RELU, false>);
+  take(node_fwd_persistentKP_kernel<-1, true>); take(node_fwd_persistentKP_kernel<-1, false>);
   take(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>); take(node_bwd_persistentK_kernel<-1>);
   if (g->by_t.slot_w) {
     take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false, true>);
@@ -1861,8 +2022,13 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     if ((st = launch_zero(a.state + a.row_elems, 6 * a.row_elems * sizeof(float), stream))) return st;   // k_0 .. k_5 start from zero
     const dim3 gridk(ps.pair_wgs), blockk(kThreads);
     NGPDE_REQUIRE(!k.m.slot_w || a.k_tiles <= kMaxTileRoundsW, NGPDE_ERR_STATE, "weighted tile rounds: at most %d tiles per workgroup", kMaxTileRoundsW);
+    const char *nopipe = std::getenv("NGPDE_NO_TILE_PIPE");
+    const bool pipe = !k.m.slot_w && !(nopipe && nopipe[0] == '1');
 #define NGPDE_PFK_LAUNCH(AA, TT)                                                                                                  \
-    if (k.m.slot_w) {                                                                                                             \
+    if (pipe) {                                                                                                                   \
+      if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentKP_kernel<AA, TT>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+      else hipLaunchKernelGGL((node_fwd_persistentKP_kernel<AA, TT>), gridk, blockk, 0, stream, k);                                \
+    } else if (k.m.slot_w) {                                                                                                             \
       if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT, true>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
       else hipLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT, true>), gridk, blockk, 0, stream, k);                           \
     } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistentK_kernel<AA, TT>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \

@@ -503,6 +503,58 @@ def test_c3_gat_as_ode_right_hand_side_full_size_against_the_oracle(monkeypatch)
         close(ps[k].grad, acc[k], 5e-4, 5e-3, "d" + k)
 
 
+def c3_node_inputs():
+    """inputs of tests/golden/full/make_c3_full_golden.py (the same calls)"""
+    N, D, H, C_ = 16384, 64, 4, 16
+    _, s, t = S.closest_pairs_graph(N, 65536, seed=2)
+    W = S.glorot_uniform(21, H * C_, D)
+    a = S.glorot_uniform(22, 2 * C_, H)
+    b = S.normal(23, H * C_) * 0.1
+    u0 = S.normal(33, D * N).reshape(N, D).T
+    return s, t, W, a, b, u0
+
+
+def test_c3_full_bench_workload_against_float64_golden(monkeypatch):
+    # BASELINE config 3 "as ODE right-hand side" at the BENCH's settings -- GATConv(64 => 4 x 16, relu) on the C2 graph, Tsit5 x 50,
+    # forward + discrete adjoint of sum(u(T)) on the device-resident solver (ngpde_node_gat_*) -- against the float64 numpy oracle.
+    # The oracle needs ~20 minutes at this size: its results are a committed fixture (tests/golden/full/c3_full_tsit5x50.npz, generator
+    # make_c3_full_golden.py).  Same treatment as C2's: u(T) and the parameter gradients entry by entry; du0 allows for the relu /
+    # leakyrelu kinks that rounding decides (a handful of 300 x 16 384 x (64 + 4 x 9) branch decisions flip, each moves du0 in the
+    # rows around it), bounded per sampled row and in the l2 norm of the whole field.
+    monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+    monkeypatch.delenv("NGPDE_NO_FUSED_GAT_LAYER", raising=False)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full", "c3_full_tsit5x50.npz"))
+    s, t, W, a, b, u0 = c3_node_inputs()
+    r32 = lambda v: np.asarray(v, np.float64).astype(np.float32).astype(np.float64)
+    chk = np.array([r32(u0).sum(), r32(W).sum(), r32(a).sum(), r32(b).sum(), float(s.sum()), float(t.sum())])
+    assert np.array_equal(chk, G["in_checksum"]), "the generator's inputs are not this test's inputs: regenerate the fixture"
+    N = 16384
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    l = ng.GATConv((64, 16), "relu", heads=4, initialgraph=g)
+    node = ng.NeuralODE(l, solver="tsit5", n_steps=int(G["nsteps"]), dt=1.0 / 50)
+    ps, st = ng.setup(0, node)
+    ps = ng.to_device(ps, DEV)
+    for k, v in (("weight", W), ("a", a), ("bias", b)):
+        ps[k] = torch.as_tensor(np.asarray(v, np.float32).reshape(tuple(ps[k].shape)), device=DEV).requires_grad_(True)
+    ut = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(ut, ps, st)
+    uT.sum().backward()
+    plans = [p for pool in node._plans.values() for p in pool]
+    assert plans and all("gat" in p.flags() and not p.fault() for p in plans), "config 3 is meant to run on the device-resident solver"
+    cols = torch.as_tensor(G["cols"], device=DEV)
+    got = uT.detach()[:, cols].cpu().double().numpy()
+    assert np.abs(got - G["uT_cols"]).max() <= 2e-4 * float(G["uT_absmax"]), f"u(T): {np.abs(got - G['uT_cols']).max():.3e}"
+    assert abs(float(uT.detach().double().norm()) - float(G["uT_norm"])) <= 1e-5 * float(G["uT_norm"])
+    for name, key in (("dW", "weight"), ("da", "a"), ("db", "bias")):
+        ref = G[name]
+        err = np.abs(ps[key].grad.detach().cpu().double().numpy().reshape(ref.shape) - ref).max()
+        assert err <= 5e-4 * np.abs(ref).max(), f"{name}: {err:.3e} vs {5e-4 * np.abs(ref).max():.3e}"
+    d = np.abs(ut.grad[:, cols].cpu().double().numpy() - G["du0_cols"]).max(axis=0)
+    bound = 5e-4 * float(G["du0_absmax"])
+    assert (d > bound).sum() <= 0.03 * d.size and d.max() <= 40 * bound, f"du0: {(d > bound).sum()} of {d.size} rows beyond {bound:.2e}, max {d.max():.2e}"
+    assert abs(float(ut.grad.double().norm()) - float(G["du0_norm"])) <= 2e-4 * float(G["du0_norm"])
+
+
 def test_c4_shard_backward_per_trajectory_oracle_and_batch_sum_rule():
     # C4 per-GPU shard (64 trajectories x 8 192-node periodic mesh = 524 288 nodes, 3 145 728 edges), forward + backward:
     #  (a) a cotangent supported on ONE trajectory: dx and every parameter gradient of the batched launch equal the float64
