@@ -651,6 +651,17 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
   for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s, ++KT) tile_tables_to_lds<false>(p.m, t0 + s * W, ldsMeta + s * kMS);
   __syncthreads();
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[q];
+  // no weight reload per phase (the tile-round kernel stages the phase's W^T in LDS every phase: ~1.2 k cycles per turn at four
+  // tiles per workgroup): W2^T stays in LDS, W1^T is B fragments in registers for the whole launch (gcn_tile.h)
+  float bw1[16];
+  {
+    const int i16 = lane & 15, kq = lane >> 4, ct = wave_u / PG::RT;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bw1[4 * kb + r] = p.w1[(16 * kb + 4 * kq + r) * PD + 16 * ct + i16];
+  }
+  load_weight_lds(p.w2, ldsW, tid, true);
   bool ok = true, pre = false;
   unsigned *pend_flags = nullptr;
   int pend_ph = 0, n_ahead = 0;
@@ -670,17 +681,17 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
         const float *X = layer == 0 ? ((n == 0 && i == 0) ? p.u_in : p.bufA) : p.bufB;
         const size_t ev = (size_t)(n * p.S + i) * 2 + layer;
         const bool last_phase = (n == p.n_steps - 1 && i == p.S - 1 && layer == 1);
-        // (every wave is past the previous phase's last product: the barrier behind it.  The first product of this phase is
-        // behind two more barriers.)
-        load_weight_lds(layer == 0 ? p.w1 : p.w2, ldsW, tid, true);
         for (int s = 0; s < KT; ++s) {
           const int tile = t0 + s * W;
           TileCtx c;
           tile_ctx_from_lds<false>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
           // ---- T0
+          const int turn = (ph - 1) * KT + s + 1;   // (stamps: one record per turn)
+          NGPDE_PST(p.m, turn, 0);
           wait_vmcnt0();
           __syncthreads();
+          NGPDE_PST(p.m, turn, 1);
           n_ahead += pre ? 1 : 0;
           if (pend_flags && tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           pend_flags = nullptr;
@@ -691,6 +702,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
             wait_vmcnt0();
             __syncthreads();
           }
+          NGPDE_PST(p.m, turn, 2);
           // ---- the turn after this one: the next tile of this phase, or this workgroup's first tile in the next phase
           const bool same_phase = s + 1 < KT;
           const int ns = same_phase ? s + 1 : 0, nph = same_phase ? ph : ph + 1, nlayer = same_phase ? layer : 1 - layer;
@@ -717,6 +729,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
           }
           __syncthreads();
           // ---- T2: the halo region is free; the next turn's rows travel under the product and the epilogue
+          NGPDE_PST(p.m, turn, 3);
           pre = *s_pre != 0;
           TileCtx cn;
           unsigned ownn = 0;
@@ -725,8 +738,11 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
             ownn = (unsigned)cn.node * (unsigned)(PD * 4) + (unsigned)(cn.q * 16);
             halo_fill_all(cn, nX, ldsXh);
           }
-          mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, wave_u, lane);
+          NGPDE_PST(p.m, turn, 4);
+          if (layer == 0) mfma_rows_times_bfrag64(ldsT, bw1, ldsZ, wave_u, lane);
+          else mfma_rows_times_bt<PD>(ldsT, ldsW, ldsZ, wave_u, lane);
           __syncthreads();
+          NGPDE_PST(p.m, turn, 5);
           // ---- T5
           const float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsZ[c.grp * PG::TS + 4 * c.q]), layer == 0 ? bias1 : bias2);
           const float cself = ldsC[36 + i], cf0 = ldsC[i * 6 + 0], cf1 = ldsC[i * 6 + 1], cf2 = ldsC[i * 6 + 2], cf3 = ldsC[i * 6 + 3],
@@ -753,6 +769,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
           pend_ph = ph;
           if constexpr (TAPE && ACT == NGPDE_ACT_RELU) stu8_g(p.masks + ev * p.mask_bytes + (size_t)tile * kThreads, (unsigned)tid, sign_bits);
           else if (TAPE && c.valid) st4_stream_g(p.ztape + ev * p.row_elems, own, z);
+          NGPDE_PST(p.m, turn, 6);
         }
       }
     }
