@@ -755,7 +755,9 @@ def main():
                          "traffic_source": "static: profiles/traffic.json, the rocprofv3 --pmc passes of tools/profile_round.sh "
                                            "(FETCH_SIZE x 2 + WRITE_SIZE per launch), not collected in this run",
                          "algorithmic_MB_per_launch": round(algo[dom] / 1e6, 2),
-                         "avg_launch_us": round(float(us[dom]), 3)},
+                         "avg_launch_us": round(float(us[dom]), 3),
+                         "avg_launch_source": "the library's own dispatch events (hipExtLaunchKernelGGL start / stop, median of five passes); "
+                                              "rocprofv3 --kernel-trace reads ~1-3 % longer for the same launch (profiles/r04_*_kernel_stats.csv)"},
             "kernels": kernels,
             "plan": sorted(plan.flags()), "fault": bool(plan.fault()),
         }
