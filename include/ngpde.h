@@ -35,6 +35,7 @@ extern "C" {
 typedef struct ngpde_graph ngpde_graph_t;     /* derived graph: CSR by target + CSR by source  */
 typedef struct ngpde_node ngpde_node_t;       /* fixed-step neural-ODE plan over 2 x GCNConv   */
 typedef struct ngpde_node_gat ngpde_node_gat_t; /* fixed-step neural-ODE plan over one GAT-style layer */
+typedef struct ngpde_node_vmh ngpde_node_vmh_t; /* fixed-step neural-ODE plan over VMHConv(phi, gamma) */
 typedef void *ngpde_stream_t;                 /* hipStream_t                                   */
 
 typedef enum {
@@ -477,6 +478,29 @@ int32_t ngpde_node_gat_forward(ngpde_node_gat_t *plan, const float *u0, const fl
                                float *uT, ngpde_stream_t stream);
 int32_t ngpde_node_gat_backward(ngpde_node_gat_t *plan, const float *weight, const float *a, const float *duT, float *du0,
                                 float *dweight, float *da, float *dbias, ngpde_stream_t stream);
+/* ---- NeuralODE(VMHConv(phi, gamma)) device-resident (node_vmh.hip) -----------------------------------------------------------
+ * The reference's second neural-ODE caller: docs/src/tutorials/VMH.md:75-89 -- du/dt = VMHConv(phi, gamma)(u) (src/layers.jl:308-332:
+ * m_i = aggr_j phi([h_i; h_j - h_i; x_j - x_i]), h' = gamma([h_i; m_i])) under a fixed-step solver, forward + discrete adjoint as ONE
+ * persistent launch each (+ one weight-pullback GEMM per Dense layer).  Shapes taken: a scalar state (hd = 1: u0, uT, duT, du0 are
+ * [N]), pd = 1..3 position coordinates (pos: device [N][pd], copied at creation), MLPs of 2..4 Dense layers up to 64 wide --
+ * phi: dims[0] = 2 hd + pd, gamma: dims[0] = hd + phi's output width, gamma's output width = hd --, hidden activations identity /
+ * relu / tanh / sigmoid, identity output layers, + or mean aggregation, graphs of at most one 16-row half tile per CU.
+ * ngpde_node_vmh_supported says so; the host's generic solver takes everything else.  Weights are [in][out] (Julia's (out x in)
+ * column-major), passed as HOST arrays of device pointers (bias pointers / the bias arrays may be NULL).  One solve's tape per plan. */
+int32_t ngpde_node_vmh_supported(const ngpde_graph_t *g, int32_t hd, int32_t pd, int32_t n_phi, const int32_t *phi_dims, const int32_t *phi_acts,
+                                 int32_t n_gamma, const int32_t *gamma_dims, const int32_t *gamma_acts, int32_t aggr);
+int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, const float *pos, int32_t n_phi, const int32_t *phi_dims,
+                              const int32_t *phi_acts, int32_t n_gamma, const int32_t *gamma_dims, const int32_t *gamma_acts, int32_t aggr,
+                              int32_t tableau, int32_t n_steps, double dt, int32_t with_backward, ngpde_node_vmh_t **out);
+int32_t ngpde_node_vmh_destroy(ngpde_node_vmh_t *plan);
+size_t ngpde_node_vmh_tape_bytes(const ngpde_node_vmh_t *plan);
+int32_t ngpde_node_vmh_fault(ngpde_node_vmh_t *plan, ngpde_stream_t stream, int32_t *fault);
+int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *plan, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
+                               const float *const *gamma_weight, const float *const *gamma_bias, float *uT, ngpde_stream_t stream);
+int32_t ngpde_node_vmh_backward(ngpde_node_vmh_t *plan, const float *const *phi_weight, const float *const *gamma_weight, const float *duT,
+                                float *du0, float *const *dphi_weight, float *const *dphi_bias, float *const *dgamma_weight,
+                                float *const *dgamma_bias, ngpde_stream_t stream);
+
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every
  * `stride`-th dispatch and returns the mean DEVICE time per launch in microseconds -- the quantity

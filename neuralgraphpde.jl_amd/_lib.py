@@ -57,6 +57,13 @@ SIGNATURES = {
     "ngpde_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngpde_grad_allreduce": (_i32, [_vp, _vp, _i64, _vp]),
     "ngpde_grad_allreduce_adam": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp]),
+    "ngpde_node_vmh_supported": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32]),
+    "ngpde_node_vmh_create": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, C.c_double, _i32, C.POINTER(_vp)]),
+    "ngpde_node_vmh_destroy": (_i32, [_vp]),
+    "ngpde_node_vmh_tape_bytes": (_sz, [_vp]),
+    "ngpde_node_vmh_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ngpde_node_vmh_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_node_vmh_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "ngpde_rprop_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ngpde_graph_destroy": (_i32, [_vp]),

@@ -294,6 +294,30 @@ size_t gat_node_dscore_elems(const ngpde_graph *g);                       // flo
 int32_t launch_gat_node_xpad(const ngpde_graph *g, int *pad_of_p, int *xpad, hipStream_t stream);
 int32_t launch_gat_node_fwd(const GatNodeFwd &a, hipStream_t stream);
 int32_t launch_gat_node_bwd(const GatNodeBwd &a, hipStream_t stream);
+// NeuralODE(VMHConv(phi, gamma)) device-resident (node_vmh.hip; plan: node.hip)
+constexpr int kVmhMaxL = 4;      // Dense layers per MLP
+struct VmhShape {
+  int hd = 1, pd = 2, aggr = 1, n_phi = 0, n_gam = 0;
+  int phi_dims[kVmhMaxL + 1] = {0, 0, 0, 0, 0}, gam_dims[kVmhMaxL + 1] = {0, 0, 0, 0, 0};   // layer l: dims[l] => dims[l + 1]
+  int phi_act[kVmhMaxL] = {0, 0, 0, 0}, gam_act[kVmhMaxL] = {0, 0, 0, 0};
+};
+struct VmhLaunch {
+  const ngpde_graph *g = nullptr;
+  const NodePersist *ps = nullptr;
+  VmhShape shape;
+  int n_steps = 0, S = 0;
+  const float *pos = nullptr;
+  const float *phi_w[kVmhMaxL] = {nullptr, nullptr, nullptr, nullptr}, *phi_b[kVmhMaxL] = {nullptr, nullptr, nullptr, nullptr};
+  const float *gam_w[kVmhMaxL] = {nullptr, nullptr, nullptr, nullptr}, *gam_b[kVmhMaxL] = {nullptr, nullptr, nullptr, nullptr};
+  const float *u_in = nullptr;
+  float *u_out = nullptr, *x0 = nullptr, *x1 = nullptr, *tape_phi = nullptr, *tape_gam = nullptr;
+  float *lam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;   // dsrc: [2][E]
+  const float *cf = nullptr, *cb = nullptr;
+};
+bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s);
+int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream);
+int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream);
+int32_t launch_vmh_copy_block(const float *src, int sp, float *dst, int dp, int rows, int cols, hipStream_t stream);
 bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
 int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                              float *out, float *alpha, hipStream_t stream);

@@ -1020,4 +1020,203 @@ int32_t ngpde_node_gat_backward(ngpde_node_gat_t *p, const float *weight, const 
   return launch_gat_node_bwd(b, (hipStream_t)stream_);
 }
 
+
+/* ---- VMHConv as right-hand side: device-resident solve + discrete adjoint (node_vmh.hip) -------------------------------------- */
+}  // extern "C"
+
+struct ngpde_node_vmh {
+  const ngpde_graph *g = nullptr;
+  VmhShape shape;
+  int S = 0, n_steps = 0;
+  bool with_bwd = false, solved = false;
+  NodePersist persist;
+  float *pos = nullptr, *cf = nullptr, *cb = nullptr, *x = nullptr;         // x: [2][N] exchanged stage input
+  float *tape_phi = nullptr, *tape_gam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;
+  float *partial = nullptr, *dwpad = nullptr;                                // weight-pullback workspace; [64 x 64 + 64] padded result
+  size_t tape_bytes = 0, partial_floats = 0;
+};
+
+static void node_vmh_free(ngpde_node_vmh *p) {
+  if (!p) return;
+  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->tape_phi, p->tape_gam, p->dz_phi, p->dz_gam, p->dsrc, p->partial, p->dwpad};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  node_persistent_free(&p->persist);
+  delete p;
+}
+
+static int32_t vmh_shape(int32_t hd, int32_t pd, int32_t n_phi, const int32_t *phi_dims, const int32_t *phi_acts, int32_t n_gamma,
+                         const int32_t *gamma_dims, const int32_t *gamma_acts, int32_t aggr, VmhShape *s) {
+  NGPDE_REQUIRE(phi_dims && phi_acts && gamma_dims && gamma_acts, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh: NULL layer table");
+  NGPDE_REQUIRE(n_phi >= 1 && n_phi <= kVmhMaxL && n_gamma >= 1 && n_gamma <= kVmhMaxL, NGPDE_ERR_UNSUPPORTED,
+                "ngpde_node_vmh: 1 to %d Dense layers per MLP", kVmhMaxL);
+  s->hd = hd; s->pd = pd; s->aggr = aggr; s->n_phi = n_phi; s->n_gam = n_gamma;
+  for (int l = 0; l <= n_phi; ++l) s->phi_dims[l] = phi_dims[l];
+  for (int l = 0; l <= n_gamma; ++l) s->gam_dims[l] = gamma_dims[l];
+  for (int l = 0; l < n_phi; ++l) s->phi_act[l] = phi_acts[l];
+  for (int l = 0; l < n_gamma; ++l) s->gam_act[l] = gamma_acts[l];
+  return NGPDE_OK;
+}
+
+extern "C" {
+
+int32_t ngpde_node_vmh_supported(const ngpde_graph_t *g, int32_t hd, int32_t pd, int32_t n_phi, const int32_t *phi_dims, const int32_t *phi_acts,
+                                 int32_t n_gamma, const int32_t *gamma_dims, const int32_t *gamma_acts, int32_t aggr) {
+  VmhShape s;
+  if (!g || vmh_shape(hd, pd, n_phi, phi_dims, phi_acts, n_gamma, gamma_dims, gamma_acts, aggr, &s) != NGPDE_OK) return 0;
+  return node_vmh_supported(g, s) ? 1 : 0;
+}
+
+int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, const float *pos, int32_t n_phi, const int32_t *phi_dims,
+                              const int32_t *phi_acts, int32_t n_gamma, const int32_t *gamma_dims, const int32_t *gamma_acts, int32_t aggr,
+                              int32_t tableau, int32_t n_steps, double dt, int32_t with_backward, ngpde_node_vmh_t **out) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(g != nullptr && out != nullptr && pos != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_create: NULL argument");
+  *out = nullptr;
+  NGPDE_REQUIRE(tableau == NGPDE_TABLEAU_EULER || tableau == NGPDE_TABLEAU_TSIT5, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_create: unknown tableau %d", tableau);
+  NGPDE_REQUIRE(n_steps >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_create: n_steps >= 1 required");
+  VmhShape shape;
+  int32_t st = vmh_shape(hd, pd, n_phi, phi_dims, phi_acts, n_gamma, gamma_dims, gamma_acts, aggr, &shape);
+  if (st) return st;
+  NGPDE_REQUIRE(node_vmh_supported(g, shape), NGPDE_ERR_UNSUPPORTED,
+                "ngpde_node_vmh_create: needs a scalar state, 1-3 position coordinates, MLPs of 2-4 Dense layers up to 64 wide with identity / relu / "
+                "tanh / sigmoid hidden and identity output layers, + or mean aggregation, tiles that fit the LDS halo in both directions and "
+                "at most one 16-row half tile per CU (use the generic solver otherwise)");
+  ngpde_node_vmh *p = new (std::nothrow) ngpde_node_vmh();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_create: out of host memory");
+  p->g = g; p->shape = shape; p->n_steps = n_steps; p->with_bwd = with_backward != 0;
+  const Tableau tb = make_tableau(tableau);
+  const int S = p->S = tb.S;
+  float cf[48] = {0}, cb[64] = {0};
+  for (int i = 0; i < S; ++i) {   // forward: node_persistent.hip's table; adjoint: cb[i][i] = dt b_i, cb[i][j] (j > i) = dt a[j][i]
+    const std::vector<double> &row = (i == S - 1) ? tb.b : tb.a[i + 1];
+    for (int j = 0; j < i; ++j) cf[i * 6 + j] = (float)(dt * row[j]);
+    cf[36 + i] = (float)(dt * row[i]);
+    cb[i * 8 + i] = (float)(dt * tb.b[i]);
+    for (int j = i + 1; j < S; ++j) cb[i * 8 + j] = (float)(dt * tb.a[j][i]);
+  }
+  const size_t N = (size_t)g->n_nodes, E = (size_t)std::max<int64_t>(g->n_edges, 1), evals = (size_t)n_steps * S;
+  auto alloc = [&](float **ptr, size_t floats, bool zero) -> int32_t {
+    NGPDE_HIP_CHECK(hipMalloc((void **)ptr, std::max<size_t>(floats * 4, 256)));
+    if (zero) NGPDE_HIP_CHECK(hipMemset(*ptr, 0, std::max<size_t>(floats * 4, 256)));
+    return NGPDE_OK;
+  };
+  auto step = [&](int32_t r) { if (st == NGPDE_OK) st = r; };
+  const float coef_unused[90] = {0.f};
+  step(node_persistent_setup(g, coef_unused, &p->persist, false));
+  if (st == NGPDE_OK) step(alloc(&p->pos, N * pd, false));
+  if (st == NGPDE_OK && hipMemcpy(p->pos, pos, N * pd * 4, hipMemcpyDeviceToDevice) != hipSuccess) st = fail(NGPDE_ERR_HIP, "ngpde_node_vmh_create: copying the positions failed");
+  if (st == NGPDE_OK) step(alloc(&p->cf, 48, false));
+  if (st == NGPDE_OK) step(alloc(&p->cb, 64, false));
+  if (st == NGPDE_OK) step(alloc(&p->x, 2 * N, true));
+  if (st == NGPDE_OK && p->with_bwd) {
+    // (zeroed once: the padded columns of a layer's rows are never written, and the weight-pullback GEMMs read whole 64-wide rows)
+    const size_t tp = (size_t)n_phi * evals * E * 64, tg = (size_t)n_gamma * evals * N * 64;
+    step(alloc(&p->tape_phi, tp, true));
+    if (st == NGPDE_OK) step(alloc(&p->tape_gam, tg, true));
+    if (st == NGPDE_OK) step(alloc(&p->dz_phi, tp, true));
+    if (st == NGPDE_OK) step(alloc(&p->dz_gam, tg, true));
+    if (st == NGPDE_OK) step(alloc(&p->dsrc, 2 * E, true));
+    p->tape_bytes = 2 * (tp + tg) * 4;
+    p->partial_floats = (size_t)dense_weight_chunks((int64_t)(evals * E), 64, 64) * 65 * 64 + 64;
+    p->partial_floats = std::max(p->partial_floats, (size_t)dense_weight_chunks((int64_t)(evals * N), 64, 64) * 65 * 64 + 64);
+    if (st == NGPDE_OK) step(alloc(&p->partial, p->partial_floats, false));
+    if (st == NGPDE_OK) step(alloc(&p->dwpad, 64 * 64 + 64, false));
+  }
+  if (st == NGPDE_OK && (hipMemcpy(p->cf, cf, sizeof cf, hipMemcpyHostToDevice) != hipSuccess ||
+                         hipMemcpy(p->cb, cb, sizeof cb, hipMemcpyHostToDevice) != hipSuccess))
+    st = fail(NGPDE_ERR_HIP, "ngpde_node_vmh_create: copying the coefficient tables failed");
+  if (st != NGPDE_OK) {
+    const std::string keep = last_error();
+    node_vmh_free(p);
+    last_error() = keep;
+    return st;
+  }
+  *out = p;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_node_vmh_destroy(ngpde_node_vmh_t *p) {
+  NGPDE_RANGE();
+  node_vmh_free(p);
+  return NGPDE_OK;
+}
+
+size_t ngpde_node_vmh_tape_bytes(const ngpde_node_vmh_t *p) { return p ? p->tape_bytes : 0; }
+
+int32_t ngpde_node_vmh_fault(ngpde_node_vmh_t *p, ngpde_stream_t stream_, int32_t *fault) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_fault: NULL argument");
+  NGPDE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  *fault = (p->persist.fault_host && *p->persist.fault_host) ? 1 : 0;
+  return NGPDE_OK;
+}
+
+static void vmh_fill(const ngpde_node_vmh *p, VmhLaunch &a, const float *const *phi_w, const float *const *phi_b, const float *const *gam_w,
+                     const float *const *gam_b) {
+  a.g = p->g; a.ps = &p->persist; a.shape = p->shape; a.n_steps = p->n_steps; a.S = p->S; a.pos = p->pos;
+  for (int l = 0; l < p->shape.n_phi; ++l) { a.phi_w[l] = phi_w[l]; a.phi_b[l] = phi_b ? phi_b[l] : nullptr; }
+  for (int l = 0; l < p->shape.n_gam; ++l) { a.gam_w[l] = gam_w[l]; a.gam_b[l] = gam_b ? gam_b[l] : nullptr; }
+  a.x0 = p->x; a.x1 = p->x + p->g->n_nodes; a.tape_phi = p->tape_phi; a.tape_gam = p->tape_gam; a.dz_phi = p->dz_phi; a.dz_gam = p->dz_gam;
+  a.dsrc = p->dsrc; a.cf = p->cf; a.cb = p->cb;
+}
+
+int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *p, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
+                               const float *const *gamma_weight, const float *const *gamma_bias, float *uT, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: plan is NULL");
+  if (p->g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(u0 && uT && phi_weight && gamma_weight && u0 != uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: NULL argument (or uT aliasing u0)");
+  for (int l = 0; l < p->shape.n_phi; ++l) NGPDE_REQUIRE(phi_weight[l], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: phi weight %d is NULL", l);
+  for (int l = 0; l < p->shape.n_gam; ++l) NGPDE_REQUIRE(gamma_weight[l], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: gamma weight %d is NULL", l);
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_vmh_forward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_vmh_fault); destroy the plan");
+  VmhLaunch a;
+  vmh_fill(p, a, phi_weight, phi_bias, gamma_weight, gamma_bias);
+  a.u_in = u0; a.u_out = uT;
+  const int32_t st = launch_node_vmh_fwd(a, (hipStream_t)stream_);
+  if (st == NGPDE_OK) p->solved = true;
+  return st;
+}
+
+int32_t ngpde_node_vmh_backward(ngpde_node_vmh_t *p, const float *const *phi_weight, const float *const *gamma_weight, const float *duT,
+                                float *du0, float *const *dphi_weight, float *const *dphi_bias, float *const *dgamma_weight,
+                                float *const *dgamma_bias, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward: plan is NULL");
+  NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_vmh_backward: the plan was created without a backward pass");
+  NGPDE_REQUIRE(p->solved, NGPDE_ERR_STATE, "ngpde_node_vmh_backward: no forward solve has filled the tape");
+  NGPDE_REQUIRE(phi_weight && gamma_weight && duT && du0 && dphi_weight && dgamma_weight, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward: NULL argument");
+  NGPDE_REQUIRE(!(p->persist.fault_host && *p->persist.fault_host), NGPDE_ERR_STATE,
+                "ngpde_node_vmh_backward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_vmh_fault); destroy the plan");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t N = (size_t)p->g->n_nodes, E = (size_t)p->g->n_edges, evals = (size_t)p->n_steps * p->S;
+  if (du0 != duT) NGPDE_HIP_CHECK(hipMemcpyAsync(du0, duT, N * 4, hipMemcpyDeviceToDevice, stream));
+  VmhLaunch a;
+  vmh_fill(p, a, phi_weight, nullptr, gamma_weight, nullptr);
+  a.lam = du0;
+  int32_t st;
+  if ((st = launch_node_vmh_bwd(a, stream))) return st;
+  // dW_l = A_l^T dZ_l, db_l = column sums of dZ_l over the rows of ALL evaluations: one weight-pullback GEMM per layer on the tapes
+  auto layer_grad = [&](const float *tape, const float *dz, size_t rows, int din, int dout, float *dw, float *db) -> int32_t {
+    SegTable segs;
+    segs.n = 1; segs.ptr[0] = tape; segs.width[0] = 64; segs.row_div[0] = 1; segs.vec[0] = 1;
+    for (int k = 1; k <= 4; ++k) segs.offset[k] = 64;
+    int32_t s2;
+    if ((s2 = launch_dense_seg_bwd_weight((int64_t)rows, segs, 64, 64, dz, p->dwpad, p->dwpad + 64 * 64, p->partial, stream))) return s2;
+    if (dw && (s2 = launch_vmh_copy_block(p->dwpad, 64, dw, dout, din, dout, stream))) return s2;
+    if (db && (s2 = launch_vmh_copy_block(p->dwpad + 64 * 64, 64, db, dout, 1, dout, stream))) return s2;
+    return NGPDE_OK;
+  };
+  for (int l = 0; l < p->shape.n_phi; ++l)
+    if ((st = layer_grad(p->tape_phi + (size_t)l * evals * E * 64, p->dz_phi + (size_t)l * evals * E * 64, evals * E, p->shape.phi_dims[l],
+                         p->shape.phi_dims[l + 1], dphi_weight[l], dphi_bias ? dphi_bias[l] : nullptr)))
+      return st;
+  for (int l = 0; l < p->shape.n_gam; ++l)
+    if ((st = layer_grad(p->tape_gam + (size_t)l * evals * N * 64, p->dz_gam + (size_t)l * evals * N * 64, evals * N, p->shape.gam_dims[l],
+                         p->shape.gam_dims[l + 1], dgamma_weight[l], dgamma_bias ? dgamma_bias[l] : nullptr)))
+      return st;
+  return NGPDE_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,724 @@
+// node_vmh.hip -- NeuralODE(VMHConv(phi, gamma)) device-resident: the fixed-step solve and its discrete adjoint as ONE persistent
+// launch each (+ one weight-pullback GEMM per Dense layer behind the adjoint).
+// [caller in the reference: docs/src/tutorials/VMH.md:75-89 (NeuralODE(VMHConv(phi, gamma), tspan, Tsit5(); ...)); layer:
+//  src/layers.jl:308-332: m_i = mean_j phi([h_i; h_j - h_i; x_j - x_i]), h' = gamma([h_i; m_i])]
+//
+// The tutorial's graph is small (3 000 nodes, 18 000 edges) and its MLPs are deep (4 Dense layers each, 60 wide): through the
+// generic solver a right-hand side + pullback is 38 dependent launches of one under-filled wave of workgroups each (~250 us).  Here:
+//   * a workgroup (4 waves, one per SIMD, one workgroup per CU) owns 16 target nodes -- half of one 32-row tile of the handle's
+//     locality schedule -- and all their in-edges for the whole solve;
+//   * every Dense layer of phi and gamma is held in LDS zero-padded to 64 x 64, UNPADDED in stride and XOR-swizzled (16 KB per
+//     matrix: eight matrices are 128 KB; gcn_tile.h, mfma_rows_times_bswz64 has the read pattern);
+//   * the message MLP runs per 16-edge wave slice as a chain of TRANSPOSED fp32 MFMA products in registers (edge_mlp_fused.hip),
+//     the node MLP on the 16 rows with its four output-column blocks dealt to the four waves;
+//   * tiles exchange ONE float per node per right-hand-side evaluation (the scalar state h): write-through stores, per-workgroup
+//     phase flags, bounded spins, abort word (node_persistent.hip's protocol);
+//   * the forward tapes every layer's INPUT rows; the adjoint reads them back (activation derivatives come from the taped
+//     outputs: identity / relu / tanh / sigmoid), walks both MLPs backwards, tapes every layer's dz, and exchanges one float per
+//     EDGE (the gradient towards the edge's source: the by-source sum crosses tiles) per evaluation;
+//   * parameter gradients are NOT accumulated in the launch (eight 64 x 64 accumulators per workgroup fit neither registers nor
+//     LDS): dW_l = A_l^T dZ_l is one large weight-pullback GEMM per layer over the tapes of all evaluations afterwards
+//     (dense_mfma.hip), at full-chip efficiency.
+// State width 1 (a scalar field, as in the tutorial), positions of 1-3 coordinates, MLPs of 2-4 layers up to 64 wide with
+// identity output layers; graphs of at most 2 x (CUs) half tiles.  Anything else keeps the generic solver.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+#include "device_utils.h"
+#include "persistent_mem.h"
+
+namespace ngpde {
+
+namespace {
+
+constexpr int VT = 256;               // threads per workgroup
+constexpr int VW = 64;                // padded layer width
+constexpr int VR = 16;                // target rows per workgroup
+constexpr int VTS = VW + 4;           // staging tile stride
+constexpr int VMaxE = VR * kSlotWidth;   // edges a workgroup may own
+constexpr int VNbr = 64;
+
+struct VmhMeta {
+  const int4 *sched_t;
+  const int2 *halo_t, *info_t;
+  const uint8_t *slots_t;
+  const int *rowptr_s, *xpos_s;
+  const int *nbr;                    // [n_tiles][64] tile-level wait lists (node_persistent_setup)
+  unsigned *flags, *abort_word;      // one 128-byte line per WORKGROUP (2 per tile)
+  int n_tiles, n_nodes;
+  const float *pos;                  // [N][pd]
+  int pd, aggr;
+  int n_phi, n_gam;
+  int phi_din[kVmhMaxL], phi_dout[kVmhMaxL], phi_act[kVmhMaxL];
+  int gam_din[kVmhMaxL], gam_dout[kVmhMaxL], gam_act[kVmhMaxL];
+  const float *phi_w[kVmhMaxL], *phi_b[kVmhMaxL], *gam_w[kVmhMaxL], *gam_b[kVmhMaxL];
+  size_t n_edges;
+  int evals;                         // right-hand-side evaluations of a solve: the tapes are [layer][evals][rows][64] (a layer's rows contiguous)
+};
+
+// derivative of an activation from its OUTPUT y = act(z)
+__device__ __forceinline__ float dact_out(int act, float y) {
+  switch (act) {
+    case NGPDE_ACT_RELU: return y > 0.f ? 1.0f : 0.0f;
+    case NGPDE_ACT_TANH: return 1.0f - y * y;
+    case NGPDE_ACT_SIGMOID: return y * (1.0f - y);
+    default: return 1.0f;
+  }
+}
+__device__ __forceinline__ float4 f4_dact_out(int act, float4 y) {
+  return make_float4(dact_out(act, y.x), dact_out(act, y.y), dact_out(act, y.z), dact_out(act, y.w));
+}
+
+struct VCtx {
+  int tid, lane, wave, g16, q, ei, kq;
+  int wg, tile, half, hcount, total;
+  bool row_valid;          // (threads of group g16: row g16 is a node)
+  int node;                // node of row g16
+};
+
+// static tables of the workgroup in LDS
+struct VTabs {
+  float *W;                // [(n_phi + n_gam)][64][64] swizzled
+  float *S;                // [64][VTS] staging
+  float *bias;             // [8][64]
+  float *hh;               // [96] h of the halo nodes
+  float *px;               // [96][4] positions of the halo nodes
+  int *hnode;              // [96]
+  int *off;                // [17]
+  int *rs;                 // [16]
+  int *rnode;              // [16]
+  float *inv;              // [16]
+  unsigned short *edge;    // [VMaxE]  r | slot << 8
+  float *misc;             // [64]: coefficients etc.
+  int *s_ok;
+};
+
+__device__ __forceinline__ size_t vtabs_dyn_floats(int n_mats) { return (size_t)n_mats * VW * VW + (size_t)VW * VTS; }
+
+// W (row-major [din][dout]) -> LDS 64 x 64 zero-padded, row j / quad k4 at quad k4 ^ (j & 15).
+// transpose = true: row j = OUTPUT j, columns = inputs (the forward's A operand rows: W^T); false: row j = INPUT j (W itself)
+__device__ __forceinline__ void stage_weight(const float *w, int din, int dout, float *dst, int tid, bool transpose) {
+  for (int idx = tid; idx < VW * VW / 4; idx += VT) {
+    const int j = idx >> 4, k4 = idx & 15;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * k4 + r;
+      if (transpose) v[r] = (w && k < din && j < dout) ? w[(size_t)k * dout + j] : 0.f;
+      else v[r] = (w && j < din && k < dout) ? w[(size_t)j * dout + k] : 0.f;
+    }
+    *reinterpret_cast<float4 *>(&dst[j * VW + 4 * (k4 ^ (j & 15))]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// rows (block*16 + ei) of a staged matrix, quad (4 cb + kq): the A-operand fragment of one transposed MFMA k-block
+__device__ __forceinline__ float4 wfrag(const float *mat, int block, int cb, int ei, int kq) {
+  return *reinterpret_cast<const float4 *>(&mat[(block * 16 + ei) * VW + 4 * ((4 * cb + kq) ^ ei)]);
+}
+
+__device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs &t) {
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.g16 = c.tid >> 4;
+  c.q = c.tid & 15;
+  c.ei = c.lane & 15;
+  c.kq = c.lane >> 4;
+  c.wg = blockIdx.x;
+  c.tile = c.wg >> 1;
+  c.half = c.wg & 1;
+  const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + c.g16];
+  c.row_valid = sc.x >= 0;
+  c.node = max(sc.x, 0);
+  c.hcount = __builtin_amdgcn_readfirstlane(m.info_t[c.tile].x);
+  if (c.q == 0) {
+    const int d = sc.x >= 0 ? sc.z : 0;
+    t.off[c.g16 + 1] = d;
+    t.rs[c.g16] = sc.y;
+    t.rnode[c.g16] = sc.x;
+    t.inv[c.g16] = m.aggr == NGPDE_AGGR_MEAN ? (d > 0 ? 1.0f / (float)d : 0.f) : 1.0f;
+    if (c.g16 == 0) t.off[0] = 0;
+  }
+  if (c.tid < kHaloCap) {
+    const int nd = m.halo_t[(size_t)c.tile * kHaloCap + c.tid].x;
+    t.hnode[c.tid] = nd;
+    for (int k = 0; k < 4; ++k) t.px[c.tid * 4 + k] = (c.tid < c.hcount && k < m.pd) ? m.pos[(size_t)nd * m.pd + k] : 0.f;
+    t.hh[c.tid] = 0.f;
+  }
+  if (c.tid == 0) *t.s_ok = 1;
+  __syncthreads();
+  if (c.tid < VR) {
+    int v = t.off[c.tid + 1];
+#pragma unroll
+    for (int o = 1; o < VR; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (c.tid >= o) v += u;
+    }
+    t.off[c.tid + 1] = v;
+  }
+  __syncthreads();
+  c.total = t.off[VR];
+  {   // edge table: k -> (row, halo slot of the source)
+    const int lo = t.off[c.g16], hi = t.off[c.g16 + 1];
+    const uint8_t *sl = m.slots_t + ((size_t)c.tile * kTileRows + c.half * VR + c.g16) * kSlotWidth;
+    for (int k = lo + c.q; k < hi; k += 16) t.edge[k] = (unsigned short)(c.g16 | ((unsigned)sl[k - lo] << 8));
+  }
+  __syncthreads();
+}
+
+// wave 0 polls: lane l < 63 watches both halves of tile nbr[l], lane 0 also this tile's other half, lane 63 the abort word
+__device__ __forceinline__ bool vmh_wait(const VmhMeta &m, const VCtx &c, int need, int *s_ok) {
+  if (need <= 0) return true;
+  if (c.wave == 0) {
+    const int nb = c.lane < 63 ? m.nbr[(size_t)c.tile * VNbr + c.lane] : -1;
+    const unsigned *a0 = (c.lane == 63) ? m.abort_word : (nb >= 0 ? m.flags + 32 * (2 * nb) : nullptr);
+    const unsigned *a1 = (c.lane < 63 && nb >= 0) ? m.flags + 32 * (2 * nb + 1) : nullptr;
+    const unsigned *a2 = (c.lane == 0) ? m.flags + 32 * (c.wg ^ 1) : nullptr;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (unsigned it = 1;; ++it) {
+      unsigned f0 = (c.lane == 63) ? 0u : (unsigned)need, f1 = (unsigned)need, f2 = (unsigned)need;
+      if (a0) f0 = __hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a1) f1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a2) f2 = __hip_atomic_load(a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__any((int)(c.lane == 63 && f0 != 0))) { ok = false; break; }
+      if (__all((int)(c.lane == 63 || (f0 >= (unsigned)need && f1 >= (unsigned)need && f2 >= (unsigned)need)))) break;
+      if ((it & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (c.lane == 0) __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (c.lane == 0) *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+__device__ __forceinline__ void vmh_publish(const VmhMeta &m, const VCtx &c, int ph) {
+  wait_vmcnt0();
+  __syncthreads();
+  if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.wg, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ float ld_sc1(const float *p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward solve
+// ---------------------------------------------------------------------------------------------------------------------
+struct VmhFwdK {
+  VmhMeta m;
+  int n_steps, S;
+  const float *u_in;
+  float *u_out, *x0, *x1;     // the exchanged stage input [N], ping-pong
+  float *tape_phi;            // [n_phi][evals][E][64] inputs of phi's layers (p order), or null (forward-only plan)
+  float *tape_gam;            // [n_gam][evals][N][64] inputs of gamma's layers
+  const float *cf;            // [42] forward coefficient table (node_persistent.hip's layout)
+};
+
+__global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  __shared__ __attribute__((aligned(16))) float s_bias[2 * kVmhMaxL * VW];
+  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VR], s_misc[64];
+  __shared__ int s_hnode[kHaloCap], s_off[VR + 1], s_rs[VR], s_rnode[VR], s_okw[2];
+  __shared__ unsigned short s_edge[VMaxE];
+  const VmhMeta &m = p.m;
+  const int n_mats = m.n_phi + m.n_gam;
+  VTabs t;
+  t.W = dyn; t.S = dyn + (size_t)n_mats * VW * VW; t.bias = s_bias; t.hh = s_hh; t.px = s_px; t.hnode = s_hnode; t.off = s_off; t.rs = s_rs;
+  t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
+  VCtx c;
+  vctx_init(m, c, t);
+  for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, true);
+  for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, true);
+  if (c.tid < VW) {
+    for (int l = 0; l < m.n_phi; ++l) t.bias[l * VW + c.tid] = (m.phi_b[l] && c.tid < m.phi_dout[l]) ? m.phi_b[l][c.tid] : 0.f;
+    for (int l = 0; l < m.n_gam; ++l) t.bias[(kVmhMaxL + l) * VW + c.tid] = (m.gam_b[l] && c.tid < m.gam_dout[l]) ? m.gam_b[l][c.tid] : 0.f;
+  }
+  if (c.tid < 42) t.misc[c.tid] = p.cf[c.tid];
+  __syncthreads();
+  const int ei = c.ei, kq = c.kq;
+  const int Mw = m.phi_dout[m.n_phi - 1];      // message width
+  const int n_rounds = (c.total + 63) >> 6;
+  const size_t E = m.n_edges, N = (size_t)m.n_nodes;
+  // the 16 row lanes (tid < 16 <-> row tid) keep the Runge-Kutta state of their node
+  float su = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f, sk4 = 0.f;
+  const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  if (my_node >= 0) su = p.u_in[my_node];
+  bool ok = true;
+  int ph = 0;
+  for (int n = 0; n < p.n_steps && ok; ++n) {
+    for (int i = 0; i < p.S && ok; ++i) {
+      ++ph;
+      const float *X = ph == 1 ? p.u_in : (((ph - 1) & 1) ? p.x1 : p.x0);
+      float *Xn = (ph & 1) ? p.x1 : p.x0;
+      const size_t ev = (size_t)(n * p.S + i);
+      if (!vmh_wait(m, c, ph - 1, t.s_ok)) { ok = false; break; }
+      if (c.tid < c.hcount) t.hh[c.tid] = ph == 1 ? X[t.hnode[c.tid]] : ld_sc1(X + t.hnode[c.tid]);
+      __syncthreads();
+      // ---- message MLP per 16-edge wave slice, messages summed per target through the staging tile
+      float4 racc = f4_zero();
+      const int lo = t.off[c.g16], hi = t.off[c.g16 + 1];
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        const int c0 = rd * 64;
+        const bool wave_on = c0 + c.wave * 16 < c.total;   // wave-uniform
+        const int k = c0 + c.wave * 16 + ei;
+        const bool valid = k < c.total;
+        float4 msg[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+        if (wave_on) {
+          const unsigned ew = t.edge[valid ? k : 0];
+          const int r = ew & 0xff, slot = ew >> 8, trow = c.half * VR + r;
+          const size_t pe = (size_t)(t.rs[r] + (k - t.off[r]));
+          const float hi_ = t.hh[trow], hj = t.hh[slot];
+          float feat[8] = {hi_, hj - hi_, t.px[slot * 4] - t.px[trow * 4], t.px[slot * 4 + 1] - t.px[trow * 4 + 1],
+                           t.px[slot * 4 + 2] - t.px[trow * 4 + 2], 0.f, 0.f, 0.f};
+          if (m.pd < 3) feat[4] = 0.f;
+          if (m.pd < 2) feat[3] = 0.f;
+          float4 a[4];
+          a[0] = valid ? (kq == 0 ? make_float4(feat[0], feat[1], feat[2], feat[3]) : (kq == 1 ? make_float4(feat[4], 0.f, 0.f, 0.f) : f4_zero()))
+                       : f4_zero();
+          a[1] = a[2] = a[3] = f4_zero();
+          for (int l = 0; l < m.n_phi; ++l) {
+            const int din = m.phi_din[l], dw = m.phi_dout[l];
+            const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
+            if (p.tape_phi && valid) {
+              float *row = p.tape_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct)
+                if (ct < n_ct) __builtin_nontemporal_store((f4v){a[ct].x, a[ct].y, a[ct].z, a[ct].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(row + 16 * ct)));
+            }
+            const float *mat = t.W + (size_t)l * VW * VW;
+            float4 z[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              if (mt < n_mt) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                  if (ct < n_ct) {
+                    const float4 w4 = wfrag(mat, mt, ct, ei, kq);
+                    acc = mfma16(w4.x, a[ct].x, acc);
+                    acc = mfma16(w4.y, a[ct].y, acc);
+                    acc = mfma16(w4.z, a[ct].z, acc);
+                    acc = mfma16(w4.w, a[ct].w, acc);
+                  }
+                }
+                const float4 b4 = *reinterpret_cast<const float4 *>(&t.bias[l * VW + 16 * mt + 4 * kq]);
+                z[mt] = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+              }
+            }
+            if (l + 1 < m.n_phi) {
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) a[mt] = (valid && 16 * mt + 4 * kq < dw) ? f4_act(m.phi_act[l], z[mt]) : f4_zero();
+            } else {
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) msg[mt] = (valid && 16 * mt + 4 * kq < dw) ? z[mt] : f4_zero();
+            }
+          }
+        }
+        float *mine = t.S + (size_t)(c.wave * 16) * VTS;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * VTS + 16 * mt + 4 * kq]) = msg[mt];
+        __syncthreads();
+        {
+          const float *base = t.S + 4 * c.q - c0 * VTS;
+          for (int kk = max(lo, c0); kk < min(hi, c0 + 64); ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * VTS));
+        }
+        __syncthreads();
+      }
+      // ---- node MLP on the 16 rows: input [h_i; m_i; 0 ...] in tile A (rows 0..15 of the staging area), layers ping-pong A <-> B
+      float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
+      {
+        const float iv = t.inv[c.g16];
+        const float4 mm = f4_scale(iv, racc);
+        float *row = tA + c.g16 * VTS;
+        // columns 1 + 4 q .. 4 + 4 q (the message sits behind the state value); columns beyond the message width are zero already
+        if (1 + 4 * c.q < VW) row[1 + 4 * c.q] = mm.x;
+        if (2 + 4 * c.q < VW) row[2 + 4 * c.q] = mm.y;
+        if (3 + 4 * c.q < VW) row[3 + 4 * c.q] = mm.z;
+        if (4 + 4 * c.q < VW) row[4 + 4 * c.q] = mm.w;
+        if (c.q == 0) row[0] = t.hh[c.half * VR + c.g16];
+      }
+      __syncthreads();
+      for (int l = 0; l < m.n_gam; ++l) {
+        const int din = m.gam_din[l], dw = m.gam_dout[l];
+        const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
+        const float *tin = (l & 1) ? tB : tA;
+        float *tout = (l & 1) ? tA : tB;
+        if (p.tape_gam && c.row_valid && 4 * c.q < 16 * n_ct)
+          *reinterpret_cast<float4 *>(p.tape_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = *reinterpret_cast<const float4 *>(&tin[c.g16 * VTS + 4 * c.q]);
+        const int mt = c.wave;   // the wave's block of output columns
+        float4 zo = f4_zero();
+        if (mt < n_mt) {
+          const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int ct = 0; ct < n_ct; ++ct) {
+            const float4 w4 = wfrag(mat, mt, ct, ei, kq);
+            const float4 av = *reinterpret_cast<const float4 *>(&tin[ei * VTS + 16 * ct + 4 * kq]);
+            acc = mfma16(w4.x, av.x, acc);
+            acc = mfma16(w4.y, av.y, acc);
+            acc = mfma16(w4.z, av.z, acc);
+            acc = mfma16(w4.w, av.w, acc);
+          }
+          const float4 b4 = *reinterpret_cast<const float4 *>(&t.bias[(kVmhMaxL + l) * VW + 16 * mt + 4 * kq]);
+          const float4 z = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+          zo = (16 * mt + 4 * kq < dw) ? f4_act(m.gam_act[l], z) : f4_zero();
+          // (padded columns inside a quad: the staged weights and biases are zero there, act(0) = 0 for the supported activations
+          // except sigmoid -- the next layer's weight rows for them are zero, so they never feed a real column)
+        }
+        *reinterpret_cast<float4 *>(&tout[ei * VTS + 16 * mt + 4 * kq]) = zo;
+        __syncthreads();
+      }
+      // ---- stage derivative k_i = gamma's output (column 0); the next stage input (or the step update) of the own nodes
+      const float *tfin = (m.n_gam & 1) ? tB : tA;
+      if (c.tid < VR) {
+        const float yv = my_node >= 0 ? tfin[c.tid * VTS] : 0.f;
+        sk0 = i == 0 ? yv : sk0; sk1 = i == 1 ? yv : sk1; sk2 = i == 2 ? yv : sk2; sk3 = i == 3 ? yv : sk3; sk4 = i == 4 ? yv : sk4;
+        float v = t.misc[36 + i] * yv;
+        v = fmaf(1.0f, su, v);
+        v = fmaf(t.misc[i * 6 + 0], sk0, v); v = fmaf(t.misc[i * 6 + 1], sk1, v); v = fmaf(t.misc[i * 6 + 2], sk2, v);
+        v = fmaf(t.misc[i * 6 + 3], sk3, v); v = fmaf(t.misc[i * 6 + 4], sk4, v);
+        if (i == p.S - 1) su = v;
+        if (my_node >= 0) st_sc1(Xn + my_node, v);
+      }
+      vmh_publish(m, c, ph);
+    }
+  }
+  // (u_out may alias u_in: a workgroup writes its rows only after every reader of its u0 rows is past its first phase -- the
+  // host takes this plan for solves of at least two right-hand-side evaluations)
+  if (my_node >= 0) p.u_out[my_node] = ok ? su : __int_as_float(0x7fc00000);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// discrete adjoint
+// ---------------------------------------------------------------------------------------------------------------------
+struct VmhBwdK {
+  VmhMeta m;
+  int n_steps, S;
+  float *lam;                 // [N] in: dL/du(T); out: dL/du0
+  const float *tape_phi, *tape_gam;
+  float *dz_phi, *dz_gam;     // same shapes: every layer's dz
+  float *dsrc0, *dsrc1;       // [E] the per-edge gradient towards the edge's SOURCE (p order), ping-pong by phase parity
+  const float *cb;            // [S][8]: cb[i][i] = dt b_i, cb[i][j] (j > i) = dt a[j][i]
+};
+
+__global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VR], s_misc[64], s_es[VMaxE], s_row[VR * 4];
+  __shared__ int s_hnode[kHaloCap], s_off[VR + 1], s_rs[VR], s_rnode[VR], s_okw[2], s_srcpos[VR * kSlotWidth], s_srcdeg[VR];
+  __shared__ unsigned short s_edge[VMaxE];
+  const VmhMeta &m = p.m;
+  const int n_mats = m.n_phi + m.n_gam;
+  VTabs t;
+  t.W = dyn; t.S = dyn + (size_t)n_mats * VW * VW; t.bias = nullptr; t.hh = s_hh; t.px = s_px; t.hnode = s_hnode; t.off = s_off; t.rs = s_rs;
+  t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
+  VCtx c;
+  vctx_init(m, c, t);
+  for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, false);
+  for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
+  if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
+  {   // positions, in the by-target order, of the out-edges of the own nodes (static): the by-source gather's addresses
+    const int nd = t.rnode[c.g16];
+    const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
+    if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
+    for (int j = c.q; j < kSlotWidth; j += 16) s_srcpos[c.g16 * kSlotWidth + j] = j < dg ? m.xpos_s[rp + j] : 0;
+  }
+  __syncthreads();
+  const int ei = c.ei, kq = c.kq;
+  const int Mw = m.phi_dout[m.n_phi - 1];
+  const int n_rounds = (c.total + 63) >> 6;
+  const size_t E = m.n_edges, N = (size_t)m.n_nodes;
+  const int S = p.S;
+  // the 16 row lanes keep lambda and the stage adjoints of their node
+  const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  float lam = my_node >= 0 ? p.lam[my_node] : 0.f;
+  float ub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
+  bool ok = true;
+  int ph = 0;
+  for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+    for (int i = S - 1; i >= 0 && ok; --i) {
+      ++ph;
+      const size_t ev = (size_t)(n * S + i);
+      float *dsrc = (ph & 1) ? p.dsrc1 : p.dsrc0;
+      // ---- K-bar_i of the own nodes -> the gradient of gamma's output (column 0 of tile A)
+      if (c.tid < VR) {
+        float kbar = t.misc[i * 8 + i] * lam;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j > i && j < S) kbar = fmaf(t.misc[i * 8 + j], ub[j], kbar);
+        s_row[c.tid] = my_node >= 0 ? kbar : 0.f;
+      }
+      __syncthreads();
+      *reinterpret_cast<float4 *>(&tA[c.g16 * VTS + 4 * c.q]) = (c.q == 0) ? make_float4(s_row[c.g16], 0.f, 0.f, 0.f) : f4_zero();
+      __syncthreads();
+      // ---- gamma backwards: g (tile) -> dz_l = g . act'(output of layer l) -> tape; g <- W_l dz_l
+      for (int l = m.n_gam - 1; l >= 0; --l) {
+        const int din = m.gam_din[l], dw = m.gam_dout[l];
+        const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
+        float *tg = ((m.n_gam - 1 - l) & 1) ? tB : tA;       // holds g (gradient of layer l's output), becomes dz in place
+        float *tn = ((m.n_gam - 1 - l) & 1) ? tA : tB;
+        {
+          float4 g = *reinterpret_cast<const float4 *>(&tg[c.g16 * VTS + 4 * c.q]);
+          if (l + 1 < m.n_gam && c.row_valid && 4 * c.q < 16 * n_mt) {
+            const float4 y = *reinterpret_cast<const float4 *>(p.tape_gam + (((size_t)(l + 1) * m.evals + ev) * N + c.node) * VW + 4 * c.q);
+            g = f4_mul(g, f4_dact_out(m.gam_act[l], y));
+          }
+          if (!(c.row_valid && 4 * c.q < dw)) g = f4_zero();
+          *reinterpret_cast<float4 *>(&tg[c.g16 * VTS + 4 * c.q]) = g;
+          if (c.row_valid && 4 * c.q < 16 * n_mt) *reinterpret_cast<float4 *>(p.dz_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = g;
+        }
+        __syncthreads();
+        const int ct = c.wave;   // the wave's block of INPUT columns
+        float4 go = f4_zero();
+        if (ct < n_ct) {
+          const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int mt = 0; mt < n_mt; ++mt) {
+            const float4 w4 = wfrag(mat, ct, mt, ei, kq);
+            const float4 dv = *reinterpret_cast<const float4 *>(&tg[ei * VTS + 16 * mt + 4 * kq]);
+            acc = mfma16(w4.x, dv.x, acc);
+            acc = mfma16(w4.y, dv.y, acc);
+            acc = mfma16(w4.z, dv.z, acc);
+            acc = mfma16(w4.w, dv.w, acc);
+          }
+          go = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        *reinterpret_cast<float4 *>(&tn[ei * VTS + 16 * ct + 4 * kq]) = go;
+        __syncthreads();
+      }
+      // d(gamma's input) = [dh_i; dm_i]: tile tgin, row r; the message gradient is scaled by 1 / deg (mean)
+      const float *tgin = (m.n_gam & 1) ? tB : tA;
+      // ---- phi backwards per 16-edge wave slice
+      for (int k = c.tid; k < c.total; k += VT) s_es[k] = 0.f;
+      __syncthreads();
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        const int c0 = rd * 64;
+        const bool wave_on = c0 + c.wave * 16 < c.total;
+        const int k = c0 + c.wave * 16 + ei;
+        const bool valid = k < c.total;
+        if (wave_on) {
+          const unsigned ew = t.edge[valid ? k : 0];
+          const int r = ew & 0xff;
+          const size_t pe = (size_t)(t.rs[r] + (k - t.off[r]));
+          const float inv = valid ? t.inv[r] : 0.f;
+          float4 g[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int f = 16 * mt + 4 * kq;
+            const float *src = tgin + r * VTS + 1 + f;     // (the message sits behind the state value in gamma's input)
+            g[mt] = (valid && f < Mw) ? make_float4(inv * src[0], f + 1 < Mw ? inv * src[1] : 0.f, f + 2 < Mw ? inv * src[2] : 0.f, f + 3 < Mw ? inv * src[3] : 0.f)
+                                      : f4_zero();
+          }
+          for (int l = m.n_phi - 1; l >= 0; --l) {
+            const int din = m.phi_din[l], dw = m.phi_dout[l];
+            const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
+            if (l + 1 < m.n_phi) {
+              const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe) * VW + 4 * kq;
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) {
+                if (mt < n_mt) {
+                  const float4 y = valid ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero();
+                  g[mt] = f4_mul(g[mt], f4_dact_out(m.phi_act[l], y));
+                }
+              }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              if (!(valid && 16 * mt + 4 * kq < dw)) g[mt] = f4_zero();
+            if (valid) {
+              float *zrow = p.dz_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt)
+                if (mt < n_mt) __builtin_nontemporal_store((f4v){g[mt].x, g[mt].y, g[mt].z, g[mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
+            }
+            const float *mat = t.W + (size_t)l * VW * VW;
+            float4 gn[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              if (ct < n_ct) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                  if (mt < n_mt) {
+                    const float4 w4 = wfrag(mat, ct, mt, ei, kq);
+                    acc = mfma16(w4.x, g[mt].x, acc);
+                    acc = mfma16(w4.y, g[mt].y, acc);
+                    acc = mfma16(w4.z, g[mt].z, acc);
+                    acc = mfma16(w4.w, g[mt].w, acc);
+                  }
+                }
+                gn[ct] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+              }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) g[ct] = gn[ct];
+          }
+          // d(input) = [d h_i, d (h_j - h_i), ...]: lane kq = 0 holds features 0..3
+          if (valid && kq == 0) {
+            s_es[k] = g[0].x - g[0].y;          // towards the target
+            st_sc1(dsrc + pe, g[0].y);          // towards the source: gathered by its owner after the hand-off
+          }
+        }
+      }
+      __syncthreads();
+      if (c.tid < VR) {   // what the own rows get from their own edges and from gamma
+        float a = tgin[c.tid * VTS];
+        for (int k = t.off[c.tid]; k < t.off[c.tid + 1]; ++k) a += s_es[k];
+        s_row[VR + c.tid] = a;
+      }
+      vmh_publish(m, c, ph);
+      if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
+      {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
+        const int dg = s_srcdeg[c.g16];
+        float a = 0.f;
+        if (c.q < dg) a = ld_sc1(dsrc + s_srcpos[c.g16 * kSlotWidth + c.q]);
+        if (c.q + 16 < dg) a += ld_sc1(dsrc + s_srcpos[c.g16 * kSlotWidth + c.q + 16]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
+        if (c.q == 0) s_row[2 * VR + c.g16] = a;
+      }
+      __syncthreads();
+      if (c.tid < VR) {
+        const float ubar = my_node >= 0 ? s_row[VR + c.tid] + s_row[2 * VR + c.tid] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) ub[j] = (j == i) ? ubar : ub[j];
+        if (i == 0) {
+          float v = lam;
+          for (int j = 0; j < S; ++j) v += ub[j];
+          lam = v;
+        }
+      }
+    }
+  }
+  if (my_node >= 0) p.lam[my_node] = ok ? lam : __int_as_float(0x7fc00000);
+}
+
+__global__ void vmh_set_word_kernel(unsigned *w, unsigned v) {
+  if (threadIdx.x == 0) *w = v;
+}
+__global__ void vmh_latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
+  if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
+}
+__global__ void vmh_copy_block_kernel(const float *src, int sp, float *dst, int dp, int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows * cols) dst[(idx / cols) * dp + idx % cols] = src[(idx / cols) * sp + idx % cols];
+}
+
+size_t vmh_lds_bytes(int n_mats) { return ((size_t)n_mats * VW * VW + (size_t)VW * VTS) * sizeof(float); }
+
+}  // namespace
+
+bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s) {
+  const char *off = std::getenv("NGPDE_NO_VMH_NODE");
+  if (off && off[0] == '1') return false;
+  if (!g || !g->has_norm || !g->by_t.halo_ok || !g->by_s.halo_ok) return false;
+  if (s.hd != 1 || s.pd < 1 || s.pd > 3) return false;
+  if (s.n_phi < 2 || s.n_phi > kVmhMaxL || s.n_gam < 2 || s.n_gam > kVmhMaxL) return false;
+  if (s.aggr != NGPDE_AGGR_SUM && s.aggr != NGPDE_AGGR_MEAN) return false;
+  auto act_ok = [](int a) { return a == NGPDE_ACT_IDENTITY || a == NGPDE_ACT_RELU || a == NGPDE_ACT_TANH || a == NGPDE_ACT_SIGMOID; };
+  if (s.phi_dims[0] != 2 * s.hd + s.pd || s.gam_dims[0] != s.hd + s.phi_dims[s.n_phi] || s.gam_dims[s.n_gam] != s.hd) return false;
+  for (int l = 0; l <= s.n_phi; ++l)
+    if (s.phi_dims[l] < 1 || s.phi_dims[l] > VW) return false;
+  for (int l = 0; l <= s.n_gam; ++l)
+    if (s.gam_dims[l] < 1 || s.gam_dims[l] > VW) return false;
+  if (s.phi_dims[s.n_phi] + s.hd > VW) return false;
+  for (int l = 0; l < s.n_phi; ++l)
+    if (!act_ok(s.phi_act[l])) return false;
+  for (int l = 0; l < s.n_gam; ++l)
+    if (!act_ok(s.gam_act[l])) return false;
+  if (s.phi_act[s.n_phi - 1] != NGPDE_ACT_IDENTITY || s.gam_act[s.n_gam - 1] != NGPDE_ACT_IDENTITY) return false;   // (output layers)
+  if (g->max_in_degree > kSlotWidth || g->max_out_degree > kSlotWidth) return false;
+  int dev = 0, cus = 0, occ = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  const size_t lds = vmh_lds_bytes(s.n_phi + s.n_gam);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  int of = 0, ob = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, node_vmh_fwd_kernel, VT, lds) != hipSuccess) of = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, node_vmh_bwd_kernel, VT, lds) != hipSuccess) ob = 0;
+  occ = std::min(of, ob);
+  const int wgs = 2 * (g->n_sched / kTileRows);
+  return occ >= 1 && wgs <= cus * occ;
+}
+
+static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
+  const ngpde_graph *g = a.g;
+  m.sched_t = g->by_t.sched; m.halo_t = g->by_t.halo; m.info_t = g->by_t.tile_info; m.slots_t = g->by_t.slots;
+  m.rowptr_s = g->by_s.rowptr; m.xpos_s = g->by_s.xpos;
+  m.nbr = a.ps->nbr;
+  m.n_tiles = g->n_sched / kTileRows;
+  m.flags = a.ps->sync; m.abort_word = a.ps->sync + (size_t)(2 * m.n_tiles) * 32;
+  m.n_nodes = (int)g->n_nodes; m.pos = a.pos; m.pd = a.shape.pd; m.aggr = a.shape.aggr;
+  m.n_phi = a.shape.n_phi; m.n_gam = a.shape.n_gam;
+  for (int l = 0; l < kVmhMaxL; ++l) {
+    m.phi_din[l] = l < m.n_phi ? a.shape.phi_dims[l] : 0; m.phi_dout[l] = l < m.n_phi ? a.shape.phi_dims[l + 1] : 0;
+    m.phi_act[l] = l < m.n_phi ? a.shape.phi_act[l] : 0;
+    m.gam_din[l] = l < m.n_gam ? a.shape.gam_dims[l] : 0; m.gam_dout[l] = l < m.n_gam ? a.shape.gam_dims[l + 1] : 0;
+    m.gam_act[l] = l < m.n_gam ? a.shape.gam_act[l] : 0;
+    m.phi_w[l] = l < m.n_phi ? a.phi_w[l] : nullptr; m.phi_b[l] = l < m.n_phi ? a.phi_b[l] : nullptr;
+    m.gam_w[l] = l < m.n_gam ? a.gam_w[l] : nullptr; m.gam_b[l] = l < m.n_gam ? a.gam_b[l] : nullptr;
+  }
+  m.n_edges = (size_t)g->n_edges;
+  m.evals = a.n_steps * a.S;
+}
+
+int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  VmhFwdK k;
+  fill_meta(k.m, a);
+  {
+    const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
+    if (fa && fa[0] == '1') hipLaunchKernelGGL(vmh_set_word_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, 1u);
+  }
+  k.n_steps = a.n_steps; k.S = a.S; k.u_in = a.u_in; k.u_out = a.u_out; k.x0 = a.x0; k.x1 = a.x1;
+  k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.cf = a.cf;
+  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam);
+  NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(node_vmh_fwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
+  NGPDE_LAUNCH_CHECK("node_vmh_fwd_kernel");
+  hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+  return turn.leave();
+}
+
+int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
+  const NodePersist &ps = *a.ps;
+  int32_t st;
+  PersistentTurn turn;
+  if ((st = turn.enter(stream))) return st;
+  if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
+  VmhBwdK k;
+  fill_meta(k.m, a);
+  k.n_steps = a.n_steps; k.S = a.S; k.lam = a.lam; k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.dz_phi = a.dz_phi; k.dz_gam = a.dz_gam;
+  k.dsrc0 = a.dsrc; k.dsrc1 = a.dsrc + k.m.n_edges; k.cb = a.cb;
+  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam);
+  NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(node_vmh_bwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
+  NGPDE_LAUNCH_CHECK("node_vmh_bwd_kernel");
+  hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+  return turn.leave();
+}
+
+int32_t launch_vmh_copy_block(const float *src, int sp, float *dst, int dp, int rows, int cols, hipStream_t stream) {
+  if (rows * cols == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(vmh_copy_block_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, stream, src, sp, dst, dp, rows, cols);
+  NGPDE_LAUNCH_CHECK("vmh_copy_block_kernel");
+  return NGPDE_OK;
+}
+
+}  // namespace ngpde

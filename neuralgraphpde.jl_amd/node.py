@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from .graphs import GNNGraph
 from .layers import AbstractExplicitLayer, Chain, GCNConv, rows_of
-from .layers_mp import GATConv
+from .layers_mp import GATConv, VMHConv, _dense_stack, _node_data, _wt_b
 
 _TSIT5_A = [
     [],
@@ -226,6 +226,96 @@ class _NodeGatFn(torch.autograd.Function):
                                                _lib.ptr(dwt), _lib.ptr(da), _lib.ptr(db), _lib.current_stream()))
         plan._pending = False
         return du0, dwt, da, db, None
+
+
+class _VmhPlan:
+    """Device-resident solve + discrete adjoint with VMHConv(phi, gamma) as the right-hand side (ngpde_node_vmh_*: one persistent
+    launch per direction + one weight-pullback GEMM per Dense layer).  Holds the tape of ONE solve (every layer's input rows and
+    dz rows of every right-hand-side evaluation)."""
+
+    def __init__(self, handle, pos, pd, phi_dims, phi_acts, gam_dims, gam_acts, aggr, tableau, n_steps, dt, with_backward):
+        self.lib = _lib.load()
+        _lib.flush_destroy()
+        self.handle = handle
+        self.ptr = None
+        self.gen = 0
+        self.members = 1
+        self.n_nodes = int(handle._n_nodes)
+        self.n_phi, self.n_gam = len(phi_acts), len(gam_acts)
+        out = C.c_void_p()
+        ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
+        _lib.check(self.lib.ngpde_node_vmh_create(handle.ptr, 1, int(pd), _lib.ptr(pos), self.n_phi, ia(phi_dims), ia(phi_acts), self.n_gam,
+                                                  ia(gam_dims), ia(gam_acts), int(aggr), _lib.TABLEAU[tableau], int(n_steps), float(dt),
+                                                  int(with_backward), C.byref(out)))
+        self.ptr = out
+
+    def tape_bytes(self):
+        return int(self.lib.ngpde_node_vmh_tape_bytes(self.ptr))
+
+    def flags(self):
+        return {"persistent_fwd", "persistent_bwd", "vmh"}
+
+    def fault(self):
+        f = C.c_int32()
+        _lib.check(self.lib.ngpde_node_vmh_fault(self.ptr, _lib.current_stream(), C.byref(f)))
+        return bool(f.value)
+
+    claim = _GatPlan.claim
+    busy = _GatPlan.busy
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.destroy_later("ngpde_node_vmh_destroy", self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def _ptrs(ts):
+    return (C.c_void_p * max(len(ts), 1))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+class _NodeVmhFn(torch.autograd.Function):
+    """u(T) = solve(du/dt = VMHConv(phi, gamma)(u)) on the device-resident plan; args: u [N], plan, n_phi, then per layer (weight
+    [in][out], bias or None) of phi followed by gamma's"""
+
+    @staticmethod
+    def forward(ctx, u, plan, *wb):
+        lib = _lib.load()
+        u = u.contiguous()
+        ws = [w.contiguous() for w in wb[0::2]]
+        bs = [None if b is None else b.contiguous() for b in wb[1::2]]
+        n_phi = plan.n_phi
+        uT = torch.empty_like(u)
+        _lib.check(lib.ngpde_node_vmh_forward(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]), _ptrs(bs[n_phi:]),
+                                              _lib.ptr(uT), _lib.current_stream()))
+        plan.gen += 1
+        ctx.plan, ctx.gen, ctx.token = plan, plan.gen, plan.claim()
+        ctx.save_for_backward(*ws)
+        ctx.has_bias = [b is not None for b in bs]
+        return uT
+
+    @staticmethod
+    def backward(ctx, duT):
+        lib = _lib.load()
+        plan = ctx.plan
+        if ctx.gen != plan.gen:
+            raise _lib.NgpdeError(_lib.ERR_STATE, "NeuralODE: another forward solve has replaced this solve's tape")
+        ws = list(ctx.saved_tensors)
+        n_phi = plan.n_phi
+        dev = ws[0].device
+        du0 = torch.empty_like(duT, memory_format=torch.contiguous_format)
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty((w.shape[1],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
+        _lib.check(lib.ngpde_node_vmh_backward(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), _lib.ptr(duT.contiguous()), _lib.ptr(du0),
+                                               _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]), _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]),
+                                               _lib.current_stream()))
+        plan._pending = False
+        grads = []
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return (du0, None, *grads)
 
 
 # ---- any right-hand side: explicit RK stepping with every combination as ONE library launch ---------------------------------
@@ -624,6 +714,58 @@ class NeuralODE(AbstractExplicitLayer):
         pool.append(plan)
         return plan
 
+    def vmh_plan_for(self, ps, st, u, needs_grad):
+        """the device-resident plan when the right-hand side is VMHConv(phi, gamma) on a scalar state in the shapes the library takes
+        (ngpde_node_vmh_supported: docs/src/tutorials/VMH.md:75-89's model); (plan, weights and biases) or None"""
+        m = self.model
+        if not (isinstance(m, VMHConv) and u.is_cuda and u.dim() == 2 and u.shape[1] == 1):
+            return None
+        g = st["graph"]
+        if list(g.ndata) != ["x"] or getattr(g, "_members", None):
+            return None
+        try:
+            phi, gam = _dense_stack(m.ϕ, ps["ϕ"], "ϕ"), _dense_stack(m.γ, ps["γ"], "γ")
+        except _lib.NgpdeError:
+            return None
+        pos = _node_data(g, u.device)
+        pd = pos.shape[1]
+        wb, dims, acts = [], [], []
+        for stack in (phi, gam):
+            d, a = [], []
+            for layer, p in stack:
+                wt, b = _wt_b(p)
+                wb += [wt, b]
+                d.append(wt.shape[0])
+                a.append(layer.act)
+            d.append(rows_of(stack[-1][1]["weight"]).shape[1])
+            dims.append(d)
+            acts.append(a)
+        aggr = _lib.AGGR.get(m.aggr)
+        if aggr is None:
+            return None
+        handle = g.handle()
+        lib = _lib.load()
+        ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
+        key = ("vmh", id(handle), tuple(dims[0]), tuple(acts[0]), tuple(dims[1]), tuple(acts[1]), aggr, bool(needs_grad))
+        pool = self._plans.get(key)
+        if pool is None:
+            if not lib.ngpde_node_vmh_supported(handle.ptr, 1, pd, len(acts[0]), ia(dims[0]), ia(acts[0]), len(acts[1]), ia(dims[1]), ia(acts[1]), aggr):
+                return None
+            pool = self._plans[key] = []
+            while len(self._plans) > self.max_plans:
+                self._plans.pop(next(iter(self._plans)))
+        else:
+            self._plans[key] = self._plans.pop(key)
+        for plan in pool:
+            if not (needs_grad and plan.busy()):
+                return plan, wb
+        if len(pool) >= self.max_outstanding:
+            raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
+                                                  "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
+        plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
+        pool.append(plan)
+        return plan, wb
+
     def __call__(self, x, ps, st):
         u = rows_of(x)
         needs_grad = torch.is_grad_enabled() and (u.requires_grad or any(
@@ -656,6 +798,11 @@ class NeuralODE(AbstractExplicitLayer):
                                              f"{a.numel()} entries, expected 2 x {gm.out_chs} x {gm.heads}")
             uT = _NodeGatFn.apply(u, w, a, b, gplan)
             return uT.T, st
+        vplan = self.vmh_plan_for(ps, st, u, needs_grad) if not self.save_every else None
+        if vplan is not None:
+            plan_v, wb = vplan
+            uT = _NodeVmhFn.apply(u.reshape(-1), plan_v, *wb)
+            return uT.reshape(u.shape).T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch
         if not u.is_cuda:
