@@ -5,7 +5,7 @@
 //
 // The tutorial's graph is small (3 000 nodes, 18 000 edges) and its MLPs are deep (4 Dense layers each, 60 wide): through the
 // generic solver a right-hand side + pullback is 38 dependent launches of one under-filled wave of workgroups each (~250 us).  Here:
-//   * a workgroup (4 waves, one per SIMD, one workgroup per CU) owns 16 target nodes -- half of one 32-row tile of the handle's
+//   * a workgroup (8 waves, one workgroup per CU) owns 16 target nodes -- half of one 32-row tile of the handle's
 //     locality schedule -- and all their in-edges for the whole solve;
 //   * every Dense layer of phi and gamma is held in LDS zero-padded to 64 x 64, UNPADDED in stride and XOR-swizzled (16 KB per
 //     matrix: eight matrices are 128 KB; gcn_tile.h, mfma_rows_times_bswz64 has the read pattern);
@@ -35,7 +35,8 @@ namespace ngpde {
 
 namespace {
 
-constexpr int VT = 256;               // threads per workgroup
+constexpr int VT = 512;               // threads per workgroup: 8 waves, two per SIMD (the tutorial graph's 96 edges per workgroup are one round)
+constexpr int VROUND = (VT / 64) * 16;   // edges per round: one 16-edge slice per wave
 constexpr int VW = 64;                // padded layer width
 constexpr int VR = 16;                // target rows per workgroup
 constexpr int VTS = VW + 4;           // staging tile stride
@@ -131,11 +132,11 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   c.wg = blockIdx.x;
   c.tile = c.wg >> 1;
   c.half = c.wg & 1;
-  const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + c.g16];
-  c.row_valid = sc.x >= 0;
+  const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + min(c.g16, VR - 1)];   // (lane groups 16.. have no row)
+  c.row_valid = sc.x >= 0 && c.g16 < VR;
   c.node = max(sc.x, 0);
   c.hcount = __builtin_amdgcn_readfirstlane(m.info_t[c.tile].x);
-  if (c.q == 0) {
+  if (c.q == 0 && c.g16 < VR) {
     const int d = sc.x >= 0 ? sc.z : 0;
     t.off[c.g16 + 1] = d;
     t.rs[c.g16] = sc.y;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   }
   __syncthreads();
   c.total = t.off[VR];
-  {   // edge table: k -> (row, halo slot of the source)
+  if (c.g16 < VR) {   // edge table: k -> (row, halo slot of the source)
     const int lo = t.off[c.g16], hi = t.off[c.g16 + 1];
     const uint8_t *sl = m.slots_t + ((size_t)c.tile * kTileRows + c.half * VR + c.g16) * kSlotWidth;
     for (int k = lo + c.q; k < hi; k += 16) t.edge[k] = (unsigned short)(c.g16 | ((unsigned)sl[k - lo] << 8));
@@ -248,8 +249,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   __syncthreads();
   const int ei = c.ei, kq = c.kq;
   const int Mw = m.phi_dout[m.n_phi - 1];      // message width
-  const int n_rounds = (c.total + 63) >> 6;
+  const int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
+  const int rg = min(c.g16, VR - 1);   // the row of this lane group (groups 16.. idle in the row-wise steps)
+  const bool has_row = c.g16 < VR;
   // the 16 row lanes (tid < 16 <-> row tid) keep the Runge-Kutta state of their node
   float su = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f, sk4 = 0.f;
   const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
@@ -267,9 +270,15 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       __syncthreads();
       // ---- message MLP per 16-edge wave slice, messages summed per target through the staging tile
       float4 racc = f4_zero();
-      const int lo = t.off[c.g16], hi = t.off[c.g16 + 1];
+      const int lo = t.off[rg], hi = has_row ? t.off[rg + 1] : t.off[rg];
+      // with ONE round (the usual case) the tape rows of the slice stay in registers and leave behind the publish: the drain in
+      // front of the flag then waits for the 16 state values alone, not for ~100 KB of tape on its way to memory
+      const bool defer = p.tape_phi != nullptr && n_rounds == 1;
+      float4 ta[kVmhMaxL][4];
+      size_t pe_keep = 0;
+      bool valid_keep = false;
       for (int rd = 0; rd < n_rounds; ++rd) {
-        const int c0 = rd * 64;
+        const int c0 = rd * VROUND;
         const bool wave_on = c0 + c.wave * 16 < c.total;   // wave-uniform
         const int k = c0 + c.wave * 16 + ei;
         const bool valid = k < c.total;
@@ -290,7 +299,14 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
           for (int l = 0; l < m.n_phi; ++l) {
             const int din = m.phi_din[l], dw = m.phi_dout[l];
             const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
-            if (p.tape_phi && valid) {
+            if (defer) {
+#pragma unroll
+              for (int ll = 0; ll < kVmhMaxL; ++ll)   // (static indices: the rows stay in registers)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) ta[ll][ct] = f4_sel(ll == l, a[ct], ta[ll][ct]);
+              pe_keep = pe;
+              valid_keep = valid;
+            } else if (p.tape_phi && valid) {
               float *row = p.tape_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
 #pragma unroll
               for (int ct = 0; ct < 4; ++ct)
@@ -325,28 +341,34 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
             }
           }
         }
-        float *mine = t.S + (size_t)(c.wave * 16) * VTS;
+        // messages through the 64-row staging tile, four waves at a time; lane group r sums the rows of target r in edge order
+        for (int sub = 0; sub < VT / 256; ++sub) {
+          const int cs = c0 + 64 * sub;
+          if ((c.wave >> 2) == sub) {
+            float *mine = t.S + (size_t)((c.wave & 3) * 16) * VTS;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * VTS + 16 * mt + 4 * kq]) = msg[mt];
-        __syncthreads();
-        {
-          const float *base = t.S + 4 * c.q - c0 * VTS;
-          for (int kk = max(lo, c0); kk < min(hi, c0 + 64); ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * VTS));
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * VTS + 16 * mt + 4 * kq]) = msg[mt];
+          }
+          __syncthreads();
+          {
+            const float *base = t.S + 4 * c.q - cs * VTS;
+            for (int kk = max(lo, cs); kk < min(hi, cs + 64); ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * VTS));
+          }
+          __syncthreads();
         }
-        __syncthreads();
       }
       // ---- node MLP on the 16 rows: input [h_i; m_i; 0 ...] in tile A (rows 0..15 of the staging area), layers ping-pong A <-> B
       float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
-      {
-        const float iv = t.inv[c.g16];
+      if (has_row) {
+        const float iv = t.inv[rg];
         const float4 mm = f4_scale(iv, racc);
-        float *row = tA + c.g16 * VTS;
+        float *row = tA + rg * VTS;
         // columns 1 + 4 q .. 4 + 4 q (the message sits behind the state value); columns beyond the message width are zero already
         if (1 + 4 * c.q < VW) row[1 + 4 * c.q] = mm.x;
         if (2 + 4 * c.q < VW) row[2 + 4 * c.q] = mm.y;
         if (3 + 4 * c.q < VW) row[3 + 4 * c.q] = mm.z;
         if (4 + 4 * c.q < VW) row[4 + 4 * c.q] = mm.w;
-        if (c.q == 0) row[0] = t.hh[c.half * VR + c.g16];
+        if (c.q == 0) row[0] = t.hh[c.half * VR + rg];
       }
       __syncthreads();
       for (int l = 0; l < m.n_gam; ++l) {
@@ -355,10 +377,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         const float *tin = (l & 1) ? tB : tA;
         float *tout = (l & 1) ? tA : tB;
         if (p.tape_gam && c.row_valid && 4 * c.q < 16 * n_ct)
-          *reinterpret_cast<float4 *>(p.tape_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = *reinterpret_cast<const float4 *>(&tin[c.g16 * VTS + 4 * c.q]);
-        const int mt = c.wave;   // the wave's block of output columns
+          *reinterpret_cast<float4 *>(p.tape_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = *reinterpret_cast<const float4 *>(&tin[rg * VTS + 4 * c.q]);
+        const int mt = c.wave;   // the wave's block of output columns (waves 4.. idle here)
         float4 zo = f4_zero();
-        if (mt < n_mt) {
+        if (mt < n_mt && mt < 4) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           for (int ct = 0; ct < n_ct; ++ct) {
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
           // (padded columns inside a quad: the staged weights and biases are zero there, act(0) = 0 for the supported activations
           // except sigmoid -- the next layer's weight rows for them are zero, so they never feed a real column)
         }
-        *reinterpret_cast<float4 *>(&tout[ei * VTS + 16 * mt + 4 * kq]) = zo;
+        if (mt < 4) *reinterpret_cast<float4 *>(&tout[ei * VTS + 16 * mt + 4 * kq]) = zo;
         __syncthreads();
       }
       // ---- stage derivative k_i = gamma's output (column 0); the next stage input (or the step update) of the own nodes
@@ -391,6 +413,17 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         if (my_node >= 0) st_sc1(Xn + my_node, v);
       }
       vmh_publish(m, c, ph);
+      if (defer && valid_keep) {
+#pragma unroll
+        for (int l = 0; l < kVmhMaxL; ++l) {
+          if (l >= m.n_phi) break;
+          const int n_ct = (m.phi_din[l] + 15) >> 4;
+          float *row = p.tape_phi + (((size_t)l * m.evals + ev) * E + pe_keep) * VW + 4 * kq;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            if (ct < n_ct) __builtin_nontemporal_store((f4v){ta[l][ct].x, ta[l][ct].y, ta[l][ct].z, ta[l][ct].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(row + 16 * ct)));
+        }
+      }
     }
   }
   // (u_out may alias u_in: a workgroup writes its rows only after every reader of its u0 rows is past its first phase -- the
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, false);
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
   if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
-  {   // positions, in the by-target order, of the out-edges of the own nodes (static): the by-source gather's addresses
+  if (c.g16 < VR) {   // positions, in the by-target order, of the out-edges of the own nodes (static): the by-source gather's addresses
     const int nd = t.rnode[c.g16];
     const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
     if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
@@ -435,9 +468,11 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   __syncthreads();
   const int ei = c.ei, kq = c.kq;
   const int Mw = m.phi_dout[m.n_phi - 1];
-  const int n_rounds = (c.total + 63) >> 6;
+  const int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
   const int S = p.S;
+  const int rg = min(c.g16, VR - 1);
+  const bool has_row = c.g16 < VR;
   // the 16 row lanes keep lambda and the stage adjoints of their node
   const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
   float lam = my_node >= 0 ? p.lam[my_node] : 0.f;
@@ -459,7 +494,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         s_row[c.tid] = my_node >= 0 ? kbar : 0.f;
       }
       __syncthreads();
-      *reinterpret_cast<float4 *>(&tA[c.g16 * VTS + 4 * c.q]) = (c.q == 0) ? make_float4(s_row[c.g16], 0.f, 0.f, 0.f) : f4_zero();
+      if (has_row) *reinterpret_cast<float4 *>(&tA[rg * VTS + 4 * c.q]) = (c.q == 0) ? make_float4(s_row[rg], 0.f, 0.f, 0.f) : f4_zero();
       __syncthreads();
       // ---- gamma backwards: g (tile) -> dz_l = g . act'(output of layer l) -> tape; g <- W_l dz_l
       for (int l = m.n_gam - 1; l >= 0; --l) {
@@ -467,20 +502,20 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
         float *tg = ((m.n_gam - 1 - l) & 1) ? tB : tA;       // holds g (gradient of layer l's output), becomes dz in place
         float *tn = ((m.n_gam - 1 - l) & 1) ? tA : tB;
-        {
-          float4 g = *reinterpret_cast<const float4 *>(&tg[c.g16 * VTS + 4 * c.q]);
+        if (has_row) {
+          float4 g = *reinterpret_cast<const float4 *>(&tg[rg * VTS + 4 * c.q]);
           if (l + 1 < m.n_gam && c.row_valid && 4 * c.q < 16 * n_mt) {
             const float4 y = *reinterpret_cast<const float4 *>(p.tape_gam + (((size_t)(l + 1) * m.evals + ev) * N + c.node) * VW + 4 * c.q);
             g = f4_mul(g, f4_dact_out(m.gam_act[l], y));
           }
           if (!(c.row_valid && 4 * c.q < dw)) g = f4_zero();
-          *reinterpret_cast<float4 *>(&tg[c.g16 * VTS + 4 * c.q]) = g;
+          *reinterpret_cast<float4 *>(&tg[rg * VTS + 4 * c.q]) = g;
           if (c.row_valid && 4 * c.q < 16 * n_mt) *reinterpret_cast<float4 *>(p.dz_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = g;
         }
         __syncthreads();
-        const int ct = c.wave;   // the wave's block of INPUT columns
+        const int ct = c.wave;   // the wave's block of INPUT columns (waves 4.. idle here)
         float4 go = f4_zero();
-        if (ct < n_ct) {
+        if (ct < n_ct && ct < 4) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           for (int mt = 0; mt < n_mt; ++mt) {
@@ -493,7 +528,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           }
           go = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        *reinterpret_cast<float4 *>(&tn[ei * VTS + 16 * ct + 4 * kq]) = go;
+        if (ct < 4) *reinterpret_cast<float4 *>(&tn[ei * VTS + 16 * ct + 4 * kq]) = go;
         __syncthreads();
       }
       // d(gamma's input) = [dh_i; dm_i]: tile tgin, row r; the message gradient is scaled by 1 / deg (mean)
@@ -501,8 +536,12 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       // ---- phi backwards per 16-edge wave slice
       for (int k = c.tid; k < c.total; k += VT) s_es[k] = 0.f;
       __syncthreads();
+      const bool defer = n_rounds == 1;   // (see the forward kernel: the dz rows leave behind the publish)
+      float4 tz[kVmhMaxL][4];
+      size_t pe_keep = 0;
+      bool valid_keep = false;
       for (int rd = 0; rd < n_rounds; ++rd) {
-        const int c0 = rd * 64;
+        const int c0 = rd * VROUND;
         const bool wave_on = c0 + c.wave * 16 < c.total;
         const int k = c0 + c.wave * 16 + ei;
         const bool valid = k < c.total;
@@ -510,6 +549,8 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           const unsigned ew = t.edge[valid ? k : 0];
           const int r = ew & 0xff;
           const size_t pe = (size_t)(t.rs[r] + (k - t.off[r]));
+          pe_keep = pe;
+          valid_keep = valid;
           const float inv = valid ? t.inv[r] : 0.f;
           float4 g[4];
 #pragma unroll
@@ -535,7 +576,12 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
               if (!(valid && 16 * mt + 4 * kq < dw)) g[mt] = f4_zero();
-            if (valid) {
+            if (defer) {
+#pragma unroll
+              for (int ll = 0; ll < kVmhMaxL; ++ll)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) tz[ll][mt] = f4_sel(ll == l, g[mt], tz[ll][mt]);
+            } else if (valid) {
               float *zrow = p.dz_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt)
@@ -577,15 +623,26 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         s_row[VR + c.tid] = a;
       }
       vmh_publish(m, c, ph);
+      if (defer && valid_keep) {
+#pragma unroll
+        for (int l = 0; l < kVmhMaxL; ++l) {
+          if (l >= m.n_phi) break;
+          const int n_mt = (m.phi_dout[l] + 15) >> 4;
+          float *zrow = p.dz_phi + (((size_t)l * m.evals + ev) * E + pe_keep) * VW + 4 * kq;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            if (mt < n_mt) __builtin_nontemporal_store((f4v){tz[l][mt].x, tz[l][mt].y, tz[l][mt].z, tz[l][mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
+        }
+      }
       if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
       {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
-        const int dg = s_srcdeg[c.g16];
+        const int dg = has_row ? s_srcdeg[rg] : 0;
         float a = 0.f;
-        if (c.q < dg) a = ld_sc1(dsrc + s_srcpos[c.g16 * kSlotWidth + c.q]);
-        if (c.q + 16 < dg) a += ld_sc1(dsrc + s_srcpos[c.g16 * kSlotWidth + c.q + 16]);
+        if (c.q < dg) a = ld_sc1(dsrc + s_srcpos[rg * kSlotWidth + c.q]);
+        if (c.q + 16 < dg) a += ld_sc1(dsrc + s_srcpos[rg * kSlotWidth + c.q + 16]);
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
-        if (c.q == 0) s_row[2 * VR + c.g16] = a;
+        if (c.q == 0 && has_row) s_row[2 * VR + rg] = a;
       }
       __syncthreads();
       if (c.tid < VR) {
