@@ -372,9 +372,28 @@ def secondary(dev, world, rank, dist):
             uT, _ = nodev(uv, psv_, stv_)
             uT.sum().backward()
         msv = _time_ms(solvev, 5)
+        flags_v = sorted({f for pool in nodev._plans.values() for pl in pool for f in pl.flags()})
         out["VMH_node_tsit5x20"] = {"nodes": nv, "edges": int(gv.num_edges), "ode_steps": steps_v, "ms_solve_forward_backward": round(msv, 3),
                                     "value": round(steps_v / (msv * 1e-3), 1), "unit": "ODE-steps/s",
-                                    "path": "NeuralODE(VMHConv, capture=True): HIP-graph replay of the generic solver"}
+                                    "path": ("device-resident plan (ngpde_node_vmh_*): one forward and one adjoint launch per solve + a "
+                                             "weight-pullback GEMM per layer over the tapes") if "vmh" in flags_v
+                                            else "NeuralODE(VMHConv, capture=True): HIP-graph replay of the generic solver",
+                                    "plan_flags": flags_v}
+        if "vmh" in flags_v:   # the same solve on the generic solver (every stage the layer's own kernels), captured into HIP graphs
+            os.environ["NGPDE_NO_VMH_NODE"] = "1"
+            try:
+                nodeg = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gv), solver="tsit5", n_steps=steps_v, dt=0.2 / steps_v, capture=True)
+
+                def solveg():
+                    for v in [uv] + _grad_leaves(psv_):
+                        v.grad = None
+                    uT, _ = nodeg(uv, psv_, stv_)
+                    uT.sum().backward()
+                msg_ = _time_ms(solveg, 5)
+                out["VMH_node_tsit5x20"]["generic_captured_ms"] = round(msg_, 3)
+                out["VMH_node_tsit5x20"]["generic_captured_value"] = round(steps_v / (msg_ * 1e-3), 1)
+            finally:
+                os.environ.pop("NGPDE_NO_VMH_NODE", None)
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))

@@ -43,6 +43,21 @@ constexpr int VTS = VW + 4;           // staging tile stride
 constexpr int VMaxE = VR * kSlotWidth;   // edges a workgroup may own
 constexpr int VNbr = 64;
 
+#ifdef NGPDE_STAMPS
+// diagnostic build only (tools/stamps_vmh.py): shader-clock stamps of thread 0 at 8 points of the first g_vst_max phases
+unsigned long long *g_vst_base = nullptr;
+int g_vst_max = 0;
+#define NGPDE_VST_FIELD unsigned long long *stamps; int stamps_max;
+#define NGPDE_VST(m, ph, k)                                                                                   \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && (m).stamps && (ph) <= (m).stamps_max)                                             \
+      (m).stamps[((size_t)blockIdx.x * (m).stamps_max + ((ph) - 1)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define NGPDE_VST_FIELD
+#define NGPDE_VST(m, ph, k)
+#endif
+
 struct VmhMeta {
   const int4 *sched_t;
   const int2 *halo_t, *info_t;
@@ -59,6 +74,8 @@ struct VmhMeta {
   const float *phi_w[kVmhMaxL], *phi_b[kVmhMaxL], *gam_w[kVmhMaxL], *gam_b[kVmhMaxL];
   size_t n_edges;
   int evals;                         // right-hand-side evaluations of a solve: the tapes are [layer][evals][rows][64] (a layer's rows contiguous)
+  int s_rows;                        // rows of the staging tile: 64, 96 or 128 (what the LDS left by the weights allows)
+  NGPDE_VST_FIELD
 };
 
 // derivative of an activation from its OUTPUT y = act(z)
@@ -70,8 +87,19 @@ __device__ __forceinline__ float dact_out(int act, float y) {
     default: return 1.0f;
   }
 }
-__device__ __forceinline__ float4 f4_dact_out(int act, float4 y) {
-  return make_float4(dact_out(act, y.x), dact_out(act, y.y), dact_out(act, y.z), dact_out(act, y.w));
+template <int ACT, int N>
+__device__ __forceinline__ void dact_out_n(float4 (&y)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = make_float4(dact_out(ACT, y[i].x), dact_out(ACT, y[i].y), dact_out(ACT, y[i].z), dact_out(ACT, y[i].w));
+}
+template <int N>
+__device__ __forceinline__ void f4n_dact_out(int act, float4 (&y)[N]) {   // y <- act'(.) from the outputs y, one uniform switch
+  switch (act) {
+    case NGPDE_ACT_RELU: dact_out_n<NGPDE_ACT_RELU>(y); break;
+    case NGPDE_ACT_TANH: dact_out_n<NGPDE_ACT_TANH>(y); break;
+    case NGPDE_ACT_SIGMOID: dact_out_n<NGPDE_ACT_SIGMOID>(y); break;
+    default: dact_out_n<NGPDE_ACT_IDENTITY>(y); break;
+  }
 }
 
 struct VCtx {
@@ -119,6 +147,39 @@ __device__ __forceinline__ void stage_weight(const float *w, int din, int dout, 
 // rows (block*16 + ei) of a staged matrix, quad (4 cb + kq): the A-operand fragment of one transposed MFMA k-block
 __device__ __forceinline__ float4 wfrag(const float *mat, int block, int cb, int ei, int kq) {
   return *reinterpret_cast<const float4 *>(&mat[(block * 16 + ei) * VW + 4 * ((4 * cb + kq) ^ ei)]);
+}
+
+// out[ob] += sum_ib (block (ob, ib) of a staged matrix) x in[ib] on a wave's 16 columns (edges or rows); out comes in holding the
+// initial accumulators (the bias, or zeros).  The NOUT accumulator chains advance side by side -- a chain's MFMAs are NOUT issue slots
+// apart, so none waits out the 40-cycle dependent latency -- and the fragments of the next input block are on their way from LDS while
+// the MFMAs of this one issue.  Every chain adds its products in the same order as a plain loop over the inputs.  Blocks beyond a
+// layer's real widths are zero in the staged matrix: running them changes nothing, skipping them (NOUT / NIN) saves their MFMAs.
+template <int NOUT, int NIN>
+__device__ __forceinline__ void slice_matmul(const float *mat, const float4 (&in)[4], f32x4 (&out)[4], int ei, int kq) {
+  float4 w[NOUT], wn[NOUT];
+#pragma unroll
+  for (int ob = 0; ob < NOUT; ++ob) w[ob] = wfrag(mat, ob, 0, ei, kq);
+#pragma unroll
+  for (int ib = 0; ib < NIN; ++ib) {
+    if (ib + 1 < NIN) {
+#pragma unroll
+      for (int ob = 0; ob < NOUT; ++ob) wn[ob] = wfrag(mat, ob, ib + 1, ei, kq);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink each read to its first use to save registers)
+#pragma unroll
+    for (int ob = 0; ob < NOUT; ++ob) out[ob] = mfma16(w[ob].x, in[ib].x, out[ob]);
+#pragma unroll
+    for (int ob = 0; ob < NOUT; ++ob) out[ob] = mfma16(w[ob].y, in[ib].y, out[ob]);
+#pragma unroll
+    for (int ob = 0; ob < NOUT; ++ob) out[ob] = mfma16(w[ob].z, in[ib].z, out[ob]);
+#pragma unroll
+    for (int ob = 0; ob < NOUT; ++ob) out[ob] = mfma16(w[ob].w, in[ib].w, out[ob]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ib + 1 < NIN) {
+#pragma unroll
+      for (int ob = 0; ob < NOUT; ++ob) w[ob] = wn[ob];
+    }
+  }
 }
 
 __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs &t) {
@@ -206,6 +267,10 @@ __device__ __forceinline__ void vmh_publish(const VmhMeta &m, const VCtx &c, int
   if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.wg, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ float4 ld4_nt(const float *p) {   // a tape row: read once
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(p)));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float ld_sc1(const float *p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -239,6 +304,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
   VCtx c;
   vctx_init(m, c, t);
+  // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
+  // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
+  if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
   for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, true);
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, true);
   if (c.tid < VW) {
@@ -265,9 +333,12 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       const float *X = ph == 1 ? p.u_in : (((ph - 1) & 1) ? p.x1 : p.x0);
       float *Xn = (ph & 1) ? p.x1 : p.x0;
       const size_t ev = (size_t)(n * p.S + i);
+      NGPDE_VST(m, ph, 0);
       if (!vmh_wait(m, c, ph - 1, t.s_ok)) { ok = false; break; }
+      NGPDE_VST(m, ph, 1);
       if (c.tid < c.hcount) t.hh[c.tid] = ph == 1 ? X[t.hnode[c.tid]] : ld_sc1(X + t.hnode[c.tid]);
       __syncthreads();
+      NGPDE_VST(m, ph, 2);
       // ---- message MLP per 16-edge wave slice, messages summed per target through the staging tile
       float4 racc = f4_zero();
       const int lo = t.off[rg], hi = has_row ? t.off[rg + 1] : t.off[rg];
@@ -296,14 +367,15 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
           a[0] = valid ? (kq == 0 ? make_float4(feat[0], feat[1], feat[2], feat[3]) : (kq == 1 ? make_float4(feat[4], 0.f, 0.f, 0.f) : f4_zero()))
                        : f4_zero();
           a[1] = a[2] = a[3] = f4_zero();
-          for (int l = 0; l < m.n_phi; ++l) {
+          // (the layer loop is unrolled: the kept rows have static register indices and a layer's shape words are loaded once)
+#pragma unroll
+          for (int l = 0; l < kVmhMaxL; ++l) {
+            if (l >= m.n_phi) break;
             const int din = m.phi_din[l], dw = m.phi_dout[l];
             const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
             if (defer) {
 #pragma unroll
-              for (int ll = 0; ll < kVmhMaxL; ++ll)   // (static indices: the rows stay in registers)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) ta[ll][ct] = f4_sel(ll == l, a[ct], ta[ll][ct]);
+              for (int ct = 0; ct < 4; ++ct) ta[l][ct] = a[ct];
               pe_keep = pe;
               valid_keep = valid;
             } else if (p.tape_phi && valid) {
@@ -313,50 +385,50 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
                 if (ct < n_ct) __builtin_nontemporal_store((f4v){a[ct].x, a[ct].y, a[ct].z, a[ct].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(row + 16 * ct)));
             }
             const float *mat = t.W + (size_t)l * VW * VW;
-            float4 z[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            f32x4 acc[4];   // (the accumulators start from the bias: z = b + W a)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-              if (mt < n_mt) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                  if (ct < n_ct) {
-                    const float4 w4 = wfrag(mat, mt, ct, ei, kq);
-                    acc = mfma16(w4.x, a[ct].x, acc);
-                    acc = mfma16(w4.y, a[ct].y, acc);
-                    acc = mfma16(w4.z, a[ct].z, acc);
-                    acc = mfma16(w4.w, a[ct].w, acc);
-                  }
-                }
-                const float4 b4 = *reinterpret_cast<const float4 *>(&t.bias[l * VW + 16 * mt + 4 * kq]);
-                z[mt] = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
-              }
+              const float4 b4 = *reinterpret_cast<const float4 *>(&t.bias[l * VW + 16 * mt + 4 * kq]);
+              acc[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
             }
-            if (l + 1 < m.n_phi) {
+            if (n_ct == 1) slice_matmul<4, 1>(mat, a, acc, ei, kq);
+            else if (n_mt <= 3) slice_matmul<3, 4>(mat, a, acc, ei, kq);
+            else slice_matmul<4, 4>(mat, a, acc, ei, kq);
+            float4 z[4];
 #pragma unroll
-              for (int mt = 0; mt < 4; ++mt) a[mt] = (valid && 16 * mt + 4 * kq < dw) ? f4_act(m.phi_act[l], z[mt]) : f4_zero();
+            for (int mt = 0; mt < 4; ++mt) z[mt] = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            if (l + 1 < m.n_phi) {
+              f4n_act<4>(m.phi_act[l], z);
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) a[mt] = (valid && 16 * mt + 4 * kq < dw) ? z[mt] : f4_zero();
             } else {
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt) msg[mt] = (valid && 16 * mt + 4 * kq < dw) ? z[mt] : f4_zero();
             }
           }
         }
-        // messages through the 64-row staging tile, four waves at a time; lane group r sums the rows of target r in edge order
-        for (int sub = 0; sub < VT / 256; ++sub) {
-          const int cs = c0 + 64 * sub;
-          if ((c.wave >> 2) == sub) {
-            float *mine = t.S + (size_t)((c.wave & 3) * 16) * VTS;
+        NGPDE_VST(m, ph, 3);
+        // messages through the staging tile, as many waves at a time as it has 16-row blocks (all, when the LDS left by the
+        // weights allows); lane group r sums the rows of target r in edge order
+        const int sw = m.s_rows >> 4;
+        for (int w0 = 0; w0 < VT / 64; w0 += sw) {
+          const int cs = c0 + 16 * w0;
+          if (cs >= c.total) break;   // (uniform)
+          if (c.wave >= w0 && c.wave < w0 + sw) {
+            float *mine = t.S + (size_t)((c.wave - w0) * 16) * VTS;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * VTS + 16 * mt + 4 * kq]) = msg[mt];
           }
           __syncthreads();
           {
             const float *base = t.S + 4 * c.q - cs * VTS;
-            for (int kk = max(lo, cs); kk < min(hi, cs + 64); ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * VTS));
+            const int ce = min(cs + 16 * sw, c0 + VROUND);   // (the last wave group of a round may be a partial one)
+            for (int kk = max(lo, cs); kk < min(hi, ce); ++kk) racc = f4_add(racc, *reinterpret_cast<const float4 *>(base + kk * VTS));
           }
           __syncthreads();
         }
       }
+      NGPDE_VST(m, ph, 4);
       // ---- node MLP on the 16 rows: input [h_i; m_i; 0 ...] in tile A (rows 0..15 of the staging area), layers ping-pong A <-> B
       float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
       if (has_row) {
@@ -371,7 +443,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         if (c.q == 0) row[0] = t.hh[c.half * VR + rg];
       }
       __syncthreads();
-      for (int l = 0; l < m.n_gam; ++l) {
+#pragma unroll
+      for (int l = 0; l < kVmhMaxL; ++l) {
+        if (l >= m.n_gam) break;
         const int din = m.gam_din[l], dw = m.gam_dout[l];
         const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
         const float *tin = (l & 1) ? tB : tA;
@@ -383,13 +457,23 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         if (mt < n_mt && mt < 4) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          for (int ct = 0; ct < n_ct; ++ct) {
-            const float4 w4 = wfrag(mat, mt, ct, ei, kq);
-            const float4 av = *reinterpret_cast<const float4 *>(&tin[ei * VTS + 16 * ct + 4 * kq]);
-            acc = mfma16(w4.x, av.x, acc);
-            acc = mfma16(w4.y, av.y, acc);
-            acc = mfma16(w4.z, av.z, acc);
-            acc = mfma16(w4.w, av.w, acc);
+          // (all four input blocks in flight at once; the columns of the tile beyond the layer's input width are zeros, and so are
+          // the staged weights there)
+          float4 w4[4], av[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            w4[ct] = wfrag(mat, mt, ct, ei, kq);
+            av[ct] = *reinterpret_cast<const float4 *>(&tin[ei * VTS + 16 * ct + 4 * kq]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            if (ct < n_ct) {
+              acc = mfma16(w4[ct].x, av[ct].x, acc);
+              acc = mfma16(w4[ct].y, av[ct].y, acc);
+              acc = mfma16(w4[ct].z, av[ct].z, acc);
+              acc = mfma16(w4[ct].w, av[ct].w, acc);
+            }
           }
           const float4 b4 = *reinterpret_cast<const float4 *>(&t.bias[(kVmhMaxL + l) * VW + 16 * mt + 4 * kq]);
           const float4 z = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
@@ -400,6 +484,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         if (mt < 4) *reinterpret_cast<float4 *>(&tout[ei * VTS + 16 * mt + 4 * kq]) = zo;
         __syncthreads();
       }
+      NGPDE_VST(m, ph, 5);
       // ---- stage derivative k_i = gamma's output (column 0); the next stage input (or the step update) of the own nodes
       const float *tfin = (m.n_gam & 1) ? tB : tA;
       if (c.tid < VR) {
@@ -413,6 +498,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         if (my_node >= 0) st_sc1(Xn + my_node, v);
       }
       vmh_publish(m, c, ph);
+      NGPDE_VST(m, ph, 6);
       if (defer && valid_keep) {
 #pragma unroll
         for (int l = 0; l < kVmhMaxL; ++l) {
@@ -456,6 +542,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
   VCtx c;
   vctx_init(m, c, t);
+  // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
+  // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
+  if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
   for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, false);
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
   if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
@@ -478,6 +567,31 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   float lam = my_node >= 0 ? p.lam[my_node] : 0.f;
   float ub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
+  // With ONE round a lane's edge is the same in every phase, and what a phase reads from the tapes does not depend on the exchange:
+  // the outputs of gamma's hidden layers and of phi's last hidden layer are fetched a phase ahead, behind the publish, and land while
+  // the workgroup waits for its neighbours; phi's lower layers are fetched one layer ahead, under the layer's MFMAs.
+  const bool one_round = n_rounds == 1;
+  const int k1 = c.wave * 16 + ei;
+  const bool valid1 = one_round && k1 < c.total;
+  const int r1 = t.edge[valid1 ? k1 : 0] & 0xff;
+  const size_t pe1 = (size_t)(t.rs[r1] + (k1 - t.off[r1]));
+  float4 ytop[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, yg[kVmhMaxL - 1];
+  auto fetch_phi = [&](int l, size_t ev, float4 (&y)[4]) {   // the output of phi's layer l: the input tape of layer l + 1
+    const int n_mt = (m.phi_dout[l] + 15) >> 4;
+    const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe1) * VW + 4 * kq;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) y[mt] = (valid1 && mt < n_mt) ? ld4_nt(yrow + 16 * mt) : f4_zero();
+  };
+  auto fetch_phase = [&](size_t ev) {
+#pragma unroll
+    for (int l = 0; l < kVmhMaxL - 1; ++l) {
+      yg[l] = f4_zero();
+      if (l + 1 < m.n_gam && c.row_valid && 4 * c.q < 16 * ((m.gam_dout[l] + 15) >> 4))
+        yg[l] = ld4_nt(p.tape_gam + (((size_t)(l + 1) * m.evals + ev) * N + c.node) * VW + 4 * c.q);
+    }
+    if (one_round && m.n_phi >= 2) fetch_phi(m.n_phi - 2, ev, ytop);
+  };
+  fetch_phase((size_t)(p.n_steps * S - 1));
   bool ok = true;
   int ph = 0;
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
@@ -485,6 +599,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       ++ph;
       const size_t ev = (size_t)(n * S + i);
       float *dsrc = (ph & 1) ? p.dsrc1 : p.dsrc0;
+      NGPDE_VST(m, ph, 0);
       // ---- K-bar_i of the own nodes -> the gradient of gamma's output (column 0 of tile A)
       if (c.tid < VR) {
         float kbar = t.misc[i * 8 + i] * lam;
@@ -497,7 +612,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       if (has_row) *reinterpret_cast<float4 *>(&tA[rg * VTS + 4 * c.q]) = (c.q == 0) ? make_float4(s_row[rg], 0.f, 0.f, 0.f) : f4_zero();
       __syncthreads();
       // ---- gamma backwards: g (tile) -> dz_l = g . act'(output of layer l) -> tape; g <- W_l dz_l
-      for (int l = m.n_gam - 1; l >= 0; --l) {
+#pragma unroll
+      for (int li = 0; li < kVmhMaxL; ++li) {
+        const int l = kVmhMaxL - 1 - li;
+        if (l >= m.n_gam) continue;
         const int din = m.gam_din[l], dw = m.gam_dout[l];
         const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
         float *tg = ((m.n_gam - 1 - l) & 1) ? tB : tA;       // holds g (gradient of layer l's output), becomes dz in place
@@ -505,8 +623,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         if (has_row) {
           float4 g = *reinterpret_cast<const float4 *>(&tg[rg * VTS + 4 * c.q]);
           if (l + 1 < m.n_gam && c.row_valid && 4 * c.q < 16 * n_mt) {
-            const float4 y = *reinterpret_cast<const float4 *>(p.tape_gam + (((size_t)(l + 1) * m.evals + ev) * N + c.node) * VW + 4 * c.q);
-            g = f4_mul(g, f4_dact_out(m.gam_act[l], y));
+            float4 dy[1] = {yg[l < kVmhMaxL - 1 ? l : 0]};
+            f4n_dact_out<1>(m.gam_act[l], dy);
+            g = f4_mul(g, dy[0]);
           }
           if (!(c.row_valid && 4 * c.q < dw)) g = f4_zero();
           *reinterpret_cast<float4 *>(&tg[rg * VTS + 4 * c.q]) = g;
@@ -518,13 +637,21 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         if (ct < n_ct && ct < 4) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          for (int mt = 0; mt < n_mt; ++mt) {
-            const float4 w4 = wfrag(mat, ct, mt, ei, kq);
-            const float4 dv = *reinterpret_cast<const float4 *>(&tg[ei * VTS + 16 * mt + 4 * kq]);
-            acc = mfma16(w4.x, dv.x, acc);
-            acc = mfma16(w4.y, dv.y, acc);
-            acc = mfma16(w4.z, dv.z, acc);
-            acc = mfma16(w4.w, dv.w, acc);
+          float4 w4[4], dv[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            w4[mt] = wfrag(mat, ct, mt, ei, kq);
+            dv[mt] = *reinterpret_cast<const float4 *>(&tg[ei * VTS + 16 * mt + 4 * kq]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            if (mt < n_mt) {
+              acc = mfma16(w4[mt].x, dv[mt].x, acc);
+              acc = mfma16(w4[mt].y, dv[mt].y, acc);
+              acc = mfma16(w4[mt].z, dv[mt].z, acc);
+              acc = mfma16(w4[mt].w, dv[mt].w, acc);
+            }
           }
           go = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
@@ -533,6 +660,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       }
       // d(gamma's input) = [dh_i; dm_i]: tile tgin, row r; the message gradient is scaled by 1 / deg (mean)
       const float *tgin = (m.n_gam & 1) ? tB : tA;
+      NGPDE_VST(m, ph, 1);
       // ---- phi backwards per 16-edge wave slice
       for (int k = c.tid; k < c.total; k += VT) s_es[k] = 0.f;
       __syncthreads();
@@ -560,27 +688,31 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
             g[mt] = (valid && f < Mw) ? make_float4(inv * src[0], f + 1 < Mw ? inv * src[1] : 0.f, f + 2 < Mw ? inv * src[2] : 0.f, f + 3 < Mw ? inv * src[3] : 0.f)
                                       : f4_zero();
           }
-          for (int l = m.n_phi - 1; l >= 0; --l) {
+          float4 ycur[4], ynext[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) ycur[mt] = ynext[mt] = ytop[mt];
+#pragma unroll
+          for (int li = 0; li < kVmhMaxL; ++li) {
+            const int l = kVmhMaxL - 1 - li;
+            if (l >= m.n_phi) continue;
             const int din = m.phi_din[l], dw = m.phi_dout[l];
             const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;
             if (l + 1 < m.n_phi) {
               const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe) * VW + 4 * kq;
+              float4 dy[4];
 #pragma unroll
-              for (int mt = 0; mt < 4; ++mt) {
-                if (mt < n_mt) {
-                  const float4 y = valid ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero();
-                  g[mt] = f4_mul(g[mt], f4_dact_out(m.phi_act[l], y));
-                }
-              }
+              for (int mt = 0; mt < 4; ++mt) dy[mt] = one_round ? ycur[mt] : ((valid && mt < n_mt) ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero());
+              f4n_dact_out<4>(m.phi_act[l], dy);
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) g[mt] = f4_mul(g[mt], dy[mt]);
             }
+            if (one_round && l >= 1 && l + 1 < m.n_phi) fetch_phi(l - 1, ev, ynext);   // for the layer below, under this layer's MFMAs
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
               if (!(valid && 16 * mt + 4 * kq < dw)) g[mt] = f4_zero();
             if (defer) {
 #pragma unroll
-              for (int ll = 0; ll < kVmhMaxL; ++ll)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) tz[ll][mt] = f4_sel(ll == l, g[mt], tz[ll][mt]);
+              for (int mt = 0; mt < 4; ++mt) tz[l][mt] = g[mt];
             } else if (valid) {
               float *zrow = p.dz_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
 #pragma unroll
@@ -588,26 +720,15 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
                 if (mt < n_mt) __builtin_nontemporal_store((f4v){g[mt].x, g[mt].y, g[mt].z, g[mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
             }
             const float *mat = t.W + (size_t)l * VW * VW;
-            float4 gn[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            f32x4 gn[4] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            if (n_ct == 1) slice_matmul<1, 4>(mat, g, gn, ei, kq);
+            else if (n_mt <= 3) slice_matmul<4, 3>(mat, g, gn, ei, kq);
+            else slice_matmul<4, 4>(mat, g, gn, ei, kq);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-              if (ct < n_ct) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                  if (mt < n_mt) {
-                    const float4 w4 = wfrag(mat, ct, mt, ei, kq);
-                    acc = mfma16(w4.x, g[mt].x, acc);
-                    acc = mfma16(w4.y, g[mt].y, acc);
-                    acc = mfma16(w4.z, g[mt].z, acc);
-                    acc = mfma16(w4.w, g[mt].w, acc);
-                  }
-                }
-                gn[ct] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-              }
+              g[ct] = make_float4(gn[ct][0], gn[ct][1], gn[ct][2], gn[ct][3]);
+              ycur[ct] = ynext[ct];
             }
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) g[ct] = gn[ct];
           }
           // d(input) = [d h_i, d (h_j - h_i), ...]: lane kq = 0 holds features 0..3
           if (valid && kq == 0) {
@@ -616,13 +737,16 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           }
         }
       }
+      NGPDE_VST(m, ph, 2);
       __syncthreads();
+      NGPDE_VST(m, ph, 3);
       if (c.tid < VR) {   // what the own rows get from their own edges and from gamma
         float a = tgin[c.tid * VTS];
         for (int k = t.off[c.tid]; k < t.off[c.tid + 1]; ++k) a += s_es[k];
         s_row[VR + c.tid] = a;
       }
       vmh_publish(m, c, ph);
+      NGPDE_VST(m, ph, 4);
       if (defer && valid_keep) {
 #pragma unroll
         for (int l = 0; l < kVmhMaxL; ++l) {
@@ -634,7 +758,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
             if (mt < n_mt) __builtin_nontemporal_store((f4v){tz[l][mt].x, tz[l][mt].y, tz[l][mt].z, tz[l][mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
         }
       }
+      if (ev > 0) fetch_phase(ev - 1);
+      NGPDE_VST(m, ph, 5);
       if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
+      NGPDE_VST(m, ph, 6);
       {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
         const int dg = has_row ? s_srcdeg[rg] : 0;
         float a = 0.f;
@@ -671,7 +798,17 @@ __global__ void vmh_copy_block_kernel(const float *src, int sp, float *dst, int 
   if (idx < rows * cols) dst[(idx / cols) * dp + idx % cols] = src[(idx / cols) * sp + idx % cols];
 }
 
-size_t vmh_lds_bytes(int n_mats) { return ((size_t)n_mats * VW * VW + (size_t)VW * VTS) * sizeof(float); }
+size_t vmh_lds_bytes(int n_mats, int s_rows) { return ((size_t)n_mats * VW * VW + (size_t)s_rows * VTS) * sizeof(float); }
+// rows of the staging tile: as many of the workgroup's waves as the LDS holds beside the weights and the kernels' static arrays
+int vmh_staging_rows(int n_mats) {
+  hipFuncAttributes fa{}, ba{};
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(node_vmh_fwd_kernel)) != hipSuccess) return 64;
+  if (hipFuncGetAttributes(&ba, reinterpret_cast<const void *>(node_vmh_bwd_kernel)) != hipSuccess) return 64;
+  const size_t fixed = std::max(fa.sharedSizeBytes, ba.sharedSizeBytes), cap = 160 * 1024;
+  for (int rows = VROUND; rows > 64; rows -= 32)
+    if (vmh_lds_bytes(n_mats, rows) + fixed <= cap) return rows;
+  return 64;
+}
 
 }  // namespace
 
@@ -697,7 +834,7 @@ bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s) {
   if (g->max_in_degree > kSlotWidth || g->max_out_degree > kSlotWidth) return false;
   int dev = 0, cus = 0, occ = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  const size_t lds = vmh_lds_bytes(s.n_phi + s.n_gam);
+  const size_t lds = vmh_lds_bytes(s.n_phi + s.n_gam, vmh_staging_rows(s.n_phi + s.n_gam));
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   int of = 0, ob = 0;
@@ -727,6 +864,10 @@ static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
   }
   m.n_edges = (size_t)g->n_edges;
   m.evals = a.n_steps * a.S;
+  m.s_rows = vmh_staging_rows(m.n_phi + m.n_gam);
+#ifdef NGPDE_STAMPS
+  m.stamps = g_vst_base; m.stamps_max = g_vst_max;
+#endif
 }
 
 int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
@@ -743,7 +884,7 @@ int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
   }
   k.n_steps = a.n_steps; k.S = a.S; k.u_in = a.u_in; k.u_out = a.u_out; k.x0 = a.x0; k.x1 = a.x1;
   k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.cf = a.cf;
-  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam);
+  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
   NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(node_vmh_fwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
   NGPDE_LAUNCH_CHECK("node_vmh_fwd_kernel");
@@ -762,7 +903,7 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   fill_meta(k.m, a);
   k.n_steps = a.n_steps; k.S = a.S; k.lam = a.lam; k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.dz_phi = a.dz_phi; k.dz_gam = a.dz_gam;
   k.dsrc0 = a.dsrc; k.dsrc1 = a.dsrc + k.m.n_edges; k.cb = a.cb;
-  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam);
+  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
   NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(node_vmh_bwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
   NGPDE_LAUNCH_CHECK("node_vmh_bwd_kernel");
@@ -779,3 +920,11 @@ int32_t launch_vmh_copy_block(const float *src, int sp, float *dst, int dp, int 
 }
 
 }  // namespace ngpde
+
+#ifdef NGPDE_STAMPS
+extern "C" int32_t ngpde_debug_set_vmh_stamps(unsigned long long *dev_buf, int32_t max_phases) {
+  ngpde::g_vst_base = dev_buf;
+  ngpde::g_vst_max = max_phases;
+  return 0;
+}
+#endif

@@ -1,0 +1,197 @@
+"""GPU parity tests of the device-resident NeuralODE(VMHConv) plan (ngpde_node_vmh_*: /root/reference/docs/src/tutorials/VMH.md:75-89
+-- phi and gamma Dense stacks on a scalar state, /root/reference/src/layers.jl:402-416 as the right-hand side of every Runge-Kutta
+stage): the float64 oracle's rk_solve / rk_adjoint, the generic solver on the same inputs, shape checks, the abort protocol."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+from ngpde_amd import _lib, synth as S
+from oracle import ngpde_oracle as O
+from test_mp_gpu import check_grads, close, mlp_grad_pairs, omlp, prep
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def spatial(N, seed, pd=2):
+    pts, s, t = S.closest_pairs_graph(N, 3 * N, seed=seed)
+    extra = np.random.default_rng(seed).random((1, N))           # (a third coordinate for pd = 3; the graph is the planar one)
+    nd = {"x": np.concatenate([pts.T, extra], axis=0)[:pd].copy()}
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0, ndata=nd), O.Graph(s, t, num_nodes=N, index_base=0, ndata=nd)
+
+
+def tutorial_mlps(width=60, msg=40, depth=4, act="tanh", pd=2):
+    hid = [ng.Dense(width, width, act) for _ in range(depth - 2)]
+    phi = ng.Chain(ng.Dense(2 + pd, width, act), *hid, ng.Dense(width, msg))
+    gam = ng.Chain(ng.Dense(1 + msg, width, act), *[ng.Dense(width, width, act) for _ in range(depth - 2)], ng.Dense(width, 1))
+    return phi, gam
+
+
+def plan_flags(node):
+    return sorted({f for pool in node._plans.values() for p in pool for f in p.flags()})
+
+
+def oracle_solve(phi, gam, ps, og, u0, tab_name, dt, n_steps, R, aggr="mean"):
+    ophi, ogam = omlp(phi, ps["ϕ"]), omlp(gam, ps["γ"])
+    tab = O.TABLEAUS[tab_name]
+    gphi = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ophi]
+    ggam = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ogam]
+
+    def vjp(cache, kbar):
+        gr = O.vmh_conv_backward(cache, kbar)
+        return gr["x"], gr
+
+    def accumulate(gr):
+        for dst, src in ((gphi, gr["phi"]), (ggam, gr["gamma"])):
+            for d_, s_ in zip(dst, src):
+                d_["weight"] += s_["weight"]
+                d_["bias"] += np.asarray(s_["bias"]).reshape(d_["bias"].shape)
+    uT, tape = O.rk_solve(lambda u: O.vmh_conv(u, ophi, ogam, og, aggr=aggr), u0.astype(np.float64), tab, dt, n_steps)
+    du0 = O.rk_adjoint(vjp, tape, R, tab, dt, accumulate)
+    return uT, du0, gphi, ggam
+
+
+@pytest.mark.parametrize("solver,n_steps,act,aggr,depth,pd", [
+    ("tsit5", 2, "tanh", "mean", 4, 2),      # the tutorial's model
+    ("euler", 3, "tanh", "+", 3, 2),
+    ("tsit5", 1, "relu", "mean", 2, 1),
+    ("euler", 2, "sigmoid", "mean", 3, 3),
+])
+def test_vmh_resident_solve_and_adjoint_against_the_oracle(solver, n_steps, act, aggr, depth, pd, monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    N, dt = 700, 0.05
+    g, og = spatial(N, 31 + depth, pd=pd)
+    phi, gam = tutorial_mlps(depth=depth, act=act, pd=pd)
+    node = ng.NeuralODE(ng.VMHConv(phi, gam, aggr=aggr, initialgraph=g), solver=solver, n_steps=n_steps, dt=dt)
+    ps0, st = ng.setup(3, node)
+    ps = prep(ps0, 3)
+    rng = np.random.default_rng(9)
+    u0 = rng.normal(size=(1, N)).astype(np.float32)
+    R = rng.normal(size=(1, N))
+    u = torch.as_tensor(u0, device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    assert "vmh" in plan_flags(node), plan_flags(node)       # the device-resident plan ran, not the generic solver
+    uTo, du0, gphi, ggam = oracle_solve(phi, gam, ps, og, u0, solver, dt, n_steps, R, aggr=aggr)
+    close(uT, uTo, rtol=2e-4)
+    (uT * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gphi, phi)
+    n2, o2 = mlp_grad_pairs(ps["γ"], ggam, gam)
+    check_grads(ps, (n1 + n2, o1 + o2), u, du0)
+    assert not any(p.fault() for pool in node._plans.values() for p in pool)
+
+
+def test_vmh_resident_plan_equals_the_generic_solver_at_the_tutorial_shape(monkeypatch):
+    # 3 000 points, 6 neighbours, phi = 4 => 60 => 60 => 60 => 40, gamma = 41 => 60 => 60 => 60 => 1 (docs/src/tutorials/VMH.md:75-83),
+    # Tsit5 x 4: values, du0 and all 16 parameter gradients of both paths; repeated solves of the plan are bitwise equal
+    nv, steps = 3000, 4
+    pts = torch.as_tensor(S.uniform01(41, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+    gv = ng.GNNGraph(ng.knn_graph(pts, 6), ndata={"x": pts})
+    phi, gam = tutorial_mlps()
+    u0 = torch.as_tensor(S.normal(42, nv).reshape(1, nv).astype(np.float32), device=DEV)
+    R = torch.as_tensor(S.normal(43, nv).reshape(1, nv).astype(np.float32), device=DEV)
+    res = {}
+    for mode in ("resident", "generic", "resident2"):
+        if mode == "generic":
+            monkeypatch.setenv("NGPDE_NO_VMH_NODE", "1")
+        else:
+            monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gv), solver="tsit5", n_steps=steps, dt=0.05)
+        ps0, st = ng.setup(4, node)
+        ps = prep(ps0, 4)
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * R).sum().backward()
+        assert ("vmh" in plan_flags(node)) == (mode != "generic")
+        n1, _ = mlp_grad_pairs(ps["ϕ"], [{"weight": 0, "bias": 0}] * 4, phi)
+        n2, _ = mlp_grad_pairs(ps["γ"], [{"weight": 0, "bias": 0}] * 4, gam)
+        res[mode] = [uT.detach().clone(), u.grad.clone()] + [p.grad.clone() for _, p in n1 + n2]
+    for a, b in zip(res["resident"], res["generic"]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6
+    for a, b in zip(res["resident"], res["resident2"]):
+        assert torch.equal(a, b)     # no atomics, fixed summation orders, and every hand-off waited for
+
+
+def test_vmh_resident_plan_leaves_unsupported_models_to_the_generic_solver(monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    N = 400
+    pts = torch.as_tensor(S.uniform01(5, 2 * N).reshape(2, N).astype(np.float32), device=DEV)
+    g = ng.GNNGraph(ng.knn_graph(pts, 5), ndata={"x": pts})      # (every node has neighbours: a max over none is -Inf, as NNlib's)
+    # a state of three features, a max aggregation, saveat: none of them is the plan's; the solve runs on the generic solver
+    phi3 = ng.Chain(ng.Dense(2 * 3 + 2, 16, "tanh"), ng.Dense(16, 8))
+    gam3 = ng.Chain(ng.Dense(3 + 8, 16, "tanh"), ng.Dense(16, 3))
+    cases = [(ng.NeuralODE(ng.VMHConv(phi3, gam3, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05), 3)]
+    phi, gam = tutorial_mlps(depth=3)
+    cases.append((ng.NeuralODE(ng.VMHConv(phi, gam, aggr="max", initialgraph=g), solver="tsit5", n_steps=2, dt=0.05), 1))
+    cases.append((ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", tspan=(0.0, 0.2), n_steps=4, saveat=0.1), 1))
+    for node, h in cases:
+        ps, st = ng.setup(1, node)
+        ps = prep(ps, 1)
+        u = torch.randn(h, N, device=DEV, requires_grad=True)
+        out, _ = node(u, ps, st)
+        out.sum().backward()
+        assert "vmh" not in plan_flags(node)
+        assert torch.isfinite(out).all() and torch.isfinite(u.grad).all()
+
+
+def test_vmh_abi_rejects_null_and_mismatched_arguments():
+    lib = _lib.load()
+    N = 300
+    g, _ = spatial(N, 8)
+    ia = lambda v: (C.c_int32 * len(v))(*v)
+    acts = [_lib.ACT["tanh"], _lib.ACT["identity"]]
+    dims_p, dims_g, mean = [4, 60, 40], [41, 60, 1], _lib.AGGR["mean"]
+    h = g.handle()
+    sup = lambda gp, hd, dp, dg, aggr: lib.ngpde_node_vmh_supported(gp, hd, 2, 2, ia(dp), ia(acts), 2, ia(dg), ia(acts), aggr)
+    assert sup(h.ptr, 1, dims_p, dims_g, mean) == 1
+    assert sup(None, 1, dims_p, dims_g, mean) == 0
+    assert sup(h.ptr, 2, dims_p, dims_g, mean) == 0                   # a state of two features
+    assert sup(h.ptr, 1, [4, 80, 40], dims_g, mean) == 0              # wider than 64
+    assert sup(h.ptr, 1, dims_p, [40, 60, 1], mean) == 0              # gamma's input != 1 + the message width
+    assert sup(h.ptr, 1, dims_p, dims_g, _lib.AGGR["max"]) == 0
+    pos = torch.zeros(N, 2, device=DEV)
+    out = C.c_void_p()
+    mk = lambda gp, posp, outp: lib.ngpde_node_vmh_create(gp, 1, 2, posp, 2, ia(dims_p), ia(acts), 2, ia(dims_g), ia(acts), mean,
+                                                          _lib.TABLEAU["tsit5"], 2, 0.1, 1, outp)
+    assert mk(None, _lib.ptr(pos), C.byref(out)) == _lib.ERR_INVALID_ARGUMENT and not out.value
+    assert mk(h.ptr, None, C.byref(out)) == _lib.ERR_INVALID_ARGUMENT and not out.value
+    assert mk(h.ptr, _lib.ptr(pos), None) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.ngpde_node_vmh_destroy(None) == _lib.OK       # a no-op, as every destroy of the ABI
+    assert lib.ngpde_node_vmh_tape_bytes(None) == 0
+    f = C.c_int32()
+    assert lib.ngpde_node_vmh_fault(None, None, C.byref(f)) == _lib.ERR_INVALID_ARGUMENT
+    assert mk(h.ptr, _lib.ptr(pos), C.byref(out)) == _lib.OK and out.value
+    u = torch.zeros(N, device=DEV)
+    assert lib.ngpde_node_vmh_forward(out, None, None, None, None, None, _lib.ptr(u), None) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.ngpde_node_vmh_backward(out, None, None, _lib.ptr(u), _lib.ptr(u), None, None, None, None, None) in (_lib.ERR_INVALID_ARGUMENT, _lib.ERR_STATE)
+    assert lib.ngpde_node_vmh_destroy(out) == _lib.OK
+
+
+def test_vmh_resident_plan_reports_an_abort_instead_of_hanging(monkeypatch):
+    # a launch whose waits give up (forced: NGPDE_DEBUG_FORCE_ABORT=1 starts it with the abort word set) writes NaN outputs and
+    # latches the plan's fault word; the next entry of the plan fails instead of computing on garbage; a fresh plan works
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    N = 700
+    g, _ = spatial(N, 12)
+    phi, gam = tutorial_mlps(depth=3)
+    node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05)
+    ps, st = ng.setup(1, node)
+    ps = ng.to_device(ps, DEV)
+    u = torch.randn(1, N, device=DEV)
+    out, _ = node(u, ps, st)
+    assert torch.isfinite(out).all() and "vmh" in plan_flags(node)
+    monkeypatch.setenv("NGPDE_DEBUG_FORCE_ABORT", "1")
+    out, _ = node(u, ps, st)
+    monkeypatch.delenv("NGPDE_DEBUG_FORCE_ABORT")
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+    assert any(p.fault() for pool in node._plans.values() for p in pool)
+    with pytest.raises(_lib.NgpdeError, match="gave up waiting"):
+        node(u, ps, st)
+    fresh = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05)
+    out, _ = fresh(u, ps, st)
+    assert torch.isfinite(out).all()
