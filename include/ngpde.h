@@ -500,6 +500,17 @@ int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *plan, const float *u0, const fl
 int32_t ngpde_node_vmh_backward(ngpde_node_vmh_t *plan, const float *const *phi_weight, const float *const *gamma_weight, const float *duT,
                                 float *du0, float *const *dphi_weight, float *const *dphi_bias, float *const *dgamma_weight,
                                 float *const *dgamma_bias, ngpde_stream_t stream);
+/* saveat (docs/src/tutorials/VMH.md:85 `NeuralODE(gnn, tspan, Tsit5(); saveat = dt_train)`, the loss of :104-108 reads every saved
+ * state): usave / dusave are [T][N], T = n_steps / save_every + (save_start ? 1 : 0), slot 0 = u0 when save_start, the last slot =
+ * u(T); save_every must divide the plan's steps.  The adjoint adds dusave[j] to lambda at the time of state j; du0 must not lie
+ * inside dusave.  (forward / backward above are the T = 1 case.) */
+int32_t ngpde_node_vmh_forward_saveat(ngpde_node_vmh_t *plan, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
+                                      const float *const *gamma_weight, const float *const *gamma_bias, int32_t save_every,
+                                      int32_t save_start, float *usave, ngpde_stream_t stream);
+int32_t ngpde_node_vmh_backward_saveat(ngpde_node_vmh_t *plan, const float *const *phi_weight, const float *const *gamma_weight,
+                                       int32_t save_every, int32_t save_start, const float *dusave, float *du0, float *const *dphi_weight,
+                                       float *const *dphi_bias, float *const *dgamma_weight, float *const *dgamma_bias,
+                                       ngpde_stream_t stream);
 
 /* Measurement aid (not on the product path): re-runs the last solve (forward, and backward of
  * loss = sum(u(T)) when the plan has one) launch by launch with start/stop events attached to every

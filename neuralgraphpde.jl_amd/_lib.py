@@ -64,6 +64,8 @@ SIGNATURES = {
     "ngpde_node_vmh_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ngpde_node_vmh_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_node_vmh_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_node_vmh_forward_saveat": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ngpde_node_vmh_backward_saveat": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "ngpde_rprop_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ngpde_graph_destroy": (_i32, [_vp]),

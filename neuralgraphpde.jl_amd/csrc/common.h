@@ -313,6 +313,11 @@ struct VmhLaunch {
   float *u_out = nullptr, *x0 = nullptr, *x1 = nullptr, *tape_phi = nullptr, *tape_gam = nullptr;
   float *lam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;   // dsrc: [2][E]
   const float *cf = nullptr, *cb = nullptr;
+  // saveat (docs/src/tutorials/VMH.md:85): the state after every save_every steps goes to save[j][N], j = step / save_every - 1 + save_off
+  // (save_off = 1: slot 0 holds u0); the adjoint adds dsave[j] to lambda at that time
+  float *save = nullptr;
+  const float *dsave = nullptr;
+  int save_every = 0, save_off = 0;
 };
 bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s);
 int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream);

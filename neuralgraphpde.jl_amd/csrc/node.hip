@@ -1161,10 +1161,32 @@ static void vmh_fill(const ngpde_node_vmh *p, VmhLaunch &a, const float *const *
   a.dsrc = p->dsrc; a.cf = p->cf; a.cb = p->cb;
 }
 
+// the number of saved states of a plan under saveat, or -1 (save_every must divide the plan's steps)
+static int vmh_saved_states(const ngpde_node_vmh *p, int32_t save_every, int32_t save_start) {
+  if (save_every < 1 || p->n_steps % save_every) return -1;
+  return p->n_steps / save_every + (save_start ? 1 : 0);
+}
+
+int32_t ngpde_node_vmh_forward_saveat(ngpde_node_vmh_t *p, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
+                                      const float *const *gamma_weight, const float *const *gamma_bias, int32_t save_every,
+                                      int32_t save_start, float *usave, ngpde_stream_t stream_);
+
 int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *p, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
                                const float *const *gamma_weight, const float *const *gamma_bias, float *uT, ngpde_stream_t stream_) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: plan is NULL");
+  // u(T) alone = the one state saved after the last step
+  return ngpde_node_vmh_forward_saveat(p, u0, phi_weight, phi_bias, gamma_weight, gamma_bias, p->n_steps, 0, uT, stream_);
+}
+
+int32_t ngpde_node_vmh_forward_saveat(ngpde_node_vmh_t *p, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
+                                      const float *const *gamma_weight, const float *const *gamma_bias, int32_t save_every,
+                                      int32_t save_start, float *uT, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: plan is NULL");
+  const int T = vmh_saved_states(p, save_every, save_start);
+  NGPDE_REQUIRE(T >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward_saveat: save_every = %d must be >= 1 and divide the plan's %d steps",
+                (int)save_every, p->n_steps);
   if (p->g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(u0 && uT && phi_weight && gamma_weight && u0 != uT, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: NULL argument (or uT aliasing u0)");
   for (int l = 0; l < p->shape.n_phi; ++l) NGPDE_REQUIRE(phi_weight[l], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_forward: phi weight %d is NULL", l);
@@ -1173,17 +1195,38 @@ int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *p, const float *u0, const float
                 "ngpde_node_vmh_forward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_vmh_fault); destroy the plan");
   VmhLaunch a;
   vmh_fill(p, a, phi_weight, phi_bias, gamma_weight, gamma_bias);
-  a.u_in = u0; a.u_out = uT;
+  a.u_in = u0;
+  if (T == 1 && !save_start) {
+    a.u_out = uT;
+  } else {
+    a.save = uT; a.save_every = save_every; a.save_off = save_start ? 1 : 0;
+  }
   const int32_t st = launch_node_vmh_fwd(a, (hipStream_t)stream_);
   if (st == NGPDE_OK) p->solved = true;
   return st;
 }
+
+int32_t ngpde_node_vmh_backward_saveat(ngpde_node_vmh_t *p, const float *const *phi_weight, const float *const *gamma_weight, int32_t save_every,
+                                       int32_t save_start, const float *dusave, float *du0, float *const *dphi_weight,
+                                       float *const *dphi_bias, float *const *dgamma_weight, float *const *dgamma_bias, ngpde_stream_t stream_);
 
 int32_t ngpde_node_vmh_backward(ngpde_node_vmh_t *p, const float *const *phi_weight, const float *const *gamma_weight, const float *duT,
                                 float *du0, float *const *dphi_weight, float *const *dphi_bias, float *const *dgamma_weight,
                                 float *const *dgamma_bias, ngpde_stream_t stream_) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward: plan is NULL");
+  return ngpde_node_vmh_backward_saveat(p, phi_weight, gamma_weight, p->n_steps, 0, duT, du0, dphi_weight, dphi_bias, dgamma_weight, dgamma_bias,
+                                        stream_);
+}
+
+int32_t ngpde_node_vmh_backward_saveat(ngpde_node_vmh_t *p, const float *const *phi_weight, const float *const *gamma_weight, int32_t save_every,
+                                       int32_t save_start, const float *duT, float *du0, float *const *dphi_weight,
+                                       float *const *dphi_bias, float *const *dgamma_weight, float *const *dgamma_bias, ngpde_stream_t stream_) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(p != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward: plan is NULL");
+  const int T = vmh_saved_states(p, save_every, save_start);
+  NGPDE_REQUIRE(T >= 1, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward_saveat: save_every = %d must be >= 1 and divide the plan's %d steps",
+                (int)save_every, p->n_steps);
   NGPDE_REQUIRE(p->with_bwd, NGPDE_ERR_STATE, "ngpde_node_vmh_backward: the plan was created without a backward pass");
   NGPDE_REQUIRE(p->solved, NGPDE_ERR_STATE, "ngpde_node_vmh_backward: no forward solve has filled the tape");
   NGPDE_REQUIRE(phi_weight && gamma_weight && duT && du0 && dphi_weight && dgamma_weight, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward: NULL argument");
@@ -1191,10 +1234,16 @@ int32_t ngpde_node_vmh_backward(ngpde_node_vmh_t *p, const float *const *phi_wei
                 "ngpde_node_vmh_backward: an earlier launch of this plan gave up waiting for its neighbours (ngpde_node_vmh_fault); destroy the plan");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t N = (size_t)p->g->n_nodes, E = (size_t)p->g->n_edges, evals = (size_t)p->n_steps * p->S;
-  if (du0 != duT) NGPDE_HIP_CHECK(hipMemcpyAsync(du0, duT, N * 4, hipMemcpyDeviceToDevice, stream));
+  // lambda starts as the cotangent of the last saved state (= u(T)); the kernel adds the earlier ones at their times
+  const float *last = duT + (size_t)(T - 1) * N;
+  if (du0 != last) NGPDE_HIP_CHECK(hipMemcpyAsync(du0, last, N * 4, hipMemcpyDeviceToDevice, stream));
   VmhLaunch a;
   vmh_fill(p, a, phi_weight, nullptr, gamma_weight, nullptr);
   a.lam = du0;
+  if (T > 1) {
+    NGPDE_REQUIRE(du0 < duT || du0 >= duT + (size_t)T * N, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_backward_saveat: du0 lies inside the cotangent array");
+    a.dsave = duT; a.save_every = save_every; a.save_off = save_start ? 1 : 0;
+  }
   int32_t st;
   if ((st = launch_node_vmh_bwd(a, stream))) return st;
   // dW_l = A_l^T dZ_l, db_l = column sums of dZ_l over the rows of ALL evaluations: one weight-pullback GEMM per layer on the tapes

@@ -286,6 +286,8 @@ struct VmhFwdK {
   int n_steps, S;
   const float *u_in;
   float *u_out, *x0, *x1;     // the exchanged stage input [N], ping-pong
+  float *save;                // saveat: [T][N] or null
+  int save_every, save_off;
   float *tape_phi;            // [n_phi][evals][E][64] inputs of phi's layers (p order), or null (forward-only plan)
   float *tape_gam;            // [n_gam][evals][N][64] inputs of gamma's layers
   const float *cf;            // [42] forward coefficient table (node_persistent.hip's layout)
@@ -494,7 +496,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         v = fmaf(1.0f, su, v);
         v = fmaf(t.misc[i * 6 + 0], sk0, v); v = fmaf(t.misc[i * 6 + 1], sk1, v); v = fmaf(t.misc[i * 6 + 2], sk2, v);
         v = fmaf(t.misc[i * 6 + 3], sk3, v); v = fmaf(t.misc[i * 6 + 4], sk4, v);
-        if (i == p.S - 1) su = v;
+        if (i == p.S - 1) {
+          su = v;
+          if (p.save && (n + 1) % p.save_every == 0 && my_node >= 0) p.save[(size_t)((n + 1) / p.save_every - 1 + p.save_off) * N + my_node] = v;
+        }
         if (my_node >= 0) st_sc1(Xn + my_node, v);
       }
       vmh_publish(m, c, ph);
@@ -514,7 +519,14 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   }
   // (u_out may alias u_in: a workgroup writes its rows only after every reader of its u0 rows is past its first phase -- the
   // host takes this plan for solves of at least two right-hand-side evaluations)
-  if (my_node >= 0) p.u_out[my_node] = ok ? su : __int_as_float(0x7fc00000);
+  if (my_node >= 0) {
+    if (p.u_out) p.u_out[my_node] = ok ? su : __int_as_float(0x7fc00000);
+    if (p.save) {
+      if (p.save_off) p.save[my_node] = ok ? p.u_in[my_node] : __int_as_float(0x7fc00000);
+      if (!ok)
+        for (int j = 0; j < p.n_steps / p.save_every; ++j) p.save[(size_t)(j + p.save_off) * N + my_node] = __int_as_float(0x7fc00000);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -528,6 +540,8 @@ struct VmhBwdK {
   float *dz_phi, *dz_gam;     // same shapes: every layer's dz
   float *dsrc0, *dsrc1;       // [E] the per-edge gradient towards the edge's SOURCE (p order), ping-pong by phase parity
   const float *cb;            // [S][8]: cb[i][i] = dt b_i, cb[i][j] (j > i) = dt a[j][i]
+  const float *dsave;         // saveat: the cotangents of the saved states [T][N] (lam comes in holding the last one's), or null
+  int save_every, save_off;
 };
 
 __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
@@ -595,6 +609,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   bool ok = true;
   int ph = 0;
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+    // a state saved after step n + 1 hands its cotangent to lambda before step n + 1 is walked back
+    if (p.dsave && n + 1 < p.n_steps && (n + 1) % p.save_every == 0 && my_node >= 0)
+      lam += p.dsave[(size_t)((n + 1) / p.save_every - 1 + p.save_off) * N + my_node];
     for (int i = S - 1; i >= 0 && ok; --i) {
       ++ph;
       const size_t ev = (size_t)(n * S + i);
@@ -784,6 +801,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       }
     }
   }
+  if (p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
   if (my_node >= 0) p.lam[my_node] = ok ? lam : __int_as_float(0x7fc00000);
 }
 
@@ -883,6 +901,7 @@ int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
     if (fa && fa[0] == '1') hipLaunchKernelGGL(vmh_set_word_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, 1u);
   }
   k.n_steps = a.n_steps; k.S = a.S; k.u_in = a.u_in; k.u_out = a.u_out; k.x0 = a.x0; k.x1 = a.x1;
+  k.save = a.save; k.save_every = a.save_every; k.save_off = a.save_off;
   k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.cf = a.cf;
   const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
   NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -901,6 +920,7 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   VmhBwdK k;
   fill_meta(k.m, a);
+  k.dsave = a.dsave; k.save_every = a.save_every; k.save_off = a.save_off;
   k.n_steps = a.n_steps; k.S = a.S; k.lam = a.lam; k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.dz_phi = a.dz_phi; k.dz_gam = a.dz_gam;
   k.dsrc0 = a.dsrc; k.dsrc1 = a.dsrc + k.m.n_edges; k.cb = a.cb;
   const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);

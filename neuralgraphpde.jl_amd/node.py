@@ -242,6 +242,7 @@ class _VmhPlan:
         self.members = 1
         self.n_nodes = int(handle._n_nodes)
         self.n_phi, self.n_gam = len(phi_acts), len(gam_acts)
+        self.n_steps = int(n_steps)
         out = C.c_void_p()
         ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
         _lib.check(self.lib.ngpde_node_vmh_create(handle.ptr, 1, int(pd), _lib.ptr(pos), self.n_phi, ia(phi_dims), ia(phi_acts), self.n_gam,
@@ -277,19 +278,27 @@ def _ptrs(ts):
 
 
 class _NodeVmhFn(torch.autograd.Function):
-    """u(T) = solve(du/dt = VMHConv(phi, gamma)(u)) on the device-resident plan; args: u [N], plan, n_phi, then per layer (weight
-    [in][out], bias or None) of phi followed by gamma's"""
+    """u(T) = solve(du/dt = VMHConv(phi, gamma)(u)) on the device-resident plan; args: u [N], plan, (save_every, save_start) or None,
+    then per layer (weight [in][out], bias or None) of phi followed by gamma's.  With saveat the result is the [T][N] array of the
+    saved states (ngpde_node_vmh_forward_saveat) and the cotangent of every one of them enters the adjoint at its time."""
 
     @staticmethod
-    def forward(ctx, u, plan, *wb):
+    def forward(ctx, u, plan, save, *wb):
         lib = _lib.load()
         u = u.contiguous()
         ws = [w.contiguous() for w in wb[0::2]]
         bs = [None if b is None else b.contiguous() for b in wb[1::2]]
         n_phi = plan.n_phi
-        uT = torch.empty_like(u)
-        _lib.check(lib.ngpde_node_vmh_forward(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]), _ptrs(bs[n_phi:]),
-                                              _lib.ptr(uT), _lib.current_stream()))
+        if save is None:
+            uT = torch.empty_like(u)
+            _lib.check(lib.ngpde_node_vmh_forward(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]), _ptrs(bs[n_phi:]),
+                                                  _lib.ptr(uT), _lib.current_stream()))
+        else:
+            k, start = save
+            uT = torch.empty((plan.n_steps // k + int(start), u.numel()), dtype=torch.float32, device=u.device)
+            _lib.check(lib.ngpde_node_vmh_forward_saveat(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]),
+                                                         _ptrs(bs[n_phi:]), int(k), int(start), _lib.ptr(uT), _lib.current_stream()))
+        ctx.save = save
         plan.gen += 1
         ctx.plan, ctx.gen, ctx.token = plan, plan.gen, plan.claim()
         ctx.save_for_backward(*ws)
@@ -305,17 +314,23 @@ class _NodeVmhFn(torch.autograd.Function):
         ws = list(ctx.saved_tensors)
         n_phi = plan.n_phi
         dev = ws[0].device
-        du0 = torch.empty_like(duT, memory_format=torch.contiguous_format)
+        duT = duT.contiguous()
+        du0 = torch.empty((duT.shape[-1],), dtype=torch.float32, device=dev)
         dws = [torch.empty_like(w) for w in ws]
         dbs = [torch.empty((w.shape[1],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
-        _lib.check(lib.ngpde_node_vmh_backward(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), _lib.ptr(duT.contiguous()), _lib.ptr(du0),
-                                               _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]), _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]),
-                                               _lib.current_stream()))
+        if ctx.save is None:
+            _lib.check(lib.ngpde_node_vmh_backward(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), _lib.ptr(duT), _lib.ptr(du0),
+                                                   _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]), _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]),
+                                                   _lib.current_stream()))
+        else:
+            _lib.check(lib.ngpde_node_vmh_backward_saveat(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), int(ctx.save[0]), int(ctx.save[1]),
+                                                          _lib.ptr(duT), _lib.ptr(du0), _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]),
+                                                          _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]), _lib.current_stream()))
         plan._pending = False
         grads = []
         for dw, db in zip(dws, dbs):
             grads += [dw, db]
-        return (du0, None, *grads)
+        return (du0, None, None, *grads)
 
 
 # ---- any right-hand side: explicit RK stepping with every combination as ONE library launch ---------------------------------
@@ -721,7 +736,7 @@ class NeuralODE(AbstractExplicitLayer):
         if not (isinstance(m, VMHConv) and u.is_cuda and u.dim() == 2 and u.shape[1] == 1):
             return None
         g = st["graph"]
-        if list(g.ndata) != ["x"] or getattr(g, "_members", None):
+        if list(g.ndata) != ["x"]:      # (a batched graph is one block-diagonal graph to this plan: its members' tiles never neighbour)
             return None
         try:
             phi, gam = _dense_stack(m.ϕ, ps["ϕ"], "ϕ"), _dense_stack(m.γ, ps["γ"], "γ")
@@ -798,10 +813,13 @@ class NeuralODE(AbstractExplicitLayer):
                                              f"{a.numel()} entries, expected 2 x {gm.out_chs} x {gm.heads}")
             uT = _NodeGatFn.apply(u, w, a, b, gplan)
             return uT.T, st
-        vplan = self.vmh_plan_for(ps, st, u, needs_grad) if not self.save_every else None
+        vplan = self.vmh_plan_for(ps, st, u, needs_grad)
         if vplan is not None:
             plan_v, wb = vplan
-            uT = _NodeVmhFn.apply(u.reshape(-1), plan_v, *wb)
+            if self.save_every:      # saveat: the (1 x N x T) array of the solution at t0 (+ j saveat)
+                us = _NodeVmhFn.apply(u.reshape(-1), plan_v, (self.save_every, self.save_start), *wb)
+                return us.T.unsqueeze(0), st
+            uT = _NodeVmhFn.apply(u.reshape(-1), plan_v, None, *wb)
             return uT.reshape(u.shape).T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch

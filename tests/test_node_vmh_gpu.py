@@ -116,18 +116,76 @@ def test_vmh_resident_plan_equals_the_generic_solver_at_the_tutorial_shape(monke
         assert torch.equal(a, b)     # no atomics, fixed summation orders, and every hand-off waited for
 
 
+@pytest.mark.parametrize("solver,save_start,batched", [("tsit5", True, False), ("euler", False, False), ("tsit5", True, True)])
+def test_vmh_resident_saveat_against_the_oracle_segment_by_segment(solver, save_start, batched, monkeypatch):
+    # NeuralODE(gnn, tspan, Tsit5(); saveat = dt_train) (docs/src/tutorials/VMH.md:85): the (1 x N x T) array of the solution at the
+    # saved times on the device-resident plan, the loss reads every one of them (:104-108); the oracle solves segment by segment and
+    # its adjoint walks the segments backwards, adding each saved state's cotangent.  batched: a block-diagonal batch of three
+    # point clouds (:132-134) is one graph to the plan
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    k, nseg, dt = 2, 3, 0.05
+    if batched:
+        gs, ogs = zip(*[spatial(220 + 16 * j, 50 + j) for j in range(3)])
+        g, og = ng.batch(list(gs)), O.batch(list(ogs))
+    else:
+        g, og = spatial(600, 44)
+    N = g.num_nodes
+    phi, gam = tutorial_mlps(depth=3)
+    node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver=solver, n_steps=k * nseg, dt=dt, saveat=k * dt, save_start=save_start)
+    ps0, st = ng.setup(6, node)
+    ps = prep(ps0, 6)
+    rng = np.random.default_rng(10)
+    u0 = rng.normal(size=(1, N)).astype(np.float32)
+    T = nseg + int(save_start)
+    R = rng.normal(size=(1, N, T))
+    u = torch.as_tensor(u0, device=DEV).requires_grad_(True)
+    us, _ = node(u, ps, st)
+    assert "vmh" in plan_flags(node) and tuple(us.shape) == (1, N, T)
+    ophi, ogam = omlp(phi, ps["ϕ"]), omlp(gam, ps["γ"])
+    tab = O.TABLEAUS[solver]
+    gphi = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ophi]
+    ggam = [dict(weight=np.zeros_like(L["weight"]), bias=np.zeros_like(L["bias"])) for L in ogam]
+
+    def vjp(cache, kbar):
+        gr = O.vmh_conv_backward(cache, kbar)
+        return gr["x"], gr
+
+    def accumulate(gr):
+        for dst, src in ((gphi, gr["phi"]), (ggam, gr["gamma"])):
+            for d_, s_ in zip(dst, src):
+                d_["weight"] += s_["weight"]
+                d_["bias"] += np.asarray(s_["bias"]).reshape(d_["bias"].shape)
+    states, tapes, cur = [u0.astype(np.float64)], [], u0.astype(np.float64)
+    for _ in range(nseg):
+        cur, tape = O.rk_solve(lambda x: O.vmh_conv(x, ophi, ogam, og), cur, tab, dt, k)
+        states.append(cur); tapes.append(tape)
+    want = np.stack(states[0 if save_start else 1:], axis=2)
+    close(us, want, rtol=2e-4)
+    (us * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    off = 1 if save_start else 0
+    lam = np.zeros_like(cur)
+    for j in range(nseg - 1, -1, -1):
+        lam = O.rk_adjoint(vjp, tapes[j], lam + R[:, :, j + off], tab, dt, accumulate)
+    if save_start:
+        lam = lam + R[:, :, 0]
+    n1, o1 = mlp_grad_pairs(ps["ϕ"], gphi, phi)
+    n2, o2 = mlp_grad_pairs(ps["γ"], ggam, gam)
+    check_grads(ps, (n1 + n2, o1 + o2), u, lam)
+
+
 def test_vmh_resident_plan_leaves_unsupported_models_to_the_generic_solver(monkeypatch):
     monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
     N = 400
     pts = torch.as_tensor(S.uniform01(5, 2 * N).reshape(2, N).astype(np.float32), device=DEV)
     g = ng.GNNGraph(ng.knn_graph(pts, 5), ndata={"x": pts})      # (every node has neighbours: a max over none is -Inf, as NNlib's)
-    # a state of three features, a max aggregation, saveat: none of them is the plan's; the solve runs on the generic solver
+    # a state of three features, a max aggregation, a message MLP wider than 64: none of them is the plan's; the solve runs on the generic solver
     phi3 = ng.Chain(ng.Dense(2 * 3 + 2, 16, "tanh"), ng.Dense(16, 8))
     gam3 = ng.Chain(ng.Dense(3 + 8, 16, "tanh"), ng.Dense(16, 3))
     cases = [(ng.NeuralODE(ng.VMHConv(phi3, gam3, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05), 3)]
     phi, gam = tutorial_mlps(depth=3)
     cases.append((ng.NeuralODE(ng.VMHConv(phi, gam, aggr="max", initialgraph=g), solver="tsit5", n_steps=2, dt=0.05), 1))
-    cases.append((ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", tspan=(0.0, 0.2), n_steps=4, saveat=0.1), 1))
+    wide = ng.Chain(ng.Dense(4, 80, "tanh"), ng.Dense(80, 40))           # wider than the 64 columns the kernels stage
+    cases.append((ng.NeuralODE(ng.VMHConv(wide, gam, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05), 1))
     for node, h in cases:
         ps, st = ng.setup(1, node)
         ps = prep(ps, 1)
