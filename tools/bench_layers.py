@@ -12,7 +12,7 @@ DEV = "cuda"
 
 
 def timeit(fn, reps):
-    for _ in range(2): fn()
+    for _ in range(5): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -31,6 +31,12 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -o k -- python3 $R/tools/bench_layers.py --only c4 --traj 64 --reps 10 > $O/c4_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -o k -- python3 $R/tools/bench_layers.py --only c5 --width 128 --radius 0.1 --reps 10 > $O/c5_stats.log 2>&1
 cd $R
+# NeuralODE(VMHConv) on the device-resident plan: outputs against the generic solver, kernel stats, phase stamps (diagnostic library)
+STEPS=20 TAB=tsit5 REPS=5 timeout 200 python3 tools/debug_vmh_node.py > $O/vmh_node.txt 2>/dev/null
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vmh_stats -o k -- python3 $R/tools/debug_vmh_node.py > $O/vmh_stats.log 2>&1
+cd $R
+[ -f neuralgraphpde.jl_amd/libngpde_diag.so ] && timeout 200 python3 tools/stamps_vmh.py > $O/vmh_stamps.txt 2>/dev/null
 python3 tools/hbm_rw_probe.py > $O/hbm_rw_probe.jsonl 2>/dev/null
 [ -f neuralgraphpde.jl_amd/libngpde_diag.so ] && timeout 200 python3 tools/stamps_pair.py > $O/pair_stamps.txt 2>/dev/null
 # does the fp32 matrix instruction run beside the VALU?
