@@ -327,6 +327,20 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   float su = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f, sk4 = 0.f;
   const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
   if (my_node >= 0) su = p.u_in[my_node];
+  // With ONE round (the usual case) the tape rows of a slice stay in registers and leave one evaluation LATE: layer l's rows of the
+  // previous evaluation are stored right before this evaluation's overwrite them -- four stores per lane in front of every layer's 64
+  // MFMAs instead of ~100 KB per workgroup in one burst, and the drain in front of the flag waits for the 16 state values alone
+  const bool defer = p.tape_phi != nullptr && n_rounds == 1;
+  float4 ta[kVmhMaxL][4];
+  size_t pe_keep = 0, ev_prev = 0;
+  bool valid_keep = false, have_prev = false;
+  auto store_tape_rows = [&](int l, size_t evx) {
+    const int n_ct = (m.phi_din[l] + 15) >> 4;
+    float *row = p.tape_phi + (((size_t)l * m.evals + evx) * E + pe_keep) * VW + 4 * kq;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      if (ct < n_ct) __builtin_nontemporal_store((f4v){ta[l][ct].x, ta[l][ct].y, ta[l][ct].z, ta[l][ct].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(row + 16 * ct)));
+  };
   bool ok = true;
   int ph = 0;
   for (int n = 0; n < p.n_steps && ok; ++n) {
@@ -344,12 +358,6 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       // ---- message MLP per 16-edge wave slice, messages summed per target through the staging tile
       float4 racc = f4_zero();
       const int lo = t.off[rg], hi = has_row ? t.off[rg + 1] : t.off[rg];
-      // with ONE round (the usual case) the tape rows of the slice stay in registers and leave behind the publish: the drain in
-      // front of the flag then waits for the 16 state values alone, not for ~100 KB of tape on its way to memory
-      const bool defer = p.tape_phi != nullptr && n_rounds == 1;
-      float4 ta[kVmhMaxL][4];
-      size_t pe_keep = 0;
-      bool valid_keep = false;
       for (int rd = 0; rd < n_rounds; ++rd) {
         const int c0 = rd * VROUND;
         const bool wave_on = c0 + c.wave * 16 < c.total;   // wave-uniform
@@ -376,10 +384,13 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
             const int din = m.phi_din[l], dw = m.phi_dout[l];
             const int n_ct = (din + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
             if (defer) {
+              if (have_prev && valid_keep) store_tape_rows(l, ev_prev);
 #pragma unroll
               for (int ct = 0; ct < 4; ++ct) ta[l][ct] = a[ct];
-              pe_keep = pe;
-              valid_keep = valid;
+              if (l + 1 == m.n_phi) {   // (a lane's edge is the same in every evaluation of a one-round solve)
+                pe_keep = pe;
+                valid_keep = valid;
+              }
             } else if (p.tape_phi && valid) {
               float *row = p.tape_phi + (((size_t)l * m.evals + ev) * E + pe) * VW + 4 * kq;
 #pragma unroll
@@ -504,18 +515,14 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       }
       vmh_publish(m, c, ph);
       NGPDE_VST(m, ph, 6);
-      if (defer && valid_keep) {
-#pragma unroll
-        for (int l = 0; l < kVmhMaxL; ++l) {
-          if (l >= m.n_phi) break;
-          const int n_ct = (m.phi_din[l] + 15) >> 4;
-          float *row = p.tape_phi + (((size_t)l * m.evals + ev) * E + pe_keep) * VW + 4 * kq;
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            if (ct < n_ct) __builtin_nontemporal_store((f4v){ta[l][ct].x, ta[l][ct].y, ta[l][ct].z, ta[l][ct].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(row + 16 * ct)));
-        }
-      }
+      have_prev = true;
+      ev_prev = ev;
     }
+  }
+  if (defer && have_prev && valid_keep) {   // the last evaluation's rows
+#pragma unroll
+    for (int l = 0; l < kVmhMaxL; ++l)
+      if (l < m.n_phi) store_tape_rows(l, ev_prev);
   }
   // (u_out may alias u_in: a workgroup writes its rows only after every reader of its u0 rows is past its first phase -- the
   // host takes this plan for solves of at least two right-hand-side evaluations)
@@ -606,6 +613,18 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
     if (one_round && m.n_phi >= 2) fetch_phi(m.n_phi - 2, ev, ytop);
   };
   fetch_phase((size_t)(p.n_steps * S - 1));
+  // the dz rows of a one-round solve leave one evaluation late, layer by layer in front of the layer's MFMAs (see the forward kernel)
+  const bool defer = one_round;
+  float4 tz[kVmhMaxL][4];
+  size_t pe_keep = pe1, ev_prev = 0;
+  bool valid_keep = valid1, have_prev = false;
+  auto store_dz_rows = [&](int l, size_t evx) {
+    const int n_mt = (m.phi_dout[l] + 15) >> 4;
+    float *zrow = p.dz_phi + (((size_t)l * m.evals + evx) * E + pe_keep) * VW + 4 * kq;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < n_mt) __builtin_nontemporal_store((f4v){tz[l][mt].x, tz[l][mt].y, tz[l][mt].z, tz[l][mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
+  };
   bool ok = true;
   int ph = 0;
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
@@ -681,10 +700,6 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       // ---- phi backwards per 16-edge wave slice
       for (int k = c.tid; k < c.total; k += VT) s_es[k] = 0.f;
       __syncthreads();
-      const bool defer = n_rounds == 1;   // (see the forward kernel: the dz rows leave behind the publish)
-      float4 tz[kVmhMaxL][4];
-      size_t pe_keep = 0;
-      bool valid_keep = false;
       for (int rd = 0; rd < n_rounds; ++rd) {
         const int c0 = rd * VROUND;
         const bool wave_on = c0 + c.wave * 16 < c.total;
@@ -694,8 +709,6 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           const unsigned ew = t.edge[valid ? k : 0];
           const int r = ew & 0xff;
           const size_t pe = (size_t)(t.rs[r] + (k - t.off[r]));
-          pe_keep = pe;
-          valid_keep = valid;
           const float inv = valid ? t.inv[r] : 0.f;
           float4 g[4];
 #pragma unroll
@@ -728,6 +741,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
             for (int mt = 0; mt < 4; ++mt)
               if (!(valid && 16 * mt + 4 * kq < dw)) g[mt] = f4_zero();
             if (defer) {
+              if (have_prev && valid_keep) store_dz_rows(l, ev_prev);
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt) tz[l][mt] = g[mt];
             } else if (valid) {
@@ -764,17 +778,8 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       }
       vmh_publish(m, c, ph);
       NGPDE_VST(m, ph, 4);
-      if (defer && valid_keep) {
-#pragma unroll
-        for (int l = 0; l < kVmhMaxL; ++l) {
-          if (l >= m.n_phi) break;
-          const int n_mt = (m.phi_dout[l] + 15) >> 4;
-          float *zrow = p.dz_phi + (((size_t)l * m.evals + ev) * E + pe_keep) * VW + 4 * kq;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            if (mt < n_mt) __builtin_nontemporal_store((f4v){tz[l][mt].x, tz[l][mt].y, tz[l][mt].z, tz[l][mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
-        }
-      }
+      have_prev = true;
+      ev_prev = ev;
       if (ev > 0) fetch_phase(ev - 1);
       NGPDE_VST(m, ph, 5);
       if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
@@ -800,6 +805,11 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         }
       }
     }
+  }
+  if (defer && have_prev && valid_keep) {   // the last evaluation's dz rows
+#pragma unroll
+    for (int l = 0; l < kVmhMaxL; ++l)
+      if (l < m.n_phi) store_dz_rows(l, ev_prev);
   }
   if (p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
   if (my_node >= 0) p.lam[my_node] = ok ? lam : __int_as_float(0x7fc00000);

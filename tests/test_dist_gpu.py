@@ -100,7 +100,8 @@ def _run_bench(extra_env, *argv, timeout=900):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    # (bench.py asserts nothing about the plan, these tests do: the child runs without the suite's library switches)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT") and not k.startswith("NGPDE_")}
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], cwd=root, env=env, capture_output=True, text=True,
                        timeout=timeout)

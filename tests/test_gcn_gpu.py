@@ -513,14 +513,19 @@ def _oracle_node_with_seed(params, og, u0, seed, tableau, dt, nsteps, act="relu"
     return uT, du0, acc
 
 
+PLAN_SWITCHES = ("NGPDE_NO_PERSISTENT", "NGPDE_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_TILE_PAIRS", "NGPDE_TILE_ROUNDS", "NGPDE_NO_INTERLEAVE",
+                 "NGPDE_WEIGHTED_TILE_ROUNDS", "NGPDE_NO_TILE_PIPE", "NGPDE_FUSED_RHS", "NGPDE_FUSED_RHS_BATCH", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK")
+
+
 def needs_persistent_plan(monkeypatch=None):
     """The persistent solver plan is what these tests are about: they lift a suite-wide NGPDE_NO_PERSISTENT (read at every plan
     creation) and skip under NGPDE_NO_HALO, which the library reads once and which leaves no plan it could run on."""
     import os
     if os.environ.get("NGPDE_NO_HALO") == "1":
         pytest.skip("NGPDE_NO_HALO=1: no LDS-staged tiles, so no persistent plan")
-    if monkeypatch is not None:
-        monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+    if monkeypatch is not None:      # (the suite may run under any of the plan-selecting switches: tools/switch_matrix.sh)
+        for var in PLAN_SWITCHES:
+            monkeypatch.delenv(var, raising=False)
 
 
 @pytest.mark.parametrize("tab,persistent", [("tsit5", True), ("euler", True), ("tsit5", False)])
