@@ -766,7 +766,7 @@ def test_graph_node_tutorial_training_loop(graph_kind):
         l, yhat = loss_fn()
         acc = float((yhat.T[~mask].argmax(1) == y[~mask]).double().mean())
     plan = next(iter(node._plans.values()))[0]
-    switched = any(os.environ.get(v) for v in ("NGPDE_NO_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_HALO", "NGPDE_PERSISTENT"))
+    switched = any(os.environ.get(v) for v in ("NGPDE_NO_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_HALO", "NGPDE_PERSISTENT", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK"))
     assert switched or ("persistent_fwd" in plan.flags()) == (graph_kind == "spatial"), plan.flags()
     assert not plan.fault()
     assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses[::8]

@@ -147,7 +147,7 @@ def test_two_persistent_plans_on_two_streams_take_turns():
     import ngpde_amd as ng
     from ngpde_amd import _lib, synth as S
     from ngpde_amd.node import _Plan
-    if os.environ.get("NGPDE_NO_HALO") == "1" or os.environ.get("NGPDE_NO_PERSISTENT") == "1":
+    if any(os.environ.get(v) == "1" for v in ("NGPDE_NO_HALO", "NGPDE_NO_PERSISTENT", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK")):
         pytest.skip("no persistent plan under this switch")
     lib, p = _lib.load(), _lib.ptr
     N, D, STEPS = 16384, 64, 10
