@@ -379,6 +379,15 @@ def secondary(dev, world, rank, dist):
                                              "weight-pullback GEMM per layer over the tapes") if "vmh" in flags_v
                                             else "NeuralODE(VMHConv, capture=True): HIP-graph replay of the generic solver",
                                     "plan_flags": flags_v}
+        # the arithmetic of one right-hand-side evaluation and its pullback (products of the two Dense chains: forward, input gradient,
+        # weight gradient), priced against the fp32-MFMA peak as C4 / C5 are
+        ne_v = int(gv.num_edges)
+        mac_phi = 4 * 60 + 60 * 60 + 60 * 60 + 60 * 40
+        mac_gam = 41 * 60 + 60 * 60 + 60 * 60 + 60 * 1
+        gflop_v = 3 * 2 * (ne_v * mac_phi + nv * mac_gam) * 6 * steps_v / 1e9
+        ach_v = gflop_v / msv
+        out["VMH_node_tsit5x20"]["roofline"] = {"bound": "mfma", "achieved": round(ach_v, 2), "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                                                "frac": round(ach_v / FP32_MFMA_PEAK_TFS, 4), "algorithmic_GFLOP_solve_and_adjoint": round(gflop_v, 2)}
         if "vmh" in flags_v:   # the same solve on the generic solver (every stage the layer's own kernels), captured into HIP graphs
             os.environ["NGPDE_NO_VMH_NODE"] = "1"
             try:
