@@ -98,6 +98,7 @@ struct ngpde_graph {
   int32_t n_sched = 0;  // n_tiles * kTileRows
   // derived on first use, under lazy_mu (the handle stays shareable between host threads)
   mutable std::mutex lazy_mu;
+  mutable int sched_same = -1;   // do the by-target and by-source schedules name the same node at every position? (-1: not asked yet; gat_fused.hip)
   mutable ngpde::HaloInverse halo_inv;
 };
 

@@ -1453,7 +1453,10 @@ bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c) {
   }
   const int nt = g->n_sched / kTileRows;
   if (nt < 1 || nt > cus * occ) return false;
-  // both directions' schedules must name the same node at every position (the solver keeps per-thread state across the halves)
+  // both directions' schedules must name the same node at every position (the solver keeps per-thread state across the halves):
+  // compared on the device ONCE per handle (a launch on the NULL stream and a blocking copy -- not something to repeat per solve)
+  std::lock_guard<std::mutex> lock(g->lazy_mu);
+  if (g->sched_same >= 0) return g->sched_same == 1;
   unsigned *bad = nullptr, h = 1;
   if (hipMalloc((void **)&bad, sizeof(unsigned)) != hipSuccess) return false;
   bool same = hipMemset(bad, 0, sizeof(unsigned)) == hipSuccess;
@@ -1462,6 +1465,7 @@ bool gat_node_persistent_supported(const ngpde_graph *g, int heads, int c) {
     same = hipMemcpy(&h, bad, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && h == 0;
   }
   (void)hipFree(bad);
+  g->sched_same = same ? 1 : 0;
   return same;
 }
 

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
           tile_ctx_from_lds<false>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
           // ---- T0
-          const int turn = (ph - 1) * KT + s + 1;   // (stamps: one record per turn)
+          [[maybe_unused]] const int turn = (ph - 1) * KT + s + 1;   // (stamps: one record per turn)
           NGPDE_PST(p.m, turn, 0);
           wait_vmcnt0();
           __syncthreads();

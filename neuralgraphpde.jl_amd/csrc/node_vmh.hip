@@ -318,7 +318,6 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   if (c.tid < 42) t.misc[c.tid] = p.cf[c.tid];
   __syncthreads();
   const int ei = c.ei, kq = c.kq;
-  const int Mw = m.phi_dout[m.n_phi - 1];      // message width
   const int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
   const int rg = min(c.g16, VR - 1);   // the row of this lane group (groups 16.. idle in the row-wise steps)
