@@ -196,7 +196,8 @@ def test_vmh_resident_plan_leaves_unsupported_models_to_the_generic_solver(monke
         assert torch.isfinite(out).all() and torch.isfinite(u.grad).all()
 
 
-def test_vmh_abi_rejects_null_and_mismatched_arguments():
+def test_vmh_abi_rejects_null_and_mismatched_arguments(monkeypatch):
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)       # (the suite may run under that switch)
     lib = _lib.load()
     N = 300
     g, _ = spatial(N, 8)
