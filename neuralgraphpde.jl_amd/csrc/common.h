@@ -316,6 +316,7 @@ struct VmhLaunch {
   const float *cf = nullptr, *cb = nullptr;
   // saveat (docs/src/tutorials/VMH.md:85): the state after every save_every steps goes to save[j][N], j = step / save_every - 1 + save_off
   // (save_off = 1: slot 0 holds u0); the adjoint adds dsave[j] to lambda at that time
+  float *state = nullptr;        // tile rounds: [16][N] per-node state between a half tile's turns (forward 6 rows, adjoint 8)
   float *save = nullptr;
   const float *dsave = nullptr;
   int save_every = 0, save_off = 0;

@@ -1031,6 +1031,7 @@ struct ngpde_node_vmh {
   bool with_bwd = false, solved = false;
   NodePersist persist;
   float *pos = nullptr, *cf = nullptr, *cb = nullptr, *x = nullptr;         // x: [2][N] exchanged stage input
+  float *state = nullptr;                                                     // [16][N] tile rounds: per-node state between turns
   float *tape_phi = nullptr, *tape_gam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;
   float *partial = nullptr, *dwpad = nullptr;                                // weight-pullback workspace; [64 x 64 + 64] padded result
   size_t tape_bytes = 0, partial_floats = 0;
@@ -1038,7 +1039,7 @@ struct ngpde_node_vmh {
 
 static void node_vmh_free(ngpde_node_vmh *p) {
   if (!p) return;
-  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->tape_phi, p->tape_gam, p->dz_phi, p->dz_gam, p->dsrc, p->partial, p->dwpad};
+  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->tape_phi, p->tape_gam, p->dz_phi, p->dz_gam, p->dsrc, p->partial, p->dwpad};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   node_persistent_free(&p->persist);
@@ -1109,6 +1110,7 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
   if (st == NGPDE_OK) step(alloc(&p->cf, 48, false));
   if (st == NGPDE_OK) step(alloc(&p->cb, 64, false));
   if (st == NGPDE_OK) step(alloc(&p->x, 2 * N, true));
+  if (st == NGPDE_OK) step(alloc(&p->state, 16 * N, true));
   if (st == NGPDE_OK && p->with_bwd) {
     // (zeroed once: the padded columns of a layer's rows are never written, and the weight-pullback GEMMs read whole 64-wide rows)
     const size_t tp = (size_t)n_phi * evals * E * 64, tg = (size_t)n_gamma * evals * N * 64;
@@ -1157,7 +1159,7 @@ static void vmh_fill(const ngpde_node_vmh *p, VmhLaunch &a, const float *const *
   a.g = p->g; a.ps = &p->persist; a.shape = p->shape; a.n_steps = p->n_steps; a.S = p->S; a.pos = p->pos;
   for (int l = 0; l < p->shape.n_phi; ++l) { a.phi_w[l] = phi_w[l]; a.phi_b[l] = phi_b ? phi_b[l] : nullptr; }
   for (int l = 0; l < p->shape.n_gam; ++l) { a.gam_w[l] = gam_w[l]; a.gam_b[l] = gam_b ? gam_b[l] : nullptr; }
-  a.x0 = p->x; a.x1 = p->x + p->g->n_nodes; a.tape_phi = p->tape_phi; a.tape_gam = p->tape_gam; a.dz_phi = p->dz_phi; a.dz_gam = p->dz_gam;
+  a.x0 = p->x; a.x1 = p->x + p->g->n_nodes; a.state = p->state; a.tape_phi = p->tape_phi; a.tape_gam = p->tape_gam; a.dz_phi = p->dz_phi; a.dz_gam = p->dz_gam;
   a.dsrc = p->dsrc; a.cf = p->cf; a.cb = p->cb;
 }
 

@@ -42,6 +42,7 @@ constexpr int VR = 16;                // target rows per workgroup
 constexpr int VTS = VW + 4;           // staging tile stride
 constexpr int VMaxE = VR * kSlotWidth;   // edges a workgroup may own
 constexpr int VNbr = 64;
+constexpr int kVmhMaxTurns = 64;       // tile rounds: half tiles per workgroup (64 x 256 CUs x 16 rows = 262 144 nodes)
 
 #ifdef NGPDE_STAMPS
 // diagnostic build only (tools/stamps_vmh.py): shader-clock stamps of thread 0 at 8 points of the first g_vst_max phases
@@ -182,7 +183,8 @@ __device__ __forceinline__ void slice_matmul(const float *mat, const float4 (&in
   }
 }
 
-__device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs &t) {
+// the context of half tile h (= 2 tile + half): the workgroup's only one, or the one whose turn it is (tile rounds)
+__device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs &t, int h) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
@@ -190,7 +192,7 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   c.q = c.tid & 15;
   c.ei = c.lane & 15;
   c.kq = c.lane >> 4;
-  c.wg = blockIdx.x;
+  c.wg = h;
   c.tile = c.wg >> 1;
   c.half = c.wg & 1;
   const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + min(c.g16, VR - 1)];   // (lane groups 16.. have no row)
@@ -288,11 +290,13 @@ struct VmhFwdK {
   float *u_out, *x0, *x1;     // the exchanged stage input [N], ping-pong
   float *save;                // saveat: [T][N] or null
   int save_every, save_off;
+  float *state;               // tile rounds: [6][N] u and k_0 .. k_4 of the own nodes between a half tile's turns
   float *tape_phi;            // [n_phi][evals][E][64] inputs of phi's layers (p order), or null (forward-only plan)
   float *tape_gam;            // [n_gam][evals][N][64] inputs of gamma's layers
   const float *cf;            // [42] forward coefficient table (node_persistent.hip's layout)
 };
 
+template <bool ROUNDS>
 __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ __attribute__((aligned(16))) float s_bias[2 * kVmhMaxL * VW];
@@ -305,7 +309,13 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   t.W = dyn; t.S = dyn + (size_t)n_mats * VW * VW; t.bias = s_bias; t.hh = s_hh; t.px = s_px; t.hnode = s_hnode; t.off = s_off; t.rs = s_rs;
   t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
   VCtx c;
-  vctx_init(m, c, t);
+  // TILE ROUNDS: a graph of more half tiles than the device keeps resident gives every workgroup K of them -- b, b + G, b + 2 G, ... --
+  // which it walks in that order in every phase; the weights stay in LDS for all of them, a half tile's tables are rebuilt at its
+  // turn and the Runge-Kutta state of its rows waits in memory.  By the time a half tile's turn comes again its neighbours' rows of
+  // the previous phase have long arrived: the hand-off that bounds the one-tile form costs nothing here.
+  // (ROUNDS is a template parameter: the one-half-tile form keeps its register allocation, the rounds form carries no rows across phases)
+  const int nh = 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
+  vctx_init(m, c, t, blockIdx.x);
   // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
   // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
   if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
@@ -318,18 +328,19 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   if (c.tid < 42) t.misc[c.tid] = p.cf[c.tid];
   __syncthreads();
   const int ei = c.ei, kq = c.kq;
-  const int n_rounds = (c.total + VROUND - 1) / VROUND;
+  int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
   const int rg = min(c.g16, VR - 1);   // the row of this lane group (groups 16.. idle in the row-wise steps)
   const bool has_row = c.g16 < VR;
   // the 16 row lanes (tid < 16 <-> row tid) keep the Runge-Kutta state of their node
   float su = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f, sk4 = 0.f;
-  const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
   if (my_node >= 0) su = p.u_in[my_node];
+  const int last_ph = p.n_steps * p.S;
   // With ONE round (the usual case) the tape rows of a slice stay in registers and leave one evaluation LATE: layer l's rows of the
   // previous evaluation are stored right before this evaluation's overwrite them -- four stores per lane in front of every layer's 64
   // MFMAs instead of ~100 KB per workgroup in one burst, and the drain in front of the flag waits for the 16 state values alone
-  const bool defer = p.tape_phi != nullptr && n_rounds == 1;
+  const bool defer = !ROUNDS && p.tape_phi != nullptr && n_rounds == 1;
   float4 ta[kVmhMaxL][4];
   size_t pe_keep = 0, ev_prev = 0;
   bool valid_keep = false, have_prev = false;
@@ -348,6 +359,19 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       const float *X = ph == 1 ? p.u_in : (((ph - 1) & 1) ? p.x1 : p.x0);
       float *Xn = (ph & 1) ? p.x1 : p.x0;
       const size_t ev = (size_t)(n * p.S + i);
+      for (int s = 0; s < K; ++s) {
+      if constexpr (ROUNDS) {   // this turn's half tile: tables, rows' state
+        const int h = blockIdx.x + s * G;
+        if (h >= nh) break;
+        vctx_init(m, c, t, h);
+        n_rounds = (c.total + VROUND - 1) / VROUND;
+        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+        if (my_node >= 0) {
+          su = ph == 1 ? p.u_in[my_node] : p.state[my_node];
+          sk0 = ph == 1 ? 0.f : p.state[N + my_node]; sk1 = ph == 1 ? 0.f : p.state[2 * N + my_node]; sk2 = ph == 1 ? 0.f : p.state[3 * N + my_node];
+          sk3 = ph == 1 ? 0.f : p.state[4 * N + my_node]; sk4 = ph == 1 ? 0.f : p.state[5 * N + my_node];
+        }
+      }
       NGPDE_VST(m, ph, 0);
       if (!vmh_wait(m, c, ph - 1, t.s_ok)) { ok = false; break; }
       NGPDE_VST(m, ph, 1);
@@ -514,9 +538,34 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       }
       vmh_publish(m, c, ph);
       NGPDE_VST(m, ph, 6);
+      if (ROUNDS && my_node >= 0) {
+        p.state[my_node] = su; p.state[N + my_node] = sk0; p.state[2 * N + my_node] = sk1; p.state[3 * N + my_node] = sk2;
+        p.state[4 * N + my_node] = sk3; p.state[5 * N + my_node] = sk4;
+        if (ph == last_ph) {
+          if (p.u_out) p.u_out[my_node] = su;
+          if (p.save && p.save_off) p.save[my_node] = p.u_in[my_node];
+        }
+      }
+      }   // turns
       have_prev = true;
       ev_prev = ev;
     }
+  }
+  if constexpr (ROUNDS) {
+    if (!ok) {   // a wait gave up: every output row of this workgroup's half tiles says so
+      const float bad = __int_as_float(0x7fc00000);
+      for (int s = 0; s < K; ++s) {
+        const int h = blockIdx.x + s * G;
+        if (h >= nh) break;
+        const int nd = c.tid < VR ? m.sched_t[(size_t)(h >> 1) * kTileRows + (h & 1) * VR + c.tid].x : -1;
+        if (nd >= 0) {
+          if (p.u_out) p.u_out[nd] = bad;
+          if (p.save)
+            for (int j = 0; j < p.n_steps / p.save_every + p.save_off; ++j) p.save[(size_t)j * N + nd] = bad;
+        }
+      }
+    }
+    return;
   }
   if (defer && have_prev && valid_keep) {   // the last evaluation's rows
 #pragma unroll
@@ -548,8 +597,10 @@ struct VmhBwdK {
   const float *cb;            // [S][8]: cb[i][i] = dt b_i, cb[i][j] (j > i) = dt a[j][i]
   const float *dsave;         // saveat: the cotangents of the saved states [T][N] (lam comes in holding the last one's), or null
   int save_every, save_off;
+  float *state;               // tile rounds: [8][N] lambda, U-bar_0 .. U-bar_5 and the first half's own-row sums between a half tile's turns
 };
 
+template <bool ROUNDS>
 __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VR], s_misc[64], s_es[VMaxE], s_row[VR * 4];
@@ -561,36 +612,63 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   t.W = dyn; t.S = dyn + (size_t)n_mats * VW * VW; t.bias = nullptr; t.hh = s_hh; t.px = s_px; t.hnode = s_hnode; t.off = s_off; t.rs = s_rs;
   t.rnode = s_rnode; t.inv = s_inv; t.edge = s_edge; t.misc = s_misc; t.s_ok = s_okw;
   VCtx c;
-  vctx_init(m, c, t);
+  // TILE ROUNDS (see the forward kernel): K half tiles per workgroup.  A phase of the adjoint has its hand-off in the middle, so a
+  // workgroup makes TWO passes over its half tiles: pass 1 walks every one back to the per-edge gradients and publishes, pass 2 gathers by
+  // source -- a half tile waiting for a later one of the same workgroup would otherwise wait forever.
+  // (ROUNDS is a template parameter: the one-half-tile form keeps its register allocation, the rounds form carries no rows across phases)
+  const int nh = 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
+  vctx_init(m, c, t, blockIdx.x);
   // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
   // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
   if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
   for (int l = 0; l < m.n_phi; ++l) stage_weight(m.phi_w[l], m.phi_din[l], m.phi_dout[l], t.W + (size_t)l * VW * VW, c.tid, false);
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
   if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
-  if (c.g16 < VR) {   // positions, in the by-target order, of the out-edges of the own nodes (static): the by-source gather's addresses
-    const int nd = t.rnode[c.g16];
-    const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
-    if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
-    for (int j = c.q; j < kSlotWidth; j += 16) s_srcpos[c.g16 * kSlotWidth + j] = j < dg ? m.xpos_s[rp + j] : 0;
-  }
+  auto fill_srcpos = [&]() {   // positions, in the by-target order, of the out-edges of the own nodes: the by-source gather's addresses
+    if (c.g16 < VR) {
+      const int nd = t.rnode[c.g16];
+      const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
+      if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
+      for (int j = c.q; j < kSlotWidth; j += 16) s_srcpos[c.g16 * kSlotWidth + j] = j < dg ? m.xpos_s[rp + j] : 0;
+    }
+  };
+  fill_srcpos();
   __syncthreads();
   const int ei = c.ei, kq = c.kq;
   const int Mw = m.phi_dout[m.n_phi - 1];
-  const int n_rounds = (c.total + VROUND - 1) / VROUND;
+  int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
   const int S = p.S;
   const int rg = min(c.g16, VR - 1);
   const bool has_row = c.g16 < VR;
   // the 16 row lanes keep lambda and the stage adjoints of their node
-  const int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
   float lam = my_node >= 0 ? p.lam[my_node] : 0.f;
   float ub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int last_ph = p.n_steps * S;
+  auto load_state = [&](int ph) {   // (tile rounds) lambda and the stage adjoints of this turn's rows
+    if (my_node >= 0) {
+      lam = ph == 1 ? p.lam[my_node] : p.state[my_node];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ub[j] = ph == 1 ? 0.f : p.state[(size_t)(1 + j) * N + my_node];
+    } else {
+      lam = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ub[j] = 0.f;
+    }
+  };
+  auto store_state = [&]() {
+    if (my_node >= 0) {
+      p.state[my_node] = lam;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) p.state[(size_t)(1 + j) * N + my_node] = ub[j];
+    }
+  };
   float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
   // With ONE round a lane's edge is the same in every phase, and what a phase reads from the tapes does not depend on the exchange:
   // the outputs of gamma's hidden layers and of phi's last hidden layer are fetched a phase ahead, behind the publish, and land while
   // the workgroup waits for its neighbours; phi's lower layers are fetched one layer ahead, under the layer's MFMAs.
-  const bool one_round = n_rounds == 1;
+  const bool one_round = !ROUNDS && n_rounds == 1;
   const int k1 = c.wave * 16 + ei;
   const bool valid1 = one_round && k1 < c.total;
   const int r1 = t.edge[valid1 ? k1 : 0] & 0xff;
@@ -627,13 +705,24 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   bool ok = true;
   int ph = 0;
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
-    // a state saved after step n + 1 hands its cotangent to lambda before step n + 1 is walked back
-    if (p.dsave && n + 1 < p.n_steps && (n + 1) % p.save_every == 0 && my_node >= 0)
-      lam += p.dsave[(size_t)((n + 1) / p.save_every - 1 + p.save_off) * N + my_node];
     for (int i = S - 1; i >= 0 && ok; --i) {
       ++ph;
       const size_t ev = (size_t)(n * S + i);
       float *dsrc = (ph & 1) ? p.dsrc1 : p.dsrc0;
+      // ======== pass 1 over the workgroup's half tiles: K-bar, gamma and phi backwards, the per-edge gradients, publish
+      for (int s = 0; s < K; ++s) {
+      if constexpr (ROUNDS) {
+        const int h = blockIdx.x + s * G;
+        if (h >= nh) break;
+        vctx_init(m, c, t, h);
+        n_rounds = (c.total + VROUND - 1) / VROUND;
+        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+        load_state(ph);
+        fetch_phase(ev);
+      }
+      // a state saved after step n + 1 hands its cotangent to lambda before step n + 1 is walked back
+      if (i == S - 1 && p.dsave && n + 1 < p.n_steps && (n + 1) % p.save_every == 0 && my_node >= 0)
+        lam += p.dsave[(size_t)((n + 1) / p.save_every - 1 + p.save_off) * N + my_node];
       NGPDE_VST(m, ph, 0);
       // ---- K-bar_i of the own nodes -> the gradient of gamma's output (column 0 of tile A)
       if (c.tid < VR) {
@@ -777,10 +866,29 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       }
       vmh_publish(m, c, ph);
       NGPDE_VST(m, ph, 4);
+      if constexpr (ROUNDS) {
+        store_state();                                                                     // (the saved state's cotangent may have come in)
+        if (my_node >= 0) p.state[(size_t)7 * N + my_node] = s_row[VR + c.tid];          // the rows' own sums wait for pass 2
+        __syncthreads();   // the tables are rebuilt for the next half tile
+      }
+      }   // pass 1
+      if (!ok) break;
       have_prev = true;
       ev_prev = ev;
-      if (ev > 0) fetch_phase(ev - 1);
+      if (K == 1 && ev > 0) fetch_phase(ev - 1);
       NGPDE_VST(m, ph, 5);
+      // ======== pass 2: the by-source gather behind the hand-off, the stage adjoint
+      for (int s = 0; s < K; ++s) {
+      if constexpr (ROUNDS) {
+        const int h = blockIdx.x + s * G;
+        if (h >= nh) break;
+        vctx_init(m, c, t, h);
+        fill_srcpos();
+        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+        load_state(2);     // (pass 1 of this phase has written lambda)
+        if (my_node >= 0) s_row[VR + c.tid] = p.state[(size_t)7 * N + my_node];
+        __syncthreads();
+      }
       if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
       NGPDE_VST(m, ph, 6);
       {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
@@ -803,7 +911,25 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           lam = v;
         }
       }
+      if constexpr (ROUNDS) {
+        if (ph == last_ph && p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
+        store_state();
+        if (ph == last_ph && my_node >= 0) p.lam[my_node] = lam;
+        __syncthreads();   // the tables are rebuilt for the next half tile
+      }
+      }   // pass 2
     }
+  }
+  if constexpr (ROUNDS) {
+    if (!ok) {   // a wait gave up: every output row of this workgroup's half tiles says so
+      for (int s = 0; s < K; ++s) {
+        const int h = blockIdx.x + s * G;
+        if (h >= nh) break;
+        const int nd = c.tid < VR ? m.sched_t[(size_t)(h >> 1) * kTileRows + (h & 1) * VR + c.tid].x : -1;
+        if (nd >= 0) p.lam[nd] = __int_as_float(0x7fc00000);
+      }
+    }
+    return;
   }
   if (defer && have_prev && valid_keep) {   // the last evaluation's dz rows
 #pragma unroll
@@ -829,8 +955,8 @@ size_t vmh_lds_bytes(int n_mats, int s_rows) { return ((size_t)n_mats * VW * VW 
 // rows of the staging tile: as many of the workgroup's waves as the LDS holds beside the weights and the kernels' static arrays
 int vmh_staging_rows(int n_mats) {
   hipFuncAttributes fa{}, ba{};
-  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(node_vmh_fwd_kernel)) != hipSuccess) return 64;
-  if (hipFuncGetAttributes(&ba, reinterpret_cast<const void *>(node_vmh_bwd_kernel)) != hipSuccess) return 64;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(node_vmh_fwd_kernel<false>)) != hipSuccess) return 64;
+  if (hipFuncGetAttributes(&ba, reinterpret_cast<const void *>(node_vmh_bwd_kernel<false>)) != hipSuccess) return 64;
   const size_t fixed = std::max(fa.sharedSizeBytes, ba.sharedSizeBytes), cap = 160 * 1024;
   for (int rows = VROUND; rows > 64; rows -= 32)
     if (vmh_lds_bytes(n_mats, rows) + fixed <= cap) return rows;
@@ -862,14 +988,29 @@ bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s) {
   int dev = 0, cus = 0, occ = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   const size_t lds = vmh_lds_bytes(s.n_phi + s.n_gam, vmh_staging_rows(s.n_phi + s.n_gam));
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-  int of = 0, ob = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, node_vmh_fwd_kernel, VT, lds) != hipSuccess) of = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, node_vmh_bwd_kernel, VT, lds) != hipSuccess) ob = 0;
-  occ = std::min(of, ob);
+  occ = 1 << 30;
+  auto take = [&](auto kernel) {
+    int o = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) o = 0;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, VT, lds) != hipSuccess) o = 0;
+    occ = std::min(occ, o);
+  };
+  take(node_vmh_fwd_kernel<false>); take(node_vmh_bwd_kernel<false>); take(node_vmh_fwd_kernel<true>); take(node_vmh_bwd_kernel<true>);
   const int wgs = 2 * (g->n_sched / kTileRows);
-  return occ >= 1 && wgs <= cus * occ;
+  if (occ < 1 || wgs < 1) return false;
+  // more half tiles than resident workgroups: tile rounds, up to kVmhMaxTurns half tiles per workgroup (NGPDE_NO_VMH_ROUNDS=1: one only)
+  const char *nr = std::getenv("NGPDE_NO_VMH_ROUNDS");
+  const int turns = (wgs + cus * occ - 1) / (cus * occ);
+  return turns <= ((nr && nr[0] == '1') ? 1 : kVmhMaxTurns);
+}
+
+// the grid of the two launches: every half tile its own workgroup when they are all resident at once, else as many as are
+static int vmh_grid(const VmhMeta &m, size_t lds) {
+  int dev = 0, cus = 0, of = 0, ob = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 2 * m.n_tiles;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, node_vmh_fwd_kernel<true>, VT, lds) != hipSuccess) of = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, node_vmh_bwd_kernel<true>, VT, lds) != hipSuccess) ob = 1;
+  return std::min(2 * m.n_tiles, std::max(1, cus * std::min(of, ob)));
 }
 
 static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
@@ -911,10 +1052,17 @@ int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
   }
   k.n_steps = a.n_steps; k.S = a.S; k.u_in = a.u_in; k.u_out = a.u_out; k.x0 = a.x0; k.x1 = a.x1;
   k.save = a.save; k.save_every = a.save_every; k.save_off = a.save_off;
+  k.state = a.state;
   k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.cf = a.cf;
   const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
-  NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(node_vmh_fwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
+  const int grid = vmh_grid(k.m, lds);
+  if (grid < 2 * k.m.n_tiles) {   // tile rounds
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(node_vmh_fwd_kernel<true>, dim3(grid), dim3(VT), lds, stream, k);
+  } else {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(node_vmh_fwd_kernel<false>, dim3(grid), dim3(VT), lds, stream, k);
+  }
   NGPDE_LAUNCH_CHECK("node_vmh_fwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
@@ -930,11 +1078,18 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   VmhBwdK k;
   fill_meta(k.m, a);
   k.dsave = a.dsave; k.save_every = a.save_every; k.save_off = a.save_off;
+  k.state = a.state;
   k.n_steps = a.n_steps; k.S = a.S; k.lam = a.lam; k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.dz_phi = a.dz_phi; k.dz_gam = a.dz_gam;
   k.dsrc0 = a.dsrc; k.dsrc1 = a.dsrc + k.m.n_edges; k.cb = a.cb;
   const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
-  NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(node_vmh_bwd_kernel, dim3(2 * k.m.n_tiles), dim3(VT), lds, stream, k);
+  const int grid = vmh_grid(k.m, lds);
+  if (grid < 2 * k.m.n_tiles) {   // tile rounds
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(node_vmh_bwd_kernel<true>, dim3(grid), dim3(VT), lds, stream, k);
+  } else {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(node_vmh_bwd_kernel<false>, dim3(grid), dim3(VT), lds, stream, k);
+  }
   NGPDE_LAUNCH_CHECK("node_vmh_bwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
