@@ -703,22 +703,80 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       if (mt < n_mt) __builtin_nontemporal_store((f4v){tz[l][mt].x, tz[l][mt].y, tz[l][mt].z, tz[l][mt].w}, reinterpret_cast<NGPDE_GLOBAL_AS f4v *>(reinterpret_cast<uintptr_t>(zrow + 16 * mt)));
   };
   bool ok = true;
-  int ph = 0;
-  for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
-    for (int i = S - 1; i >= 0 && ok; --i) {
-      ++ph;
+  // the second half of a phase: the by-source gather behind the hand-off, the stage adjoint (false: the wait gave up)
+  auto pass2 = [&](int ph2, int i2, const float *dsrc2) -> bool {
+    if (!vmh_wait(m, c, ph2, t.s_ok)) return false;
+    NGPDE_VST(m, ph2, 6);
+    {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
+      const int dg = has_row ? s_srcdeg[rg] : 0;
+      float a = 0.f;
+      if (c.q < dg) a = ld_sc1(dsrc2 + s_srcpos[rg * kSlotWidth + c.q]);
+      if (c.q + 16 < dg) a += ld_sc1(dsrc2 + s_srcpos[rg * kSlotWidth + c.q + 16]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
+      if (c.q == 0 && has_row) s_row[2 * VR + rg] = a;
+    }
+    __syncthreads();
+    if (c.tid < VR) {
+      const float ubar = my_node >= 0 ? s_row[VR + c.tid] + s_row[2 * VR + c.tid] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ub[j] = (j == i2) ? ubar : ub[j];
+      if (i2 == 0) {
+        float v = lam;
+        for (int j = 0; j < S; ++j) v += ub[j];
+        lam = v;
+      }
+    }
+    return true;
+  };
+  // TILE ROUNDS sweep the half tiles evals + 1 times: a half tile's turn in sweep ph is the second half of phase ph - 1 -- its neighbours
+  // published that phase during the sweep before -- followed at once by the first half of phase ph: one rebuild of its tables and one
+  // round trip of its rows' state per phase
+  const int n_sweeps = last_ph + (ROUNDS ? 1 : 0);
+  float4 yall[kVmhMaxL - 1][4];   // (tile rounds) the outputs of phi's hidden layers of this turn's edge, asked for at the head of the turn
+  for (int ph = 1; ph <= n_sweeps && ok; ++ph) {
+    {
+      const bool do1 = ph <= last_ph;
+      const int idx = min(ph, last_ph) - 1;
+      const int n = p.n_steps - 1 - idx / S, i = S - 1 - idx % S;
       const size_t ev = (size_t)(n * S + i);
       float *dsrc = (ph & 1) ? p.dsrc1 : p.dsrc0;
-      // ======== pass 1 over the workgroup's half tiles: K-bar, gamma and phi backwards, the per-edge gradients, publish
+      // ======== the workgroup's half tiles: K-bar, gamma and phi backwards, the per-edge gradients, publish
       for (int s = 0; s < K; ++s) {
       if constexpr (ROUNDS) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
         vctx_init(m, c, t, h);
+        fill_srcpos();
         n_rounds = (c.total + VROUND - 1) / VROUND;
         my_node = c.tid < VR ? t.rnode[c.tid] : -1;
         load_state(ph);
-        fetch_phase(ev);
+        if (do1) {   // this phase's tape rows: they land under the second half of the phase before and K-bar / gamma
+          fetch_phase(ev);
+          const int k1r = c.wave * 16 + ei;
+          const bool v1r = n_rounds == 1 && k1r < c.total;
+          const int r1r = t.edge[v1r ? k1r : 0] & 0xff;
+          const size_t pe1r = (size_t)(t.rs[r1r] + (k1r - t.off[r1r]));
+#pragma unroll
+          for (int l = 0; l < kVmhMaxL - 1; ++l) {
+            const int n_mt = (m.phi_dout[l] + 15) >> 4;
+            const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe1r) * VW + 4 * kq;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) yall[l][mt] = (l + 1 < m.n_phi && v1r && mt < n_mt) ? ld4_nt(yrow + 16 * mt) : f4_zero();
+          }
+        }
+        if (ph > 1) {
+          if (my_node >= 0) s_row[VR + c.tid] = p.state[(size_t)7 * N + my_node];
+          __syncthreads();
+          const int idx2 = ph - 2;
+          if (!pass2(ph - 1, S - 1 - idx2 % S, ((ph - 1) & 1) ? p.dsrc1 : p.dsrc0)) { ok = false; break; }
+          if (!do1) {   // the sweep behind the last phase: the rows' lambda is dL/du0
+            if (p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
+            if (my_node >= 0) p.lam[my_node] = lam;
+            __syncthreads();
+            continue;
+          }
+        }
       }
       // a state saved after step n + 1 hands its cotangent to lambda before step n + 1 is walked back
       if (i == S - 1 && p.dsave && n + 1 < p.n_steps && (n + 1) % p.save_every == 0 && my_node >= 0)
@@ -819,7 +877,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
               const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe) * VW + 4 * kq;
               float4 dy[4];
 #pragma unroll
-              for (int mt = 0; mt < 4; ++mt) dy[mt] = one_round ? ycur[mt] : ((valid && mt < n_mt) ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero());
+              for (int mt = 0; mt < 4; ++mt)
+                dy[mt] = one_round ? ycur[mt]
+                                   : ((ROUNDS && n_rounds == 1) ? yall[l < kVmhMaxL - 1 ? l : 0][mt]
+                                                                : ((valid && mt < n_mt) ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero()));
               f4n_dact_out<4>(m.phi_act[l], dy);
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt) g[mt] = f4_mul(g[mt], dy[mt]);
@@ -867,57 +928,19 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       vmh_publish(m, c, ph);
       NGPDE_VST(m, ph, 4);
       if constexpr (ROUNDS) {
-        store_state();                                                                     // (the saved state's cotangent may have come in)
-        if (my_node >= 0) p.state[(size_t)7 * N + my_node] = s_row[VR + c.tid];          // the rows' own sums wait for pass 2
-        __syncthreads();   // the tables are rebuilt for the next half tile
-      }
-      }   // pass 1
-      if (!ok) break;
-      have_prev = true;
-      ev_prev = ev;
-      if (K == 1 && ev > 0) fetch_phase(ev - 1);
-      NGPDE_VST(m, ph, 5);
-      // ======== pass 2: the by-source gather behind the hand-off, the stage adjoint
-      for (int s = 0; s < K; ++s) {
-      if constexpr (ROUNDS) {
-        const int h = blockIdx.x + s * G;
-        if (h >= nh) break;
-        vctx_init(m, c, t, h);
-        fill_srcpos();
-        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
-        load_state(2);     // (pass 1 of this phase has written lambda)
-        if (my_node >= 0) s_row[VR + c.tid] = p.state[(size_t)7 * N + my_node];
-        __syncthreads();
-      }
-      if (!vmh_wait(m, c, ph, t.s_ok)) { ok = false; break; }
-      NGPDE_VST(m, ph, 6);
-      {   // the by-source sum: the out-edges of row g16 (16 lanes, two entries each), then a fixed-order lane reduction
-        const int dg = has_row ? s_srcdeg[rg] : 0;
-        float a = 0.f;
-        if (c.q < dg) a = ld_sc1(dsrc + s_srcpos[rg * kSlotWidth + c.q]);
-        if (c.q + 16 < dg) a += ld_sc1(dsrc + s_srcpos[rg * kSlotWidth + c.q + 16]);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
-        if (c.q == 0 && has_row) s_row[2 * VR + rg] = a;
-      }
-      __syncthreads();
-      if (c.tid < VR) {
-        const float ubar = my_node >= 0 ? s_row[VR + c.tid] + s_row[2 * VR + c.tid] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) ub[j] = (j == i) ? ubar : ub[j];
-        if (i == 0) {
-          float v = lam;
-          for (int j = 0; j < S; ++j) v += ub[j];
-          lam = v;
-        }
-      }
-      if constexpr (ROUNDS) {
-        if (ph == last_ph && p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
         store_state();
-        if (ph == last_ph && my_node >= 0) p.lam[my_node] = lam;
+        if (my_node >= 0) p.state[(size_t)7 * N + my_node] = s_row[VR + c.tid];          // the rows' own sums wait for the next sweep
         __syncthreads();   // the tables are rebuilt for the next half tile
       }
-      }   // pass 2
+      }   // half tiles
+      if (!ok) break;
+      if constexpr (!ROUNDS) {
+        have_prev = true;
+        ev_prev = ev;
+        if (ev > 0) fetch_phase(ev - 1);
+        NGPDE_VST(m, ph, 5);
+        if (!pass2(ph, i, dsrc)) { ok = false; break; }
+      }
     }
   }
   if constexpr (ROUNDS) {

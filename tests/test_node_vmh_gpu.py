@@ -55,15 +55,18 @@ def oracle_solve(phi, gam, ps, og, u0, tab_name, dt, n_steps, R, aggr="mean"):
     return uT, du0, gphi, ggam
 
 
-@pytest.mark.parametrize("solver,n_steps,act,aggr,depth,pd", [
-    ("tsit5", 2, "tanh", "mean", 4, 2),      # the tutorial's model
-    ("euler", 3, "tanh", "+", 3, 2),
-    ("tsit5", 1, "relu", "mean", 2, 1),
-    ("euler", 2, "sigmoid", "mean", 3, 3),
+@pytest.mark.parametrize("solver,n_steps,act,aggr,depth,pd,N", [
+    ("tsit5", 2, "tanh", "mean", 4, 2, 700),      # the tutorial's model
+    ("euler", 3, "tanh", "+", 3, 2, 700),
+    ("tsit5", 1, "relu", "mean", 2, 1, 700),
+    ("euler", 2, "sigmoid", "mean", 3, 3, 700),
+    ("tsit5", 2, "tanh", "mean", 4, 2, 4700),     # more half tiles than compute units: two per workgroup, taking turns (tile rounds)
+    ("euler", 3, "relu", "+", 3, 2, 9100),        # ... and three
 ])
-def test_vmh_resident_solve_and_adjoint_against_the_oracle(solver, n_steps, act, aggr, depth, pd, monkeypatch):
+def test_vmh_resident_solve_and_adjoint_against_the_oracle(solver, n_steps, act, aggr, depth, pd, N, monkeypatch):
     monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
-    N, dt = 700, 0.05
+    monkeypatch.delenv("NGPDE_NO_VMH_ROUNDS", raising=False)
+    dt = 0.05
     g, og = spatial(N, 31 + depth, pd=pd)
     phi, gam = tutorial_mlps(depth=depth, act=act, pd=pd)
     node = ng.NeuralODE(ng.VMHConv(phi, gam, aggr=aggr, initialgraph=g), solver=solver, n_steps=n_steps, dt=dt)
@@ -116,15 +119,19 @@ def test_vmh_resident_plan_equals_the_generic_solver_at_the_tutorial_shape(monke
         assert torch.equal(a, b)     # no atomics, fixed summation orders, and every hand-off waited for
 
 
-@pytest.mark.parametrize("solver,save_start,batched", [("tsit5", True, False), ("euler", False, False), ("tsit5", True, True)])
+@pytest.mark.parametrize("solver,save_start,batched", [("tsit5", True, False), ("euler", False, False), ("tsit5", True, True), ("tsit5", True, "rounds")])
 def test_vmh_resident_saveat_against_the_oracle_segment_by_segment(solver, save_start, batched, monkeypatch):
     # NeuralODE(gnn, tspan, Tsit5(); saveat = dt_train) (docs/src/tutorials/VMH.md:85): the (1 x N x T) array of the solution at the
     # saved times on the device-resident plan, the loss reads every one of them (:104-108); the oracle solves segment by segment and
     # its adjoint walks the segments backwards, adding each saved state's cotangent.  batched: a block-diagonal batch of three
     # point clouds (:132-134) is one graph to the plan
     monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    monkeypatch.delenv("NGPDE_NO_VMH_ROUNDS", raising=False)
     k, nseg, dt = 2, 3, 0.05
-    if batched:
+    if batched == "rounds":      # a batch of point clouds with more half tiles than compute units (VMH.md:120: 24 clouds of 3 000 points)
+        gs, ogs = zip(*[spatial(1500 + 100 * j, 60 + j) for j in range(3)])
+        g, og = ng.batch(list(gs)), O.batch(list(ogs))
+    elif batched:
         gs, ogs = zip(*[spatial(220 + 16 * j, 50 + j) for j in range(3)])
         g, og = ng.batch(list(gs)), O.batch(list(ogs))
     else:
@@ -228,6 +235,44 @@ def test_vmh_abi_rejects_null_and_mismatched_arguments(monkeypatch):
     assert lib.ngpde_node_vmh_forward(out, None, None, None, None, None, _lib.ptr(u), None) == _lib.ERR_INVALID_ARGUMENT
     assert lib.ngpde_node_vmh_backward(out, None, None, _lib.ptr(u), _lib.ptr(u), None, None, None, None, None) in (_lib.ERR_INVALID_ARGUMENT, _lib.ERR_STATE)
     assert lib.ngpde_node_vmh_destroy(out) == _lib.OK
+
+
+def test_vmh_tile_rounds_equal_the_generic_solver_and_can_be_switched_off(monkeypatch):
+    # 9 000 points, 6 neighbours: 564 half tiles on 256 compute units -- three turns per workgroup and phase, the adjoint's second half
+    # of a phase fused in front of the next phase's first.  Against the generic solver (which NGPDE_NO_VMH_ROUNDS=1 selects for such a
+    # graph), repeated solves bitwise equal, and the forced abort poisons every half tile's rows
+    nv, steps = 9000, 3
+    pts = torch.as_tensor(S.uniform01(51, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+    gv = ng.GNNGraph(ng.knn_graph(pts, 6), ndata={"x": pts})
+    phi, gam = tutorial_mlps()
+    u0 = torch.as_tensor(S.normal(52, nv).reshape(1, nv).astype(np.float32), device=DEV)
+    R = torch.as_tensor(S.normal(53, nv).reshape(1, nv).astype(np.float32), device=DEV)
+    res = {}
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    for mode in ("rounds", "generic", "rounds2"):
+        if mode == "generic":
+            monkeypatch.setenv("NGPDE_NO_VMH_ROUNDS", "1")
+        else:
+            monkeypatch.delenv("NGPDE_NO_VMH_ROUNDS", raising=False)
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gv), solver="tsit5", n_steps=steps, dt=0.05)
+        ps0, st = ng.setup(4, node)
+        ps = prep(ps0, 4)
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * R).sum().backward()
+        assert ("vmh" in plan_flags(node)) == (mode != "generic")
+        n1, _ = mlp_grad_pairs(ps["ϕ"], [{"weight": 0, "bias": 0}] * 4, phi)
+        n2, _ = mlp_grad_pairs(ps["γ"], [{"weight": 0, "bias": 0}] * 4, gam)
+        res[mode] = [uT.detach().clone(), u.grad.clone()] + [p.grad.clone() for _, p in n1 + n2]
+    for a, b in zip(res["rounds"], res["generic"]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+    for a, b in zip(res["rounds"], res["rounds2"]):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("NGPDE_DEBUG_FORCE_ABORT", "1")
+    out, _ = node(u0, ng.to_device(ps0, DEV), st)
+    monkeypatch.delenv("NGPDE_DEBUG_FORCE_ABORT")
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all() and any(p.fault() for pool in node._plans.values() for p in pool)
 
 
 def test_vmh_resident_plan_reports_an_abort_instead_of_hanging(monkeypatch):
