@@ -403,6 +403,38 @@ def secondary(dev, world, rank, dist):
                 out["VMH_node_tsit5x20"]["generic_captured_value"] = round(steps_v / (msg_ * 1e-3), 1)
             finally:
                 os.environ.pop("NGPDE_NO_VMH_NODE", None)
+        # the tutorial's minibatch form (VMH.md:120-134: a DataLoader batch of point clouds as ONE block-diagonal graph per step), 8 clouds of
+        # 3 008 points: 1 504 half tiles on 256 compute units -- the device-resident plan walks them in tile rounds.  (3 008 = 94 whole
+        # 32-row tiles per cloud: a cloud boundary INSIDE a tile merges two neighbourhoods into one tile's halo, which can overflow the
+        # 96 rows a tile stages; the plan then leaves the batch to the generic solver -- plan_flags says which path ran.)
+        nb, nvb = 8, 3008
+        gcl = []
+        for kb in range(nb):
+            pk = torch.as_tensor(S.uniform01(200 + kb, 2 * nvb).reshape(2, nvb).astype(np.float32), device=dev)
+            gcl.append(ng.GNNGraph(ng.knn_graph(pk, kv), ndata={"x": pk}))
+        gb = ng.batch(gcl)
+        ub = torch.as_tensor(S.normal(44, nb * nvb).reshape(1, nb * nvb).astype(np.float32), device=dev).requires_grad_(True)
+        res_b = {}
+        for mode in ("plan", "generic"):
+            if mode == "generic":
+                os.environ["NGPDE_NO_VMH_NODE"] = "1"
+            try:
+                nodeb = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gb), solver="tsit5", n_steps=steps_v, dt=0.2 / steps_v, capture=(mode == "generic"))
+
+                def solveb():
+                    for v in [ub] + _grad_leaves(psv_):
+                        v.grad = None
+                    uT, _ = nodeb(ub, psv_, ng.updategraph(stv_, gb))
+                    uT.sum().backward()
+                res_b[mode] = (_time_ms(solveb, 3), sorted({f for pool in nodeb._plans.values() for pl in pool for f in pl.flags()}))
+                del nodeb
+            finally:
+                os.environ.pop("NGPDE_NO_VMH_NODE", None)
+        msb = res_b["plan"][0]
+        out["VMH_node_batch8_tsit5x20"] = {"clouds": nb, "nodes": nb * nvb, "edges": int(gb.num_edges), "ms_solve_forward_backward": round(msb, 3),
+                                           "value": round(nb * steps_v / (msb * 1e-3), 1), "unit": "trajectory ODE-steps/s",
+                                           "plan_flags": res_b["plan"][1], "generic_captured_ms": round(res_b["generic"][0], 3),
+                                           "generic_captured_value": round(nb * steps_v / (res_b["generic"][0] * 1e-3), 1)}
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
     flat, psv = ng.optim.flatten_parameters(ng.to_device(ps, dev))
