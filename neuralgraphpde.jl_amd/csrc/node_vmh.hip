@@ -40,7 +40,6 @@ constexpr int VROUND = (VT / 64) * 16;   // edges per round: one 16-edge slice p
 constexpr int VW = 64;                // padded layer width
 constexpr int VR = 16;                // target rows per workgroup
 constexpr int VTS = VW + 4;           // staging tile stride
-constexpr int VMaxE = VR * kSlotWidth;   // edges a workgroup may own
 constexpr int VNbr = 64;
 constexpr int kVmhMaxTurns = 64;       // tile rounds: half tiles per workgroup (64 x 256 CUs x 16 rows = 262 144 nodes)
 
@@ -122,7 +121,7 @@ struct VTabs {
   int *rs;                 // [16]
   int *rnode;              // [16]
   float *inv;              // [16]
-  unsigned short *edge;    // [VMaxE]  r | slot << 8
+  unsigned short *edge;    // [rows x kSlotWidth]  r | slot << 8
   float *misc;             // [64]: coefficients etc.
   int *s_ok;
 };
@@ -183,7 +182,9 @@ __device__ __forceinline__ void slice_matmul(const float *mat, const float4 (&in
   }
 }
 
-// the context of half tile h (= 2 tile + half): the workgroup's only one, or the one whose turn it is (tile rounds)
+// the context of unit h: half tile 2 tile + half (VRT = 16: the workgroup's only one), or whole tile h (VRT = 32: the one whose turn it
+// is in the tile rounds -- twelve 16-edge slices at degree 6, three per SIMD, where a half tile's six leave two SIMDs half idle)
+template <int VRT>
 __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs &t, int h) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
@@ -192,14 +193,14 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   c.q = c.tid & 15;
   c.ei = c.lane & 15;
   c.kq = c.lane >> 4;
-  c.wg = h;
+  c.wg = VRT == 32 ? 2 * h : h;   // (the unit's first flag line)
   c.tile = c.wg >> 1;
   c.half = c.wg & 1;
-  const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + min(c.g16, VR - 1)];   // (lane groups 16.. have no row)
-  c.row_valid = sc.x >= 0 && c.g16 < VR;
+  const int4 sc = m.sched_t[(size_t)c.tile * kTileRows + c.half * VR + min(c.g16, VRT - 1)];   // (lane groups beyond VRT have no row)
+  c.row_valid = sc.x >= 0 && c.g16 < VRT;
   c.node = max(sc.x, 0);
   c.hcount = __builtin_amdgcn_readfirstlane(m.info_t[c.tile].x);
-  if (c.q == 0 && c.g16 < VR) {
+  if (c.q == 0 && c.g16 < VRT) {
     const int d = sc.x >= 0 ? sc.z : 0;
     t.off[c.g16 + 1] = d;
     t.rs[c.g16] = sc.y;
@@ -215,18 +216,18 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   }
   if (c.tid == 0) *t.s_ok = 1;
   __syncthreads();
-  if (c.tid < VR) {
+  if (c.tid < VRT) {
     int v = t.off[c.tid + 1];
 #pragma unroll
-    for (int o = 1; o < VR; o <<= 1) {
+    for (int o = 1; o < VRT; o <<= 1) {
       const int u = __shfl_up(v, o);
       if (c.tid >= o) v += u;
     }
     t.off[c.tid + 1] = v;
   }
   __syncthreads();
-  c.total = t.off[VR];
-  if (c.g16 < VR) {   // edge table: k -> (row, halo slot of the source)
+  c.total = t.off[VRT];
+  if (c.g16 < VRT) {   // edge table: k -> (row, halo slot of the source)
     const int lo = t.off[c.g16], hi = t.off[c.g16 + 1];
     const uint8_t *sl = m.slots_t + ((size_t)c.tile * kTileRows + c.half * VR + c.g16) * kSlotWidth;
     for (int k = lo + c.q; k < hi; k += 16) t.edge[k] = (unsigned short)(c.g16 | ((unsigned)sl[k - lo] << 8));
@@ -263,10 +264,11 @@ __device__ __forceinline__ bool vmh_wait(const VmhMeta &m, const VCtx &c, int ne
   __syncthreads();
   return *s_ok != 0;
 }
-__device__ __forceinline__ void vmh_publish(const VmhMeta &m, const VCtx &c, int ph) {
+__device__ __forceinline__ void vmh_publish(const VmhMeta &m, const VCtx &c, int ph, bool whole_tile) {
   wait_vmcnt0();
   __syncthreads();
   if (c.tid == 0) __hip_atomic_store(m.flags + 32 * c.wg, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (whole_tile && c.tid == 1) __hip_atomic_store(m.flags + 32 * (c.wg + 1), (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ float4 ld4_nt(const float *p) {   // a tape row: read once
@@ -298,11 +300,13 @@ struct VmhFwdK {
 
 template <bool ROUNDS>
 __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
+  constexpr int VRT = ROUNDS ? 2 * VR : VR;      // rows of a unit: a half tile, or (tile rounds) a whole tile
+  constexpr int VMaxET = VRT * kSlotWidth;
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ __attribute__((aligned(16))) float s_bias[2 * kVmhMaxL * VW];
-  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VR], s_misc[64];
-  __shared__ int s_hnode[kHaloCap], s_off[VR + 1], s_rs[VR], s_rnode[VR], s_okw[2];
-  __shared__ unsigned short s_edge[VMaxE];
+  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VRT], s_misc[64];
+  __shared__ int s_hnode[kHaloCap], s_off[VRT + 1], s_rs[VRT], s_rnode[VRT], s_okw[2];
+  __shared__ unsigned short s_edge[VMaxET];
   const VmhMeta &m = p.m;
   const int n_mats = m.n_phi + m.n_gam;
   VTabs t;
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   // turn and the Runge-Kutta state of its rows waits in memory.  By the time a half tile's turn comes again its neighbours' rows of
   // the previous phase have long arrived: the hand-off that bounds the one-tile form costs nothing here.
   // (ROUNDS is a template parameter: the one-half-tile form keeps its register allocation, the rounds form carries no rows across phases)
-  const int nh = 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
-  vctx_init(m, c, t, blockIdx.x);
+  const int nh = ROUNDS ? m.n_tiles : 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
+  vctx_init<VRT>(m, c, t, blockIdx.x);
   // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
   // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
   if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   const int ei = c.ei, kq = c.kq;
   int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
-  const int rg = min(c.g16, VR - 1);   // the row of this lane group (groups 16.. idle in the row-wise steps)
-  const bool has_row = c.g16 < VR;
+  const int rg = min(c.g16, VRT - 1);   // the row of this lane group (groups 16.. idle in the row-wise steps)
+  const bool has_row = c.g16 < VRT;
   // the 16 row lanes (tid < 16 <-> row tid) keep the Runge-Kutta state of their node
   float su = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f, sk4 = 0.f;
-  int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  int my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
   if (my_node >= 0) su = p.u_in[my_node];
   const int last_ph = p.n_steps * p.S;
   // With ONE round (the usual case) the tape rows of a slice stay in registers and leave one evaluation LATE: layer l's rows of the
@@ -363,9 +367,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       if constexpr (ROUNDS) {   // this turn's half tile: tables, rows' state
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
-        vctx_init(m, c, t, h);
+        vctx_init<VRT>(m, c, t, h);
         n_rounds = (c.total + VROUND - 1) / VROUND;
-        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+        my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
         if (my_node >= 0) {
           su = ph == 1 ? p.u_in[my_node] : p.state[my_node];
           sk0 = ph == 1 ? 0.f : p.state[N + my_node]; sk1 = ph == 1 ? 0.f : p.state[2 * N + my_node]; sk2 = ph == 1 ? 0.f : p.state[3 * N + my_node];
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       }
       NGPDE_VST(m, ph, 4);
       // ---- node MLP on the 16 rows: input [h_i; m_i; 0 ...] in tile A (rows 0..15 of the staging area), layers ping-pong A <-> B
-      float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
+      float *tA = t.S, *tB = t.S + (size_t)VRT * VTS;
       if (has_row) {
         const float iv = t.inv[rg];
         const float4 mm = f4_scale(iv, racc);
@@ -488,9 +492,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         float *tout = (l & 1) ? tA : tB;
         if (p.tape_gam && c.row_valid && 4 * c.q < 16 * n_ct)
           *reinterpret_cast<float4 *>(p.tape_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = *reinterpret_cast<const float4 *>(&tin[rg * VTS + 4 * c.q]);
-        const int mt = c.wave;   // the wave's block of output columns (waves 4.. idle here)
+        const int mt = c.wave & 3, rgp = c.wave >> 2;   // the wave's block of output columns and its 16 rows (a half tile: waves 4.. idle)
+        const bool g_on = rgp < VRT / 16;
         float4 zo = f4_zero();
-        if (mt < n_mt && mt < 4) {
+        if (mt < n_mt && g_on) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           // (all four input blocks in flight at once; the columns of the tile beyond the layer's input width are zeros, and so are
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) {
             w4[ct] = wfrag(mat, mt, ct, ei, kq);
-            av[ct] = *reinterpret_cast<const float4 *>(&tin[ei * VTS + 16 * ct + 4 * kq]);
+            av[ct] = *reinterpret_cast<const float4 *>(&tin[(16 * rgp + ei) * VTS + 16 * ct + 4 * kq]);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -517,13 +522,13 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
           // (padded columns inside a quad: the staged weights and biases are zero there, act(0) = 0 for the supported activations
           // except sigmoid -- the next layer's weight rows for them are zero, so they never feed a real column)
         }
-        if (mt < 4) *reinterpret_cast<float4 *>(&tout[ei * VTS + 16 * mt + 4 * kq]) = zo;
+        if (g_on) *reinterpret_cast<float4 *>(&tout[(16 * rgp + ei) * VTS + 16 * mt + 4 * kq]) = zo;
         __syncthreads();
       }
       NGPDE_VST(m, ph, 5);
       // ---- stage derivative k_i = gamma's output (column 0); the next stage input (or the step update) of the own nodes
       const float *tfin = (m.n_gam & 1) ? tB : tA;
-      if (c.tid < VR) {
+      if (c.tid < VRT) {
         const float yv = my_node >= 0 ? tfin[c.tid * VTS] : 0.f;
         sk0 = i == 0 ? yv : sk0; sk1 = i == 1 ? yv : sk1; sk2 = i == 2 ? yv : sk2; sk3 = i == 3 ? yv : sk3; sk4 = i == 4 ? yv : sk4;
         float v = t.misc[36 + i] * yv;
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         }
         if (my_node >= 0) st_sc1(Xn + my_node, v);
       }
-      vmh_publish(m, c, ph);
+      vmh_publish(m, c, ph, ROUNDS);
       NGPDE_VST(m, ph, 6);
       if (ROUNDS && my_node >= 0) {
         p.state[my_node] = su; p.state[N + my_node] = sk0; p.state[2 * N + my_node] = sk1; p.state[3 * N + my_node] = sk2;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       for (int s = 0; s < K; ++s) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
-        const int nd = c.tid < VR ? m.sched_t[(size_t)(h >> 1) * kTileRows + (h & 1) * VR + c.tid].x : -1;
+        const int nd = c.tid < VRT ? m.sched_t[(size_t)h * kTileRows + c.tid].x : -1;
         if (nd >= 0) {
           if (p.u_out) p.u_out[nd] = bad;
           if (p.save)
@@ -602,10 +607,12 @@ struct VmhBwdK {
 
 template <bool ROUNDS>
 __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
+  constexpr int VRT = ROUNDS ? 2 * VR : VR;
+  constexpr int VMaxET = VRT * kSlotWidth;
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VR], s_misc[64], s_es[VMaxE], s_row[VR * 4];
-  __shared__ int s_hnode[kHaloCap], s_off[VR + 1], s_rs[VR], s_rnode[VR], s_okw[2], s_srcpos[VR * kSlotWidth], s_srcdeg[VR];
-  __shared__ unsigned short s_edge[VMaxE];
+  __shared__ float s_hh[kHaloCap], s_px[kHaloCap * 4], s_inv[VRT], s_misc[64], s_es[VMaxET], s_row[VRT * 4];
+  __shared__ int s_hnode[kHaloCap], s_off[VRT + 1], s_rs[VRT], s_rnode[VRT], s_okw[2], s_srcpos[VRT * kSlotWidth], s_srcdeg[VRT];
+  __shared__ unsigned short s_edge[VMaxET];
   const VmhMeta &m = p.m;
   const int n_mats = m.n_phi + m.n_gam;
   VTabs t;
@@ -616,8 +623,8 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   // workgroup makes TWO passes over its half tiles: pass 1 walks every one back to the per-edge gradients and publishes, pass 2 gathers by
   // source -- a half tile waiting for a later one of the same workgroup would otherwise wait forever.
   // (ROUNDS is a template parameter: the one-half-tile form keeps its register allocation, the rounds form carries no rows across phases)
-  const int nh = 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
-  vctx_init(m, c, t, blockIdx.x);
+  const int nh = ROUNDS ? m.n_tiles : 2 * m.n_tiles, G = gridDim.x, K = ROUNDS ? (nh + G - 1) / G : 1;
+  vctx_init<VRT>(m, c, t, blockIdx.x);
   // two waves share a SIMD (waves w and w + 4): the first runs at high priority, so the pair does not march in lockstep through
   // MFMA chain and activation code alike -- the second fills the matrix pipe while the first is in its VALU stretches
   if (c.wave < 4) __builtin_amdgcn_s_setprio(3);
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
   if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
   auto fill_srcpos = [&]() {   // positions, in the by-target order, of the out-edges of the own nodes: the by-source gather's addresses
-    if (c.g16 < VR) {
+    if (c.g16 < VRT) {
       const int nd = t.rnode[c.g16];
       const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
       if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
@@ -639,10 +646,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   int n_rounds = (c.total + VROUND - 1) / VROUND;
   const size_t E = m.n_edges, N = (size_t)m.n_nodes;
   const int S = p.S;
-  const int rg = min(c.g16, VR - 1);
-  const bool has_row = c.g16 < VR;
+  const int rg = min(c.g16, VRT - 1);
+  const bool has_row = c.g16 < VRT;
   // the 16 row lanes keep lambda and the stage adjoints of their node
-  int my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+  int my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
   float lam = my_node >= 0 ? p.lam[my_node] : 0.f;
   float ub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int last_ph = p.n_steps * S;
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       for (int j = 0; j < 6; ++j) p.state[(size_t)(1 + j) * N + my_node] = ub[j];
     }
   };
-  float *tA = t.S, *tB = t.S + (size_t)VR * VTS;
+  float *tA = t.S, *tB = t.S + (size_t)VRT * VTS;
   // With ONE round a lane's edge is the same in every phase, and what a phase reads from the tapes does not depend on the exchange:
   // the outputs of gamma's hidden layers and of phi's last hidden layer are fetched a phase ahead, behind the publish, and land while
   // the workgroup waits for its neighbours; phi's lower layers are fetched one layer ahead, under the layer's MFMAs.
@@ -714,11 +721,11 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       if (c.q + 16 < dg) a += ld_sc1(dsrc2 + s_srcpos[rg * kSlotWidth + c.q + 16]);
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
-      if (c.q == 0 && has_row) s_row[2 * VR + rg] = a;
+      if (c.q == 0 && has_row) s_row[2 * VRT + rg] = a;
     }
     __syncthreads();
-    if (c.tid < VR) {
-      const float ubar = my_node >= 0 ? s_row[VR + c.tid] + s_row[2 * VR + c.tid] : 0.f;
+    if (c.tid < VRT) {
+      const float ubar = my_node >= 0 ? s_row[VRT + c.tid] + s_row[2 * VRT + c.tid] : 0.f;
 #pragma unroll
       for (int j = 0; j < 6; ++j) ub[j] = (j == i2) ? ubar : ub[j];
       if (i2 == 0) {
@@ -733,7 +740,17 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   // published that phase during the sweep before -- followed at once by the first half of phase ph: one rebuild of its tables and one
   // round trip of its rows' state per phase
   const int n_sweeps = last_ph + (ROUNDS ? 1 : 0);
-  float4 yall[kVmhMaxL - 1][4];   // (tile rounds) the outputs of phi's hidden layers of this turn's edge, asked for at the head of the turn
+  float4 yall[kVmhMaxL - 1][4];   // (tile rounds) the outputs of phi's hidden layers of the lane's edge in the coming round
+  auto fetch_y = [&](int l, size_t ev, int rd) {   // yall[l] <- the output of phi's layer l (the input tape of layer l + 1) for round rd
+    const int k = rd * VROUND + c.wave * 16 + ei;
+    const bool valid = l + 1 < m.n_phi && k < c.total;
+    const int r = t.edge[valid ? k : 0] & 0xff;
+    const size_t pe = (size_t)(t.rs[r] + (k - t.off[r]));
+    const int n_mt = (m.phi_dout[l] + 15) >> 4;
+    const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe) * VW + 4 * kq;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) yall[l][mt] = (valid && mt < n_mt) ? ld4_nt(yrow + 16 * mt) : f4_zero();
+  };
   for (int ph = 1; ph <= n_sweeps && ok; ++ph) {
     {
       const bool do1 = ph <= last_ph;
@@ -746,27 +763,18 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       if constexpr (ROUNDS) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
-        vctx_init(m, c, t, h);
+        vctx_init<VRT>(m, c, t, h);
         fill_srcpos();
         n_rounds = (c.total + VROUND - 1) / VROUND;
-        my_node = c.tid < VR ? t.rnode[c.tid] : -1;
+        my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
         load_state(ph);
         if (do1) {   // this phase's tape rows: they land under the second half of the phase before and K-bar / gamma
           fetch_phase(ev);
-          const int k1r = c.wave * 16 + ei;
-          const bool v1r = n_rounds == 1 && k1r < c.total;
-          const int r1r = t.edge[v1r ? k1r : 0] & 0xff;
-          const size_t pe1r = (size_t)(t.rs[r1r] + (k1r - t.off[r1r]));
 #pragma unroll
-          for (int l = 0; l < kVmhMaxL - 1; ++l) {
-            const int n_mt = (m.phi_dout[l] + 15) >> 4;
-            const float *yrow = p.tape_phi + (((size_t)(l + 1) * m.evals + ev) * E + pe1r) * VW + 4 * kq;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) yall[l][mt] = (l + 1 < m.n_phi && v1r && mt < n_mt) ? ld4_nt(yrow + 16 * mt) : f4_zero();
-          }
+          for (int l = 0; l < kVmhMaxL - 1; ++l) fetch_y(l, ev, 0);   // (the first round's; a later round's rows are asked for a round ahead)
         }
         if (ph > 1) {
-          if (my_node >= 0) s_row[VR + c.tid] = p.state[(size_t)7 * N + my_node];
+          if (my_node >= 0) s_row[VRT + c.tid] = p.state[(size_t)7 * N + my_node];
           __syncthreads();
           const int idx2 = ph - 2;
           if (!pass2(ph - 1, S - 1 - idx2 % S, ((ph - 1) & 1) ? p.dsrc1 : p.dsrc0)) { ok = false; break; }
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         lam += p.dsave[(size_t)((n + 1) / p.save_every - 1 + p.save_off) * N + my_node];
       NGPDE_VST(m, ph, 0);
       // ---- K-bar_i of the own nodes -> the gradient of gamma's output (column 0 of tile A)
-      if (c.tid < VR) {
+      if (c.tid < VRT) {
         float kbar = t.misc[i * 8 + i] * lam;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -814,16 +822,17 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           if (c.row_valid && 4 * c.q < 16 * n_mt) *reinterpret_cast<float4 *>(p.dz_gam + (((size_t)l * m.evals + ev) * N + c.node) * VW + 4 * c.q) = g;
         }
         __syncthreads();
-        const int ct = c.wave;   // the wave's block of INPUT columns (waves 4.. idle here)
+        const int ct = c.wave & 3, rgp = c.wave >> 2;   // the wave's block of INPUT columns and its 16 rows
+        const bool g_on = rgp < VRT / 16;
         float4 go = f4_zero();
-        if (ct < n_ct && ct < 4) {
+        if (ct < n_ct && g_on) {
           const float *mat = t.W + (size_t)(m.n_phi + l) * VW * VW;
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           float4 w4[4], dv[4];
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             w4[mt] = wfrag(mat, ct, mt, ei, kq);
-            dv[mt] = *reinterpret_cast<const float4 *>(&tg[ei * VTS + 16 * mt + 4 * kq]);
+            dv[mt] = *reinterpret_cast<const float4 *>(&tg[(16 * rgp + ei) * VTS + 16 * mt + 4 * kq]);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
           }
           go = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        if (ct < 4) *reinterpret_cast<float4 *>(&tn[ei * VTS + 16 * ct + 4 * kq]) = go;
+        if (g_on) *reinterpret_cast<float4 *>(&tn[(16 * rgp + ei) * VTS + 16 * ct + 4 * kq]) = go;
         __syncthreads();
       }
       // d(gamma's input) = [dh_i; dm_i]: tile tgin, row r; the message gradient is scaled by 1 / deg (mean)
@@ -879,8 +888,9 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt)
                 dy[mt] = one_round ? ycur[mt]
-                                   : ((ROUNDS && n_rounds == 1) ? yall[l < kVmhMaxL - 1 ? l : 0][mt]
-                                                                : ((valid && mt < n_mt) ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero()));
+                                   : (ROUNDS ? yall[l < kVmhMaxL - 1 ? l : 0][mt]
+                                             : ((valid && mt < n_mt) ? *reinterpret_cast<const float4 *>(yrow + 16 * mt) : f4_zero()));
+              if (ROUNDS && rd + 1 < n_rounds) fetch_y(l < kVmhMaxL - 1 ? l : 0, ev, rd + 1);   // the registers are free again: the next round's rows
               f4n_dact_out<4>(m.phi_act[l], dy);
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt) g[mt] = f4_mul(g[mt], dy[mt]);
@@ -920,16 +930,16 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       NGPDE_VST(m, ph, 2);
       __syncthreads();
       NGPDE_VST(m, ph, 3);
-      if (c.tid < VR) {   // what the own rows get from their own edges and from gamma
+      if (c.tid < VRT) {   // what the own rows get from their own edges and from gamma
         float a = tgin[c.tid * VTS];
         for (int k = t.off[c.tid]; k < t.off[c.tid + 1]; ++k) a += s_es[k];
-        s_row[VR + c.tid] = a;
+        s_row[VRT + c.tid] = a;
       }
-      vmh_publish(m, c, ph);
+      vmh_publish(m, c, ph, ROUNDS);
       NGPDE_VST(m, ph, 4);
       if constexpr (ROUNDS) {
         store_state();
-        if (my_node >= 0) p.state[(size_t)7 * N + my_node] = s_row[VR + c.tid];          // the rows' own sums wait for the next sweep
+        if (my_node >= 0) p.state[(size_t)7 * N + my_node] = s_row[VRT + c.tid];          // the rows' own sums wait for the next sweep
         __syncthreads();   // the tables are rebuilt for the next half tile
       }
       }   // half tiles
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       for (int s = 0; s < K; ++s) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
-        const int nd = c.tid < VR ? m.sched_t[(size_t)(h >> 1) * kTileRows + (h & 1) * VR + c.tid].x : -1;
+        const int nd = c.tid < VRT ? m.sched_t[(size_t)h * kTileRows + c.tid].x : -1;
         if (nd >= 0) p.lam[nd] = __int_as_float(0x7fc00000);
       }
     }
@@ -975,15 +985,50 @@ __global__ void vmh_copy_block_kernel(const float *src, int sp, float *dst, int 
 }
 
 size_t vmh_lds_bytes(int n_mats, int s_rows) { return ((size_t)n_mats * VW * VW + (size_t)s_rows * VTS) * sizeof(float); }
-// rows of the staging tile: as many of the workgroup's waves as the LDS holds beside the weights and the kernels' static arrays
-int vmh_staging_rows(int n_mats) {
+// How a graph of n_tiles tiles runs: every half tile its own workgroup when all of them are resident at once (rounds = false), else
+// whole tiles in tile rounds on as many workgroups as are resident.  s_rows: the staging tile, as many of the workgroup's waves as the
+// LDS holds beside the weights and the instantiation's static arrays.  grid = 0: neither form fits.
+struct VmhPlanGeo {
+  bool rounds = false;
+  int grid = 0, turns = 0, s_rows = 64;
+  size_t lds = 0;
+};
+template <bool ROUNDS>
+static VmhPlanGeo vmh_geo_of(int n_mats, int units, int cus) {
+  VmhPlanGeo geo;
+  geo.rounds = ROUNDS;
   hipFuncAttributes fa{}, ba{};
-  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(node_vmh_fwd_kernel<false>)) != hipSuccess) return 64;
-  if (hipFuncGetAttributes(&ba, reinterpret_cast<const void *>(node_vmh_bwd_kernel<false>)) != hipSuccess) return 64;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(node_vmh_fwd_kernel<ROUNDS>)) != hipSuccess) return geo;
+  if (hipFuncGetAttributes(&ba, reinterpret_cast<const void *>(node_vmh_bwd_kernel<ROUNDS>)) != hipSuccess) return geo;
   const size_t fixed = std::max(fa.sharedSizeBytes, ba.sharedSizeBytes), cap = 160 * 1024;
-  for (int rows = VROUND; rows > 64; rows -= 32)
-    if (vmh_lds_bytes(n_mats, rows) + fixed <= cap) return rows;
-  return 64;
+  geo.s_rows = 0;
+  for (int rows = VROUND; rows >= 64; rows -= 32)
+    if (vmh_lds_bytes(n_mats, rows) + fixed <= cap) { geo.s_rows = rows; break; }
+  if (geo.s_rows == 0) return geo;
+  geo.lds = vmh_lds_bytes(n_mats, geo.s_rows);
+  int occ = 1 << 30;
+  auto take = [&](auto kernel) {
+    int o = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.lds) != hipSuccess) o = 0;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, VT, geo.lds) != hipSuccess) o = 0;
+    occ = std::min(occ, o);
+  };
+  take(node_vmh_fwd_kernel<ROUNDS>); take(node_vmh_bwd_kernel<ROUNDS>);
+  if (occ < 1 || units < 1) return geo;
+  geo.grid = std::min(units, cus * occ);
+  geo.turns = (units + geo.grid - 1) / geo.grid;
+  return geo;
+}
+static VmhPlanGeo vmh_geo(int n_mats, int n_tiles) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return VmhPlanGeo();
+  VmhPlanGeo one = vmh_geo_of<false>(n_mats, 2 * n_tiles, cus);
+  if (one.grid > 0 && one.turns == 1) return one;
+  const char *nr = std::getenv("NGPDE_NO_VMH_ROUNDS");   // (tests and A/B runs: such graphs to the generic solver)
+  if (nr && nr[0] == '1') return VmhPlanGeo();
+  VmhPlanGeo many = vmh_geo_of<true>(n_mats, n_tiles, cus);
+  if (many.grid > 0 && many.turns <= kVmhMaxTurns) return many;
+  return VmhPlanGeo();
 }
 
 }  // namespace
@@ -1008,32 +1053,7 @@ bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s) {
     if (!act_ok(s.gam_act[l])) return false;
   if (s.phi_act[s.n_phi - 1] != NGPDE_ACT_IDENTITY || s.gam_act[s.n_gam - 1] != NGPDE_ACT_IDENTITY) return false;   // (output layers)
   if (g->max_in_degree > kSlotWidth || g->max_out_degree > kSlotWidth) return false;
-  int dev = 0, cus = 0, occ = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  const size_t lds = vmh_lds_bytes(s.n_phi + s.n_gam, vmh_staging_rows(s.n_phi + s.n_gam));
-  occ = 1 << 30;
-  auto take = [&](auto kernel) {
-    int o = 0;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) o = 0;
-    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, VT, lds) != hipSuccess) o = 0;
-    occ = std::min(occ, o);
-  };
-  take(node_vmh_fwd_kernel<false>); take(node_vmh_bwd_kernel<false>); take(node_vmh_fwd_kernel<true>); take(node_vmh_bwd_kernel<true>);
-  const int wgs = 2 * (g->n_sched / kTileRows);
-  if (occ < 1 || wgs < 1) return false;
-  // more half tiles than resident workgroups: tile rounds, up to kVmhMaxTurns half tiles per workgroup (NGPDE_NO_VMH_ROUNDS=1: one only)
-  const char *nr = std::getenv("NGPDE_NO_VMH_ROUNDS");
-  const int turns = (wgs + cus * occ - 1) / (cus * occ);
-  return turns <= ((nr && nr[0] == '1') ? 1 : kVmhMaxTurns);
-}
-
-// the grid of the two launches: every half tile its own workgroup when they are all resident at once, else as many as are
-static int vmh_grid(const VmhMeta &m, size_t lds) {
-  int dev = 0, cus = 0, of = 0, ob = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 2 * m.n_tiles;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, node_vmh_fwd_kernel<true>, VT, lds) != hipSuccess) of = 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, node_vmh_bwd_kernel<true>, VT, lds) != hipSuccess) ob = 1;
-  return std::min(2 * m.n_tiles, std::max(1, cus * std::min(of, ob)));
+  return vmh_geo(s.n_phi + s.n_gam, g->n_sched / kTileRows).grid > 0;
 }
 
 static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
@@ -1055,7 +1075,6 @@ static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
   }
   m.n_edges = (size_t)g->n_edges;
   m.evals = a.n_steps * a.S;
-  m.s_rows = vmh_staging_rows(m.n_phi + m.n_gam);
 #ifdef NGPDE_STAMPS
   m.stamps = g_vst_base; m.stamps_max = g_vst_max;
 #endif
@@ -1077,15 +1096,11 @@ int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
   k.save = a.save; k.save_every = a.save_every; k.save_off = a.save_off;
   k.state = a.state;
   k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.cf = a.cf;
-  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
-  const int grid = vmh_grid(k.m, lds);
-  if (grid < 2 * k.m.n_tiles) {   // tile rounds
-    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(node_vmh_fwd_kernel<true>, dim3(grid), dim3(VT), lds, stream, k);
-  } else {
-    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(node_vmh_fwd_kernel<false>, dim3(grid), dim3(VT), lds, stream, k);
-  }
+  const VmhPlanGeo geo = vmh_geo(k.m.n_phi + k.m.n_gam, k.m.n_tiles);
+  NGPDE_REQUIRE(geo.grid > 0, NGPDE_ERR_UNSUPPORTED, "node_vmh_fwd_kernel: the graph does not fit the device-resident plan");
+  k.m.s_rows = geo.s_rows;
+  if (geo.rounds) hipLaunchKernelGGL(node_vmh_fwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  else hipLaunchKernelGGL(node_vmh_fwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
   NGPDE_LAUNCH_CHECK("node_vmh_fwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
@@ -1104,15 +1119,11 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   k.state = a.state;
   k.n_steps = a.n_steps; k.S = a.S; k.lam = a.lam; k.tape_phi = a.tape_phi; k.tape_gam = a.tape_gam; k.dz_phi = a.dz_phi; k.dz_gam = a.dz_gam;
   k.dsrc0 = a.dsrc; k.dsrc1 = a.dsrc + k.m.n_edges; k.cb = a.cb;
-  const size_t lds = vmh_lds_bytes(k.m.n_phi + k.m.n_gam, k.m.s_rows);
-  const int grid = vmh_grid(k.m, lds);
-  if (grid < 2 * k.m.n_tiles) {   // tile rounds
-    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(node_vmh_bwd_kernel<true>, dim3(grid), dim3(VT), lds, stream, k);
-  } else {
-    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(node_vmh_bwd_kernel<false>, dim3(grid), dim3(VT), lds, stream, k);
-  }
+  const VmhPlanGeo geo = vmh_geo(k.m.n_phi + k.m.n_gam, k.m.n_tiles);
+  NGPDE_REQUIRE(geo.grid > 0, NGPDE_ERR_UNSUPPORTED, "node_vmh_bwd_kernel: the graph does not fit the device-resident plan");
+  k.m.s_rows = geo.s_rows;
+  if (geo.rounds) hipLaunchKernelGGL(node_vmh_bwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  else hipLaunchKernelGGL(node_vmh_bwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
   NGPDE_LAUNCH_CHECK("node_vmh_bwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
