@@ -199,8 +199,15 @@ def _graph_ms(fn, reps):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        fn()
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()      # (a cyclic collection inside the capture could finalise an older captured solve: destroying its graphs is not
+    try:              # permitted on a capturing stream)
+        with torch.cuda.graph(gr):
+            fn()
+    finally:
+        if gc_was:
+            gc.enable()
     return _time_ms(gr.replay, reps)
 
 

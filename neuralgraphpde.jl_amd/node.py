@@ -514,6 +514,23 @@ class _NodeGenericFn(torch.autograd.Function):
         return (lam, None, None, None, *out)
 
 
+class _NoCyclicGC:
+    """No cyclic garbage collection while a HIP graph is being captured: a collection in the middle of a capture may finalise an older
+    captured solve, and destroying ITS graphs is an operation the capturing stream does not permit (the capture dies with
+    hipErrorStreamCaptureUnsupported).  torch.cuda.graph collects once before the capture starts; this keeps it that way until it ends."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class _CapturedSolve:
     """The generic solve as two HIP graphs (NeuralODE(..., capture=True)): the forward stepping loop -- every layer launch
     and every Runge-Kutta combination of all steps -- is captured once and replayed per call, and so is the whole discrete
@@ -537,7 +554,7 @@ class _CapturedSolve:
         torch.cuda.current_stream().wait_stream(side)
         self.fwd_graph = torch.cuda.CUDAGraph()
         # (relaxed: a finaliser that frees device memory in the middle of the capture must not invalidate it)
-        with torch.cuda.graph(self.fwd_graph, capture_error_mode="relaxed"):
+        with _NoCyclicGC(), torch.cuda.graph(self.fwd_graph, capture_error_mode="relaxed"):
             self.uT_static, self.tape, _ = _rk_forward(node, self.u_static, self.ps_in, st, needs, fresh=True)
         self.bwd_graph = None
         self.generation = 0                                # forward replays so far: the single static tape belongs to the last one
@@ -557,7 +574,7 @@ class _CapturedSolve:
         if self.bwd_graph is None:
             self.duT_static = duT.detach().clone()
             self.bwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="relaxed"):
+            with _NoCyclicGC(), torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="relaxed"):
                 self.lam_static, self.acc_static = _rk_backward(self.node, self.tape, self.duT_static, self.params, retain=True)
         else:
             self.duT_static.copy_(duT)

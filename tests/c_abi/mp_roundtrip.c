@@ -2,7 +2,8 @@
  * plan (ngpde_node_gcn2_*), the message path of the edge-function layers (ngpde_dense_forward, ngpde_edge_mlp_forward next to
  * the primitives ngpde_edge_combine_forward / ngpde_segment_reduce_forward), the reassociated and the literal GNOConv message
  * (ngpde_gno_apply_forward / ngpde_gno_contract_forward), the one-launch GAT layer next to its composition
- * (ngpde_gat_layer_forward vs ngpde_dense_forward + ngpde_gat_forward + ngpde_bias_act_forward), ngpde_rk_stage_combine, and the
+ * (ngpde_gat_layer_forward vs ngpde_dense_forward + ngpde_gat_forward + ngpde_bias_act_forward), ngpde_rk_stage_combine, the
+ * device-resident NeuralODE(VMHConv) plan with saveat (ngpde_node_vmh_*), and the
  * node-level Dense pair / chain launches (ngpde_dense_pair_forward / _backward, ngpde_dense_chain2_forward) at a streaming size.
  * No Python, torch or C++ on the calling side.  Checkers: the C restatement of the reference solver (oracle/ngpde_oracle.c) and
  * plain double-precision loops over the CSR lists the library hands out.  Exit code 0 = every comparison within tolerance.
@@ -362,6 +363,100 @@ int main(void) {
     report("dense_pair_backward dWp", max_rel(dwp, rwp, din * hw), 3e-4);
     report("dense_pair_backward dWq", max_rel(dwq, rwq, din * hw), 3e-4);
     report("dense_pair_backward dbp", max_rel(dbp, rbp, hw), 3e-4);
+  }
+  /* ---- NeuralODE(VMHConv(phi, gamma)) device-resident (ngpde_node_vmh_*; docs/src/tutorials/VMH.md:75-89, src/layers.jl:308-332): two
+   * Euler steps on a scalar state with positions as node data, saved after every step (saveat); values against a double-precision
+   * loop over the edge list, du0 of L = sum of all saved states against central differences of that loop ---- */
+  {
+    const int pd = 1, hp = 8, mw = 4, hg = 8, steps = 2;
+    const float dtv = 0.05f;
+    const int32_t phi_dims[3] = {2 + pd, hp, mw}, gam_dims[3] = {1 + mw, hg, 1};
+    const int32_t acts[2] = {NGPDE_ACT_TANH, NGPDE_ACT_IDENTITY};
+    ngpde_graph_t *gv = NULL;   /* the plain handle of the edge-function layers: no self loops */
+    CHECK_NG(ngpde_graph_create(n, e, s, t, /*index_base=*/0, 1, &gv));
+    CHECK_NG(ngpde_graph_set_gcn_norm(gv, /*add_self_loops=*/0, NULL, 0));
+    if (ngpde_node_vmh_supported(gv, 1, pd, 2, phi_dims, acts, 2, gam_dims, acts, NGPDE_AGGR_MEAN)) {
+      float *pos = malloc(sizeof(float) * n), *u0 = host_rand(n, 1.f);
+      for (int64_t i = 0; i < n; ++i) pos[i] = (float)i / (float)n;
+      float *wp1 = host_rand((size_t)phi_dims[0] * hp, 0.5f), *bp1 = host_rand(hp, 0.2f), *wp2 = host_rand((size_t)hp * mw, 0.5f),
+            *bp2 = host_rand(mw, 0.2f), *wg1 = host_rand((size_t)gam_dims[0] * hg, 0.5f), *bg1 = host_rand(hg, 0.2f),
+            *wg2 = host_rand(hg, 0.5f), *bg2 = host_rand(1, 0.2f);
+      float *pos_d = dev_copy(pos, n), *u0_d = dev_copy(u0, n), *us_d = dev_copy(NULL, (size_t)(steps + 1) * n), *du0_d = dev_copy(NULL, n);
+      const float *pw[2] = {dev_copy(wp1, (size_t)phi_dims[0] * hp), dev_copy(wp2, (size_t)hp * mw)}, *pb[2] = {dev_copy(bp1, hp), dev_copy(bp2, mw)};
+      const float *gw[2] = {dev_copy(wg1, (size_t)gam_dims[0] * hg), dev_copy(wg2, hg)}, *gb[2] = {dev_copy(bg1, hg), dev_copy(bg2, 1)};
+      float *dpw[2] = {dev_copy(NULL, (size_t)phi_dims[0] * hp), dev_copy(NULL, (size_t)hp * mw)}, *dpb[2] = {dev_copy(NULL, hp), dev_copy(NULL, mw)};
+      float *dgw[2] = {dev_copy(NULL, (size_t)gam_dims[0] * hg), dev_copy(NULL, hg)}, *dgb[2] = {dev_copy(NULL, hg), dev_copy(NULL, 1)};
+      float *ones = malloc(sizeof(float) * (steps + 1) * n);
+      for (int64_t i = 0; i < (steps + 1) * n; ++i) ones[i] = 1.f;
+      float *ones_d = dev_copy(ones, (size_t)(steps + 1) * n);
+      ngpde_node_vmh_t *vp = NULL;
+      CHECK_NG(ngpde_node_vmh_create(gv, 1, pd, pos_d, 2, phi_dims, acts, 2, gam_dims, acts, NGPDE_AGGR_MEAN, NGPDE_TABLEAU_EULER, steps, dtv, 1, &vp));
+      CHECK_NG(ngpde_node_vmh_forward_saveat(vp, u0_d, pw, pb, gw, gb, 1, 1, us_d, NULL));
+      CHECK_NG(ngpde_node_vmh_backward_saveat(vp, pw, gw, 1, 1, ones_d, du0_d, dpw, dpb, dgw, dgb, NULL));
+      int32_t fault = 1;
+      CHECK_NG(ngpde_node_vmh_fault(vp, NULL, &fault));
+      CHECK_HIP(hipDeviceSynchronize());
+      if (fault || ngpde_node_vmh_tape_bytes(vp) == 0) { fprintf(stderr, "node_vmh: fault %d\n", fault); return 11; }
+      /* the same in double precision: loss(u0) = sum over the saved states (u0 itself, u1, u2) */
+      double *deg = calloc(n, sizeof(double)), *cur = malloc(sizeof(double) * n), *nxt = malloc(sizeof(double) * n),
+             *msg = malloc(sizeof(double) * n * mw), *ref = malloc(sizeof(double) * (steps + 1) * n);
+      for (int64_t k = 0; k < e; ++k) deg[t[k]] += 1.0;
+      for (int pass = 0; pass < 7; ++pass) {   /* pass 0: the values; 1..6: u0[probe] +- eps for three probes */
+        const int64_t probe[3] = {3, n / 2, n - 7};
+        const double eps = 1e-3;
+        for (int64_t i = 0; i < n; ++i) cur[i] = u0[i];
+        if (pass > 0) cur[probe[(pass - 1) / 2]] += ((pass - 1) % 2 ? -eps : eps);
+        double loss = 0;
+        for (int64_t i = 0; i < n; ++i) { loss += cur[i]; if (pass == 0) ref[i] = cur[i]; }
+        for (int st = 0; st < steps; ++st) {
+          memset(msg, 0, sizeof(double) * n * mw);
+          for (int64_t k = 0; k < e; ++k) {
+            const int64_t a = t[k], b = s[k];
+            const double in[3] = {cur[a], cur[b] - cur[a], (double)pos[b] - (double)pos[a]};
+            double hid[8];
+            for (int o = 0; o < hp; ++o) {
+              double z = bp1[o];
+              for (int c2 = 0; c2 < 3; ++c2) z += in[c2] * wp1[c2 * hp + o];
+              hid[o] = tanh(z);
+            }
+            for (int o = 0; o < mw; ++o) {
+              double z = bp2[o];
+              for (int c2 = 0; c2 < hp; ++c2) z += hid[c2] * wp2[c2 * mw + o];
+              msg[a * mw + o] += z;
+            }
+          }
+          for (int64_t i = 0; i < n; ++i) {
+            double gin[5] = {cur[i], 0, 0, 0, 0}, hid[8], z2 = bg2[0];
+            for (int o = 0; o < mw; ++o) gin[1 + o] = deg[i] > 0 ? msg[i * mw + o] / deg[i] : 0.0;
+            for (int o = 0; o < hg; ++o) {
+              double z = bg1[o];
+              for (int c2 = 0; c2 < 5; ++c2) z += gin[c2] * wg1[c2 * hg + o];
+              hid[o] = tanh(z);
+            }
+            for (int c2 = 0; c2 < hg; ++c2) z2 += hid[c2] * wg2[c2];
+            nxt[i] = cur[i] + (double)dtv * z2;
+          }
+          for (int64_t i = 0; i < n; ++i) { cur[i] = nxt[i]; loss += cur[i]; if (pass == 0) ref[(st + 1) * n + i] = cur[i]; }
+        }
+        if (pass == 0) {
+          float *us = host_copy(us_d, (size_t)(steps + 1) * n), *reff = malloc(sizeof(float) * (steps + 1) * n);
+          for (int64_t i = 0; i < (steps + 1) * n; ++i) reff[i] = (float)ref[i];
+          report("node_vmh_forward_saveat (2 Euler steps)", max_rel(us, reff, (size_t)(steps + 1) * n), 1e-4);
+        } else {
+          static double lp;
+          if (pass % 2) lp = loss;
+          else {
+            const float *du0 = host_copy(du0_d, n);
+            const double fd = (lp - loss) / (2 * eps), got = du0[probe[(pass - 1) / 2]];
+            report("node_vmh_backward_saveat du0 vs central difference", fabs(got - fd) / (fabs(fd) > 1e-30 ? fabs(fd) : 1e-30), 5e-3);
+          }
+        }
+      }
+      CHECK_NG(ngpde_node_vmh_destroy(vp));
+    } else {
+      printf("node_vmh: plan not supported on this graph (skipped)\n");
+    }
+    CHECK_NG(ngpde_graph_destroy(gv));
   }
   CHECK_NG(ngpde_graph_destroy(g));
   return fails ? 1 : 0;
