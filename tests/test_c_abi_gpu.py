@@ -52,3 +52,4 @@ def test_solver_plan_message_path_gno_gat_from_plain_c(exe_mp):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "FAIL" not in r.stdout and "node_gcn2 u(T)" in r.stdout and "gat_layer_forward" in r.stdout
     assert "dense_pair_backward dWq" in r.stdout and "dense_chain2_forward" in r.stdout
+    assert "node_vmh_forward_saveat" in r.stdout and r.stdout.count("node_vmh_backward_saveat du0") == 3, r.stdout   # (ran, not skipped)
