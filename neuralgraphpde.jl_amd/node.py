@@ -273,6 +273,39 @@ class _VmhPlan:
             pass
 
 
+def _padded_batch(g, device):
+    """(padded graph, index of the real nodes in it) for a batch of single graphs whose sizes are not all multiples of the 32-row tile,
+    cached on the batch; None when `g` is no such batch.  Every member keeps its node order and gets isolated nodes behind it up to a
+    whole number of tiles; node data are zero there."""
+    cached = getattr(g, "_vmh_pad", None)
+    if cached is not None:
+        return cached if cached[1].device == torch.device(device) else (cached[0], cached[1].to(device))
+    members = getattr(g, "_members", None)
+    if not members or list(g.ndata) != ["x"] or all(mg.num_nodes % 32 == 0 for mg in members):
+        return None
+    from .graphs import GNNGraph, _as_matrix_t
+    sizes = np.array([mg.num_nodes for mg in members], dtype=np.int64)
+    padded = (sizes + 31) // 32 * 32
+    off, poff = np.concatenate([[0], np.cumsum(sizes)]), np.concatenate([[0], np.cumsum(padded)])
+    index = np.concatenate([np.arange(n, dtype=np.int64) + po for n, po in zip(sizes, poff[:-1])])
+    s0, t0 = g.edge_index(index_base=0)
+    s0, t0 = np.asarray(s0.cpu() if isinstance(s0, torch.Tensor) else s0), np.asarray(t0.cpu() if isinstance(t0, torch.Tensor) else t0)
+    gp = GNNGraph(index[s0], index[t0], num_nodes=int(poff[-1]), index_base=0, num_graphs=len(members))
+    x = _as_matrix_t(g.ndata["x"], g.num_nodes).to(device)                      # [N][pd]
+    idx_t = torch.as_tensor(index, device=device)
+    xp = torch.zeros((int(poff[-1]), x.shape[1]), dtype=torch.float32, device=device).index_copy(0, idx_t, x.to(torch.float32))
+    gp.ndata = {"x": xp.T}
+    order = g._shared.get("order")
+    if order is not None:      # the members' locality orders, each followed by its padding nodes
+        parts = []
+        for k in range(len(members)):
+            parts.append(index[np.asarray(order[off[k]:off[k + 1]], dtype=np.int64)])
+            parts.append(np.arange(poff[k] + sizes[k], poff[k + 1], dtype=np.int64))
+        gp._shared["order"] = np.concatenate(parts).astype(np.int32)
+    g._vmh_pad = (gp, idx_t)
+    return g._vmh_pad
+
+
 def _ptrs(ts):
     return (C.c_void_p * max(len(ts), 1))(*[(t.data_ptr() if t is not None else None) for t in ts])
 
@@ -778,11 +811,26 @@ class NeuralODE(AbstractExplicitLayer):
         handle = g.handle()
         lib = _lib.load()
         ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
+        supported = lambda h: lib.ngpde_node_vmh_supported(h.ptr, 1, pd, len(acts[0]), ia(dims[0]), ia(acts[0]), len(acts[1]), ia(dims[1]),
+                                                            ia(acts[1]), aggr)
         key = ("vmh", id(handle), tuple(dims[0]), tuple(acts[0]), tuple(dims[1]), tuple(acts[1]), aggr, bool(needs_grad))
         pool = self._plans.get(key)
-        if pool is None:
-            if not lib.ngpde_node_vmh_supported(handle.ptr, 1, pd, len(acts[0]), ia(dims[0]), ia(acts[0]), len(acts[1]), ia(dims[1]), ia(acts[1]), aggr):
+        index = None
+        if pool is None and (getattr(g, "_vmh_pad", None) is not None or not supported(handle)):
+            # a batch of point clouds whose sizes are not multiples of the 32-row tile (VMH.md:120-134: 24 clouds of 3 000 points): a tile
+            # that holds the end of one cloud and the start of the next stages two neighbourhoods and can overflow its halo, which takes
+            # the persistent forms away from the whole handle.  The same batch with every cloud padded to whole tiles by isolated nodes
+            # (no edges: no messages, a zero cotangent on their outputs) is served; u goes in and out through an index map.
+            pad = _padded_batch(g, u.device)
+            if pad is None:
                 return None
+            g, index = pad
+            handle, pos = g.handle(), _node_data(g, u.device)
+            key = ("vmh", id(handle), tuple(dims[0]), tuple(acts[0]), tuple(dims[1]), tuple(acts[1]), aggr, bool(needs_grad))
+            pool = self._plans.get(key)
+            if pool is None and not supported(handle):
+                return None
+        if pool is None:
             pool = self._plans[key] = []
             while len(self._plans) > self.max_plans:
                 self._plans.pop(next(iter(self._plans)))
@@ -790,7 +838,7 @@ class NeuralODE(AbstractExplicitLayer):
             self._plans[key] = self._plans.pop(key)
         for plan in pool:
             if not (needs_grad and plan.busy()):
-                return plan, wb
+                return plan, wb, index
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
@@ -806,7 +854,7 @@ class NeuralODE(AbstractExplicitLayer):
                 return None
         plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
         pool.append(plan)
-        return plan, wb
+        return plan, wb, index
 
     def __call__(self, x, ps, st):
         u = rows_of(x)
@@ -842,11 +890,18 @@ class NeuralODE(AbstractExplicitLayer):
             return uT.T, st
         vplan = self.vmh_plan_for(ps, st, u, needs_grad)
         if vplan is not None:
-            plan_v, wb = vplan
+            plan_v, wb, index = vplan
+            uin = u.reshape(-1)
+            if index is not None:      # (a padded batch: the real nodes' rows among the isolated padding nodes')
+                uin = torch.zeros(plan_v.n_nodes, dtype=torch.float32, device=u.device).index_copy(0, index, uin)
             if self.save_every:      # saveat: the (1 x N x T) array of the solution at t0 (+ j saveat)
-                us = _NodeVmhFn.apply(u.reshape(-1), plan_v, (self.save_every, self.save_start), *wb)
+                us = _NodeVmhFn.apply(uin, plan_v, (self.save_every, self.save_start), *wb)
+                if index is not None:
+                    us = us.index_select(1, index)
                 return us.T.unsqueeze(0), st
-            uT = _NodeVmhFn.apply(u.reshape(-1), plan_v, None, *wb)
+            uT = _NodeVmhFn.apply(uin, plan_v, None, *wb)
+            if index is not None:
+                uT = uT.index_select(0, index)
             return uT.reshape(u.shape).T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch

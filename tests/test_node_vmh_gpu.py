@@ -275,6 +275,47 @@ def test_vmh_tile_rounds_equal_the_generic_solver_and_can_be_switched_off(monkey
     assert torch.isnan(out).all() and any(p.fault() for pool in node._plans.values() for p in pool)
 
 
+def test_vmh_batch_of_clouds_that_share_tiles_runs_padded(monkeypatch):
+    # four clouds of 3 000 points (VMH.md:120-134 batches 24 of them): 3 000 is not a multiple of the 32-row tile, a tile at a cloud
+    # boundary stages two neighbourhoods and overflows its halo, and the union handle loses the persistent forms.  NeuralODE then runs the
+    # plan on the same batch with every cloud padded to whole tiles by isolated nodes; values, du0 and parameter gradients against the
+    # generic solver on the unpadded batch, with saveat
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    monkeypatch.delenv("NGPDE_NO_VMH_ROUNDS", raising=False)
+    nv, nb, steps = 3000, 4, 2
+    clouds = []
+    for kb in range(nb):
+        pk = torch.as_tensor(S.uniform01(200 + kb, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+        clouds.append(ng.GNNGraph(ng.knn_graph(pk, 6), ndata={"x": pk}))
+    gb = ng.batch(clouds)
+    lib = _lib.load()
+    ia = lambda v: (C.c_int32 * len(v))(*v)
+    acts = [_lib.ACT["tanh"]] * 3 + [_lib.ACT["identity"]]
+    if lib.ngpde_node_vmh_supported(gb.handle().ptr, 1, 2, 4, ia([4, 60, 60, 60, 40]), ia(acts), 4, ia([41, 60, 60, 60, 1]), ia(acts), _lib.AGGR["mean"]):
+        pytest.skip("this batch's boundary tiles happen to fit their halos: nothing to pad")
+    phi, gam = tutorial_mlps()
+    N = nb * nv
+    u0 = torch.as_tensor(S.normal(62, N).reshape(1, N).astype(np.float32), device=DEV)
+    R = torch.as_tensor(S.normal(63, N * (steps + 1)).reshape(1, N, steps + 1).astype(np.float32), device=DEV)
+    res = {}
+    for mode in ("padded", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("NGPDE_NO_VMH_NODE", "1")
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=gb), solver="tsit5", n_steps=steps, dt=0.05, saveat=0.05)
+        ps0, st = ng.setup(4, node)
+        ps = prep(ps0, 4)
+        u = u0.clone().requires_grad_(True)
+        us, _ = node(u, ps, st)
+        assert tuple(us.shape) == (1, N, steps + 1)
+        (us * R).sum().backward()
+        assert ("vmh" in plan_flags(node)) == (mode == "padded")
+        n1, _ = mlp_grad_pairs(ps["ϕ"], [{"weight": 0, "bias": 0}] * 4, phi)
+        n2, _ = mlp_grad_pairs(ps["γ"], [{"weight": 0, "bias": 0}] * 4, gam)
+        res[mode] = [us.detach().clone(), u.grad.clone()] + [p.grad.clone() for _, p in n1 + n2]
+    for a, b in zip(res["padded"], res["generic"]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+
+
 def test_vmh_resident_plan_reports_an_abort_instead_of_hanging(monkeypatch):
     # a launch whose waits give up (forced: NGPDE_DEBUG_FORCE_ABORT=1 starts it with the abort word set) writes NaN outputs and
     # latches the plan's fault word; the next entry of the plan fails instead of computing on garbage; a fresh plan works
