@@ -411,10 +411,10 @@ def secondary(dev, world, rank, dist):
             finally:
                 os.environ.pop("NGPDE_NO_VMH_NODE", None)
         # the tutorial's minibatch form (VMH.md:120-134: a DataLoader batch of point clouds as ONE block-diagonal graph per step), 8 clouds of
-        # 3 008 points: 1 504 half tiles on 256 compute units -- the device-resident plan walks them in tile rounds.  (3 008 = 94 whole
-        # 32-row tiles per cloud: a cloud boundary INSIDE a tile merges two neighbourhoods into one tile's halo, which can overflow the
-        # 96 rows a tile stages; the plan then leaves the batch to the generic solver -- plan_flags says which path ran.)
-        nb, nvb = 8, 3008
+        # 3 000 points: 752 tiles on 256 compute units -- the device-resident plan walks them in tile rounds.  (3 000 is not a multiple of
+        # the 32-row tile: NeuralODE pads every cloud to whole tiles with isolated nodes, node.py: _padded_batch; plan_flags says which
+        # path ran.)
+        nb, nvb = 8, 3000
         gcl = []
         for kb in range(nb):
             pk = torch.as_tensor(S.uniform01(200 + kb, 2 * nvb).reshape(2, nvb).astype(np.float32), device=dev)

@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 import weakref
 
+import numpy as np
+
 import torch
 
 from . import _lib
