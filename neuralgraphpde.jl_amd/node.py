@@ -849,6 +849,7 @@ class NeuralODE(AbstractExplicitLayer):
             # fit beside what the device already holds; else the generic solver (which keeps O(stages) arrays) takes the solve
             evals = self.n_steps * (6 if self.solver == "tsit5" else 1)
             need = 2 * 256 * evals * (len(acts[0]) * max(int(g.num_edges), 1) + len(acts[1]) * int(g.num_nodes))
+            _lib.flush_destroy()      # (plans evicted above give their tapes back first)
             free, _total = torch.cuda.mem_get_info(u.device)
             if need > 0.9 * free:
                 if not pool:
