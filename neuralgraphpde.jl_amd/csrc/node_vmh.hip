@@ -19,8 +19,15 @@
 //   * parameter gradients are NOT accumulated in the launch (eight 64 x 64 accumulators per workgroup fit neither registers nor
 //     LDS): dW_l = A_l^T dZ_l is one large weight-pullback GEMM per layer over the tapes of all evaluations afterwards
 //     (dense_mfma.hip), at full-chip efficiency.
+//   * tape rows (layer inputs forward, dz rows in the adjoint) of a one-round half tile stay in registers and are stored ONE EVALUATION
+//     LATE, layer by layer in front of the layer's MFMAs: no burst of ~90 KB per workgroup at the hand-off; the tape rows the adjoint
+//     reads are asked for a phase (gamma, phi's last hidden layer) or a layer ahead;
+//   * graphs of more half tiles than the device keeps resident -- the tutorial's minibatch is 24 clouds of 3 000 points as one graph,
+//     VMH.md:120-134 -- run in TILE ROUNDS (template parameter ROUNDS): whole 32-row tiles, K per workgroup, walked in the same order in
+//     every phase with the weights resident, the rows' Runge-Kutta state in memory between turns; the adjoint's sweep ph runs, per tile,
+//     the second half of phase ph - 1 and at once the first half of phase ph.
 // State width 1 (a scalar field, as in the tutorial), positions of 1-3 coordinates, MLPs of 2-4 layers up to 64 wide with
-// identity output layers; graphs of at most 2 x (CUs) half tiles.  Anything else keeps the generic solver.
+// identity output layers; up to kVmhMaxTurns tiles per resident workgroup.  Anything else keeps the generic solver.
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -38,10 +45,10 @@ namespace {
 constexpr int VT = 512;               // threads per workgroup: 8 waves, two per SIMD (the tutorial graph's 96 edges per workgroup are one round)
 constexpr int VROUND = (VT / 64) * 16;   // edges per round: one 16-edge slice per wave
 constexpr int VW = 64;                // padded layer width
-constexpr int VR = 16;                // target rows per workgroup
+constexpr int VR = 16;                // target rows of a half tile (the unit of the one-tile form; tile rounds: whole tiles, 2 VR)
 constexpr int VTS = VW + 4;           // staging tile stride
 constexpr int VNbr = 64;
-constexpr int kVmhMaxTurns = 64;       // tile rounds: half tiles per workgroup (64 x 256 CUs x 16 rows = 262 144 nodes)
+constexpr int kVmhMaxTurns = 64;       // tile rounds: tiles per workgroup (64 x 256 CUs x 32 rows = 524 288 nodes)
 
 #ifdef NGPDE_STAMPS
 // diagnostic build only (tools/stamps_vmh.py): shader-clock stamps of thread 0 at 8 points of the first g_vst_max phases
