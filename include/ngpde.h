@@ -484,8 +484,8 @@ int32_t ngpde_node_gat_backward(ngpde_node_gat_t *plan, const float *weight, con
  * persistent launch each (+ one weight-pullback GEMM per Dense layer).  Shapes taken: a scalar state (hd = 1: u0, uT, duT, du0 are
  * [N]), pd = 1..3 position coordinates (pos: device [N][pd], copied at creation), MLPs of 2..4 Dense layers up to 64 wide --
  * phi: dims[0] = 2 hd + pd, gamma: dims[0] = hd + phi's output width, gamma's output width = hd --, hidden activations identity /
- * relu / tanh / sigmoid, identity output layers, + or mean aggregation, graphs of up to 64 16-row half tiles per CU (more half tiles
- * than resident workgroups: every workgroup walks its K half tiles in turn in every phase, "tile rounds").
+ * relu / tanh / sigmoid, identity output layers, + or mean aggregation, graphs of up to 64 tiles per resident workgroup (more half tiles than resident
+ * workgroups: whole 32-row tiles, K per workgroup, walked in turn in every phase -- "tile rounds").
  * ngpde_node_vmh_supported says so; the host's generic solver takes everything else.  Weights are [in][out] (Julia's (out x in)
  * column-major), passed as HOST arrays of device pointers (bias pointers / the bias arrays may be NULL).  One solve's tape per plan. */
 int32_t ngpde_node_vmh_supported(const ngpde_graph_t *g, int32_t hd, int32_t pd, int32_t n_phi, const int32_t *phi_dims, const int32_t *phi_acts,
