@@ -33,6 +33,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "common.h"
 #include "device_utils.h"
@@ -1026,16 +1029,32 @@ static VmhPlanGeo vmh_geo_of(int n_mats, int units, int cus) {
   geo.turns = (units + geo.grid - 1) / geo.grid;
   return geo;
 }
-static VmhPlanGeo vmh_geo(int n_mats, int n_tiles) {
+static VmhPlanGeo vmh_geo_uncached(int n_mats, int n_tiles, bool no_rounds) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return VmhPlanGeo();
   VmhPlanGeo one = vmh_geo_of<false>(n_mats, 2 * n_tiles, cus);
   if (one.grid > 0 && one.turns == 1) return one;
-  const char *nr = std::getenv("NGPDE_NO_VMH_ROUNDS");   // (tests and A/B runs: such graphs to the generic solver)
-  if (nr && nr[0] == '1') return VmhPlanGeo();
+  if (no_rounds) return VmhPlanGeo();
   VmhPlanGeo many = vmh_geo_of<true>(n_mats, n_tiles, cus);
   if (many.grid > 0 && many.turns <= kVmhMaxTurns) return many;
   return VmhPlanGeo();
+}
+// (asked at every launch: the attribute / occupancy queries behind it are remembered per shape and device)
+static VmhPlanGeo vmh_geo(int n_mats, int n_tiles) {
+  const char *nr = std::getenv("NGPDE_NO_VMH_ROUNDS");   // (tests and A/B runs: graphs beyond the resident half tiles to the generic solver)
+  const bool no_rounds = nr && nr[0] == '1';
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return VmhPlanGeo();
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, bool>, VmhPlanGeo> seen;
+  const auto key = std::make_tuple(dev, n_mats, n_tiles, no_rounds);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(key);
+  if (it != seen.end()) return it->second;
+  if (seen.size() > 256) seen.clear();
+  const VmhPlanGeo geo = vmh_geo_uncached(n_mats, n_tiles, no_rounds);
+  seen[key] = geo;
+  return geo;
 }
 
 }  // namespace
@@ -1106,8 +1125,14 @@ int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream) {
   const VmhPlanGeo geo = vmh_geo(k.m.n_phi + k.m.n_gam, k.m.n_tiles);
   NGPDE_REQUIRE(geo.grid > 0, NGPDE_ERR_UNSUPPORTED, "node_vmh_fwd_kernel: the graph does not fit the device-resident plan");
   k.m.s_rows = geo.s_rows;
-  if (geo.rounds) hipLaunchKernelGGL(node_vmh_fwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
-  else hipLaunchKernelGGL(node_vmh_fwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  // (the attribute is per function, and another shape's geometry may have lowered it since)
+  if (geo.rounds) {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.lds));
+    hipLaunchKernelGGL(node_vmh_fwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  } else {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.lds));
+    hipLaunchKernelGGL(node_vmh_fwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  }
   NGPDE_LAUNCH_CHECK("node_vmh_fwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
@@ -1129,8 +1154,13 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   const VmhPlanGeo geo = vmh_geo(k.m.n_phi + k.m.n_gam, k.m.n_tiles);
   NGPDE_REQUIRE(geo.grid > 0, NGPDE_ERR_UNSUPPORTED, "node_vmh_bwd_kernel: the graph does not fit the device-resident plan");
   k.m.s_rows = geo.s_rows;
-  if (geo.rounds) hipLaunchKernelGGL(node_vmh_bwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
-  else hipLaunchKernelGGL(node_vmh_bwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  if (geo.rounds) {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.lds));
+    hipLaunchKernelGGL(node_vmh_bwd_kernel<true>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  } else {
+    NGPDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(node_vmh_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.lds));
+    hipLaunchKernelGGL(node_vmh_bwd_kernel<false>, dim3(geo.grid), dim3(VT), geo.lds, stream, k);
+  }
   NGPDE_LAUNCH_CHECK("node_vmh_bwd_kernel");
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
