@@ -440,7 +440,10 @@ def secondary(dev, world, rank, dist):
         msb = res_b["plan"][0]
         out["VMH_node_batch8_tsit5x20"] = {"clouds": nb, "nodes": nb * nvb, "edges": int(gb.num_edges), "ms_solve_forward_backward": round(msb, 3),
                                            "value": round(nb * steps_v / (msb * 1e-3), 1), "unit": "trajectory ODE-steps/s",
-                                           "plan_flags": res_b["plan"][1], "generic_captured_ms": round(res_b["generic"][0], 3),
+                                           "plan_flags": res_b["plan"][1],
+                                           "roofline": {"bound": "mfma", "achieved": round(nb * gflop_v / msb, 2), "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                                                        "frac": round(nb * gflop_v / msb / FP32_MFMA_PEAK_TFS, 4)},
+                                           "generic_captured_ms": round(res_b["generic"][0], 3),
                                            "generic_captured_value": round(nb * steps_v / (res_b["generic"][0] * 1e-3), 1)}
     # C4: the per-GPU shard of the 512-trajectory config
     layer, ps, st, x, n_edges = c4_layer(dev, 64, rank)
