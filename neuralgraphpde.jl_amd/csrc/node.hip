@@ -1035,13 +1035,63 @@ struct ngpde_node_vmh {
   float *tape_phi = nullptr, *tape_gam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;
   float *partial = nullptr, *dwpad = nullptr;                                // weight-pullback workspace; [64 x 64 + 64] padded result
   size_t tape_bytes = 0, partial_floats = 0;
+  size_t tape_floats[2] = {0, 0};   // capacity of tape_phi / dz_phi and of tape_gam / dz_gam (they may come from the pool, larger than needed)
 };
+
+// The tapes of a VMH plan are tens of GB at the tutorial's minibatch size, and a training loop that batches its point clouds in a new
+// order every epoch (VMH.md:120, DataLoader(shuffle = true)) builds a new plan per step: allocating and freeing such blocks each time
+// costs 0.02 - 6 s per step (measured: hipFree of 124 GB 0.8 s, the hipMalloc after it up to 6 s).  Freed tapes are therefore parked
+// (at most kTapePoolMax blocks) and handed to the next plan whose need they fit.  A parked block is not zeroed again: it was zeroed
+// when allocated, what it holds since is finite, and the 16-float blocks of a row a solve does not write feed only the rows /
+// columns of the padded 64 x 64 weight-pullback result that launch_vmh_copy_block never copies out.
+namespace {
+constexpr size_t kTapePoolMax = 8;
+struct TapeBlock {
+  float *ptr;
+  size_t floats;
+};
+std::mutex g_tape_mu;
+std::vector<TapeBlock> g_tape_pool;
+
+float *tape_pool_take(size_t floats) {   // the smallest parked block that fits without wasting more than half of itself
+  std::lock_guard<std::mutex> lock(g_tape_mu);
+  int best = -1;
+  for (int i = 0; i < (int)g_tape_pool.size(); ++i)
+    if (g_tape_pool[i].floats >= floats && g_tape_pool[i].floats <= 2 * floats + 1024 &&
+        (best < 0 || g_tape_pool[i].floats < g_tape_pool[best].floats))
+      best = i;
+  if (best < 0) return nullptr;
+  float *ptr = g_tape_pool[best].ptr;
+  g_tape_pool.erase(g_tape_pool.begin() + best);
+  return ptr;
+}
+size_t tape_pool_release_all() {   // (before a fresh allocation that would not fit beside the parked blocks)
+  std::lock_guard<std::mutex> lock(g_tape_mu);
+  size_t n = g_tape_pool.size();
+  for (auto &b : g_tape_pool) (void)hipFree(b.ptr);
+  g_tape_pool.clear();
+  return n;
+}
+void tape_pool_give(float *ptr, size_t floats) {
+  if (!ptr) return;
+  std::lock_guard<std::mutex> lock(g_tape_mu);
+  if (floats < (64u << 20) / 4 || g_tape_pool.size() >= kTapePoolMax) {   // small blocks and an overfull pool: back to the device
+    (void)hipFree(ptr);
+    return;
+  }
+  g_tape_pool.push_back({ptr, floats});
+}
+}  // namespace
 
 static void node_vmh_free(ngpde_node_vmh *p) {
   if (!p) return;
-  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->tape_phi, p->tape_gam, p->dz_phi, p->dz_gam, p->dsrc, p->partial, p->dwpad};
+  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->dsrc, p->partial, p->dwpad};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  tape_pool_give(p->tape_phi, p->tape_floats[0]);
+  tape_pool_give(p->tape_gam, p->tape_floats[1]);
+  tape_pool_give(p->dz_phi, p->tape_floats[0]);
+  tape_pool_give(p->dz_gam, p->tape_floats[1]);
   node_persistent_free(&p->persist);
   delete p;
 }
@@ -1114,10 +1164,26 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
   if (st == NGPDE_OK && p->with_bwd) {
     // (zeroed once: the padded columns of a layer's rows are never written, and the weight-pullback GEMMs read whole 64-wide rows)
     const size_t tp = (size_t)n_phi * evals * E * 64, tg = (size_t)n_gamma * evals * N * 64;
-    step(alloc(&p->tape_phi, tp, true));
-    if (st == NGPDE_OK) step(alloc(&p->tape_gam, tg, true));
-    if (st == NGPDE_OK) step(alloc(&p->dz_phi, tp, true));
-    if (st == NGPDE_OK) step(alloc(&p->dz_gam, tg, true));
+    auto tape = [&](float **ptr, size_t floats) -> int32_t {   // a parked block that fits, else a fresh zeroed one
+      floats = std::max<size_t>(floats, 64);
+      if ((*ptr = tape_pool_take(floats)) != nullptr) return NGPDE_OK;
+      if (hipMalloc((void **)ptr, floats * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        if (tape_pool_release_all() == 0 || hipMalloc((void **)ptr, floats * 4) != hipSuccess) {
+          (void)hipGetLastError();
+          *ptr = nullptr;
+          return fail(NGPDE_ERR_HIP, "ngpde_node_vmh_create: %.1f GB of tape do not fit the device", floats * 4 / 1e9);
+        }
+      }
+      NGPDE_HIP_CHECK(hipMemset(*ptr, 0, floats * 4));
+      return NGPDE_OK;
+    };
+    p->tape_floats[0] = std::max<size_t>(tp, 64); p->tape_floats[1] = std::max<size_t>(tg, 64);
+    step(tape(&p->tape_phi, tp));
+    if (st == NGPDE_OK) step(tape(&p->tape_gam, tg));
+    if (st == NGPDE_OK) step(tape(&p->dz_phi, tp));
+    if (st == NGPDE_OK) step(tape(&p->dz_gam, tg));
     if (st == NGPDE_OK) step(alloc(&p->dsrc, 2 * E, true));
     p->tape_bytes = 2 * (tp + tg) * 4;
     p->partial_floats = (size_t)dense_weight_chunks((int64_t)(evals * E), 64, 64) * 65 * 64 + 64;
@@ -1131,6 +1197,7 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
   if (st != NGPDE_OK) {
     const std::string keep = last_error();
     node_vmh_free(p);
+    (void)tape_pool_release_all();   // (a plan that did not fit: nothing of it stays parked)
     last_error() = keep;
     return st;
   }

@@ -844,18 +844,17 @@ class NeuralODE(AbstractExplicitLayer):
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
-        if needs_grad:
-            # the tapes of a solve -- every layer's input rows and dz rows of every right-hand-side evaluation, 64 floats wide -- must
-            # fit beside what the device already holds; else the generic solver (which keeps O(stages) arrays) takes the solve
-            evals = self.n_steps * (6 if self.solver == "tsit5" else 1)
-            need = 2 * 256 * evals * (len(acts[0]) * max(int(g.num_edges), 1) + len(acts[1]) * int(g.num_nodes))
-            _lib.flush_destroy()      # (plans evicted above give their tapes back first)
-            free, _total = torch.cuda.mem_get_info(u.device)
-            if need > 0.9 * free:
-                if not pool:
-                    self._plans.pop(key, None)
-                return None
-        plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
+        try:
+            plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
+        except _lib.NgpdeError as e:
+            # the tapes of a solve -- every layer's input rows and dz rows of every right-hand-side evaluation, 64 floats wide -- did not
+            # fit the device (the library parks and re-uses the tapes of plans that went away, and frees them before it gives up): the
+            # generic solver, which keeps O(stages) arrays, takes the solve
+            if e.code != _lib.ERR_HIP:
+                raise
+            if not pool:
+                self._plans.pop(key, None)
+            return None
         pool.append(plan)
         return plan, wb, index
 
