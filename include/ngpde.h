@@ -495,6 +495,11 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
                               int32_t tableau, int32_t n_steps, double dt, int32_t with_backward, ngpde_node_vmh_t **out);
 int32_t ngpde_node_vmh_destroy(ngpde_node_vmh_t *plan);
 size_t ngpde_node_vmh_tape_bytes(const ngpde_node_vmh_t *plan);
+/* The tapes of destroyed VMH plans are parked for the next plan they fit (a training loop that re-batches its point clouds every epoch,
+ * VMH.md:120-141, builds a plan per step; blocks of tens of GB cost seconds to allocate and free).  Gives them back to the device;
+ * returns the bytes released.  The library does it by itself before it reports that a plan's tapes do not fit.  [no reference
+ * counterpart: CUDA.reclaim() is the caller-side analogue] */
+size_t ngpde_release_cached_memory(void);
 int32_t ngpde_node_vmh_fault(ngpde_node_vmh_t *plan, ngpde_stream_t stream, int32_t *fault);
 int32_t ngpde_node_vmh_forward(ngpde_node_vmh_t *plan, const float *u0, const float *const *phi_weight, const float *const *phi_bias,
                                const float *const *gamma_weight, const float *const *gamma_bias, float *uT, ngpde_stream_t stream);

@@ -14,6 +14,13 @@ from .node import NeuralODE
 from .layers_mp import ExplicitEdgeConv, GATConv, GNOConv, MPPDEConv, SpectralConv, VMHConv
 from . import dist, optim, synth
 
+
+def release_cached_memory():
+    """device memory the library keeps parked for re-use (the tapes of destroyed NeuralODE(VMHConv) plans) back to the device; bytes released
+    (the analogue of CUDA.reclaim() / torch.cuda.empty_cache() for the library's own allocations)"""
+    _lib.flush_destroy()
+    return int(_lib.load().ngpde_release_cached_memory())
+
 __all__ = [
     "AbstractExplicitLayer", "AbstractGNNLayer", "AbstractGNNContainerLayer", "GCNConv", "Dense", "Chain", "NeuralODE",
     "ExplicitEdgeConv", "VMHConv", "MPPDEConv", "GNOConv", "SpectralConv", "GATConv",

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ngpde_node_vmh_create": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, C.c_double, _i32, C.POINTER(_vp)]),
     "ngpde_node_vmh_destroy": (_i32, [_vp]),
     "ngpde_node_vmh_tape_bytes": (_sz, [_vp]),
+    "ngpde_release_cached_memory": (_sz, []),
     "ngpde_node_vmh_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ngpde_node_vmh_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_node_vmh_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1213,6 +1213,16 @@ int32_t ngpde_node_vmh_destroy(ngpde_node_vmh_t *p) {
 
 size_t ngpde_node_vmh_tape_bytes(const ngpde_node_vmh_t *p) { return p ? p->tape_bytes : 0; }
 
+size_t ngpde_release_cached_memory(void) {
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_tape_mu);
+    for (const auto &b : g_tape_pool) bytes += b.floats * 4;
+  }
+  (void)tape_pool_release_all();
+  return bytes;
+}
+
 int32_t ngpde_node_vmh_fault(ngpde_node_vmh_t *p, ngpde_stream_t stream_, int32_t *fault) {
   NGPDE_RANGE();
   NGPDE_REQUIRE(p != nullptr && fault != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_vmh_fault: NULL argument");

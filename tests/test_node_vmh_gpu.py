@@ -316,6 +316,34 @@ def test_vmh_batch_of_clouds_that_share_tiles_runs_padded(monkeypatch):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
 
 
+def test_vmh_tapes_of_a_destroyed_plan_are_parked_and_can_be_released(monkeypatch):
+    # a training loop that re-batches every epoch builds a plan per step (VMH.md:120-141): the tapes of a plan that went away are re-used
+    # by the next one instead of going through hipFree / hipMalloc; ng.release_cached_memory() gives them back
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    import gc
+    ng.release_cached_memory()
+    nv = 3000
+    phi, gam = tutorial_mlps()
+    outs = []
+    for rep in range(2):      # two graphs of one size: the second plan takes the first one's tapes
+        pts = torch.as_tensor(S.uniform01(70 + rep, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+        g = ng.GNNGraph(ng.knn_graph(pts, 6), ndata={"x": pts})
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", n_steps=4, dt=0.05)
+        ps0, st = ng.setup(4, node)
+        ps = prep(ps0, 4)
+        u = torch.as_tensor(S.normal(71, nv).reshape(1, nv).astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        uT.sum().backward()
+        assert "vmh" in plan_flags(node) and torch.isfinite(u.grad).all()
+        outs.append(uT.detach().clone())
+        del node, uT
+        gc.collect()
+        torch.cuda.synchronize()
+    released = ng.release_cached_memory()
+    assert released >= 2 * 256 * 24 * (4 * 18000 + 4 * 3000)      # at least one plan's four tapes (24 evaluations) were parked
+    assert ng.release_cached_memory() == 0
+
+
 def test_vmh_resident_plan_reports_an_abort_instead_of_hanging(monkeypatch):
     # a launch whose waits give up (forced: NGPDE_DEBUG_FORCE_ABORT=1 starts it with the abort word set) writes NaN outputs and
     # latches the plan's fault word; the next entry of the plan fails instead of computing on garbage; a fresh plan works
