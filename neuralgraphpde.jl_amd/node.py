@@ -844,6 +844,10 @@ class NeuralODE(AbstractExplicitLayer):
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
+        # plans of this right-hand side on OTHER graphs are of no use any more (updategraph per minibatch, VMH.md:132-134): their tapes --
+        # tens of GB at the tutorial's batch size -- go back to the library's pool before the new plan asks for its own
+        for old_key in [k for k in self._plans if k[0] == "vmh" and k[1] != id(handle)]:
+            self._plans.pop(old_key)
         try:
             plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
         except _lib.NgpdeError as e:
