@@ -810,15 +810,18 @@ class NeuralODE(AbstractExplicitLayer):
         aggr = _lib.AGGR.get(m.aggr)
         if aggr is None:
             return None
-        handle = g.handle()
         lib = _lib.load()
         ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
         supported = lambda h: lib.ngpde_node_vmh_supported(h.ptr, 1, pd, len(acts[0]), ia(dims[0]), ia(acts[0]), len(acts[1]), ia(dims[1]),
                                                             ia(acts[1]), aggr)
-        key = ("vmh", id(handle), tuple(dims[0]), tuple(acts[0]), tuple(dims[1]), tuple(acts[1]), aggr, bool(needs_grad))
-        pool = self._plans.get(key)
-        index = None
-        if pool is None and (getattr(g, "_vmh_pad", None) is not None or not supported(handle)):
+        members = getattr(g, "_members", None)
+        straddles = bool(members) and len(members) > 1 and any(mg.num_nodes % 32 for mg in members)
+        index, pool, key, handle = None, None, None, None
+        if not straddles:      # (a batch whose clouds share tiles goes to its padded form at once: no handle of the unpadded union is built)
+            handle = g.handle()
+            key = ("vmh", id(handle), tuple(dims[0]), tuple(acts[0]), tuple(dims[1]), tuple(acts[1]), aggr, bool(needs_grad))
+            pool = self._plans.get(key)
+        if pool is None and (straddles or not supported(handle)):
             # a batch of point clouds whose sizes are not multiples of the 32-row tile (VMH.md:120-134: 24 clouds of 3 000 points): a tile
             # that holds the end of one cloud and the start of the next stages two neighbourhoods and can overflow its halo, which takes
             # the persistent forms away from the whole handle.  The same batch with every cloud padded to whole tiles by isolated nodes
