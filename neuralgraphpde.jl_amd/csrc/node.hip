@@ -1049,15 +1049,22 @@ constexpr size_t kTapePoolMax = 8;
 struct TapeBlock {
   float *ptr;
   size_t floats;
+  int device;
 };
+int tape_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
 std::mutex g_tape_mu;
 std::vector<TapeBlock> g_tape_pool;
 
 float *tape_pool_take(size_t floats) {   // the smallest parked block that fits without wasting more than half of itself
+  const int dev = tape_device();
   std::lock_guard<std::mutex> lock(g_tape_mu);
   int best = -1;
   for (int i = 0; i < (int)g_tape_pool.size(); ++i)
-    if (g_tape_pool[i].floats >= floats && g_tape_pool[i].floats <= 2 * floats + 1024 &&
+    if (g_tape_pool[i].device == dev && g_tape_pool[i].floats >= floats && g_tape_pool[i].floats <= 2 * floats + 1024 &&
         (best < 0 || g_tape_pool[i].floats < g_tape_pool[best].floats))
       best = i;
   if (best < 0) return nullptr;
@@ -1079,7 +1086,7 @@ void tape_pool_give(float *ptr, size_t floats) {
     (void)hipFree(ptr);
     return;
   }
-  g_tape_pool.push_back({ptr, floats});
+  g_tape_pool.push_back({ptr, floats, tape_device()});
 }
 }  // namespace
 
