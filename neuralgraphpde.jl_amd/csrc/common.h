@@ -317,6 +317,7 @@ struct VmhLaunch {
   // saveat (docs/src/tutorials/VMH.md:85): the state after every save_every steps goes to save[j][N], j = step / save_every - 1 + save_off
   // (save_off = 1: slot 0 holds u0); the adjoint adds dsave[j] to lambda at that time
   float *state = nullptr;        // tile rounds: [16][N] per-node state between a half tile's turns (forward 6 rows, adjoint 8)
+  const int *srcpos = nullptr, *srcdeg = nullptr;   // launch_vmh_srcpos
   float *save = nullptr;
   const float *dsave = nullptr;
   int save_every = 0, save_off = 0;
@@ -325,6 +326,9 @@ bool node_vmh_supported(const ngpde_graph *g, const VmhShape &s);
 int32_t launch_node_vmh_fwd(const VmhLaunch &a, hipStream_t stream);
 int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream);
 int32_t launch_vmh_copy_block(const float *src, int sp, float *dst, int dp, int rows, int cols, hipStream_t stream);
+// srcpos[r][kSlotWidth] / srcdeg[r] for every row r of the by-target schedule: the positions (in the by-target edge order) of the out-edges
+// of the row's node -- the by-source gather's addresses, laid out by schedule row so that a tile reads them with one coalesced load
+int32_t launch_vmh_srcpos(const ngpde_graph *g, int *srcpos, int *srcdeg, hipStream_t stream);
 bool gat_fused_supported(const ngpde_graph *g, int heads, int c);
 int32_t launch_gat_fused_fwd(const ngpde_graph *g, int heads, int c, float slope, const float *wx, const float *al, const float *ar,
                              float *out, float *alpha, hipStream_t stream);

@@ -1032,6 +1032,7 @@ struct ngpde_node_vmh {
   NodePersist persist;
   float *pos = nullptr, *cf = nullptr, *cb = nullptr, *x = nullptr;         // x: [2][N] exchanged stage input
   float *state = nullptr;                                                     // [16][N] tile rounds: per-node state between turns
+  int *srcpos = nullptr, *srcdeg = nullptr;                                   // schedule-ordered by-source positions (launch_vmh_srcpos)
   float *tape_phi = nullptr, *tape_gam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;
   float *partial = nullptr, *dwpad = nullptr;                                // weight-pullback workspace; [64 x 64 + 64] padded result
   size_t tape_bytes = 0, partial_floats = 0;
@@ -1092,7 +1093,7 @@ void tape_pool_give(float *ptr, size_t floats) {
 
 static void node_vmh_free(ngpde_node_vmh *p) {
   if (!p) return;
-  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->dsrc, p->partial, p->dwpad};
+  void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->dsrc, p->partial, p->dwpad, p->srcpos, p->srcdeg};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   tape_pool_give(p->tape_phi, p->tape_floats[0]);
@@ -1169,6 +1170,14 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
   if (st == NGPDE_OK) step(alloc(&p->x, 2 * N, true));
   if (st == NGPDE_OK) step(alloc(&p->state, 16 * N, true));
   if (st == NGPDE_OK && p->with_bwd) {
+    float *sp = nullptr, *sd = nullptr;
+    step(alloc(&sp, (size_t)g->n_sched * kSlotWidth, false));
+    if (st == NGPDE_OK) step(alloc(&sd, (size_t)g->n_sched, false));
+    p->srcpos = reinterpret_cast<int *>(sp); p->srcdeg = reinterpret_cast<int *>(sd);
+    if (st == NGPDE_OK) step(launch_vmh_srcpos(g, p->srcpos, p->srcdeg, nullptr));
+    if (st == NGPDE_OK && hipStreamSynchronize(nullptr) != hipSuccess) st = fail(NGPDE_ERR_HIP, "ngpde_node_vmh_create: building the by-source positions failed");
+  }
+  if (st == NGPDE_OK && p->with_bwd) {
     // (zeroed once: the padded columns of a layer's rows are never written, and the weight-pullback GEMMs read whole 64-wide rows)
     const size_t tp = (size_t)n_phi * evals * E * 64, tg = (size_t)n_gamma * evals * N * 64;
     auto tape = [&](float **ptr, size_t floats) -> int32_t {   // a parked block that fits, else a fresh zeroed one
@@ -1243,7 +1252,7 @@ static void vmh_fill(const ngpde_node_vmh *p, VmhLaunch &a, const float *const *
   a.g = p->g; a.ps = &p->persist; a.shape = p->shape; a.n_steps = p->n_steps; a.S = p->S; a.pos = p->pos;
   for (int l = 0; l < p->shape.n_phi; ++l) { a.phi_w[l] = phi_w[l]; a.phi_b[l] = phi_b ? phi_b[l] : nullptr; }
   for (int l = 0; l < p->shape.n_gam; ++l) { a.gam_w[l] = gam_w[l]; a.gam_b[l] = gam_b ? gam_b[l] : nullptr; }
-  a.x0 = p->x; a.x1 = p->x + p->g->n_nodes; a.state = p->state; a.tape_phi = p->tape_phi; a.tape_gam = p->tape_gam; a.dz_phi = p->dz_phi; a.dz_gam = p->dz_gam;
+  a.x0 = p->x; a.x1 = p->x + p->g->n_nodes; a.state = p->state; a.srcpos = p->srcpos; a.srcdeg = p->srcdeg; a.tape_phi = p->tape_phi; a.tape_gam = p->tape_gam; a.dz_phi = p->dz_phi; a.dz_gam = p->dz_gam;
   a.dsrc = p->dsrc; a.cf = p->cf; a.cb = p->cb;
 }
 

@@ -83,6 +83,7 @@ struct VmhMeta {
   int gam_din[kVmhMaxL], gam_dout[kVmhMaxL], gam_act[kVmhMaxL];
   const float *phi_w[kVmhMaxL], *phi_b[kVmhMaxL], *gam_w[kVmhMaxL], *gam_b[kVmhMaxL];
   size_t n_edges;
+  const int *srcpos, *srcdeg;        // by schedule row: positions of the node's out-edges in the by-target order, their count (launch_vmh_srcpos)
   int evals;                         // right-hand-side evaluations of a solve: the tapes are [layer][evals][rows][64] (a layer's rows contiguous)
   int s_rows;                        // rows of the staging tile: 64, 96 or 128 (what the LDS left by the weights allows)
   NGPDE_VST_FIELD
@@ -642,11 +643,10 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   for (int l = 0; l < m.n_gam; ++l) stage_weight(m.gam_w[l], m.gam_din[l], m.gam_dout[l], t.W + (size_t)(m.n_phi + l) * VW * VW, c.tid, false);
   if (c.tid < p.S * 8 && c.tid < 64) t.misc[c.tid] = p.cb[c.tid];
   auto fill_srcpos = [&]() {   // positions, in the by-target order, of the out-edges of the own nodes: the by-source gather's addresses
-    if (c.g16 < VRT) {
-      const int nd = t.rnode[c.g16];
-      const int rp = nd >= 0 ? m.rowptr_s[nd] : 0, dg = nd >= 0 ? m.rowptr_s[nd + 1] - rp : 0;
-      if (c.q == 0) s_srcdeg[c.g16] = min(dg, kSlotWidth);
-      for (int j = c.q; j < kSlotWidth; j += 16) s_srcpos[c.g16 * kSlotWidth + j] = j < dg ? m.xpos_s[rp + j] : 0;
+    if (c.g16 < VRT) {         // (one coalesced read of the plan's schedule-ordered copy: no node -> row pointer -> position chain per turn)
+      const size_t row = (size_t)c.tile * kTileRows + c.half * VR + c.g16;
+      if (c.q == 0) s_srcdeg[c.g16] = m.srcdeg[row];
+      for (int j = c.q; j < kSlotWidth; j += 16) s_srcpos[c.g16 * kSlotWidth + j] = m.srcpos[row * kSlotWidth + j];
     }
   };
   fill_srcpos();
@@ -773,6 +773,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
       if constexpr (ROUNDS) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
+        NGPDE_VST(m, ph, 7);
         vctx_init<VRT>(m, c, t, h);
         fill_srcpos();
         n_rounds = (c.total + VROUND - 1) / VROUND;
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
 #pragma unroll
           for (int l = 0; l < kVmhMaxL - 1; ++l) fetch_y(l, ev, 0);   // (the first round's; a later round's rows are asked for a round ahead)
         }
+        NGPDE_VST(m, ph, 5);
         if (ph > 1) {
           if (my_node >= 0) s_row[VRT + c.tid] = p.state[(size_t)7 * N + my_node];
           __syncthreads();
@@ -1100,6 +1102,7 @@ static void fill_meta(VmhMeta &m, const VmhLaunch &a) {
     m.gam_w[l] = l < m.n_gam ? a.gam_w[l] : nullptr; m.gam_b[l] = l < m.n_gam ? a.gam_b[l] : nullptr;
   }
   m.n_edges = (size_t)g->n_edges;
+  m.srcpos = a.srcpos; m.srcdeg = a.srcdeg;
   m.evals = a.n_steps * a.S;
 #ifdef NGPDE_STAMPS
   m.stamps = g_vst_base; m.stamps_max = g_vst_max;
@@ -1165,6 +1168,24 @@ int32_t launch_node_vmh_bwd(const VmhLaunch &a, hipStream_t stream) {
   hipLaunchKernelGGL(vmh_latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
   return turn.leave();
+}
+
+__global__ void vmh_srcpos_kernel(const int4 *__restrict__ sched_t, int n_sched, const int *__restrict__ rowptr_s, const int *__restrict__ xpos_s,
+                                  int *__restrict__ srcpos, int *__restrict__ srcdeg) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, r = idx / kSlotWidth, j = idx % kSlotWidth;
+  if (r >= n_sched) return;
+  const int nd = sched_t[r].x;
+  const int rp = nd >= 0 ? rowptr_s[nd] : 0, dg = nd >= 0 ? min(rowptr_s[nd + 1] - rp, kSlotWidth) : 0;
+  srcpos[idx] = j < dg ? xpos_s[rp + j] : 0;
+  if (j == 0) srcdeg[r] = dg;
+}
+
+int32_t launch_vmh_srcpos(const ngpde_graph *g, int *srcpos, int *srcdeg, hipStream_t stream) {
+  const int n = g->n_sched;
+  if (n == 0) return NGPDE_OK;
+  hipLaunchKernelGGL(vmh_srcpos_kernel, dim3((n * kSlotWidth + 255) / 256), dim3(256), 0, stream, g->by_t.sched, n, g->by_s.rowptr, g->by_s.xpos, srcpos, srcdeg);
+  NGPDE_LAUNCH_CHECK("vmh_srcpos_kernel");
+  return NGPDE_OK;
 }
 
 int32_t launch_vmh_copy_block(const float *src, int sp, float *dst, int dp, int rows, int cols, hipStream_t stream) {

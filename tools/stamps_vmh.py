@@ -68,3 +68,14 @@ report("forward", fw, ["wait for the neighbours' flags", "halo values + barrier"
                        "node MLP (4 layers, a barrier each)", "stage update + drain + flag", "tape rows issued, loop overhead"])
 report("adjoint", bw, ["K-bar + node MLP backwards", "message MLP backwards of the wave's 16 edges", "barrier (the slowest wave)", "own-row sums + drain + flag",
                        "dz rows issued", "wait for the neighbours' flags", "by-source gather + stage adjoint"])
+
+if int(os.environ.get("N", 3000)) > 4096:      # tile rounds: a turn of the adjoint = tables, second half of the phase before, first half of this one
+    used = bw[:, 0, 0] > 0
+    b = bw[used][:, 8:PH - 1, :]
+    seq = [7, 5, 6, 0, 1, 2, 3, 4]
+    names = ["tables, by-source positions, state, tape rows asked for", "wait for the phase before (published a sweep ago)", "by-source gather + stage adjoint",
+             "K-bar + node MLP backwards", "message MLP backwards (both rounds)", "barrier", "own-row sums + drain + flag"]
+    print("adjoint, last turn of a sweep (tile rounds):")
+    for k, nm in enumerate(names):
+        dd = b[:, :, seq[k + 1]] - b[:, :, seq[k]]
+        print(f"   {nm}: mean {dd.mean():.0f}  p10 {np.percentile(dd, 10):.0f}  p90 {np.percentile(dd, 90):.0f}")
