@@ -246,6 +246,91 @@ __device__ __forceinline__ void vctx_init(const VmhMeta &m, VCtx &c, const VTabs
   __syncthreads();
 }
 
+// TILE ROUNDS: what a unit's tables are built from, asked for a turn ahead (registers; the loads travel under the turn before):
+// part A needs only the unit's index, part B (positions of the halo nodes, the rows' state) needs what A brought.
+struct VPre {
+  int4 sc;            // schedule row of lane group g16
+  int hcount, hnode;  // rows staged; halo node of thread tid < kHaloCap
+  unsigned slots2;    // slot bytes q and q + 16 of row g16
+  int sp0, sp1, sdeg; // (adjoint) by-source positions q, q + 16 and their count of row g16
+  int rnode;          // node of row tid (tid < VRT)
+  float px[3];
+  float st[8];        // the rows' state (forward: u, k_0 .. k_4; adjoint: lambda, U-bar_0 .. 5, own sum)
+};
+template <int VRT>
+__device__ __forceinline__ void vctx_fetch_a(const VmhMeta &m, int h, VPre &pre, bool adjoint) {
+  const int tid = threadIdx.x, g16 = tid >> 4, q = tid & 15;
+  const int line = VRT == 32 ? 2 * h : h, tile = line >> 1, half = line & 1;
+  const size_t row = (size_t)tile * kTileRows + half * VR + min(g16, VRT - 1);
+  pre.sc = m.sched_t[row];
+  pre.hcount = m.info_t[tile].x;
+  pre.hnode = tid < kHaloCap ? m.halo_t[(size_t)tile * kHaloCap + tid].x : 0;
+  const uint8_t *sl = m.slots_t + row * kSlotWidth;
+  pre.slots2 = (unsigned)sl[q] | ((unsigned)sl[q + 16] << 8);
+  pre.rnode = tid < VRT ? m.sched_t[(size_t)tile * kTileRows + half * VR + tid].x : -1;
+  pre.sp0 = pre.sp1 = pre.sdeg = 0;
+  if (adjoint) {
+    pre.sp0 = m.srcpos[row * kSlotWidth + q];
+    pre.sp1 = m.srcpos[row * kSlotWidth + q + 16];
+    pre.sdeg = m.srcdeg[row];
+  }
+}
+__device__ __forceinline__ void vctx_fetch_px(const VmhMeta &m, VPre &pre) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pre.px[k] = (tid < pre.hcount && tid < kHaloCap && k < m.pd) ? m.pos[(size_t)pre.hnode * m.pd + k] : 0.f;
+}
+// the tables of unit h from what vctx_fetch_a / _px brought: vctx_init without its loads
+template <int VRT>
+__device__ __forceinline__ void vctx_commit(const VmhMeta &m, VCtx &c, const VTabs &t, int h, const VPre &pre) {
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.g16 = c.tid >> 4;
+  c.q = c.tid & 15;
+  c.ei = c.lane & 15;
+  c.kq = c.lane >> 4;
+  c.wg = VRT == 32 ? 2 * h : h;
+  c.tile = c.wg >> 1;
+  c.half = c.wg & 1;
+  const int4 sc = pre.sc;
+  c.row_valid = sc.x >= 0 && c.g16 < VRT;
+  c.node = max(sc.x, 0);
+  c.hcount = __builtin_amdgcn_readfirstlane(pre.hcount);
+  const int d = sc.x >= 0 ? sc.z : 0;
+  if (c.q == 0 && c.g16 < VRT) {
+    t.off[c.g16 + 1] = d;
+    t.rs[c.g16] = sc.y;
+    t.rnode[c.g16] = sc.x;
+    t.inv[c.g16] = m.aggr == NGPDE_AGGR_MEAN ? (d > 0 ? 1.0f / (float)d : 0.f) : 1.0f;
+    if (c.g16 == 0) t.off[0] = 0;
+  }
+  if (c.tid < kHaloCap) {
+    t.hnode[c.tid] = pre.hnode;
+    for (int k = 0; k < 4; ++k) t.px[c.tid * 4 + k] = k < 3 ? pre.px[k] : 0.f;
+    t.hh[c.tid] = 0.f;
+  }
+  if (c.tid == 0) *t.s_ok = 1;
+  __syncthreads();
+  if (c.tid < VRT) {
+    int v = t.off[c.tid + 1];
+#pragma unroll
+    for (int o = 1; o < VRT; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (c.tid >= o) v += u;
+    }
+    t.off[c.tid + 1] = v;
+  }
+  __syncthreads();
+  c.total = t.off[VRT];
+  if (c.g16 < VRT) {   // edge table: k -> (row, halo slot of the source); a row has at most kSlotWidth = 32 entries, two per lane
+    const int lo = t.off[c.g16];
+    if (c.q < d) t.edge[lo + c.q] = (unsigned short)(c.g16 | ((pre.slots2 & 0xffu) << 8));
+    if (c.q + 16 < d) t.edge[lo + c.q + 16] = (unsigned short)(c.g16 | ((pre.slots2 >> 8) << 8));
+  }
+  __syncthreads();
+}
+
 // wave 0 polls: lane l < 63 watches both halves of tile nbr[l], lane 0 also this tile's other half, lane 63 the abort word
 __device__ __forceinline__ bool vmh_wait(const VmhMeta &m, const VCtx &c, int need, int *s_ok) {
   if (need <= 0) return true;
@@ -352,6 +437,8 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
   int my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
   if (my_node >= 0) su = p.u_in[my_node];
   const int last_ph = p.n_steps * p.S;
+  VPre pre;          // (tile rounds) the next turn's tables and state, on their way
+  int pre_h = -1, pre_ph = 0;
   // With ONE round (the usual case) the tape rows of a slice stay in registers and leave one evaluation LATE: layer l's rows of the
   // previous evaluation are stored right before this evaluation's overwrite them -- four stores per lane in front of every layer's 64
   // MFMAs instead of ~100 KB per workgroup in one burst, and the drain in front of the flag waits for the 16 state values alone
@@ -375,17 +462,29 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
       float *Xn = (ph & 1) ? p.x1 : p.x0;
       const size_t ev = (size_t)(n * p.S + i);
       for (int s = 0; s < K; ++s) {
-      if constexpr (ROUNDS) {   // this turn's half tile: tables, rows' state
+      if constexpr (ROUNDS) {   // this turn's tile: tables, rows' state -- from what the turn before asked for, when there was one
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
-        vctx_init<VRT>(m, c, t, h);
-        n_rounds = (c.total + VROUND - 1) / VROUND;
-        my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
-        if (my_node >= 0) {
-          su = ph == 1 ? p.u_in[my_node] : p.state[my_node];
-          sk0 = ph == 1 ? 0.f : p.state[N + my_node]; sk1 = ph == 1 ? 0.f : p.state[2 * N + my_node]; sk2 = ph == 1 ? 0.f : p.state[3 * N + my_node];
-          sk3 = ph == 1 ? 0.f : p.state[4 * N + my_node]; sk4 = ph == 1 ? 0.f : p.state[5 * N + my_node];
+        if (pre_h == h) {
+          vctx_commit<VRT>(m, c, t, h, pre);
+          my_node = c.tid < VRT ? pre.rnode : -1;
+          su = pre.st[0]; sk0 = pre.st[1]; sk1 = pre.st[2]; sk2 = pre.st[3]; sk3 = pre.st[4]; sk4 = pre.st[5];
+        } else {
+          vctx_init<VRT>(m, c, t, h);
+          my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
+          if (my_node >= 0) {
+            su = ph == 1 ? p.u_in[my_node] : p.state[my_node];
+            sk0 = ph == 1 ? 0.f : p.state[N + my_node]; sk1 = ph == 1 ? 0.f : p.state[2 * N + my_node]; sk2 = ph == 1 ? 0.f : p.state[3 * N + my_node];
+            sk3 = ph == 1 ? 0.f : p.state[4 * N + my_node]; sk4 = ph == 1 ? 0.f : p.state[5 * N + my_node];
+          }
         }
+        n_rounds = (c.total + VROUND - 1) / VROUND;
+        // the next turn's unit (this sweep's next tile, or the first one of the next sweep): part A of its tables is asked for now
+        int hn = h + G;
+        pre_ph = ph;
+        if (hn >= nh) { hn = blockIdx.x; pre_ph = ph + 1; }
+        pre_h = (hn != h && pre_ph <= last_ph) ? hn : -1;      // (a workgroup's only tile keeps its state in registers: nothing to fetch)
+        if (pre_h >= 0) vctx_fetch_a<VRT>(m, pre_h, pre, false);
       }
       NGPDE_VST(m, ph, 0);
       if (!vmh_wait(m, c, ph - 1, t.s_ok)) { ok = false; break; }
@@ -480,6 +579,21 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
         }
       }
       NGPDE_VST(m, ph, 4);
+      if constexpr (ROUNDS) {   // part B of the next turn's prefetch: the halo nodes' positions and the rows' state (part A has landed by now)
+        if (pre_h >= 0) {
+          vctx_fetch_px(m, pre);
+          const int nd = c.tid < VRT ? pre.rnode : -1;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) pre.st[j] = 0.f;
+          if (nd >= 0) {
+            pre.st[0] = pre_ph == 1 ? p.u_in[nd] : p.state[nd];
+            if (pre_ph > 1) {
+#pragma unroll
+              for (int j = 1; j < 6; ++j) pre.st[j] = p.state[(size_t)j * N + nd];
+            }
+          }
+        }
+      }
       // ---- node MLP on the 16 rows: input [h_i; m_i; 0 ...] in tile A (rows 0..15 of the staging area), layers ping-pong A <-> B
       float *tA = t.S, *tB = t.S + (size_t)VRT * VTS;
       if (has_row) {
@@ -750,6 +864,22 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
   // published that phase during the sweep before -- followed at once by the first half of phase ph: one rebuild of its tables and one
   // round trip of its rows' state per phase
   const int n_sweeps = last_ph + (ROUNDS ? 1 : 0);
+  VPre pre;          // (tile rounds) the next turn's tables, by-source positions and state, on their way
+  int pre_h = -1, pre_ph = 0;
+  auto fetch_b = [&]() {   // part B of the next turn's prefetch: the halo nodes' positions, the rows' state
+    if (pre_h < 0) return;
+    vctx_fetch_px(m, pre);
+    const int nd = c.tid < VRT ? pre.rnode : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pre.st[j] = 0.f;
+    if (nd >= 0) {
+      pre.st[0] = pre_ph == 1 ? p.lam[nd] : p.state[nd];
+      if (pre_ph > 1) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) pre.st[j] = p.state[(size_t)j * N + nd];
+      }
+    }
+  };
   float4 yall[kVmhMaxL - 1][4];   // (tile rounds) the outputs of phi's hidden layers of the lane's edge in the coming round
   auto fetch_y = [&](int l, size_t ev, int rd) {   // yall[l] <- the output of phi's layer l (the input tape of layer l + 1) for round rd
     const int k = rd * VROUND + c.wave * 16 + ei;
@@ -774,11 +904,34 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         const int h = blockIdx.x + s * G;
         if (h >= nh) break;
         NGPDE_VST(m, ph, 7);
-        vctx_init<VRT>(m, c, t, h);
-        fill_srcpos();
+        float own_sum = 0.f;
+        if (pre_h == h) {      // tables, by-source positions and the rows' state from what the turn before asked for
+          vctx_commit<VRT>(m, c, t, h, pre);
+          if (c.g16 < VRT) {
+            if (c.q == 0) s_srcdeg[c.g16] = pre.sdeg;
+            s_srcpos[c.g16 * kSlotWidth + c.q] = pre.sp0;
+            s_srcpos[c.g16 * kSlotWidth + c.q + 16] = pre.sp1;
+          }
+          my_node = c.tid < VRT ? pre.rnode : -1;
+          lam = pre.st[0];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) ub[j] = pre.st[1 + j];
+          own_sum = pre.st[7];
+        } else {
+          vctx_init<VRT>(m, c, t, h);
+          fill_srcpos();
+          my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
+          load_state(ph);
+          if (ph > 1 && my_node >= 0) own_sum = p.state[(size_t)7 * N + my_node];
+        }
         n_rounds = (c.total + VROUND - 1) / VROUND;
-        my_node = c.tid < VRT ? t.rnode[c.tid] : -1;
-        load_state(ph);
+        {   // the next turn's unit: part A of its tables is asked for now
+          int hn = h + G;
+          pre_ph = ph;
+          if (hn >= nh) { hn = blockIdx.x; pre_ph = ph + 1; }
+          pre_h = (hn != h && pre_ph <= n_sweeps) ? hn : -1;
+          if (pre_h >= 0) vctx_fetch_a<VRT>(m, pre_h, pre, true);
+        }
         if (do1) {   // this phase's tape rows: they land under the second half of the phase before and K-bar / gamma
           fetch_phase(ev);
 #pragma unroll
@@ -786,13 +939,14 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         }
         NGPDE_VST(m, ph, 5);
         if (ph > 1) {
-          if (my_node >= 0) s_row[VRT + c.tid] = p.state[(size_t)7 * N + my_node];
+          if (my_node >= 0) s_row[VRT + c.tid] = own_sum;
           __syncthreads();
           const int idx2 = ph - 2;
           if (!pass2(ph - 1, S - 1 - idx2 % S, ((ph - 1) & 1) ? p.dsrc1 : p.dsrc0)) { ok = false; break; }
           if (!do1) {   // the sweep behind the last phase: the rows' lambda is dL/du0
             if (p.dsave && p.save_off && my_node >= 0) lam += p.dsave[my_node];
             if (my_node >= 0) p.lam[my_node] = lam;
+            fetch_b();
             __syncthreads();
             continue;
           }
@@ -940,6 +1094,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_bwd_kernel(const VmhBwdK p) {
         }
       }
       NGPDE_VST(m, ph, 2);
+      if constexpr (ROUNDS) fetch_b();   // (part A of the next turn's prefetch has landed by now)
       __syncthreads();
       NGPDE_VST(m, ph, 3);
       if (c.tid < VRT) {   // what the own rows get from their own edges and from gamma
