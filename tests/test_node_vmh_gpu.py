@@ -344,6 +344,54 @@ def test_vmh_tapes_of_a_destroyed_plan_are_parked_and_can_be_released(monkeypatc
     assert ng.release_cached_memory() == 0
 
 
+def test_vmh_solve_on_parked_tapes_of_another_graph_is_bitwise_the_solve_on_fresh_tapes(monkeypatch):
+    # parked tapes are handed on unzeroed (node.hip: tape_pool_*): what the next plan reads of them must all have been written by its own
+    # solve.  A wide, dense first model (k = 8: every edge row of a round is real; 60-wide layers) leaves its rows behind; the second
+    # one -- variable degrees, 20 / 12-wide layers, fewer nodes -- runs on them, then again on freshly zeroed tapes: every output equal
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    import gc
+
+    def first():
+        nv = 3000
+        pts = torch.as_tensor(S.uniform01(80, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+        g = ng.GNNGraph(ng.knn_graph(pts, 8), ndata={"x": pts})
+        phi, gam = tutorial_mlps()
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, aggr="+", initialgraph=g), solver="tsit5", n_steps=2, dt=0.05)
+        ps0, st = ng.setup(5, node)
+        ps = prep(ps0, 5)
+        u = torch.as_tensor(S.normal(81, nv).reshape(1, nv).astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * uT).sum().backward()
+        assert "vmh" in plan_flags(node)
+
+    def second():
+        nv = 2800
+        g, _ = spatial(nv, 82)
+        phi, gam = tutorial_mlps(width=20, msg=12, depth=3)
+        node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="tsit5", n_steps=2, dt=0.05)
+        ps0, st = ng.setup(6, node)
+        ps = prep(ps0, 6)
+        u = torch.as_tensor(S.normal(83, nv).reshape(1, nv).astype(np.float32), device=DEV).requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        (uT * uT).sum().backward()
+        assert "vmh" in plan_flags(node)
+        n1, _ = mlp_grad_pairs(ps["ϕ"], [{"weight": 0, "bias": 0}] * 3, phi)
+        n2, _ = mlp_grad_pairs(ps["γ"], [{"weight": 0, "bias": 0}] * 3, gam)
+        return [uT.detach().clone(), u.grad.clone()] + [p_.grad.clone() for _, p_ in n1 + n2]
+
+    ng.release_cached_memory()
+    first()
+    gc.collect()
+    torch.cuda.synchronize()
+    on_parked = second()
+    gc.collect()
+    torch.cuda.synchronize()
+    assert ng.release_cached_memory() > 0
+    on_fresh = second()
+    for a, b in zip(on_parked, on_fresh):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_vmh_resident_plan_reports_an_abort_instead_of_hanging(monkeypatch):
     # a launch whose waits give up (forced: NGPDE_DEBUG_FORCE_ABORT=1 starts it with the abort word set) writes NaN outputs and
     # latches the plan's fault word; the next entry of the plan fails instead of computing on garbage; a fresh plan works
