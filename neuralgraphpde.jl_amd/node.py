@@ -13,6 +13,7 @@ launch (_NodeGenericFn): no torch element-wise kernel on the path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -306,6 +307,41 @@ def _padded_batch(g, device):
         gp._shared["order"] = np.concatenate(parts).astype(np.int32)
     g._vmh_pad = (gp, idx_t)
     return g._vmh_pad
+
+
+_CANON_BATCHES = {}      # sorted member ids -> (the first batch seen of these members, its members): at most _CANON_MAX entries
+_CANON_MAX = 2
+
+
+def _canonical_batch(g, device):
+    """A DataLoader(shuffle = true) hands the training loop the SAME point clouds in a new order every epoch (VMH.md:120-134): a new
+    block-diagonal graph whose members are the members of an earlier batch, permuted.  The trajectories of a batch's members are
+    independent, so such a batch is solved on the earlier batch's graph -- its handle, plan and tapes -- with the state's rows sent
+    through the permutation.  Returns (earlier batch, int64 map: node of `g` -> node of the earlier batch) or None (`g` is no batch
+    of single graphs, or the first of its kind: it is remembered).  Members are compared by identity; the entry keeps them alive."""
+    members = getattr(g, "_members", None)
+    if not members or len(members) < 2 or list(g.ndata) != ["x"] or os.environ.get("NGPDE_NO_BATCH_REUSE") == "1":
+        return None
+    key = tuple(sorted(id(mg) for mg in members))
+    hit = _CANON_BATCHES.get(key)
+    if hit is None:
+        _CANON_BATCHES[key] = (g, list(members))
+        while len(_CANON_BATCHES) > _CANON_MAX:
+            _CANON_BATCHES.pop(next(iter(_CANON_BATCHES)))
+        return None
+    g0, members0 = hit
+    _CANON_BATCHES[key] = _CANON_BATCHES.pop(key)
+    if g0 is g:
+        return None
+    cached = getattr(g, "_vmh_canon", None)
+    if cached is not None and cached[0] is g0:
+        return cached if cached[1].device == torch.device(device) else (g0, cached[1].to(device))
+    off0, slots = np.concatenate([[0], np.cumsum([mg.num_nodes for mg in members0])]), {}
+    for j, mg in enumerate(members0):
+        slots.setdefault(id(mg), []).append(j)          # (a cloud that occurs twice: its copies are interchangeable)
+    parts = [np.arange(mg.num_nodes, dtype=np.int64) + off0[slots[id(mg)].pop()] for mg in members]
+    g._vmh_canon = (g0, torch.as_tensor(np.concatenate(parts), device=device))
+    return g._vmh_canon
 
 
 def _ptrs(ts):
@@ -790,6 +826,10 @@ class NeuralODE(AbstractExplicitLayer):
         g = st["graph"]
         if list(g.ndata) != ["x"]:      # (a batched graph is one block-diagonal graph to this plan: its members' tiles never neighbour)
             return None
+        remap = _canonical_batch(g, u.device)      # the members of an earlier batch in a new order: that batch's graph and plan serve
+        nodemap, g_given = None, g
+        if remap is not None:
+            g, nodemap = remap
         try:
             phi, gam = _dense_stack(m.ϕ, ps["ϕ"], "ϕ"), _dense_stack(m.γ, ps["γ"], "γ")
         except _lib.NgpdeError:
@@ -841,6 +881,11 @@ class NeuralODE(AbstractExplicitLayer):
                 self._plans.pop(next(iter(self._plans)))
         else:
             self._plans[key] = self._plans.pop(key)
+        if nodemap is not None:      # node of the given batch -> node of the earlier batch (-> its row among the padding nodes'), kept on the batch
+            comp = getattr(g_given, "_vmh_comp", None)
+            if comp is None or comp[0] is not index or comp[1] is not nodemap:
+                comp = g_given._vmh_comp = (index, nodemap, nodemap if index is None else index.index_select(0, nodemap))
+            index = comp[2]
         for plan in pool:
             if not (needs_grad and plan.busy()):
                 return plan, wb, index

@@ -316,6 +316,60 @@ def test_vmh_batch_of_clouds_that_share_tiles_runs_padded(monkeypatch):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("sizes", [(700, 650, 900), (640, 960, 640)])
+def test_vmh_reshuffled_batch_runs_on_the_first_batch_s_plan(sizes, monkeypatch):
+    # DataLoader(shuffle = true) (VMH.md:120): the same clouds in a new order every epoch.  The second order is solved on the first
+    # batch's graph and plan, the state's rows going through the permutation: ONE plan afterwards, the reshuffled solve equal bit for
+    # bit to the first one's rows permuted (independent trajectories, the same tiles), and equal within rounding to a plan built for
+    # the reshuffled batch itself (NGPDE_NO_BATCH_REUSE=1).  Sizes with and without padding to whole tiles; a cloud that occurs twice
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    monkeypatch.delenv("NGPDE_NO_BATCH_REUSE", raising=False)
+    from ngpde_amd import node as node_mod
+    node_mod._CANON_BATCHES.clear()
+    clouds = []
+    for kb, nv in enumerate(sizes):
+        pk = torch.as_tensor(S.uniform01(300 + kb, 2 * nv).reshape(2, nv).astype(np.float32), device=DEV)
+        clouds.append(ng.GNNGraph(ng.knn_graph(pk, 6), ndata={"x": pk}))
+    clouds.append(clouds[0])                                    # the first cloud again: four members, two of them one object
+    phi, gam = tutorial_mlps(width=24, msg=12, depth=3)
+    node = ng.NeuralODE(ng.VMHConv(phi, gam), solver="tsit5", n_steps=2, dt=0.05, saveat=0.05)
+    ps0, st = ng.setup(4, node)
+    member_u = [torch.as_tensor(S.normal(310 + k, c.num_nodes).astype(np.float32), device=DEV) for k, c in enumerate(clouds)]
+
+    def solve(order, reuse=True):
+        if reuse:
+            monkeypatch.delenv("NGPDE_NO_BATCH_REUSE", raising=False)
+        else:
+            monkeypatch.setenv("NGPDE_NO_BATCH_REUSE", "1")
+        gb = ng.batch([clouds[k] for k in order])
+        st2 = ng.updategraph(st, gb)
+        ps = prep(ps0, 4)
+        u = torch.cat([member_u[k] for k in order]).reshape(1, -1).clone().requires_grad_(True)
+        out, _ = node(u, ps, st2)
+        (out * out).sum().backward()
+        assert "vmh" in plan_flags(node)
+        offs = np.concatenate([[0], np.cumsum([clouds[k].num_nodes for k in order])])
+        n1, _ = mlp_grad_pairs(ps["ϕ"], [{"weight": 0, "bias": 0}] * 3, phi)
+        n2, _ = mlp_grad_pairs(ps["γ"], [{"weight": 0, "bias": 0}] * 3, gam)
+        per_member = {k: (out[:, offs[j]:offs[j + 1]].detach().clone(), u.grad[:, offs[j]:offs[j + 1]].clone()) for j, k in enumerate(order)}
+        return per_member, [p_.grad.clone() for _, p_ in n1 + n2]
+
+    first, gfirst = solve([0, 1, 2, 3])
+    n_plans = sum(len(pool) for pool in node._plans.values())
+    second, gsecond = solve([2, 3, 1, 0])
+    assert sum(len(pool) for pool in node._plans.values()) == n_plans == 1      # no new plan for the new order
+    for k in range(len(clouds)):
+        assert torch.equal(first[k][0], second[k][0]) and torch.equal(first[k][1], second[k][1])
+    for a, b in zip(gfirst, gsecond):
+        assert torch.equal(a, b)
+    own, gown = solve([2, 3, 1, 0], reuse=False)                               # a plan of the reshuffled batch itself
+    for k in range(len(clouds)):
+        for a, b in zip(second[k], own[k]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+    for a, b in zip(gsecond, gown):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+
+
 def test_vmh_tapes_of_a_destroyed_plan_are_parked_and_can_be_released(monkeypatch):
     # a training loop that re-batches every epoch builds a plan per step (VMH.md:120-141): the tapes of a plan that went away are re-used
     # by the next one instead of going through hipFree / hipMalloc; ng.release_cached_memory() gives them back
