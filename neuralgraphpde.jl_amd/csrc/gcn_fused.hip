@@ -145,6 +145,103 @@ __device__ __forceinline__ void aggregate_rows(const float4 *__restrict__ X4, co
   }
 }
 
+// Long rows of the per-row gather, cooperatively.  A row's entries are walked by the LPR lanes that own the row, U row fetches in
+// flight: a hub of a citation graph (Cora: degree 168 beside a median of 3; BASELINE config 1, graph_node.md:78-83) is 11 dependent
+// rounds at D = 64 and 42 at D = 16 while the rest of the workgroup -- and, its tile being the last to finish, the whole launch --
+// waits.  Here the rows of a tile with more than kCoopDeg entries (at most kCoopRows of them; more: the tile is dense and the plain
+// walk, which serves all rows at once, is the better one) are taken one at a time by kCoopGroups lane groups, each a contiguous run of
+// the row's entries; the partial sums meet in LDS and the group that owns the row adds them in group order (fixed: the result does
+// not depend on timing; it differs from the serial order in the last bits).  The row leaves with degree 0 and start -1, and coop_add
+// puts its sum in after aggregate_rows.  Every thread of the workgroup must call this (barriers); `cnt` is common to the workgroup
+// (one int per half), `list` / `part` / `hold` belong to the caller's half.  Measured on the 2 708-node graph of config 1 (Tsit5 x 10
+// solve + adjoint on the replayed plan, tools/bench_c1_cora.py): 342 -> 240 us per ODE step at D = 16, 282 -> 240 at D = 32, 297 -> 300
+// at D = 64 (seven rounds there; the launches' own floor is ~ 9 us).  Sharing the groups among ALL long rows of a tile in proportion
+// to their degrees, in one pass, was built and is slower (277 / 262 / 309: the serial share-out and two more barriers).
+constexpr int kCoopDeg = 48, kCoopRows = 4, kCoopGroups = 32;
+template <int LPR, int U>
+__device__ __forceinline__ float4 gather_run(const float4 *__restrict__ X4, const int2 *__restrict__ ent, int start, int cnt, int q) {
+  float4 acc = f4_zero();
+  for (int base = 0; base < cnt; base += LPR) {
+    const bool ok = base + q < cnt;
+    const int2 ev = ent[ok ? start + base + q : 0];
+    const int ecol = ok ? ev.x : 0, ecf = ok ? ev.y : 0;
+    const int nin = min(LPR, cnt - base);
+    for (int e = 0; e < nin; e += U) {
+      float4 v[U];
+      float cf[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int col = __shfl(ecol, e + u, LPR);
+        cf[u] = __int_as_float(__shfl(ecf, e + u, LPR));
+        v[u] = load_row4<LPR>(X4, col, q);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool vld = (base + e + u) < cnt;
+        float4 t = v[u];
+        t.x = vld ? t.x : 0.f; t.y = vld ? t.y : 0.f; t.z = vld ? t.z : 0.f; t.w = vld ? t.w : 0.f;
+        acc = f4_fma(cf[u], t, acc);
+      }
+    }
+  }
+  return acc;
+}
+
+template <int LPR, int R, int U>
+__device__ __forceinline__ void coop_long_rows(const float4 *__restrict__ X4, const int2 *__restrict__ ent, int4 (&sc)[R], int grp,
+                                               int q, int tid, int half, bool pair, int *cnt, int4 *list, float4 *part,
+                                               float4 *hold) {
+  constexpr int NGC = (kThreads / LPR < kCoopGroups) ? kThreads / LPR : kCoopGroups;   // D = 128 has 16 groups
+  if (tid == 0) cnt[half] = 0;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (sc[r].x >= 0 && sc[r].z > kCoopDeg) {
+        const int at = atomicAdd(&cnt[half], 1);   // (the list's order does not enter the sums)
+        if (at < kCoopRows) list[at] = make_int4(grp * R + r, sc[r].y, sc[r].z, 0);
+      }
+    }
+  }
+  __syncthreads();
+  int mine = cnt[half], other = pair ? cnt[half ^ 1] : 0;
+  if (mine > kCoopRows) mine = 0;
+  if (other > kCoopRows) other = 0;
+  const int n = max(mine, other);   // the same for every thread of the workgroup: both halves pass the same barriers
+  for (int i = 0; i < n; ++i) {
+    const int4 row = i < mine ? list[i] : make_int4(-1, 0, 0, 0);
+    const int per = (row.z + NGC - 1) / NGC;
+    if (grp < NGC) {
+      const int b = min(grp * per, row.z), e = min(b + per, row.z);
+      // (a run is deg / 32 entries: eight fetches in flight are one round up to degree 256; sixteen spill at D = 64)
+      part[grp * LPR + q] = gather_run<LPR, (U < 8 ? U : 8)>(X4, ent, row.y + b, e - b, q);
+    }
+    __syncthreads();
+    if (row.x >= 0 && row.x / R == grp) {
+      float4 sum = f4_zero();
+      for (int g = 0; g < NGC; ++g) sum = f4_add(sum, part[g * LPR + q]);
+      hold[row.x * LPR + q] = sum;   // read back by its own thread in coop_add
+    }
+    __syncthreads();
+  }
+  if (mine > 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (sc[r].x >= 0 && sc[r].z > kCoopDeg) {
+        sc[r].z = 0;    // nothing left for aggregate_rows ...
+        sc[r].y = -1;   // ... and coop_add knows the row
+      }
+    }
+  }
+}
+// acc = c (sum + c self) with the sum formed above: aggregate_rows left c (0 + c self)
+template <int LPR, int R>
+__device__ __forceinline__ void coop_add(const int4 (&sc)[R], int grp, int q, const float4 *hold, float4 (&acc)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (sc[r].x >= 0 && sc[r].y < 0) acc[r] = f4_fma(__int_as_float(sc[r].w), hold[(grp * R + r) * LPR + q], acc[r]);
+}
+
 // First round of a tile's gather for one thread: schedule entries, first entry chunk, own rows.
 template <int D>
 __device__ __forceinline__ void tile_prologue(const int4 *__restrict__ sched, const int2 *__restrict__ ell,
@@ -324,7 +421,13 @@ __global__ __launch_bounds__(kThreads, (D <= 64 ? 4 : 2)) void gcn_fused_fwd_ker
   if (HALO) {
     halo_finish<D, PRE, true>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, acc, NGPDE_STAMP_PTR(p));
   } else {
+    // (LDS: the product's operand tiles are not written yet -- W waits in registers, the row sums are what this forms)
+    // counter + row list (20 words) in W's tile, partial sums in the row tile, the rows' sums in the result tile (kTM x D floats each)
+    coop_long_rows<G::LPR, G::R, G::U>(X4, p.ent, sc, grp, q, tid, 0, false, reinterpret_cast<int *>(ldsBt),
+                                       reinterpret_cast<int4 *>(ldsBt + 4), reinterpret_cast<float4 *>(ldsT),
+                                       reinterpret_cast<float4 *>(ldsZ));
     aggregate_rows<G::LPR, G::R, G::U>(X4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, acc);
+    coop_add<G::LPR, G::R>(sc, grp, q, reinterpret_cast<const float4 *>(ldsZ), acc);
   }
   NGPDE_STAMP(1);
   if (p.order & 1) load_w();
@@ -530,7 +633,14 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * kThreads, (PAIR || D <= 64 ? 4 : 2
       halo_finish<D, false, !PRE, NoHook, !PRE>(hr, h_slot_w != nullptr, p.self_loops, grp, q, ldsXh, sc, t);
     }
   } else if (AGG) {
+    // the counters (one per half, read by both) in the first half's W tile; per half: row list in the X tile, partial sums in the dz
+    // tile, the rows' sums in the result tile
+    coop_long_rows<G::LPR, G::R, G::U>(G4, p.ent, sc, grp, q, tid, half, PAIR,
+                                       reinterpret_cast<int *>(lds_all + (PAIR ? 2 : 1) * kXZ + 2 * kTM * G::TS),
+                                       reinterpret_cast<int4 *>(ldsX), reinterpret_cast<float4 *>(ldsDZ),
+                                       reinterpret_cast<float4 *>(ldsXh));
     aggregate_rows<G::LPR, G::R, G::U>(G4, p.ent, p.self_loops, sc, q, ecol, ecf, selfv, t);
+    coop_add<G::LPR, G::R>(sc, grp, q, reinterpret_cast<const float4 *>(ldsXh), t);
   } else {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) t[r] = G4[(size_t)max(sc[r].x, 0) * G::LPR + q];
