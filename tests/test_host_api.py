@@ -143,3 +143,32 @@ def test_neuralode_generic_path_host_helpers():
     assert abs(sum(b) - 1.0) < 1e-14 and len(a) == len(b) == 6
     node = NeuralODE(object(), solver="Tsit5", n_steps=7, tspan=(0.0, 2.0), capture=True)
     assert node.solver == "tsit5" and abs(node.dt - 2.0 / 7) < 1e-15 and node.capture
+
+
+def test_reshuffled_batch_maps_onto_the_first_batch_of_the_same_members(monkeypatch):
+    # node.py: _canonical_batch -- DataLoader(shuffle = true) (VMH.md:120) hands the loop the same clouds in a new order; the solver
+    # runs such a batch on the first batch's plan through this node map.  Host logic only: the map is a permutation under which the
+    # first batch's node data ARE the reshuffled batch's, a cloud that occurs twice gets two different slots, other members start
+    # their own entry, and the switch turns it off.
+    from ngpde_amd import node as node_mod
+    monkeypatch.delenv("NGPDE_NO_BATCH_REUSE", raising=False)
+    node_mod._CANON_BATCHES.clear()
+    rng = np.random.default_rng(0)
+    clouds = []
+    for n in (5, 7, 4, 6):
+        s, t = rng.integers(0, n, size=3 * n), rng.integers(0, n, size=3 * n)
+        clouds.append(ng.GNNGraph(s, t, num_nodes=n, index_base=0, ndata={"x": torch.as_tensor(rng.random((2, n)).astype(np.float32))}))
+    first = ng.batch([clouds[0], clouds[1], clouds[2], clouds[0]])
+    assert node_mod._canonical_batch(first, "cpu") is None            # the first of its kind: remembered, solved as it is
+    assert node_mod._canonical_batch(first, "cpu") is None            # ... and again itself
+    again = ng.batch([clouds[2], clouds[0], clouds[1], clouds[0]])
+    g0, nodemap = node_mod._canonical_batch(again, "cpu")
+    assert g0 is first and sorted(nodemap.tolist()) == list(range(first.num_nodes))
+    assert torch.equal(torch.as_tensor(again.ndata["x"]), torch.as_tensor(first.ndata["x"])[:, nodemap])
+    assert node_mod._canonical_batch(again, "cpu")[1] is nodemap      # kept on the batch
+    other = ng.batch([clouds[0], clouds[1], clouds[3], clouds[0]])    # another member: its own entry
+    assert node_mod._canonical_batch(other, "cpu") is None
+    assert node_mod._canonical_batch(clouds[0], "cpu") is None        # not a batch
+    monkeypatch.setenv("NGPDE_NO_BATCH_REUSE", "1")
+    assert node_mod._canonical_batch(ng.batch([clouds[1], clouds[0], clouds[2], clouds[0]]), "cpu") is None
+    node_mod._CANON_BATCHES.clear()
