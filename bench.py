@@ -356,6 +356,35 @@ def secondary(dev, world, rank, dist):
             finally:
                 os.environ.pop("NGPDE_NO_PERSISTENT", None)
     if world == 1:
+        # BASELINE config 1 (the reference's own CPU-runnable case, docs/src/tutorials/graph_node.md:44-83): NeuralODE(2 x GCNConv(32 => 32,
+        # relu)) on a Cora-sized graph with Cora's degree skew (2 708 nodes, 5 278 pairs, hubs of degree ~100 beside a median of 3),
+        # Euler x 10.  Its hub tiles do not fit the 96-row LDS halo, so the solver replays the per-layer kernels with the per-row
+        # gather (hub rows walked by 32 lane groups, gcn_fused.hip: coop_long_rows); `same_size_without_hubs` is the persistent plan
+        # on a closest-pairs graph of the same size -- what a persistent form for hub graphs would buy
+        n1, pairs1, d1, steps1 = 2708, 5278, 32, 10
+        c1 = {}
+        for name, (s1, t1) in (("cora_like", S.preferential_pairs_graph(n1, pairs1, seed=1)),
+                               ("same_size_without_hubs", S.closest_pairs_graph(n1, pairs1, seed=1)[1:])):
+            g1 = ng.GNNGraph(s1, t1, num_nodes=n1, index_base=0)
+            rhs1 = ng.Chain(ng.GCNConv((d1, d1), "relu", initialgraph=g1), ng.GCNConv((d1, d1), "relu", initialgraph=g1))
+            node1 = ng.NeuralODE(rhs1, solver="euler", n_steps=steps1, dt=0.1)
+            ps1, st1 = ng.setup(0, node1)
+            ps1 = ng.to_device(ps1, dev)
+            for v in _grad_leaves(ps1):
+                v.requires_grad_(True)
+            u1 = torch.as_tensor(S.normal(51, d1 * n1).reshape(n1, d1).astype(np.float32), device=dev).T.requires_grad_(True)
+
+            def solve1():
+                for v in [u1] + _grad_leaves(ps1):
+                    v.grad = None
+                uT, _ = node1(u1, ps1, st1)
+                uT.sum().backward()
+            ms1 = _time_ms(solve1, 10)
+            c1[name] = {"ms_solve_forward_backward": round(ms1, 3), "value": round(steps1 / (ms1 * 1e-3), 1), "unit": "ODE-steps/s",
+                        "plan": sorted({f for pool in node1._plans.values() for q in pool for f in q.flags()})}
+        out["C1_cora_gcn32_eulerx10"] = {"nodes": n1, "edges": 2 * pairs1, **c1["cora_like"],
+                                         "same_size_without_hubs": c1["same_size_without_hubs"]}
+    if world == 1:
         # NeuralODE(VMHConv(phi, gamma)) of docs/src/tutorials/VMH.md:75-89 at the tutorial's size: 3 000 points in the unit square,
         # the 6 nearest neighbours of every point (the tutorial links Delaunay neighbours), h = 1, positions as node data, phi = 4 =>
         # 60 => 60 => 60 => 40 and gamma = 41 => 60 => 60 => 60 => 1, tanh.  Generic solver (every stage the layer's own kernels --
