@@ -139,3 +139,20 @@ def test_random_small_dense_layers_against_float64(seed):
         if bad:
             failures.append((case, n, widths, divs, dout, act, bias, bad))
     assert not failures, failures
+
+
+def test_random_vmh_node_shapes_plan_against_generic_solver():
+    # tools/fuzz_vmh_node.py, a short fixed run: random depths, widths, activations, aggregation, coordinates, sizes on both sides of the
+    # tile-round boundary, saveat -- NeuralODE(VMHConv) on the device-resident plan against the generic solver; a case above 5e-5 is
+    # settled by a torch float64 autograd transcription (relu kinks).  One child process; the tool exits 1 on a mismatch
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CASES="10", SEED="5")
+    for k in ("NGPDE_NO_VMH_NODE", "ONLY", "VERBOSE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_vmh_node.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("10 cases") and last.endswith("0 mismatches"), last
+    if not os.environ.get("NGPDE_NO_VMH_NODE") and not os.environ.get("NGPDE_NO_PERSISTENT"):
+        assert int(last.split(" cases, ")[1].split(" on the plan")[0]) >= 5, last
