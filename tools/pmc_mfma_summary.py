@@ -3,7 +3,7 @@ import collections, csv, glob, json, sys
 
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in glob.glob(root + "/c[245]_*/*/*_counter_collection.csv"):
+for path in glob.glob(root + "/*_S*/*/*_counter_collection.csv"):      # <config>_<counter group>/<pid>/..., config = c2 / c4 / c5 / vmh / vmhb
     cfg = path.split("/")[-3].split("_")[0]
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
