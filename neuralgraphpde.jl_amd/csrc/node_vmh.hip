@@ -570,6 +570,7 @@ __global__ __launch_bounds__(VT, 1) void node_vmh_fwd_kernel(const VmhFwdK p) {
             for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * VTS + 16 * mt + 4 * kq]) = msg[mt];
           }
           __syncthreads();
+          if (rd == 0 && w0 == 0) NGPDE_VST(m, ph, 7);   // (diagnostic build: every wave's messages of the first step are staged)
           {
             const float *base = t.S + 4 * c.q - cs * VTS;
             const int ce = min(cs + 16 * sw, c0 + VROUND);   // (the last wave group of a round may be a partial one)

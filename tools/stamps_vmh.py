@@ -66,6 +66,11 @@ def report(title, st, names):
 
 report("forward", fw, ["wait for the neighbours' flags", "halo values + barrier", "message MLP of the wave's 16 edges", "staging + per-target sums",
                        "node MLP (4 layers, a barrier each)", "stage update + drain + flag", "tape rows issued, loop overhead"])
+if (fw[:, 8:PH - 1, 7] > 0).any():      # the forward's staging step, split at its first barrier (stamp 7)
+    usedf = fw[:, 0, 0] > 0
+    f = fw[usedf][:, 8:PH - 1, :]
+    print(f"   staging, split: message MLP end of wave 0 -> all waves staged {np.mean(f[:, :, 7] - f[:, :, 3]):.0f}, "
+          f"-> sums done {np.mean(f[:, :, 4] - f[:, :, 7]):.0f}")
 report("adjoint", bw, ["K-bar + node MLP backwards", "message MLP backwards of the wave's 16 edges", "barrier (the slowest wave)", "own-row sums + drain + flag",
                        "dz rows issued", "wait for the neighbours' flags", "by-source gather + stage adjoint"])
 
