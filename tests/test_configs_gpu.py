@@ -64,6 +64,30 @@ def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
         close(ps[f"layer_{k + 1}"]["bias"].grad, acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
 
 
+@pytest.mark.parametrize("D,act", [(16, "relu"), (64, "tanh"), (128, "relu")])
+def test_hub_rows_of_the_per_row_gather_at_every_width(D, act):
+    # the graph of config 1 at the other widths of the fused kernels: the rows with more than 48 entries (largest degree 101) are
+    # walked by 32 lane groups (gcn_fused.hip: coop_long_rows; 16 groups at D = 128) in the forward and in the by-source gather of the
+    # pullback; Euler x 3 solve + adjoint against the float64 oracle
+    N, PAIRS = 2708, 5278
+    rng = np.random.default_rng(2)
+    s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
+    assert np.bincount(t, minlength=N).max() > 64
+    params = [dict(weight=S.glorot_uniform(60 + k, D, D), bias=rng.normal(size=(D, 1)) * 0.1) for k in range(2)]
+    u0 = rng.normal(size=(D, N))
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    node, ps, st = gcn2_node(g, D, "euler", 3, 0.1, params, act=act)
+    u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
+    uT, _ = node(u, ps, st)
+    uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, O.Graph(s, t, num_nodes=N, index_base=0), u0, O.TABLEAUS["euler"], 0.1, 3, act)
+    close(uT, uTo, 2e-4, what="u(T)")
+    uT.sum().backward()
+    close(u.grad, du0o, 5e-4, 1e-4, "du0")
+    for k in range(2):
+        close(ps[f"layer_{k + 1}"]["weight"].grad, acc[k]["weight"], 5e-4, 1e-3, f"dW{k + 1}")
+        close(ps[f"layer_{k + 1}"]["bias"].grad, acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
+
+
 @pytest.mark.parametrize("dims,act", [((1433, 16), "relu"), ((16, 1433), "tanh")])
 def test_cora_sized_first_layer_any_width_path(dims, act):
     # the tutorial's input layer GCNConv(nin => 16) at Cora size (docs/src/tutorials/graph_node.md:83: nin = 1433 bag-of-words
