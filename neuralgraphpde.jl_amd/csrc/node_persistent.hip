@@ -1060,7 +1060,18 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
 
   // the dense half of a phase: dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the next gather,
   // dW += A^T dZ, db += column sums; then publish and keep the own rows of G in the halo slots
-  auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout) {
+  auto tape_row = [&](size_t ev) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
+  auto mask_of = [&](size_t ev) -> Aux {
+    if constexpr (RELU) return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
+    else return ld4_stream_g(p.ztape + ev * p.row_elems, own);
+  };
+  // The tape row and the sign bits of the NEXT phase (mk_n / xrow_n) are asked for between the publish and the parameter-gradient
+  // products: cold rows from HBM, ~4.6 k cycles away.  Asked for at the head of their own phase -- in front of the poll, as rounds
+  // 2 - 3 had it -- they hold the poll up, because a wave's loads return in order: the first look at the flags came back only behind
+  // the tape row (wait 4.6 k cycles against the forward kernel's 3.0 k for the same hand-off).
+  Aux mk_n{};
+  float4 xrow_n = f4_zero();
+  auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout, bool pf, size_t ev_n) {
     kbar = f4_scale(c.ci, kbar);
     float4 dz;
     if constexpr (RELU) {
@@ -1083,6 +1094,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     tile_publish(p.m, c, ph);
     NGPDE_PST(p.m, ph, 6);
     Xh4[c.grp * PG::LPR + c.q] = gv;   // behind the barrier: every thread has read its row of G (same LDS region)
+    if (pf) {
+      mk_n = mask_of(ev_n);
+      xrow_n = tape_row(ev_n);
+    }
     // The parameter-gradient products run AFTER the rows are published: nobody waits for them, so they fill the time the
     // neighbours need to see the flag and this tile needs to see theirs.  (The operand tiles stay intact until the next
     // phase's dense half, two barriers away.)
@@ -1116,11 +1131,6 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     }
     NGPDE_PST(p.m, ph, 7);
   };
-  auto tape_row = [&](size_t ev) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
-  auto mask_of = [&](size_t ev) -> Aux {
-    if constexpr (RELU) return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
-    else return ld4_stream_g(p.ztape + ev * p.row_elems, own);
-  };
 
   bool ok = true;
   int ph = 0;   // phases count on across the members (the parameter-gradient accumulators too: the gradient of a batch is the sum)
@@ -1133,16 +1143,19 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
               // g2 was last read two phases ago, so no wait either)
     ++ph;
     const size_t ev = ev0 + (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
-    dense(ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev), tape_row(ev), p.g2);
+    dense(ph, ldsW2, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev), tape_row(ev), p.g2, true,
+          ev0 + (size_t)((p.n_steps - 1) * S + (S - 1)) * 2);   // (next: layer 1 of the last stage of the last step)
   }
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
     for (int i = S - 1; i >= 0 && ok; --i) {
       {   // layer 1 of stage i: dL/dy1 = A^T g2
         ++ph;
-        const size_t ev = ev0 + (size_t)(n * S + i) * 2;
         NGPDE_PST(p.m, ph, 0);
-        const Aux mk = mask_of(ev);               // own-row loads: in flight during the wait
-        const float4 xrow = tape_row(ev);
+        const Aux mk = mk_n;                      // asked for behind the publish of the phase before
+        const float4 xrow = xrow_n;
+        // next: layer 2 of the stage evaluated before this one (none in the very last phase of the member)
+        const bool last_next = (i == 0 && n == 0);
+        const size_t ev_next = ev0 + ((i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1);
         float4 t;
         if constexpr (WGT) {
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
@@ -1159,19 +1172,16 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
           NGPDE_PST(p.m, ph, 2);
           t = tile_aggregate(c, sw, ldsXh);
         }
-        dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1);
+        dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1, !last_next, ev_next);
       }
       {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
         ++ph;
         const bool last = (i == 0 && n == 0);
-        const size_t ev = ev0 + ((i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1);
-        Aux mk{};
-        float4 xrow = f4_zero();
         NGPDE_PST(p.m, ph, 0);
-        if (!last) {
-          mk = mask_of(ev);
-          xrow = tape_row(ev);
-        }
+        const Aux mk = mk_n;                      // (the last phase of a member runs no dense half: nothing was asked for)
+        const float4 xrow = xrow_n;
+        // next: layer 1 of stage i - 1, or of the last stage of the step before
+        const size_t ev_next = ev0 + (size_t)(i >= 1 ? n * S + i - 1 : (max(n, 1) - 1) * S + (S - 1)) * 2;
         float4 t;
         if constexpr (WGT) {
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
           kbar = f4_scale(ldsC[S - 1], v);
         }
         if (last) break;   // (this phase writes nothing other tiles read: no flag; the next member's first phase publishes ph + 1)
-        dense(ph, ldsW2, dw2, db2, kbar, mk, xrow, p.g2);
+        dense(ph, ldsW2, dw2, db2, kbar, mk, xrow, p.g2, true, ev_next);
       }
     }
   }
