@@ -1590,7 +1590,25 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
   __syncthreads();
 
   // the dense half of a turn (node_bwd_persistent_kernel's, with the tile context as an argument)
-  auto dense = [&](const TileCtx &c, unsigned own, int ph, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout) {
+  // The tape row and sign bits of the NEXT turn (mk_n / xrow_n: the workgroup's next tile in this phase, or its first tile in the next
+  // phase) are asked for at the head of this turn's dense half, when this turn's own have just gone to LDS: cold rows, ~4.5 k cycles
+  // away, with the product, the stores, the drain and the parameter-gradient products to arrive in.  (The drain in front of the flag
+  // waits for them, which costs the publish ~1.5 k cycles -- nobody reads a tile's rows before the workgroup's other turns are through.
+  // Asked for at the head of their own turn, in front of the poll, they held every turn's first look at the flags up by their
+  // latency: a wave's loads return in order.)
+  Aux mk_n{};
+  float4 xrow_n = f4_zero();
+  int Kv = 0;
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s) Kv = s + 1;
+  auto fetch = [&](size_t ev, int s) {
+    const int node = max(reinterpret_cast<const int4 *>(ldsMeta + s * kMS + kMetaF)[tid >> 4].x, 0);
+    const unsigned own = (unsigned)node * (unsigned)(PD * 4) + (unsigned)((tid & 15) * 16);
+    if constexpr (RELU) mk_n = ldu8_g(p.masks + ev * p.mask_bytes + (size_t)(t0 + s * W) * kThreads, (unsigned)tid);
+    else mk_n = ld4_stream_g(p.ztape + ev * p.row_elems, own);
+    xrow_n = ld4_stream_g(p.tape + ev * p.row_elems, own);
+  };
+  auto dense = [&](const TileCtx &c, unsigned own, int ph, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout,
+                   bool pf, size_t ev_n, int s_n) {
     kbar = f4_scale(c.ci, kbar);
     float4 dz;
     if constexpr (RELU) {
@@ -1601,6 +1619,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
     }
     *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
     *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
+    if (pf) fetch(ev_n, s_n);
     __syncthreads();
     mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, c.wave_u, c.lane);
     __syncthreads();
@@ -1635,11 +1654,6 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
       dbl += s;
     }
   };
-  auto tape_row = [&](size_t ev, unsigned own) { return ld4_stream_g(p.tape + ev * p.row_elems, own); };
-  auto mask_of = [&](size_t ev, const TileCtx &c, unsigned own) -> Aux {
-    if constexpr (RELU) return ldu8_g(p.masks + ev * p.mask_bytes + (size_t)c.tile * kThreads, (unsigned)c.tid);
-    else return ld4_stream_g(p.ztape + ev * p.row_elems, own);
-  };
 
   bool ok = true;
   int ph = 0;
@@ -1647,6 +1661,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
     ++ph;
     const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
     load_weight_lds(p.w2, ldsW, tid, false);
+    if (Kv > 0) fetch(ev, 0);
     for (int s = 0; s < K; ++s) {
       const int tile = t0 + s * W;
       if (tile >= p.m.n_tiles) break;
@@ -1655,7 +1670,11 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
       const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
       __syncthreads();   // (the phase's W is in LDS; the previous turn's products are done with the operand tiles)
       const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
-      dense(c, own, ph, dw2, db2, f4_scale(ldsC[S - 1], lam), mask_of(ev, c, own), tape_row(ev, own), p.g2);
+      const Aux mk = mk_n;
+      const float4 xrow = xrow_n;
+      const bool more = s + 1 < Kv;   // next: the workgroup's next tile, or layer 1 of the last stage of the last step on its first one
+      dense(c, own, ph, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, true,
+            more ? ev : (size_t)((p.n_steps - 1) * S + (S - 1)) * 2, more ? s + 1 : 0);
     }
   }
   for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
@@ -1671,15 +1690,18 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           TileCtx c;
           tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-          const Aux mk = mask_of(ev, c, own);
-          const float4 xrow = tape_row(ev, own);
+          const Aux mk = mk_n;
+          const float4 xrow = xrow_n;
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           halo_fill_all(c, p.g2, ldsXh);
           wait_vmcnt0();
           __syncthreads();
           const float4 t = tile_aggregate_rounds<WGT>(c, ldsXh);
           __syncthreads();   // every thread has its sum: the region becomes the product's result tile
-          dense(c, own, ph, dw1, db1, t, mk, xrow, p.g1);
+          // next: the workgroup's next tile, or layer 2 of the stage evaluated before this one (the very last phase asks for nothing)
+          const bool more = s + 1 < Kv;
+          const size_t ev_b = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;
+          dense(c, own, ph, dw1, db1, t, mk, xrow, p.g1, more || !(i == 0 && n == 0), more ? ev : ev_b, more ? s + 1 : 0);
         }
         if (!ok) break;
       }
@@ -1695,12 +1717,8 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           TileCtx c;
           tile_ctx_from_lds<WGT>(c, tile, ldsMeta + s * kMS);
           const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
-          Aux mk{};
-          float4 xrow = f4_zero();
-          if (!last) {
-            mk = mask_of(ev, c, own);
-            xrow = tape_row(ev, own);
-          }
+          const Aux mk = mk_n;        // (the last phase runs no dense half: nothing was asked for)
+          const float4 xrow = xrow_n;
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           halo_fill_all(c, p.g1, ldsXh);
           // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5), in flight under the gather
@@ -1729,8 +1747,13 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
             if (c.valid) st4_g(p.lam, own, v);
             kbar = f4_scale(ldsC[S - 1], v);
           }
-          if (!last) dense(c, own, ph, dw2, db2, kbar, mk, xrow, p.g2);
-          else __syncthreads();
+          if (!last) {   // next: the workgroup's next tile, or layer 1 of stage i - 1 / of the last stage of the step before
+            const bool more = s + 1 < Kv;
+            const size_t ev_a = (size_t)(i >= 1 ? n * S + i - 1 : (max(n, 1) - 1) * S + (S - 1)) * 2;
+            dense(c, own, ph, dw2, db2, kbar, mk, xrow, p.g2, true, more ? ev : ev_a, more ? s + 1 : 0);
+          } else {
+            __syncthreads();
+          }
         }
         if (!ok) break;
       }
