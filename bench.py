@@ -856,7 +856,7 @@ def main():
                          "algorithmic_MB_per_launch": round(algo[dom] / 1e6, 2),
                          "avg_launch_us": round(float(us[dom]), 3),
                          "avg_launch_source": "the library's own dispatch events (hipExtLaunchKernelGGL start / stop, median of five passes); "
-                                              "rocprofv3 --kernel-trace reads ~1-4.5 % longer for the same launch (profiles/r04_g_kernel_stats.csv: 3.196 ms, frac 0.41)"},
+                                              "rocprofv3 --kernel-trace reads ~1-4.5 % longer for the same launch (profiles/r04_o_kernel_stats.csv: 2.949 ms, frac 0.44)"},
             "kernels": kernels,
             "plan": sorted(plan.flags()), "fault": bool(plan.fault()),
         }
