@@ -22,6 +22,13 @@
 //      all four tags carry the producer's phase, then put the values into LDS.  One fabric traversal per phase instead of
 //      flag-then-rows; needs a symmetric halo relation (a tile that reads a neighbour's rows is read by it) for the
 //      write-after-read safety of the two ping-pong buffers.  Own rows stay in LDS (foreign rows only).
+//   8  tagged QUADS, no flags, no drain (round 5): a row travels as 22 sixteen-byte quads {f, f, f, phase tag}
+//      (lane q of the row's 16 lanes stores {its floats 0..2, tag}; lanes 0, 3, .. 15 also store the three neighbouring lanes'
+//      fourth floats as quad 16 + q / 3) -- one dwordx4 store per quad, 352 B per row in a 384-B stride.  The consumer's gather IS
+//      the poll: LDS-DMA of the quads, s_waitcnt, every lane checks the tag of the quad it asked for IN LDS and asks again only
+//      for the stale ones (exec-masked DMA).  argv[6] = s_sleep rounds between polling rounds.
+//   9  tagged quads + flags WITHOUT the drain: the producer stores its rows, meets at a barrier (stores issued, not acknowledged),
+//      one lane stores the flag; the consumer polls the flags as in mode 1, gathers, validates the tags and re-gathers stale quads.
 // argv: [mode or -1] [phases] [work in 10 ns ticks] [foreign rows only 0/1] [poll without s_sleep 0/1] [mode 5: s_sleep between polls]
 // Every payload word carries (phase, row), every gathered word is checked, and every spin is bounded (abort word + timeout).
 // build + run:  hipcc -O2 --offload-arch=gfx950 tools/persistent_floor.hip -o /tmp/persistent_floor && /tmp/persistent_floor
@@ -34,6 +41,7 @@
 
 constexpr int kRows = 32, kD = 64, kLpr = kD / 4, kThreads = 512, kHalo = 56, kNbr = 9;
 constexpr int kGridX = 32, kGridY = 16, kTiles = kGridX * kGridY;
+constexpr int kQStride = 24;   // quads per row of the tagged-quad buffers (22 used): 384 B = three 128-B lines
 
 typedef unsigned gu32 __attribute__((address_space(1)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -78,6 +86,7 @@ __device__ __forceinline__ bool spin_ok(unsigned long long t0, unsigned *abort_w
 
 __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p) {
   __shared__ __attribute__((aligned(16))) float lds[(kHalo + 8) * kD];
+  __shared__ __attribute__((aligned(16))) unsigned tag_lds[2 * kHalo * 16 * 4];   // modes 8 / 9
   __shared__ int s_ok, s_go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = tid / kLpr, q = tid % kLpr;
@@ -154,6 +163,92 @@ __global__ __launch_bounds__(kThreads, 4) void persistent_kernel(const Params p)
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(d), "v"(a), "v"(b) : "memory");
       }
       __syncthreads();   // everybody is done with the LDS halo before the next phase refills it
+    }
+    if (bad) atomicAdd(p.errors, bad);
+    return;
+  }
+  if (p.mode == 8 || p.mode == 9) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    // LDS image of the gathered quads: [main | extra][slot][16] -- a wave's DMA lands lane-linearly, so the main quads of its four
+    // slots are 64 consecutive quads; the extra region uses the first 6 of every 16 (prototype: not packed)
+    u4v *tl = reinterpret_cast<u4v *>(tag_lds);
+    volatile __attribute__((address_space(3))) unsigned *tag3 = (volatile __attribute__((address_space(3))) unsigned *)tag_lds;
+    const int hh = grp + kRows;                      // this thread's foreign slot (32 .. 55 for waves 0 .. 5)
+    const bool have = hh < kHalo;
+    const int wbase = (kRows + 4 * __builtin_amdgcn_readfirstlane(wave)) * 16;   // first quad of the wave's four slots
+    const int frow = p.halo[tile * kHalo + min(hh, kHalo - 1)];
+    for (int ph = 1; ph <= p.phases; ++ph) {
+      const unsigned *src = reinterpret_cast<const unsigned *>(p.pbuf[(ph + 1) & 1]);
+      unsigned *dst = reinterpret_cast<unsigned *>(p.pbuf[ph & 1]);
+      if (ph > 1) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned want = (unsigned)(ph - 1);
+        bool ok = true;
+        if (p.mode == 9) {
+          if (wave == 0) {
+            for (;;) {
+              const unsigned f = __hip_atomic_load(p.flags + 32 * my_nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__all((int)(f >= want))) break;
+              if (!spin_ok(t0, p.abort_word)) { ok = false; break; }
+              if (!p.no_sleep) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) s_ok = 0;
+          }
+          __syncthreads();
+          if (!s_ok) break;
+        }
+        bool need_m = have, need_x = have && q < 6;
+        const char *gm = reinterpret_cast<const char *>(src) + (size_t)frow * (kQStride * 16) + q * 16;
+        const char *gx = gm + 16 * 16;
+        for (unsigned it = 1;; ++it) {
+          if (need_m)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gm,
+                                             (__attribute__((address_space(3))) void *)(tl + wbase), 16, 0, 16);
+          if (need_x)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gx,
+                                             (__attribute__((address_space(3))) void *)(tl + kHalo * 16 + wbase), 16, 0, 16);
+          __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt / lgkmcnt left at max)
+          if (need_m) need_m = (tag3[(hh * 16 + q) * 4 + 3] != want);
+          if (need_x) need_x = (tag3[(kHalo * 16 + hh * 16 + q) * 4 + 3] != want);
+          if (!__any((int)(need_m || need_x))) break;
+          if ((it & 63u) == 0 && !spin_ok(t0, p.abort_word)) { ok = false; break; }
+          for (int sl = 0; sl < p.poll_sleep; ++sl) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) s_ok = 0;
+        __syncthreads();
+        if (!s_ok) break;
+        if (p.check && have) {
+          const u4v m = tl[hh * 16 + q];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) bad += (m[c] != payload(ph - 1, frow, 4 * q + c));
+          if (q < 6) {
+            const u4v x = tl[kHalo * 16 + hh * 16 + q];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              if (3 * q + c < 16) bad += (x[c] != payload(ph - 1, frow, 4 * (3 * q + c) + 3));
+          }
+        }
+      }
+      if (p.work_ticks > 0) {
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - w0 < (unsigned long long)p.work_ticks) __builtin_amdgcn_s_sleep(2);
+      }
+      {
+        const int row = tile * kRows + grp;
+        unsigned *d = dst + (size_t)row * (kQStride * 4);
+        u4v m = {payload(ph, row, 4 * q), payload(ph, row, 4 * q + 1), payload(ph, row, 4 * q + 2), (unsigned)ph};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d + 4 * q), "v"(m) : "memory");
+        if (q % 3 == 0) {   // the real kernel gets the neighbours' fourth floats by two DPP row shifts
+          u4v x = {payload(ph, row, 4 * q + 3), q + 1 < 16 ? payload(ph, row, 4 * (q + 1) + 3) : 0u,
+                   q + 2 < 16 ? payload(ph, row, 4 * (q + 2) + 3) : 0u, (unsigned)ph};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d + 4 * (16 + q / 3)), "v"(x) : "memory");
+        }
+      }
+      if (p.mode == 9) {
+        __builtin_amdgcn_s_barrier();    // every wave has ISSUED its stores; nobody waits for their acknowledgement
+        if (tid == 0) __hip_atomic_store(p.flags + 32 * tile, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();   // everybody is done with the LDS image before the next phase refills it
     }
     if (bad) atomicAdd(p.errors, bad);
     return;
@@ -332,8 +427,10 @@ int main(int argc, char **argv) {
                          "grid barrier (8 shards), plain stores + release / acquire fences",
                          "tagged 8-byte packets {value, phase}, no flags (foreign rows only)",
                          "neighbour flags, sc1, several polling waves out of step",
-                         "inbox counters (one polled word per tile, producers atomic-add), sc1"};
-  for (int mode = 0; mode < 8; ++mode) {
+                         "inbox counters (one polled word per tile, producers atomic-add), sc1",
+                         "tagged 16-byte quads {f, f, f, phase}: the LDS-DMA gather is the poll, no flags, no drain",
+                         "tagged quads + flags without the drain (stale quads re-gathered)"};
+  for (int mode = 0; mode < 10; ++mode) {
     if (only >= 0 && mode != only) continue;
     for (int check = 1; check >= 0; --check) {
       p.mode = mode; p.check = check;
