@@ -35,6 +35,8 @@ __device__ __forceinline__ void static_for(F &&f) {
 // sched_barriers of the pipelined block, so what computes the value stays before it and what uses it after it.  Without the pins
 // instruction selection places pure arithmetic next to its use -- the whole activation of the next slice behind the last MFMA.
 #define PIN(x) asm volatile("" : "+v"(x))
+// nothing moves across this point in instruction scheduling
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // LDS reads issued by hand (the compiler does not track them: the consumer waits with an explicit s_waitcnt that takes the
 // destination registers as operands, so nothing that uses them can move above it)
 __device__ __forceinline__ unsigned lds_addr(const void *ptr) { return (unsigned)(uintptr_t)ptr; }   // low half of a generic LDS pointer
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
   float *ldsQ = dyn;                                              // [halo_rows + 1][kTS]
   float *ldsP = ldsQ + (size_t)(p.halo_rows + 1) * kTS;           // [32][kTS]
   float *ldsS = ldsP + kRows * kTS;                               // [64][kTS]  wave-private transposes, then dz1 of the chunk
-  float *ldsWf = ldsS + kChunk4 * kTS;                            // [64 out][kTS]  W2^T
-  float *ldsWb = ldsWf + kW * kTS;                                // [64 in][kTS]   W2
+  float *ldsWf = ldsS + kChunk4 * kTS;                            // [64 out][kTS]  W2^T   (an unpadded XOR-swizzled image of both was measured in
+  float *ldsWb = ldsWf + kW * kTS;                                // [64 in][kTS]   W2     round 5: conflict share 0.375 -> 0.231, launch 932 -> 958 us)
   __shared__ int ldsOff[kRows + 1], ldsRs[kRows], ldsNode[kRows];
   __shared__ float ldsInv[kRows];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kRows * 8];
@@ -628,23 +630,36 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
           act_both<ACT1>(z.w, a1[ct].w, d1[ct].w);
           if (!valid) a1[ct] = f4_zero();
         }
-        // ---- z2 (transposed product), dz2 = g . act2'(z2)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        // ---- z2 (transposed product), dz2 = g . act2'(z2).  The W2^T fragment of group (mt, ct) + 1 is asked for in front of the
+        // four products of group (mt, ct): left to itself the compiler puts every ds_read right before its use and waits for it
+        // (16 exposed LDS latencies per product; `SCHED_FENCE` keeps the order through scheduling)
+        {
+          const float *wl0 = ldsWf + ei * kTS + 4 * kq;
+          float4 wq[2];
+          float4 bq[2];
+          wq[0] = *reinterpret_cast<const float4 *>(wl0);
+          bq[0] = *reinterpret_cast<const float4 *>(&ldsBias[4 * kq]);
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float *wl = ldsWf + (mt * 16 + ei) * kTS + 4 * kq;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * ct);
+          for (int g = 0; g < 16; ++g) {
+            const int mt = g >> 2, ct = g & 3;
+            if (g + 1 < 16) wq[(g + 1) & 1] = *reinterpret_cast<const float4 *>(wl0 + ((g + 1) >> 2) * 16 * kTS + 16 * ((g + 1) & 3));
+            if (ct == 0 && mt + 1 < 4) bq[(mt + 1) & 1] = *reinterpret_cast<const float4 *>(&ldsBias[16 * (mt + 1) + 4 * kq]);
+            SCHED_FENCE();
+            const float4 w4 = wq[g & 1];
             acc = mfma16(w4.x, a1[ct].x, acc);
             acc = mfma16(w4.y, a1[ct].y, acc);
             acc = mfma16(w4.z, a1[ct].z, acc);
             acc = mfma16(w4.w, a1[ct].w, acc);
+            SCHED_FENCE();
+            if (ct == 3) {
+              const float4 b4 = bq[mt & 1];
+              const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+              gz[mt] = f4_mul(f4_scale(inv, gz[mt]), make_float4(dact_c<ACT2>(z2.x), dact_c<ACT2>(z2.y), dact_c<ACT2>(z2.z), dact_c<ACT2>(z2.w)));
+              dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
+              acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
           }
-          const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
-          const float4 z2 = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
-          gz[mt] = f4_mul(f4_scale(inv, gz[mt]), make_float4(dact_c<ACT2>(z2.x), dact_c<ACT2>(z2.y), dact_c<ACT2>(z2.z), dact_c<ACT2>(z2.w)));
-          dbacc[mt] = f4_add(dbacc[mt], gz[mt]);
         }
         // ---- dW2 += a1^T dz2 over this wave's 16 edges: both operands transposed through the wave's LDS rows
 #pragma unroll
@@ -666,21 +681,29 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
 #pragma unroll
             for (int sI = 0; sI < 4; ++sI) accW[ct][mt] = mfma16(a1T[ct][sI], dzT[sI], accW[ct][mt]);
         }
-        // ---- da1 (transposed product with W2), dz1 = da1 . act1'(z1)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        // ---- da1 (transposed product with W2), dz1 = da1 . act1'(z1); fragments one group ahead as above
+        {
+          const float *wl0 = ldsWb + ei * kTS + 4 * kq;
+          float4 wq[2];
+          wq[0] = *reinterpret_cast<const float4 *>(wl0);
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float *wl = ldsWb + (ct * 16 + ei) * kTS + 4 * kq;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * mt);
+          for (int g = 0; g < 16; ++g) {
+            const int ct = g >> 2, mt = g & 3;
+            if (g + 1 < 16) wq[(g + 1) & 1] = *reinterpret_cast<const float4 *>(wl0 + ((g + 1) >> 2) * 16 * kTS + 16 * ((g + 1) & 3));
+            SCHED_FENCE();
+            const float4 w4 = wq[g & 1];
             acc = mfma16(w4.x, gz[mt].x, acc);
             acc = mfma16(w4.y, gz[mt].y, acc);
             acc = mfma16(w4.z, gz[mt].z, acc);
             acc = mfma16(w4.w, gz[mt].w, acc);
+            SCHED_FENCE();
+            if (mt == 3) {
+              dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), d1[ct]);
+              if (!DQ && valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];   // (a non-temporal store here: +3 %)
+              acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
           }
-          dz1[ct] = f4_mul(make_float4(acc[0], acc[1], acc[2], acc[3]), d1[ct]);
-          if (!DQ && valid) *reinterpret_cast<float4 *>(p.dE + pe * kW + 16 * ct + 4 * kq) = dz1[ct];   // (a non-temporal store here: +3 %)
         }
       }
       // ---- dz1 of the chunk -> LDS, lane group g16 sums the rows of targets g16 and g16 + 16 in edge order (= dP)
@@ -806,7 +829,8 @@ int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStr
   k.stamps = g_edge64_stamps;
 #endif
   const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kW * kTS + 2 * (size_t)kChunk4 * kTS) * sizeof(float);
-  const int per_xcd = std::max(1, std::min(lds + 4096 <= 80 * 1024 ? 64 : 32, (k.n_tiles + 7) / 8));   // two persistent workgroups per CU (one when the halo
+  int per_xcd = std::max(1, std::min(lds + 4096 <= 80 * 1024 ? 64 : 32, (k.n_tiles + 7) / 8));
+  if (const char *e = std::getenv("NGPDE_EDGE64_WGS_PER_XCD")) per_xcd = std::max(1, std::min(per_xcd, atoi(e)));   // diagnostic: fewer resident workgroups   // two persistent workgroups per CU (one when the halo
                                                                                                    // region is large), a multiple of the 8 XCDs
   const dim3 grid(8 * per_xcd), block(kT4);
   auto launch = [&](auto kernel) -> hipError_t {
@@ -879,7 +903,8 @@ int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hip
   NGPDE_REQUIRE(dq || a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
   k.dqpart = dq ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.workspace) + edge64_slab_bytes(g)) : nullptr;
   const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kChunk4 * kTS + 2 * (size_t)kW * kTS) * sizeof(float);
-  const int grid = (lds + 4096 <= 80 * 1024) ? edge64_bwd_grid(g) : std::max(8, edge64_bwd_grid(g) / 2);
+  int grid = (lds + 4096 <= 80 * 1024) ? edge64_bwd_grid(g) : std::max(8, edge64_bwd_grid(g) / 2);
+  if (const char *e = std::getenv("NGPDE_EDGE64_WGS_PER_XCD")) grid = std::max(8, std::min(grid, 8 * atoi(e)));   // diagnostic: fewer resident workgroups
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
