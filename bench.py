@@ -559,6 +559,32 @@ def secondary(dev, world, rank, dist):
     return out
 
 
+def visible_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process would see, WITHOUT the HIP runtime: the launcher parent must never touch the GPU (a process that has
+    initialised HIP may not start ranks that re-use its state, and on this pool may not exec at all).  The kernel driver lists every
+    agent under /sys/class/kfd/kfd/topology/nodes/<k>/properties; GPU agents are the ones with simd_count > 0.  The visibility
+    variables of the runtime (ROCR_VISIBLE_DEVICES, HIP_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES: comma lists of indices / UUIDs)
+    narrow that set.  Returns (count, source)."""
+    import glob
+    n = 0
+    nodes = sorted(glob.glob(os.path.join(topology, "*", "properties")))
+    for path in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    if not nodes:
+        return None, "no /sys/class/kfd"
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            n = min(n, len(ids))
+    return n, "kfd topology"
+
+
 def spawn_ranks(args, backend):
     """`python3 bench.py --gpus N` typed as is (no torch.distributed.run around it): start the N ranks as fresh child processes
     of this one -- which has made no GPU call and makes none -- with the rendezvous in the environment, relay rank 0's JSON
@@ -567,12 +593,14 @@ def spawn_ranks(args, backend):
     import socket
     import subprocess
     n = args.gpus
-    have = torch.cuda.device_count()        # (does not initialise the GPU)
+    have, how = visible_gpu_count()          # sysfs only: this process never loads the HIP runtime
+    if have is None:
+        have, how = torch.cuda.device_count(), "torch.cuda.device_count()"   # (no kfd node: not a ROCm box; counting does not initialise HIP)
     if backend == "nccl" and have < n:
         print(json.dumps({"metric": "ODE-steps/sec (fwd+bwd) on 16k-node graph, 64-d feats", "value": None, "unit": "ODE-steps/s",
                           "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "skipped": True,
                           "reason": f"--gpus {n} needs {n} devices for one RCCL rank per GPU; this box has {have}",
-                          "devices_visible": have, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic"}))
+                          "devices_visible": have, "devices_counted_by": how, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic"}))
         return 0
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -619,8 +647,8 @@ def main():
     # collective goes through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU
     backend = os.environ.get("NGPDE_BENCH_BACKEND", "nccl")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python3 bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (counting devices
-        # does not initialise HIP on this image) and never will: the ranks are fresh child processes
+        # plain `python3 bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (devices are counted
+        # from the kernel driver's sysfs topology, visible_gpu_count) and never will: the ranks are fresh child processes
         sys.exit(spawn_ranks(args, backend))
     if args.gpus != world:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -643,11 +671,36 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # NGPDE_BENCH_COMM=native: the gradient all-reduce + Adam through the library's own communicator (ngpde_comm_*, RCCL behind the
-    # C ABI: the call a Julia host makes) instead of torch.distributed's; same collective, same stream
-    native = None
-    if dist is not None and backend == "nccl" and os.environ.get("NGPDE_BENCH_COMM") == "native":
-        native = ng.dist.NativeComm.from_torch()
+    # Under nccl the gradient all-reduce + Adam go through the library's own communicator (ngpde_comm_*, RCCL behind the C ABI: the
+    # call a Julia host makes); NGPDE_BENCH_COMM=torch keeps torch.distributed's all_reduce + ngpde_adam_step.  Same collective, same
+    # stream.  The ranks AGREE on the choice (a rank whose communicator failed would otherwise wait in a collective the others never
+    # enter), and the line carries what RCCL itself reports: ncclCommCount / ncclCommUserRank and a checked sum over the ranks.
+    native, comm_record = None, None
+    if dist is not None:
+        comm_record = {"impl": "torch.distributed all_reduce (" + backend + ")", "world": dist.get_world_size()}
+    if dist is not None and backend == "nccl" and os.environ.get("NGPDE_BENCH_COMM", "native") == "native":
+        err = None
+        try:
+            native = ng.dist.NativeComm.from_torch()
+        except Exception as e:                        # (librccl.so missing, ncclCommInitRank refused, ...)
+            err = f"{type(e).__name__}: {e}"
+        okv = torch.tensor([0 if native is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        if int(okv.item()) == 1:
+            probe = torch.full((257,), float(rank + 1), dtype=torch.float32, device=dev)
+            native.all_reduce(probe)                   # sum over the ranks of (rank + 1), on the bench's stream
+            torch.cuda.synchronize()
+            want = world * (world + 1) / 2.0
+            cnt, urank = native.rccl_count_and_rank()
+            comm_record = {"impl": "ngpde_grad_allreduce_adam (RCCL behind the C ABI)", "world": native.world, "rccl_comm_count": cnt,
+                           "rccl_user_rank_of_rank0": urank, "probe_sum_ok": bool((probe == want).all().item())}
+            if not comm_record["probe_sum_ok"] or cnt != world:
+                raise RuntimeError(f"native communicator: {cnt} ranks met, probe sum {float(probe[0])} (expected {want})")
+        else:
+            if native is not None:
+                native.close()
+            native = None
+            comm_record["native_fallback"] = err or "another rank could not create its communicator"
     s, t, u0_h, w1_h, b1_h, w2_h, b2_h = make_inputs(rank)
     g = ng.GNNGraph(s, t, num_nodes=N_NODES, index_base=0)
     lib = _lib.load()
@@ -847,8 +900,7 @@ def main():
                        "ms_forward_solve": round(ms_fwd, 3), "ms_backward_solve": round(ms_bwd, 3),
                        "tape_GB": round(plan.tape_bytes() / 1e9, 3),
                        "parallelism": f"dp{world} (independent trajectories, all-reduce of 8320-float grads)",
-                       "collective": ("ngpde_grad_allreduce_adam (RCCL behind the C ABI)" if native is not None else
-                                      ("torch.distributed all_reduce (" + backend + ")" if world > 1 else "none (one rank)"))},
+                       "collective": comm_record if comm_record is not None else {"impl": "none (one rank)", "world": 1}},
             "roofline": {"bound": "hbm", "kernel": roles[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "static: profiles/traffic.json, the rocprofv3 --pmc passes of tools/profile_round.sh "

@@ -438,9 +438,7 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int3
 enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4, NGPDE_NODE_PERSISTENT_FWD = 8,
        NGPDE_NODE_PERSISTENT_BWD = 16, NGPDE_NODE_TILE_PAIRS = 32 /* persistent launches with two tiles per workgroup */,
        NGPDE_NODE_TILE_ROUNDS = 64 /* persistent launches with k tiles per workgroup taking turns (larger graphs) */,
-       NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */,
-       NGPDE_NODE_FUSED_RHS = 256 /* persistent launches with ONE hand-off per right-hand-side evaluation: both layers per tile from a
-                                     2-hop halo (relu, one tile per workgroup; opt-in: NGPDE_FUSED_RHS=1 -- measured slower than the one-hop plan) */ };
+       NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`
@@ -566,6 +564,8 @@ int32_t ngpde_comm_unique_id(void *id_out, size_t id_bytes);
 int32_t ngpde_comm_create(const void *unique_id, int32_t rank, int32_t world, ngpde_comm_t **out);
 int32_t ngpde_comm_destroy(ngpde_comm_t *comm);
 int32_t ngpde_comm_info(const ngpde_comm_t *comm, int32_t *rank, int32_t *world);
+/* what RCCL reports about the communicator (ncclCommCount, ncclCommUserRank): evidence in a run's record that `count` ranks met */
+int32_t ngpde_comm_rccl_info(const ngpde_comm_t *comm, int32_t *count, int32_t *user_rank);
 int32_t ngpde_grad_allreduce(ngpde_comm_t *comm, float *flat, int64_t count, ngpde_stream_t stream);
 int32_t ngpde_grad_allreduce_adam(ngpde_comm_t *comm, int64_t n, float *x, float *grad, float *m, float *v, float eta, float beta1,
                                   float beta2, float eps, int64_t step, ngpde_stream_t stream);

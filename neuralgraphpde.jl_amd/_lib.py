@@ -55,6 +55,7 @@ SIGNATURES = {
     "ngpde_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "ngpde_comm_destroy": (_i32, [_vp]),
     "ngpde_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ngpde_comm_rccl_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngpde_grad_allreduce": (_i32, [_vp, _vp, _i64, _vp]),
     "ngpde_grad_allreduce_adam": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp]),
     "ngpde_node_vmh_supported": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32]),

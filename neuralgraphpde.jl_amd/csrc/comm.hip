@@ -30,6 +30,8 @@ struct RcclApi {
   ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
   ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*error_string)(ncclResult_t) = nullptr;
+  ncclResult_t (*comm_count)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*comm_user_rank)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 
@@ -44,7 +46,9 @@ const RcclApi &rccl() {
     a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
     a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(h, "ncclAllReduce"));
     a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
-    a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_reduce && a.error_string;
+    a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(h, "ncclCommCount"));
+    a.comm_user_rank = reinterpret_cast<decltype(a.comm_user_rank)>(dlsym(h, "ncclCommUserRank"));
+    a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_reduce && a.error_string && a.comm_count && a.comm_user_rank;
     return a;
   }();
   return api;
@@ -111,6 +115,17 @@ int32_t ngpde_comm_info(const ngpde_comm_t *c, int32_t *rank, int32_t *world) {
   NGPDE_REQUIRE(c != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_comm_info: communicator is NULL");
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
+  return NGPDE_OK;
+}
+
+int32_t ngpde_comm_rccl_info(const ngpde_comm_t *c, int32_t *count, int32_t *user_rank) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(c != nullptr && c->comm != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_comm_rccl_info: communicator is NULL");
+  int n = 0, r = 0;
+  NGPDE_RCCL_CHECK(rccl().comm_count(c->comm, &n));
+  NGPDE_RCCL_CHECK(rccl().comm_user_rank(c->comm, &r));
+  if (count) *count = n;
+  if (user_rank) *user_rank = r;
   return NGPDE_OK;
 }
 

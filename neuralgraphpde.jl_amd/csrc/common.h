@@ -74,7 +74,6 @@ struct HaloInverse {
 constexpr int kTileRows = 32;  // node rows per workgroup of the fused kernels
 constexpr int kHaloCap = 96;   // unique rows a tile may stage in LDS (24 KB at D = 64), plus one zero row
 constexpr int kSlotWidth = 32;  // slot bytes per row of the LDS-staged aggregation (rows with more: global gather)
-constexpr int kHop2Cap = 160;  // rows of a tile's 2-hop halo (fused right-hand side, node_fused_rhs.hip): 40 KB of LDS at D = 64
 constexpr int kEllWidth = 16;  // entries per row held in the fixed-width block (rows with more spill to the CSR list)
 
 }  // namespace ngpde
@@ -178,17 +177,8 @@ int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, flo
 int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-capture-safe replacement of hipMemsetAsync(ptr, 0, bytes)
 // ---- persistent solver launches (node_persistent.hip): the whole forward solve / adjoint of the 2 x GCNConv(64 => 64) plan as
 // ONE launch each, tiles synchronised by per-tile phase flags
-// 2-hop halo tables of one direction (node_fused_rhs.hip): the persistent solver with ONE hand-off per right-hand side
-struct Hop2Dev {
-  unsigned *slots2 = nullptr;  // [n_tiles][kHaloCap][8] slot bytes of every 1-hop halo row: 2-hop slot + 1, 0 = unused
-  int *hnode = nullptr;        // [n_tiles][kHop2Cap] node of every 2-hop slot (-1: padding row of the last tile)
-  int2 *info = nullptr;        // [n_tiles] {rows of the 1-hop halo, rows of the 2-hop halo}
-  uint8_t *deg = nullptr;      // [n_tiles][kHaloCap] list length of every 1-hop halo row
-};
 struct NodePersist {
   int n_tiles = 0;
-  Hop2Dev hop2[2];             // fused right-hand side: by target (forward), by source (adjoint); null otherwise
-  int *nbr2 = nullptr;         // ... and its wait lists [n_tiles][64] over the 2-hop halos
   int pair_wgs = 0;            // tile-pair mode: workgroups of a launch (each holds tiles t and t + pair_wgs), else 0
   int *nbr = nullptr;          // [n_tiles][64] wait lists, -1 padded
   unsigned *sync = nullptr;    // [2 n_tiles + 1] 128-byte lines: phase flag per tile for slot 0, for slot 1, then the abort word
@@ -239,12 +229,6 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [9
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);
-// node_fused_rhs.hip: both layers of the right-hand side per tile from a 2-hop halo -- one hand-off per evaluation
-bool node_fused_rhs_possible(const ngpde_graph *g, int act, int n_evals);
-int32_t node_fused_setup(const ngpde_graph *g, NodePersist *ps);
-void node_fused_free(NodePersist *ps);
-int32_t launch_node_fwd_fused(const NodePersistFwd &a, hipStream_t stream);
-int32_t launch_node_bwd_fused(const NodePersistBwd &a, hipStream_t stream);
 // Persistent launches of one process take turns per device (node_persistent.hip): enter() takes the device's turnstile lock and makes
 // `stream` wait for the previous persistent launch on the device, leave() records this one and releases the lock; the lock is
 // held from enter to leave, so two host threads cannot both pass the wait and then launch side by side.  The destructor releases

@@ -166,7 +166,6 @@ struct ngpde_node {
   bool interleave = false;
   bool pair = false;         // ONE member, two tiles per workgroup (graphs of up to twice the co-resident tile count)
   int ktiles = 0;            // > 0: tile rounds -- ktiles tiles per workgroup taking turns (larger graphs still); kstate = their u, k_j rows
-  bool fused = false;        // ONE hand-off per right-hand side: both layers per tile from a 2-hop halo (node_fused_rhs.hip)
   float *kstate = nullptr;
   float *pubar = nullptr;
 
@@ -374,7 +373,6 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   }
   a.interleave = p->interleave; a.pair = p->pair; a.k_tiles = p->ktiles; a.state = p->kstate;
   a.ev_start = ev0; a.ev_stop = ev1;
-  if (p->fused) return launch_node_fwd_fused(a, stream);
   return launch_node_fwd_persistent(a, stream);
 }
 
@@ -387,7 +385,7 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   a.interleave = p->interleave; a.pair = p->pair; a.ubar = p->pubar; a.k_tiles = p->ktiles;
   a.ev_start = ev0; a.ev_stop = ev1;
   int32_t st;
-  if ((st = p->fused ? launch_node_bwd_fused(a, stream) : launch_node_bwd_persistent(a, stream))) return st;
+  if ((st = launch_node_bwd_persistent(a, stream))) return st;
   const int dd = p->d * p->d;
   const int ns = (p->pair || p->ktiles) ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
   if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
@@ -529,17 +527,6 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
     }
   }
   if (!p->persist_fwd) p->ktiles = 0;
-  // One hand-off per right-hand side (node_fused_rhs.hip) where the one-tile-per-workgroup plan runs: relu, both directions
-  // persistent (the sign-bit masks of the fused forward are indexed by node: only the fused adjoint reads them), a single member
-  // (NGPDE_FUSED_RHS_BATCH=1: batches too, member after member), every tile's 2-hop halo within kHop2Cap rows
-  if (pmode == 1 && p->persist_fwd && (p->persist_bwd || !p->with_bwd) && (!p->with_bwd || p->mask_mode) && !p->pair && p->ktiles == 0) {
-    const char *fb = std::getenv("NGPDE_FUSED_RHS_BATCH");
-    if ((members == 1 || (fb && fb[0] == '1')) && node_fused_rhs_possible(g, act, n_steps * S)) {
-      st = node_fused_setup(g, &p->persist);
-      if (st == NGPDE_OK) p->fused = true;
-      else if (st == NGPDE_ERR_UNSUPPORTED) st = NGPDE_OK;   // the one-hop plan
-    }
-  }
   // activations other than relu: the persistent pair needs BOTH directions persistent (the tapes' layouts differ from the replayed plan's)
   if (p->with_bwd && !p->mask_mode && !(p->persist_fwd && p->persist_bwd)) p->persist_fwd = p->persist_bwd = false;
   p->ztape_mode = p->with_bwd && !p->mask_mode && p->persist_fwd && p->persist_bwd;
@@ -547,7 +534,7 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
-  p->interleave = members > 1 && node_persistent_interleave_env() && !p->fused;
+  p->interleave = members > 1 && node_persistent_interleave_env();
   const size_t xslots = p->interleave ? 2 : 1;   // [N][d] arrays per exchanged buffer
   auto A = [&](float **ptr, size_t elems) {
     if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
@@ -651,8 +638,7 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
-           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0) |
-           (p->fused ? NGPDE_NODE_FUSED_RHS : 0);
+           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0);
   return NGPDE_OK;
 }
 

@@ -1953,7 +1953,6 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
 }
 
 void node_persistent_free(NodePersist *ps) {
-  node_fused_free(ps);
   if (ps->nbr) (void)hipFree(ps->nbr);
   if (ps->sync) (void)hipFree(ps->sync);
   if (ps->fault_host) (void)hipHostFree(const_cast<unsigned *>(ps->fault_host));

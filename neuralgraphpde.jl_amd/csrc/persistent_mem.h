@@ -1,4 +1,4 @@
-// persistent_mem.h -- memory-access helpers shared by the persistent solver kernels (node_persistent.hip, node_fused_rhs.hip):
+// persistent_mem.h -- memory-access helpers shared by the persistent solver kernels (node_persistent.hip, node_vmh.hip, gat_fused.hip):
 // write-through row stores, scalar-base global / streaming accesses, float4 selects.  Internal (anonymous namespace).
 #pragma once
 

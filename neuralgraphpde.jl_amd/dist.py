@@ -174,6 +174,13 @@ class NativeComm:
         self._lib.check(self.lib.ngpde_grad_allreduce_adam(self.ptr, x.numel(), p(x), p(grad), p(m), p(v), eta, beta1, beta2, eps, int(step),
                                                            self._lib.current_stream()))
 
+    def rccl_count_and_rank(self):
+        """(ncclCommCount, ncclCommUserRank) of the communicator: what RCCL itself says about who met"""
+        C = self._C
+        cnt, ur = C.c_int32(), C.c_int32()
+        self._lib.check(self.lib.ngpde_comm_rccl_info(self.ptr, C.byref(cnt), C.byref(ur)))
+        return int(cnt.value), int(ur.value)
+
     def close(self):
         if self.ptr is not None:
             self.lib.ngpde_comm_destroy(self.ptr)

@@ -86,7 +86,7 @@ class _Plan:
         f = C.c_int32()
         _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
         return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"),
-                                       (16, "persistent_bwd"), (32, "tile_pairs"), (64, "tile_rounds"), (128, "widened"), (256, "fused_rhs")) if f.value & bit}
+                                       (16, "persistent_bwd"), (32, "tile_pairs"), (64, "tile_rounds"), (128, "widened")) if f.value & bit}
 
     def fault(self):
         """True when a persistent launch of this plan gave up waiting (its outputs are NaN).  Synchronises."""
@@ -850,6 +850,18 @@ class NeuralODE(AbstractExplicitLayer):
         aggr = _lib.AGGR.get(m.aggr)
         if aggr is None:
             return None
+        # the plan's entries take pointers only: a parameter tree that does not chain (layer l's output width against layer l + 1's
+        # input width, every bias against its layer, phi's input = [h_i; h_j - h_i; x_j - x_i], gamma's = [h_i; m_i]) would make the
+        # kernels read past the weight arrays -- the reference fails in the matrix product with a DimensionMismatch
+        k = 0
+        for name, d, first in (("ϕ", dims[0], 2 + pd), ("γ", dims[1], 1 + dims[0][-1])):
+            if d[0] != first:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: NeuralODE(VMHConv): {name}.layer_1 takes {d[0]} "
+                                             f"inputs, the layer feeds it {first}")
+            _check_plan_shapes("NeuralODE(VMHConv)", u, u.shape[0], 1,
+                               [(f"{name}.layer_{l + 1}.weight", wb[k + 2 * l], (d[l], d[l + 1])) for l in range(len(d) - 1)],
+                               [(f"{name}.layer_{l + 1}.bias", wb[k + 2 * l + 1], d[l + 1]) for l in range(len(d) - 1)])
+            k += 2 * (len(d) - 1)
         lib = _lib.load()
         ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
         supported = lambda h: lib.ngpde_node_vmh_supported(h.ptr, 1, pd, len(acts[0]), ia(dims[0]), ia(acts[0]), len(acts[1]), ia(dims[1]),
@@ -945,6 +957,12 @@ class NeuralODE(AbstractExplicitLayer):
         vplan = self.vmh_plan_for(ps, st, u, needs_grad)
         if vplan is not None:
             plan_v, wb, index = vplan
+            # a state whose node count is not the plan's graph's (a forgotten updategraph in the minibatch loop): the reference's
+            # check_num_nodes DimensionMismatch, not N floats read and written through buffers of N'
+            n_expected = plan_v.n_nodes if index is None else int(index.numel())
+            if u.shape[0] != n_expected:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: NeuralODE(VMHConv): the state has {u.shape[0]} "
+                                             f"nodes, the graph in the layer's state has {n_expected}")
             uin = u.reshape(-1)
             if index is not None:      # (a padded batch: the real nodes' rows among the isolated padding nodes')
                 uin = torch.zeros(plan_v.n_nodes, dtype=torch.float32, device=u.device).index_copy(0, index, uin)

@@ -154,3 +154,65 @@ def test_bench_gpus_n_without_enough_devices_prints_a_skip_record():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["skipped"] is True and d["n_gpus"] == 8 and d["value"] is None and d["steps"] == 5 and "8 devices" in d["reason"]
+    assert d["devices_counted_by"] in ("kfd topology", "torch.cuda.device_count()")
+
+
+def test_launcher_counts_gpus_from_the_kernel_drivers_topology_without_the_hip_runtime(tmp_path, monkeypatch):
+    # bench.py's launcher parent decides "enough devices for N ranks?" from /sys/class/kfd (GPU agents have simd_count > 0, CPU
+    # agents 0) narrowed by the runtime's visibility variables -- never from a HIP call
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k, simd in enumerate([0, 0, 1024, 1024, 1024]):                 # two CPU sockets, three GPUs
+        (tmp_path / str(k)).mkdir()
+        (tmp_path / str(k) / "properties").write_text(f"cpu_cores_count {96 if simd == 0 else 0}\nsimd_count {simd}\ngfx_target_version 90500\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == (3, "kfd topology")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == (2, "kfd topology")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(tmp_path)) == (1, "kfd topology")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count(str(tmp_path))[0] == 0
+    assert bench.visible_gpu_count(str(tmp_path / "absent")) == (None, "no /sys/class/kfd")
+
+
+def _world8_worker(rank, world, port, out):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # shards of whole trajectories: BASELINE config 4's 512 over 8 ranks, and a count that does not divide
+    D = ng.dist
+    lo, hi = D.shard_range(512, rank, world)
+    lo2, hi2 = D.shard_range(13, rank, world)
+    grads = {"layer_1": {"weight": torch.full((4, 3), float(rank + 1)), "bias": torch.full((4,), float(hi2 - lo2))}}
+    D.allreduce_gradients(grads)
+    # the bench's timing rule: barrier, time the region, the MAX over the ranks is the job's time
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    out[rank] = (lo, hi, lo2, hi2, grads["layer_1"]["weight"][0, 0].item(), grads["layer_1"]["bias"][0].item(), float(tt.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_count_specific_paths_with_eight_gloo_ranks():
+    # the paths that only exist at N = 8 (512 trajectories -> 64 per GPU): a rendezvous of eight, shard ranges with and
+    # without a remainder, one all-reduce of the flat gradient, max-over-ranks timing.  CPU ranks: the GPU box admits at most six
+    # processes on its card, so an eight-rank rehearsal cannot touch the GPU there; the driver's 8-GPU run is the measurement.
+    world, port = 8, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [out[r] for r in range(world)]
+    assert [(r[0], r[1]) for r in res] == [(64 * k, 64 * (k + 1)) for k in range(8)]
+    cover = [i for r in res for i in range(r[2], r[3])]
+    assert cover == list(range(13)) and [r[3] - r[2] for r in res] == [2, 2, 2, 2, 2, 1, 1, 1]
+    assert all(r[4] == 36.0 and r[5] == 13.0 for r in res)              # sum of (rank + 1); the shard sizes add up to the item count
+    assert all(abs(r[6] - res[0][6]) < 1e-12 and r[6] >= 0.08 for r in res)   # every rank holds the slowest rank's time

@@ -514,7 +514,7 @@ def _oracle_node_with_seed(params, og, u0, seed, tableau, dt, nsteps, act="relu"
 
 
 PLAN_SWITCHES = ("NGPDE_NO_PERSISTENT", "NGPDE_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_TILE_PAIRS", "NGPDE_TILE_ROUNDS", "NGPDE_NO_INTERLEAVE",
-                 "NGPDE_WEIGHTED_TILE_ROUNDS", "NGPDE_NO_TILE_PIPE", "NGPDE_FUSED_RHS", "NGPDE_FUSED_RHS_BATCH", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK")
+                 "NGPDE_WEIGHTED_TILE_ROUNDS", "NGPDE_NO_TILE_PIPE", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK")
 
 
 def needs_persistent_plan(monkeypatch=None):
@@ -800,50 +800,6 @@ def test_node_persistent_and_replayed_plans_agree_bitwise(monkeypatch):
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-5) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("N,tab,nsteps,with_grad", [(4096, "tsit5", 3, True), (1000, "euler", 4, True), (16384, "tsit5", 2, True), (2500, "tsit5", 2, False)])
-def test_node_fused_rhs_plan_equals_the_one_hop_plan_bitwise(N, tab, nsteps, with_grad, monkeypatch):
-    # NGPDE_FUSED_RHS=1 (opt-in: measured slower than the default): ONE hand-off per right-hand-side evaluation --
-    # both layers per tile from a 2-hop halo (node_fused_rhs.hip).  A row's neighbours are summed in the row's own list order
-    # whichever tile evaluates it and the products contract in the same order, so EVERY output equals the one-hop persistent plan
-    # bit for bit, parameter gradients included (same per-tile accumulation, same slab order): the test of the tables, of the
-    # node-indexed sign bits read across tiles and of the synchronisation.  N = 1000 / 2500: a last tile with padding rows.
-    needs_persistent_plan(monkeypatch)
-    d, dt = 64, 0.05
-    g, og, params = spatial_case(N, 4 * N, d, seed=400 + nsteps)
-    rng = np.random.default_rng(401)
-    u0 = torch.as_tensor(rng.normal(size=(d, N)).astype(np.float32), device=DEV)
-    outs = {}
-    for mode in ("one_hop", "fused"):
-        if mode == "fused":
-            monkeypatch.setenv("NGPDE_FUSED_RHS", "1")
-        else:
-            monkeypatch.delenv("NGPDE_FUSED_RHS", raising=False)
-        rhs = ng.Chain(ng.GCNConv((d, d), "relu", initialgraph=g), ng.GCNConv((d, d), "relu", initialgraph=g))
-        node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
-        ps, st = ng.setup(0, node)
-        for k, name in enumerate(["layer_1", "layer_2"]):
-            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
-            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
-        ps = ng.to_device(ps, DEV)
-        if with_grad:
-            for lp in ps.values():
-                for v in lp.values():
-                    v.requires_grad_(True)
-        u = u0.clone().requires_grad_(with_grad)
-        for rep in range(2):                                 # (twice: the plan is re-used, flags and fault word re-armed)
-            uT, _ = node(u, ps, st)
-            plan = next(iter(node._plans.values()))[0]
-            assert ("fused_rhs" in plan.flags()) == (mode == "fused"), plan.flags()
-            assert "persistent_fwd" in plan.flags() and not plan.fault()
-            if with_grad:
-                for t in [u] + [v for lp in ps.values() for v in lp.values()]:
-                    t.grad = None
-                uT.sum().backward()
-        outs[mode] = [uT.detach().clone()] + ([u.grad.clone()] + [v.grad.clone() for lp in ps.values() for v in lp.values()] if with_grad else [])
-    for a, b in zip(outs["one_hop"], outs["fused"]):
-        assert not torch.isnan(b).any() and torch.equal(a, b)
-
-
 @pytest.mark.parametrize("K,N,tab,nsteps", [(2, 1000, "tsit5", 3), (3, 1000, "euler", 4), (8, 2048, "tsit5", 2), (2, 16384, "tsit5", 4)])
 def test_node_batch_interleaved_members_equal_member_by_member_bitwise(K, N, tab, nsteps, monkeypatch):
     # a batch of identical structures runs two members at a time per workgroup (one computes while the other's rows travel);
@@ -1003,23 +959,18 @@ def test_node_persistent_tile_rounds_beyond_1024_tiles(N, tab, nsteps, act, monk
         assert (dcol > bound).sum() <= 0.005 * dcol.size and dcol.max() <= 20 * bound, f"du0: {(dcol > bound).sum()} nodes beyond {bound:.2e}, max {dcol.max():.2e}"
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_node_persistent_abort_poisons_outputs_and_the_plan_refuses_further_work(fused, monkeypatch):
+def test_node_persistent_abort_poisons_outputs_and_the_plan_refuses_further_work(monkeypatch):
     # a persistent launch whose waits give up (forced here: NGPDE_DEBUG_FORCE_ABORT=1 starts the launch with its abort word set;
     # in production: another kernel holding the compute units for ~2 s) writes NaN outputs and latches the plan's fault word,
     # which lives in pinned host memory: the NEXT entry of the plan fails with ERR_STATE instead of computing on garbage
     needs_persistent_plan(monkeypatch)
     from ngpde_amd import _lib
     from ngpde_amd.node import _Plan
-    if fused:
-        monkeypatch.setenv("NGPDE_FUSED_RHS", "1")           # the one-hand-off-per-evaluation kernels (node_fused_rhs.hip)
-    else:
-        monkeypatch.delenv("NGPDE_FUSED_RHS", raising=False)
     N, d = 4096, 64
     g, og, params = spatial_case(N, 4 * N, d, seed=12)
     lib, p = _lib.load(), _lib.ptr
     plan = _Plan(g.handle((True, None, False)), d, _lib.ACT["relu"], "tsit5", 3, 0.05, True)
-    assert "persistent_fwd" in plan.flags() and ("fused_rhs" in plan.flags()) == fused
+    assert "persistent_fwd" in plan.flags()
     dv = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=DEV)
     u0 = dv(np.random.default_rng(1).normal(size=(N, d)))
     w1, w2, b = dv(params[0]["weight"].T), dv(params[1]["weight"].T), torch.zeros(d, device=DEV)

@@ -237,6 +237,41 @@ def test_vmh_abi_rejects_null_and_mismatched_arguments(monkeypatch):
     assert lib.ngpde_node_vmh_destroy(out) == _lib.OK
 
 
+def test_vmh_plan_rejects_a_state_or_parameters_that_do_not_match_the_graph(monkeypatch):
+    # the plan's C entries take pointers only (advisor, round 4): a state whose node count is not the graph's -- a forgotten updategraph in
+    # the minibatch loop -- or a parameter tree that does not chain must raise the reference's DimensionMismatch (check_num_nodes / the
+    # matrix product) BEFORE any kernel reads N floats through a buffer of N'
+    monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
+    nv = 704
+    g, _ = spatial(nv, 77)
+    phi, gam = tutorial_mlps(width=24, msg=16, depth=3)
+    node = ng.NeuralODE(ng.VMHConv(phi, gam, initialgraph=g), solver="euler", n_steps=2, dt=0.05)
+    ps0, st = ng.setup(5, node)
+    ps = prep(ps0, 5)
+    u0 = torch.zeros(1, nv, device=DEV)
+    with torch.no_grad():
+        out, _ = node(u0, ps, st)
+        assert any(k[0] == "vmh" for k in node._plans) and out.shape == (1, nv)
+        for n_bad in (nv - 32, nv + 32):                                  # not the node count of the graph in st
+            with pytest.raises(_lib.DimensionMismatch):
+                node(torch.zeros(1, n_bad, device=DEV), ps, st)
+        copy = lambda: {k: {l: dict(v) for l, v in sub.items()} for k, sub in ps.items()}
+        bad = copy()
+        bad["ϕ"]["layer_2"]["weight"] = torch.zeros(24, 23, device=DEV)   # layer_1 gives 24 rows, this one takes 23
+        with pytest.raises(_lib.DimensionMismatch):
+            node(u0, bad, st)
+        bad = copy()
+        bad["γ"]["layer_1"]["bias"] = torch.zeros(23, 1, device=DEV)
+        with pytest.raises(_lib.DimensionMismatch):
+            node(u0, bad, st)
+        bad = copy()
+        bad["γ"]["layer_1"]["weight"] = torch.zeros(24, 16, device=DEV)   # gamma takes [h_i; m_i] = 1 + 16 inputs
+        with pytest.raises(_lib.DimensionMismatch):
+            node(u0, bad, st)
+        out2, _ = node(u0, ps, st)                                        # ... and the plan is still usable
+    assert torch.equal(out, out2)
+
+
 def test_vmh_tile_rounds_equal_the_generic_solver_and_can_be_switched_off(monkeypatch):
     # 9 000 points, 6 neighbours: 564 half tiles on 256 compute units -- three turns per workgroup and phase, the adjoint's second half
     # of a phase fused in front of the next phase's first.  Against the generic solver (which NGPDE_NO_VMH_ROUNDS=1 selects for such a

@@ -102,6 +102,7 @@ def test_native_communicator_world_of_one_and_fused_adam():
     from ngpde_amd import _lib
     comm = ng.dist.NativeComm(ng.dist.NativeComm.unique_id(), 0, 1)
     assert (comm.rank, comm.world) == (0, 1)
+    assert comm.rccl_count_and_rank() == (1, 0)          # what RCCL itself reports (ncclCommCount, ncclCommUserRank)
     rng = np.random.default_rng(5)
     n = 8320
     x0 = torch.as_tensor(rng.normal(size=n).astype(np.float32), device="cuda:0")
