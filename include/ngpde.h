@@ -588,6 +588,74 @@ int32_t ngpde_transpose(int32_t rows, int32_t cols, const float *src, float *dst
 /* out[i][:] = x[i][:] * scale[i]  (mean aggregation's 1 / degree applied once per node to a cotangent, :534) */
 int32_t ngpde_rows_scale(int64_t n, int32_t d, const float *x, const float *scale, float *out, ngpde_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Layer-level entries: ONE call evaluates an edge-function layer of the reference, one call its pullback.
+ *   ExplicitEdgeConv  h'_i = aggr_j phi([h_i; h_j; x_j - x_i])                                    /root/reference/src/layers.jl:94-112
+ *   VMHConv           m_i = aggr_j phi([h_i; h_j - h_i; x_j - x_i]),  h'_i = gamma([h_i; m_i])     :308-332
+ *   MPPDEConv         m_i = aggr_j phi([h_i; h_j; d_i - d_j; e_ij; theta]),  h'_i = psi([h_i; m_i; theta])   :390-422
+ * The caller describes the layer -- the blocks the reference vcats and the Dense stacks phi / update (gamma, psi) -- and the
+ * library does what the host side had to orchestrate before: the split of phi's first weight into a target-side and a
+ * source-side matrix (the signed row blocks of :106, :316, :409-410), the node-level terms P, Q (one pass over h when the shape
+ * allows) and the per-edge term of the edge features, the message path (one fused launch where the message MLP fits the fused
+ * kernels, the gather / Dense / segmented-reduce primitives otherwise), the node update as a chained launch, and in the pullback
+ * the same steps in reverse with every temporary and saved activation laid out in ONE caller-provided workspace.
+ *
+ * Blocks are row-major device arrays (= the reference's column-major matrices):
+ *   state[k] [N][state_width[k]]   the values of `x` (an array = one block; a NamedTuple = its values in order, :94-96, :308-310);
+ *                                  MPPDEConv takes exactly one (h)
+ *   node_feat [N][node_feat_width] EdgeConv / VMH: vcat of g.ndata WITHOUT :x (constants, concatenated behind the state on both
+ *                                  sides of the message, :104, :315, :324); MPPDE: vcat(values(g.ndata)...) = d (:403-405)
+ *   pos [N][pos_width]             EdgeConv / VMH: g.ndata.x (x_j - x_i);  MPPDE: unused
+ *   edge_feat [E][edge_feat_width] MPPDE: vcat(values(g.edata)...) in p order (ngpde_edge_permute), nullable (:407)
+ *   theta [G][theta_width]         MPPDE: vcat(values(g.gdata)...) per graph of the batch, repeated over each graph's nodes / edges
+ *                                  (:397, :410, :418); the batch's graphs share one structure (:359-361)
+ * Only `state` carries a gradient (graph features are closed-over constants, theta is @ignore_derivatives).
+ * A Dense stack: n_layers in 1..NGPDE_MLP_MAX_LAYERS, layer l maps dims[l] => dims[l + 1] with activation act[l], weight[l]
+ * (dims[l + 1] x dims[l]) column-major, bias[l] nullable.  update.n_layers = 0 for ExplicitEdgeConv.
+ *
+ * forward:  y [N][out]; `training` != 0 keeps what the pullback needs in the workspace (ngpde_edge_layer_workspace_bytes with the
+ *           same flag); the workspace must be left untouched until ngpde_edge_layer_backward has run with the SAME descriptor.
+ * backward: dy [N][out]; d_state[k] nullable (NULL array: no state gradient); gradients of every weight and bias of phi / update
+ *           are written (dbias[l] may be NULL where bias[l] is).
+ * Errors: NGPDE_ERR_DIMENSION_MISMATCH when the stacks do not chain or phi's / update's input width is not the message's / the
+ * node update's vcat (the reference fails in its matrix product), NGPDE_ERR_WORKSPACE, NGPDE_ERR_UNSUPPORTED for more than four
+ * blocks on one side of the message. */
+#define NGPDE_MLP_MAX_LAYERS 8
+typedef struct ngpde_mlp {
+  int32_t n_layers;
+  int32_t dims[NGPDE_MLP_MAX_LAYERS + 1];
+  int32_t act[NGPDE_MLP_MAX_LAYERS];
+  const float *weight[NGPDE_MLP_MAX_LAYERS];
+  const float *bias[NGPDE_MLP_MAX_LAYERS];
+} ngpde_mlp_t;
+typedef struct ngpde_mlp_grad {
+  float *dweight[NGPDE_MLP_MAX_LAYERS];
+  float *dbias[NGPDE_MLP_MAX_LAYERS];
+} ngpde_mlp_grad_t;
+typedef enum { NGPDE_LAYER_EDGECONV = 0, NGPDE_LAYER_VMH = 1, NGPDE_LAYER_MPPDE = 2 } ngpde_edge_layer_kind_t;
+typedef struct ngpde_edge_layer {
+  int32_t kind;                 /* ngpde_edge_layer_kind_t */
+  int32_t aggr;                 /* ngpde_aggr_t */
+  int32_t n_state;
+  const float *state[4];
+  int32_t state_width[4];
+  const float *node_feat;
+  int32_t node_feat_width;
+  const float *pos;
+  int32_t pos_width;
+  const float *edge_feat;
+  int32_t edge_feat_width;
+  const float *theta;
+  int32_t theta_width;
+  ngpde_mlp_t phi, update;
+} ngpde_edge_layer_t;
+size_t ngpde_edge_layer_workspace_bytes(const ngpde_graph_t *g, const ngpde_edge_layer_t *layer, int32_t training);
+int32_t ngpde_edge_layer_forward(const ngpde_graph_t *g, const ngpde_edge_layer_t *layer, int32_t training, float *y, void *workspace,
+                                 size_t workspace_bytes, ngpde_stream_t stream);
+int32_t ngpde_edge_layer_backward(const ngpde_graph_t *g, const ngpde_edge_layer_t *layer, const float *dy, float *const *d_state,
+                                  const ngpde_mlp_grad_t *dphi, const ngpde_mlp_grad_t *dupdate, void *workspace,
+                                  size_t workspace_bytes, ngpde_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,30 @@ TABLEAU = {"euler": 0, "tsit5": 1}
 
 _vp, _i32, _i64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
 
+MLP_MAX_LAYERS = 8
+
+
+class Mlp(C.Structure):
+    """ngpde_mlp_t: a Dense stack (layer l: dims[l] => dims[l + 1])"""
+    _fields_ = [("n_layers", _i32), ("dims", _i32 * (MLP_MAX_LAYERS + 1)), ("act", _i32 * MLP_MAX_LAYERS),
+                ("weight", _vp * MLP_MAX_LAYERS), ("bias", _vp * MLP_MAX_LAYERS)]
+
+
+class MlpGrad(C.Structure):
+    """ngpde_mlp_grad_t"""
+    _fields_ = [("dweight", _vp * MLP_MAX_LAYERS), ("dbias", _vp * MLP_MAX_LAYERS)]
+
+
+class EdgeLayer(C.Structure):
+    """ngpde_edge_layer_t: ExplicitEdgeConv / VMHConv / MPPDEConv as blocks + Dense stacks"""
+    _fields_ = [("kind", _i32), ("aggr", _i32), ("n_state", _i32), ("state", _vp * 4), ("state_width", _i32 * 4),
+                ("node_feat", _vp), ("node_feat_width", _i32), ("pos", _vp), ("pos_width", _i32),
+                ("edge_feat", _vp), ("edge_feat_width", _i32), ("theta", _vp), ("theta_width", _i32),
+                ("phi", Mlp), ("update", Mlp)]
+
+
+LAYER_EDGECONV, LAYER_VMH, LAYER_MPPDE = 0, 1, 2
+
 # name -> (restype, argtypes).  Every symbol include/ngpde.h declares must be listed here:
 # tests/test_abi.py checks the header against this table and against the built library.
 SIGNATURES = {
@@ -51,6 +75,9 @@ SIGNATURES = {
     "ngpde_spatial_order": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "ngpde_graph_set_gcn_norm_device": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "ngpde_graph_array": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "ngpde_edge_layer_workspace_bytes": (_sz, [_vp, C.POINTER(EdgeLayer), _i32]),
+    "ngpde_edge_layer_forward": (_i32, [_vp, C.POINTER(EdgeLayer), _i32, _vp, _vp, _sz, _vp]),
+    "ngpde_edge_layer_backward": (_i32, [_vp, C.POINTER(EdgeLayer), _vp, _vp, C.POINTER(MlpGrad), C.POINTER(MlpGrad), _vp, _sz, _vp]),
     "ngpde_comm_unique_id": (_i32, [_vp, _sz]),
     "ngpde_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "ngpde_comm_destroy": (_i32, [_vp]),

@@ -908,6 +908,114 @@ def edge_mlp_fused(P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, tail):
                                  n_edges, tuple(a for _, _, a in tail), *wb)
 
 
+# ---- layer-level entries (api_layers.hip): one call per layer, one per pullback ----------------------------------------------------
+
+
+def _mlp_struct(wts, bs, acts):
+    m = _lib.Mlp()
+    m.n_layers = len(wts)
+    for l, w in enumerate(wts):
+        m.dims[l], m.dims[l + 1] = w.shape[0], w.shape[1]
+        m.act[l] = acts[l]
+        m.weight[l] = w.data_ptr()
+        m.bias[l] = bs[l].data_ptr() if bs[l] is not None else None
+    return m
+
+
+class _EdgeLayerFn(torch.autograd.Function):
+    """ExplicitEdgeConv / VMHConv / MPPDEConv in ONE library call (ngpde_edge_layer_forward), the pullback in one
+    (ngpde_edge_layer_backward): the split of phi's first weight, P / Q / E, the message path, the node update and every saved
+    activation live behind the C ABI, in one workspace.  tensors = state blocks, then (weight, bias) of every phi layer, then of
+    every update layer (bias None where the layer has none)."""
+
+    @staticmethod
+    def forward(ctx, handle, kind, aggr, consts, phi_acts, upd_acts, n_state, *tensors):
+        import ctypes as C
+        lib = _lib.load()
+        _need_cuda(*[t for t in tensors if t is not None], *[t for t in consts.values() if t is not None])
+        n_phi, n_upd = len(phi_acts), len(upd_acts)
+        tensors = [None if t is None else t.contiguous() for t in tensors]
+        state = tensors[:n_state]
+        pw = tensors[n_state:n_state + 2 * n_phi]
+        uw = tensors[n_state + 2 * n_phi:]
+        for l in range(1, n_phi):
+            if pw[2 * l].shape[0] != pw[2 * l - 2].shape[1]:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: Dense expects {pw[2 * l].shape[0]} input "
+                                             f"features, got {pw[2 * l - 2].shape[1]}")
+        for l in range(1, n_upd):
+            if uw[2 * l].shape[0] != uw[2 * l - 2].shape[1]:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: Dense expects {uw[2 * l].shape[0]} input "
+                                             f"features, got {uw[2 * l - 2].shape[1]}")
+        d = _lib.EdgeLayer()
+        d.kind, d.aggr, d.n_state = kind, aggr, n_state
+        for k, t in enumerate(state):
+            d.state[k], d.state_width[k] = t.data_ptr(), t.shape[1]
+        keep = []
+        for name in ("node_feat", "pos", "edge_feat", "theta"):
+            t = consts.get(name)
+            if t is not None and t.shape[1] > 0:
+                t = t.contiguous()
+                keep.append(t)
+                setattr(d, name, t.data_ptr())
+                setattr(d, name + "_width", t.shape[1])
+        d.phi = _mlp_struct(pw[0::2], pw[1::2], phi_acts)
+        if n_upd:
+            d.update = _mlp_struct(uw[0::2], uw[1::2], upd_acts)
+        training = any(ctx.needs_input_grad)
+        dev = state[0].device
+        n_nodes = state[0].shape[0]
+        out_w = (uw[-2] if n_upd else pw[-2]).shape[1]
+        nbytes = int(lib.ngpde_edge_layer_workspace_bytes(handle.ptr, C.byref(d), int(training)))
+        ws = _ws(nbytes, dev)
+        y = torch.empty((n_nodes, out_w), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_edge_layer_forward(handle.ptr, C.byref(d), int(training), _lib.ptr(y), _lib.ptr(ws), ws.numel(),
+                                                _lib.current_stream()))
+        if training:
+            ctx.desc, ctx.ws, ctx.keep, ctx.handle = d, ws, keep, handle
+            ctx.counts = (n_state, n_phi, n_upd)
+            ctx.present = [t is not None for t in tensors]
+            ctx.save_for_backward(*[t for t in tensors if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        lib = _lib.load()
+        n_state, n_phi, n_upd = ctx.counts
+        it = iter(ctx.saved_tensors)
+        tensors = [next(it) if pr else None for pr in ctx.present]
+        dev = dy.device
+        dy = dy.contiguous()
+        grads = [None] * len(tensors)
+        dstate = (C.c_void_p * 4)()
+        for k in range(n_state):
+            if ctx.needs_input_grad[7 + k]:
+                grads[k] = torch.empty_like(tensors[k])
+                dstate[k] = grads[k].data_ptr()
+        gphi, gupd = _lib.MlpGrad(), _lib.MlpGrad()
+        for base, n, gs in ((n_state, n_phi, gphi), (n_state + 2 * n_phi, n_upd, gupd)):
+            for l in range(n):
+                grads[base + 2 * l] = torch.empty_like(tensors[base + 2 * l])
+                gs.dweight[l] = grads[base + 2 * l].data_ptr()
+                if tensors[base + 2 * l + 1] is not None:
+                    grads[base + 2 * l + 1] = torch.empty_like(tensors[base + 2 * l + 1])
+                    gs.dbias[l] = grads[base + 2 * l + 1].data_ptr()
+        _lib.check(lib.ngpde_edge_layer_backward(ctx.handle.ptr, C.byref(ctx.desc), _lib.ptr(dy), dstate, C.byref(gphi), C.byref(gupd),
+                                                 _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.current_stream()))
+        ctx.ws = None          # (the workspace holds every saved activation: let it go with the node)
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def edge_layer(handle, kind, aggr, state, phi, update=(), node_feat=None, pos=None, edge_feat=None, theta=None):
+    """state: list of [N][w] blocks; phi / update: lists of (weight [in][out], bias or None, activation code).  Returns [N][out]."""
+    tensors = list(state)
+    for wt, b, _ in list(phi) + list(update):
+        tensors += [wt, b]
+    consts = {"node_feat": node_feat, "pos": pos, "edge_feat": edge_feat, "theta": theta}
+    return _EdgeLayerFn.apply(handle, int(kind), _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr), consts,
+                              tuple(a for _, _, a in phi), tuple(a for _, _, a in update), len(state), *tensors)
+
+
 # ---- weight-sized rearrangements as library launches (row_blocks.hip) ---------------------------------------------------------
 
 

@@ -38,6 +38,11 @@ def _wt_b(ps):
     return rows_of(ps["weight"]), (ps["bias"].reshape(-1) if "bias" in ps else None)
 
 
+def _stack_spec(stack):
+    """[(weight [in][out], bias or None, activation code)] of a Dense stack: what ngpde_edge_layer_* takes"""
+    return [(*_wt_b(ps), layer.act) for layer, ps in stack]
+
+
 def _tail(stack, a):
     """layers 2..k of a Dense stack on row-major activations"""
     for layer, ps in stack[1:]:
@@ -138,9 +143,21 @@ class ExplicitEdgeConv(AbstractGNNContainerLayer):
         g = st["graph"]
         xn = {k: rows_of(v) for k, v in _as_named(x).items()}
         dev = next(iter(xn.values())).device
-        handle = g.handle()
         for v in xn.values():
             _check_nodes(v, g)
+        if os.environ.get("NGPDE_LAYERS_COMPOSED") == "1":
+            return self._composed(xn, ps, st)
+        pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])        # xi.x
+        others = _node_data(g, dev, exclude=["x"])                                # drop(xi, :x) fixed part
+        y = F.edge_layer(g.handle(), _lib.LAYER_EDGECONV, self.aggr, list(xn.values()), _stack_spec(_dense_stack(self.ϕ, ps, "ϕ")),
+                         node_feat=others, pos=pos)                                # propagate(message, g, aggr)  (:111)
+        return y.T, st
+
+    def _composed(self, xn, ps, st):
+        """the same layer composed from the primitives' autograd nodes (rounds 1 - 4's host path; NGPDE_LAYERS_COMPOSED=1: the
+        test of ngpde_edge_layer_* against it)"""
+        g = st["graph"]
+        dev = next(iter(xn.values())).device
         pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])        # xi.x
         others = _node_data(g, dev, exclude=["x"])                                # drop(xi, :x) fixed part
         hblocks = list(xn.values()) + ([others] if others.shape[1] else [])
@@ -174,9 +191,20 @@ class VMHConv(AbstractGNNContainerLayer):
         g = st["graph"]
         xn = {k: rows_of(v) for k, v in _as_named(x).items()}
         dev = next(iter(xn.values())).device
-        handle = g.handle()
         for v in xn.values():
             _check_nodes(v, g)
+        if os.environ.get("NGPDE_LAYERS_COMPOSED") == "1":
+            return self._composed(xn, ps, st)
+        pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])
+        others = _node_data(g, dev, exclude=["x"])
+        y = F.edge_layer(g.handle(), _lib.LAYER_VMH, self.aggr, list(xn.values()), _stack_spec(_dense_stack(self.ϕ, ps["ϕ"], "ϕ")),
+                         _stack_spec(_dense_stack(self.γ, ps["γ"], "γ")), node_feat=others, pos=pos)     # :316-328
+        return y.T, st
+
+    def _composed(self, xn, ps, st):
+        """composed from the primitives' autograd nodes (NGPDE_LAYERS_COMPOSED=1)"""
+        g = st["graph"]
+        dev = next(iter(xn.values())).device
         pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])
         others = _node_data(g, dev, exclude=["x"])
         hblocks = list(xn.values()) + ([others] if others.shape[1] else [])
@@ -217,6 +245,18 @@ class MPPDEConv(AbstractGNNContainerLayer):
         h = rows_of(x)
         dev = h.device
         _check_nodes(h, g)
+        if os.environ.get("NGPDE_LAYERS_COMPOSED") == "1":
+            return self._composed(h, ps, st)
+        handle = g.handle()
+        y = F.edge_layer(handle, _lib.LAYER_MPPDE, self.aggr, [h], _stack_spec(_dense_stack(self.ϕ, ps["ϕ"], "ϕ")),
+                         _stack_spec(_dense_stack(self.ψ, ps["ψ"], "ψ")), node_feat=g.packed("ndata", dev),     # :403-405
+                         edge_feat=_edge_data_p(g, handle, dev), theta=g.packed("gdata", dev))                 # :407, :397
+        return y.T, st
+
+    def _composed(self, h, ps, st):
+        """composed from the primitives' autograd nodes (NGPDE_LAYERS_COMPOSED=1)"""
+        g = st["graph"]
+        dev = h.device
         handle = g.handle()
         N, E, G = g.num_nodes, g.num_edges, max(g.num_graphs, 1)
         d = g.packed("ndata", dev)                                                 # :403-405

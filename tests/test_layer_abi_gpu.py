@@ -1,0 +1,170 @@
+"""The layer-level C entries (include/ngpde.h: ngpde_edge_layer_*, api_layers.hip) against the same layers composed from the
+primitives' autograd nodes (NGPDE_LAYERS_COMPOSED=1: rounds 1 - 4's host path, itself checked against the float64 oracle in
+test_mp_gpu.py / test_configs_gpu.py).  One call per layer and one per pullback must give the composed path's bits: the entry
+only sequences the primitives' launches (/root/reference/src/layers.jl:94-112, :308-332, :390-422)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import ngpde_amd as ng
+from ngpde_amd import _lib, synth as S
+from test_mp_gpu import grad_leaves, prep, rgraph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def spatial(N, seed, ndata_extra=0, edata=0, gdata=0, n_graphs=1):
+    pts, s, t = S.closest_pairs_graph(N, 3 * N, seed=seed)
+    rng = np.random.default_rng(seed)
+    nd = {"x": pts.T.astype(np.float32).copy()}
+    for k in range(ndata_extra):
+        nd[f"f{k}"] = rng.normal(size=(1 + k, N)).astype(np.float32)
+    kw = dict(ndata=nd)
+    if edata:
+        kw["edata"] = {"e": rng.normal(size=(edata, s.size)).astype(np.float32)}
+    if gdata:
+        kw["gdata"] = {"θ": rng.normal(size=(gdata, n_graphs)).astype(np.float32)}
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0, num_graphs=n_graphs, **kw)
+
+
+def mesh_batch(n, traj, seed):
+    s, t = S.periodic_mesh_batch(n, traj)
+    N = n * traj
+    rng = np.random.default_rng(seed)
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0, num_graphs=traj,
+                       ndata={"u": rng.random((1, N)).astype(np.float32), "x": np.tile(np.arange(n) / n, traj)[None, :].astype(np.float32)},
+                       gdata={"θ": rng.random((2, traj)).astype(np.float32)})
+
+
+def both_ways(layer, x, seed, monkeypatch, training=True):
+    """(y, dx or [dx...], parameter gradients) through the layer-level entry and through the composed path"""
+    ps0, st = ng.setup(seed, layer)
+    outs = []
+    for composed in (False, True):
+        if composed:
+            monkeypatch.setenv("NGPDE_LAYERS_COMPOSED", "1")
+        else:
+            monkeypatch.delenv("NGPDE_LAYERS_COMPOSED", raising=False)
+        ps = prep(ps0, seed)
+        xs = {k: v.detach().clone().requires_grad_(training) for k, v in x.items()} if isinstance(x, dict) else x.detach().clone().requires_grad_(training)
+        if training:
+            y, _ = layer(xs, ps, st)
+            R = torch.as_tensor(np.random.default_rng(seed + 1).normal(size=tuple(y.shape)).astype(np.float32), device=DEV)
+            (y * R).sum().backward()
+            gx = [v.grad for v in xs.values()] if isinstance(xs, dict) else [xs.grad]
+            outs.append([y.detach()] + gx + [p.grad for p in grad_leaves(ps)])
+        else:
+            with torch.no_grad():
+                outs.append([layer(xs, ps, st)[0]])
+    monkeypatch.delenv("NGPDE_LAYERS_COMPOSED", raising=False)
+    return outs
+
+
+def assert_same(outs):
+    a, b = outs
+    assert len(a) == len(b)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert u is not None and v is not None, k
+        # bit for bit (max / min of an empty neighbourhood is -inf / +inf in both, as NNlib's scatter leaves it)
+        assert u.shape == v.shape and torch.equal(u.contiguous().view(torch.int32), v.contiguous().view(torch.int32)), \
+            f"output {k}: max diff {float((u - v).abs().nan_to_num(0.0).max()):.3e}"
+
+
+@pytest.mark.parametrize("aggr,widths,extra", [("mean", (16, 8), 0), ("+", (24,), 1), ("max", (12, 20, 8), 0), ("*", (8,), 0), ("mean", (7, 5), 2)])
+def test_edgeconv_entry_equals_the_composed_layer(aggr, widths, extra, monkeypatch):
+    g = spatial(700, 3, ndata_extra=extra)
+    dh = 6 + sum(1 + k for k in range(extra))
+    dims = (2 * dh + 2,) + widths
+    acts = ["tanh", "swish", "relu"]
+    phi = ng.Chain(*[ng.Dense(dims[l], dims[l + 1], acts[l % 3] if l + 1 < len(widths) else "identity") for l in range(len(widths))])
+    layer = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr=aggr)
+    x = torch.randn(6, 700, device=DEV)
+    assert_same(both_ways(layer, x, 11, monkeypatch))
+    assert_same(both_ways(layer, x, 11, monkeypatch, training=False))
+
+
+@pytest.mark.parametrize("aggr,msg,upd,named", [("mean", (60, 60, 40), (60, 60, 1), False), ("+", (16, 8), (12,), False),
+                                                ("mean", (32, 32), (20, 20, 20, 2), True), ("min", (8, 4), (8, 3), False)])
+def test_vmh_entry_equals_the_composed_layer(aggr, msg, upd, named, monkeypatch):
+    g = spatial(900, 5)
+    if named:
+        x = {"u": torch.randn(2, 900, device=DEV), "v": torch.randn(3, 900, device=DEV)}
+        dh = 5
+    else:
+        x = torch.randn(1, 900, device=DEV)
+        dh = 1
+    pd = (2 * dh + 2,) + msg
+    gd = (dh + msg[-1],) + upd
+    phi = ng.Chain(*[ng.Dense(pd[l], pd[l + 1], "tanh" if l + 1 < len(msg) else "identity") for l in range(len(msg))])
+    gam = ng.Chain(*[ng.Dense(gd[l], gd[l + 1], "swish" if l + 1 < len(upd) else "identity") for l in range(len(upd))])
+    layer = ng.VMHConv(phi, gam, initialgraph=g, aggr=aggr)
+    assert_same(both_ways(layer, x, 21, monkeypatch))
+    assert_same(both_ways(layer, x, 21, monkeypatch, training=False))
+
+
+@pytest.mark.parametrize("h,edata,theta,traj,msg,upd", [(64, 0, True, 4, (64, 64), (64, 64)),      # BASELINE config 4's shape: every fused launch
+                                                         (64, 0, True, 160, (64, 64), (64, 64)),    # ... at a size where the pair's pullback is ONE launch
+                                                         (64, 3, True, 2, (64, 64), (64, 64)),      # ... with edge features (dE is needed)
+                                                         (16, 2, False, 1, (24, 12), (20,)),
+                                                         (10, 0, True, 3, (30,), (14, 6)),          # widths outside the fused kernels
+                                                         (32, 0, False, 1, (48, 48, 48, 32), (40, 40, 32))])
+def test_mppde_entry_equals_the_composed_layer(h, edata, theta, traj, msg, upd, monkeypatch):
+    n = 256
+    g = mesh_batch(n, traj, 7)
+    N = n * traj
+    if edata:
+        g = ng.GNNGraph(*g.edge_index(0), num_nodes=N, index_base=0, num_graphs=traj, ndata=dict(g.ndata), gdata=dict(g.gdata),
+                        edata={"e": np.random.default_rng(3).normal(size=(edata, g.num_edges)).astype(np.float32)})
+    if not theta:
+        g = ng.GNNGraph(*g.edge_index(0), num_nodes=N, index_base=0, num_graphs=traj, ndata=dict(g.ndata), edata=dict(g.edata))
+    dth = 2 if theta else 0
+    pd = (2 * h + 2 + edata + dth,) + msg
+    ud = (h + msg[-1] + dth,) + upd
+    phi = ng.Chain(*[ng.Dense(pd[l], pd[l + 1], "swish") for l in range(len(msg))])
+    psi = ng.Chain(*[ng.Dense(ud[l], ud[l + 1], "swish" if l + 1 < len(upd) else "identity") for l in range(len(upd))])
+    layer = ng.MPPDEConv(phi, psi, initialgraph=g)
+    x = torch.randn(N, h, device=DEV).T
+    assert_same(both_ways(layer, x, 31, monkeypatch))
+    assert_same(both_ways(layer, x, 31, monkeypatch, training=False))
+
+
+@pytest.mark.parametrize("switch", ["NGPDE_NO_FUSED_EDGE", "NGPDE_NO_FUSED_EDGE_BWD", "NGPDE_DEEP_EDGE_BWD"])
+def test_entry_follows_the_librarys_path_switches(switch, monkeypatch):
+    # the fused forward with the primitives' pullback (saved pre-activations), no fused launch at all, the deep one-launch pullback
+    monkeypatch.setenv(switch, "1")
+    g = spatial(640, 9)
+    phi = ng.Chain(ng.Dense(4, 32, "tanh"), ng.Dense(32, 32, "tanh"), ng.Dense(32, 16))
+    gam = ng.Chain(ng.Dense(17, 24, "tanh"), ng.Dense(24, 1))
+    layer = ng.VMHConv(phi, gam, initialgraph=g)
+    assert_same(both_ways(layer, torch.randn(1, 640, device=DEV), 41, monkeypatch))
+
+
+def test_entry_rejects_what_the_reference_rejects():
+    lib = _lib.load()
+    g = spatial(64, 2)
+    h = g.handle()
+    d = _lib.EdgeLayer()
+    assert lib.ngpde_edge_layer_workspace_bytes(None, C.byref(d), 1) == 0
+    assert lib.ngpde_edge_layer_forward(h.ptr, None, 0, None, None, 0, None) == _lib.ERR_INVALID_ARGUMENT
+    x = torch.zeros(64, 3, device=DEV)
+    w = torch.zeros(8, 8, device=DEV)
+    d.kind, d.aggr, d.n_state = _lib.LAYER_EDGECONV, 1, 1
+    d.state[0], d.state_width[0] = x.data_ptr(), 3
+    d.phi.n_layers, d.phi.dims[0], d.phi.dims[1], d.phi.weight[0] = 1, 7, 8, w.data_ptr()      # the message has 2 * 3 + 0 rows, not 7
+    y = torch.zeros(64, 8, device=DEV)
+    assert lib.ngpde_edge_layer_forward(h.ptr, C.byref(d), 0, y.data_ptr(), y.data_ptr(), 1 << 20, None) == _lib.ERR_DIMENSION_MISMATCH
+    assert b"first layer expects 7 input features, the message has 6" in lib.ngpde_last_error()
+    d.phi.dims[0] = 6
+    assert lib.ngpde_edge_layer_forward(h.ptr, C.byref(d), 0, y.data_ptr(), y.data_ptr(), 16, None) == _lib.ERR_WORKSPACE
+    d.kind = 7
+    assert lib.ngpde_edge_layer_forward(h.ptr, C.byref(d), 0, y.data_ptr(), y.data_ptr(), 1 << 20, None) == _lib.ERR_INVALID_ARGUMENT
+    # MPPDEConv on a batch whose graphs do not share one structure (src/layers.jl:359-361)
+    gb = ng.GNNGraph(np.array([0, 1, 2, 3, 4]), np.array([1, 0, 3, 2, 2]), num_nodes=5, index_base=0, num_graphs=2,
+                     gdata={"θ": np.zeros((1, 2), np.float32)})
+    layer = ng.MPPDEConv(ng.Dense(2 * 4 + 1, 8), ng.Dense(4 + 8 + 1, 4), initialgraph=gb)
+    ps, st = ng.setup(0, layer)
+    with pytest.raises(_lib.DimensionMismatch):
+        layer(torch.zeros(4, 5, device=DEV), ng.to_device(ps, DEV), st)
