@@ -656,6 +656,32 @@ int32_t ngpde_edge_layer_backward(const ngpde_graph_t *g, const ngpde_edge_layer
                                   const ngpde_mlp_grad_t *dphi, const ngpde_mlp_grad_t *dupdate, void *workspace,
                                   size_t workspace_bytes, ngpde_stream_t stream);
 
+/* GNOConv (/root/reference/src/layers.jl:509-547) in one call, its pullback in one:
+ *   K_e = reshape(phi([s_i; s_j; e_ij]), out, in),  m_i = aggr_j K_e h_j,  y = act.(W h + m + b)
+ * h [N][in]; node_feat = vcat(values(g.ndata)...) [N][ds] (:517-519); edge_feat = vcat(values(g.edata)...) [E][de] in p order (:521);
+ * phi: dims[0] = 2 ds + de, dims[n_layers] = in * out (column-major reshape: element o + out * i, :527); weight (out x in), bias [out]
+ * nullable.  The library picks the form: reassociated (the last Dense of phi without activation: T_j = W2 (x) h_j at node level, the
+ * in*out x E tensor is never formed), with the per-edge input formed inside the message launch for a two-layer phi, or the literal
+ * batched_mul (NGPDE_GNO_MATERIALIZE=1 forces it).  Workspace / training / pullback conventions as ngpde_edge_layer_*; dh nullable. */
+typedef struct ngpde_gno_layer {
+  int32_t in_chs, out_chs;
+  int32_t aggr;                 /* ngpde_aggr_t */
+  int32_t act;                  /* ngpde_act_t of the layer's tail */
+  const float *h;
+  const float *node_feat;
+  int32_t node_feat_width;
+  const float *edge_feat;
+  int32_t edge_feat_width;
+  ngpde_mlp_t phi;
+  const float *weight, *bias;
+} ngpde_gno_layer_t;
+size_t ngpde_gno_layer_workspace_bytes(const ngpde_graph_t *g, const ngpde_gno_layer_t *layer, int32_t training);
+int32_t ngpde_gno_layer_forward(const ngpde_graph_t *g, const ngpde_gno_layer_t *layer, int32_t training, float *y, void *workspace,
+                                size_t workspace_bytes, ngpde_stream_t stream);
+int32_t ngpde_gno_layer_backward(const ngpde_graph_t *g, const ngpde_gno_layer_t *layer, const float *dy, float *dh,
+                                 const ngpde_mlp_grad_t *dphi, float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
+                                 ngpde_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,12 @@ class EdgeLayer(C.Structure):
                 ("phi", Mlp), ("update", Mlp)]
 
 
+class GnoLayer(C.Structure):
+    """ngpde_gno_layer_t"""
+    _fields_ = [("in_chs", _i32), ("out_chs", _i32), ("aggr", _i32), ("act", _i32), ("h", _vp), ("node_feat", _vp), ("node_feat_width", _i32),
+                ("edge_feat", _vp), ("edge_feat_width", _i32), ("phi", Mlp), ("weight", _vp), ("bias", _vp)]
+
+
 LAYER_EDGECONV, LAYER_VMH, LAYER_MPPDE = 0, 1, 2
 
 # name -> (restype, argtypes).  Every symbol include/ngpde.h declares must be listed here:
@@ -78,6 +84,9 @@ SIGNATURES = {
     "ngpde_edge_layer_workspace_bytes": (_sz, [_vp, C.POINTER(EdgeLayer), _i32]),
     "ngpde_edge_layer_forward": (_i32, [_vp, C.POINTER(EdgeLayer), _i32, _vp, _vp, _sz, _vp]),
     "ngpde_edge_layer_backward": (_i32, [_vp, C.POINTER(EdgeLayer), _vp, _vp, C.POINTER(MlpGrad), C.POINTER(MlpGrad), _vp, _sz, _vp]),
+    "ngpde_gno_layer_workspace_bytes": (_sz, [_vp, C.POINTER(GnoLayer), _i32]),
+    "ngpde_gno_layer_forward": (_i32, [_vp, C.POINTER(GnoLayer), _i32, _vp, _vp, _sz, _vp]),
+    "ngpde_gno_layer_backward": (_i32, [_vp, C.POINTER(GnoLayer), _vp, _vp, C.POINTER(MlpGrad), _vp, _vp, _vp, _sz, _vp]),
     "ngpde_comm_unique_id": (_i32, [_vp, _sz]),
     "ngpde_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "ngpde_comm_destroy": (_i32, [_vp]),

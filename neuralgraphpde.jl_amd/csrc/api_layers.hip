@@ -39,6 +39,11 @@ struct Arena {
   void *take_bytes(size_t bytes) { return take((bytes + 3) / 4); }
 };
 
+constexpr size_t kArenaSlack = 256;   // the arena starts at the first 256-byte boundary inside the caller's buffer
+inline float *arena_base(void *workspace) {
+  return reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + (kArenaSlack - 1)) & ~(uintptr_t)(kArenaSlack - 1));
+}
+
 struct Blocks {   // a virtual vcat: the block table of one Dense call
   int n = 0;
   const float *ptr[kMaxBlocks] = {nullptr, nullptr, nullptr, nullptr};
@@ -321,6 +326,129 @@ int32_t check_common(const char *fn, const ngpde_graph *g, const ngpde_edge_laye
   return NGPDE_OK;
 }
 
+
+// ---- GNOConv -------------------------------------------------------------------------------------------------------------------
+// inv[i] = 1 / max(in-degree(i), 1): a mean aggregation's pullback multiplies a node's gradient by it once per node
+__global__ void inv_in_degree_kernel(int n, const int32_t *__restrict__ rowptr, float *__restrict__ inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[i] = 1.0f / fmaxf((float)(rowptr[i + 1] - rowptr[i]), 1.0f);
+}
+
+struct GnoPlan {
+  int64_t N = 0, E = 0;
+  int cin = 0, cout = 0, ds = 0, de = 0, h1 = 0, L = 0, kdim = 0, aggr = 1, act = 0, act1 = 0;
+  bool reassoc = false, fused_msg = false, fused_agg = false, has_b2 = false;
+  int n_mid = 0;           // Dense layers of phi evaluated on [E] rows by the primitives (reassociated: 1 .. L - 2; literal: 1 .. L - 1)
+  RowSpec rows;
+  // forward region
+  float *wa = nullptr, *wb = nullptr, *wd = nullptr, *wr = nullptr, *P = nullptr, *Q = nullptr, *Et = nullptr, *Bh = nullptr, *Wh = nullptr,
+        *T = nullptr, *a = nullptr, *m = nullptr, *agg = nullptr, *z0 = nullptr, *a0 = nullptr, *zt = nullptr;
+  float *ty[kMaxL], *tz[kMaxL];
+  // pullback scratch
+  float *dz = nullptr, *dagg_s = nullptr, *inv = nullptr, *dT = nullptr, *dBh = nullptr, *dzE = nullptr, *dP = nullptr, *dQ = nullptr,
+        *dm = nullptr, *eg[2] = {nullptr, nullptr}, *dwa = nullptr, *dwb = nullptr, *dwd = nullptr, *dwr = nullptr, *dxB = nullptr,
+        *dxW = nullptr, *dxT = nullptr, *dxC = nullptr, *dsum = nullptr;
+  void *ws = nullptr;
+  size_t ws_bytes = 0, total_floats = 0;
+};
+
+int32_t make_gno_plan(const ngpde_graph *g, const ngpde_gno_layer_t &L, bool training, Arena &a, GnoPlan &p) {
+  NGPDE_REQUIRE(L.in_chs > 0 && L.out_chs > 0, NGPDE_ERR_DIMENSION_MISMATCH, "ngpde_gno_layer: in_chs / out_chs must be positive");
+  NGPDE_REQUIRE(L.aggr >= NGPDE_AGGR_SUM && L.aggr <= NGPDE_AGGR_MUL, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer: unknown aggregation %d", L.aggr);
+  NGPDE_REQUIRE(L.act >= NGPDE_ACT_IDENTITY && L.act <= NGPDE_ACT_SOFTPLUS, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer: unknown activation %d", L.act);
+  NGPDE_REQUIRE(L.h != nullptr && L.weight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer: h or weight is NULL");
+  NGPDE_REQUIRE(L.node_feat_width >= 0 && L.edge_feat_width >= 0 && (L.node_feat_width == 0 || L.node_feat) && (L.edge_feat_width == 0 || L.edge_feat),
+                NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer: a feature block with a width is NULL");
+  int32_t st;
+  if ((st = check_mlp("phi", L.phi, 1))) return st;
+  const ngpde_mlp_t &phi = L.phi;
+  p.N = g->n_nodes; p.E = g->n_edges;
+  p.cin = L.in_chs; p.cout = L.out_chs; p.ds = L.node_feat_width; p.de = L.edge_feat_width; p.aggr = L.aggr; p.act = L.act;
+  p.L = phi.n_layers; p.h1 = phi.dims[1]; p.act1 = phi.act[0];
+  NGPDE_REQUIRE(phi.dims[0] == 2 * p.ds + p.de && phi.dims[0] > 0, NGPDE_ERR_DIMENSION_MISMATCH,
+                "DimensionMismatch: first layer expects %d input features, the message has %d", phi.dims[0], 2 * p.ds + p.de);
+  NGPDE_REQUIRE(phi.dims[p.L] == p.cin * p.cout, NGPDE_ERR_DIMENSION_MISMATCH,
+                "DimensionMismatch: phi must output in_chs*out_chs = %d rows, got %d", p.cin * p.cout, phi.dims[p.L]);
+  // [si; sj; e]  (:523)
+  int o = 0;
+  if (p.ds) { p.rows.block(o++, p.ds, {{0, 1.f}}); p.rows.block(o++, p.ds, {{p.ds, 1.f}}); }
+  if (p.de) p.rows.block(o++, p.de, {{2 * p.ds, 1.f}});
+  p.rows.n_out = o;
+  p.kdim = phi.dims[p.L - 1];
+  p.reassoc = p.L >= 2 && phi.act[p.L - 1] == NGPDE_ACT_IDENTITY && !env_is("NGPDE_GNO_MATERIALIZE", '1') &&
+              ngpde_gno_apply_supported(p.cout, p.kdim) == 1;
+  p.has_b2 = p.reassoc && phi.bias[p.L - 1] != nullptr;
+  p.fused_msg = p.reassoc && p.L == 2 && p.E > 0 && !env_is("NGPDE_NO_GNO_MFMA", '1') && (p.act1 == NGPDE_ACT_IDENTITY || p.act1 == NGPDE_ACT_RELU) &&
+                ngpde_gno_message_supported(p.cout, p.kdim) == 1;
+  p.fused_agg = p.fused_msg && (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN);
+  p.n_mid = p.fused_msg ? 0 : (p.reassoc ? p.L - 2 : p.L - 1);
+  const size_t N = (size_t)p.N, E = (size_t)p.E;
+  const size_t msg_w = (size_t)p.cout;
+  for (int l = 0; l < kMaxL; ++l) p.ty[l] = p.tz[l] = nullptr;
+  // ---- forward region
+  if (p.ds) { p.wa = a.take((size_t)p.ds * p.h1); p.wb = a.take((size_t)p.ds * p.h1); }
+  if (p.de) p.wd = a.take((size_t)p.de * p.h1);
+  if (p.ds) { p.P = a.take(N * p.h1); p.Q = a.take(N * p.h1); }
+  if (p.de) p.Et = a.take(E * p.h1);
+  if (p.reassoc) {
+    p.wr = a.take((size_t)p.cin * p.cout * p.kdim);
+    p.T = a.take(N * p.cout * p.kdim);
+    if (p.has_b2) p.Bh = a.take(N * p.cout);
+  }
+  p.Wh = a.take(N * p.cout);
+  if (p.fused_msg) {
+    p.a = training ? a.take(E * p.kdim) : nullptr;
+  } else {
+    p.a0 = a.take(E * p.h1);
+    p.z0 = (training && p.act1 != 0) ? a.take(E * p.h1) : nullptr;
+    for (int l = 0; l < p.n_mid; ++l) {
+      p.ty[l] = a.take(E * phi.dims[l + 2]);
+      p.tz[l] = (training && phi.act[l + 1] != 0) ? a.take(E * phi.dims[l + 2]) : nullptr;
+    }
+  }
+  p.m = a.take(E * msg_w);
+  p.agg = a.take(N * msg_w);
+  p.zt = (training && p.act != 0) ? a.take(N * msg_w) : nullptr;
+  if (!training) {
+    p.total_floats = a.off;
+    return NGPDE_OK;
+  }
+  // ---- pullback scratch
+  size_t wsb = ngpde_bias_act_workspace_bytes(p.cout);
+  auto dense_ws = [&](int64_t n, int din, int dout) { wsb = std::max(wsb, ngpde_dense_workspace_bytes(n, din, dout)); };
+  p.dz = a.take(N * msg_w);
+  if (p.fused_agg && p.aggr == NGPDE_AGGR_MEAN) { p.dagg_s = a.take(N * msg_w); p.inv = a.take(N); }
+  if (p.reassoc) {
+    p.dT = a.take(N * p.cout * p.kdim);
+    p.dwr = a.take((size_t)p.cin * p.cout * p.kdim);
+    p.dxT = a.take(N * p.cin);
+    if (p.has_b2) { p.dBh = a.take(N * p.cout); p.dxB = a.take(N * p.cin); p.dsum = a.take(N * p.cin); }
+    dense_ws(p.N, p.cin, p.cout * p.kdim);
+  } else {
+    p.dxC = a.take(N * p.cin);
+    wsb = std::max(wsb, (size_t)p.E * p.cin * sizeof(float));
+  }
+  p.dxW = a.take(N * p.cin);
+  dense_ws(p.N, p.cin, p.cout);
+  p.dzE = a.take(E * p.h1);
+  if (p.ds) { p.dP = a.take(N * p.h1); p.dQ = a.take(N * p.h1); p.dwa = a.take((size_t)p.ds * p.h1); p.dwb = a.take((size_t)p.ds * p.h1); dense_ws(p.N, p.ds, p.h1); }
+  if (p.de) { p.dwd = a.take((size_t)p.de * p.h1); dense_ws(p.E, p.de, p.h1); }
+  if (!p.fused_agg) p.dm = a.take(E * msg_w);
+  if (!p.fused_msg) {
+    int emax = p.h1;
+    for (int l = 0; l <= p.n_mid; ++l) emax = std::max(emax, (int)phi.dims[l + 1]);
+    p.eg[0] = a.take(E * emax);
+    p.eg[1] = a.take(E * emax);
+    for (int l = 0; l < p.n_mid; ++l) dense_ws(p.E, phi.dims[l + 1], phi.dims[l + 2]);
+  } else if (!p.fused_agg) {
+    p.eg[0] = a.take(E * p.kdim);
+  }
+  p.ws_bytes = wsb;
+  p.ws = a.take_bytes(wsb);
+  p.total_floats = a.off;
+  return NGPDE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,7 +458,7 @@ size_t ngpde_edge_layer_workspace_bytes(const ngpde_graph_t *g, const ngpde_edge
   Arena a;
   Plan p;
   if (make_plan(g, *L, training != 0, a, p) != NGPDE_OK) return 0;
-  return p.total_floats * sizeof(float) + 256;
+  return p.total_floats * sizeof(float) + kArenaSlack;
 }
 
 int32_t ngpde_edge_layer_forward(const ngpde_graph_t *g, const ngpde_edge_layer_t *L, int32_t training, float *y, void *workspace,
@@ -339,13 +467,13 @@ int32_t ngpde_edge_layer_forward(const ngpde_graph_t *g, const ngpde_edge_layer_
   int32_t st;
   if ((st = check_common("ngpde_edge_layer_forward", g, L))) return st;
   Arena a;
-  a.base = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  a.base = arena_base(workspace);
   Plan p;
   if ((st = make_plan(g, *L, training != 0, a, p))) return st;
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(y != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_layer_forward: y is NULL");
-  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + 256, NGPDE_ERR_WORKSPACE,
-                "ngpde_edge_layer_forward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + 256);
+  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
+                "ngpde_edge_layer_forward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
   const ngpde_mlp_t &phi = L->phi;
   // the recombined first-layer weights in one launch
   float *outs[3] = {p.wA, p.wB, p.wD};
@@ -411,14 +539,14 @@ int32_t ngpde_edge_layer_backward(const ngpde_graph_t *g, const ngpde_edge_layer
   int32_t st;
   if ((st = check_common("ngpde_edge_layer_backward", g, L))) return st;
   Arena a;
-  a.base = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  a.base = arena_base(workspace);
   Plan p;
   if ((st = make_plan(g, *L, true, a, p))) return st;
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(dy != nullptr && dphi != nullptr && (p.n_upd == 0 || dupd != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_edge_layer_backward: dy or a gradient table is NULL");
-  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + 256, NGPDE_ERR_WORKSPACE,
-                "ngpde_edge_layer_backward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + 256);
+  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
+                "ngpde_edge_layer_backward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
   const ngpde_mlp_t &phi = L->phi;
   for (int l = 0; l < phi.n_layers; ++l)
     NGPDE_REQUIRE(dphi->dweight[l] != nullptr && (phi.bias[l] == nullptr || dphi->dbias[l] != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
@@ -557,6 +685,219 @@ int32_t ngpde_edge_layer_backward(const ngpde_graph_t *g, const ngpde_edge_layer
   float *douts[3] = {p.dwA, p.dwB, p.dwD};
   return ngpde_row_blocks_scatter(p.h1, p.w1_rows, dphi->dweight[0], p.rows.n_seg, p.rows.out_index, p.rows.dst0, p.rows.src0, p.rows.nrows, p.rows.sign,
                                   p.rows.n_out, douts, p.rows.out_rows, stream);
+}
+
+
+size_t ngpde_gno_layer_workspace_bytes(const ngpde_graph_t *g, const ngpde_gno_layer_t *L, int32_t training) {
+  if (!g || !L) return 0;
+  Arena a;
+  GnoPlan p;
+  if (make_gno_plan(g, *L, training != 0, a, p) != NGPDE_OK) return 0;
+  return p.total_floats * sizeof(float) + kArenaSlack;
+}
+
+int32_t ngpde_gno_layer_forward(const ngpde_graph_t *g, const ngpde_gno_layer_t *L, int32_t training, float *y, void *workspace,
+                                size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(g != nullptr && L != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer_forward: graph or layer descriptor is NULL");
+  Arena a;
+  a.base = arena_base(workspace);
+  GnoPlan p;
+  int32_t st;
+  if ((st = make_gno_plan(g, *L, training != 0, a, p))) return st;
+  if (g->n_nodes == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(y != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer_forward: y is NULL");
+  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
+                "ngpde_gno_layer_forward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
+  const ngpde_mlp_t &phi = L->phi;
+  float *outs[3];
+  int no = 0;
+  if (p.ds) { outs[no++] = p.wa; outs[no++] = p.wb; }
+  if (p.de) outs[no++] = p.wd;
+  if ((st = ngpde_row_blocks_gather(p.h1, phi.dims[0], phi.weight[0], p.rows.n_seg, p.rows.out_index, p.rows.dst0, p.rows.src0, p.rows.nrows,
+                                    p.rows.sign, p.rows.n_out, outs, p.rows.out_rows, stream)))
+    return st;
+  const int32_t one[1] = {1};
+  if (p.de) {   // the edge features' term (it carries phi's first bias when there are no node features)
+    const float *eb[1] = {L->edge_feat};
+    const int32_t ew[1] = {p.de};
+    if ((st = ngpde_dense_forward(p.E, 1, eb, ew, one, p.h1, NGPDE_ACT_IDENTITY, p.wd, p.ds ? nullptr : phi.bias[0], p.Et, nullptr, stream))) return st;
+  }
+  const float *w2 = phi.weight[p.L - 1], *b2 = phi.bias[p.L - 1];
+  if (p.reassoc) {   // W2 as [in][out][k]: the transpose of [k][in * out]
+    if ((st = ngpde_transpose(p.kdim, p.cin * p.cout, w2, p.wr, stream))) return st;
+  }
+  {   // the small node-level Dense layers -- P, Q on the node coordinates, B2 h, W h -- in ONE launch
+    int64_t n[4];
+    int32_t nseg[4], sw[4], srd[4], dout[4], act[4];
+    const float *sp[4], *wt[4], *bs[4];
+    float *ys[4], *zs[4];
+    int q = 0;
+    auto add = [&](const float *x, int xw, const float *w, const float *b, int d, float *yq) {
+      n[q] = p.N; nseg[q] = 1; sp[q] = x; sw[q] = xw; srd[q] = 1; dout[q] = d; act[q] = NGPDE_ACT_IDENTITY; wt[q] = w; bs[q] = b; ys[q] = yq; zs[q] = nullptr;
+      ++q;
+    };
+    if (p.ds) { add(L->node_feat, p.ds, p.wa, phi.bias[0], p.h1, p.P); add(L->node_feat, p.ds, p.wb, nullptr, p.h1, p.Q); }
+    if (p.has_b2) add(L->h, p.cin, b2, nullptr, p.cout, p.Bh);     // b2 read as the [in][out] matrix B2[i][o] = b2[o + out * i]
+    add(L->h, p.cin, L->weight, nullptr, p.cout, p.Wh);
+    if ((st = ngpde_dense_multi_forward(q, n, nseg, sp, sw, srd, dout, act, wt, bs, ys, zs, stream))) return st;
+  }
+  if (p.reassoc) {
+    const float *hb[1] = {L->h};
+    const int32_t hw[1] = {p.cin};
+    if ((st = ngpde_dense_forward(p.N, 1, hb, hw, one, p.cout * p.kdim, NGPDE_ACT_IDENTITY, p.wr, nullptr, p.T, nullptr, stream))) return st;
+  }
+  if (p.fused_msg) {
+    if ((st = ngpde_gno_message_forward(g, p.cout, p.kdim, p.act1, p.P, p.Q, p.Et, p.T, p.Bh, p.a, p.m, stream))) return st;
+  } else {
+    if ((st = ngpde_edge_combine_forward(g, p.h1, p.act1, p.P, p.Q, p.Et, p.a0, p.z0, stream))) return st;
+    const float *cur = p.a0;
+    for (int l = 0; l < p.n_mid; ++l) {
+      const float *b1[1] = {cur};
+      const int32_t w1[1] = {phi.dims[l + 1]};
+      if ((st = ngpde_dense_forward(p.E, 1, b1, w1, one, phi.dims[l + 2], phi.act[l + 1], phi.weight[l + 1], phi.bias[l + 1], p.ty[l], p.tz[l], stream)))
+        return st;
+      cur = p.ty[l];
+    }
+    if (p.reassoc) st = ngpde_gno_apply_forward(g, p.cout, p.kdim, p.T, p.Bh, cur, p.m, stream);
+    else st = ngpde_gno_contract_forward(g, p.cin, p.cout, cur, L->h, p.m, stream);
+    if (st) return st;
+  }
+  if ((st = ngpde_segment_reduce_forward(g, p.cout, p.aggr, p.m, p.agg, stream))) return st;
+  return ngpde_bias_act_forward(p.N, p.cout, p.act, p.agg, p.Wh, L->bias, y, p.zt, stream);
+}
+
+int32_t ngpde_gno_layer_backward(const ngpde_graph_t *g, const ngpde_gno_layer_t *L, const float *dy, float *dh, const ngpde_mlp_grad_t *dphi,
+                                 float *dweight, float *dbias, void *workspace, size_t workspace_bytes, ngpde_stream_t stream) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(g != nullptr && L != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer_backward: graph or layer descriptor is NULL");
+  Arena a;
+  a.base = arena_base(workspace);
+  GnoPlan p;
+  int32_t st;
+  if ((st = make_gno_plan(g, *L, true, a, p))) return st;
+  if (g->n_nodes == 0) return NGPDE_OK;
+  const ngpde_mlp_t &phi = L->phi;
+  NGPDE_REQUIRE(dy != nullptr && dphi != nullptr && dweight != nullptr && (L->bias == nullptr || dbias != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_gno_layer_backward: dy or a gradient buffer is NULL");
+  for (int l = 0; l < p.L; ++l)
+    NGPDE_REQUIRE(dphi->dweight[l] != nullptr && (phi.bias[l] == nullptr || dphi->dbias[l] != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
+                  "ngpde_gno_layer_backward: phi.layer_%d without its gradient buffers", l + 1);
+  NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
+                "ngpde_gno_layer_backward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
+  const int32_t one[1] = {1};
+  const size_t N = (size_t)p.N;
+  // ---- the tail y = act.(agg + W h + b): dz is the gradient of the aggregate AND of W h
+  const float *dz = dy;
+  if (p.act != 0 || L->bias) {
+    float *dzo = p.act != 0 ? p.dz : const_cast<float *>(dy);   // identity: the library only sums the columns for the bias
+    if ((st = ngpde_bias_act_backward(p.N, p.cout, p.act, dy, p.zt, dzo, L->bias ? dbias : nullptr, p.ws, p.ws_bytes, stream))) return st;
+    dz = dzo;
+  }
+  const float *hb[1] = {L->h};
+  const int32_t hw[1] = {p.cin};
+  // ---- the message: gradient of the aggregate -> dT, dBh (reassociated) / dh (literal), and the per-edge pre-activation's gradient
+  const float *dlast = nullptr;   // gradient of the last per-edge array the primitives formed (their tail walks back from it)
+  if (p.fused_agg) {
+    const float *dagg = dz;
+    if (p.aggr == NGPDE_AGGR_MEAN) {   // a node's 1 / deg once per node, not once per edge inside the launch
+      hipLaunchKernelGGL(inv_in_degree_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)p.N, g->by_t.rowptr, p.inv);
+      if ((st = ngpde_rows_scale(p.N, p.cout, dz, p.inv, p.dagg_s, stream))) return st;
+      dagg = p.dagg_s;
+    }
+    if ((st = ngpde_gno_message_backward_from_nodes(g, p.cout, p.kdim, NGPDE_AGGR_SUM, p.act1, p.T, p.a, dagg, p.dT, p.has_b2 ? p.dBh : nullptr,
+                                                    (p.ds || p.de) ? p.dzE : nullptr, p.ds ? p.dQ : nullptr, stream)))
+      return st;
+    if (p.ds && (st = ngpde_segment_reduce_forward(g, p.kdim, NGPDE_AGGR_SUM, p.dzE, p.dP, stream))) return st;   // dP = sums of dz by target
+  } else {
+    if ((st = ngpde_segment_reduce_backward(g, p.cout, p.aggr, p.m, p.agg, dz, p.dm, stream))) return st;
+    if (p.fused_msg) {
+      if ((st = ngpde_gno_apply_backward(g, p.cout, p.kdim, p.T, p.a, p.dm, p.dT, p.has_b2 ? p.dBh : nullptr, p.eg[0], stream))) return st;
+      if ((st = ngpde_edge_combine_backward(g, p.kdim, p.act1, p.eg[0], p.a, p.dzE, p.ds ? p.dP : nullptr, p.ds ? p.dQ : nullptr, stream))) return st;
+    } else {
+      const float *last = p.n_mid ? p.ty[p.n_mid - 1] : p.a0;
+      if (p.reassoc) st = ngpde_gno_apply_backward(g, p.cout, p.kdim, p.T, last, p.dm, p.dT, p.has_b2 ? p.dBh : nullptr, p.eg[0], stream);
+      else st = ngpde_gno_contract_backward(g, p.cin, p.cout, last, L->h, p.dm, p.eg[0], p.dxC, p.ws, p.ws_bytes, stream);
+      if (st) return st;
+      dlast = p.eg[0];
+    }
+  }
+  if (!p.fused_msg) {
+    int flip = 1;
+    const float *cur = dlast;
+    for (int l = p.n_mid - 1; l >= 0; --l) {   // phi's layers l + 2 on [E] rows, last first
+      const float *in = l ? p.ty[l - 1] : p.a0;
+      const float *b1[1] = {in};
+      const int32_t w1[1] = {phi.dims[l + 1]};
+      float *dseg[1] = {p.eg[flip]};
+      if ((st = ngpde_dense_backward(p.E, 1, b1, w1, one, phi.dims[l + 2], phi.act[l + 1], phi.weight[l + 1], p.tz[l], cur, dseg, dphi->dweight[l + 1],
+                                     phi.bias[l + 1] ? dphi->dbias[l + 1] : nullptr, p.ws, p.ws_bytes, stream)))
+        return st;
+      cur = p.eg[flip];
+      flip ^= 1;
+    }
+    if ((st = ngpde_edge_combine_backward(g, p.h1, p.act1, cur, p.z0, p.dzE, p.ds ? p.dP : nullptr, p.ds ? p.dQ : nullptr, stream))) return st;
+  }
+  // ---- phi's first layer: the edge features' block, the two node-feature blocks (constants: weight gradients only)
+  if (p.de) {
+    const float *eb[1] = {L->edge_feat};
+    const int32_t ew[1] = {p.de};
+    float *dseg[1] = {nullptr};
+    if ((st = ngpde_dense_backward(p.E, 1, eb, ew, one, p.h1, NGPDE_ACT_IDENTITY, p.wd, nullptr, p.dzE, dseg, p.dwd,
+                                   (!p.ds && phi.bias[0]) ? dphi->dbias[0] : nullptr, p.ws, p.ws_bytes, stream)))
+      return st;
+  }
+  if (p.ds) {
+    const float *sb[1] = {L->node_feat};
+    const int32_t sw[1] = {p.ds};
+    float *dseg[1] = {nullptr};
+    if ((st = ngpde_dense_backward(p.N, 1, sb, sw, one, p.h1, NGPDE_ACT_IDENTITY, p.wa, nullptr, p.dP, dseg, p.dwa, phi.bias[0] ? dphi->dbias[0] : nullptr,
+                                   p.ws, p.ws_bytes, stream)))
+      return st;
+    if ((st = ngpde_dense_backward(p.N, 1, sb, sw, one, p.h1, NGPDE_ACT_IDENTITY, p.wb, nullptr, p.dQ, dseg, p.dwb, nullptr, p.ws, p.ws_bytes, stream))) return st;
+  }
+  float *douts[3];
+  int no = 0;
+  if (p.ds) { douts[no++] = p.dwa; douts[no++] = p.dwb; }
+  if (p.de) douts[no++] = p.dwd;
+  if ((st = ngpde_row_blocks_scatter(p.h1, phi.dims[0], dphi->dweight[0], p.rows.n_seg, p.rows.out_index, p.rows.dst0, p.rows.src0, p.rows.nrows,
+                                     p.rows.sign, p.rows.n_out, douts, p.rows.out_rows, stream)))
+    return st;
+  // ---- the node-level Dense layers that read h: B2 h, W h (in the forward's order), T
+  const bool want_h = dh != nullptr;
+  if (p.has_b2) {
+    float *dseg[1] = {want_h ? p.dxB : nullptr};
+    if ((st = ngpde_dense_backward(p.N, 1, hb, hw, one, p.cout, NGPDE_ACT_IDENTITY, phi.bias[p.L - 1], nullptr, p.dBh, dseg, dphi->dbias[p.L - 1], nullptr,
+                                   p.ws, p.ws_bytes, stream)))
+      return st;
+  }
+  {
+    float *dseg[1] = {want_h ? p.dxW : nullptr};
+    if ((st = ngpde_dense_backward(p.N, 1, hb, hw, one, p.cout, NGPDE_ACT_IDENTITY, L->weight, nullptr, dz, dseg, dweight, nullptr, p.ws, p.ws_bytes, stream)))
+      return st;
+  }
+  if (p.reassoc) {
+    float *dseg[1] = {want_h ? p.dxT : nullptr};
+    if ((st = ngpde_dense_backward(p.N, 1, hb, hw, one, p.cout * p.kdim, NGPDE_ACT_IDENTITY, p.wr, nullptr, p.dT, dseg, p.dwr, nullptr, p.ws, p.ws_bytes,
+                                   stream)))
+      return st;
+    if ((st = ngpde_transpose(p.cin * p.cout, p.kdim, p.dwr, dphi->dweight[p.L - 1], stream))) return st;
+  }
+  if (!want_h) return NGPDE_OK;
+  // dh: the composed layer's order -- T's term + (B2 h's + W h's) reassociated, the contraction's + W h's in the literal form
+  const float coef[1] = {1.f};
+  if (p.reassoc) {
+    const float *inner = p.dxW;
+    if (p.has_b2) {
+      const float *t1[1] = {p.dxW};
+      if ((st = ngpde_rk_stage_combine((int64_t)N * p.cin, 1.f, p.dxB, 1, t1, coef, p.dsum, stream))) return st;
+      inner = p.dsum;
+    }
+    const float *t2[1] = {inner};
+    return ngpde_rk_stage_combine((int64_t)N * p.cin, 1.f, p.dxT, 1, t2, coef, dh, stream);
+  }
+  const float *t3[1] = {p.dxW};
+  return ngpde_rk_stage_combine((int64_t)N * p.cin, 1.f, p.dxC, 1, t3, coef, dh, stream);
 }
 
 }  // extern "C"

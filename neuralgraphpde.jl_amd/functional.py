@@ -929,7 +929,7 @@ class _EdgeLayerFn(torch.autograd.Function):
     every update layer (bias None where the layer has none)."""
 
     @staticmethod
-    def forward(ctx, handle, kind, aggr, consts, phi_acts, upd_acts, n_state, *tensors):
+    def forward(ctx, handle, kind, aggr, consts, phi_acts, upd_acts, grad_on, n_state, *tensors):
         import ctypes as C
         lib = _lib.load()
         _need_cuda(*[t for t in tensors if t is not None], *[t for t in consts.values() if t is not None])
@@ -961,7 +961,9 @@ class _EdgeLayerFn(torch.autograd.Function):
         d.phi = _mlp_struct(pw[0::2], pw[1::2], phi_acts)
         if n_upd:
             d.update = _mlp_struct(uw[0::2], uw[1::2], upd_acts)
-        training = any(ctx.needs_input_grad)
+        # (grad_on: torch.is_grad_enabled() of the CALLER -- under no_grad() a leaf parameter still reports requires_grad, and nothing
+        # is to be kept for a pullback that cannot come)
+        training = grad_on and any(ctx.needs_input_grad)
         dev = state[0].device
         n_nodes = state[0].shape[0]
         out_w = (uw[-2] if n_upd else pw[-2]).shape[1]
@@ -989,7 +991,7 @@ class _EdgeLayerFn(torch.autograd.Function):
         grads = [None] * len(tensors)
         dstate = (C.c_void_p * 4)()
         for k in range(n_state):
-            if ctx.needs_input_grad[7 + k]:
+            if ctx.needs_input_grad[8 + k]:
                 grads[k] = torch.empty_like(tensors[k])
                 dstate[k] = grads[k].data_ptr()
         gphi, gupd = _lib.MlpGrad(), _lib.MlpGrad()
@@ -1003,7 +1005,7 @@ class _EdgeLayerFn(torch.autograd.Function):
         _lib.check(lib.ngpde_edge_layer_backward(ctx.handle.ptr, C.byref(ctx.desc), _lib.ptr(dy), dstate, C.byref(gphi), C.byref(gupd),
                                                  _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.current_stream()))
         ctx.ws = None          # (the workspace holds every saved activation: let it go with the node)
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
 def edge_layer(handle, kind, aggr, state, phi, update=(), node_feat=None, pos=None, edge_feat=None, theta=None):
@@ -1013,7 +1015,86 @@ def edge_layer(handle, kind, aggr, state, phi, update=(), node_feat=None, pos=No
         tensors += [wt, b]
     consts = {"node_feat": node_feat, "pos": pos, "edge_feat": edge_feat, "theta": theta}
     return _EdgeLayerFn.apply(handle, int(kind), _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr), consts,
-                              tuple(a for _, _, a in phi), tuple(a for _, _, a in update), len(state), *tensors)
+                              tuple(a for _, _, a in phi), tuple(a for _, _, a in update), torch.is_grad_enabled(), len(state), *tensors)
+
+
+class _GnoLayerFn(torch.autograd.Function):
+    """GNOConv in ONE library call (ngpde_gno_layer_forward), its pullback in one (ngpde_gno_layer_backward).
+    tensors = h, linear weight, linear bias (or None), then (weight, bias) of every phi layer."""
+
+    @staticmethod
+    def forward(ctx, handle, cin, cout, aggr, act, consts, phi_acts, grad_on, *tensors):
+        import ctypes as C
+        lib = _lib.load()
+        _need_cuda(*[t for t in tensors if t is not None], *[t for t in consts.values() if t is not None])
+        tensors = [None if t is None else t.contiguous() for t in tensors]
+        h, lwt, lb = tensors[:3]
+        pw = tensors[3:]
+        n_phi = len(phi_acts)
+        for l in range(1, n_phi):
+            if pw[2 * l].shape[0] != pw[2 * l - 2].shape[1]:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: Dense expects {pw[2 * l].shape[0]} input "
+                                             f"features, got {pw[2 * l - 2].shape[1]}")
+        if tuple(lwt.shape) != (cin, cout) or h.shape[1] != cin:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: Dense expects {lwt.shape[0]} input features, got {h.shape[1]}")
+        d = _lib.GnoLayer()
+        d.in_chs, d.out_chs, d.aggr, d.act = cin, cout, aggr, act
+        d.h, d.weight, d.bias = h.data_ptr(), lwt.data_ptr(), (lb.data_ptr() if lb is not None else None)
+        keep = []
+        for name in ("node_feat", "edge_feat"):
+            t = consts.get(name)
+            if t is not None and t.shape[1] > 0:
+                t = t.contiguous()
+                keep.append(t)
+                setattr(d, name, t.data_ptr())
+                setattr(d, name + "_width", t.shape[1])
+        d.phi = _mlp_struct(pw[0::2], pw[1::2], phi_acts)
+        # (grad_on: torch.is_grad_enabled() of the CALLER -- under no_grad() a leaf parameter still reports requires_grad, and nothing
+        # is to be kept for a pullback that cannot come)
+        training = grad_on and any(ctx.needs_input_grad)
+        dev = h.device
+        ws = _ws(int(lib.ngpde_gno_layer_workspace_bytes(handle.ptr, C.byref(d), int(training))), dev)
+        y = torch.empty((h.shape[0], cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_layer_forward(handle.ptr, C.byref(d), int(training), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        if training:
+            ctx.desc, ctx.ws, ctx.keep, ctx.handle, ctx.n_phi = d, ws, keep, handle, n_phi
+            ctx.present = [t is not None for t in tensors]
+            ctx.save_for_backward(*[t for t in tensors if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        lib = _lib.load()
+        it = iter(ctx.saved_tensors)
+        tensors = [next(it) if pr else None for pr in ctx.present]
+        grads = [None] * len(tensors)
+        dy = dy.contiguous()
+        if ctx.needs_input_grad[8]:
+            grads[0] = torch.empty_like(tensors[0])
+        grads[1] = torch.empty_like(tensors[1])
+        if tensors[2] is not None:
+            grads[2] = torch.empty_like(tensors[2])
+        gphi = _lib.MlpGrad()
+        for l in range(ctx.n_phi):
+            grads[3 + 2 * l] = torch.empty_like(tensors[3 + 2 * l])
+            gphi.dweight[l] = grads[3 + 2 * l].data_ptr()
+            if tensors[4 + 2 * l] is not None:
+                grads[4 + 2 * l] = torch.empty_like(tensors[4 + 2 * l])
+                gphi.dbias[l] = grads[4 + 2 * l].data_ptr()
+        _lib.check(lib.ngpde_gno_layer_backward(ctx.handle.ptr, C.byref(ctx.desc), _lib.ptr(dy), _lib.ptr(grads[0]), C.byref(gphi), _lib.ptr(grads[1]),
+                                                _lib.ptr(grads[2]), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.current_stream()))
+        ctx.ws = None
+        return (None, None, None, None, None, None, None, None, *grads)
+
+
+def gno_layer(handle, cin, cout, aggr, act, h, lwt, lb, phi, node_feat=None, edge_feat=None):
+    """phi: list of (weight [in][out], bias or None, activation code); lwt [in][out], lb [out] or None.  Returns [N][out]."""
+    tensors = [h, lwt, lb]
+    for wt, b, _ in phi:
+        tensors += [wt, b]
+    return _GnoLayerFn.apply(handle, int(cin), int(cout), _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr), int(act),
+                             {"node_feat": node_feat, "edge_feat": edge_feat}, tuple(a for _, _, a in phi), torch.is_grad_enabled(), *tensors)
 
 
 # ---- weight-sized rearrangements as library launches (row_blocks.hip) ---------------------------------------------------------

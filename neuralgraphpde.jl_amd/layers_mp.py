@@ -317,6 +317,18 @@ class GNOConv(AbstractGNNContainerLayer):
         h = rows_of(x)
         dev = h.device
         _check_nodes(h, g)
+        if os.environ.get("NGPDE_LAYERS_COMPOSED") == "1":
+            return self._composed(h, ps, st)
+        handle = g.handle()
+        lwt, lb = _wt_b(ps["linear"])
+        y = F.gno_layer(handle, self.in_chs, self.out_chs, self.aggr, self.linear.act, h, lwt, lb, _stack_spec(_dense_stack(self.ϕ, ps["ϕ"], "ϕ")),
+                        node_feat=g.packed("ndata", dev), edge_feat=_edge_data_p(g, handle, dev))       # :517-547
+        return y.T, st
+
+    def _composed(self, h, ps, st):
+        """composed from the primitives' autograd nodes (NGPDE_LAYERS_COMPOSED=1)"""
+        g = st["graph"]
+        dev = h.device
         handle = g.handle()
         N, E = g.num_nodes, g.num_edges
         s = g.packed("ndata", dev)                                                 # :517-519

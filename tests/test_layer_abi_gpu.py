@@ -142,6 +142,33 @@ def test_entry_follows_the_librarys_path_switches(switch, monkeypatch):
     assert_same(both_ways(layer, torch.randn(1, 640, device=DEV), 41, monkeypatch))
 
 
+@pytest.mark.parametrize("variant,aggr", [("two-layer", "mean"), ("two-layer", "+"), ("two-layer", "max"), ("three-layer", "mean"), ("materialized", "mean"),
+                                          ("single-dense", "+"), ("no-bias", "mean"), ("tanh-first", "mean"), ("edge-only", "mean")])
+def test_gno_entry_equals_the_composed_layer(variant, aggr, monkeypatch):
+    # GNOConv (src/layers.jl:509-547) through ngpde_gno_layer_*: the reassociated message with its per-edge input formed in the launch
+    # (two-layer phi, relu / identity first), on the primitives (deeper phi, other first activations), the literal batched_mul
+    cin, cout, k = 16, 32, 16
+    g = spatial(600, 13, ndata_extra=1, edata=2)          # ndata = (x (2), f0 (1)) -> s has 3 rows; edata e (2)
+    ds, de = 3, 2
+    if variant == "edge-only":
+        g = ng.GNNGraph(*g.edge_index(0), num_nodes=600, index_base=0, edata=dict(g.edata))
+        ds = 0
+    if variant == "materialized":
+        monkeypatch.setenv("NGPDE_GNO_MATERIALIZE", "1")
+    first = "tanh" if variant == "tanh-first" else "relu"
+    if variant == "three-layer":
+        phi = ng.Chain(ng.Dense(2 * ds + de, 24, first), ng.Dense(24, k, "swish"), ng.Dense(k, cin * cout))
+    elif variant == "single-dense":
+        phi = ng.Dense(2 * ds + de, cin * cout)
+    else:
+        phi = ng.Chain(ng.Dense(2 * ds + de, k, first), ng.Dense(k, cin * cout, bias=(variant != "no-bias")))
+    layer = ng.GNOConv((cin, cout), phi, "swish" if variant in ("three-layer", "no-bias") else "relu", initialgraph=g, aggr=aggr,
+                       bias=(variant != "no-bias"))
+    x = torch.randn(cin, 600, device=DEV)
+    assert_same(both_ways(layer, x, 51, monkeypatch))
+    assert_same(both_ways(layer, x, 51, monkeypatch, training=False))
+
+
 def test_entry_rejects_what_the_reference_rejects():
     lib = _lib.load()
     g = spatial(64, 2)
