@@ -1,7 +1,7 @@
-/* Plain-C caller of the layer-level entries (include/ngpde.h: ngpde_edge_layer_*): an MPPDEConv, a VMHConv and an
- * ExplicitEdgeConv layer, forward and pullback with ONE call each -- what the Julia shim of INTEGRATION.md binds.
+/* Plain-C caller of the layer-level entries (include/ngpde.h: ngpde_edge_layer_*, ngpde_gno_layer_*): an MPPDEConv, a VMHConv, an
+ * ExplicitEdgeConv and a GNOConv layer, forward and pullback with ONE call each -- what the Julia shim of INTEGRATION.md binds.
  * Checker: double-precision loops written from the reference's definitions, on the CONCATENATED message inputs exactly as
- * /root/reference/src/layers.jl:106, :316-328, :409-418 build them (so the library's split of phi's first weight into signed
+ * /root/reference/src/layers.jl:106, :316-328, :409-418, :523-536 build them (so the library's split of phi's first weight into signed
  * row blocks is checked against the unsplit form), for the values; for the gradients, central differences of those loops along
  * random directions in (state, every weight, every bias) against the inner product of the library's gradients with the direction.
  * No Python, torch or C++ on the calling side.  Exit code 0 = every comparison within tolerance.  Run by tests/test_c_abi_gpu.py. */
@@ -113,6 +113,41 @@ static void model_forward(const Model *M, double *y) {
   }
   free(agg);
   free(deg);
+}
+
+/* ---- GNOConv (:509-547): K_e = reshape(phi([s_i; s_j; e]), out, in) column-major, m_i = mean_j K_e h_j, y = act.(W h + m + b) -------- */
+typedef struct {
+  int n, e, cin, cout, sw, ew, act;
+  const int64_t *s, *t;
+  double *h, *feat, *efeat, *W, *b;   /* W [in][out] */
+  Mlp phi;
+} Gno;
+static void gno_forward(const Gno *M, double *y) {
+  const int kw = M->cin * M->cout;
+  double *agg = calloc((size_t)M->n * M->cout, sizeof(double));
+  int *deg = calloc(M->n, sizeof(int));
+  double in[64], *K = malloc(sizeof(double) * kw), tmp[512];
+  for (int k = 0; k < M->e; ++k) {
+    const int i = (int)M->t[k], j = (int)M->s[k];
+    int c = 0;
+    for (int f = 0; f < M->sw; ++f) in[c++] = M->feat[(size_t)i * M->sw + f];
+    for (int f = 0; f < M->sw; ++f) in[c++] = M->feat[(size_t)j * M->sw + f];
+    for (int f = 0; f < M->ew; ++f) in[c++] = M->efeat[(size_t)k * M->ew + f];
+    mlp_apply(&M->phi, in, K, tmp);
+    for (int o = 0; o < M->cout; ++o) {
+      double v = 0;
+      for (int q = 0; q < M->cin; ++q) v += K[o + M->cout * q] * M->h[(size_t)j * M->cin + q];   /* K_e[o, q] = phi_out[o + out * q] */
+      agg[(size_t)i * M->cout + o] += v;
+    }
+    ++deg[i];
+  }
+  for (int i = 0; i < M->n; ++i)
+    for (int o = 0; o < M->cout; ++o) {
+      double z = (deg[i] ? agg[(size_t)i * M->cout + o] / deg[i] : 0.0) + M->b[o];
+      for (int q = 0; q < M->cin; ++q) z += M->W[(size_t)q * M->cout + o] * M->h[(size_t)i * M->cin + q];
+      y[(size_t)i * M->cout + o] = act_f(M->act, z);
+    }
+  free(agg); free(deg); free(K);
 }
 
 /* ---- plumbing -------------------------------------------------------------------------------------------------------------- */
@@ -250,6 +285,102 @@ static int run_case(const char *name, ngpde_graph_t *g, Model *M) {
   return 0;
 }
 
+static int run_gno(ngpde_graph_t *g, Gno *M) {
+  const size_t ny = (size_t)M->n * M->cout;
+  ngpde_gno_layer_t L;
+  memset(&L, 0, sizeof L);
+  L.in_chs = M->cin; L.out_chs = M->cout; L.aggr = NGPDE_AGGR_MEAN; L.act = M->act;
+  L.h = dev_from_double(M->h, (size_t)M->n * M->cin);
+  L.node_feat = dev_from_double(M->feat, (size_t)M->n * M->sw); L.node_feat_width = M->sw;
+  {
+    float *coo = dev_from_double(M->efeat, (size_t)M->e * M->ew), *p = NULL;
+    CHECK_HIP(hipMalloc((void **)&p, sizeof(float) * (size_t)M->e * M->ew));
+    CHECK_NG(ngpde_edge_permute(g, M->ew, 0, coo, p, NULL));
+    L.edge_feat = p; L.edge_feat_width = M->ew;
+  }
+  L.weight = dev_from_double(M->W, (size_t)M->cin * M->cout);
+  L.bias = dev_from_double(M->b, M->cout);
+  Var vars[3 + 2 * MAXL];
+  int nv = 0;
+  float *dh_d = NULL, *dW_d = NULL, *db_d = NULL;
+  CHECK_HIP(hipMalloc((void **)&dh_d, sizeof(float) * (size_t)M->n * M->cin));
+  CHECK_HIP(hipMalloc((void **)&dW_d, sizeof(float) * (size_t)M->cin * M->cout));
+  CHECK_HIP(hipMalloc((void **)&db_d, sizeof(float) * M->cout));
+  vars[nv++] = (Var){M->h, (size_t)M->n * M->cin, dh_d};
+  vars[nv++] = (Var){M->W, (size_t)M->cin * M->cout, dW_d};
+  vars[nv++] = (Var){M->b, (size_t)M->cout, db_d};
+  ngpde_mlp_grad_t gphi;
+  memset(&gphi, 0, sizeof gphi);
+  L.phi.n_layers = M->phi.n_layers;
+  for (int l = 0; l <= M->phi.n_layers; ++l) L.phi.dims[l] = M->phi.dims[l];
+  for (int l = 0; l < M->phi.n_layers; ++l) {
+    const size_t nw = (size_t)M->phi.dims[l] * M->phi.dims[l + 1];
+    L.phi.act[l] = M->phi.act[l];
+    L.phi.weight[l] = dev_from_double(M->phi.w[l], nw);
+    L.phi.bias[l] = dev_from_double(M->phi.b[l], M->phi.dims[l + 1]);
+    CHECK_HIP(hipMalloc((void **)&gphi.dweight[l], sizeof(float) * nw));
+    CHECK_HIP(hipMalloc((void **)&gphi.dbias[l], sizeof(float) * M->phi.dims[l + 1]));
+    vars[nv++] = (Var){M->phi.w[l], nw, gphi.dweight[l]};
+    vars[nv++] = (Var){M->phi.b[l], (size_t)M->phi.dims[l + 1], gphi.dbias[l]};
+  }
+  const size_t wsb = ngpde_gno_layer_workspace_bytes(g, &L, 1);
+  if (!wsb) { fprintf(stderr, "GNOConv: workspace query failed: %s\n", ngpde_last_error()); return 4; }
+  void *ws = NULL;
+  float *y_d = NULL;
+  CHECK_HIP(hipMalloc(&ws, wsb));
+  CHECK_HIP(hipMalloc((void **)&y_d, sizeof(float) * ny));
+  double *R = rand_d(ny, 1.0);
+  float *dy_d = dev_from_double(R, ny);
+  CHECK_NG(ngpde_gno_layer_forward(g, &L, 1, y_d, ws, wsb, NULL));
+  CHECK_NG(ngpde_gno_layer_backward(g, &L, dy_d, dh_d, &gphi, dW_d, db_d, ws, wsb, NULL));
+  CHECK_HIP(hipDeviceSynchronize());
+  float *y = malloc(sizeof(float) * ny);
+  CHECK_HIP(hipMemcpy(y, y_d, sizeof(float) * ny, hipMemcpyDeviceToHost));
+  double *yo = malloc(sizeof(double) * ny), *yp = malloc(sizeof(double) * ny), *ym = malloc(sizeof(double) * ny);
+  gno_forward(M, yo);
+  double err = 0, ref = 0;
+  for (size_t i = 0; i < ny; ++i) {
+    if (fabs(y[i] - yo[i]) > err) err = fabs(y[i] - yo[i]);
+    if (fabs(yo[i]) > ref) ref = fabs(yo[i]);
+  }
+  char label[128];
+  snprintf(label, sizeof label, "GNOConv forward (%zu KB workspace)", wsb >> 10);
+  report(label, err / ref, 1e-4);
+  for (int trial = 0; trial < 3; ++trial) {   /* 0: everything; 1: h only; 2: phi only */
+    const int lo = trial == 2 ? 3 : 0, hi = trial == 1 ? 1 : nv;
+    const double eps = 1e-5;
+    double analytic = 0, scale = 0;
+    double *dir[3 + 2 * MAXL];
+    for (int v = lo; v < hi; ++v) {
+      dir[v] = malloc(sizeof(double) * vars[v].n);
+      float *gh = malloc(sizeof(float) * vars[v].n);
+      CHECK_HIP(hipMemcpy(gh, vars[v].grad_dev, sizeof(float) * vars[v].n, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < vars[v].n; ++i) {
+        dir[v][i] = rnd();
+        analytic += (double)gh[i] * dir[v][i];
+        scale += fabs((double)gh[i] * dir[v][i]);
+      }
+      free(gh);
+    }
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      for (int v = lo; v < hi; ++v)
+        for (size_t i = 0; i < vars[v].n; ++i) vars[v].ptr[i] += sgn * eps * dir[v][i];
+      gno_forward(M, sgn > 0 ? yp : ym);
+      for (int v = lo; v < hi; ++v)
+        for (size_t i = 0; i < vars[v].n; ++i) vars[v].ptr[i] -= sgn * eps * dir[v][i];
+    }
+    double fd = 0;
+    for (size_t i = 0; i < ny; ++i) fd += R[i] * (yp[i] - ym[i]) / (2 * eps);
+    for (int v = lo; v < hi; ++v) free(dir[v]);
+    static const char *what[3] = {"all gradients", "d h", "d phi"};
+    snprintf(label, sizeof label, "GNOConv pullback, %s", what[trial]);
+    report(label, fabs(analytic - fd) / (scale > 1e-30 ? scale : 1e-30), 2e-4);
+  }
+  free(y); free(yo); free(yp); free(ym); free(R);
+  CHECK_HIP(hipFree(ws));
+  return 0;
+}
+
 int main(void) {
   printf("%s\n", ngpde_version());
   /* ---- MPPDEConv on a batch of 3 periodic meshes of 96 nodes (reach 2), one node feature, two edge features, theta of width 2 */
@@ -303,6 +434,31 @@ int main(void) {
       mlp_init(&M.upd, 3, ud, ua);
     }
     int rc = run_case(kind == NGPDE_LAYER_VMH ? "VMHConv" : "ExplicitEdgeConv", g, &M);
+    if (rc) return rc;
+    CHECK_NG(ngpde_graph_destroy(g));
+  }
+  /* ---- GNOConv 8 => 16 on the same ring: 2-d node coordinates, one edge feature, phi = Dense(5 => 16, relu) -> Dense(16 => 128) */
+  {
+    const int n = 200, e = 5 * n;
+    int64_t *s = malloc(sizeof(int64_t) * e), *t = malloc(sizeof(int64_t) * e);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      const int a = (i + 1) % n, b = (i + 7) % n, c = (i + 31) % n;
+      s[m] = i; t[m++] = a; s[m] = a; t[m++] = i;
+      s[m] = i; t[m++] = b; s[m] = b; t[m++] = i;
+      s[m] = i; t[m++] = c;
+    }
+    ngpde_graph_t *g = NULL;
+    CHECK_NG(ngpde_graph_create(n, e, s, t, 0, 1, &g));
+    Gno M;
+    memset(&M, 0, sizeof M);
+    M.n = n; M.e = e; M.s = s; M.t = t; M.cin = 8; M.cout = 16; M.sw = 2; M.ew = 1; M.act = NGPDE_ACT_TANH;
+    M.h = rand_d((size_t)n * M.cin, 1.0); M.feat = rand_d((size_t)n * M.sw, 1.0); M.efeat = rand_d((size_t)e * M.ew, 1.0);
+    M.W = rand_d((size_t)M.cin * M.cout, 0.4); M.b = rand_d(M.cout, 0.2);
+    const int pd[3] = {2 * 2 + 1, 16, 8 * 16}, pa[2] = {NGPDE_ACT_RELU, NGPDE_ACT_IDENTITY};
+    mlp_init(&M.phi, 2, pd, pa);
+    for (size_t i = 0; i < (size_t)pd[1] * pd[2]; ++i) M.phi.w[1][i] *= 0.3;
+    int rc = run_gno(g, &M);
     if (rc) return rc;
     CHECK_NG(ngpde_graph_destroy(g));
   }

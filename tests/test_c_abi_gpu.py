@@ -43,13 +43,13 @@ def exe_layers(tmp_path_factory):
 
 
 def test_layer_level_entries_from_plain_c(exe_layers):
-    # MPPDEConv, VMHConv, ExplicitEdgeConv: forward and pullback with ONE call each (ngpde_edge_layer_*), values against double-precision
+    # MPPDEConv, VMHConv, ExplicitEdgeConv, GNOConv: forward and pullback with ONE call each (ngpde_edge_layer_*, ngpde_gno_layer_*), values against double-precision
     # loops on the concatenated message inputs, gradients against central differences of those loops
     env = {k: v for k, v in os.environ.items() if not k.startswith("NGPDE_")}
     r = subprocess.run([exe_layers], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "FAIL" not in r.stdout and "all comparisons within tolerance" in r.stdout
-    for name in ("MPPDEConv", "VMHConv", "ExplicitEdgeConv"):
+    for name in ("MPPDEConv", "VMHConv", "ExplicitEdgeConv", "GNOConv"):
         assert f"{name} forward" in r.stdout and f"{name} pullback, all gradients" in r.stdout, r.stdout
 
 
