@@ -274,16 +274,18 @@ __global__ __launch_bounds__(256, NOB == 8 ? 4 : 2) void gno_apply_mfma_bwd_kern
         }
       }
       if (dT) {
-        // dT[o][kk] += sum_e DM[e][o] Z[e][kk]: the edge index is the contraction (zero rows beyond nb add nothing)
+        // dT[o][kk] += sum_e DM[e][o] Z[e][kk]: the edge index is the contraction (zero rows beyond nb add nothing).  A wave's tiles
+        // (ids wave, wave + 4, ...; NKT divides 4) all have k tile ktw, so a contraction step reads its z value ONCE for the wave's
+        // eight out tiles and its eight dm values feed eight independent accumulator chains (the tile-outer form read both
+        // operands per product: 16 LDS reads per 8 products instead of 9, each product waiting on its own pair)
+        for (int es = 0; es < net * 4; ++es) {   // 4-edge contraction steps, in edge order per accumulator as before
+          const int e = 4 * es + kq;
+          const float zv = zl[e * ZS + ktw * 16 + i];
+          const float *drow = dml + e * DS + i;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const int id = wave + 4 * (t + MAXT * sweep);
-          if (id < ntile) {   // wave-uniform
-            const int ot = id / NKT, kt = id - ot * NKT;
-            for (int es = 0; es < net * 4; ++es) {  // 4-edge contraction steps
-              const int e = 4 * es + kq;
-              acc[t] = mfma16(dml[e * DS + ot * 16 + i], zl[e * ZS + kt * 16 + i], acc[t]);
-            }
+          for (int t = 0; t < MAXT; ++t) {
+            const int id = wave + 4 * (t + MAXT * sweep);
+            if (id < ntile) acc[t] = mfma16(drow[(id / NKT) * 16], zv, acc[t]);   // wave-uniform
           }
         }
       }

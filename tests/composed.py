@@ -1,0 +1,982 @@
+"""Test infrastructure: the edge-function layers COMPOSED from the library's primitives, one autograd node per primitive -- the host
+path of rounds 1 - 4 (then neuralgraphpde.jl_amd/functional.py + layers_mp.py).  The product calls the layer-level C entries
+(ngpde_edge_layer_*, ngpde_gno_layer_*) instead; this module stays as their checker (tests/test_layer_abi_gpu.py compares bit for
+bit) and as the Python face of the primitive entries for the tests and tools that time or test them one by one.
+Tensors are in KERNEL layout: features [N][D] row-major float32 on the GPU, weights [in][out]."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from ngpde_amd import _lib
+from ngpde_amd.functional import *          # noqa: F401,F403  (dense, bias_act, edge_permute, gat_*, ... : the product's wrappers)
+from ngpde_amd.functional import _int_array, _need_cuda, _ptr_array, _ws
+
+
+def _check_blocks(blocks, row_divs, n, wt):
+    widths = [b.shape[1] for b in blocks]
+    if wt.shape[0] != sum(widths):
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     f"DimensionMismatch: Dense expects {wt.shape[0]} input features, got {sum(widths)}")
+    for b, rd in zip(blocks, row_divs):
+        if b.shape[0] * rd != n and not (rd > 1 and b.shape[0] * rd >= n):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: block with {b.shape[0]} rows (x{rd}) does not cover {n} rows")
+    return widths
+
+
+def _dense_backward_call(lib, n, blocks, widths, row_divs, dout, act, wt, z, dy, want, has_bias):
+    """one ngpde_dense_backward: returns (dwt, db, [dblock or None])"""
+    dev = wt.device
+    dwt = torch.empty_like(wt)
+    db = torch.empty((dout,), dtype=torch.float32, device=dev) if has_bias else None
+    dblocks = [torch.empty_like(b) if (w and rd == 1) else None for b, w, rd in zip(blocks, want, row_divs)]
+    ws = _ws(lib.ngpde_dense_workspace_bytes(n, sum(widths), dout), dev)
+    _lib.check(lib.ngpde_dense_backward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs),
+                                        dout, act, _lib.ptr(wt), _lib.ptr(z), _lib.ptr(dy), _ptr_array(dblocks),
+                                        _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    return dwt, db, dblocks
+
+
+class _DensePairFn(torch.autograd.Function):
+    """(ya, yb[, x]) = (Dense_a(blocks_a), Dense_b(blocks_b)[, blocks_a[0]]): ngpde_dense_pair_forward -- one pass over a shared
+    leading 64-wide block (the node-level target / source halves of a message MLP's first layer), two launches otherwise.
+    passthrough: the shared block comes back as a third output; a consumer that reads it through that output (the node update
+    psi of MPPDEConv) delivers its gradient HERE, where ngpde_dense_pair_backward adds it while it writes the block's gradient --
+    no separate accumulation pass over the [N][64] arrays."""
+
+    @staticmethod
+    def forward(ctx, wta, ba, acta, rda, wtb, bb, actb, rdb, n, na, passthrough, *blocks):
+        lib = _lib.load()
+        _need_cuda(wta, ba, wtb, bb, *blocks)
+        x_in = blocks[0]
+        blocks = [b.contiguous() for b in blocks]
+        wta, wtb = wta.contiguous(), wtb.contiguous()
+        A, B = blocks[:na], blocks[na:]
+        wa, wb = _check_blocks(A, rda, n, wta), _check_blocks(B, rdb, n, wtb)
+        dev = wta.device
+        ya = torch.empty((n, wta.shape[1]), dtype=torch.float32, device=dev)
+        yb = torch.empty((n, wtb.shape[1]), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        za = torch.empty_like(ya) if (need and acta != 0) else None
+        zb = torch.empty_like(yb) if (need and actb != 0) else None
+        _lib.check(lib.ngpde_dense_pair_forward(
+            n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), wta.shape[1], acta, _lib.ptr(wta), _lib.ptr(ba), _lib.ptr(ya),
+            _lib.ptr(za), len(B), _ptr_array(B), _int_array(wb), _int_array(rdb), wtb.shape[1], actb, _lib.ptr(wtb), _lib.ptr(bb),
+            _lib.ptr(yb), _lib.ptr(zb), _lib.current_stream()))
+        ctx.meta = (acta, tuple(rda), actb, tuple(rdb), n, na, wa, wb, ba is not None, bb is not None, passthrough)
+        ctx.set_materialize_grads(False)   # an unused pass-through output must not cost a zero array and an addend read
+        ctx.save_for_backward(wta, wtb, za, zb, *blocks)
+        if passthrough:
+            return ya, yb, x_in.view_as(x_in)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb, dxp=None):
+        lib = _lib.load()
+        acta, rda, actb, rdb, n, na, wa, wb, has_ba, has_bb, passthrough = ctx.meta
+        wta, wtb, za, zb, *blocks = ctx.saved_tensors
+        A, B = blocks[:na], blocks[na:]
+        want = ctx.needs_input_grad[11:]
+        dev = wta.device
+        if dya is None:
+            dya = torch.zeros((n, wta.shape[1]), dtype=torch.float32, device=dev)
+        if dyb is None:
+            dyb = torch.zeros((n, wtb.shape[1]), dtype=torch.float32, device=dev)
+        dya, dyb = dya.contiguous(), dyb.contiguous()
+        if dxp is not None:
+            dxp = dxp.contiguous()
+        # one launch for both pullbacks when the pair shares its 64-wide leading block and only that block wants a gradient:
+        # dx arrives already summed, the pass-through consumer's gradient included (ngpde_dense_pair_backward)
+        shared = (acta == 0 and actb == 0 and wta.shape[1] == 64 and wtb.shape[1] == 64 and A[0].data_ptr() == B[0].data_ptr()
+                  and (want[0] or want[na]) and not any(w and rd == 1 for w, rd in zip(want[1:na], rda[1:]))
+                  and not any(w and rd == 1 for w, rd in zip(want[na + 1:], rdb[1:])))
+        if shared:
+            wsb = int(lib.ngpde_dense_pair_backward_workspace_bytes(n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), len(B),
+                                                                    _ptr_array(B), _int_array(wb), _int_array(rdb), 64))
+            if wsb > 0:
+                dwta, dwtb = torch.empty_like(wta), torch.empty_like(wtb)
+                dba = torch.empty((64,), dtype=torch.float32, device=dev) if has_ba else None
+                dbb = torch.empty((64,), dtype=torch.float32, device=dev) if has_bb else None
+                dx = torch.empty_like(A[0])
+                ws = _ws(wsb, dev)
+                _lib.check(lib.ngpde_dense_pair_backward(
+                    n, len(A), _ptr_array(A), _int_array(wa), _int_array(rda), _lib.ptr(wta), _lib.ptr(dya), _lib.ptr(dwta), _lib.ptr(dba),
+                    len(B), _ptr_array(B), _int_array(wb), _int_array(rdb), _lib.ptr(wtb), _lib.ptr(dyb), _lib.ptr(dwtb), _lib.ptr(dbb),
+                    64, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+                dA, dB = [None] * len(A), [None] * len(B)
+                if want[0]:
+                    dA[0] = dx
+                else:
+                    dB[0] = dx
+                return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, None, *dA, *dB)
+        dwta, dba, dA = _dense_backward_call(lib, n, A, wa, rda, wta.shape[1], acta, wta, za, dya, want[:na], has_ba)
+        dwtb, dbb, dB = _dense_backward_call(lib, n, B, wb, rdb, wtb.shape[1], actb, wtb, zb, dyb, want[na:], has_bb)
+        if dxp is not None and want[0]:
+            if dA[0] is None:
+                dA[0] = dxp
+            else:                    # one library launch (the Runge-Kutta combination kernel: out = 1 * base + 1 * term), no torch add
+                import ctypes as C
+                out = torch.empty_like(dA[0])
+                _lib.check(lib.ngpde_rk_stage_combine(out.numel(), 1.0, _lib.ptr(dA[0].contiguous()), 1, (C.c_void_p * 1)(dxp.data_ptr()),
+                                                      (C.c_float * 1)(1.0), _lib.ptr(out), _lib.current_stream()))
+                dA[0] = out
+        return (dwta, dba, None, None, dwtb, dbb, None, None, None, None, None, *dA, *dB)
+
+
+def dense_pair(blocks_a, wta, ba, acta, blocks_b, wtb, bb, actb, row_divs_a=None, row_divs_b=None, n=None, passthrough=False):
+    """Two Dense layers whose block lists start with the same tensor; returns (ya, yb), with passthrough=True (ya, yb, x) where x
+    is blocks_a[0] routed through this node (use it for further consumers of the block: their gradient is then folded into the
+    block's gradient by the pair's own pullback launch)."""
+    rda = list(row_divs_a) if row_divs_a is not None else [1] * len(blocks_a)
+    rdb = list(row_divs_b) if row_divs_b is not None else [1] * len(blocks_b)
+    if n is None:
+        n = next(b.shape[0] for b, rd in zip(blocks_a, rda) if rd == 1)
+    return _DensePairFn.apply(wta, ba, acta, tuple(rda), wtb, bb, actb, tuple(rdb), int(n), len(blocks_a), bool(passthrough),
+                              *blocks_a, *blocks_b)
+
+
+class _DenseChain2Fn(torch.autograd.Function):
+    """y = act2(act1([X1 | ...] W1t + b1) W2t + b2): ngpde_dense_chain2_forward -- the intermediate stays on chip when the shape
+    allows (inference: nothing but y is written; training keeps z1 / a1 for the two pullbacks)."""
+
+    @staticmethod
+    def forward(ctx, wt1, b1, act1, wt2, b2, act2, row_divs, n, *blocks):
+        lib = _lib.load()
+        _need_cuda(wt1, b1, wt2, b2, *blocks)
+        blocks = [b.contiguous() for b in blocks]
+        wt1, wt2 = wt1.contiguous(), wt2.contiguous()
+        widths = _check_blocks(blocks, row_divs, n, wt1)
+        dmid, dout = wt1.shape[1], wt2.shape[1]
+        if wt2.shape[0] != dmid:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"DimensionMismatch: second Dense expects {wt2.shape[0]} input features, got {dmid}")
+        dev = wt1.device
+        need = any(ctx.needs_input_grad)
+        fused = bool(lib.ngpde_dense_chain2_fused(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs), dmid, dout))
+        y = torch.empty((n, dout), dtype=torch.float32, device=dev)
+        a1 = torch.empty((n, dmid), dtype=torch.float32, device=dev) if (need or not fused) else None
+        z1 = torch.empty((n, dmid), dtype=torch.float32, device=dev) if (need and act1 != 0) else None
+        z2 = torch.empty_like(y) if (need and act2 != 0) else None
+        _lib.check(lib.ngpde_dense_chain2_forward(n, len(blocks), _ptr_array(blocks), _int_array(widths), _int_array(row_divs), dmid, act1,
+                                                  _lib.ptr(wt1), _lib.ptr(b1), _lib.ptr(a1), _lib.ptr(z1), dout, act2, _lib.ptr(wt2),
+                                                  _lib.ptr(b2), _lib.ptr(y), _lib.ptr(z2), _lib.current_stream()))
+        ctx.meta = (act1, act2, tuple(row_divs), n, widths, dmid, dout, b1 is not None, b2 is not None)
+        ctx.save_for_backward(wt1, wt2, a1, z1, z2, *blocks)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        act1, act2, row_divs, n, widths, dmid, dout, has_b1, has_b2 = ctx.meta
+        wt1, wt2, a1, z1, z2, *blocks = ctx.saved_tensors
+        dwt2, db2, (da1,) = _dense_backward_call(lib, n, [a1], [dmid], [1], dout, act2, wt2, z2, dy.contiguous(), [True], has_b2)
+        dwt1, db1, dblocks = _dense_backward_call(lib, n, blocks, widths, row_divs, dmid, act1, wt1, z1, da1, ctx.needs_input_grad[8:], has_b1)
+        return (dwt1, db1, None, dwt2, db2, None, None, None, *dblocks)
+
+
+def dense_chain2(blocks, wt1, b1, act1, wt2, b2, act2, row_divs=None, n=None):
+    """Chain(Dense, Dense) on a virtual vcat of blocks; returns [n][dout2]."""
+    row_divs = list(row_divs) if row_divs is not None else [1] * len(blocks)
+    if n is None:
+        n = next(b.shape[0] for b, rd in zip(blocks, row_divs) if rd == 1)
+    return _DenseChain2Fn.apply(wt1, b1, act1, wt2, b2, act2, tuple(row_divs), int(n), *blocks)
+
+
+class _EdgeCombineFn(torch.autograd.Function):
+    """a_p = act(P[t_p] + Q[s_p] + E_p): gather at t + gather at s + first Dense layer of the message MLP."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, handle, act, n_edges):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm)
+        ref = next(t for t in (P, Q, Eterm) if t is not None)
+        h = ref.shape[1]
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        a = torch.empty((n_edges, h), dtype=torch.float32, device=ref.device)
+        z = torch.empty_like(a) if act != 0 else None
+        _lib.check(lib.ngpde_edge_combine_forward(handle.ptr, h, act, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(a),
+                                                  _lib.ptr(z), _lib.current_stream()))
+        ctx.handle, ctx.act, ctx.h = handle, act, h
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None)
+        ctx.save_for_backward(z)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        da = da.contiguous()
+        ps, qs, has_e = ctx.shapes
+        dev = da.device
+        dz = torch.empty_like(da)
+        dP = torch.empty(ps, dtype=torch.float32, device=dev) if (ps is not None and ctx.needs_input_grad[0]) else None
+        dQ = torch.empty(qs, dtype=torch.float32, device=dev) if (qs is not None and ctx.needs_input_grad[1]) else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, ctx.h, ctx.act, _lib.ptr(da), _lib.ptr(z), _lib.ptr(dz),
+                                                   _lib.ptr(dP), _lib.ptr(dQ), _lib.current_stream()))
+        return dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), None, None, None
+
+
+def edge_combine(P, Q, Eterm, handle, act, n_edges):
+    return _EdgeCombineFn.apply(P, Q, Eterm, handle, act, n_edges)
+
+
+class _SegmentReduceFn(torch.autograd.Function):
+    """aggregate_neighbors(g, aggr, m): segmented reduction over each node's incoming edges."""
+
+    @staticmethod
+    def forward(ctx, M, handle, aggr, n_nodes):
+        lib = _lib.load()
+        _need_cuda(M)
+        M = M.contiguous()
+        d = M.shape[1]
+        out = torch.empty((n_nodes, d), dtype=torch.float32, device=M.device)
+        _lib.check(lib.ngpde_segment_reduce_forward(handle.ptr, d, aggr, _lib.ptr(M), _lib.ptr(out), _lib.current_stream()))
+        ctx.handle, ctx.aggr, ctx.d = handle, aggr, d
+        ctx.save_for_backward(M, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        M, out = ctx.saved_tensors
+        dout = dout.contiguous()
+        dM = torch.empty_like(M)
+        _lib.check(lib.ngpde_segment_reduce_backward(ctx.handle.ptr, ctx.d, ctx.aggr, _lib.ptr(M), _lib.ptr(out),
+                                                     _lib.ptr(dout), _lib.ptr(dM), _lib.current_stream()))
+        return dM, None, None, None
+
+
+def segment_reduce(M, handle, aggr, n_nodes):
+    return _SegmentReduceFn.apply(M, handle, _lib.AGGR[aggr] if isinstance(aggr, str) else aggr, n_nodes)
+
+
+class _GnoContractFn(torch.autograd.Function):
+    """m_e = reshape(K_e, out, in) * h[:, s_e]   (NNlib.batched_mul, src/layers.jl:527-530)."""
+
+    @staticmethod
+    def forward(ctx, K, h, handle, cin, cout):
+        lib = _lib.load()
+        _need_cuda(K, h)
+        K, h = K.contiguous(), h.contiguous()
+        m = torch.empty((K.shape[0], cout), dtype=torch.float32, device=K.device)
+        _lib.check(lib.ngpde_gno_contract_forward(handle.ptr, cin, cout, _lib.ptr(K), _lib.ptr(h), _lib.ptr(m),
+                                                  _lib.current_stream()))
+        ctx.handle, ctx.dims = handle, (cin, cout)
+        ctx.save_for_backward(K, h)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        K, h = ctx.saved_tensors
+        cin, cout = ctx.dims
+        dm = dm.contiguous()
+        dK = torch.empty_like(K) if ctx.needs_input_grad[0] else None
+        dh = torch.empty_like(h) if ctx.needs_input_grad[1] else None
+        ws = _ws(K.shape[0] * cin * 4, K.device)
+        _lib.check(lib.ngpde_gno_contract_backward(ctx.handle.ptr, cin, cout, _lib.ptr(K), _lib.ptr(h), _lib.ptr(dm),
+                                                   _lib.ptr(dK), _lib.ptr(dh), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return dK, dh, None, None, None
+
+
+def gno_contract(K, h, handle, cin, cout):
+    return _GnoContractFn.apply(K, h, handle, cin, cout)
+
+
+class _GnoApplyFn(torch.autograd.Function):
+    """Reassociated GNOConv message  m_e = T_{s_e} z_e + Bh_{s_e}  (include/ngpde.h: ngpde_gno_apply_forward)."""
+
+    @staticmethod
+    def forward(ctx, T, Bh, z, handle, cout, kdim):
+        lib = _lib.load()
+        _need_cuda(T, z)
+        T, z = T.contiguous(), z.contiguous()
+        Bh = Bh.contiguous() if Bh is not None else None
+        m = torch.empty((z.shape[0], cout), dtype=torch.float32, device=z.device)
+        _lib.check(lib.ngpde_gno_apply_forward(handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(Bh), _lib.ptr(z), _lib.ptr(m),
+                                               _lib.current_stream()))
+        ctx.handle, ctx.dims, ctx.has_bh = handle, (cout, kdim), Bh is not None
+        ctx.save_for_backward(T, z)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        T, z = ctx.saved_tensors
+        cout, kdim = ctx.dims
+        dm = dm.contiguous()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[0] else None
+        dBh = (torch.empty((T.shape[0], cout), dtype=torch.float32, device=T.device)
+               if ctx.has_bh and ctx.needs_input_grad[1] else None)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[2] else None
+        _lib.check(lib.ngpde_gno_apply_backward(ctx.handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(z), _lib.ptr(dm),
+                                                _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(dz), _lib.current_stream()))
+        return dT, dBh, dz, None, None, None
+
+
+def gno_apply_supported(cout, kdim):
+    return bool(_lib.load().ngpde_gno_apply_supported(int(cout), int(kdim)))
+
+
+def gno_apply(T, Bh, z, handle, cout, kdim):
+    return _GnoApplyFn.apply(T, Bh, z, handle, cout, kdim)
+
+
+class _GnoMessageFn(torch.autograd.Function):
+    """m_e = T_{s_e} act1(P[t_e] + Q[s_e] + E_e) + Bh_{s_e} in ONE launch (ngpde_gno_message_forward): the per-edge input of the
+    reassociated GNOConv message is formed while the per-source GEMM stages its rows.  act1 in {identity, relu}: the activated
+    input kept for the pullback also tells act1' (pullback = ngpde_gno_apply_backward + ngpde_edge_combine_backward)."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, T, Bh)
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        T = T.contiguous()
+        Bh = None if Bh is None else Bh.contiguous()
+        dev = T.device
+        need = any(ctx.needs_input_grad)
+        a = torch.empty((n_edges, kdim), dtype=torch.float32, device=dev) if need else None
+        m = torch.empty((n_edges, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_message_forward(handle.ptr, cout, kdim, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(T),
+                                                 _lib.ptr(Bh), _lib.ptr(a), _lib.ptr(m), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (act1, cout, kdim)
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None, Bh is not None)
+        ctx.save_for_backward(T, a)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        T, a = ctx.saved_tensors
+        act1, cout, kdim = ctx.meta
+        pshape, qshape, has_e, has_bh = ctx.shapes
+        dm = dm.contiguous()
+        dev = dm.device
+        stream = _lib.current_stream()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
+        dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None
+        da = torch.empty_like(a)
+        _lib.check(lib.ngpde_gno_apply_backward(ctx.handle.ptr, cout, kdim, _lib.ptr(T), _lib.ptr(a), _lib.ptr(dm), _lib.ptr(dT),
+                                                _lib.ptr(dBh), _lib.ptr(da), stream))
+        dz = torch.empty_like(a)
+        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if (pshape is not None and ctx.needs_input_grad[0]) else None
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if (qshape is not None and ctx.needs_input_grad[1]) else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, kdim, act1, _lib.ptr(da), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dP),
+                                                   _lib.ptr(dQ), stream))
+        return dP, dQ, (dz if (has_e and ctx.needs_input_grad[2]) else None), dT, dBh, None, None, None, None, None
+
+
+class _GnoMessageAggFn(torch.autograd.Function):
+    """agg = aggregate_neighbors(g, aggr, m) of the fused message above, aggr in {+, mean} (src/layers.jl:527-534): forward = the
+    message launch + the segmented reduction; the pullback forms dm_e = dagg[t_e] (/ deg) inside the per-source launch
+    (ngpde_gno_message_backward_from_nodes) instead of writing and re-reading an [E][out] array."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, T, Bh)
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        T = T.contiguous()
+        Bh = None if Bh is None else Bh.contiguous()
+        dev = T.device
+        stream = _lib.current_stream()
+        need = any(ctx.needs_input_grad)
+        a = torch.empty((n_edges, kdim), dtype=torch.float32, device=dev) if need else None
+        m = torch.empty((n_edges, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_message_forward(handle.ptr, cout, kdim, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), _lib.ptr(T),
+                                                 _lib.ptr(Bh), _lib.ptr(a), _lib.ptr(m), stream))
+        agg = torch.empty((n_nodes, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_segment_reduce_forward(handle.ptr, cout, aggr, _lib.ptr(m), _lib.ptr(agg), stream))
+        ctx.handle, ctx.meta = handle, (act1, cout, kdim, aggr)
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None, Bh is not None)
+        ctx.save_for_backward(T, a)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        lib = _lib.load()
+        T, a = ctx.saved_tensors
+        act1, cout, kdim, aggr = ctx.meta
+        pshape, qshape, has_e, has_bh = ctx.shapes
+        dev = dagg.device
+        if aggr == _lib.AGGR["mean"]:      # a node's 1 / deg once per node here, not once per edge in the launch (where it would hang
+            dagg = rows_scale(dagg, ctx.handle.inv_in_degree(dev))   # on the edge's target index: one more dependent load per pass)
+            aggr = _lib.AGGR["+"]
+        dagg = dagg.contiguous()
+        stream = _lib.current_stream()
+        dT = torch.empty_like(T) if ctx.needs_input_grad[3] else None
+        dBh = torch.empty((T.shape[0], cout), dtype=torch.float32, device=dev) if (has_bh and ctx.needs_input_grad[4]) else None
+        want_p = pshape is not None and ctx.needs_input_grad[0]
+        want_q = qshape is not None and ctx.needs_input_grad[1]
+        want_e = has_e and ctx.needs_input_grad[2]
+        dz = torch.empty_like(a) if (want_p or want_q or want_e) else None     # gradient of the pre-activation P[t] + Q[s] + E
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if want_q else None
+        _lib.check(lib.ngpde_gno_message_backward_from_nodes(ctx.handle.ptr, cout, kdim, aggr, act1, _lib.ptr(T), _lib.ptr(a),
+                                                             _lib.ptr(dagg), _lib.ptr(dT), _lib.ptr(dBh), _lib.ptr(dz), _lib.ptr(dQ), stream))
+        dP = None
+        if want_p:                                                               # dP = sums of dz by target
+            dP = torch.empty(pshape, dtype=torch.float32, device=dev)
+            _lib.check(lib.ngpde_segment_reduce_forward(ctx.handle.ptr, kdim, _lib.AGGR["+"], _lib.ptr(dz), _lib.ptr(dP), stream))
+        return (dP, dQ, (dz if want_e else None), dT, dBh) + (None,) * 7
+
+
+def gno_message_aggregate(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):
+    """Fused message + sum / mean aggregation (aggr: name or code); other aggregations: gno_message + segment_reduce."""
+    code = _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr)
+    if code not in (_lib.AGGR["+"], _lib.AGGR["mean"]):
+        return segment_reduce(gno_message(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges), handle, code, n_nodes)
+    return _GnoMessageAggFn.apply(P, Q, Eterm, T, Bh, handle, int(act1), int(cout), int(kdim), int(n_edges), code, int(n_nodes))
+
+
+def gno_message_supported(cout, kdim, act1):
+    return act1 in (0, 1) and bool(_lib.load().ngpde_gno_message_supported(int(cout), int(kdim)))
+
+
+def gno_message(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges):
+    return _GnoMessageFn.apply(P, Q, Eterm, T, Bh, handle, int(act1), int(cout), int(kdim), int(n_edges))
+
+
+class _EdgeMlpFusedFn(torch.autograd.Function):
+    """m_i = aggr_e phi(...) in one launch (ngpde_edge_mlp_forward): gather through LDS, MFMA layers, in-tile
+    segmented reduction.  Training keeps the per-edge pre-activations and the pullback runs on the primitives."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, acts, *wb):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, *[t for t in wb if t is not None])
+        ref = next(t for t in (P, Q, Eterm) if t is not None)
+        dev, h1 = ref.device, ref.shape[1]
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        wts = [w.contiguous() for w in wb[0::2]]
+        bs = list(wb[1::2])
+        n_tail = len(wts)
+        douts = [w.shape[1] for w in wts]
+        need = any(ctx.needs_input_grad)
+        widths = [h1] + douts
+        # fused pullback available: it recomputes the per-edge activations, so the forward saves nothing per edge
+        fused_bwd = need and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(lib.ngpde_edge_mlp_backward_supported(
+            handle.ptr, h1, n_tail, _int_array(douts) if n_tail else None, aggr))
+        if fused_bwd and n_tail >= 2:
+            # message MLPs of three / four layers (edge_mlp_deep_bwd.hip): one 4-wave workgroup per CU walks a long dependent chain per
+            # tile, which pays where a workgroup has many tiles to amortise it over -- 262 144 nodes: 3.4 against 4.7 ms forward +
+            # backward; 3 000 nodes (the VMH tutorial): 105 us for the one launch against ~60 us of primitives' launches spread over
+            # the whole chip (tools/bench_deep_mlp.py, tools/bench_vmh_node.py).  NGPDE_DEEP_EDGE_BWD=1 / 0 forces it on / off.
+            force = os.environ.get("NGPDE_DEEP_EDGE_BWD")
+            fused_bwd = force == "1" or (force != "0" and n_nodes >= 32768)
+        saves = [torch.empty((n_edges, w), dtype=torch.float32, device=dev) if (need and not fused_bwd) else None for w in widths]
+        out = torch.empty((n_nodes, widths[-1]), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_edge_mlp_forward(handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,
+                                              _int_array(douts) if n_tail else None, _int_array(acts) if n_tail else None,
+                                              _ptr_array(wts) if n_tail else None, _ptr_array(bs) if n_tail else None,
+                                              aggr, _lib.ptr(out), _ptr_array(saves), _lib.current_stream()))
+        ctx.handle, ctx.meta = handle, (act1, aggr, n_nodes, n_edges, tuple(acts), h1, tuple(douts))
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None,
+                      [b is not None for b in bs])
+        ctx.fused_bwd = fused_bwd
+        if fused_bwd:
+            ctx.present = (P is not None, Q is not None, Eterm is not None)
+            ctx.save_for_backward(*wts, *[b for b in bs if b is not None], *[t for t in (P, Q, Eterm) if t is not None])
+        else:
+            ctx.save_for_backward(*wts, *[s for s in saves if s is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        act1, aggr, n_nodes, n_edges, acts, h1, douts = ctx.meta
+        n_tail = len(douts)
+        if ctx.fused_bwd:
+            return _EdgeMlpFusedFn._fused_backward(ctx, dout)
+        saved = ctx.saved_tensors
+        wts, zs = saved[:n_tail], saved[n_tail:]
+        pshape, qshape, has_e, has_b = ctx.shapes
+        dev = dout.device
+        stream = _lib.current_stream()
+        widths = [h1] + list(douts)
+        dM = torch.empty((n_edges, widths[-1]), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_segment_reduce_backward(ctx.handle.ptr, widths[-1], aggr, None, None, _lib.ptr(dout.contiguous()),
+                                                     _lib.ptr(dM), stream))
+        grads_wb = [None] * (2 * n_tail)
+        for l in range(n_tail, 0, -1):
+            z_prev, z_l, wt = zs[l - 1], zs[l], wts[l - 1]
+            a_prev = torch.empty_like(z_prev)
+            _lib.check(lib.ngpde_activation_forward(z_prev.numel(), act1 if l == 1 else acts[l - 2], _lib.ptr(z_prev),
+                                                    _lib.ptr(a_prev), stream))
+            dwt = torch.empty_like(wt)
+            db = torch.empty((douts[l - 1],), dtype=torch.float32, device=dev) if has_b[l - 1] else None
+            da = torch.empty_like(a_prev)
+            ws = _ws(lib.ngpde_dense_workspace_bytes(n_edges, widths[l - 1], douts[l - 1]), dev)
+            _lib.check(lib.ngpde_dense_backward(n_edges, 1, _ptr_array([a_prev]), _int_array([widths[l - 1]]), _int_array([1]),
+                                                douts[l - 1], acts[l - 1], _lib.ptr(wt), _lib.ptr(z_l), _lib.ptr(dM),
+                                                _ptr_array([da]), _lib.ptr(dwt), _lib.ptr(db), _lib.ptr(ws), ws.numel(), stream))
+            grads_wb[2 * (l - 1)], grads_wb[2 * (l - 1) + 1] = dwt, db
+            dM = da
+        dz = torch.empty_like(dM)
+        dP = torch.empty(pshape, dtype=torch.float32, device=dev) if pshape is not None else None
+        dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if qshape is not None else None
+        _lib.check(lib.ngpde_edge_combine_backward(ctx.handle.ptr, h1, act1, _lib.ptr(dM), _lib.ptr(zs[0]), _lib.ptr(dz),
+                                                   _lib.ptr(dP), _lib.ptr(dQ), stream))
+        return (dP, dQ, dz if has_e else None, None, None, None, None, None, None, *grads_wb)
+
+
+def _edge_mlp_fused_backward(ctx, dout):
+    """ngpde_edge_mlp_backward: one fused launch (+ slab reduce + by-source sum)"""
+    lib = _lib.load()
+    act1, aggr, n_nodes, n_edges, acts, h1, douts = ctx.meta
+    n_tail = len(douts)
+    pshape, qshape, has_e, has_b = ctx.shapes
+    saved = list(ctx.saved_tensors)
+    wts = saved[:n_tail]
+    nb = sum(has_b)
+    bs_present = saved[n_tail:n_tail + nb]
+    bs, it = [], iter(bs_present)
+    for hb in has_b:
+        bs.append(next(it) if hb else None)
+    rest = iter(saved[n_tail + nb:])
+    P = next(rest) if ctx.present[0] else None
+    Q = next(rest) if ctx.present[1] else None
+    Eterm = next(rest) if ctx.present[2] else None
+    dev = dout.device
+    dout = dout.contiguous()
+    dP = torch.empty(pshape, dtype=torch.float32, device=dev) if pshape is not None else None
+    dQ = torch.empty(qshape, dtype=torch.float32, device=dev) if qshape is not None else None
+    # the [E][h1] array dz1: not needed where the 64-wide kernel sums it by source inside its launch (no per-edge term, mesh-like halos)
+    need_de = has_e or dQ is None or bool(lib.ngpde_edge_mlp_backward_needs_edge_buffer(
+        ctx.handle.ptr, h1, act1, 0, n_tail, _int_array(list(douts)) if n_tail else None, _int_array(list(acts)) if n_tail else None, aggr))
+    dE = torch.empty((n_edges, h1), dtype=torch.float32, device=dev) if need_de else None
+    dwts = [torch.empty_like(w) for w in wts]
+    dbs = [torch.empty((douts[l],), dtype=torch.float32, device=dev) if has_b[l] else None for l in range(n_tail)]
+    ws = _ws(lib.ngpde_edge_mlp_backward_workspace_bytes(ctx.handle.ptr, h1, n_tail, _int_array(list(douts)) if n_tail else None), dev)
+    _lib.check(lib.ngpde_edge_mlp_backward(ctx.handle.ptr, h1, act1, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(Eterm), n_tail,
+                                           _int_array(list(douts)) if n_tail else None, _int_array(list(acts)) if n_tail else None,
+                                           _ptr_array(wts) if n_tail else None, _ptr_array(bs) if n_tail else None, aggr,
+                                           _lib.ptr(dout), _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dE),
+                                           _ptr_array(dwts) if n_tail else None, _ptr_array(dbs) if n_tail else None,
+                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    grads_wb = []
+    for l in range(n_tail):
+        grads_wb += [dwts[l], dbs[l]]
+    return (dP, dQ, dE if has_e else None, None, None, None, None, None, None, *grads_wb)
+
+
+_EdgeMlpFusedFn._fused_backward = staticmethod(_edge_mlp_fused_backward)
+
+
+def edge_mlp_supported(handle, h1, tail_douts):
+    lib = _lib.load()
+    return bool(lib.ngpde_edge_mlp_supported(handle.ptr, int(h1), len(tail_douts), _int_array(tail_douts) if tail_douts else None))
+
+
+def edge_mlp_fused(P, Q, Eterm, handle, act1, aggr, n_nodes, n_edges, tail):
+    """tail: list of (wt [in][out], bias or None, act code) for the layers after the first."""
+    wb = []
+    for wt, b, _ in tail:
+        wb += [wt, b]
+    return _EdgeMlpFusedFn.apply(P, Q, Eterm, handle, act1, _lib.AGGR[aggr] if isinstance(aggr, str) else aggr, n_nodes,
+                                 n_edges, tuple(a for _, _, a in tail), *wb)
+
+
+# ---- layer-level entries (api_layers.hip): one call per layer, one per pullback ----------------------------------------------------
+
+
+class _RowBlocksFn(torch.autograd.Function):
+    """Recombined row blocks of a [rows][width] weight: every output is a vertical stack of blocks, a block the signed sum of
+    equally long row ranges of the source (ExplicitEdgeConv [wa; -wc], VMHConv [wa - wb; -wc], MPPDEConv [wa; wc; we] ...).
+    ONE launch builds all outputs, ONE launch their pullback -- no slices, cat, neg, zero-fills or adds of slice gradients."""
+
+    @staticmethod
+    def forward(ctx, wt, spec):
+        import ctypes as C
+        lib = _lib.load()
+        wt = wt.contiguous()
+        rows, width = wt.shape
+        out_index, dst0, src0, nrows, sign, out_rows = [], [], [], [], [], []
+        for o, blocks in enumerate(spec):
+            r = 0
+            for n, terms in blocks:
+                for s0, sg in terms:
+                    out_index.append(o); dst0.append(r); src0.append(s0); nrows.append(n); sign.append(float(sg))
+                r += n
+            out_rows.append(r)
+        outs = [torch.empty((r, width), dtype=torch.float32, device=wt.device) for r in out_rows]
+        meta = (rows, width, _int_array(out_index), _int_array(dst0), _int_array(src0), _int_array(nrows),
+                (C.c_float * max(len(sign), 1))(*sign), len(out_index), _int_array(out_rows), len(outs))
+        _lib.check(lib.ngpde_row_blocks_gather(width, rows, _lib.ptr(wt), meta[7], meta[2], meta[3], meta[4], meta[5], meta[6], len(outs),
+                                               _ptr_array(outs), meta[8], _lib.current_stream()))
+        ctx.meta, ctx.dev = meta, wt.device
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        lib = _lib.load()
+        rows, width, out_index, dst0, src0, nrows, sign, n_seg, out_rows, n_out = ctx.meta
+        douts = [None if d is None else d.contiguous() for d in douts]
+        dwt = torch.empty((rows, width), dtype=torch.float32, device=ctx.dev)
+        _lib.check(lib.ngpde_row_blocks_scatter(width, rows, _lib.ptr(dwt), n_seg, out_index, dst0, src0, nrows, sign, n_out,
+                                                _ptr_array(douts), out_rows, _lib.current_stream()))
+        return dwt, None
+
+
+def row_blocks(wt, spec):
+    """spec: per output a list of blocks (n_rows, [(src_row0, sign), ...]); blocks with n_rows == 0 are dropped.  Returns the
+    list of output matrices ([sum n_rows][width] each)."""
+    spec = [[(int(n), list(terms)) for n, terms in blocks if n > 0] for blocks in spec]
+    return list(_RowBlocksFn.apply(wt, spec))
+
+
+class _TransposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        out = torch.empty((a.shape[1], a.shape[0]), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().ngpde_transpose(a.shape[0], a.shape[1], _lib.ptr(a), _lib.ptr(out), _lib.current_stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        out = torch.empty((d.shape[1], d.shape[0]), dtype=torch.float32, device=d.device)
+        _lib.check(_lib.load().ngpde_transpose(d.shape[0], d.shape[1], _lib.ptr(d), _lib.ptr(out), _lib.current_stream()))
+        return out
+
+
+def transpose(a):
+    """contiguous transpose of a 2-D float32 tensor as a library launch (its pullback: the transpose of the cotangent)"""
+    return _TransposeFn.apply(a)
+
+
+def rows_scale(x, scale):
+    """out[i][:] = x[i][:] * scale[i] (no autograd: used inside pullbacks)"""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().ngpde_rows_scale(x.shape[0], x.shape[1], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+# ---- several independent small Dense layers in one launch; fan-out of a tensor to several consumers ----------------------------
+
+
+def _sum_list(tensors):
+    """sum of equally shaped float32 tensors as ONE library launch (the Runge-Kutta combination kernel), no torch adds"""
+    import ctypes as C
+    tensors = [t.contiguous() for t in tensors]
+    if len(tensors) == 1:
+        return tensors[0]
+    out = torch.empty_like(tensors[0])
+    terms = tensors[1:]
+    _lib.check(_lib.load().ngpde_rk_stage_combine(out.numel(), 1.0, _lib.ptr(tensors[0]), len(terms),
+                                                  (C.c_void_p * len(terms))(*[t.data_ptr() for t in terms]),
+                                                  (C.c_float * len(terms))(*([1.0] * len(terms))), _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+class _FanoutFn(torch.autograd.Function):
+    """k aliases of one tensor for k consumers; the pullback sums their cotangents in ONE launch (autograd would add them pairwise
+    with torch kernels)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *ds):
+        ds = [d for d in ds if d is not None]
+        return (_sum_list(ds) if ds else None), None
+
+
+def fanout(x, k):
+    return list(_FanoutFn.apply(x, k)) if (k > 1 and x.requires_grad and torch.is_grad_enabled()) else [x] * k
+
+
+class _DenseMultiFn(torch.autograd.Function):
+    """Up to four independent Dense layers y_q = act_q(x_q W_q + b_q) (ONE input block each) in one launch
+    (ngpde_dense_multi_forward); the pullbacks are the single-problem launches; inputs that are the same tensor get the sum."""
+
+    @staticmethod
+    def forward(ctx, acts, *args):          # args: x_0, wt_0, b_0, x_1, wt_1, b_1, ...
+        import ctypes as C
+        lib = _lib.load()
+        q = len(acts)
+        xs = [args[3 * i].contiguous() for i in range(q)]
+        wts = [args[3 * i + 1].contiguous() for i in range(q)]
+        bs = [args[3 * i + 2] for i in range(q)]
+        _need_cuda(*xs, *wts, *bs)
+        for x, wt in zip(xs, wts):
+            if wt.shape[0] != x.shape[1]:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                             f"DimensionMismatch: Dense expects {wt.shape[0]} input features, got {x.shape[1]}")
+        dev = wts[0].device
+        need = any(ctx.needs_input_grad)
+        ys = [torch.empty((x.shape[0], wt.shape[1]), dtype=torch.float32, device=dev) for x, wt in zip(xs, wts)]
+        zs = [torch.empty_like(y) if (need and a != 0) else None for y, a in zip(ys, acts)]
+        n = (C.c_int64 * q)(*[x.shape[0] for x in xs])
+        _lib.check(lib.ngpde_dense_multi_forward(q, n, _int_array([1] * q), _ptr_array(xs), _int_array([x.shape[1] for x in xs]),
+                                                 _int_array([1] * q), _int_array([wt.shape[1] for wt in wts]), _int_array(acts),
+                                                 _ptr_array(wts), _ptr_array(bs), _ptr_array(ys), _ptr_array(zs), _lib.current_stream()))
+        ctx.acts = tuple(acts)
+        ctx.has_b = tuple(b is not None for b in bs)
+        ctx.same = [next(j for j in range(q) if args[3 * j] is args[3 * i]) for i in range(q)]   # first problem with the same input
+        ctx.save_for_backward(*xs, *wts, *[z if z is not None else torch.empty(0, device=dev) for z in zs])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        q = len(ctx.acts)
+        saved = ctx.saved_tensors
+        xs, wts, zs = saved[:q], saved[q:2 * q], saved[2 * q:]
+        grads = [None] * (3 * q)
+        dxs = [None] * q
+        for i in range(q):
+            if dys[i] is None:
+                continue
+            want_x = ctx.needs_input_grad[1 + 3 * i]
+            z = zs[i] if zs[i].numel() else None
+            dwt, db, dblocks = _dense_backward_call(lib, xs[i].shape[0], [xs[i]], [xs[i].shape[1]], [1], wts[i].shape[1], ctx.acts[i], wts[i],
+                                                    z, dys[i].contiguous(), [want_x], ctx.has_b[i])
+            grads[3 * i + 1], grads[3 * i + 2], dxs[i] = dwt, db, dblocks[0]
+        for i in range(q):                                   # one gradient per distinct input tensor
+            if ctx.same[i] != i or not ctx.needs_input_grad[1 + 3 * i]:
+                continue
+            parts = [dxs[j] for j in range(q) if ctx.same[j] == i and dxs[j] is not None]
+            grads[3 * i] = _sum_list(parts) if parts else None
+        return (None, *grads)
+
+
+def dense_multi(problems):
+    """problems: list of (x [n][k], wt [k][m], bias or None, act code); returns the list of outputs.  Empty inputs are allowed
+    (zero rows)."""
+    args = []
+    for x, wt, b, _ in problems:
+        args += [x, wt, b]
+    return list(_DenseMultiFn.apply([int(a) for *_, a in problems], *args))
+
+
+# ---- the layers composed from the autograd nodes above (layers_mp.py of rounds 1 - 4) -------------------------------------------------
+import numpy as np  # noqa: E402
+
+from ngpde_amd.layers import rows_of  # noqa: E402
+from ngpde_amd.layers_mp import (ExplicitEdgeConv, GNOConv, MPPDEConv, VMHConv, _as_named, _check_nodes, _dense_stack, _edge_data_p,  # noqa: E402
+                                 _node_data, _wt_b)
+
+
+def _tail(stack, a):
+    """layers 2..k of a Dense stack on row-major activations"""
+    for layer, ps in stack[1:]:
+        wt, b = _wt_b(ps)
+        a = dense([a], wt, b, layer.act)
+    return a
+
+
+def _node_update(stack, blocks, row_divs, n):
+    """a Dense stack (psi / gamma) on a virtual vcat of node-level blocks: the first two layers as one chained call"""
+    l1, p1 = stack[0]
+    wt1, b1 = _wt_b(p1)
+    if len(stack) >= 2:
+        l2, p2 = stack[1]
+        wt2, b2 = _wt_b(p2)
+        y = dense_chain2(blocks, wt1, b1, l1.act, wt2, b2, l2.act, row_divs=row_divs, n=n)
+        return _tail(stack[1:], y)
+    return dense(blocks, wt1, b1, l1.act, row_divs=row_divs, n=n)
+
+
+def _message_path(g, P, Q, Et, stack, aggr):
+    """aggr_e phi(...) given the node-level first-layer terms: ONE fused launch when the message MLP fits the fused
+    kernel (widths <= 64, multiples of 4, <= 3 further Dense layers, tiles fit the LDS halo; max/min only without
+    gradients), the primitives otherwise."""
+    l1 = stack[0][0]
+    ref = next(t for t in (P, Q, Et) if t is not None)
+    tail = [(_wt_b(ps)[0], _wt_b(ps)[1], layer.act) for layer, ps in stack[1:]]
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
+    aggr_code = _lib.AGGR[aggr]
+    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or (aggr_code in (2, 3, 4) and not needs_grad)):
+        fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
+        if edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
+            return edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)
+    handle = g.handle()
+    a = edge_combine(P, Q, Et, handle, l1.act, g.num_edges)
+    return segment_reduce(_tail(stack, a), handle, aggr, g.num_nodes)
+
+
+def _row_offsets(wt, sizes):
+    """first rows of the consecutive row blocks of the first-layer weight (the order of the message's vcat)"""
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += n
+    if o != wt.shape[0]:
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     f"DimensionMismatch: first layer expects {wt.shape[0]} input features, the message has {o}")
+    return offs
+
+
+def explicitedgeconv_composed(self, xn, ps, st):
+    """the same layer composed from the primitives' autograd nodes (rounds 1 - 4's host path: the
+    test of ngpde_edge_layer_* against it)"""
+    g = st["graph"]
+    dev = next(iter(xn.values())).device
+    pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])        # xi.x
+    others = _node_data(g, dev, exclude=["x"])                                # drop(xi, :x) fixed part
+    hblocks = list(xn.values()) + ([others] if others.shape[1] else [])
+    stack = _dense_stack(self.ϕ, ps, "ϕ")                                     # reference passes the whole ps (:106)
+    l1, p1 = stack[0]
+    wt, b = _wt_b(p1)
+    dh = sum(hb.shape[1] for hb in hblocks)
+    dp = pos.shape[1]
+    oa, ob, oc = _row_offsets(wt, [dh, dh, dp])                               # [hi...; hj...; xj - xi]
+    wA, wB = row_blocks(wt, [[(dh, [(oa, 1)]), (dp, [(oc, -1)])], [(dh, [(ob, 1)]), (dp, [(oc, 1)])]])   # [wa; -wc], [wb; wc]
+    fan = [fanout(hb, 2) for hb in hblocks]         # target side / source side: their cotangents are summed in one launch
+    P, Q = dense_pair([f[0] for f in fan] + [pos], wA, b, 0, [f[1] for f in fan] + [pos], wB, None, 0)
+    y = _message_path(g, P, Q, None, stack, self.aggr)                          # propagate(message, g, aggr)  (:111)
+    return y.T, st
+
+
+def vmhconv_composed(self, xn, ps, st):
+    """composed from the primitives' autograd nodes"""
+    g = st["graph"]
+    dev = next(iter(xn.values())).device
+    pos = _node_data(g, dev, exclude=[k for k in g.ndata if k != "x"])
+    others = _node_data(g, dev, exclude=["x"])
+    hblocks = list(xn.values()) + ([others] if others.shape[1] else [])
+    stack = _dense_stack(self.ϕ, ps["ϕ"], "ϕ")
+    l1, p1 = stack[0]
+    wt, b = _wt_b(p1)
+    dh = sum(hb.shape[1] for hb in hblocks)
+    dp = pos.shape[1]
+    oa, ob, oc = _row_offsets(wt, [dh, dh, dp])                               # [hi...; (hj - hi)...; xj - xi]  (:316)
+    wA, wB = row_blocks(wt, [[(dh, [(oa, 1), (ob, -1)]), (dp, [(oc, -1)])],   # [wa - wb; -wc]
+                               [(dh, [(ob, 1)]), (dp, [(oc, 1)])]])             # [wb; wc]
+    nx = len(xn)
+    fan = [fanout(hb, 3 if k < nx else 2) for k, hb in enumerate(hblocks)]   # target side, source side, (features:) γ
+    P, Q = dense_pair([f[0] for f in fan] + [pos], wA, b, 0, [f[1] for f in fan] + [pos], wB, None, 0)
+    m = _message_path(g, P, Q, None, stack, self.aggr)                          # :326
+    gstack = _dense_stack(self.γ, ps["γ"], "γ")
+    blocks = [f[2] for f in fan[:nx]] + [m]
+    y = _node_update(gstack, blocks, [1] * len(blocks), m.shape[0])           # γ(vcat(values(x)..., m))  (:328)
+    return y.T, st
+
+
+def mppdeconv_composed(self, h, ps, st):
+    """composed from the primitives' autograd nodes"""
+    g = st["graph"]
+    dev = h.device
+    handle = g.handle()
+    N, E, G = g.num_nodes, g.num_edges, max(g.num_graphs, 1)
+    d = g.packed("ndata", dev)                                                 # :403-405
+    theta = g.packed("gdata", dev)                                             # :397  [G][dθ]
+    e_p = _edge_data_p(g, handle, dev)                                         # :407
+    dh, dd, de, dth = h.shape[1], d.shape[1], e_p.shape[1], theta.shape[1]
+    if dth and (N % G or E % G):
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     "DimensionMismatch: batched graphs must have the same structure (src/layers.jl:359-361)")
+    stack = _dense_stack(self.ϕ, ps["ϕ"], "ϕ")
+    l1, p1 = stack[0]
+    wt, b = _wt_b(p1)
+    oa, ob, oc, od, oe = _row_offsets(wt, [dh, dh, dd, de, dth])               # [hi; hj; di - dj; e; θ]  (:409-410)
+    tb, trd = [h], [1]
+    if dd:
+        tb.append(d); trd.append(1)
+    if dth:
+        tb.append(theta); trd.append(N // G)                                   # θ of the target's graph = the edge's graph
+    # the three recombined weights in one launch: target side [wa; wc; we], source side [wb; -wc], edge features wd
+    mats = row_blocks(wt, [[(dh, [(oa, 1)]), (dd, [(oc, 1)]), (dth, [(oe, 1)])], [(dh, [(ob, 1)]), (dd, [(oc, -1)])]] +
+                        ([[(de, [(od, 1)])]] if de else []))
+    # one pass over h when the shapes allow; h comes back routed through the pair so that psi's gradient w.r.t. h is added
+    # inside the pair's pullback launch
+    P, Q, h = dense_pair(tb, mats[0], b, 0, [h] + ([d] if dd else []), mats[1], None, 0, row_divs_a=trd, n=N, passthrough=True)
+    Et = dense([e_p], mats[2], None, 0) if de else None
+    m = _message_path(g, P, Q, Et, stack, self.aggr)                            # :416
+    pstack = _dense_stack(self.ψ, ps["ψ"], "ψ")
+    blocks, rd = [h, m], [1, 1]
+    if dth:
+        blocks.append(theta); rd.append(N // G)
+    y = _node_update(pstack, blocks, rd, N)                                    # ψ(vcat(x, m, repeat(θ)))  (:418)
+    return y.T, st
+
+
+def gnoconv_composed(self, h, ps, st):
+    """composed from the primitives' autograd nodes"""
+    g = st["graph"]
+    dev = h.device
+    handle = g.handle()
+    N, E = g.num_nodes, g.num_edges
+    s = g.packed("ndata", dev)                                                 # :517-519
+    e_p = _edge_data_p(g, handle, dev)                                         # :521
+    ds, de = s.shape[1], e_p.shape[1]
+    stack = _dense_stack(self.ϕ, ps["ϕ"], "ϕ")
+    l1, p1 = stack[0]
+    wt, b = _wt_b(p1)
+    oa, ob, od = _row_offsets(wt, [ds, ds, de])                                # [si; sj; e]  (:523)
+    mats = row_blocks(wt, ([[(ds, [(oa, 1)])], [(ds, [(ob, 1)])]] if ds else []) + ([[(de, [(od, 1)])]] if de else []))
+    wa, wb = (mats[0], mats[1]) if ds else (None, None)
+    wd = mats[-1] if de else None
+    Et = dense([e_p], wd, b if not ds else None, 0) if de else None
+    P = Q = None                                                               # (node-level terms: below, in one launch)
+    kout = _wt_b(stack[-1][1])[0].shape[1]
+    if kout != self.in_chs * self.out_chs:
+        raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                     f"DimensionMismatch: ϕ must output in_chs*out_chs = {self.in_chs * self.out_chs} rows, got {kout}")
+    last, plast = stack[-1]
+    kdim = _wt_b(plast)[0].shape[0]
+    reassoc = (len(stack) >= 2 and last.act == 0 and os.environ.get("NGPDE_GNO_MATERIALIZE") != "1"
+               and gno_apply_supported(self.out_chs, kdim))
+    if reassoc:
+        # reassociated: K_e h_j = T_j z_e + B2 h_j with T_j = W2 (x) h_j at node level; K is never formed
+        w2, b2 = _wt_b(plast)                                                  # [k][in*out], [in*out]; row r = o + out*i
+        wr = transpose(w2).view(self.in_chs, self.out_chs * kdim)            # [in][out][k]: the transpose of [k][in * out]
+    lwt, lb = _wt_b(ps["linear"])
+    # h has up to three consumers (T, B2 h, W h): one fan-out node sums their cotangents in one launch.  The small node-level
+    # Dense layers -- P, Q on the node coordinates, B2 h, W h -- are latency-bound launches of a few dozen workgroups each:
+    # ONE launch for all of them (ngpde_dense_multi_forward)
+    hT, hS = fanout(h, 2) if reassoc else (None, h)
+    small = ([(s, wa, b, 0), (s, wb, None, 0)] if ds else []) + ([(hS, b2.view(self.in_chs, self.out_chs), None, 0)] if (reassoc and b2 is not None) else []) + [(hS, lwt, None, 0)]
+    outs = dense_multi(small)
+    if ds:
+        P, Q = outs[0], outs[1]
+    Wh = outs[-1]
+    Bh = None
+    if reassoc:
+        T = dense([hT], wr, None, 0)
+        Bh = outs[-2] if b2 is not None else None
+    if (reassoc and len(stack) == 2 and E > 0 and os.environ.get("NGPDE_NO_GNO_MFMA") != "1"
+            and gno_message_supported(self.out_chs, kdim, l1.act)):
+        # two-layer phi: the per-edge input act1(P[t] + Q[s] + E) is formed inside the message launch
+        agg = gno_message_aggregate(P, Q, Et, T, Bh, handle, l1.act, self.out_chs, kdim, E, self.aggr, N)   # :527-534
+        m = None
+    elif reassoc:
+        z = _tail(stack[:-1], edge_combine(P, Q, Et, handle, l1.act, E))
+        m = gno_apply(T, Bh, z, handle, self.out_chs, kdim)
+    else:
+        K = _tail(stack, edge_combine(P, Q, Et, handle, l1.act, E))
+        m = gno_contract(K, h, handle, self.in_chs, self.out_chs)            # :527-530
+    if m is not None:
+        agg = segment_reduce(m, handle, self.aggr, N)                        # :534
+    y = bias_act(agg, Wh, lb, self.linear.act)                               # σ(W x + m + b)  (:536-547)
+    return y.T, st
+
+
+
+
+def apply(layer, x, ps, st):
+    """y, st = layer(x, ps, st) through the composed path"""
+    g = st["graph"]
+    if isinstance(layer, (ExplicitEdgeConv, VMHConv)):
+        xn = {k: rows_of(v) for k, v in _as_named(x).items()}
+        for v in xn.values():
+            _check_nodes(v, g)
+        return (explicitedgeconv_composed if isinstance(layer, ExplicitEdgeConv) else vmhconv_composed)(layer, xn, ps, st)
+    h = rows_of(x)
+    _check_nodes(h, g)
+    return (mppdeconv_composed if isinstance(layer, MPPDEConv) else gnoconv_composed)(layer, h, ps, st)

@@ -94,7 +94,7 @@ def test_random_small_dense_layers_against_float64(seed):
     # launch) and the general kernels around their limits: random row counts (fewer than a tile, ragged, up to 70 000), widths 1 .. 70,
     # one to three blocks of a virtual vcat of which per-graph blocks carry no gradient, every activation, with and without bias --
     # y, dW, db and the blocks' gradients against a float64 restatement with torch
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     rng = np.random.default_rng(seed)
     ACTS = ["identity", "relu", "tanh", "sigmoid", "swish", "gelu", "leakyrelu", "elu", "softplus"]
     REF = {"identity": lambda z: z, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "swish": lambda z: z * torch.sigmoid(z),

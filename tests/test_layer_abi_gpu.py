@@ -1,6 +1,6 @@
-"""The layer-level C entries (include/ngpde.h: ngpde_edge_layer_*, api_layers.hip) against the same layers composed from the
-primitives' autograd nodes (NGPDE_LAYERS_COMPOSED=1: rounds 1 - 4's host path, itself checked against the float64 oracle in
-test_mp_gpu.py / test_configs_gpu.py).  One call per layer and one per pullback must give the composed path's bits: the entry
+"""The layer-level C entries (include/ngpde.h: ngpde_edge_layer_*, ngpde_gno_layer_*, api_layers.hip) against the same layers composed
+from the primitives' autograd nodes (tests/composed.py: rounds 1 - 4's host path; the layers themselves are checked against the
+float64 oracle in test_mp_gpu.py / test_configs_gpu.py).  One call per layer and one per pullback must give the composed path's bits: the entry
 only sequences the primitives' launches (/root/reference/src/layers.jl:94-112, :308-332, :390-422)."""
 import ctypes as C
 
@@ -10,6 +10,7 @@ import torch
 
 import ngpde_amd as ng
 from ngpde_amd import _lib, synth as S
+import composed
 from test_mp_gpu import grad_leaves, prep, rgraph
 
 pytestmark = pytest.mark.gpu
@@ -43,23 +44,18 @@ def both_ways(layer, x, seed, monkeypatch, training=True):
     """(y, dx or [dx...], parameter gradients) through the layer-level entry and through the composed path"""
     ps0, st = ng.setup(seed, layer)
     outs = []
-    for composed in (False, True):
-        if composed:
-            monkeypatch.setenv("NGPDE_LAYERS_COMPOSED", "1")
-        else:
-            monkeypatch.delenv("NGPDE_LAYERS_COMPOSED", raising=False)
+    for call in (lambda xs, ps: layer(xs, ps, st), lambda xs, ps: composed.apply(layer, xs, ps, st)):
         ps = prep(ps0, seed)
         xs = {k: v.detach().clone().requires_grad_(training) for k, v in x.items()} if isinstance(x, dict) else x.detach().clone().requires_grad_(training)
         if training:
-            y, _ = layer(xs, ps, st)
+            y, _ = call(xs, ps)
             R = torch.as_tensor(np.random.default_rng(seed + 1).normal(size=tuple(y.shape)).astype(np.float32), device=DEV)
             (y * R).sum().backward()
             gx = [v.grad for v in xs.values()] if isinstance(xs, dict) else [xs.grad]
             outs.append([y.detach()] + gx + [p.grad for p in grad_leaves(ps)])
         else:
             with torch.no_grad():
-                outs.append([layer(xs, ps, st)[0]])
-    monkeypatch.delenv("NGPDE_LAYERS_COMPOSED", raising=False)
+                outs.append([call(xs, ps)[0]])
     return outs
 
 

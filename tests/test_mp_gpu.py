@@ -139,7 +139,7 @@ def test_dense_chain_parity():
 def test_dense_wide_tiles_segmented(widths, dout, act):
     # enough rows that the 128-row tile kernels serve forward and input pullback (>= 512 tiles), ragged last tile,
     # blocks that do / do not allow 16-byte loads, a per-graph block (row_div) as MPPDEConv's theta  (src/layers.jl:397)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     n, per_graph = 70001, 10000
     rng = np.random.default_rng(21)
     blocks, divs = [], []
@@ -176,7 +176,7 @@ def test_dense_small_pullback_one_launch(n, widths, divs, dout, act):
     # dense_small_bwd.hip: the whole pullback of a Dense of at most 64 x 64 at latency-bound row counts in one launch -- the
     # tutorial MLPs' shapes (VMH.md:75-79), ragged last tiles, fewer rows than a tile, widths that are no multiple of 4 or 16, blocks of
     # a virtual vcat with and without a gradient (per-graph blocks, src/layers.jl:397), one input / one output -- against float64
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     rng = np.random.default_rng(n + dout)
     blocks = []
     for w, rd in zip(widths, divs):
@@ -213,7 +213,7 @@ def test_dense_few_rows_wide_output_pullbacks(n, din, dout, bias, monkeypatch):
     # both pullbacks on the same tiles with the contraction split over workgroups (dense_gemm128_split_kernel: input pullback
     # over the 8192 outputs, weight pullback over the rows) when the layer has no bias gradient -- against float64, and against
     # the older kernels (NGPDE_DENSE_NO_GEMM128 is read once per process, so that comparison is with the float64 values only)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     rng = np.random.default_rng(n + din)
     x = torch.as_tensor(rng.normal(size=(n, din)), dtype=torch.float32, device=DEV).requires_grad_(True)
     wt = torch.as_tensor(rng.normal(size=(din, dout)) / np.sqrt(din), dtype=torch.float32, device=DEV).requires_grad_(True)
@@ -238,7 +238,7 @@ def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
     # dense_stream_bwd.hip: dz, input pullbacks, weight pullback and bias gradient of a 64-output Dense in one launch (one or two
     # 64-wide blocks + narrow blocks without gradient, the last block per graph as MPPDEConv's theta, src/layers.jl:397, :418);
     # ragged last tile; against the oracle and against the composed path (NGPDE_DENSE_NO_STREAM_BWD=1)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD", raising=False)
     n, per_graph, dout = 70001, 10000, 64
     rng = np.random.default_rng(33)
@@ -285,7 +285,7 @@ def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
 def test_dense_pair_streaming_backward(nwa, nwb, monkeypatch):
     # ngpde_dense_pair_backward: both pullbacks of an activation-free pair in one launch (dx already summed, narrow features and
     # bias on the matrix pipe as a 16-wide block), against the oracle and the composed path
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD", raising=False)
     n, per_graph = 70001, 10000
     res = []
@@ -339,7 +339,7 @@ def test_dense_pair_streaming_backward(nwa, nwb, monkeypatch):
 def test_dense_pair_streaming_forward(nwa, nwb, douts, monkeypatch):
     # ngpde_dense_pair_forward: two Dense layers from one pass over their shared 64-wide block (dense_pair_fwd_kernel, weights in
     # registers), against the oracle and the two-launch path (NGPDE_DENSE_NO_STREAM2=1); ragged last tile, a per-graph block
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2", raising=False)
     n, per_graph = 70001, 10000
     rng = np.random.default_rng(71)
@@ -388,7 +388,7 @@ def test_dense_chain2_streaming_forward(widths, dout, acts, monkeypatch):
     # ngpde_dense_chain2_forward: Chain(Dense(. => 64), Dense(64 => dout)) with the intermediate on chip (dense_chain_fwd_kernel),
     # inference (nothing saved) and training (z1 / a1 kept, both pullbacks), against the oracle and the two-launch path; the last
     # case (no 64-wide leading block) takes the two-launch path by itself
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     monkeypatch.delenv("NGPDE_DENSE_NO_STREAM2", raising=False)
     n, per_graph = 70001, 10000
     rng = np.random.default_rng(73)
@@ -729,7 +729,7 @@ def test_gno_message_aggregate_pullback_from_node_gradient(aggr):
     # node-level gradient inside the per-source launch -- the same arithmetic as ngpde_segment_reduce_backward followed by
     # ngpde_gno_apply_backward, so every output must be bit-identical to the composed path; isolated nodes included; max takes
     # the composed path through the same entry point
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     N, E, cout, kdim = 300, 2600, 32, 16
     rng = np.random.default_rng(5)
     s, t = rng.integers(0, N - 7, size=E), rng.integers(0, N - 7, size=E)          # the last 7 nodes are isolated
@@ -807,7 +807,7 @@ def test_gat_c3_full_size_forward():
 # ---- aggregation edge cases ----------------------------------------------------------------------------------------------------
 
 def test_segment_reduce_edge_cases():
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     g = ng.GNNGraph([1, 2, 2], [2, 1, 1], num_nodes=4)            # nodes 3, 4 isolated; node 1 has two incoming edges
     h = g.handle()
     M = torch.tensor([[1.0, -2.0], [3.0, 5.0], [7.0, 5.0]], device=DEV)   # COO order
@@ -885,7 +885,7 @@ def test_gat_layer_one_launch_forward_and_pullback(heads, act, bias, loops, monk
     l = ng.GATConv((64, C), act, heads=heads, concat=True, add_self_loops=loops, bias=bias, initialgraph=g)
     ps, st = ng.setup(61, l)
     ps = prep(ps, 61)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     assert F.gat_layer_supported(l._graph(g).handle(), 64, heads, C)
     x = torch.randn(64, n, device=DEV, requires_grad=True)
     y, _ = l(x, ps, st)
@@ -939,7 +939,7 @@ def test_gat_layer_and_solver_with_long_rows(heads, monkeypatch):
     l = ng.GATConv((64, C), "tanh", heads=heads, concat=True, initialgraph=g)
     ps, st = ng.setup(131, l)
     ps = prep(ps, 131)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     assert F.gat_layer_supported(l._graph(g).handle(), 64, heads, C)
     x = torch.randn(64, n, device=DEV, requires_grad=True)
     y, _ = l(x, ps, st)
@@ -1036,7 +1036,7 @@ def test_gat_one_launch_layer_as_ode_right_hand_side(solver, steps, monkeypatch)
     node = ng.NeuralODE(l, solver=solver, n_steps=steps, dt=0.05)
     ps, st = ng.setup(77, node)
     ps = prep(ps, 77)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     assert F.gat_layer_supported(l._graph(g).handle(), 64, H, C_)
     u0 = torch.randn(64, n, device=DEV, requires_grad=True)
     uT, _ = node(u0, ps, st)
@@ -1372,7 +1372,7 @@ def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
     ps, st = ng.setup(21, l)
     ps = prep(ps, 21)
     x = torch.randn(h, n * G, device=DEV)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     fh = g.handle((False, None, False))
     assert F.edge_mlp_supported(fh, 64, [64])
     with torch.no_grad():
@@ -1402,7 +1402,7 @@ def test_fused_message_path_matches_primitives_and_oracle(aggr, monkeypatch):
 def test_fused_message_path_layer_counts_and_ragged_rows(widths, acts):
     # 0, 2 and 3 Dense layers after the first (the last shape is the VMH tutorial's message MLP, VMH.md:75-83), rows of
     # varying degree (0..9), a ragged last tile, per-edge features in the first layer -- fused kernel vs oracle, fwd + grads
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     n, h = 203, 6
     rng = np.random.default_rng(31)
     ss, tt = [], []
@@ -1523,7 +1523,7 @@ def test_fused_paths_with_edge_features_and_fused_pullback(phi_widths, monkeypat
     l = ng.MPPDEConv(phi, psi, initialgraph=g, aggr="mean")
     ps, st = ng.setup(41, l)
     ps = prep(ps, 41)
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     assert F.edge_mlp_supported(g.handle(), phi_widths[0], list(phi_widths[1:]))
     R = rng.normal(size=(h, n * G))
     Rt = torch.as_tensor(R, dtype=torch.float32, device=DEV)
@@ -1555,7 +1555,7 @@ def test_fused_paths_with_edge_features_and_fused_pullback(phi_widths, monkeypat
 
 
 def test_fused_message_path_falls_back_when_unsupported():
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     g = ng.rand_graph(50, 200, seed=1)
     fh = g.handle((False, None, False))
     assert not F.edge_mlp_supported(fh, 66, [64])       # wider than 64
@@ -1595,7 +1595,7 @@ def test_rk_stage_combine_all_term_counts_and_aliasing(count):
 @pytest.mark.parametrize("d", [128, 7])
 def test_bias_act_tail_forward_and_pullback(act, d):
     # y = act(a + addend + b): GNOConv's sigma(W x + m + b) tail (src/layers.jl:536-547); 16-byte and scalar paths
-    from ngpde_amd import functional as F
+    import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     n = 1000
     rng = np.random.default_rng(d)
     mk = lambda *s: torch.as_tensor(rng.normal(size=s).astype(np.float32), device=DEV).requires_grad_(True)

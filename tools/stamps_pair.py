@@ -5,7 +5,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ngpde_amd as ng
-from ngpde_amd import _lib, functional as F
+from ngpde_amd import _lib
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import composed as F      # the primitives' autograd wrappers (tests/composed.py)
 _lib.LIB_PATH = os.path.join(ROOT, "neuralgraphpde.jl_amd", "libngpde_diag.so")
 lib = _lib.load()
 lib.ngpde_debug_set_pair_stamps.argtypes = [C.c_void_p]; lib.ngpde_debug_set_pair_stamps.restype = C.c_int32
