@@ -62,12 +62,16 @@ struct Csr {
   std::vector<int32_t> h_rowptr, h_col, h_eid;
 };
 
-// Inverse of the by-target halo lists, built on first use (graph_halo_inverse): for every node the (tile, halo slot) pairs that hold
-// it, as tile * stride + slot, ascending by tile.  Lets a kernel leave one partial row per (tile, slot) and a second pass add, per
-// node, the rows of the tiles that reference it -- a by-source sum without an [E][h] array (edge_mlp64.hip).
+// Inverse of the FOREIGN part of the by-target halo lists, built on first use (graph_halo_inverse): the nodes that some OTHER tile's
+// halo references (slot >= kTileRows), and for each of them the (tile, halo slot) pairs that hold it, as tile * stride + slot,
+// ascending by tile.  Lets a kernel leave one partial row per (tile, foreign slot), write the partial row of an OWN slot straight
+// to the node, and a second pass add the foreign rows -- a by-source sum without an [E][h] array (edge_mlp64.hip).  One stride per
+// handle for its whole life (a published table is never freed before ngpde_graph_destroy).
 struct HaloInverse {
-  int32_t *ptr = nullptr;   // [n_nodes + 1]
-  int32_t *ent = nullptr;   // [ptr[n_nodes]]
+  int32_t *node = nullptr;  // [n_listed] nodes with at least one foreign entry, ascending
+  int32_t *ptr = nullptr;   // [n_listed + 1]
+  int32_t *ent = nullptr;   // [ptr[n_listed]]
+  int32_t n_listed = 0;
   int stride = 0;
 };
 

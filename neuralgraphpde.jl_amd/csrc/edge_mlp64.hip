@@ -448,7 +448,8 @@ struct EdgeMlp64BwdK {
   int n_tiles, halo_rows, aggr;
   const float *P, *Q, *wt, *bias, *dout;
   float *dP, *dE, *partial;   // partial: [n_workgroups][65][64]  (row 64 = bias gradient)
-  float *dqpart;              // DQ: [n_tiles][kDqStride][64] per-tile sums of dz1 by halo slot (the by-source sum, first half)
+  float *dqpart;              // DQ: [n_tiles][kDqStride][64] per-tile sums of dz1 by FOREIGN halo slot (the by-source sum, first half)
+  float *dQ;                  // DQ: the sums of a tile's OWN slots (= its own rows) go straight to the node's row
 };
 constexpr int kDqSlots = 3;                 // halo slots per 16-lane group whose sums stay in registers (DQ)
 constexpr int kDqStride = 16 * kDqSlots;    // = the largest halo the in-launch by-source sum takes (48 rows)
@@ -476,8 +477,11 @@ __device__ __forceinline__ void act_both(float z, float &a, float &d) {
 // DQ (no per-edge first-layer term, halos of at most kDqStride rows: meshes such as BASELINE config 4's): the [E][64] array dz1
 // is NOT written.  Its only reader would be the by-source sum dQ; instead each 16-lane group keeps the sums of dz1 over the edges of
 // "its" halo slots (slot = the edge's source row in the tile's halo list) in registers -- the edges of a chunk that carry a slot
-// are found by ballots over the chunk's slot ids and added in edge order, so the result is reproducible -- and writes one row per
-// slot and tile; edge64_dq_combine_kernel then adds, per node, the rows of the tiles whose halo holds it (graph handle: halo_inverse).
+// are found by ballots over the chunk's slot ids and added in edge order, so the result is reproducible.  The sums of the tile's OWN
+// slots (slot k < 32 = its k-th row: most of a mesh's edges stay inside their tile) are the node's row of dQ up to what other tiles
+// add: they are stored there; the sums of FOREIGN slots go to one row per (tile, slot), and edge64_dq_combine_kernel adds them to
+// the few nodes that other tiles reference (graph handle: halo_inverse), ascending by tile.  (Round 4 wrote every slot's row and
+// summed all of them per node: 452 MB of traffic for the 134 MB result; now 134 + 3 x 25 MB.)
 template <int ACT1, int ACT2, bool DQ>
 __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64BwdK p) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -749,7 +753,12 @@ __global__ __launch_bounds__(kT4, 2) void edge_mlp64_bwd_kernel(const EdgeMlp64B
 #pragma unroll
       for (int j = 0; j < kDqSlots; ++j) {
         const int sl = g16 + 16 * j;
-        if (sl < p.halo_rows) *reinterpret_cast<float4 *>(p.dqpart + ((size_t)(range_lo + jt) * kDqStride + sl) * kW + 4 * q) = qacc[j];
+        if (j < 2) {   // own rows g16 / g16 + 16 of the tile
+          const int node = j == 0 ? sc0.x : sc1.x;
+          if (node >= 0) *reinterpret_cast<float4 *>(p.dQ + (size_t)node * kW + 4 * q) = qacc[j];
+        } else if (sl < p.halo_rows) {
+          *reinterpret_cast<float4 *>(p.dqpart + ((size_t)(range_lo + jt) * kDqStride + sl) * kW + 4 * q) = qacc[j];
+        }
       }
     }
     if (p.dP) {
@@ -851,15 +860,17 @@ int32_t launch_edge_mlp64_fwd(const ngpde_graph *g, const EdgeMlpArgs &a, hipStr
   return NGPDE_OK;
 }
 
-// dQ[node] = sum over the tiles whose halo list holds the node of that tile's partial row (entries ascending by tile: fixed order)
-__global__ __launch_bounds__(256) void edge64_dq_combine_kernel(int n_nodes, const int *__restrict__ ptr, const int *__restrict__ ent,
-                                                                const float *__restrict__ part, float *__restrict__ dQ) {
-  const int node = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4), q = threadIdx.x & 15;
-  if (node >= n_nodes) return;
-  const int lo = ptr[node], hi = ptr[node + 1];
-  float4 a = f4_zero();
+// dQ[node] += the partial rows of the OTHER tiles whose halo list holds the node (entries ascending by tile: fixed order); the node's
+// own tile has stored its share.  One 16-lane group per listed node (the nodes no other tile references are not touched).
+__global__ __launch_bounds__(256) void edge64_dq_combine_kernel(int n_listed, const int *__restrict__ nodes, const int *__restrict__ ptr,
+                                                                const int *__restrict__ ent, const float *__restrict__ part, float *__restrict__ dQ) {
+  const int k = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4), q = threadIdx.x & 15;
+  if (k >= n_listed) return;
+  const int lo = ptr[k], hi = ptr[k + 1];
+  float4 *dst = reinterpret_cast<float4 *>(dQ + (size_t)nodes[k] * kW + 4 * q);
+  float4 a = *dst;
   for (int e = lo; e < hi; ++e) a = f4_add(a, *reinterpret_cast<const float4 *>(part + (size_t)ent[e] * kW + 4 * q));
-  *reinterpret_cast<float4 *>(dQ + (size_t)node * kW + 4 * q) = a;
+  *dst = a;
 }
 
 // ---- pullback launch.  Same conditions as the forward specialisation (the activation pairs instantiated below); workspace =
@@ -902,6 +913,7 @@ int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hip
   }
   NGPDE_REQUIRE(dq || a.dE != nullptr || g->n_edges == 0, NGPDE_ERR_INVALID_ARGUMENT, "fused edge-MLP pullback: the [E][h1] buffer dE is required");
   k.dqpart = dq ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.workspace) + edge64_slab_bytes(g)) : nullptr;
+  k.dQ = dq ? a.dQ : nullptr;
   const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + (size_t)kRows * kTS + (size_t)kChunk4 * kTS + 2 * (size_t)kW * kTS) * sizeof(float);
   int grid = (lds + 4096 <= 80 * 1024) ? edge64_bwd_grid(g) : std::max(8, edge64_bwd_grid(g) / 2);
   if (const char *e = std::getenv("NGPDE_EDGE64_WGS_PER_XCD")) grid = std::max(8, std::min(grid, 8 * atoi(e)));   // diagnostic: fewer resident workgroups
@@ -925,10 +937,12 @@ int32_t launch_edge_mlp64_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hip
   int32_t st;
   if ((st = launch_dense_weight_reduce(grid, kW, kW, k.partial, a.dwt, a.dbias, stream))) return st;
   if (dq) {
-    const int64_t threads = g->n_nodes * 16;
-    hipLaunchKernelGGL(edge64_dq_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (int)g->n_nodes, hinv->ptr, hinv->ent,
-                       k.dqpart, a.dQ);
-    NGPDE_LAUNCH_CHECK("edge64_dq_combine_kernel");
+    if (hinv->n_listed > 0) {
+      const int64_t threads = (int64_t)hinv->n_listed * 16;
+      hipLaunchKernelGGL(edge64_dq_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, hinv->n_listed, hinv->node, hinv->ptr,
+                         hinv->ent, k.dqpart, a.dQ);
+      NGPDE_LAUNCH_CHECK("edge64_dq_combine_kernel");
+    }
     return NGPDE_OK;
   }
   if (a.dQ && (st = launch_edge_sum_by_source(g, kW, a.dE, a.dQ, stream))) return st;

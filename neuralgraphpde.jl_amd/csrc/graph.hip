@@ -160,35 +160,45 @@ namespace ngpde {
 int32_t graph_halo_inverse(const ngpde_graph *g, int stride, const HaloInverse **out) {
   std::lock_guard<std::mutex> lock(g->lazy_mu);
   HaloInverse &hi = g->halo_inv;
-  if (hi.ptr && hi.stride == stride) {
+  if (hi.ptr) {
+    // one stride per handle: a table another caller's enqueued kernel may still read is never rebuilt
+    NGPDE_REQUIRE(hi.stride == stride, NGPDE_ERR_STATE, "graph_halo_inverse: the handle's table has stride %d, %d asked for", hi.stride, stride);
     *out = &hi;
     return NGPDE_OK;
   }
   NGPDE_REQUIRE(g->by_t.halo && g->by_t.tile_info && g->by_t.halo_ok && g->by_t.max_halo <= stride, NGPDE_ERR_STATE,
                 "graph_halo_inverse: the handle has no halo lists of at most %d rows", stride);
-  if (hi.ptr) (void)hipFree(hi.ptr);
-  if (hi.ent) (void)hipFree(hi.ent);
-  hi = HaloInverse();
   const size_t nt = (size_t)g->n_sched / kTileRows, n = (size_t)g->n_nodes;
+  NGPDE_REQUIRE(nt * (size_t)stride < (1ull << 31), NGPDE_ERR_UNSUPPORTED, "graph_halo_inverse: too many tiles for int32 entries");
   std::vector<int2> halo(nt * kHaloCap), info(nt);
   NGPDE_HIP_CHECK(hipMemcpy(halo.data(), g->by_t.halo, halo.size() * sizeof(int2), hipMemcpyDeviceToHost));
   NGPDE_HIP_CHECK(hipMemcpy(info.data(), g->by_t.tile_info, info.size() * sizeof(int2), hipMemcpyDeviceToHost));
-  auto each = [&](auto &&f) {   // (tile, slot, node) of every real halo entry, tiles ascending; own slots beyond the last node are padding
+  auto each = [&](auto &&f) {   // (tile, slot, node) of every FOREIGN halo entry (own rows are slots 0 .. kTileRows - 1), tiles ascending
     for (size_t tl = 0; tl < nt; ++tl)
-      for (int k = 0; k < info[tl].x; ++k) {
-        if (k < kTileRows && tl * kTileRows + k >= n) continue;
-        f(tl, k, halo[tl * kHaloCap + k].x);
-      }
+      for (int k = kTileRows; k < info[tl].x; ++k) f(tl, k, halo[tl * kHaloCap + k].x);
   };
-  std::vector<int32_t> ptr(n + 1, 0);
-  each([&](size_t, int, int32_t v) { ptr[(size_t)v + 1]++; });
-  for (size_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-  std::vector<int32_t> ent((size_t)ptr[n]), cur(ptr.begin(), ptr.end() - 1);
-  each([&](size_t tl, int k, int32_t v) { ent[(size_t)cur[v]++] = (int32_t)(tl * (size_t)stride + k); });
-  NGPDE_REQUIRE(nt * (size_t)stride < (1ull << 31), NGPDE_ERR_UNSUPPORTED, "graph_halo_inverse: too many tiles for int32 entries");
+  std::vector<int32_t> cnt(n, 0);
+  each([&](size_t, int, int32_t v) { cnt[(size_t)v]++; });
+  std::vector<int32_t> node, ptr(1, 0), where(n, -1);
+  for (size_t v = 0; v < n; ++v)
+    if (cnt[v]) {
+      where[v] = (int32_t)node.size();
+      node.push_back((int32_t)v);
+      ptr.push_back(ptr.back() + cnt[v]);
+    }
+  std::vector<int32_t> ent((size_t)ptr.back()), cur(ptr.begin(), ptr.end() - 1);
+  each([&](size_t tl, int k, int32_t v) { ent[(size_t)cur[(size_t)where[v]]++] = (int32_t)(tl * (size_t)stride + k); });
+  HaloInverse built;
   int32_t st;
-  if ((st = upload(&hi.ptr, ptr.data(), ptr.size())) || (st = upload(&hi.ent, ent.data(), ent.size()))) return st;
-  hi.stride = stride;
+  if ((st = upload(&built.node, node.data(), node.size())) || (st = upload(&built.ptr, ptr.data(), ptr.size())) ||
+      (st = upload(&built.ent, ent.data(), ent.size()))) {
+    if (built.node) (void)hipFree(built.node);
+    if (built.ptr) (void)hipFree(built.ptr);
+    return st;
+  }
+  built.n_listed = (int32_t)node.size();
+  built.stride = stride;
+  hi = built;
   *out = &hi;
   return NGPDE_OK;
 }
@@ -269,6 +279,7 @@ int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
   if (g->c) (void)hipFree(g->c);
   if (g->order) (void)hipFree(g->order);
   if (g->halo_inv.ptr) (void)hipFree(g->halo_inv.ptr);
+  if (g->halo_inv.node) (void)hipFree(g->halo_inv.node);
   if (g->halo_inv.ent) (void)hipFree(g->halo_inv.ent);
   delete g;
   return NGPDE_OK;
