@@ -585,6 +585,12 @@ int32_t ngpde_row_blocks_scatter(int32_t width, int32_t src_rows, float *dsrc, i
 /* dst [cols][rows] = transpose of src [rows][cols] (GNOConv's reassociated form reads phi's last weight transposed,
  * src/layers.jl:527-530; its pullback transposes the gradient back) */
 int32_t ngpde_transpose(int32_t rows, int32_t cols, const float *src, float *dst, ngpde_stream_t stream);
+/* Rows by an index list (int64, device, 0-based; entries distinct): gather  dst[o][i][:] = src[o][index[i]][:]  (src [outer][n_rows][d],
+ * dst [outer][n_index][d]) or, scatter != 0, dst[o][index[i]][:] = src[o][i][:] with every other row of dst zero (each is the other's
+ * pullback).  The state of a batch of point clouds whose members were padded to whole tiles goes in and out of the device-resident
+ * NeuralODE(VMHConv) plan through it (docs/src/tutorials/VMH.md:120-134: the batch is one block-diagonal graph). */
+int32_t ngpde_rows_index(int64_t outer, int64_t n_rows, int64_t n_index, int32_t d, const int64_t *index, const float *src, float *dst,
+                         int32_t scatter, ngpde_stream_t stream);
 /* out[i][:] = x[i][:] * scale[i]  (mean aggregation's 1 / degree applied once per node to a cotangent, :534) */
 int32_t ngpde_rows_scale(int64_t n, int32_t d, const float *x, const float *scale, float *out, ngpde_stream_t stream);
 

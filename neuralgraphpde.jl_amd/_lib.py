@@ -87,6 +87,7 @@ SIGNATURES = {
     "ngpde_gno_layer_workspace_bytes": (_sz, [_vp, C.POINTER(GnoLayer), _i32]),
     "ngpde_gno_layer_forward": (_i32, [_vp, C.POINTER(GnoLayer), _i32, _vp, _vp, _sz, _vp]),
     "ngpde_gno_layer_backward": (_i32, [_vp, C.POINTER(GnoLayer), _vp, _vp, C.POINTER(MlpGrad), _vp, _vp, _vp, _sz, _vp]),
+    "ngpde_rows_index": (_i32, [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ngpde_comm_unique_id": (_i32, [_vp, _sz]),
     "ngpde_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "ngpde_comm_destroy": (_i32, [_vp]),

@@ -97,6 +97,21 @@ int32_t fill_segments(const char *fn, int32_t n_seg, const int32_t *out_index, c
 
 using namespace ngpde;
 
+namespace ngpde {
+namespace {
+// gather: dst[o][i][:] = src[o][index[i]][:]; scatter: dst[o][index[i]][:] = src[o][i][:] (dst zeroed beforehand)
+__global__ void rows_index_kernel(int64_t outer, int64_t n_src, int64_t n_idx, int d, const int64_t *__restrict__ index,
+                                  const float *__restrict__ src, float *__restrict__ dst, int scatter) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, total = outer * n_idx * d;
+  if (k >= total) return;
+  const int c = (int)(k % d);
+  const int64_t i = (k / d) % n_idx, o = k / ((int64_t)d * n_idx), j = index[i];
+  if (scatter) dst[(o * n_src + j) * d + c] = src[(o * n_idx + i) * d + c];
+  else dst[(o * n_idx + i) * d + c] = src[(o * n_src + j) * d + c];
+}
+}  // namespace
+}  // namespace ngpde
+
 extern "C" {
 
 int32_t ngpde_row_blocks_gather(int32_t width, int32_t src_rows, const float *src, int32_t n_seg, const int32_t *out_index,
@@ -157,6 +172,24 @@ int32_t ngpde_rows_scale(int64_t n, int32_t d, const float *x, const float *scal
   NGPDE_REQUIRE(x && scale && out, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rows_scale: NULL argument");
   hipLaunchKernelGGL(rows_scale_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d, x, scale, out);
   NGPDE_LAUNCH_CHECK("rows_scale_kernel");
+  return NGPDE_OK;
+}
+
+int32_t ngpde_rows_index(int64_t outer, int64_t n_rows, int64_t n_index, int32_t d, const int64_t *index, const float *src, float *dst,
+                         int32_t scatter, ngpde_stream_t stream) {
+  NGPDE_RANGE();
+  NGPDE_REQUIRE(outer >= 0 && n_rows >= 0 && n_index >= 0 && d > 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rows_index: bad sizes");
+  if (scatter && outer * n_rows > 0) {
+    NGPDE_REQUIRE(dst != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rows_index: dst is NULL");
+    int32_t st = launch_zero(dst, (size_t)(outer * n_rows * d) * sizeof(float), (hipStream_t)stream);   // rows no index names are zero
+    if (st) return st;
+  }
+  const int64_t total = outer * n_index * d;
+  if (total == 0) return NGPDE_OK;
+  NGPDE_REQUIRE(index && src && dst, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_rows_index: NULL argument");
+  hipLaunchKernelGGL(ngpde::rows_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, outer, n_rows, n_index, d, index,
+                     src, dst, scatter);
+  NGPDE_LAUNCH_CHECK("rows_index_kernel");
   return NGPDE_OK;
 }
 

@@ -42,6 +42,30 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
+class _RowsIndexFn(torch.autograd.Function):
+    """rows of a [n] / [T][n] float32 array by an index list through ngpde_rows_index (gather, or scatter into zeros): a padded batch's
+    state on its way into and out of the device-resident VMH plan -- a library launch, its pullback the opposite one"""
+
+    @staticmethod
+    def forward(ctx, x, index, n_rows, scatter):
+        x = x.contiguous()
+        outer = 1 if x.dim() == 1 else x.shape[0]
+        n_idx = int(index.numel())
+        out = torch.empty((n_rows if scatter else n_idx,) if x.dim() == 1 else (outer, n_rows if scatter else n_idx), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().ngpde_rows_index(outer, n_rows, n_idx, 1, _lib.ptr(index), _lib.ptr(x), _lib.ptr(out), int(scatter), _lib.current_stream()))
+        ctx.meta = (index, n_rows, scatter)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        index, n_rows, scatter = ctx.meta
+        return _RowsIndexFn.apply(g, index, n_rows, not scatter), None, None, None
+
+
+def _rows_index(x, index, n_rows, scatter):
+    return _RowsIndexFn.apply(x, index, int(n_rows), bool(scatter))
+
+
 def _check_plan_shapes(what, u, n_rows, d, weights, biases):
     """DimensionMismatch (the reference's error for these: check_num_nodes / the matrix product) unless u is [n_rows][d], every
     weight has its shape and every bias its length -- the device-resident plans' C entries take pointers only"""
@@ -965,15 +989,15 @@ class NeuralODE(AbstractExplicitLayer):
                                              f"nodes, the graph in the layer's state has {n_expected}")
             uin = u.reshape(-1)
             if index is not None:      # (a padded batch: the real nodes' rows among the isolated padding nodes')
-                uin = torch.zeros(plan_v.n_nodes, dtype=torch.float32, device=u.device).index_copy(0, index, uin)
+                uin = _rows_index(uin, index, plan_v.n_nodes, True)
             if self.save_every:      # saveat: the (1 x N x T) array of the solution at t0 (+ j saveat)
                 us = _NodeVmhFn.apply(uin, plan_v, (self.save_every, self.save_start), *wb)
                 if index is not None:
-                    us = us.index_select(1, index)
+                    us = _rows_index(us, index, plan_v.n_nodes, False)
                 return us.T.unsqueeze(0), st
             uT = _NodeVmhFn.apply(uin, plan_v, None, *wb)
             if index is not None:
-                uT = uT.index_select(0, index)
+                uT = _rows_index(uT, index, plan_v.n_nodes, False)
             return uT.reshape(u.shape).T, st
         # any other right-hand side: explicit RK stepping through the layers' own kernels, every Runge-Kutta combination (and
         # every combination of the discrete adjoint) one library launch
