@@ -1022,7 +1022,8 @@ struct ngpde_node_vmh {
   float *tape_phi = nullptr, *tape_gam = nullptr, *dz_phi = nullptr, *dz_gam = nullptr, *dsrc = nullptr;
   float *partial = nullptr, *dwpad = nullptr;                                // weight-pullback workspace; [64 x 64 + 64] padded result
   size_t tape_bytes = 0, partial_floats = 0;
-  size_t tape_floats[2] = {0, 0};   // capacity of tape_phi / dz_phi and of tape_gam / dz_gam (they may come from the pool, larger than needed)
+  size_t tape_cap[4] = {0, 0, 0, 0};   // capacity in floats of tape_phi, tape_gam, dz_phi, dz_gam (a block from the pool may be larger than the need)
+  int tape_dev = 0;                    // the device they were allocated on
 };
 
 // The tapes of a VMH plan are tens of GB at the tutorial's minibatch size, and a training loop that batches its point clouds in a new
@@ -1046,7 +1047,9 @@ int tape_device() {
 std::mutex g_tape_mu;
 std::vector<TapeBlock> g_tape_pool;
 
-float *tape_pool_take(size_t floats) {   // the smallest parked block that fits without wasting more than half of itself
+// (the block's CAPACITY and the device it was allocated on travel with it: a block that came from the pool larger than the plan's
+// need goes back with its full size, on its own device)
+float *tape_pool_take(size_t floats, size_t *capacity) {   // the smallest parked block that fits without wasting more than half of itself
   const int dev = tape_device();
   std::lock_guard<std::mutex> lock(g_tape_mu);
   int best = -1;
@@ -1056,6 +1059,7 @@ float *tape_pool_take(size_t floats) {   // the smallest parked block that fits 
       best = i;
   if (best < 0) return nullptr;
   float *ptr = g_tape_pool[best].ptr;
+  *capacity = g_tape_pool[best].floats;
   g_tape_pool.erase(g_tape_pool.begin() + best);
   return ptr;
 }
@@ -1066,14 +1070,14 @@ size_t tape_pool_release_all() {   // (before a fresh allocation that would not 
   g_tape_pool.clear();
   return n;
 }
-void tape_pool_give(float *ptr, size_t floats) {
+void tape_pool_give(float *ptr, size_t floats, int device) {
   if (!ptr) return;
   std::lock_guard<std::mutex> lock(g_tape_mu);
   if (floats < (64u << 20) / 4 || g_tape_pool.size() >= kTapePoolMax) {   // small blocks and an overfull pool: back to the device
     (void)hipFree(ptr);
     return;
   }
-  g_tape_pool.push_back({ptr, floats, tape_device()});
+  g_tape_pool.push_back({ptr, floats, device});
 }
 }  // namespace
 
@@ -1082,10 +1086,10 @@ static void node_vmh_free(ngpde_node_vmh *p) {
   void *bufs[] = {p->pos, p->cf, p->cb, p->x, p->state, p->dsrc, p->partial, p->dwpad, p->srcpos, p->srcdeg};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
-  tape_pool_give(p->tape_phi, p->tape_floats[0]);
-  tape_pool_give(p->tape_gam, p->tape_floats[1]);
-  tape_pool_give(p->dz_phi, p->tape_floats[0]);
-  tape_pool_give(p->dz_gam, p->tape_floats[1]);
+  tape_pool_give(p->tape_phi, p->tape_cap[0], p->tape_dev);
+  tape_pool_give(p->tape_gam, p->tape_cap[1], p->tape_dev);
+  tape_pool_give(p->dz_phi, p->tape_cap[2], p->tape_dev);
+  tape_pool_give(p->dz_gam, p->tape_cap[3], p->tape_dev);
   node_persistent_free(&p->persist);
   delete p;
 }
@@ -1166,9 +1170,11 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
   if (st == NGPDE_OK && p->with_bwd) {
     // (zeroed once: the padded columns of a layer's rows are never written, and the weight-pullback GEMMs read whole 64-wide rows)
     const size_t tp = (size_t)n_phi * evals * E * 64, tg = (size_t)n_gamma * evals * N * 64;
-    auto tape = [&](float **ptr, size_t floats) -> int32_t {   // a parked block that fits, else a fresh zeroed one
+    p->tape_dev = tape_device();
+    auto tape = [&](float **ptr, size_t floats, size_t *cap) -> int32_t {   // a parked block that fits, else a fresh zeroed one
       floats = std::max<size_t>(floats, 64);
-      if ((*ptr = tape_pool_take(floats)) != nullptr) return NGPDE_OK;
+      *cap = floats;
+      if ((*ptr = tape_pool_take(floats, cap)) != nullptr) return NGPDE_OK;
       if (hipMalloc((void **)ptr, floats * 4) != hipSuccess) {
         (void)hipGetLastError();
         *ptr = nullptr;
@@ -1181,11 +1187,10 @@ int32_t ngpde_node_vmh_create(const ngpde_graph_t *g, int32_t hd, int32_t pd, co
       NGPDE_HIP_CHECK(hipMemset(*ptr, 0, floats * 4));
       return NGPDE_OK;
     };
-    p->tape_floats[0] = std::max<size_t>(tp, 64); p->tape_floats[1] = std::max<size_t>(tg, 64);
-    step(tape(&p->tape_phi, tp));
-    if (st == NGPDE_OK) step(tape(&p->tape_gam, tg));
-    if (st == NGPDE_OK) step(tape(&p->dz_phi, tp));
-    if (st == NGPDE_OK) step(tape(&p->dz_gam, tg));
+    step(tape(&p->tape_phi, tp, &p->tape_cap[0]));
+    if (st == NGPDE_OK) step(tape(&p->tape_gam, tg, &p->tape_cap[1]));
+    if (st == NGPDE_OK) step(tape(&p->dz_phi, tp, &p->tape_cap[2]));
+    if (st == NGPDE_OK) step(tape(&p->dz_gam, tg, &p->tape_cap[3]));
     if (st == NGPDE_OK) step(alloc(&p->dsrc, 2 * E, true));
     p->tape_bytes = 2 * (tp + tg) * 4;
     p->partial_floats = (size_t)dense_weight_chunks((int64_t)(evals * E), 64, 64) * 65 * 64 + 64;

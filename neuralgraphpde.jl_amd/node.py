@@ -346,7 +346,12 @@ def _canonical_batch(g, device):
     members = getattr(g, "_members", None)
     if not members or len(members) < 2 or list(g.ndata) != ["x"] or os.environ.get("NGPDE_NO_BATCH_REUSE") == "1":
         return None
-    key = tuple(sorted(id(mg) for mg in members))
+    # identity of the members AND of their positions' storage (data pointer + in-place version counter): a member whose cloud was
+    # moved in place, or whose ndata["x"] was reassigned, is another cloud -- it must not be solved with the first batch's positions
+    def stamp(mg):
+        x = mg.ndata.get("x") if isinstance(mg.ndata, dict) else None
+        return (id(mg), x.data_ptr(), x._version) if isinstance(x, torch.Tensor) else (id(mg), id(x), 0)
+    key = tuple(sorted(stamp(mg) for mg in members))
     hit = _CANON_BATCHES.get(key)
     if hit is None:
         _CANON_BATCHES[key] = (g, list(members))
@@ -930,8 +935,11 @@ class NeuralODE(AbstractExplicitLayer):
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
         # plans of this right-hand side on OTHER graphs are of no use any more (updategraph per minibatch, VMH.md:132-134): their tapes --
         # tens of GB at the tutorial's batch size -- go back to the library's pool before the new plan asks for its own
-        for old_key in [k for k in self._plans if k[0] == "vmh" and k[1] != id(handle)]:
-            self._plans.pop(old_key)
+        # (only when THIS plan needs tapes, and only plans that hold tapes: a forward-only validation solve between training steps
+        # must not evict the training graph's plan and make the next step rebuild it)
+        if needs_grad:
+            for old_key in [k for k in self._plans if k[0] == "vmh" and k[1] != id(handle) and k[-1]]:
+                self._plans.pop(old_key)
         try:
             plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
         except _lib.NgpdeError as e:
