@@ -1782,6 +1782,279 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
   write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// adjoint, tile rounds with the NEXT turn's hand-off taken off the current turn's instruction stream (round 5)
+// ---------------------------------------------------------------------------------------------------------------------
+// node_bwd_persistentK_kernel runs poll -> gather -> aggregate -> product -> store -> drain -> flag -> parameter-gradient products one
+// after the other for every turn.  But a workgroup's NEXT turn (its next tile in this phase, or its first tile in the next phase)
+// depends on nothing this turn produces, so -- the tile-pair kernel's pipeline (node_bwd_persistent2_kernel<true>), for K tiles:
+//   T0  s_waitcnt vmcnt(0) + barrier: this turn's halo rows (gathered during the previous turn's parameter-gradient products) have
+//       landed, the previous turn's row stores are drained -> ITS flag goes out here (deferred publish)
+//   T1  LDS aggregation, K-bar, operand tiles; the next turn's tape row and sign bits are asked for; barrier; G = dZ W^T
+//   T2  wave 0 asks for the flags of the next turn's wait list, not waited for; dW += A^T dZ, db (the longest stretch of the turn)
+//   T3  one look at the flags; if they were all there, the next turn's rows go out by LDS-DMA behind this turn's read of G (the halo
+//       region is the product's result tile); row stores (not drained)
+// A next turn whose flags were not there (the first tile of the next phase, mostly: its neighbours are in THIS phase) takes the
+// blocking path at its T0, which publishes what is pending first -- so a workgroup never spins in front of its own publish.
+// Arithmetic per tile is the tile-round kernel's, operation for operation: du0 bitwise equal, NGPDE_NO_TILE_PIPE=1 selects it.
+template <int ACT>
+__global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentKP_kernel(const PBwdK p) {
+  constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
+  using Aux = typename std::conditional<RELU, unsigned, float4>::type;
+  constexpr int kMS = meta_stride<false>(), kMT = meta_tiles<false>();
+  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + kWF + kMT * kMS + 48 + 4];
+  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW = ldsX + kTileF;
+  float *ldsMeta = ldsW + kWF, *ldsC = ldsMeta + kMT * kMS;
+  int *s_ok = reinterpret_cast<int *>(ldsC + 48), *s_pre = s_ok + 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 48) ldsC[tid] = p.cb[tid];
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+  if (tid < PG::LPR) Xh4[kHaloCap * PG::LPR + tid] = f4_zero();
+  if (tid == 0) *s_ok = 1, *s_pre = 0;
+  constexpr int NT = PG::CT * PG::CT;
+  f32x4 dw1[PG::DWT], dw2[PG::DWT];
+#pragma unroll
+  for (int mm = 0; mm < PG::DWT; ++mm) dw1[mm] = dw2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.f, db2 = 0.f;
+  const int dbc = tid / PG::DBP, dbpart = tid % PG::DBP;
+  const int S = p.S, W = p.pair_wgs, K = min(p.k_tiles, kMT);
+  const int t0 = xcd_tile(blockIdx.x, W);
+  const unsigned rowb = (unsigned)(p.row_elems * sizeof(float));
+  int Kv = 0;   // tiles this workgroup really holds
+  for (int s = 0; s < K && t0 + s * W < p.m.n_tiles; ++s, ++Kv) tile_tables_to_lds<false>(p.m, t0 + s * W, ldsMeta + s * kMS);
+  __syncthreads();
+
+  bool pre = false, ok = true;
+  unsigned *pend_flags = nullptr;
+  int pend_ph = 0, n_ahead = 0;
+  Aux mk_n{};
+  float4 xrow_n = f4_zero();
+  struct Next {          // the turn after this one
+    bool gather;         // it gathers halo rows from X once the flags of its wait list show ph - 1
+    int ph, s;
+    const float *X;
+    bool tape;           // it runs a dense half: tape row and sign bits of event ev
+    size_t ev;
+  };
+  auto fetch = [&](size_t ev, int s) {
+    const int node = max(reinterpret_cast<const int4 *>(ldsMeta + s * kMS + kMetaF)[tid >> 4].x, 0);
+    const unsigned own = (unsigned)node * (unsigned)(PD * 4) + (unsigned)((tid & 15) * 16);
+    if constexpr (RELU) mk_n = ldu8_g(p.masks + ev * p.mask_bytes + (size_t)(t0 + s * W) * kThreads, (unsigned)tid);
+    else mk_n = ld4_stream_g(p.ztape + ev * p.row_elems, own);
+    xrow_n = ld4_stream_g(p.tape + ev * p.row_elems, own);
+  };
+  auto t0_publish = [&]() {
+    wait_vmcnt0();
+    __syncthreads();
+    if (pend_flags && tid == 0) __hip_atomic_store(pend_flags, (unsigned)pend_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_flags = nullptr;
+  };
+  // T0, then (unless the rows were gathered ahead) blocking wait + gather
+  auto top = [&](const TileCtx &c, int ph, const float *X) -> bool {
+    t0_publish();
+    n_ahead += pre ? 1 : 0;
+    if (!pre) {
+      if (!tile_wait(p.m, c, ph, s_ok)) return false;
+      halo_fill_all(c, X, ldsXh);
+      wait_vmcnt0();
+      __syncthreads();
+    }
+    return true;
+  };
+  // (operand tiles __restrict__: these LDS reads must not wait for a DMA issued into the halo region)
+  auto dw_products = [&](const float *__restrict__ tX, const float *__restrict__ tDZ, f32x4 (&dwl)[PG::DWT], float &dbl) {
+    const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = wave_u + PG::WAVES * mm;
+      if (tt < NT) {   // wave-uniform
+        const int mt = tt / PG::CT, nt = tt % PG::CT;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          float a[kTM / 8], b[kTM / 8];
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) {
+            a[ks] = tX[(4 * (ks + 4 * kh) + kq) * PG::TS + mt * 16 + i16];
+            b[ks] = tDZ[(4 * (ks + 4 * kh) + kq) * PG::TS + nt * 16 + i16];
+          }
+#pragma unroll
+          for (int ks = 0; ks < kTM / 8; ++ks) dwl[mm] = mfma16(a[ks], b[ks], dwl[mm]);
+        }
+      }
+    }
+    float sdb = 0.f;
+#pragma unroll
+    for (int nn = dbpart; nn < kTM; nn += PG::DBP) sdb += tDZ[nn * PG::TS + dbc];
+#pragma unroll
+    for (int o = 1; o < PG::DBP; o <<= 1) sdb += __shfl_xor(sdb, o);
+    dbl += sdb;
+  };
+  auto dense = [&](const TileCtx &c, unsigned own, int ph, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout,
+                   const Next &nx) {
+    kbar = f4_scale(c.ci, kbar);
+    float4 dz;
+    if constexpr (RELU) {
+      dz = c.valid ? make_float4((mk & 1u) ? kbar.x : 0.f, (mk & 2u) ? kbar.y : 0.f, (mk & 4u) ? kbar.z : 0.f, (mk & 8u) ? kbar.w : 0.f)
+                   : f4_zero();
+    } else {
+      dz = f4_sel(c.valid, f4_mul(kbar, f4_dact(p.act, mk)), f4_zero());
+    }
+    *reinterpret_cast<float4 *>(&ldsDZ[c.grp * PG::TS + 4 * c.q]) = dz;
+    *reinterpret_cast<float4 *>(&ldsX[c.grp * PG::TS + 4 * c.q]) = f4_sel(c.valid, xrow, f4_zero());
+    if (nx.tape) fetch(nx.ev, nx.s);
+    __syncthreads();
+    mfma_rows_times_bt<PD>(ldsDZ, ldsW, ldsG, wave_u, lane);
+    TileCtx cn;
+    unsigned f1 = 0;
+    if (nx.gather) {   // uniform
+      tile_ctx_from_lds<false>(cn, t0 + nx.s * W, ldsMeta + nx.s * kMS);
+      if (wave_u == 0) f1 = poll_issue(p.m, cn, p.m.flags);
+    }
+    dw_products(ldsX, ldsDZ, dwl, dbl);
+    if (nx.gather) {
+      if (wave_u == 0) {
+        const bool hit = poll_ready(cn, f1, nx.ph);
+        if (lane == 0) *s_pre = hit ? 1 : 0;
+      }
+      __syncthreads();
+      pre = *s_pre != 0;
+    } else {
+      __syncthreads();
+      pre = false;
+    }
+    const float4 gv = f4_sel(c.valid, f4_scale(c.ci, *reinterpret_cast<const float4 *>(&ldsG[c.grp * PG::TS + 4 * c.q])), f4_zero());
+    if (pre) {   // uniform
+      __syncthreads();   // every thread has read its row of G: the region is the halo again
+      halo_fill_all(cn, nx.X, ldsXh);
+    }
+    if (c.valid) store_sc1(gout, own, gv);
+    pend_flags = p.m.flags + 32 * c.tile;
+    pend_ph = ph;
+  };
+
+  const bool multi = Kv > 1;   // (one tile: the next turn is this tile's own next phase, whose rows are stored in THIS turn)
+  int ph = 0;
+  {   // first phase: K-bar of the last stage of the last step = dt b_S lambda, layer 2's dense half (no gather, no wait)
+    ++ph;
+    const size_t ev = (size_t)((p.n_steps - 1) * S + (S - 1)) * 2 + 1;
+    load_weight_lds(p.w2, ldsW, tid, false);
+    if (Kv > 0) fetch(ev, 0);
+    for (int s = 0; s < Kv; ++s) {
+      TileCtx c;
+      tile_ctx_from_lds<false>(c, t0 + s * W, ldsMeta + s * kMS);
+      const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      t0_publish();   // (the phase's W is in LDS; the previous turn's products are done with the operand tiles)
+      const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
+      const Aux mk = mk_n;
+      const float4 xrow = xrow_n;
+      const bool more = s + 1 < Kv;   // next: the workgroup's next tile, or layer 1 of the last stage of the last step on its first one
+      Next nx;
+      nx.gather = !more && multi; nx.ph = ph + 1; nx.s = more ? s + 1 : 0; nx.X = p.g2; nx.tape = true;
+      nx.ev = more ? ev : (size_t)((p.n_steps - 1) * S + (S - 1)) * 2;
+      dense(c, own, ph, dw2, db2, f4_scale(ldsC[S - 1], lam), mk, xrow, p.g2, nx);
+    }
+  }
+  for (int n = p.n_steps - 1; n >= 0 && ok; --n) {
+    for (int i = S - 1; i >= 0 && ok; --i) {
+      const bool last = (i == 0 && n == 0);
+      const size_t ev_b = (i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1;   // layer-2 event behind this stage's layer 1
+      {   // layer 1 of stage i: dL/dy1 = A^T g2
+        ++ph;
+        const size_t ev = (size_t)(n * S + i) * 2;
+        __syncthreads();
+        load_weight_lds(p.w1, ldsW, tid, false);
+        for (int s = 0; s < Kv; ++s) {
+          TileCtx c;
+          tile_ctx_from_lds<false>(c, t0 + s * W, ldsMeta + s * kMS);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          const Aux mk = mk_n;
+          const float4 xrow = xrow_n;
+          if (!top(c, ph, p.g2)) { ok = false; break; }
+          const float4 t = tile_aggregate_lean(c, ldsXh);
+          const bool more = s + 1 < Kv;
+          Next nx;
+          nx.gather = multi; nx.ph = more ? ph : ph + 1; nx.s = more ? s + 1 : 0; nx.X = more ? p.g2 : p.g1;
+          nx.tape = more || !last; nx.ev = more ? ev : ev_b;
+          dense(c, own, ph, dw1, db1, t, mk, xrow, p.g1, nx);
+        }
+        if (!ok) break;
+      }
+      {   // U-bar_i = A^T g1; K-bar of the stage evaluated before it (or the lambda update), layer 2's dense half
+        ++ph;
+        const size_t ev = ev_b;
+        __syncthreads();
+        load_weight_lds(p.w2, ldsW, tid, false);
+        for (int s = 0; s < Kv; ++s) {
+          TileCtx c;
+          tile_ctx_from_lds<false>(c, t0 + s * W, ldsMeta + s * kMS);
+          const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+          const Aux mk = mk_n;        // (the last phase runs no dense half: nothing was asked for)
+          const float4 xrow = xrow_n;
+          if (!top(c, ph, p.g1)) { ok = false; break; }
+          // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5): in flight under the aggregation
+          const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
+          const float4 lb1 = ld4_g(p.ubar, own), lb2 = ld4_g(p.ubar, own + rowb), lb3 = ld4_g(p.ubar, own + 2 * rowb),
+                       lb4 = ld4_g(p.ubar, own + 3 * rowb), lb5 = ld4_g(p.ubar, own + 4 * rowb);
+          const float4 t = tile_aggregate_lean(c, ldsXh);
+          const float4 ub1 = i == 1 ? t : lb1, ub2 = i == 2 ? t : lb2, ub3 = i == 3 ? t : lb3, ub4 = i == 4 ? t : lb4,
+                       ub5 = i == 5 ? t : lb5;   // U-bar_i is t itself
+          float4 kbar;
+          if (i >= 1) {
+            if (c.valid) st4_g(p.ubar, own + (unsigned)(i - 1) * rowb, t);
+            float4 v = f4_scale(ldsC[42 + i], t);
+            v = f4_fma(ldsC[i - 1], lam, v);
+            v = f4_fma(ldsC[6 + i * 6 + 2], ub2, v); v = f4_fma(ldsC[6 + i * 6 + 3], ub3, v);
+            v = f4_fma(ldsC[6 + i * 6 + 4], ub4, v); v = f4_fma(ldsC[6 + i * 6 + 5], ub5, v);
+            kbar = v;
+          } else {
+            float4 v = f4_scale(1.0f, t);
+            v = f4_fma(1.0f, lam, v);
+            v = f4_fma(1.0f, ub1, v); v = f4_fma(1.0f, ub2, v); v = f4_fma(1.0f, ub3, v);
+            v = f4_fma(1.0f, ub4, v); v = f4_fma(1.0f, ub5, v);
+            if (c.valid) st4_g(p.lam, own, v);
+            kbar = f4_scale(ldsC[S - 1], v);
+          }
+          if (!last) {   // next: the workgroup's next tile, or layer 1 of stage i - 1 / of the last stage of the step before
+            const bool more = s + 1 < Kv;
+            const size_t ev_a = (size_t)(i >= 1 ? n * S + i - 1 : (max(n, 1) - 1) * S + (S - 1)) * 2;
+            Next nx;
+            nx.gather = multi; nx.ph = more ? ph : ph + 1; nx.s = more ? s + 1 : 0; nx.X = more ? p.g1 : p.g2;
+            nx.tape = true; nx.ev = more ? ev : ev_a;
+            dense(c, own, ph, dw2, db2, kbar, mk, xrow, p.g2, nx);
+          } else {
+            pre = false;     // (the final phase: every turn takes the blocking path; nothing is published)
+            __syncthreads();
+          }
+        }
+        if (!ok) break;
+      }
+    }
+  }
+  if (!ok) {
+    __syncthreads();
+    for (int s = 0; s < Kv; ++s) {
+      const int4 sc = p.m.sched[(size_t)(t0 + s * W) * kTM + (tid >> 4)];
+      if (sc.x >= 0) st4_g(p.lam, (unsigned)sc.x * (unsigned)(PD * 4) + (unsigned)((tid & 15) * 16), f4_nan());
+    }
+  }
+  const float bad = __int_as_float(0x7fc00000);
+  auto write_slab = [&](const f32x4 (&dwl)[PG::DWT], float dbl, float *slab_dw, float *slab_db) {
+    float4 *slab4 = reinterpret_cast<float4 *>(slab_dw + (size_t)blockIdx.x * PD * PD);
+#pragma unroll
+    for (int mm = 0; mm < PG::DWT; ++mm) {
+      const int tt = wave_u + PG::WAVES * mm;
+      if (tt < NT) slab4[tt * 64 + lane] = f4_sel(ok, make_float4(dwl[mm][0], dwl[mm][1], dwl[mm][2], dwl[mm][3]), f4_nan());
+    }
+    if (dbpart == 0) slab_db[(size_t)blockIdx.x * PD + dbc] = ok ? dbl : bad;
+  };
+  write_slab(dw1, db1, p.slab_dw1, p.slab_db1);
+  write_slab(dw2, db2, p.slab_dw2, p.slab_db2);
+  if (tid == 0 && p.m.stats && Kv > 0) p.m.stats[2 * t0 + 1] = n_ahead;
+}
+
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -1893,6 +2166,7 @@ int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per w
   take(node_fwd_persistentKP_kernel<NGPDE_ACT_RELU, true>); take(node_fwd_persistentKP_kernel<NGPDE_ACT_RELU, false>);
   take(node_fwd_persistentKP_kernel<-1, true>); take(node_fwd_persistentKP_kernel<-1, false>);
   take(node_bwd_persistentK_kernel<NGPDE_ACT_RELU>); take(node_bwd_persistentK_kernel<-1>);
+  take(node_bwd_persistentKP_kernel<NGPDE_ACT_RELU>); take(node_bwd_persistentKP_kernel<-1>);
   if (g->by_t.slot_w) {
     take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, true, true>); take(node_fwd_persistentK_kernel<NGPDE_ACT_RELU, false, true>);
     take(node_fwd_persistentK_kernel<-1, true, true>); take(node_fwd_persistentK_kernel<-1, false, true>);
@@ -2155,8 +2429,13 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     if ((st = launch_zero(a.ubar, 5 * a.row_elems * sizeof(float), stream))) return st;   // the stage adjoints start from zero
     const dim3 gridk(ps.pair_wgs), blockk(kThreads);
     NGPDE_REQUIRE(!k.m.slot_w || a.k_tiles <= kMaxTileRoundsW, NGPDE_ERR_STATE, "weighted tile rounds: at most %d tiles per workgroup", kMaxTileRoundsW);
+    const char *nopipe_b = std::getenv("NGPDE_NO_TILE_PIPE");
+    const bool piped_b = !k.m.slot_w && !(nopipe_b && nopipe_b[0] == '1');
 #define NGPDE_PBK_LAUNCH(AA)                                                                                                      \
-    if (k.m.slot_w) {                                                                                                             \
+    if (piped_b) {                                                                                                                \
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistentKP_kernel<AA>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
+      else hipLaunchKernelGGL((node_bwd_persistentKP_kernel<AA>), gridk, blockk, 0, stream, k);                                    \
+    } else if (k.m.slot_w) {                                                                                                      \
       if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistentK_kernel<AA, true>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
       else hipLaunchKernelGGL((node_bwd_persistentK_kernel<AA, true>), gridk, blockk, 0, stream, k);                               \
     } else if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistentK_kernel<AA, false>), gridk, blockk, 0, stream, a.ev_start, a.ev_stop, 0, k);  \
