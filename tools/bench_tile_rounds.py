@@ -34,8 +34,11 @@ for f in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
         torch.cuda.synchronize()
         if rep:
             best = [min(best[0], ev[0].elapsed_time(ev[1])), min(best[1], ev[1].elapsed_time(ev[2]))]
+    af, ab, tt = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(lib.ngpde_node_pipeline_stats(plan.ptr, stream, C.byref(af), C.byref(ab), C.byref(tt)))
     tot = best[0] + best[1]
     print(json.dumps({"nodes": n, "tiles": n // 32, "plan": sorted(plan.flags()), "fault": bool(plan.fault()), "ms_forward": round(best[0], 3),
                       "ms_adjoint": round(best[1], 3), "ms_total": round(tot, 3), "ode_steps_per_s": round(STEPS / (tot * 1e-3), 1),
-                      "frac_of_hbm_bound": round(f * BYTES / (tot * 1e-3) / 8e12, 4), "finite": bool(torch.isfinite(du).all())}), flush=True)
+                      "frac_of_hbm_bound": round(f * BYTES / (tot * 1e-3) / 8e12, 4), "finite": bool(torch.isfinite(du).all()),
+                      "turns": int(tt.value), "gathered_ahead_forward": int(af.value), "gathered_ahead_adjoint": int(ab.value)}), flush=True)
     plan = None
