@@ -513,35 +513,6 @@ def secondary(dev, world, rank, dist):
         out["C4_mppde_data_parallel_step"] = {"trajectories_per_rank": 64, "ranks": world, "ms_step": round(ms, 4),
                                               "value": round(world * 64 / (ms * 1e-3), 1), "unit": "trajectory-layers/s (fwd+bwd+all-reduce+Adam)",
                                               "gradient_floats": int(flat.numel()), "scaling": "weak"}
-    if world > 1:
-        # C5 replicas: every rank holds the same 64 x 64 grid graph (a single 4 096-node graph is never split) and its own input
-        # field; GNOConv 128 => 128 forward + backward, one all-reduce of the flat gradient, fused Adam -- the C4 leg's scheme
-        l5, ps5, st5, x5, n_e5 = c5_layer(dev, 0.1, seed=rank)
-        flat5, ps5v = ng.optim.flatten_parameters(ng.to_device(ps5, dev))
-        opt5 = ng.optim.setup(ng.optim.Adam(1e-4), flat5)
-        x5 = x5.detach().requires_grad_(True)
-        R5 = torch.ones(4096, 128, device=dev).T
-
-        def step5():
-            flat5.zero_grad()
-            l5(x5, ps5v, st5)[0].backward(R5)
-            ng.optim.update(opt5, flat5)
-        for _ in range(2):
-            step5()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            step5()
-        dist.barrier()
-        torch.cuda.synchronize()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms = 1e3 * float(tt.item()) / reps
-        out["C5_gno_data_parallel_step"] = {"replicas": world, "ranks": world, "edges": n_e5, "ms_step": round(ms, 4),
-                                            "value": round(world / (ms * 1e-3), 1), "unit": "layers/s (fwd+bwd+all-reduce+Adam)",
-                                            "gradient_floats": int(flat5.numel()), "scaling": "weak"}
     if world == 1:
         for radius in (0.05, 0.1):
             l5, ps5, st5, x5, n_e5 = c5_layer(dev, radius)

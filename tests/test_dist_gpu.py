@@ -92,7 +92,7 @@ def test_bench_n2_path_end_to_end_with_torchrun_and_gloo():
     assert d["unit"] == "ODE-steps/s" and d["value"] > 0 and d["higher_is_better"] is True
     assert d["value"] == pytest.approx(2 * 50 * 2 / (d["ms_per_step"] * 1e-3 * 2), rel=1e-3)   # whole-job aggregate over both ranks
     sec = d["secondary"]
-    assert sec["C4_mppde_data_parallel_step"]["ranks"] == 2 and sec["C5_gno_data_parallel_step"]["ranks"] == 2
+    assert sec["C4_mppde_data_parallel_step"]["ranks"] == 2 and set(sec) == {"C4_mppde_data_parallel_step"}   # N > 1: the C2 step + this leg only
 
 
 def _run_bench(extra_env, *argv, timeout=900):
