@@ -358,9 +358,9 @@ def secondary(dev, world, rank, dist):
     if world == 1:
         # BASELINE config 1 (the reference's own CPU-runnable case, docs/src/tutorials/graph_node.md:44-83): NeuralODE(2 x GCNConv(32 => 32,
         # relu)) on a Cora-sized graph with Cora's degree skew (2 708 nodes, 5 278 pairs, hubs of degree ~100 beside a median of 3),
-        # Euler x 10.  Its hub tiles do not fit the 96-row LDS halo, so the solver replays the per-layer kernels with the per-row
-        # gather (hub rows walked by 32 lane groups, gcn_fused.hip: coop_long_rows); `same_size_without_hubs` is the persistent plan
-        # on a closest-pairs graph of the same size -- what a persistent form for hub graphs would buy
+        # Euler x 10.  Its hub tiles do not fit the handle's 96-row halo lists: the solver runs the persistent kernels' hub geometry
+        # (node_persistent.hip: its own tile partition, 256-row halos, hub rows summed by all lane groups; round 4 replayed the per-layer
+        # kernels with the per-row gather: 0.43 ms); `same_size_without_hubs` is the 96-row geometry on a closest-pairs graph of that size
         n1, pairs1, d1, steps1 = 2708, 5278, 32, 10
         c1 = {}
         for name, (s1, t1) in (("cora_like", S.preferential_pairs_graph(n1, pairs1, seed=1)),

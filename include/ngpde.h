@@ -431,14 +431,18 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int3
  * forward solve / the adjoint run as ONE persistent launch each, tiles synchronised inside the launch by per-tile phase flags:
  * graphs whose tiles fit the LDS halo, d = 64 (d = 16 / 32 zero-padded onto it, bit 7), any activation; up to 2 tiles per
  * co-resident workgroup in registers (bit 5), up to 8 taking turns (bit 6); graphs with edge weights on the turn-taking form with
- * the slot weights in LDS (up to 3 tiles per workgroup).  d = 128 and tiles beyond the halo keep the replayed plan.  A persistent launch
+ * the slot weights in LDS (up to 3 tiles per workgroup); graphs with hubs of at most one tile per CU in the hub geometry (bit 8).  d = 128,
+ * larger graphs with hubs and weighted graphs with hubs keep the replayed plan.  A persistent launch
  * needs all its workgroups resident at once: run one such solve at a time per device (NGPDE_NO_PERSISTENT=1 selects the
  * replayed plan otherwise).  Its waits are bounded; a launch that gives up writes NaN outputs and raises the plan's fault
  * flag, which ngpde_node_fault reads (synchronises `stream`). */
 enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4, NGPDE_NODE_PERSISTENT_FWD = 8,
        NGPDE_NODE_PERSISTENT_BWD = 16, NGPDE_NODE_TILE_PAIRS = 32 /* persistent launches with two tiles per workgroup */,
        NGPDE_NODE_TILE_ROUNDS = 64 /* persistent launches with k tiles per workgroup taking turns (larger graphs) */,
-       NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */ };
+       NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */,
+       NGPDE_NODE_HUB_GEOMETRY = 256 /* persistent launches in the hub geometry: graphs of at most one 32-row tile per CU whose tiles reach
+                                        beyond the 96-row halo / 32-entry rows (a Cora-shaped graph, docs/src/tutorials/graph_node.md:14-23):
+                                        256-row halos, variable-length rows, hub rows summed by all lane groups of the workgroup */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`

@@ -191,6 +191,17 @@ struct NodePersist {
   volatile unsigned *fault_host = nullptr;   // the same word in pinned host memory: readable without a synchronisation
   int *stats = nullptr;        // [n_tiles][2]: slot-phases of the last forward / adjoint launch gathered ahead of time (interleaved kernels)
   float *coef = nullptr;       // device tables indexed by the stage: forward [42], adjoint [48] (layout: node.hip)
+  // hub geometry (node_persistent.hip: graphs whose tiles do not fit the handle's 96-row halo lists): per direction (0 by target,
+  // 1 by source) the tile lists the HUB kernels read, built by node_persistent_setup; `nbr` is then [n_tiles][256]
+  bool hub = false;
+  struct HubLists {
+    int32_t *halo = nullptr;   // [n_tiles][256]
+    uint8_t *slots = nullptr;  // [n_tiles][4096]
+    int2 *rows = nullptr;      // [n_sched]
+    int4 *info = nullptr;      // [n_tiles]
+    uint8_t *longs = nullptr;  // [n_tiles][32]
+    int4 *sched = nullptr;     // [n_sched] the geometry's own tile partition (both directions hold the same one)
+  } hub_lists[2];
 };
 struct NodePersistFwd {
   const ngpde_graph *g = nullptr;
@@ -228,8 +239,11 @@ bool node_persistent_interleave_env();
 bool node_persistent_disabled_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);
 int node_persistent_mode(const ngpde_graph *g, int d, int act, bool with_bwd);   // 0 none, 1 one tile per workgroup, 2 tile pairs, 3 tile rounds
+// graphs the modes above refuse because a tile does not fit the handle's halo lists (hubs): can the hub geometry be tried?  (Whether
+// every tile fits ITS caps is found out by node_persistent_setup(..., hub = true), which returns NGPDE_ERR_UNSUPPORTED otherwise.)
+bool node_persistent_hub_possible(const ngpde_graph *g, int d);
 int node_persistent_rounds(const ngpde_graph *g);                               // mode 3: tiles per workgroup
-int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps, bool pair = false);
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host /* [90] */, NodePersist *ps, bool pair = false, bool hub = false);
 void node_persistent_free(NodePersist *ps);
 int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream);
 int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream);

@@ -155,6 +155,7 @@ struct ngpde_node {
   // synchronised by per-tile phase flags.  Chosen when the graph is one co-resident wave of tiles (<= 2 per CU), d = 64,
   // relu (adjoint), unweighted, pre-scaled form available; NGPDE_NO_PERSISTENT=1 or NGPDE_PERSISTENT=fwd|bwd restrict it.
   bool persist_fwd = false, persist_bwd = false;
+  bool hub = false;          // ... in the hub geometry (graphs whose tiles do not fit the handle's halo lists)
   // persistent adjoint of an activation other than relu: the tape holds the aggregated inputs (first half) and the pre-activations
   // (second half, `ztape`), two rows per stage evaluation each, indexed like the relu plan's tape
   bool ztape_mode = false;
@@ -488,10 +489,18 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   p->pre = fused_prescaled_supported(g, d) && std::getenv("NGPDE_NO_PRESCALE") == nullptr;
   // The persistent form (node_persistent.hip) is decided here, before the tape is sized: with an activation other than relu its
   // adjoint reads the pre-activations from a tape of its own layout.  (Interleaved batches: relu only.)
-  const int pmode = p->pre ? node_persistent_mode(g, d, act, p->with_bwd) : 0;
+  int pmode = p->pre ? node_persistent_mode(g, d, act, p->with_bwd) : 0;
+  // Graphs with hubs (a tile beyond the handle's 96-row halo lists, BASELINE config 1): the hub geometry of the persistent kernels, on
+  // pre-scaled arrays like every persistent plan -- both directions or not at all (there is no pre-scaled replayed plan for them)
+  bool hub = !p->pre && pmode == 0 && members == 1 && std::getenv("NGPDE_NO_PRESCALE") == nullptr && node_persistent_hub_possible(g, d) &&
+             (!p->with_bwd || p->mask_mode || act != NGPDE_ACT_RELU);
+  if (hub) {
+    pmode = 4;
+    p->pre = true;
+  }
   p->pair = pmode == 2 && members == 1 && (!p->with_bwd || p->mask_mode);
   p->ktiles = (pmode == 3 && members == 1) ? node_persistent_rounds(g) : 0;
-  bool want_persist = (pmode == 1 && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1))) || p->pair || p->ktiles > 0;
+  bool want_persist = (pmode == 1 && (!p->with_bwd || p->mask_mode || (act != NGPDE_ACT_RELU && members == 1))) || p->pair || p->ktiles > 0 || hub;
   const int S = p->tb.S;
   int32_t st = NGPDE_OK;
   if (want_persist) {
@@ -512,7 +521,7 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
       for (int j = i + 1; j < S; ++j) coef[48 + i * 6 + j] = (float)(dt * tb.a[j][i - 1]);
       coef[84 + i] = (float)(dt * tb.a[i][i - 1]);
     }
-    st = node_persistent_setup(g, coef, &p->persist, p->pair);
+    st = node_persistent_setup(g, coef, &p->persist, p->pair, hub);
     if (st == NGPDE_ERR_UNSUPPORTED) {   // a wait list too long for one polling wave (or neighbouring tile pairs): the replayed plan
       st = NGPDE_OK;
       p->persist_fwd = p->persist_bwd = false;
@@ -529,6 +538,13 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   if (!p->persist_fwd) p->ktiles = 0;
   // activations other than relu: the persistent pair needs BOTH directions persistent (the tapes' layouts differ from the replayed plan's)
   if (p->with_bwd && !p->mask_mode && !(p->persist_fwd && p->persist_bwd)) p->persist_fwd = p->persist_bwd = false;
+  if (hub && !(p->persist_fwd && (p->persist_bwd || !p->with_bwd))) {   // hub geometry refused (a cap, NGPDE_PERSISTENT=fwd / bwd): the unscaled replayed plan
+    p->persist_fwd = p->persist_bwd = false;
+    p->pre = false;
+    hub = false;
+    node_persistent_free(&p->persist);
+  }
+  p->hub = hub;
   p->ztape_mode = p->with_bwd && !p->mask_mode && p->persist_fwd && p->persist_bwd;
   p->slots = p->mask_mode ? 2 : (p->ztape_mode ? 4 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4));
   p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
@@ -610,7 +626,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   // d = 16 / 32 where the 64-wide persistent solver can take the graph: run widened (NGPDE_NO_WIDEN=1: the native-width replayed plan)
   const char *nw = std::getenv("NGPDE_NO_WIDEN");
   if (out && g && (d == 16 || d == 32) && !(nw && nw[0] == '1') && g->has_norm && g->n_nodes >= 1 &&
-      node_persistent_mode(g, 64, act, with_backward != 0) != 0) {
+      (node_persistent_mode(g, 64, act, with_backward != 0) != 0 || (members == 1 && node_persistent_hub_possible(g, 64)))) {
     ngpde_node_t *w = nullptr;
     if (node_create(g, members, 64, d, act, tableau, n_steps, dt, with_backward, &w) == NGPDE_OK) {
       if (w->persist_fwd && (w->persist_bwd || !w->with_bwd)) {
@@ -638,7 +654,8 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   NGPDE_REQUIRE(p != nullptr && flags != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_node_flags: NULL argument");
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
-           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0);
+           (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0) |
+           (p->hub ? NGPDE_NODE_HUB_GEOMETRY : 0);
   return NGPDE_OK;
 }
 

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 
@@ -89,6 +90,13 @@ struct TileMeta {
   unsigned *flags, *abort_word;
   int n_tiles;
   int *stats;   // [n_tiles][2] (forward, adjoint): slot-phases of the last launch whose halo rows were gathered ahead of time
+  // hub geometry (HUB kernels only; then `nbr` is [n_tiles][kHubNbr])
+  const int *hub_halo;        // [n_tiles][kHubHalo] node ids, own rows first
+  const uint8_t *hub_slots;   // [n_tiles][kHubList]
+  const int2 *hub_rows;       // [n_sched] {start, length} of the row's list inside its tile's slot bytes
+  const int4 *hub_info;       // [n_tiles] {halo count, list bytes, long rows, 0}
+  const int4 *hub_sched;      // [n_sched] {node or -1, 0, 0, bits of c[node]}: the hub geometry's OWN tile partition (see hub_partition)
+  const uint8_t *hub_long;    // [n_tiles][kTileRows] rows (0 .. 31) with more than kSlotWidth entries
   NGPDE_PST_FIELD
 };
 
@@ -315,6 +323,161 @@ __device__ __forceinline__ float4 tile_aggregate_rounds(const TileCtx &c, const 
   else return tile_aggregate_lean(c, ldsXh);
 }
 
+// ---- hub geometry (graphs whose tiles do not fit the 96-row halo / 32-entry rows: BASELINE config 1's Cora-shaped graph) --------
+// One workgroup per CU and tile; per tile and direction (lists built by node_persistent_setup, not part of the graph handle):
+//   * a halo of up to kHubHalo = 256 distinct rows (own rows first), 64 KB of LDS -- the reach of an LDS-DMA destination;
+//   * per row a VARIABLE-length list of slot bytes in CSR order (start aligned to 4, {start, length} per row), at most kHubList bytes
+//     per tile; no zero row: the tail of a list is masked, not padded;
+//   * rows longer than kSlotWidth entries ("long rows", the hubs) are summed by all 32 lane groups together: group g takes entries
+//     g, g + 32, ..., the 32 partial rows meet in LDS and the row's own group adds them in group order;
+//   * a wait list of up to 255 tiles: four flags per lane of the polling wave (position 63 of the list is the abort word's lane).
+// Arithmetic per row otherwise as in the 96-row geometry (groups of four slots, then the own row).
+constexpr int kHubHalo = 256;
+constexpr int kHubList = 4096;
+constexpr int kHubNbr = 256;
+constexpr int kHubXhF = kHubHalo * PD;
+constexpr int kHubMetaF = kHubList / 4 + (kHubHalo - kTM) + 2 * kTM + kTM / 4;   // slot bytes, foreign node ids, {start, length} per row, long-row indices
+
+struct HubCtx : TileCtx {
+  const uint8_t *hs;         // LDS: the tile's slot bytes
+  const int2 *hrows;         // LDS: {start, length} of every row's list
+  const uint8_t *hlong;      // LDS: rows with more than kSlotWidth entries
+  int start, len;            // this row's list (len = 0 for a long row: it is summed cooperatively)
+  int n_long;
+  int nb1, nb2, nb3;         // wave 0: wait-list entries lane + 64, + 128, + 192 (my_nbr = entry lane)
+};
+
+__device__ __forceinline__ void hub_ctx_init(const TileMeta &m, HubCtx &c, float *lds_meta) {
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave_u = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.grp = c.tid >> 4;
+  c.q = c.tid & 15;
+  c.tile = xcd_tile(blockIdx.x, m.n_tiles);
+  const size_t pos = (size_t)c.tile * kTM + c.grp;
+  const int4 sc = m.hub_sched[pos];
+  c.valid = sc.x >= 0;
+  c.node = max(sc.x, 0);
+  c.ci = c.valid ? __int_as_float(sc.w) : 0.f;
+  const int4 info = m.hub_info[c.tile];   // {halo count, list bytes (multiple of 16), long rows, -}
+  uint4 *ls = reinterpret_cast<uint4 *>(lds_meta);
+  int *lh = reinterpret_cast<int *>(lds_meta + kHubList / 4);
+  int2 *lr = reinterpret_cast<int2 *>(lds_meta + kHubList / 4 + (kHubHalo - kTM));
+  unsigned *ll = reinterpret_cast<unsigned *>(lds_meta + kHubList / 4 + (kHubHalo - kTM) + 2 * kTM);
+  if (c.tid * 16 < info.y) ls[c.tid] = reinterpret_cast<const uint4 *>(m.hub_slots + (size_t)c.tile * kHubList)[c.tid];
+  if (c.tid < kHubHalo - kTM) lh[c.tid] = m.hub_halo[(size_t)c.tile * kHubHalo + kTM + c.tid];
+  if (c.tid >= 256 && c.tid < 256 + kTM) lr[c.tid - 256] = m.hub_rows[(size_t)c.tile * kTM + (c.tid - 256)];
+  if (c.tid >= 320 && c.tid < 320 + kTM / 4) ll[c.tid - 320] = reinterpret_cast<const unsigned *>(m.hub_long + (size_t)c.tile * kTM)[c.tid - 320];
+  c.hs = reinterpret_cast<const uint8_t *>(ls);
+  c.lds_hnode = lh;
+  c.lds_slots = nullptr;
+  c.lds_w = nullptr;
+  c.hrows = lr;
+  c.hlong = reinterpret_cast<const uint8_t *>(ll);
+  c.hcount = __builtin_amdgcn_readfirstlane(info.x);
+  c.n_long = __builtin_amdgcn_readfirstlane(info.z);
+  const int2 mine = m.hub_rows[pos];
+  c.start = mine.x;
+  c.len = (c.valid && mine.y <= kSlotWidth) ? mine.y : 0;
+  int wm = c.len;
+  wm = max(wm, __shfl_xor(wm, 16));
+  wm = max(wm, __shfl_xor(wm, 32));
+  c.wmax = __builtin_amdgcn_readfirstlane(wm);
+  const int *nb = m.nbr + (size_t)c.tile * kHubNbr;
+  c.my_nbr = nb[c.lane]; c.nb1 = nb[c.lane + 64]; c.nb2 = nb[c.lane + 128]; c.nb3 = nb[c.lane + 192];
+}
+
+// tile_wait for a wait list of up to 255 tiles: four independent flag loads per lane and round
+__device__ __forceinline__ bool hub_wait(const TileMeta &m, const HubCtx &c, int ph, int *s_ok) {
+  if (ph <= 1) return true;
+  if (c.wave_u == 0) {
+    const unsigned need = (unsigned)(ph - 1);
+    const unsigned *a0 = (c.lane == 63) ? m.abort_word : (c.my_nbr >= 0 ? m.flags + 32 * c.my_nbr : nullptr);
+    const unsigned *a1 = c.nb1 >= 0 ? m.flags + 32 * c.nb1 : nullptr, *a2 = c.nb2 >= 0 ? m.flags + 32 * c.nb2 : nullptr,
+                   *a3 = c.nb3 >= 0 ? m.flags + 32 * c.nb3 : nullptr;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (unsigned it = 1;; ++it) {
+      unsigned f0 = need, f1 = need, f2 = need, f3 = need;
+      if (a0) f0 = __hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a1) f1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a2) f2 = __hip_atomic_load(a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a3) f3 = __hip_atomic_load(a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__any((int)(c.lane == 63 && f0 != 0))) { ok = false; break; }              // somebody gave up
+      if (__all((int)((c.lane == 63 || f0 >= need) && f1 >= need && f2 >= need && f3 >= need))) break;
+      if ((it & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (c.lane == 0) __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (c.lane == 0) *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// tile_gather_foreign for up to 224 foreign rows (halo slots 32 .. 255)
+__device__ __forceinline__ void hub_gather_foreign(const HubCtx &c, const float *X, float *ldsXh) {
+  float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
+#pragma unroll
+  for (int k = 0; k < (kHubHalo - kTM) / kTM; ++k) {
+    if (4 * c.wave_u + 32 * (k + 1) < c.hcount) {   // wave-uniform: a wave's four groups stage four consecutive slots
+      const unsigned off = (unsigned)c.lds_hnode[c.grp + 32 * k] * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(X) + off),
+                                       (__attribute__((address_space(3))) void *)(Xh4 + (c.grp + 32 * (k + 1)) * PG::LPR + c.q), 16, 0, 16);
+    }
+  }
+  wait_vmcnt0();
+  __syncthreads();
+}
+
+// the row's first 32 slot bytes, fetched from LDS BEFORE the wait (as tile_slot_words; words beyond the row's list hold other rows'
+// bytes or table words -- valid LDS, masked at use)
+__device__ __forceinline__ void hub_slot_words(const HubCtx &c, unsigned (&w)[8]) {
+  const unsigned *s4 = reinterpret_cast<const unsigned *>(c.hs + c.start);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = s4[k];
+}
+
+// sum of the row's neighbours + its own row; `part` = 32 x 64 floats of LDS that nobody else uses during the aggregation.
+// (Measured and not kept: the long row's partial rows formed first, eight masked entries per group unrolled with their slot bytes
+// fetched together -- 8 + 8 LDS reads per lane whatever the row's length: the hub tile's aggregation 3.8 k -> 4.7 k cycles.)
+__device__ __forceinline__ float4 hub_aggregate(const HubCtx &c, const unsigned (&sw)[8], const float *ldsXh, float *part) {
+  const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
+  float4 a = f4_zero();
+#pragma unroll
+  for (int jw = 0; jw < 8; ++jw) {
+    if (jw * 4 < c.wmax) {   // wave-uniform
+      const unsigned w = sw[jw];
+      float4 v[4];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) v[jb] = f4_sel(4 * jw + jb < c.len, Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q], f4_zero());
+      a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+    }
+  }
+  for (int li = 0; li < c.n_long; ++li) {   // uniform
+    const int r = c.hlong[li];
+    const int2 rl = c.hrows[r];
+    float4 p = f4_zero();
+    for (int j = c.grp; j < rl.y; j += kTM) p = f4_add(p, Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q]);
+    reinterpret_cast<float4 *>(part)[c.grp * PG::LPR + c.q] = p;
+    __syncthreads();
+    if (c.wave_u == (r >> 2)) {   // the wave of the row's group: each of its four groups adds eight partial rows, two exchanges fold them
+      const int g4 = c.grp & 3;
+      float4 t = reinterpret_cast<const float4 *>(part)[g4 * PG::LPR + c.q];
+#pragma unroll
+      for (int k = 1; k < kTM / 4; ++k) t = f4_add(t, reinterpret_cast<const float4 *>(part)[(g4 + 4 * k) * PG::LPR + c.q]);
+      t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16); t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
+      t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32); t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
+      if (c.grp == r) a = f4_add(a, t);
+    }
+    __syncthreads();   // (the buffer is written again: by the next long row, or by the caller -- the adjoint's dz tile)
+  }
+  return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+}
+
 // W (row-major [in][out]) -> LDS, transposed (forward: B[k = in][j = out], stored Bt[j][k]) or straight (pullback: Bt[j = in][k = out])
 __device__ __forceinline__ void load_weight_lds(const float *wt, float *ldsBt, int tid, bool transpose) {
   if (transpose) {
@@ -407,15 +570,20 @@ struct PFwdK {
 
 // WGT (edge weights, src/layers.jl:206-231): the 4 KB of slot weights of the tile need LDS that two resident W^T do not leave, so layer 1's
 // W^T is B fragments in registers for the whole launch (16 per lane; the forward kernel has them to spare) and only W2^T is in LDS
-template <int ACT, bool TAPE, bool WGT = false>
-__global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const PFwdK p) {
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + kMetaF + 48 + 4];
-  float *ldsXh = lds, *ldsT = lds + kXhF, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = WGT ? ldsW1 : ldsW1 + kWF;
+// HUB: the hub geometry (256-row halo, variable-length slot lists, long rows shared by the 32 lane groups, one workgroup per CU)
+template <int ACT, bool TAPE, bool WGT = false, bool HUB = false>
+__global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_kernel(const PFwdK p) {
+  static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
+  constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
+  __shared__ __attribute__((aligned(16))) float lds[XH + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + MF + 48 + 4];
+  static_assert(!HUB || sizeof(lds) <= 160 * 1024 - 64, "one workgroup per CU");
+  float *ldsXh = lds, *ldsT = lds + XH, *ldsZ = ldsT + kTileF, *ldsW1 = ldsZ + kTileF, *ldsW2 = WGT ? ldsW1 : ldsW1 + kWF;
   float *ldsSW = ldsW2 + kWF, *ldsB = WGT ? ldsSW + kSlotWF : ldsSW;
-  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = ldsB + 2 * PD, *ldsC = ldsMeta + MF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
-  TileCtx c;
-  tile_ctx_init(p.m, c, ldsMeta);
+  typename std::conditional<HUB, HubCtx, TileCtx>::type c;
+  if constexpr (HUB) hub_ctx_init(p.m, c, ldsMeta);
+  else tile_ctx_init(p.m, c, ldsMeta);
   if (c.tid < 42) ldsC[c.tid] = p.cf[c.tid];
   const int act = ACT >= 0 ? ACT : p.act;
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
@@ -434,7 +602,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
   load_weight_lds(p.w2, ldsW2, c.tid, true);
   if (c.tid < PD) ldsB[c.tid] = p.b1 ? p.b1[c.tid] : 0.f;
   else if (c.tid < 2 * PD) ldsB[c.tid] = p.b2 ? p.b2[c.tid - PD] : 0.f;
-  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (!HUB && c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);   // byte offset of this thread's 16 bytes in a [N][64] array
   __syncthreads();
@@ -456,13 +624,25 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistent_kernel(const 
         ++ph;
         const float *X = layer == 0 ? ((n == 0 && i == 0) ? u_in : p.bufA) : p.bufB;
         NGPDE_PST(p.m, ph, 0);
-        unsigned sw[8];
-        tile_slot_words(c, sw);
-        if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
-        NGPDE_PST(p.m, ph, 1);
-        tile_gather_foreign(c, X, ldsXh);
-        NGPDE_PST(p.m, ph, 2);
-        float4 acc = f4_scale(c.ci, WGT ? tile_aggregate_weighted(c, ldsXh) : tile_aggregate(c, sw, ldsXh));   // a_i = c_i * sum of the stored (pre-scaled) rows
+        float4 agg;
+        if constexpr (HUB) {
+          unsigned sw[8];
+          hub_slot_words(c, sw);
+          if (!hub_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          hub_gather_foreign(c, X, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          agg = hub_aggregate(c, sw, ldsXh, ldsZ);   // (the product's output tile is free until this phase's product)
+        } else {
+          unsigned sw[8];
+          tile_slot_words(c, sw);
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, X, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          agg = WGT ? tile_aggregate_weighted(c, ldsXh) : tile_aggregate(c, sw, ldsXh);
+        }
+        float4 acc = f4_scale(c.ci, agg);   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
         const size_t ev = ev0 + (size_t)(n * p.S + i) * 2 + layer;
         if (TAPE && c.valid) st4_stream_g(p.tape + ev * p.row_elems, own, acc);
@@ -1017,18 +1197,21 @@ struct PBwdK {
 // WGT: the tile's slot weights need 4 KB of LDS that two padded W do not leave (and the adjoint has no 16 registers to park
 // fragments in: fetched per phase they spill).  W1 is kept UNPADDED and XOR-swizzled instead (16 KB, conflict-free fragment reads:
 // gcn_tile.h, mfma_rows_times_bswz64), which makes exactly the room.
-template <int ACT, bool WGT = false>
-__global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const PBwdK p) {
+template <int ACT, bool WGT = false, bool HUB = false>
+__global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_kernel(const PBwdK p) {
+  static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
   constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
   using Aux = typename std::conditional<RELU, unsigned, float4>::type;   // what act' is formed from: 4 sign bits / the row of z
-  __shared__ __attribute__((aligned(16))) float lds[kXhF + 2 * kTileF + (WGT ? PD * PD + kWF + kSlotWF : 2 * kWF) + kMetaF + 48 + 4];
-  static_assert(sizeof(lds) <= 80 * 1024 - 64, "two workgroups per CU");
-  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + kXhF, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + (WGT ? PD * PD : kWF);
+  constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
+  __shared__ __attribute__((aligned(16))) float lds[XH + 2 * kTileF + (WGT ? PD * PD + kWF + kSlotWF : 2 * kWF) + MF + 48 + 4];
+  static_assert(sizeof(lds) <= (HUB ? 160 : 80) * 1024 - 64, "two workgroups per CU (hub geometry: one)");
+  float *ldsXh = lds, *ldsG = lds, *ldsDZ = lds + XH, *ldsX = ldsDZ + kTileF, *ldsW1 = ldsX + kTileF, *ldsW2 = ldsW1 + (WGT ? PD * PD : kWF);
   float *ldsSW = ldsW2 + kWF;
-  float *ldsMeta = WGT ? ldsSW + kSlotWF : ldsSW, *ldsC = ldsMeta + kMetaF;
+  float *ldsMeta = WGT ? ldsSW + kSlotWF : ldsSW, *ldsC = ldsMeta + MF;
   int *s_ok = reinterpret_cast<int *>(ldsC + 48);
-  TileCtx c;
-  tile_ctx_init(p.m, c, ldsMeta);
+  typename std::conditional<HUB, HubCtx, TileCtx>::type c;
+  if constexpr (HUB) hub_ctx_init(p.m, c, ldsMeta);
+  else tile_ctx_init(p.m, c, ldsMeta);
   if (c.tid < 48) ldsC[c.tid] = p.cb[c.tid];
   float4 *Xh4 = reinterpret_cast<float4 *>(ldsXh);
   if constexpr (WGT) {
@@ -1046,7 +1229,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
     load_weight_lds(p.w1, ldsW1, c.tid, false);
   }
   load_weight_lds(p.w2, ldsW2, c.tid, false);
-  if (c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
+  if (!HUB && c.grp == 0) Xh4[kHaloCap * PG::LPR + c.q] = f4_zero();
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);
   constexpr int NT = PG::CT * PG::CT;
@@ -1157,7 +1340,15 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
         const bool last_next = (i == 0 && n == 0);
         const size_t ev_next = ev0 + ((i >= 1) ? (size_t)(n * S + i - 1) * 2 + 1 : (size_t)((max(n, 1) - 1) * S + (S - 1)) * 2 + 1);
         float4 t;
-        if constexpr (WGT) {
+        if constexpr (HUB) {
+          unsigned sw[8];
+          hub_slot_words(c, sw);
+          if (!hub_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          hub_gather_foreign(c, p.g2, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = hub_aggregate(c, sw, ldsXh, ldsDZ);   // (the operand tiles of the previous phase's products are dead: that phase ended at this wait's barrier)
+        } else if constexpr (WGT) {
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g2, ldsXh);
@@ -1183,7 +1374,15 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistent_kernel(const 
         // next: layer 1 of stage i - 1, or of the last stage of the step before
         const size_t ev_next = ev0 + (size_t)(i >= 1 ? n * S + i - 1 : (max(n, 1) - 1) * S + (S - 1)) * 2;
         float4 t;
-        if constexpr (WGT) {
+        if constexpr (HUB) {
+          unsigned sw[8];
+          hub_slot_words(c, sw);
+          if (!hub_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          hub_gather_foreign(c, p.g1, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          t = hub_aggregate(c, sw, ldsXh, ldsDZ);   // (the operand tiles of the previous phase's products are dead: that phase ended at this wait's barrier)
+        } else if constexpr (WGT) {
           if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g1, ldsXh);
@@ -2183,6 +2382,146 @@ int node_persistent_rounds(const ngpde_graph *g) {   // K of mode 3: tiles per w
 }
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd) { return node_persistent_mode(g, d, act, with_bwd) == 1; }
 
+bool node_persistent_hub_possible(const ngpde_graph *g, int d) {
+  const char *nh = std::getenv("NGPDE_NO_HALO");   // (asks for the per-row global gather everywhere)
+  if (node_persistent_disabled_env() || (nh && nh[0] == '1')) return false;
+  if (!g || d != PD || !g->has_norm || !g->self_loops || g->by_t.slot_w || g->by_s.slot_w) return false;
+  if (g->by_t.halo_ok && g->by_s.halo_ok) return false;   // the 96-row geometry takes it
+  int dev = 0, cus = 0, occ = 1 << 30;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  auto take = [&](auto kernel) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, kThreads, 0) != hipSuccess) o = 0;
+    occ = std::min(occ, o);
+  };
+  take(node_fwd_persistent_kernel<NGPDE_ACT_RELU, true, false, true>); take(node_fwd_persistent_kernel<NGPDE_ACT_RELU, false, false, true>);
+  take(node_fwd_persistent_kernel<-1, true, false, true>); take(node_fwd_persistent_kernel<-1, false, false, true>);
+  take(node_bwd_persistent_kernel<NGPDE_ACT_RELU, false, true>); take(node_bwd_persistent_kernel<-1, false, true>);
+  const int nt = g->n_sched / kTileRows;
+  return nt >= 1 && nt <= cus * occ;
+}
+
+// The hub geometry's lists of one direction, from the CSR lists and the schedule order (host copies, or downloaded from a
+// device-built handle).  Slot numbering: own rows first (slot k = k-th row of the tile), every other row in order of first reference
+// (rows of the tile in order, entries in CSR order).  false: some tile exceeds a cap.
+// The hub geometry's own tile partition.  The handle's locality order grows clusters breadth-first, which puts a hub and the hubs
+// next to it into ONE tile (Cora-shaped graphs: > 256 distinct rows).  Here the nodes are dealt out worst first, in order of
+// descending degree: the n_tiles highest-degree nodes one per tile, every further node to the tile whose set of referenced rows H_t
+// (members and all their neighbours, both directions) grows least by it, among the tiles with a free slot that stay within the cap
+// with one row reserved per slot still free; a node with more than kSlotWidth entries (a long row: summed by the whole workgroup, two
+// barriers each) prefers the tiles with the fewest long rows.  Leaves end up with the hub they hang on (growth 0), hubs apart from each
+// other: at BASELINE config 1's shape one long row per tile at most, 94 referenced rows per tile on average (the first form of this
+// deal -- least growth only -- put the hubs next to each other: the tile with most of them took 17 k cycles per phase and every other
+// tile waited for it).  Returns the positions -> node order (tile t = positions 32 t ..), or an empty vector when some node fits nowhere.
+static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> rp[2], const std::vector<int32_t> cl[2]) {
+  const int nt = (int)((n + kTileRows - 1) / kTileRows);
+  std::vector<std::vector<int32_t>> nb((size_t)n);
+  for (int64_t v = 0; v < n; ++v) {
+    std::vector<int32_t> &a = nb[(size_t)v];
+    for (int dir = 0; dir < 2; ++dir)
+      for (int32_t p = rp[dir][v]; p < rp[dir][v + 1]; ++p)
+        if (cl[dir][p] != v) a.push_back(cl[dir][p]);
+    std::sort(a.begin(), a.end());
+    a.erase(std::unique(a.begin(), a.end()), a.end());
+  }
+  std::vector<int32_t> by_degree((size_t)n);
+  for (int64_t v = 0; v < n; ++v) by_degree[(size_t)v] = (int32_t)v;
+  std::stable_sort(by_degree.begin(), by_degree.end(), [&](int32_t a, int32_t b) { return nb[a].size() > nb[b].size(); });
+  std::vector<uint8_t> in_h((size_t)nt * n, 0);
+  std::vector<int> h_size(nt, 0), cap(nt, kTileRows);
+  std::vector<int> n_long(nt, 0);
+  std::vector<std::vector<int32_t>> members(nt);
+  cap[nt - 1] = (int)(n - (int64_t)kTileRows * (nt - 1));
+  int64_t dealt = 0;
+  for (int32_t v : by_degree) {
+    const bool is_long = (int)nb[v].size() > kSlotWidth;
+    int best_t = -1, best_inc = 1 << 30, best_h = 1 << 30, best_l = 1 << 30;
+    if (dealt < nt) best_t = (int)dealt;   // the n_tiles highest-degree nodes: one per tile
+    ++dealt;
+    for (int t = 0; t < nt && dealt > nt; ++t) {
+      if ((int)members[t].size() >= cap[t]) continue;
+      const uint8_t *h = in_h.data() + (size_t)t * n;
+      int inc = h[v] ? 0 : 1;
+      for (int32_t w : nb[v]) inc += h[w] ? 0 : 1;
+      if (h_size[t] + inc + (cap[t] - (int)members[t].size() - 1) > kHubHalo) continue;
+      const int l = is_long ? n_long[t] : 0;
+      if (l < best_l || (l == best_l && (inc < best_inc || (inc == best_inc && h_size[t] < best_h)))) {
+        best_t = t; best_inc = inc; best_h = h_size[t]; best_l = l;
+      }
+    }
+    if (best_t < 0) return {};
+    uint8_t *h = in_h.data() + (size_t)best_t * n;
+    if (!h[v]) { h[v] = 1; ++h_size[best_t]; }
+    for (int32_t w : nb[v])
+      if (!h[w]) { h[w] = 1; ++h_size[best_t]; }
+    if (h_size[best_t] + (cap[best_t] - (int)members[best_t].size() - 1) > kHubHalo) return {};   // (a seed beyond the cap: a hub of > ~224 neighbours)
+    members[best_t].push_back(v);
+    n_long[best_t] += is_long ? 1 : 0;
+  }
+  std::vector<int32_t> order;
+  order.reserve((size_t)n);
+  for (int t = 0; t < nt; ++t) order.insert(order.end(), members[t].begin(), members[t].end());
+  return order;
+}
+
+struct HubHost {
+  std::vector<int32_t> halo;
+  std::vector<uint8_t> slots, longs;
+  std::vector<int2> rows;
+  std::vector<int4> info;
+};
+static bool host_csr(const ngpde_graph *g, const Csr &c, std::vector<int32_t> &rowptr, std::vector<int32_t> &col) {
+  const int64_t n = g->n_nodes, m = g->n_edges;
+  if (!c.h_rowptr.empty()) { rowptr = c.h_rowptr; col = c.h_col; return true; }
+  rowptr.resize((size_t)n + 1); col.resize((size_t)std::max<int64_t>(m, 1));
+  if (hipMemcpy(rowptr.data(), c.rowptr, rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  if (m > 0 && hipMemcpy(col.data(), c.col, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  return true;
+}
+static bool build_hub_lists(const ngpde_graph *g, const std::vector<int32_t> &rowptr, const std::vector<int32_t> &col,
+                            const std::vector<int32_t> &order, HubHost &o) {
+  const int64_t n = g->n_nodes;
+  const int nt = g->n_sched / kTileRows;
+  o.halo.assign((size_t)nt * kHubHalo, 0);
+  o.slots.assign((size_t)nt * kHubList, 0);
+  o.longs.assign((size_t)nt * kTileRows, 0);
+  o.rows.assign((size_t)nt * kTileRows, make_int2(0, 0));
+  o.info.assign((size_t)nt, make_int4(0, 0, 0, 0));
+  std::vector<int32_t> slot_of((size_t)n, -1), stamp((size_t)n, -1);
+  for (int t = 0; t < nt; ++t) {
+    int count = kTileRows, bytes = 0, n_long = 0;
+    for (int k = 0; k < kTileRows; ++k) {
+      const int64_t pos = (int64_t)t * kTileRows + k;
+      if (pos >= n) continue;
+      const int32_t v = order[pos];
+      stamp[v] = t; slot_of[v] = k;
+      o.halo[(size_t)t * kHubHalo + k] = v;
+    }
+    for (int k = 0; k < kTileRows; ++k) {
+      const int64_t pos = (int64_t)t * kTileRows + k;
+      if (pos >= n) break;
+      const int32_t v = order[pos];
+      const int32_t rs = rowptr[v], deg = rowptr[v + 1] - rs;
+      if (bytes + deg > kHubList) return false;
+      o.rows[(size_t)pos] = make_int2(bytes, deg);
+      if (deg > kSlotWidth) o.longs[(size_t)t * kTileRows + n_long++] = (uint8_t)k;
+      for (int j = 0; j < deg; ++j) {
+        const int32_t u = col[rs + j];
+        if (stamp[u] != t) {
+          if (count >= kHubHalo) return false;
+          stamp[u] = t; slot_of[u] = count;
+          o.halo[(size_t)t * kHubHalo + count++] = u;
+        }
+        o.slots[(size_t)t * kHubList + bytes + j] = (uint8_t)slot_of[u];
+      }
+      bytes = (bytes + deg + 3) & ~3;
+      if (bytes > kHubList) return false;
+    }
+    o.info[t] = make_int4(count, (bytes + 15) & ~15, n_long, 0);
+  }
+  return true;
+}
+
 // NGPDE_NO_INTERLEAVE=1: a batch's members one after the other (the round-2 form) instead of two at a time -- the A/B switch and
 // the reference the interleaved kernels are compared with bit for bit
 bool node_persistent_interleave_env() {
@@ -2190,10 +2529,65 @@ bool node_persistent_interleave_env() {
   return !(e && e[0] == '1');
 }
 
-int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps, bool pair) {
+int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps, bool pair, bool hub) {
   std::vector<int> lists;
-  NGPDE_REQUIRE(build_wait_lists(g, lists), NGPDE_ERR_UNSUPPORTED, "persistent solver: a tile's wait list exceeds %d tiles", kNbrStride);
   const int nt = g->n_sched / kTileRows;
+  ps->hub = false;
+  if (hub) {
+    NGPDE_REQUIRE(!pair && nt <= kHubNbr, NGPDE_ERR_UNSUPPORTED, "persistent solver, hub geometry: at most %d tiles, one per workgroup", kHubNbr);
+    std::vector<int32_t> rp[2], cl[2];
+    NGPDE_REQUIRE(host_csr(g, g->by_t, rp[0], cl[0]) && host_csr(g, g->by_s, rp[1], cl[1]), NGPDE_ERR_HIP, "download of the CSR lists failed");
+    const std::vector<int32_t> order = hub_partition(g->n_nodes, rp, cl);
+    NGPDE_REQUIRE((int64_t)order.size() == g->n_nodes, NGPDE_ERR_UNSUPPORTED,
+                  "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each", kHubHalo);
+    HubHost hh[2];
+    NGPDE_REQUIRE(build_hub_lists(g, rp[0], cl[0], order, hh[0]) && build_hub_lists(g, rp[1], cl[1], order, hh[1]), NGPDE_ERR_UNSUPPORTED,
+                  "persistent solver, hub geometry: a tile references more than %d distinct rows or holds more than %d entries", kHubHalo, kHubList);
+    // the partition's schedule: {node, 0, 0, bits of c[node]} per position, -1 padded
+    std::vector<float> cnode((size_t)g->n_nodes);
+    NGPDE_HIP_CHECK(hipMemcpy(cnode.data(), g->c, cnode.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<int4> hsched((size_t)nt * kTileRows, make_int4(-1, 0, 0, 0));
+    for (int64_t pos = 0; pos < g->n_nodes; ++pos) {
+      int4 e = make_int4(order[pos], 0, 0, 0);
+      std::memcpy(&e.w, &cnode[order[pos]], 4);
+      hsched[(size_t)pos] = e;
+    }
+    // wait lists: symmetric closure over both directions, up to 255 tiles, position 63 left free (that lane watches the abort word)
+    std::vector<int32_t> tile_of((size_t)g->n_nodes, 0);
+    for (int64_t pos = 0; pos < g->n_nodes; ++pos) tile_of[order[pos]] = (int32_t)(pos / kTileRows);
+    std::vector<std::vector<int>> nb(nt);
+    for (const HubHost &h : hh)
+      for (int t = 0; t < nt; ++t)
+        for (int k = kTileRows; k < h.info[t].x; ++k) {
+          const int u = tile_of[h.halo[(size_t)t * kHubHalo + k]];
+          if (u == t) continue;
+          nb[t].push_back(u);
+          nb[u].push_back(t);
+        }
+    lists.assign((size_t)nt * kHubNbr, -1);
+    for (int t = 0; t < nt; ++t) {
+      std::sort(nb[t].begin(), nb[t].end());
+      nb[t].erase(std::unique(nb[t].begin(), nb[t].end()), nb[t].end());
+      NGPDE_REQUIRE((int)nb[t].size() <= kHubNbr - 1, NGPDE_ERR_UNSUPPORTED, "persistent solver, hub geometry: a wait list exceeds %d tiles", kHubNbr - 1);
+      for (size_t k = 0; k < nb[t].size(); ++k) lists[(size_t)t * kHubNbr + (k < 63 ? k : k + 1)] = nb[t][k];
+    }
+    for (int dir = 0; dir < 2; ++dir) {
+      NodePersist::HubLists &L = ps->hub_lists[dir];
+      const HubHost &h = hh[dir];
+      auto up = [&](auto **dst, const auto &v) -> int32_t {
+        NGPDE_HIP_CHECK(hipMalloc((void **)dst, std::max<size_t>(v.size(), 1) * sizeof(v[0])));
+        NGPDE_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+        return NGPDE_OK;
+      };
+      int32_t st;
+      if ((st = up(&L.halo, h.halo)) || (st = up(&L.slots, h.slots)) || (st = up(&L.rows, h.rows)) || (st = up(&L.info, h.info)) ||
+          (st = up(&L.longs, h.longs)) || (st = up(&L.sched, hsched)))
+        return st;
+    }
+    ps->hub = true;
+  } else {
+    NGPDE_REQUIRE(build_wait_lists(g, lists), NGPDE_ERR_UNSUPPORTED, "persistent solver: a tile's wait list exceeds %d tiles", kNbrStride);
+  }
   ps->n_tiles = nt;
   ps->pair_wgs = 0;
   if (pair) {
@@ -2234,6 +2628,16 @@ void node_persistent_free(NodePersist *ps) {
   if (ps->coef) (void)hipFree(ps->coef);
   if (ps->stats) (void)hipFree(ps->stats);
   ps->stats = nullptr;
+  for (NodePersist::HubLists &L : ps->hub_lists) {
+    if (L.halo) (void)hipFree(L.halo);
+    if (L.slots) (void)hipFree(L.slots);
+    if (L.rows) (void)hipFree(L.rows);
+    if (L.info) (void)hipFree(L.info);
+    if (L.longs) (void)hipFree(L.longs);
+    if (L.sched) (void)hipFree(L.sched);
+    L = NodePersist::HubLists();
+  }
+  ps->hub = false;
   ps->nbr = nullptr; ps->sync = nullptr; ps->fault = nullptr; ps->coef = nullptr;
 }
 
@@ -2246,9 +2650,11 @@ __global__ void set_word_kernel(unsigned *w, unsigned v) {
 __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
   if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
 }
-TileMeta make_meta(const Csr &c, const NodePersist &ps) {
+TileMeta make_meta(const Csr &c, const NodePersist &ps, int dir) {
   TileMeta m;
   m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr; m.slot_w = c.slot_w;
+  const NodePersist::HubLists &L = ps.hub_lists[dir];
+  m.hub_halo = L.halo; m.hub_slots = L.slots; m.hub_rows = L.rows; m.hub_info = L.info; m.hub_long = L.longs; m.hub_sched = L.sched;
   m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 64; m.n_tiles = ps.n_tiles;   // [slot 0 | slot 1 | abort]
   m.stats = ps.stats;
 #ifdef NGPDE_STAMPS
@@ -2324,7 +2730,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
-  k.m = make_meta(g->by_t, ps);
+  k.m = make_meta(g->by_t, ps, 0);
   {
     const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
     if (fa && fa[0] == '1') hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, 1u);
@@ -2369,6 +2775,24 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   NGPDE_REQUIRE(!k.m.slot_w || (!a.pair && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE,
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
+  if (ps.hub) {   // hub geometry: one tile per workgroup and CU
+    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave && a.n_members == 1, NGPDE_ERR_STATE, "hub geometry: one unweighted member, one tile per workgroup");
+    k.ztape = a.ztape;
+    NGPDE_REQUIRE(!a.tape || (a.act == NGPDE_ACT_RELU ? a.masks != nullptr : a.ztape != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
+                  "persistent forward with a tape needs the sign-bit masks (relu) or the pre-activation tape");
+#define NGPDE_PFH_LAUNCH(AA, TT)                                                                                                   \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, true>), grid, block, 0, stream, k);
+    if (a.tape && a.act == NGPDE_ACT_RELU) { NGPDE_PFH_LAUNCH(NGPDE_ACT_RELU, true) }
+    else if (a.tape) { NGPDE_PFH_LAUNCH(-1, true) }
+    else if (a.act == NGPDE_ACT_RELU) { NGPDE_PFH_LAUNCH(NGPDE_ACT_RELU, false) }
+    else { NGPDE_PFH_LAUNCH(-1, false) }
+#undef NGPDE_PFH_LAUNCH
+    NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel (hub geometry)");
+    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    NGPDE_LAUNCH_CHECK("latch_fault_kernel");
+    return turn.leave();
+  }
 #define NGPDE_PF_LAUNCH(AA, TT)                                                                                              \
   if (k.m.slot_w) {                                                                                                          \
     if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
@@ -2409,7 +2833,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
-  k.m = make_meta(g->by_s, ps);
+  k.m = make_meta(g->by_s, ps, 1);
   k.n_steps = a.n_steps; k.S = a.S; k.n_members = a.n_members; k.act = a.act; k.ztape = a.ztape;
   k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
@@ -2451,7 +2875,17 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   NGPDE_REQUIRE(!k.m.slot_w || (!a.pair && !a.interleave && a.n_members == 1), NGPDE_ERR_STATE,
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
-  if (k.m.slot_w) {
+  if (ps.hub) {
+    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave && a.n_members == 1, NGPDE_ERR_STATE, "hub geometry: one unweighted member, one tile per workgroup");
+    NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
+    if (a.act == NGPDE_ACT_RELU) {
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, false, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, false, true>), grid, block, 0, stream, k);
+    } else {
+      if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<-1, false, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
+      else hipLaunchKernelGGL((node_bwd_persistent_kernel<-1, false, true>), grid, block, 0, stream, k);
+    }
+  } else if (k.m.slot_w) {
     NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
     if (a.act == NGPDE_ACT_RELU) {
       if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);

@@ -110,7 +110,7 @@ class _Plan:
         f = C.c_int32()
         _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
         return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"),
-                                       (16, "persistent_bwd"), (32, "tile_pairs"), (64, "tile_rounds"), (128, "widened")) if f.value & bit}
+                                       (16, "persistent_bwd"), (32, "tile_pairs"), (64, "tile_rounds"), (128, "widened"), (256, "hub_geometry")) if f.value & bit}
 
     def fault(self):
         """True when a persistent launch of this plan gave up waiting (its outputs are NaN).  Synchronises."""

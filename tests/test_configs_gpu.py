@@ -39,7 +39,8 @@ def gcn2_node(g, d, tableau, nsteps, dt, params, act="relu"):
 def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
     # C1: 2 708 nodes, 5 278 symmetric pairs -> 10 556 directed edges, D = 32, 2 x GCNConv relu, Euler x 10, dt = 0.1
     # The graph has Cora's degree skew (preferential attachment; largest degree ~100, median 3), so its tiles
-    # do NOT fit the LDS halo (degree > 32) and the per-row global-gather kernels run at config size.
+    # do NOT fit the handle's LDS halo lists (degree > 32): the solve runs on the persistent solver's hub geometry (the layer API and
+    # NGPDE_NO_PERSISTENT=1 on the per-row global-gather kernels).
     N, PAIRS, D = 2708, 5278, 32
     rng = np.random.default_rng(1)
     s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
@@ -52,7 +53,7 @@ def test_c1_cora_sized_gcn_euler_against_numpy_oracle():
     halo_ok, unused = C.c_size_t(), C.c_void_p()
     from ngpde_amd import _lib
     _lib.check(_lib.load().ngpde_graph_array(g.handle((True, None, False)).ptr, 0, 13, C.byref(unused), C.byref(halo_ok)))   # NGPDE_GRAPH_HALO_OK
-    assert halo_ok.value == 0, "C1 is meant to exercise the global-gather path"
+    assert halo_ok.value == 0, "C1 is meant to exercise the paths for graphs with hubs"
     u = torch.as_tensor(u0.astype(np.float32), device=DEV).requires_grad_(True)
     uT, _ = node(u, ps, st)
     uTo, du0o, acc = O.gcn2_node_loss_and_grads(params, O.Graph(s, t, num_nodes=N, index_base=0), u0, O.TABLEAUS["euler"], 0.1, 10, "relu")
@@ -749,7 +750,7 @@ def test_graph_node_tutorial_training_loop(graph_kind):
     # loss = logitcrossentropy on the training mask (:99-105), Optimisers.Adam(0.01) + update per epoch (:118-129).  Labels planted so
     # that the graph is homophilous; the loop must bring the training loss down and the accuracy on held-out nodes above chance.
     # "spatial": tiles fit the LDS halo -> the ODE block runs on the persistent solver (d = 16 zero-padded onto the 64-wide kernels);
-    # "citation": Cora's degree skew (hubs) -> the replayed plan.
+    # "citation": Cora's degree skew (hubs) -> the persistent solver's hub geometry (256-row halos, hub rows shared by the lane groups).
     from ngpde_amd import optim
     N, nin, nhidden, nout = 2708, 1433, 16, 7
     rng = np.random.default_rng(5)
@@ -791,7 +792,8 @@ def test_graph_node_tutorial_training_loop(graph_kind):
         acc = float((yhat.T[~mask].argmax(1) == y[~mask]).double().mean())
     plan = next(iter(node._plans.values()))[0]
     switched = any(os.environ.get(v) for v in ("NGPDE_NO_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_HALO", "NGPDE_PERSISTENT", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK"))
-    assert switched or ("persistent_fwd" in plan.flags()) == (graph_kind == "spatial"), plan.flags()
+    assert switched or "persistent_fwd" in plan.flags(), plan.flags()
+    assert switched or ("hub_geometry" in plan.flags()) == (graph_kind == "citation"), plan.flags()
     assert not plan.fault()
     assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses[::8]
     assert acc > 2.0 / nout, acc
