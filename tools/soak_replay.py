@@ -2,7 +2,8 @@
 replays the 50-step C2 solve + adjoint many times and requires every output to be bit-identical to the first run.
 usage: [N=16384] [MEMBERS=1] [WIDTH=64] [WEIGHTED=0] python tools/soak_replay.py [replays]     (MEMBERS > 1: the interleaved batch
 kernels; N > 16384: the tile-pair kernels, N > 32768: tile rounds; WIDTH=16/32: the widened plan; WEIGHTED=1: a graph with edge
-weights, the tile-round kernels with the slot weights in LDS)"""
+weights, the tile-round kernels with the slot weights in LDS; GRAPH=cora: a preferential-attachment graph with hubs of N nodes and
+2 N pairs -- the hub geometry for N <= 8192)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,10 @@ N, D, MEMBERS = int(os.environ.get("N", 16384)), int(os.environ.get("WIDTH", 64)
 WEIGHTED = os.environ.get("WEIGHTED", "0") == "1"
 PAIRS = 4 * N
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-_, s, t = S.closest_pairs_graph(N, PAIRS, seed=2)
+if os.environ.get("GRAPH", "") == "cora":
+    s, t = S.preferential_pairs_graph(N, 2 * N, seed=1)
+else:
+    _, s, t = S.closest_pairs_graph(N, PAIRS, seed=2)
 ew = (0.25 + np.random.default_rng(1).random(s.size)).astype(np.float32) if WEIGHTED else None
 g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
 plan = _Plan(g.handle((True, g.edge_weight, False)), D, 1, "tsit5", 50, 0.02, True, members=MEMBERS)
