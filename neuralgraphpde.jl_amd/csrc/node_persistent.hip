@@ -744,8 +744,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
           float4 su = f4_zero(), sk0 = f4_zero(), sk1 = f4_zero(), sk2 = f4_zero(), sk3 = f4_zero(), sk4 = f4_zero();
           if (layer == 1) {
             su = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
-            sk0 = ld4_g(p.state, own + rowb); sk1 = ld4_g(p.state, own + 2 * rowb); sk2 = ld4_g(p.state, own + 3 * rowb);
-            sk3 = ld4_g(p.state, own + 4 * rowb); sk4 = ld4_g(p.state, own + 5 * rowb);
+            // (only the stage derivatives this stage combines, k_j with j < i: the others meet a zero coefficient)
+            sk0 = i > 0 ? ld4_g(p.state, own + rowb) : f4_zero(); sk1 = i > 1 ? ld4_g(p.state, own + 2 * rowb) : f4_zero();
+            sk2 = i > 2 ? ld4_g(p.state, own + 3 * rowb) : f4_zero(); sk3 = i > 3 ? ld4_g(p.state, own + 4 * rowb) : f4_zero();
+            sk4 = i > 4 ? ld4_g(p.state, own + 5 * rowb) : f4_zero();
           }
           wait_vmcnt0();
           __syncthreads();   // halo rows landed (and the phase's W is in LDS)
@@ -847,10 +849,12 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
   int pend_ph = 0, n_ahead = 0;
   // this turn's state rows (layer-2 turns): fetched at the end of the previous turn when its gather went out ahead, else at T0
   float4 su = f4_zero(), sk0 = f4_zero(), sk1 = f4_zero(), sk2 = f4_zero(), sk3 = f4_zero(), sk4 = f4_zero();
-  auto load_state = [&](const TileCtx &c, unsigned own, int n) {
+  auto load_state = [&](const TileCtx &c, unsigned own, int n, int si) {   // si: the stage whose layer-2 turn reads them
     su = (n == 0) ? f4_sel(c.valid, ld4_g(p.u_in, own), f4_zero()) : ld4_g(p.state, own);
-    sk0 = ld4_g(p.state, own + rowb); sk1 = ld4_g(p.state, own + 2 * rowb); sk2 = ld4_g(p.state, own + 3 * rowb);
-    sk3 = ld4_g(p.state, own + 4 * rowb); sk4 = ld4_g(p.state, own + 5 * rowb);
+    // (only the stage derivatives that stage combines, k_j with j < si: the others meet a zero coefficient)
+    sk0 = si > 0 ? ld4_g(p.state, own + rowb) : f4_zero(); sk1 = si > 1 ? ld4_g(p.state, own + 2 * rowb) : f4_zero();
+    sk2 = si > 2 ? ld4_g(p.state, own + 3 * rowb) : f4_zero(); sk3 = si > 3 ? ld4_g(p.state, own + 4 * rowb) : f4_zero();
+    sk4 = si > 4 ? ld4_g(p.state, own + 5 * rowb) : f4_zero();
   };
   int ph = 0;
   for (int n = 0; n < p.n_steps && ok; ++n) {
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
           if (!pre) {
             if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
             halo_fill_all(c, X, ldsXh);
-            if (layer == 1) load_state(c, own, n);
+            if (layer == 1) load_state(c, own, n, i);
             wait_vmcnt0();
             __syncthreads();
           }
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
               store_sc1(p.bufA, own, v);
             }
           }
-          if (pre && nlayer == 1) load_state(cn, ownn, nn);   // (this turn's state rows are dead from here)
+          if (pre && nlayer == 1) load_state(cn, ownn, nn, i);   // (this turn's state rows are dead from here; a layer-2 turn that follows this one belongs to stage i)
           pend_flags = p.m.flags + 32 * tile;
           pend_ph = ph;
           if constexpr (TAPE && ACT == NGPDE_ACT_RELU) stu8_g(p.masks + ev * p.mask_bytes + (size_t)tile * kThreads, (unsigned)tid, sign_bits);
@@ -1922,8 +1926,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentK_kernel(const
           halo_fill_all(c, p.g1, ldsXh);
           // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5), in flight under the gather
           const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
-          const float4 lb1 = ld4_g(p.ubar, own), lb2 = ld4_g(p.ubar, own + rowb), lb3 = ld4_g(p.ubar, own + 2 * rowb),
-                       lb4 = ld4_g(p.ubar, own + 3 * rowb), lb5 = ld4_g(p.ubar, own + 4 * rowb);
+          // (only the stage adjoints this stage combines, U-bar_j with i < j < S: the others meet a zero coefficient or are zero)
+          const float4 lb1 = (i < 1 && S > 1) ? ld4_g(p.ubar, own) : f4_zero(), lb2 = (i < 2 && S > 2) ? ld4_g(p.ubar, own + rowb) : f4_zero(),
+                       lb3 = (i < 3 && S > 3) ? ld4_g(p.ubar, own + 2 * rowb) : f4_zero(), lb4 = (i < 4 && S > 4) ? ld4_g(p.ubar, own + 3 * rowb) : f4_zero(),
+                       lb5 = (i < 5 && S > 5) ? ld4_g(p.ubar, own + 4 * rowb) : f4_zero();
           wait_vmcnt0();
           __syncthreads();
           const float4 t = tile_aggregate_rounds<WGT>(c, ldsXh);
@@ -2195,8 +2201,10 @@ __global__ __launch_bounds__(kThreads, 4) void node_bwd_persistentKP_kernel(cons
           if (!top(c, ph, p.g1)) { ok = false; break; }
           // lambda and the stage adjoints of this step from memory (rows 0..4 of ubar = U-bar_1..5): in flight under the aggregation
           const float4 lam = f4_sel(c.valid, ld4_g(p.lam, own), f4_zero());
-          const float4 lb1 = ld4_g(p.ubar, own), lb2 = ld4_g(p.ubar, own + rowb), lb3 = ld4_g(p.ubar, own + 2 * rowb),
-                       lb4 = ld4_g(p.ubar, own + 3 * rowb), lb5 = ld4_g(p.ubar, own + 4 * rowb);
+          // (only the stage adjoints this stage combines, U-bar_j with i < j < S: the others meet a zero coefficient or are zero)
+          const float4 lb1 = (i < 1 && S > 1) ? ld4_g(p.ubar, own) : f4_zero(), lb2 = (i < 2 && S > 2) ? ld4_g(p.ubar, own + rowb) : f4_zero(),
+                       lb3 = (i < 3 && S > 3) ? ld4_g(p.ubar, own + 2 * rowb) : f4_zero(), lb4 = (i < 4 && S > 4) ? ld4_g(p.ubar, own + 3 * rowb) : f4_zero(),
+                       lb5 = (i < 5 && S > 5) ? ld4_g(p.ubar, own + 4 * rowb) : f4_zero();
           const float4 t = tile_aggregate_lean(c, ldsXh);
           const float4 ub1 = i == 1 ? t : lb1, ub2 = i == 2 ? t : lb2, ub3 = i == 3 ? t : lb3, ub4 = i == 4 ? t : lb4,
                        ub5 = i == 5 ? t : lb5;   // U-bar_i is t itself
