@@ -11,15 +11,17 @@ namespace {
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// n_rows = 0: a Dense over no rows (an edgeless graph's message MLP: /root/reference's scatter over an empty edge set gives zeros) --
+// its blocks may be NULL, as the empty arrays of most hosts are
 int32_t make_segs(const char *fn, int32_t n_seg, const float *const *seg_ptr, const int32_t *seg_width,
-                  const int32_t *seg_row_div, SegTable &t, int *din) {
+                  const int32_t *seg_row_div, SegTable &t, int *din, int64_t n_rows = -1) {
   NGPDE_REQUIRE(n_seg >= 1 && n_seg <= 4, NGPDE_ERR_INVALID_ARGUMENT, "%s: 1..4 input blocks supported, got %d", fn, n_seg);
   NGPDE_REQUIRE(seg_ptr && seg_width, NGPDE_ERR_INVALID_ARGUMENT, "%s: NULL block table", fn);
   t.n = n_seg;
   int off = 0;
   for (int i = 0; i < n_seg; ++i) {
     NGPDE_REQUIRE(seg_width[i] >= 0, NGPDE_ERR_DIMENSION_MISMATCH, "%s: negative block width", fn);
-    NGPDE_REQUIRE(seg_width[i] == 0 || seg_ptr[i], NGPDE_ERR_INVALID_ARGUMENT, "%s: block %d is NULL", fn, i);
+    NGPDE_REQUIRE(seg_width[i] == 0 || n_rows == 0 || seg_ptr[i], NGPDE_ERR_INVALID_ARGUMENT, "%s: block %d is NULL", fn, i);
     t.ptr[i] = seg_ptr[i];
     t.width[i] = seg_width[i];
     t.row_div[i] = (seg_row_div && seg_row_div[i] > 0) ? seg_row_div[i] : 1;
@@ -48,7 +50,7 @@ int32_t ngpde_dense_forward(int64_t n, int32_t n_seg, const float *const *seg_pt
   NGPDE_RANGE();
   SegTable t;
   int din = 0;
-  int32_t st = make_segs("ngpde_dense_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
+  int32_t st = make_segs("ngpde_dense_forward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din, n);
   if (st || (st = check_act("ngpde_dense_forward", act))) return st;
   NGPDE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && dout > 0, NGPDE_ERR_DIMENSION_MISMATCH,
                 "ngpde_dense_forward: DimensionMismatch (rows must be in [0, 2^31), dout > 0)");
@@ -70,7 +72,7 @@ int32_t ngpde_dense_multi_forward(int32_t count, const int64_t *n, const int32_t
   int off = 0;
   for (int q = 0; q < count; ++q) {
     int32_t st = make_segs("ngpde_dense_multi_forward", n_seg[q], seg_ptr + off, seg_width + off, seg_row_div ? seg_row_div + off : nullptr,
-                           t[q], &din[q]);
+                           t[q], &din[q], n[q]);
     if (st || (st = check_act("ngpde_dense_multi_forward", act[q]))) return st;
     NGPDE_REQUIRE(n[q] >= 0 && n[q] < ((int64_t)1 << 31) && dout[q] > 0, NGPDE_ERR_DIMENSION_MISMATCH,
                   "ngpde_dense_multi_forward: DimensionMismatch in problem %d (rows must be in [0, 2^31), dout > 0)", q);
@@ -185,7 +187,7 @@ int32_t ngpde_dense_backward(int64_t n, int32_t n_seg, const float *const *seg_p
   NGPDE_RANGE();
   SegTable t;
   int din = 0;
-  int32_t st = make_segs("ngpde_dense_backward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din);
+  int32_t st = make_segs("ngpde_dense_backward", n_seg, seg_ptr, seg_width, seg_row_div, t, &din, n);
   if (st || (st = check_act("ngpde_dense_backward", act))) return st;
   hipStream_t stream = (hipStream_t)stream_;
   NGPDE_REQUIRE(dweight != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_dense_backward: dweight is NULL");

@@ -156,3 +156,20 @@ def test_random_vmh_node_shapes_plan_against_generic_solver():
     assert last.startswith("10 cases") and last.endswith("0 mismatches"), last
     if not os.environ.get("NGPDE_NO_VMH_NODE") and not os.environ.get("NGPDE_NO_PERSISTENT"):
         assert int(last.split(" cases, ")[1].split(" on the plan")[0]) >= 5, last
+
+
+def test_random_layer_entries_against_the_composed_layers_and_the_oracle(monkeypatch):
+    # tools/fuzz_layer_entries.py, a short fixed run: ExplicitEdgeConv / VMHConv / MPPDEConv / GNOConv of random shapes through the
+    # layer-level C entries (ngpde_edge_layer_*, ngpde_gno_layer_*) -- every output and gradient bit for bit equal to the layer composed
+    # from the primitives, training and inference, and (matrix state, + / mean / *) within the suite's tolerances of the float64 oracle.
+    # Seed 1 holds two edgeless graphs with multi-layer message MLPs (a Dense over zero rows takes NULL blocks: found by this fuzz).
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_layer_entries", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                     "tools", "fuzz_layer_entries.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv("ORACLE", "1")
+    failures = fz.run(40, 1)
+    assert not failures, failures
+    assert fz.n_oracle[0] >= 15
