@@ -208,13 +208,16 @@ int32_t make_plan(const ngpde_graph *g, const ngpde_edge_layer_t &L, bool traini
   const size_t N = (size_t)p.N, E = (size_t)p.E;
 
   // ---- message path: one fused launch where the message MLP fits the fused kernel (widths <= 64, multiples of 4, <= 3 further
-  // layers, tiles within the LDS halo; max / min / * only without gradients), the primitives otherwise
+  // layers, tiles within the LDS halo; max / min only without gradients), the primitives otherwise
+  // (*: with gradients only where the one-launch pullback takes it -- the primitives' pullback of a product needs the per-edge messages,
+  // which the fused forward does not keep)
+  const bool bwd_ok = !env_is("NGPDE_NO_FUSED_EDGE_BWD", '1') &&
+                      ngpde_edge_mlp_backward_supported(g, p.h1, p.n_tail, p.n_tail ? p.tail_dout : nullptr, p.aggr) == 1;
   p.fused_msg = !env_is("NGPDE_NO_FUSED_EDGE", '1') && p.E > 0 && p.n_tail <= 3 &&
-                (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN || !training) &&
+                (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN || !training || (p.aggr == NGPDE_AGGR_MUL && bwd_ok)) &&
                 ngpde_edge_mlp_supported(g, p.h1, p.n_tail, p.n_tail ? p.tail_dout : nullptr) == 1;
   if (p.fused_msg && training) {
-    p.fused_bwd = !env_is("NGPDE_NO_FUSED_EDGE_BWD", '1') &&
-                  ngpde_edge_mlp_backward_supported(g, p.h1, p.n_tail, p.n_tail ? p.tail_dout : nullptr, p.aggr) == 1;
+    p.fused_bwd = bwd_ok;
     if (p.fused_bwd && p.n_tail >= 2) {
       // three / four-layer message MLPs: the one-launch pullback pays from ~32 k nodes up (one 4-wave workgroup per CU walks a long
       // chain per tile); NGPDE_DEEP_EDGE_BWD=1 / 0 forces it on / off

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
   float *ldsS = ldsG + kGroups * kTS;                             // [kChunk][kTS]  wave-private transposes, then dz1 of the chunk
   float *ldsWf = ldsS + kChunk * kTS;                             // [64 out][kTS]  W2^T   (NTAIL = 1)
   float *ldsWb = ldsWf + (NTAIL ? kW * kTS : 0);                  // [64 in][kTS]   W2
+  float *ldsZc = ldsWb + (NTAIL ? kW * kTS : 0);                  // [32][kTS]  aggr = *: how many of the target's messages are zero, per feature
   __shared__ int ldsOff[kGroups + 1], ldsRs[kGroups];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kGroups * 8];
   __shared__ uint8_t ldsRowOf[kGroups * kSlotWidth];
@@ -394,6 +395,47 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
 #pragma unroll
     for (int b = 0; b < (NTAIL ? 4 : 1); ++b) accW[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+
+  // the per-edge forward the pullback recomputes: z1 = P_i + Q_j + E_e, a1 = act1(z1) (zero on padded features / invalid edges) ...
+  auto first_layer = [&](int r, int slot, size_t pe, bool valid, float4 (&z1)[4], float4 (&a1)[4]) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int f = 16 * ct + 4 * kq;
+      float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
+      if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
+      z1[ct] = z;
+      a1[ct] = z;
+    }
+    f4n_act<4>(p.act1, a1);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      if (!(valid && 16 * ct + 4 * kq < h1)) a1[ct] = f4_zero();
+  };
+  // ... and z2 = W2^T a1 + b2 (transposed product: the D layout is the operand layout of the next product)
+  auto second_layer = [&](const float4 (&a1)[4], float4 (&z2)[4]) {
+    const int n_ct = (h1 + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      z2[mt] = f4_zero();
+      if (mt < n_mt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *wl = ldsWf + (mt * 16 + ei) * kTS + 4 * kq;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (ct < n_ct) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * ct);
+            acc = mfma16(w4.x, a1[ct].x, acc);
+            acc = mfma16(w4.y, a1[ct].y, acc);
+            acc = mfma16(w4.z, a1[ct].z, acc);
+            acc = mfma16(w4.w, a1[ct].w, acc);
+          }
+        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
+        z2[mt] = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+      }
+    }
+  };
+  const bool mul = p.aggr == NGPDE_AGGR_MUL;
 
   TileMeta meta;
   int jt = wg_in_xcd;
@@ -452,6 +494,56 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
     float4 racc = f4_zero();
     __syncthreads();
 
+    if (mul) {
+      // ---- aggr = *: a first pass over the tile's edges recomputes the messages and leaves, per target and feature, the product of the
+      // nonzero ones (folded into the gradient row) and the number of zeros
+      float4 pacc = make_float4(1.f, 1.f, 1.f, 1.f), zacc = f4_zero();
+      for (int c0 = 0; c0 < total; c0 += kChunk) {
+        const bool wave_on = c0 + wave * 16 < total;   // wave-uniform
+        const int k = c0 + wave * 16 + ei;
+        const bool valid = k < total;
+        int r = 0, slot = zero_slot;
+        size_t pe = 0;
+        if (valid) {
+          r = ldsRowOf[k];
+          const int j = k - ldsOff[r];
+          slot = (ldsSlots[r * 8 + (j >> 2)] >> (8 * (j & 3))) & 0xff;
+          pe = (size_t)(ldsRs[r] + j);
+        }
+        float *mine = ldsS + (size_t)(wave * 16) * kTS;
+        float4 m[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+        if (wave_on) {
+          float4 z1[4], a1[4];
+          first_layer(r, slot, pe, valid, z1, a1);
+          if (NTAIL) {
+            second_layer(a1, m);
+            f4n_act<4>(p.act2, m);
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) m[ct] = a1[ct];
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4 *>(&mine[ei * kTS + 16 * mt + 4 * kq]) = m[mt];
+        __syncthreads();
+        {
+          const int lo = max(my_lo, c0), hi = min(my_hi, c0 + kChunk);
+          for (int kk = lo; kk < hi; ++kk) {
+            const float4 v = *reinterpret_cast<const float4 *>(&ldsS[(kk - c0) * kTS + 4 * q]);
+            pacc = make_float4(pacc.x * (v.x != 0.f ? v.x : 1.f), pacc.y * (v.y != 0.f ? v.y : 1.f), pacc.z * (v.z != 0.f ? v.z : 1.f),
+                               pacc.w * (v.w != 0.f ? v.w : 1.f));
+            zacc = make_float4(zacc.x + (v.x == 0.f ? 1.f : 0.f), zacc.y + (v.y == 0.f ? 1.f : 0.f), zacc.z + (v.z == 0.f ? 1.f : 0.f),
+                               zacc.w + (v.w == 0.f ? 1.f : 0.f));
+          }
+        }
+        __syncthreads();
+      }
+      float4 *gr = reinterpret_cast<float4 *>(&ldsG[grp * kTS + 4 * q]);
+      *gr = f4_mul(*gr, pacc);
+      *reinterpret_cast<float4 *>(&ldsZc[grp * kTS + 4 * q]) = zacc;
+      __syncthreads();
+    }
+
     for (int c0 = 0; c0 < total; c0 += kChunk) {
       const bool wave_on = c0 + wave * 16 < total;   // wave-uniform
       const int k = c0 + wave * 16 + ei;
@@ -468,18 +560,7 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
       float4 dz1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
       if (wave_on) {
         float4 z1[4], a1[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int f = 16 * ct + 4 * kq;
-          float4 z = f4_add(*reinterpret_cast<const float4 *>(&ldsP[r * kTS + f]), *reinterpret_cast<const float4 *>(&ldsQ[slot * kTS + f]));
-          if (p.Eterm && valid && f < h1) z = f4_add(z, *reinterpret_cast<const float4 *>(p.Eterm + pe * h1 + f));
-          z1[ct] = z;
-          a1[ct] = z;
-        }
-        f4n_act<4>(p.act1, a1);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          if (!(valid && 16 * ct + 4 * kq < h1)) a1[ct] = f4_zero();
+        first_layer(r, slot, pe, valid, z1, a1);
         f4n_dact<4>(p.act1, z1);                       // z1 <- act1'(z1): only the derivative is needed from here on
         float4 gz[4];                                          // NTAIL = 0: g itself; NTAIL = 1: dz2 = g * act2'(z2)
 #pragma unroll
@@ -487,28 +568,27 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
           const int f = 16 * mt + 4 * kq;
           gz[mt] = (valid && f < dw) ? *reinterpret_cast<const float4 *>(&ldsG[r * kTS + f]) : f4_zero();
         }
+        // aggr = *: dL/dm_e = g_i . (product of the target's OTHER messages) = (g_i . product of its nonzero messages) / m_e where
+        // none of them is zero; the one zero message of a row gets the product of the others; two zeros leave nothing
+        auto others = [&](float4 (&gv)[4], const float4 (&m)[4]) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int f = 16 * mt + 4 * kq;
+            const float4 zc = (valid && f < dw) ? *reinterpret_cast<const float4 *>(&ldsZc[r * kTS + f]) : make_float4(2.f, 2.f, 2.f, 2.f);
+            auto one = [](float g, float mm, float z) { return mm != 0.f ? (z == 0.f ? g / mm : 0.f) : (z == 1.f ? g : 0.f); };
+            gv[mt] = make_float4(one(gv[mt].x, m[mt].x, zc.x), one(gv[mt].y, m[mt].y, zc.y), one(gv[mt].z, m[mt].z, zc.z), one(gv[mt].w, m[mt].w, zc.w));
+          }
+        };
+        if (!NTAIL && mul) others(gz, a1);
         if (NTAIL) {
           const int n_ct = (h1 + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
           // ---- z2 (transposed product), dz2
-          float4 z2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            if (mt < n_mt) {
-              f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-              const float *wl = ldsWf + (mt * 16 + ei) * kTS + 4 * kq;
-#pragma unroll
-              for (int ct = 0; ct < 4; ++ct) {
-                if (ct < n_ct) {
-                  const float4 w4 = *reinterpret_cast<const float4 *>(wl + 16 * ct);
-                  acc = mfma16(w4.x, a1[ct].x, acc);
-                  acc = mfma16(w4.y, a1[ct].y, acc);
-                  acc = mfma16(w4.z, a1[ct].z, acc);
-                  acc = mfma16(w4.w, a1[ct].w, acc);
-                }
-              }
-              const float4 b4 = *reinterpret_cast<const float4 *>(&ldsBias[16 * mt + 4 * kq]);
-              z2[mt] = make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
-            }
+          float4 z2[4];
+          second_layer(a1, z2);
+          if (mul) {
+            float4 m2[4] = {z2[0], z2[1], z2[2], z2[3]};
+            f4n_act<4>(p.act2, m2);
+            others(gz, m2);
           }
           f4n_dact<4>(p.act2, z2);
 #pragma unroll
@@ -711,7 +791,7 @@ bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int 
   if (h1 <= 0 || h1 > kW || h1 % 4) return false;
   if (n_tail < 0 || n_tail > 1) return false;                 // deeper message MLPs take the primitives' pullback
   if (n_tail == 1 && (dw <= 0 || dw > kW || dw % 4)) return false;
-  return aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN;
+  return aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN || aggr == NGPDE_AGGR_MUL;   // (* on this kernel only: the 64-wide and deep ones take + / mean)
 }
 
 size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw) {
@@ -721,7 +801,7 @@ size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, in
 
 int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
   NGPDE_REQUIRE(edge_mlp_fused_bwd_supported(g, a.h1, a.n_tail, a.dw, a.aggr), NGPDE_ERR_UNSUPPORTED,
-                "fused edge-MLP pullback needs widths <= 64 and multiples of 4, at most one layer after the first, + or mean "
+                "fused edge-MLP pullback needs widths <= 64 and multiples of 4, at most one layer after the first, +, mean or * "
                 "aggregation and a graph whose tiles fit the LDS halo");
   if (g->n_nodes == 0) return NGPDE_OK;
   const size_t need = edge_mlp_fused_bwd_workspace(g, a.h1, a.n_tail, a.dw);
@@ -736,7 +816,8 @@ int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a,
   k.halo_rows = std::max<int>(kTileRows, std::min<int>(kHaloCap, g->by_t.max_halo));
   k.P = a.P; k.Q = a.Q; k.Eterm = a.Eterm; k.wt = a.wt; k.bias = a.bias; k.dout = a.dout;
   k.dP = a.dP; k.dE = a.dE; k.partial = (float *)a.workspace;
-  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + 2 * (size_t)kGroups * kTS + (size_t)kChunk * kTS + (a.n_tail ? 2 * (size_t)kW * kTS : 0)) * sizeof(float);
+  const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + 2 * (size_t)kGroups * kTS + (size_t)kChunk * kTS + (a.n_tail ? 2 * (size_t)kW * kTS : 0) +
+                      (a.aggr == NGPDE_AGGR_MUL ? (size_t)kGroups * kTS : 0)) * sizeof(float);
   const dim3 grid(edge_bwd_grid(g)), block(kT);
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

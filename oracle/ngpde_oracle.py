@@ -220,8 +220,14 @@ def scatter_pullback(op, M, idx, n, out, dout):
     if op in ("max", "min"):  # NNlib: every entry equal to the extremum receives the gradient
         return gather(dout, idx) * (M == gather(out, idx))
     if op in ("*", "mul"):
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return gather(dout * out, idx) / M
+        # every entry receives dout times the product of the OTHER entries of its destination (what NNlib's pullback of scatter(*)
+        # forms entry by entry; dout * out / M wherever no entry is zero).  With zeros: the one zero entry of a destination gets the
+        # product of the rest, two zeros leave nothing.
+        nz = np.where(M == 0, 1.0, M)
+        p_nz = gather(scatter("*", nz, idx, n), idx)
+        zeros = gather(scatter("+", (M == 0).astype(M.dtype), idx, n), idx)
+        others = np.where(M != 0, np.where(zeros == 0, p_nz / nz, 0.0), np.where(zeros == 1, p_nz, 0.0))
+        return gather(dout, idx) * others
     raise ValueError(op)
 
 

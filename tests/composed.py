@@ -801,9 +801,13 @@ def _message_path(g, P, Q, Et, stack, aggr):
     needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in [P, Q, Et] + [w for w, _, _ in tail] + [b for _, b, _ in tail])
     aggr_code = _lib.AGGR[aggr]
-    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0 and (aggr_code in (0, 1) or (aggr_code in (2, 3, 4) and not needs_grad)):
+    if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0:
         fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
-        if edge_mlp_supported(fh, ref.shape[1], [w.shape[1] for w, _, _ in tail]):
+        douts = [w.shape[1] for w, _, _ in tail]
+        # (*: with gradients only where the one-launch pullback takes it -- the primitives' pullback of a product needs the per-edge messages)
+        mul_ok = aggr_code == 4 and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(_lib.load().ngpde_edge_mlp_backward_supported(
+            fh.ptr, ref.shape[1], len(douts), _int_array(douts) if douts else None, aggr_code))
+        if (aggr_code in (0, 1) or not needs_grad or mul_ok) and edge_mlp_supported(fh, ref.shape[1], douts):
             return edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)
     handle = g.handle()
     a = edge_combine(P, Q, Et, handle, l1.act, g.num_edges)

@@ -4,6 +4,8 @@ reference's own test cases (/root/reference/test/runtests.jl:27-162) and on larg
 
 Tolerances: forward 1e-4 * max|ref| + 1e-5, gradients 5e-4 relative (chains of 2-4 fp32 dense layers).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -489,6 +491,40 @@ def test_edgeconv_product_aggregation():
     y, _ = l(x, ps, st)
     yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, "*")
     close(y, yo)
+    R = rng.normal(size=yo.shape)
+    (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    check_grads(ps, (names, ogr), x, gr["x"])
+
+
+@pytest.mark.parametrize("widths,last_act", [((8,), "tanh"), ((16, 8), "tanh"), ((16, 12), "relu"), ((64, 64), "relu")])
+def test_product_aggregation_in_the_one_launch_pullback(widths, last_act):
+    # aggr = * with gradients on the fused message path (round 5): the one-launch pullback makes a first pass over a tile's edges for the
+    # per-target product of the nonzero messages and the number of zeros, then gives every message the product of the others -- g P / m_e,
+    # the row's one zero message the product of the rest, nothing where two are zero (a relu last layer produces exact zeros).  Values and
+    # all gradients against the float64 oracle; a single Dense phi and a two-layer one (the 64-wide pair takes this kernel too: the
+    # specialised ones are for + / mean).
+    from ngpde_amd import _lib
+    N, h = 600, 6
+    rng = np.random.default_rng(17)
+    _, s, t = S.closest_pairs_graph(N, 2 * N, seed=9)
+    nd = {"x": rng.random((2, N))}
+    g, og = ng.GNNGraph(s, t, num_nodes=N, index_base=0, ndata=nd), O.Graph(s, t, num_nodes=N, index_base=0, ndata=nd)
+    dims = (2 * h + 2,) + widths
+    phi = ng.Chain(*[ng.Dense(dims[l], dims[l + 1], "tanh" if l + 1 < len(widths) else last_act) for l in range(len(widths))]) if len(widths) > 1 else \
+        ng.Dense(dims[0], dims[1], last_act)
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr="*")
+    assert _lib.load().ngpde_edge_mlp_backward_supported(g.handle((False, None, False)).ptr, widths[0], len(widths) - 1,
+                                                         (C.c_int32 * 1)(widths[-1]) if len(widths) > 1 else None, _lib.AGGR["*"]) == 1
+    ps, st = ng.setup(5, l)
+    ps = prep(ps, 5)
+    x = torch.randn(h, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, "*")
+    if last_act == "relu":
+        assert (yo == 0).mean() > 0.2          # rows whose product holds a zero message
+    close(y, yo, rtol=2e-4)
     R = rng.normal(size=yo.shape)
     (y * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
     gr = O.explicit_edge_conv_backward(c, R)

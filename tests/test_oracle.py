@@ -115,6 +115,30 @@ def test_mean_of_empty_neighbourhood_is_zero():
     assert np.all(m[:, 2:] == 0) and np.all(np.isfinite(m))
 
 
+def test_product_scatter_pullback_with_zero_entries():
+    # scatter(*): every entry receives dout times the product of the OTHER entries of its destination -- also where entries are exactly
+    # zero (a relu message): one zero in a destination -> that entry gets the product of the rest, the rest get 0; two zeros -> all 0.
+    # Against the definition, entry by entry, and against dout * out / M where nothing is zero.
+    rng = np.random.default_rng(3)
+    n, E, d = 7, 40, 3
+    idx = rng.integers(0, n - 1, size=E)                 # destination n - 1 stays empty (neutral element 1)
+    M = rng.normal(size=(d, E))
+    M[:, rng.choice(E, size=9, replace=False)] = 0.0
+    M[1, idx == idx[0]] = 0.0                            # a destination with several zeros in one feature
+    out = O.scatter("*", M, idx, n)
+    assert (out[:, n - 1] == 1.0).all()
+    dout = rng.normal(size=(d, n))
+    got = O.scatter_pullback("*", M, idx, n, out, dout)
+    ref = np.zeros_like(M)
+    for e in range(E):
+        mates = [k for k in range(E) if idx[k] == idx[e] and k != e]
+        ref[:, e] = dout[:, idx[e]] * np.prod(M[:, mates], axis=1)
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    M2 = np.where(M == 0, 0.7, M)
+    out2 = O.scatter("*", M2, idx, n)
+    assert np.allclose(O.scatter_pullback("*", M2, idx, n, out2, dout), O.gather(dout * out2, idx) / M2, rtol=1e-12, atol=1e-14)
+
+
 def test_gcn_matches_dense_formula():
     # Y = act(W X C (A+I) C + b),  C = diag(1/sqrt(indeg+1))   
     N, D = 7, 4
