@@ -2418,10 +2418,10 @@ bool node_persistent_hub_possible(const ngpde_graph *g, int d) {
 // (members and all their neighbours, both directions) grows least by it, among the tiles with a free slot that stay within the cap
 // with one row reserved per slot still free; a node with more than kSlotWidth entries (a long row: summed by the whole workgroup, two
 // barriers each) prefers the tiles with the fewest long rows.  Leaves end up with the hub they hang on (growth 0), hubs apart from each
-// other: at BASELINE config 1's shape one long row per tile at most, 94 referenced rows per tile on average (the first form of this
-// deal -- least growth only -- put the hubs next to each other: the tile with most of them took 17 k cycles per phase and every other
-// tile waited for it).  Returns the positions -> node order (tile t = positions 32 t ..), or an empty vector when some node fits nowhere.
-static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> rp[2], const std::vector<int32_t> cl[2]) {
+// other: at BASELINE config 1's shape one long row per tile at most, 94 referenced rows per tile on average, 131 at most (the first form
+// of this deal -- least growth only -- put the hubs next to each other: the tile with most of them took 17 k cycles per phase and every
+// other tile waited for it; the second -- hubs apart, least growth -- filled the largest hub's tile to the cap of 255 rows).  Returns the positions -> node order (tile t = positions 32 t ..), or an empty vector when some node fits nowhere.
+static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> rp[2], const std::vector<int32_t> cl[2], bool balance) {
   const int nt = (int)((n + kTileRows - 1) / kTileRows);
   std::vector<std::vector<int32_t>> nb((size_t)n);
   for (int64_t v = 0; v < n; ++v) {
@@ -2443,7 +2443,7 @@ static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> 
   int64_t dealt = 0;
   for (int32_t v : by_degree) {
     const bool is_long = (int)nb[v].size() > kSlotWidth;
-    int best_t = -1, best_inc = 1 << 30, best_h = 1 << 30, best_l = 1 << 30;
+    int best_t = -1, best_score = 1 << 30, best_l = 1 << 30;
     if (dealt < nt) best_t = (int)dealt;   // the n_tiles highest-degree nodes: one per tile
     ++dealt;
     for (int t = 0; t < nt && dealt > nt; ++t) {
@@ -2453,9 +2453,11 @@ static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> 
       for (int32_t w : nb[v]) inc += h[w] ? 0 : 1;
       if (h_size[t] + inc + (cap[t] - (int)members[t].size() - 1) > kHubHalo) continue;
       const int l = is_long ? n_long[t] : 0;
-      if (l < best_l || (l == best_l && (inc < best_inc || (inc == best_inc && h_size[t] < best_h)))) {
-        best_t = t; best_inc = inc; best_h = h_size[t]; best_l = l;
-      }
+      // growth, plus a sixteenth of what the tile already references: every tile waits for the slowest one each phase, so a node that
+      // would add one row to a tile of 200 goes to a tile of 60 even if it adds three there (largest tile at config 1's shape: 255 -> 131
+      // rows, the average unchanged at 94)
+      const int score = balance ? 16 * inc + h_size[t] : 512 * inc + h_size[t];   // (not balanced: least growth, then the smaller tile)
+      if (l < best_l || (l == best_l && score < best_score)) { best_t = t; best_score = score; best_l = l; }
     }
     if (best_t < 0) return {};
     uint8_t *h = in_h.data() + (size_t)best_t * n;
@@ -2545,7 +2547,9 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
     NGPDE_REQUIRE(!pair && nt <= kHubNbr, NGPDE_ERR_UNSUPPORTED, "persistent solver, hub geometry: at most %d tiles, one per workgroup", kHubNbr);
     std::vector<int32_t> rp[2], cl[2];
     NGPDE_REQUIRE(host_csr(g, g->by_t, rp[0], cl[0]) && host_csr(g, g->by_s, rp[1], cl[1]), NGPDE_ERR_HIP, "download of the CSR lists failed");
-    const std::vector<int32_t> order = hub_partition(g->n_nodes, rp, cl);
+    // (the balanced deal can strand the last nodes when a hub's tile is near the cap and only its own leaves would fit it: then least growth alone)
+    std::vector<int32_t> order = hub_partition(g->n_nodes, rp, cl, true);
+    if ((int64_t)order.size() != g->n_nodes) order = hub_partition(g->n_nodes, rp, cl, false);
     NGPDE_REQUIRE((int64_t)order.size() == g->n_nodes, NGPDE_ERR_UNSUPPORTED,
                   "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each", kHubHalo);
     HubHost hh[2];
