@@ -379,8 +379,13 @@ def secondary(dev, world, rank, dist):
                     v.grad = None
                 uT, _ = node1(u1, ps1, st1)
                 uT.sum().backward()
-            ms1 = _time_ms(solve1, 10)
-            c1[name] = {"ms_solve_forward_backward": round(ms1, 3), "value": round(steps1 / (ms1 * 1e-3), 1), "unit": "ODE-steps/s",
+            ms1e = _time_ms(solve1, 10)
+            try:      # the solve is ~0.2 ms of device time: the eager call is bound by Python's dispatch, so the figure of record is the HIP-graph replay
+                ms1 = _graph_ms(solve1, 20)
+            except Exception:  # noqa: BLE001 -- a plan that cannot be captured keeps the eager figure
+                ms1 = ms1e
+            c1[name] = {"ms_solve_forward_backward": round(ms1, 3), "ms_solve_forward_backward_eager_api": round(ms1e, 3),
+                        "value": round(steps1 / (ms1 * 1e-3), 1), "unit": "ODE-steps/s",
                         "plan": sorted({f for pool in node1._plans.values() for q in pool for f in q.flags()})}
         out["C1_cora_gcn32_eulerx10"] = {"nodes": n1, "edges": 2 * pairs1, **c1["cora_like"],
                                          "same_size_without_hubs": c1["same_size_without_hubs"]}
