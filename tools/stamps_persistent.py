@@ -63,6 +63,9 @@ def run(which):
     order = np.argsort(waits)
     print(f"{which}: cycles per phase {per_tile.mean():.0f} (s_memtime ticks); tiles waiting least (the ones waited for): " +
           ", ".join(f"tile {k}: wait {waits[k]:.0f}" for k in order[:6]))
+    if os.environ.get("DUMP"):
+        own = np.diff(st[:, 8:, :len(names) + 1], axis=2).mean(axis=1)       # [tile(workgroup)][segment]
+        np.save(os.path.join(ROOT, "gpurun_out", f"stamps_{which}.npy"), own)
     k0 = int(order[0])
     d0 = np.diff(st[k0, 8:, :len(names) + 1], axis=1).mean(axis=0)
     print(f"{which}: workgroup {k0} (waits least), mean cycles per step of a phase: " + "; ".join(f"{nm}: {d0[k]:.0f}" for k, nm in enumerate(names)))
