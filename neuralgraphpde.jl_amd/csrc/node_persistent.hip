@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentK_kernel(const
             v = f4_fma(ldsC[i * 6 + 0], k0, v); v = f4_fma(ldsC[i * 6 + 1], k1, v); v = f4_fma(ldsC[i * 6 + 2], k2, v);
             v = f4_fma(ldsC[i * 6 + 3], k3, v); v = f4_fma(ldsC[i * 6 + 4], k4, v);
             if (c.valid) {
-              st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);
+              if (i < p.S - 1) st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);   // (the last stage's derivative is combined here and never read again)
               if (i == p.S - 1) st4_g(p.state, own, v);
               if (last_phase) st4_g(p.u_out, own, v);
               store_sc1(p.bufA, own, v);
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kThreads, 4) void node_fwd_persistentKP_kernel(cons
             v = f4_fma(cf0, k0, v); v = f4_fma(cf1, k1, v); v = f4_fma(cf2, k2, v);
             v = f4_fma(cf3, k3, v); v = f4_fma(cf4, k4, v);
             if (c.valid) {
-              st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);
+              if (i < p.S - 1) st4_g(p.state, own + (unsigned)(1 + i) * rowb, yv);   // (the last stage's derivative is combined here and never read again)
               if (i == p.S - 1) st4_g(p.state, own, v);
               if (last_phase) st4_g(p.u_out, own, v);
               store_sc1(p.bufA, own, v);
