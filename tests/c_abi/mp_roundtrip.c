@@ -127,6 +127,57 @@ int main(void) {
     CHECK_NG(ngpde_node_destroy(plan));
   }
 
+  /* ---- 1b. the same plan on a graph with a hub (docs/src/tutorials/graph_node.md:14-23: Cora has nodes of degree > 100): a row of 122
+   * entries does not fit the handle's 32-entry rows, so ngpde_node_gcn2_create takes the persistent kernels' hub geometry (flag
+   * NGPDE_NODE_HUB_GEOMETRY) -- nothing for the caller to do.  tanh: no relu kinks between the float32 port and the kernels. ---- */
+  {
+    const int64_t nh = 1500, hub = 120;
+    const int64_t eh = 2 * (nh + hub);
+    int64_t *sh = malloc(sizeof(int64_t) * eh), *th = malloc(sizeof(int64_t) * eh);
+    int64_t mh = 0;
+    for (int64_t i = 0; i < nh; ++i) { sh[mh] = i; th[mh++] = (i + 1) % nh; sh[mh] = (i + 1) % nh; th[mh++] = i; }   /* ring */
+    for (int64_t k = 2; k < hub + 2; ++k) { sh[mh] = 0; th[mh++] = 3 * k; sh[mh] = 3 * k; th[mh++] = 0; }             /* node 0 <-> 120 others */
+    ngpde_graph_t *gh = NULL;
+    CHECK_NG(ngpde_graph_create(nh, mh, sh, th, 0, 1, &gh));
+    CHECK_NG(ngpde_graph_set_gcn_norm(gh, 1, NULL, 0));
+    const int d = 64, steps = 3;
+    const float dt = 0.1f;
+    float *u0 = host_rand(nh * d, 1.f), *w1 = host_rand(d * d, 0.2f), *w2 = host_rand(d * d, 0.2f), *b1 = host_rand(d, 0.1f),
+          *b2 = host_rand(d, 0.1f), *ones = malloc(sizeof(float) * nh * d);
+    for (int64_t i = 0; i < nh * d; ++i) ones[i] = 1.f;
+    float *u0_d = dev_copy(u0, nh * d), *w1_d = dev_copy(w1, d * d), *w2_d = dev_copy(w2, d * d), *b1_d = dev_copy(b1, d),
+          *b2_d = dev_copy(b2, d), *ones_d = dev_copy(ones, nh * d), *uT_d = dev_copy(NULL, nh * d), *du0_d = dev_copy(NULL, nh * d),
+          *dw1_d = dev_copy(NULL, d * d), *dw2_d = dev_copy(NULL, d * d), *db1_d = dev_copy(NULL, d), *db2_d = dev_copy(NULL, d);
+    ngpde_node_t *plan = NULL;
+    CHECK_NG(ngpde_node_gcn2_create(gh, d, NGPDE_ACT_TANH, NGPDE_TABLEAU_TSIT5, steps, dt, 1, &plan));
+    int32_t flags = 0, fault = 0;
+    CHECK_NG(ngpde_node_flags(plan, &flags));
+    CHECK_NG(ngpde_node_gcn2_forward(plan, u0_d, w1_d, b1_d, w2_d, b2_d, uT_d, NULL));
+    CHECK_NG(ngpde_node_gcn2_backward(plan, ones_d, du0_d, dw1_d, db1_d, dw2_d, db2_d, NULL));
+    CHECK_NG(ngpde_node_fault(plan, NULL, &fault));
+    CHECK_HIP(hipDeviceSynchronize());
+    printf("plan on a graph with a hub of degree %lld: flags 0x%x%s, fault %d\n", (long long)(hub + 2), flags,
+           (flags & NGPDE_NODE_HUB_GEOMETRY) ? " (hub geometry)" : "", fault);
+    if (fault) return 4;
+    if ((flags & NGPDE_NODE_PERSISTENT_FWD) && !(flags & NGPDE_NODE_HUB_GEOMETRY)) {   /* (NGPDE_NO_PERSISTENT etc.: the replayed plan is fine too) */
+      fprintf(stderr, "hub graph: a persistent plan that is not the hub geometry, flags 0x%x\n", flags);
+      return 4;
+    }
+    float *uT = host_copy(uT_d, nh * d), *du0 = host_copy(du0_d, nh * d), *dw1 = host_copy(dw1_d, d * d), *dw2 = host_copy(dw2_d, d * d),
+          *db1 = host_copy(db1_d, d), *db2 = host_copy(db2_d, d);
+    float *uTo = malloc(sizeof(float) * nh * d), *du0o = malloc(sizeof(float) * nh * d), *dw1o = malloc(sizeof(float) * d * d),
+          *dw2o = malloc(sizeof(float) * d * d), *db1o = malloc(sizeof(float) * d), *db2o = malloc(sizeof(float) * d);
+    if (ngo_node_gcn2(nh, mh, sh, th, d, NGPDE_ACT_TANH, 1, steps, dt, 1, u0, w1, b1, w2, b2, uTo, du0o, dw1o, db1o, dw2o, db2o)) return 5;
+    report("node_gcn2 (hub geometry) u(T)", max_rel(uT, uTo, nh * d), 2e-4);
+    report("node_gcn2 (hub geometry) du0", max_rel(du0, du0o, nh * d), 1e-3);
+    report("node_gcn2 (hub geometry) dW1", max_rel(dw1, dw1o, d * d), 1e-3);
+    report("node_gcn2 (hub geometry) dW2", max_rel(dw2, dw2o, d * d), 1e-3);
+    report("node_gcn2 (hub geometry) db1", max_rel(db1, db1o, d), 1e-3);
+    report("node_gcn2 (hub geometry) db2", max_rel(db2, db2o, d), 1e-3);
+    CHECK_NG(ngpde_node_destroy(plan));
+    CHECK_NG(ngpde_graph_destroy(gh));
+  }
+
   /* the lists by target (p order) as the library holds them, for the loop checkers below */
   const int32_t *rp_d = NULL, *col_d = NULL, *eid_d = NULL;
   CHECK_NG(ngpde_graph_csr_by_target(g, &rp_d, &col_d, &eid_d));

@@ -1,5 +1,5 @@
 """The boundary called from plain C: tests/c_abi/gcn_roundtrip.c (GCNConv forward + pullback) and tests/c_abi/mp_roundtrip.c
-(the solver plan, the edge-function message path fused and on the primitives, both GNOConv message forms, the one-launch GAT
+(the solver plan -- also on a graph with a hub, where it takes the hub geometry --, the edge-function message path fused and on the primitives, both GNOConv message forms, the one-launch GAT
 layer against its composition, ngpde_rk_stage_combine) are compiled with gcc against include/ngpde.h, linked with
 libngpde_hip.so, the HIP runtime and the C oracle (the checker), and run on the GPU -- no Python, torch or C++ on the
 calling side.  This is the shape of the ccall binding INTEGRATION.md sketches for the Julia package."""
@@ -67,5 +67,6 @@ def test_solver_plan_message_path_gno_gat_from_plain_c(exe_mp):
     r = subprocess.run([exe_mp], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "FAIL" not in r.stdout and "node_gcn2 u(T)" in r.stdout and "gat_layer_forward" in r.stdout
+    assert "(hub geometry), fault 0" in r.stdout and "node_gcn2 (hub geometry) dW2" in r.stdout, r.stdout   # (the program runs without switches)
     assert "dense_pair_backward dWq" in r.stdout and "dense_chain2_forward" in r.stdout
     assert "node_vmh_forward_saveat" in r.stdout and r.stdout.count("node_vmh_backward_saveat du0") == 3, r.stdout   # (ran, not skipped)
