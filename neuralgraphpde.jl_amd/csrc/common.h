@@ -219,6 +219,7 @@ struct NodePersistFwd {
   int k_tiles = 0;             // > 0: tile rounds -- k_tiles tiles per workgroup taking turns, their state in `state` [7][N][64]
   float *state = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool no_latch = false;       // the caller latches the fault word in its next kernel (node.hip: the exit scaling)
 };
 struct NodePersistBwd {
   const ngpde_graph *g = nullptr;
@@ -234,7 +235,9 @@ struct NodePersistBwd {
   int k_tiles = 0;             // > 0: tile rounds (ubar = [5][N][64], lam holds lambda between the turns)
   float *ubar = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool no_latch = false;       // the caller latches the fault word in its next kernel (node.hip: the slab reduction)
 };
+const unsigned *node_persistent_abort_word(const NodePersist *ps);   // the abort word of the plan's persistent launches
 bool node_persistent_interleave_env();
 bool node_persistent_disabled_env();
 bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_bwd);

@@ -50,22 +50,32 @@ Tableau make_tableau(int which) {
 }
 
 // dst[i][:] = src[i][:] * c[i]   (invert: / c[i]) -- entry to / exit from the pre-scaled form of the pipeline
+// What rides along with an entry / exit kernel of a plan (one launch instead of three): a raw copy of the source rows (the plan keeps u0
+// for ngpde_node_profile) and the fault latch of the persistent launch that ran just before (abort word of that launch -> the plan's
+// sticky fault word; node_persistent.hip launched a kernel of its own for it until round 5)
+struct RowsExtra {
+  float4 *keep = nullptr;
+  const unsigned *abort_word = nullptr;
+  unsigned *fault = nullptr;
+};
 __global__ void scale_rows_kernel(size_t n4, int lpr, int invert, const float4 *__restrict__ src, const float *__restrict__ c,
-                                  size_t n_nodes, float4 *__restrict__ dst) {
+                                  size_t n_nodes, float4 *__restrict__ dst, RowsExtra x) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && x.abort_word && *x.abort_word != 0) *x.fault = 1u;
   if (i >= n4) return;
   const float ci = c[(i / lpr) % n_nodes];   // (a batch of identical graphs repeats the member's coefficients)
   const float f = invert ? 1.0f / ci : ci;
   const float4 v = src[i];
+  if (x.keep) x.keep[i] = v;
   dst[i] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
 }
 
 int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t n, int d, bool invert, hipStream_t stream,
-                          int members = 1) {
+                          int members = 1, RowsExtra x = RowsExtra()) {
   const size_t n4 = (size_t)n * members * d / 4;
   if (n4 == 0) return NGPDE_OK;
   hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, d / 4, invert ? 1 : 0,
-                     reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst));
+                     reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst), x);
   NGPDE_LAUNCH_CHECK("scale_rows_kernel");
   return NGPDE_OK;
 }
@@ -73,8 +83,9 @@ int32_t launch_scale_rows(const float *src, const float *c, float *dst, int64_t 
 // The same with a change of row width: dst rows are `d_out` wide, src rows `d_in` (columns beyond the narrower of the two are
 // written as zeros / dropped) -- entry to / exit from a plan that runs a narrow state on the 64-wide persistent kernels.
 __global__ void scale_rows_width_kernel(size_t n4, int lpr_in, int lpr_out, int invert, const float4 *__restrict__ src,
-                                        const float *__restrict__ c, size_t n_nodes, float4 *__restrict__ dst) {
+                                        const float *__restrict__ c, size_t n_nodes, float4 *__restrict__ dst, RowsExtra x) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of dst
+  if (i == 0 && x.abort_word && *x.abort_word != 0) *x.fault = 1u;
   if (i >= n4) return;
   const size_t row = i / lpr_out;
   const int q = (int)(i - row * lpr_out);
@@ -83,20 +94,89 @@ __global__ void scale_rows_width_kernel(size_t n4, int lpr_in, int lpr_out, int 
     const float ci = c[row % n_nodes];
     const float f = invert ? 1.0f / ci : ci;
     const float4 s = src[row * lpr_in + q];
+    if (x.keep) x.keep[row * lpr_in + q] = s;   // (keep has the SOURCE's row width: asked for on the way in, lpr_in <= lpr_out)
     v = make_float4(s.x * f, s.y * f, s.z * f, s.w * f);
   }
   dst[i] = v;
 }
 
 int32_t launch_scale_rows_width(const float *src, int d_in, const float *c, float *dst, int d_out, int64_t n, bool invert,
-                                hipStream_t stream, int members = 1) {
-  if (d_in == d_out) return launch_scale_rows(src, c, dst, n, d_in, invert, stream, members);
+                                hipStream_t stream, int members = 1, RowsExtra x = RowsExtra()) {
+  if (d_in == d_out) return launch_scale_rows(src, c, dst, n, d_in, invert, stream, members, x);
   const size_t n4 = (size_t)n * members * d_out / 4;
   if (n4 == 0) return NGPDE_OK;
   hipLaunchKernelGGL(scale_rows_width_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, d_in / 4, d_out / 4,
-                     invert ? 1 : 0, reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst));
+                     invert ? 1 : 0, reinterpret_cast<const float4 *>(src), c, (size_t)n, reinterpret_cast<float4 *>(dst), x);
   NGPDE_LAUNCH_CHECK("scale_rows_width_kernel");
   return NGPDE_OK;
+}
+
+// The caller's parameters -> the plan's [d][d] / [d] copies in ONE launch (they were four copies, or two 2-D copies and two copies for a
+// widened plan: the du x du block of the zero-padded d x d matrix, whose padding is written once at creation); a NULL bias is zeros
+__global__ void pack_params_kernel(const float *__restrict__ w1u, const float *__restrict__ b1u, const float *__restrict__ w2u,
+                                   const float *__restrict__ b2u, int du, int d, float *__restrict__ w1, float *__restrict__ b1,
+                                   float *__restrict__ w2, float *__restrict__ b2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, mm = du * du;
+  if (i < mm) w1[(i / du) * d + i % du] = w1u[i];
+  else if (i < 2 * mm) w2[((i - mm) / du) * d + (i - mm) % du] = w2u[i - mm];
+  else if (i < 2 * mm + du) b1[i - 2 * mm] = b1u ? b1u[i - 2 * mm] : 0.f;
+  else if (i < 2 * mm + 2 * du) b2[i - 2 * mm - du] = b2u ? b2u[i - 2 * mm - du] : 0.f;
+}
+int32_t launch_pack_params(const float *w1u, const float *b1u, const float *w2u, const float *b2u, int du, int d, float *w1, float *b1,
+                           float *w2, float *b2, hipStream_t stream) {
+  const int total = 2 * du * du + 2 * du;
+  hipLaunchKernelGGL(pack_params_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w1u, b1u, w2u, b2u, du, d, w1, b1, w2, b2);
+  NGPDE_LAUNCH_CHECK("pack_params_kernel");
+  return NGPDE_OK;
+}
+
+// The four slab reductions of an adjoint (dW1, db1, dW2, db2) in ONE launch, written where the caller wants them -- its own du x du /
+// du arrays (the leading block of the plan's d x d accumulation when the plan is widened) -- with reduce_slabs_kernel's sums in its
+// order (gcn_fused.hip: bitwise the same numbers); block (0, 0) latches the fault word of the adjoint launch in front of it
+struct Reduce4 {
+  const float *slab[4];
+  float *out[4];        // NULL: not asked for
+  int len[4], ct[4];    // ct > 0: a [D][D] matrix in MFMA tile order (D = 16 ct), ct == 0: a vector
+  int n_slabs, du;
+  const unsigned *abort_word;
+  unsigned *fault;
+};
+__global__ __launch_bounds__(1024) void reduce4_slabs_kernel(const Reduce4 r) {
+  __shared__ float part[16][64];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && r.abort_word && *r.abort_word != 0) *r.fault = 1u;
+  const int job = blockIdx.y;
+  const float *__restrict__ slab = r.slab[job];
+  float *__restrict__ out = r.out[job];
+  const int len = r.len[job], ct = r.ct[job], n_slabs = r.n_slabs;
+  if (out == nullptr || (int)blockIdx.x * 64 >= len) return;   // (block-uniform)
+  const int el = threadIdx.x & 63, part_id = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < len) {
+    int b = part_id;
+    for (; b + 48 < n_slabs; b += 64) {
+      s0 += slab[(size_t)b * len + e];
+      s1 += slab[(size_t)(b + 16) * len + e];
+      s2 += slab[(size_t)(b + 32) * len + e];
+      s3 += slab[(size_t)(b + 48) * len + e];
+    }
+    for (; b < n_slabs; b += 16) s0 += slab[(size_t)b * len + e];
+  }
+  part[part_id][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part_id == 0 && e < len) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][el];
+    if (ct > 0) {  // e = (tt * 64 + lane) * 4 + reg  ->  dWt[(mt*16 + 4*kq + reg)][nt*16 + i]
+      const int reg = e & 3, ln = (e >> 2) & 63, tt = e >> 8;
+      const int mt = tt / ct, nt = tt % ct;
+      const int row = mt * 16 + 4 * (ln >> 4) + reg, col = nt * 16 + (ln & 15);
+      if (row < r.du && col < r.du) out[row * r.du + col] = v;
+    } else if (e < r.du) {
+      out[e] = v;
+    }
+  }
 }
 
 // [h][w] block between matrices of row pitch spitch / dpitch (elements): the parameters of a widened plan
@@ -362,8 +442,10 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
 }
 
 // the persistent forms: ONE launch for the whole solve / the whole adjoint (node_persistent.hip)
-int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+// fold_latch: the caller's next kernel on the stream latches the fault word (ngpde_node_gcn2_forward: the exit scaling)
+int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool fold_latch = false) {
   NodePersistFwd a;
+  a.no_latch = fold_latch;
   a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.act = p->act; a.n_members = p->members;
   a.u_in = p->u; a.u_out = p->u;     // a tile writes its rows of u(T) only after all its readers are past phase 1
   a.bufA = p->ustage; a.bufB = p->pbuf;
@@ -377,8 +459,11 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
   return launch_node_fwd_persistent(a, stream);
 }
 
-int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+// out[4] = where dW1, db1, dW2, db2 go (du x du / du arrays; NULL entries are skipped); nullptr: the plan's own d x d / d buffers
+int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                                    float *const *out = nullptr) {
   NodePersistBwd a;
+  a.no_latch = true;   // (the reduction below latches)
   a.g = p->g; a.ps = &p->persist; a.n_steps = p->n_steps; a.S = p->tb.S; a.n_members = p->members; a.act = p->act;
   a.lam = p->lam; a.g1 = p->g1; a.g2 = p->g2; a.w1 = p->w1; a.w2 = p->w2;
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
@@ -388,11 +473,21 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   int32_t st;
   if ((st = launch_node_bwd_persistent(a, stream))) return st;
   const int dd = p->d * p->d;
-  const int ns = (p->pair || p->ktiles) ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
-  if ((st = launch_reduce_slabs(p->slab_dw1, ns, dd, p->d / 16, p->dw1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db1, ns, p->d, 0, p->db1, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_dw2, ns, dd, p->d / 16, p->dw2, stream))) return st;
-  if ((st = launch_reduce_slabs(p->slab_db2, ns, p->d, 0, p->db2, stream))) return st;
+  Reduce4 r;
+  r.n_slabs = (p->pair || p->ktiles) ? p->persist.pair_wgs : p->persist.n_tiles;   // one slab per workgroup, each written once at the end of the launch
+  r.slab[0] = p->slab_dw1; r.slab[1] = p->slab_db1; r.slab[2] = p->slab_dw2; r.slab[3] = p->slab_db2;
+  r.len[0] = r.len[2] = dd; r.len[1] = r.len[3] = p->d;
+  r.ct[0] = r.ct[2] = p->d / 16; r.ct[1] = r.ct[3] = 0;
+  if (out) {
+    for (int j = 0; j < 4; ++j) r.out[j] = out[j];
+    r.du = p->du;
+  } else {
+    r.out[0] = p->dw1; r.out[1] = p->db1; r.out[2] = p->dw2; r.out[3] = p->db2;
+    r.du = p->d;
+  }
+  r.abort_word = node_persistent_abort_word(&p->persist); r.fault = p->persist.fault;
+  hipLaunchKernelGGL(reduce4_slabs_kernel, dim3((dd + 63) / 64, 4), dim3(1024), 0, stream, r);
+  NGPDE_LAUNCH_CHECK("reduce4_slabs_kernel");
   return NGPDE_OK;
 }
 
@@ -608,8 +703,8 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
     p->fwd_launches = 2 * S * n_steps;
     p->bwd_launches = p->with_bwd ? 1 + 2 * S * n_steps + 4 : 0;
   }
-  if (p->persist_fwd) p->fwd_launches = 3;                    // flag reset, the solve, fault latch
-  if (p->persist_bwd) p->bwd_launches = 3 + 4;                // ... + the four slab reductions
+  if (p->persist_fwd) p->fwd_launches = 2;                    // flag reset, the solve (the fault latch rides on the exit scaling)
+  if (p->persist_bwd) p->bwd_launches = 3;                    // flag reset, the adjoint, ONE reduction of the four slab sets (it latches too)
   if (st != NGPDE_OK) {
     std::string keep = last_error();
     ngpde_node_destroy(p);
@@ -699,29 +794,25 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
                 "another kernel held the device's compute units, or two persistent solves of different processes shared the device; "
                 "create a new plan (NGPDE_NO_PERSISTENT=1 selects the replayed plan)");
   hipStream_t stream = (hipStream_t)stream_;
-  const size_t dd = (size_t)p->d * p->d * sizeof(float), db = (size_t)p->du * sizeof(float);
   const size_t user_bytes = (size_t)p->members * p->n * p->du * sizeof(float);
+  // entry: three launches where there were up to nine stream operations (round 5) -- u0 scaled into the plan and kept raw by one kernel,
+  // the four parameter arrays by one
   if (p->pre) {
-    int32_t st = launch_scale_rows_width(u0, p->du, p->g->c, p->u, p->d, p->n, false, stream, p->members);
+    RowsExtra x;
+    x.keep = reinterpret_cast<float4 *>(p->u0keep);
+    int32_t st = launch_scale_rows_width(u0, p->du, p->g->c, p->u, p->d, p->n, false, stream, p->members, x);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->u, u0, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, user_bytes, hipMemcpyDeviceToDevice, stream));
   }
-  NGPDE_HIP_CHECK(hipMemcpyAsync(p->u0keep, u0, user_bytes, hipMemcpyDeviceToDevice, stream));
-  if (p->du != p->d) {   // widened plan: the du x du blocks of the zero-padded d x d parameters
-    int32_t st;
-    if ((st = copy_block(p->w1, p->d, w1, p->du, p->du, p->du, stream))) return st;
-    if ((st = copy_block(p->w2, p->d, w2, p->du, p->du, p->du, stream))) return st;
-  } else {
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->w1, w1, dd, hipMemcpyDeviceToDevice, stream));
-    NGPDE_HIP_CHECK(hipMemcpyAsync(p->w2, w2, dd, hipMemcpyDeviceToDevice, stream));
+  {
+    int32_t st = launch_pack_params(w1, b1, w2, b2, p->du, p->d, p->w1, p->b1, p->w2, p->b2, stream);
+    if (st) return st;
   }
-  if (b1) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b1, b1, db, hipMemcpyDeviceToDevice, stream));
-  else NGPDE_HIP_CHECK(hipMemsetAsync(p->b1, 0, db, stream));
-  if (b2) NGPDE_HIP_CHECK(hipMemcpyAsync(p->b2, b2, db, hipMemcpyDeviceToDevice, stream));
-  else NGPDE_HIP_CHECK(hipMemsetAsync(p->b2, 0, db, stream));
+  const bool fold_latch = p->persist_fwd && p->pre;   // (the exit scaling latches the launch's fault word)
   if (p->persist_fwd) {
-    int32_t st = enqueue_forward_persistent(p, stream);
+    int32_t st = enqueue_forward_persistent(p, stream, nullptr, nullptr, fold_latch);
     if (st) return st;
   } else if (p->eager) {
     int32_t st = enqueue_forward(p, stream, nullptr);
@@ -730,7 +821,9 @@ int32_t ngpde_node_gcn2_forward(ngpde_node_t *p, const float *u0, const float *w
     NGPDE_HIP_CHECK(hipGraphLaunch(p->fwd_exec, stream));
   }
   if (p->pre) {
-    int32_t st = launch_scale_rows_width(p->u, p->d, p->g->c, uT, p->du, p->n, true, stream, p->members);
+    RowsExtra x;
+    if (fold_latch) { x.abort_word = node_persistent_abort_word(&p->persist); x.fault = p->persist.fault; }
+    int32_t st = launch_scale_rows_width(p->u, p->d, p->g->c, uT, p->du, p->n, true, stream, p->members, x);
     if (st) return st;
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(uT, p->u, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -777,8 +870,9 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
   } else {
     NGPDE_HIP_CHECK(hipMemcpyAsync(p->lam, duT, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  if (p->persist_bwd) {
-    int32_t st = enqueue_backward_persistent(p, stream);
+  if (p->persist_bwd) {   // (its one reduction launch writes the four gradients where the caller wants them)
+    float *const outs[4] = {dw1, db1, dw2, db2};
+    int32_t st = enqueue_backward_persistent(p, stream, nullptr, nullptr, outs);
     if (st) return st;
   } else if (p->eager) {
     int32_t st = enqueue_backward(p, stream, nullptr);
@@ -793,6 +887,7 @@ int32_t ngpde_node_gcn2_backward(ngpde_node_t *p, const float *duT, float *du0, 
     NGPDE_HIP_CHECK(hipMemcpyAsync(du0, p->lam, p->all_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   p->backward_pending = false;
+  if (p->persist_bwd) return NGPDE_OK;
   if (p->du != p->d) {
     int32_t st;
     if (dw1 && (st = copy_block(dw1, p->du, p->dw1, p->d, p->du, p->du, stream))) return st;

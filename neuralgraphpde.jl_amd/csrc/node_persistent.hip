@@ -2662,6 +2662,9 @@ __global__ void set_word_kernel(unsigned *w, unsigned v) {
 __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) {
   if (threadIdx.x == 0 && *abort_word != 0) *fault = 1u;
 }
+}  // namespace
+const unsigned *node_persistent_abort_word(const NodePersist *ps) { return ps->sync ? ps->sync + (size_t)ps->n_tiles * 64 : nullptr; }
+namespace {
 TileMeta make_meta(const Csr &c, const NodePersist &ps, int dir) {
   TileMeta m;
   m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr; m.slot_w = c.slot_w;
@@ -2780,7 +2783,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     else { NGPDE_PFK_LAUNCH(-1, false) }
 #undef NGPDE_PFK_LAUNCH
     NGPDE_LAUNCH_CHECK("node_fwd_persistentK_kernel");
-    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    if (!a.no_latch) hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turn.leave();
   }
@@ -2801,7 +2804,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
     else { NGPDE_PFH_LAUNCH(-1, false) }
 #undef NGPDE_PFH_LAUNCH
     NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel (hub geometry)");
-    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    if (!a.no_latch) hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turn.leave();
   }
@@ -2832,7 +2835,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   }
 #undef NGPDE_PF_LAUNCH
   NGPDE_LAUNCH_CHECK("node_fwd_persistent_kernel");
-  hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  if (!a.no_latch) hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
   return turn.leave();
 }
@@ -2880,7 +2883,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
     else { NGPDE_PBK_LAUNCH(-1) }
 #undef NGPDE_PBK_LAUNCH
     NGPDE_LAUNCH_CHECK("node_bwd_persistentK_kernel");
-    hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+    if (!a.no_latch) hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
     NGPDE_LAUNCH_CHECK("latch_fault_kernel");
     return turn.leave();
   }
@@ -2921,7 +2924,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   } else if (a.ev_start) hipExtLaunchKernelGGL(node_bwd_persistent_kernel<NGPDE_ACT_RELU>, grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);
   else hipLaunchKernelGGL(node_bwd_persistent_kernel<NGPDE_ACT_RELU>, grid, block, 0, stream, k);
   NGPDE_LAUNCH_CHECK("node_bwd_persistent_kernel");
-  hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
+  if (!a.no_latch) hipLaunchKernelGGL(latch_fault_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, ps.fault);
   NGPDE_LAUNCH_CHECK("latch_fault_kernel");
   return turn.leave();
 }

@@ -602,7 +602,7 @@ def test_node_persistent_plan_against_oracle(tab, N, nsteps, act, monkeypatch):
     uT, _ = node(u, ps, st)
     plan = next(iter(node._plans.values()))[0]
     assert {"persistent_fwd", "persistent_bwd"} <= plan.flags()
-    assert plan.launch_count() == (3, 7)
+    assert plan.launch_count() == (2, 3)      # flag reset + solve; flag reset + adjoint + one reduction (the fault latches ride on the exit kernels)
     (uT * torch.as_tensor(R.astype(np.float32), device=DEV)).sum().backward()
     assert not plan.fault()
     uTo, du0o, acc = _oracle_node_with_seed(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps, act)
