@@ -364,9 +364,10 @@ int32_t ngpde_edge_mlp_forward(const ngpde_graph_t *g, int32_t h1, int32_t act1,
                                const float *q_source, const float *e_term, int32_t n_tail, const int32_t *tail_dout,
                                const int32_t *tail_act, const float *const *tail_weight, const float *const *tail_bias,
                                int32_t aggr, float *out, float *const *save_z, ngpde_stream_t stream);
-/* Fused pullback of the same message path for 0 or 1 Dense layer after the first and + / mean / * aggregation (*: a first pass over
+/* Fused pullback of the same message path for 0 or 1 Dense layer after the first and any of the five aggregations (*: a first pass over
  * a tile's edges forms each target's product of the nonzero messages and the number of zeros; every message then receives the gradient
- * times the product of the OTHERS -- the one zero message of a row the product of the rest, nothing where two are zero): recomputes the
+ * times the product of the OTHERS -- the one zero message of a row the product of the rest, nothing where two are zero; max / min: the
+ * first pass leaves the target's extremum and every message equal to it receives the gradient, as NNlib's scatter pullback): recomputes the
  * per-edge activations inside the tile (nothing per-edge has to be saved by the forward), accumulates the tail layer's
  * weight / bias gradient on MFMA in per-workgroup slabs, writes dz1 once ([E][h1], p order: de_term, required -- it is the
  * gradient of the per-edge first-layer term and the input of the by-source sum that gives dq_source) and sums it per target

@@ -209,12 +209,12 @@ int32_t make_plan(const ngpde_graph *g, const ngpde_edge_layer_t &L, bool traini
 
   // ---- message path: one fused launch where the message MLP fits the fused kernel (widths <= 64, multiples of 4, <= 3 further
   // layers, tiles within the LDS halo; max / min only without gradients), the primitives otherwise
-  // (*: with gradients only where the one-launch pullback takes it -- the primitives' pullback of a product needs the per-edge messages,
-  // which the fused forward does not keep)
+  // (max / min / *: with gradients only where the one-launch pullback takes it -- the primitives' pullbacks of those need the per-edge
+  // messages, which the fused forward does not keep)
   const bool bwd_ok = !env_is("NGPDE_NO_FUSED_EDGE_BWD", '1') &&
                       ngpde_edge_mlp_backward_supported(g, p.h1, p.n_tail, p.n_tail ? p.tail_dout : nullptr, p.aggr) == 1;
   p.fused_msg = !env_is("NGPDE_NO_FUSED_EDGE", '1') && p.E > 0 && p.n_tail <= 3 &&
-                (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN || !training || (p.aggr == NGPDE_AGGR_MUL && bwd_ok)) &&
+                (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN || !training || bwd_ok) &&
                 ngpde_edge_mlp_supported(g, p.h1, p.n_tail, p.n_tail ? p.tail_dout : nullptr) == 1;
   if (p.fused_msg && training) {
     p.fused_bwd = bwd_ok;

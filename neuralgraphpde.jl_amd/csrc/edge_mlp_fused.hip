@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
   float *ldsS = ldsG + kGroups * kTS;                             // [kChunk][kTS]  wave-private transposes, then dz1 of the chunk
   float *ldsWf = ldsS + kChunk * kTS;                             // [64 out][kTS]  W2^T   (NTAIL = 1)
   float *ldsWb = ldsWf + (NTAIL ? kW * kTS : 0);                  // [64 in][kTS]   W2
-  float *ldsZc = ldsWb + (NTAIL ? kW * kTS : 0);                  // [32][kTS]  aggr = *: how many of the target's messages are zero, per feature
+  float *ldsZc = ldsWb + (NTAIL ? kW * kTS : 0);                  // [32][kTS]  aggr = *: how many of the target's messages are zero, per feature;
+                                                                  //            max / min: the target's extremum
   __shared__ int ldsOff[kGroups + 1], ldsRs[kGroups];
   __shared__ __attribute__((aligned(16))) unsigned ldsSlots[kGroups * 8];
   __shared__ uint8_t ldsRowOf[kGroups * kSlotWidth];
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
       }
     }
   };
-  const bool mul = p.aggr == NGPDE_AGGR_MUL;
+  const bool mul = p.aggr == NGPDE_AGGR_MUL, ext = p.aggr == NGPDE_AGGR_MAX || p.aggr == NGPDE_AGGR_MIN, want_max = p.aggr == NGPDE_AGGR_MAX;
 
   TileMeta meta;
   int jt = wg_in_xcd;
@@ -494,10 +495,13 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
     float4 racc = f4_zero();
     __syncthreads();
 
-    if (mul) {
+    if (mul || ext) {
       // ---- aggr = *: a first pass over the tile's edges recomputes the messages and leaves, per target and feature, the product of the
-      // nonzero ones (folded into the gradient row) and the number of zeros
+      // nonzero ones (folded into the gradient row) and the number of zeros; max / min: the target's extremum (the second pass gives the
+      // gradient to every message equal to it, as NNlib's pullback of scatter(max) does)
       float4 pacc = make_float4(1.f, 1.f, 1.f, 1.f), zacc = f4_zero();
+      const float e0 = want_max ? -INFINITY : INFINITY;
+      float4 eacc = make_float4(e0, e0, e0, e0);
       for (int c0 = 0; c0 < total; c0 += kChunk) {
         const bool wave_on = c0 + wave * 16 < total;   // wave-uniform
         const int k = c0 + wave * 16 + ei;
@@ -534,13 +538,17 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
                                pacc.w * (v.w != 0.f ? v.w : 1.f));
             zacc = make_float4(zacc.x + (v.x == 0.f ? 1.f : 0.f), zacc.y + (v.y == 0.f ? 1.f : 0.f), zacc.z + (v.z == 0.f ? 1.f : 0.f),
                                zacc.w + (v.w == 0.f ? 1.f : 0.f));
+            eacc = want_max ? make_float4(fmaxf(eacc.x, v.x), fmaxf(eacc.y, v.y), fmaxf(eacc.z, v.z), fmaxf(eacc.w, v.w))
+                            : make_float4(fminf(eacc.x, v.x), fminf(eacc.y, v.y), fminf(eacc.z, v.z), fminf(eacc.w, v.w));
           }
         }
         __syncthreads();
       }
-      float4 *gr = reinterpret_cast<float4 *>(&ldsG[grp * kTS + 4 * q]);
-      *gr = f4_mul(*gr, pacc);
-      *reinterpret_cast<float4 *>(&ldsZc[grp * kTS + 4 * q]) = zacc;
+      if (mul) {
+        float4 *gr = reinterpret_cast<float4 *>(&ldsG[grp * kTS + 4 * q]);
+        *gr = f4_mul(*gr, pacc);
+      }
+      *reinterpret_cast<float4 *>(&ldsZc[grp * kTS + 4 * q]) = mul ? zacc : eacc;
       __syncthreads();
     }
 
@@ -575,17 +583,22 @@ __global__ __launch_bounds__(kT, 2) void edge_mlp_fused_bwd_kernel(const EdgeMlp
           for (int mt = 0; mt < 4; ++mt) {
             const int f = 16 * mt + 4 * kq;
             const float4 zc = (valid && f < dw) ? *reinterpret_cast<const float4 *>(&ldsZc[r * kTS + f]) : make_float4(2.f, 2.f, 2.f, 2.f);
+            if (ext) {   // (zc holds the extremum; invalid edges / padded features carry a zero gradient already)
+              gv[mt] = make_float4(m[mt].x == zc.x ? gv[mt].x : 0.f, m[mt].y == zc.y ? gv[mt].y : 0.f, m[mt].z == zc.z ? gv[mt].z : 0.f,
+                                   m[mt].w == zc.w ? gv[mt].w : 0.f);
+              continue;
+            }
             auto one = [](float g, float mm, float z) { return mm != 0.f ? (z == 0.f ? g / mm : 0.f) : (z == 1.f ? g : 0.f); };
             gv[mt] = make_float4(one(gv[mt].x, m[mt].x, zc.x), one(gv[mt].y, m[mt].y, zc.y), one(gv[mt].z, m[mt].z, zc.z), one(gv[mt].w, m[mt].w, zc.w));
           }
         };
-        if (!NTAIL && mul) others(gz, a1);
+        if (!NTAIL && (mul || ext)) others(gz, a1);
         if (NTAIL) {
           const int n_ct = (h1 + 15) >> 4, n_mt = (dw + 15) >> 4;   // uniform
           // ---- z2 (transposed product), dz2
           float4 z2[4];
           second_layer(a1, z2);
-          if (mul) {
+          if (mul || ext) {
             float4 m2[4] = {z2[0], z2[1], z2[2], z2[3]};
             f4n_act<4>(p.act2, m2);
             others(gz, m2);
@@ -791,7 +804,7 @@ bool edge_mlp_fused_bwd_supported(const ngpde_graph *g, int h1, int n_tail, int 
   if (h1 <= 0 || h1 > kW || h1 % 4) return false;
   if (n_tail < 0 || n_tail > 1) return false;                 // deeper message MLPs take the primitives' pullback
   if (n_tail == 1 && (dw <= 0 || dw > kW || dw % 4)) return false;
-  return aggr == NGPDE_AGGR_SUM || aggr == NGPDE_AGGR_MEAN || aggr == NGPDE_AGGR_MUL;   // (* on this kernel only: the 64-wide and deep ones take + / mean)
+  return aggr >= NGPDE_AGGR_SUM && aggr <= NGPDE_AGGR_MUL;   // (max / min / * on this kernel only: the 64-wide and deep ones take + / mean)
 }
 
 size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, int dw) {
@@ -801,8 +814,8 @@ size_t edge_mlp_fused_bwd_workspace(const ngpde_graph *g, int h1, int n_tail, in
 
 int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a, hipStream_t stream) {
   NGPDE_REQUIRE(edge_mlp_fused_bwd_supported(g, a.h1, a.n_tail, a.dw, a.aggr), NGPDE_ERR_UNSUPPORTED,
-                "fused edge-MLP pullback needs widths <= 64 and multiples of 4, at most one layer after the first, +, mean or * "
-                "aggregation and a graph whose tiles fit the LDS halo");
+                "fused edge-MLP pullback needs widths <= 64 and multiples of 4, at most one layer after the first and a graph whose tiles fit "
+                "the LDS halo");
   if (g->n_nodes == 0) return NGPDE_OK;
   const size_t need = edge_mlp_fused_bwd_workspace(g, a.h1, a.n_tail, a.dw);
   NGPDE_REQUIRE(a.workspace && a.workspace_bytes >= need, NGPDE_ERR_WORKSPACE, "fused edge-MLP pullback: workspace too small (%zu < %zu bytes)",
@@ -817,7 +830,7 @@ int32_t launch_edge_mlp_fused_bwd(const ngpde_graph *g, const EdgeMlpBwdArgs &a,
   k.P = a.P; k.Q = a.Q; k.Eterm = a.Eterm; k.wt = a.wt; k.bias = a.bias; k.dout = a.dout;
   k.dP = a.dP; k.dE = a.dE; k.partial = (float *)a.workspace;
   const size_t lds = ((size_t)(k.halo_rows + 1) * kTS + 2 * (size_t)kGroups * kTS + (size_t)kChunk * kTS + (a.n_tail ? 2 * (size_t)kW * kTS : 0) +
-                      (a.aggr == NGPDE_AGGR_MUL ? (size_t)kGroups * kTS : 0)) * sizeof(float);
+                      (a.aggr >= NGPDE_AGGR_MAX ? (size_t)kGroups * kTS : 0)) * sizeof(float);
   const dim3 grid(edge_bwd_grid(g)), block(kT);
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -804,8 +804,8 @@ def _message_path(g, P, Q, Et, stack, aggr):
     if os.environ.get("NGPDE_NO_FUSED_EDGE") != "1" and g.num_edges > 0:
         fh = g.handle((False, None, False))          # the handle that carries the tile schedule / halo lists
         douts = [w.shape[1] for w, _, _ in tail]
-        # (*: with gradients only where the one-launch pullback takes it -- the primitives' pullback of a product needs the per-edge messages)
-        mul_ok = aggr_code == 4 and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(_lib.load().ngpde_edge_mlp_backward_supported(
+        # (max / min / *: with gradients only where the one-launch pullback takes it -- the primitives' pullbacks need the per-edge messages)
+        mul_ok = aggr_code in (2, 3, 4) and os.environ.get("NGPDE_NO_FUSED_EDGE_BWD") != "1" and bool(_lib.load().ngpde_edge_mlp_backward_supported(
             fh.ptr, ref.shape[1], len(douts), _int_array(douts) if douts else None, aggr_code))
         if (aggr_code in (0, 1) or not needs_grad or mul_ok) and edge_mlp_supported(fh, ref.shape[1], douts):
             return edge_mlp_fused(P, Q, Et, fh, l1.act, aggr, g.num_nodes, g.num_edges, tail)

@@ -532,6 +532,38 @@ def test_product_aggregation_in_the_one_launch_pullback(widths, last_act):
     check_grads(ps, (names, ogr), x, gr["x"])
 
 
+@pytest.mark.parametrize("aggr", ["max", "min"])
+@pytest.mark.parametrize("widths", [(8,), (16, 12), (64, 64)])
+def test_extremum_aggregation_in_the_one_launch_pullback(aggr, widths):
+    # aggr = max / min with gradients on the fused message path (round 5): the pullback's first pass over a tile's edges leaves every
+    # target's extremum, the second gives the gradient to the messages equal to it (NNlib's pullback of scatter(max): ties all receive it).
+    # Values and all gradients against the float64 oracle.
+    from ngpde_amd import _lib
+    N, h = 600, 6
+    rng = np.random.default_rng(23)
+    _, s, t = S.closest_pairs_graph(N, 2 * N, seed=9)
+    nd = {"x": rng.random((2, N))}
+    g, og = ng.GNNGraph(s, t, num_nodes=N, index_base=0, ndata=nd), O.Graph(s, t, num_nodes=N, index_base=0, ndata=nd)
+    dims = (2 * h + 2,) + widths
+    phi = ng.Chain(*[ng.Dense(dims[l], dims[l + 1], "tanh") for l in range(len(widths))]) if len(widths) > 1 else ng.Dense(dims[0], dims[1], "tanh")
+    l = ng.ExplicitEdgeConv(phi, initialgraph=g, aggr=aggr)
+    assert _lib.load().ngpde_edge_mlp_backward_supported(g.handle((False, None, False)).ptr, widths[0], len(widths) - 1,
+                                                         (C.c_int32 * 1)(widths[-1]) if len(widths) > 1 else None, _lib.AGGR[aggr]) == 1
+    ps, st = ng.setup(5, l)
+    ps = prep(ps, 5)
+    x = torch.randn(h, N, device=DEV, requires_grad=True)
+    y, _ = l(x, ps, st)
+    yo, c = O.explicit_edge_conv(x.detach().cpu().double().numpy(), omlp(phi, ps), og, aggr)
+    fin = np.isfinite(yo)                       # (a node without incoming edges keeps -inf / +inf, as NNlib's scatter leaves it)
+    assert torch.equal(torch.isfinite(y).cpu(), torch.as_tensor(fin))
+    close(torch.where(torch.isfinite(y), y, torch.zeros_like(y)), np.where(fin, yo, 0.0), rtol=2e-4)
+    R = rng.normal(size=yo.shape) * fin
+    (torch.where(torch.isfinite(y), y, torch.zeros_like(y)) * torch.as_tensor(R, dtype=torch.float32, device=DEV)).sum().backward()
+    gr = O.explicit_edge_conv_backward(c, R)
+    names, ogr = mlp_grad_pairs(ps, gr["phi"], phi)
+    check_grads(ps, (names, ogr), x, gr["x"])
+
+
 # ---- VMHConv ---------------------------------------------------------------------------------------------------------------
 
 def test_vmh_reference_fixture_and_parity():
