@@ -1,7 +1,7 @@
 """Which tiles set the pace of the persistent solver?  Reads the per-workgroup stamp segments that `DUMP=1 python3 tools/stamps_persistent.py`
 leaves in gpurun_out/stamps_{fwd,bwd}.npy (diagnostic build) and relates a workgroup's own work per phase (everything but the wait) to its
 tile: referenced rows, sum and maximum of the degrees, aggregation rounds of its slowest wave, and the XCD it runs on.  Finding of round 5
-(DESIGN 5.2): the phase period is the slowest tile's own work plus one poll round trip; own work spreads 5.1 k - 6.8 k cycles (5 - 95 %) in
+(DESIGN 5.2): the phase period is the cycle through two neighbouring tiles -- the mean of their own work plus one hand-off; own work spreads 5.1 k - 6.8 k cycles (5 - 95 %) in
 the forward with correlations of only 0.2 - 0.3 to any tile property (+ ~150 cycles per aggregation round); the workgroups of XCD 2 are
 15 % slower in the forward launch on every box measured, with tiles like everybody else's."""
 import os, sys, ctypes as C
