@@ -141,6 +141,29 @@ def test_one_hub_of_growing_degree(hub_degree, expect_hub):
         close(grads[2 * k + 1], acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
 
 
+@pytest.mark.parametrize("direction", ["out", "in"])
+def test_directed_hub(direction):
+    # a hub with 150 one-way edges: its row is long in ONE direction's lists only (by source for "out", by target for "in"), the other
+    # direction's rows are short -- the two launches of the plan walk different lists over the same tile partition (the union of both
+    # directions' neighbourhoods budgets it)
+    N, d, deg = 1200, 64, 150
+    ring_s = np.arange(N); ring_t = (ring_s + 1) % N
+    leaves = 3 + 7 * np.arange(deg)
+    hs, ht = (np.zeros(deg, np.int64), leaves) if direction == "out" else (leaves, np.zeros(deg, np.int64))
+    s, t = np.concatenate([ring_s, ring_t, hs]), np.concatenate([ring_t, ring_s, ht])
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    params, u0, R = case(N, s, t, d, seed=7)
+    uT, du0, grads, flags = solve(g, d, "tanh", "tsit5", 3, 0.05, params, u0, R)
+    if hub_plan_expected():
+        assert {"hub_geometry", "persistent_fwd", "persistent_bwd"} <= flags, flags
+    uTo, du0o, acc = oracle(params, O.Graph(s, t, num_nodes=N, index_base=0), u0, R, "tsit5", 0.05, 3, "tanh")
+    close(uT, uTo, 2e-4, what="u(T)")
+    close(du0, du0o, 5e-4, 1e-4, "du0")
+    for k in range(2):
+        close(grads[2 * k], acc[k]["weight"], 5e-4, 1e-3, f"dW{k + 1}")
+        close(grads[2 * k + 1], acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
+
+
 def test_hub_geometry_forward_only_and_abort(monkeypatch):
     # a forward-only plan (no tape), then the bounded waits: a launch that starts with its abort word set poisons u(T) and latches the
     # plan's fault word; the next entry refuses
