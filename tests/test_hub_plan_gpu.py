@@ -194,3 +194,17 @@ def test_hub_geometry_forward_only_and_abort(monkeypatch):
     assert plan.fault() and torch.isnan(uT).all()
     with pytest.raises(_lib.NgpdeError, match="gave up waiting"):
         _lib.check(lib.ngpde_node_gcn2_forward(plan.ptr, p(u), p(w1), p(b1), p(w2), p(b2), p(uT), st))
+
+
+def test_random_graphs_with_hubs_against_the_replayed_plan():
+    # tools/fuzz_hub_node.py, a short fixed run: preferential-attachment graphs of 200 - 8 000 nodes (hubs of degree 30 - 250, sometimes with
+    # extra one-way edges at the largest hub), d = 16 / 32 / 64, smooth activations, Euler / Tsit5 -- the hub geometry (or, where a tile
+    # exceeds its caps, the fallback) against the replayed plan of the same build: u(T) to 2e-5, gradients to 1e-4 / 2e-4, no fault
+    if not hub_plan_expected():
+        pytest.skip("a switch of this run selects another plan")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_hub_node", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "fuzz_hub_node.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.main(10, 5) == 0
