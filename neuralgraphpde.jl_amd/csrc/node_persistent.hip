@@ -2551,7 +2551,8 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
     std::vector<int32_t> order = hub_partition(g->n_nodes, rp, cl, true);
     if ((int64_t)order.size() != g->n_nodes) order = hub_partition(g->n_nodes, rp, cl, false);
     NGPDE_REQUIRE((int64_t)order.size() == g->n_nodes, NGPDE_ERR_UNSUPPORTED,
-                  "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each", kHubHalo);
+                  "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each (a node of more than %d distinct in+out neighbours, or tiles that do not close)",
+                  kHubHalo, kHubHalo - kTileRows);
     HubHost hh[2];
     NGPDE_REQUIRE(build_hub_lists(g, rp[0], cl[0], order, hh[0]) && build_hub_lists(g, rp[1], cl[1], order, hh[1]), NGPDE_ERR_UNSUPPORTED,
                   "persistent solver, hub geometry: a tile references more than %d distinct rows or holds more than %d entries", kHubHalo, kHubList);

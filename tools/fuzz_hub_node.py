@@ -2,7 +2,8 @@
 preferential-attachment graphs of 200 - 8 000 nodes and 1.2 - 3 pairs per node (hubs of degree 30 - 250), sometimes with extra one-way
 edges into or out of the largest hub, d = 16 / 32 / 64, smooth activations (relu kinks at hubs spread: tests/test_hub_plan_gpu.py), Euler
 or Tsit5.  u(T), du0 and the parameter gradients must agree to 2e-5 / 1e-4 relative (another summation order in hub rows: not bitwise),
-no fault; a graph whose tiles do not fit the geometry's caps must fall back to the replayed plan and still agree.
+no fault; a graph whose tiles do not fit the geometry's caps (in practice: a hub of more than 224 distinct in+out neighbours, which the
+extra one-way edges produce in about one case of seven) must fall back to the replayed plan, bitwise, and the line prints the setup's reason.
 usage: python3 tools/fuzz_hub_node.py [cases=30] [seed=1]"""
 import os
 import sys
@@ -13,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ngpde_amd as ng  # noqa: E402
-from ngpde_amd import synth as S  # noqa: E402
+from ngpde_amd import _lib, synth as S  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -61,6 +62,7 @@ def main(cases, seed):
         g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
         os.environ.pop("NGPDE_NO_PERSISTENT", None)
         a = solve(g, d, act, tab, nsteps, 0.1, params, u0, R)
+        why = "" if "hub_geometry" in a[3] else " (" + _lib.load().ngpde_last_error().decode()[:120] + ")"
         os.environ["NGPDE_NO_PERSISTENT"] = "1"
         b = solve(g, d, act, tab, nsteps, 0.1, params, u0, R)
         os.environ.pop("NGPDE_NO_PERSISTENT", None)
@@ -69,7 +71,7 @@ def main(cases, seed):
         errs = [rel(a[0], b[0]), rel(a[1], b[1])] + [rel(x, y) for x, y in zip(a[2], b[2])]
         ok = (not a[4]) and errs[0] <= 2e-5 and errs[1] <= 1e-4 and max(errs[2:]) <= 2e-4 and "persistent_fwd" not in b[3]
         print(f"case {case}: N={N} E={s.size} max degree {int(np.bincount(t, minlength=N).max())} d={d} {act} {tab}: "
-              f"{'hub geometry' if is_hub else 'plan ' + str(sorted(a[3]))}; u(T) {errs[0]:.1e} du0 {errs[1]:.1e} grads {max(errs[2:]):.1e}"
+              f"{'hub geometry' if is_hub else 'plan ' + str(sorted(a[3])) + why}; u(T) {errs[0]:.1e} du0 {errs[1]:.1e} grads {max(errs[2:]):.1e}"
               f"{'' if ok else '   <-- FAIL'}", flush=True)
         if not ok:
             bad.append(case)
