@@ -880,7 +880,7 @@ unsigned long long *g_pair_stamps = nullptr;   // diagnostic build only (tools/s
 #define PAIR_STAMP(k)
 #endif
 __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64_t n, int n_tiles, const float *__restrict__ x,
-                                                                           const StreamOut a, const StreamOut b
+                                                                           const StreamOut a, const StreamOut b, int dephase
 #ifdef NGPDE_STAMPS
                                                                            , unsigned long long *stamps
 #endif
@@ -912,6 +912,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
     const NarrowRef nqb = narrow_ref(b, 64, nf & 3);
     if (nf >= 4) nq = nqb;
   }
+  dephase_second_half(dephase);
   const int G = (int)gridDim.x;
   int t = blockIdx.x, it = 0;
   if (t < n_tiles) dma_tile<TR>(x, (int64_t)t * TR, n, dyn, wave, lane);
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_pair_fwd_kernel(int64
 template <int NIN>
 __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int64_t n, int n_tiles, const float *__restrict__ x0,
                                                                             const float *__restrict__ x1, const StreamOut l1,
-                                                                            const StreamOut l2) {
+                                                                            const StreamOut l2, int dephase) {
   constexpr int TR = 64;
   constexpr int kBuf = TR * OS2 + (NIN == 2 ? TR * 64 : 0);   // [TR][OS2]: X0 image, then z1 / a1, then y; [TR][64]: X1 image
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -983,6 +984,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
   // narrow features of a tile's rows: thread -> (row tid / 8, feature tid % 8 < 4), resolved once
   const int nr = tid >> 3, nf = tid & 7;
   const NarrowRef nq = nf < kNarrow ? narrow_ref(l1, 64 * NIN, nf) : NarrowRef{nullptr, 0, 1};
+  dephase_second_half(dephase);
   const int G = (int)gridDim.x;
   int t = blockIdx.x, it = 0;
   if (t < n_tiles) dma_in(t, dyn);
@@ -1480,6 +1482,11 @@ static bool stream2_enabled(int64_t n) {
   return !(e && e[0] == '1') && (n + BM2 - 1) / BM2 >= 512;
 }
 
+static int dephase_cycles() {
+  static const int v = [] { const char *e = std::getenv("NGPDE_DENSE_DEPHASE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
 bool dense_pair_fwd_applicable(int64_t n, const SegTable &ta, int dina, int douta, const SegTable &tb, int dinb, int doutb) {
   return stream2_enabled(n) && douta <= 64 && doutb <= 64 && stream_main_blocks(ta, dina) == 1 && stream_main_blocks(tb, dinb) == 1 &&
          ta.ptr[0] == tb.ptr[0];
@@ -1496,9 +1503,9 @@ int32_t launch_dense_pair_fwd(int64_t n, const SegTable &ta, int dina, int douta
   if (!cap) cap = stream_grid(reinterpret_cast<const void *>(dense_pair_fwd_kernel), lds, 1 << 30);
   const int grid = std::min(n_tiles, cap);
 #ifdef NGPDE_STAMPS
-  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b, g_pair_stamps);
+  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b, dephase_cycles(), g_pair_stamps);
 #else
-  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b);
+  hipLaunchKernelGGL(dense_pair_fwd_kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, ta.ptr[0], a, b, dephase_cycles());
 #endif
   NGPDE_LAUNCH_CHECK("dense_pair_fwd_kernel");
   return NGPDE_OK;
@@ -1524,7 +1531,7 @@ int32_t launch_dense_chain_fwd(int64_t n, const SegTable &t1, int din1, int act1
     if (!cap[nm]) cap[nm] = stream_grid(reinterpret_cast<const void *>(kernel), lds, 1 << 30);
     const int grid = std::min(n_tiles, cap[nm]);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, n, n_tiles, t1.ptr[0], nm == 2 ? t1.ptr[1] : nullptr,
-                       l1, l2);
+                       l1, l2, dephase_cycles());
     return hipSuccess;
   };
   const hipError_t le = nm == 2 ? launch(dense_chain_fwd_kernel<2>) : launch(dense_chain_fwd_kernel<1>);

@@ -202,6 +202,16 @@ __device__ __forceinline__ void wait_vmcnt0() {
   asm volatile("" ::: "memory");
 }
 
+// The streaming Dense launches run two workgroups per CU whose tiles alternate a matrix-pipe phase and a memory phase.  Started
+// together the two fall into step (both on the pipe at half rate, then both on the memory system) and a launch costs the SUM of its
+// MFMA time and its memory time; the second workgroup of every CU therefore starts `cycles` late.
+__device__ __forceinline__ void dephase_second_half(int cycles) {
+  if (cycles > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 // ---- fp32 MFMA -------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[l&15][l>>4], B[l>>4][l&15];
 // result register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (bitwise an fmaf chain), 256 FLOP/clk/CU.
