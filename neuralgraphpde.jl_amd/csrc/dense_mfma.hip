@@ -814,14 +814,15 @@ __device__ __forceinline__ void narrow_weights(const StreamOut &o, int kmain, fl
 struct NarrowRef {
   const float *ptr;   // column of the feature in its block (NULL: no such feature)
   int width, row_div;
+  uint32_t magic;     // div_magic(row_div)
 };
 __device__ __forceinline__ NarrowRef narrow_ref(const StreamOut &o, int kmain, int f) {
-  if (kmain + f >= o.din_all) return NarrowRef{nullptr, 0, 1};
+  if (kmain + f >= o.din_all) return NarrowRef{nullptr, 0, 1, 0xFFFFFFFFu};
   const SegRef r = seg_find(o.segs, kmain + f);
-  return NarrowRef{r.ptr + (kmain + f - r.offset), r.width, r.row_div};
+  return NarrowRef{r.ptr + (kmain + f - r.offset), r.width, r.row_div, div_magic((uint32_t)r.row_div)};
 }
 __device__ __forceinline__ float narrow_fetch(const NarrowRef &q, int64_t r, int64_t n) {
-  return (q.ptr && r < n) ? q.ptr[seg_row(r, q.row_div) * q.width] : 0.f;
+  return (q.ptr && r < n) ? q.ptr[(int64_t)fast_div((uint32_t)r, (uint32_t)q.row_div, q.magic) * q.width] : 0.f;
 }
 
 // epilogue of one Dense on a staged TR x 64 tile: thread (row = tid / 16 + 32 p, columns 4 (tid % 16) .. + 3) adds bias and the
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(kStreamThreads, 4) void dense_chain_fwd_kernel(int6
   };
   // narrow features of a tile's rows: thread -> (row tid / 8, feature tid % 8 < 4), resolved once
   const int nr = tid >> 3, nf = tid & 7;
-  const NarrowRef nq = nf < kNarrow ? narrow_ref(l1, 64 * NIN, nf) : NarrowRef{nullptr, 0, 1};
+  const NarrowRef nq = nf < kNarrow ? narrow_ref(l1, 64 * NIN, nf) : NarrowRef{nullptr, 0, 1, 0xFFFFFFFFu};
   dephase_second_half(dephase);
   const int G = (int)gridDim.x;
   int t = blockIdx.x, it = 0;

@@ -7,13 +7,17 @@
 // BASELINE config 4's shard (524 288 rows) against 0.10 ms for the 402 MB this launch moves.
 //
 // Persistent workgroups of 4 waves walk 64-row tiles.  Per tile: dy (and z) come through registers -- dz is formed there, feeds
-// the rank-1 accumulations of the narrow features and the bias, and is written to LDS --, the 64 x 64 tile of X_b goes memory ->
-// LDS by LDS-DMA (dense_stream64_fwd_kernel's scheme); then every wave runs 64 MFMAs of X_b^T dz (its 16 input features x all
-// 64 outputs, contraction over the tile's rows, accumulators live in registers for the whole launch) and 64 MFMAs of dz W_b^T
-// (its 16 rows), whose result leaves through the X tile's LDS image as full 256-byte rows.  Both tiles use one XOR swizzle
-// of the 16-byte chunk index, slot = chunk ^ R(row), R = the row's low two bit pairs swapped, which makes BOTH access
+// the rank-1 accumulations of the narrow features and the bias, and is written to LDS --, the 64 x 64 tiles of X_b go memory ->
+// LDS by LDS-DMA a tile ahead (NMAIN + 1 rotating buffers); then every wave runs 64 MFMAs per block of X_b^T dz (its 16 input
+// features x all 64 outputs, contraction over the tile's rows, accumulators live in registers for the whole launch, all blocks from
+// one read of dz) and 64 MFMAs per block of dz W_b^T (all 64 rows x ITS 16 input features, whose rows of W_b it keeps in registers for
+// the launch: no weight copy in LDS), whose result leaves through an image buffer as full 256-byte rows.  All tiles use one XOR
+// swizzle of the 16-byte chunk index, slot = chunk ^ R(row), R = the row's low two bit pairs swapped, which makes BOTH access
 // patterns bank-conflict free: 16-byte row reads (16 rows x one chunk) and the 4-byte transposed reads of the weight product
-// (rows 4s .. 4s + 3 x 16 consecutive columns).  The next tile's dy / z / narrow features are in flight during the MFMAs.
+// (rows 4s .. 4s + 3 x 16 consecutive columns).  These launches are bound by instruction ISSUE on the SIMD (a wave's MFMAs, VALU
+// and waits are one in-order stream and two waves share a SIMD), not by memory: every LDS address of the product loops is a
+// register set up once per launch plus an immediate, and the reads of a product group are issued in the middle of the group before
+// (PairBwdAddr, stream_bwd_dw / stream_bwd_dx / pair_bwd_products; DESIGN 5.4, tools/stamps_pair_bwd.py).
 // Per-workgroup dW / db slabs are summed by dense_weight_reduce_kernel in a fixed order: no atomics, reproducible.
 #include <algorithm>
 #include <cstdlib>
@@ -72,7 +76,7 @@ __device__ __forceinline__ void dma_x_tile(const float *x, uint32_t row0, uint32
 //     1024 m + [256 j + 64 kq + 4 ((i / 4) ^ j) + i % 4] + 16 (c ^ kq)
 // and that of the 16-byte chunk 4 kh + kq of row 16 rt + i is  1024 rt + [64 i + 16 (kh ^ (i % 4)) + 4 (kq ^ (i / 4))]:  a register per
 // (j, c) resp. kh and an immediate per m resp. rt.  Written as sw_addr(4 s + kq, ..) in the loop the compiler either keeps ~ 100 addresses
-// in registers across the tile loop or (behind an opaque zero, as dense_stream64_bwd_kernel does it) recomputes them per slice: ~ 80 VALU
+// in registers across the tile loop or (behind an opaque zero, as both kernels did until round 5) recomputes them per slice: ~ 80 VALU
 // instructions per 10 MFMAs, and VALU issue does not overlap a wave's own MFMAs -- the products phase of a tile took 20 k cycles for
 // 9.2 k cycles of MFMA (tools/stamps_pair_bwd.py).
 struct PairBwdAddr {
@@ -211,6 +215,9 @@ __global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseB
 
   float4 dyr[4], zr[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
   float nxr[4][kMaxNarrow];
+  uint32_t nmagic[kMaxNarrow];   // (uniform: one division per feature and launch)
+#pragma unroll
+  for (int f = 0; f < kMaxNarrow; ++f) nmagic[f] = div_magic((uint32_t)p.ndiv[f]);
   auto fetch = [&](int tile) {   // dy, z and the narrow features of the thread's four rows (32-bit offsets from uniform bases)
     const uint32_t row0 = (uint32_t)tile * kTR;
 #pragma unroll
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(kBT, 2) void dense_stream64_bwd_kernel(const DenseB
       if (r >= (uint32_t)p.n) dyr[pp] = f4_zero();   // rows past the end contribute nothing
       if (p.z) zr[pp] = *reinterpret_cast<const float4 *>(p.z + e);
 #pragma unroll
-      for (int f = 0; f < kMaxNarrow; ++f) nxr[pp][f] = p.nx[f][(rc / (uint32_t)p.ndiv[f]) * (uint32_t)p.nwidth[f]];   // (unused slots alias X)
+      for (int f = 0; f < kMaxNarrow; ++f) nxr[pp][f] = p.nx[f][fast_div(rc, (uint32_t)p.ndiv[f], nmagic[f]) * (uint32_t)p.nwidth[f]];   // (unused slots alias X)
     }
   };
 
@@ -468,7 +475,8 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
   uint32_t nw1 = nsd ? (nf ? p.nwidth[1][3] : p.nwidth[1][1]) : (nf ? p.nwidth[0][3] : p.nwidth[0][1]);
   uint32_t nd0 = nsd ? (nf ? p.ndiv[1][2] : p.ndiv[1][0]) : (nf ? p.ndiv[0][2] : p.ndiv[0][0]);
   uint32_t nd1 = nsd ? (nf ? p.ndiv[1][3] : p.ndiv[1][1]) : (nf ? p.ndiv[0][3] : p.ndiv[0][1]);
-  asm volatile("" : "+v"(nb0u), "+v"(nb1u), "+v"(nw0), "+v"(nw1), "+v"(nd0), "+v"(nd1));   // (held in registers from here on)
+  uint32_t nm0 = div_magic(nd0), nm1 = div_magic(nd1);
+  asm volatile("" : "+v"(nb0u), "+v"(nb1u), "+v"(nw0), "+v"(nw1), "+v"(nd0), "+v"(nd1), "+v"(nm0), "+v"(nm1));   // (held in registers from here on)
   typedef const __attribute__((address_space(1))) float *gptr_t;   // (a pointer that went through the pin is "generic": say global again)
   const gptr_t nb0 = (gptr_t)nb0u, nb1 = (gptr_t)nb1u;
   auto fetch = [&](int tile) {
@@ -484,8 +492,8 @@ __global__ __launch_bounds__(kBT, 2) void dense_pair64_bwd_kernel(const DensePai
       }
     }
     const uint32_t rc = min(row0 + nrow, (uint32_t)(p.n - 1));
-    nv0 = nb0[(rc / nd0) * nw0];   // (unused slots alias X: their dW rows are never written)
-    nv1 = nb1[(rc / nd1) * nw1];
+    nv0 = nb0[fast_div(rc, nd0, nm0) * nw0];   // (unused slots alias X: their dW rows are never written)
+    nv1 = nb1[fast_div(rc, nd1, nm1) * nw1];
   };
 
   // Per tile: the tile's dy rows and narrow values (registers, loaded a tile ago) -> LDS; then, with the next tile's loads

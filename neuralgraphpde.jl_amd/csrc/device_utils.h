@@ -202,6 +202,17 @@ __device__ __forceinline__ void wait_vmcnt0() {
   asm volatile("" ::: "memory");
 }
 
+// row / d for a divisor that is fixed for the launch: m = div_magic(d) once, then a high multiply and one correction instead of the ~ 30
+// VALU instructions of a 32-bit division.  With m = floor(2^32 / d) (2^32 - 1 for d = 1) the estimate mulhi(r, m) is the quotient or one
+// below it for every r < 2^32.  (The narrow features of the streaming Dense launches -- coordinates per node, theta per trajectory --
+// are fetched per row and tile: 16 divisions per thread and tile in dense_stream64_bwd_kernel.)
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / d); }
+__device__ __forceinline__ uint32_t fast_div(uint32_t r, uint32_t d, uint32_t m) {
+  uint32_t q = __umulhi(r, m);
+  if (r - q * d >= d) ++q;
+  return q;
+}
+
 // The streaming Dense launches run two workgroups per CU whose tiles alternate a matrix-pipe phase and a memory phase.  Started
 // together the two fall into step (both on the pipe at half rate, then both on the memory system) and a launch costs the SUM of its
 // MFMA time and its memory time; the second workgroup of every CU therefore starts `cycles` late.
