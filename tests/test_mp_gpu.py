@@ -235,14 +235,26 @@ def test_dense_few_rows_wide_output_pullbacks(n, din, dout, bias, monkeypatch):
 @pytest.mark.parametrize("widths,grads,act", [((64,), (True,), "identity"), ((64, 2), (True, False), "swish"),
                                               ((64, 1, 1, 2), (True, False, False, False), "swish"),
                                               ((64, 64, 2), (True, True, False), "swish"), ((2, 64, 64), (False, False, True), "relu"),
-                                              ((64,), (False,), "tanh")])
+                                              ((64,), (False,), "tanh"), ((64, 64), (True, False), "tanh")])
 def test_dense_streaming_pullback(widths, grads, act, monkeypatch):
+    _dense_streaming_pullback_case(widths, grads, act, 70001, monkeypatch)
+
+
+@pytest.mark.parametrize("widths,grads,n", [((64, 2), (True, False), 32768), ((64, 64, 2), (True, True, False), 32768),
+                                            ((64, 64), (False, True), 32768 + 64 * 511 + 1)])
+def test_dense_streaming_pullback_tile_counts(widths, grads, n, monkeypatch):
+    # one tile per workgroup (no next tile to prefetch: 32 768 rows is the launch's lower limit), and a workgroup count that leaves
+    # all but one workgroup with a single tile and the last tile ragged
+    _dense_streaming_pullback_case(widths, grads, "swish", n, monkeypatch)
+
+
+def _dense_streaming_pullback_case(widths, grads, act, n, monkeypatch):
     # dense_stream_bwd.hip: dz, input pullbacks, weight pullback and bias gradient of a 64-output Dense in one launch (one or two
     # 64-wide blocks + narrow blocks without gradient, the last block per graph as MPPDEConv's theta, src/layers.jl:397, :418);
     # ragged last tile; against the oracle and against the composed path (NGPDE_DENSE_NO_STREAM_BWD=1)
     import composed as F          # the primitives' autograd wrappers (tests/composed.py)
     monkeypatch.delenv("NGPDE_DENSE_NO_STREAM_BWD", raising=False)
-    n, per_graph, dout = 70001, 10000, 64
+    per_graph, dout = 10000, 64
     rng = np.random.default_rng(33)
     res = []
     for mode in (0, 1):
