@@ -63,6 +63,13 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 v, float4 c) {
 }
 __device__ __forceinline__ float4 f4_scale(float a, float4 v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// the same sum as two packed adds (v_pk_add_f32), for files built with -fno-slp-vectorize where a loop is all additions and no MFMA
+// runs beside it (the hub geometry's row sums)
+__device__ __forceinline__ float4 f4_add_pk(float4 a, float4 b) {
+  typedef float v2f_ __attribute__((ext_vector_type(2)));
+  const v2f_ lo = (v2f_){a.x, a.y} + (v2f_){b.x, b.y}, hi = (v2f_){a.z, a.w} + (v2f_){b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 // vector forms: ONE uniform switch per call (a switch per element costs a scalar branch chain per element, which -- not the
 // transcendentals -- dominated the VALU-side time of the fused edge kernels)

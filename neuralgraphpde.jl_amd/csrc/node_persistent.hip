@@ -263,6 +263,8 @@ __device__ __forceinline__ void tile_gather_foreign(const TileCtx &c, const floa
 }
 
 // sum of the row's neighbours (slot bytes, in CSR order) + its own row (self loop), all from LDS
+// (plain adds on purpose: this file is built without SLP packing, and written as v_pk_add_f32 -- f4_add_pk -- these sums cost the
+// headline 2 %: they run beside the CU's other workgroup's MFMAs, where packed f32 VALU is slow; profiles/r05_x_ab_slp.txt)
 // the row's 32 slot bytes, fetched from LDS BEFORE the wait (one address per 16-lane group: broadcast reads): they are live
 // only across the wait and the gather, where registers are plentiful, and the aggregation does not start with a dependent read
 __device__ __forceinline__ void tile_slot_words(const TileCtx &c, unsigned (&w)[8]) {
@@ -454,28 +456,28 @@ __device__ __forceinline__ float4 hub_aggregate(const HubCtx &c, const unsigned 
       float4 v[4];
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) v[jb] = f4_sel(4 * jw + jb < c.len, Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q], f4_zero());
-      a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+      a = f4_add_pk(a, f4_add_pk(f4_add_pk(v[0], v[1]), f4_add_pk(v[2], v[3])));
     }
   }
   for (int li = 0; li < c.n_long; ++li) {   // uniform
     const int r = c.hlong[li];
     const int2 rl = c.hrows[r];
     float4 p = f4_zero();
-    for (int j = c.grp; j < rl.y; j += kTM) p = f4_add(p, Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q]);
+    for (int j = c.grp; j < rl.y; j += kTM) p = f4_add_pk(p, Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q]);
     reinterpret_cast<float4 *>(part)[c.grp * PG::LPR + c.q] = p;
     __syncthreads();
     if (c.wave_u == (r >> 2)) {   // the wave of the row's group: each of its four groups adds eight partial rows, two exchanges fold them
       const int g4 = c.grp & 3;
       float4 t = reinterpret_cast<const float4 *>(part)[g4 * PG::LPR + c.q];
 #pragma unroll
-      for (int k = 1; k < kTM / 4; ++k) t = f4_add(t, reinterpret_cast<const float4 *>(part)[(g4 + 4 * k) * PG::LPR + c.q]);
+      for (int k = 1; k < kTM / 4; ++k) t = f4_add_pk(t, reinterpret_cast<const float4 *>(part)[(g4 + 4 * k) * PG::LPR + c.q]);
       t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16); t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
       t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32); t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
-      if (c.grp == r) a = f4_add(a, t);
+      if (c.grp == r) a = f4_add_pk(a, t);
     }
     __syncthreads();   // (the buffer is written again: by the next long row, or by the caller -- the adjoint's dz tile)
   }
-  return f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
+  return f4_add_pk(a, Xh4[c.grp * PG::LPR + c.q]);
 }
 
 // W (row-major [in][out]) -> LDS, transposed (forward: B[k = in][j = out], stored Bt[j][k]) or straight (pullback: Bt[j = in][k = out])
