@@ -447,6 +447,15 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
                                         beyond the 96-row halo / 32-entry rows (a Cora-shaped graph, docs/src/tutorials/graph_node.md:14-23):
                                         256-row halos, variable-length rows, hub rows summed by all lane groups of the workgroup */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
+/* Host only, no device call: would a graph with hubs run on the persistent solver's hub geometry (NGPDE_NODE_HUB_GEOMETRY)?  The
+ * graph is given as its two 0-based CSR lists (by target: the in-neighbours of every node; by source: the out-neighbours).  On
+ * NGPDE_OK order[32 t + k] is the node the solver would put in row k of tile t (n_nodes entries) and, if tile_rows is not NULL,
+ * tile_rows[2 t + dir] the distinct rows tile t references through list dir (its own rows included; at most 256).
+ * NGPDE_ERR_UNSUPPORTED (text in ngpde_last_error) when the graph has more than 256 tiles, a node of more than ~224 distinct in+out
+ * neighbours, or a tile of more than 4 096 list entries: the solver then replays its per-stage launches.  [no reference counterpart:
+ * the reference evaluates Cora (docs/src/tutorials/graph_node.md:14-23) with the generic gather / scatter] */
+int32_t ngpde_hub_partition_host(int64_t n_nodes, const int32_t *rowptr_by_target, const int32_t *col_by_target,
+                                 const int32_t *rowptr_by_source, const int32_t *col_by_source, int32_t *order, int32_t *tile_rows);
 int32_t ngpde_node_fault(ngpde_node_t *plan, ngpde_stream_t stream, int32_t *fault);
 /* Diagnostic of the interleaved batch solve (ngpde_node_gcn2_create_batch, two members per workgroup): of the `slot_phases`
  * (tile, member, phase) units of the last forward / adjoint launch, how many found their halo rows gathered ahead of time, i.e.

@@ -2490,10 +2490,8 @@ static bool host_csr(const ngpde_graph *g, const Csr &c, std::vector<int32_t> &r
   if (m > 0 && hipMemcpy(col.data(), c.col, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
   return true;
 }
-static bool build_hub_lists(const ngpde_graph *g, const std::vector<int32_t> &rowptr, const std::vector<int32_t> &col,
+static bool build_hub_lists(int64_t n, int nt, const std::vector<int32_t> &rowptr, const std::vector<int32_t> &col,
                             const std::vector<int32_t> &order, HubHost &o) {
-  const int64_t n = g->n_nodes;
-  const int nt = g->n_sched / kTileRows;
   o.halo.assign((size_t)nt * kHubHalo, 0);
   o.slots.assign((size_t)nt * kHubList, 0);
   o.longs.assign((size_t)nt * kTileRows, 0);
@@ -2534,6 +2532,47 @@ static bool build_hub_lists(const ngpde_graph *g, const std::vector<int32_t> &ro
   return true;
 }
 
+// Host only (no device call): the hub geometry's tile partition of a graph given as its two CSR lists -- what node_persistent_setup
+// would use -- so that a caller (and the CPU tests, tests/test_hub_partition.py) can ask whether a graph with hubs fits the persistent
+// solver.  order[32 t + k] = the node in row k of tile t; tile_rows[2 t + dir] = the distinct rows tile t references in direction
+// dir (0: lists by target, 1: by source; members included).
+}  // namespace ngpde
+extern "C" int32_t ngpde_hub_partition_host(int64_t n_nodes, const int32_t *rowptr_by_target, const int32_t *col_by_target,
+                                            const int32_t *rowptr_by_source, const int32_t *col_by_source, int32_t *order,
+                                            int32_t *tile_rows) {
+  using namespace ngpde;
+  NGPDE_REQUIRE(n_nodes > 0 && rowptr_by_target && rowptr_by_source && order, NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_hub_partition_host: n_nodes > 0, both row pointer arrays and `order` are required");
+  const int nt = (int)((n_nodes + kTileRows - 1) / kTileRows);
+  NGPDE_REQUIRE(nt <= kHubNbr, NGPDE_ERR_UNSUPPORTED, "persistent solver, hub geometry: at most %d tiles, one per workgroup", kHubNbr);
+  std::vector<int32_t> rp[2], cl[2];
+  const int32_t *rps[2] = {rowptr_by_target, rowptr_by_source}, *cls[2] = {col_by_target, col_by_source};
+  for (int dir = 0; dir < 2; ++dir) {
+    rp[dir].assign(rps[dir], rps[dir] + n_nodes + 1);
+    const int64_t m = rp[dir][(size_t)n_nodes];
+    NGPDE_REQUIRE(rp[dir][0] == 0 && m >= 0 && (m == 0 || cls[dir]), NGPDE_ERR_INVALID_ARGUMENT, "ngpde_hub_partition_host: CSR list %d is malformed", dir);
+    for (int64_t v = 0; v < n_nodes; ++v)
+      NGPDE_REQUIRE(rp[dir][v] <= rp[dir][v + 1], NGPDE_ERR_INVALID_ARGUMENT, "ngpde_hub_partition_host: row pointers of list %d decrease at row %lld", dir, (long long)v);
+    cl[dir].assign(cls[dir], cls[dir] + m);
+    for (int64_t e = 0; e < m; ++e)
+      NGPDE_REQUIRE(cl[dir][e] >= 0 && cl[dir][e] < n_nodes, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_hub_partition_host: list %d names node %d of %lld", dir, cl[dir][e], (long long)n_nodes);
+  }
+  std::vector<int32_t> ord = hub_partition(n_nodes, rp, cl, true);
+  if ((int64_t)ord.size() != n_nodes) ord = hub_partition(n_nodes, rp, cl, false);
+  NGPDE_REQUIRE((int64_t)ord.size() == n_nodes, NGPDE_ERR_UNSUPPORTED,
+                "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each (a node of more than %d distinct in+out neighbours, or tiles that do not close)",
+                kHubHalo, kHubHalo - kTileRows);
+  HubHost hh[2];
+  NGPDE_REQUIRE(build_hub_lists(n_nodes, nt, rp[0], cl[0], ord, hh[0]) && build_hub_lists(n_nodes, nt, rp[1], cl[1], ord, hh[1]), NGPDE_ERR_UNSUPPORTED,
+                "persistent solver, hub geometry: a tile references more than %d distinct rows or holds more than %d entries", kHubHalo, kHubList);
+  std::copy(ord.begin(), ord.end(), order);
+  if (tile_rows)
+    for (int t = 0; t < nt; ++t)
+      for (int dir = 0; dir < 2; ++dir) tile_rows[2 * t + dir] = hh[dir].info[(size_t)t].x;
+  return NGPDE_OK;
+}
+namespace ngpde {
+
 // NGPDE_NO_INTERLEAVE=1: a batch's members one after the other (the round-2 form) instead of two at a time -- the A/B switch and
 // the reference the interleaved kernels are compared with bit for bit
 bool node_persistent_interleave_env() {
@@ -2556,7 +2595,7 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
                   "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each (a node of more than %d distinct in+out neighbours, or tiles that do not close)",
                   kHubHalo, kHubHalo - kTileRows);
     HubHost hh[2];
-    NGPDE_REQUIRE(build_hub_lists(g, rp[0], cl[0], order, hh[0]) && build_hub_lists(g, rp[1], cl[1], order, hh[1]), NGPDE_ERR_UNSUPPORTED,
+    NGPDE_REQUIRE(build_hub_lists(g->n_nodes, nt, rp[0], cl[0], order, hh[0]) && build_hub_lists(g->n_nodes, nt, rp[1], cl[1], order, hh[1]), NGPDE_ERR_UNSUPPORTED,
                   "persistent solver, hub geometry: a tile references more than %d distinct rows or holds more than %d entries", kHubHalo, kHubList);
     // the partition's schedule: {node, 0, 0, bits of c[node]} per position, -1 padded
     std::vector<float> cnode((size_t)g->n_nodes);
