@@ -325,6 +325,70 @@ __device__ __forceinline__ float4 tile_aggregate_rounds(const TileCtx &c, const 
   else return tile_aggregate_lean(c, ldsXh);
 }
 
+
+// ---- own-first aggregation (round 6 experiment, NGPDE_OWN_FIRST=1; one-tile forward kernel only) -------------------
+// A tile's own 32 rows are in LDS when a phase starts; what it waits for are the ~25 rows of other tiles.  The row's slot bytes are
+// re-ordered ONCE per launch (the tile is the workgroup's for the whole solve): slots of own rows first, padded with the all-zero row
+// to the wave's number of own rounds, then the slots of foreign rows; the own rounds are summed under the wait for the flags.
+// Measured (tools/exp_own_first.py, profiles/r06_a_own_first.txt): forward launch 2.301 -> 2.234 ms (-2.9 %); with the foreign rows
+// loaded straight into registers by every 16-lane group instead of staged in LDS once per tile (2.4 x the row requests): 3.16 ms.
+// Another summation order than the replayed plan's, so NOT bitwise equal to it: a diagnostic switch, off by default.
+// Returns the wave's number of own rounds (wave-uniform); c.wmax becomes 4 x the wave's total number of rounds.
+__device__ __forceinline__ int own_first_reorder(TileCtx &c) {
+  unsigned *ls = const_cast<unsigned *>(c.lds_slots);
+  unsigned w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = ls[c.grp * 8 + j];
+  int no = 0, nf = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    no += b < (unsigned)kTM ? 1 : 0;
+    nf += (b >= (unsigned)kTM && b < (unsigned)kHaloCap) ? 1 : 0;
+  }
+  int pre = (no + 3) >> 2;
+  pre = max(pre, __shfl_xor(pre, 16));
+  pre = max(pre, __shfl_xor(pre, 32));
+  int tot = pre + ((nf + 3) >> 2);
+  tot = max(tot, __shfl_xor(tot, 16));
+  tot = max(tot, __shfl_xor(tot, 32));
+  pre = __builtin_amdgcn_readfirstlane(pre);
+  tot = __builtin_amdgcn_readfirstlane(tot);
+  if (tot > 8) return 0;   // (wave-uniform) does not fit the 32 slot bytes in this form: the row order stays as it is
+  if (c.q == 0) {
+    uint8_t *row = reinterpret_cast<uint8_t *>(ls + c.grp * 8);
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      if (b < (unsigned)kTM) row[k++] = (uint8_t)b;
+    }
+    for (; k < 4 * pre; ++k) row[k] = (uint8_t)kHaloCap;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      if (b >= (unsigned)kTM && b < (unsigned)kHaloCap) row[k++] = (uint8_t)b;
+    }
+    for (; k < 32; ++k) row[k] = (uint8_t)kHaloCap;
+  }
+  c.wmax = 4 * tot;
+  return pre;
+}
+// rounds [r0, r1) of the row's slot words from LDS, same association as tile_aggregate
+__device__ __forceinline__ float4 tile_aggregate_rounds_range(const TileCtx &c, const unsigned (&sw)[8], const float *ldsXh, float4 a, int r0, int r1) {
+  const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
+#pragma unroll
+  for (int jw = 0; jw < 8; ++jw) {
+    if (jw >= r0 && jw < r1) {   // wave-uniform
+      const unsigned w = sw[jw];
+      float4 v[4];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) v[jb] = Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q];
+      a = f4_add(a, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+    }
+  }
+  return a;
+}
 // ---- hub geometry (graphs whose tiles do not fit the 96-row halo / 32-entry rows: BASELINE config 1's Cora-shaped graph) --------
 // One workgroup per CU and tile; per tile and direction (lists built by node_persistent_setup, not part of the graph handle):
 //   * a halo of up to kHubHalo = 256 distinct rows (own rows first), 64 KB of LDS -- the reach of an LDS-DMA destination;
@@ -573,9 +637,10 @@ struct PFwdK {
 // WGT (edge weights, src/layers.jl:206-231): the 4 KB of slot weights of the tile need LDS that two resident W^T do not leave, so layer 1's
 // W^T is B fragments in registers for the whole launch (16 per lane; the forward kernel has them to spare) and only W2^T is in LDS
 // HUB: the hub geometry (256-row halo, variable-length slot lists, long rows shared by the 32 lane groups, one workgroup per CU)
-template <int ACT, bool TAPE, bool WGT = false, bool HUB = false>
+template <int ACT, bool TAPE, bool WGT = false, bool HUB = false, int OF = 0>
 __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_kernel(const PFwdK p) {
   static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
+  static_assert(OF == 0 || (!HUB && !WGT), "own-first aggregation: the plain one-tile geometry");
   constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
   __shared__ __attribute__((aligned(16))) float lds[XH + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + MF + 48 + 4];
   static_assert(!HUB || sizeof(lds) <= 160 * 1024 - 64, "one workgroup per CU");
@@ -608,6 +673,11 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);   // byte offset of this thread's 16 bytes in a [N][64] array
   __syncthreads();
+  int of_pre = 0;
+  if constexpr (OF != 0) {
+    of_pre = own_first_reorder(c);
+    __syncthreads();
+  }
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[c.q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[c.q];
   bool ok = true;
   int ph = 0;   // phases count on across the members: a tile starts the next trajectory while its neighbours finish this one
@@ -619,6 +689,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
   // up in scratch memory
   float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
   Xh4[c.grp * PG::LPR + c.q] = u;   // (nobody reads the halo slots between a publish and the next gather's barrier)
+  if constexpr (OF != 0) __syncthreads();   // (... except the own-first form, whose first phase reads them ahead of any barrier)
   for (int n = 0; n < p.n_steps && ok; ++n) {
     for (int i = 0; i < p.S && ok; ++i) {
 #pragma unroll
@@ -635,6 +706,16 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
           hub_gather_foreign(c, X, ldsXh);
           NGPDE_PST(p.m, ph, 2);
           agg = hub_aggregate(c, sw, ldsXh, ldsZ);   // (the product's output tile is free until this phase's product)
+        } else if constexpr (OF == 1) {
+          unsigned sw[8];
+          tile_slot_words(c, sw);
+          float4 a = tile_aggregate_rounds_range(c, sw, ldsXh, f4_zero(), 0, of_pre);   // own rows: under the wait
+          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          NGPDE_PST(p.m, ph, 1);
+          tile_gather_foreign(c, X, ldsXh);
+          NGPDE_PST(p.m, ph, 2);
+          a = tile_aggregate_rounds_range(c, sw, ldsXh, a, of_pre, 8 < (c.wmax >> 2) ? 8 : (c.wmax >> 2));
+          agg = f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
         } else {
           unsigned sw[8];
           tile_slot_words(c, sw);
@@ -2860,8 +2941,13 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   } else if (a.interleave) {                                                                                                 \
     if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
     else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, k);                         \
+  } else if (own_first == 1) {                                                                                               \
+    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, false, 1>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
+    else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, false, 1>), grid, block, 0, stream, k);               \
   } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
   else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
+  const char *of_env = std::getenv("NGPDE_OWN_FIRST");   // round 6 experiment, diagnostic: 1 = the tile's own rows summed under the wait
+  const int own_first = (of_env && of_env[0] == '1') ? 1 : 0;
   k.ztape = a.ztape;
   if (a.tape && a.act == NGPDE_ACT_RELU) {
     NGPDE_REQUIRE(a.masks != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a relu tape needs the sign-bit masks");
