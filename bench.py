@@ -167,12 +167,18 @@ def torch_cpu_point(s, t, u0, w1, b1, w2, b2, budget_s=4.0):
 
 # ---- secondary workloads: one layer of BASELINE configs 3-5 (never in `value`) ---------------------------------------------
 FP32_MFMA_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense
-TIMING_NOTE = ("ms_forward / ms_forward_backward: the FASTER of (a) the layer call (and its autograd pullback) captured once into a HIP graph "
-               "and replayed and (b) the same call issued from Python every time (*_eager_api; at least 30 timed calls after 5 warm-ups) -- "
-               "short layers are bound by the Python dispatch when issued eagerly, long ones (C4: ~ 20 kernels of 0.1 - 0.9 ms) lose "
-               "~ 5 % to the gaps between the nodes of a replayed graph; *_graph_replay keeps (a)")
+TIMING_NOTE = ("ms_forward / ms_forward_backward (the figures of record, ONE method for every layer leg): the layer call (and its autograd "
+               "pullback) captured once into a HIP graph and replayed, at least 30 timed replays after 5 warm-ups -- the device-side time of "
+               "the library's launches; *_eager_api: the same call issued from Python every time (short layers are bound by the Python "
+               "dispatch there; C4's ~ 20 kernels run ~ 1 % faster than their replayed graph); roofline.kernel_sum_*: the sum of the "
+               "launches' own durations by rocprofv3 --kernel-trace --stats in a child pass (no gaps between kernels), the conservative "
+               "source for roofline.frac where present")
 # algorithmic figures of ONE layer forward
 C3_FWD_BYTES = 9.50e6        # GATConv on the C2 graph: compulsory traffic
+# ... as ODE right-hand side (one evaluation and its pullback): forward 9.50 MB + the saved attention coefficients
+# (E' x 4 heads x 4 B = 2.36 MB) = 11.86 MB; pullback: dY, Y (relu mask), X (W x is rebuilt), dX = 4 x 4.194 MB, the coefficients
+# 2.36 MB, the lists of both directions 1.31 MB, W / a and their gradients 0.03 MB = 20.48 MB
+C3_RHS_BYTES = 11.86e6 + 20.48e6
 C4_FWD_FLOP = 49.0e9         # MPPDEConv shard (64 trajectories), first-layer-split form
 # (C5: c5_fwd_flop(E) -- SURVEY's 10.6 / 16.8 GFLOP are for E ~ 115 k / 492 k; the generator gives 140 860 / 480 784 edges)
 
@@ -215,8 +221,8 @@ def _graph_ms(fn, reps):
 
 def _layer_times(layer, x, ps, st, reps):
     """ms of one forward (no autograd) and of forward + backward (gradients w.r.t. x and every parameter) through the layer
-    API: (eager forward, eager forward+backward, the faster of eager and graph-replayed forward, the same for forward+backward);
-    the graph-replayed pair stays in _layer_times.graph_replay"""
+    API: (eager forward, eager forward+backward, graph-replayed forward, graph-replayed forward+backward); the graph replays are the
+    figures of record (TIMING_NOTE)"""
     x = x.detach().requires_grad_(True)
     leaves = [x] + _grad_leaves(ps)
     reps = max(reps, 30)
@@ -236,8 +242,8 @@ def _layer_times(layer, x, ps, st, reps):
         fb()
     ms_fb = _time_ms(fb, reps)
     ms_fbg = _graph_ms(fb, reps)
-    _layer_times.graph_replay = (ms_fg, ms_fbg)      # (kept beside the figures of record, which are the faster of the two forms)
-    return ms_f, ms_fb, min(ms_fg, ms_f), min(ms_fbg, ms_fb)
+    _layer_times.graph_replay = (ms_fg, ms_fbg)
+    return ms_f, ms_fb, ms_fg, ms_fbg                # (the figures of record are the graph replays: one method for every leg)
 
 
 def _grad_leaves(ps):
@@ -283,7 +289,7 @@ def c5_fwd_flop(n_edges, width=128, k=64, n=4096):
     return 2.0 * n * width * width * k + 2.0 * width * k * n_edges + 2.0 * n * width * width
 
 
-def secondary(dev, world, rank, dist):
+def secondary(dev, world, rank, dist, rocprof=False):
     """One layer forward / forward + backward of BASELINE configs 3, 4 (per-GPU shard) and 5 through the layer API, with the
     roofline that bounds each.  N > 1: the C4 leg only, as a data-parallel training step (64 trajectories per
     rank, replicated parameters, bucketed all-reduce of the flat gradient overlapped with the pullback, fused Adam)."""
@@ -332,6 +338,11 @@ def secondary(dev, world, rank, dist):
                                                 if resident else "NeuralODE(GATConv, capture=True): HIP-graph replay of the generic solver"),
                                        "fault": any(p.fault() for p in gplans) if resident else False,
                                        "rhs_evals_per_ode_step": 6}
+        ach_n = 6 * ODE_STEPS * C3_RHS_BYTES / (ms_node * 1e-3) / 1e9
+        out["C3_gat_node_tsit5x50"]["roofline"] = {"bound": "hbm", "achieved": round(ach_n, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(ach_n / HBM_PEAK_GBS, 4),
+                                                   "algorithmic_MB_per_rhs_evaluation_fwd_bwd": C3_RHS_BYTES / 1e6,
+                                                   "algorithmic_GB_solve_and_adjoint": round(6 * ODE_STEPS * C3_RHS_BYTES / 1e9, 3)}
         if resident:      # 8 trajectories per GPU on this right-hand side: a block-diagonal batch of identical structures, two members per workgroup
             traj = 8
             lb = ng.GATConv((64, 16), "relu", heads=4, initialgraph=ng.batch([g] * traj))
@@ -349,7 +360,10 @@ def secondary(dev, world, rank, dist):
             out["C3_gat_node_tsit5x50"]["batched"] = {"trajectories_per_gpu": traj, "ms_solve_forward_backward": round(msb, 3),
                                                       "value": round(traj * ODE_STEPS / (msb * 1e-3), 1), "unit": "trajectory ODE-steps/s",
                                                       "device_resident": bool(bplans) and all("gat" in p.flags() for p in bplans),
-                                                      "fault": any(p.fault() for p in bplans)}
+                                                      "fault": any(p.fault() for p in bplans),
+                                                      "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                   "achieved": round(traj * 6 * ODE_STEPS * C3_RHS_BYTES / (msb * 1e-3) / 1e9, 1),
+                                                                   "frac": round(traj * 6 * ODE_STEPS * C3_RHS_BYTES / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             del nodeb, stb, xb, lb
         if resident:      # the generic solver (every stage the one-launch layer, captured into HIP graphs) on the same workload
             os.environ["NGPDE_NO_PERSISTENT"] = "1"
@@ -504,6 +518,7 @@ def secondary(dev, world, rank, dist):
                                        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
                                                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
                                                     "algorithmic_GFLOP_forward": C4_FWD_FLOP / 1e9}}
+        _kernel_sum_roofline(out["C4_mppde_shard_layer"], "c4", C4_FWD_FLOP, rocprof)
     else:
         st_opt = ng.optim.setup(ng.optim.Adam(1e-4), flat)
         red = ng.dist.OverlappedGradReduce(flat, psv, [("ψ.",), ("ϕ.",)])     # psi's gradient is final first: its collective
@@ -547,15 +562,17 @@ def secondary(dev, world, rank, dist):
                                                   "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFS,
                                                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFS, 4),
                                                                "algorithmic_GFLOP_forward": round(flop5 / 1e9, 2)}}
+            _kernel_sum_roofline(out[f"C5_gno_128_r{radius}_layer"], f"c5_r{radius}", flop5, rocprof)
     return out
 
 
-def visible_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes"):
+def visible_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes", dri="/dev/dri"):
     """GPUs this process would see, WITHOUT the HIP runtime: the launcher parent must never touch the GPU (a process that has
     initialised HIP may not start ranks that re-use its state, and on this pool may not exec at all).  The kernel driver lists every
     agent under /sys/class/kfd/kfd/topology/nodes/<k>/properties; GPU agents are the ones with simd_count > 0.  The visibility
-    variables of the runtime (ROCR_VISIBLE_DEVICES, HIP_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES: comma lists of indices / UUIDs)
-    narrow that set.  Returns (count, source)."""
+    variables of the runtime (ROCR_VISIBLE_DEVICES, HIP_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES: comma lists of indices / UUIDs; a
+    negative index ends the list) narrow that set, and so does the container: an agent whose render node (drm_render_minor ->
+    /dev/dri/renderD<minor>) this process cannot open is not counted.  Returns (count, source)."""
     import glob
     n = 0
     nodes = sorted(glob.glob(os.path.join(topology, "*", "properties")))
@@ -565,13 +582,26 @@ def visible_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes"):
         except OSError:
             continue
         if int(props.get("simd_count", "0")) > 0:
+            # a container or cgroup may expose only some /dev/dri/renderD* nodes while sysfs lists every GPU of the host: count the
+            # agents whose render node this process can open (no drm_render_minor in the properties: count the agent)
+            minor = props.get("drm_render_minor", "").strip()
+            if minor.isdigit() and int(minor) > 0 and os.path.isdir(dri):
+                if not os.access(os.path.join(dri, f"renderD{int(minor)}"), os.R_OK | os.W_OK):
+                    continue
             n += 1
     if not nodes:
         return None, "no /sys/class/kfd"
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            ids = [t for t in v.split(",") if t.strip() != ""]
+            ids = []
+            for t in v.split(","):
+                t = t.strip()
+                if t == "":
+                    continue
+                if t.lstrip("-").isdigit() and int(t) < 0:      # a negative index ends the list (the runtimes' rule): "-1" = no device
+                    break
+                ids.append(t)
             n = min(n, len(ids))
     return n, "kfd topology"
 
@@ -665,6 +695,95 @@ def rocprof_roofline(out, role, algo_bytes):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+CHILD_LAYER_REPS = 13      # (a prime: the layer's own kernels are the rows of the stats table whose call count is a multiple of it)
+
+
+def child_layer(spec):
+    """`bench.py --child-layer c4:fwd` (run by rocprof_layer_kernel_sum under rocprofv3): CHILD_LAYER_REPS calls of one layer leg and
+    nothing else in a loop -- forward without autograd, or forward + backward -- so that the profiler's per-kernel totals divided by
+    the repetitions are the device time of ONE call without the gaps between its launches."""
+    name, mode = spec.split(":")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    if name == "c4":
+        layer, ps, st, x, _ = c4_layer(dev, 64, 0)
+        _, ps = ng.optim.flatten_parameters(ng.to_device(ps, dev))
+    else:
+        layer, ps, st, x, _ = c5_layer(dev, float(name.split("_r")[1]))
+        ps = ng.to_device(ps, dev)
+        for v in _grad_leaves(ps):
+            v.requires_grad_(True)
+    if mode == "fwd":
+        with torch.no_grad():
+            for _ in range(CHILD_LAYER_REPS):
+                layer(x, ps, st)
+    else:
+        x = x.detach().requires_grad_(True)
+        leaves = [x] + _grad_leaves(ps)
+        y0 = None
+        for _ in range(CHILD_LAYER_REPS):
+            for v in leaves:
+                v.grad = None
+            y = layer(x, ps, st)[0]
+            if y0 is None:
+                y0 = torch.ones_like(y)
+            y.backward(y0)
+    torch.cuda.synchronize()
+
+
+def rocprof_layer_kernel_sum(name, mode):
+    """ms of device time of one call of a layer leg = (sum over the layer's kernels of rocprofv3 --kernel-trace --stats'
+    TotalDurationNs) / repetitions, from a child pass (child_layer).  None when the profiler is absent or the child fails."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ngpde_rocprof_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "k", "--", sys.executable, os.path.abspath(__file__),
+               "--child-layer", f"{name}:{mode}"]
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+        total, kernels = 0.0, 0
+        for base, _, files in os.walk(tmp):
+            for f in files:
+                if f.endswith("kernel_stats.csv"):
+                    for row in csv.DictReader(open(os.path.join(base, f))):
+                        calls = int(row["Calls"])
+                        # the layer's launches: ngpde kernels launched a multiple of the repetitions (the handle's construction and
+                        # the first call's one-off launches are not)
+                        if "ngpde" in row["Name"] and calls >= CHILD_LAYER_REPS and calls % CHILD_LAYER_REPS == 0:
+                            total += float(row["TotalDurationNs"])
+                            kernels += calls // CHILD_LAYER_REPS
+        return (total / CHILD_LAYER_REPS * 1e-6, kernels) if kernels else None
+    except Exception:  # noqa: BLE001 -- the bench line must still come out
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _kernel_sum_roofline(rec, name, flop_fwd, allow):
+    """roofline.frac of a matrix-pipe-bound layer leg from the rocprofv3 kernel sum of its forward (the conservative figure: it reads
+    longer than an un-profiled graph replay, as the headline's does); the graph-replay fraction stays beside it"""
+    r = rec["roofline"]
+    r["frac_graph_replay"], r["achieved_graph_replay"] = r["frac"], r["achieved"]
+    r["frac_source"] = "graph replay (no rocprofv3 child pass)"
+    if not allow:
+        return
+    ks_f, ks_fb = rocprof_layer_kernel_sum(name, "fwd"), rocprof_layer_kernel_sum(name, "fwdbwd")
+    if ks_f is None:
+        return
+    ach = flop_fwd / (ks_f[0] * 1e-3) / 1e12
+    r["achieved"], r["frac"] = round(ach, 2), round(ach / FP32_MFMA_PEAK_TFS, 4)
+    r["kernel_sum_ms_forward"], r["kernels_per_forward"] = round(ks_f[0], 4), ks_f[1]
+    if ks_fb is not None:
+        r["kernel_sum_ms_forward_backward"], r["kernels_per_forward_backward"] = round(ks_fb[0], 4), ks_fb[1]
+    r["frac_source"] = (f"rocprofv3 --kernel-trace --stats, child pass of {CHILD_LAYER_REPS} calls: sum of the launches' TotalDurationNs / calls "
+                        "(no gaps between kernels; profiled runs read a few % longer than un-profiled ones)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -678,7 +797,11 @@ def main():
     ap.add_argument("--batched", type=int, default=8,
                     help="N=1 only: after the BASELINE measurement, also time this many trajectories per GPU as one batched "
                          "graph (reported under 'batched', never in 'value'); 0 = skip")
+    ap.add_argument("--child-layer", default=None, help=argparse.SUPPRESS)   # (internal: one layer leg in a loop, for the rocprofv3 child pass)
     args = ap.parse_args()
+    if args.child_layer:
+        child_layer(args.child_layer)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1053,7 +1176,7 @@ def main():
     if out is not None and world == 1 and not (args.no_rocprof or args.no_secondary):
         rocprof_roofline(out, roles[dom], algo[dom])
     if not args.no_secondary:
-        sec = secondary(dev, world, rank, dist)          # every rank takes part (N > 1: the data-parallel C4 step)
+        sec = secondary(dev, world, rank, dist, rocprof=(world == 1 and not args.no_rocprof))          # every rank takes part (N > 1: the data-parallel C4 step)
         if out is not None:
             out["secondary"] = sec
     if dist is not None:

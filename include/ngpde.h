@@ -310,6 +310,31 @@ int32_t ngpde_gno_message_backward_from_nodes(const ngpde_graph_t *g, int32_t co
                                               const float *t, const float *z, const float *dagg, float *dt, float *dbh, float *dz,
                                               float *dq, ngpde_stream_t stream);
 
+/* GNOConv's aggregated message with the EDGE index contracted first, per target over its CSR row (/root/reference/src/layers.jl:523-534;
+ * the other reassociation of m_i = aggr_{e -> i} reshape(W2 z_e + b2, out, in) h_{s_e}):
+ *   ngpde_gno_gform_aggregate:  z_e = act1(P[t_e] + Q[s_e] + E_e) as in ngpde_gno_message_forward;  gout [N][k][in]:
+ *     G_i[k][i'] = sum_{e -> i} z_e[k] h_{s_e}[i']  (Z_i^T H_i on the matrix pipe);  hsum [N][in] (nullable) = sum_{e -> i} h_{s_e};
+ *     both divided by deg(i) when `mean`;  z_out [E][k] (p order, nullable) keeps the activated input for the pullback.
+ *     k = 64 and in in {32, 64, 128} (ngpde_gno_gform_supported); every array 16-byte aligned.
+ *   ngpde_gno_gform_transform:  y [N][out] = act.(G W2' + hsum B2 + h W + bias)  with W2' = phi's last weight (k x in*out, Julia
+ *     (in*out x k)) read as the [k*in][out] matrix it is in memory (row k*in + i', column o  <->  K_e[o, i'] = phi_out[o + out*i'],
+ *     :525), the contraction split into `nsplit` slabs (ngpde_gno_gform_splits); the b2 term (hsum [N][in] with b2 read as
+ *     B2[i'][o] = b2[o + out*i']; both or neither NULL) and the layer's own linear map (h [N][in], w [in][out]; both or neither NULL) are
+ *     two more slabs of the SAME launch; slabs [nsplit + 2][N][out] is scratch; bias nullable; zt (nullable) keeps the pre-activation
+ *     (:536).  in a multiple of 16, out of 4.
+ * No [E][out] message array, no scatter, no atomics; the pullback is the by-source form's (ngpde_gno_message_backward_from_nodes). */
+int32_t ngpde_gno_gform_supported(int32_t in_chs, int32_t kdim);
+/* does ngpde_gno_layer_* take this form for the shape?  (inference: whenever supported; training: from about 64 edges per node, where
+ * it wins back the T = W2 (x) h that the by-source pullback needs and only the by-source forward leaves behind) */
+int32_t ngpde_gno_gform_preferred(int64_t n_nodes, int64_t n_edges, int32_t in_chs, int32_t kdim, int32_t cout, int32_t training);
+int32_t ngpde_gno_gform_splits(int64_t n_nodes, int32_t in_chs, int32_t kdim, int32_t cout);
+int32_t ngpde_gno_gform_aggregate(const ngpde_graph_t *g, int32_t in_chs, int32_t kdim, int32_t act1, int32_t mean, const float *p_target,
+                                  const float *q_source, const float *e_term, const float *h, float *gout, float *hsum, float *z_out,
+                                  ngpde_stream_t stream);
+int32_t ngpde_gno_gform_transform(int64_t n_nodes, int32_t in_chs, int32_t kdim, int32_t cout, int32_t act, const float *gin, const float *w2,
+                                  const float *hsum, const float *b2, const float *h, const float *w, const float *bias, float *y, float *zt,
+                                  float *slabs, int32_t nsplit, ngpde_stream_t stream);
+
 /* GAT-style aggregation [GraphNeuralNetworks.jl GATConv]: wx [N][heads*c] (= reshape(W x, c, heads, N)),
  * a (2c x heads) column-major; logit_e = leakyrelu(a[1:c,k].Wx[:,k,t_e] + a[c+1:2c,k].Wx[:,k,s_e]);
  * alpha = softmax over the incoming edges of each node; out[N][heads*c] = sum_e alpha_e Wx[s_e].
@@ -601,7 +626,8 @@ int32_t ngpde_row_blocks_scatter(int32_t width, int32_t src_rows, float *dsrc, i
 /* dst [cols][rows] = transpose of src [rows][cols] (GNOConv's reassociated form reads phi's last weight transposed,
  * src/layers.jl:527-530; its pullback transposes the gradient back) */
 int32_t ngpde_transpose(int32_t rows, int32_t cols, const float *src, float *dst, ngpde_stream_t stream);
-/* Rows by an index list (int64, device, 0-based; entries distinct): gather  dst[o][i][:] = src[o][index[i]][:]  (src [outer][n_rows][d],
+/* Rows by an index list (int64, device, 0-based; entries distinct and in [0, n_rows) -- an entry outside that range names no row: the
+ * gather writes a zero row for it, the scatter skips it): gather  dst[o][i][:] = src[o][index[i]][:]  (src [outer][n_rows][d],
  * dst [outer][n_index][d]) or, scatter != 0, dst[o][index[i]][:] = src[o][i][:] with every other row of dst zero (each is the other's
  * pullback).  The state of a batch of point clouds whose members were padded to whole tiles goes in and out of the device-resident
  * NeuralODE(VMHConv) plan through it (docs/src/tutorials/VMH.md:120-134: the batch is one block-diagonal graph). */

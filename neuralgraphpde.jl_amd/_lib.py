@@ -147,6 +147,11 @@ SIGNATURES = {
     "ngpde_gno_message_supported": (_i32, [_i32, _i32]),
     "ngpde_gno_message_backward_from_nodes": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gno_message_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gno_gform_supported": (_i32, [_i32, _i32]),
+    "ngpde_gno_gform_preferred": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "ngpde_gno_gform_splits": (_i32, [_i64, _i32, _i32, _i32]),
+    "ngpde_gno_gform_aggregate": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_gno_gform_transform": (_i32, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ngpde_gat_layer_supported": (_i32, [_vp, _i32, _i32, _i32]),
     "ngpde_gat_layer_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "ngpde_gat_layer_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -341,11 +341,14 @@ struct GnoPlan {
   int64_t N = 0, E = 0;
   int cin = 0, cout = 0, ds = 0, de = 0, h1 = 0, L = 0, kdim = 0, aggr = 1, act = 0, act1 = 0;
   bool reassoc = false, fused_msg = false, fused_agg = false, has_b2 = false;
+  bool gform = false;      // aggregate-then-transform (gno_gform.hip): no [E][out] message, no T in the forward
+  int nsplit = 1;
   int n_mid = 0;           // Dense layers of phi evaluated on [E] rows by the primitives (reassociated: 1 .. L - 2; literal: 1 .. L - 1)
   RowSpec rows;
   // forward region
   float *wa = nullptr, *wb = nullptr, *wd = nullptr, *wr = nullptr, *P = nullptr, *Q = nullptr, *Et = nullptr, *Bh = nullptr, *Wh = nullptr,
-        *T = nullptr, *a = nullptr, *m = nullptr, *agg = nullptr, *z0 = nullptr, *a0 = nullptr, *zt = nullptr;
+        *T = nullptr, *a = nullptr, *m = nullptr, *agg = nullptr, *z0 = nullptr, *a0 = nullptr, *zt = nullptr, *G = nullptr, *hs = nullptr,
+        *slabs = nullptr;
   float *ty[kMaxL], *tz[kMaxL];
   // pullback scratch
   float *dz = nullptr, *dagg_s = nullptr, *inv = nullptr, *dT = nullptr, *dBh = nullptr, *dzE = nullptr, *dP = nullptr, *dQ = nullptr,
@@ -384,6 +387,9 @@ int32_t make_gno_plan(const ngpde_graph *g, const ngpde_gno_layer_t &L, bool tra
   p.fused_msg = p.reassoc && p.L == 2 && p.E > 0 && !env_is("NGPDE_NO_GNO_MFMA", '1') && (p.act1 == NGPDE_ACT_IDENTITY || p.act1 == NGPDE_ACT_RELU) &&
                 ngpde_gno_message_supported(p.cout, p.kdim) == 1;
   p.fused_agg = p.fused_msg && (p.aggr == NGPDE_AGGR_SUM || p.aggr == NGPDE_AGGR_MEAN);
+  // the edge index contracted first, per target: the forward needs neither T nor the [E][out] message (the pullback keeps the
+  // by-source form and makes its own T)
+  p.gform = p.fused_agg && ngpde_gno_gform_preferred(p.N, p.E, p.cin, p.kdim, p.cout, training ? 1 : 0) == 1;
   p.n_mid = p.fused_msg ? 0 : (p.reassoc ? p.L - 2 : p.L - 1);
   const size_t N = (size_t)p.N, E = (size_t)p.E;
   const size_t msg_w = (size_t)p.cout;
@@ -394,11 +400,20 @@ int32_t make_gno_plan(const ngpde_graph *g, const ngpde_gno_layer_t &L, bool tra
   if (p.ds) { p.P = a.take(N * p.h1); p.Q = a.take(N * p.h1); }
   if (p.de) p.Et = a.take(E * p.h1);
   if (p.reassoc) {
-    p.wr = a.take((size_t)p.cin * p.cout * p.kdim);
-    p.T = a.take(N * p.cout * p.kdim);
-    if (p.has_b2) p.Bh = a.take(N * p.cout);
+    if (!p.gform || training) {
+      p.wr = a.take((size_t)p.cin * p.cout * p.kdim);
+      p.T = a.take(N * p.cout * p.kdim);
+    }
+    if (p.has_b2 && !p.gform) p.Bh = a.take(N * p.cout);
   }
-  p.Wh = a.take(N * p.cout);
+  if (p.gform) {
+    p.G = a.take(N * p.cin * p.kdim);
+    if (p.has_b2) p.hs = a.take(N * p.cin);
+    p.nsplit = ngpde_gno_gform_splits(p.N, p.cin, p.kdim, p.cout);
+    p.slabs = a.take((size_t)(p.nsplit + 2) * N * p.cout);   // + the b2 term and W h, formed in the same launch
+  } else {
+    p.Wh = a.take(N * p.cout);
+  }
   if (p.fused_msg) {
     p.a = training ? a.take(E * p.kdim) : nullptr;
   } else {
@@ -409,8 +424,10 @@ int32_t make_gno_plan(const ngpde_graph *g, const ngpde_gno_layer_t &L, bool tra
       p.tz[l] = (training && phi.act[l + 1] != 0) ? a.take(E * phi.dims[l + 2]) : nullptr;
     }
   }
-  p.m = a.take(E * msg_w);
-  p.agg = a.take(N * msg_w);
+  if (!p.gform) {
+    p.m = a.take(E * msg_w);
+    p.agg = a.take(N * msg_w);
+  }
   p.zt = (training && p.act != 0) ? a.take(N * msg_w) : nullptr;
   if (!training) {
     p.total_floats = a.off;
@@ -727,7 +744,7 @@ int32_t ngpde_gno_layer_forward(const ngpde_graph_t *g, const ngpde_gno_layer_t 
     if ((st = ngpde_dense_forward(p.E, 1, eb, ew, one, p.h1, NGPDE_ACT_IDENTITY, p.wd, p.ds ? nullptr : phi.bias[0], p.Et, nullptr, stream))) return st;
   }
   const float *w2 = phi.weight[p.L - 1], *b2 = phi.bias[p.L - 1];
-  if (p.reassoc) {   // W2 as [in][out][k]: the transpose of [k][in * out]
+  if (p.reassoc && !p.gform) {   // W2 as [in][out][k]: the transpose of [k][in * out]
     if ((st = ngpde_transpose(p.kdim, p.cin * p.cout, w2, p.wr, stream))) return st;
   }
   {   // the small node-level Dense layers -- P, Q on the node coordinates, B2 h, W h -- in ONE launch
@@ -741,9 +758,18 @@ int32_t ngpde_gno_layer_forward(const ngpde_graph_t *g, const ngpde_gno_layer_t 
       ++q;
     };
     if (p.ds) { add(L->node_feat, p.ds, p.wa, phi.bias[0], p.h1, p.P); add(L->node_feat, p.ds, p.wb, nullptr, p.h1, p.Q); }
-    if (p.has_b2) add(L->h, p.cin, b2, nullptr, p.cout, p.Bh);     // b2 read as the [in][out] matrix B2[i][o] = b2[o + out * i]
-    add(L->h, p.cin, L->weight, nullptr, p.cout, p.Wh);
-    if ((st = ngpde_dense_multi_forward(q, n, nseg, sp, sw, srd, dout, act, wt, bs, ys, zs, stream))) return st;
+    if (p.has_b2 && !p.gform) add(L->h, p.cin, b2, nullptr, p.cout, p.Bh);     // b2 read as the [in][out] matrix B2[i][o] = b2[o + out * i]
+    if (!p.gform) add(L->h, p.cin, L->weight, nullptr, p.cout, p.Wh);
+    if (q && (st = ngpde_dense_multi_forward(q, n, nseg, sp, sw, srd, dout, act, wt, bs, ys, zs, stream))) return st;
+  }
+  if (p.gform) {
+    // G_i = Z_i^T H_i and the sum of the neighbours' h per target, then ONE node-level product against W2 as it lies in memory, the
+    // b2 term on the summed rows, and the layer's tail in the slab reduction (:523-536)
+    if ((st = ngpde_gno_gform_aggregate(g, p.cin, p.kdim, p.act1, p.aggr == NGPDE_AGGR_MEAN ? 1 : 0, p.P, p.Q, p.Et, L->h, p.G, p.has_b2 ? p.hs : nullptr, p.a,
+                                        stream)))
+      return st;
+    return ngpde_gno_gform_transform(p.N, p.cin, p.kdim, p.cout, p.act, p.G, w2, p.has_b2 ? p.hs : nullptr, p.has_b2 ? b2 : nullptr, L->h, L->weight, L->bias, y,
+                                     p.zt, p.slabs, p.nsplit, stream);
   }
   if (p.reassoc) {
     const float *hb[1] = {L->h};
@@ -801,6 +827,10 @@ int32_t ngpde_gno_layer_backward(const ngpde_graph_t *g, const ngpde_gno_layer_t
   const int32_t hw[1] = {p.cin};
   // ---- the message: gradient of the aggregate -> dT, dBh (reassociated) / dh (literal), and the per-edge pre-activation's gradient
   const float *dlast = nullptr;   // gradient of the last per-edge array the primitives formed (their tail walks back from it)
+  if (p.gform) {   // the forward contracted the edge index first and formed no T: the by-source pullback makes its own
+    if ((st = ngpde_transpose(p.kdim, p.cin * p.cout, phi.weight[p.L - 1], p.wr, stream))) return st;
+    if ((st = ngpde_dense_forward(p.N, 1, hb, hw, one, p.cout * p.kdim, NGPDE_ACT_IDENTITY, p.wr, nullptr, p.T, nullptr, stream))) return st;
+  }
   if (p.fused_agg) {
     const float *dagg = dz;
     if (p.aggr == NGPDE_AGGR_MEAN) {   // a node's 1 / deg once per node, not once per edge inside the launch

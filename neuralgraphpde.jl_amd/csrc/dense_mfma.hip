@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_fwd_kernel(int64_t n, co
 // contraction-contiguous operand is staged as [128][16 + 4] and read as one 16-byte fragment per 16 x 4 block; the other kind
 // stays row-major [16][128 + 4] and is read 4 bytes at a time (dense_gemm128_fwd_kernel's two forms).  K, kper multiples of 16;
 // M, N multiples of 4.
+// one 128 x 128 tile of C = A x B over the contraction range [kbeg, kend) (the body of the two kernels below)
 template <bool A_MN, bool B_K>
-__global__ __launch_bounds__(256, 3) void dense_gemm128_split_kernel(int M, int N, int K, int kper, const float *__restrict__ A, int lda,
-                                                                     const float *__restrict__ B, int ldb, float *__restrict__ c0,
-                                                                     float *__restrict__ cpart, size_t part_stride, int ldc) {
+__device__ __forceinline__ void gemm128_tile(int M, int N, int kbeg, int kend, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                             int ldb, float *__restrict__ C, int ldc) {
   constexpr int BS = BG + 4, kOp = BG * LSG, kBuf = 2 * kOp;   // per buffer: two operand tiles of at most 128 x 20 floats
   __shared__ __attribute__((aligned(16))) float lds[2 * kBuf];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -484,8 +484,6 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_split_kernel(int M, int 
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * BG, n0 = blockIdx.y * BG;
-  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
-  float *C = blockIdx.z == 0 ? c0 : cpart + (size_t)(blockIdx.z - 1) * part_stride;
   // staging roles: contraction-contiguous operand: float4 (row = tid / 4 + 64 p, k = 4 (tid % 4)); row-major-in-k operand: float4
   // (k = tid / 32 + 8 p, column 4 (tid % 32) .. + 3); rows / columns past the end re-read the last ones (never stored)
   const int kr = tid >> 2, kk = 4 * (tid & 3), rk = tid >> 5, rc = 4 * (tid & 31);
@@ -580,6 +578,36 @@ __global__ __launch_bounds__(256, 3) void dense_gemm128_split_kernel(int M, int 
       const int r = m0 + 64 * wr + 16 * rt + (lane >> 4) + 4 * pp, c = n0 + 64 * wc + pc;
       if (r < M && c < N) *reinterpret_cast<float4 *>(C + (size_t)r * ldc + c) = *reinterpret_cast<const float4 *>(&patch[((lane >> 4) + 4 * pp) * OS2 + pc]);
     }
+  }
+}
+
+template <bool A_MN, bool B_K>
+__global__ __launch_bounds__(256, 3) void dense_gemm128_split_kernel(int M, int N, int K, int kper, const float *__restrict__ A, int lda,
+                                                                     const float *__restrict__ B, int ldb, float *__restrict__ c0,
+                                                                     float *__restrict__ cpart, size_t part_stride, int ldc) {
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  float *C = blockIdx.z == 0 ? c0 : cpart + (size_t)(blockIdx.z - 1) * part_stride;
+  gemm128_tile<A_MN, B_K>(M, N, kbeg, kend, A, lda, B, ldb, C, ldc);
+}
+
+// the row-major x row-major form with up to two further SHORT products of the same output shape in the same launch: blockIdx.z <
+// nsplit takes range z of the main contraction, blockIdx.z = nsplit + e the whole of product e; every z writes its own slab
+// (gno_gform.hip: G W2' split 16 ways, plus hsum B2 and h W -- three launches' worth of workgroups in one)
+struct GemmSide {
+  int n;
+  const float *A[2], *B[2];
+  int lda[2], ldb[2], K[2];
+};
+__global__ __launch_bounds__(256, 3) void dense_gemm128_split_nn_kernel(int M, int N, int K, int kper, int nsplit, const float *__restrict__ A, int lda,
+                                                                        const float *__restrict__ B, int ldb, float *__restrict__ slabs,
+                                                                        size_t slab_stride, int ldc, const GemmSide side) {
+  const int z = blockIdx.z;
+  float *C = slabs + (size_t)z * slab_stride;
+  if (z < nsplit) {
+    gemm128_tile<false, false>(M, N, z * kper, min(K, (z + 1) * kper), A, lda, B, ldb, C, ldc);
+  } else {
+    const int e = z - nsplit;
+    gemm128_tile<false, false>(M, N, 0, side.K[e], side.A[e], side.lda[e], side.B[e], side.ldb[e], C, ldc);
   }
 }
 
@@ -1339,6 +1367,30 @@ int32_t launch_dense_seg_fwd_splitk(int64_t n, const SegTable &segs, int din, in
 int dense_fwd_split_count(int din, int nsplit) {   // partial slabs launch_dense_seg_fwd_splitk actually writes
   const int kper = ((din + nsplit - 1) / nsplit + BK - 1) / BK * BK;
   return (din + kper - 1) / kper;
+}
+
+// C [M][N] = A [M][K] x B [K][N] (both row-major) on the 128 x 128 tiles, the contraction split into nsplit ranges of whole 16-chunks:
+// range z writes slab z of `slabs` ([nsplit + n_side][M][ldc], slab_stride floats apart); up to two further short products
+// side_a[e] [M][side_k[e]] x side_b[e] [side_k[e]][N] (row-major, leading dimensions side_k[e] and N) write slabs nsplit + e in the
+// same launch; the caller sums the slabs in order.  For a node-level product with a long contraction and few row tiles
+// (gno_gform.hip: 4096 x 8192 x 128).  K and side_k multiples of 16, N % 4 == 0.
+int32_t launch_gemm128_split_nn(int M, int N, int K, int nsplit, const float *A, int lda, const float *B, int ldb, float *slabs,
+                                size_t slab_stride, int ldc, int n_side, const float *const *side_a, const float *const *side_b, const int *side_k,
+                                hipStream_t stream) {
+  if (M == 0 || N == 0) return NGPDE_OK;
+  const int kper = ((K + nsplit - 1) / nsplit + BKG - 1) / BKG * BKG;
+  NGPDE_REQUIRE(K % BKG == 0 && N % 4 == 0 && (size_t)kper * nsplit >= (size_t)K && n_side >= 0 && n_side <= 2, NGPDE_ERR_DIMENSION_MISMATCH,
+                "gemm128 split: K = %d must be a multiple of %d and N = %d of 4", K, BKG, N);
+  GemmSide side{};
+  side.n = n_side;
+  for (int e = 0; e < n_side; ++e) {
+    NGPDE_REQUIRE(side_k[e] % BKG == 0 && side_a[e] && side_b[e], NGPDE_ERR_DIMENSION_MISMATCH, "gemm128 split: side product %d: K = %d", e, side_k[e]);
+    side.A[e] = side_a[e]; side.B[e] = side_b[e]; side.lda[e] = side_k[e]; side.ldb[e] = N; side.K[e] = side_k[e];
+  }
+  hipLaunchKernelGGL(dense_gemm128_split_nn_kernel, dim3((M + BG - 1) / BG, (N + BG - 1) / BG, nsplit + n_side), dim3(256), 0, stream, M, N, K, kper,
+                     nsplit, A, lda, B, ldb, slabs, slab_stride, ldc, side);
+  NGPDE_LAUNCH_CHECK("dense_gemm128_split_nn_kernel");
+  return NGPDE_OK;
 }
 
 int32_t launch_dense_seg_bwd_input(int64_t n, const SegGrad &segs, int din, int dout, const float *dz, const float *wt,

@@ -106,8 +106,13 @@ __global__ void rows_index_kernel(int64_t outer, int64_t n_src, int64_t n_idx, i
   if (k >= total) return;
   const int c = (int)(k % d);
   const int64_t i = (k / d) % n_idx, o = k / ((int64_t)d * n_idx), j = index[i];
-  if (scatter) dst[(o * n_src + j) * d + c] = src[(o * n_idx + i) * d + c];
-  else dst[(o * n_idx + i) * d + c] = src[(o * n_src + j) * d + c];
+  // an entry outside [0, n_rows) names no row: the gather leaves a zero row, the scatter writes nothing (never an out-of-bounds access)
+  const bool in_range = (uint64_t)j < (uint64_t)n_src;
+  if (scatter) {
+    if (in_range) dst[(o * n_src + j) * d + c] = src[(o * n_idx + i) * d + c];
+  } else {
+    dst[(o * n_idx + i) * d + c] = in_range ? src[(o * n_src + j) * d + c] : 0.f;
+  }
 }
 }  // namespace
 }  // namespace ngpde

@@ -428,7 +428,8 @@ class _EdgeLayerFn(torch.autograd.Function):
                     gs.dbias[l] = grads[base + 2 * l + 1].data_ptr()
         _lib.check(lib.ngpde_edge_layer_backward(ctx.handle.ptr, C.byref(ctx.desc), _lib.ptr(dy), dstate, C.byref(gphi), C.byref(gupd),
                                                  _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.current_stream()))
-        ctx.ws = None          # (the workspace holds every saved activation: let it go with the node)
+        # (the workspace holds every saved activation and is only read by the pullback: it stays with the node, so a second backward
+        # through a retained graph finds it, and goes when autograd frees the node)
         return (None, None, None, None, None, None, None, None, *grads)
 
 
@@ -508,7 +509,6 @@ class _GnoLayerFn(torch.autograd.Function):
                 gphi.dbias[l] = grads[4 + 2 * l].data_ptr()
         _lib.check(lib.ngpde_gno_layer_backward(ctx.handle.ptr, C.byref(ctx.desc), _lib.ptr(dy), _lib.ptr(grads[0]), C.byref(gphi), _lib.ptr(grads[1]),
                                                 _lib.ptr(grads[2]), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.current_stream()))
-        ctx.ws = None
         return (None, None, None, None, None, None, None, None, *grads)
 
 

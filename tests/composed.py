@@ -429,6 +429,57 @@ class _GnoMessageAggFn(torch.autograd.Function):
         return (dP, dQ, (dz if want_e else None), dT, dBh) + (None,) * 7
 
 
+class _GnoGformAggFn(torch.autograd.Function):
+    """The aggregate PLUS the layer's linear map, S = aggr_e K_e h_j + W h, in the aggregate-then-transform form (csrc/gno_gform.hip):
+    forward = ngpde_gno_gform_aggregate (G_i = Z_i^T H_i and the neighbours' summed h per target) and ngpde_gno_gform_transform (one
+    node-level product against phi's last weight, the b2 term and W h as two more slabs of the same launch).  T, Bh (per source) and
+    Wh = h W are autograd inputs only for the pullback: dT, dBh as the by-source form's (_GnoMessageAggFn.backward), dWh = dS."""
+
+    @staticmethod
+    def forward(ctx, P, Q, Eterm, T, Bh, Wh, h, w2, b2, lwt, handle, act1, cin, cout, kdim, n_edges, aggr, n_nodes):
+        lib = _lib.load()
+        _need_cuda(P, Q, Eterm, T, Bh, h, w2, b2, lwt)
+        P = None if P is None else P.contiguous()
+        Q = None if Q is None else Q.contiguous()
+        Eterm = None if Eterm is None else Eterm.contiguous()
+        T, h, w2, lwt = T.contiguous(), h.contiguous(), w2.contiguous(), lwt.contiguous()
+        b2 = None if b2 is None else b2.contiguous()
+        dev = T.device
+        stream = _lib.current_stream()
+        need = any(ctx.needs_input_grad)
+        a = torch.empty((n_edges, kdim), dtype=torch.float32, device=dev) if need else None
+        G = torch.empty((n_nodes, kdim * cin), dtype=torch.float32, device=dev)
+        hs = torch.empty((n_nodes, cin), dtype=torch.float32, device=dev) if b2 is not None else None
+        _lib.check(lib.ngpde_gno_gform_aggregate(handle.ptr, cin, kdim, act1, 1 if aggr == _lib.AGGR["mean"] else 0, _lib.ptr(P), _lib.ptr(Q),
+                                                 _lib.ptr(Eterm), _lib.ptr(h), _lib.ptr(G), _lib.ptr(hs), _lib.ptr(a), stream))
+        nsplit = int(lib.ngpde_gno_gform_splits(n_nodes, cin, kdim, cout))
+        slabs = torch.empty((nsplit + 2, n_nodes, cout), dtype=torch.float32, device=dev)
+        S = torch.empty((n_nodes, cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.ngpde_gno_gform_transform(n_nodes, cin, kdim, cout, 0, _lib.ptr(G), _lib.ptr(w2), _lib.ptr(hs), _lib.ptr(b2), _lib.ptr(h),
+                                                 _lib.ptr(lwt), None, _lib.ptr(S), None, _lib.ptr(slabs), nsplit, stream))
+        ctx.handle, ctx.meta = handle, (act1, cout, kdim, aggr)
+        ctx.shapes = (None if P is None else P.shape, None if Q is None else Q.shape, Eterm is not None, Bh is not None)
+        ctx.save_for_backward(T, a)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        return _GnoMessageAggFn.backward(ctx, dS)[:5] + (dS,) + (None,) * 12
+
+
+def gno_gform_preferred(n_nodes, n_edges, cin, cout, kdim, act1, aggr, training):
+    """the layer entry's own choice (api_layers.hip: make_gno_plan), through the same library call"""
+    code = _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr)
+    return (act1 in (0, 1) and code in (_lib.AGGR["+"], _lib.AGGR["mean"])
+            and bool(_lib.load().ngpde_gno_gform_preferred(int(n_nodes), int(n_edges), int(cin), int(kdim), int(cout), int(bool(training)))))
+
+
+def gno_gform_sum(P, Q, Eterm, T, Bh, Wh, h, w2, b2, lwt, handle, act1, cin, cout, kdim, n_edges, aggr, n_nodes):
+    code = _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr)
+    return _GnoGformAggFn.apply(P, Q, Eterm, T, Bh, Wh, h.detach(), w2.detach(), None if b2 is None else b2.detach(), lwt.detach(), handle, int(act1),
+                                int(cin), int(cout), int(kdim), int(n_edges), code, int(n_nodes))
+
+
 def gno_message_aggregate(P, Q, Eterm, T, Bh, handle, act1, cout, kdim, n_edges, aggr, n_nodes):
     """Fused message + sum / mean aggregation (aggr: name or code); other aggregations: gno_message + segment_reduce."""
     code = _lib.AGGR[aggr] if isinstance(aggr, str) else int(aggr)
@@ -957,6 +1008,10 @@ def gnoconv_composed(self, h, ps, st):
     if (reassoc and len(stack) == 2 and E > 0 and os.environ.get("NGPDE_NO_GNO_MFMA") != "1"
             and gno_message_supported(self.out_chs, kdim, l1.act)):
         # two-layer phi: the per-edge input act1(P[t] + Q[s] + E) is formed inside the message launch
+        training = torch.is_grad_enabled() and (h.requires_grad or any(t.requires_grad for t in (lwt, w2, wt) if t is not None))
+        if gno_gform_preferred(N, E, self.in_chs, self.out_chs, kdim, l1.act, self.aggr, training):   # the edge index contracted first (gno_gform.hip)
+            S = gno_gform_sum(P, Q, Et, T, Bh, Wh, h, w2, b2, lwt, handle, l1.act, self.in_chs, self.out_chs, kdim, E, self.aggr, N)
+            return bias_act(S, None, lb, self.linear.act).T, st                # σ(W x + m + b)  (:536-547)
         agg = gno_message_aggregate(P, Q, Et, T, Bh, handle, l1.act, self.out_chs, kdim, E, self.aggr, N)   # :527-534
         m = None
     elif reassoc:

@@ -178,6 +178,23 @@ def test_launcher_counts_gpus_from_the_kernel_drivers_topology_without_the_hip_r
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
     assert bench.visible_gpu_count(str(tmp_path))[0] == 0
     assert bench.visible_gpu_count(str(tmp_path / "absent")) == (None, "no /sys/class/kfd")
+    # a negative index ends a visibility list ("-1": no device at all)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "-1")
+    assert bench.visible_gpu_count(str(tmp_path))[0] == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,-1,2")
+    assert bench.visible_gpu_count(str(tmp_path))[0] == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # a container that exposes only some render nodes: sysfs still lists every GPU of the host, the inaccessible ones are not counted
+    topo, dri = tmp_path / "topo2", tmp_path / "dri"
+    topo.mkdir(); dri.mkdir()
+    for k, minor in enumerate([0, 128, 129, 130]):                      # one CPU agent, three GPUs
+        (topo / str(k)).mkdir()
+        (topo / str(k) / "properties").write_text(f"simd_count {0 if minor == 0 else 1024}\ndrm_render_minor {minor}\n")
+    (dri / "renderD128").write_text("")
+    (dri / "renderD130").write_text("")
+    assert bench.visible_gpu_count(str(topo), str(dri)) == (2, "kfd topology")
+    assert bench.visible_gpu_count(str(topo), str(tmp_path / "no_dri")) == (3, "kfd topology")
 
 
 def _world8_worker(rank, world, port, out):

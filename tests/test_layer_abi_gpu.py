@@ -165,6 +165,114 @@ def test_gno_entry_equals_the_composed_layer(variant, aggr, monkeypatch):
     assert_same(both_ways(layer, x, 51, monkeypatch, training=False))
 
 
+def dense_spatial(N, deg, seed, edata=0):
+    """a random graph of `deg` incoming edges per node with 2-d positions and one more node feature: the density at which the layer
+    entry takes the aggregate-then-transform form in training too (ngpde_gno_gform_preferred: >= 64 edges per node)"""
+    rng = np.random.default_rng(seed)
+    t = np.repeat(np.arange(N), deg)
+    s = rng.integers(0, N, N * deg)
+    perm = rng.permutation(N * deg)
+    s, t = s[perm], t[perm]
+    kw = dict(ndata={"x": rng.random((2, N)).astype(np.float32), "f0": rng.normal(size=(1, N)).astype(np.float32)})
+    if edata:
+        kw["edata"] = {"e": rng.normal(size=(edata, s.size)).astype(np.float32)}
+    return ng.GNNGraph(s, t, num_nodes=N, index_base=0, **kw)
+
+
+@pytest.mark.parametrize("cin,cout,aggr,edata,bias,first,deg", [(128, 128, "mean", 0, True, "relu", 70),    # BASELINE config 5's shape and density
+                                                                 (32, 48, "+", 2, True, "identity", 64), (64, 20, "mean", 0, False, "relu", 65),
+                                                                 (128, 64, "+", 1, True, "relu", 6)])        # sparse: by-source when training
+def test_gno_gform_entry_equals_the_composed_layer(cin, cout, aggr, edata, bias, first, deg, monkeypatch):
+    # the aggregate-then-transform form (csrc/gno_gform.hip: k = 64, in in {32, 64, 128}, sum / mean): the entry and the composed path
+    # run the same launches; with NGPDE_NO_GNO_GFORM=1 both fall back to the by-source form
+    k, N = 64, 300
+    g = dense_spatial(N, deg, 17, edata=edata)
+    ds = 3
+    phi = ng.Chain(ng.Dense(2 * ds + edata, k, first), ng.Dense(k, cin * cout, bias=bias))
+    layer = ng.GNOConv((cin, cout), phi, "relu", initialgraph=g, aggr=aggr, bias=bias)
+    x = torch.randn(cin, N, device=DEV)
+    act1 = 1 if first == "relu" else 0
+    assert composed.gno_gform_preferred(N, N * deg, cin, cout, k, act1, aggr, False)
+    assert composed.gno_gform_preferred(N, N * deg, cin, cout, k, act1, aggr, True) == (deg >= 64)
+    a = both_ways(layer, x, 61, monkeypatch)
+    assert_same(a)
+    ai = both_ways(layer, x, 61, monkeypatch, training=False)
+    assert_same(ai)
+    monkeypatch.setenv("NGPDE_NO_GNO_GFORM", "1")
+    assert not composed.gno_gform_preferred(N, N * deg, cin, cout, k, act1, aggr, False)
+    b = both_ways(layer, x, 61, monkeypatch)
+    assert_same(b)
+    bi = both_ways(layer, x, 61, monkeypatch, training=False)
+    # the two forms are two summation orders of the same layer: outputs and every gradient agree to rounding
+    for u, v in list(zip(a[0], b[0])) + list(zip(ai[0], bi[0])):
+        scale = float(v.abs().max()) + 1e-30
+        assert float((u - v).abs().max()) <= 2e-5 * scale + 1e-6, (float((u - v).abs().max()), scale)
+
+
+def test_gno_gform_aggregate_against_float64():
+    # G_i[k][i'] = sum_{e -> i} z_e[k] h_{s_e}[i'], hsum_i, z_out: rows of 0, 1, 33 and 70 edges, sum and mean, all three feature blocks
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    N, k = 90, 64
+    s, t = [], []
+    for node, deg in ((1, 1), (2, 33), (3, 70), (5, 4), (7, 32)):
+        src = rng.integers(0, N, deg)
+        s += list(src); t += [node] * deg
+    perm = rng.permutation(len(s))
+    s, t = np.asarray(s)[perm], np.asarray(t)[perm]
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    handle = g.handle()
+    E = len(s)
+    order = np.argsort(t, kind="stable")                    # p order: by target, COO order inside a row
+    for cin in (32, 64, 128):
+        for mean in (0, 1):
+            P, Q, Et = (rng.normal(size=(N, k)).astype(np.float32), rng.normal(size=(N, k)).astype(np.float32),
+                        rng.normal(size=(E, k)).astype(np.float32))
+            h = rng.normal(size=(N, cin)).astype(np.float32)
+            dv = lambda a: torch.as_tensor(a, device=DEV)
+            G = torch.full((N, k * cin), float("nan"), device=DEV)
+            hs = torch.full((N, cin), float("nan"), device=DEV)
+            zo = torch.full((E, k), float("nan"), device=DEV)
+            tP, tQ, tE, th = dv(P), dv(Q), dv(Et), dv(h)
+            _lib.check(lib.ngpde_gno_gform_aggregate(handle.ptr, cin, k, 1, mean, _lib.ptr(tP), _lib.ptr(tQ), _lib.ptr(tE), _lib.ptr(th), _lib.ptr(G),
+                                                     _lib.ptr(hs), _lib.ptr(zo), _lib.current_stream()))
+            z = np.maximum(P[t[order]].astype(np.float64) + Q[s[order]] + Et, 0.0)          # [E][k], p order
+            Gr, hr = np.zeros((N, k, cin)), np.zeros((N, cin))
+            for p_, e in enumerate(order):
+                Gr[t[e]] += np.outer(z[p_], h[s[e]].astype(np.float64))
+                hr[t[e]] += h[s[e]]
+            if mean:
+                deg = np.maximum(np.bincount(t, minlength=N), 1)[:, None]
+                Gr, hr = Gr / deg[:, :, None], hr / deg
+            assert np.abs(zo.cpu().numpy() - z).max() <= 1e-6
+            assert np.abs(G.cpu().numpy().reshape(N, k, cin) - Gr).max() <= 1e-4 * np.abs(Gr).max() + 1e-6
+            assert np.abs(hs.cpu().numpy() - hr).max() <= 1e-5 * np.abs(hr).max() + 1e-6
+    assert lib.ngpde_gno_gform_supported(16, 64) == 0 and lib.ngpde_gno_gform_supported(128, 32) == 0
+    assert lib.ngpde_gno_gform_aggregate(handle.ptr, 16, 64, 1, 0, None, None, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+
+
+def test_second_backward_through_a_retained_graph(monkeypatch):
+    # the layer entries keep their workspace (every saved activation) with the autograd node: a second pullback through a retained
+    # graph reads the same saved state and gives the same bits as the first
+    g = spatial(640, 9)
+    phi = ng.Chain(ng.Dense(4, 32, "tanh"), ng.Dense(32, 16))
+    gam = ng.Chain(ng.Dense(17, 24, "tanh"), ng.Dense(24, 1))
+    vmh = ng.VMHConv(phi, gam, initialgraph=g)
+    g2 = spatial(600, 13, ndata_extra=1)
+    gno = ng.GNOConv((32, 32), ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, 32 * 32)), "relu", initialgraph=g2, aggr="mean")
+    for layer, x in ((vmh, torch.randn(1, 640, device=DEV)), (gno, torch.randn(32, 600, device=DEV))):
+        ps0, st = ng.setup(71, layer)
+        ps = prep(ps0, 71)
+        xs = x.clone().requires_grad_(True)
+        y, _ = layer(xs, ps, st)
+        leaves = [xs] + list(grad_leaves(ps))
+        loss = (y * y).sum()
+        first = torch.autograd.grad(loss, leaves, retain_graph=True)
+        second = torch.autograd.grad(loss, leaves)
+        for a, b in zip(first, second):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_entry_rejects_what_the_reference_rejects():
     lib = _lib.load()
     g = spatial(64, 2)
