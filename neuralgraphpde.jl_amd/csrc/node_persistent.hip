@@ -1341,6 +1341,15 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
   // the tape row (wait 4.6 k cycles against the forward kernel's 3.0 k for the same hand-off).
   Aux mk_n{};
   float4 xrow_n = f4_zero();
+  // The first look at the NEXT phase's flags is asked for right behind the publish, in front of the tape prefetch and the
+  // parameter-gradient products (poll_issue), and read when the next phase begins (tile_wait_primed): a tile whose neighbours have all
+  // published before it no longer pays a poll round trip at the top of the phase.  Measured (round 6, same box, alternating): adjoint
+  // launch 2.81 -> 2.78 ms.  (Also measured there and NOT kept: wave 0's tape rows fetched memory -> LDS by DMA a phase early, or by
+  // four helper waves, so that nothing of wave 0's is in flight in front of its polls -- the hypothesis being that a wave's loads return
+  // in order and the cold tape lines hold the polls up: adjoint 2.93 - 2.95 ms, the wait unchanged at 2.6 - 2.8 k cycles; and every
+  // added register spills here -- 123 of 128 are taken -- a spilled dW accumulator is reloaded with s_waitcnt vmcnt(0) in front of the
+  // products, which then waits for the tape rows.)
+  unsigned f_next = 0;
   auto dense = [&](int ph, const float *ldsW, f32x4 (&dwl)[PG::DWT], float &dbl, float4 kbar, Aux mk, float4 xrow, float *gout, bool pf, size_t ev_n) {
     kbar = f4_scale(c.ci, kbar);
     float4 dz;
@@ -1364,6 +1373,9 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
     tile_publish(p.m, c, ph);
     NGPDE_PST(p.m, ph, 6);
     Xh4[c.grp * PG::LPR + c.q] = gv;   // behind the barrier: every thread has read its row of G (same LDS region)
+    if constexpr (!HUB) {
+      if (c.wave_u == 0) f_next = poll_issue(p.m, c, p.m.flags);
+    }
     if (pf) {
       mk_n = mask_of(ev_n);
       xrow_n = tape_row(ev_n);
@@ -1436,7 +1448,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
           NGPDE_PST(p.m, ph, 2);
           t = hub_aggregate(c, sw, ldsXh, ldsDZ);   // (the operand tiles of the previous phase's products are dead: that phase ended at this wait's barrier)
         } else if constexpr (WGT) {
-          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g2, ldsXh);
           NGPDE_PST(p.m, ph, 2);
@@ -1444,7 +1456,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
         } else {
           unsigned sw[8];
           tile_slot_words(c, sw);
-          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g2, ldsXh);
           NGPDE_PST(p.m, ph, 2);
@@ -1470,7 +1482,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
           NGPDE_PST(p.m, ph, 2);
           t = hub_aggregate(c, sw, ldsXh, ldsDZ);   // (the operand tiles of the previous phase's products are dead: that phase ended at this wait's barrier)
         } else if constexpr (WGT) {
-          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g1, ldsXh);
           NGPDE_PST(p.m, ph, 2);
@@ -1478,7 +1490,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
         } else {
           unsigned sw[8];
           tile_slot_words(c, sw);
-          if (!tile_wait(p.m, c, ph, s_ok)) { ok = false; break; }
+          if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g1, ldsXh);
           NGPDE_PST(p.m, ph, 2);
