@@ -730,6 +730,62 @@ int32_t ngpde_gno_layer_backward(const ngpde_graph_t *g, const ngpde_gno_layer_t
                                  const ngpde_mlp_grad_t *dphi, float *dweight, float *dbias, void *workspace, size_t workspace_bytes,
                                  ngpde_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * Solver level, ONE create call: the device-resident fixed-step neural-ODE plan for a right-hand side, chosen and checked by the library.
+ * What a Lux / DiffEqFlux host binds where the tutorials write  NeuralODE(model, tspan, Tsit5(); saveat = ...)  and differentiate through
+ * the solve (/root/reference/docs/src/tutorials/graph_node.md:44-66, :78; docs/src/tutorials/VMH.md:85-89, :104-108, :132-141):
+ *   rhs = NGPDE_RHS_GCN2: Chain(GCNConv(d => d, act), GCNConv(d => d, act)), width = d in {16, 32, 64, 128}; `members` > 1: a block-diagonal
+ *         batch of identical structures on the MEMBER's handle (test/runtests.jl:89-102; ERR_UNSUPPORTED when the persistent plan does not
+ *         take it: create again on the batch's own handle with members = 1)            -> ngpde_node_gcn2_create[_batch]
+ *   rhs = NGPDE_RHS_GAT:  one GAT-style layer, width = 64 = heads * head_width          -> ngpde_node_gat_create[_batch]
+ *   rhs = NGPDE_RHS_VMH:  VMHConv(phi, gamma) on a state of `width` rows per node (1), pos [N][pos_width] (copied), phi / gamma given by
+ *         their layer widths and activations; the entry checks that the stacks chain as src/layers.jl:316, :328 feed them
+ *         (phi_dims[0] = 2 width + pos_width, gamma_dims[0] = width + phi's output, gamma's output = width: DimensionMismatch otherwise)
+ *                                                                                       -> ngpde_node_vmh_create
+ * NGPDE_ERR_UNSUPPORTED (text in ngpde_last_error) = no device-resident plan takes this right-hand side on this graph: the host steps the
+ * layer itself, every Runge-Kutta combination one ngpde_rk_stage_combine launch (any other right-hand side does that too).
+ * *flags (nullable): the NGPDE_NODE_* bits of the plan chosen.  Parameters travel per call (no hidden parameter state):
+ *   GCN2: first.weight[0..1], first.bias[0..1] (nullable);  GAT: first.weight[0], attention (2c x heads), first.bias[0] (nullable);
+ *   VMH: first = phi's layers, second = gamma's.  Gradients come back in the same places of ngpde_ode_grads_t.
+ * forward: out = u(T) [N * members][width], or with save_every > 0 (VMH only) the saved states [T][N] of ngpde_node_vmh_forward_saveat;
+ * backward: dout in the same shape, du0 [N * members][width].  One solve in flight per plan (ngpde_node_generation's rule). */
+typedef struct ngpde_ode ngpde_ode_t;
+typedef enum { NGPDE_RHS_GCN2 = 1, NGPDE_RHS_GAT = 2, NGPDE_RHS_VMH = 3 } ngpde_rhs_t;
+typedef struct ngpde_ode_desc {
+  int32_t rhs;                 /* ngpde_rhs_t */
+  int32_t tableau;             /* ngpde_tableau_t */
+  int32_t n_steps, with_backward, members;
+  double dt;
+  int32_t width;               /* GCN2: d; GAT: 64; VMH: rows of the state per node */
+  int32_t act;                 /* GCN2 / GAT: the layers' activation */
+  int32_t heads, head_width;   /* GAT */
+  float negative_slope;        /* GAT */
+  int32_t pos_width, aggr;     /* VMH */
+  const float *pos;            /* VMH: device [N][pos_width] */
+  int32_t n_phi, phi_dims[NGPDE_MLP_MAX_LAYERS + 1], phi_acts[NGPDE_MLP_MAX_LAYERS];
+  int32_t n_gamma, gamma_dims[NGPDE_MLP_MAX_LAYERS + 1], gamma_acts[NGPDE_MLP_MAX_LAYERS];
+} ngpde_ode_desc_t;
+typedef struct ngpde_ode_wb {
+  const float *weight[NGPDE_MLP_MAX_LAYERS];
+  const float *bias[NGPDE_MLP_MAX_LAYERS];
+} ngpde_ode_wb_t;
+typedef struct ngpde_ode_params {
+  ngpde_ode_wb_t first, second;
+  const float *attention;
+} ngpde_ode_params_t;
+typedef struct ngpde_ode_grads {
+  ngpde_mlp_grad_t first, second;
+  float *dattention;
+} ngpde_ode_grads_t;
+int32_t ngpde_ode_create(const ngpde_graph_t *g, const ngpde_ode_desc_t *desc, ngpde_ode_t **out, int32_t *flags);
+int32_t ngpde_ode_destroy(ngpde_ode_t *plan);
+size_t ngpde_ode_tape_bytes(const ngpde_ode_t *plan);
+int32_t ngpde_ode_fault(ngpde_ode_t *plan, ngpde_stream_t stream, int32_t *fault);
+int32_t ngpde_ode_forward(ngpde_ode_t *plan, const float *u0, const ngpde_ode_params_t *params, int32_t save_every, int32_t save_start,
+                          float *out, ngpde_stream_t stream);
+int32_t ngpde_ode_backward(ngpde_ode_t *plan, const ngpde_ode_params_t *params, int32_t save_every, int32_t save_start, const float *dout,
+                           float *du0, const ngpde_ode_grads_t *grads, ngpde_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

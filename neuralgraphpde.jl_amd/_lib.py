@@ -67,6 +67,31 @@ class GnoLayer(C.Structure):
 
 
 LAYER_EDGECONV, LAYER_VMH, LAYER_MPPDE = 0, 1, 2
+RHS_GCN2, RHS_GAT, RHS_VMH = 1, 2, 3
+
+
+class OdeDesc(C.Structure):
+    """ngpde_ode_desc_t: the right-hand side of a fixed-step neural ODE, for ngpde_ode_create"""
+    _fields_ = [("rhs", _i32), ("tableau", _i32), ("n_steps", _i32), ("with_backward", _i32), ("members", _i32), ("dt", C.c_double),
+                ("width", _i32), ("act", _i32), ("heads", _i32), ("head_width", _i32), ("negative_slope", _f32),
+                ("pos_width", _i32), ("aggr", _i32), ("pos", _vp),
+                ("n_phi", _i32), ("phi_dims", _i32 * (MLP_MAX_LAYERS + 1)), ("phi_acts", _i32 * MLP_MAX_LAYERS),
+                ("n_gamma", _i32), ("gamma_dims", _i32 * (MLP_MAX_LAYERS + 1)), ("gamma_acts", _i32 * MLP_MAX_LAYERS)]
+
+
+class OdeWb(C.Structure):
+    """ngpde_ode_wb_t"""
+    _fields_ = [("weight", _vp * MLP_MAX_LAYERS), ("bias", _vp * MLP_MAX_LAYERS)]
+
+
+class OdeParams(C.Structure):
+    """ngpde_ode_params_t"""
+    _fields_ = [("first", OdeWb), ("second", OdeWb), ("attention", _vp)]
+
+
+class OdeGrads(C.Structure):
+    """ngpde_ode_grads_t"""
+    _fields_ = [("first", MlpGrad), ("second", MlpGrad), ("dattention", _vp)]
 
 # name -> (restype, argtypes).  Every symbol include/ngpde.h declares must be listed here:
 # tests/test_abi.py checks the header against this table and against the built library.
@@ -147,6 +172,12 @@ SIGNATURES = {
     "ngpde_gno_message_supported": (_i32, [_i32, _i32]),
     "ngpde_gno_message_backward_from_nodes": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_gno_message_forward": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_ode_create": (_i32, [_vp, C.POINTER(OdeDesc), C.POINTER(_vp), C.POINTER(_i32)]),
+    "ngpde_ode_destroy": (_i32, [_vp]),
+    "ngpde_ode_tape_bytes": (_sz, [_vp]),
+    "ngpde_ode_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ngpde_ode_forward": (_i32, [_vp, _vp, C.POINTER(OdeParams), _i32, _i32, _vp, _vp]),
+    "ngpde_ode_backward": (_i32, [_vp, C.POINTER(OdeParams), _i32, _i32, _vp, _vp, C.POINTER(OdeGrads), _vp]),
     "ngpde_gno_gform_supported": (_i32, [_i32, _i32]),
     "ngpde_gno_gform_preferred": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "ngpde_gno_gform_splits": (_i32, [_i64, _i32, _i32, _i32]),
@@ -285,6 +316,6 @@ def flush_destroy():
 
 
 def destroy_later(fn, ptr):
-    """fn: "ngpde_graph_destroy" | "ngpde_node_destroy"; ptr: the handle"""
+    """fn: "ngpde_graph_destroy" | "ngpde_node_destroy" | "ngpde_ode_destroy"; ptr: the handle"""
     _pending_destroy.append((fn, ptr))
     flush_destroy()

@@ -175,33 +175,38 @@ class _NodeGCN2Fn(torch.autograd.Function):
         return du0, dw1, db1, dw2, db2, None
 
 
-class _GatPlan:
-    """Device-resident solve + discrete adjoint with ONE GAT-style layer as the right-hand side (ngpde_node_gat_*): two persistent
-    launches.  Holds the tape of ONE solve (stage inputs, y / z rows, attention coefficients)."""
+_FLAG_NAMES = ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"), (16, "persistent_bwd"), (32, "tile_pairs"),
+               (64, "tile_rounds"), (128, "widened"), (256, "hub_geometry"))
 
-    def __init__(self, handle, heads, c, slope, act, tableau, n_steps, dt, with_backward, members=1):
-        """members > 1: `handle` is ONE member of a block-diagonal batch of identical structures (ngpde_node_gat_create_batch)"""
+
+class _OdePlan:
+    """A device-resident solve + discrete adjoint chosen by the library's ONE create call (ngpde_ode_create: include/ngpde.h, csrc/api_ode.hip):
+    the right-hand side is described, the library checks that its layers chain and picks the plan -- a GAT-style layer (ngpde_node_gat_*),
+    VMHConv(phi, gamma) (ngpde_node_vmh_*) or the two-GCNConv chain (ngpde_node_gcn2_*).  Holds the tape of ONE solve."""
+
+    def __init__(self, handle, desc, kind):
         self.lib = _lib.load()
         _lib.flush_destroy()
         self.handle = handle
         self.ptr = None
         self.gen = 0
-        self.members = int(members)
+        self.kind = kind
+        self.members = int(desc.members)
         self.n_nodes = int(handle._n_nodes)
-        out = C.c_void_p()
-        _lib.check(self.lib.ngpde_node_gat_create_batch(handle.ptr, self.members, int(heads), int(c), float(slope), int(act),
-                                                        _lib.TABLEAU[tableau], int(n_steps), float(dt), int(with_backward), C.byref(out)))
-        self.ptr = out
+        self.n_first, self.n_steps = int(desc.n_phi), int(desc.n_steps)
+        out, fl = C.c_void_p(), C.c_int32()
+        _lib.check(self.lib.ngpde_ode_create(handle.ptr, C.byref(desc), C.byref(out), C.byref(fl)))
+        self.ptr, self._flags = out, fl.value
 
     def tape_bytes(self):
-        return int(self.lib.ngpde_node_gat_tape_bytes(self.ptr))
+        return int(self.lib.ngpde_ode_tape_bytes(self.ptr))
 
     def flags(self):
-        return {"persistent_fwd", "persistent_bwd", "gat"}
+        return {name for bit, name in _FLAG_NAMES if self._flags & bit} | {self.kind}
 
     def fault(self):
         f = C.c_int32()
-        _lib.check(self.lib.ngpde_node_gat_fault(self.ptr, _lib.current_stream(), C.byref(f)))
+        _lib.check(self.lib.ngpde_ode_fault(self.ptr, _lib.current_stream(), C.byref(f)))
         return bool(f.value)
 
     def claim(self):
@@ -218,86 +223,81 @@ class _GatPlan:
     def __del__(self):
         try:
             if self.ptr:
-                _lib.destroy_later("ngpde_node_gat_destroy", self.ptr)
+                _lib.destroy_later("ngpde_ode_destroy", self.ptr)
                 self.ptr = None
         except Exception:
             pass
 
 
-class _NodeGatFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, u, wt, a, bias, plan):
-        lib = _lib.load()
-        u, wt, a = u.contiguous(), wt.contiguous(), a.contiguous()
-        uT = torch.empty_like(u)
-        _lib.check(lib.ngpde_node_gat_forward(plan.ptr, _lib.ptr(u), _lib.ptr(wt), _lib.ptr(a), _lib.ptr(bias), _lib.ptr(uT),
-                                              _lib.current_stream()))
-        plan.gen += 1
-        ctx.plan, ctx.gen, ctx.token = plan, plan.gen, plan.claim()
-        ctx.save_for_backward(wt, a)
-        ctx.has_bias, ctx.shape = bias is not None, u.shape
-        return uT
+def _ode_desc(rhs, tableau, n_steps, dt, with_backward, members=1, **kw):
+    d = _lib.OdeDesc()
+    d.rhs, d.tableau, d.n_steps, d.dt, d.with_backward, d.members = rhs, _lib.TABLEAU[tableau], int(n_steps), float(dt), int(with_backward), int(members)
+    for k, v in kw.items():
+        if k in ("phi_dims", "phi_acts", "gamma_dims", "gamma_acts"):
+            for j, t in enumerate(v):
+                getattr(d, k)[j] = int(t)
+        else:
+            setattr(d, k, v)
+    return d
+
+
+class _NodeOdeFn(torch.autograd.Function):
+    """u(T) -- or with saveat the [T][N] array of the saved states -- of the plan's solve (ngpde_ode_forward), its pullback the discrete
+    adjoint (ngpde_ode_backward).  args: u, plan, (save_every, save_start) or None, the attention vector or None, then per layer (weight
+    [in][out], bias or None): the first `plan.n_first` layers are the descriptor's `first` stack (phi / the GAT weight / layer_1, layer_2),
+    the rest its `second` (gamma)."""
 
     @staticmethod
-    def backward(ctx, duT):
+    def forward(ctx, u, plan, save, att, *wb):
+        lib = _lib.load()
+        u = u.contiguous()
+        ws = [w.contiguous() for w in wb[0::2]]
+        bs = [None if b is None else b.contiguous() for b in wb[1::2]]
+        att = None if att is None else att.contiguous()
+        nf = plan.n_first if plan.n_first else len(ws)
+        prm = _lib.OdeParams()
+        for l, (w, b) in enumerate(zip(ws, bs)):
+            blk, j = (prm.first, l) if l < nf else (prm.second, l - nf)
+            blk.weight[j], blk.bias[j] = w.data_ptr(), (b.data_ptr() if b is not None else None)
+        prm.attention = att.data_ptr() if att is not None else None
+        k, start = save if save is not None else (0, 0)
+        out = torch.empty_like(u) if save is None else torch.empty((plan.n_steps // k + int(start), u.numel()), dtype=torch.float32, device=u.device)
+        _lib.check(lib.ngpde_ode_forward(plan.ptr, _lib.ptr(u), C.byref(prm), int(k), int(start), _lib.ptr(out), _lib.current_stream()))
+        plan.gen += 1
+        ctx.plan, ctx.gen, ctx.token, ctx.save, ctx.nf = plan, plan.gen, plan.claim(), (int(k), int(start)), nf
+        ctx.save_for_backward(*([att] if att is not None else []), *ws)
+        ctx.has_att, ctx.has_bias, ctx.ushape = att is not None, [b is not None for b in bs], u.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
         lib = _lib.load()
         plan = ctx.plan
         if ctx.gen != plan.gen:
             raise _lib.NgpdeError(_lib.ERR_STATE, "NeuralODE: another forward solve has replaced this solve's tape")
-        wt, a = ctx.saved_tensors
-        dev = wt.device
-        du0 = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
-        dwt, da = torch.empty_like(wt), torch.empty_like(a)
-        db = torch.empty((wt.shape[1],), dtype=torch.float32, device=dev) if ctx.has_bias else None
-        _lib.check(lib.ngpde_node_gat_backward(plan.ptr, _lib.ptr(wt), _lib.ptr(a), _lib.ptr(duT.contiguous()), _lib.ptr(du0),
-                                               _lib.ptr(dwt), _lib.ptr(da), _lib.ptr(db), _lib.current_stream()))
+        saved = list(ctx.saved_tensors)
+        att = saved.pop(0) if ctx.has_att else None
+        ws = saved
+        dev = ws[0].device
+        dout = dout.contiguous()
+        du0 = torch.empty(ctx.ushape, dtype=torch.float32, device=dev)
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty((w.shape[1],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
+        datt = torch.empty_like(att) if att is not None else None
+        prm, gr = _lib.OdeParams(), _lib.OdeGrads()
+        for l, (w, dw, db) in enumerate(zip(ws, dws, dbs)):
+            (blk, gb), j = ((prm.first, gr.first), l) if l < ctx.nf else ((prm.second, gr.second), l - ctx.nf)
+            blk.weight[j] = w.data_ptr()
+            gb.dweight[j], gb.dbias[j] = dw.data_ptr(), (db.data_ptr() if db is not None else None)
+        prm.attention = att.data_ptr() if att is not None else None
+        gr.dattention = datt.data_ptr() if datt is not None else None
+        _lib.check(lib.ngpde_ode_backward(plan.ptr, C.byref(prm), ctx.save[0], ctx.save[1], _lib.ptr(dout), _lib.ptr(du0), C.byref(gr),
+                                          _lib.current_stream()))
         plan._pending = False
-        return du0, dwt, da, db, None
-
-
-class _VmhPlan:
-    """Device-resident solve + discrete adjoint with VMHConv(phi, gamma) as the right-hand side (ngpde_node_vmh_*: one persistent
-    launch per direction + one weight-pullback GEMM per Dense layer).  Holds the tape of ONE solve (every layer's input rows and
-    dz rows of every right-hand-side evaluation)."""
-
-    def __init__(self, handle, pos, pd, phi_dims, phi_acts, gam_dims, gam_acts, aggr, tableau, n_steps, dt, with_backward):
-        self.lib = _lib.load()
-        _lib.flush_destroy()
-        self.handle = handle
-        self.ptr = None
-        self.gen = 0
-        self.members = 1
-        self.n_nodes = int(handle._n_nodes)
-        self.n_phi, self.n_gam = len(phi_acts), len(gam_acts)
-        self.n_steps = int(n_steps)
-        out = C.c_void_p()
-        ia = lambda v: (C.c_int32 * len(v))(*[int(t) for t in v])
-        _lib.check(self.lib.ngpde_node_vmh_create(handle.ptr, 1, int(pd), _lib.ptr(pos), self.n_phi, ia(phi_dims), ia(phi_acts), self.n_gam,
-                                                  ia(gam_dims), ia(gam_acts), int(aggr), _lib.TABLEAU[tableau], int(n_steps), float(dt),
-                                                  int(with_backward), C.byref(out)))
-        self.ptr = out
-
-    def tape_bytes(self):
-        return int(self.lib.ngpde_node_vmh_tape_bytes(self.ptr))
-
-    def flags(self):
-        return {"persistent_fwd", "persistent_bwd", "vmh"}
-
-    def fault(self):
-        f = C.c_int32()
-        _lib.check(self.lib.ngpde_node_vmh_fault(self.ptr, _lib.current_stream(), C.byref(f)))
-        return bool(f.value)
-
-    claim = _GatPlan.claim
-    busy = _GatPlan.busy
-
-    def __del__(self):
-        try:
-            if self.ptr:
-                _lib.destroy_later("ngpde_node_vmh_destroy", self.ptr)
-                self.ptr = None
-        except Exception:
-            pass
+        grads = []
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return (du0, None, None, datt, *grads)
 
 
 def _padded_batch(g, device):
@@ -371,66 +371,6 @@ def _canonical_batch(g, device):
     parts = [np.arange(mg.num_nodes, dtype=np.int64) + off0[slots[id(mg)].pop()] for mg in members]
     g._vmh_canon = (g0, torch.as_tensor(np.concatenate(parts), device=device))
     return g._vmh_canon
-
-
-def _ptrs(ts):
-    return (C.c_void_p * max(len(ts), 1))(*[(t.data_ptr() if t is not None else None) for t in ts])
-
-
-class _NodeVmhFn(torch.autograd.Function):
-    """u(T) = solve(du/dt = VMHConv(phi, gamma)(u)) on the device-resident plan; args: u [N], plan, (save_every, save_start) or None,
-    then per layer (weight [in][out], bias or None) of phi followed by gamma's.  With saveat the result is the [T][N] array of the
-    saved states (ngpde_node_vmh_forward_saveat) and the cotangent of every one of them enters the adjoint at its time."""
-
-    @staticmethod
-    def forward(ctx, u, plan, save, *wb):
-        lib = _lib.load()
-        u = u.contiguous()
-        ws = [w.contiguous() for w in wb[0::2]]
-        bs = [None if b is None else b.contiguous() for b in wb[1::2]]
-        n_phi = plan.n_phi
-        if save is None:
-            uT = torch.empty_like(u)
-            _lib.check(lib.ngpde_node_vmh_forward(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]), _ptrs(bs[n_phi:]),
-                                                  _lib.ptr(uT), _lib.current_stream()))
-        else:
-            k, start = save
-            uT = torch.empty((plan.n_steps // k + int(start), u.numel()), dtype=torch.float32, device=u.device)
-            _lib.check(lib.ngpde_node_vmh_forward_saveat(plan.ptr, _lib.ptr(u), _ptrs(ws[:n_phi]), _ptrs(bs[:n_phi]), _ptrs(ws[n_phi:]),
-                                                         _ptrs(bs[n_phi:]), int(k), int(start), _lib.ptr(uT), _lib.current_stream()))
-        ctx.save = save
-        plan.gen += 1
-        ctx.plan, ctx.gen, ctx.token = plan, plan.gen, plan.claim()
-        ctx.save_for_backward(*ws)
-        ctx.has_bias = [b is not None for b in bs]
-        return uT
-
-    @staticmethod
-    def backward(ctx, duT):
-        lib = _lib.load()
-        plan = ctx.plan
-        if ctx.gen != plan.gen:
-            raise _lib.NgpdeError(_lib.ERR_STATE, "NeuralODE: another forward solve has replaced this solve's tape")
-        ws = list(ctx.saved_tensors)
-        n_phi = plan.n_phi
-        dev = ws[0].device
-        duT = duT.contiguous()
-        du0 = torch.empty((duT.shape[-1],), dtype=torch.float32, device=dev)
-        dws = [torch.empty_like(w) for w in ws]
-        dbs = [torch.empty((w.shape[1],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
-        if ctx.save is None:
-            _lib.check(lib.ngpde_node_vmh_backward(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), _lib.ptr(duT), _lib.ptr(du0),
-                                                   _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]), _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]),
-                                                   _lib.current_stream()))
-        else:
-            _lib.check(lib.ngpde_node_vmh_backward_saveat(plan.ptr, _ptrs(ws[:n_phi]), _ptrs(ws[n_phi:]), int(ctx.save[0]), int(ctx.save[1]),
-                                                          _lib.ptr(duT), _lib.ptr(du0), _ptrs(dws[:n_phi]), _ptrs(dbs[:n_phi]),
-                                                          _ptrs(dws[n_phi:]), _ptrs(dbs[n_phi:]), _lib.current_stream()))
-        plan._pending = False
-        grads = []
-        for dw, db in zip(dws, dbs):
-            grads += [dw, db]
-        return (du0, None, None, *grads)
 
 
 # ---- any right-hand side: explicit RK stepping with every combination as ONE library launch ---------------------------------
@@ -841,8 +781,8 @@ class NeuralODE(AbstractExplicitLayer):
         if len(pool) >= self.max_outstanding:
             raise _lib.NgpdeError(_lib.ERR_STATE, f"NeuralODE: {len(pool)} solves await their backward pass on this graph; "
                                                   "each holds a tape -- run backward (or raise NeuralODE.max_outstanding)")
-        plan = _GatPlan(handle, m.heads, m.out_chs, m.negative_slope, m.act, self.solver, self.n_steps, self.dt, with_backward,
-                        members=len(members) if member_plan else 1)
+        plan = _OdePlan(handle, _ode_desc(_lib.RHS_GAT, self.solver, self.n_steps, self.dt, with_backward, len(members) if member_plan else 1, width=64,
+                                          act=int(m.act), heads=int(m.heads), head_width=int(m.out_chs), negative_slope=float(m.negative_slope)), "gat")
         pool.append(plan)
         return plan
 
@@ -883,10 +823,7 @@ class NeuralODE(AbstractExplicitLayer):
         # input width, every bias against its layer, phi's input = [h_i; h_j - h_i; x_j - x_i], gamma's = [h_i; m_i]) would make the
         # kernels read past the weight arrays -- the reference fails in the matrix product with a DimensionMismatch
         k = 0
-        for name, d, first in (("ϕ", dims[0], 2 + pd), ("γ", dims[1], 1 + dims[0][-1])):
-            if d[0] != first:
-                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: NeuralODE(VMHConv): {name}.layer_1 takes {d[0]} "
-                                             f"inputs, the layer feeds it {first}")
+        for name, d in (("ϕ", dims[0]), ("γ", dims[1])):      # (that the stacks chain as the layer feeds them is ngpde_ode_create's check)
             _check_plan_shapes("NeuralODE(VMHConv)", u, u.shape[0], 1,
                                [(f"{name}.layer_{l + 1}.weight", wb[k + 2 * l], (d[l], d[l + 1])) for l in range(len(d) - 1)],
                                [(f"{name}.layer_{l + 1}.bias", wb[k + 2 * l + 1], d[l + 1]) for l in range(len(d) - 1)])
@@ -941,7 +878,9 @@ class NeuralODE(AbstractExplicitLayer):
             for old_key in [k for k in self._plans if k[0] == "vmh" and k[1] != id(handle) and k[-1]]:
                 self._plans.pop(old_key)
         try:
-            plan = _VmhPlan(handle, pos, pd, dims[0], acts[0], dims[1], acts[1], aggr, self.solver, self.n_steps, self.dt, needs_grad)
+            plan = _OdePlan(handle, _ode_desc(_lib.RHS_VMH, self.solver, self.n_steps, self.dt, needs_grad, width=1, pos_width=int(pd), aggr=int(aggr),
+                                              pos=pos.data_ptr(), n_phi=len(acts[0]), phi_dims=dims[0], phi_acts=acts[0], n_gamma=len(acts[1]),
+                                              gamma_dims=dims[1], gamma_acts=acts[1]), "vmh")
         except _lib.NgpdeError as e:
             # the tapes of a solve -- every layer's input rows and dz rows of every right-hand-side evaluation, 64 floats wide -- did not
             # fit the device (the library parks and re-uses the tapes of plans that went away, and frees them before it gives up): the
@@ -984,7 +923,7 @@ class NeuralODE(AbstractExplicitLayer):
             if a.numel() != 2 * gm.out_chs * gm.heads:
                 raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, f"DimensionMismatch: NeuralODE(GATConv): attention vector has "
                                              f"{a.numel()} entries, expected 2 x {gm.out_chs} x {gm.heads}")
-            uT = _NodeGatFn.apply(u, w, a, b, gplan)
+            uT = _NodeOdeFn.apply(u, gplan, None, a, w, b)
             return uT.T, st
         vplan = self.vmh_plan_for(ps, st, u, needs_grad)
         if vplan is not None:
@@ -999,11 +938,11 @@ class NeuralODE(AbstractExplicitLayer):
             if index is not None:      # (a padded batch: the real nodes' rows among the isolated padding nodes')
                 uin = _rows_index(uin, index, plan_v.n_nodes, True)
             if self.save_every:      # saveat: the (1 x N x T) array of the solution at t0 (+ j saveat)
-                us = _NodeVmhFn.apply(uin, plan_v, (self.save_every, self.save_start), *wb)
+                us = _NodeOdeFn.apply(uin, plan_v, (self.save_every, self.save_start), None, *wb)
                 if index is not None:
                     us = _rows_index(us, index, plan_v.n_nodes, False)
                 return us.T.unsqueeze(0), st
-            uT = _NodeVmhFn.apply(uin, plan_v, None, *wb)
+            uT = _NodeOdeFn.apply(uin, plan_v, None, None, *wb)
             if index is not None:
                 uT = _rows_index(uT, index, plan_v.n_nodes, False)
             return uT.reshape(u.shape).T, st

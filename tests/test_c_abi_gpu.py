@@ -42,6 +42,21 @@ def exe_layers(tmp_path_factory):
     return build(tmp_path_factory, "layers_roundtrip")
 
 
+@pytest.fixture(scope="module")
+def exe_ode(tmp_path_factory):
+    return build(tmp_path_factory, "ode_roundtrip")
+
+
+def test_solver_level_create_call_from_plain_c(exe_ode):
+    # ngpde_ode_create / _forward / _backward (csrc/api_ode.hip): NeuralODE(VMHConv) with saveat and NeuralODE(GCNConv, GCNConv) bit for bit
+    # the plans' own entries, one Euler step against a double-precision loop, the refusals (DimensionMismatch / ERR_UNSUPPORTED)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("NGPDE_")}
+    r = subprocess.run([exe_ode], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout and "all comparisons within tolerance" in r.stdout
+    assert r.stdout.count("ok: ") >= 14, r.stdout
+
+
 def test_layer_level_entries_from_plain_c(exe_layers):
     # MPPDEConv, VMHConv, ExplicitEdgeConv, GNOConv: forward and pullback with ONE call each (ngpde_edge_layer_*, ngpde_gno_layer_*), values against double-precision
     # loops on the concatenated message inputs, gradients against central differences of those loops
