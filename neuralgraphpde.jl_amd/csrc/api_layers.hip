@@ -13,6 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 using namespace ngpde;
@@ -79,6 +82,30 @@ struct RowSpec {   // ngpde_row_blocks_gather / _scatter tables of phi's first w
 };
 
 // Everything a forward / backward pair of one layer call needs to agree on: shapes, the path taken, and where each array lives.
+// What the training forward decided, remembered per workspace so that the pullback can refuse a workspace it would misread: the plan
+// is re-derived by every call from the descriptor, the graph and the environment switches (NGPDE_NO_FUSED_EDGE, NGPDE_DEEP_EDGE_BWD,
+// NGPDE_GNO_MATERIALIZE, NGPDE_NO_GNO_GFORM ...), and the pullback reads saved activations at offsets of ITS plan -- a switch flipped or
+// a descriptor changed between the two calls used to give wrong gradients without an error.  Host memory only (a few words per live
+// workspace, bounded), nothing on the stream: the calls stay capture-safe.  A workspace the table does not know is trusted as before.
+struct PlanStamp { const void *ws; uint64_t key; };
+inline std::mutex &stamp_mu() { static std::mutex m; return m; }
+inline std::vector<PlanStamp> &stamps() { static std::vector<PlanStamp> v; return v; }
+inline void stamp_set(const void *ws, uint64_t key) {
+  std::lock_guard<std::mutex> lk(stamp_mu());
+  auto &v = stamps();
+  for (auto &e : v)
+    if (e.ws == ws) { e.key = key; return; }
+  if (v.size() >= 256) v.erase(v.begin());   // (oldest first: a long-running host that never runs the pullback of old workspaces)
+  v.push_back({ws, key});
+}
+inline bool stamp_agrees(const void *ws, uint64_t key) {
+  std::lock_guard<std::mutex> lk(stamp_mu());
+  for (auto &e : stamps())
+    if (e.ws == ws) return e.key == key;
+  return true;
+}
+inline uint64_t mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x9E3779B97F4A7C15ull + (h >> 29); }
+
 struct Plan {
   int64_t N = 0, E = 0;
   int G = 1, kind = 0, aggr = 1;
@@ -469,6 +496,22 @@ int32_t make_gno_plan(const ngpde_graph *g, const ngpde_gno_layer_t &L, bool tra
   return NGPDE_OK;
 }
 
+uint64_t edge_plan_key(const ngpde_graph *g, const Plan &p) {
+  uint64_t h = mix(0x6e677064u, (uint64_t)(uintptr_t)g);
+  h = mix(h, (uint64_t)p.N); h = mix(h, (uint64_t)p.E); h = mix(h, (uint64_t)p.kind * 16 + p.aggr);
+  h = mix(h, ((uint64_t)p.h1 << 32) | (uint64_t)(p.n_tail * 64 + p.n_upd));
+  h = mix(h, (uint64_t)p.fused_msg | (uint64_t)p.fused_bwd << 1 | (uint64_t)p.need_dE << 2 | (uint64_t)p.chain2 << 3 | (uint64_t)p.chain2_fused << 4 |
+             (uint64_t)p.pair_shared << 5);
+  return mix(h, (uint64_t)p.total_floats);
+}
+uint64_t gno_plan_key(const ngpde_graph *g, const GnoPlan &p) {
+  uint64_t h = mix(0x676e6f00u, (uint64_t)(uintptr_t)g);
+  h = mix(h, (uint64_t)p.N); h = mix(h, (uint64_t)p.E); h = mix(h, ((uint64_t)p.cin << 32) | (uint64_t)p.cout);
+  h = mix(h, ((uint64_t)p.kdim << 32) | (uint64_t)(p.L * 64 + p.aggr * 8 + p.act1));
+  h = mix(h, (uint64_t)p.reassoc | (uint64_t)p.fused_msg << 1 | (uint64_t)p.fused_agg << 2 | (uint64_t)p.has_b2 << 3 | (uint64_t)p.gform << 4 | (uint64_t)p.nsplit << 8);
+  return mix(h, (uint64_t)p.total_floats);
+}
+
 }  // namespace
 
 extern "C" {
@@ -494,6 +537,7 @@ int32_t ngpde_edge_layer_forward(const ngpde_graph_t *g, const ngpde_edge_layer_
   NGPDE_REQUIRE(y != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_edge_layer_forward: y is NULL");
   NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
                 "ngpde_edge_layer_forward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
+  if (training) stamp_set(workspace, edge_plan_key(g, p));
   const ngpde_mlp_t &phi = L->phi;
   // the recombined first-layer weights in one launch
   float *outs[3] = {p.wA, p.wB, p.wD};
@@ -565,6 +609,9 @@ int32_t ngpde_edge_layer_backward(const ngpde_graph_t *g, const ngpde_edge_layer
   if (g->n_nodes == 0) return NGPDE_OK;
   NGPDE_REQUIRE(dy != nullptr && dphi != nullptr && (p.n_upd == 0 || dupd != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
                 "ngpde_edge_layer_backward: dy or a gradient table is NULL");
+  NGPDE_REQUIRE(stamp_agrees(workspace, edge_plan_key(g, p)), NGPDE_ERR_STATE,
+                "ngpde_edge_layer_backward: this workspace was filled by a forward that chose another kernel sequence or layout (descriptor, graph or "
+                "an NGPDE_* path switch changed between the two calls)");
   NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
                 "ngpde_edge_layer_backward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
   const ngpde_mlp_t &phi = L->phi;
@@ -729,6 +776,7 @@ int32_t ngpde_gno_layer_forward(const ngpde_graph_t *g, const ngpde_gno_layer_t 
   NGPDE_REQUIRE(y != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_gno_layer_forward: y is NULL");
   NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
                 "ngpde_gno_layer_forward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
+  if (training) stamp_set(workspace, gno_plan_key(g, p));
   const ngpde_mlp_t &phi = L->phi;
   float *outs[3];
   int no = 0;
@@ -812,6 +860,9 @@ int32_t ngpde_gno_layer_backward(const ngpde_graph_t *g, const ngpde_gno_layer_t
   for (int l = 0; l < p.L; ++l)
     NGPDE_REQUIRE(dphi->dweight[l] != nullptr && (phi.bias[l] == nullptr || dphi->dbias[l] != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
                   "ngpde_gno_layer_backward: phi.layer_%d without its gradient buffers", l + 1);
+  NGPDE_REQUIRE(stamp_agrees(workspace, gno_plan_key(g, p)), NGPDE_ERR_STATE,
+                "ngpde_gno_layer_backward: this workspace was filled by a forward that chose another kernel sequence or layout (descriptor, graph or "
+                "an NGPDE_* path switch changed between the two calls)");
   NGPDE_REQUIRE(workspace != nullptr && workspace_bytes >= p.total_floats * sizeof(float) + kArenaSlack, NGPDE_ERR_WORKSPACE,
                 "ngpde_gno_layer_backward: workspace of %zu bytes, %zu needed", workspace_bytes, p.total_floats * sizeof(float) + kArenaSlack);
   const int32_t one[1] = {1};

@@ -273,6 +273,36 @@ def test_second_backward_through_a_retained_graph(monkeypatch):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_pullback_refuses_a_workspace_filled_under_another_plan(monkeypatch):
+    # the plan (kernel sequence + workspace layout) is re-derived by every call; a path switch flipped between the forward and its pullback
+    # used to give wrong gradients silently -- now the pullback compares the plan with the one the forward recorded for this workspace
+    g = spatial(640, 9)
+    phi = ng.Chain(ng.Dense(4, 32, "tanh"), ng.Dense(32, 16))
+    gam = ng.Chain(ng.Dense(17, 24, "tanh"), ng.Dense(24, 1))
+    layer = ng.VMHConv(phi, gam, initialgraph=g)
+    ps0, st = ng.setup(81, layer)
+    ps = prep(ps0, 81)
+    x = torch.randn(1, 640, device=DEV, requires_grad=True)
+    y, _ = layer(x, ps, st)
+    monkeypatch.setenv("NGPDE_NO_FUSED_EDGE_BWD", "1")
+    with pytest.raises(_lib.NgpdeError) as err:
+        y.sum().backward()
+    assert err.value.code == _lib.ERR_STATE and "another kernel sequence" in str(err.value)
+    monkeypatch.delenv("NGPDE_NO_FUSED_EDGE_BWD")
+    y2, _ = layer(x, ps, st)
+    y2.sum().backward()                      # the same switches on both sides: fine
+    g2 = dense_spatial(300, 70, 23)
+    gno = ng.GNOConv((32, 32), ng.Chain(ng.Dense(6, 64, "relu"), ng.Dense(64, 32 * 32)), "relu", initialgraph=g2, aggr="mean")
+    psg0, stg = ng.setup(82, gno)
+    psg = prep(psg0, 82)
+    xg = torch.randn(32, 300, device=DEV, requires_grad=True)
+    yg, _ = gno(xg, psg, stg)                # (training, 70 edges per node: the aggregate-then-transform form)
+    monkeypatch.setenv("NGPDE_NO_GNO_GFORM", "1")
+    with pytest.raises(_lib.NgpdeError) as err:
+        yg.sum().backward()
+    assert err.value.code == _lib.ERR_STATE
+
+
 def test_entry_rejects_what_the_reference_rejects():
     lib = _lib.load()
     g = spatial(64, 2)
