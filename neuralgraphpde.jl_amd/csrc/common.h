@@ -126,6 +126,7 @@ struct Comb {
   float coef_self = 0.f;
 };
 
+struct OwnFirst;   // a solver plan's own-first slot tables (below)
 struct FusedFwdArgs {
   const ngpde_graph *g = nullptr;
   int d = 0, act = 0;
@@ -137,6 +138,7 @@ struct FusedFwdArgs {
   float *save_z = nullptr;       // [N][d] or null
   uint8_t *save_mask = nullptr;  // [fused_mask_bytes] or null: 4 sign bits of z per thread and row (relu' for the pullback)
   bool pre = false;              // pre-scaled pipeline: x holds c .* x, y / comb_out are written as c .* y (see fused_prescaled_supported)
+  const OwnFirst *of = nullptr;  // a solver plan's own-first slot tables (halo path only), or NULL: the handle's lists
   // optional Runge-Kutta stage combination evaluated on the freshly computed rows of y
   bool has_comb = false;
   Comb comb;
@@ -164,6 +166,7 @@ struct FusedBwdArgs {
   const float *z = nullptr;      // [N][d] saved pre-activation (or y for relu/identity); unused when mask is given
   const uint8_t *mask = nullptr; // sign bits written by the forward launch (same tile / thread layout), relu only
   bool pre = false;              // pre-scaled pipeline: g_in holds c .* G, T is dL/d(c .* x), g_out is written as c .* G
+  const OwnFirst *of = nullptr;  // as in FusedFwdArgs (the by-source tables)
   const float *saved_agg = nullptr;  // [N][d]
   const float *wt = nullptr;     // [d][d]
   float *g_out = nullptr;        // [N][d]  dZ * W
@@ -181,6 +184,23 @@ int32_t launch_reduce_slabs(const float *slab, int n_slabs, int len, int ct, flo
 int32_t launch_zero(void *ptr, size_t bytes, hipStream_t stream);   // graph-capture-safe replacement of hipMemsetAsync(ptr, 0, bytes)
 // ---- persistent solver launches (node_persistent.hip): the whole forward solve / adjoint of the 2 x GCNConv(64 => 64) plan as
 // ONE launch each, tiles synchronised by per-tile phase flags
+// Own-first slot tables of a solver plan over GCNConv layers (node_persistent.hip: own_first_tables_build).  A 32-row tile's own rows
+// are in LDS when a phase of the persistent solver starts; what it waits for are the rows of other tiles.  Per direction the plan
+// holds a COPY of the handle's slot bytes in which every row lists the slots of its tile's own rows first, padded with the all-zero
+// row to a whole number of 4-slot rounds common to the four rows of a wave, then the slots of foreign rows -- and the schedule
+// entries with the padded length in place of the degree, so that every kernel of the plan (persistent in all its forms, replayed)
+// walks the same rounds in the same order and the results stay bitwise comparable -- plus, per wave, the number of own rounds,
+// which the one-tile persistent kernels sum BEFORE they wait for their neighbours.  The handle's own lists are untouched (the
+// edge-function, GAT and VMH kernels index per-edge arrays by a row's CSR position).
+struct OwnFirst {
+  uint8_t *slots[2] = {nullptr, nullptr};   // [n_sched][kSlotWidth]            (0: by target, 1: by source)
+  int4 *sched[2] = {nullptr, nullptr};      // [n_sched] {node, row start, PADDED length, bits of c}
+  float *slot_w[2] = {nullptr, nullptr};    // [n_sched][kSlotWidth] or NULL (unweighted)
+  uint8_t *pre[2] = {nullptr, nullptr};     // [n_tiles][8] own rounds of wave w's rows 4 w .. 4 w + 3 (0: that wave keeps the handle's order)
+};
+int32_t own_first_tables_build(const ngpde_graph *g, OwnFirst *of, hipStream_t stream);
+void own_first_tables_free(OwnFirst *of);
+
 struct NodePersist {
   int n_tiles = 0;
   int pair_wgs = 0;            // tile-pair mode: workgroups of a launch (each holds tiles t and t + pair_wgs), else 0
@@ -220,6 +240,7 @@ struct NodePersistFwd {
   float *state = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool no_latch = false;       // the caller latches the fault word in its next kernel (node.hip: the exit scaling)
+  const OwnFirst *of = nullptr;   // the plan's own-first slot tables, or NULL (the handle's lists)
 };
 struct NodePersistBwd {
   const ngpde_graph *g = nullptr;
@@ -236,6 +257,7 @@ struct NodePersistBwd {
   float *ubar = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool no_latch = false;       // the caller latches the fault word in its next kernel (node.hip: the slab reduction)
+  const OwnFirst *of = nullptr;   // the plan's own-first slot tables, or NULL (the handle's lists)
 };
 const unsigned *node_persistent_abort_word(const NodePersist *ps);   // the abort word of the plan's persistent launches
 bool node_persistent_interleave_env();

@@ -946,6 +946,10 @@ int32_t launch_fused_fwd(const FusedFwdArgs &a, hipStream_t stream) {
   FwdK k;
   k.x = a.x; k.sched = g->by_t.sched; k.ent = g->by_t.ent; k.ell = g->by_t.ell;
   k.halo = g->by_t.halo; k.tile_info = g->by_t.tile_info; k.slots = g->by_t.slots; k.slot_w = g->by_t.slot_w;
+  if (a.of && a.of->slots[0] && g->by_t.halo_ok && !no_halo_env()) {   // a solver plan's own-first tables (LDS-staged aggregation only:
+    k.slots = a.of->slots[0]; k.sched = a.of->sched[0];                 // the same rows in another order, padded lengths in the schedule)
+    if (k.slot_w) k.slot_w = a.of->slot_w[0];
+  }
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.wt = a.wt; k.bias = a.bias; k.y = a.y; k.save_agg = a.save_agg; k.save_z = a.save_z;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb); k.comb_out = a.comb_out;
@@ -998,6 +1002,10 @@ int32_t launch_fused_bwd(const FusedBwdArgs &a, hipStream_t stream) {
   BwdK k;
   k.g_in = a.g_in; k.sched = g->by_s.sched; k.ent = g->by_s.ent; k.ell = g->by_s.ell;
   k.halo = g->by_s.halo; k.tile_info = g->by_s.tile_info; k.slots = g->by_s.slots; k.slot_w = g->by_s.slot_w;
+  if (a.of && a.of->slots[1] && g->by_s.halo_ok && !no_halo_env()) {
+    k.slots = a.of->slots[1]; k.sched = a.of->sched[1];
+    if (k.slot_w) k.slot_w = a.of->slot_w[1];
+  }
   k.self_loops = g->self_loops; k.n_tiles = fused_num_blocks(g->n_nodes); k.act = a.act;
   k.has_comb = a.has_comb ? 1 : 0; k.comb = to_dev(a.comb);
   k.store_t = a.store_t; k.store_v = a.store_v; k.v_scale = a.v_scale;

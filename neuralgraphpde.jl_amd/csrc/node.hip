@@ -241,6 +241,8 @@ struct ngpde_node {
   bool ztape_mode = false;
   float *ztape = nullptr;
   NodePersist persist;
+  OwnFirst of;               // the plan's own-first slot tables (common.h): every kernel of the plan, persistent or replayed, reads them
+  bool has_of = false;
   float *pbuf = nullptr;     // layer-1 output exchanged between tiles in the persistent forward
   // a batch (members > 1) runs two members at a time per workgroup (node_persistent.hip, "slots"): the exchanged arrays
   // (ustage, pbuf, g1, g2) hold one [N][d] array per slot, pubar is the adjoint's stage-adjoint scratch [2][5][N][d]
@@ -317,6 +319,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f1.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 4) : nullptr;
       f1.save_mask = p->mask_mode ? p->mask_slot(n, i, 1) : nullptr;
       f1.pre = p->pre;
+      f1.of = p->has_of ? &p->of : nullptr;
       if (prof) prof->want(0, &f1.ev_start, &f1.ev_stop);
       if ((st = launch_fused_fwd(f1, stream))) return st;
       FusedFwdArgs f2;
@@ -328,6 +331,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
       f2.save_z = (p->with_bwd && p->needs_z) ? p->slot(n, i, 5) : nullptr;
       f2.save_mask = p->mask_mode ? p->mask_slot(n, i, 2) : nullptr;
       f2.pre = p->pre;
+      f2.of = p->has_of ? &p->of : nullptr;
       // epilogue: next stage input, or the step update after the last stage
       const bool last = (i == tb.S - 1);
       const std::vector<double> &row = last ? tb.b : tb.a[i + 1];
@@ -354,6 +358,7 @@ int32_t enqueue_forward(ngpde_node *p, hipStream_t stream, int *launches, Prof *
 void fill_dense(const ngpde_node *p, FusedBwdArgs &a, int layer, int step, int stage) {
   a.do_dense = true;
   a.pre = p->pre;
+  a.of = p->has_of ? &p->of : nullptr;
   if (p->mask_mode) a.mask = p->mask_slot(step, stage, layer);
   if (layer == 2) {
     a.z = p->needs_z ? p->slot(step, stage, 5) : p->slot(step, stage, 3);
@@ -423,6 +428,7 @@ int32_t enqueue_backward(ngpde_node *p, hipStream_t stream, int *launches, Prof 
         } else {
           e.do_dense = false;
           e.pre = p->pre;
+          e.of = p->has_of ? &p->of : nullptr;
         }
       }
       if (prof && e.do_dense) prof->want(3, &e.ev_start, &e.ev_stop);
@@ -455,6 +461,7 @@ int32_t enqueue_forward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_t
     a.tape = p->tape; a.masks = p->masks; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   }
   a.interleave = p->interleave; a.pair = p->pair; a.k_tiles = p->ktiles; a.state = p->kstate;
+  a.of = p->has_of ? &p->of : nullptr;
   a.ev_start = ev0; a.ev_stop = ev1;
   return launch_node_fwd_persistent(a, stream);
 }
@@ -469,6 +476,7 @@ int32_t enqueue_backward_persistent(ngpde_node *p, hipStream_t stream, hipEvent_
   a.tape = p->tape; a.masks = p->masks; a.row_elems = p->row_elems; a.mask_bytes = p->mask_bytes; a.ztape = p->ztape;
   a.slab_dw1 = p->slab_dw1; a.slab_db1 = p->slab_db1; a.slab_dw2 = p->slab_dw2; a.slab_db2 = p->slab_db2;
   a.interleave = p->interleave; a.pair = p->pair; a.ubar = p->pubar; a.k_tiles = p->ktiles;
+  a.of = p->has_of ? &p->of : nullptr;
   a.ev_start = ev0; a.ev_stop = ev1;
   int32_t st;
   if ((st = launch_node_bwd_persistent(a, stream))) return st;
@@ -543,6 +551,7 @@ int32_t ngpde_node_destroy(ngpde_node_t *p) {
   if (p->pubar) (void)hipFree(p->pubar);
   if (p->kstate) (void)hipFree(p->kstate);
   node_persistent_free(&p->persist);
+  own_first_tables_free(&p->of);
   delete p;
   return NGPDE_OK;
 }
@@ -640,6 +649,16 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
     node_persistent_free(&p->persist);
   }
   p->hub = hub;
+  // own-first slot tables (common.h: OwnFirst): for every pre-scaled plan on the handle's own tile lists -- persistent in any form or
+  // replayed, one member or a batch, weighted or not -- so that all of them sum a row's neighbours in ONE order and stay bitwise
+  // comparable; NGPDE_NO_OWN_FIRST=1 keeps the handle's order (A/B runs)
+  if (st == NGPDE_OK && p->pre && !hub) {
+    const char *nof = std::getenv("NGPDE_NO_OWN_FIRST");
+    if (!(nof && nof[0] == '1')) {
+      st = own_first_tables_build(g, &p->of, nullptr);
+      p->has_of = st == NGPDE_OK;
+    }
+  }
   p->ztape_mode = p->with_bwd && !p->mask_mode && p->persist_fwd && p->persist_bwd;
   p->slots = p->mask_mode ? 2 : (p->ztape_mode ? 4 : (p->with_bwd ? (p->needs_z ? 6 : 4) : 4));
   p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;

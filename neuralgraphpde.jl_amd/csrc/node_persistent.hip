@@ -89,6 +89,7 @@ struct TileMeta {
   const float *slot_w;   // [n_sched][kSlotWidth] edge weights in slot order, or NULL (unweighted)
   unsigned *flags, *abort_word;
   int n_tiles;
+  const uint8_t *of_pre;   // [n_tiles][8] own rounds per wave when slots / sched are a plan's own-first tables, else NULL
   int *stats;   // [n_tiles][2] (forward, adjoint): slot-phases of the last launch whose halo rows were gathered ahead of time
   // hub geometry (HUB kernels only; then `nbr` is [n_tiles][kHubNbr])
   const int *hub_halo;        // [n_tiles][kHubHalo] node ids, own rows first
@@ -326,54 +327,11 @@ __device__ __forceinline__ float4 tile_aggregate_rounds(const TileCtx &c, const 
 }
 
 
-// ---- own-first aggregation (round 6 experiment, NGPDE_OWN_FIRST=1; one-tile forward kernel only) -------------------
-// A tile's own 32 rows are in LDS when a phase starts; what it waits for are the ~25 rows of other tiles.  The row's slot bytes are
-// re-ordered ONCE per launch (the tile is the workgroup's for the whole solve): slots of own rows first, padded with the all-zero row
-// to the wave's number of own rounds, then the slots of foreign rows; the own rounds are summed under the wait for the flags.
-// Measured (tools/exp_own_first.py, profiles/r06_a_own_first.txt): forward launch 2.301 -> 2.234 ms (-2.9 %); with the foreign rows
-// loaded straight into registers by every 16-lane group instead of staged in LDS once per tile (2.4 x the row requests): 3.16 ms.
-// Another summation order than the replayed plan's, so NOT bitwise equal to it: a diagnostic switch, off by default.
-// Returns the wave's number of own rounds (wave-uniform); c.wmax becomes 4 x the wave's total number of rounds.
-__device__ __forceinline__ int own_first_reorder(TileCtx &c) {
-  unsigned *ls = const_cast<unsigned *>(c.lds_slots);
-  unsigned w[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) w[j] = ls[c.grp * 8 + j];
-  int no = 0, nf = 0;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-    no += b < (unsigned)kTM ? 1 : 0;
-    nf += (b >= (unsigned)kTM && b < (unsigned)kHaloCap) ? 1 : 0;
-  }
-  int pre = (no + 3) >> 2;
-  pre = max(pre, __shfl_xor(pre, 16));
-  pre = max(pre, __shfl_xor(pre, 32));
-  int tot = pre + ((nf + 3) >> 2);
-  tot = max(tot, __shfl_xor(tot, 16));
-  tot = max(tot, __shfl_xor(tot, 32));
-  pre = __builtin_amdgcn_readfirstlane(pre);
-  tot = __builtin_amdgcn_readfirstlane(tot);
-  if (tot > 8) return 0;   // (wave-uniform) does not fit the 32 slot bytes in this form: the row order stays as it is
-  if (c.q == 0) {
-    uint8_t *row = reinterpret_cast<uint8_t *>(ls + c.grp * 8);
-    int k = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-      if (b < (unsigned)kTM) row[k++] = (uint8_t)b;
-    }
-    for (; k < 4 * pre; ++k) row[k] = (uint8_t)kHaloCap;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const unsigned b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-      if (b >= (unsigned)kTM && b < (unsigned)kHaloCap) row[k++] = (uint8_t)b;
-    }
-    for (; k < 32; ++k) row[k] = (uint8_t)kHaloCap;
-  }
-  c.wmax = 4 * tot;
-  return pre;
-}
+// ---- own-first aggregation (round 6; the plan's OwnFirst tables, common.h) ------------------------------------------------------------
+// The slot bytes a plan's kernels read list every row's own-tile slots first (padded to the wave's number of own rounds), then the
+// foreign ones; TileMeta::of_pre names the own rounds per wave.  The one-tile kernels sum those rounds BEFORE they wait for their
+// neighbours' flags -- a tile's own rows are in LDS since its last epilogue -- and only the foreign rounds behind the gather.  Measured
+// with an in-kernel re-ordering of the same kind (profiles/r06_a_own_first.txt): forward launch 2.301 -> 2.234 ms.
 // rounds [r0, r1) of the row's slot words from LDS, same association as tile_aggregate
 __device__ __forceinline__ float4 tile_aggregate_rounds_range(const TileCtx &c, const unsigned (&sw)[8], const float *ldsXh, float4 a, int r0, int r1) {
   const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
@@ -637,10 +595,9 @@ struct PFwdK {
 // WGT (edge weights, src/layers.jl:206-231): the 4 KB of slot weights of the tile need LDS that two resident W^T do not leave, so layer 1's
 // W^T is B fragments in registers for the whole launch (16 per lane; the forward kernel has them to spare) and only W2^T is in LDS
 // HUB: the hub geometry (256-row halo, variable-length slot lists, long rows shared by the 32 lane groups, one workgroup per CU)
-template <int ACT, bool TAPE, bool WGT = false, bool HUB = false, int OF = 0>
+template <int ACT, bool TAPE, bool WGT = false, bool HUB = false>
 __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_kernel(const PFwdK p) {
   static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
-  static_assert(OF == 0 || (!HUB && !WGT), "own-first aggregation: the plain one-tile geometry");
   constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
   __shared__ __attribute__((aligned(16))) float lds[XH + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + MF + 48 + 4];
   static_assert(!HUB || sizeof(lds) <= 160 * 1024 - 64, "one workgroup per CU");
@@ -673,10 +630,10 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
   if (c.tid == 0) *s_ok = 1;
   const unsigned own = (unsigned)c.node * (unsigned)(PD * 4) + (unsigned)(c.q * 16);   // byte offset of this thread's 16 bytes in a [N][64] array
   __syncthreads();
+  // own rounds of this wave's rows (the plan's own-first tables; 0: everything is summed behind the gather, as without them)
   int of_pre = 0;
-  if constexpr (OF != 0) {
-    of_pre = own_first_reorder(c);
-    __syncthreads();
+  if constexpr (!HUB && !WGT) {
+    if (p.m.of_pre) of_pre = __builtin_amdgcn_readfirstlane((int)p.m.of_pre[(size_t)c.tile * 8 + c.wave_u]);
   }
   const float4 bias1 = reinterpret_cast<const float4 *>(ldsB)[c.q], bias2 = reinterpret_cast<const float4 *>(ldsB + PD)[c.q];
   bool ok = true;
@@ -688,8 +645,8 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
   // six named values written through component-wise selects (f4_sel): an array written as `k[j] = (j == i) ? yv : k[j]` ends
   // up in scratch memory
   float4 k0 = f4_zero(), k1 = f4_zero(), k2 = f4_zero(), k3 = f4_zero(), k4 = f4_zero(), k5 = f4_zero();
-  Xh4[c.grp * PG::LPR + c.q] = u;   // (nobody reads the halo slots between a publish and the next gather's barrier)
-  if constexpr (OF != 0) __syncthreads();   // (... except the own-first form, whose first phase reads them ahead of any barrier)
+  Xh4[c.grp * PG::LPR + c.q] = u;   // (nobody reads the halo slots between a publish and the next gather's barrier ...
+  if constexpr (!HUB && !WGT) __syncthreads();   // ... except the own rounds of a member's first phase, summed ahead of any barrier)
   for (int n = 0; n < p.n_steps && ok; ++n) {
     for (int i = 0; i < p.S && ok; ++i) {
 #pragma unroll
@@ -706,7 +663,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
           hub_gather_foreign(c, X, ldsXh);
           NGPDE_PST(p.m, ph, 2);
           agg = hub_aggregate(c, sw, ldsXh, ldsZ);   // (the product's output tile is free until this phase's product)
-        } else if constexpr (OF == 1) {
+        } else if constexpr (!WGT) {
           unsigned sw[8];
           tile_slot_words(c, sw);
           float4 a = tile_aggregate_rounds_range(c, sw, ldsXh, f4_zero(), 0, of_pre);   // own rows: under the wait
@@ -714,7 +671,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, X, ldsXh);
           NGPDE_PST(p.m, ph, 2);
-          a = tile_aggregate_rounds_range(c, sw, ldsXh, a, of_pre, 8 < (c.wmax >> 2) ? 8 : (c.wmax >> 2));
+          a = tile_aggregate_rounds_range(c, sw, ldsXh, a, of_pre, (c.wmax + 3) >> 2);
           agg = f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
         } else {
           unsigned sw[8];
@@ -723,7 +680,7 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_ker
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, X, ldsXh);
           NGPDE_PST(p.m, ph, 2);
-          agg = WGT ? tile_aggregate_weighted(c, ldsXh) : tile_aggregate(c, sw, ldsXh);
+          agg = tile_aggregate_weighted(c, ldsXh);
         }
         float4 acc = f4_scale(c.ci, agg);   // a_i = c_i * sum of the stored (pre-scaled) rows
         *reinterpret_cast<float4 *>(&ldsT[c.grp * PG::TS + 4 * c.q]) = acc;
@@ -1326,6 +1283,10 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
   float db1 = 0.f, db2 = 0.f;
   const int dbc = c.tid / PG::DBP, dbpart = c.tid % PG::DBP;
   const int S = p.S;
+  int of_pre = 0;   // own rounds of this wave's rows (the plan's own-first tables): summed before the wait
+  if constexpr (!HUB && !WGT) {
+    if (p.m.of_pre) of_pre = __builtin_amdgcn_readfirstlane((int)p.m.of_pre[(size_t)c.tile * 8 + c.wave_u]);
+  }
   __syncthreads();
 
   // the dense half of a phase: dL/dy = c .* K-bar, relu' by the sign bits, G = dZ W^T -> c .* G stored for the next gather,
@@ -1456,11 +1417,13 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
         } else {
           unsigned sw[8];
           tile_slot_words(c, sw);
+          float4 a = tile_aggregate_rounds_range(c, sw, ldsXh, f4_zero(), 0, of_pre);   // own rows (in LDS since the last publish): under the wait
           if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g2, ldsXh);
           NGPDE_PST(p.m, ph, 2);
-          t = tile_aggregate(c, sw, ldsXh);
+          a = tile_aggregate_rounds_range(c, sw, ldsXh, a, of_pre, (c.wmax + 3) >> 2);
+          t = f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
         }
         dense(ph, ldsW1, dw1, db1, t, mk, xrow, p.g1, !last_next, ev_next);
       }
@@ -1490,11 +1453,13 @@ __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_ker
         } else {
           unsigned sw[8];
           tile_slot_words(c, sw);
+          float4 a = tile_aggregate_rounds_range(c, sw, ldsXh, f4_zero(), 0, of_pre);   // own rows (in LDS since the last publish): under the wait
           if (!tile_wait_primed(p.m, c, ph, s_ok, p.m.flags, f_next)) { ok = false; break; }
           NGPDE_PST(p.m, ph, 1);
           tile_gather_foreign(c, p.g1, ldsXh);
           NGPDE_PST(p.m, ph, 2);
-          t = tile_aggregate(c, sw, ldsXh);
+          a = tile_aggregate_rounds_range(c, sw, ldsXh, a, of_pre, (c.wmax + 3) >> 2);
+          t = f4_add(a, Xh4[c.grp * PG::LPR + c.q]);
         }
         float4 kbar;
         if (i >= 1) {
@@ -2673,6 +2638,97 @@ bool node_persistent_interleave_env() {
   return !(e && e[0] == '1');
 }
 
+// ---- a plan's own-first slot tables (OwnFirst, common.h) ----------------------------------------------------------------------------
+namespace {
+// one 64-thread workgroup per tile, thread r < 32 = row r: the row's slot bytes with the own-tile slots (< 32) first, padded with the
+// all-zero row (kHaloCap) to 4 x the own rounds of the row's group of four (= a wave of the 64-wide kernels), then the foreign slots;
+// weights travel with their slots; a group in which some row would not fit its 32 bytes keeps the handle's order (pre = 0)
+__global__ __launch_bounds__(64) void own_first_tables_kernel(int n_tiles, const uint8_t *__restrict__ slots, const int4 *__restrict__ sched,
+                                                              const float *__restrict__ slot_w, uint8_t *__restrict__ o_slots,
+                                                              int4 *__restrict__ o_sched, float *__restrict__ o_w, uint8_t *__restrict__ o_pre) {
+  const int tile = blockIdx.x, r = threadIdx.x;
+  const bool row = r < kTileRows;
+  const size_t pos = (size_t)tile * kTileRows + (row ? r : 0);
+  int4 sc = sched[pos];
+  const int deg = (row && sc.x >= 0) ? min(sc.z, kSlotWidth) : 0;
+  uint8_t b[kSlotWidth];
+  {
+    const uint4 lo = reinterpret_cast<const uint4 *>(slots + pos * kSlotWidth)[0], hi = reinterpret_cast<const uint4 *>(slots + pos * kSlotWidth)[1];
+    const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < kSlotWidth; ++j) b[j] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xff);
+  }
+  int no = 0, nf = 0;
+#pragma unroll
+  for (int j = 0; j < kSlotWidth; ++j) {
+    if (j < deg) {
+      if (b[j] < kTileRows) ++no;
+      else ++nf;
+    }
+  }
+  int pre = (no + 3) >> 2;
+  pre = max(pre, __shfl_xor(pre, 1));
+  pre = max(pre, __shfl_xor(pre, 2));
+  int fits = (4 * pre + nf <= kSlotWidth) ? 1 : 0;
+  fits = min(fits, __shfl_xor(fits, 1));
+  fits = min(fits, __shfl_xor(fits, 2));
+  if (!fits) pre = 0;
+  if (row) {
+    uint8_t *ob = o_slots + pos * kSlotWidth;
+    float *ow = o_w ? o_w + pos * kSlotWidth : nullptr;
+    const float *iw = slot_w ? slot_w + pos * kSlotWidth : nullptr;
+    if (fits) {
+      int k = 0;
+      for (int j = 0; j < deg; ++j)
+        if (b[j] < kTileRows) { ob[k] = b[j]; if (ow) ow[k] = iw[j]; ++k; }
+      for (; k < 4 * pre; ++k) { ob[k] = (uint8_t)kHaloCap; if (ow) ow[k] = 0.f; }
+      for (int j = 0; j < deg; ++j)
+        if (b[j] >= kTileRows) { ob[k] = b[j]; if (ow) ow[k] = iw[j]; ++k; }
+      const int len = k;
+      for (; k < kSlotWidth; ++k) { ob[k] = (uint8_t)kHaloCap; if (ow) ow[k] = 0.f; }
+      if (sc.x >= 0) sc.z = len;
+    } else {
+      for (int j = 0; j < kSlotWidth; ++j) { ob[j] = b[j]; if (ow) ow[j] = iw[j]; }
+    }
+    o_sched[pos] = sc;
+    if ((r & 3) == 0) o_pre[(size_t)tile * 8 + (r >> 2)] = (uint8_t)pre;
+  }
+}
+}  // namespace
+
+int32_t own_first_tables_build(const ngpde_graph *g, OwnFirst *of, hipStream_t stream) {
+  const int nt = g->n_sched / kTileRows;
+  const Csr *cs[2] = {&g->by_t, &g->by_s};
+  // the by-target lists only: the adjoint's tiles reach their wait with the flags already set (its parameter-gradient products sit
+  // between publish and wait), so there the padding rounds cost more than the early sums win (2.913 -> 2.925 ms, profiles/r06_l_own_first.txt);
+  // NGPDE_OWN_FIRST_ADJOINT=1 builds both (A/B runs)
+  const char *adj = std::getenv("NGPDE_OWN_FIRST_ADJOINT");
+  const int n_dir = (adj && adj[0] == '1') ? 2 : 1;
+  for (int dir = 0; dir < n_dir; ++dir) {
+    const Csr &c = *cs[dir];
+    if (!c.halo_ok || !c.slots || !c.sched) continue;
+    NGPDE_HIP_CHECK(hipMalloc((void **)&of->slots[dir], (size_t)g->n_sched * kSlotWidth));
+    NGPDE_HIP_CHECK(hipMalloc((void **)&of->sched[dir], (size_t)g->n_sched * sizeof(int4)));
+    NGPDE_HIP_CHECK(hipMalloc((void **)&of->pre[dir], (size_t)nt * 8));
+    if (c.slot_w) NGPDE_HIP_CHECK(hipMalloc((void **)&of->slot_w[dir], (size_t)g->n_sched * kSlotWidth * sizeof(float)));
+    hipLaunchKernelGGL(own_first_tables_kernel, dim3(nt), dim3(64), 0, stream, nt, c.slots, c.sched, c.slot_w, of->slots[dir], of->sched[dir],
+                       of->slot_w[dir], of->pre[dir]);
+    NGPDE_LAUNCH_CHECK("own_first_tables_kernel");
+  }
+  NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
+  return NGPDE_OK;
+}
+
+void own_first_tables_free(OwnFirst *of) {
+  for (int dir = 0; dir < 2; ++dir) {
+    if (of->slots[dir]) (void)hipFree(of->slots[dir]);
+    if (of->sched[dir]) (void)hipFree(of->sched[dir]);
+    if (of->slot_w[dir]) (void)hipFree(of->slot_w[dir]);
+    if (of->pre[dir]) (void)hipFree(of->pre[dir]);
+  }
+  *of = OwnFirst();
+}
+
 int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, NodePersist *ps, bool pair, bool hub) {
   std::vector<int> lists;
   const int nt = g->n_sched / kTileRows;
@@ -2800,9 +2856,14 @@ __global__ void latch_fault_kernel(const unsigned *abort_word, unsigned *fault) 
 }  // namespace
 const unsigned *node_persistent_abort_word(const NodePersist *ps) { return ps->sync ? ps->sync + (size_t)ps->n_tiles * 64 : nullptr; }
 namespace {
-TileMeta make_meta(const Csr &c, const NodePersist &ps, int dir) {
+TileMeta make_meta(const Csr &c, const NodePersist &ps, int dir, const OwnFirst *of) {
   TileMeta m;
   m.halo = c.halo; m.slots = c.slots; m.sched = c.sched; m.tile_info = c.tile_info; m.nbr = ps.nbr; m.slot_w = c.slot_w;
+  m.of_pre = nullptr;
+  if (of && of->slots[dir] && !ps.hub) {   // the plan's own-first tables: the same rows in another order, padded lengths in the schedule
+    m.slots = of->slots[dir]; m.sched = of->sched[dir]; m.of_pre = of->pre[dir];
+    if (m.slot_w) m.slot_w = of->slot_w[dir];
+  }
   const NodePersist::HubLists &L = ps.hub_lists[dir];
   m.hub_halo = L.halo; m.hub_slots = L.slots; m.hub_rows = L.rows; m.hub_info = L.info; m.hub_long = L.longs; m.hub_sched = L.sched;
   m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 64; m.n_tiles = ps.n_tiles;   // [slot 0 | slot 1 | abort]
@@ -2880,7 +2941,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PFwdK k;
-  k.m = make_meta(g->by_t, ps, 0);
+  k.m = make_meta(g->by_t, ps, 0, a.of);
   {
     const char *fa = std::getenv("NGPDE_DEBUG_FORCE_ABORT");
     if (fa && fa[0] == '1') hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, stream, k.m.abort_word, 1u);
@@ -2953,13 +3014,8 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
   } else if (a.interleave) {                                                                                                 \
     if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
     else hipLaunchKernelGGL((node_fwd_persistent2_kernel<AA, TT, false>), grid, block, 0, stream, k);                         \
-  } else if (own_first == 1) {                                                                                               \
-    if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, false, 1>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
-    else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT, false, false, 1>), grid, block, 0, stream, k);               \
   } else if (a.ev_start) hipExtLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k); \
   else hipLaunchKernelGGL((node_fwd_persistent_kernel<AA, TT>), grid, block, 0, stream, k);
-  const char *of_env = std::getenv("NGPDE_OWN_FIRST");   // round 6 experiment, diagnostic: 1 = the tile's own rows summed under the wait
-  const int own_first = (of_env && of_env[0] == '1') ? 1 : 0;
   k.ztape = a.ztape;
   if (a.tape && a.act == NGPDE_ACT_RELU) {
     NGPDE_REQUIRE(a.masks != nullptr, NGPDE_ERR_INVALID_ARGUMENT, "persistent forward with a relu tape needs the sign-bit masks");
@@ -2988,7 +3044,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
   if ((st = turn.enter(stream))) return st;
   if ((st = launch_zero(ps.sync, ps.sync_bytes, stream))) return st;
   PBwdK k;
-  k.m = make_meta(g->by_s, ps, 1);
+  k.m = make_meta(g->by_s, ps, 1, a.of);
   k.n_steps = a.n_steps; k.S = a.S; k.n_members = a.n_members; k.act = a.act; k.ztape = a.ztape;
   k.lam = a.lam; k.g1 = a.g1; k.g2 = a.g2; k.w1 = a.w1; k.w2 = a.w2;
   k.tape = a.tape; k.masks = a.masks; k.row_elems = a.row_elems; k.mask_bytes = a.mask_bytes;
