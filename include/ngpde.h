@@ -470,7 +470,10 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
        NGPDE_NODE_WIDENED = 128 /* d = 16 / 32 run zero-padded on the 64-wide persistent kernels (NGPDE_NO_WIDEN=1 turns it off) */,
        NGPDE_NODE_HUB_GEOMETRY = 256 /* persistent launches in the hub geometry: graphs of at most one 32-row tile per CU whose tiles reach
                                         beyond the 96-row halo / 32-entry rows (a Cora-shaped graph, docs/src/tutorials/graph_node.md:14-23):
-                                        256-row halos, variable-length rows, hub rows summed by all lane groups of the workgroup */ };
+                                        256-row halos, variable-length rows, hub rows summed by all lane groups of the workgroup */,
+       NGPDE_NODE_OWN_FIRST = 512 /* the plan reads its own slot tables (by-target lists): each row's own-tile neighbours first, which the
+                                     one-tile forward launch sums while it waits for the neighbouring tiles; every kernel of the plan
+                                     sums in that order (NGPDE_NO_OWN_FIRST=1 at create keeps the handle's order) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 /* Host only, no device call: would a graph with hubs run on the persistent solver's hub geometry (NGPDE_NODE_HUB_GEOMETRY)?  The
  * graph is given as its two 0-based CSR lists (by target: the in-neighbours of every node; by source: the out-neighbours).  On

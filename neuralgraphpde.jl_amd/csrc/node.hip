@@ -769,7 +769,7 @@ int32_t ngpde_node_flags(const ngpde_node_t *p, int32_t *flags) {
   *flags = (p->pre ? NGPDE_NODE_PRESCALED : 0) | (p->mask_mode ? NGPDE_NODE_SIGN_MASKS : 0) | (p->eager ? NGPDE_NODE_EAGER : 0) |
            (p->persist_fwd ? NGPDE_NODE_PERSISTENT_FWD : 0) | (p->persist_bwd ? NGPDE_NODE_PERSISTENT_BWD : 0) |
            (p->pair ? NGPDE_NODE_TILE_PAIRS : 0) | (p->ktiles ? NGPDE_NODE_TILE_ROUNDS : 0) | (p->du != p->d ? NGPDE_NODE_WIDENED : 0) |
-           (p->hub ? NGPDE_NODE_HUB_GEOMETRY : 0);
+           (p->hub ? NGPDE_NODE_HUB_GEOMETRY : 0) | (p->has_of ? NGPDE_NODE_OWN_FIRST : 0);
   return NGPDE_OK;
 }
 

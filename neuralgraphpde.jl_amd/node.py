@@ -105,12 +105,10 @@ class _Plan:
         return f.value, b.value
 
     def flags(self):
-        """subset of {'prescaled', 'sign_masks', 'eager', 'persistent_fwd', 'persistent_bwd'}: the internal forms the plan
-        chose (ngpde_node_flags)"""
+        """the internal forms the plan chose (ngpde_node_flags; names in _FLAG_NAMES)"""
         f = C.c_int32()
         _lib.check(self.lib.ngpde_node_flags(self.ptr, C.byref(f)))
-        return {name for bit, name in ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"),
-                                       (16, "persistent_bwd"), (32, "tile_pairs"), (64, "tile_rounds"), (128, "widened"), (256, "hub_geometry")) if f.value & bit}
+        return {name for bit, name in _FLAG_NAMES if f.value & bit}
 
     def fault(self):
         """True when a persistent launch of this plan gave up waiting (its outputs are NaN).  Synchronises."""
@@ -176,7 +174,7 @@ class _NodeGCN2Fn(torch.autograd.Function):
 
 
 _FLAG_NAMES = ((1, "prescaled"), (2, "sign_masks"), (4, "eager"), (8, "persistent_fwd"), (16, "persistent_bwd"), (32, "tile_pairs"),
-               (64, "tile_rounds"), (128, "widened"), (256, "hub_geometry"))
+               (64, "tile_rounds"), (128, "widened"), (256, "hub_geometry"), (512, "own_first"))
 
 
 class _OdePlan:

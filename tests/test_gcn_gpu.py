@@ -514,7 +514,7 @@ def _oracle_node_with_seed(params, og, u0, seed, tableau, dt, nsteps, act="relu"
 
 
 PLAN_SWITCHES = ("NGPDE_NO_PERSISTENT", "NGPDE_PERSISTENT", "NGPDE_NO_WIDEN", "NGPDE_NO_TILE_PAIRS", "NGPDE_TILE_ROUNDS", "NGPDE_NO_INTERLEAVE",
-                 "NGPDE_WEIGHTED_TILE_ROUNDS", "NGPDE_NO_TILE_PIPE", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK")
+                 "NGPDE_WEIGHTED_TILE_ROUNDS", "NGPDE_NO_TILE_PIPE", "NGPDE_NO_PRESCALE", "NGPDE_NO_MASK", "NGPDE_NO_OWN_FIRST", "NGPDE_OWN_FIRST_ADJOINT")
 
 
 def needs_persistent_plan(monkeypatch=None):
@@ -798,6 +798,62 @@ def test_node_persistent_and_replayed_plans_agree_bitwise(monkeypatch):
     a, b = outs["persistent"], outs["replayed"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-5) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,weighted", [(4096, False), (1000, False), (2048, True)])
+def test_node_own_first_tables_change_the_order_of_a_sum_only(N, weighted, monkeypatch):
+    needs_persistent_plan(monkeypatch)
+    # a GCN solver plan reads its own slot tables (NGPDE_NODE_OWN_FIRST: a row's own-tile neighbours first, padded with the all-zero
+    # row; csrc/node_persistent.hip own_first_tables_kernel).  Against the plan on the handle's order (NGPDE_NO_OWN_FIRST=1): the
+    # same neighbours and weights in another order, so u(T), du0 and the parameter gradients agree to rounding, and both agree with
+    # the float64 oracle; the own-first persistent plan and the own-first replayed plan stay bitwise equal (one table for both)
+    d, nsteps, dt = 64, 3, 0.05
+    g, og, params = spatial_case(N, 4 * N, d, seed=N + 3)
+    if weighted:
+        _, s, t = S.closest_pairs_graph(N, 4 * N, seed=N + 3)
+        ew = (0.5 + np.random.default_rng(N).random(s.size)).astype(np.float32)
+        g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+        og = O.Graph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+    rng = np.random.default_rng(N + 4)
+    u0n, Rn = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+    u0 = torch.as_tensor(u0n.astype(np.float32), device=DEV)
+    R = torch.as_tensor(Rn.astype(np.float32), device=DEV)
+    outs = {}
+    for mode in ("own_first", "handle_order", "own_first_replayed"):
+        monkeypatch.delenv("NGPDE_NO_OWN_FIRST", raising=False)
+        monkeypatch.delenv("NGPDE_NO_PERSISTENT", raising=False)
+        if mode == "handle_order":
+            monkeypatch.setenv("NGPDE_NO_OWN_FIRST", "1")
+        if mode == "own_first_replayed":
+            monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        kw = dict(initialgraph=g, use_edge_weight=True) if weighted else dict(initialgraph=g)
+        rhs = ng.Chain(ng.GCNConv((d, d), "tanh", **kw), ng.GCNConv((d, d), "tanh", **kw))
+        node = ng.NeuralODE(rhs, solver="tsit5", n_steps=nsteps, dt=dt)
+        ps, st = ng.setup(0, node)
+        for k, name in enumerate(["layer_1", "layer_2"]):
+            ps[name]["weight"] = torch.as_tensor(params[k]["weight"].astype(np.float32))
+            ps[name]["bias"] = torch.as_tensor(params[k]["bias"].astype(np.float32))
+        ps = ng.to_device(ps, DEV)
+        for lp in ps.values():
+            for v in lp.values():
+                v.requires_grad_(True)
+        u = u0.clone().requires_grad_(True)
+        uT, _ = node(u, ps, st)
+        flags = next(iter(node._plans.values()))[0].flags()
+        assert ("own_first" in flags) == (mode != "handle_order"), flags
+        assert ("persistent_fwd" in flags) == (mode != "own_first_replayed"), flags
+        (uT * R).sum().backward()
+        outs[mode] = (uT.detach().clone(), u.grad.clone(), ps["layer_1"]["weight"].grad.clone(), ps["layer_2"]["bias"].grad.clone())
+    a, b, c = outs["own_first"], outs["handle_order"], outs["own_first_replayed"]
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    assert not torch.equal(a[0], b[0]), "the two orders give the same bits: the own-first tables were not read"
+    for x, y, what in zip(a, b, ("u(T)", "du0", "dW1", "db2")):
+        scale = float(y.abs().max())
+        assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-6, (what, float((x - y).abs().max()), scale)
+    oracle = _oracle_weighted_node if weighted else _oracle_node_with_seed
+    uTo, du0o, acc = oracle(params, og, u0n, Rn, O.TABLEAUS["tsit5"], dt, nsteps, "tanh")
+    close(a[0], uTo, rtol=2e-4, what="u(T)")
+    close(a[1], du0o, rtol=5e-4, atol=1e-4, what="du0")
 
 
 @pytest.mark.parametrize("K,N,tab,nsteps", [(2, 1000, "tsit5", 3), (3, 1000, "euler", 4), (8, 2048, "tsit5", 2), (2, 16384, "tsit5", 4)])
