@@ -606,11 +606,54 @@ __device__ __forceinline__ void gat_load_bt(const float *wt, float *ldsBt, int t
   }
 }
 
+// The by-source half's loads that do not depend on the by-target halves of this pullback (gat_bwd_source_indices: static per tile;
+// gat_bwd_source_prefetch: the saved coefficients and the row of x): the persistent solver issues both BEFORE it waits for its
+// neighbours' dz / dscore -- behind the wait only the rows and the dscore entries are left (adjoint launch 7.21 -> 7.10 ms at C3's
+// size, profiles/r06_o_gat_adjoint_variants.txt; the same file has what did NOT pay: the indices kept in registers for the whole
+// launch, W / coefficients / stage adjoints asked for in one batch at the head of the by-target half, the forward's combination
+// rows in one batch -- every one of them costs registers the kernels do not have (128, 53 spilled) and came out 1 - 40 % slower).
+struct GatBwdSPre {
+  int pp[2], xq[2];     // this lane's two outgoing entries: position in the by-target list, entry of the padded dscore blocks (PAD)
+  float va[2][4];       // their saved coefficients
+  float4 xo;            // the row of x
+};
+template <bool PAD>
+__device__ __forceinline__ void gat_bwd_source_indices(const GatBwdSK &p, const GatThread &t, int4 sc, GatBwdSPre &r) {
+  const int q = t.q;
+  const int deg = sc.x >= 0 ? sc.z : 0;
+  const int elast = p.n_edges - 1;      // (>= 0: gat_layer_fused_supported refuses a graph without edges)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // (a lane beyond its row's degree re-reads the row's first entry and drops it: the same address as lane 0, so no further request --
+    // reading on into the next rows' entries made the persistent adjoint 25 % slower, its dscore loads go to memory)
+    const int ent = max(min(sc.y + (q + 16 * s < deg ? q + 16 * s : 0), elast), 0);
+    r.pp[s] = p.xpos[ent];
+    r.xq[s] = PAD ? p.xpad[ent] : 0;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    asm volatile("" : "+v"(r.pp[s]));
+    asm volatile("" : "+v"(r.xq[s]));
+  }
+}
+template <int H>
+__device__ __forceinline__ void gat_bwd_source_prefetch(const GatBwdSK &p, const GatThread &t, int4 sc, GatBwdSPre &r) {
+  r.xo = reinterpret_cast<const float4 *>(p.x)[(size_t)max(sc.x, 0) * GG::LPR + t.q];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.va[s][k] = 0.f;
+    if (H == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)r.pp[s] * 4); r.va[s][0] = t4.x; r.va[s][1] = t4.y; r.va[s][2] = t4.z; r.va[s][3] = t4.w; }
+    else if (H == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)r.pp[s] * 2); r.va[s][0] = t2.x; r.va[s][1] = t2.y; }
+    else r.va[s][0] = p.alpha[r.pp[s]];
+  }
+}
+
 // The by-source half of the pullback for one tile whose dz halo rows are staged (in flight or landed): returns this thread's quad of
 // the tile's dx row; dW / u accumulate in the caller's registers.  Ends with the barrier after which the LDS regions may be reused.
 template <int H, bool PAD>
-__device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, const GatBwdSLds &L, const GatThread &t, const TileMeta &m,
-                                                         float4 al4, float4 ar4, f32x4 (&dw)[GG::DWT], float &uacc) {
+__device__ __forceinline__ float4 gat_bwd_source_core(const GatBwdSK &p, const GatBwdSLds &L, const GatThread &t, const TileMeta &m,
+                                                      float4 al4, float4 ar4, f32x4 (&dw)[GG::DWT], float &uacc, const GatBwdSPre &pre) {
   constexpr int C = GD / H;
   constexpr int NT = GG::CT * GG::CT;
   const int tid = t.tid, lane = t.lane, wave_u = t.wave_u, grp = t.grp, q = t.q;
@@ -619,50 +662,25 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
   const int hq = (4 * q) / C;                                                    // this lane's head
   const bool ok = m.sc.x >= 0;
   const int deg = ok ? m.sc.z : 0;
-  const size_t idx4 = (size_t)max(m.sc.x, 0) * GG::LPR + q;
-  float4 xo = reinterpret_cast<const float4 *>(p.x)[idx4];
-  // Every load below is unconditional, from a clamped position, pinned after its batch and neutralised afterwards.  As
-  // `valid ? load : 0` each was an exec-masked branch whose join waits for the load, and the lane's two entries went one after the
-  // other: list position, wait, coefficient + dscore, wait, twice -- four round trips behind the row gather instead of two.
+  float4 xo = pre.xo;
+  // Every load here and in the two functions above is unconditional, from a clamped position, pinned after its batch and neutralised
+  // afterwards.  As `valid ? load : 0` each was an exec-masked branch whose join waits for the load, and the lane's two entries went
+  // one after the other: list position, wait, coefficient + dscore, wait, twice -- four round trips behind the row gather instead of two.
   float dalq = p.dal[(size_t)max(m.sc.x, 0) * H + min(q, H - 1)];
-  // this lane's two outgoing entries: coefficient and dscore of the same edge in the by-target list
+  // dscore of this lane's two outgoing entries (the same edges in the by-target list)
   float av[2][4], ds[2][4];
-  const int elast = p.n_edges - 1;      // (>= 0: gat_layer_fused_supported refuses a graph without edges)
-  int ent[2], pp[2], xq[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    // (a lane beyond its row's degree re-reads the row's first entry and drops it: the same address as lane 0, so no further request --
-    // reading on into the next rows' entries made the persistent adjoint 25 % slower, its dscore loads go to memory)
-    ent[s] = max(min(m.sc.y + (q + 16 * s < deg ? q + 16 * s : 0), elast), 0);
-    pp[s] = p.xpos[ent[s]];
-    xq[s] = PAD ? p.xpad[ent[s]] : 0;
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    asm volatile("" : "+v"(pp[s]));
-    asm volatile("" : "+v"(xq[s]));
-  }
   float va[2][4], vd[2][4];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) va[s][k] = vd[s][k] = 0.f;
-    if (PAD) {   // the persistent solver: alpha from the tape (list order), dscore from the target tile's padded block, sc1
-      const float4 u = gat_load4_sc1(p.dscore + (size_t)xq[s] * 4);
+    for (int k = 0; k < 4; ++k) { va[s][k] = pre.va[s][k]; vd[s][k] = 0.f; }
+    if (PAD) {   // the persistent solver: dscore from the target tile's padded block, sc1
+      const float4 u = gat_load4_sc1(p.dscore + (size_t)pre.xq[s] * 4);
       vd[s][0] = u.x; vd[s][1] = u.y; vd[s][2] = u.z; vd[s][3] = u.w;
-      if (H == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp[s] * 4); va[s][0] = t4.x; va[s][1] = t4.y; va[s][2] = t4.z; va[s][3] = t4.w; }
-      else if (H == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp[s] * 2); va[s][0] = t2.x; va[s][1] = t2.y; }
-      else va[s][0] = p.alpha[pp[s]];
     } else {
-      if (H == 4) {
-        const float4 t4 = *reinterpret_cast<const float4 *>(p.alpha + (size_t)pp[s] * 4), u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pp[s] * 4);
-        va[s][0] = t4.x; va[s][1] = t4.y; va[s][2] = t4.z; va[s][3] = t4.w; vd[s][0] = u.x; vd[s][1] = u.y; vd[s][2] = u.z; vd[s][3] = u.w;
-      } else if (H == 2) {
-        const float2 t2 = *reinterpret_cast<const float2 *>(p.alpha + (size_t)pp[s] * 2), u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pp[s] * 2);
-        va[s][0] = t2.x; va[s][1] = t2.y; vd[s][0] = u.x; vd[s][1] = u.y;
-      } else {
-        va[s][0] = p.alpha[pp[s]]; vd[s][0] = p.dscore[pp[s]];
-      }
+      if (H == 4) { const float4 u = *reinterpret_cast<const float4 *>(p.dscore + (size_t)pre.pp[s] * 4); vd[s][0] = u.x; vd[s][1] = u.y; vd[s][2] = u.z; vd[s][3] = u.w; }
+      else if (H == 2) { const float2 u = *reinterpret_cast<const float2 *>(p.dscore + (size_t)pre.pp[s] * 2); vd[s][0] = u.x; vd[s][1] = u.y; }
+      else vd[s][0] = p.dscore[pre.pp[s]];
     }
   }
 #pragma unroll
@@ -745,6 +763,14 @@ __device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, cons
   const float4 dxv = *reinterpret_cast<const float4 *>(&ldsXh[grp * GG::TS + 4 * q]);
   __syncthreads();   // the next tile's rows land where the dx tile is
   return dxv;
+}
+template <int H, bool PAD>
+__device__ __forceinline__ float4 gat_bwd_source_compute(const GatBwdSK &p, const GatBwdSLds &L, const GatThread &t, const TileMeta &m,
+                                                         float4 al4, float4 ar4, f32x4 (&dw)[GG::DWT], float &uacc) {
+  GatBwdSPre pre;
+  gat_bwd_source_indices<PAD>(p, t, m.sc, pre);
+  gat_bwd_source_prefetch<H>(p, t, m.sc, pre);
+  return gat_bwd_source_core<H, PAD>(p, L, t, m, al4, ar4, dw, uacc, pre);
 }
 
 // this workgroup's share of da from its u accumulators (needs W in L.Bt)
@@ -976,13 +1002,13 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_batch_ker
           ys.flags = p.s.flags + (size_t)sl * p.flag_stride;
           float *xs = p.xs + (size_t)(mb + sl) * p.xs_stride, *kb = p.kbuf + (size_t)sl * 7 * p.row_elems;
           const float *X = xs + (p.taped ? e : (e & 1)) * p.row_elems;
+          const int row = (i + 1 < S) ? i + 1 : S;
           if (!gat_wait(ys, t, my_nbr, lp > 1 ? ph - 1 : 0u, &s_ok)) { dead = true; break; }
           halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
           l.alpha = p.alpha ? p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems : nullptr;
           const float4 z = gat_fwd_compute<H>(l, L, t, m, tile, breg, b4);
           const float4 y = f4_act(l.act, z);
           if (p.yz && ok) gat_st4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
-          const int row = (i + 1 < S) ? i + 1 : S;
           float4 v = f4_scale(1.0f, gat_ld4(kb + (size_t)6 * p.row_elems, own));
           for (int j = 0; j < i; ++j) v = f4_fma(ldsC[row * 8 + j], gat_ld4(kb + (size_t)j * p.row_elems, own), v);
           v = f4_fma(ldsC[row * 8 + i], y, v);
@@ -1038,6 +1064,8 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
       NGPDE_GSTP(NGPDE_GSTP_OF(l), 0);
       const size_t e = ph - 1;
       const float *X = p.xs + (p.taped ? e : (e & 1)) * p.row_elems;
+      // the input of the next stage / the step update, as ngpde_rk_stage_combine forms it: 1 * u, then the k_j in order
+      const int row = (i + 1 < S) ? i + 1 : S;
       if (!gat_wait(p.s, t, my_nbr, ph - 1, &s_ok)) { dead = true; break; }
       NGPDE_GSTP(NGPDE_GSTP_OF(l), 13);
       halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(X), t.q, t.grp, ldsXh, hr);
@@ -1045,8 +1073,6 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_fwd_persistent_kernel(co
       const float4 z = gat_fwd_compute<H>(l, L, t, m, tile, breg, b4);
       const float4 y = f4_act(l.act, z);
       if (p.yz && ok) gat_st4(p.yz + e * p.row_elems, own, l.act == NGPDE_ACT_RELU ? y : z);
-      // the input of the next stage / the step update, as ngpde_rk_stage_combine forms it: 1 * u, then the k_j in order
-      const int row = (i + 1 < S) ? i + 1 : S;
       float4 v = f4_scale(1.0f, u);
       for (int j = 0; j < i; ++j) v = f4_fma(ldsC[row * 8 + j], gat_ld4(p.kbuf + (size_t)j * p.row_elems, own), v);
       v = f4_fma(ldsC[row * 8 + i], y, v);
@@ -1119,6 +1145,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_batch_ker
   const unsigned P = (unsigned)(p.n_steps * S);
   GatBwdTK tk = p.t;
   GatBwdSK sk = p.s;
+  GatBwdSPre spre;   // the by-source half's loads from the tape, asked for in front of its wait
   bool dead = false;
   unsigned ph0 = 0;
   __syncthreads();
@@ -1139,15 +1166,18 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_batch_ker
           float *lam = p.lam + (size_t)(mb + sl) * p.row_elems, *ub = p.ubar + (size_t)sl * 6 * p.row_elems;
           TileMeta mt;
           tile_meta(p.t.halo, p.t.slots, p.t.sched, X, tile, t.grp, t.q, ldsXh, mt);
-          float4 v = f4_scale(ldsC[i * 8 + i], ok ? gat_ld4(lam, own) : f4_zero());
-          for (int j = i + 1; j < S; ++j) v = f4_fma(ldsC[i * 8 + j], gat_ld4(ub + (size_t)j * p.row_elems, own), v);
-          if (p.yz) v = f4_mul(v, f4_dact(tk.act, gat_ld4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own)));
-          if (!ok) v = f4_zero();
-          float *dzb = p.dzbuf + (size_t)(sl * 2 + (ph & 1)) * p.row_elems;
-          if (ok) gat_store_sc1(dzb, own, v);
           tk.alpha = p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems;
           tk.dscore = p.dscore + (size_t)(sl * 2 + (ph & 1)) * p.dscore_elems;
           tk.dal = p.t.dal + (size_t)sl * p.dal_stride;
+          const float4 lamv = gat_ld4(lam, own);
+          float4 yzv = f4_zero();
+          if (p.yz) yzv = gat_ld4(p.yz + (size_t)(mb + sl) * p.yz_stride + e * p.row_elems, own);
+          float4 v = f4_scale(ldsC[i * 8 + i], ok ? lamv : f4_zero());
+          for (int j = i + 1; j < S; ++j) v = f4_fma(ldsC[i * 8 + j], gat_ld4(ub + (size_t)j * p.row_elems, own), v);
+          if (p.yz) v = f4_mul(v, f4_dact(tk.act, yzv));
+          if (!ok) v = f4_zero();
+          float *dzb = p.dzbuf + (size_t)(sl * 2 + (ph & 1)) * p.row_elems;
+          if (ok) gat_store_sc1(dzb, own, v);
           dbacc += gat_bwd_target_compute<H, true>(tk, LT, t, mt, tile, v);
           gat_publish(ys, t, tile, ph);
         }
@@ -1162,13 +1192,15 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_batch_ker
           HaloRegs<GD> hrs;
           tile_meta_load(p.s.halo, p.s.slots, p.s.sched, tile, t.grp, t.q, hrs, ms);
           tile_meta_words(hrs, ms);
-          if (!gat_wait(ys, t, my_nbr, ph, &s_ok)) { dead = true; break; }
-          halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
           sk.x = X;
           sk.alpha = p.alpha + (size_t)(mb + sl) * p.alpha_stride + e * p.alpha_elems;
           sk.dscore = p.dscore + (size_t)(sl * 2 + (ph & 1)) * p.dscore_elems;
           sk.dal = p.s.dal + (size_t)sl * p.dal_stride;
-          const float4 dxv = gat_bwd_source_compute<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc);
+          gat_bwd_source_indices<true>(sk, t, ms.sc, spre);
+          gat_bwd_source_prefetch<H>(sk, t, ms.sc, spre);   // the tape's share of the half's loads: under the wait
+          if (!gat_wait(ys, t, my_nbr, ph, &s_ok)) { dead = true; break; }
+          halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
+          const float4 dxv = gat_bwd_source_core<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc, spre);
           if (i > 0) {
             if (ok) gat_st4(ub + (size_t)i * p.row_elems, own, dxv);
           } else {
@@ -1230,6 +1262,7 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(co
   const int S = p.S;
   GatBwdTK tk = p.t;
   GatBwdSK sk = p.s;
+  GatBwdSPre spre;   // the by-source half's loads from the tape, asked for in front of its wait
   bool dead = false;
   unsigned ph = 0;
   __syncthreads();
@@ -1242,14 +1275,16 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(co
       // ---- by target.  K-bar_i = (dt b_i) lambda + sum_{j > i} (dt a_ji) U-bar_j, in ngpde_rk_stage_combine's order
       TileMeta mt;
       tile_meta(p.t.halo, p.t.slots, p.t.sched, X, tile, t.grp, t.q, ldsXh, mt);
+      tk.alpha = p.alpha + e * p.alpha_elems;
+      tk.dscore = p.dscore + (size_t)(ph & 1) * p.dscore_elems;
+      float4 yzv = f4_zero();
+      if (p.yz) yzv = gat_ld4(p.yz + e * p.row_elems, own);
       float4 v = f4_scale(ldsC[i * 8 + i], lam);
       for (int j = i + 1; j < S; ++j) v = f4_fma(ldsC[i * 8 + j], gat_ld4(p.ubar + (size_t)j * p.row_elems, own), v);
-      if (p.yz) v = f4_mul(v, f4_dact(tk.act, gat_ld4(p.yz + e * p.row_elems, own)));
+      if (p.yz) v = f4_mul(v, f4_dact(tk.act, yzv));
       if (!ok) v = f4_zero();
       float *dzb = p.dzbuf + (size_t)(ph & 1) * p.row_elems;
       if (ok) gat_store_sc1(dzb, own, v);
-      tk.alpha = p.alpha + e * p.alpha_elems;
-      tk.dscore = p.dscore + (size_t)(ph & 1) * p.dscore_elems;
       NGPDE_GSTP(NGPDE_GSTP_OF(p), 1);
       dbacc += gat_bwd_target_compute<H, true>(tk, LT, t, mt, tile, v);
       NGPDE_GSTP(NGPDE_GSTP_OF(p), 2);
@@ -1261,14 +1296,16 @@ __global__ __launch_bounds__(kThreads, 4) void gat_node_bwd_persistent_kernel(co
       tile_meta_load(p.s.halo, p.s.slots, p.s.sched, tile, t.grp, t.q, hrs, ms);
       tile_meta_words(hrs, ms);
       gat_load_bt(p.s.wt, LS.Bt, t.tid);
+      sk.x = X;
+      sk.alpha = tk.alpha;
+      sk.dscore = tk.dscore;
+      gat_bwd_source_indices<true>(sk, t, ms.sc, spre);
+      gat_bwd_source_prefetch<H>(sk, t, ms.sc, spre);   // the tape's share of the half's loads: under the wait
       NGPDE_GSTP(NGPDE_GSTP_OF(p), 4);
       if (!gat_wait(p.y, t, my_nbr, ph, &s_ok)) { dead = true; break; }
       NGPDE_GSTP(NGPDE_GSTP_OF(p), 5);
       halo_round2<GD, true, 16>(reinterpret_cast<const float4 *>(dzb), t.q, t.grp, ldsXh, hrs);
-      sk.x = X;
-      sk.alpha = tk.alpha;
-      sk.dscore = tk.dscore;
-      const float4 dxv = gat_bwd_source_compute<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc);
+      const float4 dxv = gat_bwd_source_core<H, true>(sk, LS, t, ms, al4, ar4, dw, uacc, spre);
       NGPDE_GSTP(NGPDE_GSTP_OF(p), 6);
       if (i > 0) {
         if (ok) gat_st4(p.ubar + (size_t)i * p.row_elems, own, dxv);
