@@ -475,6 +475,17 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
                                      one-tile forward launch sums while it waits for the neighbouring tiles; every kernel of the plan
                                      sums in that order (NGPDE_NO_OWN_FIRST=1 at create keeps the handle's order) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
+/* Host only, no device call: the node numbering of a block-diagonal batch (Flux.batch / MLUtils.batch of single graphs,
+ * /root/reference/test/runtests.jl:89-102, docs/src/tutorials/VMH.md:120-134) whose members are padded to whole 32-row tiles, so
+ * that a solver plan for `n_members` identical-shape members (ngpde_ode_create, members > 1) or the tile kernels can take it:
+ * member k keeps its node order and is followed by isolated nodes up to the next multiple of 32.  sizes[k] = nodes of member k.
+ * Out: padded_offsets[k] = first node of member k in the padded batch (n_members + 1 entries, the last = padded node count);
+ * index[v] = position of node v of the unpadded batch (sum of sizes entries) -- the gather / scatter index of
+ * ngpde_rows_index; if `order` (a locality order of the unpadded batch, each member's nodes contiguous) is given, order_padded
+ * (padded node count entries) = the same order with every member's padding nodes behind it.  NGPDE_ERR_INVALID_ARGUMENT for a
+ * negative size or an `order` that is no such permutation. */
+int32_t ngpde_batch_pad_host(int32_t n_members, const int64_t *sizes, int64_t *padded_offsets, int64_t *index, const int32_t *order,
+                             int32_t *order_padded);
 /* Host only, no device call: would a graph with hubs run on the persistent solver's hub geometry (NGPDE_NODE_HUB_GEOMETRY)?  The
  * graph is given as its two 0-based CSR lists (by target: the in-neighbours of every node; by source: the out-neighbours).  On
  * NGPDE_OK order[32 t + k] is the node the solver would put in row k of tile t (n_nodes entries) and, if tile_rows is not NULL,

@@ -208,6 +208,7 @@ SIGNATURES = {
     "ngpde_node_launch_count": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngpde_node_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "ngpde_hub_partition_host": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngpde_batch_pad_host": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "ngpde_node_fault": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ngpde_row_blocks_gather": (_i32, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ngpde_row_blocks_scatter": (_i32, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -558,4 +558,39 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   return NGPDE_OK;
 }
 
+// host only (include/ngpde.h): the numbering of a batch whose members are padded to whole tiles
+int32_t ngpde_batch_pad_host(int32_t n_members, const int64_t *sizes, int64_t *padded_offsets, int64_t *index, const int32_t *order,
+                             int32_t *order_padded) {
+  NGPDE_REQUIRE(n_members >= 0 && (n_members == 0 || sizes) && padded_offsets && (!order || order_padded), NGPDE_ERR_INVALID_ARGUMENT,
+                "ngpde_batch_pad_host: sizes, padded_offsets (and order_padded with order) are required");
+  int64_t off = 0, poff = 0;
+  std::vector<int64_t> offs((size_t)n_members + 1, 0);
+  for (int32_t k = 0; k < n_members; ++k) {
+    NGPDE_REQUIRE(sizes[k] >= 0, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_batch_pad_host: member %d has %lld nodes", k, (long long)sizes[k]);
+    padded_offsets[k] = poff;
+    if (index)
+      for (int64_t i = 0; i < sizes[k]; ++i) index[off + i] = poff + i;
+    off += sizes[k];
+    offs[(size_t)k + 1] = off;
+    poff += (sizes[k] + kTileRows - 1) / kTileRows * kTileRows;
+  }
+  padded_offsets[n_members] = poff;
+  NGPDE_REQUIRE(poff <= INT32_MAX, NGPDE_ERR_INVALID_ARGUMENT, "ngpde_batch_pad_host: %lld padded nodes exceed the 32-bit node ids", (long long)poff);
+  if (order) {
+    std::vector<uint8_t> seen((size_t)off, 0);
+    int64_t w = 0;
+    for (int32_t k = 0; k < n_members; ++k) {
+      for (int64_t i = offs[(size_t)k]; i < offs[(size_t)k + 1]; ++i) {
+        const int64_t v = order[i];
+        NGPDE_REQUIRE(v >= offs[(size_t)k] && v < offs[(size_t)k + 1] && !seen[(size_t)v], NGPDE_ERR_INVALID_ARGUMENT,
+                      "ngpde_batch_pad_host: order[%lld] = %lld is not a permutation inside member %d", (long long)i, (long long)v, k);
+        seen[(size_t)v] = 1;
+        order_padded[w++] = (int32_t)(padded_offsets[k] + (v - offs[(size_t)k]));
+      }
+      for (int64_t v = padded_offsets[k] + sizes[k]; v < padded_offsets[k + 1]; ++v) order_padded[w++] = (int32_t)v;
+    }
+  }
+  return NGPDE_OK;
+}
+
 }  // extern "C"

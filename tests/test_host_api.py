@@ -146,11 +146,11 @@ def test_neuralode_generic_path_host_helpers():
 
 
 def test_reshuffled_batch_maps_onto_the_first_batch_of_the_same_members(monkeypatch):
-    # node.py: _canonical_batch -- DataLoader(shuffle = true) (VMH.md:120) hands the loop the same clouds in a new order; the solver
+    # batches.py: _canonical_batch -- DataLoader(shuffle = true) (VMH.md:120) hands the loop the same clouds in a new order; the solver
     # runs such a batch on the first batch's plan through this node map.  Host logic only: the map is a permutation under which the
     # first batch's node data ARE the reshuffled batch's, a cloud that occurs twice gets two different slots, other members start
     # their own entry, and the switch turns it off.
-    from ngpde_amd import node as node_mod
+    from ngpde_amd import batches as node_mod
     monkeypatch.delenv("NGPDE_NO_BATCH_REUSE", raising=False)
     node_mod._CANON_BATCHES.clear()
     rng = np.random.default_rng(0)

@@ -359,7 +359,7 @@ def test_vmh_reshuffled_batch_runs_on_the_first_batch_s_plan(sizes, monkeypatch)
     # the reshuffled batch itself (NGPDE_NO_BATCH_REUSE=1).  Sizes with and without padding to whole tiles; a cloud that occurs twice
     monkeypatch.delenv("NGPDE_NO_VMH_NODE", raising=False)
     monkeypatch.delenv("NGPDE_NO_BATCH_REUSE", raising=False)
-    from ngpde_amd import node as node_mod
+    from ngpde_amd import batches as node_mod
     node_mod._CANON_BATCHES.clear()
     clouds = []
     for kb, nv in enumerate(sizes):
