@@ -596,7 +596,7 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   int pmode = p->pre ? node_persistent_mode(g, d, act, p->with_bwd) : 0;
   // Graphs with hubs (a tile beyond the handle's 96-row halo lists, BASELINE config 1): the hub geometry of the persistent kernels, on
   // pre-scaled arrays like every persistent plan -- both directions or not at all (there is no pre-scaled replayed plan for them)
-  bool hub = !p->pre && pmode == 0 && members == 1 && std::getenv("NGPDE_NO_PRESCALE") == nullptr && node_persistent_hub_possible(g, d) &&
+  bool hub = !p->pre && pmode == 0 && std::getenv("NGPDE_NO_PRESCALE") == nullptr && node_persistent_hub_possible(g, d) &&
              (!p->with_bwd || p->mask_mode || act != NGPDE_ACT_RELU);
   if (hub) {
     pmode = 4;
@@ -664,7 +664,7 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   p->mask_bytes = p->mask_mode ? fused_mask_bytes(p->n, d) : 0;
   const char *eager = std::getenv("NGPDE_NODE_EAGER");
   p->eager = eager && eager[0] == '1';
-  p->interleave = members > 1 && node_persistent_interleave_env();
+  p->interleave = members > 1 && !hub && node_persistent_interleave_env();   // (hub geometry: the members one after the other)
   const size_t xslots = p->interleave ? 2 : 1;   // [N][d] arrays per exchanged buffer
   auto A = [&](float **ptr, size_t elems) {
     if (st == NGPDE_OK) st = dev_alloc(ptr, elems);
@@ -740,7 +740,7 @@ int32_t ngpde_node_gcn2_create_batch(const ngpde_graph_t *g, int32_t members, in
   // d = 16 / 32 where the 64-wide persistent solver can take the graph: run widened (NGPDE_NO_WIDEN=1: the native-width replayed plan)
   const char *nw = std::getenv("NGPDE_NO_WIDEN");
   if (out && g && (d == 16 || d == 32) && !(nw && nw[0] == '1') && g->has_norm && g->n_nodes >= 1 &&
-      (node_persistent_mode(g, 64, act, with_backward != 0) != 0 || (members == 1 && node_persistent_hub_possible(g, 64)))) {
+      (node_persistent_mode(g, 64, act, with_backward != 0) != 0 || node_persistent_hub_possible(g, 64))) {
     ngpde_node_t *w = nullptr;
     if (node_create(g, members, 64, d, act, tableau, n_steps, dt, with_backward, &w) == NGPDE_OK) {
       if (w->persist_fwd && (w->persist_bwd || !w->with_bwd)) {

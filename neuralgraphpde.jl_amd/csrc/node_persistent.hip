@@ -2987,7 +2987,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (ps.hub) {   // hub geometry: one tile per workgroup and CU
-    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave && a.n_members == 1, NGPDE_ERR_STATE, "hub geometry: one unweighted member, one tile per workgroup");
+    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: unweighted, one tile per workgroup, the members of a batch one after the other");
     k.ztape = a.ztape;
     NGPDE_REQUIRE(!a.tape || (a.act == NGPDE_ACT_RELU ? a.masks != nullptr : a.ztape != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
                   "persistent forward with a tape needs the sign-bit masks (relu) or the pre-activation tape");
@@ -3087,7 +3087,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (ps.hub) {
-    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave && a.n_members == 1, NGPDE_ERR_STATE, "hub geometry: one unweighted member, one tile per workgroup");
+    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: unweighted, one tile per workgroup, the members of a batch one after the other");
     NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
     if (a.act == NGPDE_ACT_RELU) {
       if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, false, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);

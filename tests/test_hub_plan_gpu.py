@@ -208,3 +208,44 @@ def test_random_graphs_with_hubs_against_the_replayed_plan():
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.main(10, 5) == 0
+
+
+@pytest.mark.parametrize("act,tab,nsteps,K", [("relu", "euler", 5, 3), ("tanh", "tsit5", 2, 2)])
+def test_batch_of_cora_shaped_graphs_member_by_member_on_the_hub_geometry(act, tab, nsteps, K):
+    # batch([g, g, g]) of a graph with hubs (test/runtests.jl:89-102; "all graphs need to have the same structure", src/layers.jl:359-361):
+    # ONE plan on the member's handle, the hub geometry's launches solving the members one after the other (phases count on across them).
+    # Every member against the float64 port of that member alone, the parameter gradients against the sum over the members, and every
+    # member bitwise equal to the same solve of that member as a single graph (same tiles, same order of every sum).
+    N, PAIRS, d, dt = 2708, 5278, 64, 0.1
+    s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+    gb = ng.batch([g] + [g.copy() for _ in range(K - 1)])
+    og = O.Graph(s, t, num_nodes=N, index_base=0)
+    rng = np.random.default_rng(K)
+    params = [dict(weight=S.glorot_uniform(40 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    u0, R = rng.normal(size=(d, K * N)), rng.normal(size=(d, K * N))
+    uT, du0, grads, flags = solve(gb, d, act, tab, nsteps, dt, params, u0, R)
+    if hub_plan_expected():
+        assert {"hub_geometry", "persistent_fwd", "persistent_bwd"} <= flags, flags
+    accW = [np.zeros((d, d)), np.zeros((d, d))]
+    accb = [np.zeros((d, 1)), np.zeros((d, 1))]
+    for m in range(K):
+        sl = slice(m * N, (m + 1) * N)
+        uTo, du0o, acc = oracle(params, og, u0[:, sl], R[:, sl], tab, dt, nsteps, act)
+        close(uT[:, sl], uTo, 2e-4, what=f"u(T) member {m}")
+        if act == "relu":
+            ref = torch.as_tensor(du0o)
+            bad = (torch.abs(du0[:, sl].double().cpu() - ref) > 1e-4 + 5e-4 * torch.abs(ref)).any(0)
+            assert bad.double().mean() <= 5e-3, f"du0 member {m}: {int(bad.sum())} of {N} nodes off (relu kinks allow a few)"
+        else:
+            close(du0[:, sl], du0o, 5e-4, 1e-4, f"du0 member {m}")
+        for k in range(2):
+            accW[k] += acc[k]["weight"]
+            accb[k] += acc[k]["bias"]
+        if hub_plan_expected():
+            uT1, du01, _, flags1 = solve(g, d, act, tab, nsteps, dt, params, u0[:, sl], R[:, sl])
+            assert "hub_geometry" in flags1
+            assert torch.equal(uT[:, sl], uT1) and torch.equal(du0[:, sl], du01), f"member {m} differs from its single-graph solve"
+    for k in range(2):
+        close(grads[2 * k], accW[k], 5e-4, 2e-3, f"dW{k + 1}")
+        close(grads[2 * k + 1], accb[k], 5e-4, 2e-3, f"db{k + 1}")
