@@ -460,7 +460,7 @@ int32_t ngpde_node_launch_count(const ngpde_node_t *plan, int32_t *forward, int3
  * graphs whose tiles fit the LDS halo, d = 64 (d = 16 / 32 zero-padded onto it, bit 7), any activation; up to 2 tiles per
  * co-resident workgroup in registers (bit 5), up to 8 taking turns (bit 6); graphs with edge weights on the turn-taking form with
  * the slot weights in LDS (up to 3 tiles per workgroup); graphs with hubs of at most one tile per CU in the hub geometry (bit 8).  d = 128,
- * larger graphs with hubs and weighted graphs with hubs keep the replayed plan.  A persistent launch
+ * larger graphs with hubs keep the replayed plan (edge weights and batches of same-structure graphs with hubs run in the hub geometry).  A persistent launch
  * needs all its workgroups resident at once: run one such solve at a time per device (NGPDE_NO_PERSISTENT=1 selects the
  * replayed plan otherwise).  Its waits are bounded; a launch that gives up writes NaN outputs and raises the plan's fault
  * flag, which ngpde_node_fault reads (synchronises `stream`). */

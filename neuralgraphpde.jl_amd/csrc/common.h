@@ -90,6 +90,8 @@ struct ngpde_graph {
   bool has_norm = false;
   int32_t self_loops = 0;
   float *c = nullptr;  // [n_nodes] 1/sqrt(degree)
+  float *w_coo = nullptr;  // [n_edges] the edge weights set_gcn_norm was given, in COO order (owned copy), or NULL: what the persistent
+                           // solver's hub geometry builds its per-entry weight lists from (node_persistent_setup)
   int32_t max_in_degree = 0, max_out_degree = 0;
   // Locality schedule: a permutation of the nodes in which consecutive runs of kTileRows nodes are
   // graph-compact clusters (BFS-grown) and consecutive clusters are adjacent.  The fused kernels give
@@ -220,6 +222,7 @@ struct NodePersist {
     int2 *rows = nullptr;      // [n_sched]
     int4 *info = nullptr;      // [n_tiles]
     uint8_t *longs = nullptr;  // [n_tiles][32]
+    float *w = nullptr;        // [n_tiles][4096] the entries' edge weights beside their slot bytes, or NULL (unweighted)
     int4 *sched = nullptr;     // [n_sched] the geometry's own tile partition (both directions hold the same one)
   } hub_lists[2];
 };

@@ -277,6 +277,7 @@ int32_t ngpde_graph_destroy(ngpde_graph_t *g) {
   free_csr(g->by_t);
   free_csr(g->by_s);
   if (g->c) (void)hipFree(g->c);
+  if (g->w_coo) (void)hipFree(g->w_coo);
   if (g->order) (void)hipFree(g->order);
   if (g->halo_inv.ptr) (void)hipFree(g->halo_inv.ptr);
   if (g->halo_inv.node) (void)hipFree(g->halo_inv.node);
@@ -532,8 +533,11 @@ int32_t ngpde_graph_set_gcn_norm(ngpde_graph_t *g, int32_t add_self_loops, const
   if (g->by_t.sched) { (void)hipFree(g->by_t.sched); g->by_t.sched = nullptr; }
   if (g->by_s.sched) { (void)hipFree(g->by_s.sched); g->by_s.sched = nullptr; }
   if (g->c) { (void)hipFree(g->c); g->c = nullptr; }
+  if (g->w_coo) { (void)hipFree(g->w_coo); g->w_coo = nullptr; }
   g->has_norm = false;
   int32_t st;
+  // (the weights themselves are kept only where the hub geometry of the persistent solver could want them: some tile does not fit the halo lists)
+  if (edge_weight && m > 0 && !(g->by_t.halo_ok && g->by_s.halo_ok) && (st = upload(&g->w_coo, edge_weight, (size_t)m))) return st;
   if ((st = upload(&g->by_t.ent, et.data(), (size_t)m))) return st;
   if ((st = upload(&g->by_s.ent, es.data(), (size_t)m))) return st;
   if ((st = upload(&g->by_t.sched, st_.data(), st_.size()))) return st;

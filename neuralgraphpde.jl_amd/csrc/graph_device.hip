@@ -309,6 +309,7 @@ void free_norm(ngpde_graph *g) {
     c2->halo_ok = false;
   }
   if (g->c) { (void)hipFree(g->c); g->c = nullptr; }
+  if (g->w_coo) { (void)hipFree(g->w_coo); g->w_coo = nullptr; }
   g->has_norm = false;
 }
 
@@ -358,6 +359,11 @@ int32_t set_gcn_norm_device(ngpde_graph *g, int add_self_loops, const float *w_d
   NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
   g->by_t.halo_ok = n_tiles > 0 && h_bad[0] == 0;
   g->by_s.halo_ok = n_tiles > 0 && h_bad[4] == 0;
+  if (w_dev && m > 0 && !(g->by_t.halo_ok && g->by_s.halo_ok)) {   // (kept for the persistent solver's hub geometry: graph.hip)
+    if ((st = dalloc(&g->w_coo, (size_t)m))) return st;
+    NGPDE_HIP_CHECK(hipMemcpyAsync(g->w_coo, w_dev, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NGPDE_HIP_CHECK(hipStreamSynchronize(stream));
+  }
   g->by_t.max_halo = h_bad[2];
   g->by_s.max_halo = h_bad[6];
   g->self_loops = add_self_loops ? 1 : 0;

@@ -98,6 +98,7 @@ struct TileMeta {
   const int4 *hub_info;       // [n_tiles] {halo count, list bytes, long rows, 0}
   const int4 *hub_sched;      // [n_sched] {node or -1, 0, 0, bits of c[node]}: the hub geometry's OWN tile partition (see hub_partition)
   const uint8_t *hub_long;    // [n_tiles][kTileRows] rows (0 .. 31) with more than kSlotWidth entries
+  const float *hub_w;         // [n_tiles][kHubList] edge weights of the entries, or NULL (unweighted)
   NGPDE_PST_FIELD
 };
 
@@ -360,12 +361,13 @@ constexpr int kHubHalo = 256;
 constexpr int kHubList = 4096;
 constexpr int kHubNbr = 256;
 constexpr int kHubXhF = kHubHalo * PD;
-constexpr int kHubMetaF = kHubList / 4 + (kHubHalo - kTM) + 2 * kTM + kTM / 4;   // slot bytes, foreign node ids, {start, length} per row, long-row indices
+constexpr int kHubMetaF = kHubList / 4 + (kHubHalo - kTM) + 2 * kTM + kTM / 4 + kHubList;   // slot bytes, foreign node ids, {start, length} per row, long-row indices, entry weights
 
 struct HubCtx : TileCtx {
   const uint8_t *hs;         // LDS: the tile's slot bytes
   const int2 *hrows;         // LDS: {start, length} of every row's list
   const uint8_t *hlong;      // LDS: rows with more than kSlotWidth entries
+  const float *hw;           // LDS: the entries' edge weights (same positions as the slot bytes), or NULL: unweighted graph
   int start, len;            // this row's list (len = 0 for a long row: it is summed cooperatively)
   int n_long;
   int nb1, nb2, nb3;         // wave 0: wait-list entries lane + 64, + 128, + 192 (my_nbr = entry lane)
@@ -398,6 +400,15 @@ __device__ __forceinline__ void hub_ctx_init(const TileMeta &m, HubCtx &c, float
   c.lds_w = nullptr;
   c.hrows = lr;
   c.hlong = reinterpret_cast<const uint8_t *>(ll);
+  c.hw = nullptr;
+  if (m.hub_w) {   // (uniform) edge weights (src/layers.jl:206-231): one float beside every slot byte
+    float4 *lw = reinterpret_cast<float4 *>(lds_meta + kHubList / 4 + (kHubHalo - kTM) + 2 * kTM + kTM / 4);
+    const float4 *gw = reinterpret_cast<const float4 *>(m.hub_w + (size_t)c.tile * kHubList);
+#pragma unroll
+    for (int k = 0; k < kHubList / 4 / kThreads; ++k)
+      if ((c.tid + k * kThreads) * 4 < info.y) lw[c.tid + k * kThreads] = gw[c.tid + k * kThreads];
+    c.hw = reinterpret_cast<const float *>(lw);
+  }
   c.hcount = __builtin_amdgcn_readfirstlane(info.x);
   c.n_long = __builtin_amdgcn_readfirstlane(info.z);
   const int2 mine = m.hub_rows[pos];
@@ -468,24 +479,44 @@ __device__ __forceinline__ void hub_slot_words(const HubCtx &c, unsigned (&w)[8]
 // sum of the row's neighbours + its own row; `part` = 32 x 64 floats of LDS that nobody else uses during the aggregation.
 // (Measured and not kept: the long row's partial rows formed first, eight masked entries per group unrolled with their slot bytes
 // fetched together -- 8 + 8 LDS reads per lane whatever the row's length: the hub tile's aggregation 3.8 k -> 4.7 k cycles.)
+// Weighted graphs (c.hw): one fma per entry in list order, as the 96-row geometry's weighted rows (tile_aggregate_weighted); a long
+// row's groups fold weight * row into their partial sums.
 __device__ __forceinline__ float4 hub_aggregate(const HubCtx &c, const unsigned (&sw)[8], const float *ldsXh, float *part) {
   const float4 *Xh4 = reinterpret_cast<const float4 *>(ldsXh);
   float4 a = f4_zero();
-#pragma unroll
-  for (int jw = 0; jw < 8; ++jw) {
-    if (jw * 4 < c.wmax) {   // wave-uniform
+  if (c.hw) {   // (uniform)
+#pragma unroll 1
+    for (int jw = 0; jw * 4 < c.wmax; ++jw) {   // wave-uniform
       const unsigned w = sw[jw];
-      float4 v[4];
+      const float4 wv = *reinterpret_cast<const float4 *>(c.hw + c.start + 4 * jw);   // (list starts are multiples of four: 16-byte aligned)
+      const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) v[jb] = f4_sel(4 * jw + jb < c.len, Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q], f4_zero());
-      a = f4_add_pk(a, f4_add_pk(f4_add_pk(v[0], v[1]), f4_add_pk(v[2], v[3])));
+      for (int jb = 0; jb < 4; ++jb) {
+        const float4 v = f4_sel(4 * jw + jb < c.len, Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q], f4_zero());
+        a = f4_fma(4 * jw + jb < c.len ? ww[jb] : 0.f, v, a);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jw = 0; jw < 8; ++jw) {
+      if (jw * 4 < c.wmax) {   // wave-uniform
+        const unsigned w = sw[jw];
+        float4 v[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) v[jb] = f4_sel(4 * jw + jb < c.len, Xh4[((w >> (8 * jb)) & 0xff) * PG::LPR + c.q], f4_zero());
+        a = f4_add_pk(a, f4_add_pk(f4_add_pk(v[0], v[1]), f4_add_pk(v[2], v[3])));
+      }
     }
   }
   for (int li = 0; li < c.n_long; ++li) {   // uniform
     const int r = c.hlong[li];
     const int2 rl = c.hrows[r];
     float4 p = f4_zero();
-    for (int j = c.grp; j < rl.y; j += kTM) p = f4_add_pk(p, Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q]);
+    if (c.hw) {
+      for (int j = c.grp; j < rl.y; j += kTM) p = f4_fma(c.hw[rl.x + j], Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q], p);
+    } else {
+      for (int j = c.grp; j < rl.y; j += kTM) p = f4_add_pk(p, Xh4[(unsigned)c.hs[rl.x + j] * PG::LPR + c.q]);
+    }
     reinterpret_cast<float4 *>(part)[c.grp * PG::LPR + c.q] = p;
     __syncthreads();
     if (c.wave_u == (r >> 2)) {   // the wave of the row's group: each of its four groups adds eight partial rows, two exchanges fold them
@@ -597,7 +628,7 @@ struct PFwdK {
 // HUB: the hub geometry (256-row halo, variable-length slot lists, long rows shared by the 32 lane groups, one workgroup per CU)
 template <int ACT, bool TAPE, bool WGT = false, bool HUB = false>
 __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_fwd_persistent_kernel(const PFwdK p) {
-  static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
+  static_assert(!(HUB && WGT), "hub geometry: its own weight lists (HubCtx::hw), not the WGT form");
   constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
   __shared__ __attribute__((aligned(16))) float lds[XH + 2 * kTileF + (WGT ? kWF + kSlotWF : 2 * kWF) + 2 * PD + MF + 48 + 4];
   static_assert(!HUB || sizeof(lds) <= 160 * 1024 - 64, "one workgroup per CU");
@@ -1243,7 +1274,7 @@ struct PBwdK {
 // gcn_tile.h, mfma_rows_times_bswz64), which makes exactly the room.
 template <int ACT, bool WGT = false, bool HUB = false>
 __global__ __launch_bounds__(kThreads, HUB ? 2 : 4) void node_bwd_persistent_kernel(const PBwdK p) {
-  static_assert(!(HUB && WGT), "hub geometry: unweighted graphs");
+  static_assert(!(HUB && WGT), "hub geometry: its own weight lists (HubCtx::hw), not the WGT form");
   constexpr bool RELU = (ACT == NGPDE_ACT_RELU);
   using Aux = typename std::conditional<RELU, unsigned, float4>::type;   // what act' is formed from: 4 sign bits / the row of z
   constexpr int XH = HUB ? kHubXhF : kXhF, MF = HUB ? kHubMetaF : kMetaF;
@@ -2453,7 +2484,7 @@ bool node_persistent_supported(const ngpde_graph *g, int d, int act, bool with_b
 bool node_persistent_hub_possible(const ngpde_graph *g, int d) {
   const char *nh = std::getenv("NGPDE_NO_HALO");   // (asks for the per-row global gather everywhere)
   if (node_persistent_disabled_env() || (nh && nh[0] == '1')) return false;
-  if (!g || d != PD || !g->has_norm || !g->self_loops || g->by_t.slot_w || g->by_s.slot_w) return false;
+  if (!g || d != PD || !g->has_norm || !g->self_loops || ((g->by_t.slot_w || g->by_s.slot_w) && !g->w_coo)) return false;
   if (g->by_t.halo_ok && g->by_s.halo_ok) return false;   // the 96-row geometry takes it
   int dev = 0, cus = 0, occ = 1 << 30;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -2536,6 +2567,7 @@ static std::vector<int32_t> hub_partition(int64_t n, const std::vector<int32_t> 
 
 struct HubHost {
   std::vector<int32_t> halo;
+  std::vector<float> w;   // beside `slots` (weighted graphs), else empty
   std::vector<uint8_t> slots, longs;
   std::vector<int2> rows;
   std::vector<int4> info;
@@ -2548,10 +2580,12 @@ static bool host_csr(const ngpde_graph *g, const Csr &c, std::vector<int32_t> &r
   if (m > 0 && hipMemcpy(col.data(), c.col, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
   return true;
 }
+// w_csr: the entries' edge weights in the list's own order, or NULL
 static bool build_hub_lists(int64_t n, int nt, const std::vector<int32_t> &rowptr, const std::vector<int32_t> &col,
-                            const std::vector<int32_t> &order, HubHost &o) {
+                            const std::vector<int32_t> &order, HubHost &o, const float *w_csr = nullptr) {
   o.halo.assign((size_t)nt * kHubHalo, 0);
   o.slots.assign((size_t)nt * kHubList, 0);
+  if (w_csr) o.w.assign((size_t)nt * kHubList, 0.f);
   o.longs.assign((size_t)nt * kTileRows, 0);
   o.rows.assign((size_t)nt * kTileRows, make_int2(0, 0));
   o.info.assign((size_t)nt, make_int4(0, 0, 0, 0));
@@ -2581,6 +2615,7 @@ static bool build_hub_lists(int64_t n, int nt, const std::vector<int32_t> &rowpt
           o.halo[(size_t)t * kHubHalo + count++] = u;
         }
         o.slots[(size_t)t * kHubList + bytes + j] = (uint8_t)slot_of[u];
+        if (w_csr) o.w[(size_t)t * kHubList + bytes + j] = w_csr[rs + j];
       }
       bytes = (bytes + deg + 3) & ~3;
       if (bytes > kHubList) return false;
@@ -2743,8 +2778,26 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
     NGPDE_REQUIRE((int64_t)order.size() == g->n_nodes, NGPDE_ERR_UNSUPPORTED,
                   "persistent solver, hub geometry: no partition into 32-row tiles of at most %d referenced rows each (a node of more than %d distinct in+out neighbours, or tiles that do not close)",
                   kHubHalo, kHubHalo - kTileRows);
+    // edge weights: the handle's COO copy through each list's entry -> COO position map
+    std::vector<float> wcsr[2];
+    if (g->w_coo && g->n_edges > 0) {
+      std::vector<float> wc((size_t)g->n_edges);
+      NGPDE_HIP_CHECK(hipMemcpy(wc.data(), g->w_coo, wc.size() * sizeof(float), hipMemcpyDeviceToHost));
+      const Csr *cs[2] = {&g->by_t, &g->by_s};
+      for (int dir = 0; dir < 2; ++dir) {
+        std::vector<int32_t> eid = cs[dir]->h_eid;
+        if (eid.empty()) {
+          eid.resize((size_t)g->n_edges);
+          NGPDE_HIP_CHECK(hipMemcpy(eid.data(), cs[dir]->eid, eid.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        wcsr[dir].resize((size_t)g->n_edges);
+        for (int64_t e = 0; e < g->n_edges; ++e) wcsr[dir][(size_t)e] = wc[(size_t)eid[(size_t)e]];
+      }
+    }
     HubHost hh[2];
-    NGPDE_REQUIRE(build_hub_lists(g->n_nodes, nt, rp[0], cl[0], order, hh[0]) && build_hub_lists(g->n_nodes, nt, rp[1], cl[1], order, hh[1]), NGPDE_ERR_UNSUPPORTED,
+    NGPDE_REQUIRE(build_hub_lists(g->n_nodes, nt, rp[0], cl[0], order, hh[0], wcsr[0].empty() ? nullptr : wcsr[0].data()) &&
+                      build_hub_lists(g->n_nodes, nt, rp[1], cl[1], order, hh[1], wcsr[1].empty() ? nullptr : wcsr[1].data()),
+                  NGPDE_ERR_UNSUPPORTED,
                   "persistent solver, hub geometry: a tile references more than %d distinct rows or holds more than %d entries", kHubHalo, kHubList);
     // the partition's schedule: {node, 0, 0, bits of c[node]} per position, -1 padded
     std::vector<float> cnode((size_t)g->n_nodes);
@@ -2786,6 +2839,7 @@ int32_t node_persistent_setup(const ngpde_graph *g, const float *coef_host, Node
       if ((st = up(&L.halo, h.halo)) || (st = up(&L.slots, h.slots)) || (st = up(&L.rows, h.rows)) || (st = up(&L.info, h.info)) ||
           (st = up(&L.longs, h.longs)) || (st = up(&L.sched, hsched)))
         return st;
+      if (!h.w.empty() && (st = up(&L.w, h.w))) return st;
     }
     ps->hub = true;
   } else {
@@ -2838,6 +2892,7 @@ void node_persistent_free(NodePersist *ps) {
     if (L.info) (void)hipFree(L.info);
     if (L.longs) (void)hipFree(L.longs);
     if (L.sched) (void)hipFree(L.sched);
+    if (L.w) (void)hipFree(L.w);
     L = NodePersist::HubLists();
   }
   ps->hub = false;
@@ -2866,6 +2921,8 @@ TileMeta make_meta(const Csr &c, const NodePersist &ps, int dir, const OwnFirst 
   }
   const NodePersist::HubLists &L = ps.hub_lists[dir];
   m.hub_halo = L.halo; m.hub_slots = L.slots; m.hub_rows = L.rows; m.hub_info = L.info; m.hub_long = L.longs; m.hub_sched = L.sched;
+  m.hub_w = L.w;
+  if (ps.hub) m.slot_w = nullptr;   // (the hub geometry reads its own weight lists)
   m.flags = ps.sync; m.abort_word = ps.sync + (size_t)ps.n_tiles * 64; m.n_tiles = ps.n_tiles;   // [slot 0 | slot 1 | abort]
   m.stats = ps.stats;
 #ifdef NGPDE_STAMPS
@@ -2987,7 +3044,7 @@ int32_t launch_node_fwd_persistent(const NodePersistFwd &a, hipStream_t stream) 
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (ps.hub) {   // hub geometry: one tile per workgroup and CU
-    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: unweighted, one tile per workgroup, the members of a batch one after the other");
+    NGPDE_REQUIRE(!a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: one tile per workgroup, the members of a batch one after the other");
     k.ztape = a.ztape;
     NGPDE_REQUIRE(!a.tape || (a.act == NGPDE_ACT_RELU ? a.masks != nullptr : a.ztape != nullptr), NGPDE_ERR_INVALID_ARGUMENT,
                   "persistent forward with a tape needs the sign-bit masks (relu) or the pre-activation tape");
@@ -3087,7 +3144,7 @@ int32_t launch_node_bwd_persistent(const NodePersistBwd &a, hipStream_t stream) 
                 "weighted graphs: one tile per workgroup or tile rounds, one member");
   const dim3 grid(a.pair ? ps.pair_wgs : ps.n_tiles), block(kThreads);
   if (ps.hub) {
-    NGPDE_REQUIRE(!k.m.slot_w && !a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: unweighted, one tile per workgroup, the members of a batch one after the other");
+    NGPDE_REQUIRE(!a.pair && !a.interleave, NGPDE_ERR_STATE, "hub geometry: one tile per workgroup, the members of a batch one after the other");
     NGPDE_REQUIRE(a.act == NGPDE_ACT_RELU || a.ztape, NGPDE_ERR_INVALID_ARGUMENT, "persistent adjoint: activations other than relu need the saved pre-activations");
     if (a.act == NGPDE_ACT_RELU) {
       if (a.ev_start) hipExtLaunchKernelGGL((node_bwd_persistent_kernel<NGPDE_ACT_RELU, false, true>), grid, block, 0, stream, a.ev_start, a.ev_stop, 0, k);

@@ -31,8 +31,9 @@ def close(a, ref, rtol, atol=1e-5, what=""):
     assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e}"
 
 
-def solve(g, d, act, tab, nsteps, dt, params, u0, R):
-    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+def solve(g, d, act, tab, nsteps, dt, params, u0, R, use_edge_weight=False):
+    kw = dict(initialgraph=g, use_edge_weight=True) if use_edge_weight else dict(initialgraph=g)
+    rhs = ng.Chain(ng.GCNConv((d, d), act, **kw), ng.GCNConv((d, d), act, **kw))
     node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
     _, st = ng.setup(0, node)
     ps = {f"layer_{k + 1}": {"weight": torch.as_tensor(params[k]["weight"].astype(np.float32), device=DEV).requires_grad_(True),
@@ -249,3 +250,49 @@ def test_batch_of_cora_shaped_graphs_member_by_member_on_the_hub_geometry(act, t
     for k in range(2):
         close(grads[2 * k], accW[k], 5e-4, 2e-3, f"dW{k + 1}")
         close(grads[2 * k + 1], accb[k], 5e-4, 2e-3, f"db{k + 1}")
+
+
+@pytest.mark.parametrize("d,act,tab,nsteps,device_built", [(64, "tanh", "tsit5", 3, False), (64, "relu", "euler", 6, False), (32, "swish", "tsit5", 2, False),
+                                                           (64, "tanh", "euler", 4, True)])
+def test_weighted_cora_shaped_graph_on_the_hub_geometry(d, act, tab, nsteps, device_built, monkeypatch):
+    # GCNConv(use_edge_weight = true) on a graph with stored edge weights AND hubs (src/layers.jl:206-231 on the graph of graph_node.md:14-23):
+    # the hub geometry carries one weight beside every slot byte of its variable-length lists (node_persistent.hip: HubCtx::hw; hub rows fold
+    # weight * row into their 32 partial sums).  u(T), du0 and the parameter gradients against the float64 port of the weighted layer, against
+    # the replayed plan of the same build to rounding, run to run bit for bit; handles built on the host and on the device.
+    from test_gcn_gpu import _oracle_weighted_node
+    N, PAIRS, dt = 2708, 5278, 0.1
+    s, t = S.preferential_pairs_graph(N, PAIRS, seed=1)
+    rng = np.random.default_rng(d + nsteps)
+    ew = (0.25 + rng.random(s.size)).astype(np.float32)
+    if device_built:
+        monkeypatch.delenv("NGPDE_HOST_GRAPH_BUILD", raising=False)
+    else:
+        monkeypatch.setenv("NGPDE_HOST_GRAPH_BUILD", "1")      # (read when a handle is built: graphs.py)
+    g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+    og = O.Graph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+    params = [dict(weight=S.glorot_uniform(70 + k, d, d), bias=rng.normal(size=(d, 1)) * 0.1) for k in range(2)]
+    u0, R = rng.normal(size=(d, N)), rng.normal(size=(d, N))
+    uT, du0, grads, flags = solve(g, d, act, tab, nsteps, dt, params, u0, R, use_edge_weight=True)
+    if hub_plan_expected():
+        assert {"hub_geometry", "persistent_fwd", "persistent_bwd", "prescaled"} <= flags, flags
+    uTo, du0o, acc = _oracle_weighted_node(params, og, u0, R, O.TABLEAUS[tab], dt, nsteps, act)
+    close(uT, uTo, 2e-4, what="u(T)")
+    if act == "relu":
+        ref = torch.as_tensor(du0o)
+        bad = (torch.abs(du0.double().cpu() - ref) > 1e-4 + 5e-4 * torch.abs(ref)).any(0)
+        assert bad.double().mean() <= 5e-3, f"du0: {int(bad.sum())} of {N} nodes off (relu kinks allow a few)"
+    else:
+        close(du0, du0o, 5e-4, 1e-4, "du0")
+    for k in range(2):
+        close(grads[2 * k], acc[k]["weight"], 5e-4, 1e-3, f"dW{k + 1}")
+        close(grads[2 * k + 1], acc[k]["bias"], 5e-4, 1e-3, f"db{k + 1}")
+    again = solve(g, d, act, tab, nsteps, dt, params, u0, R, use_edge_weight=True)
+    assert torch.equal(uT, again[0]) and torch.equal(du0, again[1]) and all(torch.equal(a, b) for a, b in zip(grads, again[2]))
+    if hub_plan_expected():
+        monkeypatch.setenv("NGPDE_NO_PERSISTENT", "1")
+        uTr, du0r, gradsr, flagsr = solve(g, d, act, tab, nsteps, dt, params, u0, R, use_edge_weight=True)
+        monkeypatch.delenv("NGPDE_NO_PERSISTENT")
+        assert "hub_geometry" not in flagsr, flagsr
+        close(uT, uTr, 2e-5, what="u(T) against the replayed plan")
+        if act != "relu":
+            close(du0, du0r, 1e-4, 1e-5, "du0 against the replayed plan")
