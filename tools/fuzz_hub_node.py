@@ -19,8 +19,9 @@ from ngpde_amd import _lib, synth as S  # noqa: E402
 DEV = "cuda:0"
 
 
-def solve(g, d, act, tab, nsteps, dt, params, u0, R):
-    rhs = ng.Chain(ng.GCNConv((d, d), act, initialgraph=g), ng.GCNConv((d, d), act, initialgraph=g))
+def solve(g, d, act, tab, nsteps, dt, params, u0, R, weighted=False):
+    kw = dict(initialgraph=g, use_edge_weight=True) if weighted else dict(initialgraph=g)
+    rhs = ng.Chain(ng.GCNConv((d, d), act, **kw), ng.GCNConv((d, d), act, **kw))
     node = ng.NeuralODE(rhs, solver=tab, n_steps=nsteps, dt=dt)
     _, st = ng.setup(0, node)
     ps = {f"layer_{k + 1}": {"weight": torch.as_tensor(params[k]["weight"].astype(np.float32), device=DEV).requires_grad_(True),
@@ -58,19 +59,25 @@ def main(cases, seed):
         act = str(rng.choice(["tanh", "swish", "sigmoid"]))
         tab, nsteps = ("euler", 4) if rng.random() < 0.4 else ("tsit5", 2)
         params = [dict(weight=S.glorot_uniform(int(rng.integers(1, 1000)), d, d), bias=rng.normal(size=(d, 1)) * 0.1) for _ in range(2)]
-        u0, R = rng.normal(size=(d, N)), rng.normal(size=(d, N))
-        g = ng.GNNGraph(s, t, num_nodes=N, index_base=0)
+        # round 6: a third of the cases with stored edge weights (use_edge_weight = true), a third as a batch of 2 - 3 same-structure members
+        weighted = rng.random() < 0.33
+        members = int(rng.choice([2, 3])) if (rng.random() < 0.33 and N <= 4000) else 1
+        ew = (0.25 + rng.random(s.size)).astype(np.float32) if weighted else None
+        g = ng.GNNGraph(s, t, num_nodes=N, index_base=0, edge_weight=ew)
+        if members > 1:
+            g = ng.batch([g] + [g.copy() for _ in range(members - 1)])
+        u0, R = rng.normal(size=(d, members * N)), rng.normal(size=(d, members * N))
         os.environ.pop("NGPDE_NO_PERSISTENT", None)
-        a = solve(g, d, act, tab, nsteps, 0.1, params, u0, R)
+        a = solve(g, d, act, tab, nsteps, 0.1, params, u0, R, weighted)
         why = "" if "hub_geometry" in a[3] else " (" + _lib.load().ngpde_last_error().decode()[:120] + ")"
         os.environ["NGPDE_NO_PERSISTENT"] = "1"
-        b = solve(g, d, act, tab, nsteps, 0.1, params, u0, R)
+        b = solve(g, d, act, tab, nsteps, 0.1, params, u0, R, weighted)
         os.environ.pop("NGPDE_NO_PERSISTENT", None)
         is_hub = "hub_geometry" in a[3]
         n_hub += is_hub
         errs = [rel(a[0], b[0]), rel(a[1], b[1])] + [rel(x, y) for x, y in zip(a[2], b[2])]
         ok = (not a[4]) and errs[0] <= 2e-5 and errs[1] <= 1e-4 and max(errs[2:]) <= 2e-4 and "persistent_fwd" not in b[3]
-        print(f"case {case}: N={N} E={s.size} max degree {int(np.bincount(t, minlength=N).max())} d={d} {act} {tab}: "
+        print(f"case {case}: N={N} E={s.size} max degree {int(np.bincount(t, minlength=N).max())} d={d} {act} {tab}{' weighted' if weighted else ''}{' x' + str(members) if members > 1 else ''}: "
               f"{'hub geometry' if is_hub else 'plan ' + str(sorted(a[3])) + why}; u(T) {errs[0]:.1e} du0 {errs[1]:.1e} grads {max(errs[2:]):.1e}"
               f"{'' if ok else '   <-- FAIL'}", flush=True)
         if not ok:
