@@ -652,8 +652,11 @@ def spawn_ranks(args, backend):
 ROCPROF_KERNEL_OF_ROLE = {"fwd_persistent_solve": "node_fwd_persistent_kernel", "bwd_persistent_adjoint": "node_bwd_persistent_kernel"}
 
 
+ROCPROF_CHILD_STEPS = 20     # (3 until round 6: of its 14 launches the first five and the two behind a pause ran cold -- profiles/r06_t_*)
+
+
 def rocprof_roofline(out, role, algo_bytes):
-    """roofline.frac from rocprofv3's own average for the dominant kernel: a CHILD process repeats three headline steps under
+    """roofline.frac from rocprofv3's own average for the dominant kernel: a CHILD process repeats ROCPROF_CHILD_STEPS headline steps under
     `rocprofv3 --kernel-trace --stats` (the command of tools/profile_round.sh, whose summary is committed under profiles/), its
     k_kernel_stats.csv gives the kernel's AverageNs, and `achieved` / `frac` are recomputed from that -- it reads 1-4.5 % longer
     than the library's dispatch events, so it is the conservative one.  The event figures stay in the record as *_events.  When
@@ -673,7 +676,7 @@ def rocprof_roofline(out, role, algo_bytes):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "k", "--", sys.executable,
-               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batched", "0", "--no-secondary"]
+               os.path.abspath(__file__), "--steps", str(ROCPROF_CHILD_STEPS), "--warmup", "3", "--no-cpu-baseline", "--batched", "0", "--no-secondary"]
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
         found = None
         for base, _, files in os.walk(tmp):
@@ -688,14 +691,15 @@ def rocprof_roofline(out, role, algo_bytes):
         achieved = algo_bytes / (us * 1e-6) / 1e9
         r["achieved"], r["frac"], r["avg_launch_us"] = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4), round(us, 3)
         r["avg_launch_source"] = (f"rocprofv3 --kernel-trace --stats AverageNs over {calls} launches of {want}, collected by a child run of "
-                                  "this script (--steps 3 --warmup 1, the command of tools/profile_round.sh); *_events: " + events)
+                                  f"this script (--steps {ROCPROF_CHILD_STEPS} --warmup 3, the command of tools/profile_round.sh: a device that was idle runs its first four or "
+                                  "five launches 3 - 20 % slower, so a pass of 3 steps read 5 % above the timed region's launches); *_events: " + events)
     except Exception as e:  # noqa: BLE001 -- the bench line must still come out
         r["avg_launch_source"] = events + f"; the rocprofv3 child pass failed ({type(e).__name__}: {e})"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-CHILD_LAYER_REPS = 13      # (a prime: the layer's own kernels are the rows of the stats table whose call count is a multiple of it)
+CHILD_LAYER_REPS = 53      # (a prime: the layer's own kernels are the rows of the stats table whose call count is a multiple of it)
 
 
 def child_layer(spec):

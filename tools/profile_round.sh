@@ -9,7 +9,7 @@ mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batched 0 --no-secondary > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --batched 0 --no-secondary > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batched 0 --no-secondary > $O/pmc_$c.log 2>&1
 done
