@@ -185,6 +185,7 @@ def dense_spatial(N, deg, seed, edata=0):
 def test_gno_gform_entry_equals_the_composed_layer(cin, cout, aggr, edata, bias, first, deg, monkeypatch):
     # the aggregate-then-transform form (csrc/gno_gform.hip: k = 64, in in {32, 64, 128}, sum / mean): the entry and the composed path
     # run the same launches; with NGPDE_NO_GNO_GFORM=1 both fall back to the by-source form
+    monkeypatch.delenv("NGPDE_NO_GNO_GFORM", raising=False)      # (the suite may run under the switch: tools/switch_matrix.sh)
     k, N = 64, 300
     g = dense_spatial(N, deg, 17, edata=edata)
     ds = 3
@@ -209,8 +210,9 @@ def test_gno_gform_entry_equals_the_composed_layer(cin, cout, aggr, edata, bias,
         assert float((u - v).abs().max()) <= 2e-5 * scale + 1e-6, (float((u - v).abs().max()), scale)
 
 
-def test_gno_gform_aggregate_against_float64():
+def test_gno_gform_aggregate_against_float64(monkeypatch):
     # G_i[k][i'] = sum_{e -> i} z_e[k] h_{s_e}[i'], hsum_i, z_out: rows of 0, 1, 33 and 70 edges, sum and mean, all three feature blocks
+    monkeypatch.delenv("NGPDE_NO_GNO_GFORM", raising=False)
     lib = _lib.load()
     rng = np.random.default_rng(5)
     N, k = 90, 64
@@ -276,6 +278,8 @@ def test_second_backward_through_a_retained_graph(monkeypatch):
 def test_pullback_refuses_a_workspace_filled_under_another_plan(monkeypatch):
     # the plan (kernel sequence + workspace layout) is re-derived by every call; a path switch flipped between the forward and its pullback
     # used to give wrong gradients silently -- now the pullback compares the plan with the one the forward recorded for this workspace
+    for var in ("NGPDE_NO_GNO_GFORM", "NGPDE_NO_FUSED_EDGE_BWD"):
+        monkeypatch.delenv(var, raising=False)
     g = spatial(640, 9)
     phi = ng.Chain(ng.Dense(4, 32, "tanh"), ng.Dense(32, 16))
     gam = ng.Chain(ng.Dense(17, 24, "tanh"), ng.Dense(24, 1))
