@@ -784,6 +784,8 @@ def _kernel_sum_roofline(rec, name, flop_fwd, allow):
     r["kernel_sum_ms_forward"], r["kernels_per_forward"] = round(ks_f[0], 4), ks_f[1]
     if ks_fb is not None:
         r["kernel_sum_ms_forward_backward"], r["kernels_per_forward_backward"] = round(ks_fb[0], 4), ks_fb[1]
+        # forward + pullback = three times the forward's products (input and weight gradients of every Dense / contraction)
+        r["frac_forward_backward"] = round(3 * flop_fwd / (ks_fb[0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS, 4)
     r["frac_source"] = (f"rocprofv3 --kernel-trace --stats, child pass of {CHILD_LAYER_REPS} calls: sum of the launches' TotalDurationNs / calls "
                         "(no gaps between kernels; profiled runs read a few % longer than un-profiled ones)")
 
