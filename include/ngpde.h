@@ -473,7 +473,7 @@ enum { NGPDE_NODE_PRESCALED = 1, NGPDE_NODE_SIGN_MASKS = 2, NGPDE_NODE_EAGER = 4
                                         256-row halos, variable-length rows, hub rows summed by all lane groups of the workgroup */,
        NGPDE_NODE_OWN_FIRST = 512 /* the plan reads its own slot tables (by-target lists): each row's own-tile neighbours first, which the
                                      one-tile forward launch sums while it waits for the neighbouring tiles; every kernel of the plan
-                                     sums in that order (NGPDE_NO_OWN_FIRST=1 at create keeps the handle's order) */ };
+                                     sums in that order (graphs of at most two tiles per CU; NGPDE_NO_OWN_FIRST=1 at create keeps the handle's order) */ };
 int32_t ngpde_node_flags(const ngpde_node_t *plan, int32_t *flags);
 /* Host only, no device call: the node numbering of a block-diagonal batch (Flux.batch / MLUtils.batch of single graphs,
  * /root/reference/test/runtests.jl:89-102, docs/src/tutorials/VMH.md:120-134) whose members are padded to whole 32-row tiles, so

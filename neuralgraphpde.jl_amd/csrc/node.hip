@@ -652,7 +652,13 @@ static int32_t node_create(const ngpde_graph_t *g, int32_t members, int32_t d, i
   // own-first slot tables (common.h: OwnFirst): for every pre-scaled plan on the handle's own tile lists -- persistent in any form or
   // replayed, one member or a batch, weighted or not -- so that all of them sum a row's neighbours in ONE order and stay bitwise
   // comparable; NGPDE_NO_OWN_FIRST=1 keeps the handle's order (A/B runs)
-  if (st == NGPDE_OK && p->pre && !hub) {
+  // Only for graphs of one wave of workgroups (<= two 32-row tiles per CU): the forms for larger graphs -- tile pairs, tile rounds -- have
+  // no exposed wait to fill and would only pay the padding rounds (32 768 nodes - 1.2 %, 65 536 - 0.7 %); the rule looks at the graph
+  // and the device alone, never at a plan-selecting switch, so a graph's persistent and replayed plans always agree on it.
+  int dev_ = 0, cus_ = 0;
+  const bool one_wave = hipGetDevice(&dev_) == hipSuccess && hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess &&
+                        p->nb <= 2 * cus_;
+  if (st == NGPDE_OK && p->pre && !hub && one_wave) {
     const char *nof = std::getenv("NGPDE_NO_OWN_FIRST");
     if (!(nof && nof[0] == '1')) {
       st = own_first_tables_build(g, &p->of, nullptr);
